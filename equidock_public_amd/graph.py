@@ -1,0 +1,308 @@
+"""Batched ligand/receptor pair-graph container: the input boundary of the hot path.
+
+The reference hands its model a batched DGL heterograph built by
+`hetero_graph_from_sg_l_r_pair` + `dgl.batch` (src/utils/train_utils.py:61-100).  DGL is a
+third-party pin that is absent here, so this module provides the accessor subset the callers
+and the model use:
+
+    g.nodes['ligand'].data['new_x'], g.nodes['receptor'].data['x'], ...['res_feat'], ['mu_r_norm']
+    g.edges['ll'].data['he'], g.edges['rr'].data['he']
+    g.batch_num_nodes('ligand'), g.to(device), batch(list_of_pairs), unbatch(g)
+
+and, for the HIP path, `PairBatch.pack()` which lays the batch out for the kernels:
+
+  * ONE node array: all ligand nodes of all pairs, then all receptor nodes (ll and rr edges
+    share every weight, rigid_docking_model.py:236-237,263-265, so one launch covers both);
+  * edges destination-sorted (they already are: protein_utils.py:339-346; validated here,
+    stably sorted otherwise) -> CSR `rowptr` by destination, CSC (`csc_ptr`, `csc_eid`) by
+    source for the atomics-free backward scatter;
+  * node-aligned edge tiles of <= 32 edges (`tile_node`) so the per-destination mean
+    (DGL copy_edge + mean, rigid_docking_model.py:274-283) is a within-tile reduction;
+  * per-pair segment offsets + a work list of 32-node blocks for the block-diagonal
+    cross-attention (replaces the dense get_mask, rigid_docking_model.py:68-78).
+
+All index arrays are int32 (graph indexing is bit-exact with the reference's int32 edges).
+"""
+import numpy as np
+import torch
+
+TILE_EDGES = 32      # must equal eqd_tile_edges() of the C-ABI library
+TILE_NODES = 32
+ATT_BLOCK = 32
+
+
+class _DataView:
+    def __init__(self, store):
+        self.data = store
+
+
+class _Indexer:
+    def __init__(self, stores):
+        self._stores = stores
+
+    def __getitem__(self, key):
+        if isinstance(key, tuple):      # ('ligand', 'll', 'ligand') style canonical etype
+            key = key[1]
+        return _DataView(self._stores[key])
+
+
+class PairGraph:
+    """One (ligand, receptor) pair or a batch of them (same class, like a DGL graph)."""
+
+    NTYPES = ('ligand', 'receptor')
+    ETYPES = {'ll': 'ligand', 'rr': 'receptor'}
+
+    def __init__(self, ndata, edata, edges, batch_nodes, batch_edges):
+        self._ndata = ndata
+        self._edata = edata
+        self._edges = edges                 # {'ll': (src, dst), 'rr': (src, dst)} int32, block-local ids
+        self._batch_nodes = batch_nodes     # {'ligand': [n...], 'receptor': [n...]}
+        self._batch_edges = batch_edges     # {'ll': [e...], 'rr': [e...]}
+        self._packed = None
+
+    # ---- DGL-like accessors ------------------------------------------------------------------
+    @property
+    def nodes(self):
+        return _Indexer(self._ndata)
+
+    @property
+    def edges(self):
+        return _Indexer(self._edata)
+
+    def num_nodes(self, ntype):
+        return int(sum(self._batch_nodes[ntype]))
+
+    def num_edges(self, etype):
+        return int(sum(self._batch_edges[etype]))
+
+    def batch_num_nodes(self, ntype):
+        return torch.tensor(self._batch_nodes[ntype], dtype=torch.int64)
+
+    def batch_num_edges(self, etype):
+        return torch.tensor(self._batch_edges[etype], dtype=torch.int64)
+
+    @property
+    def batch_size(self):
+        return len(self._batch_nodes['ligand'])
+
+    @property
+    def device(self):
+        return self._ndata['receptor']['x'].device
+
+    def edge_endpoints(self, etype):
+        return self._edges[etype]
+
+    def to(self, device):
+        device = torch.device(device)
+        for store in list(self._ndata.values()) + list(self._edata.values()):
+            for k in list(store):
+                store[k] = store[k].to(device)
+        self._edges = {k: (s.to(device), d.to(device)) for k, (s, d) in self._edges.items()}
+        if self._packed is not None:
+            self._packed = self._packed.to(device)
+        return self
+
+    # ---- packing for the HIP path ---------------------------------------------------------------
+    def pack(self):
+        """Device-resident kernel layout (topology cached; coordinates re-read every call)."""
+        if self._packed is None or self._packed.device != self.device:
+            self._packed = PackedGraph.build(self)
+        self._packed.refresh_coords(self)
+        return self._packed
+
+
+def pair_from_arrays(lig, rec):
+    """Build a single-pair graph from two dicts of arrays (numpy or torch) with keys
+    x, res_feat, mu_r_norm, src, dst, he and (ligand only) new_x -- the node/edge data the
+    reference attaches in hetero_graph_from_sg_l_r_pair (src/utils/train_utils.py:71-82)."""
+    def t(a, dtype):
+        return torch.as_tensor(np.asarray(a) if not torch.is_tensor(a) else a).to(dtype).contiguous()
+
+    ndata = {
+        'ligand': {'res_feat': t(lig['res_feat'], torch.float32).view(-1, 1), 'x': t(lig['x'], torch.float32),
+                   'new_x': t(lig['new_x'], torch.float32), 'mu_r_norm': t(lig['mu_r_norm'], torch.float32)},
+        'receptor': {'res_feat': t(rec['res_feat'], torch.float32).view(-1, 1), 'x': t(rec['x'], torch.float32),
+                     'mu_r_norm': t(rec['mu_r_norm'], torch.float32)},
+    }
+    edata = {'ll': {'he': t(lig['he'], torch.float32)}, 'rr': {'he': t(rec['he'], torch.float32)}}
+    edges = {'ll': (t(lig['src'], torch.int32), t(lig['dst'], torch.int32)),
+             'rr': (t(rec['src'], torch.int32), t(rec['dst'], torch.int32))}
+    nl, nr = ndata['ligand']['x'].shape[0], ndata['receptor']['x'].shape[0]
+    for et, n in (('ll', nl), ('rr', nr)):
+        s, d = edges[et]
+        if s.numel():
+            if int(s.min()) < 0 or int(d.min()) < 0 or int(s.max()) >= n or int(d.max()) >= n:
+                raise ValueError(f"edge endpoint out of range for edge type {et}")
+        if edata[et]['he'].shape[0] != s.numel():
+            raise ValueError(f"'he' has {edata[et]['he'].shape[0]} rows for {s.numel()} {et} edges")
+    return PairGraph(ndata, edata, edges,
+                     {'ligand': [nl], 'receptor': [nr]},
+                     {'ll': [int(edges['ll'][0].numel())], 'rr': [int(edges['rr'][0].numel())]})
+
+
+def batch(graphs):
+    """dgl.batch equivalent (src/utils/train_utils.py:98): concatenate node/edge data per type,
+    offset edge endpoints by the cumulative node counts, remember per-pair counts."""
+    graphs = list(graphs)
+    if not graphs:
+        raise ValueError("empty batch")
+    ndata = {nt: {k: torch.cat([g._ndata[nt][k] for g in graphs], 0) for k in graphs[0]._ndata[nt]}
+             for nt in PairGraph.NTYPES}
+    edata = {et: {k: torch.cat([g._edata[et][k] for g in graphs], 0) for k in graphs[0]._edata[et]}
+             for et in PairGraph.ETYPES}
+    edges = {}
+    for et, nt in PairGraph.ETYPES.items():
+        off, ss, dd = 0, [], []
+        for g in graphs:
+            s, d = g._edges[et]
+            ss.append(s + off)
+            dd.append(d + off)
+            off += g.num_nodes(nt)
+        edges[et] = (torch.cat(ss).to(torch.int32), torch.cat(dd).to(torch.int32))
+    bn = {nt: [n for g in graphs for n in g._batch_nodes[nt]] for nt in PairGraph.NTYPES}
+    be = {et: [n for g in graphs for n in g._batch_edges[et]] for et in PairGraph.ETYPES}
+    return PairGraph(ndata, edata, edges, bn, be)
+
+
+def unbatch(g):
+    """dgl.unbatch equivalent: per-pair graphs carrying (views of) all current node/edge data."""
+    outs = []
+    noff = {nt: 0 for nt in PairGraph.NTYPES}
+    eoff = {et: 0 for et in PairGraph.ETYPES}
+    for i in range(g.batch_size):
+        nn = {nt: g._batch_nodes[nt][i] for nt in PairGraph.NTYPES}
+        ne = {et: g._batch_edges[et][i] for et in PairGraph.ETYPES}
+        ndata = {nt: {k: v[noff[nt]:noff[nt] + nn[nt]] for k, v in g._ndata[nt].items()} for nt in PairGraph.NTYPES}
+        edata = {et: {k: v[eoff[et]:eoff[et] + ne[et]] for k, v in g._edata[et].items()} for et in PairGraph.ETYPES}
+        edges = {}
+        for et, nt in PairGraph.ETYPES.items():
+            s, d = g._edges[et]
+            edges[et] = (s[eoff[et]:eoff[et] + ne[et]] - noff[nt], d[eoff[et]:eoff[et] + ne[et]] - noff[nt])
+        outs.append(PairGraph(ndata, edata, edges, {nt: [nn[nt]] for nt in nn}, {et: [ne[et]] for et in ne}))
+        for nt in noff:
+            noff[nt] += nn[nt]
+        for et in eoff:
+            eoff[et] += ne[et]
+    return outs
+
+
+def batch_pairs(pairs):
+    """Convenience: list of (ligand_dict, receptor_dict) -> batched PairGraph."""
+    return batch([pair_from_arrays(l, r) for l, r in pairs])
+
+
+class PackedGraph:
+    """Kernel-side layout of a batch; every tensor lives on the batch's device.
+
+    int32: lig_off[B+1], rec_off[B+1] (block-local), src[E], dst[E] (global node ids, dst-sorted),
+           rowptr[N+1], csc_ptr[N+1], csc_eid[E], tile_node[T+1], att_items[I,4], res_id[N],
+           seg_off[2B+1] (global node offsets of the 2B segments: B ligands then B receptors)
+    fp32 : mu_r_norm[N,5], he[E,27], x0[N,3] (ligand new_x rows then receptor x rows)
+    """
+
+    INT_FIELDS = ('lig_off', 'rec_off', 'src', 'dst', 'rowptr', 'csc_ptr', 'csc_eid', 'tile_node',
+                  'att_items', 'res_id', 'seg_off')
+
+    def __init__(self):
+        self.device = None
+
+    @staticmethod
+    def build(g):
+        p = PackedGraph()
+        dev = g.device
+        nl, nr = g.num_nodes('ligand'), g.num_nodes('receptor')
+        n = nl + nr
+        B = g.batch_size
+        p.n_pairs, p.n_lig, p.n_rec, p.n_nodes = B, nl, nr, n
+        lig_off = np.concatenate([[0], np.cumsum(g._batch_nodes['ligand'])]).astype(np.int32)
+        rec_off = np.concatenate([[0], np.cumsum(g._batch_nodes['receptor'])]).astype(np.int32)
+
+        srcs, dsts, perms, eoff = [], [], [], 0
+        for et, base in (('ll', 0), ('rr', nl)):
+            s, d = g._edges[et]
+            s = s.detach().cpu().numpy().astype(np.int64)
+            d = d.detach().cpu().numpy().astype(np.int64)
+            perm = np.arange(len(d), dtype=np.int64)
+            if len(d) > 1 and np.any(d[1:] < d[:-1]):
+                perm = np.argsort(d, kind='stable')
+                s, d = s[perm], d[perm]
+            srcs.append(s + base)
+            dsts.append(d + base)
+            perms.append(perm + eoff)
+            eoff += len(d)
+        src = np.concatenate(srcs).astype(np.int32)
+        dst = np.concatenate(dsts).astype(np.int32)
+        perm = np.concatenate(perms)
+        E = len(src)
+        p.n_edges = E
+        deg = np.bincount(dst, minlength=n).astype(np.int64)
+        if E and deg.max() > TILE_EDGES:
+            raise ValueError(f"in-degree {int(deg.max())} exceeds the supported maximum of {TILE_EDGES} "
+                             "(the reference caps it at graph_max_neighbor=10, src/utils/args.py:47)")
+        rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+        order = np.argsort(src, kind='stable').astype(np.int32)
+        csc_ptr = np.concatenate([[0], np.cumsum(np.bincount(src, minlength=n))]).astype(np.int32)
+
+        # node-aligned edge tiles
+        tiles = [0]
+        cur_e, cur_n = 0, 0
+        for i in range(n):
+            di = int(deg[i])
+            if cur_n > 0 and (cur_e + di > TILE_EDGES or cur_n + 1 > TILE_NODES):
+                tiles.append(i)
+                cur_e, cur_n = 0, 0
+            cur_e += di
+            cur_n += 1
+        tiles.append(n)
+        tile_node = np.asarray(tiles, dtype=np.int32)
+        p.n_tiles = len(tiles) - 1
+
+        # segments: B ligand segments then B receptor segments (global node ids)
+        seg_off = np.concatenate([lig_off[:-1], nl + rec_off]).astype(np.int32)
+        items = []
+        for b in range(B):
+            l0, l1 = int(lig_off[b]), int(lig_off[b + 1])
+            r0, r1 = nl + int(rec_off[b]), nl + int(rec_off[b + 1])
+            for (a0, a1, o0, o1) in ((l0, l1, r0, r1), (r0, r1, l0, l1)):
+                for s0 in range(a0, a1, ATT_BLOCK):
+                    items.append((s0, min(s0 + ATT_BLOCK, a1), o0, o1))
+        # biggest "other" segment first: the block-diagonal attention cost is ~ block x other
+        items.sort(key=lambda it: -(it[3] - it[2]))
+        att_items = np.asarray(items, dtype=np.int32).reshape(-1, 4)
+        p.n_att_items = att_items.shape[0]
+        p.max_seg = int(max(max(g._batch_nodes['ligand']), max(g._batch_nodes['receptor'])))
+
+        res = torch.cat([g._ndata['ligand']['res_feat'].view(-1), g._ndata['receptor']['res_feat'].view(-1)])
+        res_id = res.detach().cpu().numpy().astype(np.int32)
+        if n and (res_id.min() < 0 or res_id.max() > 20):
+            raise ValueError("res_feat must hold residue ids 0..20 (nn.Embedding(21, .), rigid_docking_model.py:382)")
+
+        def ti(a):
+            return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+        p.lig_off, p.rec_off, p.src, p.dst = ti(lig_off), ti(rec_off), ti(src), ti(dst)
+        p.rowptr, p.csc_ptr, p.csc_eid = ti(rowptr), ti(csc_ptr), ti(order)
+        p.tile_node, p.att_items, p.res_id, p.seg_off = ti(tile_node), ti(att_items), ti(res_id), ti(seg_off)
+        p.edge_perm = torch.from_numpy(perm).to(dev)
+        he = torch.cat([g._edata['ll']['he'], g._edata['rr']['he']], 0).to(torch.float32)
+        p.he = he[p.edge_perm].contiguous() if E else he.contiguous()
+        p.mu_r_norm = torch.cat([g._ndata['ligand']['mu_r_norm'], g._ndata['receptor']['mu_r_norm']], 0) \
+            .to(torch.float32).contiguous()
+        if n and float(p.mu_r_norm.min()) <= 0.0:
+            raise ValueError("mu_r_norm must be > 0 (the model takes its log, rigid_docking_model.py:469)")
+        p.x0 = None
+        p.device = dev
+        p.lig_counts = list(g._batch_nodes['ligand'])
+        p.rec_counts = list(g._batch_nodes['receptor'])
+        return p
+
+    def refresh_coords(self, g):
+        self.x0 = torch.cat([g._ndata['ligand']['new_x'], g._ndata['receptor']['x']], 0) \
+            .to(torch.float32).contiguous()
+
+    def to(self, device):
+        for k, v in list(self.__dict__.items()):
+            if torch.is_tensor(v):
+                setattr(self, k, v.to(device))
+        self.device = torch.device(device)
+        return self

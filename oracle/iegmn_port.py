@@ -1,0 +1,314 @@
+"""ORACLE (test infrastructure, "port" kind): plain-PyTorch fp32 CPU restatement of the
+reference hot path -- Rigid_Body_Docking_Net.forward and everything under it.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this file.
+The product package `equidock_public_amd` never does; it fails loudly without its HIP library.
+
+Parity pin: `oracle/make_golden.py` runs the REAL reference module
+(/root/reference/src/model/rigid_docking_model.py, imported unmodified with the DGL stand-in in
+oracle/_dgl_standin) in this container and commits its inputs/outputs/gradients under
+tests/golden/; tests/test_oracle_golden.py checks this restatement against those vectors
+(<= 1e-5 fp32).  The reference ships no tests of its own for this path, so
+the golden vectors generated from the imported reference are the only pin.
+
+Every function cites the reference lines it restates (paths relative to /root/reference).
+"faithful=True" keeps the reference's op sequence including the dense batch-wide attention
+mask (that is the CPU baseline that gets timed); "faithful=False" uses the per-pair
+block-diagonal softmax the HIP path implements (equal to 9.5e-7).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+RBF_SIGMAS = [1.5 ** k for k in range(15)]   # src/model/rigid_docking_model.py:116
+
+
+def default_args(**over):
+    """The published configuration family (src/utils/args.py:227-280, src/inference_rigid.py:90,93)."""
+    a = dict(input_edge_feats_dim=27, dropout=0.0, nonlin='lkyrelu', cross_msgs=True, layer_norm='LN',
+             layer_norm_coors='0', final_h_layer_norm='0', use_dist_in_layers=True, skip_weight_h=0.75,
+             x_connection_init=0.0, leakyrelu_neg_slope=0.01, debug=False, device=torch.device('cpu'),
+             graph_nodes='residues', rot_model='kb_att', noise_decay_rate=0.0, noise_initial=0.0,
+             use_edge_features_in_gmn=True, use_mean_node_features=True, residue_emb_dim=64,
+             iegmn_lay_hid_dim=64, shared_layers=False, num_att_heads=50, iegmn_n_lays=8, fine_tune=False)
+    a.update(over)
+    return a
+
+
+def _lrelu(x, slope):
+    return F.leaky_relu(x, negative_slope=slope)
+
+
+def _mlp5(x, sd, prefix, slope, norm):
+    """Linear -> Dropout(p=0) -> LeakyReLU -> LayerNorm/Identity -> Linear
+    (edge_mlp :119-125, node_mlp :142-148, coors_mlp :153-159)."""
+    y = F.linear(x, sd[prefix + '.0.weight'], sd[prefix + '.0.bias'])
+    y = _lrelu(y, slope)
+    if norm == 'LN':
+        y = F.layer_norm(y, (y.shape[-1],), sd[prefix + '.3.weight'], sd[prefix + '.3.bias'], 1e-5)
+    else:
+        assert norm == '0'
+    return F.linear(y, sd[prefix + '.4.weight'], sd[prefix + '.4.bias'])
+
+
+def get_mask(lig_counts, rec_counts):
+    """src/model/rigid_docking_model.py:68-78."""
+    mask = torch.zeros(sum(lig_counts), sum(rec_counts))
+    pl = pr = 0
+    for ln, rn in zip(lig_counts, rec_counts):
+        mask[pl:pl + ln, pr:pr + rn] = 1
+        pl += ln
+        pr += rn
+    return mask
+
+
+def cross_attention_dense(q, k, v, mask):
+    """src/model/rigid_docking_model.py:46-64 (no 1/sqrt(d), single head, -1000 fill)."""
+    a = mask * torch.mm(q, k.t()) - 1000. * (1. - mask)
+    return torch.mm(torch.softmax(a, dim=1), v)
+
+
+def cross_attention_blockdiag(q, k, v, q_counts, k_counts):
+    """Per-pair softmax: what the reference computes whenever in-pair logits are not < -900."""
+    outs, qo, ko = [], 0, 0
+    for nq, nk in zip(q_counts, k_counts):
+        a = torch.mm(q[qo:qo + nq], k[ko:ko + nk].t())
+        outs.append(torch.mm(torch.softmax(a, dim=1), v[ko:ko + nk]))
+        qo += nq
+        ko += nk
+    return torch.cat(outs, 0)
+
+
+def _mean_by_dst(val, dst, n):
+    """DGL update_all(copy_edge, mean): per-destination mean, zeros for in-degree 0
+    (src/model/rigid_docking_model.py:274-283)."""
+    acc = torch.zeros((n,) + tuple(val.shape[1:]), dtype=val.dtype).index_add(0, dst, val)
+    deg = torch.zeros(n, dtype=val.dtype).index_add(0, dst, torch.ones(dst.numel(), dtype=val.dtype))
+    return acc / deg.clamp(min=1.0).view(n, *([1] * (val.dim() - 1)))
+
+
+def iegmn_layer(sd, pfx, args, d_in, raw, x_l, h_l, h0_l, he_l, x0_l, x_r, h_r, h0_r, he_r, x0_r, faithful, inter=None):
+    """IEGMN_Layer.forward, src/model/rigid_docking_model.py:189-352."""
+    slope = args['leakyrelu_neg_slope']
+    out = {}
+    msgs = {}
+    for side, x, h, he, (src, dst) in (('l', x_l, h_l, he_l, (raw['ll_src'], raw['ll_dst'])),
+                                       ('r', x_r, h_r, he_r, (raw['rr_src'], raw['rr_dst']))):
+        src, dst = src.long(), dst.long()
+        x_rel = x[src] - x[dst]                                              # :204-205
+        d2 = (x_rel ** 2).sum(1, keepdim=True)                               # :208-209
+        rbf = torch.cat([torch.exp(-d2 / s) for s in RBF_SIGMAS], dim=-1)    # :210
+        if not args['use_dist_in_layers']:
+            rbf = rbf * 0.                                                   # :216-218
+        cat = torch.cat([h[src], h[dst], he, rbf], dim=-1)                   # :226-234
+        msg = _mlp5(cat, sd, pfx + 'edge_mlp', slope, args['layer_norm'])    # :236-237
+        coef = _mlp5(msg, sd, pfx + 'coors_mlp', slope, args['layer_norm_coors'])   # :263-265
+        n = x.shape[0]
+        msgs[side] = dict(x_update=_mean_by_dst(x_rel * coef, dst, n),       # :274-277
+                          aggr_msg=_mean_by_dst(msg, dst, n))                # :280-283
+
+    def qkv(h):
+        q = _lrelu(F.linear(h, sd[pfx + 'att_mlp_Q.0.weight']), slope)       # :130-133
+        k = _lrelu(F.linear(h, sd[pfx + 'att_mlp_K.0.weight']), slope)       # :134-137
+        v = F.linear(h, sd[pfx + 'att_mlp_V.0.weight'])                      # :138-140
+        return q, k, v
+    ql, kl, vl = qkv(h_l)
+    qr, kr, vr = qkv(h_r)
+    lc, rc = raw['lig_counts'], raw['rec_counts']
+    if not args['cross_msgs']:
+        cross_l, cross_r = ql * 0., qr * 0.                                  # :59-60
+    elif faithful:
+        mask = get_mask(lc, rc)                                              # :244
+        cross_l = cross_attention_dense(ql, kr, vr, mask)                    # :247-251
+        cross_r = cross_attention_dense(qr, kl, vl, mask.t())                # :252-256
+    else:
+        cross_l = cross_attention_blockdiag(ql, kr, vr, lc, rc)
+        cross_r = cross_attention_blockdiag(qr, kl, vl, rc, lc)
+
+    eta = args['x_connection_init']
+    res = []
+    for side, x, h, h0, x0, cross in (('l', x_l, h_l, h0_l, x0_l, cross_l), ('r', x_r, h_r, h0_r, x0_r, cross_r)):
+        x_new = eta * x0 + (1. - eta) * x + msgs[side]['x_update']           # :286-292
+        inp = torch.cat([h, msgs[side]['aggr_msg'], cross, h0], dim=-1)      # :319-329
+        upd = _mlp5(inp, sd, pfx + 'node_mlp', slope, args['layer_norm'])
+        if d_in == args['iegmn_lay_hid_dim']:                                # :332-337
+            upd = args['skip_weight_h'] * upd + (1. - args['skip_weight_h']) * h
+        assert args['final_h_layer_norm'] == '0'                             # :348-349 (Identity)
+        res.append((x_new, upd))
+    if inter is not None:
+        inter['aggr_cross_l'], inter['aggr_cross_r'] = cross_l, cross_r
+        inter['aggr_msg_l'], inter['aggr_msg_r'] = msgs['l']['aggr_msg'], msgs['r']['aggr_msg']
+    return res[0][0], res[0][1], res[1][0], res[1][1]
+
+
+def kabsch(Yr, Yl, rand_fn=None, status=None):
+    """src/model/rigid_docking_model.py:563-589. Returns T (3,3), b (1,3), A (3,3)."""
+    Yr_mean = Yr.mean(0, keepdim=True)
+    Yl_mean = Yl.mean(0, keepdim=True)
+    A = (Yr - Yr_mean).t() @ (Yl - Yl_mean)                                  # :567
+    assert not torch.isnan(A).any()                                          # :570
+    U, S, Vt = torch.linalg.svd(A)                                           # :571
+    num_it = 0
+    while torch.min(S) < 1e-3 or \
+            torch.min(torch.abs((S ** 2).view(1, 3) - (S ** 2).view(3, 1) + torch.eye(3))) < 1e-2:   # :574
+        draw = torch.rand(3, 3) if rand_fn is None else rand_fn(num_it)
+        A = A + draw * torch.eye(3)                                          # :578
+        U, S, Vt = torch.linalg.svd(A)
+        num_it += 1
+        if num_it > 10:
+            raise RuntimeError('SVD consistently numerically unstable')      # :582-584 (sys.exit there)
+    if status is not None:
+        status.append(num_it)
+    corr = torch.diag(torch.tensor([1., 1., float(torch.sign(torch.det(A.detach())))]))   # :586
+    T = (U @ corr) @ Vt                                                      # :587
+    b = Yr_mean - torch.t(T @ Yl_mean.t())                                   # :589
+    return T, b, A
+
+
+def forward(sd, args, raw, faithful=True, prefix='iegmn_original.', rand_fn=None, return_inter=False):
+    """Rigid_Body_Docking_Net.forward (:642-692) for the single-stage (fine_tune=False) model.
+
+    sd : state_dict with the reference's key names; raw: dict with lig_counts, rec_counts, and per
+    side x / res / mu / src / dst / he tensors (ligand x is `new_x`).
+    Returns (ligand_coords_list, keypts_ligand_list, keypts_receptor_list, rotation_list,
+    translation_list) [+ intermediates]."""
+    assert not args['fine_tune'] and args['dropout'] == 0.0 and args['nonlin'] == 'lkyrelu'
+    slope = args['leakyrelu_neg_slope']
+    L = args['iegmn_n_lays']
+    x_l = x0_l = raw['lig_x']                                                # :452-456
+    x_r = x0_r = raw['rec_x']
+    emb = sd[prefix + 'residue_emb_layer.weight']
+    h_l = emb[raw['lig_res'].view(-1).long()]                                # :459-462
+    h_r = emb[raw['rec_res'].view(-1).long()]
+    if args['use_mean_node_features']:
+        h_l = torch.cat([h_l, torch.log(raw['lig_mu'])], dim=1)              # :467-471
+        h_r = torch.cat([h_r, torch.log(raw['rec_mu'])], dim=1)
+    h0_l, h0_r = h_l, h_r
+    flag = 1.0 if args['use_edge_features_in_gmn'] else 0.0
+    he_l = raw['ll_he'] * flag                                               # :480-481
+    he_r = raw['rr_he'] * flag
+    inter = {'layers': []}
+    for i in range(L):                                                       # :483-501
+        pfx = f'{prefix}iegmn_layers.{i}.'
+        d_in = h_l.shape[1]
+        li = {} if return_inter else None
+        x_l, h_l, x_r, h_r = iegmn_layer(sd, pfx, args, d_in, raw, x_l, h_l, h0_l, he_l, x0_l,
+                                         x_r, h_r, h0_r, he_r, x0_r, faithful, li)
+        if return_inter:
+            li.update(x_l=x_l, h_l=h_l, x_r=x_r, h_r=h_r)
+            inter['layers'].append(li)
+
+    K = args['num_att_heads']
+    d = args['iegmn_lay_hid_dim']
+    Wk = sd[prefix + 'att_mlp_key_ROT.0.weight']
+    Wq = sd[prefix + 'att_mlp_query_ROT.0.weight']
+    Wm, bm = sd[prefix + 'mlp_h_mean_ROT.0.weight'], sd[prefix + 'mlp_h_mean_ROT.0.bias']
+    Ts, bs, Yls, Yrs, As, ligs, status = [], [], [], [], [], [], []
+    lo = ro = 0
+    for nl, nr in zip(raw['lig_counts'], raw['rec_counts']):                 # :521-600
+        H_r, H_l = h_r[ro:ro + nr], h_l[lo:lo + nl]
+        Z_r, Z_l = x_r[ro:ro + nr], x_l[lo:lo + nl]
+        q_r = _lrelu(F.linear(H_r, Wm, bm), slope).mean(0, keepdim=True)     # :524-525
+        q_l = _lrelu(F.linear(H_l, Wm, bm), slope).mean(0, keepdim=True)     # :528-529
+        att_r = torch.softmax(
+            F.linear(H_r, Wk).view(-1, K, d).transpose(0, 1) @
+            F.linear(q_l, Wq).view(1, K, d).transpose(0, 1).transpose(1, 2) / math.sqrt(d),
+            dim=1).view(K, -1)                                               # :542-546
+        Y_r = att_r @ Z_r                                                    # :548
+        att_l = torch.softmax(
+            F.linear(H_l, Wk).view(-1, K, d).transpose(0, 1) @
+            F.linear(q_r, Wq).view(1, K, d).transpose(0, 1).transpose(1, 2) / math.sqrt(d),
+            dim=1).view(K, -1)                                               # :553-557
+        Y_l = att_l @ Z_l                                                    # :559
+        T, b, A = kabsch(Y_r, Y_l, rand_fn, status)
+        Ts.append(T); bs.append(b); Yls.append(Y_l); Yrs.append(Y_r); As.append(A)
+        ligs.append((T @ raw['lig_x'][lo:lo + nl].t()).t() + b)              # :665
+        lo += nl
+        ro += nr
+    outs = (ligs, Yls, Yrs, Ts, bs)
+    if return_inter:
+        inter.update(A=As, svd_iters=status)
+        return outs, inter
+    return outs
+
+
+def scalar_loss(outs):
+    """Fixed scalar loss of SURVEY.md section 8c: sum over pairs of mean(lig'^2)+mean(Yl^2)+mean(Yr^2)."""
+    ligs, Yls, Yrs, _, _ = outs
+    loss = 0.
+    for lig, yl, yr in zip(ligs, Yls, Yrs):
+        loss = loss + (lig ** 2).mean() + (yl ** 2).mean() + (yr ** 2).mean()
+    return loss
+
+
+def raw_from_graph(g):
+    """PairGraph-like object (DGL accessor subset) -> the raw dict this port consumes."""
+    return dict(
+        lig_counts=[int(v) for v in g.batch_num_nodes('ligand')],
+        rec_counts=[int(v) for v in g.batch_num_nodes('receptor')],
+        lig_x=g.nodes['ligand'].data['new_x'].detach().cpu().float(),
+        rec_x=g.nodes['receptor'].data['x'].detach().cpu().float(),
+        lig_res=g.nodes['ligand'].data['res_feat'].detach().cpu(),
+        rec_res=g.nodes['receptor'].data['res_feat'].detach().cpu(),
+        lig_mu=g.nodes['ligand'].data['mu_r_norm'].detach().cpu().float(),
+        rec_mu=g.nodes['receptor'].data['mu_r_norm'].detach().cpu().float(),
+        ll_src=g.edge_endpoints('ll')[0].detach().cpu(), ll_dst=g.edge_endpoints('ll')[1].detach().cpu(),
+        rr_src=g.edge_endpoints('rr')[0].detach().cpu(), rr_dst=g.edge_endpoints('rr')[1].detach().cpu(),
+        ll_he=g.edges['ll'].data['he'].detach().cpu().float(),
+        rr_he=g.edges['rr'].data['he'].detach().cpu().float(),
+    )
+
+
+def init_state_dict(args, seed, rot_scale=40.0):
+    """PyTorch-default-initialised parameters with the reference's names and shapes
+    (IEGMN_Layer.__init__ :82-175, IEGMN.__init__ :360-440), drawn in the reference's module
+    construction order so that, for the same torch seed, they equal the reference's own init;
+    att_mlp_{key,query}_ROT are then scaled x40 (keeps the SVD guard silent)."""
+    import torch.nn as nn
+    g = torch.Generator().manual_seed(seed)
+    state = torch.get_rng_state()
+    torch.manual_seed(seed)
+    try:
+        sd = {}
+        d0 = args['residue_emb_dim'] + (5 if args['use_mean_node_features'] else 0)
+        hid = args['iegmn_lay_hid_dim']
+        emb = nn.Embedding(21, args['residue_emb_dim'])
+        sd['iegmn_original.residue_emb_layer.weight'] = emb.weight.detach().clone()
+
+        def layer(idx, d_in):
+            p = f'iegmn_original.iegmn_layers.{idx}.'
+            mods = [('edge_mlp.0', nn.Linear(2 * d_in + args['input_edge_feats_dim'] + 15, hid)),
+                    ('edge_mlp.3', nn.LayerNorm(hid)), ('edge_mlp.4', nn.Linear(hid, hid)),
+                    ('att_mlp_Q.0', nn.Linear(d_in, d_in, bias=False)),
+                    ('att_mlp_K.0', nn.Linear(d_in, d_in, bias=False)),
+                    ('att_mlp_V.0', nn.Linear(d_in, d_in, bias=False)),
+                    ('node_mlp.0', nn.Linear(d0 + 2 * d_in + hid, d_in)), ('node_mlp.3', nn.LayerNorm(d_in)),
+                    ('node_mlp.4', nn.Linear(d_in, hid)),
+                    ('coors_mlp.0', nn.Linear(hid, hid)), ('coors_mlp.4', nn.Linear(hid, 1))]
+            out = {}
+            for name, m in mods:
+                for k, v in m.state_dict().items():
+                    out[p + name + '.' + k] = v.detach().clone()
+            return out
+        sd.update(layer(0, d0))
+        L = args['iegmn_n_lays']
+        if args['shared_layers']:
+            shared = layer(1, hid)
+            sd.update(shared)
+            for i in range(2, L):
+                for k, v in shared.items():
+                    sd[k.replace('iegmn_layers.1.', f'iegmn_layers.{i}.')] = v
+        else:
+            for i in range(1, L):
+                sd.update(layer(i, hid))
+        K = args['num_att_heads']
+        sd['iegmn_original.att_mlp_key_ROT.0.weight'] = nn.Linear(hid, K * hid, bias=False).weight.detach() * rot_scale
+        sd['iegmn_original.att_mlp_query_ROT.0.weight'] = nn.Linear(hid, K * hid, bias=False).weight.detach() * rot_scale
+        m = nn.Linear(hid, hid)
+        sd['iegmn_original.mlp_h_mean_ROT.0.weight'] = m.weight.detach().clone()
+        sd['iegmn_original.mlp_h_mean_ROT.0.bias'] = m.bias.detach().clone()
+    finally:
+        torch.set_rng_state(state)
+    del g
+    return sd
