@@ -1,0 +1,115 @@
+// Shared device helpers + host-side launcher declarations for libequidock_hip.so (gfx950).
+//
+// MFMA convention used by every matrix kernel in this library ("transposed formulation"):
+// a wave owns a tile of ITEMS (edges or nodes) that live on the N axis of
+// v_mfma_f32_16x16x4_f32 and FEATURES that live on the M axis, i.e. it computes
+//      D^T[feature][item] = W[feature][k] * X^T[k][item].
+// With the gfx950 register layout (A[i=lane&15][k=lane>>4], B[k=lane>>4][j=lane&15],
+// D[row=4*(lane>>4)+reg][col=lane&15]) lane (l15, g) then holds, for item 16*nb+l15, the
+// features f = 16*mb + 4*g + r in acc[mb][nb][r] ("F-layout").  Two consequences:
+//   * per-item reductions over features (LayerNorm, dot products, softmax over keys) are
+//     16 in-lane adds + 2 cross-lane steps (xor 16, 32);
+//   * an F-layout tile IS the B operand of the next GEMM if that GEMM walks its K dimension
+//     in the order k(s=4*mbi+r, g) = 16*mbi + 4*g + r -- so MLP chains (edge_mlp, coors_mlp,
+//     attention P.V, all backward data GEMMs) never leave registers; only the weight (A)
+//     operand is read, as one float4 per (mb_out, mb_in).
+// f32-input MFMA is bit-for-bit an fmaf chain at the fp32 vector peak rate (157 TF), so the
+// 1e-4 fp32 parity bar is met with fp32 summation-order differences only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/equidock_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define EQD_BLOCK 256
+#define EQD_WAVES 4
+#define EQD_NEG_BIG (-1.0e30f)
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 f4zero() {
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    return z;
+}
+__device__ __forceinline__ float lrelu(float v, float s) { return v > 0.f ? v : v * s; }
+__device__ __forceinline__ float lrelu_grad(float y, float s) { return y > 0.f ? 1.f : s; }
+
+// sum / max over the 4 lane groups (same l15): after this every lane of the column has the total
+__device__ __forceinline__ float group_sum(float v) {
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+__device__ __forceinline__ float group_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16));
+    v = fmaxf(v, __shfl_xor(v, 32));
+    return v;
+}
+// sum over the 16 lanes of a lane group (same g)
+__device__ __forceinline__ float l16_sum(float v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) { return group_sum(l16_sum(v)); }
+
+// Ordering point for wave-private LDS traffic (one wave writes, other lanes of the SAME wave
+// read).  The hardware executes a wave's LDS instructions in order; this only stops the
+// compiler from reordering them.  (The host simulator turns it into a wave rendezvous.)
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+void eqd_set_error(const char* fmt, ...);
+int eqd_check_launch(const char* what);
+
+static inline size_t eqd_align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+// bump allocator over a caller-provided workspace
+struct EqdArena {
+    char* base;
+    size_t size, off;
+    bool ok;
+    EqdArena(void* p, size_t n) : base((char*)p), size(n), off(0), ok(true) {}
+    template <typename T>
+    T* take(size_t count) {
+        size_t bytes = eqd_align_up(count * sizeof(T));
+        if (base == nullptr || off + bytes > size) {
+            ok = false;
+            off += bytes;
+            return nullptr;
+        }
+        T* r = (T*)(base + off);
+        off += bytes;
+        return r;
+    }
+};
+
+// internal launchers (defined across the .hip files)
+int eqd_launch_vec_reduce(const float* partial, int nparts, int pstride, int n, float* out, hipStream_t st);
+int eqd_launch_embed_fwd(const EqdGraph* g, const float* emb, int d_emb, int use_mu, float* h0, int ld, hipStream_t st);
+int eqd_launch_embed_bwd(const EqdGraph* g, const float* dh0, int ld, int d_emb, float* demb, float* partial,
+                         hipStream_t st);
+size_t eqd_embed_bwd_partial_floats(const EqdGraph* g, int d_emb);
+int eqd_launch_csc_gather(const EqdGraph* g, const float* dz, const float* dxrel, float* dP, float* dx, hipStream_t st);
+int eqd_launch_ln_act_bwd(const float* y_act, const float* d_out, const float* gamma, int rows, int d, int ld,
+                          float slope, float eps, float* dz, float* dgamma, float* dbeta, float* partial,
+                          hipStream_t st);
+size_t eqd_ln_act_bwd_partial_floats(int rows, int d);
+int eqd_launch_fill(float* p, float v, size_t n, hipStream_t st);
+int eqd_launch_seg_mean(const EqdGraph* g, const float* hm, float* qmean, hipStream_t st);
+int eqd_launch_head_u_bwd(const EqdGraph* g, int K, const float* Wk, const float* Wq, const float* qmean,
+                          const float* qp, const float* du, float* dWk, float* dWq, float* dqm_part, hipStream_t st);
+int eqd_launch_qmean_bwd(const EqdGraph* g, int K, const float* dqm_part, float* dhm, hipStream_t st);
+int eqd_launch_keypoint_bwd(const EqdGraph* g, int K, const float* H, const float* Z, const float* scores,
+                            const float* lse, const float* u, const float* dY, float* dscores, float* du,
+                            float* dH, float* dZ, hipStream_t st);

@@ -1,0 +1,681 @@
+// Edge message + coordinate update of one IEGMN layer, forward and backward, for the ll and rr
+// graphs of every pair in ONE launch (both edge types share all weights).
+//
+// Reference arithmetic replaced (src/model/rigid_docking_model.py):
+//   :204-205  x_rel = x[src] - x[dst]                (DGL u_sub_v)
+//   :208-214  15 RBFs exp(-|x_rel|^2 / 1.5^k)
+//   :226-237  edge_mlp([h_src, h_dst, he, rbf])      = Linear, LeakyReLU, LayerNorm, Linear
+//   :263-266  coef = coors_mlp(msg); x_moment = x_rel * coef
+//   :274-283  per-destination means of x_moment and msg (DGL copy_edge + mean, zero if no in-edge)
+//   :286-292  x' = eta x0 + (1 - eta) x + x_update
+// and its autograd backward (src/train.py:154).
+//
+// Design (see eqd_common.h for the MFMA convention):
+//   * the first Linear is split algebraically: W1 [h_s; h_d; he; rbf] + b1 =
+//     P[src] + Q[dst] + W1c he + W1d rbf with P = h W1a^T, Q = h W1b^T + b1 computed once per NODE
+//     by k_linear -- per-edge MFMA work drops from K=170 to K=42;
+//   * a wave owns a node-aligned tile of <= 32 edges (edges are destination-sorted, so the
+//     per-destination mean is a within-tile reduction; no atomics); the three 64x64 GEMMs chain
+//     through registers; weights (45 KB) are staged once per workgroup in LDS;
+//   * nothing per-edge goes to HBM in the forward; the backward recomputes the tile forward and
+//     writes the five per-edge operands of the weight-gradient GEMMs (a1, m, d_chid, dm, dz1) for
+//     k_atb, plus dz1/dx_rel for the CSC (by-source) gather.
+#include "eqd_common.h"
+
+#include <string.h>
+
+#define WS1 45   /* row stride of the staged W1[:, 2d_in:] block (42 used + 3 zero) */
+#define WS2 68   /* row stride of staged 64x64 weights: 272 B = 17 x 16 B -> conflict-free b128 */
+#define TS 68    /* row stride of the per-wave [32][64+4] tile */
+#define FS 45    /* row stride of the per-wave [32][42+3] feature tile (aliases the tile) */
+#define VEC_LNG 0
+#define VEC_LNB 64
+#define VEC_B2 128
+#define VEC_BC1 192
+#define VEC_WC2 256
+#define VEC_BC2 320
+#define VEC_N 324
+
+struct alignas(16) EdgeSmem {
+    float w1[64 * WS1];
+    float w2[64 * WS2];
+    float wc1[64 * WS2];
+    float vec[VEC_N];
+    float tile[EQD_WAVES][32 * TS];
+};
+
+__device__ __forceinline__ void edge_stage_weights(EdgeSmem& sm, const EqdEdgeParams& P) {
+    const int t = threadIdx.x;
+    const int koff = 2 * P.d_in;
+    for (int i = t; i < 64 * WS1; i += EQD_BLOCK) {
+        const int r = i / WS1, c = i - r * WS1;
+        sm.w1[i] = (c < 42) ? P.W1[(size_t)r * P.ldw1 + koff + c] : 0.f;
+    }
+    for (int i = t; i < 64 * 64; i += EQD_BLOCK) {
+        const int r = i >> 6, c = i & 63;
+        sm.w2[r * WS2 + c] = P.W2[i];
+        sm.wc1[r * WS2 + c] = P.Wc1[i];
+    }
+    if (t < 64) {
+        sm.vec[VEC_LNG + t] = P.ln_g[t];
+        sm.vec[VEC_LNB + t] = P.ln_b[t];
+        sm.vec[VEC_B2 + t] = P.b2[t];
+        sm.vec[VEC_BC1 + t] = P.bc1[t];
+        sm.vec[VEC_WC2 + t] = P.wc2[t];
+    }
+    if (t == 0) sm.vec[VEC_BC2] = P.bc2[0];
+    __syncthreads();
+}
+
+__device__ __forceinline__ float rbf_sigma(int k) {
+    // 1.5 ** k as fp32, k = 0..14 (rigid_docking_model.py:116)
+    const float t[16] = {1.f,          1.5f,         2.25f,        3.375f,        5.0625f,     7.59375f,
+                         11.390625f,   17.0859375f,  25.62890625f, 38.443359375f, 57.6650390625f,
+                         86.49755859375f, 129.746337890625f, 194.6195068359375f, 291.92926025390625f, 1.f};
+    return t[k & 15];
+}
+
+// y = W x chained through registers: out[mbo][nb] += sum_{mbi,r} W[16 mbo + l15][16 mbi + 4 g + r] * in[mbi][nb][r]
+// W staged in LDS with row stride WS2.  If AFF, `in` is first mapped through v * ga[f] + be[f].
+template <bool AFF>
+__device__ __forceinline__ void chain64(f32x4 (&out)[4][2], const f32x4 (&in)[4][2], const float* __restrict__ W,
+                                        const float* __restrict__ ga, const float* __restrict__ be, int l15, int g) {
+#pragma unroll
+    for (int mbi = 0; mbi < 4; ++mbi) {
+        f32x4 b0 = in[mbi][0], b1 = in[mbi][1];
+        if (AFF) {
+            const float4 gg = *(const float4*)&ga[16 * mbi + 4 * g];
+            const float4 bb = *(const float4*)&be[16 * mbi + 4 * g];
+            b0[0] = b0[0] * gg.x + bb.x; b0[1] = b0[1] * gg.y + bb.y; b0[2] = b0[2] * gg.z + bb.z; b0[3] = b0[3] * gg.w + bb.w;
+            b1[0] = b1[0] * gg.x + bb.x; b1[1] = b1[1] * gg.y + bb.y; b1[2] = b1[2] * gg.z + bb.z; b1[3] = b1[3] * gg.w + bb.w;
+        }
+#pragma unroll
+        for (int mbo = 0; mbo < 4; ++mbo) {
+            const float4 w = *(const float4*)&W[(16 * mbo + l15) * WS2 + 16 * mbi + 4 * g];
+            out[mbo][0] = mfma4(w.x, b0[0], out[mbo][0]);
+            out[mbo][1] = mfma4(w.x, b1[0], out[mbo][1]);
+            out[mbo][0] = mfma4(w.y, b0[1], out[mbo][0]);
+            out[mbo][1] = mfma4(w.y, b1[1], out[mbo][1]);
+            out[mbo][0] = mfma4(w.z, b0[2], out[mbo][0]);
+            out[mbo][1] = mfma4(w.z, b1[2], out[mbo][1]);
+            out[mbo][0] = mfma4(w.w, b0[3], out[mbo][0]);
+            out[mbo][1] = mfma4(w.w, b1[3], out[mbo][1]);
+        }
+    }
+}
+// y = W^T x: out[mbo][nb] += sum_{mbi,r} W[16 mbi + 4 g + r][16 mbo + l15] * in[mbi][nb][r]
+__device__ __forceinline__ void chain64T(f32x4 (&out)[4][2], const f32x4 (&in)[4][2], const float* __restrict__ W,
+                                         int l15, int g) {
+#pragma unroll
+    for (int mbi = 0; mbi < 4; ++mbi) {
+#pragma unroll
+        for (int mbo = 0; mbo < 4; ++mbo) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float w = W[(16 * mbi + 4 * g + r) * WS2 + 16 * mbo + l15];
+                out[mbo][0] = mfma4(w, in[mbi][0][r], out[mbo][0]);
+                out[mbo][1] = mfma4(w, in[mbi][1][r], out[mbo][1]);
+            }
+        }
+    }
+}
+
+struct EdgeTileState {
+    int e0, ne, n0, n1;
+    int src[2], dst[2];
+    bool ev[2];
+    float xrel[2][3];
+    float d2[2];
+    float mean[2], rstd[2];
+    float coef[2];
+};
+
+// Forward of one tile up to (and including) the coefficient. On return:
+//   xh = LayerNorm-normalised hidden (before the affine), m = msg, ch = coors_mlp hidden pre-activation.
+// If rbf_out != nullptr the 15 RBFs of each edge are also written there ([E][16]).
+__device__ __forceinline__ void edge_tile_forward(const EqdGraph& G, const EqdEdgeParams& P, EdgeSmem& sm,
+                                                  float* __restrict__ tile, const float* __restrict__ Pn,
+                                                  const float* __restrict__ Qn, const float* __restrict__ x,
+                                                  int lane, EdgeTileState& S, f32x4 (&xh)[4][2], f32x4 (&m)[4][2],
+                                                  f32x4 (&ch)[4][2], float* __restrict__ rbf_out) {
+    const int l15 = lane & 15, g = lane >> 4;
+    // ---- geometry ---------------------------------------------------------------------------
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int el = 16 * nb + l15;
+        S.ev[nb] = el < S.ne;
+        int s = 0, d = 0;
+        if (S.ev[nb]) {
+            s = G.src[S.e0 + el];
+            d = G.dst[S.e0 + el];
+        }
+        S.src[nb] = s;
+        S.dst[nb] = d;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = S.ev[nb] ? x[(size_t)s * 3 + c] - x[(size_t)d * 3 + c] : 0.f;
+            S.xrel[nb][c] = v;
+            q += v * v;
+        }
+        S.d2[nb] = q;
+    }
+    // ---- feature tile [32][45]: he (27) | rbf (15) | 0 -------------------------------------------
+    for (int i = lane; i < 32 * FS; i += 64) tile[i] = 0.f;
+    wave_lds_fence();
+    if (P.use_he) {
+        const float* __restrict__ he = G.he + (size_t)S.e0 * 27;
+        for (int i = lane; i < S.ne * 27; i += 64) {
+            const int e = i / 27, c = i - e * 27;
+            tile[e * FS + c] = he[i];
+        }
+    }
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int el = 16 * nb + l15;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = g + 4 * j;
+            if (k < 15 && S.ev[nb]) {
+                const float v = P.use_dist ? expf(-S.d2[nb] / rbf_sigma(k)) : 0.f;
+                tile[el * FS + 27 + k] = v;
+                if (rbf_out) rbf_out[(size_t)(S.e0 + el) * 16 + k] = v;
+            }
+        }
+        if (rbf_out && g == 3 && S.ev[nb]) rbf_out[(size_t)(S.e0 + el) * 16 + 15] = 0.f;
+    }
+    wave_lds_fence();
+    // ---- stage 1: z1 = P[src] + Q[dst] + W1cd feat ----------------------------------------------
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            f32x4 a = f4zero();
+            if (S.ev[nb]) {
+                const float4 p = *(const float4*)&Pn[(size_t)S.src[nb] * 64 + 16 * mb + 4 * g];
+                const float4 q = *(const float4*)&Qn[(size_t)S.dst[nb] * 64 + 16 * mb + 4 * g];
+                a[0] = p.x + q.x; a[1] = p.y + q.y; a[2] = p.z + q.z; a[3] = p.w + q.w;
+            }
+            xh[mb][nb] = a;
+        }
+#pragma unroll
+    for (int s = 0; s < 11; ++s) {
+        const int k = 4 * s + g;
+        const float b0 = tile[l15 * FS + k];
+        const float b1 = tile[(16 + l15) * FS + k];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const float a = sm.w1[(16 * mb + l15) * WS1 + k];
+            xh[mb][0] = mfma4(a, b0, xh[mb][0]);
+            xh[mb][1] = mfma4(a, b1, xh[mb][1]);
+        }
+    }
+    // ---- LeakyReLU + LayerNorm statistics (two-pass like torch) ------------------------------------
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        float s = 0.f;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = lrelu(xh[mb][nb][r], P.slope);
+                xh[mb][nb][r] = v;
+                s += v;
+            }
+        const float mean = group_sum(s) * (1.f / 64.f);
+        float q = 0.f;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = xh[mb][nb][r] - mean;
+                q += d * d;
+            }
+        const float rstd = 1.f / sqrtf(group_sum(q) * (1.f / 64.f) + P.ln_eps);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xh[mb][nb][r] = (xh[mb][nb][r] - mean) * rstd;
+        S.mean[nb] = mean;
+        S.rstd[nb] = rstd;
+    }
+    // ---- stage 2: m = W2 (xh * gamma + beta) + b2 --------------------------------------------------
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        const float4 b = *(const float4*)&sm.vec[VEC_B2 + 16 * mb + 4 * g];
+        f32x4 v = {b.x, b.y, b.z, b.w};
+        m[mb][0] = v;
+        m[mb][1] = v;
+    }
+    chain64<true>(m, xh, sm.w2, &sm.vec[VEC_LNG], &sm.vec[VEC_LNB], l15, g);
+    // ---- stage 3: ch = Wc1 m + bc1; coef = wc2 . LeakyReLU(ch) + bc2 ---------------------------------
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        const float4 b = *(const float4*)&sm.vec[VEC_BC1 + 16 * mb + 4 * g];
+        f32x4 v = {b.x, b.y, b.z, b.w};
+        ch[mb][0] = v;
+        ch[mb][1] = v;
+    }
+    chain64<false>(ch, m, sm.wc1, nullptr, nullptr, l15, g);
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        float s = 0.f;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const float4 w = *(const float4*)&sm.vec[VEC_WC2 + 16 * mb + 4 * g];
+            s += lrelu(ch[mb][nb][0], P.slope) * w.x + lrelu(ch[mb][nb][1], P.slope) * w.y +
+                 lrelu(ch[mb][nb][2], P.slope) * w.z + lrelu(ch[mb][nb][3], P.slope) * w.w;
+        }
+        S.coef[nb] = group_sum(s) + sm.vec[VEC_BC2];
+    }
+}
+
+// store an F-layout tile into the per-wave LDS tile as [edge][feature] (stride TS)
+__device__ __forceinline__ void tile_store(float* __restrict__ tile, const f32x4 (&v)[4][2], int l15, int g) {
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+            *(float4*)&tile[(16 * nb + l15) * TS + 16 * mb + 4 * g] =
+                make_float4(v[mb][nb][0], v[mb][nb][1], v[mb][nb][2], v[mb][nb][3]);
+}
+// store an F-layout tile to HBM as [edge][64]
+__device__ __forceinline__ void hbm_store(float* __restrict__ dst, const f32x4 (&v)[4][2], const EdgeTileState& S,
+                                          int l15, int g) {
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+        if (S.ev[nb]) {
+            float* row = dst + (size_t)(S.e0 + 16 * nb + l15) * 64;
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+                *(float4*)&row[16 * mb + 4 * g] = make_float4(v[mb][nb][0], v[mb][nb][1], v[mb][nb][2], v[mb][nb][3]);
+        }
+}
+
+__global__ __launch_bounds__(EQD_BLOCK) void k_edge_fwd(EqdGraph G, EqdEdgeParams P, const float* __restrict__ Pn,
+                                                        const float* __restrict__ Qn, const float* __restrict__ x,
+                                                        float* __restrict__ aggr_msg, float* __restrict__ x_new) {
+    __shared__ EdgeSmem sm;
+    edge_stage_weights(sm, P);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    float* tile = sm.tile[wave];
+    for (int t = blockIdx.x * EQD_WAVES + wave; t < G.n_tiles; t += gridDim.x * EQD_WAVES) {
+        EdgeTileState S;
+        S.n0 = G.tile_node[t];
+        S.n1 = G.tile_node[t + 1];
+        S.e0 = G.rowptr[S.n0];
+        S.ne = G.rowptr[S.n1] - S.e0;
+        f32x4 xh[4][2], m[4][2], ch[4][2];
+        edge_tile_forward(G, P, sm, tile, Pn, Qn, x, lane, S, xh, m, ch, nullptr);
+        wave_lds_fence();   // feature tile is dead: reuse as the message tile
+        tile_store(tile, m, l15, g);
+        if (g == 0) {
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) tile[(16 * nb + l15) * TS + 64 + c] = S.xrel[nb][c] * S.coef[nb];
+        }
+        wave_lds_fence();
+        for (int n = S.n0; n < S.n1; ++n) {
+            const int a = G.rowptr[n] - S.e0, b = G.rowptr[n + 1] - S.e0;
+            float s = 0.f, sx = 0.f;
+            for (int e = a; e < b; ++e) {
+                s += tile[e * TS + lane];
+                if (lane < 3) sx += tile[e * TS + 64 + lane];
+            }
+            const float inv = b > a ? 1.f / (float)(b - a) : 0.f;
+            aggr_msg[(size_t)n * 64 + lane] = s * inv;
+            if (lane < 3) {
+                const size_t o = (size_t)n * 3 + lane;
+                x_new[o] = P.eta * G.x0[o] + (1.f - P.eta) * x[o] + sx * inv;
+            }
+        }
+        wave_lds_fence();
+    }
+}
+
+extern "C" int eqd_edge_message_fwd(const EqdGraph* g, const EqdEdgeParams* p, const float* P, const float* Q,
+                                    const float* x, float* aggr_msg, float* x_new, void* stream) {
+    if (!g || !p || !P || !Q || !x || !aggr_msg || !x_new) {
+        eqd_set_error("eqd_edge_message_fwd: NULL argument");
+        return EQD_ERR_NULL;
+    }
+    if (g->n_tiles <= 0) return EQD_OK;
+    int blocks = (g->n_tiles + EQD_WAVES - 1) / EQD_WAVES;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_edge_fwd, dim3(blocks), dim3(EQD_BLOCK), 0, (hipStream_t)stream, *g, *p, P, Q, x, aggr_msg,
+                       x_new);
+    return eqd_check_launch("k_edge_fwd");
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------
+struct EdgeBwdWs {
+    float* a1;     // [E][64] LayerNorm output (input of edge_mlp.4)
+    float* m;      // [E][64] messages
+    float* dchid;  // [E][64] grad wrt coors_mlp.0 output
+    float* dm;     // [E][64] grad wrt messages
+    float* dz1;    // [E][64] grad wrt edge_mlp.0 output
+    float* rbf;    // [E][16]
+    float* dxrel;  // [E][4]
+    float* vecp;   // [nwaves][256]: d ln_g | d ln_b | d wc2 | d bc2 (slot 192)
+};
+
+__global__ __launch_bounds__(EQD_BLOCK) void k_edge_bwd(EqdGraph G, EqdEdgeParams P, const float* __restrict__ Pn,
+                                                        const float* __restrict__ Qn, const float* __restrict__ x,
+                                                        const float* __restrict__ d_aggr,
+                                                        const float* __restrict__ d_xnew, float* __restrict__ dQ,
+                                                        float* __restrict__ dx, EdgeBwdWs W) {
+    __shared__ EdgeSmem sm;
+    __shared__ float vacc[EQD_WAVES][256];
+    edge_stage_weights(sm, P);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    float* tile = sm.tile[wave];
+    for (int i = lane; i < 256; i += 64) vacc[wave][i] = 0.f;
+    wave_lds_fence();
+    for (int t = blockIdx.x * EQD_WAVES + wave; t < G.n_tiles; t += gridDim.x * EQD_WAVES) {
+        EdgeTileState S;
+        S.n0 = G.tile_node[t];
+        S.n1 = G.tile_node[t + 1];
+        S.e0 = G.rowptr[S.n0];
+        S.ne = G.rowptr[S.n1] - S.e0;
+        f32x4 xh[4][2], m[4][2], ch[4][2];
+        edge_tile_forward(G, P, sm, tile, Pn, Qn, x, lane, S, xh, m, ch, W.rbf);
+        wave_lds_fence();
+        // ---- operands of the weight-gradient GEMMs that the forward defines --------------------
+        {
+            f32x4 a1[4][2];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const float4 gg = *(const float4*)&sm.vec[VEC_LNG + 16 * mb + 4 * g];
+                const float4 bb = *(const float4*)&sm.vec[VEC_LNB + 16 * mb + 4 * g];
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    a1[mb][nb][0] = xh[mb][nb][0] * gg.x + bb.x;
+                    a1[mb][nb][1] = xh[mb][nb][1] * gg.y + bb.y;
+                    a1[mb][nb][2] = xh[mb][nb][2] * gg.z + bb.z;
+                    a1[mb][nb][3] = xh[mb][nb][3] * gg.w + bb.w;
+                }
+            }
+            hbm_store(W.a1, a1, S, l15, g);
+        }
+        hbm_store(W.m, m, S, l15, g);
+        // ---- coordinate path ---------------------------------------------------------------------
+        float invdeg[2], dcoef[2], dxr[2][3];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            float dc = 0.f;
+            invdeg[nb] = 0.f;
+            if (S.ev[nb]) {
+                const int d = S.dst[nb];
+                invdeg[nb] = 1.f / (float)(G.rowptr[d + 1] - G.rowptr[d]);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float gx = d_xnew[(size_t)d * 3 + c] * invdeg[nb];
+                    dc += gx * S.xrel[nb][c];
+                    dxr[nb][c] = gx * S.coef[nb];
+                }
+            } else {
+                dxr[nb][0] = dxr[nb][1] = dxr[nb][2] = 0.f;
+            }
+            dcoef[nb] = dc;
+        }
+        // d wc2 / d bc2 partials, then ch := d_chid = wc2 * dcoef * LeakyReLU'(ch)
+        float pw[4][4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const float4 w = *(const float4*)&sm.vec[VEC_WC2 + 16 * mb + 4 * g];
+            const float wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float acc = 0.f;
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    const float c = ch[mb][nb][r];
+                    acc += lrelu(c, P.slope) * dcoef[nb];
+                    ch[mb][nb][r] = wv[r] * dcoef[nb] * lrelu_grad(c, P.slope);
+                }
+                pw[mb][r] = acc;
+            }
+        }
+        hbm_store(W.dchid, ch, S, l15, g);
+        // ---- dm = d_aggr[dst] / deg + Wc1^T d_chid ---------------------------------------------------
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                f32x4 a = f4zero();
+                if (S.ev[nb]) {
+                    const float4 v = *(const float4*)&d_aggr[(size_t)S.dst[nb] * 64 + 16 * mb + 4 * g];
+                    a[0] = v.x * invdeg[nb]; a[1] = v.y * invdeg[nb]; a[2] = v.z * invdeg[nb]; a[3] = v.w * invdeg[nb];
+                }
+                m[mb][nb] = a;
+            }
+        chain64T(m, ch, sm.wc1, l15, g);
+        hbm_store(W.dm, m, S, l15, g);
+        // ---- da1 = W2^T dm ---------------------------------------------------------------------------
+        f32x4 dz[4][2];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            dz[mb][0] = f4zero();
+            dz[mb][1] = f4zero();
+        }
+        chain64T(dz, m, sm.w2, l15, g);
+        // ---- LayerNorm + LeakyReLU backward --------------------------------------------------------------
+        float pg[4][4], pb[4][4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pg[mb][r] = 0.f;
+                pb[mb][r] = 0.f;
+            }
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const float4 gg = *(const float4*)&sm.vec[VEC_LNG + 16 * mb + 4 * g];
+                const float gv[4] = {gg.x, gg.y, gg.z, gg.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float da = dz[mb][nb][r];
+                    pg[mb][r] += da * xh[mb][nb][r];
+                    pb[mb][r] += da;
+                    const float dxh = da * gv[r];
+                    dz[mb][nb][r] = dxh;
+                    s1 += dxh;
+                    s2 += dxh * xh[mb][nb][r];
+                }
+            }
+            s1 = group_sum(s1) * (1.f / 64.f);
+            s2 = group_sum(s2) * (1.f / 64.f);
+            const float std = 1.f / S.rstd[nb];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float xhv = xh[mb][nb][r];
+                    const float y = xhv * std + S.mean[nb];
+                    dz[mb][nb][r] = S.ev[nb] ? S.rstd[nb] * (dz[mb][nb][r] - s1 - xhv * s2) * lrelu_grad(y, P.slope) : 0.f;
+                }
+        }
+        hbm_store(W.dz1, dz, S, l15, g);
+        // ---- d rbf = W1d^T dz1 -> d(d^2) -> d x_rel --------------------------------------------------------
+        if (P.use_dist) {
+            f32x4 dr[2] = {f4zero(), f4zero()};
+#pragma unroll
+            for (int mbi = 0; mbi < 4; ++mbi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float w = (l15 < 15) ? sm.w1[(16 * mbi + 4 * g + r) * WS1 + 27 + l15] : 0.f;
+                    dr[0] = mfma4(w, dz[mbi][0][r], dr[0]);
+                    dr[1] = mfma4(w, dz[mbi][1][r], dr[1]);
+                }
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                float s = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = 4 * g + r;
+                    if (k < 15) {
+                        const float sg = rbf_sigma(k);
+                        s += dr[nb][r] * expf(-S.d2[nb] / sg) * (-1.f / sg);
+                    }
+                }
+                const float dd2 = group_sum(s);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) dxr[nb][c] += 2.f * S.xrel[nb][c] * dd2;
+            }
+        }
+        // ---- per-destination sums: dQ[dst] = sum dz1, dx[dst] = (1-eta) d_xnew - sum dx_rel ------------------
+        tile_store(tile, dz, l15, g);
+        if (g == 0) {
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                const int el = 16 * nb + l15;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) tile[el * TS + 64 + c] = dxr[nb][c];
+                if (S.ev[nb]) {
+                    float* o = W.dxrel + (size_t)(S.e0 + el) * 4;
+                    o[0] = dxr[nb][0]; o[1] = dxr[nb][1]; o[2] = dxr[nb][2]; o[3] = 0.f;
+                }
+            }
+        }
+        wave_lds_fence();
+        for (int n = S.n0; n < S.n1; ++n) {
+            const int a = G.rowptr[n] - S.e0, b = G.rowptr[n + 1] - S.e0;
+            float s = 0.f, sx = 0.f;
+            for (int e = a; e < b; ++e) {
+                s += tile[e * TS + lane];
+                if (lane < 3) sx += tile[e * TS + 64 + lane];
+            }
+            dQ[(size_t)n * 64 + lane] = s;
+            if (lane < 3) {
+                const size_t o = (size_t)n * 3 + lane;
+                dx[o] = (1.f - P.eta) * d_xnew[o] - sx;
+            }
+        }
+        wave_lds_fence();
+        // ---- vector-gradient partials: reduce over the 16 edge lanes, accumulate per wave in LDS ----------
+        float dbc2 = dcoef[0] + dcoef[1];
+        dbc2 = l16_sum(dbc2);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float a = l16_sum(pg[mb][r]);
+                const float b = l16_sum(pb[mb][r]);
+                const float c = l16_sum(pw[mb][r]);
+                if (l15 == 0) {
+                    const int f = 16 * mb + 4 * g + r;
+                    vacc[wave][f] += a;
+                    vacc[wave][64 + f] += b;
+                    vacc[wave][128 + f] += c;
+                }
+            }
+        if (lane == 0) vacc[wave][192] += dbc2;
+        wave_lds_fence();
+    }
+    wave_lds_fence();
+    float* vp = W.vecp + (size_t)(blockIdx.x * EQD_WAVES + wave) * 256;
+    for (int i = lane; i < 256; i += 64) vp[i] = vacc[wave][i];
+}
+
+static int edge_bwd_blocks(const EqdGraph* g) {
+    int blocks = (g->n_tiles + EQD_WAVES - 1) / EQD_WAVES;
+    if (blocks > 512) blocks = 512;
+    if (blocks < 1) blocks = 1;
+    return blocks;
+}
+
+static void edge_atb_jobs(const EqdGraph* g, const EqdEdgeParams* p, const EqdEdgeGrads* gr, const EdgeBwdWs& W,
+                          EqdAtbJob* jobs) {
+    const int E = g->n_edges;
+    const int koff = 2 * p->d_in;
+    memset(jobs, 0, 4 * sizeof(EqdAtbJob));
+    // dW1[:, 2d:2d+27] = dz1^T he
+    jobs[0].X = W.dz1; jobs[0].ldx = 64; jobs[0].M = 64; jobs[0].Y = g->he; jobs[0].ldy = 27; jobs[0].N = 27;
+    jobs[0].rows = p->use_he ? E : 0; jobs[0].out = gr->dW1 + koff; jobs[0].o_rs = gr->ldw1; jobs[0].o_cs = 1;
+    // dW1[:, 2d+27:] = dz1^T rbf
+    jobs[1].X = W.dz1; jobs[1].ldx = 64; jobs[1].M = 64; jobs[1].Y = W.rbf; jobs[1].ldy = 16; jobs[1].N = 15;
+    jobs[1].rows = E; jobs[1].out = gr->dW1 + koff + 27; jobs[1].o_rs = gr->ldw1; jobs[1].o_cs = 1;
+    // dW2 = dm^T a1, db2 = colsum dm
+    jobs[2].X = W.dm; jobs[2].ldx = 64; jobs[2].M = 64; jobs[2].Y = W.a1; jobs[2].ldy = 64; jobs[2].N = 64;
+    jobs[2].rows = E; jobs[2].out = gr->dW2; jobs[2].o_rs = 64; jobs[2].o_cs = 1; jobs[2].bias_out = gr->db2;
+    // dWc1 = dchid^T m, dbc1 = colsum dchid
+    jobs[3].X = W.dchid; jobs[3].ldx = 64; jobs[3].M = 64; jobs[3].Y = W.m; jobs[3].ldy = 64; jobs[3].N = 64;
+    jobs[3].rows = E; jobs[3].out = gr->dWc1; jobs[3].o_rs = 64; jobs[3].o_cs = 1; jobs[3].bias_out = gr->dbc1;
+}
+
+static size_t edge_bwd_carve(const EqdGraph* g, EqdArena& A, EdgeBwdWs* W, float** atb_partial, size_t* atb_bytes) {
+    const size_t E = (size_t)g->n_edges;
+    EdgeBwdWs w;
+    w.a1 = A.take<float>(E * 64);
+    w.m = A.take<float>(E * 64);
+    w.dchid = A.take<float>(E * 64);
+    w.dm = A.take<float>(E * 64);
+    w.dz1 = A.take<float>(E * 64);
+    w.rbf = A.take<float>(E * 16);
+    w.dxrel = A.take<float>(E * 4);
+    w.vecp = A.take<float>((size_t)edge_bwd_blocks(g) * EQD_WAVES * 256);
+    // worst-case partial size for the four weight-gradient GEMMs (depends only on E)
+    EqdAtbJob jobs[4];
+    EqdEdgeParams p;
+    memset(&p, 0, sizeof(p));
+    p.use_he = 1;
+    EqdEdgeGrads gr;
+    memset(&gr, 0, sizeof(gr));
+    edge_atb_jobs(g, &p, &gr, w, jobs);
+    size_t pb = eqd_atb_partial_bytes(jobs, 4);
+    float* part = (float*)A.take<char>(pb);
+    if (W) *W = w;
+    if (atb_partial) *atb_partial = part;
+    if (atb_bytes) *atb_bytes = pb;
+    return A.off;
+}
+
+extern "C" size_t eqd_edge_message_bwd_workspace_bytes(const EqdGraph* g) {
+    EqdArena A(nullptr, 0);
+    return edge_bwd_carve(g, A, nullptr, nullptr, nullptr) + 256;
+}
+
+extern "C" int eqd_edge_message_bwd(const EqdGraph* g, const EqdEdgeParams* p, const float* P, const float* Q,
+                                    const float* x, const float* d_aggr_msg, const float* d_xnew, float* dP,
+                                    float* dQ, float* dx, const EqdEdgeGrads* grads, void* workspace,
+                                    size_t ws_bytes, void* stream) {
+    if (!g || !p || !P || !Q || !x || !d_aggr_msg || !d_xnew || !dP || !dQ || !dx || !grads) {
+        eqd_set_error("eqd_edge_message_bwd: NULL argument");
+        return EQD_ERR_NULL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    EqdArena A(workspace, ws_bytes);
+    EdgeBwdWs W;
+    float* part = nullptr;
+    size_t pb = 0;
+    edge_bwd_carve(g, A, &W, &part, &pb);
+    if (!A.ok) {
+        eqd_set_error("eqd_edge_message_bwd: workspace too small (%zu needed, %zu given)", A.off, ws_bytes);
+        return EQD_ERR_WORKSPACE;
+    }
+    const int blocks = edge_bwd_blocks(g);
+    if (g->n_tiles > 0) {
+        hipLaunchKernelGGL(k_edge_bwd, dim3(blocks), dim3(EQD_BLOCK), 0, st, *g, *p, P, Q, x, d_aggr_msg, d_xnew, dQ,
+                           dx, W);
+        int rc = eqd_check_launch("k_edge_bwd");
+        if (rc) return rc;
+        const int nw = blocks * EQD_WAVES;
+        if ((rc = eqd_launch_vec_reduce(W.vecp, nw, 256, 64, grads->dln_g, st))) return rc;
+        if ((rc = eqd_launch_vec_reduce(W.vecp + 64, nw, 256, 64, grads->dln_b, st))) return rc;
+        if ((rc = eqd_launch_vec_reduce(W.vecp + 128, nw, 256, 64, grads->dwc2, st))) return rc;
+        if ((rc = eqd_launch_vec_reduce(W.vecp + 192, nw, 256, 1, grads->dbc2, st))) return rc;
+    }
+    EqdAtbJob jobs[4];
+    edge_atb_jobs(g, p, grads, W, jobs);
+    int rc = eqd_atb(jobs + (p->use_he ? 0 : 1), p->use_he ? 4 : 3, part, pb, st);
+    if (rc) return rc;
+    return eqd_launch_csc_gather(g, W.dz1, W.dxrel, dP, dx, st);
+}

@@ -1,0 +1,542 @@
+// Node-level building blocks: multi-source linear (fwd and dX), A^T B weight gradients with a
+// deterministic two-stage reduction, LayerNorm+LeakyReLU backward, embedding fwd/bwd, CSC gather.
+//
+// Reference arithmetic replaced: every nn.Linear / nn.LayerNorm / nn.Embedding on the hot path
+// (src/model/rigid_docking_model.py:119-159, 382, 427-438) and their autograd backward.
+#include "eqd_common.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+// ------------------------------------------------------------------------------------------
+// error plumbing (host)
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void eqd_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+int eqd_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        eqd_set_error("launch of %s failed: %s", what, hipGetErrorString(e));
+        return EQD_ERR_LAUNCH;
+    }
+    return EQD_OK;
+}
+extern "C" const char* eqd_last_error(void) { return g_err; }
+extern "C" int eqd_abi_version(void) { return EQD_ABI_VERSION; }
+extern "C" int eqd_tile_edges(void) { return EQD_TILE_EDGES; }
+
+// ------------------------------------------------------------------------------------------
+// k_linear: Y = alpha * f(sum_s (X_s * lrelu'(mask_s)) W_s^T + bias) + beta * R
+// wave tile: 32 rows (items on the MFMA N axis) x up to 80 outputs (M axis, MB = 5 blocks)
+// ------------------------------------------------------------------------------------------
+#define LIN_MAXJOBS 8
+struct LinJobsArg {
+    EqdLinJob j[LIN_MAXJOBS];
+};
+
+__global__ __launch_bounds__(EQD_BLOCK) void k_linear(LinJobsArg jobs) {
+    const EqdLinJob& J = jobs.j[blockIdx.y];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int row0 = ((int)blockIdx.x * EQD_WAVES + wave) * 32;
+    if (row0 >= J.rows) return;
+    const int M = J.M;
+    const int mbn = (M + 15) >> 4;
+    f32x4 acc[5][2];
+#pragma unroll
+    for (int mb = 0; mb < 5; ++mb) {
+        acc[mb][0] = f4zero();
+        acc[mb][1] = f4zero();
+    }
+    int rowi[2] = {row0 + l15, row0 + 16 + l15};
+    bool rv[2] = {rowi[0] < J.rows, rowi[1] < J.rows};
+
+    for (int s = 0; s < J.nsrc; ++s) {
+        const EqdLinSrc& S = J.s[s];
+        const float* __restrict__ X = S.X;
+        const float* __restrict__ W = S.W;
+        const float* __restrict__ mk = S.mask;
+        const int K = S.K;
+#pragma unroll 2
+        for (int k0 = 0; k0 < K; k0 += 4) {
+            const int k = k0 + g;
+            const bool kv = k < K;
+            float b[2];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                float v = 0.f;
+                if (rv[nb] && kv) {
+                    const size_t o = (size_t)rowi[nb] * S.ldx + k;
+                    v = X[o];
+                    if (mk) v *= lrelu_grad(mk[o], J.slope);
+                }
+                b[nb] = v;
+            }
+#pragma unroll
+            for (int mb = 0; mb < 5; ++mb) {
+                if (mb < mbn) {
+                    const int m = 16 * mb + l15;
+                    const float a = (m < M && kv) ? W[(size_t)m * S.w_rs + (size_t)k * S.w_cs] : 0.f;
+                    acc[mb][0] = mfma4(a, b[0], acc[mb][0]);
+                    acc[mb][1] = mfma4(a, b[1], acc[mb][1]);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue in F-layout: feature f = 16 mb + 4 g + r, row = rowi[nb] --------------------
+#pragma unroll
+    for (int mb = 0; mb < 5; ++mb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = 16 * mb + 4 * g + r;
+            const float bi = (J.bias && f < M) ? J.bias[f] : 0.f;
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                float v = acc[mb][nb][r] + bi;
+                if (J.act) v = lrelu(v, J.slope);
+                acc[mb][nb][r] = (f < M) ? v : 0.f;
+            }
+        }
+    }
+    if (J.ln_g) {
+        const float invM = 1.f / (float)M;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            float s = 0.f;
+#pragma unroll
+            for (int mb = 0; mb < 5; ++mb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s += acc[mb][nb][r];
+            const float mean = group_sum(s) * invM;
+            float q = 0.f;
+#pragma unroll
+            for (int mb = 0; mb < 5; ++mb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int f = 16 * mb + 4 * g + r;
+                    const float dlt = (f < M) ? acc[mb][nb][r] - mean : 0.f;
+                    q += dlt * dlt;
+                }
+            const float rstd = 1.f / sqrtf(group_sum(q) * invM + J.ln_eps);
+#pragma unroll
+            for (int mb = 0; mb < 5; ++mb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int f = 16 * mb + 4 * g + r;
+                    if (f < M) {
+                        const float v = acc[mb][nb][r];
+                        if (J.pre_ln && rv[nb]) J.pre_ln[(size_t)rowi[nb] * J.ld_pre + f] = v;
+                        acc[mb][nb][r] = (v - mean) * rstd * J.ln_g[f] + J.ln_b[f];
+                    }
+                }
+        }
+    }
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        if (!rv[nb]) continue;
+#pragma unroll
+        for (int mb = 0; mb < 5; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = 16 * mb + 4 * g + r;
+                if (f < M) {
+                    float v = J.alpha * acc[mb][nb][r];
+                    if (J.R) v += J.beta * J.R[(size_t)rowi[nb] * J.ldr + f];
+                    J.Y[(size_t)rowi[nb] * J.ldy + f] = v;
+                }
+            }
+    }
+}
+
+extern "C" int eqd_linear(const EqdLinJob* jobs, int njobs, void* stream) {
+    if (!jobs || njobs <= 0) {
+        eqd_set_error("eqd_linear: no jobs");
+        return EQD_ERR_NULL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    for (int base = 0; base < njobs; base += LIN_MAXJOBS) {
+        LinJobsArg arg;
+        memset(&arg, 0, sizeof(arg));
+        int n = njobs - base < LIN_MAXJOBS ? njobs - base : LIN_MAXJOBS;
+        int maxrows = 0;
+        for (int i = 0; i < n; ++i) {
+            const EqdLinJob& J = jobs[base + i];
+            if (J.M <= 0 || J.M > 80 || J.nsrc <= 0 || J.nsrc > EQD_MAX_SRC || !J.Y) {
+                eqd_set_error("eqd_linear: job %d has M=%d nsrc=%d (need 1..80 outputs, 1..%d sources)", base + i, J.M,
+                              J.nsrc, EQD_MAX_SRC);
+                return EQD_ERR_SHAPE;
+            }
+            if (J.ln_g && !J.ln_b) {
+                eqd_set_error("eqd_linear: job %d has LayerNorm weight without bias", base + i);
+                return EQD_ERR_NULL;
+            }
+            arg.j[i] = J;
+            if (J.rows > maxrows) maxrows = J.rows;
+        }
+        if (maxrows == 0) continue;
+        dim3 grid((maxrows + 127) / 128, n);
+        hipLaunchKernelGGL(k_linear, grid, dim3(EQD_BLOCK), 0, st, arg);
+        int rc = eqd_check_launch("k_linear");
+        if (rc) return rc;
+    }
+    return EQD_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_atb: partial[unit][chunk][m][n] = sum_{rows in chunk} Xm[row][m] * Y[row][n0 + n]
+//   wave tile: 80 (M axis, output rows m) x 64 (N axis, output cols n), K axis = graph rows.
+//   then k_atb_reduce sums the chunks in a fixed order and accumulates into the gradient.
+// ------------------------------------------------------------------------------------------
+#define ATB_MAXUNITS 16
+#define ATB_TILE 5120  /* 80 x 64 */
+#define ATB_PSTRIDE 5200
+struct AtbUnit {
+    EqdAtbJob job;
+    int n0, nparts, rpw;
+    long long poff;  // float offset of this unit's partials
+};
+struct AtbUnitsArg {
+    AtbUnit u[ATB_MAXUNITS];
+};
+
+__global__ __launch_bounds__(EQD_BLOCK) void k_atb(AtbUnitsArg U, float* __restrict__ partial) {
+    const AtbUnit& u = U.u[blockIdx.y];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int c = (int)blockIdx.x * EQD_WAVES + wave;
+    if (c >= u.nparts) return;
+    const EqdAtbJob& J = u.job;
+    const int r0 = c * u.rpw;
+    const int r1 = (r0 + u.rpw < J.rows) ? r0 + u.rpw : J.rows;
+    const int M = J.M, N = J.N;
+    const int mbn = (M + 15) >> 4;
+    f32x4 acc[5][4];
+    float bsum[5];
+#pragma unroll
+    for (int mb = 0; mb < 5; ++mb) {
+        bsum[mb] = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = f4zero();
+    }
+    const float* __restrict__ X = J.X;
+    const float* __restrict__ Y = J.Y;
+    const float* __restrict__ xm = J.xmask;
+#pragma unroll 2
+    for (int r = r0; r < r1; r += 4) {
+        const int row = r + g;
+        const bool rv = row < r1;
+        float a[5], b[4];
+#pragma unroll
+        for (int mb = 0; mb < 5; ++mb) {
+            const int m = 16 * mb + l15;
+            float v = 0.f;
+            if (rv && m < M) {
+                const size_t o = (size_t)row * J.ldx + m;
+                v = X[o];
+                if (xm) v *= lrelu_grad(xm[o], J.slope);
+            }
+            a[mb] = v;
+            bsum[mb] += v;
+        }
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            const int n = u.n0 + 16 * nb + l15;
+            b[nb] = (rv && n < N) ? Y[(size_t)row * J.ldy + n] : 0.f;
+        }
+#pragma unroll
+        for (int mb = 0; mb < 5; ++mb)
+            if (mb < mbn) {
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = mfma4(a[mb], b[nb], acc[mb][nb]);
+            }
+    }
+    float* P = partial + u.poff + (long long)c * ATB_PSTRIDE;
+#pragma unroll
+    for (int mb = 0; mb < 5; ++mb) {
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) P[(16 * mb + 4 * g + r) * 64 + 16 * nb + l15] = acc[mb][nb][r];
+        const float bs = group_sum(bsum[mb]);
+        if (g == 0) P[ATB_TILE + 16 * mb + l15] = bs;
+    }
+}
+
+__global__ __launch_bounds__(EQD_BLOCK) void k_atb_reduce(AtbUnitsArg U, const float* __restrict__ partial) {
+    const AtbUnit& u = U.u[blockIdx.y];
+    const EqdAtbJob& J = u.job;
+    const int e = blockIdx.x * EQD_BLOCK + threadIdx.x;
+    if (e >= ATB_PSTRIDE) return;
+    int m, n = 0;
+    bool is_bias = e >= ATB_TILE;
+    if (is_bias) {
+        m = e - ATB_TILE;
+        if (!(J.bias_out && u.n0 == 0 && m < J.M)) return;
+    } else {
+        m = e >> 6;
+        n = u.n0 + (e & 63);
+        if (m >= J.M || n >= J.N) return;
+    }
+    const float* P = partial + u.poff + e;
+    float s = 0.f;
+    for (int p = 0; p < u.nparts; ++p) s += P[(long long)p * ATB_PSTRIDE];
+    if (is_bias)
+        J.bias_out[m] += s;
+    else
+        J.out[(size_t)m * J.o_rs + (size_t)n * J.o_cs] += s;
+}
+
+static int atb_plan(const EqdAtbJob* jobs, int njobs, AtbUnit* units, int max_units, int* nunits_out,
+                    long long* total_floats) {
+    int nu = 0;
+    long long off = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const EqdAtbJob& J = jobs[i];
+        if (J.M <= 0 || J.M > 80 || J.N <= 0 || J.rows < 0) {
+            eqd_set_error("eqd_atb: job %d has M=%d N=%d rows=%d (need M in 1..80)", i, J.M, J.N, J.rows);
+            return EQD_ERR_SHAPE;
+        }
+        int target = J.rows / 64;
+        if (target < 1) target = 1;
+        if (target > 256) target = 256;
+        int rpw = (J.rows + target - 1) / target;
+        rpw = (rpw + 3) / 4 * 4;
+        if (rpw < 4) rpw = 4;
+        int nparts = J.rows > 0 ? (J.rows + rpw - 1) / rpw : 0;
+        for (int n0 = 0; n0 < J.N; n0 += 64) {
+            if (nu >= max_units) {
+                eqd_set_error("eqd_atb: too many output tiles");
+                return EQD_ERR_SHAPE;
+            }
+            units[nu].job = J;
+            units[nu].n0 = n0;
+            units[nu].nparts = nparts;
+            units[nu].rpw = rpw;
+            units[nu].poff = off;
+            off += (long long)nparts * ATB_PSTRIDE;
+            ++nu;
+        }
+    }
+    *nunits_out = nu;
+    *total_floats = off;
+    return EQD_OK;
+}
+
+extern "C" size_t eqd_atb_partial_bytes(const EqdAtbJob* jobs, int njobs) {
+    static thread_local AtbUnit units[256];
+    int nu = 0;
+    long long tot = 0;
+    if (atb_plan(jobs, njobs, units, 256, &nu, &tot) != EQD_OK) return 0;
+    return (size_t)tot * sizeof(float) + 256;
+}
+
+extern "C" int eqd_atb(const EqdAtbJob* jobs, int njobs, void* partial, size_t partial_bytes, void* stream) {
+    static thread_local AtbUnit units[256];
+    int nu = 0;
+    long long tot = 0;
+    int rc = atb_plan(jobs, njobs, units, 256, &nu, &tot);
+    if (rc) return rc;
+    if ((size_t)tot * sizeof(float) > partial_bytes || (!partial && tot > 0)) {
+        eqd_set_error("eqd_atb: partial workspace too small (%zu < %lld)", partial_bytes, tot * 4LL);
+        return EQD_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    for (int base = 0; base < nu; base += ATB_MAXUNITS) {
+        AtbUnitsArg arg;
+        memset(&arg, 0, sizeof(arg));
+        int n = nu - base < ATB_MAXUNITS ? nu - base : ATB_MAXUNITS;
+        int maxparts = 0;
+        for (int i = 0; i < n; ++i) {
+            arg.u[i] = units[base + i];
+            if (arg.u[i].nparts > maxparts) maxparts = arg.u[i].nparts;
+        }
+        if (maxparts > 0) {
+            hipLaunchKernelGGL(k_atb, dim3((maxparts + EQD_WAVES - 1) / EQD_WAVES, n), dim3(EQD_BLOCK), 0, st, arg,
+                               (float*)partial);
+            rc = eqd_check_launch("k_atb");
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL(k_atb_reduce, dim3((ATB_PSTRIDE + EQD_BLOCK - 1) / EQD_BLOCK, n), dim3(EQD_BLOCK), 0, st,
+                           arg, (const float*)partial);
+        rc = eqd_check_launch("k_atb_reduce");
+        if (rc) return rc;
+    }
+    return EQD_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------
+__global__ void k_vec_reduce(const float* __restrict__ partial, int nparts, int pstride, int n, float* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * pstride + i];
+    out[i] += s;
+}
+int eqd_launch_vec_reduce(const float* partial, int nparts, int pstride, int n, float* out, hipStream_t st) {
+    if (n <= 0) return EQD_OK;
+    hipLaunchKernelGGL(k_vec_reduce, dim3((n + 255) / 256), dim3(256), 0, st, partial, nparts, pstride, n, out);
+    return eqd_check_launch("k_vec_reduce");
+}
+
+__global__ void k_fill(float* p, float v, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+int eqd_launch_fill(float* p, float v, size_t n, hipStream_t st) {
+    if (n == 0) return EQD_OK;
+    hipLaunchKernelGGL(k_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, v, n);
+    return eqd_check_launch("k_fill");
+}
+
+// Embedding lookup + log(mu_r_norm) concat (rigid_docking_model.py:459-471)
+__global__ void k_embed_fwd(const int32_t* __restrict__ res, const float* __restrict__ mu,
+                            const float* __restrict__ emb, int n, int d_emb, int use_mu, float* __restrict__ h0,
+                            int ld) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int c = threadIdx.x & 63;
+    if (i >= n) return;
+    const int t = res[i];
+    for (int cc = c; cc < d_emb; cc += 64) h0[(size_t)i * ld + cc] = emb[(size_t)t * d_emb + cc];
+    if (use_mu && c < 5) h0[(size_t)i * ld + d_emb + c] = logf(mu[(size_t)i * 5 + c]);
+}
+int eqd_launch_embed_fwd(const EqdGraph* g, const float* emb, int d_emb, int use_mu, float* h0, int ld,
+                         hipStream_t st) {
+    if (g->n_nodes == 0) return EQD_OK;
+    hipLaunchKernelGGL(k_embed_fwd, dim3((g->n_nodes + 3) / 4), dim3(256), 0, st, g->res_id, g->mu_r_norm, emb,
+                       g->n_nodes, d_emb, use_mu, h0, ld);
+    return eqd_check_launch("k_embed_fwd");
+}
+
+// Embedding backward: per block of 128 nodes, thread c owns column c -> deterministic per-type sums
+#define EMB_ROWS 128
+__global__ void k_embed_bwd(const int32_t* __restrict__ res, const float* __restrict__ dh0, int ld, int n, int d_emb,
+                            float* __restrict__ partial) {
+    __shared__ float acc[21 * 64];
+    const int c = threadIdx.x;  // 64 threads
+    for (int t = 0; t < 21; ++t) acc[t * 64 + c] = 0.f;
+    const int i0 = blockIdx.x * EMB_ROWS;
+    const int i1 = i0 + EMB_ROWS < n ? i0 + EMB_ROWS : n;
+    if (c < d_emb)
+        for (int i = i0; i < i1; ++i) acc[res[i] * 64 + c] += dh0[(size_t)i * ld + c];
+    for (int t = 0; t < 21; ++t)
+        if (c < d_emb) partial[((size_t)blockIdx.x * 21 + t) * d_emb + c] = acc[t * 64 + c];
+}
+size_t eqd_embed_bwd_partial_floats(const EqdGraph* g, int d_emb) {
+    return (size_t)((g->n_nodes + EMB_ROWS - 1) / EMB_ROWS) * 21 * d_emb;
+}
+int eqd_launch_embed_bwd(const EqdGraph* g, const float* dh0, int ld, int d_emb, float* demb, float* partial,
+                         hipStream_t st) {
+    if (g->n_nodes == 0) return EQD_OK;
+    if (d_emb > 64) {
+        eqd_set_error("embedding width %d > 64 unsupported", d_emb);
+        return EQD_ERR_UNSUPPORTED;
+    }
+    const int nb = (g->n_nodes + EMB_ROWS - 1) / EMB_ROWS;
+    hipLaunchKernelGGL(k_embed_bwd, dim3(nb), dim3(64), 0, st, g->res_id, dh0, ld, g->n_nodes, d_emb, partial);
+    int rc = eqd_check_launch("k_embed_bwd");
+    if (rc) return rc;
+    return eqd_launch_vec_reduce(partial, nb, 21 * d_emb, 21 * d_emb, demb, st);
+}
+
+// dP[j] = sum over out-edges e of node j (CSC) of dz[e]; dx[j] += sum of dxrel[e]
+__global__ void k_csc_gather(const int32_t* __restrict__ csc_ptr, const int32_t* __restrict__ csc_eid, int n,
+                             const float* __restrict__ dz, const float* __restrict__ dxrel, float* __restrict__ dP,
+                             float* __restrict__ dx) {
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int c = threadIdx.x & 63;
+    if (j >= n) return;
+    const int e0 = csc_ptr[j], e1 = csc_ptr[j + 1];
+    float s = 0.f, sx = 0.f;
+    for (int q = e0; q < e1; ++q) {
+        const int e = csc_eid[q];
+        s += dz[(size_t)e * 64 + c];
+        if (c < 3) sx += dxrel[(size_t)e * 4 + c];
+    }
+    dP[(size_t)j * 64 + c] = s;
+    if (c < 3) dx[(size_t)j * 3 + c] += sx;
+}
+int eqd_launch_csc_gather(const EqdGraph* g, const float* dz, const float* dxrel, float* dP, float* dx,
+                          hipStream_t st) {
+    if (g->n_nodes == 0) return EQD_OK;
+    hipLaunchKernelGGL(k_csc_gather, dim3((g->n_nodes + 3) / 4), dim3(256), 0, st, g->csc_ptr, g->csc_eid, g->n_nodes,
+                       dz, dxrel, dP, dx);
+    return eqd_check_launch("k_csc_gather");
+}
+
+// Backward of LeakyReLU -> LayerNorm (node_mlp.2/.3): y_act = LeakyReLU(z) is saved by the forward.
+// One wave per row group; lane owns features lane and lane+64 (d <= 128).
+#define LNB_ROWS_PER_BLOCK 64
+__global__ __launch_bounds__(EQD_BLOCK) void k_ln_act_bwd(const float* __restrict__ y_act,
+                                                          const float* __restrict__ d_out,
+                                                          const float* __restrict__ gamma, int rows, int d, int ld,
+                                                          float slope, float eps, float* __restrict__ dz,
+                                                          float* __restrict__ partial) {
+    __shared__ float red[EQD_WAVES][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int f0 = lane, f1 = lane + 64;
+    const bool v0 = f0 < d, v1 = f1 < d;
+    const float g0 = v0 ? gamma[f0] : 0.f, g1 = v1 ? gamma[f1] : 0.f;
+    float dg0 = 0.f, dg1 = 0.f, db0 = 0.f, db1 = 0.f;
+    const float invd = 1.f / (float)d;
+    const int rbase = blockIdx.x * LNB_ROWS_PER_BLOCK;
+    for (int rr = wave; rr < LNB_ROWS_PER_BLOCK; rr += EQD_WAVES) {
+        const int row = rbase + rr;
+        if (row >= rows) break;   // wave-uniform
+        const size_t o = (size_t)row * ld;
+        const float y0 = v0 ? y_act[o + f0] : 0.f, y1 = v1 ? y_act[o + f1] : 0.f;
+        const float o0 = v0 ? d_out[o + f0] : 0.f, o1 = v1 ? d_out[o + f1] : 0.f;
+        const float mean = wave_sum(y0 + y1) * invd;
+        const float c0 = v0 ? y0 - mean : 0.f, c1 = v1 ? y1 - mean : 0.f;
+        const float rstd = 1.f / sqrtf(wave_sum(c0 * c0 + c1 * c1) * invd + eps);
+        const float xh0 = c0 * rstd, xh1 = c1 * rstd;
+        const float dx0 = o0 * g0, dx1 = o1 * g1;
+        const float s1 = wave_sum(dx0 + dx1) * invd;
+        const float s2 = wave_sum(dx0 * xh0 + dx1 * xh1) * invd;
+        if (v0) dz[o + f0] = rstd * (dx0 - s1 - xh0 * s2) * lrelu_grad(y0, slope);
+        if (v1) dz[o + f1] = rstd * (dx1 - s1 - xh1 * s2) * lrelu_grad(y1, slope);
+        dg0 += o0 * xh0;
+        dg1 += o1 * xh1;
+        db0 += o0;
+        db1 += o1;
+    }
+    red[wave][lane] = dg0;
+    red[wave][64 + lane] = dg1;
+    red[wave][128 + lane] = db0;
+    red[wave][192 + lane] = db1;
+    __syncthreads();
+    const int t = threadIdx.x;
+    const float s = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+    // partial layout per block: [dgamma(128) | dbeta(128)]
+    partial[(size_t)blockIdx.x * 256 + t] = s;
+}
+size_t eqd_ln_act_bwd_partial_floats(int rows, int d) {
+    (void)d;
+    return (size_t)((rows + LNB_ROWS_PER_BLOCK - 1) / LNB_ROWS_PER_BLOCK) * 256;
+}
+int eqd_launch_ln_act_bwd(const float* y_act, const float* d_out, const float* gamma, int rows, int d, int ld,
+                          float slope, float eps, float* dz, float* dgamma, float* dbeta, float* partial,
+                          hipStream_t st) {
+    if (rows == 0) return EQD_OK;
+    if (d > 128) {
+        eqd_set_error("ln_act_bwd: width %d > 128 unsupported", d);
+        return EQD_ERR_UNSUPPORTED;
+    }
+    const int nb = (rows + LNB_ROWS_PER_BLOCK - 1) / LNB_ROWS_PER_BLOCK;
+    hipLaunchKernelGGL(k_ln_act_bwd, dim3(nb), dim3(EQD_BLOCK), 0, st, y_act, d_out, gamma, rows, d, ld, slope, eps,
+                       dz, partial);
+    int rc = eqd_check_launch("k_ln_act_bwd");
+    if (rc) return rc;
+    rc = eqd_launch_vec_reduce(partial, nb, 256, d, dgamma, st);
+    if (rc) return rc;
+    return eqd_launch_vec_reduce(partial + 128, nb, 256, d, dbeta, st);
+}

@@ -1,0 +1,231 @@
+/*
+ * equidock_hip.h -- C ABI of libequidock_hip.so: the MI355X (gfx950) implementation of EquiDock's
+ * IEGMN forward/backward hot path.
+ *
+ * The reference (octavian-ganea/equidock_public) is pure Python: it has NO FFI/plugin boundary
+ * of its own.  Its "operator surface" for this path is three nn.Modules
+ * (src/model/rigid_docking_model.py: IEGMN_Layer :82, IEGMN :360, Rigid_Body_Docking_Net :611)
+ * whose arithmetic runs in PyTorch + DGL kernels.  This header is the boundary a maintainer
+ * binds with ctypes; each entry point cites the reference lines whose
+ * arithmetic it replaces.  The Python drop-in modules in equidock_public_amd/model.py call
+ * exactly these functions.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless stated otherwise; fp32 is `float`,
+ *     indices are int32; row-major, leading dimension given where it is not the width;
+ *   - ownership: the caller owns every buffer including workspaces; the library allocates
+ *     nothing persistent and keeps no global mutable state except a thread-local error string;
+ *   - every function enqueues its work on `stream` (a hipStream_t passed as void*) and returns
+ *     without synchronising; return value 0 = EQD_OK, otherwise an EQD_ERR_* code, and
+ *     eqd_last_error() describes it.  Nothing throws or exits across this boundary (the
+ *     reference sys.exit()s on an unstable SVD, rigid_docking_model.py:582-584; here the
+ *     per-pair status word reports it);
+ *   - node order: all ligand nodes of all pairs, then all receptor nodes; edges are
+ *     destination-sorted (ll edges then rr edges), endpoints are global node ids.
+ */
+#ifndef EQUIDOCK_HIP_H
+#define EQUIDOCK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EQD_ABI_VERSION 1
+#define EQD_TILE_EDGES 32   /* edges per node-aligned tile (max supported in-degree) */
+#define EQD_ATT_BLOCK 32    /* nodes per cross-attention work item */
+#define EQD_MAX_SRC 6
+#define EQD_PARAMS_PER_LAYER 19
+#define EQD_GLOBAL_PARAMS 5
+
+enum {
+    EQD_OK = 0,
+    EQD_ERR_NULL = 1,         /* a required pointer is NULL */
+    EQD_ERR_SHAPE = 2,        /* inconsistent sizes */
+    EQD_ERR_UNSUPPORTED = 3,  /* configuration outside the HIP path (see eqd_model_check) */
+    EQD_ERR_WORKSPACE = 4,    /* workspace too small */
+    EQD_ERR_LAUNCH = 5        /* a kernel launch failed */
+};
+
+int eqd_abi_version(void);
+const char* eqd_last_error(void);
+int eqd_tile_edges(void);
+/* 1 when the library is the x86 host simulator built by tests/hostsim (never shipped), else 0 */
+int eqd_is_simulator(void);
+
+/* ---- batched pair graph: kernel-side view of what the reference passes as a batched DGL
+ *      heterograph (src/utils/train_utils.py:61-100). Built by equidock_public_amd/graph.py. ---- */
+typedef struct EqdGraph {
+    int32_t n_pairs, n_lig, n_rec, n_nodes, n_edges, n_tiles, n_att_items, max_seg;
+    const int32_t* seg_off;    /* [2*n_pairs+1] global node offsets: ligand segments then receptor segments */
+    const int32_t* src;        /* [n_edges] */
+    const int32_t* dst;        /* [n_edges] sorted ascending */
+    const int32_t* rowptr;     /* [n_nodes+1] CSR by destination */
+    const int32_t* csc_ptr;    /* [n_nodes+1] edges grouped by source ... */
+    const int32_t* csc_eid;    /* [n_edges]   ... as edge ids */
+    const int32_t* tile_node;  /* [n_tiles+1] node ranges; each tile has <= EQD_TILE_EDGES in-edges */
+    const int32_t* att_items;  /* [n_att_items][4] = {blk_begin, blk_end, other_begin, other_end} */
+    const int32_t* res_id;     /* [n_nodes] residue type 0..20 */
+    const float* mu_r_norm;    /* [n_nodes][5] */
+    const float* he;           /* [n_edges][27] */
+    const float* x0;           /* [n_nodes][3] ligand new_x rows then receptor x rows */
+} EqdGraph;
+
+/* ---- model configuration: the `args` keys the reference's modules consume
+ *      (rigid_docking_model.py:95-110, 366-379, 617-623) ---- */
+typedef struct EqdModelDesc {
+    int32_t n_layers;               /* iegmn_n_lays */
+    int32_t d_emb;                  /* residue_emb_dim (64) */
+    int32_t d_hid;                  /* iegmn_lay_hid_dim (64) */
+    int32_t use_mean_node_features; /* layer-0 width d0 = d_emb + 5 */
+    int32_t edge_feats;             /* input_edge_feats_dim (27) */
+    int32_t n_heads;                /* num_att_heads (50) */
+    int32_t cross_msgs, use_dist_in_layers, use_edge_features;
+    float skip_weight_h, x_connection_init, lrelu_slope, ln_eps;
+    int32_t svd_seed;               /* seed of the counter-based draws used if the SVD guard fires */
+} EqdModelDesc;
+
+/* Parameter table: device pointers in this fixed order.  Per layer i (base = 19*i):
+ *   0 edge_mlp.0.weight [64, 2*d_in+42]   1 edge_mlp.0.bias [64]
+ *   2 edge_mlp.3.weight [64] (LayerNorm)  3 edge_mlp.3.bias [64]
+ *   4 edge_mlp.4.weight [64,64]           5 edge_mlp.4.bias [64]
+ *   6 att_mlp_Q.0.weight [d_in,d_in]      7 att_mlp_K.0.weight   8 att_mlp_V.0.weight
+ *   9 node_mlp.0.weight [d_in, d0+2*d_in+64]  10 node_mlp.0.bias [d_in]
+ *  11 node_mlp.3.weight [d_in]           12 node_mlp.3.bias [d_in]
+ *  13 node_mlp.4.weight [64, d_in]       14 node_mlp.4.bias [64]
+ *  15 coors_mlp.0.weight [64,64]         16 coors_mlp.0.bias [64]
+ *  17 coors_mlp.4.weight [1,64]          18 coors_mlp.4.bias [1]
+ * then (base = 19*n_layers): residue_emb_layer.weight [21,64], att_mlp_key_ROT.0.weight [K*64,64],
+ * att_mlp_query_ROT.0.weight [K*64,64], mlp_h_mean_ROT.0.weight [64,64], mlp_h_mean_ROT.0.bias [64]
+ * (names: rigid_docking_model.py:119-159, 382, 427-438).  With shared layers the same pointers
+ * repeat for layers 1..L-1. */
+
+/* workspace sizes (bytes) for a graph of the given dimensions */
+size_t eqd_model_saved_bytes(const EqdModelDesc* m, const EqdGraph* g);    /* forward -> backward state */
+size_t eqd_model_scratch_bytes(const EqdModelDesc* m, const EqdGraph* g);  /* transient, either pass */
+int eqd_model_check(const EqdModelDesc* m, const EqdGraph* g);
+
+/* Rigid_Body_Docking_Net.forward (rigid_docking_model.py:642-692) for the single-stage model:
+ * embedding + L IEGMN layers + keypoint attention + Kabsch + rigid apply.
+ * Outputs: lig_out [n_lig][3], Y_lig / Y_rec [n_pairs][n_heads][3], T [n_pairs][9], b [n_pairs][3],
+ * svd_status [n_pairs] int32 (number of guard perturbations, 11 = "consistently unstable").
+ * `svd_draws` may be NULL, or [n_pairs][10][3] diagonal perturbations to use when the guard
+ * (:574) fires.  `saved` may be NULL for inference (no backward possible). */
+int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const float* const* params,
+                      const float* svd_draws,
+                      float* lig_out, float* Y_lig, float* Y_rec, float* T, float* b, int32_t* svd_status,
+                      void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream);
+
+/* Backward of the above (the autograd the reference gets from loss.backward(), src/train.py:154).
+ * d_* are gradients w.r.t. the five outputs (any may be NULL = zero).  Parameter gradients are
+ * ACCUMULATED into grad_flat at grad_offsets[i] (in floats, same order as the parameter table;
+ * shared entries share offsets); the caller zeroes grad_flat. */
+int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, const float* const* params,
+                       const float* d_lig, const float* d_Ylig, const float* d_Yrec, const float* d_T,
+                       const float* d_b,
+                       float* grad_flat, const int64_t* grad_offsets,
+                       const void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Operator-level entry points (used by the model functions above; exported for unit parity
+ * tests and for callers that want a single IEGMN_Layer).
+ * ------------------------------------------------------------------------------------------- */
+
+/* Generic node-level building block: Y = alpha * f(sum_s X_s W_s^T + bias) + beta * R with
+ * f = [LeakyReLU] [-> LayerNorm]; used for every nn.Linear of the path
+ * (rigid_docking_model.py:119-159, 427-438) and, with transposed weight strides, for dX = dY W. */
+typedef struct EqdLinSrc {
+    const float* X;     /* [rows][ldx] */
+    const float* mask;  /* optional: X is multiplied by LeakyReLU'(mask) (same layout as X) */
+    const float* W;     /* element (m, k) at W[m * w_rs + k * w_cs] */
+    int32_t ldx, K, w_rs, w_cs;
+} EqdLinSrc;
+typedef struct EqdLinJob {
+    EqdLinSrc s[EQD_MAX_SRC];
+    int32_t nsrc, M, act, rows;
+    const float* bias;
+    const float* ln_g; const float* ln_b; float* pre_ln; int32_t ld_pre;
+    const float* R; int32_t ldr;
+    float alpha, beta, slope, ln_eps;
+    float* Y; int32_t ldy;
+} EqdLinJob;
+int eqd_linear(const EqdLinJob* jobs /* host */, int njobs, void* stream);
+
+/* dW[m][n] (+)= sum_rows (X * LeakyReLU'(xmask))[row][m] * Y[row][n]; optional column sums of X
+ * (bias gradients).  Deterministic two-stage reduction through `partial`. */
+typedef struct EqdAtbJob {
+    const float* X; const float* xmask; int32_t ldx, M;
+    const float* Y; int32_t ldy, N;
+    int32_t rows;
+    float* out; int32_t o_rs, o_cs;
+    float* bias_out;
+    float slope;
+} EqdAtbJob;
+size_t eqd_atb_partial_bytes(const EqdAtbJob* jobs /* host */, int njobs);
+int eqd_atb(const EqdAtbJob* jobs /* host */, int njobs, void* partial, size_t partial_bytes, void* stream);
+
+/* Edge message + coordinate update of one IEGMN layer for both graphs of all pairs
+ * (rigid_docking_model.py:204-237, 263-292): gathers, 15 RBFs, edge_mlp, coors_mlp, per-destination
+ * means (DGL copy_edge + mean), x' = eta x0 + (1-eta) x + mean(x_rel * coef). */
+typedef struct EqdEdgeParams {
+    const float* W1; int32_t ldw1;  /* edge_mlp.0.weight [64][2*d_in+42]; columns >= 2*d_in are used here */
+    int32_t d_in;
+    const float* ln_g; const float* ln_b;
+    const float* W2; const float* b2;
+    const float* Wc1; const float* bc1; const float* wc2; const float* bc2;
+    float slope, ln_eps, eta;
+    int32_t use_dist, use_he;
+} EqdEdgeParams;
+/* P = h W1[:, :d_in]^T, Q = h W1[:, d_in:2 d_in]^T + b1 are node-level inputs ([n_nodes][64]). */
+int eqd_edge_message_fwd(const EqdGraph* g, const EqdEdgeParams* p, const float* P, const float* Q,
+                         const float* x, float* aggr_msg, float* x_new, void* stream);
+/* Backward: recomputes the tile forward; outputs dP, dQ [n_nodes][64], dx [n_nodes][3]
+ * (= (1-eta) d_xnew + geometric terms), and the parameter gradients (accumulated). */
+typedef struct EqdEdgeGrads {
+    float* dW1; int32_t ldw1;   /* only columns >= 2*d_in are written here */
+    float* db1_unused;
+    float* dln_g; float* dln_b; float* dW2; float* db2; float* dWc1; float* dbc1; float* dwc2; float* dbc2;
+} EqdEdgeGrads;
+size_t eqd_edge_message_bwd_workspace_bytes(const EqdGraph* g);
+int eqd_edge_message_bwd(const EqdGraph* g, const EqdEdgeParams* p, const float* P, const float* Q,
+                         const float* x, const float* d_aggr_msg, const float* d_xnew,
+                         float* dP, float* dQ, float* dx, const EqdEdgeGrads* grads,
+                         void* workspace, size_t ws_bytes, void* stream);
+
+/* Block-diagonal cross attention, both directions (rigid_docking_model.py:46-64, 244-256):
+ * out_i = sum_j softmax_j(q_i . k_j) v_j over the partner protein of the same pair (no 1/sqrt(d)).
+ * q, k, v, out: [n_nodes][d]; lse: [n_nodes]. */
+int eqd_cross_attention_fwd(const EqdGraph* g, int d, const float* q, const float* k, const float* v,
+                            float* out, float* lse, void* stream);
+int eqd_cross_attention_bwd(const EqdGraph* g, int d, const float* q, const float* k, const float* v,
+                            const float* out, const float* lse, const float* d_out,
+                            float* dq, float* dk, float* dv, float* delta /* [n_nodes] scratch */, void* stream);
+
+/* K-head attention keypoint pooling (rigid_docking_model.py:521-560) with collapsed heads:
+ * u[s][k] = W_K^(k)T (W_Q^(k) qmean[partner(s)]) / sqrt(d);  scores = H u^T; softmax over the
+ * segment's nodes; Y = att^T Z.  qmean: [2B][64]; H [n_nodes][64]; Z [n_nodes][3];
+ * outputs Y [2B][K][3] (ligand segments first), scores [n_nodes][K], lse [2B][K], qp [2B][K][64], u [2B][K][64]. */
+int eqd_keypoint_pool_fwd(const EqdGraph* g, int n_heads, const float* Wk, const float* Wq, const float* qmean,
+                          const float* H, const float* Z, float* Y, float* scores, float* lse,
+                          float* qp, float* u, void* stream);
+
+/* Kabsch / 3x3 SVD (rigid_docking_model.py:563-589): per pair A = (Yr - mean)^T (Yl - mean),
+ * T = U diag(1,1,sign det A) V^T, b = mean_r - T mean_l.  Y: [2B][K][3].  A_out [B][9] is the
+ * (possibly perturbed) matrix that was decomposed. */
+int eqd_kabsch_fwd(int n_pairs, int n_heads, const float* Y, const float* svd_draws, int svd_seed,
+                   float* T, float* b, float* A_out, int32_t* status, void* stream);
+/* Closed-form backward. dY: [2B][K][3] is OVERWRITTEN with dL/dY. */
+int eqd_kabsch_bwd(int n_pairs, int n_heads, const float* Y, const float* A, const float* T,
+                   const float* dT, const float* db, float* dY, void* stream);
+
+/* lig' = (T x^T)^T + b per pair (rigid_docking_model.py:665). */
+int eqd_rigid_apply_fwd(const EqdGraph* g, const float* T, const float* b, float* lig_out, void* stream);
+/* dT[b] += sum_i d_lig_i x_i^T, db[b] += sum_i d_lig_i (dT, db must be initialised by the caller). */
+int eqd_rigid_apply_bwd(const EqdGraph* g, const float* d_lig, float* dT, float* db, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
