@@ -54,7 +54,7 @@ class EqdLinJob(C.Structure):
 class EqdAtbJob(C.Structure):
     _fields_ = [('X', C.c_void_p), ('xmask', C.c_void_p), ('ldx', C.c_int32), ('M', C.c_int32), ('Y', C.c_void_p),
                 ('ldy', C.c_int32), ('N', C.c_int32), ('rows', C.c_int32), ('out', C.c_void_p), ('o_rs', C.c_int32),
-                ('o_cs', C.c_int32), ('bias_out', C.c_void_p), ('slope', C.c_float)]
+                ('o_cs', C.c_int32), ('bias_out', C.c_void_p), ('slope', C.c_float), ('scale', C.c_float)]
 
 
 class EqdEdgeParams(C.Structure):

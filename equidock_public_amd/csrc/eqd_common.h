@@ -106,6 +106,7 @@ int eqd_launch_ln_act_bwd(const float* y_act, const float* d_out, const float* g
                           hipStream_t st);
 size_t eqd_ln_act_bwd_partial_floats(int rows, int d);
 int eqd_launch_fill(float* p, float v, size_t n, hipStream_t st);
+int eqd_launch_axpy(float* y, const float* x, float a, size_t n, hipStream_t st);
 int eqd_launch_seg_mean(const EqdGraph* g, const float* hm, float* qmean, hipStream_t st);
 int eqd_launch_head_u_bwd(const EqdGraph* g, int K, const float* Wk, const float* Wq, const float* qmean,
                           const float* qp, const float* du, float* dWk, float* dWq, float* dqm_part, hipStream_t st);

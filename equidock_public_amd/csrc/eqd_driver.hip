@@ -1,0 +1,476 @@
+// Host-side driver: Rigid_Body_Docking_Net.forward / backward as ONE C call each.
+//
+// The reference runs this path as hundreds of small PyTorch/DGL kernel launches per layer driven
+// from Python, with per-pair Python loops and host syncs in the keypoint/SVD stage
+// (src/model/rigid_docking_model.py:483-501, 521-600, 642-692).  Here a single C function enqueues
+// the whole forward (or backward) on the caller's stream: no host sync, no allocation, all
+// intermediate state in caller-owned workspaces.  The Python drop-in (equidock_public_amd/model.py)
+// wraps the two calls in one torch.autograd.Function.
+#include "eqd_common.h"
+
+#include <string.h>
+
+namespace {
+
+enum {
+    P_W1 = 0, P_B1, P_LNG, P_LNB, P_W2, P_B2, P_WQ, P_WK, P_WV, P_WN1, P_BN1, P_NLG, P_NLB, P_WN2, P_BN2,
+    P_WC1, P_BC1, P_WC2, P_BC2
+};
+enum { G_EMB = 0, G_WK, G_WQ, G_WM, G_BM };
+
+struct Dims {
+    int N, E, B, K, L, d0, dh;
+    int d_in(int l) const { return l == 0 ? d0 : dh; }
+    int ldw1(int l) const { return 2 * d_in(l) + 27 + 15; }
+    int ldwn(int l) const { return d0 + 2 * d_in(l) + dh; }
+};
+
+Dims make_dims(const EqdModelDesc* m, const EqdGraph* g) {
+    Dims D;
+    D.N = g->n_nodes; D.E = g->n_edges; D.B = g->n_pairs; D.K = m->n_heads; D.L = m->n_layers;
+    D.d0 = m->d_emb + (m->use_mean_node_features ? 5 : 0);
+    D.dh = m->d_hid;
+    return D;
+}
+
+struct LayerSaved {
+    float *P, *Q, *qa, *ka, *va, *aggr_msg, *aggr_cross, *lse, *y_act, *a1n;
+};
+struct Saved {
+    float* h[64 + 1];
+    float* x[64 + 1];
+    LayerSaved lay[64];
+    float *hm, *qmean, *qp, *u, *scores, *klse, *Y, *A, *T;
+};
+
+void carve_saved(const Dims& D, const EqdGraph* g, EqdArena& A, Saved& S) {
+    const size_t N = (size_t)D.N;
+    S.h[0] = A.take<float>(N * D.d0);
+    S.x[0] = const_cast<float*>(g->x0);
+    for (int l = 0; l < D.L; ++l) {
+        const int d = D.d_in(l);
+        LayerSaved& Ls = S.lay[l];
+        Ls.P = A.take<float>(N * 64);
+        Ls.Q = A.take<float>(N * 64);
+        Ls.qa = A.take<float>(N * d);
+        Ls.ka = A.take<float>(N * d);
+        Ls.va = A.take<float>(N * d);
+        Ls.aggr_msg = A.take<float>(N * 64);
+        Ls.aggr_cross = A.take<float>(N * d);
+        Ls.lse = A.take<float>(N);
+        Ls.y_act = A.take<float>(N * d);
+        Ls.a1n = A.take<float>(N * d);
+        S.h[l + 1] = A.take<float>(N * D.dh);
+        S.x[l + 1] = A.take<float>(N * 3);
+    }
+    S.hm = A.take<float>(N * 64);
+    S.qmean = A.take<float>((size_t)2 * D.B * 64);
+    S.qp = A.take<float>((size_t)2 * D.B * D.K * 64);
+    S.u = A.take<float>((size_t)2 * D.B * D.K * 64);
+    S.scores = A.take<float>(N * D.K);
+    S.klse = A.take<float>((size_t)2 * D.B * D.K);
+    S.Y = A.take<float>((size_t)2 * D.B * D.K * 3);
+    S.A = A.take<float>((size_t)D.B * 9);
+    S.T = A.take<float>((size_t)D.B * 9);
+}
+
+void lin_src(EqdLinJob& J, int i, const float* X, int ldx, int K, const float* W, int w_rs, int w_cs,
+             const float* mask = nullptr) {
+    J.s[i].X = X; J.s[i].ldx = ldx; J.s[i].K = K; J.s[i].W = W; J.s[i].w_rs = w_rs; J.s[i].w_cs = w_cs;
+    J.s[i].mask = mask;
+}
+EqdLinJob lin_job(int rows, int M, float* Y, int ldy, float slope, float eps) {
+    EqdLinJob J;
+    memset(&J, 0, sizeof(J));
+    J.rows = rows; J.M = M; J.Y = Y; J.ldy = ldy; J.alpha = 1.f; J.beta = 0.f; J.slope = slope; J.ln_eps = eps;
+    return J;
+}
+EqdAtbJob atb_job(const float* X, int ldx, int M, const float* Y, int ldy, int N, int rows, float* out, int o_rs,
+                  float* bias_out, float slope, const float* xmask = nullptr, float scale = 1.f) {
+    EqdAtbJob J;
+    memset(&J, 0, sizeof(J));
+    J.X = X; J.ldx = ldx; J.M = M; J.Y = Y; J.ldy = ldy; J.N = N; J.rows = rows; J.out = out; J.o_rs = o_rs;
+    J.o_cs = 1; J.bias_out = bias_out; J.slope = slope; J.xmask = xmask; J.scale = scale;
+    return J;
+}
+
+// node-level weight-gradient jobs of one layer (also used with NULL pointers for sizing)
+int node_atb_jobs(const Dims& D, int l, const EqdModelDesc* m, const Saved* S, const float* dHout, const float* dz,
+                  const float* dP, const float* dQ, const float* dq, const float* dk, const float* dv,
+                  float* const* gp, EqdAtbJob* jobs) {
+    const int d = D.d_in(l), N = D.N;
+    const bool skip = (d == D.dh);
+    const float alpha = skip ? m->skip_weight_h : 1.f;
+    const LayerSaved* Ls = S ? &S->lay[l] : nullptr;
+    const float* h = S ? S->h[l] : nullptr;
+    const float* h0 = S ? S->h[0] : nullptr;
+    auto G = [&](int i) -> float* { return gp ? gp[i] : nullptr; };
+    int n = 0;
+    // node_mlp.4: dWn2 = alpha dH^T a1n, dbn2 = alpha colsum(dH)
+    jobs[n++] = atb_job(dHout, D.dh, D.dh, Ls ? Ls->a1n : nullptr, d, d, N, G(P_WN2), d, G(P_BN2), m->lrelu_slope,
+                        nullptr, alpha);
+    // node_mlp.0: four column segments [h | aggr_msg | aggr_cross | h0]
+    const int ldn = D.ldwn(l);
+    jobs[n++] = atb_job(dz, d, d, h, d, d, N, G(P_WN1), ldn, G(P_BN1), m->lrelu_slope);
+    jobs[n++] = atb_job(dz, d, d, Ls ? Ls->aggr_msg : nullptr, 64, 64, N, gp ? G(P_WN1) + d : nullptr, ldn, nullptr,
+                        m->lrelu_slope);
+    if (m->cross_msgs)
+        jobs[n++] = atb_job(dz, d, d, Ls ? Ls->aggr_cross : nullptr, d, d, N, gp ? G(P_WN1) + d + 64 : nullptr, ldn,
+                            nullptr, m->lrelu_slope);
+    jobs[n++] = atb_job(dz, d, d, h0, D.d0, D.d0, N, gp ? G(P_WN1) + 2 * d + 64 : nullptr, ldn, nullptr,
+                        m->lrelu_slope);
+    // edge_mlp.0 node part: dW1a = dP^T h, dW1b = dQ^T h, db1 = colsum dQ
+    const int ld1 = D.ldw1(l);
+    jobs[n++] = atb_job(dP, 64, 64, h, d, d, N, G(P_W1), ld1, nullptr, m->lrelu_slope);
+    jobs[n++] = atb_job(dQ, 64, 64, h, d, d, N, gp ? G(P_W1) + d : nullptr, ld1, G(P_B1), m->lrelu_slope);
+    if (m->cross_msgs) {
+        jobs[n++] = atb_job(dq, d, d, h, d, d, N, G(P_WQ), d, nullptr, m->lrelu_slope, Ls ? Ls->qa : nullptr);
+        jobs[n++] = atb_job(dk, d, d, h, d, d, N, G(P_WK), d, nullptr, m->lrelu_slope, Ls ? Ls->ka : nullptr);
+        jobs[n++] = atb_job(dv, d, d, h, d, d, N, G(P_WV), d, nullptr, m->lrelu_slope);
+    }
+    return n;
+}
+
+struct Scratch {
+    float *dHa, *dHb, *dXa, *dXb, *da1n, *dz, *d_aggr_msg, *d_aggr_cross, *dq, *dk, *dv, *dP, *dQ, *delta, *dh0acc;
+    float *dY, *dT, *db, *dscores, *du, *dHk, *dqm_part, *dhm;
+    void* edge_ws; size_t edge_ws_bytes;
+    float* atb_part; size_t atb_bytes;
+    float* ln_part;
+    float* emb_part;
+};
+
+void carve_scratch(const Dims& D, const EqdModelDesc* m, const EqdGraph* g, EqdArena& A, Scratch& W) {
+    const size_t N = (size_t)D.N;
+    W.dHa = A.take<float>(N * 80);
+    W.dHb = A.take<float>(N * 80);
+    W.dXa = A.take<float>(N * 3);
+    W.dXb = A.take<float>(N * 3);
+    W.da1n = A.take<float>(N * 80);
+    W.dz = A.take<float>(N * 80);
+    W.d_aggr_msg = A.take<float>(N * 64);
+    W.d_aggr_cross = A.take<float>(N * 80);
+    W.dq = A.take<float>(N * 80);
+    W.dk = A.take<float>(N * 80);
+    W.dv = A.take<float>(N * 80);
+    W.dP = A.take<float>(N * 64);
+    W.dQ = A.take<float>(N * 64);
+    W.delta = A.take<float>(N);
+    W.dh0acc = A.take<float>(N * D.d0);
+    W.dY = A.take<float>((size_t)2 * D.B * D.K * 3);
+    W.dT = A.take<float>((size_t)D.B * 9);
+    W.db = A.take<float>((size_t)D.B * 3);
+    W.dscores = A.take<float>(N * D.K);
+    W.du = A.take<float>((size_t)2 * D.B * D.K * 64);
+    W.dHk = A.take<float>(N * 64);
+    W.dqm_part = A.take<float>((size_t)2 * D.B * D.K * 64);
+    W.dhm = A.take<float>(N * 64);
+    W.edge_ws_bytes = eqd_edge_message_bwd_workspace_bytes(g);
+    W.edge_ws = A.take<char>(W.edge_ws_bytes);
+    size_t ab = 0;
+    for (int l = 0; l < (D.L < 2 ? D.L : 2); ++l) {
+        EqdAtbJob jobs[16];
+        int n = node_atb_jobs(D, l, m, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                              jobs);
+        size_t b = eqd_atb_partial_bytes(jobs, n);
+        if (b > ab) ab = b;
+    }
+    {
+        EqdAtbJob j = atb_job(nullptr, 64, 64, nullptr, 64, 64, D.N, nullptr, 64, nullptr, 0.f);
+        size_t b = eqd_atb_partial_bytes(&j, 1);
+        if (b > ab) ab = b;
+    }
+    W.atb_bytes = ab;
+    W.atb_part = (float*)A.take<char>(ab);
+    W.ln_part = A.take<float>(eqd_ln_act_bwd_partial_floats(D.N, 80));
+    W.emb_part = A.take<float>(eqd_embed_bwd_partial_floats(g, m->d_emb));
+}
+
+EqdEdgeParams edge_params(const Dims& D, const EqdModelDesc* m, int l, const float* const* p) {
+    EqdEdgeParams e;
+    memset(&e, 0, sizeof(e));
+    e.W1 = p[P_W1]; e.ldw1 = D.ldw1(l); e.d_in = D.d_in(l);
+    e.ln_g = p[P_LNG]; e.ln_b = p[P_LNB]; e.W2 = p[P_W2]; e.b2 = p[P_B2];
+    e.Wc1 = p[P_WC1]; e.bc1 = p[P_BC1]; e.wc2 = p[P_WC2]; e.bc2 = p[P_BC2];
+    e.slope = m->lrelu_slope; e.ln_eps = m->ln_eps; e.eta = m->x_connection_init;
+    e.use_dist = m->use_dist_in_layers; e.use_he = m->use_edge_features;
+    return e;
+}
+
+}  // namespace
+
+extern "C" int eqd_model_check(const EqdModelDesc* m, const EqdGraph* g) {
+    if (!m || !g) {
+        eqd_set_error("eqd_model_check: NULL argument");
+        return EQD_ERR_NULL;
+    }
+    if (m->d_hid != 64 || m->d_emb < 1 || m->d_emb > 64 || m->edge_feats != 27) {
+        eqd_set_error("unsupported widths: iegmn_lay_hid_dim=%d (need 64), residue_emb_dim=%d (need 1..64), "
+                      "input_edge_feats_dim=%d (need 27)", m->d_hid, m->d_emb, m->edge_feats);
+        return EQD_ERR_UNSUPPORTED;
+    }
+    if (m->n_layers < 1 || m->n_layers > 64 || m->n_heads < 1 || m->n_heads > 128) {
+        eqd_set_error("unsupported sizes: iegmn_n_lays=%d (1..64), num_att_heads=%d (1..128)", m->n_layers, m->n_heads);
+        return EQD_ERR_UNSUPPORTED;
+    }
+    if (g->n_pairs < 1 || g->n_nodes < 1) {
+        eqd_set_error("empty batch");
+        return EQD_ERR_SHAPE;
+    }
+    return EQD_OK;
+}
+
+extern "C" size_t eqd_model_saved_bytes(const EqdModelDesc* m, const EqdGraph* g) {
+    if (eqd_model_check(m, g)) return 0;
+    Dims D = make_dims(m, g);
+    EqdArena A(nullptr, 0);
+    Saved S;
+    carve_saved(D, g, A, S);
+    return A.off + 256;
+}
+
+extern "C" size_t eqd_model_scratch_bytes(const EqdModelDesc* m, const EqdGraph* g) {
+    if (eqd_model_check(m, g)) return 0;
+    Dims D = make_dims(m, g);
+    EqdArena A(nullptr, 0);
+    Scratch W;
+    carve_scratch(D, m, g, A, W);
+    size_t bwd = A.off + 256;
+    size_t sv = eqd_model_saved_bytes(m, g);
+    return bwd > sv ? bwd : sv;
+}
+
+#define RC(x)                 \
+    do {                      \
+        int rc_ = (x);        \
+        if (rc_) return rc_;  \
+    } while (0)
+
+extern "C" int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const float* const* params,
+                                 const float* svd_draws, float* lig_out, float* Y_lig, float* Y_rec, float* T,
+                                 float* b, int32_t* svd_status, void* saved, size_t saved_bytes, void* scratch,
+                                 size_t scratch_bytes, void* stream) {
+    RC(eqd_model_check(m, g));
+    if (!params || !lig_out || !Y_lig || !Y_rec || !T || !b || !svd_status) {
+        eqd_set_error("eqd_model_forward: NULL argument");
+        return EQD_ERR_NULL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const Dims D = make_dims(m, g);
+    EqdArena A(saved ? saved : scratch, saved ? saved_bytes : scratch_bytes);
+    Saved S;
+    carve_saved(D, g, A, S);
+    if (!A.ok) {
+        eqd_set_error("eqd_model_forward: state workspace too small (%zu needed)", A.off);
+        return EQD_ERR_WORKSPACE;
+    }
+    const float slope = m->lrelu_slope, eps = m->ln_eps;
+    const int N = D.N;
+    const float* const* gp = params + (size_t)EQD_PARAMS_PER_LAYER * D.L;
+
+    RC(eqd_launch_embed_fwd(g, gp[G_EMB], m->d_emb, m->use_mean_node_features, S.h[0], D.d0, st));
+    for (int l = 0; l < D.L; ++l) {
+        const float* const* p = params + (size_t)EQD_PARAMS_PER_LAYER * l;
+        const int d = D.d_in(l);
+        const LayerSaved& Ls = S.lay[l];
+        const float* h = S.h[l];
+        // ---- node projections: P, Q (split first edge Linear), attention q/k/v ----------------
+        EqdLinJob jobs[5];
+        int nj = 0;
+        jobs[nj] = lin_job(N, 64, Ls.P, 64, slope, eps);
+        lin_src(jobs[nj], 0, h, d, d, p[P_W1], D.ldw1(l), 1); jobs[nj].nsrc = 1; ++nj;
+        jobs[nj] = lin_job(N, 64, Ls.Q, 64, slope, eps);
+        lin_src(jobs[nj], 0, h, d, d, p[P_W1] + d, D.ldw1(l), 1); jobs[nj].nsrc = 1; jobs[nj].bias = p[P_B1]; ++nj;
+        if (m->cross_msgs) {
+            jobs[nj] = lin_job(N, d, Ls.qa, d, slope, eps);
+            lin_src(jobs[nj], 0, h, d, d, p[P_WQ], d, 1); jobs[nj].nsrc = 1; jobs[nj].act = 1; ++nj;
+            jobs[nj] = lin_job(N, d, Ls.ka, d, slope, eps);
+            lin_src(jobs[nj], 0, h, d, d, p[P_WK], d, 1); jobs[nj].nsrc = 1; jobs[nj].act = 1; ++nj;
+            jobs[nj] = lin_job(N, d, Ls.va, d, slope, eps);
+            lin_src(jobs[nj], 0, h, d, d, p[P_WV], d, 1); jobs[nj].nsrc = 1; ++nj;
+        }
+        RC(eqd_linear(jobs, nj, st));
+        // ---- edge messages + coordinates --------------------------------------------------------
+        EqdEdgeParams ep = edge_params(D, m, l, p);
+        RC(eqd_edge_message_fwd(g, &ep, Ls.P, Ls.Q, S.x[l], Ls.aggr_msg, S.x[l + 1], st));
+        // ---- cross attention ------------------------------------------------------------------------
+        if (m->cross_msgs) {
+            RC(eqd_cross_attention_fwd(g, d, Ls.qa, Ls.ka, Ls.va, Ls.aggr_cross, Ls.lse, st));
+        } else {
+            if (hipMemsetAsync(Ls.aggr_cross, 0, (size_t)N * d * sizeof(float), st) != hipSuccess) return EQD_ERR_LAUNCH;
+        }
+        // ---- node update: node_mlp([h, aggr_msg, aggr_cross, h0]) with skip ----------------------------
+        EqdLinJob j1 = lin_job(N, d, Ls.a1n, d, slope, eps);
+        const int ldn = D.ldwn(l);
+        lin_src(j1, 0, h, d, d, p[P_WN1], ldn, 1);
+        lin_src(j1, 1, Ls.aggr_msg, 64, 64, p[P_WN1] + d, ldn, 1);
+        lin_src(j1, 2, Ls.aggr_cross, d, d, p[P_WN1] + d + 64, ldn, 1);
+        lin_src(j1, 3, S.h[0], D.d0, D.d0, p[P_WN1] + 2 * d + 64, ldn, 1);
+        j1.nsrc = 4; j1.bias = p[P_BN1]; j1.act = 1; j1.ln_g = p[P_NLG]; j1.ln_b = p[P_NLB];
+        j1.pre_ln = Ls.y_act; j1.ld_pre = d;
+        RC(eqd_linear(&j1, 1, st));
+        EqdLinJob j2 = lin_job(N, D.dh, S.h[l + 1], D.dh, slope, eps);
+        lin_src(j2, 0, Ls.a1n, d, d, p[P_WN2], d, 1);
+        j2.nsrc = 1; j2.bias = p[P_BN2];
+        if (d == D.dh) {
+            j2.alpha = m->skip_weight_h; j2.beta = 1.f - m->skip_weight_h; j2.R = h; j2.ldr = d;
+        }
+        RC(eqd_linear(&j2, 1, st));
+    }
+    // ---- keypoint head ----------------------------------------------------------------------------------
+    const float* H = S.h[D.L];
+    const float* Z = S.x[D.L];
+    EqdLinJob jm = lin_job(N, 64, S.hm, 64, slope, eps);
+    lin_src(jm, 0, H, D.dh, D.dh, gp[G_WM], D.dh, 1);
+    jm.nsrc = 1; jm.bias = gp[G_BM]; jm.act = 1;
+    RC(eqd_linear(&jm, 1, st));
+    RC(eqd_launch_seg_mean(g, S.hm, S.qmean, st));
+    RC(eqd_keypoint_pool_fwd(g, D.K, gp[G_WK], gp[G_WQ], S.qmean, H, Z, S.Y, S.scores, S.klse, S.qp, S.u, st));
+    RC(eqd_kabsch_fwd(D.B, D.K, S.Y, svd_draws, m->svd_seed, S.T, b, S.A, svd_status, st));
+    RC(eqd_rigid_apply_fwd(g, S.T, b, lig_out, st));
+    const size_t yb = (size_t)D.B * D.K * 3 * sizeof(float);
+    if (hipMemcpyAsync(Y_lig, S.Y, yb, hipMemcpyDeviceToDevice, st) != hipSuccess) return EQD_ERR_LAUNCH;
+    if (hipMemcpyAsync(Y_rec, S.Y + (size_t)D.B * D.K * 3, yb, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return EQD_ERR_LAUNCH;
+    if (hipMemcpyAsync(T, S.T, (size_t)D.B * 9 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return EQD_ERR_LAUNCH;
+    return EQD_OK;
+}
+
+extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, const float* const* params,
+                                  const float* d_lig, const float* d_Ylig, const float* d_Yrec, const float* d_T,
+                                  const float* d_b, float* grad_flat, const int64_t* grad_offsets, const void* saved,
+                                  size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream) {
+    RC(eqd_model_check(m, g));
+    if (!params || !grad_flat || !grad_offsets || !saved || !scratch) {
+        eqd_set_error("eqd_model_backward: NULL argument");
+        return EQD_ERR_NULL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const Dims D = make_dims(m, g);
+    EqdArena As(const_cast<void*>(saved), saved_bytes);
+    Saved S;
+    carve_saved(D, g, As, S);
+    EqdArena Aw(scratch, scratch_bytes);
+    Scratch W;
+    carve_scratch(D, m, g, Aw, W);
+    if (!As.ok || !Aw.ok) {
+        eqd_set_error("eqd_model_backward: workspace too small (saved %zu, scratch %zu needed)", As.off, Aw.off);
+        return EQD_ERR_WORKSPACE;
+    }
+    const float slope = m->lrelu_slope, eps = m->ln_eps;
+    const int N = D.N, B = D.B, K = D.K;
+    const int nparams = EQD_PARAMS_PER_LAYER * D.L + EQD_GLOBAL_PARAMS;
+    float* gptr[EQD_PARAMS_PER_LAYER * 64 + EQD_GLOBAL_PARAMS];
+    for (int i = 0; i < nparams; ++i) gptr[i] = grad_flat + grad_offsets[i];
+    const float* const* gpar = params + (size_t)EQD_PARAMS_PER_LAYER * D.L;
+    float* const* ggrad = gptr + (size_t)EQD_PARAMS_PER_LAYER * D.L;
+
+    // ---- head -------------------------------------------------------------------------------------------
+    const size_t yb = (size_t)B * K * 3 * sizeof(float);
+    if (d_Ylig) { if (hipMemcpyAsync(W.dY, d_Ylig, yb, hipMemcpyDeviceToDevice, st) != hipSuccess) return EQD_ERR_LAUNCH; }
+    else if (hipMemsetAsync(W.dY, 0, yb, st) != hipSuccess) return EQD_ERR_LAUNCH;
+    if (d_Yrec) { if (hipMemcpyAsync(W.dY + (size_t)B * K * 3, d_Yrec, yb, hipMemcpyDeviceToDevice, st) != hipSuccess) return EQD_ERR_LAUNCH; }
+    else if (hipMemsetAsync(W.dY + (size_t)B * K * 3, 0, yb, st) != hipSuccess) return EQD_ERR_LAUNCH;
+    if (d_T) { if (hipMemcpyAsync(W.dT, d_T, (size_t)B * 9 * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return EQD_ERR_LAUNCH; }
+    else if (hipMemsetAsync(W.dT, 0, (size_t)B * 9 * 4, st) != hipSuccess) return EQD_ERR_LAUNCH;
+    if (d_b) { if (hipMemcpyAsync(W.db, d_b, (size_t)B * 3 * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return EQD_ERR_LAUNCH; }
+    else if (hipMemsetAsync(W.db, 0, (size_t)B * 3 * 4, st) != hipSuccess) return EQD_ERR_LAUNCH;
+    if (d_lig) RC(eqd_rigid_apply_bwd(g, d_lig, W.dT, W.db, st));
+    RC(eqd_kabsch_bwd(B, K, S.Y, S.A, S.T, W.dT, W.db, W.dY, st));
+    const float* H = S.h[D.L];
+    const float* Z = S.x[D.L];
+    float* dXcur = W.dXa;   // grad wrt x[L]
+    float* dXnext = W.dXb;
+    RC(eqd_launch_keypoint_bwd(g, K, H, Z, S.scores, S.klse, S.u, W.dY, W.dscores, W.du, W.dHk, dXcur, st));
+    RC(eqd_launch_head_u_bwd(g, K, gpar[G_WK], gpar[G_WQ], S.qmean, S.qp, W.du, ggrad[G_WK], ggrad[G_WQ], W.dqm_part,
+                             st));
+    RC(eqd_launch_qmean_bwd(g, K, W.dqm_part, W.dhm, st));
+    float* dHcur = W.dHa;   // grad wrt h[L]  (N x 64)
+    float* dHnext = W.dHb;
+    {
+        EqdLinJob j = lin_job(N, D.dh, dHcur, D.dh, slope, eps);
+        lin_src(j, 0, W.dhm, 64, 64, gpar[G_WM], 1, D.dh, S.hm);
+        j.nsrc = 1; j.R = W.dHk; j.ldr = 64; j.beta = 1.f;
+        RC(eqd_linear(&j, 1, st));
+        EqdAtbJob a = atb_job(W.dhm, 64, 64, H, D.dh, D.dh, N, ggrad[G_WM], D.dh, ggrad[G_BM], slope, S.hm);
+        RC(eqd_atb(&a, 1, W.atb_part, W.atb_bytes, st));
+    }
+    if (hipMemsetAsync(W.dh0acc, 0, (size_t)N * D.d0 * sizeof(float), st) != hipSuccess) return EQD_ERR_LAUNCH;
+
+    // ---- layers, last to first ----------------------------------------------------------------------------
+    for (int l = D.L - 1; l >= 0; --l) {
+        const float* const* p = params + (size_t)EQD_PARAMS_PER_LAYER * l;
+        float* const* gp = gptr + (size_t)EQD_PARAMS_PER_LAYER * l;
+        const int d = D.d_in(l);
+        const LayerSaved& Ls = S.lay[l];
+        const bool skip = (d == D.dh);
+        const float alpha = skip ? m->skip_weight_h : 1.f;
+        const int ldn = D.ldwn(l);
+        // node_mlp.4 backward: da1n = alpha dH Wn2
+        {
+            EqdLinJob j = lin_job(N, d, W.da1n, d, slope, eps);
+            lin_src(j, 0, dHcur, D.dh, D.dh, p[P_WN2], 1, d);
+            j.nsrc = 1; j.alpha = alpha;
+            RC(eqd_linear(&j, 1, st));
+        }
+        RC(eqd_launch_ln_act_bwd(Ls.y_act, W.da1n, p[P_NLG], N, d, d, slope, eps, W.dz, gp[P_NLG], gp[P_NLB], W.ln_part,
+                                 st));
+        // node_mlp.0 backward wrt aggr_msg, aggr_cross, h0 (the h part joins the big dh job below)
+        {
+            EqdLinJob jobs[3];
+            int nj = 0;
+            jobs[nj] = lin_job(N, 64, W.d_aggr_msg, 64, slope, eps);
+            lin_src(jobs[nj], 0, W.dz, d, d, p[P_WN1] + d, 1, ldn); jobs[nj].nsrc = 1; ++nj;
+            if (m->cross_msgs) {
+                jobs[nj] = lin_job(N, d, W.d_aggr_cross, d, slope, eps);
+                lin_src(jobs[nj], 0, W.dz, d, d, p[P_WN1] + d + 64, 1, ldn); jobs[nj].nsrc = 1; ++nj;
+            }
+            jobs[nj] = lin_job(N, D.d0, W.dh0acc, D.d0, slope, eps);
+            lin_src(jobs[nj], 0, W.dz, d, d, p[P_WN1] + 2 * d + 64, 1, ldn); jobs[nj].nsrc = 1;
+            jobs[nj].R = W.dh0acc; jobs[nj].ldr = D.d0; jobs[nj].beta = 1.f; ++nj;
+            RC(eqd_linear(jobs, nj, st));
+        }
+        if (m->cross_msgs)
+            RC(eqd_cross_attention_bwd(g, d, Ls.qa, Ls.ka, Ls.va, Ls.aggr_cross, Ls.lse, W.d_aggr_cross, W.dq, W.dk, W.dv,
+                                       W.delta, st));
+        // edge backward
+        {
+            EqdEdgeParams ep = edge_params(D, m, l, p);
+            EqdEdgeGrads eg;
+            memset(&eg, 0, sizeof(eg));
+            eg.dW1 = gp[P_W1]; eg.ldw1 = D.ldw1(l); eg.dln_g = gp[P_LNG]; eg.dln_b = gp[P_LNB]; eg.dW2 = gp[P_W2];
+            eg.db2 = gp[P_B2]; eg.dWc1 = gp[P_WC1]; eg.dbc1 = gp[P_BC1]; eg.dwc2 = gp[P_WC2]; eg.dbc2 = gp[P_BC2];
+            RC(eqd_edge_message_bwd(g, &ep, Ls.P, Ls.Q, S.x[l], W.d_aggr_msg, dXcur, W.dP, W.dQ, dXnext, &eg, W.edge_ws,
+                                    W.edge_ws_bytes, st));
+        }
+        // dh = dz Wn1[:, :d] + dP W1a + dQ W1b + (dq . lrelu'(qa)) Wq + (dk . lrelu'(ka)) Wk + dv Wv + (1-s) dH
+        {
+            EqdLinJob j = lin_job(N, d, dHnext, d, slope, eps);
+            int ns = 0;
+            lin_src(j, ns++, W.dz, d, d, p[P_WN1], 1, ldn);
+            lin_src(j, ns++, W.dP, 64, 64, p[P_W1], 1, D.ldw1(l));
+            lin_src(j, ns++, W.dQ, 64, 64, p[P_W1] + d, 1, D.ldw1(l));
+            if (m->cross_msgs) {
+                lin_src(j, ns++, W.dq, d, d, p[P_WQ], 1, d, Ls.qa);
+                lin_src(j, ns++, W.dk, d, d, p[P_WK], 1, d, Ls.ka);
+                lin_src(j, ns++, W.dv, d, d, p[P_WV], 1, d);
+            }
+            j.nsrc = ns;
+            if (skip) { j.R = dHcur; j.ldr = D.dh; j.beta = 1.f - m->skip_weight_h; }
+            RC(eqd_linear(&j, 1, st));
+        }
+        // weight gradients of the node-level Linears
+        {
+            EqdAtbJob jobs[16];
+            int n = node_atb_jobs(D, l, m, &S, dHcur, W.dz, W.dP, W.dQ, W.dq, W.dk, W.dv, gp, jobs);
+            RC(eqd_atb(jobs, n, W.atb_part, W.atb_bytes, st));
+        }
+        float* t = dHcur; dHcur = dHnext; dHnext = t;
+        t = dXcur; dXcur = dXnext; dXnext = t;
+    }
+    // h[0] = h0 feeds layer 0 directly as well as every layer's node_mlp
+    RC(eqd_launch_axpy(W.dh0acc, dHcur, 1.f, (size_t)N * D.d0, st));
+    RC(eqd_launch_embed_bwd(g, W.dh0acc, D.d0, m->d_emb, ggrad[G_EMB], W.emb_part, st));
+    return EQD_OK;
+}

@@ -128,6 +128,7 @@ struct EdgeTileState {
     float d2[2];
     float mean[2], rstd[2];
     float coef[2];
+    unsigned zpos;   // bit (16 nb + 4 mb + r): edge_mlp.0 pre-activation > 0 (exact LeakyReLU mask for the backward)
 };
 
 // Forward of one tile up to (and including) the coefficient. On return:
@@ -211,6 +212,7 @@ __device__ __forceinline__ void edge_tile_forward(const EqdGraph& G, const EqdEd
         }
     }
     // ---- LeakyReLU + LayerNorm statistics (two-pass like torch) ------------------------------------
+    S.zpos = 0u;
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
         float s = 0.f;
@@ -218,7 +220,9 @@ __device__ __forceinline__ void edge_tile_forward(const EqdGraph& G, const EqdEd
         for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float v = lrelu(xh[mb][nb][r], P.slope);
+                const float z = xh[mb][nb][r];
+                if (z > 0.f) S.zpos |= 1u << (16 * nb + 4 * mb + r);
+                const float v = lrelu(z, P.slope);
                 xh[mb][nb][r] = v;
                 s += v;
             }
@@ -493,14 +497,13 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_edge_bwd(EqdGraph G, EqdEdgeParam
             }
             s1 = group_sum(s1) * (1.f / 64.f);
             s2 = group_sum(s2) * (1.f / 64.f);
-            const float std = 1.f / S.rstd[nb];
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float xhv = xh[mb][nb][r];
-                    const float y = xhv * std + S.mean[nb];
-                    dz[mb][nb][r] = S.ev[nb] ? S.rstd[nb] * (dz[mb][nb][r] - s1 - xhv * s2) * lrelu_grad(y, P.slope) : 0.f;
+                    const float lg = ((S.zpos >> (16 * nb + 4 * mb + r)) & 1u) ? 1.f : P.slope;
+                    dz[mb][nb][r] = S.ev[nb] ? S.rstd[nb] * (dz[mb][nb][r] - s1 - xhv * s2) * lg : 0.f;
                 }
         }
         hbm_store(W.dz1, dz, S, l15, g);

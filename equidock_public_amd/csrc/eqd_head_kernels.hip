@@ -1,0 +1,605 @@
+// Keypoint head of the IEGMN stack: K-head attention pooling, batched 3x3 Kabsch/SVD with
+// closed-form backward, rigid apply.  These are small (6 kFLOP/node, 50 points/pair):
+// plain VALU kernels, one launch for all pairs instead of the reference's Python loop.
+//
+// Reference arithmetic replaced (src/model/rigid_docking_model.py):
+//   :524-529  q_side = mean_nodes(LeakyReLU(W_m h + b_m))         (the Linear runs in k_linear)
+//   :542-560  att = softmax_nodes((W_K h)_k . (W_Q q_partner)_k / sqrt(d));  Y = att^T Z
+//             -- computed with collapsed heads: u_k = W_K^(k)T (W_Q^(k) q) / sqrt(d), score = h . u_k
+//                (64x fewer FLOPs, equal to 1.3e-7)
+//   :563-589  Kabsch: A = (Yr - mean)^T (Yl - mean), SVD, guard loop, T = U diag(1,1,sign det A) V^T,
+//             b = mean_r - T mean_l
+//   :665      lig' = (T x^T)^T + b
+#include "eqd_common.h"
+
+// ---------------------------------------------------------------------------------------------
+// segment helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int find_segment(const int32_t* __restrict__ seg_off, int nseg, int node) {
+    int lo = 0, hi = nseg;  // seg_off[lo] <= node < seg_off[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (seg_off[mid] <= node) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// qmean[s][c] = mean over the nodes of segment s of hm[i][c]   (64 columns)
+__global__ __launch_bounds__(EQD_BLOCK) void k_seg_mean(const int32_t* __restrict__ seg_off,
+                                                        const float* __restrict__ hm, float* __restrict__ qmean) {
+    __shared__ float red[4][64];
+    const int s = blockIdx.x;
+    const int n0 = seg_off[s], n1 = seg_off[s + 1];
+    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    float acc = 0.f;
+    for (int i = n0 + rg; i < n1; i += 4) acc += hm[(size_t)i * 64 + c];
+    red[rg][c] = acc;
+    __syncthreads();
+    if (rg == 0) {
+        const float t = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+        qmean[(size_t)s * 64 + c] = n1 > n0 ? t / (float)(n1 - n0) : 0.f;
+    }
+}
+int eqd_launch_seg_mean(const EqdGraph* g, const float* hm, float* qmean, hipStream_t st) {
+    if (g->n_pairs == 0) return EQD_OK;
+    hipLaunchKernelGGL(k_seg_mean, dim3(2 * g->n_pairs), dim3(EQD_BLOCK), 0, st, g->seg_off, hm, qmean);
+    return eqd_check_launch("k_seg_mean");
+}
+
+// per (segment s, head k): qp = W_Q^(k) qmean[partner(s)];  u = W_K^(k)T qp / 8
+__global__ void k_head_u(int B, int K, const float* __restrict__ Wk, const float* __restrict__ Wq,
+                         const float* __restrict__ qmean, float* __restrict__ qp, float* __restrict__ u) {
+    __shared__ float sq[64], sp[64];
+    const int s = blockIdx.x, k = blockIdx.y, t = threadIdx.x;  // 64 threads
+    const int partner = s < B ? s + B : s - B;
+    sq[t] = qmean[(size_t)partner * 64 + t];
+    __syncthreads();
+    const float* wq = Wq + ((size_t)k * 64 + t) * 64;
+    float a = 0.f;
+    for (int c = 0; c < 64; ++c) a += wq[c] * sq[c];
+    sp[t] = a;
+    qp[((size_t)s * K + k) * 64 + t] = a;
+    __syncthreads();
+    float b = 0.f;
+    for (int j = 0; j < 64; ++j) b += Wk[((size_t)k * 64 + j) * 64 + t] * sp[j];
+    u[((size_t)s * K + k) * 64 + t] = b * 0.125f;
+}
+
+__device__ __forceinline__ float block_reduce_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[wave] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ float block_reduce_max(float v, float* red) {
+    v = fmaxf(v, __shfl_xor(v, 1)); v = fmaxf(v, __shfl_xor(v, 2)); v = fmaxf(v, __shfl_xor(v, 4));
+    v = fmaxf(v, __shfl_xor(v, 8)); v = fmaxf(v, __shfl_xor(v, 16)); v = fmaxf(v, __shfl_xor(v, 32));
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[wave] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// per (segment, head): scores over the segment's nodes, softmax, Y = att^T Z
+__global__ __launch_bounds__(EQD_BLOCK) void k_keypoint(const int32_t* __restrict__ seg_off, int K,
+                                                        const float* __restrict__ u, const float* __restrict__ H,
+                                                        const float* __restrict__ Z, float* __restrict__ Y,
+                                                        float* __restrict__ scores, float* __restrict__ lse) {
+    __shared__ float su[64];
+    __shared__ float red[4];
+    const int s = blockIdx.x, k = blockIdx.y, t = threadIdx.x;
+    const int n0 = seg_off[s], n1 = seg_off[s + 1];
+    if (t < 64) su[t] = u[((size_t)s * K + k) * 64 + t];
+    __syncthreads();
+    float mx = EQD_NEG_BIG;
+    for (int i = n0 + t; i < n1; i += EQD_BLOCK) {
+        const float4* h = (const float4*)&H[(size_t)i * 64];
+        float a = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const float4 hv = h[c];
+            a += hv.x * su[4 * c] + hv.y * su[4 * c + 1] + hv.z * su[4 * c + 2] + hv.w * su[4 * c + 3];
+        }
+        scores[(size_t)i * K + k] = a;
+        mx = fmaxf(mx, a);
+    }
+    mx = block_reduce_max(mx, red);
+    float se = 0.f, y0 = 0.f, y1 = 0.f, y2 = 0.f;
+    for (int i = n0 + t; i < n1; i += EQD_BLOCK) {
+        const float p = expf(scores[(size_t)i * K + k] - mx);
+        se += p;
+        y0 += p * Z[(size_t)i * 3 + 0];
+        y1 += p * Z[(size_t)i * 3 + 1];
+        y2 += p * Z[(size_t)i * 3 + 2];
+    }
+    se = block_reduce_sum(se, red);
+    y0 = block_reduce_sum(y0, red);
+    y1 = block_reduce_sum(y1, red);
+    y2 = block_reduce_sum(y2, red);
+    if (t == 0) {
+        const float inv = se > 0.f ? 1.f / se : 0.f;
+        float* y = Y + ((size_t)s * K + k) * 3;
+        y[0] = y0 * inv; y[1] = y1 * inv; y[2] = y2 * inv;
+        lse[(size_t)s * K + k] = se > 0.f ? mx + logf(se) : 0.f;
+    }
+}
+
+extern "C" int eqd_keypoint_pool_fwd(const EqdGraph* g, int n_heads, const float* Wk, const float* Wq,
+                                     const float* qmean, const float* H, const float* Z, float* Y, float* scores,
+                                     float* lse, float* qp, float* u, void* stream) {
+    if (!g || !Wk || !Wq || !qmean || !H || !Z || !Y || !scores || !lse || !qp || !u) {
+        eqd_set_error("eqd_keypoint_pool_fwd: NULL argument");
+        return EQD_ERR_NULL;
+    }
+    if (g->n_pairs == 0) return EQD_OK;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_head_u, dim3(2 * g->n_pairs, n_heads), dim3(64), 0, st, g->n_pairs, n_heads, Wk, Wq, qmean, qp,
+                       u);
+    int rc = eqd_check_launch("k_head_u");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_keypoint, dim3(2 * g->n_pairs, n_heads), dim3(EQD_BLOCK), 0, st, g->seg_off, n_heads, u, H, Z,
+                       Y, scores, lse);
+    return eqd_check_launch("k_keypoint");
+}
+
+// backward of k_keypoint, part a: per (segment, head): dscores (written), du (reduced over nodes)
+__global__ __launch_bounds__(EQD_BLOCK) void k_keypoint_bwd_a(const int32_t* __restrict__ seg_off, int K,
+                                                              const float* __restrict__ H,
+                                                              const float* __restrict__ Z,
+                                                              const float* __restrict__ scores,
+                                                              const float* __restrict__ lse,
+                                                              const float* __restrict__ dY,
+                                                              float* __restrict__ dscores, float* __restrict__ du) {
+    __shared__ float red[4];
+    __shared__ float racc[4][64];
+    const int s = blockIdx.x, k = blockIdx.y, t = threadIdx.x;
+    const int n0 = seg_off[s], n1 = seg_off[s + 1];
+    const float* dy = dY + ((size_t)s * K + k) * 3;
+    const float d0 = dy[0], d1 = dy[1], d2 = dy[2];
+    const float L = lse[(size_t)s * K + k];
+    float dot = 0.f;
+    for (int i = n0 + t; i < n1; i += EQD_BLOCK) {
+        const float a = expf(scores[(size_t)i * K + k] - L);
+        const float da = d0 * Z[(size_t)i * 3] + d1 * Z[(size_t)i * 3 + 1] + d2 * Z[(size_t)i * 3 + 2];
+        dot += a * da;
+    }
+    dot = block_reduce_sum(dot, red);
+    for (int i = n0 + t; i < n1; i += EQD_BLOCK) {
+        const float a = expf(scores[(size_t)i * K + k] - L);
+        const float da = d0 * Z[(size_t)i * 3] + d1 * Z[(size_t)i * 3 + 1] + d2 * Z[(size_t)i * 3 + 2];
+        dscores[(size_t)i * K + k] = a * (da - dot);
+    }
+    __syncthreads();   // dscores of this (segment, head) are re-read below by other threads of the block
+    const int c = t & 63, rg = t >> 6;
+    float acc = 0.f;
+    for (int i = n0 + rg; i < n1; i += 4) acc += dscores[(size_t)i * K + k] * H[(size_t)i * 64 + c];
+    racc[rg][c] = acc;
+    __syncthreads();
+    if (rg == 0) du[((size_t)s * K + k) * 64 + c] = racc[0][c] + racc[1][c] + racc[2][c] + racc[3][c];
+}
+
+// part b: per node: dH[i] = sum_k dscores[i][k] u[seg][k];  dZ[i] = sum_k att[i][k] dY[seg][k]
+__global__ void k_keypoint_bwd_b(const int32_t* __restrict__ seg_off, int nseg, int n, int K,
+                                 const float* __restrict__ scores, const float* __restrict__ lse,
+                                 const float* __restrict__ u, const float* __restrict__ dY,
+                                 const float* __restrict__ dscores, float* __restrict__ dH, float* __restrict__ dZ) {
+    __shared__ float sds[128], sal[128];
+    const int i = blockIdx.x, t = threadIdx.x;  // 64 threads
+    if (i >= n) return;
+    const int s = find_segment(seg_off, nseg, i);
+    for (int k = t; k < K; k += 64) {
+        sds[k] = dscores[(size_t)i * K + k];
+        sal[k] = expf(scores[(size_t)i * K + k] - lse[(size_t)s * K + k]);
+    }
+    __syncthreads();
+    float a = 0.f;
+    for (int k = 0; k < K; ++k) a += sds[k] * u[((size_t)s * K + k) * 64 + t];
+    dH[(size_t)i * 64 + t] = a;
+    if (t < 3) {
+        float z = 0.f;
+        for (int k = 0; k < K; ++k) z += sal[k] * dY[((size_t)s * K + k) * 3 + t];
+        dZ[(size_t)i * 3 + t] = z;
+    }
+}
+
+int eqd_launch_keypoint_bwd(const EqdGraph* g, int K, const float* H, const float* Z, const float* scores,
+                            const float* lse, const float* u, const float* dY, float* dscores, float* du, float* dH,
+                            float* dZ, hipStream_t st) {
+    if (g->n_pairs == 0 || g->n_nodes == 0) return EQD_OK;
+    if (K > 128) {
+        eqd_set_error("num_att_heads %d > 128 unsupported", K);
+        return EQD_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(k_keypoint_bwd_a, dim3(2 * g->n_pairs, K), dim3(EQD_BLOCK), 0, st, g->seg_off, K, H, Z, scores,
+                       lse, dY, dscores, du);
+    int rc = eqd_check_launch("k_keypoint_bwd_a");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_keypoint_bwd_b, dim3(g->n_nodes), dim3(64), 0, st, g->seg_off, 2 * g->n_pairs, g->n_nodes, K,
+                       scores, lse, u, dY, dscores, dH, dZ);
+    return eqd_check_launch("k_keypoint_bwd_b");
+}
+
+// backward of k_head_u: one block per head, sequential over segments (deterministic):
+//   dWk^(k) += qp (x) du / 8,  dqp = W_K^(k) du / 8,  dWq^(k) += dqp (x) qmean[partner],
+//   dqm_part[s][k] = W_Q^(k)T dqp   (gradient wrt qmean[partner(s)], reduced over k later)
+__global__ __launch_bounds__(EQD_BLOCK) void k_head_u_bwd(int B, int K, const float* __restrict__ Wk,
+                                                          const float* __restrict__ Wq,
+                                                          const float* __restrict__ qmean,
+                                                          const float* __restrict__ qp, const float* __restrict__ du,
+                                                          float* __restrict__ dWk, float* __restrict__ dWq,
+                                                          float* __restrict__ dqm_part) {
+    __shared__ float sqp[64], sdu[64], sdq[64], sqm[64];
+    const int k = blockIdx.x, t = threadIdx.x;
+    const int c = t & 63, j0 = t >> 6;  // thread owns elements (j, c) for j = j0, j0+4, ...
+    float accK[16], accQ[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accK[i] = accQ[i] = 0.f;
+    for (int s = 0; s < 2 * B; ++s) {
+        const int partner = s < B ? s + B : s - B;
+        __syncthreads();
+        if (t < 64) {
+            sqp[t] = qp[((size_t)s * K + k) * 64 + t];
+            sdu[t] = du[((size_t)s * K + k) * 64 + t] * 0.125f;
+            sqm[t] = qmean[(size_t)partner * 64 + t];
+        }
+        __syncthreads();
+        if (t < 64) {
+            const float* wk = Wk + ((size_t)k * 64 + t) * 64;
+            float a = 0.f;
+            for (int cc = 0; cc < 64; ++cc) a += wk[cc] * sdu[cc];
+            sdq[t] = a;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int j = j0 + 4 * i;
+            accK[i] += sqp[j] * sdu[c];
+            accQ[i] += sdq[j] * sqm[c];
+        }
+        if (t < 64) {
+            float a = 0.f;
+            for (int j = 0; j < 64; ++j) a += Wq[((size_t)k * 64 + j) * 64 + t] * sdq[j];
+            dqm_part[((size_t)s * K + k) * 64 + t] = a;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int j = j0 + 4 * i;
+        dWk[((size_t)k * 64 + j) * 64 + c] += accK[i];
+        dWq[((size_t)k * 64 + j) * 64 + c] += accQ[i];
+    }
+}
+int eqd_launch_head_u_bwd(const EqdGraph* g, int K, const float* Wk, const float* Wq, const float* qmean,
+                          const float* qp, const float* du, float* dWk, float* dWq, float* dqm_part, hipStream_t st) {
+    if (g->n_pairs == 0) return EQD_OK;
+    hipLaunchKernelGGL(k_head_u_bwd, dim3(K), dim3(EQD_BLOCK), 0, st, g->n_pairs, K, Wk, Wq, qmean, qp, du, dWk, dWq,
+                       dqm_part);
+    return eqd_check_launch("k_head_u_bwd");
+}
+
+// dqmean[p] = sum_k dqm_part[partner(p)][k]; dhm[i] = dqmean[seg(i)] / n_seg for the nodes of segment p
+__global__ void k_qmean_bwd(const int32_t* __restrict__ seg_off, int B, int K, const float* __restrict__ dqm_part,
+                            float* __restrict__ dhm) {
+    const int p = blockIdx.x, t = threadIdx.x;  // 64 threads
+    const int s = p < B ? p + B : p - B;        // the segment whose keypoints used qmean[p]
+    float a = 0.f;
+    for (int k = 0; k < K; ++k) a += dqm_part[((size_t)s * K + k) * 64 + t];
+    const int n0 = seg_off[p], n1 = seg_off[p + 1];
+    const float v = n1 > n0 ? a / (float)(n1 - n0) : 0.f;
+    for (int i = n0; i < n1; ++i) dhm[(size_t)i * 64 + t] = v;
+}
+int eqd_launch_qmean_bwd(const EqdGraph* g, int K, const float* dqm_part, float* dhm, hipStream_t st) {
+    if (g->n_pairs == 0) return EQD_OK;
+    hipLaunchKernelGGL(k_qmean_bwd, dim3(2 * g->n_pairs), dim3(64), 0, st, g->seg_off, g->n_pairs, K, dqm_part, dhm);
+    return eqd_check_launch("k_qmean_bwd");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kabsch: 3x3 SVD by one-sided Jacobi in fp64 (one thread per pair; singular values descending)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void svd3(const double A[3][3], double U[3][3], double S[3], double V[3][3]) {
+    double Bm[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            Bm[i][j] = A[i][j];
+            V[i][j] = (i == j) ? 1.0 : 0.0;
+        }
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                double al = 0, be = 0, ga = 0;
+                for (int i = 0; i < 3; ++i) {
+                    al += Bm[i][p] * Bm[i][p];
+                    be += Bm[i][q] * Bm[i][q];
+                    ga += Bm[i][p] * Bm[i][q];
+                }
+                if (fabs(ga) <= 1e-18 * sqrt(al * be) || ga == 0.0) continue;
+                off += fabs(ga);
+                const double zeta = (be - al) / (2.0 * ga);
+                const double tt = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
+                for (int i = 0; i < 3; ++i) {
+                    const double bp = Bm[i][p], bq = Bm[i][q];
+                    Bm[i][p] = cs * bp - sn * bq;
+                    Bm[i][q] = sn * bp + cs * bq;
+                    const double vp = V[i][p], vq = V[i][q];
+                    V[i][p] = cs * vp - sn * vq;
+                    V[i][q] = sn * vp + cs * vq;
+                }
+            }
+        if (off == 0.0) break;
+    }
+    for (int j = 0; j < 3; ++j) {
+        double n = 0;
+        for (int i = 0; i < 3; ++i) n += Bm[i][j] * Bm[i][j];
+        S[j] = sqrt(n);
+    }
+    // sort descending (selection sort on columns)
+    for (int a = 0; a < 2; ++a) {
+        int best = a;
+        for (int b = a + 1; b < 3; ++b)
+            if (S[b] > S[best]) best = b;
+        if (best != a) {
+            const double ts = S[a]; S[a] = S[best]; S[best] = ts;
+            for (int i = 0; i < 3; ++i) {
+                double tb = Bm[i][a]; Bm[i][a] = Bm[i][best]; Bm[i][best] = tb;
+                double tv = V[i][a]; V[i][a] = V[i][best]; V[i][best] = tv;
+            }
+        }
+    }
+    for (int j = 0; j < 3; ++j)
+        for (int i = 0; i < 3; ++i) U[i][j] = S[j] > 1e-300 ? Bm[i][j] / S[j] : 0.0;
+    if (!(S[2] > 1e-300)) {  // rank deficient: complete the basis so that U stays orthonormal
+        U[0][2] = U[1][0] * U[2][1] - U[2][0] * U[1][1];
+        U[1][2] = U[2][0] * U[0][1] - U[0][0] * U[2][1];
+        U[2][2] = U[0][0] * U[1][1] - U[1][0] * U[0][1];
+    }
+}
+__device__ __forceinline__ double det3(const double A[3][3]) {
+    return A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
+           A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+}
+__device__ __forceinline__ bool svd_unstable(const double S[3]) {
+    // rigid_docking_model.py:574 (the "+ eye" keeps the diagonal out of the min)
+    double mn = fmin(S[0], fmin(S[1], S[2]));
+    if (mn < 1e-3) return true;
+    const double s0 = S[0] * S[0], s1 = S[1] * S[1], s2 = S[2] * S[2];
+    const double gap = fmin(fabs(s0 - s1), fmin(fabs(s0 - s2), fabs(s1 - s2)));
+    return gap < 1e-2;
+}
+__device__ __forceinline__ float uniform_draw(unsigned seed, unsigned pair, unsigned it, unsigned c) {
+    unsigned h = seed * 0x9E3779B9u + pair * 0x85EBCA6Bu + it * 0xC2B2AE35u + c * 0x27D4EB2Fu + 0x165667B1u;
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+
+__global__ void k_kabsch_fwd(int B, int K, const float* __restrict__ Y, const float* __restrict__ draws, int seed,
+                             float* __restrict__ T, float* __restrict__ bvec, float* __restrict__ A_out,
+                             int32_t* __restrict__ status) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= B) return;
+    const float* Yl = Y + (size_t)p * K * 3;
+    const float* Yr = Y + (size_t)(B + p) * K * 3;
+    float ml[3] = {0, 0, 0}, mr[3] = {0, 0, 0};
+    for (int k = 0; k < K; ++k)
+        for (int c = 0; c < 3; ++c) {
+            ml[c] += Yl[k * 3 + c];
+            mr[c] += Yr[k * 3 + c];
+        }
+    for (int c = 0; c < 3; ++c) {
+        ml[c] /= (float)K;
+        mr[c] /= (float)K;
+    }
+    float Af[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (int k = 0; k < K; ++k)
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) Af[i][j] += (Yr[k * 3 + i] - mr[i]) * (Yl[k * 3 + j] - ml[j]);
+    double A[3][3], U[3][3], S[3], V[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) A[i][j] = (double)Af[i][j];
+    svd3(A, U, S, V);
+    int it = 0;
+    while (svd_unstable(S)) {
+        if (it >= 10) {   // reference: sys.exit(1) (:582-584); here: status 11, keep going
+            it = 11;
+            break;
+        }
+        for (int c = 0; c < 3; ++c) {
+            const float dr = draws ? draws[((size_t)p * 10 + it) * 3 + c] : uniform_draw((unsigned)seed, p, it, c);
+            Af[c][c] += dr;                       // A = A + rand(3,3) * eye(3)  (:578), in fp32 like the reference
+            A[c][c] = (double)Af[c][c];
+        }
+        svd3(A, U, S, V);
+        ++it;
+    }
+    status[p] = it;
+    const double sd = det3(A) < 0.0 ? -1.0 : 1.0;
+    float Tm[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            const double t = U[i][0] * V[j][0] + U[i][1] * V[j][1] + sd * U[i][2] * V[j][2];
+            Tm[i][j] = (float)t;
+            T[(size_t)p * 9 + i * 3 + j] = (float)t;
+            A_out[(size_t)p * 9 + i * 3 + j] = Af[i][j];
+        }
+    for (int i = 0; i < 3; ++i)
+        bvec[(size_t)p * 3 + i] = mr[i] - (Tm[i][0] * ml[0] + Tm[i][1] * ml[1] + Tm[i][2] * ml[2]);
+}
+
+extern "C" int eqd_kabsch_fwd(int n_pairs, int n_heads, const float* Y, const float* svd_draws, int svd_seed, float* T,
+                              float* b, float* A_out, int32_t* status, void* stream) {
+    if (!Y || !T || !b || !A_out || !status) {
+        eqd_set_error("eqd_kabsch_fwd: NULL argument");
+        return EQD_ERR_NULL;
+    }
+    if (n_pairs <= 0) return EQD_OK;
+    hipLaunchKernelGGL(k_kabsch_fwd, dim3((n_pairs + 63) / 64), dim3(64), 0, (hipStream_t)stream, n_pairs, n_heads, Y,
+                       svd_draws, svd_seed, T, b, A_out, status);
+    return eqd_check_launch("k_kabsch_fwd");
+}
+
+// Closed-form backward: with G = dL/dT (including the b = mean_r - T mean_l
+// path), M = U^T G V, c = (1, 1, sign det A):
+//   dP_ij = (c_j M_ij - c_i M_ji) / (s_j + c_i c_j s_i)  (i != j),  dA = U dP V^T
+__global__ void k_kabsch_bwd(int B, int K, const float* __restrict__ Y, const float* __restrict__ A_in,
+                             const float* __restrict__ T, const float* __restrict__ dT, const float* __restrict__ db,
+                             float* __restrict__ dY) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= B) return;
+    const float* Yl = Y + (size_t)p * K * 3;
+    const float* Yr = Y + (size_t)(B + p) * K * 3;
+    float* dYl = dY + (size_t)p * K * 3;
+    float* dYr = dY + (size_t)(B + p) * K * 3;
+    double ml[3] = {0, 0, 0}, mr[3] = {0, 0, 0};
+    for (int k = 0; k < K; ++k)
+        for (int c = 0; c < 3; ++c) {
+            ml[c] += Yl[k * 3 + c];
+            mr[c] += Yr[k * 3 + c];
+        }
+    for (int c = 0; c < 3; ++c) {
+        ml[c] /= K;
+        mr[c] /= K;
+    }
+    double A[3][3], U[3][3], S[3], V[3][3], G[3][3], Tm[3][3], dbv[3];
+    for (int i = 0; i < 3; ++i) {
+        dbv[i] = db ? (double)db[(size_t)p * 3 + i] : 0.0;
+        for (int j = 0; j < 3; ++j) {
+            A[i][j] = (double)A_in[(size_t)p * 9 + i * 3 + j];
+            Tm[i][j] = (double)T[(size_t)p * 9 + i * 3 + j];
+        }
+    }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) G[i][j] = (dT ? (double)dT[(size_t)p * 9 + i * 3 + j] : 0.0) - dbv[i] * ml[j];
+    svd3(A, U, S, V);
+    const double c[3] = {1.0, 1.0, det3(A) < 0.0 ? -1.0 : 1.0};
+    double M[3][3], dP[3][3], dA[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double t = 0;
+            for (int a = 0; a < 3; ++a)
+                for (int b2 = 0; b2 < 3; ++b2) t += U[a][i] * G[a][b2] * V[b2][j];
+            M[i][j] = t;
+        }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            if (i == j) {
+                dP[i][j] = 0.0;
+                continue;
+            }
+            double den = S[j] + c[i] * c[j] * S[i];
+            if (fabs(den) < 1e-12) den = den < 0 ? -1e-12 : 1e-12;
+            dP[i][j] = (c[j] * M[i][j] - c[i] * M[j][i]) / den;
+        }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double t = 0;
+            for (int a = 0; a < 3; ++a)
+                for (int b2 = 0; b2 < 3; ++b2) t += U[i][a] * dP[a][b2] * V[j][b2];
+            dA[i][j] = t;
+        }
+    // means: d mean_r = db ; d mean_l = -T^T db
+    double dml[3];
+    for (int j = 0; j < 3; ++j) dml[j] = -(Tm[0][j] * dbv[0] + Tm[1][j] * dbv[1] + Tm[2][j] * dbv[2]);
+    // centred-point gradients, then un-centre (the mean of the centred gradients is removed)
+    double gl_mean[3] = {0, 0, 0}, gr_mean[3] = {0, 0, 0};
+    for (int k = 0; k < K; ++k)
+        for (int i = 0; i < 3; ++i) {
+            double gr = 0, gl = 0;
+            for (int j = 0; j < 3; ++j) {
+                gr += dA[i][j] * ((double)Yl[k * 3 + j] - ml[j]);
+                gl += dA[j][i] * ((double)Yr[k * 3 + j] - mr[j]);
+            }
+            gr_mean[i] += gr;
+            gl_mean[i] += gl;
+        }
+    for (int i = 0; i < 3; ++i) {
+        gr_mean[i] /= K;
+        gl_mean[i] /= K;
+    }
+    for (int k = 0; k < K; ++k)
+        for (int i = 0; i < 3; ++i) {
+            double gr = 0, gl = 0;
+            for (int j = 0; j < 3; ++j) {
+                gr += dA[i][j] * ((double)Yl[k * 3 + j] - ml[j]);
+                gl += dA[j][i] * ((double)Yr[k * 3 + j] - mr[j]);
+            }
+            dYr[k * 3 + i] += (float)(gr - gr_mean[i] + dbv[i] / K);
+            dYl[k * 3 + i] += (float)(gl - gl_mean[i] + dml[i] / K);
+        }
+}
+
+extern "C" int eqd_kabsch_bwd(int n_pairs, int n_heads, const float* Y, const float* A, const float* T,
+                              const float* dT, const float* db, float* dY, void* stream) {
+    if (!Y || !A || !T || !dY) {
+        eqd_set_error("eqd_kabsch_bwd: NULL argument");
+        return EQD_ERR_NULL;
+    }
+    if (n_pairs <= 0) return EQD_OK;
+    hipLaunchKernelGGL(k_kabsch_bwd, dim3((n_pairs + 63) / 64), dim3(64), 0, (hipStream_t)stream, n_pairs, n_heads, Y,
+                       A, T, dT, db, dY);
+    return eqd_check_launch("k_kabsch_bwd");
+}
+
+// ---------------------------------------------------------------------------------------------
+// rigid apply
+// ---------------------------------------------------------------------------------------------
+__global__ void k_apply_fwd(const int32_t* __restrict__ seg_off, int B, int n_lig, const float* __restrict__ x0,
+                            const float* __restrict__ T, const float* __restrict__ b, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_lig) return;
+    const int p = find_segment(seg_off, B, i);   // ligand segments are the first B entries
+    const float* t = T + (size_t)p * 9;
+    const float x = x0[(size_t)i * 3], y = x0[(size_t)i * 3 + 1], z = x0[(size_t)i * 3 + 2];
+    for (int r = 0; r < 3; ++r) out[(size_t)i * 3 + r] = t[r * 3] * x + t[r * 3 + 1] * y + t[r * 3 + 2] * z + b[(size_t)p * 3 + r];
+}
+extern "C" int eqd_rigid_apply_fwd(const EqdGraph* g, const float* T, const float* b, float* lig_out, void* stream) {
+    if (!g || !T || !b || !lig_out) {
+        eqd_set_error("eqd_rigid_apply_fwd: NULL argument");
+        return EQD_ERR_NULL;
+    }
+    if (g->n_lig <= 0) return EQD_OK;
+    hipLaunchKernelGGL(k_apply_fwd, dim3((g->n_lig + 255) / 256), dim3(256), 0, (hipStream_t)stream, g->seg_off,
+                       g->n_pairs, g->n_lig, g->x0, T, b, lig_out);
+    return eqd_check_launch("k_apply_fwd");
+}
+
+__global__ __launch_bounds__(EQD_BLOCK) void k_apply_bwd(const int32_t* __restrict__ seg_off,
+                                                         const float* __restrict__ x0,
+                                                         const float* __restrict__ d_lig, float* __restrict__ dT,
+                                                         float* __restrict__ db) {
+    __shared__ float red[4];
+    const int p = blockIdx.x, t = threadIdx.x;
+    const int n0 = seg_off[p], n1 = seg_off[p + 1];
+    float acc[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] = 0.f;
+    for (int i = n0 + t; i < n1; i += EQD_BLOCK) {
+        const float g0 = d_lig[(size_t)i * 3], g1 = d_lig[(size_t)i * 3 + 1], g2 = d_lig[(size_t)i * 3 + 2];
+        const float x = x0[(size_t)i * 3], y = x0[(size_t)i * 3 + 1], z = x0[(size_t)i * 3 + 2];
+        acc[0] += g0 * x; acc[1] += g0 * y; acc[2] += g0 * z;
+        acc[3] += g1 * x; acc[4] += g1 * y; acc[5] += g1 * z;
+        acc[6] += g2 * x; acc[7] += g2 * y; acc[8] += g2 * z;
+        acc[9] += g0; acc[10] += g1; acc[11] += g2;
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        const float s = block_reduce_sum(acc[i], red);
+        if (t == 0) {
+            if (i < 9) dT[(size_t)p * 9 + i] += s; else db[(size_t)p * 3 + (i - 9)] += s;
+        }
+    }
+}
+extern "C" int eqd_rigid_apply_bwd(const EqdGraph* g, const float* d_lig, float* dT, float* db, void* stream) {
+    if (!g || !d_lig || !dT || !db) {
+        eqd_set_error("eqd_rigid_apply_bwd: NULL argument");
+        return EQD_ERR_NULL;
+    }
+    if (g->n_pairs <= 0) return EQD_OK;
+    hipLaunchKernelGGL(k_apply_bwd, dim3(g->n_pairs), dim3(EQD_BLOCK), 0, (hipStream_t)stream, g->seg_off, g->x0, d_lig,
+                       dT, db);
+    return eqd_check_launch("k_apply_bwd");
+}

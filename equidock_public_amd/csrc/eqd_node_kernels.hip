@@ -288,6 +288,7 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_atb_reduce(AtbUnitsArg U, const f
     const float* P = partial + u.poff + e;
     float s = 0.f;
     for (int p = 0; p < u.nparts; ++p) s += P[(long long)p * ATB_PSTRIDE];
+    if (J.scale != 0.f) s *= J.scale;
     if (is_bias)
         J.bias_out[m] += s;
     else
@@ -391,6 +392,15 @@ int eqd_launch_vec_reduce(const float* partial, int nparts, int pstride, int n, 
 __global__ void k_fill(float* p, float v, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
+}
+__global__ void k_axpy(float* y, const float* x, float a, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] += a * x[i];
+}
+int eqd_launch_axpy(float* y, const float* x, float a, size_t n, hipStream_t st) {
+    if (n == 0) return EQD_OK;
+    hipLaunchKernelGGL(k_axpy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, y, x, a, n);
+    return eqd_check_launch("k_axpy");
 }
 int eqd_launch_fill(float* p, float v, size_t n, hipStream_t st) {
     if (n == 0) return EQD_OK;

@@ -1,0 +1,323 @@
+"""Drop-in nn.Modules for the reference's IEGMN hot path, running on MI355X through
+libequidock_hip.so.
+
+Same operator surface as src/model/rigid_docking_model.py in the reference:
+
+    Rigid_Body_Docking_Net(args, log=None)                     (:611-696)
+    IEGMN(args, n_lays, fine_tune, log=None)                   (:360-606)
+    IEGMN_Layer(orig_h_feats_dim, h_feats_dim, out_feats_dim, fine_tune, args, log=None)   (:82-356)
+    model(batch_hetero_graph, epoch) -> (ligand_coords_list, keypts_ligand_list,
+                                         keypts_receptor_list, rotation_list, translation_list)
+
+with identical constructor arguments, `args` keys, parameter names/shapes (so
+`load_state_dict(checkpoint['state_dict'])` of a reference checkpoint works, :109 of
+src/inference_rigid.py) and default initialisation (the parameter-holding sub-modules are the
+same torch modules created in the same order, so a given torch seed yields the reference's
+initial weights).  The arithmetic does NOT run in those sub-modules: forward and backward are
+two C calls into the HIP library (include/equidock_hip.h) wrapped in one autograd.Function.
+
+There is no CPU/PyTorch fallback: a missing library, a CPU tensor or a configuration outside
+the HIP path raises.  Supported configuration = the published family (src/utils/args.py:227-280):
+nonlin 'lkyrelu', layer_norm 'LN', layer_norm_coors '0', final_h_layer_norm '0', dropout 0 (or
+eval mode), fine_tune False, hidden/embedding width 64.
+"""
+import ctypes as C
+
+import torch
+from torch import nn
+
+from . import _lib
+from .graph import PairGraph
+
+
+def get_non_lin(type, negative_slope):
+    if type != 'lkyrelu':
+        raise NotImplementedError(f"nonlin='{type}': only 'lkyrelu' runs on the HIP path (published configs, "
+                                  "src/utils/args.py:263)")
+    return nn.LeakyReLU(negative_slope=negative_slope)
+
+
+def get_layer_norm(layer_norm_type, dim):
+    if layer_norm_type == 'LN':
+        return nn.LayerNorm(dim)
+    if layer_norm_type == '0':
+        return nn.Identity()
+    raise NotImplementedError(f"layer_norm='{layer_norm_type}' is not supported on the HIP path")
+
+
+class IEGMN_Layer(nn.Module):
+    """Parameter container of one IEGMN layer (same names/shapes as the reference, :119-159)."""
+
+    def __init__(self, orig_h_feats_dim, h_feats_dim, out_feats_dim, fine_tune, args, log=None):
+        super().__init__()
+        if fine_tune:
+            raise NotImplementedError("fine_tune=True is outside the HIP path (reference: 'didn't work', "
+                                      "src/utils/args.py:110)")
+        if args['layer_norm'] != 'LN' or args['layer_norm_coors'] != '0' or args['final_h_layer_norm'] != '0':
+            raise NotImplementedError(
+                "HIP path supports layer_norm='LN', layer_norm_coors='0', final_h_layer_norm='0' (the published "
+                f"configuration); got {args['layer_norm']!r}, {args['layer_norm_coors']!r}, "
+                f"{args['final_h_layer_norm']!r}")
+        input_edge_feats_dim = args['input_edge_feats_dim']
+        dropout = args['dropout']
+        nonlin = args['nonlin']
+        slope = args['leakyrelu_neg_slope']
+        self.cross_msgs = args['cross_msgs']
+        self.use_dist_in_layers = args['use_dist_in_layers']
+        self.skip_weight_h = args['skip_weight_h']
+        self.x_connection_init = args['x_connection_init']
+        self.fine_tune = fine_tune
+        self.debug = args['debug']
+        self.log = log
+        self.h_feats_dim = h_feats_dim
+        self.out_feats_dim = out_feats_dim
+        self.dropout_p = dropout
+        self.all_sigmas_dist = [1.5 ** x for x in range(15)]
+
+        self.edge_mlp = nn.Sequential(
+            nn.Linear((h_feats_dim * 2) + input_edge_feats_dim + len(self.all_sigmas_dist), out_feats_dim),
+            nn.Dropout(dropout), get_non_lin(nonlin, slope), get_layer_norm(args['layer_norm'], out_feats_dim),
+            nn.Linear(out_feats_dim, out_feats_dim))
+        self.node_norm = nn.Identity()
+        self.att_mlp_Q = nn.Sequential(nn.Linear(h_feats_dim, h_feats_dim, bias=False), get_non_lin(nonlin, slope))
+        self.att_mlp_K = nn.Sequential(nn.Linear(h_feats_dim, h_feats_dim, bias=False), get_non_lin(nonlin, slope))
+        self.att_mlp_V = nn.Sequential(nn.Linear(h_feats_dim, h_feats_dim, bias=False))
+        self.node_mlp = nn.Sequential(
+            nn.Linear(orig_h_feats_dim + 2 * h_feats_dim + out_feats_dim, h_feats_dim), nn.Dropout(dropout),
+            get_non_lin(nonlin, slope), get_layer_norm(args['layer_norm'], h_feats_dim),
+            nn.Linear(h_feats_dim, out_feats_dim))
+        self.final_h_layernorm_layer = nn.Identity()
+        self.coors_mlp = nn.Sequential(
+            nn.Linear(out_feats_dim, out_feats_dim), nn.Dropout(dropout), get_non_lin(nonlin, slope),
+            get_layer_norm(args['layer_norm_coors'], out_feats_dim), nn.Linear(out_feats_dim, 1))
+
+    def param_table(self):
+        """The 19 tensors in the order of include/equidock_hip.h's parameter table."""
+        return [self.edge_mlp[0].weight, self.edge_mlp[0].bias, self.edge_mlp[3].weight, self.edge_mlp[3].bias,
+                self.edge_mlp[4].weight, self.edge_mlp[4].bias, self.att_mlp_Q[0].weight, self.att_mlp_K[0].weight,
+                self.att_mlp_V[0].weight, self.node_mlp[0].weight, self.node_mlp[0].bias, self.node_mlp[3].weight,
+                self.node_mlp[3].bias, self.node_mlp[4].weight, self.node_mlp[4].bias, self.coors_mlp[0].weight,
+                self.coors_mlp[0].bias, self.coors_mlp[4].weight, self.coors_mlp[4].bias]
+
+    def forward(self, *a, **k):
+        raise NotImplementedError(
+            "IEGMN_Layer is a parameter container here: the layer loop runs inside eqd_model_forward "
+            "(include/equidock_hip.h). Call IEGMN / Rigid_Body_Docking_Net instead.")
+
+    def __repr__(self):
+        return f"IEGMN Layer (HIP) h_feats_dim={self.h_feats_dim} out_feats_dim={self.out_feats_dim}"
+
+
+class _IEGMNFunction(torch.autograd.Function):
+    """forward = eqd_model_forward, backward = eqd_model_backward (one C call each)."""
+
+    @staticmethod
+    def forward(ctx, packed, desc, table_idx, svd_draws, need_grad, *uniq):
+        lib = _lib.load_library()
+        dev = packed.x0.device
+        gs = _lib.graph_struct(packed)
+        tensors = [_lib.require_device(p.detach(), 'parameter') for p in uniq]
+        for t in tensors:
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise _lib.EquidockHipError("parameters must be contiguous fp32 tensors")
+        ptrs = (C.c_void_p * len(table_idx))(*[tensors[i].data_ptr() for i in table_idx])
+        B, K = packed.n_pairs, desc.n_heads
+        f32 = dict(dtype=torch.float32, device=dev)
+        lig = torch.empty(packed.n_lig, 3, **f32)
+        Yl = torch.empty(B, K, 3, **f32)
+        Yr = torch.empty(B, K, 3, **f32)
+        T = torch.empty(B, 3, 3, **f32)
+        b = torch.empty(B, 3, **f32)
+        status = torch.empty(B, dtype=torch.int32, device=dev)
+        sb = lib.eqd_model_saved_bytes(C.byref(desc), C.byref(gs))
+        wb = lib.eqd_model_scratch_bytes(C.byref(desc), C.byref(gs))
+        if sb == 0 or wb == 0:
+            _lib.check(lib.eqd_model_check(C.byref(desc), C.byref(gs)))
+        saved = torch.empty(sb, dtype=torch.uint8, device=dev) if need_grad else None
+        scratch = torch.empty(wb, dtype=torch.uint8, device=dev)
+        if svd_draws is not None:
+            svd_draws = _lib.require_device(svd_draws.to(torch.float32).contiguous(), 'svd_draws')
+        _lib.check(lib.eqd_model_forward(
+            C.byref(desc), C.byref(gs), ptrs, _lib.ptr(svd_draws), _lib.ptr(lig), _lib.ptr(Yl), _lib.ptr(Yr),
+            _lib.ptr(T), _lib.ptr(b), _lib.ptr(status), _lib.ptr(saved), C.c_size_t(sb if need_grad else 0),
+            _lib.ptr(scratch), C.c_size_t(wb), _lib.stream_ptr(dev)))
+        ctx.packed, ctx.desc, ctx.table_idx, ctx.saved, ctx.sb, ctx.wb = packed, desc, table_idx, saved, sb, wb
+        ctx.tensors = tensors
+        ctx.x0 = packed.x0      # keep the coordinates this forward used alive (the saved state points at them)
+        ctx.mark_non_differentiable(status)
+        return lig, Yl, Yr, T, b, status
+
+    @staticmethod
+    def backward(ctx, d_lig, d_Yl, d_Yr, d_T, d_b, _d_status):
+        if ctx.saved is None:
+            raise _lib.EquidockHipError("backward called on a forward that ran without saving state")
+        lib = _lib.load_library()
+        packed, desc = ctx.packed, ctx.desc
+        dev = packed.x0.device
+        if packed.x0 is not ctx.x0:
+            packed.x0 = ctx.x0
+        gs = _lib.graph_struct(packed)
+        tensors = ctx.tensors
+        ptrs = (C.c_void_p * len(ctx.table_idx))(*[tensors[i].data_ptr() for i in ctx.table_idx])
+        offs, total = [], 0
+        for t in tensors:
+            offs.append(total)
+            total += (t.numel() + 63) // 64 * 64
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        goffs = (C.c_int64 * len(ctx.table_idx))(*[offs[i] for i in ctx.table_idx])
+        scratch = torch.empty(ctx.wb, dtype=torch.uint8, device=dev)
+
+        def prep(t):
+            return None if t is None else _lib.require_device(t.to(torch.float32).contiguous(), 'output gradient')
+        d_lig, d_Yl, d_Yr, d_T, d_b = (prep(t) for t in (d_lig, d_Yl, d_Yr, d_T, d_b))
+        _lib.check(lib.eqd_model_backward(
+            C.byref(desc), C.byref(gs), ptrs, _lib.ptr(d_lig), _lib.ptr(d_Yl), _lib.ptr(d_Yr), _lib.ptr(d_T),
+            _lib.ptr(d_b), _lib.ptr(flat), goffs, _lib.ptr(ctx.saved), C.c_size_t(ctx.sb), _lib.ptr(scratch),
+            C.c_size_t(ctx.wb), _lib.stream_ptr(dev)))
+        grads = tuple(flat[o:o + t.numel()].view(t.shape) for o, t in zip(offs, tensors))
+        return (None, None, None, None, None) + grads
+
+
+class IEGMN(nn.Module):
+
+    def __init__(self, args, n_lays, fine_tune, log=None):
+        super().__init__()
+        if fine_tune:
+            raise NotImplementedError("fine_tune IEGMN stage is outside the HIP path")
+        self.debug = args['debug']
+        self.log = log
+        self.device = args['device']
+        self.graph_nodes = args['graph_nodes']
+        self.rot_model = args['rot_model']
+        self.noise_decay_rate = args['noise_decay_rate']
+        self.noise_initial = args['noise_initial']
+        self.use_edge_features_in_gmn = args['use_edge_features_in_gmn']
+        self.use_mean_node_features = args['use_mean_node_features']
+        self.n_lays = n_lays
+        self.args = dict(args)
+
+        self.residue_emb_layer = nn.Embedding(num_embeddings=21, embedding_dim=args['residue_emb_dim'])
+        assert self.graph_nodes == 'residues'
+        input_node_feats_dim = args['residue_emb_dim']
+        if self.use_mean_node_features:
+            input_node_feats_dim += 5
+        self.iegmn_layers = nn.ModuleList()
+        self.iegmn_layers.append(IEGMN_Layer(orig_h_feats_dim=input_node_feats_dim, h_feats_dim=input_node_feats_dim,
+                                             out_feats_dim=args['iegmn_lay_hid_dim'], fine_tune=fine_tune, args=args,
+                                             log=log))
+        if args['shared_layers']:
+            interm_lay = IEGMN_Layer(orig_h_feats_dim=input_node_feats_dim, h_feats_dim=args['iegmn_lay_hid_dim'],
+                                     out_feats_dim=args['iegmn_lay_hid_dim'], args=args, fine_tune=fine_tune, log=log)
+            for _ in range(1, n_lays):
+                self.iegmn_layers.append(interm_lay)
+        else:
+            for _ in range(1, n_lays):
+                self.iegmn_layers.append(IEGMN_Layer(orig_h_feats_dim=input_node_feats_dim,
+                                                     h_feats_dim=args['iegmn_lay_hid_dim'],
+                                                     out_feats_dim=args['iegmn_lay_hid_dim'], args=args,
+                                                     fine_tune=fine_tune, log=log))
+        assert args['rot_model'] == 'kb_att'
+        self.num_att_heads = args['num_att_heads']
+        self.out_feats_dim = args['iegmn_lay_hid_dim']
+        self.att_mlp_key_ROT = nn.Sequential(
+            nn.Linear(self.out_feats_dim, self.num_att_heads * self.out_feats_dim, bias=False))
+        self.att_mlp_query_ROT = nn.Sequential(
+            nn.Linear(self.out_feats_dim, self.num_att_heads * self.out_feats_dim, bias=False))
+        self.mlp_h_mean_ROT = nn.Sequential(
+            nn.Linear(self.out_feats_dim, self.out_feats_dim), nn.Dropout(args['dropout']),
+            get_non_lin(args['nonlin'], args['leakyrelu_neg_slope']))
+        self.svd_seed = 0
+        self.svd_draws = None           # optional [B,10,3] tensor of guard perturbations (tests)
+        self.last_svd_status = None     # int32 [B] device tensor: guard perturbations per pair (11 = unstable)
+
+    # ---- C-ABI plumbing -------------------------------------------------------------------------
+    def _desc(self):
+        a = self.args
+        d = _lib.EqdModelDesc()
+        d.n_layers = self.n_lays
+        d.d_emb = a['residue_emb_dim']
+        d.d_hid = a['iegmn_lay_hid_dim']
+        d.use_mean_node_features = int(bool(a['use_mean_node_features']))
+        d.edge_feats = a['input_edge_feats_dim']
+        d.n_heads = a['num_att_heads']
+        d.cross_msgs = int(bool(a['cross_msgs']))
+        d.use_dist_in_layers = int(bool(a['use_dist_in_layers']))
+        d.use_edge_features = int(bool(a['use_edge_features_in_gmn']))
+        d.skip_weight_h = a['skip_weight_h']
+        d.x_connection_init = a['x_connection_init']
+        d.lrelu_slope = a['leakyrelu_neg_slope']
+        d.ln_eps = 1e-5
+        d.svd_seed = int(self.svd_seed)
+        return d
+
+    def _param_table(self):
+        table = []
+        for lay in self.iegmn_layers:
+            table.extend(lay.param_table())
+        table.extend([self.residue_emb_layer.weight, self.att_mlp_key_ROT[0].weight,
+                      self.att_mlp_query_ROT[0].weight, self.mlp_h_mean_ROT[0].weight, self.mlp_h_mean_ROT[0].bias])
+        uniq, index, table_idx = [], {}, []
+        for t in table:
+            k = id(t)
+            if k not in index:
+                index[k] = len(uniq)
+                uniq.append(t)
+            table_idx.append(index[k])
+        return uniq, table_idx
+
+    def run(self, batch_hetero_graph):
+        """Returns the raw batched outputs (lig [n_lig,3], Yl, Yr [B,K,3], T [B,3,3], b [B,3])."""
+        if not isinstance(batch_hetero_graph, PairGraph):
+            raise TypeError("expected an equidock_public_amd.graph.PairGraph batch (DGL is not used on this path)")
+        if self.training and self.args['dropout'] > 0:
+            raise NotImplementedError("dropout > 0 in training mode is outside the HIP path")
+        packed = batch_hetero_graph.pack()
+        uniq, table_idx = self._param_table()
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in uniq)
+        lig, Yl, Yr, T, b, status = _IEGMNFunction.apply(packed, self._desc(), table_idx, self.svd_draws, need_grad,
+                                                         *uniq)
+        self.last_svd_status = status
+        return packed, lig, Yl, Yr, T, b
+
+    def forward(self, batch_hetero_graph, epoch):
+        """[T_align list, b_align list, Y_ligand list, Y_receptor list] like the reference (:602)."""
+        packed, lig, Yl, Yr, T, b = self.run(batch_hetero_graph)
+        B = packed.n_pairs
+        return [[T[i] for i in range(B)], [b[i].view(1, 3) for i in range(B)],
+                [Yl[i] for i in range(B)], [Yr[i] for i in range(B)]]
+
+    def __repr__(self):
+        return f"IEGMN (HIP) n_lays={self.n_lays}"
+
+
+class Rigid_Body_Docking_Net(nn.Module):
+
+    def __init__(self, args, log=None):
+        super().__init__()
+        self.debug = args['debug']
+        self.log = log
+        self.device = args['device']
+        if args['fine_tune']:
+            raise NotImplementedError("fine_tune=True is outside the HIP path (src/utils/args.py:110)")
+        self.iegmn_original = IEGMN(args, n_lays=args['iegmn_n_lays'], fine_tune=False, log=log)
+        self.list_iegmns = [('finetune', self.iegmn_original)]
+
+    def forward(self, batch_hetero_graph, epoch):
+        packed, lig, Yl, Yr, T, b = self.iegmn_original.run(batch_hetero_graph)
+        B = packed.n_pairs
+        ligs = list(torch.split(lig, packed.lig_counts, dim=0))
+        return ligs, [Yl[i] for i in range(B)], [Yr[i] for i in range(B)], [T[i] for i in range(B)], \
+            [b[i].view(1, 3) for i in range(B)]
+
+    def forward_batched(self, batch_hetero_graph):
+        """Same computation, batched tensors instead of per-pair lists (no Python loop over pairs)."""
+        _, lig, Yl, Yr, T, b = self.iegmn_original.run(batch_hetero_graph)
+        return lig, Yl, Yr, T, b
+
+    def __repr__(self):
+        return "Rigid_Body_Docking_Net (HIP)"
+
+
+def create_model(args, log=None):
+    """src/utils/train_utils.py:111-114."""
+    return Rigid_Body_Docking_Net(args=args, log=log)

@@ -162,6 +162,7 @@ typedef struct EqdAtbJob {
     float* out; int32_t o_rs, o_cs;
     float* bias_out;
     float slope;
+    float scale;   /* multiplier applied to both results; 0 means 1 */
 } EqdAtbJob;
 size_t eqd_atb_partial_bytes(const EqdAtbJob* jobs /* host */, int njobs);
 int eqd_atb(const EqdAtbJob* jobs /* host */, int njobs, void* partial, size_t partial_bytes, void* stream);

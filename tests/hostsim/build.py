@@ -17,7 +17,7 @@ FLAGS = ['-O2', '-g', '-std=c++17', '-fPIC', '-ffp-contract=off', '-I', HERE, '-
 
 def build(force=False):
     os.makedirs(OUT, exist_ok=True)
-    srcs = sorted(glob.glob(os.path.join(CSRC, '*.hip')))
+    srcs = [s for s in sorted(glob.glob(os.path.join(CSRC, '*.hip'))) if not s.endswith('eqd_target_gfx950.hip')]
     deps = sorted(glob.glob(os.path.join(CSRC, '*.h'))) + [os.path.join(HERE, 'hip', 'hip_runtime.h'),
                                                            os.path.join(ROOT, 'include', 'equidock_hip.h')]
     objs, jobs = [], []
