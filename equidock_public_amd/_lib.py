@@ -88,7 +88,8 @@ def _declare(lib):
     lib.eqd_atb_partial_bytes.restype = C.c_size_t
     lib.eqd_edge_message_bwd_workspace_bytes.restype = C.c_size_t
     for name in ('eqd_model_check', 'eqd_model_forward', 'eqd_model_backward', 'eqd_linear', 'eqd_atb',
-                 'eqd_edge_message_fwd', 'eqd_edge_message_bwd', 'eqd_cross_attention_fwd',
+                 'eqd_edge_message_fwd', 'eqd_edge_message_bwd', 'eqd_edge_message_bwd_kernel_only',
+                 'eqd_cross_attention_fwd',
                  'eqd_cross_attention_bwd', 'eqd_keypoint_pool_fwd', 'eqd_kabsch_fwd', 'eqd_kabsch_bwd',
                  'eqd_rigid_apply_fwd', 'eqd_rigid_apply_bwd'):
         getattr(lib, name).restype = C.c_int
@@ -97,7 +98,8 @@ def _declare(lib):
 EXPORTS = ('eqd_abi_version', 'eqd_last_error', 'eqd_tile_edges', 'eqd_is_simulator', 'eqd_model_saved_bytes',
            'eqd_model_scratch_bytes', 'eqd_model_check', 'eqd_model_forward', 'eqd_model_backward', 'eqd_linear',
            'eqd_atb_partial_bytes', 'eqd_atb', 'eqd_edge_message_fwd', 'eqd_edge_message_bwd_workspace_bytes',
-           'eqd_edge_message_bwd', 'eqd_cross_attention_fwd', 'eqd_cross_attention_bwd', 'eqd_keypoint_pool_fwd',
+           'eqd_edge_message_bwd', 'eqd_edge_message_bwd_kernel_only', 'eqd_cross_attention_fwd',
+           'eqd_cross_attention_bwd', 'eqd_keypoint_pool_fwd',
            'eqd_kabsch_fwd', 'eqd_kabsch_bwd', 'eqd_rigid_apply_fwd', 'eqd_rigid_apply_bwd')
 
 

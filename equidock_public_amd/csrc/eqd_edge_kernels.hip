@@ -646,6 +646,29 @@ extern "C" size_t eqd_edge_message_bwd_workspace_bytes(const EqdGraph* g) {
     return edge_bwd_carve(g, A, nullptr, nullptr, nullptr) + 256;
 }
 
+// Profiling aid: ONLY the per-edge backward kernel of eqd_edge_message_bwd (no weight-gradient GEMMs,
+// no vector reductions, no CSC gather), so that its duration can be bracketed with HIP events.
+extern "C" int eqd_edge_message_bwd_kernel_only(const EqdGraph* g, const EqdEdgeParams* p, const float* P,
+                                                const float* Q, const float* x, const float* d_aggr_msg,
+                                                const float* d_xnew, float* dQ, float* dx, void* workspace,
+                                                size_t ws_bytes, void* stream) {
+    if (!g || !p || !P || !Q || !x || !d_aggr_msg || !d_xnew || !dQ || !dx) {
+        eqd_set_error("eqd_edge_message_bwd_kernel_only: NULL argument");
+        return EQD_ERR_NULL;
+    }
+    EqdArena A(workspace, ws_bytes);
+    EdgeBwdWs W;
+    edge_bwd_carve(g, A, &W, nullptr, nullptr);
+    if (!A.ok) {
+        eqd_set_error("eqd_edge_message_bwd_kernel_only: workspace too small");
+        return EQD_ERR_WORKSPACE;
+    }
+    if (g->n_tiles <= 0) return EQD_OK;
+    hipLaunchKernelGGL(k_edge_bwd, dim3(edge_bwd_blocks(g)), dim3(EQD_BLOCK), 0, (hipStream_t)stream, *g, *p, P, Q, x,
+                       d_aggr_msg, d_xnew, dQ, dx, W);
+    return eqd_check_launch("k_edge_bwd");
+}
+
 extern "C" int eqd_edge_message_bwd(const EqdGraph* g, const EqdEdgeParams* p, const float* P, const float* Q,
                                     const float* x, const float* d_aggr_msg, const float* d_xnew, float* dP,
                                     float* dQ, float* dx, const EqdEdgeGrads* grads, void* workspace,

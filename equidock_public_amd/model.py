@@ -108,11 +108,20 @@ class IEGMN_Layer(nn.Module):
         return f"IEGMN Layer (HIP) h_feats_dim={self.h_feats_dim} out_feats_dim={self.out_feats_dim}"
 
 
+def flat_layout(tensors):
+    """Offsets (in floats, 64-float aligned) of each unique parameter in a flat gradient buffer."""
+    offs, total = [], 0
+    for t in tensors:
+        offs.append(total)
+        total += (t.numel() + 63) // 64 * 64
+    return offs, total
+
+
 class _IEGMNFunction(torch.autograd.Function):
     """forward = eqd_model_forward, backward = eqd_model_backward (one C call each)."""
 
     @staticmethod
-    def forward(ctx, packed, desc, table_idx, svd_draws, need_grad, *uniq):
+    def forward(ctx, packed, desc, table_idx, svd_draws, need_grad, flat_state, *uniq):
         lib = _lib.load_library()
         dev = packed.x0.device
         gs = _lib.graph_struct(packed)
@@ -143,6 +152,7 @@ class _IEGMNFunction(torch.autograd.Function):
             _lib.ptr(scratch), C.c_size_t(wb), _lib.stream_ptr(dev)))
         ctx.packed, ctx.desc, ctx.table_idx, ctx.saved, ctx.sb, ctx.wb = packed, desc, table_idx, saved, sb, wb
         ctx.tensors = tensors
+        ctx.flat_state = flat_state
         ctx.x0 = packed.x0      # keep the coordinates this forward used alive (the saved state points at them)
         ctx.mark_non_differentiable(status)
         return lig, Yl, Yr, T, b, status
@@ -159,11 +169,11 @@ class _IEGMNFunction(torch.autograd.Function):
         gs = _lib.graph_struct(packed)
         tensors = ctx.tensors
         ptrs = (C.c_void_p * len(ctx.table_idx))(*[tensors[i].data_ptr() for i in ctx.table_idx])
-        offs, total = [], 0
-        for t in tensors:
-            offs.append(total)
-            total += (t.numel() + 63) // 64 * 64
-        flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        if ctx.flat_state is not None:      # accumulate straight into the model's persistent flat buffer
+            flat, offs = ctx.flat_state
+        else:
+            offs, total = flat_layout(tensors)
+            flat = torch.zeros(total, dtype=torch.float32, device=dev)
         goffs = (C.c_int64 * len(ctx.table_idx))(*[offs[i] for i in ctx.table_idx])
         scratch = torch.empty(ctx.wb, dtype=torch.uint8, device=dev)
 
@@ -174,8 +184,10 @@ class _IEGMNFunction(torch.autograd.Function):
             C.byref(desc), C.byref(gs), ptrs, _lib.ptr(d_lig), _lib.ptr(d_Yl), _lib.ptr(d_Yr), _lib.ptr(d_T),
             _lib.ptr(d_b), _lib.ptr(flat), goffs, _lib.ptr(ctx.saved), C.c_size_t(ctx.sb), _lib.ptr(scratch),
             C.c_size_t(ctx.wb), _lib.stream_ptr(dev)))
+        if ctx.flat_state is not None:
+            return (None,) * (6 + len(tensors))
         grads = tuple(flat[o:o + t.numel()].view(t.shape) for o, t in zip(offs, tensors))
-        return (None, None, None, None, None) + grads
+        return (None, None, None, None, None, None) + grads
 
 
 class IEGMN(nn.Module):
@@ -226,6 +238,7 @@ class IEGMN(nn.Module):
         self.mlp_h_mean_ROT = nn.Sequential(
             nn.Linear(self.out_feats_dim, self.out_feats_dim), nn.Dropout(args['dropout']),
             get_non_lin(args['nonlin'], args['leakyrelu_neg_slope']))
+        self._flat = None               # (flat grad buffer, offsets, ids) once enable_flat_grads() is called
         self.svd_seed = 0
         self.svd_draws = None           # optional [B,10,3] tensor of guard perturbations (tests)
         self.last_svd_status = None     # int32 [B] device tensor: guard perturbations per pair (11 = unstable)
@@ -265,6 +278,26 @@ class IEGMN(nn.Module):
             table_idx.append(index[k])
         return uniq, table_idx
 
+    # ---- flat gradient buffer (one buffer, one collective: SURVEY.md section 8e) -------------------
+    def enable_flat_grads(self):
+        """Make every parameter's .grad a view into ONE persistent fp32 buffer that the backward C call
+        accumulates into directly (no per-parameter autograd work, one all-reduce for data parallel).
+        Use zero_flat_grads() instead of optimizer.zero_grad(set_to_none=True)."""
+        uniq, _ = self._param_table()
+        offs, total = flat_layout(uniq)
+        flat = torch.zeros(total, dtype=torch.float32, device=uniq[0].device)
+        for p, o in zip(uniq, offs):
+            p.grad = flat[o:o + p.numel()].view(p.shape)
+        self._flat = (flat, offs, [id(p) for p in uniq])
+        return flat
+
+    def zero_flat_grads(self):
+        self._flat[0].zero_()
+
+    @property
+    def grad_flat(self):
+        return None if self._flat is None else self._flat[0]
+
     def run(self, batch_hetero_graph):
         """Returns the raw batched outputs (lig [n_lig,3], Yl, Yr [B,K,3], T [B,3,3], b [B,3])."""
         if not isinstance(batch_hetero_graph, PairGraph):
@@ -274,8 +307,13 @@ class IEGMN(nn.Module):
         packed = batch_hetero_graph.pack()
         uniq, table_idx = self._param_table()
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in uniq)
+        flat_state = None
+        if self._flat is not None and need_grad:
+            if self._flat[2] != [id(p) for p in uniq] or self._flat[0].device != packed.x0.device:
+                raise _lib.EquidockHipError("parameters changed since enable_flat_grads(); call it again")
+            flat_state = (self._flat[0], self._flat[1])
         lig, Yl, Yr, T, b, status = _IEGMNFunction.apply(packed, self._desc(), table_idx, self.svd_draws, need_grad,
-                                                         *uniq)
+                                                         flat_state, *uniq)
         self.last_svd_status = status
         return packed, lig, Yl, Yr, T, b
 

@@ -195,6 +195,11 @@ int eqd_edge_message_bwd(const EqdGraph* g, const EqdEdgeParams* p, const float*
                          float* dP, float* dQ, float* dx, const EqdEdgeGrads* grads,
                          void* workspace, size_t ws_bytes, void* stream);
 
+/* Profiling aid: only the per-edge backward kernel (k_edge_bwd) of eqd_edge_message_bwd. */
+int eqd_edge_message_bwd_kernel_only(const EqdGraph* g, const EqdEdgeParams* p, const float* P, const float* Q,
+                                     const float* x, const float* d_aggr_msg, const float* d_xnew,
+                                     float* dQ, float* dx, void* workspace, size_t ws_bytes, void* stream);
+
 /* Block-diagonal cross attention, both directions (rigid_docking_model.py:46-64, 244-256):
  * out_i = sum_j softmax_j(q_i . k_j) v_j over the partner protein of the same pair (no 1/sqrt(d)).
  * q, k, v, out: [n_nodes][d]; lse: [n_nodes]. */

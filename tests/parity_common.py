@@ -1,0 +1,412 @@
+"""Parity checks shared by the simulator tests (CPU, tests/test_sim_parity.py) and the GPU tests
+(tests/test_gpu_parity.py).  Every check calls the C ABI (include/equidock_hip.h) through ctypes
+and compares with a plain fp32 PyTorch restatement of the same op on the host, or -- for the whole
+model -- with the golden vectors / the oracle (oracle/iegmn_port.py).
+
+Tolerances (fp32, BASELINE.json: "within 1e-4 fp32"):
+  outputs   : |got - ref| <= 1e-4 * max(1, max|ref|)   (the reference's own fp32 result differs from
+              an fp64 evaluation by 2.6e-4 absolute on case B, so this is the fp32 noise floor)
+  gradients : relative L2 error <= 1e-3 and max-abs error <= 1e-2 * max|ref|.  The looser max-abs
+              bound covers LeakyReLU kinks: one pre-activation within rounding of 0 gets the other
+              slope (x100) under ANY change of fp32 summation order (observed: 1 element in 450k).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from equidock_public_amd import _lib as L
+from equidock_public_amd import graph as G
+from equidock_public_amd import model as M
+from equidock_public_amd import synthetic
+from oracle import iegmn_port as port
+from tests.util import cat_out, load_case, pairs_from_raw, state_dict_for
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def lib():
+    return L._lib
+
+
+def st(dev):
+    return L.stream_ptr(dev)
+
+
+def sync(dev):
+    if torch.device(dev).type == 'cuda':
+        torch.cuda.synchronize()
+
+
+def close(got, ref, tol=1e-4, what=''):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    scale = max(1.0, float(ref.abs().max()))
+    err = float((got - ref).abs().max())
+    assert err <= tol * scale, f'{what}: max abs err {err:.3e} > {tol:.0e} * {scale:.3g}'
+
+
+def grad_close(got, ref, what='', l2=1e-3, mx=1e-2):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    n = float(ref.norm())
+    if n < 1e-12:
+        assert float(got.norm()) < 1e-6, what
+        return
+    e2 = float((got - ref).norm()) / n
+    em = float((got - ref).abs().max()) / float(ref.abs().max())
+    assert e2 <= l2 and em <= mx, f'{what}: rel-L2 {e2:.3e} (<= {l2}), max-abs/max {em:.3e} (<= {mx})'
+
+
+def small_graph(dev, sizes=((23, 31), (17, 12)), seed=5, degrade=True):
+    pairs = synthetic.make_pairs(list(sizes), seed)
+    if degrade:
+        for lig, rec in pairs:
+            for p in (lig, rec):
+                keep = np.ones(len(p['dst']), bool)
+                keep[p['dst'] == 3] = False
+                keep[(p['dst'] == 5) & (np.arange(len(keep)) % 2 == 0)] = False
+                for k in ('src', 'dst', 'he'):
+                    p[k] = p[k][keep]
+    g = G.batch_pairs(pairs).to(dev)
+    pk = g.pack()
+    return g, pk, L.graph_struct(pk)
+
+
+# ------------------------------------------------------------------------------------------------
+def check_linear(dev):
+    torch.manual_seed(0)
+    rows, K1, K2, Mo = 77, 69, 64, 69
+    X1, X2 = torch.randn(rows, K1), torch.randn(rows, K2)
+    W, b = torch.randn(Mo, K1 + K2) * 0.2, torch.randn(Mo)
+    g, be, R = torch.randn(Mo), torch.randn(Mo), torch.randn(rows, Mo)
+    d = [t.to(dev) for t in (X1, X2, W, b, g, be, R)]
+    Y, pre = torch.zeros(rows, Mo, device=dev), torch.zeros(rows, Mo, device=dev)
+    J = L.EqdLinJob()
+    J.nsrc = 2
+    for i, (X, K, off) in enumerate(((d[0], K1, 0), (d[1], K2, K1))):
+        J.s[i].X, J.s[i].W, J.s[i].ldx, J.s[i].K = X.data_ptr(), d[2].data_ptr() + 4 * off, K, K
+        J.s[i].w_rs, J.s[i].w_cs = K1 + K2, 1
+    J.M, J.act, J.rows, J.bias = Mo, 1, rows, d[3].data_ptr()
+    J.ln_g, J.ln_b, J.pre_ln, J.ld_pre = d[4].data_ptr(), d[5].data_ptr(), pre.data_ptr(), Mo
+    J.R, J.ldr, J.alpha, J.beta, J.slope, J.ln_eps = d[6].data_ptr(), Mo, 0.75, 0.25, 0.01, 1e-5
+    J.Y, J.ldy = Y.data_ptr(), Mo
+    L.check(lib().eqd_linear(C.byref(J), 1, st(dev)))
+    sync(dev)
+    z = F.leaky_relu(torch.cat([X1, X2], 1) @ W.t() + b, 0.01)
+    close(pre, z, what='pre-LN')
+    close(Y, 0.75 * F.layer_norm(z, (Mo,), g, be, 1e-5) + 0.25 * R, what='linear+LN+residual')
+    # transposed-weight / masked mode (dX = (dY * lrelu'(mask)) W)
+    dY, mask = torch.randn(rows, Mo), torch.randn(rows, Mo)
+    dYd, md = dY.to(dev), mask.to(dev)
+    dX = torch.zeros(rows, 64, device=dev)
+    J2 = L.EqdLinJob()
+    J2.nsrc = 1
+    J2.s[0].X, J2.s[0].mask, J2.s[0].W = dYd.data_ptr(), md.data_ptr(), d[2].data_ptr() + 4 * K1
+    J2.s[0].ldx, J2.s[0].K, J2.s[0].w_rs, J2.s[0].w_cs = Mo, Mo, 1, K1 + K2
+    J2.M, J2.rows, J2.alpha, J2.slope, J2.Y, J2.ldy = 64, rows, 1.0, 0.01, dX.data_ptr(), 64
+    L.check(lib().eqd_linear(C.byref(J2), 1, st(dev)))
+    sync(dev)
+    close(dX, (dY * torch.where(mask > 0, 1.0, 0.01)) @ W[:, K1:K1 + 64], what='dX')
+
+
+def check_atb(dev):
+    torch.manual_seed(1)
+    rows = 1000
+    Xa, Ya, xm = torch.randn(rows, 69), torch.randn(rows, 271), torch.randn(rows, 69)
+    out, bo = torch.zeros(69, 300, device=dev), torch.zeros(69, device=dev)
+    Xd, Yd, xd = Xa.to(dev), Ya.to(dev), xm.to(dev)
+    A = L.EqdAtbJob()
+    A.X, A.xmask, A.ldx, A.M, A.Y, A.ldy, A.N = Xd.data_ptr(), xd.data_ptr(), 69, 69, Yd.data_ptr(), 271, 271
+    A.rows, A.out, A.o_rs, A.o_cs, A.bias_out, A.slope, A.scale = rows, out.data_ptr() + 40, 300, 1, bo.data_ptr(), 0.01, 0.5
+    nb = lib().eqd_atb_partial_bytes(C.byref(A), 1)
+    part = torch.zeros(nb // 4 + 64, device=dev)
+    for _ in range(2):     # accumulating semantics: two calls = twice the result
+        L.check(lib().eqd_atb(C.byref(A), 1, P(part), C.c_size_t(nb), st(dev)))
+    sync(dev)
+    Xm = Xa * torch.where(xm > 0, 1.0, 0.01)
+    close(out[:, 10:281], Xm.t() @ Ya, what='A^T B')
+    close(bo, Xm.sum(0), what='column sums')
+    assert float(out[:, :10].abs().max()) == 0.0 and float(out[:, 281:].abs().max()) == 0.0
+
+
+def _edge_setup(dev, d_in=64):
+    g, pk, gs = small_graph(dev)
+    torch.manual_seed(2)
+    N = pk.n_nodes
+    ldw1 = 2 * d_in + 42
+    host = dict(W1=torch.randn(64, ldw1) * 0.2, lng=torch.randn(64) * 0.5 + 1, lnb=torch.randn(64) * 0.1,
+                W2=torch.randn(64, 64) * 0.2, b2=torch.randn(64) * 0.1, Wc1=torch.randn(64, 64) * 0.2,
+                bc1=torch.randn(64) * 0.1, wc2=torch.randn(1, 64) * 0.2, bc2=torch.randn(1) * 0.1,
+                Pn=torch.randn(N, 64), Qn=torch.randn(N, 64), x=pk.x0.cpu() + 0.1 * torch.randn(N, 3))
+    d = {k: v.to(dev).contiguous() for k, v in host.items()}
+    ep = L.EqdEdgeParams()
+    ep.W1, ep.ldw1, ep.d_in, ep.ln_g, ep.ln_b = d['W1'].data_ptr(), ldw1, d_in, d['lng'].data_ptr(), d['lnb'].data_ptr()
+    ep.W2, ep.b2, ep.Wc1, ep.bc1 = (d[k].data_ptr() for k in ('W2', 'b2', 'Wc1', 'bc1'))
+    ep.wc2, ep.bc2 = d['wc2'].data_ptr(), d['bc2'].data_ptr()
+    ep.slope, ep.ln_eps, ep.eta, ep.use_dist, ep.use_he = 0.01, 1e-5, 0.25, 1, 1
+    return g, pk, gs, host, d, ep, ldw1, d_in
+
+
+def _edge_ref(pk, eta, Pn, Qn, x, W1cd, lng, lnb, W2, b2, Wc1, bc1, wc2, bc2):
+    N, E = pk.n_nodes, pk.n_edges
+    src, dst = pk.src.cpu().long(), pk.dst.cpu().long()
+    he, x0 = pk.he.cpu(), pk.x0.cpu()
+    xrel = x[src] - x[dst]
+    d2 = (xrel ** 2).sum(1, keepdim=True)
+    rbf = torch.cat([torch.exp(-d2 / (1.5 ** k)) for k in range(15)], 1)
+    z1 = Pn[src] + Qn[dst] + torch.cat([he, rbf], 1) @ W1cd.t()
+    a1 = F.layer_norm(F.leaky_relu(z1, 0.01), (64,), lng, lnb, 1e-5)
+    m = a1 @ W2.t() + b2
+    coef = F.leaky_relu(m @ Wc1.t() + bc1, 0.01) @ wc2.t() + bc2
+    deg = torch.zeros(N).index_add(0, dst, torch.ones(E)).clamp(min=1)
+    am = torch.zeros(N, 64).index_add(0, dst, m) / deg[:, None]
+    xu = torch.zeros(N, 3).index_add(0, dst, xrel * coef) / deg[:, None]
+    return am, eta * x0 + (1 - eta) * x + xu
+
+
+def check_edge(dev):
+    g, pk, gs, host, d, ep, ldw1, d_in = _edge_setup(dev)
+    N = pk.n_nodes
+    aggr, xnew = torch.zeros(N, 64, device=dev), torch.zeros(N, 3, device=dev)
+    L.check(lib().eqd_edge_message_fwd(C.byref(gs), C.byref(ep), P(d['Pn']), P(d['Qn']), P(d['x']), P(aggr), P(xnew),
+                                       st(dev)))
+    sync(dev)
+    names = ('Pn', 'Qn', 'x', 'W1cd', 'lng', 'lnb', 'W2', 'b2', 'Wc1', 'bc1', 'wc2', 'bc2')
+    host = dict(host, W1cd=host['W1'][:, 2 * d_in:].contiguous())
+    leaves = [host[k].clone().requires_grad_(True) for k in names]
+    am, xn = _edge_ref(pk, 0.25, *leaves)
+    close(aggr, am, what='aggr_msg')
+    close(xnew, xn, what='x_new')
+    torch.manual_seed(3)
+    dag, dxn = torch.randn(N, 64), torch.randn(N, 3)
+    ((am * dag).sum() + (xn * dxn).sum()).backward()
+    wsb = lib().eqd_edge_message_bwd_workspace_bytes(C.byref(gs))
+    ws = torch.zeros(wsb // 4 + 64, device=dev)
+    dP, dQ, dx = (torch.zeros(N, w, device=dev) for w in (64, 64, 3))
+    gr = {k: torch.zeros_like(d[k]) for k in ('W1', 'lng', 'lnb', 'W2', 'b2', 'Wc1', 'bc1', 'wc2', 'bc2')}
+    eg = L.EqdEdgeGrads()
+    eg.dW1, eg.ldw1, eg.dln_g, eg.dln_b = gr['W1'].data_ptr(), ldw1, gr['lng'].data_ptr(), gr['lnb'].data_ptr()
+    eg.dW2, eg.db2, eg.dWc1, eg.dbc1 = (gr[k].data_ptr() for k in ('W2', 'b2', 'Wc1', 'bc1'))
+    eg.dwc2, eg.dbc2 = gr['wc2'].data_ptr(), gr['bc2'].data_ptr()
+    dagd, dxnd = dag.to(dev), dxn.to(dev)
+    L.check(lib().eqd_edge_message_bwd(C.byref(gs), C.byref(ep), P(d['Pn']), P(d['Qn']), P(d['x']), P(dagd), P(dxnd),
+                                       P(dP), P(dQ), P(dx), C.byref(eg), P(ws), C.c_size_t(wsb), st(dev)))
+    sync(dev)
+    got = [dP, dQ, dx, gr['W1'][:, 2 * d_in:], gr['lng'], gr['lnb'], gr['W2'], gr['b2'], gr['Wc1'], gr['bc1'],
+           gr['wc2'], gr['bc2']]
+    for n, a, l in zip(names, got, leaves):
+        grad_close(a, l.grad, what='edge d' + n, l2=1e-4, mx=1e-4)
+    assert float(gr['W1'][:, :2 * d_in].abs().max()) == 0.0
+
+
+def _attn_ref(pk, q, k, v):
+    nl = pk.n_lig
+    o_l, o_r, lo, ro = [], [], 0, 0
+    for a, b in zip(pk.lig_counts, pk.rec_counts):
+        L0, L1, R0, R1 = lo, lo + a, nl + ro, nl + ro + b
+        o_l.append(torch.softmax(q[L0:L1] @ k[R0:R1].t(), 1) @ v[R0:R1])
+        o_r.append(torch.softmax(q[R0:R1] @ k[L0:L1].t(), 1) @ v[L0:L1])
+        lo += a
+        ro += b
+    return torch.cat(o_l + o_r, 0)
+
+
+def check_attention(dev, d, sizes=((70, 45), (33, 101))):
+    g, pk, gs = small_graph(dev, sizes=sizes, degrade=False)
+    N = pk.n_nodes
+    torch.manual_seed(4)
+    q, k, v = torch.randn(N, d) * 0.5, torch.randn(N, d) * 0.5, torch.randn(N, d)
+    qd, kd, vd = (t.to(dev) for t in (q, k, v))
+    out, lse = torch.zeros(N, d, device=dev), torch.zeros(N, device=dev)
+    L.check(lib().eqd_cross_attention_fwd(C.byref(gs), d, P(qd), P(kd), P(vd), P(out), P(lse), st(dev)))
+    sync(dev)
+    ql, kl, vl = (t.clone().requires_grad_(True) for t in (q, k, v))
+    o = _attn_ref(pk, ql, kl, vl)
+    close(out, o, what=f'cross attention d={d}')
+    do = torch.randn(N, d)
+    (o * do).sum().backward()
+    dq, dk, dv = (torch.zeros(N, d, device=dev) for _ in range(3))
+    delta = torch.zeros(N, device=dev)
+    dod = do.to(dev)
+    L.check(lib().eqd_cross_attention_bwd(C.byref(gs), d, P(qd), P(kd), P(vd), P(out), P(lse), P(dod), P(dq), P(dk),
+                                          P(dv), P(delta), st(dev)))
+    sync(dev)
+    for n, a, b in (('dq', dq, ql.grad), ('dk', dk, kl.grad), ('dv', dv, vl.grad)):
+        grad_close(a, b, what=f'attention {n} d={d}', l2=1e-4, mx=1e-4)
+
+
+def check_kabsch(dev):
+    """Kabsch forward + closed-form backward vs torch.linalg.svd autograd, both det signs."""
+    torch.manual_seed(6)
+    B, K = 6, 50
+    Y = torch.randn(2 * B, K, 3) * 3.0
+    Y[B + 1] = Y[1] @ torch.diag(torch.tensor([1., 1., -1.])) + 0.05 * torch.randn(K, 3)   # reflection -> det < 0
+    Yd = Y.to(dev)
+    T, b, A, status = (torch.zeros(B, 9, device=dev), torch.zeros(B, 3, device=dev), torch.zeros(B, 9, device=dev),
+                       torch.zeros(B, dtype=torch.int32, device=dev))
+    L.check(lib().eqd_kabsch_fwd(B, K, P(Yd), None, 0, P(T), P(b), P(A), P(status), st(dev)))
+    sync(dev)
+    Yl = Y.clone().requires_grad_(True)
+    Ts, bs = [], []
+    dets = []
+    for p in range(B):
+        t, bb, a = port.kabsch(Yl[B + p], Yl[p])
+        Ts.append(t)
+        bs.append(bb.view(3))
+        dets.append(float(torch.det(a)))
+    assert min(dets) < 0 < max(dets)
+    Tr, br = torch.stack(Ts), torch.stack(bs)
+    close(T.view(B, 3, 3), Tr, tol=2e-5, what='Kabsch T')
+    close(b, br, tol=2e-5, what='Kabsch b')
+    assert status.cpu().tolist() == [0] * B
+    dT, db = torch.randn(B, 3, 3), torch.randn(B, 3)
+    ((Tr * dT).sum() + (br * db).sum()).backward()
+    dY = torch.zeros(2 * B, K, 3, device=dev)
+    dTd, dbd = dT.to(dev).contiguous(), db.to(dev).contiguous()
+    L.check(lib().eqd_kabsch_bwd(B, K, P(Yd), P(A), P(T), P(dTd), P(dbd), P(dY), st(dev)))
+    sync(dev)
+    grad_close(dY, Yl.grad, what='Kabsch dY', l2=2e-4, mx=2e-4)
+
+
+def check_keypoints_and_apply(dev):
+    g, pk, gs = small_graph(dev, sizes=((40, 33), (25, 61)), degrade=False)
+    torch.manual_seed(7)
+    N, B, K = pk.n_nodes, pk.n_pairs, 50
+    Wk, Wq = torch.randn(K * 64, 64) * 0.3, torch.randn(K * 64, 64) * 0.3
+    qmean, H, Z = torch.randn(2 * B, 64), torch.randn(N, 64), torch.randn(N, 3) * 5
+    dd = [t.to(dev) for t in (Wk, Wq, qmean, H, Z)]
+    Y, scores, lse = torch.zeros(2 * B, K, 3, device=dev), torch.zeros(N, K, device=dev), torch.zeros(2 * B, K, device=dev)
+    qp, u = torch.zeros(2 * B, K, 64, device=dev), torch.zeros(2 * B, K, 64, device=dev)
+    L.check(lib().eqd_keypoint_pool_fwd(C.byref(gs), K, P(dd[0]), P(dd[1]), P(dd[2]), P(dd[3]), P(dd[4]), P(Y), P(scores),
+                                        P(lse), P(qp), P(u), st(dev)))
+    sync(dev)
+    seg = pk.seg_off.cpu().tolist()
+    for s in range(2 * B):
+        partner = s + B if s < B else s - B
+        n0, n1 = seg[s], seg[s + 1]
+        att = torch.softmax(
+            F.linear(H[n0:n1], Wk).view(-1, K, 64).transpose(0, 1) @
+            F.linear(qmean[partner:partner + 1], Wq).view(1, K, 64).transpose(0, 1).transpose(1, 2) / 8.0, dim=1).view(K, -1)
+        close(Y[s], att @ Z[n0:n1], what=f'keypoints segment {s}')
+    # rigid apply + its backward
+    T = torch.randn(B, 3, 3)
+    bb = torch.randn(B, 3)
+    Td, bd = T.to(dev).contiguous(), bb.to(dev).contiguous()
+    lig = torch.zeros(pk.n_lig, 3, device=dev)
+    L.check(lib().eqd_rigid_apply_fwd(C.byref(gs), P(Td), P(bd), P(lig), st(dev)))
+    sync(dev)
+    x0 = pk.x0.cpu()
+    ref, lo = [], 0
+    for p, n in enumerate(pk.lig_counts):
+        ref.append((T[p] @ x0[lo:lo + n].t()).t() + bb[p])
+        lo += n
+    close(lig, torch.cat(ref), what='rigid apply')
+    dl = torch.randn(pk.n_lig, 3)
+    dT, db = torch.zeros(B, 9, device=dev), torch.zeros(B, 3, device=dev)
+    dld = dl.to(dev)
+    L.check(lib().eqd_rigid_apply_bwd(C.byref(gs), P(dld), P(dT), P(db), st(dev)))
+    sync(dev)
+    lo = 0
+    for p, n in enumerate(pk.lig_counts):
+        close(dT[p].view(3, 3), dl[lo:lo + n].t() @ x0[lo:lo + n], what='apply dT')
+        close(db[p], dl[lo:lo + n].sum(0), what='apply db')
+        lo += n
+
+
+# ------------------------------------------------------------------------------------------------
+def build_model(args, sd, dev):
+    args = dict(args, device=torch.device(dev))
+    net = M.Rigid_Body_Docking_Net(args).to(dev)
+    net.load_state_dict(sd)
+    return net
+
+
+def check_model_case(dev, name, check_grads=True):
+    """Whole model vs the golden vectors captured from the imported reference."""
+    z, meta, args, raw = load_case(name)
+    sd = state_dict_for(meta, args)
+    net = build_model(args, sd, dev)
+    g = G.batch_pairs(pairs_from_raw(raw)).to(dev)
+    if 'svd_draws' in z.files:
+        dr = torch.zeros(len(raw['lig_counts']), 10, 3)
+        for i, m in enumerate(z['svd_draws']):
+            dr[0, i] = torch.from_numpy(np.diag(m).copy())
+        net.iegmn_original.svd_draws = dr.to(dev)
+    outs = net(g, epoch=0)
+    assert len(outs) == 5 and all(len(o) == len(raw['lig_counts']) for o in outs)
+    assert outs[4][0].shape == (1, 3) and outs[3][0].shape == (3, 3)
+    for nm, lst in zip(('lig', 'Yl', 'Yr', 'T', 'b'), outs):
+        close(cat_out(lst), torch.from_numpy(z['out_' + nm]), what=f'{name} {nm}')
+    assert net.iegmn_original.last_svd_status.cpu().tolist() == meta['svd_iters']
+    # inference-style identity (src/inference_rigid.py:199-205): lig' == (R x^T)^T + t
+    lo = 0
+    for p, n in enumerate(raw['lig_counts']):
+        x = raw['lig_x'][lo:lo + n]
+        close(outs[0][p], (outs[3][p].detach().cpu() @ x.t()).t() + outs[4][p].detach().cpu(), what='R,t identity')
+        lo += n
+    if not check_grads:
+        return
+    loss = port.scalar_loss(outs)
+    loss.backward()
+    sync(dev)
+    assert abs(float(loss) - float(z['loss'])) <= 1e-4 * abs(float(z['loss']))
+    gf = meta['grad_fingerprint']
+    for k, p in net.named_parameters():
+        if 'grad_' + k in z.files:
+            grad_close(p.grad, torch.from_numpy(z['grad_' + k]), what=f'{name} grad {k}')
+        else:
+            nrm = gf[k][1]
+            assert abs(float(p.grad.double().norm().cpu()) - nrm) <= 2e-3 * max(nrm, 1e-6), f'{name} grad norm {k}'
+
+
+def check_flat_grads_equal_autograd(dev):
+    z, meta, args, raw = load_case('D_degraded3')
+    sd = state_dict_for(meta, args)
+    g = G.batch_pairs(pairs_from_raw(raw)).to(dev)
+    n1, n2 = build_model(args, sd, dev), build_model(args, sd, dev)
+    port.scalar_loss(n1(g, epoch=0)).backward()
+    flat = n2.iegmn_original.enable_flat_grads()
+    for _ in range(2):          # second iteration checks zero_flat_grads()
+        n2.iegmn_original.zero_flat_grads()
+        port.scalar_loss(n2(g, epoch=0)).backward()
+    sync(dev)
+    for (k, a), (_, b) in zip(n1.named_parameters(), n2.named_parameters()):
+        assert torch.equal(a.grad, b.grad), k
+    assert float(flat.abs().sum()) > 0
+
+
+def check_properties(dev, sizes=((60, 75), (90, 48)), layers=3):
+    """Known-answer/property checks that need no oracle."""
+    args = port.default_args(iegmn_n_lays=layers, skip_weight_h=0.5)
+    sd = port.init_state_dict(args, seed=21)
+    net = build_model(args, sd, dev)
+    pairs = synthetic.make_pairs(list(sizes), 21)
+    with torch.no_grad():
+        g = G.batch_pairs(pairs).to(dev)
+        lig, Yl, Yr, T, b = [t.cpu() for t in net.forward_batched(g)]
+        # rotation matrices: T T^T = I, det = +1
+        for t in T:
+            close(t @ t.t(), torch.eye(3), tol=1e-5, what='T T^T')
+            assert abs(float(torch.det(t)) - 1.0) < 1e-5
+        # batch of one == same pair inside the bigger batch; pair permutation permutes outputs
+        g1 = G.batch_pairs(pairs[1:2]).to(dev)
+        lig1, Yl1, Yr1, T1, b1 = [t.cpu() for t in net.forward_batched(g1)]
+        close(T1[0], T[1], what='batch-of-one T')
+        close(lig1, lig[sizes[0][0]:], what='batch-of-one lig')
+        gp = G.batch_pairs(pairs[::-1]).to(dev)
+        ligp = net.forward_batched(gp)[0].cpu()
+        close(ligp[:sizes[1][0]], lig[sizes[0][0]:], what='pair permutation')
+        # SE(3): rotate + translate the input ligand -> final complex unchanged (<= 1e-3)
+        rng = np.random.default_rng(0)
+        R = torch.from_numpy(synthetic._random_rotation(rng)).float()
+        tvec = torch.tensor([3.0, -2.0, 5.0])
+        moved = []
+        for l, r in pairs:
+            l2 = dict(l)
+            l2['new_x'] = ((R @ torch.from_numpy(l['new_x']).t()).t() + tvec).numpy()
+            moved.append((l2, r))
+        ligm = net.forward_batched(G.batch_pairs(moved).to(dev))[0].cpu()
+        err = float((ligm - lig).abs().max())
+        assert err < 2e-3, f'SE(3) equivariance violated: {err}'

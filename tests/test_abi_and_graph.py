@@ -1,0 +1,157 @@
+"""CPU tests: the gfx950 library builds, loads and exports every symbol declared in
+include/equidock_hip.h (no compute calls); the graph container's packing invariants."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from equidock_public_amd import graph as G
+from equidock_public_amd import synthetic
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_hip_library_builds_and_exports_header_symbols():
+    from equidock_public_amd import build as hip_build
+    from equidock_public_amd import _lib
+    lib = hip_build.build(verbose=False)
+    handle = ctypes.CDLL(lib)
+    header = open(os.path.join(ROOT, 'include', 'equidock_hip.h')).read()
+    declared = set(re.findall(r'\b(eqd_[a-z0-9_]+)\s*\(', header))
+    assert declared, "no declarations parsed"
+    for sym in sorted(declared):
+        assert hasattr(handle, sym), f"{sym} declared in include/equidock_hip.h but not exported"
+    assert set(_lib.EXPORTS) <= declared
+    handle.eqd_abi_version.restype = ctypes.c_int
+    assert handle.eqd_abi_version() == 1
+    assert handle.eqd_is_simulator() == 0
+    assert handle.eqd_tile_edges() == G.TILE_EDGES
+
+
+def test_product_refuses_cpu_tensors():
+    from equidock_public_amd import _lib
+    _lib.unload_for_testing()
+    _lib.load_library()
+    with pytest.raises(_lib.EquidockHipError):
+        _lib.require_device(torch.zeros(2), 'x')
+    _lib.unload_for_testing()
+
+
+def test_unsupported_configs_raise():
+    from equidock_public_amd import model as M
+    from oracle import iegmn_port as port
+    for over in (dict(nonlin='swish'), dict(layer_norm='BN'), dict(final_h_layer_norm='GN'), dict(fine_tune=True),
+                 dict(layer_norm_coors='LN')):
+        with pytest.raises(NotImplementedError):
+            M.Rigid_Body_Docking_Net(port.default_args(**over))
+
+
+def test_state_dict_keys_match_reference_layout():
+    """157 keys for the 8-layer model, 100 for the 5-layer shared one."""
+    from equidock_public_amd import model as M
+    from oracle import iegmn_port as port
+    n8 = M.Rigid_Body_Docking_Net(port.default_args(iegmn_n_lays=8))
+    n5 = M.Rigid_Body_Docking_Net(port.default_args(iegmn_n_lays=5, shared_layers=True))
+    assert len(n8.state_dict()) == 157 and len(n5.state_dict()) == 100
+    assert sum(p.numel() for p in n8.parameters()) == 842477
+    assert sum(p.numel() for p in n5.parameters()) == 525671
+    sd = port.init_state_dict(port.default_args(iegmn_n_lays=5, shared_layers=True), 0)
+    assert set(sd) == set(n5.state_dict())
+    n5.load_state_dict(sd)
+
+
+def _pairs():
+    return synthetic.make_pairs([(21, 34), (40, 17), (9, 12)], 3)
+
+
+def test_batch_unbatch_roundtrip():
+    pairs = _pairs()
+    g = G.batch_pairs(pairs)
+    assert g.batch_num_nodes('ligand').tolist() == [21, 40, 9]
+    assert g.nodes['receptor'].data['x'].shape == (34 + 17 + 12, 3)
+    parts = G.unbatch(g)
+    for (lig, rec), h in zip(pairs, parts):
+        np.testing.assert_array_equal(h.nodes['ligand'].data['new_x'].numpy(), lig['new_x'])
+        np.testing.assert_array_equal(h.edge_endpoints('rr')[0].numpy(), rec['src'])
+        np.testing.assert_array_equal(h.edges['ll'].data['he'].numpy(), lig['he'])
+    g2 = G.batch(parts)
+    np.testing.assert_array_equal(g2.edge_endpoints('ll')[1].numpy(), g.edge_endpoints('ll')[1].numpy())
+
+
+def test_pack_invariants():
+    g = G.batch_pairs(_pairs())
+    p = g.pack()
+    N, E = p.n_nodes, p.n_edges
+    src, dst = p.src.numpy(), p.dst.numpy()
+    assert src.dtype == np.int32 and dst.dtype == np.int32
+    assert np.all(dst[1:] >= dst[:-1])
+    rp = p.rowptr.numpy()
+    assert rp[0] == 0 and rp[-1] == E
+    for i in range(N):
+        assert np.all(dst[rp[i]:rp[i + 1]] == i)
+    cp, ce = p.csc_ptr.numpy(), p.csc_eid.numpy()
+    assert sorted(ce.tolist()) == list(range(E))
+    for j in range(N):
+        assert np.all(src[ce[cp[j]:cp[j + 1]]] == j)
+    tn = p.tile_node.numpy()
+    assert tn[0] == 0 and tn[-1] == N and np.all(np.diff(tn) > 0)
+    for t in range(p.n_tiles):
+        assert rp[tn[t + 1]] - rp[tn[t]] <= G.TILE_EDGES
+    # ligand edges never touch receptor nodes and vice versa
+    lig_e = dst < p.n_lig
+    assert np.all(src[lig_e] < p.n_lig) and np.all(src[~lig_e] >= p.n_lig)
+    items = p.att_items.numpy()
+    covered = np.zeros(N, int)
+    seg = p.seg_off.numpy()
+    for b0, b1, o0, o1 in items:
+        covered[b0:b1] += 1
+        assert b1 - b0 <= G.ATT_BLOCK
+        s = np.searchsorted(seg, b0, side='right') - 1
+        partner = s + p.n_pairs if s < p.n_pairs else s - p.n_pairs
+        assert (o0, o1) == (seg[partner], seg[partner + 1])
+    assert np.all(covered == 1)
+
+
+def test_unsorted_edges_are_sorted_stably():
+    pairs = _pairs()
+    rng = np.random.default_rng(0)
+    shuffled = []
+    for lig, rec in pairs:
+        out = []
+        for p in (lig, rec):
+            perm = rng.permutation(len(p['dst']))
+            q = dict(p)
+            for k in ('src', 'dst', 'he'):
+                q[k] = p[k][perm]
+            out.append(q)
+        shuffled.append(tuple(out))
+    a, b = G.batch_pairs(pairs).pack(), G.batch_pairs(shuffled).pack()
+    np.testing.assert_array_equal(a.dst.numpy(), b.dst.numpy())
+    # same multiset of (src, dst, he) per destination
+    ka = np.lexsort((a.src.numpy(), a.dst.numpy()))
+    kb = np.lexsort((b.src.numpy(), b.dst.numpy()))
+    np.testing.assert_array_equal(a.src.numpy()[ka], b.src.numpy()[kb])
+    np.testing.assert_allclose(a.he.numpy()[ka], b.he.numpy()[kb])
+
+
+def test_in_degree_limit_is_reported():
+    lig, rec = synthetic.make_pairs([(50, 20)], 1, k=40)[0]
+    with pytest.raises(ValueError, match='in-degree'):
+        G.batch_pairs([(lig, rec)]).pack()
+
+
+def test_bad_inputs_rejected():
+    lig, rec = _pairs()[0]
+    bad = dict(lig)
+    bad['mu_r_norm'] = lig['mu_r_norm'].copy()
+    bad['mu_r_norm'][0, 0] = 0.0
+    with pytest.raises(ValueError, match='mu_r_norm'):
+        G.batch_pairs([(bad, rec)]).pack()
+    bad = dict(lig)
+    bad['src'] = lig['src'].copy()
+    bad['src'][0] = 10 ** 6
+    with pytest.raises(ValueError, match='out of range'):
+        G.batch_pairs([(bad, rec)])

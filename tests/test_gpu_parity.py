@@ -1,0 +1,116 @@
+"""GPU parity tests (-m gpu): the HIP path through the C ABI on a real MI355X against torch fp32
+restatements, the golden vectors captured from the imported reference, and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    from equidock_public_amd import _lib
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    _lib.unload_for_testing()
+    _lib.load_library()
+    assert not _lib.is_simulator(), "GPU tests must run the real gfx950 library"
+    return torch.device('cuda:0')
+
+
+def test_linear(dev):
+    from tests import parity_common as pc
+    pc.check_linear(dev)
+
+
+def test_atb(dev):
+    from tests import parity_common as pc
+    pc.check_atb(dev)
+
+
+def test_edge_message_fwd_bwd(dev):
+    from tests import parity_common as pc
+    pc.check_edge(dev)
+
+
+@pytest.mark.parametrize('d', [64, 69])
+def test_cross_attention(dev, d):
+    from tests import parity_common as pc
+    pc.check_attention(dev, d)
+    pc.check_attention(dev, d, sizes=((300, 257), (129, 64)))
+
+
+def test_kabsch(dev):
+    from tests import parity_common as pc
+    pc.check_kabsch(dev)
+
+
+def test_keypoints_and_apply(dev):
+    from tests import parity_common as pc
+    pc.check_keypoints_and_apply(dev)
+
+
+@pytest.mark.parametrize('name', ['A_b1_shared5', 'B_b3_dips8', 'C_b2_200', 'D_degraded3', 'E_svd_guard'])
+def test_model_vs_golden(dev, name):
+    from tests import parity_common as pc
+    pc.check_model_case(dev, name)
+
+
+def test_flat_grads(dev):
+    from tests import parity_common as pc
+    pc.check_flat_grads_equal_autograd(dev)
+
+
+def test_properties_small(dev):
+    from tests import parity_common as pc
+    pc.check_properties(dev)
+
+
+def test_properties_baseline_sizes(dev):
+    """Size-independent properties at BASELINE.json's full sizes (config B graphs, 8 layers)."""
+    from tests import parity_common as pc
+    pc.check_properties(dev, sizes=((200, 200), (200, 200), (200, 200), (200, 200)), layers=8)
+
+
+def test_model_vs_oracle_config_b(dev):
+    """Config B shapes (8 x 200/200, 8 layers): outputs and gradients vs the oracle on the host."""
+    from equidock_public_amd import graph as G, synthetic
+    from oracle import iegmn_port as port
+    from tests import parity_common as pc
+    args = port.default_args(iegmn_n_lays=8, skip_weight_h=0.75)
+    sd = port.init_state_dict(args, seed=3)
+    net = pc.build_model(args, sd, dev)
+    pairs = synthetic.make_pairs([(200, 200)] * 4, 33)
+    g = G.batch_pairs(pairs).to(dev)
+    outs = net(g, epoch=0)
+    port.scalar_loss(outs).backward()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = port.forward(leaves, args, port.raw_from_graph(g), faithful=True)
+    port.scalar_loss(ref).backward()
+    for a, b in zip(outs, ref):
+        for x, y in zip(a, b):
+            pc.close(x, y, tol=1e-4, what='config-B output')
+    for k, p in net.named_parameters():
+        pc.grad_close(p.grad, leaves[k].grad, what=f'config-B grad {k}')
+
+
+def test_large_complex_runs(dev):
+    """Stress shape (one 2000 + 2000 residue pair, 2 layers): finite outputs, valid rotation."""
+    from equidock_public_amd import graph as G, synthetic
+    from oracle import iegmn_port as port
+    from tests import parity_common as pc
+    args = port.default_args(iegmn_n_lays=2, skip_weight_h=0.5)
+    net = pc.build_model(args, port.init_state_dict(args, seed=4), dev)
+    g = G.batch_pairs(synthetic.make_pairs([(2000, 2000)], 44)).to(dev)
+    lig, Yl, Yr, T, b = net.forward_batched(g)
+    (lig.square().mean() + Yl.square().mean()).backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(lig).all() and torch.isfinite(T).all()
+    t = T[0].cpu()
+    np.testing.assert_allclose((t @ t.t()).numpy(), np.eye(3), atol=1e-5)
+    for p in net.parameters():
+        assert torch.isfinite(p.grad).all()
+
+
+def test_smoke_entry(dev):
+    import __graft_entry__ as ge
+    ge.smoke()

@@ -1,0 +1,70 @@
+"""CPU tests: the product's kernel sources compiled for x86 with the host simulator
+(tests/hostsim) and driven through the same C ABI + Python modules as on the GPU, compared with
+torch restatements / the golden vectors.  This debugs index arithmetic without a GPU; the real
+parity gate is tests/test_gpu_parity.py (-m gpu)."""
+import pytest
+import torch
+
+from equidock_public_amd import _lib
+from tests import parity_common as pc
+
+DEV = torch.device('cpu')
+
+
+@pytest.fixture(scope='module', autouse=True)
+def simulator():
+    from tests.hostsim import build as hs
+    lib = hs.build()
+    _lib.load_library_for_testing(lib)
+    assert _lib.is_simulator()
+    yield
+    _lib.unload_for_testing()
+
+
+def test_linear():
+    pc.check_linear(DEV)
+
+
+def test_atb():
+    pc.check_atb(DEV)
+
+
+def test_edge_message_fwd_bwd():
+    pc.check_edge(DEV)
+
+
+@pytest.mark.parametrize('d', [64, 69])
+def test_cross_attention(d):
+    pc.check_attention(DEV, d)
+
+
+def test_kabsch():
+    pc.check_kabsch(DEV)
+
+
+def test_keypoints_and_apply():
+    pc.check_keypoints_and_apply(DEV)
+
+
+@pytest.mark.parametrize('name', ['A_b1_shared5', 'D_degraded3', 'E_svd_guard'])
+def test_model_vs_golden(name):
+    pc.check_model_case(DEV, name)
+
+
+def test_flat_grads():
+    pc.check_flat_grads_equal_autograd(DEV)
+
+
+def test_properties():
+    pc.check_properties(DEV, sizes=((30, 41), (52, 27)), layers=2)
+
+
+def test_cpu_tensor_rejected_by_real_library_contract():
+    """The product refuses CPU tensors unless the explicitly loaded library is the simulator."""
+    t = torch.zeros(3)
+    _lib._is_sim = False
+    try:
+        with pytest.raises(_lib.EquidockHipError):
+            _lib.require_device(t, 'x')
+    finally:
+        _lib._is_sim = True
