@@ -394,10 +394,11 @@ def check_properties(dev, sizes=((60, 75), (90, 48)), layers=3):
         g1 = G.batch_pairs(pairs[1:2]).to(dev)
         lig1, Yl1, Yr1, T1, b1 = [t.cpu() for t in net.forward_batched(g1)]
         close(T1[0], T[1], what='batch-of-one T')
-        close(lig1, lig[sizes[0][0]:], what='batch-of-one lig')
+        close(lig1, lig[sizes[0][0]:sizes[0][0] + sizes[1][0]], what='batch-of-one lig')
         gp = G.batch_pairs(pairs[::-1]).to(dev)
         ligp = net.forward_batched(gp)[0].cpu()
-        close(ligp[:sizes[1][0]], lig[sizes[0][0]:], what='pair permutation')
+        nlast = sizes[-1][0]
+        close(ligp[:nlast], lig[lig.shape[0] - nlast:], what='pair permutation')
         # SE(3): rotate + translate the input ligand -> final complex unchanged (<= 1e-3)
         rng = np.random.default_rng(0)
         R = torch.from_numpy(synthetic._random_rotation(rng)).float()

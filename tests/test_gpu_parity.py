@@ -105,7 +105,7 @@ def test_large_complex_runs(dev):
     (lig.square().mean() + Yl.square().mean()).backward()
     torch.cuda.synchronize()
     assert torch.isfinite(lig).all() and torch.isfinite(T).all()
-    t = T[0].cpu()
+    t = T[0].detach().cpu()
     np.testing.assert_allclose((t @ t.t()).numpy(), np.eye(3), atol=1e-5)
     for p in net.parameters():
         assert torch.isfinite(p.grad).all()
