@@ -15,6 +15,10 @@
 //   forward / backward pass 1: block = queries (N axis), other = keys   (M axis)  -> out / dq
 //   backward pass 2          : block = keys    (N axis), other = queries(M axis)  -> dk, dv
 // One work list (EqdGraph.att_items) serves all three.
+// A WORKGROUP owns one work item; its 4 waves split the partner protein's tiles round-robin and
+// merge their partial results through LDS (flash-decoding style split along the streamed axis):
+// 4x the waves and 4x shorter dependent load->MFMA chains on DB5-sized proteins (200 residues =
+// 4 tiles), where a single wave per item left the chip latency-bound.
 #include "eqd_common.h"
 
 template <int DB>
@@ -24,8 +28,9 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_fwd(EqdGraph G, int d, const
     constexpr int KS = DB * 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const int item = blockIdx.x * EQD_WAVES + wave;
-    if (item >= G.n_att_items) return;
+    __shared__ float red[EQD_WAVES][DB * 2 * 4 * 64];
+    __shared__ float sm_m[EQD_WAVES][32], sm_l[EQD_WAVES][32];
+    const int item = blockIdx.x;
     const int b0 = G.att_items[item * 4 + 0], b1 = G.att_items[item * 4 + 1];
     const int o0 = G.att_items[item * 4 + 2], o1 = G.att_items[item * 4 + 3];
     int rowq[2] = {b0 + l15, b0 + 16 + l15};
@@ -45,7 +50,7 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_fwd(EqdGraph G, int d, const
         O[db][1] = f4zero();
     }
     float mrun[2] = {EQD_NEG_BIG, EQD_NEG_BIG}, lrun[2] = {0.f, 0.f};
-    for (int kt = o0; kt < o1; kt += 64) {
+    for (int kt = o0 + 64 * wave; kt < o1; kt += 64 * EQD_WAVES) {
         f32x4 S[4][2];
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
@@ -107,18 +112,54 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_fwd(EqdGraph G, int d, const
                 }
             }
     }
+    // ---- merge the 4 waves' partial softmax states -----------------------------------------------
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][((db * 2 + nb) * 4 + r) * 64 + lane] = O[db][nb][r];
+    if (g == 0) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            sm_m[wave][16 * nb + l15] = mrun[nb];
+            sm_l[wave][16 * nb + l15] = lrun[nb];
+        }
+    }
+    __syncthreads();
+    float sc[2][EQD_WAVES], inv[2], mtot[2], ltot[2];
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
-        if (!qv[nb]) continue;
-        const float inv = lrun[nb] > 0.f ? 1.f / lrun[nb] : 0.f;
+        float mm = EQD_NEG_BIG;
 #pragma unroll
-        for (int db = 0; db < DB; ++db)
+        for (int w = 0; w < EQD_WAVES; ++w) mm = fmaxf(mm, sm_m[w][16 * nb + l15]);
+        float ll = 0.f;
+#pragma unroll
+        for (int w = 0; w < EQD_WAVES; ++w) {
+            sc[nb][w] = expf(sm_m[w][16 * nb + l15] - mm);
+            ll += sm_l[w][16 * nb + l15] * sc[nb][w];
+        }
+        mtot[nb] = mm;
+        ltot[nb] = ll;
+        inv[nb] = ll > 0.f ? 1.f / ll : 0.f;
+    }
+    for (int db = wave; db < DB; db += EQD_WAVES)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            if (!qv[nb]) continue;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
+                float o = 0.f;
+#pragma unroll
+                for (int w = 0; w < EQD_WAVES; ++w) o += red[w][((db * 2 + nb) * 4 + r) * 64 + lane] * sc[nb][w];
                 const int f = 16 * db + 4 * g + r;
-                if (f < d) out[(size_t)rowq[nb] * d + f] = O[db][nb][r] * inv;
+                if (f < d) out[(size_t)rowq[nb] * d + f] = o * inv[nb];
             }
-        if (g == 0) lse[rowq[nb]] = lrun[nb] > 0.f ? mrun[nb] + logf(lrun[nb]) : 0.f;
+        }
+    if (wave == 0 && g == 0) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+            if (qv[nb]) lse[rowq[nb]] = ltot[nb] > 0.f ? mtot[nb] + logf(ltot[nb]) : 0.f;
     }
 }
 
@@ -133,8 +174,8 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd_q(EqdGraph G, int d, con
     constexpr int KS = DB * 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const int item = blockIdx.x * EQD_WAVES + wave;
-    if (item >= G.n_att_items) return;
+    __shared__ float red[EQD_WAVES][DB * 2 * 4 * 64];
+    const int item = blockIdx.x;
     const int b0 = G.att_items[item * 4 + 0], b1 = G.att_items[item * 4 + 1];
     const int o0 = G.att_items[item * 4 + 2], o1 = G.att_items[item * 4 + 3];
     int rowq[2] = {b0 + l15, b0 + 16 + l15};
@@ -154,7 +195,7 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd_q(EqdGraph G, int d, con
         }
         dl[nb] = group_sum(s);
         lq[nb] = qv[nb] ? lse[rowq[nb]] : 0.f;
-        if (g == 0 && qv[nb]) delta[rowq[nb]] = dl[nb];
+        if (wave == 0 && g == 0 && qv[nb]) delta[rowq[nb]] = dl[nb];
     }
     f32x4 dQ[DB][2];
 #pragma unroll
@@ -162,7 +203,7 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd_q(EqdGraph G, int d, con
         dQ[db][0] = f4zero();
         dQ[db][1] = f4zero();
     }
-    for (int kt = o0; kt < o1; kt += 32) {
+    for (int kt = o0 + 32 * wave; kt < o1; kt += 32 * EQD_WAVES) {
         f32x4 S[2][2], dP[2][2];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
@@ -209,16 +250,23 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd_q(EqdGraph G, int d, con
             }
     }
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-        if (!qv[nb]) continue;
+    for (int db = 0; db < DB; ++db)
 #pragma unroll
-        for (int db = 0; db < DB; ++db)
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][((db * 2 + nb) * 4 + r) * 64 + lane] = dQ[db][nb][r];
+    __syncthreads();
+    for (int db = wave; db < DB; db += EQD_WAVES)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            if (!qv[nb]) continue;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
+                const int o = ((db * 2 + nb) * 4 + r) * 64 + lane;
                 const int f = 16 * db + 4 * g + r;
-                if (f < d) dq[(size_t)rowq[nb] * d + f] = dQ[db][nb][r];
+                if (f < d) dq[(size_t)rowq[nb] * d + f] = red[0][o] + red[1][o] + red[2][o] + red[3][o];
             }
-    }
+        }
 }
 
 // backward pass 2: dk, dv for the block's keys (queries = the partner protein)
@@ -232,8 +280,8 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd_kv(EqdGraph G, int d, co
     constexpr int KS = DB * 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const int item = blockIdx.x * EQD_WAVES + wave;
-    if (item >= G.n_att_items) return;
+    __shared__ float red[EQD_WAVES][DB * 2 * 4 * 64];
+    const int item = blockIdx.x;
     const int b0 = G.att_items[item * 4 + 0], b1 = G.att_items[item * 4 + 1];
     const int o0 = G.att_items[item * 4 + 2], o1 = G.att_items[item * 4 + 3];
     int rowk[2] = {b0 + l15, b0 + 16 + l15};
@@ -255,7 +303,7 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd_kv(EqdGraph G, int d, co
         dK[db][0] = dK[db][1] = f4zero();
         dV[db][0] = dV[db][1] = f4zero();
     }
-    for (int qt = o0; qt < o1; qt += 32) {
+    for (int qt = o0 + 32 * wave; qt < o1; qt += 32 * EQD_WAVES) {
         f32x4 S[2][2], dP[2][2];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
@@ -311,16 +359,26 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd_kv(EqdGraph G, int d, co
             }
     }
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-        if (!kvd[nb]) continue;
+    for (int pass = 0; pass < 2; ++pass) {     // dK then dV through the same LDS buffer
+        if (pass) __syncthreads();
 #pragma unroll
         for (int db = 0; db < DB; ++db)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int f = 16 * db + 4 * g + r;
-                if (f < d) {
-                    dk[(size_t)rowk[nb] * d + f] = dK[db][nb][r];
-                    dv[(size_t)rowk[nb] * d + f] = dV[db][nb][r];
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    red[wave][((db * 2 + nb) * 4 + r) * 64 + lane] = pass ? dV[db][nb][r] : dK[db][nb][r];
+        __syncthreads();
+        float* __restrict__ dst = pass ? dv : dk;
+        for (int db = wave; db < DB; db += EQD_WAVES)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                if (!kvd[nb]) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = ((db * 2 + nb) * 4 + r) * 64 + lane;
+                    const int f = 16 * db + 4 * g + r;
+                    if (f < d) dst[(size_t)rowk[nb] * d + f] = red[0][o] + red[1][o] + red[2][o] + red[3][o];
                 }
             }
     }
@@ -337,7 +395,7 @@ extern "C" int eqd_cross_attention_fwd(const EqdGraph* g, int d, const float* q,
         return EQD_ERR_UNSUPPORTED;
     }
     if (g->n_att_items <= 0) return EQD_OK;
-    dim3 grid((g->n_att_items + EQD_WAVES - 1) / EQD_WAVES);
+    dim3 grid(g->n_att_items);
     if (d <= 64)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_fwd<4>), grid, dim3(EQD_BLOCK), 0, (hipStream_t)stream, *g, d, q, k, v,
                            out, lse);
@@ -360,7 +418,7 @@ extern "C" int eqd_cross_attention_bwd(const EqdGraph* g, int d, const float* q,
     }
     if (g->n_att_items <= 0) return EQD_OK;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((g->n_att_items + EQD_WAVES - 1) / EQD_WAVES);
+    dim3 grid(g->n_att_items);
     if (d <= 64) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_q<4>), grid, dim3(EQD_BLOCK), 0, st, *g, d, q, k, v, out, lse,
                            d_out, dq, delta);

@@ -94,6 +94,18 @@ struct EqdArena {
     }
 };
 
+// deterministic column reduction of per-block partials: out[i] += sum_p partial[p * pstride + i]
+#define EQD_RED_MAXSEG 8
+struct EqdRedSeg {
+    const float* partial;
+    int nparts, pstride, n;
+    float* out;
+};
+struct EqdRedArg {
+    EqdRedSeg s[EQD_RED_MAXSEG];
+};
+int eqd_launch_reduce_segments(const EqdRedSeg* segs, int nseg, hipStream_t st);
+
 // internal launchers (defined across the .hip files)
 int eqd_launch_vec_reduce(const float* partial, int nparts, int pstride, int n, float* out, hipStream_t st);
 int eqd_launch_embed_fwd(const EqdGraph* g, const float* emb, int d_emb, int use_mu, float* h0, int ld, hipStream_t st);

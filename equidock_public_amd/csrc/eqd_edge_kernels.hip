@@ -45,16 +45,45 @@ struct alignas(16) EdgeSmem {
 };
 
 __device__ __forceinline__ void edge_stage_weights(EdgeSmem& sm, const EqdEdgeParams& P) {
+    // all global loads of a thread are issued before the first LDS store (constant trip counts, fully
+    // unrolled): one L2 round trip per batch instead of one per element
     const int t = threadIdx.x;
     const int koff = 2 * P.d_in;
-    for (int i = t; i < 64 * WS1; i += EQD_BLOCK) {
-        const int r = i / WS1, c = i - r * WS1;
-        sm.w1[i] = (c < 42) ? P.W1[(size_t)r * P.ldw1 + koff + c] : 0.f;
+    {
+        float v[11];
+#pragma unroll
+        for (int j = 0; j < 11; ++j) {       // 64 x 42 = 2688 elements, 10.5 per thread
+            const int i = t + j * EQD_BLOCK;
+            const int r = i / 42, c = i - r * 42;
+            v[j] = (i < 64 * 42) ? P.W1[(size_t)r * P.ldw1 + koff + c] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 11; ++j) {
+            const int i = t + j * EQD_BLOCK;
+            const int r = i / 42, c = i - r * 42;
+            if (i < 64 * 42) sm.w1[r * WS1 + c] = v[j];
+        }
+        if (t < 64) {
+            sm.w1[t * WS1 + 42] = 0.f;
+            sm.w1[t * WS1 + 43] = 0.f;
+            sm.w1[t * WS1 + 44] = 0.f;
+        }
     }
-    for (int i = t; i < 64 * 64; i += EQD_BLOCK) {
-        const int r = i >> 6, c = i & 63;
-        sm.w2[r * WS2 + c] = P.W2[i];
-        sm.wc1[r * WS2 + c] = P.Wc1[i];
+    {
+        float4 a[4], b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {        // 64 x 64 floats = 1024 float4, 4 per thread
+            const int i = t + j * EQD_BLOCK;
+            a[j] = ((const float4*)P.W2)[i];
+            b[j] = ((const float4*)P.Wc1)[i];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = t + j * EQD_BLOCK;
+            const int r = i >> 4, c = (i & 15) * 4;
+            *(float4*)&sm.w2[r * WS2 + c] = a[j];
+            *(float4*)&sm.wc1[r * WS2 + c] = b[j];
+        }
     }
     if (t < 64) {
         sm.vec[VEC_LNG + t] = P.ln_g[t];
@@ -694,10 +723,9 @@ extern "C" int eqd_edge_message_bwd(const EqdGraph* g, const EqdEdgeParams* p, c
         int rc = eqd_check_launch("k_edge_bwd");
         if (rc) return rc;
         const int nw = blocks * EQD_WAVES;
-        if ((rc = eqd_launch_vec_reduce(W.vecp, nw, 256, 64, grads->dln_g, st))) return rc;
-        if ((rc = eqd_launch_vec_reduce(W.vecp + 64, nw, 256, 64, grads->dln_b, st))) return rc;
-        if ((rc = eqd_launch_vec_reduce(W.vecp + 128, nw, 256, 64, grads->dwc2, st))) return rc;
-        if ((rc = eqd_launch_vec_reduce(W.vecp + 192, nw, 256, 1, grads->dbc2, st))) return rc;
+        EqdRedSeg segs[4] = {{W.vecp, nw, 256, 64, grads->dln_g}, {W.vecp + 64, nw, 256, 64, grads->dln_b},
+                             {W.vecp + 128, nw, 256, 64, grads->dwc2}, {W.vecp + 192, nw, 256, 1, grads->dbc2}};
+        if ((rc = eqd_launch_reduce_segments(segs, 4, st))) return rc;
     }
     EqdAtbJob jobs[4];
     edge_atb_jobs(g, p, grads, W, jobs);

@@ -34,126 +34,112 @@ extern "C" int eqd_tile_edges(void) { return EQD_TILE_EDGES; }
 
 // ------------------------------------------------------------------------------------------
 // k_linear: Y = alpha * f(sum_s (X_s * lrelu'(mask_s)) W_s^T + bias) + beta * R
-// wave tile: 32 rows (items on the MFMA N axis) x up to 80 outputs (M axis, MB = 5 blocks)
+// wave tile: 16 rows (items on the MFMA N axis) x up to 80 outputs (M axis, MB = 5 blocks)
 // ------------------------------------------------------------------------------------------
 #define LIN_MAXJOBS 8
 struct LinJobsArg {
     EqdLinJob j[LIN_MAXJOBS];
 };
 
+#define LIN_U 8   /* k-steps (of 4) whose loads are issued together: hides the L2 round trip */
 __global__ __launch_bounds__(EQD_BLOCK) void k_linear(LinJobsArg jobs) {
     const EqdLinJob& J = jobs.j[blockIdx.y];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const int row0 = ((int)blockIdx.x * EQD_WAVES + wave) * 32;
+    const int row0 = ((int)blockIdx.x * EQD_WAVES + wave) * 16;
     if (row0 >= J.rows) return;
     const int M = J.M;
     const int mbn = (M + 15) >> 4;
-    f32x4 acc[5][2];
+    f32x4 acc[5];
 #pragma unroll
-    for (int mb = 0; mb < 5; ++mb) {
-        acc[mb][0] = f4zero();
-        acc[mb][1] = f4zero();
-    }
-    int rowi[2] = {row0 + l15, row0 + 16 + l15};
-    bool rv[2] = {rowi[0] < J.rows, rowi[1] < J.rows};
+    for (int mb = 0; mb < 5; ++mb) acc[mb] = f4zero();
+    const int rowi = row0 + l15;
+    const bool rv = rowi < J.rows;
 
     for (int s = 0; s < J.nsrc; ++s) {
         const EqdLinSrc& S = J.s[s];
-        const float* __restrict__ X = S.X;
+        const float* __restrict__ X = S.X + (size_t)(rv ? rowi : 0) * S.ldx;
+        const float* __restrict__ mk = S.mask ? S.mask + (size_t)(rv ? rowi : 0) * S.ldx : nullptr;
         const float* __restrict__ W = S.W;
-        const float* __restrict__ mk = S.mask;
         const int K = S.K;
-#pragma unroll 2
-        for (int k0 = 0; k0 < K; k0 += 4) {
-            const int k = k0 + g;
-            const bool kv = k < K;
-            float b[2];
+        for (int k0 = 0; k0 < K; k0 += 4 * LIN_U) {
+            float a[LIN_U][5], b[LIN_U];
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
+            for (int u = 0; u < LIN_U; ++u) {
+                const int k = k0 + 4 * u + g;
+                const bool kv = k < K;
                 float v = 0.f;
-                if (rv[nb] && kv) {
-                    const size_t o = (size_t)rowi[nb] * S.ldx + k;
-                    v = X[o];
-                    if (mk) v *= lrelu_grad(mk[o], J.slope);
+                if (rv && kv) {
+                    v = X[k];
+                    if (mk) v *= lrelu_grad(mk[k], J.slope);
                 }
-                b[nb] = v;
+                b[u] = v;
+#pragma unroll
+                for (int mb = 0; mb < 5; ++mb) {
+                    const int m = 16 * mb + l15;
+                    a[u][mb] = (mb < mbn && m < M && kv) ? W[(size_t)m * S.w_rs + (size_t)k * S.w_cs] : 0.f;
+                }
             }
 #pragma unroll
-            for (int mb = 0; mb < 5; ++mb) {
-                if (mb < mbn) {
-                    const int m = 16 * mb + l15;
-                    const float a = (m < M && kv) ? W[(size_t)m * S.w_rs + (size_t)k * S.w_cs] : 0.f;
-                    acc[mb][0] = mfma4(a, b[0], acc[mb][0]);
-                    acc[mb][1] = mfma4(a, b[1], acc[mb][1]);
-                }
-            }
+            for (int u = 0; u < LIN_U; ++u)
+#pragma unroll
+                for (int mb = 0; mb < 5; ++mb)
+                    if (mb < mbn) acc[mb] = mfma4(a[u][mb], b[u], acc[mb]);
         }
     }
 
-    // ---- epilogue in F-layout: feature f = 16 mb + 4 g + r, row = rowi[nb] --------------------
+    // ---- epilogue in F-layout: feature f = 16 mb + 4 g + r, row = rowi ------------------------
 #pragma unroll
-    for (int mb = 0; mb < 5; ++mb) {
+    for (int mb = 0; mb < 5; ++mb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int f = 16 * mb + 4 * g + r;
-            const float bi = (J.bias && f < M) ? J.bias[f] : 0.f;
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                float v = acc[mb][nb][r] + bi;
-                if (J.act) v = lrelu(v, J.slope);
-                acc[mb][nb][r] = (f < M) ? v : 0.f;
-            }
+            float v = acc[mb][r] + ((J.bias && f < M) ? J.bias[f] : 0.f);
+            if (J.act) v = lrelu(v, J.slope);
+            acc[mb][r] = (f < M) ? v : 0.f;
         }
-    }
     if (J.ln_g) {
         const float invM = 1.f / (float)M;
+        float s = 0.f;
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-            float s = 0.f;
+        for (int mb = 0; mb < 5; ++mb)
 #pragma unroll
-            for (int mb = 0; mb < 5; ++mb)
+            for (int r = 0; r < 4; ++r) s += acc[mb][r];
+        const float mean = group_sum(s) * invM;
+        float q = 0.f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s += acc[mb][nb][r];
-            const float mean = group_sum(s) * invM;
-            float q = 0.f;
+        for (int mb = 0; mb < 5; ++mb)
 #pragma unroll
-            for (int mb = 0; mb < 5; ++mb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int f = 16 * mb + 4 * g + r;
-                    const float dlt = (f < M) ? acc[mb][nb][r] - mean : 0.f;
-                    q += dlt * dlt;
-                }
-            const float rstd = 1.f / sqrtf(group_sum(q) * invM + J.ln_eps);
-#pragma unroll
-            for (int mb = 0; mb < 5; ++mb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int f = 16 * mb + 4 * g + r;
-                    if (f < M) {
-                        const float v = acc[mb][nb][r];
-                        if (J.pre_ln && rv[nb]) J.pre_ln[(size_t)rowi[nb] * J.ld_pre + f] = v;
-                        acc[mb][nb][r] = (v - mean) * rstd * J.ln_g[f] + J.ln_b[f];
-                    }
-                }
-        }
-    }
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-        if (!rv[nb]) continue;
+            for (int r = 0; r < 4; ++r) {
+                const int f = 16 * mb + 4 * g + r;
+                const float dlt = (f < M) ? acc[mb][r] - mean : 0.f;
+                q += dlt * dlt;
+            }
+        const float rstd = 1.f / sqrtf(group_sum(q) * invM + J.ln_eps);
 #pragma unroll
         for (int mb = 0; mb < 5; ++mb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int f = 16 * mb + 4 * g + r;
                 if (f < M) {
-                    float v = J.alpha * acc[mb][nb][r];
-                    if (J.R) v += J.beta * J.R[(size_t)rowi[nb] * J.ldr + f];
-                    J.Y[(size_t)rowi[nb] * J.ldy + f] = v;
+                    const float v = acc[mb][r];
+                    if (J.pre_ln && rv) J.pre_ln[(size_t)rowi * J.ld_pre + f] = v;
+                    acc[mb][r] = (v - mean) * rstd * J.ln_g[f] + J.ln_b[f];
                 }
             }
     }
+    if (!rv) return;
+#pragma unroll
+    for (int mb = 0; mb < 5; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = 16 * mb + 4 * g + r;
+            if (f < M) {
+                float v = J.alpha * acc[mb][r];
+                if (J.R) v += J.beta * J.R[(size_t)rowi * J.ldr + f];
+                J.Y[(size_t)rowi * J.ldy + f] = v;
+            }
+        }
 }
 
 extern "C" int eqd_linear(const EqdLinJob* jobs, int njobs, void* stream) {
@@ -182,7 +168,7 @@ extern "C" int eqd_linear(const EqdLinJob* jobs, int njobs, void* stream) {
             if (J.rows > maxrows) maxrows = J.rows;
         }
         if (maxrows == 0) continue;
-        dim3 grid((maxrows + 127) / 128, n);
+        dim3 grid((maxrows + 63) / 64, n);
         hipLaunchKernelGGL(k_linear, grid, dim3(EQD_BLOCK), 0, st, arg);
         int rc = eqd_check_launch("k_linear");
         if (rc) return rc;
@@ -198,6 +184,7 @@ extern "C" int eqd_linear(const EqdLinJob* jobs, int njobs, void* stream) {
 #define ATB_MAXUNITS 16
 #define ATB_TILE 5120  /* 80 x 64 */
 #define ATB_PSTRIDE 5200
+#define ATB_U 4
 struct AtbUnit {
     EqdAtbJob job;
     int n0, nparts, rpw;
@@ -229,34 +216,38 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_atb(AtbUnitsArg U, float* __restr
     const float* __restrict__ X = J.X;
     const float* __restrict__ Y = J.Y;
     const float* __restrict__ xm = J.xmask;
-#pragma unroll 2
-    for (int r = r0; r < r1; r += 4) {
-        const int row = r + g;
-        const bool rv = row < r1;
-        float a[5], b[4];
+    for (int rb = r0; rb < r1; rb += 4 * ATB_U) {
+        float a[ATB_U][5], b[ATB_U][4];
 #pragma unroll
-        for (int mb = 0; mb < 5; ++mb) {
-            const int m = 16 * mb + l15;
-            float v = 0.f;
-            if (rv && m < M) {
-                const size_t o = (size_t)row * J.ldx + m;
-                v = X[o];
-                if (xm) v *= lrelu_grad(xm[o], J.slope);
+        for (int uu = 0; uu < ATB_U; ++uu) {
+            const int row = rb + 4 * uu + g;
+            const bool rv = row < r1;
+#pragma unroll
+            for (int mb = 0; mb < 5; ++mb) {
+                const int m = 16 * mb + l15;
+                float v = 0.f;
+                if (rv && mb < mbn && m < M) {
+                    const size_t o = (size_t)row * J.ldx + m;
+                    v = X[o];
+                    if (xm) v *= lrelu_grad(xm[o], J.slope);
+                }
+                a[uu][mb] = v;
+                bsum[mb] += v;
             }
-            a[mb] = v;
-            bsum[mb] += v;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                const int n = u.n0 + 16 * nb + l15;
+                b[uu][nb] = (rv && n < N) ? Y[(size_t)row * J.ldy + n] : 0.f;
+            }
         }
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-            const int n = u.n0 + 16 * nb + l15;
-            b[nb] = (rv && n < N) ? Y[(size_t)row * J.ldy + n] : 0.f;
-        }
+        for (int uu = 0; uu < ATB_U; ++uu)
 #pragma unroll
-        for (int mb = 0; mb < 5; ++mb)
-            if (mb < mbn) {
+            for (int mb = 0; mb < 5; ++mb)
+                if (mb < mbn) {
 #pragma unroll
-                for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = mfma4(a[mb], b[nb], acc[mb][nb]);
-            }
+                    for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = mfma4(a[uu][mb], b[uu][nb], acc[mb][nb]);
+                }
     }
     float* P = partial + u.poff + (long long)c * ATB_PSTRIDE;
 #pragma unroll
@@ -270,29 +261,43 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_atb(AtbUnitsArg U, float* __restr
     }
 }
 
-__global__ __launch_bounds__(EQD_BLOCK) void k_atb_reduce(AtbUnitsArg U, const float* __restrict__ partial) {
+__global__ __launch_bounds__(1024) void k_atb_reduce(AtbUnitsArg U, const float* __restrict__ partial) {
+    __shared__ float red[16][64];
     const AtbUnit& u = U.u[blockIdx.y];
     const EqdAtbJob& J = u.job;
-    const int e = blockIdx.x * EQD_BLOCK + threadIdx.x;
-    if (e >= ATB_PSTRIDE) return;
-    int m, n = 0;
-    bool is_bias = e >= ATB_TILE;
-    if (is_bias) {
-        m = e - ATB_TILE;
-        if (!(J.bias_out && u.n0 == 0 && m < J.M)) return;
-    } else {
-        m = e >> 6;
-        n = u.n0 + (e & 63);
-        if (m >= J.M || n >= J.N) return;
+    const int c = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + c;
+    int m = 0, n = 0;
+    bool ok = e < ATB_PSTRIDE;
+    const bool is_bias = e >= ATB_TILE;
+    if (ok) {
+        if (is_bias) {
+            m = e - ATB_TILE;
+            ok = J.bias_out && u.n0 == 0 && m < J.M;
+        } else {
+            m = e >> 6;
+            n = u.n0 + (e & 63);
+            ok = m < J.M && n < J.N;
+        }
     }
-    const float* P = partial + u.poff + e;
-    float s = 0.f;
-    for (int p = 0; p < u.nparts; ++p) s += P[(long long)p * ATB_PSTRIDE];
-    if (J.scale != 0.f) s *= J.scale;
-    if (is_bias)
-        J.bias_out[m] += s;
-    else
-        J.out[(size_t)m * J.o_rs + (size_t)n * J.o_cs] += s;
+    float acc = 0.f;
+    if (ok) {
+        const float* P = partial + u.poff + e;
+#pragma unroll 4
+        for (int p = pl; p < u.nparts; p += 16) acc += P[(long long)p * ATB_PSTRIDE];
+    }
+    red[pl][c] = acc;
+    __syncthreads();
+    if (pl == 0 && ok) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s += red[j][c];
+        if (J.scale != 0.f) s *= J.scale;
+        if (is_bias)
+            J.bias_out[m] += s;
+        else
+            J.out[(size_t)m * J.o_rs + (size_t)n * J.o_cs] += s;
+    }
 }
 
 static int atb_plan(const EqdAtbJob* jobs, int njobs, AtbUnit* units, int max_units, int* nunits_out,
@@ -365,8 +370,8 @@ extern "C" int eqd_atb(const EqdAtbJob* jobs, int njobs, void* partial, size_t p
             rc = eqd_check_launch("k_atb");
             if (rc) return rc;
         }
-        hipLaunchKernelGGL(k_atb_reduce, dim3((ATB_PSTRIDE + EQD_BLOCK - 1) / EQD_BLOCK, n), dim3(EQD_BLOCK), 0, st,
-                           arg, (const float*)partial);
+        hipLaunchKernelGGL(k_atb_reduce, dim3((ATB_PSTRIDE + 63) / 64, n), dim3(1024), 0, st, arg,
+                           (const float*)partial);
         rc = eqd_check_launch("k_atb_reduce");
         if (rc) return rc;
     }
@@ -376,17 +381,45 @@ extern "C" int eqd_atb(const EqdAtbJob* jobs, int njobs, void* partial, size_t p
 // ------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------
-__global__ void k_vec_reduce(const float* __restrict__ partial, int nparts, int pstride, int n, float* out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * pstride + i];
-    out[i] += s;
+__global__ __launch_bounds__(1024) void k_reduce_segments(EqdRedArg A) {
+    __shared__ float red[16][64];
+    const EqdRedSeg& S = A.s[blockIdx.y];
+    const int c = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + c;
+    float acc = 0.f;
+    if (i < S.n) {
+#pragma unroll 4
+        for (int p = pl; p < S.nparts; p += 16) acc += S.partial[(size_t)p * S.pstride + i];
+    }
+    red[pl][c] = acc;
+    __syncthreads();
+    if (pl == 0 && i < S.n) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s += red[j][c];
+        S.out[i] += s;
+    }
+}
+int eqd_launch_reduce_segments(const EqdRedSeg* segs, int nseg, hipStream_t st) {
+    for (int base = 0; base < nseg; base += EQD_RED_MAXSEG) {
+        EqdRedArg arg;
+        memset(&arg, 0, sizeof(arg));
+        const int n = nseg - base < EQD_RED_MAXSEG ? nseg - base : EQD_RED_MAXSEG;
+        int maxn = 0;
+        for (int i = 0; i < n; ++i) {
+            arg.s[i] = segs[base + i];
+            if (arg.s[i].n > maxn) maxn = arg.s[i].n;
+        }
+        if (maxn <= 0) continue;
+        hipLaunchKernelGGL(k_reduce_segments, dim3((maxn + 63) / 64, n), dim3(1024), 0, st, arg);
+        int rc = eqd_check_launch("k_reduce_segments");
+        if (rc) return rc;
+    }
+    return EQD_OK;
 }
 int eqd_launch_vec_reduce(const float* partial, int nparts, int pstride, int n, float* out, hipStream_t st) {
-    if (n <= 0) return EQD_OK;
-    hipLaunchKernelGGL(k_vec_reduce, dim3((n + 255) / 256), dim3(256), 0, st, partial, nparts, pstride, n, out);
-    return eqd_check_launch("k_vec_reduce");
+    EqdRedSeg s = {partial, nparts, pstride, n, out};
+    return eqd_launch_reduce_segments(&s, 1, st);
 }
 
 __global__ void k_fill(float* p, float v, size_t n) {
@@ -546,7 +579,6 @@ int eqd_launch_ln_act_bwd(const float* y_act, const float* d_out, const float* g
                        dz, partial);
     int rc = eqd_check_launch("k_ln_act_bwd");
     if (rc) return rc;
-    rc = eqd_launch_vec_reduce(partial, nb, 256, d, dgamma, st);
-    if (rc) return rc;
-    return eqd_launch_vec_reduce(partial + 128, nb, 256, d, dbeta, st);
+    EqdRedSeg segs[2] = {{partial, nb, 256, d, dgamma}, {partial + 128, nb, 256, d, dbeta}};
+    return eqd_launch_reduce_segments(segs, 2, st);
 }
