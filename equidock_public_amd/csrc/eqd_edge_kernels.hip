@@ -194,10 +194,21 @@ __device__ __forceinline__ void edge_tile_forward(const EqdGraph& G, const EqdEd
     for (int i = lane; i < 32 * FS; i += 64) tile[i] = 0.f;
     wave_lds_fence();
     if (P.use_he) {
+        // the tile's he rows are contiguous in HBM (edges are destination-sorted): 32 x 27 floats,
+        // 13.5 per lane, all loads issued before the first LDS store
         const float* __restrict__ he = G.he + (size_t)S.e0 * 27;
-        for (int i = lane; i < S.ne * 27; i += 64) {
+        const int nhe = S.ne * 27;
+        float hv[14];
+#pragma unroll
+        for (int j = 0; j < 14; ++j) {
+            const int i = lane + 64 * j;
+            hv[j] = i < nhe ? he[i] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 14; ++j) {
+            const int i = lane + 64 * j;
             const int e = i / 27, c = i - e * 27;
-            tile[e * FS + c] = he[i];
+            if (i < nhe) tile[e * FS + c] = hv[j];
         }
     }
 #pragma unroll
@@ -350,8 +361,11 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_edge_fwd(EqdGraph G, EqdEdgeParam
                 for (int c = 0; c < 3; ++c) tile[(16 * nb + l15) * TS + 64 + c] = S.xrel[nb][c] * S.coef[nb];
         }
         wave_lds_fence();
-        for (int n = S.n0; n < S.n1; ++n) {
-            const int a = G.rowptr[n] - S.e0, b = G.rowptr[n + 1] - S.e0;
+        const int nn = S.n1 - S.n0;   // <= 32 nodes per tile: one rowptr entry per lane, broadcast by shuffle
+        const int rp = (lane <= nn) ? G.rowptr[S.n0 + lane] - S.e0 : 0;
+        for (int i = 0; i < nn; ++i) {
+            const int n = S.n0 + i;
+            const int a = __shfl(rp, i), b = __shfl(rp, i + 1);
             float s = 0.f, sx = 0.f;
             for (int e = a; e < b; ++e) {
                 s += tile[e * TS + lane];
@@ -578,8 +592,11 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_edge_bwd(EqdGraph G, EqdEdgeParam
             }
         }
         wave_lds_fence();
-        for (int n = S.n0; n < S.n1; ++n) {
-            const int a = G.rowptr[n] - S.e0, b = G.rowptr[n + 1] - S.e0;
+        const int nn = S.n1 - S.n0;
+        const int rp = (lane <= nn) ? G.rowptr[S.n0 + lane] - S.e0 : 0;
+        for (int i = 0; i < nn; ++i) {
+            const int n = S.n0 + i;
+            const int a = __shfl(rp, i), b = __shfl(rp, i + 1);
             float s = 0.f, sx = 0.f;
             for (int e = a; e < b; ++e) {
                 s += tile[e * TS + lane];

@@ -317,7 +317,7 @@ __device__ __forceinline__ void svd3(const double A[3][3], double U[3][3], doubl
                     be += Bm[i][q] * Bm[i][q];
                     ga += Bm[i][p] * Bm[i][q];
                 }
-                if (fabs(ga) <= 1e-18 * sqrt(al * be) || ga == 0.0) continue;
+                if (fabs(ga) <= 2e-16 * sqrt(al * be) || ga == 0.0) continue;   // converged to fp64 rounding
                 off += fabs(ga);
                 const double zeta = (be - al) / (2.0 * ga);
                 const double tt = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));

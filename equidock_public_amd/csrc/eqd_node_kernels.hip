@@ -34,20 +34,24 @@ extern "C" int eqd_tile_edges(void) { return EQD_TILE_EDGES; }
 
 // ------------------------------------------------------------------------------------------
 // k_linear: Y = alpha * f(sum_s (X_s * lrelu'(mask_s)) W_s^T + bias) + beta * R
-// wave tile: 16 rows (items on the MFMA N axis) x up to 80 outputs (M axis, MB = 5 blocks)
+// workgroup tile: 16 rows (items on the MFMA N axis) x up to 80 outputs (M axis, MB = 5 blocks)
 // ------------------------------------------------------------------------------------------
 #define LIN_MAXJOBS 8
 struct LinJobsArg {
     EqdLinJob j[LIN_MAXJOBS];
 };
 
-#define LIN_U 8   /* k-steps (of 4) whose loads are issued together: hides the L2 round trip */
+#define LIN_U 4   /* k-steps (of 4) per chunk: their loads are issued together (one L2 round trip) */
+// A workgroup owns 16 rows; its 4 waves take the 16-wide K chunks of all sources round-robin and
+// sum their partial tiles through LDS (these GEMMs are tiny -- 3200 x 64..384 x 64 at config B -- so
+// the only thing that matters is the length of the dependent load->MFMA chain and the wave count).
 __global__ __launch_bounds__(EQD_BLOCK) void k_linear(LinJobsArg jobs) {
+    __shared__ float red[EQD_WAVES][5 * 4 * 64];
     const EqdLinJob& J = jobs.j[blockIdx.y];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const int row0 = ((int)blockIdx.x * EQD_WAVES + wave) * 16;
-    if (row0 >= J.rows) return;
+    const int row0 = (int)blockIdx.x * 16;
+    if (row0 >= J.rows) return;      // uniform for the whole workgroup
     const int M = J.M;
     const int mbn = (M + 15) >> 4;
     f32x4 acc[5];
@@ -56,13 +60,15 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_linear(LinJobsArg jobs) {
     const int rowi = row0 + l15;
     const bool rv = rowi < J.rows;
 
+    int chunk = 0;
     for (int s = 0; s < J.nsrc; ++s) {
         const EqdLinSrc& S = J.s[s];
         const float* __restrict__ X = S.X + (size_t)(rv ? rowi : 0) * S.ldx;
         const float* __restrict__ mk = S.mask ? S.mask + (size_t)(rv ? rowi : 0) * S.ldx : nullptr;
         const float* __restrict__ W = S.W;
         const int K = S.K;
-        for (int k0 = 0; k0 < K; k0 += 4 * LIN_U) {
+        for (int k0 = 0; k0 < K; k0 += 4 * LIN_U, ++chunk) {
+            if ((chunk & (EQD_WAVES - 1)) != wave) continue;
             float a[LIN_U][5], b[LIN_U];
 #pragma unroll
             for (int u = 0; u < LIN_U; ++u) {
@@ -87,6 +93,19 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_linear(LinJobsArg jobs) {
                     if (mb < mbn) acc[mb] = mfma4(a[u][mb], b[u], acc[mb]);
         }
     }
+#pragma unroll
+    for (int mb = 0; mb < 5; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][(mb * 4 + r) * 64 + lane] = acc[mb][r];
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int mb = 0; mb < 5; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = (mb * 4 + r) * 64 + lane;
+            acc[mb][r] = red[0][o] + red[1][o] + red[2][o] + red[3][o];
+        }
 
     // ---- epilogue in F-layout: feature f = 16 mb + 4 g + r, row = rowi ------------------------
 #pragma unroll
@@ -168,7 +187,7 @@ extern "C" int eqd_linear(const EqdLinJob* jobs, int njobs, void* stream) {
             if (J.rows > maxrows) maxrows = J.rows;
         }
         if (maxrows == 0) continue;
-        dim3 grid((maxrows + 63) / 64, n);
+        dim3 grid((maxrows + 15) / 16, n);
         hipLaunchKernelGGL(k_linear, grid, dim3(EQD_BLOCK), 0, st, arg);
         int rc = eqd_check_launch("k_linear");
         if (rc) return rc;
@@ -310,9 +329,9 @@ static int atb_plan(const EqdAtbJob* jobs, int njobs, AtbUnit* units, int max_un
             eqd_set_error("eqd_atb: job %d has M=%d N=%d rows=%d (need M in 1..80)", i, J.M, J.N, J.rows);
             return EQD_ERR_SHAPE;
         }
-        int target = J.rows / 64;
+        int target = J.rows / 32;
         if (target < 1) target = 1;
-        if (target > 256) target = 256;
+        if (target > 512) target = 512;
         int rpw = (J.rows + target - 1) / target;
         rpw = (rpw + 3) / 4 * 4;
         if (rpw < 4) rpw = 4;
@@ -518,7 +537,7 @@ int eqd_launch_csc_gather(const EqdGraph* g, const float* dz, const float* dxrel
 
 // Backward of LeakyReLU -> LayerNorm (node_mlp.2/.3): y_act = LeakyReLU(z) is saved by the forward.
 // One wave per row group; lane owns features lane and lane+64 (d <= 128).
-#define LNB_ROWS_PER_BLOCK 64
+#define LNB_ROWS_PER_BLOCK 16
 __global__ __launch_bounds__(EQD_BLOCK) void k_ln_act_bwd(const float* __restrict__ y_act,
                                                           const float* __restrict__ d_out,
                                                           const float* __restrict__ gamma, int rows, int d, int ld,
