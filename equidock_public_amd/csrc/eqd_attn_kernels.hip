@@ -8,41 +8,140 @@
 // to exactly 0 in fp32 unless every in-pair logit is < -900, so the per-pair softmax computed here
 // is bit-identical in practice (0.0 difference on the golden vectors).
 //
-// Flash-style: a wave owns 32 nodes of one protein ("block") and streams over the partner
-// protein ("other") in tiles, with an online softmax; score tiles and the P.V / dS.K products
-// chain through registers in the transposed MFMA formulation (eqd_common.h), so neither the
-// (N_l x N_r) scores nor any transposed copy ever exists in memory.
-//   forward / backward pass 1: block = queries (N axis), other = keys   (M axis)  -> out / dq
-//   backward pass 2          : block = keys    (N axis), other = queries(M axis)  -> dk, dv
+// Flash-style: a WORKGROUP owns 32 nodes of one protein ("block"); its 4 waves split the partner
+// protein ("other") into 32-row tiles round-robin, each wave running an online softmax over its
+// tiles, and the partial states are merged through LDS (flash-decoding style).  Score tiles and
+// the P.V / dS.K products chain through registers in the transposed MFMA formulation
+// (eqd_common.h), so neither the (N_l x N_r) scores nor any transposed copy ever exists in memory.
+//   forward / backward pass 1: block = queries (N axis), other = keys    (M axis)  -> out / dq
+//   backward pass 2          : block = keys    (N axis), other = queries (M axis)  -> dk, dv
 // One work list (EqdGraph.att_items) serves all three.
-// A WORKGROUP owns one work item; its 4 waves split the partner protein's tiles round-robin and
-// merge their partial results through LDS (flash-decoding style split along the streamed axis):
-// 4x the waves and 4x shorter dependent load->MFMA chains on DB5-sized proteins (200 residues =
-// 4 tiles), where a single wave per item left the chip latency-bound.
+//
+// Memory: every tile is a CONTIGUOUS [32][d] slab of a row-major matrix, so a wave fetches it with
+// fully coalesced loads (float4 when d == 64) that are all in flight at once, parks them in
+// registers while it multiplies the previous tile, then writes them to its private LDS tile
+// (row stride 16*DB + 4 floats); MFMA operands are read from LDS.  One HBM/L2 round trip per tile.
 #include "eqd_common.h"
 
 template <int DB>
+struct AttnCfg {
+    enum { DS = 16 * DB + 4, KS = 4 * DB, NL = 8 * DB, TILE = 32 * (16 * DB + 4), RED = DB * 2 * 4 * 64 };
+};
+
+template <int DB, bool FAST>
+struct TileRegs {
+    float v[FAST ? 1 : 8 * DB];
+    float4 q[FAST ? 8 : 1];
+};
+
+// rows r0 .. r0+31 of M (row stride d), clipped at r1 -> registers (zeros beyond)
+template <int DB, bool FAST>
+__device__ __forceinline__ void tile_load(TileRegs<DB, FAST>& R, const float* __restrict__ M, int d, int r0, int r1,
+                                          int lane) {
+    int nrows = r1 - r0;
+    nrows = nrows < 0 ? 0 : (nrows > 32 ? 32 : nrows);
+    const int nvalid = nrows * d;
+    const float* __restrict__ base = M + (size_t)r0 * d;
+    if (FAST) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i4 = lane + 64 * j;
+            R.q[j] = (4 * i4 < nvalid) ? ((const float4*)base)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < AttnCfg<DB>::NL; ++j) {
+            const int i = lane + 64 * j;
+            R.v[j] = i < nvalid ? base[i] : 0.f;
+        }
+    }
+}
+template <int DB, bool FAST>
+__device__ __forceinline__ void tile_store(const TileRegs<DB, FAST>& R, float* __restrict__ L, int d, int lane) {
+    constexpr int DS = AttnCfg<DB>::DS;
+    if (FAST) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i4 = lane + 64 * j;
+            *(float4*)&L[(i4 >> 4) * DS + 4 * (i4 & 15)] = R.q[j];
+        }
+    } else {
+        int row = lane / d, col = lane - row * d;
+#pragma unroll
+        for (int j = 0; j < AttnCfg<DB>::NL; ++j) {
+            if (row < 32) L[row * DS + col] = R.v[j];
+            col += 64;
+            while (col >= d) {
+                col -= d;
+                ++row;
+            }
+        }
+    }
+}
+// cooperative (256 threads) [32][d] tile -> LDS, used once per workgroup for the block's own rows
+__device__ __forceinline__ void block_tile_stage(const float* __restrict__ M, int d, int DS, int r0, int r1,
+                                                 float* __restrict__ L, int t) {
+    int nrows = r1 - r0;
+    nrows = nrows > 32 ? 32 : nrows;
+    const int nvalid = nrows * d;
+    const float* __restrict__ base = M + (size_t)r0 * d;
+    float v[10];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+        const int i = t + 256 * j;
+        v[j] = i < nvalid ? base[i] : 0.f;
+    }
+    int row = t / d, col = t - row * d;
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+        if (row < 32) L[row * DS + col] = v[j];
+        col += 256;
+        while (col >= d) {
+            col -= d;
+            ++row;
+        }
+    }
+}
+__device__ __forceinline__ void zero_fill(float* __restrict__ L, int n, int t, int nthreads) {
+    for (int i = t; i < n; i += nthreads) L[i] = 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int DB, bool FAST>
 __global__ __launch_bounds__(EQD_BLOCK) void k_attn_fwd(EqdGraph G, int d, const float* __restrict__ q,
                                                         const float* __restrict__ k, const float* __restrict__ v,
                                                         float* __restrict__ out, float* __restrict__ lse) {
-    constexpr int KS = DB * 4;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int l15 = lane & 15, g = lane >> 4;
-    __shared__ float red[EQD_WAVES][DB * 2 * 4 * 64];
+    typedef AttnCfg<DB> C;
+    constexpr int DS = C::DS, KS = C::KS;
+    __shared__ __attribute__((aligned(16))) float Qt[C::TILE];
+    __shared__ __attribute__((aligned(16))) float Kt[EQD_WAVES][C::TILE];
+    __shared__ __attribute__((aligned(16))) float Vt[EQD_WAVES][C::TILE];
+    __shared__ float red[EQD_WAVES][C::RED];
     __shared__ float sm_m[EQD_WAVES][32], sm_l[EQD_WAVES][32];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
     const int item = blockIdx.x;
     const int b0 = G.att_items[item * 4 + 0], b1 = G.att_items[item * 4 + 1];
     const int o0 = G.att_items[item * 4 + 2], o1 = G.att_items[item * 4 + 3];
     int rowq[2] = {b0 + l15, b0 + 16 + l15};
     bool qv[2] = {rowq[0] < b1, rowq[1] < b1};
+
+    TileRegs<DB, FAST> rk, rv;
+    int kt = o0 + 32 * wave;
+    tile_load<DB, FAST>(rk, k, d, kt, o1, lane);
+    tile_load<DB, FAST>(rv, v, d, kt, o1, lane);
+    zero_fill(Qt, C::TILE, t, EQD_BLOCK);
+    zero_fill(Kt[wave], C::TILE, lane, 64);
+    zero_fill(Vt[wave], C::TILE, lane, 64);
+    __syncthreads();
+    block_tile_stage(q, d, DS, b0, b1, Qt, t);
+    __syncthreads();
     float qf[2][KS];
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int kk = 4 * ks + g;
-            qf[nb][ks] = (qv[nb] && kk < d) ? q[(size_t)rowq[nb] * d + kk] : 0.f;
-        }
+        for (int ks = 0; ks < KS; ++ks) qf[nb][ks] = Qt[(16 * nb + l15) * DS + 4 * ks + g];
+
     f32x4 O[DB][2];
 #pragma unroll
     for (int db = 0; db < DB; ++db) {
@@ -50,29 +149,31 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_fwd(EqdGraph G, int d, const
         O[db][1] = f4zero();
     }
     float mrun[2] = {EQD_NEG_BIG, EQD_NEG_BIG}, lrun[2] = {0.f, 0.f};
-    for (int kt = o0 + 64 * wave; kt < o1; kt += 64 * EQD_WAVES) {
-        f32x4 S[4][2];
+    const float* __restrict__ Kw = Kt[wave];
+    const float* __restrict__ Vw = Vt[wave];
+    for (; kt < o1; kt += 32 * EQD_WAVES) {
+        wave_lds_fence();
+        tile_store<DB, FAST>(rk, Kt[wave], d, lane);
+        tile_store<DB, FAST>(rv, Vt[wave], d, lane);
+        wave_lds_fence();
+        tile_load<DB, FAST>(rk, k, d, kt + 32 * EQD_WAVES, o1, lane);   // prefetch the wave's next tile
+        tile_load<DB, FAST>(rv, v, d, kt + 32 * EQD_WAVES, o1, lane);
+        f32x4 S[2][2];
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
-            S[mb][0] = f4zero();
-            S[mb][1] = f4zero();
-        }
+        for (int mb = 0; mb < 2; ++mb) S[mb][0] = S[mb][1] = f4zero();
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int kk = 4 * ks + g;
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
-                const int key = kt + 16 * mb + l15;
-                const float a = (key < o1 && kk < d) ? k[(size_t)key * d + kk] : 0.f;
+            for (int mb = 0; mb < 2; ++mb) {
+                const float a = Kw[(16 * mb + l15) * DS + 4 * ks + g];
                 S[mb][0] = mfma4(a, qf[0][ks], S[mb][0]);
                 S[mb][1] = mfma4(a, qf[1][ks], S[mb][1]);
             }
-        }
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
             float mx = EQD_NEG_BIG;
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
+            for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = kt + 16 * mb + 4 * g + r;
@@ -85,7 +186,7 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_fwd(EqdGraph G, int d, const
             const float alpha = expf(mrun[nb] - mnew);
             float ps = 0.f;
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
+            for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = kt + 16 * mb + 4 * g + r;
@@ -99,18 +200,15 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_fwd(EqdGraph G, int d, const
             for (int db = 0; db < DB; ++db) O[db][nb] *= alpha;
         }
 #pragma unroll
-        for (int mbk = 0; mbk < 4; ++mbk)
+        for (int mbk = 0; mbk < 2; ++mbk)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kt + 16 * mbk + 4 * g + r;
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int db = 0; db < DB; ++db) {
-                    const int f = 16 * db + l15;
-                    const float a = (key < o1 && f < d) ? v[(size_t)key * d + f] : 0.f;
+                    const float a = Vw[(16 * mbk + 4 * g + r) * DS + 16 * db + l15];
                     O[db][0] = mfma4(a, S[mbk][0][r], O[db][0]);
                     O[db][1] = mfma4(a, S[mbk][1][r], O[db][1]);
                 }
-            }
     }
     // ---- merge the 4 waves' partial softmax states -----------------------------------------------
 #pragma unroll
@@ -164,46 +262,78 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_fwd(EqdGraph G, int d, const
 }
 
 // backward pass 1: dq for the block's queries; also writes delta[q] = sum_f dO[q][f] O[q][f]
-template <int DB>
+template <int DB, bool FAST>
 __global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd_q(EqdGraph G, int d, const float* __restrict__ q,
                                                           const float* __restrict__ k, const float* __restrict__ v,
                                                           const float* __restrict__ out,
                                                           const float* __restrict__ lse,
                                                           const float* __restrict__ d_out, float* __restrict__ dq,
                                                           float* __restrict__ delta) {
-    constexpr int KS = DB * 4;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    typedef AttnCfg<DB> C;
+    constexpr int DS = C::DS, KS = C::KS;
+    __shared__ __attribute__((aligned(16))) float Qt[C::TILE];
+    __shared__ __attribute__((aligned(16))) float Gt[C::TILE];   // dO rows of the block
+    __shared__ __attribute__((aligned(16))) float Kt[EQD_WAVES][C::TILE];
+    __shared__ __attribute__((aligned(16))) float Vt[EQD_WAVES][C::TILE];
+    __shared__ float red[EQD_WAVES][C::RED];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    __shared__ float red[EQD_WAVES][DB * 2 * 4 * 64];
     const int item = blockIdx.x;
     const int b0 = G.att_items[item * 4 + 0], b1 = G.att_items[item * 4 + 1];
     const int o0 = G.att_items[item * 4 + 2], o1 = G.att_items[item * 4 + 3];
     int rowq[2] = {b0 + l15, b0 + 16 + l15};
     bool qv[2] = {rowq[0] < b1, rowq[1] < b1};
-    float qf[2][KS], dof[2][KS], dl[2], lq[2];
+
+    TileRegs<DB, FAST> rk, rv;
+    int kt = o0 + 32 * wave;
+    tile_load<DB, FAST>(rk, k, d, kt, o1, lane);
+    tile_load<DB, FAST>(rv, v, d, kt, o1, lane);
+    float dl[2], lq[2];
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
         float s = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int kk = 4 * ks + g;
-            const bool ok = qv[nb] && kk < d;
-            const size_t o = (size_t)rowq[nb] * d + kk;
-            qf[nb][ks] = ok ? q[o] : 0.f;
-            dof[nb][ks] = ok ? d_out[o] : 0.f;
-            s += ok ? dof[nb][ks] * out[o] : 0.f;
+            if (qv[nb] && kk < d) {
+                const size_t o = (size_t)rowq[nb] * d + kk;
+                s += d_out[o] * out[o];
+            }
         }
-        dl[nb] = group_sum(s);
+        dl[nb] = s;
         lq[nb] = qv[nb] ? lse[rowq[nb]] : 0.f;
+    }
+    zero_fill(Qt, C::TILE, t, EQD_BLOCK);
+    zero_fill(Gt, C::TILE, t, EQD_BLOCK);
+    zero_fill(Kt[wave], C::TILE, lane, 64);
+    zero_fill(Vt[wave], C::TILE, lane, 64);
+    __syncthreads();
+    block_tile_stage(q, d, DS, b0, b1, Qt, t);
+    block_tile_stage(d_out, d, DS, b0, b1, Gt, t);
+    __syncthreads();
+    float qf[2][KS], dof[2][KS];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[nb][ks] = Qt[(16 * nb + l15) * DS + 4 * ks + g];
+            dof[nb][ks] = Gt[(16 * nb + l15) * DS + 4 * ks + g];
+        }
+        dl[nb] = group_sum(dl[nb]);
         if (wave == 0 && g == 0 && qv[nb]) delta[rowq[nb]] = dl[nb];
     }
     f32x4 dQ[DB][2];
 #pragma unroll
-    for (int db = 0; db < DB; ++db) {
-        dQ[db][0] = f4zero();
-        dQ[db][1] = f4zero();
-    }
-    for (int kt = o0 + 32 * wave; kt < o1; kt += 32 * EQD_WAVES) {
+    for (int db = 0; db < DB; ++db) dQ[db][0] = dQ[db][1] = f4zero();
+    const float* __restrict__ Kw = Kt[wave];
+    const float* __restrict__ Vw = Vt[wave];
+    for (; kt < o1; kt += 32 * EQD_WAVES) {
+        wave_lds_fence();
+        tile_store<DB, FAST>(rk, Kt[wave], d, lane);
+        tile_store<DB, FAST>(rv, Vt[wave], d, lane);
+        wave_lds_fence();
+        tile_load<DB, FAST>(rk, k, d, kt + 32 * EQD_WAVES, o1, lane);
+        tile_load<DB, FAST>(rv, v, d, kt + 32 * EQD_WAVES, o1, lane);
         f32x4 S[2][2], dP[2][2];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
@@ -211,20 +341,16 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd_q(EqdGraph G, int d, con
             dP[mb][0] = dP[mb][1] = f4zero();
         }
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int kk = 4 * ks + g;
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
-                const int key = kt + 16 * mb + l15;
-                const bool ok = key < o1 && kk < d;
-                const float a = ok ? k[(size_t)key * d + kk] : 0.f;
-                const float b = ok ? v[(size_t)key * d + kk] : 0.f;
+                const float a = Kw[(16 * mb + l15) * DS + 4 * ks + g];
+                const float b = Vw[(16 * mb + l15) * DS + 4 * ks + g];
                 S[mb][0] = mfma4(a, qf[0][ks], S[mb][0]);
                 S[mb][1] = mfma4(a, qf[1][ks], S[mb][1]);
                 dP[mb][0] = mfma4(b, dof[0][ks], dP[mb][0]);
                 dP[mb][1] = mfma4(b, dof[1][ks], dP[mb][1]);
             }
-        }
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -238,16 +364,13 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd_q(EqdGraph G, int d, con
 #pragma unroll
         for (int mbk = 0; mbk < 2; ++mbk)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kt + 16 * mbk + 4 * g + r;
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int db = 0; db < DB; ++db) {
-                    const int f = 16 * db + l15;
-                    const float a = (key < o1 && f < d) ? k[(size_t)key * d + f] : 0.f;
+                    const float a = Kw[(16 * mbk + 4 * g + r) * DS + 16 * db + l15];
                     dQ[db][0] = mfma4(a, S[mbk][0][r], dQ[db][0]);
                     dQ[db][1] = mfma4(a, S[mbk][1][r], dQ[db][1]);
                 }
-            }
     }
 #pragma unroll
     for (int db = 0; db < DB; ++db)
@@ -270,32 +393,56 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd_q(EqdGraph G, int d, con
 }
 
 // backward pass 2: dk, dv for the block's keys (queries = the partner protein)
-template <int DB>
+template <int DB, bool FAST>
 __global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd_kv(EqdGraph G, int d, const float* __restrict__ q,
                                                            const float* __restrict__ k, const float* __restrict__ v,
                                                            const float* __restrict__ lse,
                                                            const float* __restrict__ d_out,
                                                            const float* __restrict__ delta, float* __restrict__ dk,
                                                            float* __restrict__ dv) {
-    constexpr int KS = DB * 4;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    typedef AttnCfg<DB> C;
+    constexpr int DS = C::DS, KS = C::KS;
+    __shared__ __attribute__((aligned(16))) float Kb[C::TILE];   // the block's own key / value rows
+    __shared__ __attribute__((aligned(16))) float Vb[C::TILE];
+    __shared__ __attribute__((aligned(16))) float Qt[EQD_WAVES][C::TILE];   // streamed query / dO tiles
+    __shared__ __attribute__((aligned(16))) float Gt[EQD_WAVES][C::TILE];
+    __shared__ float red[EQD_WAVES][C::RED];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    __shared__ float red[EQD_WAVES][DB * 2 * 4 * 64];
     const int item = blockIdx.x;
     const int b0 = G.att_items[item * 4 + 0], b1 = G.att_items[item * 4 + 1];
     const int o0 = G.att_items[item * 4 + 2], o1 = G.att_items[item * 4 + 3];
     int rowk[2] = {b0 + l15, b0 + 16 + l15};
     bool kvd[2] = {rowk[0] < b1, rowk[1] < b1};
+
+    TileRegs<DB, FAST> rq, rg;
+    int qt = o0 + 32 * wave;
+    tile_load<DB, FAST>(rq, q, d, qt, o1, lane);
+    tile_load<DB, FAST>(rg, d_out, d, qt, o1, lane);
+    float lr[2][4], dr[2][4];   // lse / delta of the tile's query rows 16 mb + 4 g + r
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qr = qt + 16 * mb + 4 * g + r;
+            lr[mb][r] = qr < o1 ? lse[qr] : 0.f;
+            dr[mb][r] = qr < o1 ? delta[qr] : 0.f;
+        }
+    zero_fill(Kb, C::TILE, t, EQD_BLOCK);
+    zero_fill(Vb, C::TILE, t, EQD_BLOCK);
+    zero_fill(Qt[wave], C::TILE, lane, 64);
+    zero_fill(Gt[wave], C::TILE, lane, 64);
+    __syncthreads();
+    block_tile_stage(k, d, DS, b0, b1, Kb, t);
+    block_tile_stage(v, d, DS, b0, b1, Vb, t);
+    __syncthreads();
     float kf[2][KS], vf[2][KS];
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const int kk = 4 * ks + g;
-            const bool ok = kvd[nb] && kk < d;
-            const size_t o = (size_t)rowk[nb] * d + kk;
-            kf[nb][ks] = ok ? k[o] : 0.f;
-            vf[nb][ks] = ok ? v[o] : 0.f;
+            kf[nb][ks] = Kb[(16 * nb + l15) * DS + 4 * ks + g];
+            vf[nb][ks] = Vb[(16 * nb + l15) * DS + 4 * ks + g];
         }
     f32x4 dK[DB][2], dV[DB][2];
 #pragma unroll
@@ -303,7 +450,32 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd_kv(EqdGraph G, int d, co
         dK[db][0] = dK[db][1] = f4zero();
         dV[db][0] = dV[db][1] = f4zero();
     }
-    for (int qt = o0 + 32 * wave; qt < o1; qt += 32 * EQD_WAVES) {
+    const float* __restrict__ Qw = Qt[wave];
+    const float* __restrict__ Gw = Gt[wave];
+    for (; qt < o1; qt += 32 * EQD_WAVES) {
+        wave_lds_fence();
+        tile_store<DB, FAST>(rq, Qt[wave], d, lane);
+        tile_store<DB, FAST>(rg, Gt[wave], d, lane);
+        float lc[2][4], dc[2][4];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                lc[mb][r] = lr[mb][r];
+                dc[mb][r] = dr[mb][r];
+            }
+        wave_lds_fence();
+        const int qn = qt + 32 * EQD_WAVES;
+        tile_load<DB, FAST>(rq, q, d, qn, o1, lane);
+        tile_load<DB, FAST>(rg, d_out, d, qn, o1, lane);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qr = qn + 16 * mb + 4 * g + r;
+                lr[mb][r] = qr < o1 ? lse[qr] : 0.f;
+                dr[mb][r] = qr < o1 ? delta[qr] : 0.f;
+            }
         f32x4 S[2][2], dP[2][2];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
@@ -311,52 +483,41 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd_kv(EqdGraph G, int d, co
             dP[mb][0] = dP[mb][1] = f4zero();
         }
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int kk = 4 * ks + g;
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
-                const int qr = qt + 16 * mb + l15;
-                const bool ok = qr < o1 && kk < d;
-                const float a = ok ? q[(size_t)qr * d + kk] : 0.f;
-                const float b = ok ? d_out[(size_t)qr * d + kk] : 0.f;
+                const float a = Qw[(16 * mb + l15) * DS + 4 * ks + g];
+                const float b = Gw[(16 * mb + l15) * DS + 4 * ks + g];
                 S[mb][0] = mfma4(a, kf[0][ks], S[mb][0]);
                 S[mb][1] = mfma4(a, kf[1][ks], S[mb][1]);
                 dP[mb][0] = mfma4(b, vf[0][ks], dP[mb][0]);
                 dP[mb][1] = mfma4(b, vf[1][ks], dP[mb][1]);
             }
-        }
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int qr = qt + 16 * mb + 4 * g + r;
-                const bool ok = qr < o1;
-                const float lq = ok ? lse[qr] : 0.f;
-                const float dl = ok ? delta[qr] : 0.f;
+                const bool ok = qt + 16 * mb + 4 * g + r < o1;
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb) {
-                    const float p = ok ? expf(S[mb][nb][r] - lq) : 0.f;
+                    const float p = ok ? expf(S[mb][nb][r] - lc[mb][r]) : 0.f;
                     S[mb][nb][r] = p;
-                    dP[mb][nb][r] = p * (dP[mb][nb][r] - dl);
+                    dP[mb][nb][r] = p * (dP[mb][nb][r] - dc[mb][r]);
                 }
             }
 #pragma unroll
         for (int mbq = 0; mbq < 2; ++mbq)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int qr = qt + 16 * mbq + 4 * g + r;
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int db = 0; db < DB; ++db) {
-                    const int f = 16 * db + l15;
-                    const bool ok = qr < o1 && f < d;
-                    const float a = ok ? d_out[(size_t)qr * d + f] : 0.f;
-                    const float b = ok ? q[(size_t)qr * d + f] : 0.f;
+                    const float a = Gw[(16 * mbq + 4 * g + r) * DS + 16 * db + l15];
+                    const float b = Qw[(16 * mbq + 4 * g + r) * DS + 16 * db + l15];
                     dV[db][0] = mfma4(a, S[mbq][0][r], dV[db][0]);
                     dV[db][1] = mfma4(a, S[mbq][1][r], dV[db][1]);
                     dK[db][0] = mfma4(b, dP[mbq][0][r], dK[db][0]);
                     dK[db][1] = mfma4(b, dP[mbq][1][r], dK[db][1]);
                 }
-            }
     }
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {     // dK then dV through the same LDS buffer
@@ -384,6 +545,28 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd_kv(EqdGraph G, int d, co
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+template <int DB, bool FAST>
+static int attn_launch_fwd(const EqdGraph* g, int d, const float* q, const float* k, const float* v, float* out,
+                           float* lse, hipStream_t st) {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_fwd<DB, FAST>), dim3(g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, d, q, k,
+                       v, out, lse);
+    return eqd_check_launch("k_attn_fwd");
+}
+template <int DB, bool FAST>
+static int attn_launch_bwd(const EqdGraph* g, int d, const float* q, const float* k, const float* v, const float* out,
+                           const float* lse, const float* d_out, float* dq, float* dk, float* dv, float* delta,
+                           hipStream_t st) {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_q<DB, FAST>), dim3(g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, d, q,
+                       k, v, out, lse, d_out, dq, delta);
+    int rc = eqd_check_launch("k_attn_bwd_q");
+    if (rc) return rc;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_kv<DB, FAST>), dim3(g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, d, q,
+                       k, v, lse, d_out, delta, dk, dv);
+    return eqd_check_launch("k_attn_bwd_kv");
+}
+static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
 extern "C" int eqd_cross_attention_fwd(const EqdGraph* g, int d, const float* q, const float* k, const float* v,
                                        float* out, float* lse, void* stream) {
     if (!g || !q || !k || !v || !out || !lse) {
@@ -395,14 +578,10 @@ extern "C" int eqd_cross_attention_fwd(const EqdGraph* g, int d, const float* q,
         return EQD_ERR_UNSUPPORTED;
     }
     if (g->n_att_items <= 0) return EQD_OK;
-    dim3 grid(g->n_att_items);
-    if (d <= 64)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_fwd<4>), grid, dim3(EQD_BLOCK), 0, (hipStream_t)stream, *g, d, q, k, v,
-                           out, lse);
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_fwd<5>), grid, dim3(EQD_BLOCK), 0, (hipStream_t)stream, *g, d, q, k, v,
-                           out, lse);
-    return eqd_check_launch("k_attn_fwd");
+    hipStream_t st = (hipStream_t)stream;
+    if (d == 64 && aligned16(k) && aligned16(v)) return attn_launch_fwd<4, true>(g, d, q, k, v, out, lse, st);
+    if (d <= 64) return attn_launch_fwd<4, false>(g, d, q, k, v, out, lse, st);
+    return attn_launch_fwd<5, false>(g, d, q, k, v, out, lse, st);
 }
 
 extern "C" int eqd_cross_attention_bwd(const EqdGraph* g, int d, const float* q, const float* k, const float* v,
@@ -418,21 +597,8 @@ extern "C" int eqd_cross_attention_bwd(const EqdGraph* g, int d, const float* q,
     }
     if (g->n_att_items <= 0) return EQD_OK;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(g->n_att_items);
-    if (d <= 64) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_q<4>), grid, dim3(EQD_BLOCK), 0, st, *g, d, q, k, v, out, lse,
-                           d_out, dq, delta);
-        int rc = eqd_check_launch("k_attn_bwd_q");
-        if (rc) return rc;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_kv<4>), grid, dim3(EQD_BLOCK), 0, st, *g, d, q, k, v, lse, d_out,
-                           delta, dk, dv);
-    } else {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_q<5>), grid, dim3(EQD_BLOCK), 0, st, *g, d, q, k, v, out, lse,
-                           d_out, dq, delta);
-        int rc = eqd_check_launch("k_attn_bwd_q");
-        if (rc) return rc;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_kv<5>), grid, dim3(EQD_BLOCK), 0, st, *g, d, q, k, v, lse, d_out,
-                           delta, dk, dv);
-    }
-    return eqd_check_launch("k_attn_bwd_kv");
+    if (d == 64 && aligned16(q) && aligned16(k) && aligned16(v) && aligned16(d_out))
+        return attn_launch_bwd<4, true>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
+    if (d <= 64) return attn_launch_bwd<4, false>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
+    return attn_launch_bwd<5, false>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
 }

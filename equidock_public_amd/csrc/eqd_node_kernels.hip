@@ -41,123 +41,170 @@ struct LinJobsArg {
     EqdLinJob j[LIN_MAXJOBS];
 };
 
-#define LIN_U 4   /* k-steps (of 4) per chunk: their loads are issued together (one L2 round trip) */
-// A workgroup owns 16 rows; its 4 waves take the 16-wide K chunks of all sources round-robin and
-// sum their partial tiles through LDS (these GEMMs are tiny -- 3200 x 64..384 x 64 at config B -- so
-// the only thing that matters is the length of the dependent load->MFMA chain and the wave count).
+#define LIN_KC 80   /* K chunk staged per step (every source of the IEGMN path has K <= 69) */
+#define LIN_S 81    /* LDS row stride: odd -> the 16 rows of a fragment read hit 16 different banks */
+// A workgroup owns 16 rows.  Per source chunk: ALL loads (X tile 16 x Kc, weight slice M x Kc) are
+// issued together by the 256 threads as coalesced 64-byte row segments, parked in registers while the
+// previous chunk is multiplied, then written to LDS; MFMA operands come from LDS.  Wave w owns output
+// blocks mb = w and w + 4, so accumulators are complete (no cross-wave reduction); LayerNorm statistics
+// are exchanged through LDS.  These GEMMs are tiny (3200 x 64..384 x 64 at config B): what matters is
+// one memory round trip per source instead of one per 4 k-values.
+struct LinRegs {
+    float x[5], w[25];
+};
+__device__ __forceinline__ void lin_load(const EqdLinJob& J, const EqdLinSrc& S, int k0, int row0, int t, LinRegs& R) {
+    const int Kc = (S.K - k0 < LIN_KC) ? S.K - k0 : LIN_KC;
+    const int tr = t >> 4, tc = t & 15;
+    const int row = row0 + tr;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int k = tc + 16 * j;
+        float v = 0.f;
+        if (row < J.rows && k < Kc) {
+            const size_t o = (size_t)row * S.ldx + k0 + k;
+            v = S.X[o];
+            if (S.mask) v *= lrelu_grad(S.mask[o], J.slope);
+        }
+        R.x[j] = v;
+    }
+    const bool kfast = (S.w_cs == 1);
+#pragma unroll
+    for (int jm = 0; jm < 5; ++jm)
+#pragma unroll
+        for (int jk = 0; jk < 5; ++jk) {
+            const int m = (kfast ? tr : tc) + 16 * jm;
+            const int k = (kfast ? tc : tr) + 16 * jk;
+            R.w[jm * 5 + jk] = (m < J.M && k < Kc) ? S.W[(size_t)m * S.w_rs + (size_t)(k0 + k) * S.w_cs] : 0.f;
+        }
+}
+__device__ __forceinline__ void lin_store(const EqdLinSrc& S, int t, const LinRegs& R, float* __restrict__ Xl,
+                                          float* __restrict__ Wl) {
+    const int tr = t >> 4, tc = t & 15;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) Xl[tr * LIN_S + tc + 16 * j] = R.x[j];
+    const bool kfast = (S.w_cs == 1);
+#pragma unroll
+    for (int jm = 0; jm < 5; ++jm)
+#pragma unroll
+        for (int jk = 0; jk < 5; ++jk) {
+            const int m = (kfast ? tr : tc) + 16 * jm;
+            const int k = (kfast ? tc : tr) + 16 * jk;
+            Wl[m * LIN_S + k] = R.w[jm * 5 + jk];
+        }
+}
+
 __global__ __launch_bounds__(EQD_BLOCK) void k_linear(LinJobsArg jobs) {
-    __shared__ float red[EQD_WAVES][5 * 4 * 64];
+    __shared__ float Xl[16 * LIN_S];
+    __shared__ float Wl[80 * LIN_S];
+    __shared__ float stat[EQD_WAVES][16];
     const EqdLinJob& J = jobs.j[blockIdx.y];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const int row0 = (int)blockIdx.x * 16;
     if (row0 >= J.rows) return;      // uniform for the whole workgroup
     const int M = J.M;
     const int mbn = (M + 15) >> 4;
-    f32x4 acc[5];
-#pragma unroll
-    for (int mb = 0; mb < 5; ++mb) acc[mb] = f4zero();
     const int rowi = row0 + l15;
     const bool rv = rowi < J.rows;
+    // this wave's output blocks and their epilogue operands (prefetched: latency hides under the GEMM)
+    const int mbs[2] = {wave, wave + 4};
+    const bool own[2] = {wave < mbn, wave + 4 < mbn};
+    float bias[2][4], lg[2][4], lb[2][4], res[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = 16 * mbs[i] + 4 * g + r;
+            const bool ok = own[i] && f < M;
+            bias[i][r] = (ok && J.bias) ? J.bias[f] : 0.f;
+            lg[i][r] = (ok && J.ln_g) ? J.ln_g[f] : 0.f;
+            lb[i][r] = (ok && J.ln_g) ? J.ln_b[f] : 0.f;
+            res[i][r] = (ok && J.R && rv) ? J.R[(size_t)rowi * J.ldr + f] : 0.f;
+        }
+    f32x4 acc[2] = {f4zero(), f4zero()};
 
-    int chunk = 0;
-    for (int s = 0; s < J.nsrc; ++s) {
+    // ---- pipelined (source, K chunk) steps ------------------------------------------------------------
+    LinRegs R;
+    int s = 0, k0 = 0;
+    lin_load(J, J.s[0], 0, row0, t, R);
+    while (s < J.nsrc) {
         const EqdLinSrc& S = J.s[s];
-        const float* __restrict__ X = S.X + (size_t)(rv ? rowi : 0) * S.ldx;
-        const float* __restrict__ mk = S.mask ? S.mask + (size_t)(rv ? rowi : 0) * S.ldx : nullptr;
-        const float* __restrict__ W = S.W;
-        const int K = S.K;
-        for (int k0 = 0; k0 < K; k0 += 4 * LIN_U, ++chunk) {
-            if ((chunk & (EQD_WAVES - 1)) != wave) continue;
-            float a[LIN_U][5], b[LIN_U];
-#pragma unroll
-            for (int u = 0; u < LIN_U; ++u) {
-                const int k = k0 + 4 * u + g;
-                const bool kv = k < K;
-                float v = 0.f;
-                if (rv && kv) {
-                    v = X[k];
-                    if (mk) v *= lrelu_grad(mk[k], J.slope);
-                }
-                b[u] = v;
-#pragma unroll
-                for (int mb = 0; mb < 5; ++mb) {
-                    const int m = 16 * mb + l15;
-                    a[u][mb] = (mb < mbn && m < M && kv) ? W[(size_t)m * S.w_rs + (size_t)k * S.w_cs] : 0.f;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < LIN_U; ++u)
-#pragma unroll
-                for (int mb = 0; mb < 5; ++mb)
-                    if (mb < mbn) acc[mb] = mfma4(a[u][mb], b[u], acc[mb]);
+        const int Kc = (S.K - k0 < LIN_KC) ? S.K - k0 : LIN_KC;
+        __syncthreads();                  // previous chunk's fragment reads are done
+        lin_store(S, t, R, Xl, Wl);
+        __syncthreads();
+        int ns = s, nk0 = k0 + LIN_KC;    // next step
+        if (nk0 >= S.K) {
+            ns = s + 1;
+            nk0 = 0;
         }
+        if (ns < J.nsrc) lin_load(J, J.s[ns], nk0, row0, t, R);
+        const int nks = (Kc + 3) >> 2;
+        for (int ks = 0; ks < nks; ++ks) {
+            const float b = Xl[l15 * LIN_S + 4 * ks + g];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                if (own[i]) acc[i] = mfma4(Wl[(16 * mbs[i] + l15) * LIN_S + 4 * ks + g], b, acc[i]);
+        }
+        s = ns;
+        k0 = nk0;
     }
-#pragma unroll
-    for (int mb = 0; mb < 5; ++mb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[wave][(mb * 4 + r) * 64 + lane] = acc[mb][r];
-    __syncthreads();
-    if (wave != 0) return;
-#pragma unroll
-    for (int mb = 0; mb < 5; ++mb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int o = (mb * 4 + r) * 64 + lane;
-            acc[mb][r] = red[0][o] + red[1][o] + red[2][o] + red[3][o];
-        }
 
-    // ---- epilogue in F-layout: feature f = 16 mb + 4 g + r, row = rowi ------------------------
+    // ---- epilogue in F-layout: feature f = 16 mb + 4 g + r, row = rowi ------------------------------------
 #pragma unroll
-    for (int mb = 0; mb < 5; ++mb)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int f = 16 * mb + 4 * g + r;
-            float v = acc[mb][r] + ((J.bias && f < M) ? J.bias[f] : 0.f);
+            const int f = 16 * mbs[i] + 4 * g + r;
+            float v = acc[i][r] + bias[i][r];
             if (J.act) v = lrelu(v, J.slope);
-            acc[mb][r] = (f < M) ? v : 0.f;
+            acc[i][r] = (own[i] && f < M) ? v : 0.f;
         }
     if (J.ln_g) {
         const float invM = 1.f / (float)M;
-        float s = 0.f;
+        float sm = 0.f;
 #pragma unroll
-        for (int mb = 0; mb < 5; ++mb)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s += acc[mb][r];
-        const float mean = group_sum(s) * invM;
+            for (int r = 0; r < 4; ++r) sm += acc[i][r];
+        sm = group_sum(sm);
+        if (g == 0) stat[wave][l15] = sm;
+        __syncthreads();
+        const float mean = (stat[0][l15] + stat[1][l15] + stat[2][l15] + stat[3][l15]) * invM;
         float q = 0.f;
 #pragma unroll
-        for (int mb = 0; mb < 5; ++mb)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int f = 16 * mb + 4 * g + r;
-                const float dlt = (f < M) ? acc[mb][r] - mean : 0.f;
+                const int f = 16 * mbs[i] + 4 * g + r;
+                const float dlt = (own[i] && f < M) ? acc[i][r] - mean : 0.f;
                 q += dlt * dlt;
             }
-        const float rstd = 1.f / sqrtf(group_sum(q) * invM + J.ln_eps);
+        q = group_sum(q);
+        __syncthreads();
+        if (g == 0) stat[wave][l15] = q;
+        __syncthreads();
+        const float rstd = 1.f / sqrtf((stat[0][l15] + stat[1][l15] + stat[2][l15] + stat[3][l15]) * invM + J.ln_eps);
 #pragma unroll
-        for (int mb = 0; mb < 5; ++mb)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int f = 16 * mb + 4 * g + r;
-                if (f < M) {
-                    const float v = acc[mb][r];
+                const int f = 16 * mbs[i] + 4 * g + r;
+                if (own[i] && f < M) {
+                    const float v = acc[i][r];
                     if (J.pre_ln && rv) J.pre_ln[(size_t)rowi * J.ld_pre + f] = v;
-                    acc[mb][r] = (v - mean) * rstd * J.ln_g[f] + J.ln_b[f];
+                    acc[i][r] = (v - mean) * rstd * lg[i][r] + lb[i][r];
                 }
             }
     }
     if (!rv) return;
 #pragma unroll
-    for (int mb = 0; mb < 5; ++mb)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int f = 16 * mb + 4 * g + r;
-            if (f < M) {
-                float v = J.alpha * acc[mb][r];
-                if (J.R) v += J.beta * J.R[(size_t)rowi * J.ldr + f];
-                J.Y[(size_t)rowi * J.ldy + f] = v;
-            }
+            const int f = 16 * mbs[i] + 4 * g + r;
+            if (own[i] && f < M) J.Y[(size_t)rowi * J.ldy + f] = J.alpha * acc[i][r] + J.beta * res[i][r];
         }
 }
 
