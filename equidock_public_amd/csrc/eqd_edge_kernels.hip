@@ -35,31 +35,37 @@
 #define VEC_WC2 256
 #define VEC_BC2 320
 #define VEC_N 324
+#define FWD_WAVES 8   /* forward: 166 VGPRs -> 2 waves per SIMD, two tiles overlap their memory latency */
+#define BWD_WAVES 4   /* backward: ~390 registers (4 live accumulator sets) -> 1 wave per SIMD */
 
+template <int NW>
 struct alignas(16) EdgeSmem {
     float w1[64 * WS1];
     float w2[64 * WS2];
     float wc1[64 * WS2];
     float vec[VEC_N];
-    float tile[EQD_WAVES][32 * TS];
+    float tile[NW][32 * TS];
 };
 
-__device__ __forceinline__ void edge_stage_weights(EdgeSmem& sm, const EqdEdgeParams& P) {
+template <int NW>
+__device__ __forceinline__ void edge_stage_weights(EdgeSmem<NW>& sm, const EqdEdgeParams& P) {
+    constexpr int NT = 64 * NW;
+    constexpr int N1 = (64 * 42 + NT - 1) / NT, N2 = 1024 / NT;
     // all global loads of a thread are issued before the first LDS store (constant trip counts, fully
     // unrolled): one L2 round trip per batch instead of one per element
     const int t = threadIdx.x;
     const int koff = 2 * P.d_in;
     {
-        float v[11];
+        float v[N1];
 #pragma unroll
-        for (int j = 0; j < 11; ++j) {       // 64 x 42 = 2688 elements, 10.5 per thread
-            const int i = t + j * EQD_BLOCK;
+        for (int j = 0; j < N1; ++j) {       // 64 x 42 = 2688 elements
+            const int i = t + j * NT;
             const int r = i / 42, c = i - r * 42;
             v[j] = (i < 64 * 42) ? P.W1[(size_t)r * P.ldw1 + koff + c] : 0.f;
         }
 #pragma unroll
-        for (int j = 0; j < 11; ++j) {
-            const int i = t + j * EQD_BLOCK;
+        for (int j = 0; j < N1; ++j) {
+            const int i = t + j * NT;
             const int r = i / 42, c = i - r * 42;
             if (i < 64 * 42) sm.w1[r * WS1 + c] = v[j];
         }
@@ -70,16 +76,16 @@ __device__ __forceinline__ void edge_stage_weights(EdgeSmem& sm, const EqdEdgePa
         }
     }
     {
-        float4 a[4], b[4];
+        float4 a[N2], b[N2];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {        // 64 x 64 floats = 1024 float4, 4 per thread
-            const int i = t + j * EQD_BLOCK;
+        for (int j = 0; j < N2; ++j) {       // 64 x 64 floats = 1024 float4
+            const int i = t + j * NT;
             a[j] = ((const float4*)P.W2)[i];
             b[j] = ((const float4*)P.Wc1)[i];
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int i = t + j * EQD_BLOCK;
+        for (int j = 0; j < N2; ++j) {
+            const int i = t + j * NT;
             const int r = i >> 4, c = (i & 15) * 4;
             *(float4*)&sm.w2[r * WS2 + c] = a[j];
             *(float4*)&sm.wc1[r * WS2 + c] = b[j];
@@ -163,7 +169,8 @@ struct EdgeTileState {
 // Forward of one tile up to (and including) the coefficient. On return:
 //   xh = LayerNorm-normalised hidden (before the affine), m = msg, ch = coors_mlp hidden pre-activation.
 // If rbf_out != nullptr the 15 RBFs of each edge are also written there ([E][16]).
-__device__ __forceinline__ void edge_tile_forward(const EqdGraph& G, const EqdEdgeParams& P, EdgeSmem& sm,
+template <int NW>
+__device__ __forceinline__ void edge_tile_forward(const EqdGraph& G, const EqdEdgeParams& P, EdgeSmem<NW>& sm,
                                                   float* __restrict__ tile, const float* __restrict__ Pn,
                                                   const float* __restrict__ Qn, const float* __restrict__ x,
                                                   int lane, EdgeTileState& S, f32x4 (&xh)[4][2], f32x4 (&m)[4][2],
@@ -336,15 +343,15 @@ __device__ __forceinline__ void hbm_store(float* __restrict__ dst, const f32x4 (
         }
 }
 
-__global__ __launch_bounds__(EQD_BLOCK) void k_edge_fwd(EqdGraph G, EqdEdgeParams P, const float* __restrict__ Pn,
+__global__ __launch_bounds__(64 * FWD_WAVES) void k_edge_fwd(EqdGraph G, EqdEdgeParams P, const float* __restrict__ Pn,
                                                         const float* __restrict__ Qn, const float* __restrict__ x,
                                                         float* __restrict__ aggr_msg, float* __restrict__ x_new) {
-    __shared__ EdgeSmem sm;
+    __shared__ EdgeSmem<FWD_WAVES> sm;
     edge_stage_weights(sm, P);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     float* tile = sm.tile[wave];
-    for (int t = blockIdx.x * EQD_WAVES + wave; t < G.n_tiles; t += gridDim.x * EQD_WAVES) {
+    for (int t = blockIdx.x * FWD_WAVES + wave; t < G.n_tiles; t += gridDim.x * FWD_WAVES) {
         EdgeTileState S;
         S.n0 = G.tile_node[t];
         S.n1 = G.tile_node[t + 1];
@@ -389,9 +396,9 @@ extern "C" int eqd_edge_message_fwd(const EqdGraph* g, const EqdEdgeParams* p, c
         return EQD_ERR_NULL;
     }
     if (g->n_tiles <= 0) return EQD_OK;
-    int blocks = (g->n_tiles + EQD_WAVES - 1) / EQD_WAVES;
+    int blocks = (g->n_tiles + FWD_WAVES - 1) / FWD_WAVES;
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(k_edge_fwd, dim3(blocks), dim3(EQD_BLOCK), 0, (hipStream_t)stream, *g, *p, P, Q, x, aggr_msg,
+    hipLaunchKernelGGL(k_edge_fwd, dim3(blocks), dim3(64 * FWD_WAVES), 0, (hipStream_t)stream, *g, *p, P, Q, x, aggr_msg,
                        x_new);
     return eqd_check_launch("k_edge_fwd");
 }
@@ -410,20 +417,20 @@ struct EdgeBwdWs {
     float* vecp;   // [nwaves][256]: d ln_g | d ln_b | d wc2 | d bc2 (slot 192)
 };
 
-__global__ __launch_bounds__(EQD_BLOCK) void k_edge_bwd(EqdGraph G, EqdEdgeParams P, const float* __restrict__ Pn,
+__global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdgeParams P, const float* __restrict__ Pn,
                                                         const float* __restrict__ Qn, const float* __restrict__ x,
                                                         const float* __restrict__ d_aggr,
                                                         const float* __restrict__ d_xnew, float* __restrict__ dQ,
                                                         float* __restrict__ dx, EdgeBwdWs W) {
-    __shared__ EdgeSmem sm;
-    __shared__ float vacc[EQD_WAVES][256];
+    __shared__ EdgeSmem<BWD_WAVES> sm;
+    __shared__ float vacc[BWD_WAVES][256];
     edge_stage_weights(sm, P);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     float* tile = sm.tile[wave];
     for (int i = lane; i < 256; i += 64) vacc[wave][i] = 0.f;
     wave_lds_fence();
-    for (int t = blockIdx.x * EQD_WAVES + wave; t < G.n_tiles; t += gridDim.x * EQD_WAVES) {
+    for (int t = blockIdx.x * BWD_WAVES + wave; t < G.n_tiles; t += gridDim.x * BWD_WAVES) {
         EdgeTileState S;
         S.n0 = G.tile_node[t];
         S.n1 = G.tile_node[t + 1];
@@ -470,8 +477,8 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_edge_bwd(EqdGraph G, EqdEdgeParam
             }
             dcoef[nb] = dc;
         }
-        // d wc2 / d bc2 partials, then ch := d_chid = wc2 * dcoef * LeakyReLU'(ch)
-        float pw[4][4];
+        // d wc2 / d bc2 partials (reduced over the 16 edge lanes and banked in LDS right away to keep
+        // register pressure down), then ch := d_chid = wc2 * dcoef * LeakyReLU'(ch)
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
             const float4 w = *(const float4*)&sm.vec[VEC_WC2 + 16 * mb + 4 * g];
@@ -485,8 +492,13 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_edge_bwd(EqdGraph G, EqdEdgeParam
                     acc += lrelu(c, P.slope) * dcoef[nb];
                     ch[mb][nb][r] = wv[r] * dcoef[nb] * lrelu_grad(c, P.slope);
                 }
-                pw[mb][r] = acc;
+                acc = l16_sum(acc);
+                if (l15 == 0) vacc[wave][128 + 16 * mb + 4 * g + r] += acc;
             }
+        }
+        {
+            const float dbc2 = l16_sum(dcoef[0] + dcoef[1]);
+            if (lane == 0) vacc[wave][192] += dbc2;
         }
         hbm_store(W.dchid, ch, S, l15, g);
         // ---- dm = d_aggr[dst] / deg + Wc1^T d_chid ---------------------------------------------------
@@ -512,13 +524,19 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_edge_bwd(EqdGraph G, EqdEdgeParam
         }
         chain64T(dz, m, sm.w2, l15, g);
         // ---- LayerNorm + LeakyReLU backward --------------------------------------------------------------
-        float pg[4][4], pb[4][4];
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                pg[mb][r] = 0.f;
-                pb[mb][r] = 0.f;
+                float a = dz[mb][0][r] * xh[mb][0][r] + dz[mb][1][r] * xh[mb][1][r];
+                float b = dz[mb][0][r] + dz[mb][1][r];
+                a = l16_sum(a);
+                b = l16_sum(b);
+                if (l15 == 0) {
+                    const int f = 16 * mb + 4 * g + r;
+                    vacc[wave][f] += a;
+                    vacc[wave][64 + f] += b;
+                }
             }
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
@@ -529,10 +547,7 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_edge_bwd(EqdGraph G, EqdEdgeParam
                 const float gv[4] = {gg.x, gg.y, gg.z, gg.w};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float da = dz[mb][nb][r];
-                    pg[mb][r] += da * xh[mb][nb][r];
-                    pb[mb][r] += da;
-                    const float dxh = da * gv[r];
+                    const float dxh = dz[mb][nb][r] * gv[r];
                     dz[mb][nb][r] = dxh;
                     s1 += dxh;
                     s2 += dxh * xh[mb][nb][r];
@@ -609,33 +624,15 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_edge_bwd(EqdGraph G, EqdEdgeParam
             }
         }
         wave_lds_fence();
-        // ---- vector-gradient partials: reduce over the 16 edge lanes, accumulate per wave in LDS ----------
-        float dbc2 = dcoef[0] + dcoef[1];
-        dbc2 = l16_sum(dbc2);
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float a = l16_sum(pg[mb][r]);
-                const float b = l16_sum(pb[mb][r]);
-                const float c = l16_sum(pw[mb][r]);
-                if (l15 == 0) {
-                    const int f = 16 * mb + 4 * g + r;
-                    vacc[wave][f] += a;
-                    vacc[wave][64 + f] += b;
-                    vacc[wave][128 + f] += c;
-                }
-            }
-        if (lane == 0) vacc[wave][192] += dbc2;
         wave_lds_fence();
     }
     wave_lds_fence();
-    float* vp = W.vecp + (size_t)(blockIdx.x * EQD_WAVES + wave) * 256;
+    float* vp = W.vecp + (size_t)(blockIdx.x * BWD_WAVES + wave) * 256;
     for (int i = lane; i < 256; i += 64) vp[i] = vacc[wave][i];
 }
 
 static int edge_bwd_blocks(const EqdGraph* g) {
-    int blocks = (g->n_tiles + EQD_WAVES - 1) / EQD_WAVES;
+    int blocks = (g->n_tiles + BWD_WAVES - 1) / BWD_WAVES;
     if (blocks > 512) blocks = 512;
     if (blocks < 1) blocks = 1;
     return blocks;
@@ -670,7 +667,7 @@ static size_t edge_bwd_carve(const EqdGraph* g, EqdArena& A, EdgeBwdWs* W, float
     w.dz1 = A.take<float>(E * 64);
     w.rbf = A.take<float>(E * 16);
     w.dxrel = A.take<float>(E * 4);
-    w.vecp = A.take<float>((size_t)edge_bwd_blocks(g) * EQD_WAVES * 256);
+    w.vecp = A.take<float>((size_t)edge_bwd_blocks(g) * BWD_WAVES * 256);
     // worst-case partial size for the four weight-gradient GEMMs (depends only on E)
     EqdAtbJob jobs[4];
     EqdEdgeParams p;
@@ -710,7 +707,7 @@ extern "C" int eqd_edge_message_bwd_kernel_only(const EqdGraph* g, const EqdEdge
         return EQD_ERR_WORKSPACE;
     }
     if (g->n_tiles <= 0) return EQD_OK;
-    hipLaunchKernelGGL(k_edge_bwd, dim3(edge_bwd_blocks(g)), dim3(EQD_BLOCK), 0, (hipStream_t)stream, *g, *p, P, Q, x,
+    hipLaunchKernelGGL(k_edge_bwd, dim3(edge_bwd_blocks(g)), dim3(64 * BWD_WAVES), 0, (hipStream_t)stream, *g, *p, P, Q, x,
                        d_aggr_msg, d_xnew, dQ, dx, W);
     return eqd_check_launch("k_edge_bwd");
 }
@@ -735,11 +732,11 @@ extern "C" int eqd_edge_message_bwd(const EqdGraph* g, const EqdEdgeParams* p, c
     }
     const int blocks = edge_bwd_blocks(g);
     if (g->n_tiles > 0) {
-        hipLaunchKernelGGL(k_edge_bwd, dim3(blocks), dim3(EQD_BLOCK), 0, st, *g, *p, P, Q, x, d_aggr_msg, d_xnew, dQ,
+        hipLaunchKernelGGL(k_edge_bwd, dim3(blocks), dim3(64 * BWD_WAVES), 0, st, *g, *p, P, Q, x, d_aggr_msg, d_xnew, dQ,
                            dx, W);
         int rc = eqd_check_launch("k_edge_bwd");
         if (rc) return rc;
-        const int nw = blocks * EQD_WAVES;
+        const int nw = blocks * BWD_WAVES;
         EqdRedSeg segs[4] = {{W.vecp, nw, 256, 64, grads->dln_g}, {W.vecp + 64, nw, 256, 64, grads->dln_b},
                              {W.vecp + 128, nw, 256, 64, grads->dwc2}, {W.vecp + 192, nw, 256, 1, grads->dbc2}};
         if ((rc = eqd_launch_reduce_segments(segs, 4, st))) return rc;

@@ -250,81 +250,99 @@ extern "C" int eqd_linear(const EqdLinJob* jobs, int njobs, void* stream) {
 #define ATB_MAXUNITS 16
 #define ATB_TILE 5120  /* 80 x 64 */
 #define ATB_PSTRIDE 5200
-#define ATB_U 4
 struct AtbUnit {
     EqdAtbJob job;
-    int n0, nparts, rpw;
+    int n0, nparts, nchunks;
     long long poff;  // float offset of this unit's partials
 };
 struct AtbUnitsArg {
     AtbUnit u[ATB_MAXUNITS];
 };
 
-__global__ __launch_bounds__(EQD_BLOCK) void k_atb(AtbUnitsArg U, float* __restrict__ partial) {
-    const AtbUnit& u = U.u[blockIdx.y];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int l15 = lane & 15, g = lane >> 4;
-    const int c = (int)blockIdx.x * EQD_WAVES + wave;
-    if (c >= u.nparts) return;
-    const EqdAtbJob& J = u.job;
-    const int r0 = c * u.rpw;
-    const int r1 = (r0 + u.rpw < J.rows) ? r0 + u.rpw : J.rows;
-    const int M = J.M, N = J.N;
-    const int mbn = (M + 15) >> 4;
-    f32x4 acc[5][4];
-    float bsum[5];
+#define ATB_ROWS 64    /* graph rows per chunk */
+#define ATB_LS 81      /* LDS row stride (odd) */
+#define ATB_MAXBLOCKS 256
+// Persistent workgroups: each walks the 64-row chunks c, c + nparts, ... of its unit.  Per chunk the
+// X (<= 80 columns) and Y (64 columns) slabs are fetched with all loads in flight at once (36 per
+// thread, 64-byte coalesced row segments) WHILE the previous chunk is multiplied, then written to LDS;
+// wave w accumulates the output column block nb = w for every row block mb.  One partial tile per
+// workgroup (no cross-wave reduction), summed later in a fixed order by k_atb_reduce.
+struct AtbRegs {
+    float x[4][5], y[4][4];
+};
+__device__ __forceinline__ void atb_load(const EqdAtbJob& J, int n0, int chunk, int t, AtbRegs& R) {
+    const int tr = t >> 4, tc = t & 15;
+    const int r0 = chunk * ATB_ROWS;
 #pragma unroll
-    for (int mb = 0; mb < 5; ++mb) {
-        bsum[mb] = 0.f;
+    for (int jr = 0; jr < 4; ++jr) {
+        const int row = r0 + tr + 16 * jr;
+        const bool rv = row < J.rows;
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = f4zero();
-    }
-    const float* __restrict__ X = J.X;
-    const float* __restrict__ Y = J.Y;
-    const float* __restrict__ xm = J.xmask;
-    for (int rb = r0; rb < r1; rb += 4 * ATB_U) {
-        float a[ATB_U][5], b[ATB_U][4];
-#pragma unroll
-        for (int uu = 0; uu < ATB_U; ++uu) {
-            const int row = rb + 4 * uu + g;
-            const bool rv = row < r1;
-#pragma unroll
-            for (int mb = 0; mb < 5; ++mb) {
-                const int m = 16 * mb + l15;
-                float v = 0.f;
-                if (rv && mb < mbn && m < M) {
-                    const size_t o = (size_t)row * J.ldx + m;
-                    v = X[o];
-                    if (xm) v *= lrelu_grad(xm[o], J.slope);
-                }
-                a[uu][mb] = v;
-                bsum[mb] += v;
+        for (int jm = 0; jm < 5; ++jm) {
+            const int m = tc + 16 * jm;
+            float v = 0.f;
+            if (rv && m < J.M) {
+                const size_t o = (size_t)row * J.ldx + m;
+                v = J.X[o];
+                if (J.xmask) v *= lrelu_grad(J.xmask[o], J.slope);
             }
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) {
-                const int n = u.n0 + 16 * nb + l15;
-                b[uu][nb] = (rv && n < N) ? Y[(size_t)row * J.ldy + n] : 0.f;
-            }
+            R.x[jr][jm] = v;
         }
 #pragma unroll
-        for (int uu = 0; uu < ATB_U; ++uu)
+        for (int jn = 0; jn < 4; ++jn) {
+            const int n = n0 + tc + 16 * jn;
+            R.y[jr][jn] = (rv && n < J.N) ? J.Y[(size_t)row * J.ldy + n] : 0.f;
+        }
+    }
+}
+__global__ __launch_bounds__(EQD_BLOCK) void k_atb(AtbUnitsArg U, float* __restrict__ partial) {
+    __shared__ float Xl[ATB_ROWS * ATB_LS];
+    __shared__ float Yl[ATB_ROWS * ATB_LS];
+    const AtbUnit& u = U.u[blockIdx.y];
+    const int c = blockIdx.x;
+    if (c >= u.nparts) return;       // uniform per workgroup
+    const EqdAtbJob& J = u.job;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int tr = t >> 4, tc = t & 15;
+    const int mbn = (J.M + 15) >> 4;
+    f32x4 acc[5];
+#pragma unroll
+    for (int mb = 0; mb < 5; ++mb) acc[mb] = f4zero();
+    float bacc = 0.f;
+    AtbRegs R;
+    atb_load(J, u.n0, c, t, R);
+    for (int chunk = c; chunk < u.nchunks; chunk += u.nparts) {
+        __syncthreads();             // the previous chunk's LDS reads are done
+#pragma unroll
+        for (int jr = 0; jr < 4; ++jr) {
+            const int row = tr + 16 * jr;
+#pragma unroll
+            for (int jm = 0; jm < 5; ++jm) Xl[row * ATB_LS + tc + 16 * jm] = R.x[jr][jm];
+#pragma unroll
+            for (int jn = 0; jn < 4; ++jn) Yl[row * ATB_LS + tc + 16 * jn] = R.y[jr][jn];
+        }
+        __syncthreads();
+        if (chunk + u.nparts < u.nchunks) atb_load(J, u.n0, chunk + u.nparts, t, R);
+#pragma unroll 4
+        for (int ks = 0; ks < ATB_ROWS / 4; ++ks) {
+            const int row = 4 * ks + g;
+            const float b = Yl[row * ATB_LS + 16 * wave + l15];
 #pragma unroll
             for (int mb = 0; mb < 5; ++mb)
-                if (mb < mbn) {
-#pragma unroll
-                    for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = mfma4(a[uu][mb], b[uu][nb], acc[mb][nb]);
-                }
+                if (mb < mbn) acc[mb] = mfma4(Xl[row * ATB_LS + 16 * mb + l15], b, acc[mb]);
+        }
+        if (t < 80) {
+#pragma unroll 8
+            for (int row = 0; row < ATB_ROWS; ++row) bacc += Xl[row * ATB_LS + t];
+        }
     }
     float* P = partial + u.poff + (long long)c * ATB_PSTRIDE;
 #pragma unroll
-    for (int mb = 0; mb < 5; ++mb) {
+    for (int mb = 0; mb < 5; ++mb)
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) P[(16 * mb + 4 * g + r) * 64 + 16 * nb + l15] = acc[mb][nb][r];
-        const float bs = group_sum(bsum[mb]);
-        if (g == 0) P[ATB_TILE + 16 * mb + l15] = bs;
-    }
+        for (int r = 0; r < 4; ++r) P[(16 * mb + 4 * g + r) * 64 + 16 * wave + l15] = acc[mb][r];
+    if (t < 80) P[ATB_TILE + t] = bacc;
 }
 
 __global__ __launch_bounds__(1024) void k_atb_reduce(AtbUnitsArg U, const float* __restrict__ partial) {
@@ -376,13 +394,8 @@ static int atb_plan(const EqdAtbJob* jobs, int njobs, AtbUnit* units, int max_un
             eqd_set_error("eqd_atb: job %d has M=%d N=%d rows=%d (need M in 1..80)", i, J.M, J.N, J.rows);
             return EQD_ERR_SHAPE;
         }
-        int target = J.rows / 32;
-        if (target < 1) target = 1;
-        if (target > 512) target = 512;
-        int rpw = (J.rows + target - 1) / target;
-        rpw = (rpw + 3) / 4 * 4;
-        if (rpw < 4) rpw = 4;
-        int nparts = J.rows > 0 ? (J.rows + rpw - 1) / rpw : 0;
+        const int nchunks = J.rows > 0 ? (J.rows + ATB_ROWS - 1) / ATB_ROWS : 0;
+        const int nparts = nchunks < ATB_MAXBLOCKS ? nchunks : ATB_MAXBLOCKS;
         for (int n0 = 0; n0 < J.N; n0 += 64) {
             if (nu >= max_units) {
                 eqd_set_error("eqd_atb: too many output tiles");
@@ -391,7 +404,7 @@ static int atb_plan(const EqdAtbJob* jobs, int njobs, AtbUnit* units, int max_un
             units[nu].job = J;
             units[nu].n0 = n0;
             units[nu].nparts = nparts;
-            units[nu].rpw = rpw;
+            units[nu].nchunks = nchunks;
             units[nu].poff = off;
             off += (long long)nparts * ATB_PSTRIDE;
             ++nu;
@@ -431,8 +444,7 @@ extern "C" int eqd_atb(const EqdAtbJob* jobs, int njobs, void* partial, size_t p
             if (arg.u[i].nparts > maxparts) maxparts = arg.u[i].nparts;
         }
         if (maxparts > 0) {
-            hipLaunchKernelGGL(k_atb, dim3((maxparts + EQD_WAVES - 1) / EQD_WAVES, n), dim3(EQD_BLOCK), 0, st, arg,
-                               (float*)partial);
+            hipLaunchKernelGGL(k_atb, dim3(maxparts, n), dim3(EQD_BLOCK), 0, st, arg, (float*)partial);
             rc = eqd_check_launch("k_atb");
             if (rc) return rc;
         }

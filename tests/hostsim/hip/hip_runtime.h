@@ -80,3 +80,4 @@ static inline hostsim_f32x4 hostsim_mfma(float a, float b, hostsim_f32x4 c, int,
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hostsim_mfma
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_wave_barrier() hostsim::wave_barrier()
+#define __builtin_amdgcn_sched_barrier(mask) ((void)0)

@@ -129,6 +129,20 @@ def check_atb(dev):
     close(out[:, 10:281], Xm.t() @ Ya, what='A^T B')
     close(bo, Xm.sum(0), what='column sums')
     assert float(out[:, :10].abs().max()) == 0.0 and float(out[:, 281:].abs().max()) == 0.0
+    # more 64-row chunks than persistent workgroups: every workgroup walks several chunks
+    rows = 64 * 256 * 2 + 37
+    Xb, Yb = torch.randn(rows, 16), torch.randn(rows, 20)
+    outb, bob = torch.zeros(16, 20, device=dev), torch.zeros(16, device=dev)
+    Xbd, Ybd = Xb.to(dev), Yb.to(dev)
+    B = L.EqdAtbJob()
+    B.X, B.ldx, B.M, B.Y, B.ldy, B.N = Xbd.data_ptr(), 16, 16, Ybd.data_ptr(), 20, 20
+    B.rows, B.out, B.o_rs, B.o_cs, B.bias_out, B.scale = rows, outb.data_ptr(), 20, 1, bob.data_ptr(), 1.0
+    nb = lib().eqd_atb_partial_bytes(C.byref(B), 1)
+    part = torch.zeros(nb // 4 + 64, device=dev)
+    L.check(lib().eqd_atb(C.byref(B), 1, P(part), C.c_size_t(nb), st(dev)))
+    sync(dev)
+    close(outb, Xb.t() @ Yb, tol=2e-4, what='A^T B, multi-chunk')
+    close(bob, Xb.sum(0), tol=2e-4, what='column sums, multi-chunk')
 
 
 def _edge_setup(dev, d_in=64):
