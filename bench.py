@@ -209,6 +209,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()
+    host_dt = time.perf_counter() - t0      # host-side enqueue time (== dt when the step is launch-bound)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -231,7 +232,8 @@ def main():
             "config": {"workload": desc, "pairs_per_gpu": ppg, "nodes_per_gpu": packed.n_nodes,
                        "edges_per_gpu": packed.n_edges, "layers": L, "parallelism": f"dp{world}",
                        "weights": "PyTorch default init (seed 0), ROT key/query x40 (SURVEY.md section 8c)",
-                       "loss": float(loss), "svd_guard_pairs": svd_bad},
+                       "loss": float(loss), "svd_guard_pairs": svd_bad,
+                       "host_enqueue_ms_per_step": round(host_dt / a.steps * 1e3, 4)},
         }
         if not a.no_roofline:
             rl = edge_kernel_rooflines(net, packed, dev)

@@ -87,7 +87,7 @@ def _declare(lib):
     lib.eqd_model_scratch_bytes.restype = C.c_size_t
     lib.eqd_atb_partial_bytes.restype = C.c_size_t
     lib.eqd_edge_message_bwd_workspace_bytes.restype = C.c_size_t
-    for name in ('eqd_model_check', 'eqd_model_forward', 'eqd_model_backward', 'eqd_linear', 'eqd_atb',
+    for name in ('eqd_ctx_create', 'eqd_ctx_destroy', 'eqd_model_check', 'eqd_model_forward', 'eqd_model_backward', 'eqd_linear', 'eqd_atb',
                  'eqd_edge_message_fwd', 'eqd_edge_message_bwd', 'eqd_edge_message_bwd_kernel_only',
                  'eqd_cross_attention_fwd',
                  'eqd_cross_attention_bwd', 'eqd_keypoint_pool_fwd', 'eqd_kabsch_fwd', 'eqd_kabsch_bwd',
@@ -95,7 +95,7 @@ def _declare(lib):
         getattr(lib, name).restype = C.c_int
 
 
-EXPORTS = ('eqd_abi_version', 'eqd_last_error', 'eqd_tile_edges', 'eqd_is_simulator', 'eqd_model_saved_bytes',
+EXPORTS = ('eqd_ctx_create', 'eqd_ctx_destroy', 'eqd_abi_version', 'eqd_last_error', 'eqd_tile_edges', 'eqd_is_simulator', 'eqd_model_saved_bytes',
            'eqd_model_scratch_bytes', 'eqd_model_check', 'eqd_model_forward', 'eqd_model_backward', 'eqd_linear',
            'eqd_atb_partial_bytes', 'eqd_atb', 'eqd_edge_message_fwd', 'eqd_edge_message_bwd_workspace_bytes',
            'eqd_edge_message_bwd', 'eqd_edge_message_bwd_kernel_only', 'eqd_cross_attention_fwd',
@@ -163,6 +163,25 @@ def stream_ptr(device):
     if _is_sim:
         return C.c_void_p(0)
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+_ctx = {}
+
+
+def exec_ctx(device):
+    """Per-device execution context (auxiliary streams + events) of the C library, created once."""
+    if os.environ.get('EQD_SERIAL') == '1':
+        return C.c_void_p(0)
+    key = (id(_lib), str(device))
+    if key not in _ctx:
+        h = C.c_void_p(0)
+        if not _is_sim:
+            with torch.cuda.device(device):
+                check(_lib.eqd_ctx_create(C.byref(h)))
+        else:
+            check(_lib.eqd_ctx_create(C.byref(h)))
+        _ctx[key] = h
+    return _ctx[key]
 
 
 def graph_struct(p):

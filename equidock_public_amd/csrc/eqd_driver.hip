@@ -132,7 +132,9 @@ int node_atb_jobs(const Dims& D, int l, const EqdModelDesc* m, const Saved* S, c
 }
 
 struct Scratch {
-    float *dHa, *dHb, *dXa, *dXb, *da1n, *dz, *d_aggr_msg, *d_aggr_cross, *dq, *dk, *dv, *dP, *dQ, *delta, *dh0acc;
+    float *dHa, *dHb, *dXa, *dXb, *da1n, *d_aggr_msg, *d_aggr_cross, *delta, *dh0acc;
+    float *dz2[2], *dq2[2], *dk2[2], *dv2[2], *dP2[2], *dQ2[2];   // by layer parity: the weight-gradient stream
+                                                                 // reads layer l's while layer l-1 is produced
     float *dY, *dT, *db, *dscores, *du, *dHk, *dqm_part, *dhm;
     void* edge_ws; size_t edge_ws_bytes;
     float* atb_part; size_t atb_bytes;
@@ -147,14 +149,16 @@ void carve_scratch(const Dims& D, const EqdModelDesc* m, const EqdGraph* g, EqdA
     W.dXa = A.take<float>(N * 3);
     W.dXb = A.take<float>(N * 3);
     W.da1n = A.take<float>(N * 80);
-    W.dz = A.take<float>(N * 80);
     W.d_aggr_msg = A.take<float>(N * 64);
     W.d_aggr_cross = A.take<float>(N * 80);
-    W.dq = A.take<float>(N * 80);
-    W.dk = A.take<float>(N * 80);
-    W.dv = A.take<float>(N * 80);
-    W.dP = A.take<float>(N * 64);
-    W.dQ = A.take<float>(N * 64);
+    for (int i = 0; i < 2; ++i) {
+        W.dz2[i] = A.take<float>(N * 80);
+        W.dq2[i] = A.take<float>(N * 80);
+        W.dk2[i] = A.take<float>(N * 80);
+        W.dv2[i] = A.take<float>(N * 80);
+        W.dP2[i] = A.take<float>(N * 64);
+        W.dQ2[i] = A.take<float>(N * 64);
+    }
     W.delta = A.take<float>(N);
     W.dh0acc = A.take<float>(N * D.d0);
     W.dY = A.take<float>((size_t)2 * D.B * D.K * 3);
@@ -240,6 +244,50 @@ extern "C" size_t eqd_model_scratch_bytes(const EqdModelDesc* m, const EqdGraph*
     return bwd > sv ? bwd : sv;
 }
 
+// ---- execution context: auxiliary streams + events -----------------------------------------------------
+struct EqdCtx {
+    hipStream_t sa, sc;          // sa: attention branch, sc: node-level weight-gradient GEMMs
+    hipEvent_t fork, fork2, join_a, join_c[2];
+};
+extern "C" int eqd_ctx_create(void** ctx) {
+    if (!ctx) return EQD_ERR_NULL;
+    EqdCtx* c = new EqdCtx();
+    bool ok = hipStreamCreateWithFlags(&c->sa, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&c->sc, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&c->fork, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&c->fork2, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&c->join_a, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&c->join_c[0], hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&c->join_c[1], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        delete c;
+        eqd_set_error("eqd_ctx_create: could not create streams/events");
+        return EQD_ERR_LAUNCH;
+    }
+    *ctx = c;
+    return EQD_OK;
+}
+extern "C" int eqd_ctx_destroy(void* ctx) {
+    if (!ctx) return EQD_OK;
+    EqdCtx* c = (EqdCtx*)ctx;
+    (void)hipEventDestroy(c->fork);
+    (void)hipEventDestroy(c->fork2);
+    (void)hipEventDestroy(c->join_a);
+    (void)hipEventDestroy(c->join_c[0]);
+    (void)hipEventDestroy(c->join_c[1]);
+    (void)hipStreamDestroy(c->sa);
+    (void)hipStreamDestroy(c->sc);
+    delete c;
+    return EQD_OK;
+}
+#define HIPOK(x)                                    \
+    do {                                            \
+        if ((x) != hipSuccess) {                    \
+            eqd_set_error("HIP runtime call failed: %s", #x); \
+            return EQD_ERR_LAUNCH;                  \
+        }                                           \
+    } while (0)
+
 #define RC(x)                 \
     do {                      \
         int rc_ = (x);        \
@@ -249,13 +297,14 @@ extern "C" size_t eqd_model_scratch_bytes(const EqdModelDesc* m, const EqdGraph*
 extern "C" int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const float* const* params,
                                  const float* svd_draws, float* lig_out, float* Y_lig, float* Y_rec, float* T,
                                  float* b, int32_t* svd_status, void* saved, size_t saved_bytes, void* scratch,
-                                 size_t scratch_bytes, void* stream) {
+                                 size_t scratch_bytes, void* stream, void* ctx) {
     RC(eqd_model_check(m, g));
     if (!params || !lig_out || !Y_lig || !Y_rec || !T || !b || !svd_status) {
         eqd_set_error("eqd_model_forward: NULL argument");
         return EQD_ERR_NULL;
     }
     hipStream_t st = (hipStream_t)stream;
+    EqdCtx* cx = (EqdCtx*)ctx;
     const Dims D = make_dims(m, g);
     EqdArena A(saved ? saved : scratch, saved ? saved_bytes : scratch_bytes);
     Saved S;
@@ -290,15 +339,21 @@ extern "C" int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const
             lin_src(jobs[nj], 0, h, d, d, p[P_WV], d, 1); jobs[nj].nsrc = 1; ++nj;
         }
         RC(eqd_linear(jobs, nj, st));
-        // ---- edge messages + coordinates --------------------------------------------------------
-        EqdEdgeParams ep = edge_params(D, m, l, p);
-        RC(eqd_edge_message_fwd(g, &ep, Ls.P, Ls.Q, S.x[l], Ls.aggr_msg, S.x[l + 1], st));
-        // ---- cross attention ------------------------------------------------------------------------
+        // ---- cross attention (on the auxiliary stream when a context is given) || edge messages ----------
+        hipStream_t sat = (cx && m->cross_msgs) ? cx->sa : st;
+        if (sat != st) {
+            HIPOK(hipEventRecord(cx->fork, st));
+            HIPOK(hipStreamWaitEvent(sat, cx->fork, 0));
+        }
         if (m->cross_msgs) {
-            RC(eqd_cross_attention_fwd(g, d, Ls.qa, Ls.ka, Ls.va, Ls.aggr_cross, Ls.lse, st));
+            RC(eqd_cross_attention_fwd(g, d, Ls.qa, Ls.ka, Ls.va, Ls.aggr_cross, Ls.lse, sat));
         } else {
             if (hipMemsetAsync(Ls.aggr_cross, 0, (size_t)N * d * sizeof(float), st) != hipSuccess) return EQD_ERR_LAUNCH;
         }
+        if (sat != st) HIPOK(hipEventRecord(cx->join_a, sat));
+        EqdEdgeParams ep = edge_params(D, m, l, p);
+        RC(eqd_edge_message_fwd(g, &ep, Ls.P, Ls.Q, S.x[l], Ls.aggr_msg, S.x[l + 1], st));
+        if (sat != st) HIPOK(hipStreamWaitEvent(st, cx->join_a, 0));
         // ---- node update: node_mlp([h, aggr_msg, aggr_cross, h0]) with skip ----------------------------
         EqdLinJob j1 = lin_job(N, d, Ls.a1n, d, slope, eps);
         const int ldn = D.ldwn(l);
@@ -340,13 +395,14 @@ extern "C" int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const
 extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, const float* const* params,
                                   const float* d_lig, const float* d_Ylig, const float* d_Yrec, const float* d_T,
                                   const float* d_b, float* grad_flat, const int64_t* grad_offsets, const void* saved,
-                                  size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream) {
+                                  size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream, void* ctx) {
     RC(eqd_model_check(m, g));
     if (!params || !grad_flat || !grad_offsets || !saved || !scratch) {
         eqd_set_error("eqd_model_backward: NULL argument");
         return EQD_ERR_NULL;
     }
     hipStream_t st = (hipStream_t)stream;
+    EqdCtx* cx = (EqdCtx*)ctx;
     const Dims D = make_dims(m, g);
     EqdArena As(const_cast<void*>(saved), saved_bytes);
     Saved S;
@@ -407,6 +463,10 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
         const bool skip = (d == D.dh);
         const float alpha = skip ? m->skip_weight_h : 1.f;
         const int ldn = D.ldwn(l);
+        const int par = l & 1;
+        float *dz = W.dz2[par], *dq = W.dq2[par], *dk = W.dk2[par], *dv = W.dv2[par], *dP = W.dP2[par], *dQ = W.dQ2[par];
+        hipStream_t sa = (cx && m->cross_msgs) ? cx->sa : st;   // attention branch
+        hipStream_t sc = cx ? cx->sc : st;                       // node-level weight-gradient GEMMs
         // node_mlp.4 backward: da1n = alpha dH Wn2
         {
             EqdLinJob j = lin_job(N, d, W.da1n, d, slope, eps);
@@ -414,61 +474,79 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
             j.nsrc = 1; j.alpha = alpha;
             RC(eqd_linear(&j, 1, st));
         }
-        RC(eqd_launch_ln_act_bwd(Ls.y_act, W.da1n, p[P_NLG], N, d, d, slope, eps, W.dz, gp[P_NLG], gp[P_NLB], W.ln_part,
+        RC(eqd_launch_ln_act_bwd(Ls.y_act, W.da1n, p[P_NLG], N, d, d, slope, eps, dz, gp[P_NLG], gp[P_NLB], W.ln_part,
                                  st));
         // node_mlp.0 backward wrt aggr_msg, aggr_cross, h0 (the h part joins the big dh job below)
         {
             EqdLinJob jobs[3];
             int nj = 0;
             jobs[nj] = lin_job(N, 64, W.d_aggr_msg, 64, slope, eps);
-            lin_src(jobs[nj], 0, W.dz, d, d, p[P_WN1] + d, 1, ldn); jobs[nj].nsrc = 1; ++nj;
+            lin_src(jobs[nj], 0, dz, d, d, p[P_WN1] + d, 1, ldn); jobs[nj].nsrc = 1; ++nj;
             if (m->cross_msgs) {
                 jobs[nj] = lin_job(N, d, W.d_aggr_cross, d, slope, eps);
-                lin_src(jobs[nj], 0, W.dz, d, d, p[P_WN1] + d + 64, 1, ldn); jobs[nj].nsrc = 1; ++nj;
+                lin_src(jobs[nj], 0, dz, d, d, p[P_WN1] + d + 64, 1, ldn); jobs[nj].nsrc = 1; ++nj;
             }
             jobs[nj] = lin_job(N, D.d0, W.dh0acc, D.d0, slope, eps);
-            lin_src(jobs[nj], 0, W.dz, d, d, p[P_WN1] + 2 * d + 64, 1, ldn); jobs[nj].nsrc = 1;
+            lin_src(jobs[nj], 0, dz, d, d, p[P_WN1] + 2 * d + 64, 1, ldn); jobs[nj].nsrc = 1;
             jobs[nj].R = W.dh0acc; jobs[nj].ldr = D.d0; jobs[nj].beta = 1.f; ++nj;
             RC(eqd_linear(jobs, nj, st));
         }
-        if (m->cross_msgs)
-            RC(eqd_cross_attention_bwd(g, d, Ls.qa, Ls.ka, Ls.va, Ls.aggr_cross, Ls.lse, W.d_aggr_cross, W.dq, W.dk, W.dv,
-                                       W.delta, st));
-        // edge backward
+        // ---- fork: attention backward (sa) || early weight-gradient GEMMs (sc) || edge backward (st) --------
+        EqdAtbJob ajobs[16];
+        const int na = node_atb_jobs(D, l, m, &S, dHcur, dz, dP, dQ, dq, dk, dv, gp, ajobs);
+        const int n_early = 4 + (m->cross_msgs ? 1 : 0);   // node_mlp.4 and the node_mlp.0 column segments
+        if (cx) {
+            HIPOK(hipEventRecord(cx->fork, st));
+            if (sa != st) HIPOK(hipStreamWaitEvent(sa, cx->fork, 0));
+            HIPOK(hipStreamWaitEvent(sc, cx->fork, 0));
+        }
+        if (m->cross_msgs) {
+            RC(eqd_cross_attention_bwd(g, d, Ls.qa, Ls.ka, Ls.va, Ls.aggr_cross, Ls.lse, W.d_aggr_cross, dq, dk, dv,
+                                       W.delta, sa));
+            if (sa != st) HIPOK(hipEventRecord(cx->join_a, sa));
+        }
+        if (cx) RC(eqd_atb(ajobs, n_early, W.atb_part, W.atb_bytes, sc));
         {
             EqdEdgeParams ep = edge_params(D, m, l, p);
             EqdEdgeGrads eg;
             memset(&eg, 0, sizeof(eg));
             eg.dW1 = gp[P_W1]; eg.ldw1 = D.ldw1(l); eg.dln_g = gp[P_LNG]; eg.dln_b = gp[P_LNB]; eg.dW2 = gp[P_W2];
             eg.db2 = gp[P_B2]; eg.dWc1 = gp[P_WC1]; eg.dbc1 = gp[P_BC1]; eg.dwc2 = gp[P_WC2]; eg.dbc2 = gp[P_BC2];
-            RC(eqd_edge_message_bwd(g, &ep, Ls.P, Ls.Q, S.x[l], W.d_aggr_msg, dXcur, W.dP, W.dQ, dXnext, &eg, W.edge_ws,
+            RC(eqd_edge_message_bwd(g, &ep, Ls.P, Ls.Q, S.x[l], W.d_aggr_msg, dXcur, dP, dQ, dXnext, &eg, W.edge_ws,
                                     W.edge_ws_bytes, st));
         }
+        if (sa != st) HIPOK(hipStreamWaitEvent(st, cx->join_a, 0));
+        // the previous layer's weight-gradient GEMMs still read the buffer dHnext is about to overwrite
+        if (cx && l < D.L - 1) HIPOK(hipStreamWaitEvent(st, cx->join_c[(l + 1) & 1], 0));
         // dh = dz Wn1[:, :d] + dP W1a + dQ W1b + (dq . lrelu'(qa)) Wq + (dk . lrelu'(ka)) Wk + dv Wv + (1-s) dH
         {
             EqdLinJob j = lin_job(N, d, dHnext, d, slope, eps);
             int ns = 0;
-            lin_src(j, ns++, W.dz, d, d, p[P_WN1], 1, ldn);
-            lin_src(j, ns++, W.dP, 64, 64, p[P_W1], 1, D.ldw1(l));
-            lin_src(j, ns++, W.dQ, 64, 64, p[P_W1] + d, 1, D.ldw1(l));
+            lin_src(j, ns++, dz, d, d, p[P_WN1], 1, ldn);
+            lin_src(j, ns++, dP, 64, 64, p[P_W1], 1, D.ldw1(l));
+            lin_src(j, ns++, dQ, 64, 64, p[P_W1] + d, 1, D.ldw1(l));
             if (m->cross_msgs) {
-                lin_src(j, ns++, W.dq, d, d, p[P_WQ], 1, d, Ls.qa);
-                lin_src(j, ns++, W.dk, d, d, p[P_WK], 1, d, Ls.ka);
-                lin_src(j, ns++, W.dv, d, d, p[P_WV], 1, d);
+                lin_src(j, ns++, dq, d, d, p[P_WQ], 1, d, Ls.qa);
+                lin_src(j, ns++, dk, d, d, p[P_WK], 1, d, Ls.ka);
+                lin_src(j, ns++, dv, d, d, p[P_WV], 1, d);
             }
             j.nsrc = ns;
             if (skip) { j.R = dHcur; j.ldr = D.dh; j.beta = 1.f - m->skip_weight_h; }
             RC(eqd_linear(&j, 1, st));
         }
-        // weight gradients of the node-level Linears
-        {
-            EqdAtbJob jobs[16];
-            int n = node_atb_jobs(D, l, m, &S, dHcur, W.dz, W.dP, W.dQ, W.dq, W.dk, W.dv, gp, jobs);
-            RC(eqd_atb(jobs, n, W.atb_part, W.atb_bytes, st));
+        // remaining weight gradients (need dP, dQ, dq, dk, dv): behind the main stream on sc
+        if (cx) {
+            HIPOK(hipEventRecord(cx->fork2, st));
+            HIPOK(hipStreamWaitEvent(sc, cx->fork2, 0));
+            RC(eqd_atb(ajobs + n_early, na - n_early, W.atb_part, W.atb_bytes, sc));
+            HIPOK(hipEventRecord(cx->join_c[par], sc));
+        } else {
+            RC(eqd_atb(ajobs, na, W.atb_part, W.atb_bytes, st));
         }
         float* t = dHcur; dHcur = dHnext; dHnext = t;
         t = dXcur; dXcur = dXnext; dXnext = t;
     }
+    if (cx) HIPOK(hipStreamWaitEvent(st, cx->join_c[0], 0));   // layer 0 ran last on the weight-gradient stream
     // h[0] = h0 feeds layer 0 directly as well as every layer's node_mlp
     RC(eqd_launch_axpy(W.dh0acc, dHcur, 1.f, (size_t)N * D.d0, st));
     RC(eqd_launch_embed_bwd(g, W.dh0acc, D.d0, m->d_emb, ggrad[G_EMB], W.emb_part, st));

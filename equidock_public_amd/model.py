@@ -149,7 +149,7 @@ class _IEGMNFunction(torch.autograd.Function):
         _lib.check(lib.eqd_model_forward(
             C.byref(desc), C.byref(gs), ptrs, _lib.ptr(svd_draws), _lib.ptr(lig), _lib.ptr(Yl), _lib.ptr(Yr),
             _lib.ptr(T), _lib.ptr(b), _lib.ptr(status), _lib.ptr(saved), C.c_size_t(sb if need_grad else 0),
-            _lib.ptr(scratch), C.c_size_t(wb), _lib.stream_ptr(dev)))
+            _lib.ptr(scratch), C.c_size_t(wb), _lib.stream_ptr(dev), _lib.exec_ctx(dev)))
         ctx.packed, ctx.desc, ctx.table_idx, ctx.saved, ctx.sb, ctx.wb = packed, desc, table_idx, saved, sb, wb
         ctx.tensors = tensors
         ctx.flat_state = flat_state
@@ -183,7 +183,7 @@ class _IEGMNFunction(torch.autograd.Function):
         _lib.check(lib.eqd_model_backward(
             C.byref(desc), C.byref(gs), ptrs, _lib.ptr(d_lig), _lib.ptr(d_Yl), _lib.ptr(d_Yr), _lib.ptr(d_T),
             _lib.ptr(d_b), _lib.ptr(flat), goffs, _lib.ptr(ctx.saved), C.c_size_t(ctx.sb), _lib.ptr(scratch),
-            C.c_size_t(ctx.wb), _lib.stream_ptr(dev)))
+            C.c_size_t(ctx.wb), _lib.stream_ptr(dev), _lib.exec_ctx(dev)))
         if ctx.flat_state is not None:
             return (None,) * (6 + len(tensors))
         grads = tuple(flat[o:o + t.numel()].view(t.shape) for o, t in zip(offs, tensors))

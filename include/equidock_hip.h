@@ -102,6 +102,14 @@ typedef struct EqdModelDesc {
  * (names: rigid_docking_model.py:119-159, 382, 427-438).  With shared layers the same pointers
  * repeat for layers 1..L-1. */
 
+/* Optional execution context: two auxiliary HIP streams + events that let eqd_model_forward/backward
+ * overlap the independent branches of a layer (edge messages || cross attention || weight-gradient
+ * GEMMs).  Created and destroyed by the caller (one per device); all auxiliary work is joined back
+ * into the caller's stream before the functions return, so stream-ordered allocators stay correct.
+ * Passing ctx = NULL runs everything on the caller's stream. */
+int eqd_ctx_create(void** ctx);
+int eqd_ctx_destroy(void* ctx);
+
 /* workspace sizes (bytes) for a graph of the given dimensions */
 size_t eqd_model_saved_bytes(const EqdModelDesc* m, const EqdGraph* g);    /* forward -> backward state */
 size_t eqd_model_scratch_bytes(const EqdModelDesc* m, const EqdGraph* g);  /* transient, either pass */
@@ -116,7 +124,7 @@ int eqd_model_check(const EqdModelDesc* m, const EqdGraph* g);
 int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const float* const* params,
                       const float* svd_draws,
                       float* lig_out, float* Y_lig, float* Y_rec, float* T, float* b, int32_t* svd_status,
-                      void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream);
+                      void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream, void* ctx);
 
 /* Backward of the above (the autograd the reference gets from loss.backward(), src/train.py:154).
  * d_* are gradients w.r.t. the five outputs (any may be NULL = zero).  Parameter gradients are
@@ -126,7 +134,8 @@ int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, const float* co
                        const float* d_lig, const float* d_Ylig, const float* d_Yrec, const float* d_T,
                        const float* d_b,
                        float* grad_flat, const int64_t* grad_offsets,
-                       const void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream);
+                       const void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream,
+                       void* ctx);
 
 /* ---------------------------------------------------------------------------------------------
  * Operator-level entry points (used by the model functions above; exported for unit parity

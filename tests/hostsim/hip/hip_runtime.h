@@ -44,6 +44,15 @@ static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMem
     memmove(d, s, n); return hipSuccess;
 }
 
+typedef void* hipEvent_t;
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+
 struct float4 { float x, y, z, w; };
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 struct float2 { float x, y; };
