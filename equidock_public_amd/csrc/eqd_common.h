@@ -95,27 +95,49 @@ struct EqdArena {
 };
 
 // deterministic column reduction of per-block partials: out[i] += sum_p partial[p * pstride + i]
-#define EQD_RED_MAXSEG 8
+#define EQD_RED_MAXSEG 64
 struct EqdRedSeg {
     const float* partial;
     int nparts, pstride, n;
     float* out;
 };
+// segments that accumulate into the SAME output (shared layers) form a chain handled by one
+// workgroup column, so that no two workgroups ever update the same address
 struct EqdRedArg {
     EqdRedSeg s[EQD_RED_MAXSEG];
+    int chain_first[EQD_RED_MAXSEG], chain_len[EQD_RED_MAXSEG];
 };
 int eqd_launch_reduce_segments(const EqdRedSeg* segs, int nseg, hipStream_t st);
+// list of pending reductions, flushed in a few launches at the end of the backward pass
+struct EqdRedList {
+    EqdRedSeg seg[512];
+    int n;
+};
 
 // internal launchers (defined across the .hip files)
 int eqd_launch_vec_reduce(const float* partial, int nparts, int pstride, int n, float* out, hipStream_t st);
 int eqd_launch_embed_fwd(const EqdGraph* g, const float* emb, int d_emb, int use_mu, float* h0, int ld, hipStream_t st);
-int eqd_launch_embed_bwd(const EqdGraph* g, const float* dh0, int ld, int d_emb, float* demb, float* partial,
-                         hipStream_t st);
+int eqd_launch_embed_bwd(const EqdGraph* g, const float* dh0, const float* dh0b, int ld, int d_emb, float* demb,
+                         float* partial, hipStream_t st);
 size_t eqd_embed_bwd_partial_floats(const EqdGraph* g, int d_emb);
 int eqd_launch_csc_gather(const EqdGraph* g, const float* dz, const float* dxrel, float* dP, float* dx, hipStream_t st);
 int eqd_launch_ln_act_bwd(const float* y_act, const float* d_out, const float* gamma, int rows, int d, int ld,
                           float slope, float eps, float* dz, float* dgamma, float* dbeta, float* partial,
-                          hipStream_t st);
+                          hipStream_t st, EqdRedList* defer = nullptr);
+int eqd_edge_message_bwd_impl(const EqdGraph* g, const EqdEdgeParams* p, const float* P, const float* Q, const float* x,
+                              const float* d_aggr_msg, const float* d_xnew, float* dP, float* dQ, float* dx,
+                              const EqdEdgeGrads* grads, void* workspace, size_t ws_bytes, hipStream_t st,
+                              float* vecp_override, EqdRedList* defer);
+size_t eqd_edge_bwd_vecp_floats(const EqdGraph* g);
+int eqd_keypoint_pool_fwd_impl(const EqdGraph* g, int n_heads, const float* Wk, const float* Wq, const float* qmean,
+                               const float* H, const float* Z, float* Y, float* Y_lig_out, float* Y_rec_out,
+                               float* scores, float* lse, float* qp, float* u, hipStream_t st);
+int eqd_kabsch_fwd_impl(int n_pairs, int n_heads, const float* Y, const float* svd_draws, int svd_seed, float* T,
+                        float* T2, float* b, float* A_out, int32_t* status, hipStream_t st);
+int eqd_kabsch_bwd_impl(int n_pairs, int n_heads, const float* Y, const float* A, const float* T, const float* dT,
+                        const float* db, const float* dYl_ext, const float* dYr_ext, float* dY, hipStream_t st);
+int eqd_rigid_apply_bwd_impl(const EqdGraph* g, const float* d_lig, const float* dT_ext, const float* db_ext, float* dT,
+                             float* db, hipStream_t st);
 size_t eqd_ln_act_bwd_partial_floats(int rows, int d);
 int eqd_launch_fill(float* p, float v, size_t n, hipStream_t st);
 int eqd_launch_axpy(float* y, const float* x, float a, size_t n, hipStream_t st);

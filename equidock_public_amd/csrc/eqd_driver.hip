@@ -138,7 +138,8 @@ struct Scratch {
     float *dY, *dT, *db, *dscores, *du, *dHk, *dqm_part, *dhm;
     void* edge_ws; size_t edge_ws_bytes;
     float* atb_part; size_t atb_bytes;
-    float* ln_part;
+    float* ln_part; size_t ln_part_stride;     // per layer (reductions are deferred to the end of the pass)
+    float* vecp_all; size_t vecp_stride;
     float* emb_part;
 };
 
@@ -186,7 +187,10 @@ void carve_scratch(const Dims& D, const EqdModelDesc* m, const EqdGraph* g, EqdA
     }
     W.atb_bytes = ab;
     W.atb_part = (float*)A.take<char>(ab);
-    W.ln_part = A.take<float>(eqd_ln_act_bwd_partial_floats(D.N, 80));
+    W.ln_part_stride = eqd_align_up(eqd_ln_act_bwd_partial_floats(D.N, 80) * sizeof(float)) / sizeof(float);
+    W.ln_part = A.take<float>(W.ln_part_stride * D.L);
+    W.vecp_stride = eqd_align_up(eqd_edge_bwd_vecp_floats(g) * sizeof(float)) / sizeof(float);
+    W.vecp_all = A.take<float>(W.vecp_stride * D.L);
     W.emb_part = A.take<float>(eqd_embed_bwd_partial_floats(g, m->d_emb));
 }
 
@@ -380,15 +384,10 @@ extern "C" int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const
     jm.nsrc = 1; jm.bias = gp[G_BM]; jm.act = 1;
     RC(eqd_linear(&jm, 1, st));
     RC(eqd_launch_seg_mean(g, S.hm, S.qmean, st));
-    RC(eqd_keypoint_pool_fwd(g, D.K, gp[G_WK], gp[G_WQ], S.qmean, H, Z, S.Y, S.scores, S.klse, S.qp, S.u, st));
-    RC(eqd_kabsch_fwd(D.B, D.K, S.Y, svd_draws, m->svd_seed, S.T, b, S.A, svd_status, st));
+    RC(eqd_keypoint_pool_fwd_impl(g, D.K, gp[G_WK], gp[G_WQ], S.qmean, H, Z, S.Y, Y_lig, Y_rec, S.scores, S.klse, S.qp,
+                                  S.u, st));
+    RC(eqd_kabsch_fwd_impl(D.B, D.K, S.Y, svd_draws, m->svd_seed, S.T, T, b, S.A, svd_status, st));
     RC(eqd_rigid_apply_fwd(g, S.T, b, lig_out, st));
-    const size_t yb = (size_t)D.B * D.K * 3 * sizeof(float);
-    if (hipMemcpyAsync(Y_lig, S.Y, yb, hipMemcpyDeviceToDevice, st) != hipSuccess) return EQD_ERR_LAUNCH;
-    if (hipMemcpyAsync(Y_rec, S.Y + (size_t)D.B * D.K * 3, yb, hipMemcpyDeviceToDevice, st) != hipSuccess)
-        return EQD_ERR_LAUNCH;
-    if (hipMemcpyAsync(T, S.T, (size_t)D.B * 9 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
-        return EQD_ERR_LAUNCH;
     return EQD_OK;
 }
 
@@ -423,17 +422,14 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
     float* const* ggrad = gptr + (size_t)EQD_PARAMS_PER_LAYER * D.L;
 
     // ---- head -------------------------------------------------------------------------------------------
-    const size_t yb = (size_t)B * K * 3 * sizeof(float);
-    if (d_Ylig) { if (hipMemcpyAsync(W.dY, d_Ylig, yb, hipMemcpyDeviceToDevice, st) != hipSuccess) return EQD_ERR_LAUNCH; }
-    else if (hipMemsetAsync(W.dY, 0, yb, st) != hipSuccess) return EQD_ERR_LAUNCH;
-    if (d_Yrec) { if (hipMemcpyAsync(W.dY + (size_t)B * K * 3, d_Yrec, yb, hipMemcpyDeviceToDevice, st) != hipSuccess) return EQD_ERR_LAUNCH; }
-    else if (hipMemsetAsync(W.dY + (size_t)B * K * 3, 0, yb, st) != hipSuccess) return EQD_ERR_LAUNCH;
-    if (d_T) { if (hipMemcpyAsync(W.dT, d_T, (size_t)B * 9 * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return EQD_ERR_LAUNCH; }
-    else if (hipMemsetAsync(W.dT, 0, (size_t)B * 9 * 4, st) != hipSuccess) return EQD_ERR_LAUNCH;
-    if (d_b) { if (hipMemcpyAsync(W.db, d_b, (size_t)B * 3 * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return EQD_ERR_LAUNCH; }
-    else if (hipMemsetAsync(W.db, 0, (size_t)B * 3 * 4, st) != hipSuccess) return EQD_ERR_LAUNCH;
-    if (d_lig) RC(eqd_rigid_apply_bwd(g, d_lig, W.dT, W.db, st));
-    RC(eqd_kabsch_bwd(B, K, S.Y, S.A, S.T, W.dT, W.db, W.dY, st));
+    EqdRedList* defer = new EqdRedList();
+    defer->n = 0;
+    struct DeferGuard {
+        EqdRedList* p;
+        ~DeferGuard() { delete p; }
+    } defer_guard{defer};
+    RC(eqd_rigid_apply_bwd_impl(g, d_lig, d_T, d_b, W.dT, W.db, st));
+    RC(eqd_kabsch_bwd_impl(B, K, S.Y, S.A, S.T, W.dT, W.db, d_Ylig, d_Yrec, W.dY, st));
     const float* H = S.h[D.L];
     const float* Z = S.x[D.L];
     float* dXcur = W.dXa;   // grad wrt x[L]
@@ -452,8 +448,6 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
         EqdAtbJob a = atb_job(W.dhm, 64, 64, H, D.dh, D.dh, N, ggrad[G_WM], D.dh, ggrad[G_BM], slope, S.hm);
         RC(eqd_atb(&a, 1, W.atb_part, W.atb_bytes, st));
     }
-    if (hipMemsetAsync(W.dh0acc, 0, (size_t)N * D.d0 * sizeof(float), st) != hipSuccess) return EQD_ERR_LAUNCH;
-
     // ---- layers, last to first ----------------------------------------------------------------------------
     for (int l = D.L - 1; l >= 0; --l) {
         const float* const* p = params + (size_t)EQD_PARAMS_PER_LAYER * l;
@@ -474,8 +468,8 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
             j.nsrc = 1; j.alpha = alpha;
             RC(eqd_linear(&j, 1, st));
         }
-        RC(eqd_launch_ln_act_bwd(Ls.y_act, W.da1n, p[P_NLG], N, d, d, slope, eps, dz, gp[P_NLG], gp[P_NLB], W.ln_part,
-                                 st));
+        RC(eqd_launch_ln_act_bwd(Ls.y_act, W.da1n, p[P_NLG], N, d, d, slope, eps, dz, gp[P_NLG], gp[P_NLB],
+                                 W.ln_part + (size_t)l * W.ln_part_stride, st, defer));
         // node_mlp.0 backward wrt aggr_msg, aggr_cross, h0 (the h part joins the big dh job below)
         {
             EqdLinJob jobs[3];
@@ -488,7 +482,10 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
             }
             jobs[nj] = lin_job(N, D.d0, W.dh0acc, D.d0, slope, eps);
             lin_src(jobs[nj], 0, dz, d, d, p[P_WN1] + 2 * d + 64, 1, ldn); jobs[nj].nsrc = 1;
-            jobs[nj].R = W.dh0acc; jobs[nj].ldr = D.d0; jobs[nj].beta = 1.f; ++nj;
+            if (l < D.L - 1) {      // the last layer (processed first) initialises the accumulator
+                jobs[nj].R = W.dh0acc; jobs[nj].ldr = D.d0; jobs[nj].beta = 1.f;
+            }
+            ++nj;
             RC(eqd_linear(jobs, nj, st));
         }
         // ---- fork: attention backward (sa) || early weight-gradient GEMMs (sc) || edge backward (st) --------
@@ -512,8 +509,8 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
             memset(&eg, 0, sizeof(eg));
             eg.dW1 = gp[P_W1]; eg.ldw1 = D.ldw1(l); eg.dln_g = gp[P_LNG]; eg.dln_b = gp[P_LNB]; eg.dW2 = gp[P_W2];
             eg.db2 = gp[P_B2]; eg.dWc1 = gp[P_WC1]; eg.dbc1 = gp[P_BC1]; eg.dwc2 = gp[P_WC2]; eg.dbc2 = gp[P_BC2];
-            RC(eqd_edge_message_bwd(g, &ep, Ls.P, Ls.Q, S.x[l], W.d_aggr_msg, dXcur, dP, dQ, dXnext, &eg, W.edge_ws,
-                                    W.edge_ws_bytes, st));
+            RC(eqd_edge_message_bwd_impl(g, &ep, Ls.P, Ls.Q, S.x[l], W.d_aggr_msg, dXcur, dP, dQ, dXnext, &eg, W.edge_ws,
+                                         W.edge_ws_bytes, st, W.vecp_all + (size_t)l * W.vecp_stride, defer));
         }
         if (sa != st) HIPOK(hipStreamWaitEvent(st, cx->join_a, 0));
         // the previous layer's weight-gradient GEMMs still read the buffer dHnext is about to overwrite
@@ -547,8 +544,9 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
         t = dXcur; dXcur = dXnext; dXnext = t;
     }
     if (cx) HIPOK(hipStreamWaitEvent(st, cx->join_c[0], 0));   // layer 0 ran last on the weight-gradient stream
-    // h[0] = h0 feeds layer 0 directly as well as every layer's node_mlp
-    RC(eqd_launch_axpy(W.dh0acc, dHcur, 1.f, (size_t)N * D.d0, st));
-    RC(eqd_launch_embed_bwd(g, W.dh0acc, D.d0, m->d_emb, ggrad[G_EMB], W.emb_part, st));
+    // deferred LayerNorm / coordinate-MLP vector reductions of all layers: a few launches instead of 2 per layer
+    RC(eqd_launch_reduce_segments(defer->seg, defer->n, st));
+    // h[0] = h0 feeds layer 0 directly (dHcur) as well as every layer's node_mlp (dh0acc)
+    RC(eqd_launch_embed_bwd(g, W.dh0acc, dHcur, D.d0, m->d_emb, ggrad[G_EMB], W.emb_part, st));
     return EQD_OK;
 }

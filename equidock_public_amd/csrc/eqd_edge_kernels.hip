@@ -389,6 +389,17 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void k_edge_fwd(EqdGraph G, EqdEdge
     }
 }
 
+// Smallest grid with the minimal number of tile rounds: with one workgroup per CU (LDS-bound) the
+// makespan is ceil(tiles / (256 * waves)) tile times whatever the grid, so use as few CUs as that allows
+// and leave the rest to the kernels that run concurrently on the auxiliary streams.
+static int edge_grid(int n_tiles, int waves) {
+    if (n_tiles <= 0) return 1;
+    const int rounds = (n_tiles + 256 * waves - 1) / (256 * waves);
+    int blocks = (n_tiles + waves * rounds - 1) / (waves * rounds);
+    if (blocks > 256) blocks = 256;
+    return blocks < 1 ? 1 : blocks;
+}
+
 extern "C" int eqd_edge_message_fwd(const EqdGraph* g, const EqdEdgeParams* p, const float* P, const float* Q,
                                     const float* x, float* aggr_msg, float* x_new, void* stream) {
     if (!g || !p || !P || !Q || !x || !aggr_msg || !x_new) {
@@ -396,8 +407,7 @@ extern "C" int eqd_edge_message_fwd(const EqdGraph* g, const EqdEdgeParams* p, c
         return EQD_ERR_NULL;
     }
     if (g->n_tiles <= 0) return EQD_OK;
-    int blocks = (g->n_tiles + FWD_WAVES - 1) / FWD_WAVES;
-    if (blocks > 1024) blocks = 1024;
+    const int blocks = edge_grid(g->n_tiles, FWD_WAVES);
     hipLaunchKernelGGL(k_edge_fwd, dim3(blocks), dim3(64 * FWD_WAVES), 0, (hipStream_t)stream, *g, *p, P, Q, x, aggr_msg,
                        x_new);
     return eqd_check_launch("k_edge_fwd");
@@ -631,12 +641,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
     for (int i = lane; i < 256; i += 64) vp[i] = vacc[wave][i];
 }
 
-static int edge_bwd_blocks(const EqdGraph* g) {
-    int blocks = (g->n_tiles + BWD_WAVES - 1) / BWD_WAVES;
-    if (blocks > 512) blocks = 512;
-    if (blocks < 1) blocks = 1;
-    return blocks;
-}
+static int edge_bwd_blocks(const EqdGraph* g) { return edge_grid(g->n_tiles, BWD_WAVES); }
 
 static void edge_atb_jobs(const EqdGraph* g, const EqdEdgeParams* p, const EqdEdgeGrads* gr, const EdgeBwdWs& W,
                           EqdAtbJob* jobs) {
@@ -712,20 +717,30 @@ extern "C" int eqd_edge_message_bwd_kernel_only(const EqdGraph* g, const EqdEdge
     return eqd_check_launch("k_edge_bwd");
 }
 
+size_t eqd_edge_bwd_vecp_floats(const EqdGraph* g) { return (size_t)edge_bwd_blocks(g) * BWD_WAVES * 256; }
+
 extern "C" int eqd_edge_message_bwd(const EqdGraph* g, const EqdEdgeParams* p, const float* P, const float* Q,
                                     const float* x, const float* d_aggr_msg, const float* d_xnew, float* dP,
                                     float* dQ, float* dx, const EqdEdgeGrads* grads, void* workspace,
                                     size_t ws_bytes, void* stream) {
+    return eqd_edge_message_bwd_impl(g, p, P, Q, x, d_aggr_msg, d_xnew, dP, dQ, dx, grads, workspace, ws_bytes,
+                                     (hipStream_t)stream, nullptr, nullptr);
+}
+
+int eqd_edge_message_bwd_impl(const EqdGraph* g, const EqdEdgeParams* p, const float* P, const float* Q, const float* x,
+                              const float* d_aggr_msg, const float* d_xnew, float* dP, float* dQ, float* dx,
+                              const EqdEdgeGrads* grads, void* workspace, size_t ws_bytes, hipStream_t st,
+                              float* vecp_override, EqdRedList* defer) {
     if (!g || !p || !P || !Q || !x || !d_aggr_msg || !d_xnew || !dP || !dQ || !dx || !grads) {
         eqd_set_error("eqd_edge_message_bwd: NULL argument");
         return EQD_ERR_NULL;
     }
-    hipStream_t st = (hipStream_t)stream;
     EqdArena A(workspace, ws_bytes);
     EdgeBwdWs W;
     float* part = nullptr;
     size_t pb = 0;
     edge_bwd_carve(g, A, &W, &part, &pb);
+    if (vecp_override) W.vecp = vecp_override;
     if (!A.ok) {
         eqd_set_error("eqd_edge_message_bwd: workspace too small (%zu needed, %zu given)", A.off, ws_bytes);
         return EQD_ERR_WORKSPACE;
@@ -739,7 +754,11 @@ extern "C" int eqd_edge_message_bwd(const EqdGraph* g, const EqdEdgeParams* p, c
         const int nw = blocks * BWD_WAVES;
         EqdRedSeg segs[4] = {{W.vecp, nw, 256, 64, grads->dln_g}, {W.vecp + 64, nw, 256, 64, grads->dln_b},
                              {W.vecp + 128, nw, 256, 64, grads->dwc2}, {W.vecp + 192, nw, 256, 1, grads->dbc2}};
-        if ((rc = eqd_launch_reduce_segments(segs, 4, st))) return rc;
+        if (defer && defer->n + 4 <= 512) {
+            for (int i = 0; i < 4; ++i) defer->seg[defer->n++] = segs[i];
+        } else if ((rc = eqd_launch_reduce_segments(segs, 4, st))) {
+            return rc;
+        }
     }
     EqdAtbJob jobs[4];
     edge_atb_jobs(g, p, grads, W, jobs);

@@ -87,7 +87,8 @@ __device__ __forceinline__ float block_reduce_max(float v, float* red) {
 __global__ __launch_bounds__(EQD_BLOCK) void k_keypoint(const int32_t* __restrict__ seg_off, int K,
                                                         const float* __restrict__ u, const float* __restrict__ H,
                                                         const float* __restrict__ Z, float* __restrict__ Y,
-                                                        float* __restrict__ scores, float* __restrict__ lse) {
+                                                        float* __restrict__ Yl_out, float* __restrict__ Yr_out,
+                                                        int B, float* __restrict__ scores, float* __restrict__ lse) {
     __shared__ float su[64];
     __shared__ float red[4];
     const int s = blockIdx.x, k = blockIdx.y, t = threadIdx.x;
@@ -123,6 +124,11 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_keypoint(const int32_t* __restric
         const float inv = se > 0.f ? 1.f / se : 0.f;
         float* y = Y + ((size_t)s * K + k) * 3;
         y[0] = y0 * inv; y[1] = y1 * inv; y[2] = y2 * inv;
+        float* yo = s < B ? (Yl_out ? Yl_out + ((size_t)s * K + k) * 3 : nullptr)
+                          : (Yr_out ? Yr_out + ((size_t)(s - B) * K + k) * 3 : nullptr);
+        if (yo) {
+            yo[0] = y0 * inv; yo[1] = y1 * inv; yo[2] = y2 * inv;
+        }
         lse[(size_t)s * K + k] = se > 0.f ? mx + logf(se) : 0.f;
     }
 }
@@ -130,18 +136,23 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_keypoint(const int32_t* __restric
 extern "C" int eqd_keypoint_pool_fwd(const EqdGraph* g, int n_heads, const float* Wk, const float* Wq,
                                      const float* qmean, const float* H, const float* Z, float* Y, float* scores,
                                      float* lse, float* qp, float* u, void* stream) {
+    return eqd_keypoint_pool_fwd_impl(g, n_heads, Wk, Wq, qmean, H, Z, Y, nullptr, nullptr, scores, lse, qp, u,
+                                      (hipStream_t)stream);
+}
+int eqd_keypoint_pool_fwd_impl(const EqdGraph* g, int n_heads, const float* Wk, const float* Wq, const float* qmean,
+                               const float* H, const float* Z, float* Y, float* Y_lig_out, float* Y_rec_out,
+                               float* scores, float* lse, float* qp, float* u, hipStream_t st) {
     if (!g || !Wk || !Wq || !qmean || !H || !Z || !Y || !scores || !lse || !qp || !u) {
         eqd_set_error("eqd_keypoint_pool_fwd: NULL argument");
         return EQD_ERR_NULL;
     }
     if (g->n_pairs == 0) return EQD_OK;
-    hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_head_u, dim3(2 * g->n_pairs, n_heads), dim3(64), 0, st, g->n_pairs, n_heads, Wk, Wq, qmean, qp,
                        u);
     int rc = eqd_check_launch("k_head_u");
     if (rc) return rc;
     hipLaunchKernelGGL(k_keypoint, dim3(2 * g->n_pairs, n_heads), dim3(EQD_BLOCK), 0, st, g->seg_off, n_heads, u, H, Z,
-                       Y, scores, lse);
+                       Y, Y_lig_out, Y_rec_out, g->n_pairs, scores, lse);
     return eqd_check_launch("k_keypoint");
 }
 
@@ -378,8 +389,8 @@ __device__ __forceinline__ float uniform_draw(unsigned seed, unsigned pair, unsi
 }
 
 __global__ void k_kabsch_fwd(int B, int K, const float* __restrict__ Y, const float* __restrict__ draws, int seed,
-                             float* __restrict__ T, float* __restrict__ bvec, float* __restrict__ A_out,
-                             int32_t* __restrict__ status) {
+                             float* __restrict__ T, float* __restrict__ T2, float* __restrict__ bvec,
+                             float* __restrict__ A_out, int32_t* __restrict__ status) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= B) return;
     const float* Yl = Y + (size_t)p * K * 3;
@@ -424,6 +435,7 @@ __global__ void k_kabsch_fwd(int B, int K, const float* __restrict__ Y, const fl
             const double t = U[i][0] * V[j][0] + U[i][1] * V[j][1] + sd * U[i][2] * V[j][2];
             Tm[i][j] = (float)t;
             T[(size_t)p * 9 + i * 3 + j] = (float)t;
+            if (T2) T2[(size_t)p * 9 + i * 3 + j] = (float)t;
             A_out[(size_t)p * 9 + i * 3 + j] = Af[i][j];
         }
     for (int i = 0; i < 3; ++i)
@@ -432,13 +444,17 @@ __global__ void k_kabsch_fwd(int B, int K, const float* __restrict__ Y, const fl
 
 extern "C" int eqd_kabsch_fwd(int n_pairs, int n_heads, const float* Y, const float* svd_draws, int svd_seed, float* T,
                               float* b, float* A_out, int32_t* status, void* stream) {
+    return eqd_kabsch_fwd_impl(n_pairs, n_heads, Y, svd_draws, svd_seed, T, nullptr, b, A_out, status, (hipStream_t)stream);
+}
+int eqd_kabsch_fwd_impl(int n_pairs, int n_heads, const float* Y, const float* svd_draws, int svd_seed, float* T,
+                        float* T2, float* b, float* A_out, int32_t* status, hipStream_t stream) {
     if (!Y || !T || !b || !A_out || !status) {
         eqd_set_error("eqd_kabsch_fwd: NULL argument");
         return EQD_ERR_NULL;
     }
     if (n_pairs <= 0) return EQD_OK;
     hipLaunchKernelGGL(k_kabsch_fwd, dim3((n_pairs + 63) / 64), dim3(64), 0, (hipStream_t)stream, n_pairs, n_heads, Y,
-                       svd_draws, svd_seed, T, b, A_out, status);
+                       svd_draws, svd_seed, T, T2, b, A_out, status);
     return eqd_check_launch("k_kabsch_fwd");
 }
 
@@ -447,6 +463,7 @@ extern "C" int eqd_kabsch_fwd(int n_pairs, int n_heads, const float* Y, const fl
 //   dP_ij = (c_j M_ij - c_i M_ji) / (s_j + c_i c_j s_i)  (i != j),  dA = U dP V^T
 __global__ void k_kabsch_bwd(int B, int K, const float* __restrict__ Y, const float* __restrict__ A_in,
                              const float* __restrict__ T, const float* __restrict__ dT, const float* __restrict__ db,
+                             const float* __restrict__ dYl_ext, const float* __restrict__ dYr_ext, int use_ext,
                              float* __restrict__ dY) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= B) return;
@@ -527,8 +544,14 @@ __global__ void k_kabsch_bwd(int B, int K, const float* __restrict__ Y, const fl
                 gr += dA[i][j] * ((double)Yl[k * 3 + j] - ml[j]);
                 gl += dA[j][i] * ((double)Yr[k * 3 + j] - mr[j]);
             }
-            dYr[k * 3 + i] += (float)(gr - gr_mean[i] + dbv[i] / K);
-            dYl[k * 3 + i] += (float)(gl - gl_mean[i] + dml[i] / K);
+            const float vr = (float)(gr - gr_mean[i] + dbv[i] / K), vl = (float)(gl - gl_mean[i] + dml[i] / K);
+            if (use_ext) {   // dY = external gradient (or 0) + Kabsch path; no pre-initialised buffer needed
+                dYr[k * 3 + i] = vr + (dYr_ext ? dYr_ext[(size_t)p * K * 3 + k * 3 + i] : 0.f);
+                dYl[k * 3 + i] = vl + (dYl_ext ? dYl_ext[(size_t)p * K * 3 + k * 3 + i] : 0.f);
+            } else {
+                dYr[k * 3 + i] += vr;
+                dYl[k * 3 + i] += vl;
+            }
         }
 }
 
@@ -540,7 +563,18 @@ extern "C" int eqd_kabsch_bwd(int n_pairs, int n_heads, const float* Y, const fl
     }
     if (n_pairs <= 0) return EQD_OK;
     hipLaunchKernelGGL(k_kabsch_bwd, dim3((n_pairs + 63) / 64), dim3(64), 0, (hipStream_t)stream, n_pairs, n_heads, Y,
-                       A, T, dT, db, dY);
+                       A, T, dT, db, (const float*)nullptr, (const float*)nullptr, 0, dY);
+    return eqd_check_launch("k_kabsch_bwd");
+}
+int eqd_kabsch_bwd_impl(int n_pairs, int n_heads, const float* Y, const float* A, const float* T, const float* dT,
+                        const float* db, const float* dYl_ext, const float* dYr_ext, float* dY, hipStream_t stream) {
+    if (!Y || !A || !T || !dY) {
+        eqd_set_error("eqd_kabsch_bwd: NULL argument");
+        return EQD_ERR_NULL;
+    }
+    if (n_pairs <= 0) return EQD_OK;
+    hipLaunchKernelGGL(k_kabsch_bwd, dim3((n_pairs + 63) / 64), dim3(64), 0, (hipStream_t)stream, n_pairs, n_heads, Y,
+                       A, T, dT, db, dYl_ext, dYr_ext, 1, dY);
     return eqd_check_launch("k_kabsch_bwd");
 }
 
@@ -569,15 +603,17 @@ extern "C" int eqd_rigid_apply_fwd(const EqdGraph* g, const float* T, const floa
 
 __global__ __launch_bounds__(EQD_BLOCK) void k_apply_bwd(const int32_t* __restrict__ seg_off,
                                                          const float* __restrict__ x0,
-                                                         const float* __restrict__ d_lig, float* __restrict__ dT,
-                                                         float* __restrict__ db) {
+                                                         const float* __restrict__ d_lig,
+                                                         const float* __restrict__ dT_ext,
+                                                         const float* __restrict__ db_ext, int use_ext,
+                                                         float* __restrict__ dT, float* __restrict__ db) {
     __shared__ float red[4];
     const int p = blockIdx.x, t = threadIdx.x;
     const int n0 = seg_off[p], n1 = seg_off[p + 1];
     float acc[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) acc[i] = 0.f;
-    for (int i = n0 + t; i < n1; i += EQD_BLOCK) {
+    for (int i = n0 + t; i < n1 && d_lig; i += EQD_BLOCK) {
         const float g0 = d_lig[(size_t)i * 3], g1 = d_lig[(size_t)i * 3 + 1], g2 = d_lig[(size_t)i * 3 + 2];
         const float x = x0[(size_t)i * 3], y = x0[(size_t)i * 3 + 1], z = x0[(size_t)i * 3 + 2];
         acc[0] += g0 * x; acc[1] += g0 * y; acc[2] += g0 * z;
@@ -589,7 +625,12 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_apply_bwd(const int32_t* __restri
     for (int i = 0; i < 12; ++i) {
         const float s = block_reduce_sum(acc[i], red);
         if (t == 0) {
-            if (i < 9) dT[(size_t)p * 9 + i] += s; else db[(size_t)p * 3 + (i - 9)] += s;
+            if (use_ext) {
+                if (i < 9) dT[(size_t)p * 9 + i] = s + (dT_ext ? dT_ext[(size_t)p * 9 + i] : 0.f);
+                else db[(size_t)p * 3 + (i - 9)] = s + (db_ext ? db_ext[(size_t)p * 3 + (i - 9)] : 0.f);
+            } else {
+                if (i < 9) dT[(size_t)p * 9 + i] += s; else db[(size_t)p * 3 + (i - 9)] += s;
+            }
         }
     }
 }
@@ -600,6 +641,17 @@ extern "C" int eqd_rigid_apply_bwd(const EqdGraph* g, const float* d_lig, float*
     }
     if (g->n_pairs <= 0) return EQD_OK;
     hipLaunchKernelGGL(k_apply_bwd, dim3(g->n_pairs), dim3(EQD_BLOCK), 0, (hipStream_t)stream, g->seg_off, g->x0, d_lig,
+                       (const float*)nullptr, (const float*)nullptr, 0, dT, db);
+    return eqd_check_launch("k_apply_bwd");
+}
+int eqd_rigid_apply_bwd_impl(const EqdGraph* g, const float* d_lig, const float* dT_ext, const float* db_ext, float* dT,
+                             float* db, hipStream_t st) {
+    if (!g || !dT || !db) {
+        eqd_set_error("eqd_rigid_apply_bwd: NULL argument");
+        return EQD_ERR_NULL;
+    }
+    if (g->n_pairs <= 0) return EQD_OK;
+    hipLaunchKernelGGL(k_apply_bwd, dim3(g->n_pairs), dim3(EQD_BLOCK), 0, st, g->seg_off, g->x0, d_lig, dT_ext, db_ext, 1,
                        dT, db);
     return eqd_check_launch("k_apply_bwd");
 }

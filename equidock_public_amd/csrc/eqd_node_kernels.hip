@@ -461,35 +461,67 @@ extern "C" int eqd_atb(const EqdAtbJob* jobs, int njobs, void* partial, size_t p
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_reduce_segments(EqdRedArg A) {
     __shared__ float red[16][64];
-    const EqdRedSeg& S = A.s[blockIdx.y];
+    const int first = A.chain_first[blockIdx.y], len = A.chain_len[blockIdx.y];
     const int c = threadIdx.x & 63, pl = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + c;
+    const int n = A.s[first].n;
     float acc = 0.f;
-    if (i < S.n) {
+    if (i < n) {
+        for (int j = 0; j < len; ++j) {
+            const EqdRedSeg& S = A.s[first + j];
 #pragma unroll 4
-        for (int p = pl; p < S.nparts; p += 16) acc += S.partial[(size_t)p * S.pstride + i];
+            for (int p = pl; p < S.nparts; p += 16) acc += S.partial[(size_t)p * S.pstride + i];
+        }
     }
     red[pl][c] = acc;
     __syncthreads();
-    if (pl == 0 && i < S.n) {
+    if (pl == 0 && i < n) {
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < 16; ++j) s += red[j][c];
-        S.out[i] += s;
+        A.s[first].out[i] += s;
     }
 }
 int eqd_launch_reduce_segments(const EqdRedSeg* segs, int nseg, hipStream_t st) {
-    for (int base = 0; base < nseg; base += EQD_RED_MAXSEG) {
+    // group by output pointer (stable order), then launch whole chains, at most EQD_RED_MAXSEG segments each
+    static thread_local int order[512], cfirst[512], clen[512];
+    static thread_local bool used[512];
+    if (nseg > 512) {
+        eqd_set_error("eqd_launch_reduce_segments: too many segments");
+        return EQD_ERR_SHAPE;
+    }
+    int no = 0, nc = 0;
+    for (int i = 0; i < nseg; ++i) used[i] = false;
+    for (int i = 0; i < nseg; ++i) {
+        if (used[i]) continue;
+        cfirst[nc] = no;
+        for (int j = i; j < nseg; ++j)
+            if (!used[j] && segs[j].out == segs[i].out && segs[j].n == segs[i].n) {
+                used[j] = true;
+                order[no++] = j;
+            }
+        clen[nc] = no - cfirst[nc];
+        if (clen[nc] > EQD_RED_MAXSEG) {
+            eqd_set_error("eqd_launch_reduce_segments: chain too long");
+            return EQD_ERR_SHAPE;
+        }
+        ++nc;
+    }
+    int c0 = 0;
+    while (c0 < nc) {
         EqdRedArg arg;
         memset(&arg, 0, sizeof(arg));
-        const int n = nseg - base < EQD_RED_MAXSEG ? nseg - base : EQD_RED_MAXSEG;
-        int maxn = 0;
-        for (int i = 0; i < n; ++i) {
-            arg.s[i] = segs[base + i];
-            if (arg.s[i].n > maxn) maxn = arg.s[i].n;
+        int ns = 0, nch = 0, maxn = 0;
+        while (c0 < nc && ns + clen[c0] <= EQD_RED_MAXSEG) {
+            arg.chain_first[nch] = ns;
+            arg.chain_len[nch] = clen[c0];
+            for (int j = 0; j < clen[c0]; ++j) arg.s[ns++] = segs[order[cfirst[c0] + j]];
+            if (arg.s[arg.chain_first[nch]].n > maxn) maxn = arg.s[arg.chain_first[nch]].n;
+            ++nch;
+            ++c0;
         }
-        if (maxn <= 0) continue;
-        hipLaunchKernelGGL(k_reduce_segments, dim3((maxn + 63) / 64, n), dim3(1024), 0, st, arg);
+        if (maxn <= 0 || nch == 0) continue;
+        hipLaunchKernelGGL(k_reduce_segments, dim3((maxn + 63) / 64, nch), dim3(1024), 0, st, arg);
         int rc = eqd_check_launch("k_reduce_segments");
         if (rc) return rc;
     }
@@ -540,30 +572,31 @@ int eqd_launch_embed_fwd(const EqdGraph* g, const float* emb, int d_emb, int use
 
 // Embedding backward: per block of 128 nodes, thread c owns column c -> deterministic per-type sums
 #define EMB_ROWS 128
-__global__ void k_embed_bwd(const int32_t* __restrict__ res, const float* __restrict__ dh0, int ld, int n, int d_emb,
-                            float* __restrict__ partial) {
+__global__ void k_embed_bwd(const int32_t* __restrict__ res, const float* __restrict__ dh0,
+                            const float* __restrict__ dh0b, int ld, int n, int d_emb, float* __restrict__ partial) {
     __shared__ float acc[21 * 64];
     const int c = threadIdx.x;  // 64 threads
     for (int t = 0; t < 21; ++t) acc[t * 64 + c] = 0.f;
     const int i0 = blockIdx.x * EMB_ROWS;
     const int i1 = i0 + EMB_ROWS < n ? i0 + EMB_ROWS : n;
     if (c < d_emb)
-        for (int i = i0; i < i1; ++i) acc[res[i] * 64 + c] += dh0[(size_t)i * ld + c];
+        for (int i = i0; i < i1; ++i)
+            acc[res[i] * 64 + c] += dh0[(size_t)i * ld + c] + (dh0b ? dh0b[(size_t)i * ld + c] : 0.f);
     for (int t = 0; t < 21; ++t)
         if (c < d_emb) partial[((size_t)blockIdx.x * 21 + t) * d_emb + c] = acc[t * 64 + c];
 }
 size_t eqd_embed_bwd_partial_floats(const EqdGraph* g, int d_emb) {
     return (size_t)((g->n_nodes + EMB_ROWS - 1) / EMB_ROWS) * 21 * d_emb;
 }
-int eqd_launch_embed_bwd(const EqdGraph* g, const float* dh0, int ld, int d_emb, float* demb, float* partial,
-                         hipStream_t st) {
+int eqd_launch_embed_bwd(const EqdGraph* g, const float* dh0, const float* dh0b, int ld, int d_emb, float* demb,
+                         float* partial, hipStream_t st) {
     if (g->n_nodes == 0) return EQD_OK;
     if (d_emb > 64) {
         eqd_set_error("embedding width %d > 64 unsupported", d_emb);
         return EQD_ERR_UNSUPPORTED;
     }
     const int nb = (g->n_nodes + EMB_ROWS - 1) / EMB_ROWS;
-    hipLaunchKernelGGL(k_embed_bwd, dim3(nb), dim3(64), 0, st, g->res_id, dh0, ld, g->n_nodes, d_emb, partial);
+    hipLaunchKernelGGL(k_embed_bwd, dim3(nb), dim3(64), 0, st, g->res_id, dh0, dh0b, ld, g->n_nodes, d_emb, partial);
     int rc = eqd_check_launch("k_embed_bwd");
     if (rc) return rc;
     return eqd_launch_vec_reduce(partial, nb, 21 * d_emb, 21 * d_emb, demb, st);
@@ -646,7 +679,7 @@ size_t eqd_ln_act_bwd_partial_floats(int rows, int d) {
 }
 int eqd_launch_ln_act_bwd(const float* y_act, const float* d_out, const float* gamma, int rows, int d, int ld,
                           float slope, float eps, float* dz, float* dgamma, float* dbeta, float* partial,
-                          hipStream_t st) {
+                          hipStream_t st, EqdRedList* defer) {
     if (rows == 0) return EQD_OK;
     if (d > 128) {
         eqd_set_error("ln_act_bwd: width %d > 128 unsupported", d);
@@ -658,5 +691,10 @@ int eqd_launch_ln_act_bwd(const float* y_act, const float* d_out, const float* g
     int rc = eqd_check_launch("k_ln_act_bwd");
     if (rc) return rc;
     EqdRedSeg segs[2] = {{partial, nb, 256, d, dgamma}, {partial + 128, nb, 256, d, dbeta}};
+    if (defer && defer->n + 2 <= 512) {
+        defer->seg[defer->n++] = segs[0];
+        defer->seg[defer->n++] = segs[1];
+        return EQD_OK;
+    }
     return eqd_launch_reduce_segments(segs, 2, st);
 }

@@ -205,6 +205,18 @@ class PackedGraph:
 
     def __init__(self):
         self.device = None
+        self._cstruct = None
+        self.ws_sizes = {}
+
+    def c_struct(self):
+        """EqdGraph view of this batch (cached; only the coordinate pointer changes between calls)."""
+        from . import _lib
+        if self._cstruct is None:
+            self._cstruct = _lib.graph_struct(self)
+        else:
+            _lib.require_device(self.x0, 'graph.x0')
+            self._cstruct.x0 = self.x0.data_ptr()
+        return self._cstruct
 
     @staticmethod
     def build(g):
@@ -305,4 +317,5 @@ class PackedGraph:
             if torch.is_tensor(v):
                 setattr(self, k, v.to(device))
         self.device = torch.device(device)
+        self._cstruct = None
         return self

@@ -124,12 +124,10 @@ class _IEGMNFunction(torch.autograd.Function):
     def forward(ctx, packed, desc, table_idx, svd_draws, need_grad, flat_state, *uniq):
         lib = _lib.load_library()
         dev = packed.x0.device
-        gs = _lib.graph_struct(packed)
-        tensors = [_lib.require_device(p.detach(), 'parameter') for p in uniq]
-        for t in tensors:
-            if t.dtype != torch.float32 or not t.is_contiguous():
-                raise _lib.EquidockHipError("parameters must be contiguous fp32 tensors")
-        ptrs = (C.c_void_p * len(table_idx))(*[tensors[i].data_ptr() for i in table_idx])
+        gs = packed.c_struct()
+        tensors = uniq                      # validated (device, fp32, contiguous) when the table was cached
+        dptr = [t.data_ptr() for t in uniq]
+        ptrs = (C.c_void_p * len(table_idx))(*[dptr[i] for i in table_idx])
         B, K = packed.n_pairs, desc.n_heads
         f32 = dict(dtype=torch.float32, device=dev)
         lig = torch.empty(packed.n_lig, 3, **f32)
@@ -138,10 +136,14 @@ class _IEGMNFunction(torch.autograd.Function):
         T = torch.empty(B, 3, 3, **f32)
         b = torch.empty(B, 3, **f32)
         status = torch.empty(B, dtype=torch.int32, device=dev)
-        sb = lib.eqd_model_saved_bytes(C.byref(desc), C.byref(gs))
-        wb = lib.eqd_model_scratch_bytes(C.byref(desc), C.byref(gs))
-        if sb == 0 or wb == 0:
-            _lib.check(lib.eqd_model_check(C.byref(desc), C.byref(gs)))
+        key = (desc.n_layers, desc.n_heads, desc.d_emb, desc.use_mean_node_features)
+        if packed.ws_sizes.get(key) is None:
+            sb = lib.eqd_model_saved_bytes(C.byref(desc), C.byref(gs))
+            wb = lib.eqd_model_scratch_bytes(C.byref(desc), C.byref(gs))
+            if sb == 0 or wb == 0:
+                _lib.check(lib.eqd_model_check(C.byref(desc), C.byref(gs)))
+            packed.ws_sizes[key] = (sb, wb)
+        sb, wb = packed.ws_sizes[key]
         saved = torch.empty(sb, dtype=torch.uint8, device=dev) if need_grad else None
         scratch = torch.empty(wb, dtype=torch.uint8, device=dev)
         if svd_draws is not None:
@@ -151,7 +153,7 @@ class _IEGMNFunction(torch.autograd.Function):
             _lib.ptr(T), _lib.ptr(b), _lib.ptr(status), _lib.ptr(saved), C.c_size_t(sb if need_grad else 0),
             _lib.ptr(scratch), C.c_size_t(wb), _lib.stream_ptr(dev), _lib.exec_ctx(dev)))
         ctx.packed, ctx.desc, ctx.table_idx, ctx.saved, ctx.sb, ctx.wb = packed, desc, table_idx, saved, sb, wb
-        ctx.tensors = tensors
+        ctx.tensors, ctx.ptrs = tensors, ptrs
         ctx.flat_state = flat_state
         ctx.x0 = packed.x0      # keep the coordinates this forward used alive (the saved state points at them)
         ctx.mark_non_differentiable(status)
@@ -166,9 +168,9 @@ class _IEGMNFunction(torch.autograd.Function):
         dev = packed.x0.device
         if packed.x0 is not ctx.x0:
             packed.x0 = ctx.x0
-        gs = _lib.graph_struct(packed)
+        gs = packed.c_struct()
         tensors = ctx.tensors
-        ptrs = (C.c_void_p * len(ctx.table_idx))(*[tensors[i].data_ptr() for i in ctx.table_idx])
+        ptrs = ctx.ptrs
         if ctx.flat_state is not None:      # accumulate straight into the model's persistent flat buffer
             flat, offs = ctx.flat_state
         else:
@@ -239,6 +241,7 @@ class IEGMN(nn.Module):
             nn.Linear(self.out_feats_dim, self.out_feats_dim), nn.Dropout(args['dropout']),
             get_non_lin(args['nonlin'], args['leakyrelu_neg_slope']))
         self._flat = None               # (flat grad buffer, offsets, ids) once enable_flat_grads() is called
+        self._table_cache = None
         self.svd_seed = 0
         self.svd_draws = None           # optional [B,10,3] tensor of guard perturbations (tests)
         self.last_svd_status = None     # int32 [B] device tensor: guard perturbations per pair (11 = unstable)
@@ -264,6 +267,20 @@ class IEGMN(nn.Module):
         return d
 
     def _param_table(self):
+        """(unique parameters, table -> unique index).  Cached: Parameter objects persist across
+        .to()/load_state_dict(); their data pointers are re-read at every call."""
+        cached = self._table_cache
+        if cached is not None and cached[0][0].device == cached[2] and cached[0][0].dtype == torch.float32:
+            return cached[0], cached[1]
+        uniq, table_idx = self._build_param_table()
+        for t in uniq:
+            _lib.require_device(t, 'parameter')
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise _lib.EquidockHipError("parameters must be contiguous fp32 tensors")
+        self._table_cache = (uniq, table_idx, uniq[0].device)
+        return uniq, table_idx
+
+    def _build_param_table(self):
         table = []
         for lay in self.iegmn_layers:
             table.extend(lay.param_table())
