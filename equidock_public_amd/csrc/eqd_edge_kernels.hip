@@ -14,20 +14,22 @@
 //   * the first Linear is split algebraically: W1 [h_s; h_d; he; rbf] + b1 =
 //     P[src] + Q[dst] + W1c he + W1d rbf with P = h W1a^T, Q = h W1b^T + b1 computed once per NODE
 //     by k_linear -- per-edge MFMA work drops from K=170 to K=42;
-//   * a wave owns a node-aligned tile of <= 32 edges (edges are destination-sorted, so the
-//     per-destination mean is a within-tile reduction; no atomics); the three 64x64 GEMMs chain
-//     through registers; weights (45 KB) are staged once per workgroup in LDS;
-//   * nothing per-edge goes to HBM in the forward; the backward recomputes the tile forward and
-//     writes the five per-edge operands of the weight-gradient GEMMs (a1, m, d_chid, dm, dz1) for
-//     k_atb, plus dz1/dx_rel for the CSC (by-source) gather.
+//   * FORWARD: a wave owns a node-aligned tile of <= 32 edges (edges are destination-sorted, so the
+//     per-destination mean is a within-tile reduction; no atomics); the three 64x64 GEMMs chain through
+//     registers; weights (45 KB) are staged once per workgroup in LDS; nothing per-edge goes to HBM;
+//   * BACKWARD: a wave owns 16 consecutive edges (no node alignment needed: the per-destination sums
+//     dQ[dst], dx[dst] are done by k_node_gather from the per-edge dz1 / dx_rel that are written anyway),
+//     which halves the live accumulators -> 4 waves per SIMD instead of 1, and twice the tiles to spread
+//     over the chip at DB5 sizes.  It recomputes the tile forward and writes the five per-edge operands
+//     of the weight-gradient GEMMs (a1, m, d_chid, dm, dz1) for k_atb.
 #include "eqd_common.h"
 
 #include <string.h>
 
 #define WS1 45   /* row stride of the staged W1[:, 2d_in:] block (42 used + 3 zero) */
 #define WS2 68   /* row stride of staged 64x64 weights: 272 B = 17 x 16 B -> conflict-free b128 */
-#define TS 68    /* row stride of the per-wave [32][64+4] tile */
-#define FS 45    /* row stride of the per-wave [32][42+3] feature tile (aliases the tile) */
+#define TS 68    /* row stride of the per-wave [edges][64+4] message tile (forward) */
+#define FS 45    /* row stride of the per-wave [edges][42+3] feature tile */
 #define VEC_LNG 0
 #define VEC_LNB 64
 #define VEC_B2 128
@@ -35,24 +37,24 @@
 #define VEC_WC2 256
 #define VEC_BC2 320
 #define VEC_N 324
-#define FWD_WAVES 8   /* forward: 166 VGPRs -> 2 waves per SIMD, two tiles overlap their memory latency */
-#define BWD_WAVES 4   /* backward: ~390 registers (4 live accumulator sets) -> 1 wave per SIMD */
+#define FWD_WAVES 8   /* forward : 32-edge tiles, ~166 VGPRs -> 2 waves per SIMD */
+#define BWD_WAVES 8   /* backward: 16-edge tiles, small register footprint -> 2 workgroups per CU */
 
-template <int NW>
+template <int NW, int TILE_FLOATS>
 struct alignas(16) EdgeSmem {
     float w1[64 * WS1];
     float w2[64 * WS2];
     float wc1[64 * WS2];
     float vec[VEC_N];
-    float tile[NW][32 * TS];
+    float tile[NW][TILE_FLOATS];
 };
 
-template <int NW>
-__device__ __forceinline__ void edge_stage_weights(EdgeSmem<NW>& sm, const EqdEdgeParams& P) {
-    constexpr int NT = 64 * NW;
-    constexpr int N1 = (64 * 42 + NT - 1) / NT, N2 = 1024 / NT;
+template <int NW, int TF>
+__device__ __forceinline__ void edge_stage_weights(EdgeSmem<NW, TF>& sm, const EqdEdgeParams& P) {
     // all global loads of a thread are issued before the first LDS store (constant trip counts, fully
     // unrolled): one L2 round trip per batch instead of one per element
+    constexpr int NT = 64 * NW;
+    constexpr int N1 = (64 * 42 + NT - 1) / NT, N2 = 1024 / NT;
     const int t = threadIdx.x;
     const int koff = 2 * P.d_in;
     {
@@ -112,73 +114,79 @@ __device__ __forceinline__ float rbf_sigma(int k) {
 
 // y = W x chained through registers: out[mbo][nb] += sum_{mbi,r} W[16 mbo + l15][16 mbi + 4 g + r] * in[mbi][nb][r]
 // W staged in LDS with row stride WS2.  If AFF, `in` is first mapped through v * ga[f] + be[f].
-template <bool AFF>
-__device__ __forceinline__ void chain64(f32x4 (&out)[4][2], const f32x4 (&in)[4][2], const float* __restrict__ W,
+template <bool AFF, int NB>
+__device__ __forceinline__ void chain64(f32x4 (&out)[4][NB], const f32x4 (&in)[4][NB], const float* __restrict__ W,
                                         const float* __restrict__ ga, const float* __restrict__ be, int l15, int g) {
 #pragma unroll
     for (int mbi = 0; mbi < 4; ++mbi) {
-        f32x4 b0 = in[mbi][0], b1 = in[mbi][1];
+        f32x4 b[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) b[nb] = in[mbi][nb];
         if (AFF) {
             const float4 gg = *(const float4*)&ga[16 * mbi + 4 * g];
             const float4 bb = *(const float4*)&be[16 * mbi + 4 * g];
-            b0[0] = b0[0] * gg.x + bb.x; b0[1] = b0[1] * gg.y + bb.y; b0[2] = b0[2] * gg.z + bb.z; b0[3] = b0[3] * gg.w + bb.w;
-            b1[0] = b1[0] * gg.x + bb.x; b1[1] = b1[1] * gg.y + bb.y; b1[2] = b1[2] * gg.z + bb.z; b1[3] = b1[3] * gg.w + bb.w;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                b[nb][0] = b[nb][0] * gg.x + bb.x;
+                b[nb][1] = b[nb][1] * gg.y + bb.y;
+                b[nb][2] = b[nb][2] * gg.z + bb.z;
+                b[nb][3] = b[nb][3] * gg.w + bb.w;
+            }
         }
 #pragma unroll
         for (int mbo = 0; mbo < 4; ++mbo) {
             const float4 w = *(const float4*)&W[(16 * mbo + l15) * WS2 + 16 * mbi + 4 * g];
-            out[mbo][0] = mfma4(w.x, b0[0], out[mbo][0]);
-            out[mbo][1] = mfma4(w.x, b1[0], out[mbo][1]);
-            out[mbo][0] = mfma4(w.y, b0[1], out[mbo][0]);
-            out[mbo][1] = mfma4(w.y, b1[1], out[mbo][1]);
-            out[mbo][0] = mfma4(w.z, b0[2], out[mbo][0]);
-            out[mbo][1] = mfma4(w.z, b1[2], out[mbo][1]);
-            out[mbo][0] = mfma4(w.w, b0[3], out[mbo][0]);
-            out[mbo][1] = mfma4(w.w, b1[3], out[mbo][1]);
+            const float wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) out[mbo][nb] = mfma4(wv[r], b[nb][r], out[mbo][nb]);
         }
     }
 }
 // y = W^T x: out[mbo][nb] += sum_{mbi,r} W[16 mbi + 4 g + r][16 mbo + l15] * in[mbi][nb][r]
-__device__ __forceinline__ void chain64T(f32x4 (&out)[4][2], const f32x4 (&in)[4][2], const float* __restrict__ W,
+template <int NB>
+__device__ __forceinline__ void chain64T(f32x4 (&out)[4][NB], const f32x4 (&in)[4][NB], const float* __restrict__ W,
                                          int l15, int g) {
 #pragma unroll
-    for (int mbi = 0; mbi < 4; ++mbi) {
+    for (int mbi = 0; mbi < 4; ++mbi)
 #pragma unroll
-        for (int mbo = 0; mbo < 4; ++mbo) {
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int mbo = 0; mbo < 4; ++mbo) {
                 const float w = W[(16 * mbi + 4 * g + r) * WS2 + 16 * mbo + l15];
-                out[mbo][0] = mfma4(w, in[mbi][0][r], out[mbo][0]);
-                out[mbo][1] = mfma4(w, in[mbi][1][r], out[mbo][1]);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) out[mbo][nb] = mfma4(w, in[mbi][nb][r], out[mbo][nb]);
             }
-        }
-    }
 }
 
+template <int NB>
 struct EdgeTileState {
     int e0, ne, n0, n1;
-    int src[2], dst[2];
-    bool ev[2];
-    float xrel[2][3];
-    float d2[2];
-    float mean[2], rstd[2];
-    float coef[2];
+    int src[NB], dst[NB];
+    bool ev[NB];
+    float xrel[NB][3];
+    float d2[NB];
+    float mean[NB], rstd[NB];
+    float coef[NB];
     unsigned zpos;   // bit (16 nb + 4 mb + r): edge_mlp.0 pre-activation > 0 (exact LeakyReLU mask for the backward)
 };
 
-// Forward of one tile up to (and including) the coefficient. On return:
+// Forward of one tile of 16*NB edges up to (and including) the coefficient. On return:
 //   xh = LayerNorm-normalised hidden (before the affine), m = msg, ch = coors_mlp hidden pre-activation.
 // If rbf_out != nullptr the 15 RBFs of each edge are also written there ([E][16]).
-template <int NW>
-__device__ __forceinline__ void edge_tile_forward(const EqdGraph& G, const EqdEdgeParams& P, EdgeSmem<NW>& sm,
-                                                  float* __restrict__ tile, const float* __restrict__ Pn,
-                                                  const float* __restrict__ Qn, const float* __restrict__ x,
-                                                  int lane, EdgeTileState& S, f32x4 (&xh)[4][2], f32x4 (&m)[4][2],
-                                                  f32x4 (&ch)[4][2], float* __restrict__ rbf_out) {
+template <int NB>
+__device__ __forceinline__ void edge_tile_forward(const EqdGraph& G, const EqdEdgeParams& P, const float* __restrict__ w1,
+                                                  const float* __restrict__ w2, const float* __restrict__ wc1,
+                                                  const float* __restrict__ vec, float* __restrict__ tile,
+                                                  const float* __restrict__ Pn, const float* __restrict__ Qn,
+                                                  const float* __restrict__ x, int lane, EdgeTileState<NB>& S,
+                                                  f32x4 (&xh)[4][NB], f32x4 (&m)[4][NB], f32x4 (&ch)[4][NB],
+                                                  float* __restrict__ rbf_out) {
     const int l15 = lane & 15, g = lane >> 4;
     // ---- geometry ---------------------------------------------------------------------------
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
+    for (int nb = 0; nb < NB; ++nb) {
         const int el = 16 * nb + l15;
         S.ev[nb] = el < S.ne;
         int s = 0, d = 0;
@@ -197,29 +205,30 @@ __device__ __forceinline__ void edge_tile_forward(const EqdGraph& G, const EqdEd
         }
         S.d2[nb] = q;
     }
-    // ---- feature tile [32][45]: he (27) | rbf (15) | 0 -------------------------------------------
-    for (int i = lane; i < 32 * FS; i += 64) tile[i] = 0.f;
+    // ---- feature tile [16 NB][45]: he (27) | rbf (15) | 0 -----------------------------------------
+    for (int i = lane; i < 16 * NB * FS; i += 64) tile[i] = 0.f;
     wave_lds_fence();
     if (P.use_he) {
-        // the tile's he rows are contiguous in HBM (edges are destination-sorted): 32 x 27 floats,
-        // 13.5 per lane, all loads issued before the first LDS store
+        // the tile's he rows are contiguous in HBM: 16 NB x 27 floats, all loads issued before the first
+        // LDS store
+        constexpr int NH = (16 * NB * 27 + 63) / 64;
         const float* __restrict__ he = G.he + (size_t)S.e0 * 27;
         const int nhe = S.ne * 27;
-        float hv[14];
+        float hv[NH];
 #pragma unroll
-        for (int j = 0; j < 14; ++j) {
+        for (int j = 0; j < NH; ++j) {
             const int i = lane + 64 * j;
             hv[j] = i < nhe ? he[i] : 0.f;
         }
 #pragma unroll
-        for (int j = 0; j < 14; ++j) {
+        for (int j = 0; j < NH; ++j) {
             const int i = lane + 64 * j;
             const int e = i / 27, c = i - e * 27;
             if (i < nhe) tile[e * FS + c] = hv[j];
         }
     }
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
+    for (int nb = 0; nb < NB; ++nb) {
         const int el = 16 * nb + l15;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -235,7 +244,7 @@ __device__ __forceinline__ void edge_tile_forward(const EqdGraph& G, const EqdEd
     wave_lds_fence();
     // ---- stage 1: z1 = P[src] + Q[dst] + W1cd feat ----------------------------------------------
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
             f32x4 a = f4zero();
@@ -249,19 +258,20 @@ __device__ __forceinline__ void edge_tile_forward(const EqdGraph& G, const EqdEd
 #pragma unroll
     for (int s = 0; s < 11; ++s) {
         const int k = 4 * s + g;
-        const float b0 = tile[l15 * FS + k];
-        const float b1 = tile[(16 + l15) * FS + k];
+        float b[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) b[nb] = tile[(16 * nb + l15) * FS + k];
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
-            const float a = sm.w1[(16 * mb + l15) * WS1 + k];
-            xh[mb][0] = mfma4(a, b0, xh[mb][0]);
-            xh[mb][1] = mfma4(a, b1, xh[mb][1]);
+            const float a = w1[(16 * mb + l15) * WS1 + k];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) xh[mb][nb] = mfma4(a, b[nb], xh[mb][nb]);
         }
     }
     // ---- LeakyReLU + LayerNorm statistics (two-pass like torch) ------------------------------------
     S.zpos = 0u;
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
+    for (int nb = 0; nb < NB; ++nb) {
         float s = 0.f;
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb)
@@ -293,48 +303,40 @@ __device__ __forceinline__ void edge_tile_forward(const EqdGraph& G, const EqdEd
     // ---- stage 2: m = W2 (xh * gamma + beta) + b2 --------------------------------------------------
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
-        const float4 b = *(const float4*)&sm.vec[VEC_B2 + 16 * mb + 4 * g];
+        const float4 b = *(const float4*)&vec[VEC_B2 + 16 * mb + 4 * g];
         f32x4 v = {b.x, b.y, b.z, b.w};
-        m[mb][0] = v;
-        m[mb][1] = v;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) m[mb][nb] = v;
     }
-    chain64<true>(m, xh, sm.w2, &sm.vec[VEC_LNG], &sm.vec[VEC_LNB], l15, g);
+    chain64<true, NB>(m, xh, w2, &vec[VEC_LNG], &vec[VEC_LNB], l15, g);
     // ---- stage 3: ch = Wc1 m + bc1; coef = wc2 . LeakyReLU(ch) + bc2 ---------------------------------
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
-        const float4 b = *(const float4*)&sm.vec[VEC_BC1 + 16 * mb + 4 * g];
+        const float4 b = *(const float4*)&vec[VEC_BC1 + 16 * mb + 4 * g];
         f32x4 v = {b.x, b.y, b.z, b.w};
-        ch[mb][0] = v;
-        ch[mb][1] = v;
-    }
-    chain64<false>(ch, m, sm.wc1, nullptr, nullptr, l15, g);
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
+        for (int nb = 0; nb < NB; ++nb) ch[mb][nb] = v;
+    }
+    chain64<false, NB>(ch, m, wc1, nullptr, nullptr, l15, g);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
         float s = 0.f;
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
-            const float4 w = *(const float4*)&sm.vec[VEC_WC2 + 16 * mb + 4 * g];
+            const float4 w = *(const float4*)&vec[VEC_WC2 + 16 * mb + 4 * g];
             s += lrelu(ch[mb][nb][0], P.slope) * w.x + lrelu(ch[mb][nb][1], P.slope) * w.y +
                  lrelu(ch[mb][nb][2], P.slope) * w.z + lrelu(ch[mb][nb][3], P.slope) * w.w;
         }
-        S.coef[nb] = group_sum(s) + sm.vec[VEC_BC2];
+        S.coef[nb] = group_sum(s) + vec[VEC_BC2];
     }
 }
 
-// store an F-layout tile into the per-wave LDS tile as [edge][feature] (stride TS)
-__device__ __forceinline__ void tile_store(float* __restrict__ tile, const f32x4 (&v)[4][2], int l15, int g) {
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
-            *(float4*)&tile[(16 * nb + l15) * TS + 16 * mb + 4 * g] =
-                make_float4(v[mb][nb][0], v[mb][nb][1], v[mb][nb][2], v[mb][nb][3]);
-}
 // store an F-layout tile to HBM as [edge][64]
-__device__ __forceinline__ void hbm_store(float* __restrict__ dst, const f32x4 (&v)[4][2], const EdgeTileState& S,
+template <int NB>
+__device__ __forceinline__ void hbm_store(float* __restrict__ dst, const f32x4 (&v)[4][NB], const EdgeTileState<NB>& S,
                                           int l15, int g) {
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
+    for (int nb = 0; nb < NB; ++nb)
         if (S.ev[nb]) {
             float* row = dst + (size_t)(S.e0 + 16 * nb + l15) * 64;
 #pragma unroll
@@ -343,24 +345,34 @@ __device__ __forceinline__ void hbm_store(float* __restrict__ dst, const f32x4 (
         }
 }
 
+// ---------------------------------------------------------------------------------------------
+// forward: node-aligned 32-edge tiles
+// ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64 * FWD_WAVES) void k_edge_fwd(EqdGraph G, EqdEdgeParams P, const float* __restrict__ Pn,
-                                                        const float* __restrict__ Qn, const float* __restrict__ x,
-                                                        float* __restrict__ aggr_msg, float* __restrict__ x_new) {
-    __shared__ EdgeSmem<FWD_WAVES> sm;
+                                                              const float* __restrict__ Qn,
+                                                              const float* __restrict__ x,
+                                                              float* __restrict__ aggr_msg,
+                                                              float* __restrict__ x_new) {
+    __shared__ EdgeSmem<FWD_WAVES, 32 * TS> sm;
     edge_stage_weights(sm, P);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     float* tile = sm.tile[wave];
     for (int t = blockIdx.x * FWD_WAVES + wave; t < G.n_tiles; t += gridDim.x * FWD_WAVES) {
-        EdgeTileState S;
+        EdgeTileState<2> S;
         S.n0 = G.tile_node[t];
         S.n1 = G.tile_node[t + 1];
         S.e0 = G.rowptr[S.n0];
         S.ne = G.rowptr[S.n1] - S.e0;
         f32x4 xh[4][2], m[4][2], ch[4][2];
-        edge_tile_forward(G, P, sm, tile, Pn, Qn, x, lane, S, xh, m, ch, nullptr);
-        wave_lds_fence();   // feature tile is dead: reuse as the message tile
-        tile_store(tile, m, l15, g);
+        edge_tile_forward<2>(G, P, sm.w1, sm.w2, sm.wc1, sm.vec, tile, Pn, Qn, x, lane, S, xh, m, ch, nullptr);
+        wave_lds_fence();   // feature tile is dead: reuse as the message tile [edge][64 + x_moment]
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+                *(float4*)&tile[(16 * nb + l15) * TS + 16 * mb + 4 * g] =
+                    make_float4(m[mb][nb][0], m[mb][nb][1], m[mb][nb][2], m[mb][nb][3]);
         if (g == 0) {
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
@@ -389,14 +401,15 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void k_edge_fwd(EqdGraph G, EqdEdge
     }
 }
 
-// Smallest grid with the minimal number of tile rounds: with one workgroup per CU (LDS-bound) the
-// makespan is ceil(tiles / (256 * waves)) tile times whatever the grid, so use as few CUs as that allows
+// Smallest grid with the minimal number of tile rounds: with `wg_per_cu` workgroups per CU the makespan is
+// ceil(tiles / (256 * wg_per_cu * waves)) tile times whatever the grid, so use as few CUs as that allows
 // and leave the rest to the kernels that run concurrently on the auxiliary streams.
-static int edge_grid(int n_tiles, int waves) {
+static int edge_grid(int n_tiles, int waves, int wg_per_cu) {
     if (n_tiles <= 0) return 1;
-    const int rounds = (n_tiles + 256 * waves - 1) / (256 * waves);
+    const int slots = 256 * waves * wg_per_cu;
+    const int rounds = (n_tiles + slots - 1) / slots;
     int blocks = (n_tiles + waves * rounds - 1) / (waves * rounds);
-    if (blocks > 256) blocks = 256;
+    if (blocks > 256 * wg_per_cu) blocks = 256 * wg_per_cu;
     return blocks < 1 ? 1 : blocks;
 }
 
@@ -407,14 +420,14 @@ extern "C" int eqd_edge_message_fwd(const EqdGraph* g, const EqdEdgeParams* p, c
         return EQD_ERR_NULL;
     }
     if (g->n_tiles <= 0) return EQD_OK;
-    const int blocks = edge_grid(g->n_tiles, FWD_WAVES);
+    const int blocks = edge_grid(g->n_tiles, FWD_WAVES, 1);
     hipLaunchKernelGGL(k_edge_fwd, dim3(blocks), dim3(64 * FWD_WAVES), 0, (hipStream_t)stream, *g, *p, P, Q, x, aggr_msg,
                        x_new);
     return eqd_check_launch("k_edge_fwd");
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward
+// backward: 16-edge tiles (not node aligned)
 // ---------------------------------------------------------------------------------------------
 struct EdgeBwdWs {
     float* a1;     // [E][64] LayerNorm output (input of edge_mlp.4)
@@ -428,128 +441,104 @@ struct EdgeBwdWs {
 };
 
 __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdgeParams P, const float* __restrict__ Pn,
-                                                        const float* __restrict__ Qn, const float* __restrict__ x,
-                                                        const float* __restrict__ d_aggr,
-                                                        const float* __restrict__ d_xnew, float* __restrict__ dQ,
-                                                        float* __restrict__ dx, EdgeBwdWs W) {
-    __shared__ EdgeSmem<BWD_WAVES> sm;
-    __shared__ float vacc[BWD_WAVES][256];
+                                                              const float* __restrict__ Qn,
+                                                              const float* __restrict__ x,
+                                                              const float* __restrict__ d_aggr,
+                                                              const float* __restrict__ d_xnew, EdgeBwdWs W) {
+    __shared__ EdgeSmem<BWD_WAVES, 16 * FS> sm;
+    __shared__ float vacc[BWD_WAVES][196];
     edge_stage_weights(sm, P);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     float* tile = sm.tile[wave];
-    for (int i = lane; i < 256; i += 64) vacc[wave][i] = 0.f;
+    for (int i = lane; i < 196; i += 64) vacc[wave][i] = 0.f;
     wave_lds_fence();
-    for (int t = blockIdx.x * BWD_WAVES + wave; t < G.n_tiles; t += gridDim.x * BWD_WAVES) {
-        EdgeTileState S;
-        S.n0 = G.tile_node[t];
-        S.n1 = G.tile_node[t + 1];
-        S.e0 = G.rowptr[S.n0];
-        S.ne = G.rowptr[S.n1] - S.e0;
-        f32x4 xh[4][2], m[4][2], ch[4][2];
-        edge_tile_forward(G, P, sm, tile, Pn, Qn, x, lane, S, xh, m, ch, W.rbf);
+    const int n_tiles = (G.n_edges + 15) >> 4;
+    for (int t = blockIdx.x * BWD_WAVES + wave; t < n_tiles; t += gridDim.x * BWD_WAVES) {
+        EdgeTileState<1> S;
+        S.n0 = S.n1 = 0;
+        S.e0 = 16 * t;
+        S.ne = (G.n_edges - S.e0 < 16) ? G.n_edges - S.e0 : 16;
+        f32x4 xh[4][1], m[4][1], ch[4][1];
+        edge_tile_forward<1>(G, P, sm.w1, sm.w2, sm.wc1, sm.vec, tile, Pn, Qn, x, lane, S, xh, m, ch, W.rbf);
         wave_lds_fence();
         // ---- operands of the weight-gradient GEMMs that the forward defines --------------------
         {
-            f32x4 a1[4][2];
+            f32x4 a1[4][1];
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
                 const float4 gg = *(const float4*)&sm.vec[VEC_LNG + 16 * mb + 4 * g];
                 const float4 bb = *(const float4*)&sm.vec[VEC_LNB + 16 * mb + 4 * g];
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb) {
-                    a1[mb][nb][0] = xh[mb][nb][0] * gg.x + bb.x;
-                    a1[mb][nb][1] = xh[mb][nb][1] * gg.y + bb.y;
-                    a1[mb][nb][2] = xh[mb][nb][2] * gg.z + bb.z;
-                    a1[mb][nb][3] = xh[mb][nb][3] * gg.w + bb.w;
-                }
+                a1[mb][0][0] = xh[mb][0][0] * gg.x + bb.x;
+                a1[mb][0][1] = xh[mb][0][1] * gg.y + bb.y;
+                a1[mb][0][2] = xh[mb][0][2] * gg.z + bb.z;
+                a1[mb][0][3] = xh[mb][0][3] * gg.w + bb.w;
             }
-            hbm_store(W.a1, a1, S, l15, g);
+            hbm_store<1>(W.a1, a1, S, l15, g);
         }
-        hbm_store(W.m, m, S, l15, g);
+        hbm_store<1>(W.m, m, S, l15, g);
         // ---- coordinate path ---------------------------------------------------------------------
-        float invdeg[2], dcoef[2], dxr[2][3];
+        float invdeg = 0.f, dcoef = 0.f, dxr[3] = {0.f, 0.f, 0.f};
+        if (S.ev[0]) {
+            const int d = S.dst[0];
+            invdeg = 1.f / (float)(G.rowptr[d + 1] - G.rowptr[d]);
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-            float dc = 0.f;
-            invdeg[nb] = 0.f;
-            if (S.ev[nb]) {
-                const int d = S.dst[nb];
-                invdeg[nb] = 1.f / (float)(G.rowptr[d + 1] - G.rowptr[d]);
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float gx = d_xnew[(size_t)d * 3 + c] * invdeg[nb];
-                    dc += gx * S.xrel[nb][c];
-                    dxr[nb][c] = gx * S.coef[nb];
-                }
-            } else {
-                dxr[nb][0] = dxr[nb][1] = dxr[nb][2] = 0.f;
+            for (int c = 0; c < 3; ++c) {
+                const float gx = d_xnew[(size_t)d * 3 + c] * invdeg;
+                dcoef += gx * S.xrel[0][c];
+                dxr[c] = gx * S.coef[0];
             }
-            dcoef[nb] = dc;
         }
-        // d wc2 / d bc2 partials (reduced over the 16 edge lanes and banked in LDS right away to keep
-        // register pressure down), then ch := d_chid = wc2 * dcoef * LeakyReLU'(ch)
+        // d wc2 / d bc2 partials (reduced over the 16 edge lanes and banked in LDS right away), then
+        // ch := d_chid = wc2 * dcoef * LeakyReLU'(ch)
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
             const float4 w = *(const float4*)&sm.vec[VEC_WC2 + 16 * mb + 4 * g];
             const float wv[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float acc = 0.f;
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb) {
-                    const float c = ch[mb][nb][r];
-                    acc += lrelu(c, P.slope) * dcoef[nb];
-                    ch[mb][nb][r] = wv[r] * dcoef[nb] * lrelu_grad(c, P.slope);
-                }
-                acc = l16_sum(acc);
+                const float c = ch[mb][0][r];
+                const float acc = l16_sum(lrelu(c, P.slope) * dcoef);
+                ch[mb][0][r] = wv[r] * dcoef * lrelu_grad(c, P.slope);
                 if (l15 == 0) vacc[wave][128 + 16 * mb + 4 * g + r] += acc;
             }
         }
         {
-            const float dbc2 = l16_sum(dcoef[0] + dcoef[1]);
+            const float dbc2 = l16_sum(dcoef);
             if (lane == 0) vacc[wave][192] += dbc2;
         }
-        hbm_store(W.dchid, ch, S, l15, g);
+        hbm_store<1>(W.dchid, ch, S, l15, g);
         // ---- dm = d_aggr[dst] / deg + Wc1^T d_chid ---------------------------------------------------
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
-                f32x4 a = f4zero();
-                if (S.ev[nb]) {
-                    const float4 v = *(const float4*)&d_aggr[(size_t)S.dst[nb] * 64 + 16 * mb + 4 * g];
-                    a[0] = v.x * invdeg[nb]; a[1] = v.y * invdeg[nb]; a[2] = v.z * invdeg[nb]; a[3] = v.w * invdeg[nb];
-                }
-                m[mb][nb] = a;
-            }
-        chain64T(m, ch, sm.wc1, l15, g);
-        hbm_store(W.dm, m, S, l15, g);
-        // ---- da1 = W2^T dm ---------------------------------------------------------------------------
-        f32x4 dz[4][2];
-#pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
-            dz[mb][0] = f4zero();
-            dz[mb][1] = f4zero();
+            f32x4 a = f4zero();
+            if (S.ev[0]) {
+                const float4 v = *(const float4*)&d_aggr[(size_t)S.dst[0] * 64 + 16 * mb + 4 * g];
+                a[0] = v.x * invdeg; a[1] = v.y * invdeg; a[2] = v.z * invdeg; a[3] = v.w * invdeg;
+            }
+            m[mb][0] = a;
         }
-        chain64T(dz, m, sm.w2, l15, g);
+        chain64T<1>(m, ch, sm.wc1, l15, g);
+        hbm_store<1>(W.dm, m, S, l15, g);
+        // ---- da1 = W2^T dm ---------------------------------------------------------------------------
+        f32x4 dz[4][1];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) dz[mb][0] = f4zero();
+        chain64T<1>(dz, m, sm.w2, l15, g);
         // ---- LayerNorm + LeakyReLU backward --------------------------------------------------------------
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float a = dz[mb][0][r] * xh[mb][0][r] + dz[mb][1][r] * xh[mb][1][r];
-                float b = dz[mb][0][r] + dz[mb][1][r];
-                a = l16_sum(a);
-                b = l16_sum(b);
+                const float a = l16_sum(dz[mb][0][r] * xh[mb][0][r]);
+                const float b = l16_sum(dz[mb][0][r]);
                 if (l15 == 0) {
                     const int f = 16 * mb + 4 * g + r;
                     vacc[wave][f] += a;
                     vacc[wave][64 + f] += b;
                 }
             }
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
+        {
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
@@ -557,10 +546,10 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
                 const float gv[4] = {gg.x, gg.y, gg.z, gg.w};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float dxh = dz[mb][nb][r] * gv[r];
-                    dz[mb][nb][r] = dxh;
+                    const float dxh = dz[mb][0][r] * gv[r];
+                    dz[mb][0][r] = dxh;
                     s1 += dxh;
-                    s2 += dxh * xh[mb][nb][r];
+                    s2 += dxh * xh[mb][0][r];
                 }
             }
             s1 = group_sum(s1) * (1.f / 64.f);
@@ -569,79 +558,48 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
             for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float xhv = xh[mb][nb][r];
-                    const float lg = ((S.zpos >> (16 * nb + 4 * mb + r)) & 1u) ? 1.f : P.slope;
-                    dz[mb][nb][r] = S.ev[nb] ? S.rstd[nb] * (dz[mb][nb][r] - s1 - xhv * s2) * lg : 0.f;
+                    const float xhv = xh[mb][0][r];
+                    const float lg = ((S.zpos >> (4 * mb + r)) & 1u) ? 1.f : P.slope;
+                    dz[mb][0][r] = S.ev[0] ? S.rstd[0] * (dz[mb][0][r] - s1 - xhv * s2) * lg : 0.f;
                 }
         }
-        hbm_store(W.dz1, dz, S, l15, g);
+        hbm_store<1>(W.dz1, dz, S, l15, g);
         // ---- d rbf = W1d^T dz1 -> d(d^2) -> d x_rel --------------------------------------------------------
         if (P.use_dist) {
-            f32x4 dr[2] = {f4zero(), f4zero()};
+            f32x4 dr = f4zero();
 #pragma unroll
             for (int mbi = 0; mbi < 4; ++mbi)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float w = (l15 < 15) ? sm.w1[(16 * mbi + 4 * g + r) * WS1 + 27 + l15] : 0.f;
-                    dr[0] = mfma4(w, dz[mbi][0][r], dr[0]);
-                    dr[1] = mfma4(w, dz[mbi][1][r], dr[1]);
+                    dr = mfma4(w, dz[mbi][0][r], dr);
                 }
+            float s = 0.f;
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                float s = 0.f;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int k = 4 * g + r;
-                    if (k < 15) {
-                        const float sg = rbf_sigma(k);
-                        s += dr[nb][r] * expf(-S.d2[nb] / sg) * (-1.f / sg);
-                    }
-                }
-                const float dd2 = group_sum(s);
-#pragma unroll
-                for (int c = 0; c < 3; ++c) dxr[nb][c] += 2.f * S.xrel[nb][c] * dd2;
-            }
-        }
-        // ---- per-destination sums: dQ[dst] = sum dz1, dx[dst] = (1-eta) d_xnew - sum dx_rel ------------------
-        tile_store(tile, dz, l15, g);
-        if (g == 0) {
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                const int el = 16 * nb + l15;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) tile[el * TS + 64 + c] = dxr[nb][c];
-                if (S.ev[nb]) {
-                    float* o = W.dxrel + (size_t)(S.e0 + el) * 4;
-                    o[0] = dxr[nb][0]; o[1] = dxr[nb][1]; o[2] = dxr[nb][2]; o[3] = 0.f;
+            for (int r = 0; r < 4; ++r) {
+                const int k = 4 * g + r;
+                if (k < 15) {
+                    const float sg = rbf_sigma(k);
+                    s += dr[r] * expf(-S.d2[0] / sg) * (-1.f / sg);
                 }
             }
+            const float dd2 = group_sum(s);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) dxr[c] += 2.f * S.xrel[0][c] * dd2;
         }
-        wave_lds_fence();
-        const int nn = S.n1 - S.n0;
-        const int rp = (lane <= nn) ? G.rowptr[S.n0 + lane] - S.e0 : 0;
-        for (int i = 0; i < nn; ++i) {
-            const int n = S.n0 + i;
-            const int a = __shfl(rp, i), b = __shfl(rp, i + 1);
-            float s = 0.f, sx = 0.f;
-            for (int e = a; e < b; ++e) {
-                s += tile[e * TS + lane];
-                if (lane < 3) sx += tile[e * TS + 64 + lane];
-            }
-            dQ[(size_t)n * 64 + lane] = s;
-            if (lane < 3) {
-                const size_t o = (size_t)n * 3 + lane;
-                dx[o] = (1.f - P.eta) * d_xnew[o] - sx;
-            }
+        if (g == 0 && S.ev[0]) {
+            float* o = W.dxrel + (size_t)(S.e0 + l15) * 4;
+            o[0] = dxr[0]; o[1] = dxr[1]; o[2] = dxr[2]; o[3] = 0.f;
         }
-        wave_lds_fence();
         wave_lds_fence();
     }
     wave_lds_fence();
     float* vp = W.vecp + (size_t)(blockIdx.x * BWD_WAVES + wave) * 256;
-    for (int i = lane; i < 256; i += 64) vp[i] = vacc[wave][i];
+    for (int i = lane; i < 196; i += 64) vp[i] = vacc[wave][i];
 }
 
-static int edge_bwd_blocks(const EqdGraph* g) { return edge_grid(g->n_tiles, BWD_WAVES); }
+static int edge_bwd_blocks(const EqdGraph* g) { return edge_grid((g->n_edges + 15) / 16, BWD_WAVES, 2); }
+size_t eqd_edge_bwd_vecp_floats(const EqdGraph* g) { return (size_t)edge_bwd_blocks(g) * BWD_WAVES * 256; }
 
 static void edge_atb_jobs(const EqdGraph* g, const EqdEdgeParams* p, const EqdEdgeGrads* gr, const EdgeBwdWs& W,
                           EqdAtbJob* jobs) {
@@ -672,7 +630,7 @@ static size_t edge_bwd_carve(const EqdGraph* g, EqdArena& A, EdgeBwdWs* W, float
     w.dz1 = A.take<float>(E * 64);
     w.rbf = A.take<float>(E * 16);
     w.dxrel = A.take<float>(E * 4);
-    w.vecp = A.take<float>((size_t)edge_bwd_blocks(g) * BWD_WAVES * 256);
+    w.vecp = A.take<float>(eqd_edge_bwd_vecp_floats(g));
     // worst-case partial size for the four weight-gradient GEMMs (depends only on E)
     EqdAtbJob jobs[4];
     EqdEdgeParams p;
@@ -695,12 +653,14 @@ extern "C" size_t eqd_edge_message_bwd_workspace_bytes(const EqdGraph* g) {
 }
 
 // Profiling aid: ONLY the per-edge backward kernel of eqd_edge_message_bwd (no weight-gradient GEMMs,
-// no vector reductions, no CSC gather), so that its duration can be bracketed with HIP events.
+// no vector reductions, no CSR/CSC gather), so that its duration can be bracketed with HIP events.
 extern "C" int eqd_edge_message_bwd_kernel_only(const EqdGraph* g, const EqdEdgeParams* p, const float* P,
                                                 const float* Q, const float* x, const float* d_aggr_msg,
                                                 const float* d_xnew, float* dQ, float* dx, void* workspace,
                                                 size_t ws_bytes, void* stream) {
-    if (!g || !p || !P || !Q || !x || !d_aggr_msg || !d_xnew || !dQ || !dx) {
+    (void)dQ;
+    (void)dx;
+    if (!g || !p || !P || !Q || !x || !d_aggr_msg || !d_xnew) {
         eqd_set_error("eqd_edge_message_bwd_kernel_only: NULL argument");
         return EQD_ERR_NULL;
     }
@@ -711,13 +671,11 @@ extern "C" int eqd_edge_message_bwd_kernel_only(const EqdGraph* g, const EqdEdge
         eqd_set_error("eqd_edge_message_bwd_kernel_only: workspace too small");
         return EQD_ERR_WORKSPACE;
     }
-    if (g->n_tiles <= 0) return EQD_OK;
+    if (g->n_edges <= 0) return EQD_OK;
     hipLaunchKernelGGL(k_edge_bwd, dim3(edge_bwd_blocks(g)), dim3(64 * BWD_WAVES), 0, (hipStream_t)stream, *g, *p, P, Q, x,
-                       d_aggr_msg, d_xnew, dQ, dx, W);
+                       d_aggr_msg, d_xnew, W);
     return eqd_check_launch("k_edge_bwd");
 }
-
-size_t eqd_edge_bwd_vecp_floats(const EqdGraph* g) { return (size_t)edge_bwd_blocks(g) * BWD_WAVES * 256; }
 
 extern "C" int eqd_edge_message_bwd(const EqdGraph* g, const EqdEdgeParams* p, const float* P, const float* Q,
                                     const float* x, const float* d_aggr_msg, const float* d_xnew, float* dP,
@@ -746,9 +704,8 @@ int eqd_edge_message_bwd_impl(const EqdGraph* g, const EqdEdgeParams* p, const f
         return EQD_ERR_WORKSPACE;
     }
     const int blocks = edge_bwd_blocks(g);
-    if (g->n_tiles > 0) {
-        hipLaunchKernelGGL(k_edge_bwd, dim3(blocks), dim3(64 * BWD_WAVES), 0, st, *g, *p, P, Q, x, d_aggr_msg, d_xnew, dQ,
-                           dx, W);
+    if (g->n_edges > 0) {
+        hipLaunchKernelGGL(k_edge_bwd, dim3(blocks), dim3(64 * BWD_WAVES), 0, st, *g, *p, P, Q, x, d_aggr_msg, d_xnew, W);
         int rc = eqd_check_launch("k_edge_bwd");
         if (rc) return rc;
         const int nw = blocks * BWD_WAVES;
@@ -764,5 +721,6 @@ int eqd_edge_message_bwd_impl(const EqdGraph* g, const EqdEdgeParams* p, const f
     edge_atb_jobs(g, p, grads, W, jobs);
     int rc = eqd_atb(jobs + (p->use_he ? 0 : 1), p->use_he ? 4 : 3, part, pb, st);
     if (rc) return rc;
-    return eqd_launch_csc_gather(g, W.dz1, W.dxrel, dP, dx, st);
+    // per-node sums: dP (by source), dQ (by destination), dx = (1 - eta) d_xnew + sum_src dx_rel - sum_dst dx_rel
+    return eqd_launch_node_gather(g, W.dz1, W.dxrel, d_xnew, 1.f - p->eta, dP, dQ, dx, st);
 }

@@ -602,29 +602,39 @@ int eqd_launch_embed_bwd(const EqdGraph* g, const float* dh0, const float* dh0b,
     return eqd_launch_vec_reduce(partial, nb, 21 * d_emb, 21 * d_emb, demb, st);
 }
 
-// dP[j] = sum over out-edges e of node j (CSC) of dz[e]; dx[j] += sum of dxrel[e]
-__global__ void k_csc_gather(const int32_t* __restrict__ csc_ptr, const int32_t* __restrict__ csc_eid, int n,
-                             const float* __restrict__ dz, const float* __restrict__ dxrel, float* __restrict__ dP,
-                             float* __restrict__ dx) {
+// Per-node sums of the per-edge backward outputs (no atomics):
+//   dP[j] = sum over out-edges (CSC, edges with src == j) of dz[e]
+//   dQ[j] = sum over in-edges  (CSR, edges with dst == j) of dz[e]
+//   dx[j] = a * d_xnew[j] + sum_{src == j} dxrel[e] - sum_{dst == j} dxrel[e]      (x_rel = x[src] - x[dst])
+__global__ void k_node_gather(const int32_t* __restrict__ csc_ptr, const int32_t* __restrict__ csc_eid,
+                              const int32_t* __restrict__ rowptr, int n, const float* __restrict__ dz,
+                              const float* __restrict__ dxrel, const float* __restrict__ d_xnew, float a,
+                              float* __restrict__ dP, float* __restrict__ dQ, float* __restrict__ dx) {
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int c = threadIdx.x & 63;
     if (j >= n) return;
-    const int e0 = csc_ptr[j], e1 = csc_ptr[j + 1];
-    float s = 0.f, sx = 0.f;
-    for (int q = e0; q < e1; ++q) {
+    const int s0 = csc_ptr[j], s1 = csc_ptr[j + 1];
+    const int d0 = rowptr[j], d1 = rowptr[j + 1];
+    float sp = 0.f, sq = 0.f, sx = 0.f;
+    for (int q = s0; q < s1; ++q) {
         const int e = csc_eid[q];
-        s += dz[(size_t)e * 64 + c];
+        sp += dz[(size_t)e * 64 + c];
         if (c < 3) sx += dxrel[(size_t)e * 4 + c];
     }
-    dP[(size_t)j * 64 + c] = s;
-    if (c < 3) dx[(size_t)j * 3 + c] += sx;
+    for (int e = d0; e < d1; ++e) {
+        sq += dz[(size_t)e * 64 + c];
+        if (c < 3) sx -= dxrel[(size_t)e * 4 + c];
+    }
+    dP[(size_t)j * 64 + c] = sp;
+    dQ[(size_t)j * 64 + c] = sq;
+    if (c < 3) dx[(size_t)j * 3 + c] = a * d_xnew[(size_t)j * 3 + c] + sx;
 }
-int eqd_launch_csc_gather(const EqdGraph* g, const float* dz, const float* dxrel, float* dP, float* dx,
-                          hipStream_t st) {
+int eqd_launch_node_gather(const EqdGraph* g, const float* dz, const float* dxrel, const float* d_xnew, float a,
+                           float* dP, float* dQ, float* dx, hipStream_t st) {
     if (g->n_nodes == 0) return EQD_OK;
-    hipLaunchKernelGGL(k_csc_gather, dim3((g->n_nodes + 3) / 4), dim3(256), 0, st, g->csc_ptr, g->csc_eid, g->n_nodes,
-                       dz, dxrel, dP, dx);
-    return eqd_check_launch("k_csc_gather");
+    hipLaunchKernelGGL(k_node_gather, dim3((g->n_nodes + 3) / 4), dim3(256), 0, st, g->csc_ptr, g->csc_eid, g->rowptr,
+                       g->n_nodes, dz, dxrel, d_xnew, a, dP, dQ, dx);
+    return eqd_check_launch("k_node_gather");
 }
 
 // Backward of LeakyReLU -> LayerNorm (node_mlp.2/.3): y_act = LeakyReLU(z) is saved by the forward.
