@@ -114,6 +114,21 @@ struct EqdRedList {
     int n;
 };
 
+// row-local job chains (k_rowchain)
+#define EQD_CHAIN_MAXJOBS 8
+struct EqdChainJob {
+    EqdLinJob lin;
+    int src_local[EQD_MAX_SRC];   // >= 0: source i is the LDS tile left by an earlier job, else global lin.s[i].X
+    int out_local;                // >= 0: keep the result in this LDS tile (0..3)
+    int type;                     // 0 linear; 1 LeakyReLU->LayerNorm backward (see chain_lnbwd)
+    float* aux;                   // type 1: per-workgroup partial sums [blocks][256]
+};
+struct EqdChainArg {
+    EqdChainJob j[EQD_CHAIN_MAXJOBS];
+    int njobs;
+};
+int eqd_launch_rowchain(const EqdChainJob* jobs, int njobs, int rows, hipStream_t st);
+
 // internal launchers (defined across the .hip files)
 int eqd_launch_vec_reduce(const float* partial, int nparts, int pstride, int n, float* out, hipStream_t st);
 int eqd_launch_embed_fwd(const EqdGraph* g, const float* emb, int d_emb, int use_mu, float* h0, int ld, hipStream_t st);
@@ -128,7 +143,8 @@ int eqd_launch_ln_act_bwd(const float* y_act, const float* d_out, const float* g
 int eqd_edge_message_bwd_impl(const EqdGraph* g, const EqdEdgeParams* p, const float* P, const float* Q, const float* x,
                               const float* d_aggr_msg, const float* d_xnew, float* dP, float* dQ, float* dx,
                               const EqdEdgeGrads* grads, void* workspace, size_t ws_bytes, hipStream_t st,
-                              float* vecp_override, EqdRedList* defer);
+                              float* vecp_override, EqdRedList* defer, hipStream_t st_atb = nullptr,
+                              hipEvent_t ev_fork = nullptr, hipEvent_t ev_done = nullptr);
 size_t eqd_edge_bwd_vecp_floats(const EqdGraph* g);
 int eqd_keypoint_pool_fwd_impl(const EqdGraph* g, int n_heads, const float* Wk, const float* Wq, const float* qmean,
                                const float* H, const float* Z, float* Y, float* Y_lig_out, float* Y_rec_out,

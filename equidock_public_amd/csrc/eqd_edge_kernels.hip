@@ -688,7 +688,8 @@ extern "C" int eqd_edge_message_bwd(const EqdGraph* g, const EqdEdgeParams* p, c
 int eqd_edge_message_bwd_impl(const EqdGraph* g, const EqdEdgeParams* p, const float* P, const float* Q, const float* x,
                               const float* d_aggr_msg, const float* d_xnew, float* dP, float* dQ, float* dx,
                               const EqdEdgeGrads* grads, void* workspace, size_t ws_bytes, hipStream_t st,
-                              float* vecp_override, EqdRedList* defer) {
+                              float* vecp_override, EqdRedList* defer, hipStream_t st_atb, hipEvent_t ev_fork,
+                              hipEvent_t ev_done) {
     if (!g || !p || !P || !Q || !x || !d_aggr_msg || !d_xnew || !dP || !dQ || !dx || !grads) {
         eqd_set_error("eqd_edge_message_bwd: NULL argument");
         return EQD_ERR_NULL;
@@ -719,8 +720,21 @@ int eqd_edge_message_bwd_impl(const EqdGraph* g, const EqdEdgeParams* p, const f
     }
     EqdAtbJob jobs[4];
     edge_atb_jobs(g, p, grads, W, jobs);
-    int rc = eqd_atb(jobs + (p->use_he ? 0 : 1), p->use_he ? 4 : 3, part, pb, st);
+    // the weight-gradient GEMMs only feed the gradient buffer: run them on the side stream when one is given
+    // (the caller makes the NEXT k_edge_bwd wait for ev_done before it overwrites the per-edge operands)
+    const bool side = st_atb && st_atb != st && ev_fork && ev_done;
+    if (side) {
+        if (hipEventRecord(ev_fork, st) != hipSuccess || hipStreamWaitEvent(st_atb, ev_fork, 0) != hipSuccess) {
+            eqd_set_error("eqd_edge_message_bwd: event fork failed");
+            return EQD_ERR_LAUNCH;
+        }
+    }
+    int rc = eqd_atb(jobs + (p->use_he ? 0 : 1), p->use_he ? 4 : 3, part, pb, side ? st_atb : st);
     if (rc) return rc;
+    if (side && hipEventRecord(ev_done, st_atb) != hipSuccess) {
+        eqd_set_error("eqd_edge_message_bwd: event record failed");
+        return EQD_ERR_LAUNCH;
+    }
     // per-node sums: dP (by source), dQ (by destination), dx = (1 - eta) d_xnew + sum_src dx_rel - sum_dst dx_rel
     return eqd_launch_node_gather(g, W.dz1, W.dxrel, d_xnew, 1.f - p->eta, dP, dQ, dx, st);
 }

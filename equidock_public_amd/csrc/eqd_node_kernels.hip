@@ -4,6 +4,7 @@
 // Reference arithmetic replaced: every nn.Linear / nn.LayerNorm / nn.Embedding on the hot path
 // (src/model/rigid_docking_model.py:119-159, 382, 427-438) and their autograd backward.
 #include "eqd_common.h"
+#include "eqd_linear_inl.h"
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -41,171 +42,113 @@ struct LinJobsArg {
     EqdLinJob j[LIN_MAXJOBS];
 };
 
-#define LIN_KC 80   /* K chunk staged per step (every source of the IEGMN path has K <= 69) */
-#define LIN_S 81    /* LDS row stride: odd -> the 16 rows of a fragment read hit 16 different banks */
-// A workgroup owns 16 rows.  Per source chunk: ALL loads (X tile 16 x Kc, weight slice M x Kc) are
-// issued together by the 256 threads as coalesced 64-byte row segments, parked in registers while the
-// previous chunk is multiplied, then written to LDS; MFMA operands come from LDS.  Wave w owns output
-// blocks mb = w and w + 4, so accumulators are complete (no cross-wave reduction); LayerNorm statistics
-// are exchanged through LDS.  These GEMMs are tiny (3200 x 64..384 x 64 at config B): what matters is
-// one memory round trip per source instead of one per 4 k-values.
-struct LinRegs {
-    float x[5], w[25];
-};
-__device__ __forceinline__ void lin_load(const EqdLinJob& J, const EqdLinSrc& S, int k0, int row0, int t, LinRegs& R) {
-    const int Kc = (S.K - k0 < LIN_KC) ? S.K - k0 : LIN_KC;
-    const int tr = t >> 4, tc = t & 15;
-    const int row = row0 + tr;
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        const int k = tc + 16 * j;
-        float v = 0.f;
-        if (row < J.rows && k < Kc) {
-            const size_t o = (size_t)row * S.ldx + k0 + k;
-            v = S.X[o];
-            if (S.mask) v *= lrelu_grad(S.mask[o], J.slope);
-        }
-        R.x[j] = v;
-    }
-    const bool kfast = (S.w_cs == 1);
-#pragma unroll
-    for (int jm = 0; jm < 5; ++jm)
-#pragma unroll
-        for (int jk = 0; jk < 5; ++jk) {
-            const int m = (kfast ? tr : tc) + 16 * jm;
-            const int k = (kfast ? tc : tr) + 16 * jk;
-            R.w[jm * 5 + jk] = (m < J.M && k < Kc) ? S.W[(size_t)m * S.w_rs + (size_t)(k0 + k) * S.w_cs] : 0.f;
-        }
-}
-__device__ __forceinline__ void lin_store(const EqdLinSrc& S, int t, const LinRegs& R, float* __restrict__ Xl,
-                                          float* __restrict__ Wl) {
-    const int tr = t >> 4, tc = t & 15;
-#pragma unroll
-    for (int j = 0; j < 5; ++j) Xl[tr * LIN_S + tc + 16 * j] = R.x[j];
-    const bool kfast = (S.w_cs == 1);
-#pragma unroll
-    for (int jm = 0; jm < 5; ++jm)
-#pragma unroll
-        for (int jk = 0; jk < 5; ++jk) {
-            const int m = (kfast ? tr : tc) + 16 * jm;
-            const int k = (kfast ? tc : tr) + 16 * jk;
-            Wl[m * LIN_S + k] = R.w[jm * 5 + jk];
-        }
-}
-
 __global__ __launch_bounds__(EQD_BLOCK) void k_linear(LinJobsArg jobs) {
-    __shared__ float Xl[16 * LIN_S];
-    __shared__ float Wl[80 * LIN_S];
-    __shared__ float stat[EQD_WAVES][16];
+    __shared__ LinSmem sm;
     const EqdLinJob& J = jobs.j[blockIdx.y];
-    const int t = threadIdx.x;
-    const int lane = t & 63, wave = t >> 6;
-    const int l15 = lane & 15, g = lane >> 4;
     const int row0 = (int)blockIdx.x * 16;
     if (row0 >= J.rows) return;      // uniform for the whole workgroup
-    const int M = J.M;
-    const int mbn = (M + 15) >> 4;
-    const int rowi = row0 + l15;
-    const bool rv = rowi < J.rows;
-    // this wave's output blocks and their epilogue operands (prefetched: latency hides under the GEMM)
-    const int mbs[2] = {wave, wave + 4};
-    const bool own[2] = {wave < mbn, wave + 4 < mbn};
-    float bias[2][4], lg[2][4], lb[2][4], res[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int f = 16 * mbs[i] + 4 * g + r;
-            const bool ok = own[i] && f < M;
-            bias[i][r] = (ok && J.bias) ? J.bias[f] : 0.f;
-            lg[i][r] = (ok && J.ln_g) ? J.ln_g[f] : 0.f;
-            lb[i][r] = (ok && J.ln_g) ? J.ln_b[f] : 0.f;
-            res[i][r] = (ok && J.R && rv) ? J.R[(size_t)rowi * J.ldr + f] : 0.f;
-        }
-    f32x4 acc[2] = {f4zero(), f4zero()};
+    linear_tile(J, nullptr, -1, sm, nullptr, row0);
+}
 
-    // ---- pipelined (source, K chunk) steps ------------------------------------------------------------
-    LinRegs R;
-    int s = 0, k0 = 0;
-    lin_load(J, J.s[0], 0, row0, t, R);
-    while (s < J.nsrc) {
-        const EqdLinSrc& S = J.s[s];
-        const int Kc = (S.K - k0 < LIN_KC) ? S.K - k0 : LIN_KC;
-        __syncthreads();                  // previous chunk's fragment reads are done
-        lin_store(S, t, R, Xl, Wl);
-        __syncthreads();
-        int ns = s, nk0 = k0 + LIN_KC;    // next step
-        if (nk0 >= S.K) {
-            ns = s + 1;
-            nk0 = 0;
-        }
-        if (ns < J.nsrc) lin_load(J, J.s[ns], nk0, row0, t, R);
-        const int nks = (Kc + 3) >> 2;
-        for (int ks = 0; ks < nks; ++ks) {
-            const float b = Xl[l15 * LIN_S + 4 * ks + g];
+// ------------------------------------------------------------------------------------------
+// k_rowchain: a sequence of row-local jobs on the same 16 rows in ONE launch; intermediate tiles stay
+// in LDS.  Replaces  node_mlp.0 -> LayerNorm -> node_mlp.4 (+skip) -> next layer's P/Q/q/k/v
+// (7 jobs, was 3 launches) in the forward, and  node_mlp.4^T -> LeakyReLU/LayerNorm backward ->
+// d aggr_msg / d aggr_cross / d h0  (5 jobs, was 3 launches + a reduction) in the backward.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void chain_lnbwd(const EqdChainJob& C, float (*Lb)[16 * LIN_S], float (*red)[256],
+                                            int row0) {
+    // y_act = LeakyReLU(z) (saved by the forward) is lin.s[0].X; the incoming gradient is the LDS tile
+    // src_local[0]; dz goes to LDS tile out_local and to lin.Y; per-workgroup (d gamma | d beta) to aux.
+    const EqdLinJob& J = C.lin;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int d = J.M;
+    const int f0 = lane, f1 = lane + 64;
+    const bool v0 = f0 < d, v1 = f1 < d;
+    const float g0 = v0 ? J.ln_g[f0] : 0.f, g1 = v1 ? J.ln_g[f1] : 0.f;
+    const float invd = 1.f / (float)d;
+    const float* __restrict__ din = Lb[C.src_local[0]];
+    float* __restrict__ dout = Lb[C.out_local];
+    float dg0 = 0.f, dg1 = 0.f, db0 = 0.f, db1 = 0.f;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                if (own[i]) acc[i] = mfma4(Wl[(16 * mbs[i] + l15) * LIN_S + 4 * ks + g], b, acc[i]);
+    for (int rr = 0; rr < 4; ++rr) {
+        const int lr = 4 * wave + rr;
+        const int row = row0 + lr;
+        const bool rv = row < J.rows;
+        const size_t o = (size_t)(rv ? row : 0) * J.s[0].ldx;
+        const float y0 = (rv && v0) ? J.s[0].X[o + f0] : 0.f, y1 = (rv && v1) ? J.s[0].X[o + f1] : 0.f;
+        const float o0 = (rv && v0) ? din[lr * LIN_S + f0] : 0.f, o1 = (rv && v1) ? din[lr * LIN_S + f1] : 0.f;
+        const float mean = wave_sum(y0 + y1) * invd;
+        const float c0 = v0 ? y0 - mean : 0.f, c1 = v1 ? y1 - mean : 0.f;
+        const float rstd = 1.f / sqrtf(wave_sum(c0 * c0 + c1 * c1) * invd + J.ln_eps);
+        const float xh0 = c0 * rstd, xh1 = c1 * rstd;
+        const float dx0 = o0 * g0, dx1 = o1 * g1;
+        const float s1 = wave_sum(dx0 + dx1) * invd;
+        const float s2 = wave_sum(dx0 * xh0 + dx1 * xh1) * invd;
+        const float z0 = rstd * (dx0 - s1 - xh0 * s2) * lrelu_grad(y0, J.slope);
+        const float z1 = rstd * (dx1 - s1 - xh1 * s2) * lrelu_grad(y1, J.slope);
+        if (v0) dout[lr * LIN_S + f0] = rv ? z0 : 0.f;
+        if (v1) dout[lr * LIN_S + f1] = rv ? z1 : 0.f;
+        if (rv && J.Y) {
+            if (v0) J.Y[(size_t)row * J.ldy + f0] = z0;
+            if (v1) J.Y[(size_t)row * J.ldy + f1] = z1;
         }
-        s = ns;
-        k0 = nk0;
+        if (rv) {
+            dg0 += o0 * xh0;
+            dg1 += o1 * xh1;
+            db0 += o0;
+            db1 += o1;
+        }
     }
+    red[wave][lane] = dg0;
+    red[wave][64 + lane] = dg1;
+    red[wave][128 + lane] = db0;
+    red[wave][192 + lane] = db1;
+    __syncthreads();
+    C.aux[(size_t)blockIdx.x * 256 + t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+}
 
-    // ---- epilogue in F-layout: feature f = 16 mb + 4 g + r, row = rowi ------------------------------------
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int f = 16 * mbs[i] + 4 * g + r;
-            float v = acc[i][r] + bias[i][r];
-            if (J.act) v = lrelu(v, J.slope);
-            acc[i][r] = (own[i] && f < M) ? v : 0.f;
+__global__ __launch_bounds__(EQD_BLOCK) void k_rowchain(EqdChainArg A) {
+    __shared__ LinSmem sm;
+    __shared__ float Lb[LIN_LOCALS][16 * LIN_S];
+    __shared__ float red[EQD_WAVES][256];
+    const int row0 = (int)blockIdx.x * 16;
+    for (int i = threadIdx.x; i < LIN_LOCALS * 16 * LIN_S; i += EQD_BLOCK) (&Lb[0][0])[i] = 0.f;
+    __syncthreads();
+    for (int jj = 0; jj < A.njobs; ++jj) {
+        const EqdChainJob& C = A.j[jj];
+        if (C.type == 0)
+            linear_tile(C.lin, C.src_local, C.out_local, sm, Lb, row0);
+        else
+            chain_lnbwd(C, Lb, red, row0);
+        __syncthreads();
+    }
+}
+
+int eqd_launch_rowchain(const EqdChainJob* jobs, int njobs, int rows, hipStream_t st) {
+    if (njobs <= 0 || njobs > EQD_CHAIN_MAXJOBS) {
+        eqd_set_error("eqd_launch_rowchain: %d jobs (1..%d)", njobs, EQD_CHAIN_MAXJOBS);
+        return EQD_ERR_SHAPE;
+    }
+    if (rows <= 0) return EQD_OK;
+    EqdChainArg arg;
+    memset(&arg, 0, sizeof(arg));
+    for (int i = 0; i < njobs; ++i) {
+        arg.j[i] = jobs[i];
+        const EqdLinJob& J = jobs[i].lin;
+        if (J.M <= 0 || J.M > 80 || J.rows != rows) {
+            eqd_set_error("eqd_launch_rowchain: job %d has M=%d rows=%d (chain rows %d)", i, J.M, J.rows, rows);
+            return EQD_ERR_SHAPE;
         }
-    if (J.ln_g) {
-        const float invM = 1.f / (float)M;
-        float sm = 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sm += acc[i][r];
-        sm = group_sum(sm);
-        if (g == 0) stat[wave][l15] = sm;
-        __syncthreads();
-        const float mean = (stat[0][l15] + stat[1][l15] + stat[2][l15] + stat[3][l15]) * invM;
-        float q = 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int f = 16 * mbs[i] + 4 * g + r;
-                const float dlt = (own[i] && f < M) ? acc[i][r] - mean : 0.f;
-                q += dlt * dlt;
-            }
-        q = group_sum(q);
-        __syncthreads();
-        if (g == 0) stat[wave][l15] = q;
-        __syncthreads();
-        const float rstd = 1.f / sqrtf((stat[0][l15] + stat[1][l15] + stat[2][l15] + stat[3][l15]) * invM + J.ln_eps);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int f = 16 * mbs[i] + 4 * g + r;
-                if (own[i] && f < M) {
-                    const float v = acc[i][r];
-                    if (J.pre_ln && rv) J.pre_ln[(size_t)rowi * J.ld_pre + f] = v;
-                    acc[i][r] = (v - mean) * rstd * lg[i][r] + lb[i][r];
-                }
+        for (int s = 0; s < J.nsrc; ++s)
+            if (jobs[i].src_local[s] >= 0 && J.s[s].K > LIN_KC) {
+                eqd_set_error("eqd_launch_rowchain: LDS-resident source wider than %d", LIN_KC);
+                return EQD_ERR_SHAPE;
             }
     }
-    if (!rv) return;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int f = 16 * mbs[i] + 4 * g + r;
-            if (own[i] && f < M) J.Y[(size_t)rowi * J.ldy + f] = J.alpha * acc[i][r] + J.beta * res[i][r];
-        }
+    arg.njobs = njobs;
+    hipLaunchKernelGGL(k_rowchain, dim3((rows + 15) / 16), dim3(EQD_BLOCK), 0, st, arg);
+    return eqd_check_launch("k_rowchain");
 }
 
 extern "C" int eqd_linear(const EqdLinJob* jobs, int njobs, void* stream) {
@@ -616,14 +559,37 @@ __global__ void k_node_gather(const int32_t* __restrict__ csc_ptr, const int32_t
     const int s0 = csc_ptr[j], s1 = csc_ptr[j + 1];
     const int d0 = rowptr[j], d1 = rowptr[j + 1];
     float sp = 0.f, sq = 0.f, sx = 0.f;
-    for (int q = s0; q < s1; ++q) {
-        const int e = csc_eid[q];
-        sp += dz[(size_t)e * 64 + c];
-        if (c < 3) sx += dxrel[(size_t)e * 4 + c];
+    // batches of 8 edges: all indices, then all rows, are in flight together (2 dependent round trips per
+    // batch instead of 2 per edge)
+    for (int q0 = s0; q0 < s1; q0 += 8) {
+        int e[8];
+        float v[8], w[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) e[i] = (q0 + i < s1) ? csc_eid[q0 + i] : -1;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            v[i] = e[i] >= 0 ? dz[(size_t)e[i] * 64 + c] : 0.f;
+            w[i] = (e[i] >= 0 && c < 3) ? dxrel[(size_t)e[i] * 4 + c] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            sp += v[i];
+            sx += w[i];
+        }
     }
-    for (int e = d0; e < d1; ++e) {
-        sq += dz[(size_t)e * 64 + c];
-        if (c < 3) sx -= dxrel[(size_t)e * 4 + c];
+    for (int e0 = d0; e0 < d1; e0 += 8) {
+        float v[8], w[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bool ok = e0 + i < d1;
+            v[i] = ok ? dz[(size_t)(e0 + i) * 64 + c] : 0.f;
+            w[i] = (ok && c < 3) ? dxrel[(size_t)(e0 + i) * 4 + c] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            sq += v[i];
+            sx -= w[i];
+        }
     }
     dP[(size_t)j * 64 + c] = sp;
     dQ[(size_t)j * 64 + c] = sq;

@@ -32,3 +32,6 @@ pos = [g for g, n in gaps if g > 0]
 print(f'positive gaps: n={len(pos)} total={sum(pos)/1e3:.1f} us, mean={sum(pos)/max(1,len(pos))/1e3:.2f} us')
 if len(sys.argv) > 2:
     for r in step[:int(sys.argv[2])]: print(f'{(r[0]-t0)/1e3:8.1f} {(r[1]-r[0])/1e3:7.1f} q{r[4]} {r[2][:50]}')
+if len(sys.argv) > 3:
+    pat = sys.argv[3]
+    print(pat, [round((r[1]-r[0])/1e3, 1) for r in step if pat in r[2]])
