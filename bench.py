@@ -60,7 +60,7 @@ def time_kernel(fn, iters, stream_sync):
     return e0.elapsed_time(e1) / iters * 1e-3   # seconds per launch
 
 
-def edge_kernel_rooflines(net, packed, dev):
+def edge_kernel_rooflines(net, packed, dev, workload='B'):
     """Launch the edge-message kernels standalone (layer-1 weights, the workload's graph) on torch's
     current stream and time them with HIP events on that stream."""
     from equidock_public_amd import _lib
@@ -126,6 +126,16 @@ def edge_kernel_rooflines(net, packed, dev):
                      "algorithmic_bytes_per_launch": byte_f * mult,
                      "hbm_algorithmic_GBps": round(gb, 1), "hbm_frac_algorithmic": round(gb / PEAK_HBM_GBS, 4)}
     out['k_edge_bwd']['whole_bwd_op_us'] = round(t_bwd_op * 1e6, 2)   # + weight-grad GEMMs, reductions, CSC gather
+    # HBM bytes per launch from the committed PMC passes (profiles/r01_traffic.json; counters cannot be read
+    # from inside the process): (2 * FETCH_SIZE + WRITE_SIZE) KB, see the file's comment for the correction
+    try:
+        tr = json.load(open(os.path.join(ROOT, 'profiles', 'r01_traffic.json'))).get(workload, {})
+        for k, v in tr.items():
+            if k in out:
+                out[k]['traffic'] = int((2 * v['FETCH_SIZE_KB'] + v['WRITE_SIZE_KB']) * 1024)
+                out[k]['traffic_source'] = 'profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)'
+    except Exception:
+        pass
     return out
 
 
@@ -268,7 +278,7 @@ def main():
                        "host_enqueue_ms_per_step": round(host_dt / a.steps * 1e3, 4), "launch_mode": graph_mode},
         }
         if not a.no_roofline:
-            rl = edge_kernel_rooflines(net, packed, dev)
+            rl = edge_kernel_rooflines(net, packed, dev, a.workload)
             dom = max(rl, key=lambda k: rl[k]["avg_launch_us"])
             out["roofline"] = dict(rl[dom], kernel=dom)
             out["roofline_all"] = rl
