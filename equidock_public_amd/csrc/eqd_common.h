@@ -100,6 +100,8 @@ struct EqdRedSeg {
     const float* partial;
     int nparts, pstride, n;
     float* out;
+    int cols, cols_valid, ld_out;   // cols > 0: element i = (row i / cols, col i % cols) -> out[row * ld_out + col],
+                                    // columns >= cols_valid are skipped; cols == 0: out[i]
 };
 // segments that accumulate into the SAME output (shared layers) form a chain handled by one
 // workgroup column, so that no two workgroups ever update the same address
@@ -143,8 +145,7 @@ int eqd_launch_ln_act_bwd(const float* y_act, const float* d_out, const float* g
 int eqd_edge_message_bwd_impl(const EqdGraph* g, const EqdEdgeParams* p, const float* P, const float* Q, const float* x,
                               const float* d_aggr_msg, const float* d_xnew, float* dP, float* dQ, float* dx,
                               const EqdEdgeGrads* grads, void* workspace, size_t ws_bytes, hipStream_t st,
-                              float* vecp_override, EqdRedList* defer, hipStream_t st_atb = nullptr,
-                              hipEvent_t ev_fork = nullptr, hipEvent_t ev_done = nullptr);
+                              float* part_override, EqdRedList* defer);
 size_t eqd_edge_bwd_vecp_floats(const EqdGraph* g);
 int eqd_keypoint_pool_fwd_impl(const EqdGraph* g, int n_heads, const float* Wk, const float* Wq, const float* qmean,
                                const float* H, const float* Z, float* Y, float* Y_lig_out, float* Y_rec_out,

@@ -534,10 +534,10 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
             RC(eqd_launch_rowchain(cj, nj, N, st));
             const int nb = (N + 15) / 16;
             if (defer->n + 2 <= 512) {
-                defer->seg[defer->n++] = EqdRedSeg{lnp, nb, 256, d, gp[P_NLG]};
-                defer->seg[defer->n++] = EqdRedSeg{lnp + 128, nb, 256, d, gp[P_NLB]};
+                defer->seg[defer->n++] = EqdRedSeg{lnp, nb, 256, d, gp[P_NLG], 0, 0, 0};
+                defer->seg[defer->n++] = EqdRedSeg{lnp + 128, nb, 256, d, gp[P_NLB], 0, 0, 0};
             } else {
-                EqdRedSeg segs[2] = {{lnp, nb, 256, d, gp[P_NLG]}, {lnp + 128, nb, 256, d, gp[P_NLB]}};
+                EqdRedSeg segs[2] = {{lnp, nb, 256, d, gp[P_NLG], 0, 0, 0}, {lnp + 128, nb, 256, d, gp[P_NLB], 0, 0, 0}};
                 RC(eqd_launch_reduce_segments(segs, 2, st));
             }
         }
@@ -562,12 +562,8 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
             memset(&eg, 0, sizeof(eg));
             eg.dW1 = gp[P_W1]; eg.ldw1 = D.ldw1(l); eg.dln_g = gp[P_LNG]; eg.dln_b = gp[P_LNB]; eg.dW2 = gp[P_W2];
             eg.db2 = gp[P_B2]; eg.dWc1 = gp[P_WC1]; eg.dbc1 = gp[P_BC1]; eg.dwc2 = gp[P_WC2]; eg.dbc2 = gp[P_BC2];
-            // the previous layer's edge weight-gradient GEMMs (side stream) still read the per-edge operands
-            if (cx && l < D.L - 1) HIPOK(hipStreamWaitEvent(st, cx->edge_atb_done, 0));
             RC(eqd_edge_message_bwd_impl(g, &ep, Ls.P, Ls.Q, S.x[l], W.d_aggr_msg, dXcur, dP, dQ, dXnext, &eg, W.edge_ws,
-                                         W.edge_ws_bytes, st, W.vecp_all + (size_t)l * W.vecp_stride, defer,
-                                         cx ? cx->sc : nullptr, cx ? cx->fork3 : nullptr,
-                                         cx ? cx->edge_atb_done : nullptr));
+                                         W.edge_ws_bytes, st, W.vecp_all + (size_t)l * W.vecp_stride, defer));
         }
         if (sa != st) HIPOK(hipStreamWaitEvent(st, cx->join_a, 0));
         // the previous layer's weight-gradient GEMMs still read the buffer dHnext is about to overwrite

@@ -427,18 +427,71 @@ extern "C" int eqd_edge_message_fwd(const EqdGraph* g, const EqdEdgeParams* p, c
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward: 16-edge tiles (not node aligned)
+// backward: 16-edge tiles (not node aligned), weight-gradient GEMMs fused
 // ---------------------------------------------------------------------------------------------
+// Per workgroup iteration the 8 waves own 8 x 16 = 128 consecutive edges.  Each wave recomputes its tile
+// forward and runs the data-gradient chain in registers; three times per iteration the waves drop a
+// pair of per-edge operands (d_chid | m), (dm | a1), (dz1 | [he rbf]) as [128][.] slabs into two shared
+// LDS buffers and every wave accumulates its share of the 16x16 blocks of
+//      dWc1 = d_chid^T m,   dW2 = dm^T a1,   dW1[:, 2d:] = dz1^T [he rbf]
+// over the 128 edges (K axis of the MFMA = edges).  The per-edge operands therefore never reach HBM
+// (the unfused version wrote and re-read 1.36 KB/edge); only dz1 (for the by-source gather dP[src]) and
+// dx_rel are written: 272 B/edge.  Weight-gradient blocks are kept in registers across iterations and
+// written once per workgroup; bias / LayerNorm / coordinate-MLP vector gradients go through per-wave
+// LDS accumulators.  Both partial sets are summed in a fixed order by k_reduce_segments.
+#define US 68          /* row stride of the shared operand slabs */
+#define VP 384         /* floats per wave in the vector partial buffer */
+#define V_DLNG 0
+#define V_DLNB 64
+#define V_DWC2 128
+#define V_DBC2 192
+#define V_DB2 256
+#define V_DBC1 320
+#define VA 384         /* floats per wave actually used */
+#define WP_W2 0        /* offsets inside a workgroup's weight-gradient partial */
+#define WP_WC1 4096
+#define WP_W1 8192     /* [64][48], 42 columns used */
+#define WP_N 11264
+
 struct EdgeBwdWs {
-    float* a1;     // [E][64] LayerNorm output (input of edge_mlp.4)
-    float* m;      // [E][64] messages
-    float* dchid;  // [E][64] grad wrt coors_mlp.0 output
-    float* dm;     // [E][64] grad wrt messages
-    float* dz1;    // [E][64] grad wrt edge_mlp.0 output
-    float* rbf;    // [E][16]
+    float* dz1;    // [E][64] grad wrt edge_mlp.0 output (read by k_node_gather)
     float* dxrel;  // [E][4]
-    float* vecp;   // [nwaves][256]: d ln_g | d ln_b | d wc2 | d bc2 (slot 192)
+    float* vecp;   // [nblocks * 8][VP] vector-gradient partials per wave
+    float* wpart;  // [nblocks][WP_N]  weight-gradient partials per workgroup
 };
+
+// F-layout tile (16 edges x 64 features) -> rows 16 w .. 16 w + 15 of a shared [128][US] slab
+__device__ __forceinline__ void slab_store(float* __restrict__ slab, int wave, const f32x4 (&v)[4][1], int l15, int g) {
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+        *(float4*)&slab[(16 * wave + l15) * US + 16 * mb + 4 * g] =
+            make_float4(v[mb][0][0], v[mb][0][1], v[mb][0][2], v[mb][0][3]);
+}
+// acc[j] += X^T Y over the 128 edges of the slabs for output block (mb, nb0 + j)
+template <int NJ>
+__device__ __forceinline__ void slab_atb(f32x4 (&acc)[NJ], const float* __restrict__ X, const float* __restrict__ Y,
+                                         int mb, int nb0, int l15, int g) {
+#pragma unroll 4
+    for (int s = 0; s < 32; ++s) {
+        const int row = 4 * s + g;
+        const float a = X[row * US + 16 * mb + l15];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[j] = mfma4(a, Y[row * US + 16 * (nb0 + j) + l15], acc[j]);
+    }
+}
+
+// acc += X^T F where F = the waves' [16][FS] feature tiles stacked (row = edge within the 128-edge super-tile)
+__device__ __forceinline__ void feat_atb(f32x4 (&acc)[1], const float* __restrict__ X, const float* __restrict__ tiles,
+                                         int mb, int nb, int l15, int g) {
+    const int c = 16 * nb + l15;
+    const bool ok = c < FS;
+#pragma unroll 4
+    for (int s = 0; s < 32; ++s) {
+        const int row = 4 * s + g;
+        const float b = ok ? tiles[(row >> 4) * (16 * FS) + (row & 15) * FS + c] : 0.f;
+        acc[0] = mfma4(X[row * US + 16 * mb + l15], b, acc[0]);
+    }
+}
 
 __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdgeParams P, const float* __restrict__ Pn,
                                                               const float* __restrict__ Qn,
@@ -446,37 +499,31 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
                                                               const float* __restrict__ d_aggr,
                                                               const float* __restrict__ d_xnew, EdgeBwdWs W) {
     __shared__ EdgeSmem<BWD_WAVES, 16 * FS> sm;
-    __shared__ float vacc[BWD_WAVES][196];
+    __shared__ __attribute__((aligned(16))) float U[128 * US];
+    __shared__ __attribute__((aligned(16))) float V[128 * US];
+    __shared__ float vacc[BWD_WAVES][VA];
     edge_stage_weights(sm, P);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     float* tile = sm.tile[wave];
-    for (int i = lane; i < 196; i += 64) vacc[wave][i] = 0.f;
+    for (int i = lane; i < VA; i += 64) vacc[wave][i] = 0.f;
     wave_lds_fence();
+    // this wave's blocks of the weight gradients: rows 16*wmb.., columns 16*(2*(wave&1)) + {0,16} of the 64x64
+    // matrices; for dW1[:, 2d:] (3 column blocks) block (wmb, wave&1) and, for waves 0..3, block (wave, 2)
+    const int wmb = wave >> 1, wnb = 2 * (wave & 1);
+    f32x4 gW2[2] = {f4zero(), f4zero()}, gWc1[2] = {f4zero(), f4zero()}, gW1a[1] = {f4zero()}, gW1b[1] = {f4zero()};
     const int n_tiles = (G.n_edges + 15) >> 4;
-    for (int t = blockIdx.x * BWD_WAVES + wave; t < n_tiles; t += gridDim.x * BWD_WAVES) {
+    const int n_super = (n_tiles + BWD_WAVES - 1) / BWD_WAVES;
+    for (int it = blockIdx.x; it < n_super; it += gridDim.x) {
+        const int t = it * BWD_WAVES + wave;
         EdgeTileState<1> S;
         S.n0 = S.n1 = 0;
         S.e0 = 16 * t;
-        S.ne = (G.n_edges - S.e0 < 16) ? G.n_edges - S.e0 : 16;
+        S.ne = G.n_edges - S.e0;
+        S.ne = S.ne < 0 ? 0 : (S.ne > 16 ? 16 : S.ne);
+        if (S.ne == 0) S.e0 = 0;
         f32x4 xh[4][1], m[4][1], ch[4][1];
-        edge_tile_forward<1>(G, P, sm.w1, sm.w2, sm.wc1, sm.vec, tile, Pn, Qn, x, lane, S, xh, m, ch, W.rbf);
-        wave_lds_fence();
-        // ---- operands of the weight-gradient GEMMs that the forward defines --------------------
-        {
-            f32x4 a1[4][1];
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
-                const float4 gg = *(const float4*)&sm.vec[VEC_LNG + 16 * mb + 4 * g];
-                const float4 bb = *(const float4*)&sm.vec[VEC_LNB + 16 * mb + 4 * g];
-                a1[mb][0][0] = xh[mb][0][0] * gg.x + bb.x;
-                a1[mb][0][1] = xh[mb][0][1] * gg.y + bb.y;
-                a1[mb][0][2] = xh[mb][0][2] * gg.z + bb.z;
-                a1[mb][0][3] = xh[mb][0][3] * gg.w + bb.w;
-            }
-            hbm_store<1>(W.a1, a1, S, l15, g);
-        }
-        hbm_store<1>(W.m, m, S, l15, g);
+        edge_tile_forward<1>(G, P, sm.w1, sm.w2, sm.wc1, sm.vec, tile, Pn, Qn, x, lane, S, xh, m, ch, nullptr);
         // ---- coordinate path ---------------------------------------------------------------------
         float invdeg = 0.f, dcoef = 0.f, dxr[3] = {0.f, 0.f, 0.f};
         if (S.ev[0]) {
@@ -489,7 +536,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
                 dxr[c] = gx * S.coef[0];
             }
         }
-        // d wc2 / d bc2 partials (reduced over the 16 edge lanes and banked in LDS right away), then
+        // d wc2 / d bc2 / d bc1 partials (reduced over the 16 edge lanes, banked in LDS), then
         // ch := d_chid = wc2 * dcoef * LeakyReLU'(ch)
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
@@ -499,15 +546,24 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
             for (int r = 0; r < 4; ++r) {
                 const float c = ch[mb][0][r];
                 const float acc = l16_sum(lrelu(c, P.slope) * dcoef);
-                ch[mb][0][r] = wv[r] * dcoef * lrelu_grad(c, P.slope);
-                if (l15 == 0) vacc[wave][128 + 16 * mb + 4 * g + r] += acc;
+                const float dch = wv[r] * dcoef * lrelu_grad(c, P.slope);
+                ch[mb][0][r] = dch;
+                const float sb = l16_sum(dch);
+                if (l15 == 0) {
+                    vacc[wave][V_DWC2 + 16 * mb + 4 * g + r] += acc;
+                    vacc[wave][V_DBC1 + 16 * mb + 4 * g + r] += sb;
+                }
             }
         }
         {
             const float dbc2 = l16_sum(dcoef);
-            if (lane == 0) vacc[wave][192] += dbc2;
+            if (lane == 0) vacc[wave][V_DBC2] += dbc2;
         }
-        hbm_store<1>(W.dchid, ch, S, l15, g);
+        // ---- phase 1: dWc1 += d_chid^T m -------------------------------------------------------------
+        slab_store(U, wave, ch, l15, g);
+        slab_store(V, wave, m, l15, g);
+        __syncthreads();
+        slab_atb<2>(gWc1, U, V, wmb, wnb, l15, g);
         // ---- dm = d_aggr[dst] / deg + Wc1^T d_chid ---------------------------------------------------
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
@@ -519,7 +575,31 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
             m[mb][0] = a;
         }
         chain64T<1>(m, ch, sm.wc1, l15, g);
-        hbm_store<1>(W.dm, m, S, l15, g);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sb = l16_sum(m[mb][0][r]);
+                if (l15 == 0) vacc[wave][V_DB2 + 16 * mb + 4 * g + r] += sb;
+            }
+        // ---- phase 2: dW2 += dm^T a1 ---------------------------------------------------------------------
+        __syncthreads();                 // every wave is done reading the phase-1 slabs
+        slab_store(U, wave, m, l15, g);
+        {
+            f32x4 a1[4][1];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const float4 gg = *(const float4*)&sm.vec[VEC_LNG + 16 * mb + 4 * g];
+                const float4 bb = *(const float4*)&sm.vec[VEC_LNB + 16 * mb + 4 * g];
+                a1[mb][0][0] = xh[mb][0][0] * gg.x + bb.x;
+                a1[mb][0][1] = xh[mb][0][1] * gg.y + bb.y;
+                a1[mb][0][2] = xh[mb][0][2] * gg.z + bb.z;
+                a1[mb][0][3] = xh[mb][0][3] * gg.w + bb.w;
+            }
+            slab_store(V, wave, a1, l15, g);
+        }
+        __syncthreads();
+        slab_atb<2>(gW2, U, V, wmb, wnb, l15, g);
         // ---- da1 = W2^T dm ---------------------------------------------------------------------------
         f32x4 dz[4][1];
 #pragma unroll
@@ -534,8 +614,8 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
                 const float b = l16_sum(dz[mb][0][r]);
                 if (l15 == 0) {
                     const int f = 16 * mb + 4 * g + r;
-                    vacc[wave][f] += a;
-                    vacc[wave][64 + f] += b;
+                    vacc[wave][V_DLNG + f] += a;
+                    vacc[wave][V_DLNB + f] += b;
                 }
             }
         {
@@ -560,10 +640,17 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
                 for (int r = 0; r < 4; ++r) {
                     const float xhv = xh[mb][0][r];
                     const float lg = ((S.zpos >> (4 * mb + r)) & 1u) ? 1.f : P.slope;
-                    dz[mb][0][r] = S.ev[0] ? S.rstd[0] * (dz[mb][0][r] - s1 - xhv * s2) * lg : 0.f;
+                    const float v = S.ev[0] ? S.rstd[0] * (dz[mb][0][r] - s1 - xhv * s2) * lg : 0.f;
+                    dz[mb][0][r] = v;
                 }
         }
         hbm_store<1>(W.dz1, dz, S, l15, g);
+        // ---- phase 3: dW1[:, 2d:] += dz1^T [he | rbf] ------------------------------------------------------
+        __syncthreads();                 // phase-2 slabs are free
+        slab_store(U, wave, dz, l15, g);
+        __syncthreads();
+        feat_atb(gW1a, U, &sm.tile[0][0], wmb, wave & 1, l15, g);     // the feature tiles are the B operand as they lie
+        if (wave < 4) feat_atb(gW1b, U, &sm.tile[0][0], wave, 2, l15, g);
         // ---- d rbf = W1d^T dz1 -> d(d^2) -> d x_rel --------------------------------------------------------
         if (P.use_dist) {
             f32x4 dr = f4zero();
@@ -591,69 +678,55 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
             float* o = W.dxrel + (size_t)(S.e0 + l15) * 4;
             o[0] = dxr[0]; o[1] = dxr[1]; o[2] = dxr[2]; o[3] = 0.f;
         }
-        wave_lds_fence();
+        __syncthreads();                 // phase-3 slabs and the feature tiles are free for the next iteration
     }
-    wave_lds_fence();
-    float* vp = W.vecp + (size_t)(blockIdx.x * BWD_WAVES + wave) * 256;
-    for (int i = lane; i < 196; i += 64) vp[i] = vacc[wave][i];
+    // ---- partials: this wave's vector sums and weight-gradient blocks ---------------------------------------
+    float* vp = W.vecp + (size_t)(blockIdx.x * BWD_WAVES + wave) * VP;
+    for (int i = lane; i < VA; i += 64) vp[i] = vacc[wave][i];
+    float* wp = W.wpart + (size_t)blockIdx.x * WP_N;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * wmb + 4 * g + r, col = 16 * (wnb + j) + l15;
+            wp[WP_W2 + row * 64 + col] = gW2[j][r];
+            wp[WP_WC1 + row * 64 + col] = gWc1[j][r];
+        }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        wp[WP_W1 + (16 * wmb + 4 * g + r) * 48 + 16 * (wave & 1) + l15] = gW1a[0][r];
+        if (wave < 4) wp[WP_W1 + (16 * wave + 4 * g + r) * 48 + 32 + l15] = gW1b[0][r];
+    }
 }
 
-static int edge_bwd_blocks(const EqdGraph* g) { return edge_grid((g->n_edges + 15) / 16, BWD_WAVES, 2); }
-size_t eqd_edge_bwd_vecp_floats(const EqdGraph* g) { return (size_t)edge_bwd_blocks(g) * BWD_WAVES * 256; }
-
-static void edge_atb_jobs(const EqdGraph* g, const EqdEdgeParams* p, const EqdEdgeGrads* gr, const EdgeBwdWs& W,
-                          EqdAtbJob* jobs) {
-    const int E = g->n_edges;
-    const int koff = 2 * p->d_in;
-    memset(jobs, 0, 4 * sizeof(EqdAtbJob));
-    // dW1[:, 2d:2d+27] = dz1^T he
-    jobs[0].X = W.dz1; jobs[0].ldx = 64; jobs[0].M = 64; jobs[0].Y = g->he; jobs[0].ldy = 27; jobs[0].N = 27;
-    jobs[0].rows = p->use_he ? E : 0; jobs[0].out = gr->dW1 + koff; jobs[0].o_rs = gr->ldw1; jobs[0].o_cs = 1;
-    // dW1[:, 2d+27:] = dz1^T rbf
-    jobs[1].X = W.dz1; jobs[1].ldx = 64; jobs[1].M = 64; jobs[1].Y = W.rbf; jobs[1].ldy = 16; jobs[1].N = 15;
-    jobs[1].rows = E; jobs[1].out = gr->dW1 + koff + 27; jobs[1].o_rs = gr->ldw1; jobs[1].o_cs = 1;
-    // dW2 = dm^T a1, db2 = colsum dm
-    jobs[2].X = W.dm; jobs[2].ldx = 64; jobs[2].M = 64; jobs[2].Y = W.a1; jobs[2].ldy = 64; jobs[2].N = 64;
-    jobs[2].rows = E; jobs[2].out = gr->dW2; jobs[2].o_rs = 64; jobs[2].o_cs = 1; jobs[2].bias_out = gr->db2;
-    // dWc1 = dchid^T m, dbc1 = colsum dchid
-    jobs[3].X = W.dchid; jobs[3].ldx = 64; jobs[3].M = 64; jobs[3].Y = W.m; jobs[3].ldy = 64; jobs[3].N = 64;
-    jobs[3].rows = E; jobs[3].out = gr->dWc1; jobs[3].o_rs = 64; jobs[3].o_cs = 1; jobs[3].bias_out = gr->dbc1;
+static int edge_bwd_blocks(const EqdGraph* g) {
+    const int n_tiles = (g->n_edges + 15) / 16;
+    int n_super = (n_tiles + BWD_WAVES - 1) / BWD_WAVES;
+    if (n_super < 1) n_super = 1;
+    return n_super < 256 ? n_super : 256;      // one workgroup per CU (LDS-bound), persistent over super-tiles
+}
+size_t eqd_edge_bwd_vecp_floats(const EqdGraph* g) {
+    return (size_t)edge_bwd_blocks(g) * (BWD_WAVES * VP + WP_N);
 }
 
-static size_t edge_bwd_carve(const EqdGraph* g, EqdArena& A, EdgeBwdWs* W, float** atb_partial, size_t* atb_bytes) {
+static size_t edge_bwd_carve(const EqdGraph* g, EqdArena& A, EdgeBwdWs* W) {
     const size_t E = (size_t)g->n_edges;
     EdgeBwdWs w;
-    w.a1 = A.take<float>(E * 64);
-    w.m = A.take<float>(E * 64);
-    w.dchid = A.take<float>(E * 64);
-    w.dm = A.take<float>(E * 64);
     w.dz1 = A.take<float>(E * 64);
-    w.rbf = A.take<float>(E * 16);
     w.dxrel = A.take<float>(E * 4);
     w.vecp = A.take<float>(eqd_edge_bwd_vecp_floats(g));
-    // worst-case partial size for the four weight-gradient GEMMs (depends only on E)
-    EqdAtbJob jobs[4];
-    EqdEdgeParams p;
-    memset(&p, 0, sizeof(p));
-    p.use_he = 1;
-    EqdEdgeGrads gr;
-    memset(&gr, 0, sizeof(gr));
-    edge_atb_jobs(g, &p, &gr, w, jobs);
-    size_t pb = eqd_atb_partial_bytes(jobs, 4);
-    float* part = (float*)A.take<char>(pb);
+    w.wpart = w.vecp ? w.vecp + (size_t)edge_bwd_blocks(g) * BWD_WAVES * VP : nullptr;
     if (W) *W = w;
-    if (atb_partial) *atb_partial = part;
-    if (atb_bytes) *atb_bytes = pb;
     return A.off;
 }
 
 extern "C" size_t eqd_edge_message_bwd_workspace_bytes(const EqdGraph* g) {
     EqdArena A(nullptr, 0);
-    return edge_bwd_carve(g, A, nullptr, nullptr, nullptr) + 256;
+    return edge_bwd_carve(g, A, nullptr) + 256;
 }
 
-// Profiling aid: ONLY the per-edge backward kernel of eqd_edge_message_bwd (no weight-gradient GEMMs,
-// no vector reductions, no CSR/CSC gather), so that its duration can be bracketed with HIP events.
+// Profiling aid: ONLY the per-edge backward kernel of eqd_edge_message_bwd (no partial reductions, no
+// CSR/CSC gather), so that its duration can be bracketed with HIP events.
 extern "C" int eqd_edge_message_bwd_kernel_only(const EqdGraph* g, const EqdEdgeParams* p, const float* P,
                                                 const float* Q, const float* x, const float* d_aggr_msg,
                                                 const float* d_xnew, float* dQ, float* dx, void* workspace,
@@ -666,7 +739,7 @@ extern "C" int eqd_edge_message_bwd_kernel_only(const EqdGraph* g, const EqdEdge
     }
     EqdArena A(workspace, ws_bytes);
     EdgeBwdWs W;
-    edge_bwd_carve(g, A, &W, nullptr, nullptr);
+    edge_bwd_carve(g, A, &W);
     if (!A.ok) {
         eqd_set_error("eqd_edge_message_bwd_kernel_only: workspace too small");
         return EQD_ERR_WORKSPACE;
@@ -688,52 +761,41 @@ extern "C" int eqd_edge_message_bwd(const EqdGraph* g, const EqdEdgeParams* p, c
 int eqd_edge_message_bwd_impl(const EqdGraph* g, const EqdEdgeParams* p, const float* P, const float* Q, const float* x,
                               const float* d_aggr_msg, const float* d_xnew, float* dP, float* dQ, float* dx,
                               const EqdEdgeGrads* grads, void* workspace, size_t ws_bytes, hipStream_t st,
-                              float* vecp_override, EqdRedList* defer, hipStream_t st_atb, hipEvent_t ev_fork,
-                              hipEvent_t ev_done) {
+                              float* part_override, EqdRedList* defer) {
     if (!g || !p || !P || !Q || !x || !d_aggr_msg || !d_xnew || !dP || !dQ || !dx || !grads) {
         eqd_set_error("eqd_edge_message_bwd: NULL argument");
         return EQD_ERR_NULL;
     }
     EqdArena A(workspace, ws_bytes);
     EdgeBwdWs W;
-    float* part = nullptr;
-    size_t pb = 0;
-    edge_bwd_carve(g, A, &W, &part, &pb);
-    if (vecp_override) W.vecp = vecp_override;
+    edge_bwd_carve(g, A, &W);
     if (!A.ok) {
         eqd_set_error("eqd_edge_message_bwd: workspace too small (%zu needed, %zu given)", A.off, ws_bytes);
         return EQD_ERR_WORKSPACE;
     }
     const int blocks = edge_bwd_blocks(g);
+    if (part_override) {       // per-layer partial buffers when the reductions are deferred
+        W.vecp = part_override;
+        W.wpart = part_override + (size_t)blocks * BWD_WAVES * VP;
+    }
     if (g->n_edges > 0) {
         hipLaunchKernelGGL(k_edge_bwd, dim3(blocks), dim3(64 * BWD_WAVES), 0, st, *g, *p, P, Q, x, d_aggr_msg, d_xnew, W);
         int rc = eqd_check_launch("k_edge_bwd");
         if (rc) return rc;
         const int nw = blocks * BWD_WAVES;
-        EqdRedSeg segs[4] = {{W.vecp, nw, 256, 64, grads->dln_g}, {W.vecp + 64, nw, 256, 64, grads->dln_b},
-                             {W.vecp + 128, nw, 256, 64, grads->dwc2}, {W.vecp + 192, nw, 256, 1, grads->dbc2}};
-        if (defer && defer->n + 4 <= 512) {
-            for (int i = 0; i < 4; ++i) defer->seg[defer->n++] = segs[i];
-        } else if ((rc = eqd_launch_reduce_segments(segs, 4, st))) {
+        const int koff = 2 * p->d_in;
+        EqdRedSeg segs[9] = {
+            {W.vecp + V_DLNG, nw, VP, 64, grads->dln_g, 0, 0, 0}, {W.vecp + V_DLNB, nw, VP, 64, grads->dln_b, 0, 0, 0},
+            {W.vecp + V_DWC2, nw, VP, 64, grads->dwc2, 0, 0, 0},  {W.vecp + V_DBC2, nw, VP, 1, grads->dbc2, 0, 0, 0},
+            {W.vecp + V_DB2, nw, VP, 64, grads->db2, 0, 0, 0},    {W.vecp + V_DBC1, nw, VP, 64, grads->dbc1, 0, 0, 0},
+            {W.wpart + WP_W2, blocks, WP_N, 4096, grads->dW2, 0, 0, 0},
+            {W.wpart + WP_WC1, blocks, WP_N, 4096, grads->dWc1, 0, 0, 0},
+            {W.wpart + WP_W1, blocks, WP_N, 64 * 48, grads->dW1 + koff, 48, 42, grads->ldw1}};
+        if (defer && defer->n + 9 <= 512) {
+            for (int i = 0; i < 9; ++i) defer->seg[defer->n++] = segs[i];
+        } else if ((rc = eqd_launch_reduce_segments(segs, 9, st))) {
             return rc;
         }
-    }
-    EqdAtbJob jobs[4];
-    edge_atb_jobs(g, p, grads, W, jobs);
-    // the weight-gradient GEMMs only feed the gradient buffer: run them on the side stream when one is given
-    // (the caller makes the NEXT k_edge_bwd wait for ev_done before it overwrites the per-edge operands)
-    const bool side = st_atb && st_atb != st && ev_fork && ev_done;
-    if (side) {
-        if (hipEventRecord(ev_fork, st) != hipSuccess || hipStreamWaitEvent(st_atb, ev_fork, 0) != hipSuccess) {
-            eqd_set_error("eqd_edge_message_bwd: event fork failed");
-            return EQD_ERR_LAUNCH;
-        }
-    }
-    int rc = eqd_atb(jobs + (p->use_he ? 0 : 1), p->use_he ? 4 : 3, part, pb, side ? st_atb : st);
-    if (rc) return rc;
-    if (side && hipEventRecord(ev_done, st_atb) != hipSuccess) {
-        eqd_set_error("eqd_edge_message_bwd: event record failed");
-        return EQD_ERR_LAUNCH;
     }
     // per-node sums: dP (by source), dQ (by destination), dx = (1 - eta) d_xnew + sum_src dx_rel - sum_dst dx_rel
     return eqd_launch_node_gather(g, W.dz1, W.dxrel, d_xnew, 1.f - p->eta, dP, dQ, dx, st);

@@ -422,7 +422,13 @@ __global__ __launch_bounds__(1024) void k_reduce_segments(EqdRedArg A) {
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < 16; ++j) s += red[j][c];
-        A.s[first].out[i] += s;
+        const EqdRedSeg& S0 = A.s[first];
+        if (S0.cols > 0) {
+            const int row = i / S0.cols, col = i - row * S0.cols;
+            if (col < S0.cols_valid) S0.out[(size_t)row * S0.ld_out + col] += s;
+        } else {
+            S0.out[i] += s;
+        }
     }
 }
 int eqd_launch_reduce_segments(const EqdRedSeg* segs, int nseg, hipStream_t st) {
@@ -471,7 +477,7 @@ int eqd_launch_reduce_segments(const EqdRedSeg* segs, int nseg, hipStream_t st) 
     return EQD_OK;
 }
 int eqd_launch_vec_reduce(const float* partial, int nparts, int pstride, int n, float* out, hipStream_t st) {
-    EqdRedSeg s = {partial, nparts, pstride, n, out};
+    EqdRedSeg s = {partial, nparts, pstride, n, out, 0, 0, 0};
     return eqd_launch_reduce_segments(&s, 1, st);
 }
 
@@ -666,7 +672,7 @@ int eqd_launch_ln_act_bwd(const float* y_act, const float* d_out, const float* g
                        dz, partial);
     int rc = eqd_check_launch("k_ln_act_bwd");
     if (rc) return rc;
-    EqdRedSeg segs[2] = {{partial, nb, 256, d, dgamma}, {partial + 128, nb, 256, d, dbeta}};
+    EqdRedSeg segs[2] = {{partial, nb, 256, d, dgamma, 0, 0, 0}, {partial + 128, nb, 256, d, dbeta, 0, 0, 0}};
     if (defer && defer->n + 2 <= 512) {
         defer->seg[defer->n++] = segs[0];
         defer->seg[defer->n++] = segs[1];

@@ -192,7 +192,8 @@ typedef struct EqdEdgeParams {
 int eqd_edge_message_fwd(const EqdGraph* g, const EqdEdgeParams* p, const float* P, const float* Q,
                          const float* x, float* aggr_msg, float* x_new, void* stream);
 /* Backward: recomputes the tile forward; outputs dP, dQ [n_nodes][64], dx [n_nodes][3]
- * (= (1-eta) d_xnew + geometric terms), and the parameter gradients (accumulated). */
+ * (= (1-eta) d_xnew + geometric terms), and the parameter gradients (accumulated).  The weight-gradient
+ * GEMMs (dW2, dWc1, dW1[:, 2d:]) are fused into the kernel: per-edge operands never reach HBM. */
 typedef struct EqdEdgeGrads {
     float* dW1; int32_t ldw1;   /* only columns >= 2*d_in are written here */
     float* db1_unused;
