@@ -262,23 +262,31 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_fwd(EqdGraph G, int d, const
 }
 
 // backward pass 1: dq for the block's queries; also writes delta[q] = sum_f dO[q][f] O[q][f]
+// LDS of the backward passes: 2 block tiles + 2 x EQD_WAVES streamed tiles + the merge buffer + 32 floats per wave
+template <int DB>
+struct AttnBwdSmem {
+    typedef AttnCfg<DB> C;
+    float blk[2][C::TILE];
+    float str[2][EQD_WAVES][C::TILE];
+    float red[EQD_WAVES][C::RED];
+    float dls[EQD_WAVES][32];
+};
+
 template <int DB, bool FAST>
-__global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd_q(EqdGraph G, int d, const float* __restrict__ q,
-                                                          const float* __restrict__ k, const float* __restrict__ v,
-                                                          const float* __restrict__ out,
-                                                          const float* __restrict__ lse,
-                                                          const float* __restrict__ d_out, float* __restrict__ dq,
-                                                          float* __restrict__ delta) {
+__device__ __forceinline__ void attn_bwd_q_body(AttnBwdSmem<DB>& sm, const EqdGraph& G, int item, int d,
+                                                const float* __restrict__ q, const float* __restrict__ k,
+                                                const float* __restrict__ v, const float* __restrict__ out,
+                                                const float* __restrict__ lse, const float* __restrict__ d_out,
+                                                float* __restrict__ dq, float* __restrict__ delta) {
     typedef AttnCfg<DB> C;
     constexpr int DS = C::DS, KS = C::KS;
-    __shared__ __attribute__((aligned(16))) float Qt[C::TILE];
-    __shared__ __attribute__((aligned(16))) float Gt[C::TILE];   // dO rows of the block
-    __shared__ __attribute__((aligned(16))) float Kt[EQD_WAVES][C::TILE];
-    __shared__ __attribute__((aligned(16))) float Vt[EQD_WAVES][C::TILE];
-    __shared__ float red[EQD_WAVES][C::RED];
+    float* Qt = sm.blk[0];
+    float* Gt = sm.blk[1];   // dO rows of the block
+    float (*Kt)[C::TILE] = sm.str[0];
+    float (*Vt)[C::TILE] = sm.str[1];
+    float (*red)[C::RED] = sm.red;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const int item = blockIdx.x;
     const int b0 = G.att_items[item * 4 + 0], b1 = G.att_items[item * 4 + 1];
     const int o0 = G.att_items[item * 4 + 2], o1 = G.att_items[item * 4 + 3];
     int rowq[2] = {b0 + l15, b0 + 16 + l15};
@@ -392,33 +400,37 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd_q(EqdGraph G, int d, con
         }
 }
 
-// backward pass 2: dk, dv for the block's keys (queries = the partner protein)
-template <int DB, bool FAST>
-__global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd_kv(EqdGraph G, int d, const float* __restrict__ q,
-                                                           const float* __restrict__ k, const float* __restrict__ v,
-                                                           const float* __restrict__ lse,
-                                                           const float* __restrict__ d_out,
-                                                           const float* __restrict__ delta, float* __restrict__ dk,
-                                                           float* __restrict__ dv) {
+// backward pass 2: dk, dv for the block's keys (queries = the partner protein).
+// OWN_DELTA (float4 path only): delta = rowsum(dO * O) of each streamed query tile is recomputed here from the
+// O tile instead of being read from pass 1's output, so that both passes can run in ONE launch.
+template <int DB, bool FAST, bool OWN_DELTA>
+__device__ __forceinline__ void attn_bwd_kv_body(AttnBwdSmem<DB>& sm, const EqdGraph& G, int item, int d,
+                                                 const float* __restrict__ q, const float* __restrict__ k,
+                                                 const float* __restrict__ v, const float* __restrict__ out,
+                                                 const float* __restrict__ lse, const float* __restrict__ d_out,
+                                                 const float* __restrict__ delta, float* __restrict__ dk,
+                                                 float* __restrict__ dv) {
+    static_assert(FAST || !OWN_DELTA, "OWN_DELTA needs the float4 tile layout");
     typedef AttnCfg<DB> C;
     constexpr int DS = C::DS, KS = C::KS;
-    __shared__ __attribute__((aligned(16))) float Kb[C::TILE];   // the block's own key / value rows
-    __shared__ __attribute__((aligned(16))) float Vb[C::TILE];
-    __shared__ __attribute__((aligned(16))) float Qt[EQD_WAVES][C::TILE];   // streamed query / dO tiles
-    __shared__ __attribute__((aligned(16))) float Gt[EQD_WAVES][C::TILE];
-    __shared__ float red[EQD_WAVES][C::RED];
+    float* Kb = sm.blk[0];   // the block's own key / value rows
+    float* Vb = sm.blk[1];
+    float (*Qt)[C::TILE] = sm.str[0];   // streamed query / dO tiles
+    float (*Gt)[C::TILE] = sm.str[1];
+    float (*red)[C::RED] = sm.red;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const int item = blockIdx.x;
     const int b0 = G.att_items[item * 4 + 0], b1 = G.att_items[item * 4 + 1];
     const int o0 = G.att_items[item * 4 + 2], o1 = G.att_items[item * 4 + 3];
     int rowk[2] = {b0 + l15, b0 + 16 + l15};
     bool kvd[2] = {rowk[0] < b1, rowk[1] < b1};
 
     TileRegs<DB, FAST> rq, rg;
+    TileRegs<DB, FAST && OWN_DELTA> ro;
     int qt = o0 + 32 * wave;
     tile_load<DB, FAST>(rq, q, d, qt, o1, lane);
     tile_load<DB, FAST>(rg, d_out, d, qt, o1, lane);
+    if (OWN_DELTA) tile_load<DB, FAST && OWN_DELTA>(ro, out, d, qt, o1, lane);
     float lr[2][4], dr[2][4];   // lse / delta of the tile's query rows 16 mb + 4 g + r
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
@@ -426,7 +438,7 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd_kv(EqdGraph G, int d, co
         for (int r = 0; r < 4; ++r) {
             const int qr = qt + 16 * mb + 4 * g + r;
             lr[mb][r] = qr < o1 ? lse[qr] : 0.f;
-            dr[mb][r] = qr < o1 ? delta[qr] : 0.f;
+            dr[mb][r] = (!OWN_DELTA && qr < o1) ? delta[qr] : 0.f;
         }
     zero_fill(Kb, C::TILE, t, EQD_BLOCK);
     zero_fill(Vb, C::TILE, t, EQD_BLOCK);
@@ -456,6 +468,15 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd_kv(EqdGraph G, int d, co
         wave_lds_fence();
         tile_store<DB, FAST>(rq, Qt[wave], d, lane);
         tile_store<DB, FAST>(rg, Gt[wave], d, lane);
+        if (OWN_DELTA) {
+            // float4 j of a lane holds row (lane >> 4) + 4 j, columns 4 (lane & 15) .. + 3 of the tile
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float4 a = rg.q[FAST ? j : 0], b = ro.q[FAST && OWN_DELTA ? j : 0];
+                const float p = l16_sum(a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w);
+                if (l15 == 0) sm.dls[wave][g + 4 * j] = p;
+            }
+        }
         float lc[2][4], dc[2][4];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
@@ -465,16 +486,23 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd_kv(EqdGraph G, int d, co
                 dc[mb][r] = dr[mb][r];
             }
         wave_lds_fence();
+        if (OWN_DELTA) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dc[mb][r] = sm.dls[wave][16 * mb + 4 * g + r];
+        }
         const int qn = qt + 32 * EQD_WAVES;
         tile_load<DB, FAST>(rq, q, d, qn, o1, lane);
         tile_load<DB, FAST>(rg, d_out, d, qn, o1, lane);
+        if (OWN_DELTA) tile_load<DB, FAST && OWN_DELTA>(ro, out, d, qn, o1, lane);
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int qr = qn + 16 * mb + 4 * g + r;
                 lr[mb][r] = qr < o1 ? lse[qr] : 0.f;
-                dr[mb][r] = qr < o1 ? delta[qr] : 0.f;
+                dr[mb][r] = (!OWN_DELTA && qr < o1) ? delta[qr] : 0.f;
             }
         f32x4 S[2][2], dP[2][2];
 #pragma unroll
@@ -545,7 +573,45 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd_kv(EqdGraph G, int d, co
     }
 }
 
+template <int DB, bool FAST>
+__global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd_q(EqdGraph G, int d, const float* __restrict__ q,
+                                                          const float* __restrict__ k, const float* __restrict__ v,
+                                                          const float* __restrict__ out,
+                                                          const float* __restrict__ lse,
+                                                          const float* __restrict__ d_out, float* __restrict__ dq,
+                                                          float* __restrict__ delta) {
+    __shared__ __attribute__((aligned(16))) AttnBwdSmem<DB> sm;
+    attn_bwd_q_body<DB, FAST>(sm, G, blockIdx.x, d, q, k, v, out, lse, d_out, dq, delta);
+}
+template <int DB, bool FAST>
+__global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd_kv(EqdGraph G, int d, const float* __restrict__ q,
+                                                           const float* __restrict__ k, const float* __restrict__ v,
+                                                           const float* __restrict__ lse,
+                                                           const float* __restrict__ d_out,
+                                                           const float* __restrict__ delta, float* __restrict__ dk,
+                                                           float* __restrict__ dv) {
+    __shared__ __attribute__((aligned(16))) AttnBwdSmem<DB> sm;
+    attn_bwd_kv_body<DB, FAST, false>(sm, G, blockIdx.x, d, q, k, v, nullptr, lse, d_out, delta, dk, dv);
+}
+// both passes in one launch (float4 path): workgroups [0, n_items) run pass 1, [n_items, 2 n_items) pass 2
+template <int DB>
+__global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd(EqdGraph G, int d, const float* __restrict__ q,
+                                                        const float* __restrict__ k, const float* __restrict__ v,
+                                                        const float* __restrict__ out, const float* __restrict__ lse,
+                                                        const float* __restrict__ d_out, float* __restrict__ dq,
+                                                        float* __restrict__ dk, float* __restrict__ dv,
+                                                        float* __restrict__ delta) {
+    __shared__ __attribute__((aligned(16))) AttnBwdSmem<DB> sm;
+    const int item = blockIdx.x;
+    if (item < G.n_att_items)
+        attn_bwd_q_body<DB, true>(sm, G, item, d, q, k, v, out, lse, d_out, dq, delta);
+    else
+        attn_bwd_kv_body<DB, true, true>(sm, G, item - G.n_att_items, d, q, k, v, out, lse, d_out, nullptr, dk, dv);
+}
+
 // ---------------------------------------------------------------------------------------------
+static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
 template <int DB, bool FAST>
 static int attn_launch_fwd(const EqdGraph* g, int d, const float* q, const float* k, const float* v, float* out,
                            float* lse, hipStream_t st) {
@@ -557,6 +623,11 @@ template <int DB, bool FAST>
 static int attn_launch_bwd(const EqdGraph* g, int d, const float* q, const float* k, const float* v, const float* out,
                            const float* lse, const float* d_out, float* dq, float* dk, float* dv, float* delta,
                            hipStream_t st) {
+    if constexpr (FAST) if (aligned16(out)) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd<DB>), dim3(2 * g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, d, q, k,
+                           v, out, lse, d_out, dq, dk, dv, delta);
+        return eqd_check_launch("k_attn_bwd");
+    }
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_q<DB, FAST>), dim3(g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, d, q,
                        k, v, out, lse, d_out, dq, delta);
     int rc = eqd_check_launch("k_attn_bwd_q");
@@ -565,8 +636,6 @@ static int attn_launch_bwd(const EqdGraph* g, int d, const float* q, const float
                        k, v, lse, d_out, delta, dk, dv);
     return eqd_check_launch("k_attn_bwd_kv");
 }
-static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
-
 extern "C" int eqd_cross_attention_fwd(const EqdGraph* g, int d, const float* q, const float* k, const float* v,
                                        float* out, float* lse, void* stream) {
     if (!g || !q || !k || !v || !out || !lse) {

@@ -130,6 +130,7 @@ struct EqdChainArg {
     int njobs;
 };
 int eqd_launch_rowchain(const EqdChainJob* jobs, int njobs, int rows, hipStream_t st);
+size_t eqd_atb_batch_partial_bytes(int rows);
 
 // internal launchers (defined across the .hip files)
 int eqd_launch_vec_reduce(const float* partial, int nparts, int pstride, int n, float* out, hipStream_t st);

@@ -8,6 +8,9 @@
 // wraps the two calls in one torch.autograd.Function.
 #include "eqd_common.h"
 
+#include <vector>
+#define LIN_KC_HOST 80   /* widest LDS-resident source of a row chain (LIN_KC in eqd_linear_inl.h) */
+
 #include <string.h>
 
 namespace {
@@ -132,9 +135,11 @@ int node_atb_jobs(const Dims& D, int l, const EqdModelDesc* m, const Saved* S, c
 }
 
 struct Scratch {
-    float *dHa, *dHb, *dXa, *dXb, *da1n, *d_aggr_msg, *d_aggr_cross, *delta, *dh0acc;
-    float *dz2[2], *dq2[2], *dk2[2], *dv2[2], *dP2[2], *dQ2[2];   // by layer parity: the weight-gradient stream
-                                                                 // reads layer l's while layer l-1 is produced
+    float *dXa, *dXb, *d_aggr_msg, *d_aggr_cross, *delta, *dh0acc;
+    // kept for every layer: the weight-gradient GEMMs of ALL layers run in a few launches at the end of the pass
+    float* dH_all;   // [L + 1][N][80]: entry i = grad wrt h[i]
+    float *dz_all, *dq_all, *dk_all, *dv_all;   // [L][N][80]
+    float *dP_all, *dQ_all;                     // [L][N][64]
     float *dY, *dT, *db, *dscores, *du, *dHk, *dqm_part, *dhm;
     void* edge_ws; size_t edge_ws_bytes;
     float* atb_part; size_t atb_bytes;
@@ -144,22 +149,18 @@ struct Scratch {
 };
 
 void carve_scratch(const Dims& D, const EqdModelDesc* m, const EqdGraph* g, EqdArena& A, Scratch& W) {
-    const size_t N = (size_t)D.N;
-    W.dHa = A.take<float>(N * 80);
-    W.dHb = A.take<float>(N * 80);
+    const size_t N = (size_t)D.N, L = (size_t)D.L;
     W.dXa = A.take<float>(N * 3);
     W.dXb = A.take<float>(N * 3);
-    W.da1n = A.take<float>(N * 80);
     W.d_aggr_msg = A.take<float>(N * 64);
     W.d_aggr_cross = A.take<float>(N * 80);
-    for (int i = 0; i < 2; ++i) {
-        W.dz2[i] = A.take<float>(N * 80);
-        W.dq2[i] = A.take<float>(N * 80);
-        W.dk2[i] = A.take<float>(N * 80);
-        W.dv2[i] = A.take<float>(N * 80);
-        W.dP2[i] = A.take<float>(N * 64);
-        W.dQ2[i] = A.take<float>(N * 64);
-    }
+    W.dH_all = A.take<float>((L + 1) * N * 80);
+    W.dz_all = A.take<float>(L * N * 80);
+    W.dq_all = A.take<float>(L * N * 80);
+    W.dk_all = A.take<float>(L * N * 80);
+    W.dv_all = A.take<float>(L * N * 80);
+    W.dP_all = A.take<float>(L * N * 64);
+    W.dQ_all = A.take<float>(L * N * 64);
     W.delta = A.take<float>(N);
     W.dh0acc = A.take<float>(N * D.d0);
     W.dY = A.take<float>((size_t)2 * D.B * D.K * 3);
@@ -172,21 +173,8 @@ void carve_scratch(const Dims& D, const EqdModelDesc* m, const EqdGraph* g, EqdA
     W.dhm = A.take<float>(N * 64);
     W.edge_ws_bytes = eqd_edge_message_bwd_workspace_bytes(g);
     W.edge_ws = A.take<char>(W.edge_ws_bytes);
-    size_t ab = 0;
-    for (int l = 0; l < (D.L < 2 ? D.L : 2); ++l) {
-        EqdAtbJob jobs[16];
-        int n = node_atb_jobs(D, l, m, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                              jobs);
-        size_t b = eqd_atb_partial_bytes(jobs, n);
-        if (b > ab) ab = b;
-    }
-    {
-        EqdAtbJob j = atb_job(nullptr, 64, 64, nullptr, 64, 64, D.N, nullptr, 64, nullptr, 0.f);
-        size_t b = eqd_atb_partial_bytes(&j, 1);
-        if (b > ab) ab = b;
-    }
-    W.atb_bytes = ab;
-    W.atb_part = (float*)A.take<char>(ab);
+    W.atb_bytes = eqd_atb_batch_partial_bytes(D.N);
+    W.atb_part = (float*)A.take<char>(W.atb_bytes);
     W.ln_part_stride = eqd_align_up(eqd_ln_act_bwd_partial_floats(D.N, 80) * sizeof(float)) / sizeof(float);
     W.ln_part = A.take<float>(W.ln_part_stride * D.L);
     W.vecp_stride = eqd_align_up(eqd_edge_bwd_vecp_floats(g) * sizeof(float)) / sizeof(float);
@@ -250,21 +238,15 @@ extern "C" size_t eqd_model_scratch_bytes(const EqdModelDesc* m, const EqdGraph*
 
 // ---- execution context: auxiliary streams + events -----------------------------------------------------
 struct EqdCtx {
-    hipStream_t sa, sc;          // sa: attention branch, sc: node-level weight-gradient GEMMs
-    hipEvent_t fork, fork2, fork3, join_a, join_c[2], edge_atb_done;
+    hipStream_t sa;              // attention branch of the forward (runs beside the edge-message kernel)
+    hipEvent_t fork, join_a;
 };
 extern "C" int eqd_ctx_create(void** ctx) {
     if (!ctx) return EQD_ERR_NULL;
     EqdCtx* c = new EqdCtx();
     bool ok = hipStreamCreateWithFlags(&c->sa, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&c->sc, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&c->fork, hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&c->fork2, hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&c->fork3, hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&c->edge_atb_done, hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&c->join_a, hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&c->join_c[0], hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&c->join_c[1], hipEventDisableTiming) == hipSuccess;
+              hipEventCreateWithFlags(&c->join_a, hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         delete c;
         eqd_set_error("eqd_ctx_create: could not create streams/events");
@@ -277,14 +259,8 @@ extern "C" int eqd_ctx_destroy(void* ctx) {
     if (!ctx) return EQD_OK;
     EqdCtx* c = (EqdCtx*)ctx;
     (void)hipEventDestroy(c->fork);
-    (void)hipEventDestroy(c->fork2);
-    (void)hipEventDestroy(c->fork3);
-    (void)hipEventDestroy(c->edge_atb_done);
     (void)hipEventDestroy(c->join_a);
-    (void)hipEventDestroy(c->join_c[0]);
-    (void)hipEventDestroy(c->join_c[1]);
     (void)hipStreamDestroy(c->sa);
-    (void)hipStreamDestroy(c->sc);
     delete c;
     return EQD_OK;
 }
@@ -391,14 +367,23 @@ extern "C" int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const
         lin_src(j1, 3, S.h[0], D.d0, D.d0, p[P_WN1] + 2 * d + 64, ldn, 1);
         j1.nsrc = 4; j1.bias = p[P_BN1]; j1.act = 1; j1.ln_g = p[P_NLG]; j1.ln_b = p[P_NLB];
         j1.pre_ln = Ls.y_act; j1.ld_pre = d;
-        RC(eqd_linear(&j1, 1, st));
         EqdLinJob j2 = lin_job(N, D.dh, S.h[l + 1], D.dh, slope, eps);
         lin_src(j2, 0, Ls.a1n, d, d, p[P_WN2], d, 1);
         j2.nsrc = 1; j2.bias = p[P_BN2];
         if (d == D.dh) {
             j2.alpha = m->skip_weight_h; j2.beta = 1.f - m->skip_weight_h; j2.R = h; j2.ldr = d;
         }
-        RC(eqd_linear(&j2, 1, st));
+        {   // one launch: the LayerNorm output stays in LDS for node_mlp.4
+            EqdChainJob cj[2];
+            memset(cj, 0, sizeof(cj));
+            for (int k = 0; k < 2; ++k) {
+                for (int i = 0; i < EQD_MAX_SRC; ++i) cj[k].src_local[i] = -1;
+                cj[k].out_local = -1;
+            }
+            cj[0].lin = j1; cj[0].out_local = 0;
+            cj[1].lin = j2; cj[1].src_local[0] = 0;
+            RC(eqd_launch_rowchain(cj, 2, N, st));
+        }
     }
     {
         EqdLinJob jm = lin_job(N, 64, S.hm, 64, slope, eps);
@@ -427,7 +412,7 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
         return EQD_ERR_NULL;
     }
     hipStream_t st = (hipStream_t)stream;
-    EqdCtx* cx = (EqdCtx*)ctx;
+    (void)ctx;
     const Dims D = make_dims(m, g);
     EqdArena As(const_cast<void*>(saved), saved_bytes);
     Saved S;
@@ -464,16 +449,37 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
     RC(eqd_launch_head_u_bwd(g, K, gpar[G_WK], gpar[G_WQ], S.qmean, S.qp, W.du, ggrad[G_WK], ggrad[G_WQ], W.dqm_part,
                              st));
     RC(eqd_launch_qmean_bwd(g, K, W.dqm_part, W.dhm, st));
-    float* dHcur = W.dHa;   // grad wrt h[L]  (N x 64)
-    float* dHnext = W.dHb;
+    const size_t NS = (size_t)N * 80, NP = (size_t)N * 64;
+    auto dHof = [&](int i) -> float* { return W.dH_all + (size_t)i * NS; };   // grad wrt h[i]
+    std::vector<EqdAtbJob> wjobs;   // weight-gradient GEMMs of the whole pass, launched together at the end
+    wjobs.reserve((size_t)D.L * 10 + 1);
     {
-        EqdLinJob j = lin_job(N, D.dh, dHcur, D.dh, slope, eps);
+        EqdLinJob j = lin_job(N, D.dh, dHof(D.L), D.dh, slope, eps);
         lin_src(j, 0, W.dhm, 64, 64, gpar[G_WM], 1, D.dh, S.hm);
         j.nsrc = 1; j.R = W.dHk; j.ldr = 64; j.beta = 1.f;
         RC(eqd_linear(&j, 1, st));
-        EqdAtbJob a = atb_job(W.dhm, 64, 64, H, D.dh, D.dh, N, ggrad[G_WM], D.dh, ggrad[G_BM], slope, S.hm);
-        RC(eqd_atb(&a, 1, W.atb_part, W.atb_bytes, st));
+        wjobs.push_back(atb_job(W.dhm, 64, 64, H, D.dh, D.dh, N, ggrad[G_WM], D.dh, ggrad[G_BM], slope, S.hm));
     }
+    // dh(l) = dz Wn1[:, :d] + dP W1a + dQ W1b + (dq . lrelu'(qa)) Wq + (dk . lrelu'(ka)) Wk + dv Wv + (1-s) dH:
+    // the gradient wrt h[l] once layer l's attention and edge backward are done
+    auto dh_job = [&](int l) -> EqdLinJob {
+        const float* const* p = params + (size_t)EQD_PARAMS_PER_LAYER * l;
+        const int d = D.d_in(l);
+        const LayerSaved& Ls = S.lay[l];
+        EqdLinJob j = lin_job(N, d, dHof(l), d, slope, eps);
+        int ns = 0;
+        lin_src(j, ns++, W.dz_all + l * NS, d, d, p[P_WN1], 1, D.ldwn(l));
+        lin_src(j, ns++, W.dP_all + l * NP, 64, 64, p[P_W1], 1, D.ldw1(l));
+        lin_src(j, ns++, W.dQ_all + l * NP, 64, 64, p[P_W1] + d, 1, D.ldw1(l));
+        if (m->cross_msgs) {
+            lin_src(j, ns++, W.dq_all + l * NS, d, d, p[P_WQ], 1, d, Ls.qa);
+            lin_src(j, ns++, W.dk_all + l * NS, d, d, p[P_WK], 1, d, Ls.ka);
+            lin_src(j, ns++, W.dv_all + l * NS, d, d, p[P_WV], 1, d);
+        }
+        j.nsrc = ns;
+        if (d == D.dh) { j.R = dHof(l + 1); j.ldr = D.dh; j.beta = 1.f - m->skip_weight_h; }
+        return j;
+    };
     // ---- layers, last to first ----------------------------------------------------------------------------
     for (int l = D.L - 1; l >= 0; --l) {
         const float* const* p = params + (size_t)EQD_PARAMS_PER_LAYER * l;
@@ -483,11 +489,11 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
         const bool skip = (d == D.dh);
         const float alpha = skip ? m->skip_weight_h : 1.f;
         const int ldn = D.ldwn(l);
-        const int par = l & 1;
-        float *dz = W.dz2[par], *dq = W.dq2[par], *dk = W.dk2[par], *dv = W.dv2[par], *dP = W.dP2[par], *dQ = W.dQ2[par];
-        hipStream_t sa = (cx && m->cross_msgs) ? cx->sa : st;   // attention branch
-        hipStream_t sc = cx ? cx->sc : st;                       // node-level weight-gradient GEMMs
-        // ONE row chain: da1n = alpha dH Wn2 -> LeakyReLU/LayerNorm backward -> d aggr_msg, d aggr_cross, d h0
+        float *dz = W.dz_all + l * NS, *dq = W.dq_all + l * NS, *dk = W.dk_all + l * NS, *dv = W.dv_all + l * NS;
+        float *dP = W.dP_all + l * NP, *dQ = W.dQ_all + l * NP;
+        float* dHout = dHof(l + 1);
+        // ONE row chain: [dh of the layer above ->] da1n = alpha dH Wn2 -> LeakyReLU/LayerNorm backward ->
+        // d aggr_msg, d aggr_cross, d h0
         {
             EqdChainJob cj[8];
             int nj = 0;
@@ -496,12 +502,20 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
                 for (int i = 0; i < EQD_MAX_SRC; ++i) C.src_local[i] = -1;
                 C.out_local = -1;
             };
+            const bool fused_dh = l < D.L - 1 && D.dh <= LIN_KC_HOST;
+            if (l < D.L - 1) {
+                EqdChainJob& C = cj[nj++];
+                clear(C);
+                C.lin = dh_job(l + 1);
+                C.out_local = 2;
+            }
             {
                 EqdChainJob& C = cj[nj++];
                 clear(C);
                 C.lin = lin_job(N, d, nullptr, d, slope, eps);
-                lin_src(C.lin, 0, dHcur, D.dh, D.dh, p[P_WN2], 1, d);
+                lin_src(C.lin, 0, dHout, D.dh, D.dh, p[P_WN2], 1, d);
                 C.lin.nsrc = 1; C.lin.alpha = alpha;
+                if (fused_dh) C.src_local[0] = 2;
                 C.out_local = 0;
             }
             float* lnp = W.ln_part + (size_t)l * W.ln_part_stride;
@@ -541,21 +555,11 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
                 RC(eqd_launch_reduce_segments(segs, 2, st));
             }
         }
-        // ---- fork: attention backward (sa) || early weight-gradient GEMMs (sc) || edge backward (st) --------
-        EqdAtbJob ajobs[16];
-        const int na = node_atb_jobs(D, l, m, &S, dHcur, dz, dP, dQ, dq, dk, dv, gp, ajobs);
-        const int n_early = 4 + (m->cross_msgs ? 1 : 0);   // node_mlp.4 and the node_mlp.0 column segments
-        if (cx) {
-            HIPOK(hipEventRecord(cx->fork, st));
-            if (sa != st) HIPOK(hipStreamWaitEvent(sa, cx->fork, 0));
-            HIPOK(hipStreamWaitEvent(sc, cx->fork, 0));
-        }
-        if (m->cross_msgs) {
+        // The backward kernels of a layer each fill the chip (LDS-bound occupancy), so they run back to back
+        // on ONE stream: side streams only added event latency here.
+        if (m->cross_msgs)
             RC(eqd_cross_attention_bwd(g, d, Ls.qa, Ls.ka, Ls.va, Ls.aggr_cross, Ls.lse, W.d_aggr_cross, dq, dk, dv,
-                                       W.delta, sa));
-            if (sa != st) HIPOK(hipEventRecord(cx->join_a, sa));
-        }
-        if (cx) RC(eqd_atb(ajobs, n_early, W.atb_part, W.atb_bytes, sc));
+                                       W.delta, st));
         {
             EqdEdgeParams ep = edge_params(D, m, l, p);
             EqdEdgeGrads eg;
@@ -565,39 +569,20 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
             RC(eqd_edge_message_bwd_impl(g, &ep, Ls.P, Ls.Q, S.x[l], W.d_aggr_msg, dXcur, dP, dQ, dXnext, &eg, W.edge_ws,
                                          W.edge_ws_bytes, st, W.vecp_all + (size_t)l * W.vecp_stride, defer));
         }
-        if (sa != st) HIPOK(hipStreamWaitEvent(st, cx->join_a, 0));
-        // the previous layer's weight-gradient GEMMs still read the buffer dHnext is about to overwrite
-        if (cx && l < D.L - 1) HIPOK(hipStreamWaitEvent(st, cx->join_c[(l + 1) & 1], 0));
-        // dh = dz Wn1[:, :d] + dP W1a + dQ W1b + (dq . lrelu'(qa)) Wq + (dk . lrelu'(ka)) Wk + dv Wv + (1-s) dH
         {
-            EqdLinJob j = lin_job(N, d, dHnext, d, slope, eps);
-            int ns = 0;
-            lin_src(j, ns++, dz, d, d, p[P_WN1], 1, ldn);
-            lin_src(j, ns++, dP, 64, 64, p[P_W1], 1, D.ldw1(l));
-            lin_src(j, ns++, dQ, 64, 64, p[P_W1] + d, 1, D.ldw1(l));
-            if (m->cross_msgs) {
-                lin_src(j, ns++, dq, d, d, p[P_WQ], 1, d, Ls.qa);
-                lin_src(j, ns++, dk, d, d, p[P_WK], 1, d, Ls.ka);
-                lin_src(j, ns++, dv, d, d, p[P_WV], 1, d);
-            }
-            j.nsrc = ns;
-            if (skip) { j.R = dHcur; j.ldr = D.dh; j.beta = 1.f - m->skip_weight_h; }
-            RC(eqd_linear(&j, 1, st));
+            EqdAtbJob ajobs[16];
+            const int na = node_atb_jobs(D, l, m, &S, dHout, dz, dP, dQ, dq, dk, dv, gp, ajobs);
+            wjobs.insert(wjobs.end(), ajobs, ajobs + na);
         }
-        // remaining weight gradients (need dP, dQ, dq, dk, dv): behind the main stream on sc
-        if (cx) {
-            HIPOK(hipEventRecord(cx->fork2, st));
-            HIPOK(hipStreamWaitEvent(sc, cx->fork2, 0));
-            RC(eqd_atb(ajobs + n_early, na - n_early, W.atb_part, W.atb_bytes, sc));
-            HIPOK(hipEventRecord(cx->join_c[par], sc));
-        } else {
-            RC(eqd_atb(ajobs, na, W.atb_part, W.atb_bytes, st));
-        }
-        float* t = dHcur; dHcur = dHnext; dHnext = t;
-        t = dXcur; dXcur = dXnext; dXnext = t;
+        float* t = dXcur; dXcur = dXnext; dXnext = t;
     }
-    if (cx) HIPOK(hipStreamWaitEvent(st, cx->join_c[0], 0));   // layer 0 ran last on the weight-gradient stream
-    // deferred LayerNorm / coordinate-MLP vector reductions of all layers: a few launches instead of 2 per layer
+    {
+        EqdLinJob j = dh_job(0);
+        RC(eqd_linear(&j, 1, st));
+    }
+    float* dHcur = dHof(0);
+    RC(eqd_atb(wjobs.data(), (int)wjobs.size(), W.atb_part, W.atb_bytes, st));
+    // deferred LayerNorm / coordinate-MLP vector reductions and edge weight-gradient partials of all layers
     RC(eqd_launch_reduce_segments(defer->seg, defer->n, st));
     // h[0] = h0 feeds layer 0 directly (dHcur) as well as every layer's node_mlp (dh0acc)
     RC(eqd_launch_embed_bwd(g, W.dh0acc, dHcur, D.d0, m->d_emb, ggrad[G_EMB], W.emb_part, st));

@@ -93,7 +93,7 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const int* __res
             lb[i][r] = (ok && J.ln_g) ? J.ln_b[f] : 0.f;
             res[i][r] = (ok && J.R && rv) ? J.R[(size_t)rowi * J.ldr + f] : 0.f;
         }
-    f32x4 acc[2] = {f4zero(), f4zero()};
+    f32x4 acc[2] = {f4zero(), f4zero()}, acc2[2] = {f4zero(), f4zero()};
 
     // ---- pipelined (source, K chunk) steps ------------------------------------------------------------
     LinRegs R;
@@ -114,7 +114,28 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const int* __res
         if (ns < J.nsrc) lin_load(J, J.s[ns], src_local && src_local[ns] >= 0, nk0, row0, t, R);
         const float* __restrict__ Xs = local ? &Lb[src_local[s]][k0] : sm.Xl;
         const int nks = (Kc + 3) >> 2;
-        for (int ks = 0; ks < nks; ++ks) {
+        int ks = 0;
+        // 4 k-steps per trip: the 12 LDS reads are issued together and the MFMAs alternate between two
+        // accumulator sets (a single dependent chain would leave the matrix pipe idle 3 passes out of 4)
+        for (; ks + 4 <= nks; ks += 4) {
+            float b[4], a[2][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                b[u] = Xs[l15 * LIN_S + 4 * (ks + u) + g];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    a[i][u] = own[i] ? sm.Wl[(16 * mbs[i] + l15) * LIN_S + 4 * (ks + u) + g] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                if (own[i]) {
+                    acc[i] = mfma4(a[i][0], b[0], acc[i]);
+                    acc2[i] = mfma4(a[i][1], b[1], acc2[i]);
+                    acc[i] = mfma4(a[i][2], b[2], acc[i]);
+                    acc2[i] = mfma4(a[i][3], b[3], acc2[i]);
+                }
+        }
+        for (; ks < nks; ++ks) {
             const float b = Xs[l15 * LIN_S + 4 * ks + g];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -130,7 +151,7 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const int* __res
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int f = 16 * mbs[i] + 4 * g + r;
-            float v = acc[i][r] + bias[i][r];
+            float v = (acc[i][r] + acc2[i][r]) + bias[i][r];
             if (J.act) v = lrelu(v, J.slope);
             acc[i][r] = (own[i] && f < M) ? v : 0.f;
         }

@@ -6,6 +6,8 @@
 #include "eqd_common.h"
 #include "eqd_linear_inl.h"
 
+#include <vector>
+
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -190,7 +192,7 @@ extern "C" int eqd_linear(const EqdLinJob* jobs, int njobs, void* stream) {
 //   wave tile: 80 (M axis, output rows m) x 64 (N axis, output cols n), K axis = graph rows.
 //   then k_atb_reduce sums the chunks in a fixed order and accumulates into the gradient.
 // ------------------------------------------------------------------------------------------
-#define ATB_MAXUNITS 16
+#define ATB_MAXUNITS 36   /* 36 x 104 B of kernel arguments */
 #define ATB_TILE 5120  /* 80 x 64 */
 #define ATB_PSTRIDE 5200
 struct AtbUnit {
@@ -327,10 +329,11 @@ __global__ __launch_bounds__(1024) void k_atb_reduce(AtbUnitsArg U, const float*
     }
 }
 
-static int atb_plan(const EqdAtbJob* jobs, int njobs, AtbUnit* units, int max_units, int* nunits_out,
-                    long long* total_floats) {
-    int nu = 0;
-    long long off = 0;
+// Host side.  Every (job, 64-column block) is a unit; units are packed into launches of at most ATB_MAXUNITS
+// such that no two units of a launch accumulate into the same output (shared-weight layers), and each
+// unit's rows are split over ~ATB_TARGET_WGS / units workgroups.
+#define ATB_TARGET_WGS 1024
+static int atb_units(const EqdAtbJob* jobs, int njobs, std::vector<AtbUnit>& units) {
     for (int i = 0; i < njobs; ++i) {
         const EqdAtbJob& J = jobs[i];
         if (J.M <= 0 || J.M > 80 || J.N <= 0 || J.rows < 0) {
@@ -338,52 +341,81 @@ static int atb_plan(const EqdAtbJob* jobs, int njobs, AtbUnit* units, int max_un
             return EQD_ERR_SHAPE;
         }
         const int nchunks = J.rows > 0 ? (J.rows + ATB_ROWS - 1) / ATB_ROWS : 0;
-        const int nparts = nchunks < ATB_MAXBLOCKS ? nchunks : ATB_MAXBLOCKS;
         for (int n0 = 0; n0 < J.N; n0 += 64) {
-            if (nu >= max_units) {
-                eqd_set_error("eqd_atb: too many output tiles");
-                return EQD_ERR_SHAPE;
-            }
-            units[nu].job = J;
-            units[nu].n0 = n0;
-            units[nu].nparts = nparts;
-            units[nu].nchunks = nchunks;
-            units[nu].poff = off;
-            off += (long long)nparts * ATB_PSTRIDE;
-            ++nu;
+            AtbUnit u;
+            memset(&u, 0, sizeof(u));
+            u.job = J;
+            u.n0 = n0;
+            u.nchunks = nchunks;
+            units.push_back(u);
         }
     }
-    *nunits_out = nu;
-    *total_floats = off;
     return EQD_OK;
+}
+// [first, first + returned) is the next launch; fills nparts / poff of its units and the partial floats needed
+static int atb_next_batch(std::vector<AtbUnit>& units, size_t first, long long* floats) {
+    int n = 0;
+    while (first + n < units.size() && n < ATB_MAXUNITS) {
+        const AtbUnit& c = units[first + n];
+        bool clash = false;
+        for (int i = 0; i < n && !clash; ++i) {
+            const AtbUnit& o = units[first + i];
+            const bool same_tile = o.job.out == c.job.out && o.n0 == c.n0;
+            const bool same_bias = c.job.bias_out && o.job.bias_out == c.job.bias_out && o.n0 == 0 && c.n0 == 0;
+            clash = same_tile || same_bias;
+        }
+        if (clash) break;
+        ++n;
+    }
+    int per = (ATB_TARGET_WGS + n - 1) / (n > 0 ? n : 1);
+    per = per > ATB_MAXBLOCKS ? ATB_MAXBLOCKS : per;
+    long long off = 0;
+    for (int i = 0; i < n; ++i) {
+        AtbUnit& u = units[first + i];
+        u.nparts = u.nchunks < per ? u.nchunks : per;
+        u.poff = off;
+        off += (long long)u.nparts * ATB_PSTRIDE;
+    }
+    *floats = off;
+    return n;
+}
+
+// upper bound of the partial workspace of ANY eqd_atb call (independent of the jobs)
+size_t eqd_atb_batch_partial_bytes(int rows) {
+    (void)rows;
+    return (size_t)(ATB_TARGET_WGS + ATB_MAXBLOCKS + ATB_MAXUNITS) * ATB_PSTRIDE * sizeof(float) + 256;
 }
 
 extern "C" size_t eqd_atb_partial_bytes(const EqdAtbJob* jobs, int njobs) {
-    static thread_local AtbUnit units[256];
-    int nu = 0;
-    long long tot = 0;
-    if (atb_plan(jobs, njobs, units, 256, &nu, &tot) != EQD_OK) return 0;
-    return (size_t)tot * sizeof(float) + 256;
+    std::vector<AtbUnit> units;
+    if (atb_units(jobs, njobs, units) != EQD_OK) return 0;
+    long long worst = 0;
+    for (size_t first = 0; first < units.size();) {
+        long long f = 0;
+        const int n = atb_next_batch(units, first, &f);
+        if (f > worst) worst = f;
+        first += n;
+    }
+    return (size_t)worst * sizeof(float) + 256;
 }
 
 extern "C" int eqd_atb(const EqdAtbJob* jobs, int njobs, void* partial, size_t partial_bytes, void* stream) {
-    static thread_local AtbUnit units[256];
-    int nu = 0;
-    long long tot = 0;
-    int rc = atb_plan(jobs, njobs, units, 256, &nu, &tot);
+    std::vector<AtbUnit> units;
+    int rc = atb_units(jobs, njobs, units);
     if (rc) return rc;
-    if ((size_t)tot * sizeof(float) > partial_bytes || (!partial && tot > 0)) {
-        eqd_set_error("eqd_atb: partial workspace too small (%zu < %lld)", partial_bytes, tot * 4LL);
-        return EQD_ERR_WORKSPACE;
-    }
     hipStream_t st = (hipStream_t)stream;
-    for (int base = 0; base < nu; base += ATB_MAXUNITS) {
+    for (size_t first = 0; first < units.size();) {
+        long long f = 0;
+        const int n = atb_next_batch(units, first, &f);
+        if ((size_t)f * sizeof(float) > partial_bytes || (!partial && f > 0)) {
+            eqd_set_error("eqd_atb: partial workspace too small (%zu < %lld)", partial_bytes, f * 4LL);
+            return EQD_ERR_WORKSPACE;
+        }
         AtbUnitsArg arg;
         memset(&arg, 0, sizeof(arg));
-        int n = nu - base < ATB_MAXUNITS ? nu - base : ATB_MAXUNITS;
         int maxparts = 0;
         for (int i = 0; i < n; ++i) {
-            arg.u[i] = units[base + i];
+            arg.u[i] = units[first + i];
             if (arg.u[i].nparts > maxparts) maxparts = arg.u[i].nparts;
         }
         if (maxparts > 0) {
@@ -395,6 +427,7 @@ extern "C" int eqd_atb(const EqdAtbJob* jobs, int njobs, void* partial, size_t p
                            (const float*)partial);
         rc = eqd_check_launch("k_atb_reduce");
         if (rc) return rc;
+        first += n;
     }
     return EQD_OK;
 }
