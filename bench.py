@@ -59,8 +59,7 @@ def time_kernel(fn, iters, stream_sync):
         fn()
         e1.record()
     ev[-1][1].synchronize()
-    ts = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
-    ts = ts[:max(1, (3 * len(ts)) // 4)]          # drop the slowest quarter (clock ramps, preemption)
+    ts = [e0.elapsed_time(e1) for e0, e1 in ev]
     return sum(ts) / len(ts) * 1e-3   # seconds per launch
 
 

@@ -30,6 +30,28 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+// 16-byte global load that only needs 4-byte alignment (weight rows with odd leading dimensions, node rows
+// of width 69): gfx950 runs global memory in unaligned-access mode, the compiler emits one
+// global_load_dwordx4.  `n` = number of valid floats at p: >= 4 full vector; 1..3 tail, fetched as the 4 floats
+// that END at the last valid one (the row must hold >= 4 floats before p + n) and shifted; <= 0 zeros (the
+// load then goes to `safe`, any address with 16 readable bytes).  Branch-free on purpose: a divergent tail
+// path would put a wait behind every load instead of letting a whole batch fly together.
+// Split in two so that a batch of loads can be issued back to back: ld4u_raw is ONE unconditional load
+// instruction; ld4u_fix (shift + zero fill, selects) runs later, when the data is consumed.
+typedef float f4v __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ f32x4 ld4u_raw(const float* __restrict__ p, int n, const float* __restrict__ safe) {
+    const int sh = (n > 0 && n < 4) ? 4 - n : 0;
+    return *(const f4v*)(n > 0 ? p - sh : safe);
+}
+__device__ __forceinline__ float4 ld4u_fix(f32x4 v, int n) {
+    const int sh = (n > 0 && n < 4) ? 4 - n : 0;
+    float4 r;
+    r.x = n > 0 ? (sh == 0 ? v[0] : sh == 1 ? v[1] : sh == 2 ? v[2] : v[3]) : 0.f;
+    r.y = n > 1 ? (sh == 0 ? v[1] : sh == 1 ? v[2] : v[3]) : 0.f;
+    r.z = n > 2 ? (sh == 0 ? v[2] : v[3]) : 0.f;
+    r.w = n > 3 ? v[3] : 0.f;
+    return r;
+}
 __device__ __forceinline__ f32x4 f4zero() {
     f32x4 z = {0.f, 0.f, 0.f, 0.f};
     return z;
@@ -135,8 +157,9 @@ size_t eqd_atb_batch_partial_bytes(int rows);
 // internal launchers (defined across the .hip files)
 int eqd_launch_vec_reduce(const float* partial, int nparts, int pstride, int n, float* out, hipStream_t st);
 int eqd_launch_embed_fwd(const EqdGraph* g, const float* emb, int d_emb, int use_mu, float* h0, int ld, hipStream_t st);
+struct EqdRedList;
 int eqd_launch_embed_bwd(const EqdGraph* g, const float* dh0, const float* dh0b, int ld, int d_emb, float* demb,
-                         float* partial, hipStream_t st);
+                         float* partial, hipStream_t st, EqdRedList* defer = nullptr);
 size_t eqd_embed_bwd_partial_floats(const EqdGraph* g, int d_emb);
 int eqd_launch_node_gather(const EqdGraph* g, const float* dz, const float* dxrel, const float* d_xnew, float a,
                            float* dP, float* dQ, float* dx, hipStream_t st);

@@ -580,11 +580,10 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
         EqdLinJob j = dh_job(0);
         RC(eqd_linear(&j, 1, st));
     }
-    float* dHcur = dHof(0);
+    // h[0] = h0 feeds layer 0 directly (dH of h[0]) as well as every layer's node_mlp (dh0acc)
+    RC(eqd_launch_embed_bwd(g, W.dh0acc, dHof(0), D.d0, m->d_emb, ggrad[G_EMB], W.emb_part, st, defer));
     RC(eqd_atb(wjobs.data(), (int)wjobs.size(), W.atb_part, W.atb_bytes, st));
-    // deferred LayerNorm / coordinate-MLP vector reductions and edge weight-gradient partials of all layers
+    // deferred LayerNorm / coordinate-MLP vector reductions, edge weight-gradient partials and embedding tables
     RC(eqd_launch_reduce_segments(defer->seg, defer->n, st));
-    // h[0] = h0 feeds layer 0 directly (dHcur) as well as every layer's node_mlp (dh0acc)
-    RC(eqd_launch_embed_bwd(g, W.dh0acc, dHcur, D.d0, m->d_emb, ggrad[G_EMB], W.emb_part, st));
     return EQD_OK;
 }

@@ -54,28 +54,31 @@ __device__ __forceinline__ void edge_stage_weights(EdgeSmem<NW, TF>& sm, const E
     // all global loads of a thread are issued before the first LDS store (constant trip counts, fully
     // unrolled): one L2 round trip per batch instead of one per element
     constexpr int NT = 64 * NW;
-    constexpr int N1 = (64 * 42 + NT - 1) / NT, N2 = 1024 / NT;
+    constexpr int N1 = (64 * 11 + NT - 1) / NT, N2 = 1024 / NT;
     const int t = threadIdx.x;
     const int koff = 2 * P.d_in;
     {
-        float v[N1];
+        f32x4 v[N1];
 #pragma unroll
-        for (int j = 0; j < N1; ++j) {       // 64 x 42 = 2688 elements
+        for (int j = 0; j < N1; ++j) {       // 64 rows x 42 floats = 64 x 11 16-byte segments (the last holds 2)
             const int i = t + j * NT;
-            const int r = i / 42, c = i - r * 42;
-            v[j] = (i < 64 * 42) ? P.W1[(size_t)r * P.ldw1 + koff + c] : 0.f;
+            const int r = i / 11, c = 4 * (i - r * 11);
+            v[j] = ld4u_raw(P.W1 + (size_t)(i < 64 * 11 ? r : 0) * P.ldw1 + koff + c, i < 64 * 11 ? 42 - c : 0, P.W1);
         }
 #pragma unroll
         for (int j = 0; j < N1; ++j) {
             const int i = t + j * NT;
-            const int r = i / 42, c = i - r * 42;
-            if (i < 64 * 42) sm.w1[r * WS1 + c] = v[j];
+            const int r = i / 11, c = 4 * (i - r * 11);
+            if (i < 64 * 11) {
+                const float4 f = ld4u_fix(v[j], 42 - c);
+                float* o = &sm.w1[r * WS1 + c];
+                o[0] = f.x;
+                if (c + 1 < WS1) o[1] = f.y;      // c = 40: 42, 43, 44 are the zero padding (ld4u_fix zero-fills)
+                if (c + 2 < WS1) o[2] = f.z;
+                if (c + 3 < WS1) o[3] = f.w;
+            }
         }
-        if (t < 64) {
-            sm.w1[t * WS1 + 42] = 0.f;
-            sm.w1[t * WS1 + 43] = 0.f;
-            sm.w1[t * WS1 + 44] = 0.f;
-        }
+        if (t < 64) sm.w1[t * WS1 + 44] = 0.f;
     }
     {
         float4 a[N2], b[N2];
@@ -189,17 +192,22 @@ __device__ __forceinline__ void edge_tile_forward(const EqdGraph& G, const EqdEd
     for (int nb = 0; nb < NB; ++nb) {
         const int el = 16 * nb + l15;
         S.ev[nb] = el < S.ne;
-        int s = 0, d = 0;
-        if (S.ev[nb]) {
-            s = G.src[S.e0 + el];
-            d = G.dst[S.e0 + el];
-        }
+        // no predicated loads (they compile to exec-masked branches with a wait behind each): lanes beyond the
+        // tile read edge e0 (always a valid index) and are zeroed afterwards
+        const int ei = S.e0 + (S.ev[nb] ? el : 0);
+        const int s = G.src[ei], d = G.dst[ei];
         S.src[nb] = s;
         S.dst[nb] = d;
+        float xs[3], xd[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            xs[c] = x[(size_t)s * 3 + c];
+            xd[c] = x[(size_t)d * 3 + c];
+        }
         float q = 0.f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float v = S.ev[nb] ? x[(size_t)s * 3 + c] - x[(size_t)d * 3 + c] : 0.f;
+            const float v = S.ev[nb] ? xs[c] - xd[c] : 0.f;
             S.xrel[nb][c] = v;
             q += v * v;
         }
@@ -211,20 +219,29 @@ __device__ __forceinline__ void edge_tile_forward(const EqdGraph& G, const EqdEd
     if (P.use_he) {
         // the tile's he rows are contiguous in HBM: 16 NB x 27 floats, all loads issued before the first
         // LDS store
-        constexpr int NH = (16 * NB * 27 + 63) / 64;
+        constexpr int NH = (16 * NB * 27 / 4 + 63) / 64;       // 16-byte segments per lane
         const float* __restrict__ he = G.he + (size_t)S.e0 * 27;
         const int nhe = S.ne * 27;
-        float hv[NH];
+        f32x4 hv[NH];
 #pragma unroll
         for (int j = 0; j < NH; ++j) {
-            const int i = lane + 64 * j;
-            hv[j] = i < nhe ? he[i] : 0.f;
+            const int i = 4 * (lane + 64 * j);
+            hv[j] = ld4u_raw(he + (i < nhe ? i : 0), nhe - i, G.he);
         }
 #pragma unroll
         for (int j = 0; j < NH; ++j) {
-            const int i = lane + 64 * j;
-            const int e = i / 27, c = i - e * 27;
-            if (i < nhe) tile[e * FS + c] = hv[j];
+            const int i = 4 * (lane + 64 * j);
+            const float4 hf = ld4u_fix(hv[j], nhe - i);
+            const float vv[4] = {hf.x, hf.y, hf.z, hf.w};
+            int e = i / 27, c = i - e * 27;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (i + u < nhe) tile[e * FS + c] = vv[u];
+                if (++c == 27) {
+                    c = 0;
+                    ++e;
+                }
+            }
         }
     }
 #pragma unroll
@@ -243,18 +260,26 @@ __device__ __forceinline__ void edge_tile_forward(const EqdGraph& G, const EqdEd
     }
     wave_lds_fence();
     // ---- stage 1: z1 = P[src] + Q[dst] + W1cd feat ----------------------------------------------
+    {
+        float4 pv[NB][4], qv[NB][4];      // all 8 NB gathers in flight together
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
-            f32x4 a = f4zero();
-            if (S.ev[nb]) {
-                const float4 p = *(const float4*)&Pn[(size_t)S.src[nb] * 64 + 16 * mb + 4 * g];
-                const float4 q = *(const float4*)&Qn[(size_t)S.dst[nb] * 64 + 16 * mb + 4 * g];
-                a[0] = p.x + q.x; a[1] = p.y + q.y; a[2] = p.z + q.z; a[3] = p.w + q.w;
+            for (int mb = 0; mb < 4; ++mb) {
+                pv[nb][mb] = *(const float4*)&Pn[(size_t)S.src[nb] * 64 + 16 * mb + 4 * g];
+                qv[nb][mb] = *(const float4*)&Qn[(size_t)S.dst[nb] * 64 + 16 * mb + 4 * g];
             }
-            xh[mb][nb] = a;
-        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const float4 p = pv[nb][mb], q = qv[nb][mb];
+                f32x4 a;
+                a[0] = S.ev[nb] ? p.x + q.x : 0.f; a[1] = S.ev[nb] ? p.y + q.y : 0.f;
+                a[2] = S.ev[nb] ? p.z + q.z : 0.f; a[3] = S.ev[nb] ? p.w + q.w : 0.f;
+                xh[mb][nb] = a;
+            }
+    }
 #pragma unroll
     for (int s = 0; s < 11; ++s) {
         const int k = 4 * s + g;
@@ -526,12 +551,19 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
         edge_tile_forward<1>(G, P, sm.w1, sm.w2, sm.wc1, sm.vec, tile, Pn, Qn, x, lane, S, xh, m, ch, nullptr);
         // ---- coordinate path ---------------------------------------------------------------------
         float invdeg = 0.f, dcoef = 0.f, dxr[3] = {0.f, 0.f, 0.f};
-        if (S.ev[0]) {
-            const int d = S.dst[0];
-            invdeg = 1.f / (float)(G.rowptr[d + 1] - G.rowptr[d]);
+        float4 dag[4];                    // d_aggr[dst] rows, fetched now (unpredicated), used after phase 1
+        {
+            const int d = S.dst[0];       // lanes beyond the tile carry a valid (clamped) node index
+            const int r0 = G.rowptr[d], r1 = G.rowptr[d + 1];
+            float gxn[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) gxn[c] = d_xnew[(size_t)d * 3 + c];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) dag[mb] = *(const float4*)&d_aggr[(size_t)d * 64 + 16 * mb + 4 * g];
+            invdeg = S.ev[0] ? 1.f / (float)(r1 - r0) : 0.f;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const float gx = d_xnew[(size_t)d * 3 + c] * invdeg;
+                const float gx = gxn[c] * invdeg;
                 dcoef += gx * S.xrel[0][c];
                 dxr[c] = gx * S.coef[0];
             }
@@ -567,11 +599,9 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
         // ---- dm = d_aggr[dst] / deg + Wc1^T d_chid ---------------------------------------------------
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
-            f32x4 a = f4zero();
-            if (S.ev[0]) {
-                const float4 v = *(const float4*)&d_aggr[(size_t)S.dst[0] * 64 + 16 * mb + 4 * g];
-                a[0] = v.x * invdeg; a[1] = v.y * invdeg; a[2] = v.z * invdeg; a[3] = v.w * invdeg;
-            }
+            const float4 v = dag[mb];     // invdeg is 0 for lanes beyond the tile
+            f32x4 a;
+            a[0] = v.x * invdeg; a[1] = v.y * invdeg; a[2] = v.z * invdeg; a[3] = v.w * invdeg;
             m[mb][0] = a;
         }
         chain64T<1>(m, ch, sm.wc1, l15, g);

@@ -242,38 +242,66 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_head_u_bwd(int B, int K, const fl
                                                           const float* __restrict__ qp, const float* __restrict__ du,
                                                           float* __restrict__ dWk, float* __restrict__ dWq,
                                                           float* __restrict__ dqm_part) {
-    __shared__ float sqp[64], sdu[64], sdq[64], sqm[64];
+    // The head's two 64 x 64 matrices and 16 segments' vectors at a time live in LDS (one coalesced fetch
+    // each); all products then run out of LDS.  Sums over segments stay sequential (deterministic).
+    __shared__ float wk[64 * 65], wq[64 * 65];
+    __shared__ float sqp[16 * 64], sdu[16 * 64], sqm[16 * 64], sdq[16 * 64];
     const int k = blockIdx.x, t = threadIdx.x;
     const int c = t & 63, j0 = t >> 6;  // thread owns elements (j, c) for j = j0, j0+4, ...
+    {
+        float4 a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a[i] = ((const float4*)(Wk + (size_t)k * 4096))[t + 256 * i];
+            b[i] = ((const float4*)(Wq + (size_t)k * 4096))[t + 256 * i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = t + 256 * i, r = idx >> 4, c4 = (idx & 15) * 4;
+            wk[r * 65 + c4] = a[i].x; wk[r * 65 + c4 + 1] = a[i].y; wk[r * 65 + c4 + 2] = a[i].z; wk[r * 65 + c4 + 3] = a[i].w;
+            wq[r * 65 + c4] = b[i].x; wq[r * 65 + c4 + 1] = b[i].y; wq[r * 65 + c4 + 2] = b[i].z; wq[r * 65 + c4 + 3] = b[i].w;
+        }
+    }
     float accK[16], accQ[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) accK[i] = accQ[i] = 0.f;
-    for (int s = 0; s < 2 * B; ++s) {
-        const int partner = s < B ? s + B : s - B;
+    const int S2 = 2 * B;
+    for (int s0 = 0; s0 < S2; s0 += 16) {
+        const int ns = S2 - s0 < 16 ? S2 - s0 : 16;
         __syncthreads();
-        if (t < 64) {
-            sqp[t] = qp[((size_t)s * K + k) * 64 + t];
-            sdu[t] = du[((size_t)s * K + k) * 64 + t] * 0.125f;
-            sqm[t] = qmean[(size_t)partner * 64 + t];
-        }
-        __syncthreads();
-        if (t < 64) {
-            const float* wk = Wk + ((size_t)k * 64 + t) * 64;
-            float a = 0.f;
-            for (int cc = 0; cc < 64; ++cc) a += wk[cc] * sdu[cc];
-            sdq[t] = a;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = t + 256 * i, sl = idx >> 6, cc = idx & 63;
+            const int s = s0 + sl;
+            const bool ok = sl < ns;
+            const int partner = s < B ? s + B : s - B;
+            sqp[idx] = ok ? qp[((size_t)s * K + k) * 64 + cc] : 0.f;
+            sdu[idx] = ok ? du[((size_t)s * K + k) * 64 + cc] * 0.125f : 0.f;
+            sqm[idx] = ok ? qmean[(size_t)partner * 64 + cc] : 0.f;
         }
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int j = j0 + 4 * i;
-            accK[i] += sqp[j] * sdu[c];
-            accQ[i] += sdq[j] * sqm[c];
-        }
-        if (t < 64) {
+        for (int i = 0; i < 4; ++i) {          // dqp[s][j] = sum_c Wk[j][c] du[s][c]
+            const int sl = j0 + 4 * i;
             float a = 0.f;
-            for (int j = 0; j < 64; ++j) a += Wq[((size_t)k * 64 + j) * 64 + t] * sdq[j];
-            dqm_part[((size_t)s * K + k) * 64 + t] = a;
+            for (int cc = 0; cc < 64; ++cc) a += wk[c * 65 + cc] * sdu[sl * 64 + cc];
+            sdq[sl * 64 + c] = a;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {          // d qmean[partner(s)] part = Wq^T dqp[s]
+            const int sl = j0 + 4 * i;
+            float a = 0.f;
+            for (int j = 0; j < 64; ++j) a += wq[j * 65 + c] * sdq[sl * 64 + j];
+            if (sl < ns) dqm_part[((size_t)(s0 + sl) * K + k) * 64 + c] = a;
+        }
+        for (int sl = 0; sl < ns; ++sl) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int j = j0 + 4 * i;
+                accK[i] += sqp[sl * 64 + j] * sdu[sl * 64 + c];
+                accQ[i] += sdq[sl * 64 + j] * sqm[sl * 64 + c];
+            }
         }
     }
 #pragma unroll
@@ -388,27 +416,46 @@ __device__ __forceinline__ float uniform_draw(unsigned seed, unsigned pair, unsi
     return (float)(h >> 8) * (1.0f / 16777216.0f);
 }
 
-__global__ void k_kabsch_fwd(int B, int K, const float* __restrict__ Y, const float* __restrict__ draws, int seed,
-                             float* __restrict__ T, float* __restrict__ T2, float* __restrict__ bvec,
-                             float* __restrict__ A_out, int32_t* __restrict__ status) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= B) return;
+// One 64-thread workgroup per pair: the keypoints are staged in LDS with coalesced loads, the 6 mean and 9
+// covariance sums run on 15 lanes (each in the sequential k order of the reference's fp32 reductions), lane 0
+// does the fp64 SVD and the guard loop.
+#define KAB_MAXK 128
+__global__ __launch_bounds__(64) void k_kabsch_fwd(int B, int K, const float* __restrict__ Y,
+                                                   const float* __restrict__ draws, int seed, float* __restrict__ T,
+                                                   float* __restrict__ T2, float* __restrict__ bvec,
+                                                   float* __restrict__ A_out, int32_t* __restrict__ status) {
+    __shared__ float sy[2][KAB_MAXK * 3];
+    __shared__ float smean[6], sA[9];
+    const int p = blockIdx.x, t = threadIdx.x;
     const float* Yl = Y + (size_t)p * K * 3;
     const float* Yr = Y + (size_t)(B + p) * K * 3;
-    float ml[3] = {0, 0, 0}, mr[3] = {0, 0, 0};
-    for (int k = 0; k < K; ++k)
-        for (int c = 0; c < 3; ++c) {
-            ml[c] += Yl[k * 3 + c];
-            mr[c] += Yr[k * 3 + c];
-        }
-    for (int c = 0; c < 3; ++c) {
-        ml[c] /= (float)K;
-        mr[c] /= (float)K;
+    for (int i = t; i < 3 * K; i += 64) {
+        sy[0][i] = Yl[i];
+        sy[1][i] = Yr[i];
     }
-    float Af[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-    for (int k = 0; k < K; ++k)
-        for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) Af[i][j] += (Yr[k * 3 + i] - mr[i]) * (Yl[k * 3 + j] - ml[j]);
+    __syncthreads();
+    if (t < 6) {
+        const int side = t / 3, c = t - 3 * side;
+        float a = 0.f;
+        for (int k = 0; k < K; ++k) a += sy[side][k * 3 + c];
+        smean[t] = a / (float)K;
+    }
+    __syncthreads();
+    if (t < 9) {
+        const int i = t / 3, j = t - 3 * i;
+        float a = 0.f;
+        for (int k = 0; k < K; ++k) a += (sy[1][k * 3 + i] - smean[3 + i]) * (sy[0][k * 3 + j] - smean[j]);
+        sA[t] = a;
+    }
+    __syncthreads();
+    if (t != 0) return;
+    float ml[3], mr[3], Af[3][3];
+    for (int c = 0; c < 3; ++c) {
+        ml[c] = smean[c];
+        mr[c] = smean[3 + c];
+    }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Af[i][j] = sA[i * 3 + j];
     double A[3][3], U[3][3], S[3], V[3][3];
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) A[i][j] = (double)Af[i][j];
@@ -432,10 +479,10 @@ __global__ void k_kabsch_fwd(int B, int K, const float* __restrict__ Y, const fl
     float Tm[3][3];
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) {
-            const double t = U[i][0] * V[j][0] + U[i][1] * V[j][1] + sd * U[i][2] * V[j][2];
-            Tm[i][j] = (float)t;
-            T[(size_t)p * 9 + i * 3 + j] = (float)t;
-            if (T2) T2[(size_t)p * 9 + i * 3 + j] = (float)t;
+            const double tt = U[i][0] * V[j][0] + U[i][1] * V[j][1] + sd * U[i][2] * V[j][2];
+            Tm[i][j] = (float)tt;
+            T[(size_t)p * 9 + i * 3 + j] = (float)tt;
+            if (T2) T2[(size_t)p * 9 + i * 3 + j] = (float)tt;
             A_out[(size_t)p * 9 + i * 3 + j] = Af[i][j];
         }
     for (int i = 0; i < 3; ++i)
@@ -453,98 +500,114 @@ int eqd_kabsch_fwd_impl(int n_pairs, int n_heads, const float* Y, const float* s
         return EQD_ERR_NULL;
     }
     if (n_pairs <= 0) return EQD_OK;
-    hipLaunchKernelGGL(k_kabsch_fwd, dim3((n_pairs + 63) / 64), dim3(64), 0, (hipStream_t)stream, n_pairs, n_heads, Y,
-                       svd_draws, svd_seed, T, T2, b, A_out, status);
+    if (n_heads > KAB_MAXK) {
+        eqd_set_error("eqd_kabsch_fwd: %d keypoints > %d unsupported", n_heads, KAB_MAXK);
+        return EQD_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(k_kabsch_fwd, dim3(n_pairs), dim3(64), 0, (hipStream_t)stream, n_pairs, n_heads, Y, svd_draws,
+                       svd_seed, T, T2, b, A_out, status);
     return eqd_check_launch("k_kabsch_fwd");
 }
 
 // Closed-form backward: with G = dL/dT (including the b = mean_r - T mean_l
 // path), M = U^T G V, c = (1, 1, sign det A):
 //   dP_ij = (c_j M_ij - c_i M_ji) / (s_j + c_i c_j s_i)  (i != j),  dA = U dP V^T
-__global__ void k_kabsch_bwd(int B, int K, const float* __restrict__ Y, const float* __restrict__ A_in,
-                             const float* __restrict__ T, const float* __restrict__ dT, const float* __restrict__ db,
-                             const float* __restrict__ dYl_ext, const float* __restrict__ dYr_ext, int use_ext,
-                             float* __restrict__ dY) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= B) return;
+__global__ __launch_bounds__(64) void k_kabsch_bwd(int B, int K, const float* __restrict__ Y,
+                                                   const float* __restrict__ A_in, const float* __restrict__ T,
+                                                   const float* __restrict__ dT, const float* __restrict__ db,
+                                                   const float* __restrict__ dYl_ext,
+                                                   const float* __restrict__ dYr_ext, int use_ext,
+                                                   float* __restrict__ dY) {
+    // one 64-thread workgroup per pair; lane 0 does the 3x3 algebra, the per-keypoint work is spread over lanes,
+    // every sum over keypoints runs sequentially on one lane (fixed order)
+    __shared__ float sy[2][KAB_MAXK * 3];
+    __shared__ double smean[6], sdA[9], sdb[3], sdml[3], sg[2][KAB_MAXK * 3], sgm[6];
+    const int p = blockIdx.x, t = threadIdx.x;
     const float* Yl = Y + (size_t)p * K * 3;
     const float* Yr = Y + (size_t)(B + p) * K * 3;
     float* dYl = dY + (size_t)p * K * 3;
     float* dYr = dY + (size_t)(B + p) * K * 3;
-    double ml[3] = {0, 0, 0}, mr[3] = {0, 0, 0};
-    for (int k = 0; k < K; ++k)
-        for (int c = 0; c < 3; ++c) {
-            ml[c] += Yl[k * 3 + c];
-            mr[c] += Yr[k * 3 + c];
-        }
-    for (int c = 0; c < 3; ++c) {
-        ml[c] /= K;
-        mr[c] /= K;
+    for (int i = t; i < 3 * K; i += 64) {
+        sy[0][i] = Yl[i];
+        sy[1][i] = Yr[i];
     }
-    double A[3][3], U[3][3], S[3], V[3][3], G[3][3], Tm[3][3], dbv[3];
-    for (int i = 0; i < 3; ++i) {
-        dbv[i] = db ? (double)db[(size_t)p * 3 + i] : 0.0;
-        for (int j = 0; j < 3; ++j) {
-            A[i][j] = (double)A_in[(size_t)p * 9 + i * 3 + j];
-            Tm[i][j] = (double)T[(size_t)p * 9 + i * 3 + j];
-        }
+    __syncthreads();
+    if (t < 6) {
+        const int side = t / 3, c = t - 3 * side;
+        double a = 0.0;
+        for (int k = 0; k < K; ++k) a += sy[side][k * 3 + c];
+        smean[t] = a / K;
     }
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) G[i][j] = (dT ? (double)dT[(size_t)p * 9 + i * 3 + j] : 0.0) - dbv[i] * ml[j];
-    svd3(A, U, S, V);
-    const double c[3] = {1.0, 1.0, det3(A) < 0.0 ? -1.0 : 1.0};
-    double M[3][3], dP[3][3], dA[3][3];
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) {
-            double t = 0;
-            for (int a = 0; a < 3; ++a)
-                for (int b2 = 0; b2 < 3; ++b2) t += U[a][i] * G[a][b2] * V[b2][j];
-            M[i][j] = t;
-        }
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) {
-            if (i == j) {
-                dP[i][j] = 0.0;
-                continue;
+    __syncthreads();
+    if (t == 0) {
+        double ml[3] = {smean[0], smean[1], smean[2]};
+        double A[3][3], U[3][3], S[3], V[3][3], G[3][3], Tm[3][3], dbv[3];
+        for (int i = 0; i < 3; ++i) {
+            dbv[i] = db ? (double)db[(size_t)p * 3 + i] : 0.0;
+            for (int j = 0; j < 3; ++j) {
+                A[i][j] = (double)A_in[(size_t)p * 9 + i * 3 + j];
+                Tm[i][j] = (double)T[(size_t)p * 9 + i * 3 + j];
             }
-            double den = S[j] + c[i] * c[j] * S[i];
-            if (fabs(den) < 1e-12) den = den < 0 ? -1e-12 : 1e-12;
-            dP[i][j] = (c[j] * M[i][j] - c[i] * M[j][i]) / den;
         }
-    for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) G[i][j] = (dT ? (double)dT[(size_t)p * 9 + i * 3 + j] : 0.0) - dbv[i] * ml[j];
+        svd3(A, U, S, V);
+        const double c[3] = {1.0, 1.0, det3(A) < 0.0 ? -1.0 : 1.0};
+        double M[3][3], dP[3][3];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double tt = 0;
+                for (int a = 0; a < 3; ++a)
+                    for (int b2 = 0; b2 < 3; ++b2) tt += U[a][i] * G[a][b2] * V[b2][j];
+                M[i][j] = tt;
+            }
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                if (i == j) {
+                    dP[i][j] = 0.0;
+                    continue;
+                }
+                double den = S[j] + c[i] * c[j] * S[i];
+                if (fabs(den) < 1e-12) den = den < 0 ? -1e-12 : 1e-12;
+                dP[i][j] = (c[j] * M[i][j] - c[i] * M[j][i]) / den;
+            }
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double tt = 0;
+                for (int a = 0; a < 3; ++a)
+                    for (int b2 = 0; b2 < 3; ++b2) tt += U[i][a] * dP[a][b2] * V[j][b2];
+                sdA[i * 3 + j] = tt;
+            }
+        // means: d mean_r = db ; d mean_l = -T^T db
         for (int j = 0; j < 3; ++j) {
-            double t = 0;
-            for (int a = 0; a < 3; ++a)
-                for (int b2 = 0; b2 < 3; ++b2) t += U[i][a] * dP[a][b2] * V[j][b2];
-            dA[i][j] = t;
+            sdb[j] = dbv[j];
+            sdml[j] = -(Tm[0][j] * dbv[0] + Tm[1][j] * dbv[1] + Tm[2][j] * dbv[2]);
         }
-    // means: d mean_r = db ; d mean_l = -T^T db
-    double dml[3];
-    for (int j = 0; j < 3; ++j) dml[j] = -(Tm[0][j] * dbv[0] + Tm[1][j] * dbv[1] + Tm[2][j] * dbv[2]);
+    }
+    __syncthreads();
     // centred-point gradients, then un-centre (the mean of the centred gradients is removed)
-    double gl_mean[3] = {0, 0, 0}, gr_mean[3] = {0, 0, 0};
-    for (int k = 0; k < K; ++k)
+    for (int k = t; k < K; k += 64)
         for (int i = 0; i < 3; ++i) {
             double gr = 0, gl = 0;
             for (int j = 0; j < 3; ++j) {
-                gr += dA[i][j] * ((double)Yl[k * 3 + j] - ml[j]);
-                gl += dA[j][i] * ((double)Yr[k * 3 + j] - mr[j]);
+                gr += sdA[i * 3 + j] * ((double)sy[0][k * 3 + j] - smean[j]);
+                gl += sdA[j * 3 + i] * ((double)sy[1][k * 3 + j] - smean[3 + j]);
             }
-            gr_mean[i] += gr;
-            gl_mean[i] += gl;
+            sg[0][k * 3 + i] = gr;
+            sg[1][k * 3 + i] = gl;
         }
-    for (int i = 0; i < 3; ++i) {
-        gr_mean[i] /= K;
-        gl_mean[i] /= K;
+    __syncthreads();
+    if (t < 6) {
+        const int side = t / 3, c = t - 3 * side;
+        double a = 0.0;
+        for (int k = 0; k < K; ++k) a += sg[side][k * 3 + c];
+        sgm[t] = a / K;
     }
-    for (int k = 0; k < K; ++k)
+    __syncthreads();
+    for (int k = t; k < K; k += 64)
         for (int i = 0; i < 3; ++i) {
-            double gr = 0, gl = 0;
-            for (int j = 0; j < 3; ++j) {
-                gr += dA[i][j] * ((double)Yl[k * 3 + j] - ml[j]);
-                gl += dA[j][i] * ((double)Yr[k * 3 + j] - mr[j]);
-            }
-            const float vr = (float)(gr - gr_mean[i] + dbv[i] / K), vl = (float)(gl - gl_mean[i] + dml[i] / K);
+            const float vr = (float)(sg[0][k * 3 + i] - sgm[i] + sdb[i] / K);
+            const float vl = (float)(sg[1][k * 3 + i] - sgm[3 + i] + sdml[i] / K);
             if (use_ext) {   // dY = external gradient (or 0) + Kabsch path; no pre-initialised buffer needed
                 dYr[k * 3 + i] = vr + (dYr_ext ? dYr_ext[(size_t)p * K * 3 + k * 3 + i] : 0.f);
                 dYl[k * 3 + i] = vl + (dYl_ext ? dYl_ext[(size_t)p * K * 3 + k * 3 + i] : 0.f);
@@ -562,7 +625,11 @@ extern "C" int eqd_kabsch_bwd(int n_pairs, int n_heads, const float* Y, const fl
         return EQD_ERR_NULL;
     }
     if (n_pairs <= 0) return EQD_OK;
-    hipLaunchKernelGGL(k_kabsch_bwd, dim3((n_pairs + 63) / 64), dim3(64), 0, (hipStream_t)stream, n_pairs, n_heads, Y,
+    if (n_heads > KAB_MAXK) {
+        eqd_set_error("eqd_kabsch_bwd: %d keypoints > %d unsupported", n_heads, KAB_MAXK);
+        return EQD_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(k_kabsch_bwd, dim3(n_pairs), dim3(64), 0, (hipStream_t)stream, n_pairs, n_heads, Y,
                        A, T, dT, db, (const float*)nullptr, (const float*)nullptr, 0, dY);
     return eqd_check_launch("k_kabsch_bwd");
 }
@@ -573,7 +640,11 @@ int eqd_kabsch_bwd_impl(int n_pairs, int n_heads, const float* Y, const float* A
         return EQD_ERR_NULL;
     }
     if (n_pairs <= 0) return EQD_OK;
-    hipLaunchKernelGGL(k_kabsch_bwd, dim3((n_pairs + 63) / 64), dim3(64), 0, (hipStream_t)stream, n_pairs, n_heads, Y,
+    if (n_heads > KAB_MAXK) {
+        eqd_set_error("eqd_kabsch_bwd: %d keypoints > %d unsupported", n_heads, KAB_MAXK);
+        return EQD_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(k_kabsch_bwd, dim3(n_pairs), dim3(64), 0, (hipStream_t)stream, n_pairs, n_heads, Y,
                        A, T, dT, db, dYl_ext, dYr_ext, 1, dY);
     return eqd_check_launch("k_kabsch_bwd");
 }

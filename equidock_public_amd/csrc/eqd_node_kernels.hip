@@ -49,7 +49,14 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_linear(LinJobsArg jobs) {
     const EqdLinJob& J = jobs.j[blockIdx.y];
     const int row0 = (int)blockIdx.x * 16;
     if (row0 >= J.rows) return;      // uniform for the whole workgroup
+#ifdef EQD_TRACE
+    if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 256) eqd_trace_buf[512 + 2 * blockIdx.x] = wall_clock64();
+#endif
     linear_tile(J, nullptr, -1, sm, nullptr, row0);
+#ifdef EQD_TRACE
+    __syncthreads();
+    if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 256) eqd_trace_buf[512 + 2 * blockIdx.x + 1] = wall_clock64();
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -112,7 +119,7 @@ __device__ __forceinline__ void chain_lnbwd(const EqdChainJob& C, float (*Lb)[16
 
 __global__ __launch_bounds__(EQD_BLOCK) void k_rowchain(EqdChainArg A) {
     __shared__ LinSmem sm;
-    __shared__ float Lb[LIN_LOCALS][16 * LIN_S];
+    __shared__ __attribute__((aligned(16))) float Lb[LIN_LOCALS][16 * LIN_S];
     __shared__ float red[EQD_WAVES][256];
     const int row0 = (int)blockIdx.x * 16;
     for (int i = threadIdx.x; i < LIN_LOCALS * 16 * LIN_S; i += EQD_BLOCK) (&Lb[0][0])[i] = 0.f;
@@ -127,6 +134,27 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_rowchain(EqdChainArg A) {
     }
 }
 
+#ifdef EQD_TRACE
+__device__ long long eqd_trace_buf[1024];
+extern "C" int eqd_trace_fetch(long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(eqd_trace_buf), sizeof(long long) * 1024);
+}
+#endif
+
+// the 16-byte loaders need >= 4 elements along the contiguous axis and one unit weight stride
+static int lin_check_sources(const EqdLinJob& J) {
+    for (int s = 0; s < J.nsrc; ++s) {
+        const EqdLinSrc& S = J.s[s];
+        if (!S.W) continue;   // LayerNorm-backward jobs carry no weights
+        if (S.K < 4 || (S.w_cs != 1 && S.w_rs != 1)) {
+            eqd_set_error("eqd_linear: source %d has K=%d w_rs=%d w_cs=%d (need K >= 4 and one unit stride)", s, S.K, S.w_rs,
+                          S.w_cs);
+            return EQD_ERR_SHAPE;
+        }
+    }
+    return EQD_OK;
+}
+
 int eqd_launch_rowchain(const EqdChainJob* jobs, int njobs, int rows, hipStream_t st) {
     if (njobs <= 0 || njobs > EQD_CHAIN_MAXJOBS) {
         eqd_set_error("eqd_launch_rowchain: %d jobs (1..%d)", njobs, EQD_CHAIN_MAXJOBS);
@@ -138,10 +166,12 @@ int eqd_launch_rowchain(const EqdChainJob* jobs, int njobs, int rows, hipStream_
     for (int i = 0; i < njobs; ++i) {
         arg.j[i] = jobs[i];
         const EqdLinJob& J = jobs[i].lin;
-        if (J.M <= 0 || J.M > 80 || J.rows != rows) {
+        if (J.M < 4 || J.M > 80 || J.rows != rows) {
             eqd_set_error("eqd_launch_rowchain: job %d has M=%d rows=%d (chain rows %d)", i, J.M, J.rows, rows);
             return EQD_ERR_SHAPE;
         }
+        if (jobs[i].type == 0)
+            if (int e = lin_check_sources(J)) return e;
         for (int s = 0; s < J.nsrc; ++s)
             if (jobs[i].src_local[s] >= 0 && J.s[s].K > LIN_KC) {
                 eqd_set_error("eqd_launch_rowchain: LDS-resident source wider than %d", LIN_KC);
@@ -166,11 +196,12 @@ extern "C" int eqd_linear(const EqdLinJob* jobs, int njobs, void* stream) {
         int maxrows = 0;
         for (int i = 0; i < n; ++i) {
             const EqdLinJob& J = jobs[base + i];
-            if (J.M <= 0 || J.M > 80 || J.nsrc <= 0 || J.nsrc > EQD_MAX_SRC || !J.Y) {
-                eqd_set_error("eqd_linear: job %d has M=%d nsrc=%d (need 1..80 outputs, 1..%d sources)", base + i, J.M,
+            if (J.M < 4 || J.M > 80 || J.nsrc <= 0 || J.nsrc > EQD_MAX_SRC || !J.Y) {
+                eqd_set_error("eqd_linear: job %d has M=%d nsrc=%d (need 4..80 outputs, 1..%d sources)", base + i, J.M,
                               J.nsrc, EQD_MAX_SRC);
                 return EQD_ERR_SHAPE;
             }
+            if (int e = lin_check_sources(J)) return e;
             if (J.ln_g && !J.ln_b) {
                 eqd_set_error("eqd_linear: job %d has LayerNorm weight without bias", base + i);
                 return EQD_ERR_NULL;
@@ -205,7 +236,7 @@ struct AtbUnitsArg {
 };
 
 #define ATB_ROWS 64    /* graph rows per chunk */
-#define ATB_LS 81      /* LDS row stride (odd) */
+#define ATB_LS 80      /* LDS row stride: 20 x 16 B; a fragment read (4 rows x 16 columns) covers the 64 banks once */
 #define ATB_MAXBLOCKS 256
 // Persistent workgroups: each walks the 64-row chunks c, c + nparts, ... of its unit.  Per chunk the
 // X (<= 80 columns) and Y (64 columns) slabs are fetched with all loads in flight at once (36 per
@@ -213,36 +244,78 @@ struct AtbUnitsArg {
 // wave w accumulates the output column block nb = w for every row block mb.  One partial tile per
 // workgroup (no cross-wave reduction), summed later in a fixed order by k_atb_reduce.
 struct AtbRegs {
-    float x[4][5], y[4][4];
+    f32x4 x[4][2], xm[4][2], y[4];   // raw 16-byte loads (see ld4u_raw / ld4u_fix)
 };
+__device__ __forceinline__ int atb_nx(const EqdAtbJob& J, int chunk, int t, int jr, int h) {
+    const int row = chunk * ATB_ROWS + (t >> 4) + 16 * jr, tc = t & 15;
+    return (row < J.rows && (h == 0 || tc < 4)) ? J.M - (4 * tc + 64 * h) : 0;
+}
+__device__ __forceinline__ int atb_ny(const EqdAtbJob& J, int n0, int chunk, int t, int jr) {
+    const int row = chunk * ATB_ROWS + (t >> 4) + 16 * jr;
+    return row < J.rows ? J.N - (n0 + 4 * (t & 15)) : 0;
+}
 __device__ __forceinline__ void atb_load(const EqdAtbJob& J, int n0, int chunk, int t, AtbRegs& R) {
     const int tr = t >> 4, tc = t & 15;
     const int r0 = chunk * ATB_ROWS;
 #pragma unroll
     for (int jr = 0; jr < 4; ++jr) {
         const int row = r0 + tr + 16 * jr;
-        const bool rv = row < J.rows;
+        const size_t ro = (size_t)(row < J.rows ? row : 0);
 #pragma unroll
-        for (int jm = 0; jm < 5; ++jm) {
-            const int m = tc + 16 * jm;
-            float v = 0.f;
-            if (rv && m < J.M) {
-                const size_t o = (size_t)row * J.ldx + m;
-                v = J.X[o];
-                if (J.xmask) v *= lrelu_grad(J.xmask[o], J.slope);
-            }
-            R.x[jr][jm] = v;
+        for (int h = 0; h < 2; ++h) {
+            const int n = atb_nx(J, chunk, t, jr, h);
+            const size_t o = ro * J.ldx + 4 * tc + 64 * h;
+            R.x[jr][h] = ld4u_raw(J.X + o, n, J.X);
+            if (J.xmask) R.xm[jr][h] = ld4u_raw(J.xmask + o, n, J.xmask);
         }
-#pragma unroll
-        for (int jn = 0; jn < 4; ++jn) {
-            const int n = n0 + tc + 16 * jn;
-            R.y[jr][jn] = (rv && n < J.N) ? J.Y[(size_t)row * J.ldy + n] : 0.f;
-        }
+        R.y[jr] = ld4u_raw(J.Y + ro * J.ldy + n0 + 4 * tc, atb_ny(J, n0, chunk, t, jr), J.Y);
     }
 }
+__device__ __forceinline__ void atb_store(const EqdAtbJob& J, int n0, int chunk, int t, const AtbRegs& R,
+                                          float* __restrict__ Xl, float* __restrict__ Yl) {
+    const int tr = t >> 4, tc = t & 15;
+#pragma unroll
+    for (int jr = 0; jr < 4; ++jr) {
+        const int row = tr + 16 * jr;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h == 1 && tc >= 4) continue;
+            const int n = atb_nx(J, chunk, t, jr, h);
+            float4 v = ld4u_fix(R.x[jr][h], n);
+            if (J.xmask) {
+                const float4 mk = ld4u_fix(R.xm[jr][h], n);
+                v.x *= lrelu_grad(mk.x, J.slope); v.y *= lrelu_grad(mk.y, J.slope);
+                v.z *= lrelu_grad(mk.z, J.slope); v.w *= lrelu_grad(mk.w, J.slope);
+            }
+            *(float4*)&Xl[row * ATB_LS + 4 * tc + 64 * h] = v;
+        }
+        *(float4*)&Yl[row * ATB_LS + 4 * tc] = ld4u_fix(R.y[jr], atb_ny(J, n0, chunk, t, jr));
+    }
+}
+// one 64-row chunk: acc[mb] += X[:, 16 mb ..]^T Y[:, 16 wave ..]; MBN row blocks, no predicates in the loop
+// (4 k-steps per trip: 4 (1 + MBN) LDS reads in flight, then 4 MBN MFMAs)
+template <int MBN>
+__device__ __forceinline__ void atb_mma(f32x4 (&acc)[5], const float* __restrict__ Xl, const float* __restrict__ Yl,
+                                        int wave, int l15, int g) {
+    for (int ks = 0; ks < ATB_ROWS / 4; ks += 4) {
+        float b[4], a[4][MBN];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = 4 * (ks + u) + g;
+            b[u] = Yl[row * ATB_LS + 16 * wave + l15];
+#pragma unroll
+            for (int mb = 0; mb < MBN; ++mb) a[u][mb] = Xl[row * ATB_LS + 16 * mb + l15];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int mb = 0; mb < MBN; ++mb) acc[mb] = mfma4(a[u][mb], b[u], acc[mb]);
+    }
+}
+
 __global__ __launch_bounds__(EQD_BLOCK) void k_atb(AtbUnitsArg U, float* __restrict__ partial) {
-    __shared__ float Xl[ATB_ROWS * ATB_LS];
-    __shared__ float Yl[ATB_ROWS * ATB_LS];
+    __shared__ __attribute__((aligned(16))) float Xl[ATB_ROWS * ATB_LS];
+    __shared__ __attribute__((aligned(16))) float Yl[ATB_ROWS * ATB_LS];
     const AtbUnit& u = U.u[blockIdx.y];
     const int c = blockIdx.x;
     if (c >= u.nparts) return;       // uniform per workgroup
@@ -259,24 +332,13 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_atb(AtbUnitsArg U, float* __restr
     atb_load(J, u.n0, c, t, R);
     for (int chunk = c; chunk < u.nchunks; chunk += u.nparts) {
         __syncthreads();             // the previous chunk's LDS reads are done
-#pragma unroll
-        for (int jr = 0; jr < 4; ++jr) {
-            const int row = tr + 16 * jr;
-#pragma unroll
-            for (int jm = 0; jm < 5; ++jm) Xl[row * ATB_LS + tc + 16 * jm] = R.x[jr][jm];
-#pragma unroll
-            for (int jn = 0; jn < 4; ++jn) Yl[row * ATB_LS + tc + 16 * jn] = R.y[jr][jn];
-        }
+        atb_store(J, u.n0, chunk, t, R, Xl, Yl);
         __syncthreads();
         if (chunk + u.nparts < u.nchunks) atb_load(J, u.n0, chunk + u.nparts, t, R);
-#pragma unroll 4
-        for (int ks = 0; ks < ATB_ROWS / 4; ++ks) {
-            const int row = 4 * ks + g;
-            const float b = Yl[row * ATB_LS + 16 * wave + l15];
-#pragma unroll
-            for (int mb = 0; mb < 5; ++mb)
-                if (mb < mbn) acc[mb] = mfma4(Xl[row * ATB_LS + 16 * mb + l15], b, acc[mb]);
-        }
+        if (mbn > 4)
+            atb_mma<5>(acc, Xl, Yl, wave, l15, g);
+        else
+            atb_mma<4>(acc, Xl, Yl, wave, l15, g);
         if (t < 80) {
 #pragma unroll 8
             for (int row = 0; row < ATB_ROWS; ++row) bacc += Xl[row * ATB_LS + t];
@@ -336,8 +398,8 @@ __global__ __launch_bounds__(1024) void k_atb_reduce(AtbUnitsArg U, const float*
 static int atb_units(const EqdAtbJob* jobs, int njobs, std::vector<AtbUnit>& units) {
     for (int i = 0; i < njobs; ++i) {
         const EqdAtbJob& J = jobs[i];
-        if (J.M <= 0 || J.M > 80 || J.N <= 0 || J.rows < 0) {
-            eqd_set_error("eqd_atb: job %d has M=%d N=%d rows=%d (need M in 1..80)", i, J.M, J.N, J.rows);
+        if (J.M < 4 || J.M > 80 || J.N < 4 || J.rows < 0) {
+            eqd_set_error("eqd_atb: job %d has M=%d N=%d rows=%d (need M in 4..80, N >= 4)", i, J.M, J.N, J.rows);
             return EQD_ERR_SHAPE;
         }
         const int nchunks = J.rows > 0 ? (J.rows + ATB_ROWS - 1) / ATB_ROWS : 0;
@@ -552,18 +614,27 @@ int eqd_launch_embed_fwd(const EqdGraph* g, const float* emb, int d_emb, int use
     return eqd_check_launch("k_embed_fwd");
 }
 
-// Embedding backward: per block of 128 nodes, thread c owns column c -> deterministic per-type sums
-#define EMB_ROWS 128
-__global__ void k_embed_bwd(const int32_t* __restrict__ res, const float* __restrict__ dh0,
-                            const float* __restrict__ dh0b, int ld, int n, int d_emb, float* __restrict__ partial) {
+// Embedding backward: per block of 16 nodes, thread c owns column c -> deterministic per-type sums.  All
+// loads of the block are in flight together; the (small) per-block tables are summed by k_reduce_segments.
+#define EMB_ROWS 16
+__global__ __launch_bounds__(64) void k_embed_bwd(const int32_t* __restrict__ res, const float* __restrict__ dh0,
+                                                  const float* __restrict__ dh0b, int ld, int n, int d_emb,
+                                                  float* __restrict__ partial) {
     __shared__ float acc[21 * 64];
     const int c = threadIdx.x;  // 64 threads
     for (int t = 0; t < 21; ++t) acc[t * 64 + c] = 0.f;
     const int i0 = blockIdx.x * EMB_ROWS;
-    const int i1 = i0 + EMB_ROWS < n ? i0 + EMB_ROWS : n;
-    if (c < d_emb)
-        for (int i = i0; i < i1; ++i)
-            acc[res[i] * 64 + c] += dh0[(size_t)i * ld + c] + (dh0b ? dh0b[(size_t)i * ld + c] : 0.f);
+    int rid[EMB_ROWS];
+    float v[EMB_ROWS];
+#pragma unroll
+    for (int r = 0; r < EMB_ROWS; ++r) {
+        const int i = i0 + r;
+        const bool ok = i < n && c < d_emb;
+        rid[r] = i < n ? res[i] : 0;
+        v[r] = ok ? dh0[(size_t)i * ld + c] + (dh0b ? dh0b[(size_t)i * ld + c] : 0.f) : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < EMB_ROWS; ++r) acc[rid[r] * 64 + c] += v[r];
     for (int t = 0; t < 21; ++t)
         if (c < d_emb) partial[((size_t)blockIdx.x * 21 + t) * d_emb + c] = acc[t * 64 + c];
 }
@@ -571,7 +642,7 @@ size_t eqd_embed_bwd_partial_floats(const EqdGraph* g, int d_emb) {
     return (size_t)((g->n_nodes + EMB_ROWS - 1) / EMB_ROWS) * 21 * d_emb;
 }
 int eqd_launch_embed_bwd(const EqdGraph* g, const float* dh0, const float* dh0b, int ld, int d_emb, float* demb,
-                         float* partial, hipStream_t st) {
+                         float* partial, hipStream_t st, EqdRedList* defer) {
     if (g->n_nodes == 0) return EQD_OK;
     if (d_emb > 64) {
         eqd_set_error("embedding width %d > 64 unsupported", d_emb);
@@ -581,6 +652,10 @@ int eqd_launch_embed_bwd(const EqdGraph* g, const float* dh0, const float* dh0b,
     hipLaunchKernelGGL(k_embed_bwd, dim3(nb), dim3(64), 0, st, g->res_id, dh0, dh0b, ld, g->n_nodes, d_emb, partial);
     int rc = eqd_check_launch("k_embed_bwd");
     if (rc) return rc;
+    if (defer && defer->n + 1 <= 512) {
+        defer->seg[defer->n++] = EqdRedSeg{partial, nb, 21 * d_emb, 21 * d_emb, demb, 0, 0, 0};
+        return EQD_OK;
+    }
     return eqd_launch_vec_reduce(partial, nb, 21 * d_emb, 21 * d_emb, demb, st);
 }
 
