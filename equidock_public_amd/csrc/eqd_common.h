@@ -36,6 +36,35 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 // that END at the last valid one (the row must hold >= 4 floats before p + n) and shifted; <= 0 zeros (the
 // load then goes to `safe`, any address with 16 readable bytes).  Branch-free on purpose: a divergent tail
 // path would put a wait behind every load instead of letting a whole batch fly together.
+// Phase timestamps for the latency experiments (profiles/exp_trace_*.py build a separate library with
+// -DEQD_TRACE; the product library never defines it): lane 0 of wave 0 of workgroup 0 stores clock64().
+#ifdef EQD_TRACE
+extern __device__ long long eqd_trace_buf[1024];
+#define EQD_TR(slot)                                                                          \
+    do {                                                                                      \
+        const int trs_ = (slot);                                                              \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && trs_ < 256) {           \
+            eqd_trace_buf[2 * trs_] = clock64();                                              \
+            eqd_trace_buf[2 * trs_ + 1] = wall_clock64();                                     \
+        }                                                                                     \
+    } while (0)
+#define EQD_TR_WG()                                                                           \
+    do {                                                                                      \
+        if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 256)                          \
+            eqd_trace_buf[512 + 2 * blockIdx.x] = wall_clock64();                             \
+    } while (0)
+#define EQD_TR_WG_END()                                                                       \
+    do {                                                                                      \
+        __syncthreads();                                                                      \
+        if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 256)                          \
+            eqd_trace_buf[512 + 2 * blockIdx.x + 1] = wall_clock64();                         \
+    } while (0)
+#else
+#define EQD_TR(slot) do { } while (0)
+#define EQD_TR_WG() do { } while (0)
+#define EQD_TR_WG_END() do { } while (0)
+#endif
+
 // Split in two so that a batch of loads can be issued back to back: ld4u_raw is ONE unconditional load
 // instruction; ld4u_fix (shift + zero fill, selects) runs later, when the data is consumed.
 typedef float f4v __attribute__((ext_vector_type(4), aligned(4)));
@@ -79,6 +108,19 @@ __device__ __forceinline__ float l16_sum(float v) {
     return v;
 }
 __device__ __forceinline__ float wave_sum(float v) { return group_sum(l16_sum(v)); }
+// Sixteen sums over the 16 lanes of a lane group in 15 exchanges (instead of 16 x 4): every lane brings v[0..15],
+// lane l15 returns sum over the group's lanes of v[l15] (butterfly that halves the number of live values per step).
+__device__ __forceinline__ float reduce16x16(const float (&v)[16], int l15) {
+    const bool b3 = (l15 & 8) != 0, b2 = (l15 & 4) != 0, b1 = (l15 & 2) != 0, b0 = (l15 & 1) != 0;
+    float w8[8], w4[4], w2[2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w8[i] = (b3 ? v[i + 8] : v[i]) + __shfl_xor(b3 ? v[i] : v[i + 8], 8);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w4[i] = (b2 ? w8[i + 4] : w8[i]) + __shfl_xor(b2 ? w8[i] : w8[i + 4], 4);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) w2[i] = (b1 ? w4[i + 2] : w4[i]) + __shfl_xor(b1 ? w4[i] : w4[i + 2], 2);
+    return (b0 ? w2[1] : w2[0]) + __shfl_xor(b0 ? w2[0] : w2[1], 1);
+}
 
 // Ordering point for wave-private LDS traffic (one wave writes, other lanes of the SAME wave
 // read).  The hardware executes a wave's LDS instructions in order; this only stops the

@@ -187,62 +187,73 @@ __device__ __forceinline__ void edge_tile_forward(const EqdGraph& G, const EqdEd
                                                   f32x4 (&xh)[4][NB], f32x4 (&m)[4][NB], f32x4 (&ch)[4][NB],
                                                   float* __restrict__ rbf_out) {
     const int l15 = lane & 15, g = lane >> 4;
+    EQD_TR(2);
+    // Every global load of the tile is issued up front, unpredicated (lanes beyond the tile read edge e0, always a
+    // valid index, and are zeroed afterwards; predicated loads compile to exec-masked branches with a wait behind
+    // each): the he rows, src / dst, then - one dependent round trip later - the coordinates and the P / Q rows.
+    // ---- he rows: 16 NB x 27 contiguous floats ---------------------------------------------------
+    constexpr int NH = (16 * NB * 27 / 4 + 63) / 64;       // 16-byte segments per lane
+    const float* __restrict__ he = G.he + (size_t)S.e0 * 27;
+    const int nhe = P.use_he ? S.ne * 27 : 0;
+    f32x4 hv[NH];
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+        const int i = 4 * (lane + 64 * j);
+        hv[j] = ld4u_raw(he + (i < nhe ? i : 0), nhe - i, G.he);
+    }
     // ---- geometry ---------------------------------------------------------------------------
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int el = 16 * nb + l15;
         S.ev[nb] = el < S.ne;
-        // no predicated loads (they compile to exec-masked branches with a wait behind each): lanes beyond the
-        // tile read edge e0 (always a valid index) and are zeroed afterwards
         const int ei = S.e0 + (S.ev[nb] ? el : 0);
-        const int s = G.src[ei], d = G.dst[ei];
-        S.src[nb] = s;
-        S.dst[nb] = d;
-        float xs[3], xd[3];
+        S.src[nb] = G.src[ei];
+        S.dst[nb] = G.dst[ei];
+    }
+    float xs[NB][3], xd[NB][3];
+    float4 pv[NB][4], qv[NB][4];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            xs[c] = x[(size_t)s * 3 + c];
-            xd[c] = x[(size_t)d * 3 + c];
+            xs[nb][c] = x[(size_t)S.src[nb] * 3 + c];
+            xd[nb][c] = x[(size_t)S.dst[nb] * 3 + c];
         }
-        float q = 0.f;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float v = S.ev[nb] ? xs[c] - xd[c] : 0.f;
-            S.xrel[nb][c] = v;
-            q += v * v;
+        for (int mb = 0; mb < 4; ++mb) {
+            pv[nb][mb] = *(const float4*)&Pn[(size_t)S.src[nb] * 64 + 16 * mb + 4 * g];
+            qv[nb][mb] = *(const float4*)&Qn[(size_t)S.dst[nb] * 64 + 16 * mb + 4 * g];
         }
-        S.d2[nb] = q;
     }
     // ---- feature tile [16 NB][45]: he (27) | rbf (15) | 0 -----------------------------------------
     for (int i = lane; i < 16 * NB * FS; i += 64) tile[i] = 0.f;
     wave_lds_fence();
-    if (P.use_he) {
-        // the tile's he rows are contiguous in HBM: 16 NB x 27 floats, all loads issued before the first
-        // LDS store
-        constexpr int NH = (16 * NB * 27 / 4 + 63) / 64;       // 16-byte segments per lane
-        const float* __restrict__ he = G.he + (size_t)S.e0 * 27;
-        const int nhe = S.ne * 27;
-        f32x4 hv[NH];
+    EQD_TR(3);
 #pragma unroll
-        for (int j = 0; j < NH; ++j) {
-            const int i = 4 * (lane + 64 * j);
-            hv[j] = ld4u_raw(he + (i < nhe ? i : 0), nhe - i, G.he);
-        }
+    for (int j = 0; j < NH; ++j) {
+        const int i = 4 * (lane + 64 * j);
+        const float4 hf = ld4u_fix(hv[j], nhe - i);
+        const float vv[4] = {hf.x, hf.y, hf.z, hf.w};
+        int e = i / 27, c = i - e * 27;
 #pragma unroll
-        for (int j = 0; j < NH; ++j) {
-            const int i = 4 * (lane + 64 * j);
-            const float4 hf = ld4u_fix(hv[j], nhe - i);
-            const float vv[4] = {hf.x, hf.y, hf.z, hf.w};
-            int e = i / 27, c = i - e * 27;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (i + u < nhe) tile[e * FS + c] = vv[u];
-                if (++c == 27) {
-                    c = 0;
-                    ++e;
-                }
+        for (int u = 0; u < 4; ++u) {
+            if (i + u < nhe) tile[e * FS + c] = vv[u];
+            if (++c == 27) {
+                c = 0;
+                ++e;
             }
         }
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = S.ev[nb] ? xs[nb][c] - xd[nb][c] : 0.f;
+            S.xrel[nb][c] = v;
+            q += v * v;
+        }
+        S.d2[nb] = q;
     }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
@@ -259,27 +270,19 @@ __device__ __forceinline__ void edge_tile_forward(const EqdGraph& G, const EqdEd
         if (rbf_out && g == 3 && S.ev[nb]) rbf_out[(size_t)(S.e0 + el) * 16 + 15] = 0.f;
     }
     wave_lds_fence();
+    EQD_TR(4);
     // ---- stage 1: z1 = P[src] + Q[dst] + W1cd feat ----------------------------------------------
-    {
-        float4 pv[NB][4], qv[NB][4];      // all 8 NB gathers in flight together
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
-                pv[nb][mb] = *(const float4*)&Pn[(size_t)S.src[nb] * 64 + 16 * mb + 4 * g];
-                qv[nb][mb] = *(const float4*)&Qn[(size_t)S.dst[nb] * 64 + 16 * mb + 4 * g];
-            }
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
-                const float4 p = pv[nb][mb], q = qv[nb][mb];
-                f32x4 a;
-                a[0] = S.ev[nb] ? p.x + q.x : 0.f; a[1] = S.ev[nb] ? p.y + q.y : 0.f;
-                a[2] = S.ev[nb] ? p.z + q.z : 0.f; a[3] = S.ev[nb] ? p.w + q.w : 0.f;
-                xh[mb][nb] = a;
-            }
-    }
+        for (int mb = 0; mb < 4; ++mb) {
+            const float4 p = pv[nb][mb], q = qv[nb][mb];
+            f32x4 a;
+            a[0] = S.ev[nb] ? p.x + q.x : 0.f; a[1] = S.ev[nb] ? p.y + q.y : 0.f;
+            a[2] = S.ev[nb] ? p.z + q.z : 0.f; a[3] = S.ev[nb] ? p.w + q.w : 0.f;
+            xh[mb][nb] = a;
+        }
+    EQD_TR(5);
 #pragma unroll
     for (int s = 0; s < 11; ++s) {
         const int k = 4 * s + g;
@@ -293,6 +296,7 @@ __device__ __forceinline__ void edge_tile_forward(const EqdGraph& G, const EqdEd
             for (int nb = 0; nb < NB; ++nb) xh[mb][nb] = mfma4(a, b[nb], xh[mb][nb]);
         }
     }
+    EQD_TR(6);
     // ---- LeakyReLU + LayerNorm statistics (two-pass like torch) ------------------------------------
     S.zpos = 0u;
 #pragma unroll
@@ -325,6 +329,7 @@ __device__ __forceinline__ void edge_tile_forward(const EqdGraph& G, const EqdEd
         S.mean[nb] = mean;
         S.rstd[nb] = rstd;
     }
+    EQD_TR(7);
     // ---- stage 2: m = W2 (xh * gamma + beta) + b2 --------------------------------------------------
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
@@ -334,6 +339,7 @@ __device__ __forceinline__ void edge_tile_forward(const EqdGraph& G, const EqdEd
         for (int nb = 0; nb < NB; ++nb) m[mb][nb] = v;
     }
     chain64<true, NB>(m, xh, w2, &vec[VEC_LNG], &vec[VEC_LNB], l15, g);
+    EQD_TR(8);
     // ---- stage 3: ch = Wc1 m + bc1; coef = wc2 . LeakyReLU(ch) + bc2 ---------------------------------
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
@@ -354,6 +360,7 @@ __device__ __forceinline__ void edge_tile_forward(const EqdGraph& G, const EqdEd
         }
         S.coef[nb] = group_sum(s) + vec[VEC_BC2];
     }
+    EQD_TR(9);
 }
 
 // store an F-layout tile to HBM as [edge][64]
@@ -373,23 +380,38 @@ __device__ __forceinline__ void hbm_store(float* __restrict__ dst, const f32x4 (
 // ---------------------------------------------------------------------------------------------
 // forward: node-aligned 32-edge tiles
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64 * FWD_WAVES) void k_edge_fwd(EqdGraph G, EqdEdgeParams P, const float* __restrict__ Pn,
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_edge_fwd(EqdGraph G, EqdEdgeParams P, const float* __restrict__ Pn,
                                                               const float* __restrict__ Qn,
                                                               const float* __restrict__ x,
                                                               float* __restrict__ aggr_msg,
                                                               float* __restrict__ x_new) {
-    __shared__ EdgeSmem<FWD_WAVES, 32 * TS> sm;
+    __shared__ EdgeSmem<NW, 32 * TS> sm;
+    __shared__ float sxw[NW][96];      // per-node mean of x_rel * coef of the wave's tile
+    EQD_TR_WG();
+    EQD_TR(0);
     edge_stage_weights(sm, P);
+    EQD_TR(1);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     float* tile = sm.tile[wave];
-    for (int t = blockIdx.x * FWD_WAVES + wave; t < G.n_tiles; t += gridDim.x * FWD_WAVES) {
+    // tile t -> workgroup t % grid, wave t / grid: a batch with few tiles per CU spreads over ALL CUs one wave per
+    // SIMD first (the kernel is MFMA-bound where two waves share a SIMD)
+    for (int t = wave * gridDim.x + blockIdx.x; t < G.n_tiles; t += gridDim.x * NW) {
         EdgeTileState<2> S;
         S.n0 = G.tile_node[t];
         S.n1 = G.tile_node[t + 1];
         S.e0 = G.rowptr[S.n0];
         S.ne = G.rowptr[S.n1] - S.e0;
         f32x4 xh[4][2], m[4][2], ch[4][2];
+        // row pointers (one per lane) and coordinates (3 nn <= 96 contiguous floats) of the tile's nodes: fetched
+        // now, used by the aggregation at the end
+        const int nn_pre = S.n1 - S.n0;
+        const int rp = G.rowptr[S.n0 + (lane <= nn_pre ? lane : 0)] - S.e0;
+        const size_t xo = (size_t)S.n0 * 3;
+        const int c0 = lane, c1 = lane + 64;
+        const float x0a = G.x0[xo + (c0 < 3 * nn_pre ? c0 : 0)], xa = x[xo + (c0 < 3 * nn_pre ? c0 : 0)];
+        const float x0b = G.x0[xo + (c1 < 3 * nn_pre ? c1 : 0)], xb = x[xo + (c1 < 3 * nn_pre ? c1 : 0)];
         edge_tile_forward<2>(G, P, sm.w1, sm.w2, sm.wc1, sm.vec, tile, Pn, Qn, x, lane, S, xh, m, ch, nullptr);
         wave_lds_fence();   // feature tile is dead: reuse as the message tile [edge][64 + x_moment]
 #pragma unroll
@@ -400,30 +422,53 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void k_edge_fwd(EqdGraph G, EqdEdge
                     make_float4(m[mb][nb][0], m[mb][nb][1], m[mb][nb][2], m[mb][nb][3]);
         if (g == 0) {
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
+            for (int nb = 0; nb < 2; ++nb) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) tile[(16 * nb + l15) * TS + 64 + c] = S.xrel[nb][c] * S.coef[nb];
-        }
-        wave_lds_fence();
-        const int nn = S.n1 - S.n0;   // <= 32 nodes per tile: one rowptr entry per lane, broadcast by shuffle
-        const int rp = (lane <= nn) ? G.rowptr[S.n0 + lane] - S.e0 : 0;
-        for (int i = 0; i < nn; ++i) {
-            const int n = S.n0 + i;
-            const int a = __shfl(rp, i), b = __shfl(rp, i + 1);
-            float s = 0.f, sx = 0.f;
-            for (int e = a; e < b; ++e) {
-                s += tile[e * TS + lane];
-                if (lane < 3) sx += tile[e * TS + 64 + lane];
-            }
-            const float inv = b > a ? 1.f / (float)(b - a) : 0.f;
-            aggr_msg[(size_t)n * 64 + lane] = s * inv;
-            if (lane < 3) {
-                const size_t o = (size_t)n * 3 + lane;
-                x_new[o] = P.eta * G.x0[o] + (1.f - P.eta) * x[o] + sx * inv;
+                tile[(16 * nb + l15) * TS + 67] = 0.f;
             }
         }
         wave_lds_fence();
+        EQD_TR(10);
+        // per-node means as a small MFMA product: out[node][f] = sum_e A[node][e] tile[e][f] with the 0/1 membership
+        // matrix A built in registers from the tile's row pointers (node l15 of the block, edge 4 ks + g), then
+        // scaled by 1 / degree.  Column block 4 carries the x_rel * coef moments (columns 64..66).
+        const int nn = S.n1 - S.n0;   // <= 32 nodes per tile
+        const int degl = __shfl(rp, (lane + 1) & 63) - rp;    // lane = node
+        const float invl = (lane < nn && degl > 0) ? 1.f / (float)degl : 0.f;
+        for (int nb0 = 0; nb0 < nn; nb0 += 16) {
+            const int node = nb0 + l15;
+            const int lo = __shfl(rp, node), hi = __shfl(rp, node + 1);
+            const bool nv = node < nn;
+            f32x4 acc[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) acc[j] = f4zero();
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const int e = 4 * ks + g;
+                const float am = (nv && e >= lo && e < hi) ? 1.f : 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = mfma4(am, tile[e * TS + 16 * j + l15], acc[j]);
+                acc[4] = mfma4(am, tile[e * TS + 64 + (l15 & 3)], acc[4]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int nd = nb0 + 4 * g + r;                 // output row of this lane
+                const float inv = __shfl(invl, nd);
+                if (nd < nn) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) aggr_msg[(size_t)(S.n0 + nd) * 64 + 16 * j + l15] = acc[j][r] * inv;
+                    if (l15 < 3) sxw[wave][3 * nd + l15] = acc[4][r] * inv;
+                }
+            }
+        }
+        wave_lds_fence();
+        if (c0 < 3 * nn) x_new[xo + c0] = P.eta * x0a + (1.f - P.eta) * xa + sxw[wave][c0];
+        if (c1 < 3 * nn) x_new[xo + c1] = P.eta * x0b + (1.f - P.eta) * xb + sxw[wave][c1];
+        wave_lds_fence();
+        EQD_TR(11);
     }
+    EQD_TR_WG_END();
 }
 
 // Smallest grid with the minimal number of tile rounds: with `wg_per_cu` workgroups per CU the makespan is
@@ -445,9 +490,10 @@ extern "C" int eqd_edge_message_fwd(const EqdGraph* g, const EqdEdgeParams* p, c
         return EQD_ERR_NULL;
     }
     if (g->n_tiles <= 0) return EQD_OK;
-    const int blocks = edge_grid(g->n_tiles, FWD_WAVES, 1);
-    hipLaunchKernelGGL(k_edge_fwd, dim3(blocks), dim3(64 * FWD_WAVES), 0, (hipStream_t)stream, *g, *p, P, Q, x, aggr_msg,
-                       x_new);
+    // one workgroup per CU (LDS-bound), tiles dealt round-robin over the workgroups
+    const int blocks = g->n_tiles < 256 ? g->n_tiles : 256;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_edge_fwd<FWD_WAVES>), dim3(blocks), dim3(64 * FWD_WAVES), 0, (hipStream_t)stream,
+                       *g, *p, P, Q, x, aggr_msg, x_new);
     return eqd_check_launch("k_edge_fwd");
 }
 
@@ -526,13 +572,16 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
     __shared__ EdgeSmem<BWD_WAVES, 16 * FS> sm;
     __shared__ __attribute__((aligned(16))) float U[128 * US];
     __shared__ __attribute__((aligned(16))) float V[128 * US];
-    __shared__ float vacc[BWD_WAVES][VA];
+    EQD_TR_WG();
+    EQD_TR(0);
     edge_stage_weights(sm, P);
+    EQD_TR(1);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     float* tile = sm.tile[wave];
-    for (int i = lane; i < VA; i += 64) vacc[wave][i] = 0.f;
-    wave_lds_fence();
+    // vector-gradient sums of this lane's feature fo = 16 (l15 >> 2) + 4 g + (l15 & 3) (see reduce16x16), kept in
+    // registers over all tiles of the wave; r_dbc2 is a plain per-lane partial
+    float r_dlng = 0.f, r_dlnb = 0.f, r_dwc2 = 0.f, r_dbc1 = 0.f, r_db2 = 0.f, r_dbc2 = 0.f;
     // this wave's blocks of the weight gradients: rows 16*wmb.., columns 16*(2*(wave&1)) + {0,16} of the 64x64
     // matrices; for dW1[:, 2d:] (3 column blocks) block (wmb, wave&1) and, for waves 0..3, block (wave, 2)
     const int wmb = wave >> 1, wnb = 2 * (wave & 1);
@@ -548,18 +597,24 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
         S.ne = S.ne < 0 ? 0 : (S.ne > 16 ? 16 : S.ne);
         if (S.ne == 0) S.e0 = 0;
         f32x4 xh[4][1], m[4][1], ch[4][1];
-        edge_tile_forward<1>(G, P, sm.w1, sm.w2, sm.wc1, sm.vec, tile, Pn, Qn, x, lane, S, xh, m, ch, nullptr);
-        // ---- coordinate path ---------------------------------------------------------------------
-        float invdeg = 0.f, dcoef = 0.f, dxr[3] = {0.f, 0.f, 0.f};
-        float4 dag[4];                    // d_aggr[dst] rows, fetched now (unpredicated), used after phase 1
+        // incoming gradients of the tile's destination nodes: fetched before the forward recompute (unpredicated;
+        // lanes beyond the tile use the clamped edge e0), consumed after it
+        float4 dag[4];
+        float gxn[3];
+        int r0, r1;
         {
-            const int d = S.dst[0];       // lanes beyond the tile carry a valid (clamped) node index
-            const int r0 = G.rowptr[d], r1 = G.rowptr[d + 1];
-            float gxn[3];
+            const int d = G.dst[S.e0 + (l15 < S.ne ? l15 : 0)];
+            r0 = G.rowptr[d];
+            r1 = G.rowptr[d + 1];
 #pragma unroll
             for (int c = 0; c < 3; ++c) gxn[c] = d_xnew[(size_t)d * 3 + c];
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) dag[mb] = *(const float4*)&d_aggr[(size_t)d * 64 + 16 * mb + 4 * g];
+        }
+        edge_tile_forward<1>(G, P, sm.w1, sm.w2, sm.wc1, sm.vec, tile, Pn, Qn, x, lane, S, xh, m, ch, nullptr);
+        // ---- coordinate path ---------------------------------------------------------------------
+        float invdeg = 0.f, dcoef = 0.f, dxr[3] = {0.f, 0.f, 0.f};
+        {
             invdeg = S.ev[0] ? 1.f / (float)(r1 - r0) : 0.f;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -568,34 +623,34 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
                 dxr[c] = gx * S.coef[0];
             }
         }
-        // d wc2 / d bc2 / d bc1 partials (reduced over the 16 edge lanes, banked in LDS), then
-        // ch := d_chid = wc2 * dcoef * LeakyReLU'(ch)
+        // d wc2 / d bc1 partials, then ch := d_chid = wc2 * dcoef * LeakyReLU'(ch)
+        {
+            float va[16], vb[16];
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
-            const float4 w = *(const float4*)&sm.vec[VEC_WC2 + 16 * mb + 4 * g];
-            const float wv[4] = {w.x, w.y, w.z, w.w};
+            for (int mb = 0; mb < 4; ++mb) {
+                const float4 w = *(const float4*)&sm.vec[VEC_WC2 + 16 * mb + 4 * g];
+                const float wv[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float c = ch[mb][0][r];
-                const float acc = l16_sum(lrelu(c, P.slope) * dcoef);
-                const float dch = wv[r] * dcoef * lrelu_grad(c, P.slope);
-                ch[mb][0][r] = dch;
-                const float sb = l16_sum(dch);
-                if (l15 == 0) {
-                    vacc[wave][V_DWC2 + 16 * mb + 4 * g + r] += acc;
-                    vacc[wave][V_DBC1 + 16 * mb + 4 * g + r] += sb;
+                for (int r = 0; r < 4; ++r) {
+                    const float c = ch[mb][0][r];
+                    const float dch = wv[r] * dcoef * lrelu_grad(c, P.slope);
+                    va[4 * mb + r] = lrelu(c, P.slope) * dcoef;
+                    vb[4 * mb + r] = dch;
+                    ch[mb][0][r] = dch;
                 }
             }
+            r_dwc2 += reduce16x16(va, l15);
+            r_dbc1 += reduce16x16(vb, l15);
+            r_dbc2 += g == 0 ? dcoef : 0.f;
         }
-        {
-            const float dbc2 = l16_sum(dcoef);
-            if (lane == 0) vacc[wave][V_DBC2] += dbc2;
-        }
+        EQD_TR(12);
         // ---- phase 1: dWc1 += d_chid^T m -------------------------------------------------------------
         slab_store(U, wave, ch, l15, g);
         slab_store(V, wave, m, l15, g);
         __syncthreads();
+        EQD_TR(13);
         slab_atb<2>(gWc1, U, V, wmb, wnb, l15, g);
+        EQD_TR(14);
         // ---- dm = d_aggr[dst] / deg + Wc1^T d_chid ---------------------------------------------------
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
@@ -605,13 +660,15 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
             m[mb][0] = a;
         }
         chain64T<1>(m, ch, sm.wc1, l15, g);
+        {
+            float va[16];
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
+            for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float sb = l16_sum(m[mb][0][r]);
-                if (l15 == 0) vacc[wave][V_DB2 + 16 * mb + 4 * g + r] += sb;
-            }
+                for (int r = 0; r < 4; ++r) va[4 * mb + r] = m[mb][0][r];
+            r_db2 += reduce16x16(va, l15);
+        }
+        EQD_TR(15);
         // ---- phase 2: dW2 += dm^T a1 ---------------------------------------------------------------------
         __syncthreads();                 // every wave is done reading the phase-1 slabs
         slab_store(U, wave, m, l15, g);
@@ -629,25 +686,28 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
             slab_store(V, wave, a1, l15, g);
         }
         __syncthreads();
+        EQD_TR(16);
         slab_atb<2>(gW2, U, V, wmb, wnb, l15, g);
+        EQD_TR(17);
         // ---- da1 = W2^T dm ---------------------------------------------------------------------------
         f32x4 dz[4][1];
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) dz[mb][0] = f4zero();
         chain64T<1>(dz, m, sm.w2, l15, g);
+        EQD_TR(18);
         // ---- LayerNorm + LeakyReLU backward --------------------------------------------------------------
+        {
+            float va[16], vb[16];
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
+            for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float a = l16_sum(dz[mb][0][r] * xh[mb][0][r]);
-                const float b = l16_sum(dz[mb][0][r]);
-                if (l15 == 0) {
-                    const int f = 16 * mb + 4 * g + r;
-                    vacc[wave][V_DLNG + f] += a;
-                    vacc[wave][V_DLNB + f] += b;
+                for (int r = 0; r < 4; ++r) {
+                    va[4 * mb + r] = dz[mb][0][r] * xh[mb][0][r];
+                    vb[4 * mb + r] = dz[mb][0][r];
                 }
-            }
+            r_dlng += reduce16x16(va, l15);
+            r_dlnb += reduce16x16(vb, l15);
+        }
         {
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -674,6 +734,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
                     dz[mb][0][r] = v;
                 }
         }
+        EQD_TR(19);
         hbm_store<1>(W.dz1, dz, S, l15, g);
         // ---- phase 3: dW1[:, 2d:] += dz1^T [he | rbf] ------------------------------------------------------
         __syncthreads();                 // phase-2 slabs are free
@@ -681,6 +742,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
         __syncthreads();
         feat_atb(gW1a, U, &sm.tile[0][0], wmb, wave & 1, l15, g);     // the feature tiles are the B operand as they lie
         if (wave < 4) feat_atb(gW1b, U, &sm.tile[0][0], wave, 2, l15, g);
+        EQD_TR(20);
         // ---- d rbf = W1d^T dz1 -> d(d^2) -> d x_rel --------------------------------------------------------
         if (P.use_dist) {
             f32x4 dr = f4zero();
@@ -709,10 +771,20 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
             o[0] = dxr[0]; o[1] = dxr[1]; o[2] = dxr[2]; o[3] = 0.f;
         }
         __syncthreads();                 // phase-3 slabs and the feature tiles are free for the next iteration
+        EQD_TR(21);
     }
     // ---- partials: this wave's vector sums and weight-gradient blocks ---------------------------------------
     float* vp = W.vecp + (size_t)(blockIdx.x * BWD_WAVES + wave) * VP;
-    for (int i = lane; i < VA; i += 64) vp[i] = vacc[wave][i];
+    {
+        const int fo = 16 * (l15 >> 2) + 4 * g + (l15 & 3);
+        vp[V_DLNG + fo] = r_dlng;
+        vp[V_DLNB + fo] = r_dlnb;
+        vp[V_DWC2 + fo] = r_dwc2;
+        vp[V_DB2 + fo] = r_db2;
+        vp[V_DBC1 + fo] = r_dbc1;
+        const float t = wave_sum(r_dbc2);
+        if (lane == 0) vp[V_DBC2] = t;
+    }
     float* wp = W.wpart + (size_t)blockIdx.x * WP_N;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -727,6 +799,8 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
         wp[WP_W1 + (16 * wmb + 4 * g + r) * 48 + 16 * (wave & 1) + l15] = gW1a[0][r];
         if (wave < 4) wp[WP_W1 + (16 * wave + 4 * g + r) * 48 + 32 + l15] = gW1b[0][r];
     }
+    EQD_TR(22);
+    EQD_TR_WG_END();
 }
 
 static int edge_bwd_blocks(const EqdGraph* g) {

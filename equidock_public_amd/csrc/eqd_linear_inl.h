@@ -14,21 +14,7 @@
 // (3200 x 64..384 x 64 at config B): what matters is one memory round trip per source and few load
 // instructions (a 64 x 64 weight slice is 4 vector loads per thread, not 16 scalar ones).
 // Weights are addressed W[m * w_rs + k * w_cs] with w_cs == 1 (forward) or w_rs == 1 (transposed, backward).
-// Phase timestamps of workgroup (0, 0) for the latency experiments (profiles/exp_trace_linear.py builds a
-// separate library with -DEQD_TRACE; the product library never defines it).
-#ifdef EQD_TRACE
-extern __device__ long long eqd_trace_buf[1024];
-#define LIN_TR(i)                                                              \
-    do {                                                                       \
-        const int tri_ = (i);                                                  \
-        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && tri_ < 256) { \
-            eqd_trace_buf[2 * tri_] = clock64();                               \
-            eqd_trace_buf[2 * tri_ + 1] = wall_clock64();                      \
-        }                                                                      \
-    } while (0)
-#else
-#define LIN_TR(i) do { } while (0)
-#endif
+#define LIN_TR(i) EQD_TR(i)
 struct LinRegs {
     f32x4 x[2], xm[2], w[5][2];   // raw 16-byte loads; ld4u_fix is applied when they are written to LDS
 };

@@ -49,14 +49,9 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_linear(LinJobsArg jobs) {
     const EqdLinJob& J = jobs.j[blockIdx.y];
     const int row0 = (int)blockIdx.x * 16;
     if (row0 >= J.rows) return;      // uniform for the whole workgroup
-#ifdef EQD_TRACE
-    if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 256) eqd_trace_buf[512 + 2 * blockIdx.x] = wall_clock64();
-#endif
+    EQD_TR_WG();
     linear_tile(J, nullptr, -1, sm, nullptr, row0);
-#ifdef EQD_TRACE
-    __syncthreads();
-    if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 256) eqd_trace_buf[512 + 2 * blockIdx.x + 1] = wall_clock64();
-#endif
+    EQD_TR_WG_END();
 }
 
 // ------------------------------------------------------------------------------------------

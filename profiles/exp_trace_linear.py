@@ -9,7 +9,7 @@ OUT = os.path.join(ROOT, 'profiles', '_exp', 'libeqd_trace.so')
 
 def build():
     srcs = sorted(glob.glob(os.path.join(ROOT, 'equidock_public_amd', 'csrc', '*.hip')))
-    cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-DEQD_TRACE',
+    cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-DEQD_TRACE', '-fgpu-rdc',
            '-shared', '-o', OUT] + srcs
     subprocess.run(cmd, check=True)
 
