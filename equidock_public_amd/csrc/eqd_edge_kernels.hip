@@ -395,9 +395,7 @@ __global__ __launch_bounds__(64 * NW) void k_edge_fwd(EqdGraph G, EqdEdgeParams 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     float* tile = sm.tile[wave];
-    // tile t -> workgroup t % grid, wave t / grid: a batch with few tiles per CU spreads over ALL CUs one wave per
-    // SIMD first (the kernel is MFMA-bound where two waves share a SIMD)
-    for (int t = wave * gridDim.x + blockIdx.x; t < G.n_tiles; t += gridDim.x * NW) {
+    for (int t = blockIdx.x * NW + wave; t < G.n_tiles; t += gridDim.x * NW) {
         EdgeTileState<2> S;
         S.n0 = G.tile_node[t];
         S.n1 = G.tile_node[t + 1];
@@ -490,8 +488,10 @@ extern "C" int eqd_edge_message_fwd(const EqdGraph* g, const EqdEdgeParams* p, c
         return EQD_ERR_NULL;
     }
     if (g->n_tiles <= 0) return EQD_OK;
-    // one workgroup per CU (LDS-bound), tiles dealt round-robin over the workgroups
-    const int blocks = g->n_tiles < 256 ? g->n_tiles : 256;
+    // Smallest grid with the minimal number of tile rounds (edge_grid): at config B that is 134 of the 256 CUs, which
+    // leaves room for the attention kernel that runs beside this one on the auxiliary stream.  (Dealing the 1067
+    // tiles over all 256 CUs measured no faster - 4 % of the SIMDs still get two tiles - and serialised the two.)
+    const int blocks = edge_grid(g->n_tiles, FWD_WAVES, 1);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_edge_fwd<FWD_WAVES>), dim3(blocks), dim3(64 * FWD_WAVES), 0, (hipStream_t)stream,
                        *g, *p, P, Q, x, aggr_msg, x_new);
     return eqd_check_launch("k_edge_fwd");
