@@ -126,6 +126,8 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_fwd(EqdGraph G, int d, const
     int rowq[2] = {b0 + l15, b0 + 16 + l15};
     bool qv[2] = {rowq[0] < b1, rowq[1] < b1};
 
+    EQD_TR_WG();
+    EQD_TR(0);
     TileRegs<DB, FAST> rk, rv;
     int kt = o0 + 32 * wave;
     tile_load<DB, FAST>(rk, k, d, kt, o1, lane);
@@ -134,8 +136,10 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_fwd(EqdGraph G, int d, const
     zero_fill(Kt[wave], C::TILE, lane, 64);
     zero_fill(Vt[wave], C::TILE, lane, 64);
     __syncthreads();
+    EQD_TR(1);
     block_tile_stage(q, d, DS, b0, b1, Qt, t);
     __syncthreads();
+    EQD_TR(2);
     float qf[2][KS];
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
@@ -151,13 +155,16 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_fwd(EqdGraph G, int d, const
     float mrun[2] = {EQD_NEG_BIG, EQD_NEG_BIG}, lrun[2] = {0.f, 0.f};
     const float* __restrict__ Kw = Kt[wave];
     const float* __restrict__ Vw = Vt[wave];
+    EQD_TR(3);
     for (; kt < o1; kt += 32 * EQD_WAVES) {
         wave_lds_fence();
         tile_store<DB, FAST>(rk, Kt[wave], d, lane);
         tile_store<DB, FAST>(rv, Vt[wave], d, lane);
         wave_lds_fence();
+        EQD_TR(4);
         tile_load<DB, FAST>(rk, k, d, kt + 32 * EQD_WAVES, o1, lane);   // prefetch the wave's next tile
         tile_load<DB, FAST>(rv, v, d, kt + 32 * EQD_WAVES, o1, lane);
+        EQD_TR(5);
         f32x4 S[2][2];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) S[mb][0] = S[mb][1] = f4zero();
@@ -169,6 +176,7 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_fwd(EqdGraph G, int d, const
                 S[mb][0] = mfma4(a, qf[0][ks], S[mb][0]);
                 S[mb][1] = mfma4(a, qf[1][ks], S[mb][1]);
             }
+        EQD_TR(6);
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
             float mx = EQD_NEG_BIG;
@@ -199,6 +207,7 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_fwd(EqdGraph G, int d, const
 #pragma unroll
             for (int db = 0; db < DB; ++db) O[db][nb] *= alpha;
         }
+        EQD_TR(7);
 #pragma unroll
         for (int mbk = 0; mbk < 2; ++mbk)
 #pragma unroll
@@ -209,7 +218,9 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_fwd(EqdGraph G, int d, const
                     O[db][0] = mfma4(a, S[mbk][0][r], O[db][0]);
                     O[db][1] = mfma4(a, S[mbk][1][r], O[db][1]);
                 }
+        EQD_TR(8);
     }
+    EQD_TR(9);
     // ---- merge the 4 waves' partial softmax states -----------------------------------------------
 #pragma unroll
     for (int db = 0; db < DB; ++db)
@@ -259,6 +270,8 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_fwd(EqdGraph G, int d, const
         for (int nb = 0; nb < 2; ++nb)
             if (qv[nb]) lse[rowq[nb]] = ltot[nb] > 0.f ? mtot[nb] + logf(ltot[nb]) : 0.f;
     }
+    EQD_TR(10);
+    EQD_TR_WG_END();
 }
 
 // backward pass 1: dq for the block's queries; also writes delta[q] = sum_f dO[q][f] O[q][f]
