@@ -195,6 +195,8 @@ struct EqdChainArg {
 };
 int eqd_launch_rowchain(const EqdChainJob* jobs, int njobs, int rows, hipStream_t st);
 size_t eqd_atb_batch_partial_bytes(int rows);
+int eqd_row_tiles(int rows);          // 16-row tiles per workgroup of the row kernels
+int eqd_rowchain_blocks(int rows);    // = workgroups of a row-chain launch = LayerNorm-backward partial rows
 
 // internal launchers (defined across the .hip files)
 int eqd_launch_vec_reduce(const float* partial, int nparts, int pstride, int n, float* out, hipStream_t st);

@@ -9,7 +9,6 @@
 #include "eqd_common.h"
 
 #include <vector>
-#define LIN_KC_HOST 80   /* widest LDS-resident source of a row chain (LIN_KC in eqd_linear_inl.h) */
 
 #include <string.h>
 
@@ -502,7 +501,7 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
                 for (int i = 0; i < EQD_MAX_SRC; ++i) C.src_local[i] = -1;
                 C.out_local = -1;
             };
-            const bool fused_dh = l < D.L - 1 && D.dh <= LIN_KC_HOST;
+            const bool fused_dh = l < D.L - 1;
             if (l < D.L - 1) {
                 EqdChainJob& C = cj[nj++];
                 clear(C);
@@ -546,7 +545,7 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
                 C5.lin.R = W.dh0acc; C5.lin.ldr = D.d0; C5.lin.beta = 1.f;
             }
             RC(eqd_launch_rowchain(cj, nj, N, st));
-            const int nb = (N + 15) / 16;
+            const int nb = eqd_rowchain_blocks(N);
             if (defer->n + 2 <= 512) {
                 defer->seg[defer->n++] = EqdRedSeg{lnp, nb, 256, d, gp[P_NLG], 0, 0, 0};
                 defer->seg[defer->n++] = EqdRedSeg{lnp + 128, nb, 256, d, gp[P_NLB], 0, 0, 0};

@@ -1,257 +1,284 @@
 // Row-local linear tile shared by k_linear (one job per workgroup) and k_rowchain (a sequence of jobs on
-// the same 16 rows whose intermediate results stay in LDS).
+// the same rows whose intermediate results stay in LDS).
+//
+// A workgroup (4 waves) owns RT tiles of 16 rows.  A job is a sum over sources of X_s W_s^T; every source is
+// walked in K chunks of 64 ("full" steps) followed by chunks of <= 16 ("small" steps: the 5 columns left over
+// from the 69-wide h0 / layer-0 features).  Per step the weights are staged ONCE for the RT row tiles:
+//   * all global loads of a step are unconditional (rows and weight rows beyond the matrix are clamped to the
+//     last valid one and zeroed when written to LDS): a predicated load compiles to an exec-masked branch with
+//     a wait behind it, which turns a batch of loads into a chain of round trips (measured: 8 600 -> 3 600
+//     shader clocks per step);
+//   * full steps move 16-byte vectors along the contiguous axis (4-byte alignment is enough on gfx950);
+//   * the loads of step i + 2 are in flight while step i is multiplied (two register sets);
+//   * MFMA operands are read from LDS as b128: k-step j of a chunk belongs to lane group g as
+//     k = 16 (j >> 2) + 4 g + (j & 3), valid because both operands use the same assignment;
+//   * wave w owns output blocks mb = w and w + 4 (M <= 80), so accumulators are complete without a cross-wave
+//     reduction; LayerNorm statistics go through LDS.
+// Weights are addressed W[m * w_rs + k * w_cs] with w_cs == 1 (forward) or w_rs == 1 (transposed, backward).
 #pragma once
 #include "eqd_common.h"
 
-#define LIN_KC 80   /* K chunk staged per step (every source of the IEGMN path has K <= 69) */
-#define LIN_S 84    /* LDS row stride: 21 x 16 B (b128 stores), 20 l15 + g hits 64 different banks */
-#define LIN_LOCALS 4
-// A workgroup owns 16 rows.  Per source chunk: ALL loads (X tile 16 x Kc, weight slice M x Kc) are
-// issued together by the 256 threads as 16-byte vectors along the contiguous axis (4-byte alignment is
-// enough, see ld4u), parked in registers while the previous chunk is multiplied, then written to LDS; MFMA
-// operands come from LDS.  Wave w owns output blocks mb = w and w + 4, so accumulators are complete (no
-// cross-wave reduction); LayerNorm statistics are exchanged through LDS.  These GEMMs are tiny
-// (3200 x 64..384 x 64 at config B): what matters is one memory round trip per source and few load
-// instructions (a 64 x 64 weight slice is 4 vector loads per thread, not 16 scalar ones).
-// Weights are addressed W[m * w_rs + k * w_cs] with w_cs == 1 (forward) or w_rs == 1 (transposed, backward).
+#define LIN_S 84    /* LDS row stride: 21 x 16 B (aligned b128), 20 l15 + g hits 64 different banks */
+#define LIN_LOCALS 3
 #define LIN_TR(i) EQD_TR(i)
-struct LinRegs {
-    f32x4 x[2], xm[2], w[5][2];   // raw 16-byte loads; ld4u_fix is applied when they are written to LDS
-};
-struct alignas(16) LinSmem {
-    float Xl[16 * LIN_S];
-    float Wl[80 * LIN_S];
-    float stat[EQD_WAVES][16];
-};
-// valid floats of the thread's X segment h / weight segment (j, h) of the step (source S, chunk k0)
-__device__ __forceinline__ int lin_nx(const EqdLinJob& J, const EqdLinSrc& S, int k0, int row0, int t, int h) {
-    const int Kc = (S.K - k0 < LIN_KC) ? S.K - k0 : LIN_KC;
-    const int tr = t >> 4, tc = t & 15;
-    return (row0 + tr < J.rows && (h == 0 || tc < 4)) ? Kc - (4 * tc + 64 * h) : 0;
-}
-__device__ __forceinline__ int lin_nw(const EqdLinJob& J, const EqdLinSrc& S, int k0, int t, int j, int h) {
-    const int Kc = (S.K - k0 < LIN_KC) ? S.K - k0 : LIN_KC;
-    const int tr = t >> 4, tc = t & 15;
-    const bool kfast = (S.w_cs == 1);
-    // a = index along the strided axis (tr + 16 j), c = first index of the 4-wide segment along the
-    // contiguous axis (k when kfast, m otherwise)
-    const int na = kfast ? J.M : Kc, nc = kfast ? Kc : J.M;
-    return (tr + 16 * j < na && (h == 0 || tc < 4)) ? nc - (4 * tc + 64 * h) : 0;
-}
-// Interior steps (all 16 rows valid, a full 64-wide K chunk, 64 outputs - every step of layers >= 1) take a
-// path without any per-lane predicate: 1 + 4 unconditional 16-byte loads per thread.  Conditional loads
-// compile to exec-masked branches with a wait behind each, which serialises the batch (measured: 8600 shader
-// clocks per step with predicated loads).
-__device__ __forceinline__ bool lin_fast(const EqdLinJob& J, const EqdLinSrc& S, int k0, int row0) {
-    return S.K - k0 == 64 && J.M == 64 && row0 + 16 <= J.rows;
-}
-__device__ __forceinline__ void lin_load(const EqdLinJob& J, const EqdLinSrc& S, bool local, int k0, int row0, int t,
-                                         LinRegs& R) {
-    const int tr = t >> 4, tc = t & 15;
-    const int row = row0 + tr;
-    const bool kfast = (S.w_cs == 1);
-    const int astride = kfast ? S.w_rs : S.w_cs;
-    const float* __restrict__ Wb = S.W + (size_t)k0 * S.w_cs;
-    if (lin_fast(J, S, k0, row0)) {
-        if (!local) {
-            const size_t o = (size_t)row * S.ldx + k0 + 4 * tc;
-            R.x[0] = *(const f4v*)(S.X + o);
-            if (S.mask) R.xm[0] = *(const f4v*)(S.mask + o);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) R.w[j][0] = *(const f4v*)(Wb + (size_t)(tr + 16 * j) * astride + 4 * tc);
-        return;
-    }
-    if (!local) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int n = lin_nx(J, S, k0, row0, t, h);
-            const size_t o = (size_t)(row < J.rows ? row : 0) * S.ldx + k0 + 4 * tc + 64 * h;
-            R.x[h] = ld4u_raw(S.X + o, n, S.X);
-            if (S.mask) R.xm[h] = ld4u_raw(S.mask + o, n, S.mask);
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        const int a = tr + 16 * j;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int n = lin_nw(J, S, k0, t, j, h);
-            R.w[j][h] = ld4u_raw(Wb + (size_t)(n > 0 ? a : 0) * astride + 4 * tc + 64 * h, n, S.W);
-        }
-    }
-}
-__device__ __forceinline__ void lin_store(const EqdLinJob& J, const EqdLinSrc& S, bool local, int k0, int row0, int t,
-                                          const LinRegs& R, float* __restrict__ Xl, float* __restrict__ Wl) {
-    const int tr = t >> 4, tc = t & 15;
-    // weights always land as Wl[m][k]
-    if (lin_fast(J, S, k0, row0)) {
-        if (!local) {
-            f32x4 v = R.x[0];
-            if (S.mask) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] *= lrelu_grad(R.xm[0][i], J.slope);
-            }
-            *(f32x4*)&Xl[tr * LIN_S + 4 * tc] = v;
-        }
-        if (S.w_cs == 1) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) *(f32x4*)&Wl[(tr + 16 * j) * LIN_S + 4 * tc] = R.w[j][0];
-        } else {       // the vector runs along m: transpose on the way in (4-way bank conflict, 16 short stores)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) Wl[(4 * tc + i) * LIN_S + tr + 16 * j] = R.w[j][0][i];
-        }
-        return;
-    }
-    if (!local) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            if (h == 1 && tc >= 4) continue;
-            const int n = lin_nx(J, S, k0, row0, t, h);
-            float4 v = ld4u_fix(R.x[h], n);
-            if (S.mask) {
-                const float4 mk = ld4u_fix(R.xm[h], n);
-                v.x *= lrelu_grad(mk.x, J.slope); v.y *= lrelu_grad(mk.y, J.slope);
-                v.z *= lrelu_grad(mk.z, J.slope); v.w *= lrelu_grad(mk.w, J.slope);
-            }
-            *(float4*)&Xl[tr * LIN_S + 4 * tc + 64 * h] = v;
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        const int a = tr + 16 * j;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            if (h == 1 && tc >= 4) continue;
-            const float4 v = ld4u_fix(R.w[j][h], lin_nw(J, S, k0, t, j, h));
-            const int c = 4 * tc + 64 * h;
-            if (S.w_cs == 1) {
-                *(float4*)&Wl[a * LIN_S + c] = v;
-            } else {       // a = k, c = m
-                Wl[(c + 0) * LIN_S + a] = v.x;
-                Wl[(c + 1) * LIN_S + a] = v.y;
-                Wl[(c + 2) * LIN_S + a] = v.z;
-                Wl[(c + 3) * LIN_S + a] = v.w;
-            }
-        }
-    }
-}
 
-// acc (+)= W-fragment x X-fragment over the chunk for the wave's NOWN output blocks; no per-lane predicates.
-// The 4 k-values of MFMA step j belong to lane groups g = 0..3 as k = 16 (j >> 2) + 4 g + (j & 3): any
-// assignment is valid as long as both operands use it, and this one makes the four steps j = 4 q .. 4 q + 3 of
-// a lane ONE 16-byte LDS read per operand.  All reads of the chunk are issued before the first MFMA; the MFMAs
-// alternate between two accumulator sets (a single dependent chain leaves the matrix pipe idle).
-template <int NOWN>
-__device__ __forceinline__ void lin_mma(f32x4 (&acc)[2], f32x4 (&acc2)[2], const float* __restrict__ Xs,
-                                        const float* __restrict__ Wl, const int (&mb)[2], int Kc, int l15, int g) {
-    const int nq = (Kc + 15) >> 4;          // 16 k-values per q (zero padded in LDS up to LIN_KC = 80)
-    if (nq == 4) {
-        f32x4 b[4], a[NOWN][4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            b[q] = *(const f32x4*)&Xs[l15 * LIN_S + 16 * q + 4 * g];
-#pragma unroll
-            for (int i = 0; i < NOWN; ++i) a[i][q] = *(const f32x4*)&Wl[(16 * mb[i] + l15) * LIN_S + 16 * q + 4 * g];
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int i = 0; i < NOWN; ++i) {
-                acc[i] = mfma4(a[i][q][0], b[q][0], acc[i]);
-                acc2[i] = mfma4(a[i][q][1], b[q][1], acc2[i]);
-                acc[i] = mfma4(a[i][q][2], b[q][2], acc[i]);
-                acc2[i] = mfma4(a[i][q][3], b[q][3], acc2[i]);
-            }
-        return;
-    }
-    for (int q = 0; q < nq; ++q) {
-        const f32x4 b = *(const f32x4*)&Xs[l15 * LIN_S + 16 * q + 4 * g];
-#pragma unroll
-        for (int i = 0; i < NOWN; ++i) {
-            const f32x4 a = *(const f32x4*)&Wl[(16 * mb[i] + l15) * LIN_S + 16 * q + 4 * g];
-            acc[i] = mfma4(a[0], b[0], acc[i]);
-            acc2[i] = mfma4(a[1], b[1], acc2[i]);
-            acc[i] = mfma4(a[2], b[2], acc[i]);
-            acc2[i] = mfma4(a[3], b[3], acc2[i]);
-        }
-    }
-}
+template <int RT>
+struct LinRegs {
+    f32x4 x[RT], xm[RT], w[5];
+};
+template <int RT>
+struct alignas(16) LinSmem {
+    float Xl[RT][16 * LIN_S];
+    float Wl[80 * LIN_S];
+    float stat[RT][EQD_WAVES][16];
+};
 
 struct LinStep {
-    int s, k0;
+    int s, k0, kc;   // source, first k of the chunk, chunk width (64 = full step, 1..16 = small step)
 };
+__device__ __forceinline__ int lin_chunk(int rem) { return rem >= 64 ? 64 : (rem < 16 ? rem : 16); }
+__device__ __forceinline__ LinStep lin_first(const EqdLinJob& J) {
+    LinStep c = {0, 0, lin_chunk(J.s[0].K)};
+    return c;
+}
 __device__ __forceinline__ LinStep lin_next(const EqdLinJob& J, LinStep c) {
     if (c.s >= J.nsrc) return c;
-    c.k0 += LIN_KC;
+    c.k0 += c.kc;
     if (c.k0 >= J.s[c.s].K) {
         c.s += 1;
         c.k0 = 0;
     }
+    c.kc = c.s < J.nsrc ? lin_chunk(J.s[c.s].K - c.k0) : 0;
     return c;
 }
 
-// One linear job on rows row0 .. row0+15.  src_local[i] >= 0: source i is the LDS tile Lb[src_local[i]]
-// ([16][LIN_S], written by an earlier job of the chain; K <= 80); out_local >= 0: the result is also left
-// in Lb[out_local].  Must be called by all 256 threads of the workgroup.
+// ---- loads of one step into registers (nothing is waited for here) -------------------------------------
+template <int RT>
+__device__ __forceinline__ void lin_load(const EqdLinJob& J, const EqdLinSrc& S, bool local, LinStep c, int row0, int t,
+                                         LinRegs<RT>& R) {
+    const int tr = t >> 4, tc = t & 15;
+    const bool kfast = (S.w_cs == 1);
+    const int M = J.M;
+    if (c.kc == 64) {
+        if (!local) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                int row = row0 + 16 * rt + tr;
+                row = row < J.rows ? row : J.rows - 1;
+                const size_t o = (size_t)row * S.ldx + c.k0 + 4 * tc;
+                R.x[rt] = *(const f4v*)(S.X + o);
+                if (S.mask) R.xm[rt] = *(const f4v*)(S.mask + o);
+            }
+        }
+        if (kfast) {      // thread: weight rows m = tr + 16 j, columns k0 + 4 tc ..
+            const float* __restrict__ Wb = S.W + c.k0 + 4 * tc;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int m = tr + 16 * j;
+                m = m < M ? m : M - 1;
+                R.w[j] = *(const f4v*)(Wb + (size_t)m * S.w_rs);
+            }
+            if (M > 64) {
+                int m = 64 + tr;
+                m = m < M ? m : M - 1;
+                R.w[4] = *(const f4v*)(Wb + (size_t)m * S.w_rs);
+            }
+        } else {          // transposed: thread: k = tr + 16 j, weight rows m = 4 tc .. (tail / beyond M: ld4u)
+            const float* __restrict__ Wb = S.W + (size_t)c.k0 * S.w_cs;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                R.w[j] = ld4u_raw(Wb + (size_t)(tr + 16 * j) * S.w_cs + 4 * tc, M - 4 * tc, S.W);
+            if (M > 64) {                   // rows 64 .. 79: k = t >> 2, m = 64 + 4 (t & 3)
+                const int m = 64 + 4 * (t & 3);
+                R.w[4] = ld4u_raw(Wb + (size_t)(t >> 2) * S.w_cs + m, M - m, S.W);
+            }
+        }
+        return;
+    }
+    // small step: one element per (row, k) / (weight row, k); k clamped into the chunk
+    const int kk = c.k0 + (tc < c.kc ? tc : c.kc - 1);
+    if (!local) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            int row = row0 + 16 * rt + tr;
+            row = row < J.rows ? row : J.rows - 1;
+            const size_t o = (size_t)row * S.ldx + kk;
+            R.x[rt][0] = S.X[o];
+            if (S.mask) R.xm[rt][0] = S.mask[o];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        int m = tr + 16 * j;
+        m = m < M ? m : M - 1;
+        R.w[j][0] = S.W[(size_t)m * S.w_rs + (size_t)kk * S.w_cs];
+    }
+}
+
+// ---- registers -> LDS: Xl[rt][row][k], Wl[m][k] (always k-contiguous), zero padded ------------------------------
+template <int RT>
+__device__ __forceinline__ void lin_store(const EqdLinJob& J, const EqdLinSrc& S, bool local, LinStep c, int t,
+                                          const LinRegs<RT>& R, LinSmem<RT>& sm) {
+    const int tr = t >> 4, tc = t & 15;
+    const bool kfast = (S.w_cs == 1);
+    const int M = J.M;
+    float* __restrict__ Wl = sm.Wl;
+    if (c.kc == 64) {
+        if (!local) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                f32x4 v = R.x[rt];
+                if (S.mask) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] *= lrelu_grad(R.xm[rt][i], J.slope);
+                }
+                *(f32x4*)&sm.Xl[rt][tr * LIN_S + 4 * tc] = v;
+            }
+        }
+        const f32x4 z = f4zero();
+        if (kfast) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *(f32x4*)&Wl[(tr + 16 * j) * LIN_S + 4 * tc] = (tr + 16 * j < M) ? R.w[j] : z;
+            if (M > 64) *(f32x4*)&Wl[(64 + tr) * LIN_S + 4 * tc] = (64 + tr < M) ? R.w[4] : z;
+        } else {       // the vector runs along m: transpose on the way in (4-way bank conflict, 16 short stores)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 v = ld4u_fix(R.w[j], M - 4 * tc);
+                const int k = tr + 16 * j;
+                Wl[(4 * tc + 0) * LIN_S + k] = v.x;
+                Wl[(4 * tc + 1) * LIN_S + k] = v.y;
+                Wl[(4 * tc + 2) * LIN_S + k] = v.z;
+                Wl[(4 * tc + 3) * LIN_S + k] = v.w;
+            }
+            if (M > 64) {
+                const int m = 64 + 4 * (t & 3), k = t >> 2;
+                const float4 v = ld4u_fix(R.w[4], M - m);
+                Wl[(m + 0) * LIN_S + k] = v.x;
+                Wl[(m + 1) * LIN_S + k] = v.y;
+                Wl[(m + 2) * LIN_S + k] = v.z;
+                Wl[(m + 3) * LIN_S + k] = v.w;
+            }
+        }
+        return;
+    }
+    const bool kv = tc < c.kc;
+    if (!local) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            float v = R.x[rt][0];
+            if (S.mask) v *= lrelu_grad(R.xm[rt][0], J.slope);
+            sm.Xl[rt][tr * LIN_S + tc] = kv ? v : 0.f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int m = tr + 16 * j;
+        Wl[m * LIN_S + tc] = (kv && m < M) ? R.w[j][0] : 0.f;
+    }
+}
+
+// acc[rt][i] (+)= W-fragment x X-fragment of the chunk for the wave's NOWN output blocks; no per-lane predicates.
+// The weight fragments are read once for the RT row tiles.  MFMAs alternate between two accumulator sets (a single
+// dependent chain leaves the matrix pipe idle).
+template <int RT, int NOWN, int NQ>
+__device__ __forceinline__ void lin_mma(f32x4 (&acc)[RT][2], f32x4 (&acc2)[RT][2], const float* (&Xs)[RT],
+                                        const float* __restrict__ Wl, const int (&mb)[2], int l15, int g) {
+    f32x4 a[NOWN][NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int i = 0; i < NOWN; ++i) a[i][q] = *(const f32x4*)&Wl[(16 * mb[i] + l15) * LIN_S + 16 * q + 4 * g];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        f32x4 b[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) b[q] = *(const f32x4*)&Xs[rt][l15 * LIN_S + 16 * q + 4 * g];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int i = 0; i < NOWN; ++i) {
+                acc[rt][i] = mfma4(a[i][q][0], b[q][0], acc[rt][i]);
+                acc2[rt][i] = mfma4(a[i][q][1], b[q][1], acc2[rt][i]);
+                acc[rt][i] = mfma4(a[i][q][2], b[q][2], acc[rt][i]);
+                acc2[rt][i] = mfma4(a[i][q][3], b[q][3], acc2[rt][i]);
+            }
+    }
+}
+
+// One linear job on rows row0 .. row0 + 16 RT - 1.  src_local[i] >= 0: source i is the LDS tile Lb[rt][src_local[i]]
+// ([16][LIN_S], written by an earlier job of the chain; K <= 80); out_local >= 0: the result is also left in
+// Lb[rt][out_local].  Must be called by all 256 threads of the workgroup.
+template <int RT>
 __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const int* __restrict__ src_local, int out_local,
-                                            LinSmem& sm, float (*Lb)[16 * LIN_S], int row0) {
+                                            LinSmem<RT>& sm, float (*Lb)[LIN_LOCALS][16 * LIN_S], int row0) {
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const int M = J.M;
     const int mbn = (M + 15) >> 4;
-    const int rowi = row0 + l15;
-    const bool rv = rowi < J.rows;
-    // this wave's output blocks and their epilogue operands (prefetched: latency hides under the GEMM)
+    // this wave's output blocks and their epilogue operands (fetched now: the latency hides under the GEMM)
     const int mbs[2] = {wave, wave + 4};
     const bool own[2] = {wave < mbn, wave + 4 < mbn};
-    float bias[2][4], lg[2][4], lb[2][4], res[2][4];
+    f32x4 bias[2], lg[2], lb[2], res[RT][2];
+    int nf[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
+        const int f0 = 16 * mbs[i] + 4 * g;
+        nf[i] = own[i] ? M - f0 : 0;            // valid features at f0 (<= 0: none)
+        bias[i] = J.bias ? ld4u_raw(J.bias + f0, nf[i], J.bias) : f4zero();
+        lg[i] = J.ln_g ? ld4u_raw(J.ln_g + f0, nf[i], J.ln_g) : f4zero();
+        lb[i] = J.ln_g ? ld4u_raw(J.ln_b + f0, nf[i], J.ln_b) : f4zero();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int f = 16 * mbs[i] + 4 * g + r;
-            const bool ok = own[i] && f < M;
-            bias[i][r] = (ok && J.bias) ? J.bias[f] : 0.f;
-            lg[i][r] = (ok && J.ln_g) ? J.ln_g[f] : 0.f;
-            lb[i][r] = (ok && J.ln_g) ? J.ln_b[f] : 0.f;
-            res[i][r] = (ok && J.R && rv) ? J.R[(size_t)rowi * J.ldr + f] : 0.f;
+        for (int rt = 0; rt < RT; ++rt) {
+            int row = row0 + 16 * rt + l15;
+            row = row < J.rows ? row : J.rows - 1;
+            res[rt][i] = J.R ? ld4u_raw(J.R + (size_t)row * J.ldr + f0, nf[i], J.R) : f4zero();
         }
-    f32x4 acc[2] = {f4zero(), f4zero()}, acc2[2] = {f4zero(), f4zero()};
+    }
+    f32x4 acc[RT][2], acc2[RT][2];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[rt][i] = acc2[rt][i] = f4zero();
 
     // ---- pipelined (source, K chunk) steps: the loads of step i + 2 are issued while step i is multiplied ----
-    LinRegs RA, RB;
+    LinRegs<RT> RA, RB;
     int tr_i = 0;
     (void)tr_i;
     auto is_local = [&](int si) { return src_local && src_local[si] >= 0; };
     // one step: RX holds step `c`; after it has been written to LDS it is refilled with step `n2`
-    auto step = [&](LinStep c, LinRegs& RX, LinStep n2) {
+    auto step = [&](LinStep c, LinRegs<RT>& RX, LinStep n2) {
         const EqdLinSrc& S = J.s[c.s];
         const bool local = is_local(c.s);
-        const int Kc = (S.K - c.k0 < LIN_KC) ? S.K - c.k0 : LIN_KC;
         __syncthreads();                  // previous chunk's fragment reads are done
         LIN_TR(tr_i++);
-        lin_store(J, S, local, c.k0, row0, t, RX, sm.Xl, sm.Wl);
+        lin_store<RT>(J, S, local, c, t, RX, sm);
         LIN_TR(tr_i++);
         __syncthreads();
         LIN_TR(tr_i++);
-        if (n2.s < J.nsrc) lin_load(J, J.s[n2.s], is_local(n2.s), n2.k0, row0, t, RX);
+        if (n2.s < J.nsrc) lin_load<RT>(J, J.s[n2.s], is_local(n2.s), n2, row0, t, RX);
         LIN_TR(tr_i++);
-        const float* __restrict__ Xs = local ? &Lb[src_local[c.s]][c.k0] : sm.Xl;
-        if (own[1])
-            lin_mma<2>(acc, acc2, Xs, sm.Wl, mbs, Kc, l15, g);
-        else if (own[0])
-            lin_mma<1>(acc, acc2, Xs, sm.Wl, mbs, Kc, l15, g);
+        const float* Xs[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) Xs[rt] = local ? &Lb[rt][src_local[c.s]][c.k0] : sm.Xl[rt];
+        if (c.kc == 64) {
+            if (own[1])
+                lin_mma<RT, 2, 4>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+            else if (own[0])
+                lin_mma<RT, 1, 4>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+        } else {
+            if (own[1])
+                lin_mma<RT, 2, 1>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+            else if (own[0])
+                lin_mma<RT, 1, 1>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+        }
         LIN_TR(tr_i++);
     };
-    LinStep cur = {0, 0};
+    LinStep cur = lin_first(J);
     LinStep nx = lin_next(J, cur);
     LIN_TR(tr_i++);
-    lin_load(J, J.s[0], is_local(0), 0, row0, t, RA);
-    if (nx.s < J.nsrc) lin_load(J, J.s[nx.s], is_local(nx.s), nx.k0, row0, t, RB);
+    lin_load<RT>(J, J.s[0], is_local(0), cur, row0, t, RA);
+    if (nx.s < J.nsrc) lin_load<RT>(J, J.s[nx.s], is_local(nx.s), nx, row0, t, RB);
     LIN_TR(tr_i++);
     while (cur.s < J.nsrc) {
         LinStep n2 = lin_next(J, nx);
@@ -265,64 +292,81 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const int* __res
         nx = n2;
     }
 
-    // ---- epilogue in F-layout: feature f = 16 mb + 4 g + r, row = rowi ------------------------------------
+    // ---- epilogue in F-layout: feature f = 16 mb + 4 g + r, row = row0 + 16 rt + l15 -----------------------------
+    float4 bs[2], lgv[2], lbv[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int f = 16 * mbs[i] + 4 * g + r;
-            float v = (acc[i][r] + acc2[i][r]) + bias[i][r];
-            if (J.act) v = lrelu(v, J.slope);
-            acc[i][r] = (own[i] && f < M) ? v : 0.f;
-        }
-    if (J.ln_g) {
-        const float invM = 1.f / (float)M;
-        float sm_ = 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sm_ += acc[i][r];
-        sm_ = group_sum(sm_);
-        if (g == 0) sm.stat[wave][l15] = sm_;
-        __syncthreads();
-        const float mean = (sm.stat[0][l15] + sm.stat[1][l15] + sm.stat[2][l15] + sm.stat[3][l15]) * invM;
-        float q = 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int f = 16 * mbs[i] + 4 * g + r;
-                const float dlt = (own[i] && f < M) ? acc[i][r] - mean : 0.f;
-                q += dlt * dlt;
-            }
-        q = group_sum(q);
-        __syncthreads();
-        if (g == 0) sm.stat[wave][l15] = q;
-        __syncthreads();
-        const float rstd =
-            1.f / sqrtf((sm.stat[0][l15] + sm.stat[1][l15] + sm.stat[2][l15] + sm.stat[3][l15]) * invM + J.ln_eps);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int f = 16 * mbs[i] + 4 * g + r;
-                if (own[i] && f < M) {
-                    const float v = acc[i][r];
-                    if (J.pre_ln && rv) J.pre_ln[(size_t)rowi * J.ld_pre + f] = v;
-                    acc[i][r] = (v - mean) * rstd * lg[i][r] + lb[i][r];
-                }
-            }
+    for (int i = 0; i < 2; ++i) {
+        bs[i] = ld4u_fix(bias[i], nf[i]);
+        lgv[i] = ld4u_fix(lg[i], nf[i]);
+        lbv[i] = ld4u_fix(lb[i], nf[i]);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int rt = 0; rt < RT; ++rt) {
+        const int rowi = row0 + 16 * rt + l15;
+        const bool rv = rowi < J.rows;
+        float v[2][4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int f = 16 * mbs[i] + 4 * g + r;
-            if (own[i] && f < M) {
-                const float v = J.alpha * acc[i][r] + J.beta * res[i][r];
-                if (J.Y && rv) J.Y[(size_t)rowi * J.ldy + f] = v;
-                if (out_local >= 0) Lb[out_local][l15 * LIN_S + f] = v;
+        for (int i = 0; i < 2; ++i) {
+            const float bb[4] = {bs[i].x, bs[i].y, bs[i].z, bs[i].w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float y = (acc[rt][i][r] + acc2[rt][i][r]) + bb[r];
+                if (J.act) y = lrelu(y, J.slope);
+                v[i][r] = r < nf[i] ? y : 0.f;
             }
         }
+        if (J.ln_g) {
+            const float invM = 1.f / (float)M;
+            float s1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s1 += v[i][r];
+            s1 = group_sum(s1);
+            if (g == 0) sm.stat[rt][wave][l15] = s1;
+            __syncthreads();
+            const float mean =
+                (sm.stat[rt][0][l15] + sm.stat[rt][1][l15] + sm.stat[rt][2][l15] + sm.stat[rt][3][l15]) * invM;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float dlt = r < nf[i] ? v[i][r] - mean : 0.f;
+                    q += dlt * dlt;
+                }
+            q = group_sum(q);
+            __syncthreads();
+            if (g == 0) sm.stat[rt][wave][l15] = q;
+            __syncthreads();
+            const float rstd = 1.f / sqrtf((sm.stat[rt][0][l15] + sm.stat[rt][1][l15] + sm.stat[rt][2][l15] +
+                                            sm.stat[rt][3][l15]) * invM + J.ln_eps);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float gg[4] = {lgv[i].x, lgv[i].y, lgv[i].z, lgv[i].w};
+                const float be[4] = {lbv[i].x, lbv[i].y, lbv[i].z, lbv[i].w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r < nf[i]) {
+                        const int f = 16 * mbs[i] + 4 * g + r;
+                        if (J.pre_ln && rv) J.pre_ln[(size_t)rowi * J.ld_pre + f] = v[i][r];
+                        v[i][r] = (v[i][r] - mean) * rstd * gg[r] + be[r];
+                    }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float4 rr = ld4u_fix(res[rt][i], nf[i]);
+            const float rs[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (r < nf[i]) {
+                    const int f = 16 * mbs[i] + 4 * g + r;
+                    const float y = J.alpha * v[i][r] + J.beta * rs[r];
+                    if (J.Y && rv) J.Y[(size_t)rowi * J.ldy + f] = y;
+                    if (out_local >= 0) Lb[rt][out_local][l15 * LIN_S + f] = y;
+                }
+        }
+    }
     LIN_TR(tr_i++);
 }

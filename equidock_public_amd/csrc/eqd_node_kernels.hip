@@ -10,6 +10,7 @@
 
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 // ------------------------------------------------------------------------------------------
@@ -44,14 +45,26 @@ struct LinJobsArg {
     EqdLinJob j[LIN_MAXJOBS];
 };
 
-__global__ __launch_bounds__(EQD_BLOCK) void k_linear(LinJobsArg jobs) {
-    __shared__ LinSmem sm;
+template <int RT>
+__global__ __launch_bounds__(EQD_BLOCK, 2) void k_linear(LinJobsArg jobs) {
+    __shared__ LinSmem<RT> sm;
     const EqdLinJob& J = jobs.j[blockIdx.y];
-    const int row0 = (int)blockIdx.x * 16;
+    const int row0 = (int)blockIdx.x * 16 * RT;
     if (row0 >= J.rows) return;      // uniform for the whole workgroup
     EQD_TR_WG();
-    linear_tile(J, nullptr, -1, sm, nullptr, row0);
+    linear_tile<RT>(J, nullptr, -1, sm, nullptr, row0);
     EQD_TR_WG_END();
+}
+// 16-row tiles per workgroup: one at DB5-sized batches (3 200 rows: latency matters, spread over the CUs), two
+// once there are more tiles than the chip holds at once (the step's weights are then staged once per 32 rows)
+int eqd_row_tiles(int rows) {
+    const char* f = getenv("EQD_ROW_TILES");      // tests force the 2-tile kernels on small inputs
+    if (f && (f[0] == '1' || f[0] == '2') && f[1] == 0) return f[0] - '0';
+    return rows > 16 * 1024 ? 2 : 1;
+}
+int eqd_rowchain_blocks(int rows) {
+    const int per = 16 * eqd_row_tiles(rows);
+    return (rows + per - 1) / per;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -60,7 +73,8 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_linear(LinJobsArg jobs) {
 // (7 jobs, was 3 launches) in the forward, and  node_mlp.4^T -> LeakyReLU/LayerNorm backward ->
 // d aggr_msg / d aggr_cross / d h0  (5 jobs, was 3 launches + a reduction) in the backward.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void chain_lnbwd(const EqdChainJob& C, float (*Lb)[16 * LIN_S], float (*red)[256],
+template <int RT>
+__device__ __forceinline__ void chain_lnbwd(const EqdChainJob& C, float (*Lb)[LIN_LOCALS][16 * LIN_S], float (*red)[256],
                                             int row0) {
     // y_act = LeakyReLU(z) (saved by the forward) is lin.s[0].X; the incoming gradient is the LDS tile
     // src_local[0]; dz goes to LDS tile out_local and to lin.Y; per-workgroup (d gamma | d beta) to aux.
@@ -71,37 +85,51 @@ __device__ __forceinline__ void chain_lnbwd(const EqdChainJob& C, float (*Lb)[16
     const bool v0 = f0 < d, v1 = f1 < d;
     const float g0 = v0 ? J.ln_g[f0] : 0.f, g1 = v1 ? J.ln_g[f1] : 0.f;
     const float invd = 1.f / (float)d;
-    const float* __restrict__ din = Lb[C.src_local[0]];
-    float* __restrict__ dout = Lb[C.out_local];
     float dg0 = 0.f, dg1 = 0.f, db0 = 0.f, db1 = 0.f;
+    // all y_act rows of the wave first (unpredicated, clamped), then the arithmetic
+    float y0s[RT][4], y1s[RT][4];
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-        const int lr = 4 * wave + rr;
-        const int row = row0 + lr;
-        const bool rv = row < J.rows;
-        const size_t o = (size_t)(rv ? row : 0) * J.s[0].ldx;
-        const float y0 = (rv && v0) ? J.s[0].X[o + f0] : 0.f, y1 = (rv && v1) ? J.s[0].X[o + f1] : 0.f;
-        const float o0 = (rv && v0) ? din[lr * LIN_S + f0] : 0.f, o1 = (rv && v1) ? din[lr * LIN_S + f1] : 0.f;
-        const float mean = wave_sum(y0 + y1) * invd;
-        const float c0 = v0 ? y0 - mean : 0.f, c1 = v1 ? y1 - mean : 0.f;
-        const float rstd = 1.f / sqrtf(wave_sum(c0 * c0 + c1 * c1) * invd + J.ln_eps);
-        const float xh0 = c0 * rstd, xh1 = c1 * rstd;
-        const float dx0 = o0 * g0, dx1 = o1 * g1;
-        const float s1 = wave_sum(dx0 + dx1) * invd;
-        const float s2 = wave_sum(dx0 * xh0 + dx1 * xh1) * invd;
-        const float z0 = rstd * (dx0 - s1 - xh0 * s2) * lrelu_grad(y0, J.slope);
-        const float z1 = rstd * (dx1 - s1 - xh1 * s2) * lrelu_grad(y1, J.slope);
-        if (v0) dout[lr * LIN_S + f0] = rv ? z0 : 0.f;
-        if (v1) dout[lr * LIN_S + f1] = rv ? z1 : 0.f;
-        if (rv && J.Y) {
-            if (v0) J.Y[(size_t)row * J.ldy + f0] = z0;
-            if (v1) J.Y[(size_t)row * J.ldy + f1] = z1;
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            int row = row0 + 16 * rt + 4 * wave + rr;
+            row = row < J.rows ? row : J.rows - 1;
+            const size_t o = (size_t)row * J.s[0].ldx;
+            y0s[rt][rr] = J.s[0].X[o + (v0 ? f0 : 0)];
+            y1s[rt][rr] = J.s[0].X[o + (v1 ? f1 : 0)];
         }
-        if (rv) {
-            dg0 += o0 * xh0;
-            dg1 += o1 * xh1;
-            db0 += o0;
-            db1 += o1;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const float* __restrict__ din = Lb[rt][C.src_local[0]];
+        float* __restrict__ dout = Lb[rt][C.out_local];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int lr = 4 * wave + rr;
+            const int row = row0 + 16 * rt + lr;
+            const bool rv = row < J.rows;
+            const float y0 = (rv && v0) ? y0s[rt][rr] : 0.f, y1 = (rv && v1) ? y1s[rt][rr] : 0.f;
+            const float o0 = (rv && v0) ? din[lr * LIN_S + f0] : 0.f, o1 = (rv && v1) ? din[lr * LIN_S + f1] : 0.f;
+            const float mean = wave_sum(y0 + y1) * invd;
+            const float c0 = v0 ? y0 - mean : 0.f, c1 = v1 ? y1 - mean : 0.f;
+            const float rstd = 1.f / sqrtf(wave_sum(c0 * c0 + c1 * c1) * invd + J.ln_eps);
+            const float xh0 = c0 * rstd, xh1 = c1 * rstd;
+            const float dx0 = o0 * g0, dx1 = o1 * g1;
+            const float s1 = wave_sum(dx0 + dx1) * invd;
+            const float s2 = wave_sum(dx0 * xh0 + dx1 * xh1) * invd;
+            const float z0 = rstd * (dx0 - s1 - xh0 * s2) * lrelu_grad(y0, J.slope);
+            const float z1 = rstd * (dx1 - s1 - xh1 * s2) * lrelu_grad(y1, J.slope);
+            if (v0) dout[lr * LIN_S + f0] = rv ? z0 : 0.f;
+            if (v1) dout[lr * LIN_S + f1] = rv ? z1 : 0.f;
+            if (rv && J.Y) {
+                if (v0) J.Y[(size_t)row * J.ldy + f0] = z0;
+                if (v1) J.Y[(size_t)row * J.ldy + f1] = z1;
+            }
+            if (rv) {
+                dg0 += o0 * xh0;
+                dg1 += o1 * xh1;
+                db0 += o0;
+                db1 += o1;
+            }
         }
     }
     red[wave][lane] = dg0;
@@ -112,19 +140,20 @@ __device__ __forceinline__ void chain_lnbwd(const EqdChainJob& C, float (*Lb)[16
     C.aux[(size_t)blockIdx.x * 256 + t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
 }
 
-__global__ __launch_bounds__(EQD_BLOCK) void k_rowchain(EqdChainArg A) {
-    __shared__ LinSmem sm;
-    __shared__ __attribute__((aligned(16))) float Lb[LIN_LOCALS][16 * LIN_S];
+template <int RT>
+__global__ __launch_bounds__(EQD_BLOCK, 2) void k_rowchain(EqdChainArg A) {
+    __shared__ LinSmem<RT> sm;
+    __shared__ __attribute__((aligned(16))) float Lb[RT][LIN_LOCALS][16 * LIN_S];
     __shared__ float red[EQD_WAVES][256];
-    const int row0 = (int)blockIdx.x * 16;
-    for (int i = threadIdx.x; i < LIN_LOCALS * 16 * LIN_S; i += EQD_BLOCK) (&Lb[0][0])[i] = 0.f;
+    const int row0 = (int)blockIdx.x * 16 * RT;
+    for (int i = threadIdx.x; i < RT * LIN_LOCALS * 16 * LIN_S; i += EQD_BLOCK) (&Lb[0][0][0])[i] = 0.f;
     __syncthreads();
     for (int jj = 0; jj < A.njobs; ++jj) {
         const EqdChainJob& C = A.j[jj];
         if (C.type == 0)
-            linear_tile(C.lin, C.src_local, C.out_local, sm, Lb, row0);
+            linear_tile<RT>(C.lin, C.src_local, C.out_local, sm, Lb, row0);
         else
-            chain_lnbwd(C, Lb, red, row0);
+            chain_lnbwd<RT>(C, Lb, red, row0);
         __syncthreads();
     }
 }
@@ -168,13 +197,21 @@ int eqd_launch_rowchain(const EqdChainJob* jobs, int njobs, int rows, hipStream_
         if (jobs[i].type == 0)
             if (int e = lin_check_sources(J)) return e;
         for (int s = 0; s < J.nsrc; ++s)
-            if (jobs[i].src_local[s] >= 0 && J.s[s].K > LIN_KC) {
-                eqd_set_error("eqd_launch_rowchain: LDS-resident source wider than %d", LIN_KC);
+            if (jobs[i].src_local[s] >= 0 && (J.s[s].K > 80 || jobs[i].src_local[s] >= LIN_LOCALS)) {
+                eqd_set_error("eqd_launch_rowchain: LDS-resident source wider than %d or tile index >= %d", 80, LIN_LOCALS);
                 return EQD_ERR_SHAPE;
             }
     }
     arg.njobs = njobs;
-    hipLaunchKernelGGL(k_rowchain, dim3((rows + 15) / 16), dim3(EQD_BLOCK), 0, st, arg);
+    for (int i = 0; i < njobs; ++i)
+        if (jobs[i].out_local >= LIN_LOCALS) {
+            eqd_set_error("eqd_launch_rowchain: LDS tile index %d >= %d", jobs[i].out_local, LIN_LOCALS);
+            return EQD_ERR_SHAPE;
+        }
+    if (eqd_row_tiles(rows) == 2)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rowchain<2>), dim3(eqd_rowchain_blocks(rows)), dim3(EQD_BLOCK), 0, st, arg);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rowchain<1>), dim3(eqd_rowchain_blocks(rows)), dim3(EQD_BLOCK), 0, st, arg);
     return eqd_check_launch("k_rowchain");
 }
 
@@ -205,8 +242,11 @@ extern "C" int eqd_linear(const EqdLinJob* jobs, int njobs, void* stream) {
             if (J.rows > maxrows) maxrows = J.rows;
         }
         if (maxrows == 0) continue;
-        dim3 grid((maxrows + 15) / 16, n);
-        hipLaunchKernelGGL(k_linear, grid, dim3(EQD_BLOCK), 0, st, arg);
+        dim3 grid(eqd_rowchain_blocks(maxrows), n);
+        if (eqd_row_tiles(maxrows) == 2)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear<2>), grid, dim3(EQD_BLOCK), 0, st, arg);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear<1>), grid, dim3(EQD_BLOCK), 0, st, arg);
         int rc = eqd_check_launch("k_linear");
         if (rc) return rc;
     }

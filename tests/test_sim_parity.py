@@ -51,6 +51,14 @@ def test_model_vs_golden(name):
     pc.check_model_case(DEV, name)
 
 
+@pytest.mark.parametrize('name', ['D_degraded3'])
+def test_model_two_row_tiles(name, monkeypatch):
+    """the 32-rows-per-workgroup variants of the row kernels (picked above 16 384 rows) on a small golden case"""
+    monkeypatch.setenv('EQD_ROW_TILES', '2')
+    pc.check_linear(DEV)
+    pc.check_model_case(DEV, name)
+
+
 def test_flat_grads():
     pc.check_flat_grads_equal_autograd(DEV)
 
