@@ -177,7 +177,7 @@ def main():
     ap.add_argument('--workload', default='B', choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
-    ap.add_argument('--graph', action='store_true', help='replay a captured hipGraph of the step instead of launching eagerly (measured slower on ROCm 7.2: 2.87 vs 2.67 ms/step)')
+    ap.add_argument('--graph', action='store_true', help='replay a captured hipGraph of the whole step (zero-grad, forward, loss, backward) instead of launching eagerly; single GPU only; measured 1.6 %% faster than eager at workload B (1.98 vs 2.01 ms/step)')
     a = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))

@@ -542,8 +542,17 @@ __global__ __launch_bounds__(1024) void k_reduce_segments(EqdRedArg A) {
     if (i < n) {
         for (int j = 0; j < len; ++j) {
             const EqdRedSeg& S = A.s[first + j];
-#pragma unroll 4
-            for (int p = pl; p < S.nparts; p += 16) acc += S.partial[(size_t)p * S.pstride + i];
+            // 16 partials per trip and lane, loads unpredicated (clamped) so that they are all in flight at once
+            for (int p0 = pl; p0 < S.nparts; p0 += 256) {
+                float v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int p = p0 + 16 * u;
+                    v[u] = S.partial[(size_t)(p < S.nparts ? p : 0) * S.pstride + i];
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc += p0 + 16 * u < S.nparts ? v[u] : 0.f;
+            }
         }
     }
     red[pl][c] = acc;
