@@ -37,6 +37,7 @@ WORKLOADS = {
     'E': (4, (2000, 2000), 8, False, 0.75, 'E: stress, 4 pairs x (2000,2000) residues, k=10, 8-layer IEGMN, fp32'),
 }
 PEAK_FP32_TFLOPS = 157.3   # MI355X fp32 vector = fp32-input MFMA peak (MI355X_MICROARCH.md)
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA (MI355X_MICROARCH.md; no sparsity)
 PEAK_HBM_GBS = 8000.0      # HBM3E spec
 EDGE_FWD_FLOP_PER_EDGE = 38272          # SURVEY.md section 8d, layers >= 1, model as written
 EDGE_FWD_BYTES = lambda n, e: n * 540 + e * 112   # noqa: E731  SURVEY.md section 8d (fp32)
@@ -63,7 +64,7 @@ def time_kernel(fn, iters, stream_sync):
     return sum(ts) / len(ts) * 1e-3   # seconds per launch
 
 
-def edge_kernel_rooflines(net, packed, dev, workload='B'):
+def edge_kernel_rooflines(net, packed, dev, workload='B', bf16=False):
     """Launch the edge-message kernels standalone (layer-1 weights, the workload's graph) on torch's
     current stream and time them with HIP events on that stream."""
     from equidock_public_amd import _lib
@@ -83,6 +84,7 @@ def edge_kernel_rooflines(net, packed, dev, workload='B'):
     ep.Wc1, ep.bc1 = lay.coors_mlp[0].weight.data_ptr(), lay.coors_mlp[0].bias.data_ptr()
     ep.wc2, ep.bc2 = lay.coors_mlp[4].weight.data_ptr(), lay.coors_mlp[4].bias.data_ptr()
     ep.slope, ep.ln_eps, ep.eta, ep.use_dist, ep.use_he = 0.01, 1e-5, 0.0, 1, 1
+    ep.bf16 = int(bf16)
     st = _lib.stream_ptr(dev)
     sync = lambda: torch.cuda.current_stream(dev).synchronize()  # noqa: E731
 
@@ -120,19 +122,27 @@ def edge_kernel_rooflines(net, packed, dev, workload='B'):
     flop_f = EDGE_FWD_FLOP_PER_EDGE * E
     byte_f = EDGE_FWD_BYTES(N, E)
     out = {}
+    if bf16:
+        byte_f = N * 540 + E * (27 * 2 + 4)       # he rows in bf16
+    peak_tf = PEAK_BF16_TFLOPS if bf16 else PEAK_FP32_TFLOPS
     for name, t, mult in (('k_edge_fwd', t_fwd, 1), ('k_edge_bwd', t_bwd, 2)):
         tf = flop_f * mult / t / 1e12
         gb = byte_f * mult / t / 1e9
-        out[name] = {"bound": "mfma", "achieved": round(tf, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(tf / PEAK_FP32_TFLOPS, 4), "traffic": None,
+        out[name] = {"bound": "mfma", "achieved": round(tf, 3), "peak": peak_tf, "unit": "TFLOP/s",
+                     "frac": round(tf / peak_tf, 4), "traffic": None,
                      "avg_launch_us": round(t * 1e6, 2), "algorithmic_flops_per_launch": flop_f * mult,
                      "algorithmic_bytes_per_launch": byte_f * mult,
                      "hbm_algorithmic_GBps": round(gb, 1), "hbm_frac_algorithmic": round(gb / PEAK_HBM_GBS, 4)}
+        if bf16 and gb / PEAK_HBM_GBS > tf / peak_tf:
+            # with the GEMMs at the bf16 MFMA rate the HBM side is the closer roof of the two
+            out[name].update({"bound": "hbm", "achieved": round(gb, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                              "frac": round(gb / PEAK_HBM_GBS, 4), "mfma_TFLOPs": round(tf, 3),
+                              "mfma_frac_bf16_peak": round(tf / peak_tf, 4)})
     out['k_edge_bwd']['whole_bwd_op_us'] = round(t_bwd_op * 1e6, 2)   # + weight-grad GEMMs, reductions, CSC gather
     # HBM bytes per launch from the committed PMC passes (profiles/r01_traffic.json; counters cannot be read
     # from inside the process): (2 * FETCH_SIZE + WRITE_SIZE) KB, see the file's comment for the correction
     try:
-        tr = json.load(open(os.path.join(ROOT, 'profiles', 'r01_traffic.json'))).get(workload, {})
+        tr = {} if bf16 else json.load(open(os.path.join(ROOT, 'profiles', 'r01_traffic.json'))).get(workload, {})
         for k, v in tr.items():
             if k in out:
                 out[k]['traffic'] = int((2 * v['FETCH_SIZE_KB'] + v['WRITE_SIZE_KB']) * 1024)
@@ -175,6 +185,8 @@ def main():
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--workload', default='B', choices=sorted(WORKLOADS))
+    ap.add_argument('--dtype', default='f32', choices=('f32', 'bf16'),
+                    help='bf16: edge-message kernels in bf16 mode (he rows + GEMM inputs bf16, fp32 accumulate); the rest of the path stays fp32')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--graph', action='store_true', help='replay a captured hipGraph of the whole step (zero-grad, forward, loss, backward) instead of launching eagerly; single GPU only; measured 1.6 %% faster than eager at workload B (1.98 vs 2.01 ms/step)')
@@ -197,6 +209,8 @@ def main():
 
     ppg, (nl, nr), L, shared, skh, desc = WORKLOADS[a.workload]
     args_model = port.default_args(iegmn_n_lays=L, shared_layers=shared, skip_weight_h=skh, device=dev)
+    if a.dtype == 'bf16':
+        args_model['hip_storage_dtype'] = 'bf16'
     sd = port.init_state_dict(args_model, seed=0)
     net = model.Rigid_Body_Docking_Net(args_model).to(dev)
     net.load_state_dict(sd)
@@ -273,7 +287,9 @@ def main():
             "metric": "protein-pairs/sec (fwd+bwd) per IEGMN stack", "value": round(total_pairs / dt, 2),
             "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": "f32" if a.dtype == 'f32' else "bf16 edge-message GEMMs (fp32 accumulate) + f32 elsewhere",
+            "data": "synthetic",
             "config": {"workload": desc, "pairs_per_gpu": ppg, "nodes_per_gpu": packed.n_nodes,
                        "edges_per_gpu": packed.n_edges, "layers": L, "parallelism": f"dp{world}",
                        "weights": "PyTorch default init (seed 0), ROT key/query x40 (SURVEY.md section 8c)",
@@ -281,7 +297,7 @@ def main():
                        "host_enqueue_ms_per_step": round(host_dt / a.steps * 1e3, 4), "launch_mode": graph_mode},
         }
         if not a.no_roofline:
-            rl = edge_kernel_rooflines(net, packed, dev, a.workload)
+            rl = edge_kernel_rooflines(net, packed, dev, a.workload, bf16=(a.dtype == 'bf16'))
             dom = max(rl, key=lambda k: rl[k]["avg_launch_us"])
             out["roofline"] = dict(rl[dom], kernel=dom)
             out["roofline_all"] = rl

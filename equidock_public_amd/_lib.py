@@ -27,7 +27,7 @@ class EqdGraph(C.Structure):
                 ('seg_off', C.c_void_p), ('src', C.c_void_p), ('dst', C.c_void_p), ('rowptr', C.c_void_p),
                 ('csc_ptr', C.c_void_p), ('csc_eid', C.c_void_p), ('tile_node', C.c_void_p),
                 ('att_items', C.c_void_p), ('res_id', C.c_void_p), ('mu_r_norm', C.c_void_p), ('he', C.c_void_p),
-                ('x0', C.c_void_p)]
+                ('x0', C.c_void_p), ('he_bf16', C.c_void_p)]
 
 
 class EqdModelDesc(C.Structure):
@@ -35,7 +35,7 @@ class EqdModelDesc(C.Structure):
                 ('use_mean_node_features', C.c_int32), ('edge_feats', C.c_int32), ('n_heads', C.c_int32),
                 ('cross_msgs', C.c_int32), ('use_dist_in_layers', C.c_int32), ('use_edge_features', C.c_int32),
                 ('skip_weight_h', C.c_float), ('x_connection_init', C.c_float), ('lrelu_slope', C.c_float),
-                ('ln_eps', C.c_float), ('svd_seed', C.c_int32)]
+                ('ln_eps', C.c_float), ('svd_seed', C.c_int32), ('storage_bf16', C.c_int32)]
 
 
 class EqdLinSrc(C.Structure):
@@ -61,7 +61,8 @@ class EqdEdgeParams(C.Structure):
     _fields_ = [('W1', C.c_void_p), ('ldw1', C.c_int32), ('d_in', C.c_int32), ('ln_g', C.c_void_p),
                 ('ln_b', C.c_void_p), ('W2', C.c_void_p), ('b2', C.c_void_p), ('Wc1', C.c_void_p),
                 ('bc1', C.c_void_p), ('wc2', C.c_void_p), ('bc2', C.c_void_p), ('slope', C.c_float),
-                ('ln_eps', C.c_float), ('eta', C.c_float), ('use_dist', C.c_int32), ('use_he', C.c_int32)]
+                ('ln_eps', C.c_float), ('eta', C.c_float), ('use_dist', C.c_int32), ('use_he', C.c_int32),
+                ('bf16', C.c_int32)]
 
 
 class EqdEdgeGrads(C.Structure):
@@ -114,8 +115,8 @@ def load_library():
             "There is no CPU fallback for the IEGMN hot path.")
     lib = C.CDLL(LIB_PATH)
     _declare(lib)
-    if lib.eqd_abi_version() != 1:
-        raise EquidockHipError(f"ABI version mismatch: library {lib.eqd_abi_version()} != 1")
+    if lib.eqd_abi_version() != 2:
+        raise EquidockHipError(f"ABI version mismatch: library {lib.eqd_abi_version()} != 2")
     _lib, _is_sim = lib, bool(lib.eqd_is_simulator())
     return _lib
 
@@ -190,7 +191,7 @@ def graph_struct(p):
     g.n_pairs, g.n_lig, g.n_rec, g.n_nodes = p.n_pairs, p.n_lig, p.n_rec, p.n_nodes
     g.n_edges, g.n_tiles, g.n_att_items, g.max_seg = p.n_edges, p.n_tiles, p.n_att_items, p.max_seg
     for name in ('seg_off', 'src', 'dst', 'rowptr', 'csc_ptr', 'csc_eid', 'tile_node', 'att_items', 'res_id',
-                 'mu_r_norm', 'he', 'x0'):
+                 'mu_r_norm', 'he', 'x0', 'he_bf16'):
         t = getattr(p, name)
         require_device(t, 'graph.' + name)
         setattr(g, name, t.data_ptr())

@@ -81,6 +81,26 @@ __device__ __forceinline__ float4 ld4u_fix(f32x4 v, int n) {
     r.w = n > 3 ? v[3] : 0.f;
     return r;
 }
+// ---- bf16 MFMA path (edge-message kernels, storage_bf16 mode) ---------------------------------------------------
+// v_mfma_f32_16x16x16_bf16: lane (i = lane & 15, g = lane >> 4) supplies A[i][4g..4g+3] and B[4g..4g+3][i] as 4 bf16
+// and receives D[4g + r][i] - the same D layout as the fp32 instruction, so with features on the M axis an output
+// tile (4 fp32 per 16-feature block and lane) packed to bf16 IS the B operand of the next GEMM's k-chunk.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned short f2bf(float f) {      // round to nearest even (finite inputs)
+    unsigned u = __builtin_bit_cast(unsigned, f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
+__device__ __forceinline__ s16x4 pack_bf4(float a, float b, float c, float d) {
+    s16x4 r;
+    r[0] = (short)f2bf(a); r[1] = (short)f2bf(b); r[2] = (short)f2bf(c); r[3] = (short)f2bf(d);
+    return r;
+}
+__device__ __forceinline__ f32x4 mfma_bf(s16x4 a, s16x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+
 __device__ __forceinline__ f32x4 f4zero() {
     f32x4 z = {0.f, 0.f, 0.f, 0.f};
     return z;

@@ -188,7 +188,7 @@ EqdEdgeParams edge_params(const Dims& D, const EqdModelDesc* m, int l, const flo
     e.ln_g = p[P_LNG]; e.ln_b = p[P_LNB]; e.W2 = p[P_W2]; e.b2 = p[P_B2];
     e.Wc1 = p[P_WC1]; e.bc1 = p[P_BC1]; e.wc2 = p[P_WC2]; e.bc2 = p[P_BC2];
     e.slope = m->lrelu_slope; e.ln_eps = m->ln_eps; e.eta = m->x_connection_init;
-    e.use_dist = m->use_dist_in_layers; e.use_he = m->use_edge_features;
+    e.use_dist = m->use_dist_in_layers; e.use_he = m->use_edge_features; e.bf16 = m->storage_bf16;
     return e;
 }
 

@@ -363,6 +363,283 @@ __device__ __forceinline__ void edge_tile_forward(const EqdGraph& G, const EqdEd
     EQD_TR(9);
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16 mode (EqdEdgeParams.bf16): he is read as bf16 rows of 32 (27 used, 64 B per edge, EqdGraph.he_bf16), the
+// staged weights and the GEMM inputs (features, LayerNorm output, messages) are rounded to bf16, every product is
+// accumulated in fp32 by v_mfma_f32_16x16x16_bf16 (16x the fp32 MFMA rate).  P/Q, coordinates, RBF arguments,
+// LayerNorm statistics, biases, the coordinate head and all outputs stay fp32.
+// ---------------------------------------------------------------------------------------------
+#define WSB 72   /* bf16 row stride of the staged weights: 36 dwords = 4 mod 32 -> b64 fragment reads at the LDS rate */
+#define FSB 72   /* bf16 row stride of the per-wave [edges][48] feature tile */
+template <int NW, int TILE_FLOATS>
+struct alignas(16) EdgeSmemBf {
+    unsigned short w1[64 * WSB];    // W1[:, 2 d_in:] : 42 columns + 6 zeros
+    unsigned short w2[64 * WSB];
+    unsigned short wc1[64 * WSB];
+    float vec[VEC_N];
+    float tile[NW][TILE_FLOATS];    // fp32 message tile; the bf16 feature tile aliases its first bytes
+};
+// backward: additionally the transposed 64 x 64 matrices (data-gradient chains) and the RBF columns of W1 transposed
+template <int NW, int TILE_FLOATS>
+struct alignas(16) EdgeSmemBfBwd {
+    unsigned short w1[64 * WSB];
+    unsigned short w2[64 * WSB];
+    unsigned short wc1[64 * WSB];
+    unsigned short w2T[64 * WSB];
+    unsigned short wc1T[64 * WSB];
+    unsigned short w1rT[16 * WSB];  // [k = RBF index (15 used)][m]
+    float vec[VEC_N];
+    float tile[NW][TILE_FLOATS];
+};
+template <int NW, bool WITH_T, class SM>
+__device__ __forceinline__ void edge_stage_weights_bf(SM& sm, const EqdEdgeParams& P) {
+    constexpr int NT = 64 * NW;
+    constexpr int N1 = (64 * 12 + NT - 1) / NT, N2 = 1024 / NT;
+    const int t = threadIdx.x;
+    const int koff = 2 * P.d_in;
+    if constexpr (WITH_T) {
+        if (t < 64) sm.w1rT[15 * WSB + t] = 0;
+    }
+    {
+        f32x4 v[N1];
+#pragma unroll
+        for (int j = 0; j < N1; ++j) {       // 64 rows x 12 four-column segments (42 valid columns, rest zero)
+            const int i = t + j * NT;
+            const int r = i / 12, c = 4 * (i - r * 12);
+            v[j] = ld4u_raw(P.W1 + (size_t)(i < 64 * 12 ? r : 0) * P.ldw1 + koff + c, i < 64 * 12 ? 42 - c : 0, P.W1);
+        }
+#pragma unroll
+        for (int j = 0; j < N1; ++j) {
+            const int i = t + j * NT;
+            const int r = i / 12, c = 4 * (i - r * 12);
+            if (i < 64 * 12) {
+                const float4 f = ld4u_fix(v[j], 42 - c);
+                const s16x4 h = pack_bf4(f.x, f.y, f.z, f.w);
+                *(s16x4*)&sm.w1[r * WSB + c] = h;
+                if constexpr (WITH_T) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (c + u >= 27 && c + u < 42) sm.w1rT[(c + u - 27) * WSB + r] = (unsigned short)h[u];
+                }
+            }
+        }
+    }
+    {
+        float4 a[N2], b[N2];
+#pragma unroll
+        for (int j = 0; j < N2; ++j) {       // 64 x 64 floats = 1024 float4
+            const int i = t + j * NT;
+            a[j] = ((const float4*)P.W2)[i];
+            b[j] = ((const float4*)P.Wc1)[i];
+        }
+#pragma unroll
+        for (int j = 0; j < N2; ++j) {
+            const int i = t + j * NT;
+            const int r = i >> 4, c = (i & 15) * 4;
+            const s16x4 ha = pack_bf4(a[j].x, a[j].y, a[j].z, a[j].w), hb = pack_bf4(b[j].x, b[j].y, b[j].z, b[j].w);
+            *(s16x4*)&sm.w2[r * WSB + c] = ha;
+            *(s16x4*)&sm.wc1[r * WSB + c] = hb;
+            if constexpr (WITH_T) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    sm.w2T[(c + u) * WSB + r] = (unsigned short)ha[u];
+                    sm.wc1T[(c + u) * WSB + r] = (unsigned short)hb[u];
+                }
+            }
+        }
+    }
+    if (t < 64) {
+        sm.vec[VEC_LNG + t] = P.ln_g[t];
+        sm.vec[VEC_LNB + t] = P.ln_b[t];
+        sm.vec[VEC_B2 + t] = P.b2[t];
+        sm.vec[VEC_BC1 + t] = P.bc1[t];
+        sm.vec[VEC_WC2 + t] = P.wc2[t];
+    }
+    if (t == 0) sm.vec[VEC_BC2] = P.bc2[0];
+    __syncthreads();
+}
+
+// out[mb][nb] += W[16 mb .., :] in[.., nb] over a 64-wide contraction: `in` is the previous tile (fp32 registers, optionally
+// through the LayerNorm affine), packed to bf16 per 16-feature block - it IS the B operand of k-chunk mbi.
+template <bool AFF, int NB>
+__device__ __forceinline__ void chain64_bf(f32x4 (&out)[4][NB], const f32x4 (&in)[4][NB], const unsigned short* __restrict__ w,
+                                           const float* __restrict__ ga, const float* __restrict__ be, int l15, int g) {
+#pragma unroll
+    for (int mbi = 0; mbi < 4; ++mbi) {
+        s16x4 b[NB];
+        float gg[4] = {1.f, 1.f, 1.f, 1.f}, bb[4] = {0.f, 0.f, 0.f, 0.f};
+        if (AFF) {
+            const float4 gv = *(const float4*)&ga[16 * mbi + 4 * g];
+            const float4 bv = *(const float4*)&be[16 * mbi + 4 * g];
+            gg[0] = gv.x; gg[1] = gv.y; gg[2] = gv.z; gg[3] = gv.w;
+            bb[0] = bv.x; bb[1] = bv.y; bb[2] = bv.z; bb[3] = bv.w;
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+            b[nb] = pack_bf4(in[mbi][nb][0] * gg[0] + bb[0], in[mbi][nb][1] * gg[1] + bb[1], in[mbi][nb][2] * gg[2] + bb[2],
+                             in[mbi][nb][3] * gg[3] + bb[3]);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const s16x4 a = *(const s16x4*)&w[(16 * mb + l15) * WSB + 16 * mbi + 4 * g];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) out[mb][nb] = mfma_bf(a, b[nb], out[mb][nb]);
+        }
+    }
+}
+
+// bf16 counterpart of edge_tile_forward (same outputs, same EdgeTileState)
+template <int NB>
+__device__ __forceinline__ void edge_tile_forward_bf(const EqdGraph& G, const EqdEdgeParams& P,
+                                                     const unsigned short* __restrict__ w1,
+                                                     const unsigned short* __restrict__ w2,
+                                                     const unsigned short* __restrict__ wc1,
+                                                     const float* __restrict__ vec, float* __restrict__ tile,
+                                                     const float* __restrict__ Pn, const float* __restrict__ Qn,
+                                                     const float* __restrict__ x, int lane, EdgeTileState<NB>& S,
+                                                     f32x4 (&xh)[4][NB], f32x4 (&m)[4][NB], f32x4 (&ch)[4][NB]) {
+    const int l15 = lane & 15, g = lane >> 4;
+    unsigned short* __restrict__ ft = (unsigned short*)tile;
+    // ---- he rows: 64 B per edge, four 16-byte parts; lane -> (edge, part), all loads up front, unpredicated ------
+    f32x4 hv[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int i4 = lane + 64 * j, e = i4 >> 2, part = i4 & 3;
+        hv[j] = *(const f32x4*)(G.he_bf16 + ((size_t)S.e0 + (e < S.ne ? e : 0)) * 32 + 8 * part);
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int el = 16 * nb + l15;
+        S.ev[nb] = el < S.ne;
+        const int ei = S.e0 + (S.ev[nb] ? el : 0);
+        S.src[nb] = G.src[ei];
+        S.dst[nb] = G.dst[ei];
+    }
+    float xs[NB][3], xd[NB][3];
+    float4 pv[NB][4], qv[NB][4];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            xs[nb][c] = x[(size_t)S.src[nb] * 3 + c];
+            xd[nb][c] = x[(size_t)S.dst[nb] * 3 + c];
+        }
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            pv[nb][mb] = *(const float4*)&Pn[(size_t)S.src[nb] * 64 + 16 * mb + 4 * g];
+            qv[nb][mb] = *(const float4*)&Qn[(size_t)S.dst[nb] * 64 + 16 * mb + 4 * g];
+        }
+    }
+    // ---- feature tile [16 NB][48] bf16: he (27) | rbf (15) | 0 (6) -------------------------------------------------
+    {
+        const f32x4 z = f4zero();
+        if (lane < 32 * NB) *(f32x4*)&ft[(lane >> 1) * FSB + 32 + 8 * (lane & 1)] = z;      // columns 32..47
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int i4 = lane + 64 * j, e = i4 >> 2, part = i4 & 3;
+            *(f32x4*)&ft[e * FSB + 8 * part] = (P.use_he && e < S.ne) ? hv[j] : z;            // columns 0..31 (27.. are 0)
+        }
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = S.ev[nb] ? xs[nb][c] - xd[nb][c] : 0.f;
+            S.xrel[nb][c] = v;
+            q += v * v;
+        }
+        S.d2[nb] = q;
+        const int el = 16 * nb + l15;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = g + 4 * j;
+            if (k < 15 && S.ev[nb]) ft[el * FSB + 27 + k] = f2bf(P.use_dist ? expf(-q / rbf_sigma(k)) : 0.f);
+        }
+    }
+    wave_lds_fence();
+    // ---- stage 1: z1 = P[src] + Q[dst] (fp32) + W1cd feat (3 k-chunks of 16) ------------------------------------------
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const float4 p = pv[nb][mb], q = qv[nb][mb];
+            f32x4 a;
+            a[0] = S.ev[nb] ? p.x + q.x : 0.f; a[1] = S.ev[nb] ? p.y + q.y : 0.f;
+            a[2] = S.ev[nb] ? p.z + q.z : 0.f; a[3] = S.ev[nb] ? p.w + q.w : 0.f;
+            xh[mb][nb] = a;
+        }
+#pragma unroll
+    for (int kc = 0; kc < 3; ++kc) {
+        s16x4 b[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) b[nb] = *(const s16x4*)&ft[(16 * nb + l15) * FSB + 16 * kc + 4 * g];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const s16x4 a = *(const s16x4*)&w1[(16 * mb + l15) * WSB + 16 * kc + 4 * g];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) xh[mb][nb] = mfma_bf(a, b[nb], xh[mb][nb]);
+        }
+    }
+    // ---- LeakyReLU + LayerNorm statistics (fp32, two-pass like torch) ------------------------------------------------
+    S.zpos = 0u;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        float s = 0.f;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float z = xh[mb][nb][r];
+                if (z > 0.f) S.zpos |= 1u << (16 * nb + 4 * mb + r);
+                const float v = lrelu(z, P.slope);
+                xh[mb][nb][r] = v;
+                s += v;
+            }
+        const float mean = group_sum(s) * (1.f / 64.f);
+        float q = 0.f;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = xh[mb][nb][r] - mean;
+                q += d * d;
+            }
+        const float rstd = 1.f / sqrtf(group_sum(q) * (1.f / 64.f) + P.ln_eps);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xh[mb][nb][r] = (xh[mb][nb][r] - mean) * rstd;
+        S.mean[nb] = mean;
+        S.rstd[nb] = rstd;
+    }
+    // ---- stage 2: m = W2 bf16(xh * gamma + beta) + b2;  stage 3: ch = Wc1 bf16(m) + bc1 -----------------------------
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        const float4 b = *(const float4*)&vec[VEC_B2 + 16 * mb + 4 * g];
+        const float4 c = *(const float4*)&vec[VEC_BC1 + 16 * mb + 4 * g];
+        f32x4 v = {b.x, b.y, b.z, b.w}, u = {c.x, c.y, c.z, c.w};
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            m[mb][nb] = v;
+            ch[mb][nb] = u;
+        }
+    }
+    chain64_bf<true, NB>(m, xh, w2, &vec[VEC_LNG], &vec[VEC_LNB], l15, g);
+    chain64_bf<false, NB>(ch, m, wc1, nullptr, nullptr, l15, g);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        float s = 0.f;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const float4 w = *(const float4*)&vec[VEC_WC2 + 16 * mb + 4 * g];
+            s += lrelu(ch[mb][nb][0], P.slope) * w.x + lrelu(ch[mb][nb][1], P.slope) * w.y +
+                 lrelu(ch[mb][nb][2], P.slope) * w.z + lrelu(ch[mb][nb][3], P.slope) * w.w;
+        }
+        S.coef[nb] = group_sum(s) + vec[VEC_BC2];
+    }
+}
+
 // store an F-layout tile to HBM as [edge][64]
 template <int NB>
 __device__ __forceinline__ void hbm_store(float* __restrict__ dst, const f32x4 (&v)[4][NB], const EdgeTileState<NB>& S,
@@ -377,20 +654,33 @@ __device__ __forceinline__ void hbm_store(float* __restrict__ dst, const f32x4 (
         }
 }
 
+template <int NW, int TF, bool BF>
+struct EdgeSmemSel {
+    typedef EdgeSmem<NW, TF> type;
+};
+template <int NW, int TF>
+struct EdgeSmemSel<NW, TF, true> {
+    typedef EdgeSmemBf<NW, TF> type;
+};
+
 // ---------------------------------------------------------------------------------------------
 // forward: node-aligned 32-edge tiles
 // ---------------------------------------------------------------------------------------------
-template <int NW>
+template <int NW, bool BF>
 __global__ __launch_bounds__(64 * NW) void k_edge_fwd(EqdGraph G, EqdEdgeParams P, const float* __restrict__ Pn,
                                                               const float* __restrict__ Qn,
                                                               const float* __restrict__ x,
                                                               float* __restrict__ aggr_msg,
                                                               float* __restrict__ x_new) {
-    __shared__ EdgeSmem<NW, 32 * TS> sm;
+    typedef typename EdgeSmemSel<NW, 32 * TS, BF>::type Smem;
+    __shared__ Smem sm;
     __shared__ float sxw[NW][96];      // per-node mean of x_rel * coef of the wave's tile
     EQD_TR_WG();
     EQD_TR(0);
-    edge_stage_weights(sm, P);
+    if constexpr (BF)
+        edge_stage_weights_bf<NW, false>(sm, P);
+    else
+        edge_stage_weights(sm, P);
     EQD_TR(1);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, g = lane >> 4;
@@ -410,7 +700,10 @@ __global__ __launch_bounds__(64 * NW) void k_edge_fwd(EqdGraph G, EqdEdgeParams 
         const int c0 = lane, c1 = lane + 64;
         const float x0a = G.x0[xo + (c0 < 3 * nn_pre ? c0 : 0)], xa = x[xo + (c0 < 3 * nn_pre ? c0 : 0)];
         const float x0b = G.x0[xo + (c1 < 3 * nn_pre ? c1 : 0)], xb = x[xo + (c1 < 3 * nn_pre ? c1 : 0)];
-        edge_tile_forward<2>(G, P, sm.w1, sm.w2, sm.wc1, sm.vec, tile, Pn, Qn, x, lane, S, xh, m, ch, nullptr);
+        if constexpr (BF)
+            edge_tile_forward_bf<2>(G, P, sm.w1, sm.w2, sm.wc1, sm.vec, tile, Pn, Qn, x, lane, S, xh, m, ch);
+        else
+            edge_tile_forward<2>(G, P, sm.w1, sm.w2, sm.wc1, sm.vec, tile, Pn, Qn, x, lane, S, xh, m, ch, nullptr);
         wave_lds_fence();   // feature tile is dead: reuse as the message tile [edge][64 + x_moment]
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
@@ -492,8 +785,17 @@ extern "C" int eqd_edge_message_fwd(const EqdGraph* g, const EqdEdgeParams* p, c
     // leaves room for the attention kernel that runs beside this one on the auxiliary stream.  (Dealing the 1067
     // tiles over all 256 CUs measured no faster - 4 % of the SIMDs still get two tiles - and serialised the two.)
     const int blocks = edge_grid(g->n_tiles, FWD_WAVES, 1);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_edge_fwd<FWD_WAVES>), dim3(blocks), dim3(64 * FWD_WAVES), 0, (hipStream_t)stream,
-                       *g, *p, P, Q, x, aggr_msg, x_new);
+    if (p->bf16) {
+        if (p->use_he && !g->he_bf16) {
+            eqd_set_error("eqd_edge_message_fwd: bf16 mode needs EqdGraph.he_bf16");
+            return EQD_ERR_NULL;
+        }
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_edge_fwd<FWD_WAVES, true>), dim3(blocks), dim3(64 * FWD_WAVES), 0,
+                           (hipStream_t)stream, *g, *p, P, Q, x, aggr_msg, x_new);
+    } else {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_edge_fwd<FWD_WAVES, false>), dim3(blocks), dim3(64 * FWD_WAVES), 0,
+                           (hipStream_t)stream, *g, *p, P, Q, x, aggr_msg, x_new);
+    }
     return eqd_check_launch("k_edge_fwd");
 }
 
@@ -564,17 +866,57 @@ __device__ __forceinline__ void feat_atb(f32x4 (&acc)[1], const float* __restric
     }
 }
 
+// bf16 mode: the slabs are stored TRANSPOSED ([feature][128 edges], bf16) so that an MFMA operand - 4 consecutive
+// edges (the K axis) of one feature - is one b64 read
+#define USB 136        /* bf16 row stride of the transposed slabs: 68 dwords = 4 mod 32 */
+__device__ __forceinline__ void slab_store_bf(unsigned short* __restrict__ slab, int wave, const f32x4 (&v)[4][1], int l15,
+                                              int g) {
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab[(16 * mb + 4 * g + r) * USB + 16 * wave + l15] = f2bf(v[mb][0][r]);
+}
+template <int NJ>
+__device__ __forceinline__ void slab_atb_bf(f32x4 (&acc)[NJ], const unsigned short* __restrict__ Xt,
+                                            const unsigned short* __restrict__ Yt, int mb, int nb0, int l15, int g) {
+#pragma unroll
+    for (int kc = 0; kc < 8; ++kc) {
+        const s16x4 a = *(const s16x4*)&Xt[(16 * mb + l15) * USB + 16 * kc + 4 * g];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            acc[j] = mfma_bf(a, *(const s16x4*)&Yt[(16 * (nb0 + j) + l15) * USB + 16 * kc + 4 * g], acc[j]);
+    }
+}
+
+template <bool BF>
+struct EdgeBwdSmemSel {
+    typedef EdgeSmem<BWD_WAVES, 16 * FS> type;
+    typedef float slab_t;
+    enum { SLAB = 128 * US };
+};
+template <>
+struct EdgeBwdSmemSel<true> {
+    typedef EdgeSmemBfBwd<BWD_WAVES, 16 * FS> type;
+    typedef unsigned short slab_t;
+    enum { SLAB = 64 * USB };
+};
+
+template <bool BF>
 __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdgeParams P, const float* __restrict__ Pn,
                                                               const float* __restrict__ Qn,
                                                               const float* __restrict__ x,
                                                               const float* __restrict__ d_aggr,
                                                               const float* __restrict__ d_xnew, EdgeBwdWs W) {
-    __shared__ EdgeSmem<BWD_WAVES, 16 * FS> sm;
-    __shared__ __attribute__((aligned(16))) float U[128 * US];
-    __shared__ __attribute__((aligned(16))) float V[128 * US];
+    typedef EdgeBwdSmemSel<BF> Sel;
+    __shared__ typename Sel::type sm;
+    __shared__ __attribute__((aligned(16))) typename Sel::slab_t U[Sel::SLAB];
+    __shared__ __attribute__((aligned(16))) typename Sel::slab_t V[Sel::SLAB];
     EQD_TR_WG();
     EQD_TR(0);
-    edge_stage_weights(sm, P);
+    if constexpr (BF)
+        edge_stage_weights_bf<BWD_WAVES, true>(sm, P);
+    else
+        edge_stage_weights(sm, P);
     EQD_TR(1);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, g = lane >> 4;
@@ -611,7 +953,10 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) dag[mb] = *(const float4*)&d_aggr[(size_t)d * 64 + 16 * mb + 4 * g];
         }
-        edge_tile_forward<1>(G, P, sm.w1, sm.w2, sm.wc1, sm.vec, tile, Pn, Qn, x, lane, S, xh, m, ch, nullptr);
+        if constexpr (BF)
+            edge_tile_forward_bf<1>(G, P, sm.w1, sm.w2, sm.wc1, sm.vec, tile, Pn, Qn, x, lane, S, xh, m, ch);
+        else
+            edge_tile_forward<1>(G, P, sm.w1, sm.w2, sm.wc1, sm.vec, tile, Pn, Qn, x, lane, S, xh, m, ch, nullptr);
         // ---- coordinate path ---------------------------------------------------------------------
         float invdeg = 0.f, dcoef = 0.f, dxr[3] = {0.f, 0.f, 0.f};
         {
@@ -645,11 +990,19 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
         }
         EQD_TR(12);
         // ---- phase 1: dWc1 += d_chid^T m -------------------------------------------------------------
-        slab_store(U, wave, ch, l15, g);
-        slab_store(V, wave, m, l15, g);
+        if constexpr (BF) {
+            slab_store_bf(U, wave, ch, l15, g);
+            slab_store_bf(V, wave, m, l15, g);
+        } else {
+            slab_store(U, wave, ch, l15, g);
+            slab_store(V, wave, m, l15, g);
+        }
         __syncthreads();
         EQD_TR(13);
-        slab_atb<2>(gWc1, U, V, wmb, wnb, l15, g);
+        if constexpr (BF)
+            slab_atb_bf<2>(gWc1, U, V, wmb, wnb, l15, g);
+        else
+            slab_atb<2>(gWc1, U, V, wmb, wnb, l15, g);
         EQD_TR(14);
         // ---- dm = d_aggr[dst] / deg + Wc1^T d_chid ---------------------------------------------------
 #pragma unroll
@@ -659,7 +1012,10 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
             a[0] = v.x * invdeg; a[1] = v.y * invdeg; a[2] = v.z * invdeg; a[3] = v.w * invdeg;
             m[mb][0] = a;
         }
-        chain64T<1>(m, ch, sm.wc1, l15, g);
+        if constexpr (BF)
+            chain64_bf<false, 1>(m, ch, sm.wc1T, nullptr, nullptr, l15, g);
+        else
+            chain64T<1>(m, ch, sm.wc1, l15, g);
         {
             float va[16];
 #pragma unroll
@@ -671,7 +1027,10 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
         EQD_TR(15);
         // ---- phase 2: dW2 += dm^T a1 ---------------------------------------------------------------------
         __syncthreads();                 // every wave is done reading the phase-1 slabs
-        slab_store(U, wave, m, l15, g);
+        if constexpr (BF)
+            slab_store_bf(U, wave, m, l15, g);
+        else
+            slab_store(U, wave, m, l15, g);
         {
             f32x4 a1[4][1];
 #pragma unroll
@@ -683,17 +1042,26 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
                 a1[mb][0][2] = xh[mb][0][2] * gg.z + bb.z;
                 a1[mb][0][3] = xh[mb][0][3] * gg.w + bb.w;
             }
-            slab_store(V, wave, a1, l15, g);
+            if constexpr (BF)
+                slab_store_bf(V, wave, a1, l15, g);
+            else
+                slab_store(V, wave, a1, l15, g);
         }
         __syncthreads();
         EQD_TR(16);
-        slab_atb<2>(gW2, U, V, wmb, wnb, l15, g);
+        if constexpr (BF)
+            slab_atb_bf<2>(gW2, U, V, wmb, wnb, l15, g);
+        else
+            slab_atb<2>(gW2, U, V, wmb, wnb, l15, g);
         EQD_TR(17);
         // ---- da1 = W2^T dm ---------------------------------------------------------------------------
         f32x4 dz[4][1];
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) dz[mb][0] = f4zero();
-        chain64T<1>(dz, m, sm.w2, l15, g);
+        if constexpr (BF)
+            chain64_bf<false, 1>(dz, m, sm.w2T, nullptr, nullptr, l15, g);
+        else
+            chain64T<1>(dz, m, sm.w2, l15, g);
         EQD_TR(18);
         // ---- LayerNorm + LeakyReLU backward --------------------------------------------------------------
         {
@@ -738,21 +1106,39 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
         hbm_store<1>(W.dz1, dz, S, l15, g);
         // ---- phase 3: dW1[:, 2d:] += dz1^T [he | rbf] ------------------------------------------------------
         __syncthreads();                 // phase-2 slabs are free
-        slab_store(U, wave, dz, l15, g);
-        __syncthreads();
-        feat_atb(gW1a, U, &sm.tile[0][0], wmb, wave & 1, l15, g);     // the feature tiles are the B operand as they lie
-        if (wave < 4) feat_atb(gW1b, U, &sm.tile[0][0], wave, 2, l15, g);
+        if constexpr (BF) {
+            slab_store_bf(U, wave, dz, l15, g);
+            // this wave's [16][48] feature tile, transposed, is rows 0..47 x columns 16 w .. of V
+            const unsigned short* __restrict__ ft = (const unsigned short*)tile;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) V[(12 * g + i) * USB + 16 * wave + l15] = ft[l15 * FSB + 12 * g + i];
+            __syncthreads();
+            slab_atb_bf<1>(gW1a, U, V, wmb, wave & 1, l15, g);
+            if (wave < 4) slab_atb_bf<1>(gW1b, U, V, wave, 2, l15, g);
+        } else {
+            slab_store(U, wave, dz, l15, g);
+            __syncthreads();
+            feat_atb(gW1a, U, &sm.tile[0][0], wmb, wave & 1, l15, g);     // the feature tiles are the B operand as they lie
+            if (wave < 4) feat_atb(gW1b, U, &sm.tile[0][0], wave, 2, l15, g);
+        }
         EQD_TR(20);
         // ---- d rbf = W1d^T dz1 -> d(d^2) -> d x_rel --------------------------------------------------------
         if (P.use_dist) {
             f32x4 dr = f4zero();
+            if constexpr (BF) {
 #pragma unroll
-            for (int mbi = 0; mbi < 4; ++mbi)
+                for (int mbi = 0; mbi < 4; ++mbi)
+                    dr = mfma_bf(*(const s16x4*)&sm.w1rT[l15 * WSB + 16 * mbi + 4 * g],
+                                 pack_bf4(dz[mbi][0][0], dz[mbi][0][1], dz[mbi][0][2], dz[mbi][0][3]), dr);
+            } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float w = (l15 < 15) ? sm.w1[(16 * mbi + 4 * g + r) * WS1 + 27 + l15] : 0.f;
-                    dr = mfma4(w, dz[mbi][0][r], dr);
-                }
+                for (int mbi = 0; mbi < 4; ++mbi)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float w = (l15 < 15) ? sm.w1[(16 * mbi + 4 * g + r) * WS1 + 27 + l15] : 0.f;
+                        dr = mfma4(w, dz[mbi][0][r], dr);
+                    }
+            }
             float s = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -849,8 +1235,12 @@ extern "C" int eqd_edge_message_bwd_kernel_only(const EqdGraph* g, const EqdEdge
         return EQD_ERR_WORKSPACE;
     }
     if (g->n_edges <= 0) return EQD_OK;
-    hipLaunchKernelGGL(k_edge_bwd, dim3(edge_bwd_blocks(g)), dim3(64 * BWD_WAVES), 0, (hipStream_t)stream, *g, *p, P, Q, x,
-                       d_aggr_msg, d_xnew, W);
+    if (p->bf16)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_edge_bwd<true>), dim3(edge_bwd_blocks(g)), dim3(64 * BWD_WAVES), 0,
+                           (hipStream_t)stream, *g, *p, P, Q, x, d_aggr_msg, d_xnew, W);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_edge_bwd<false>), dim3(edge_bwd_blocks(g)), dim3(64 * BWD_WAVES), 0,
+                           (hipStream_t)stream, *g, *p, P, Q, x, d_aggr_msg, d_xnew, W);
     return eqd_check_launch("k_edge_bwd");
 }
 
@@ -883,7 +1273,17 @@ int eqd_edge_message_bwd_impl(const EqdGraph* g, const EqdEdgeParams* p, const f
         W.wpart = part_override + (size_t)blocks * BWD_WAVES * VP;
     }
     if (g->n_edges > 0) {
-        hipLaunchKernelGGL(k_edge_bwd, dim3(blocks), dim3(64 * BWD_WAVES), 0, st, *g, *p, P, Q, x, d_aggr_msg, d_xnew, W);
+        if (p->bf16) {
+            if (p->use_he && !g->he_bf16) {
+                eqd_set_error("eqd_edge_message_bwd: bf16 mode needs EqdGraph.he_bf16");
+                return EQD_ERR_NULL;
+            }
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_edge_bwd<true>), dim3(blocks), dim3(64 * BWD_WAVES), 0, st, *g, *p, P, Q, x,
+                               d_aggr_msg, d_xnew, W);
+        } else {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_edge_bwd<false>), dim3(blocks), dim3(64 * BWD_WAVES), 0, st, *g, *p, P, Q, x,
+                               d_aggr_msg, d_xnew, W);
+        }
         int rc = eqd_check_launch("k_edge_bwd");
         if (rc) return rc;
         const int nw = blocks * BWD_WAVES;

@@ -198,6 +198,7 @@ class PackedGraph:
            rowptr[N+1], csc_ptr[N+1], csc_eid[E], tile_node[T+1], att_items[I,4], res_id[N],
            seg_off[2B+1] (global node offsets of the 2B segments: B ligands then B receptors)
     fp32 : mu_r_norm[N,5], he[E,27], x0[N,3] (ligand new_x rows then receptor x rows)
+    bf16 : he_bf16[E,32] (he rounded to nearest even, 5 zero columns; stored as int16 bit patterns)
     """
 
     INT_FIELDS = ('lig_off', 'rec_off', 'src', 'dst', 'rowptr', 'csc_ptr', 'csc_eid', 'tile_node',
@@ -298,6 +299,11 @@ class PackedGraph:
         p.edge_perm = torch.from_numpy(perm).to(dev)
         he = torch.cat([g._edata['ll']['he'], g._edata['rr']['he']], 0).to(torch.float32)
         p.he = he[p.edge_perm].contiguous() if E else he.contiguous()
+        # bf16 copy for the storage_bf16 mode: 32 columns per edge (27 used), i.e. 64-byte rows
+        hb = torch.zeros(max(E, 1), 32, dtype=torch.bfloat16, device=p.he.device)
+        if E:
+            hb[:, :27] = p.he.to(torch.bfloat16)
+        p.he_bf16 = hb.view(torch.int16).contiguous()
         p.mu_r_norm = torch.cat([g._ndata['ligand']['mu_r_norm'], g._ndata['receptor']['mu_r_norm']], 0) \
             .to(torch.float32).contiguous()
         if n and float(p.mu_r_norm.min()) <= 0.0:

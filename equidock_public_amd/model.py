@@ -264,6 +264,12 @@ class IEGMN(nn.Module):
         d.lrelu_slope = a['leakyrelu_neg_slope']
         d.ln_eps = 1e-5
         d.svd_seed = int(self.svd_seed)
+        # not a reference option: 'hip_storage_dtype' = 'bf16' runs the edge-message kernels in bf16 mode (he rows and
+        # GEMM inputs in bf16, fp32 accumulate); everything else stays fp32
+        sd = a.get('hip_storage_dtype', 'fp32')
+        if sd not in ('fp32', 'bf16'):
+            raise NotImplementedError(f"hip_storage_dtype={sd!r}: only 'fp32' and 'bf16' exist")
+        d.storage_bf16 = int(sd == 'bf16')
         return d
 
     def _param_table(self):

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define EQD_ABI_VERSION 1
+#define EQD_ABI_VERSION 2
 #define EQD_TILE_EDGES 32   /* edges per node-aligned tile (max supported in-degree) */
 #define EQD_ATT_BLOCK 32    /* nodes per cross-attention work item */
 #define EQD_MAX_SRC 6
@@ -71,6 +71,8 @@ typedef struct EqdGraph {
     const float* mu_r_norm;    /* [n_nodes][5] */
     const float* he;           /* [n_edges][27] */
     const float* x0;           /* [n_nodes][3] ligand new_x rows then receptor x rows */
+    const uint16_t* he_bf16;   /* [n_edges][32] bf16 copy of he (27 used, 5 zeros; 64-byte rows) - only read in
+                                  bf16 mode (EqdEdgeParams.bf16 / EqdModelDesc.storage_bf16), may be NULL otherwise */
 } EqdGraph;
 
 /* ---- model configuration: the `args` keys the reference's modules consume
@@ -85,6 +87,7 @@ typedef struct EqdModelDesc {
     int32_t cross_msgs, use_dist_in_layers, use_edge_features;
     float skip_weight_h, x_connection_init, lrelu_slope, ln_eps;
     int32_t svd_seed;               /* seed of the counter-based draws used if the SVD guard fires */
+    int32_t storage_bf16;           /* 1: edge-message kernels in bf16 mode (EqdEdgeParams.bf16); default 0 = fp32 */
 } EqdModelDesc;
 
 /* Parameter table: device pointers in this fixed order.  Per layer i (base = 19*i):
@@ -187,6 +190,7 @@ typedef struct EqdEdgeParams {
     const float* Wc1; const float* bc1; const float* wc2; const float* bc2;
     float slope, ln_eps, eta;
     int32_t use_dist, use_he;
+    int32_t bf16;   /* 1: he from EqdGraph.he_bf16, GEMM inputs rounded to bf16, fp32 accumulate (bf16 MFMA) */
 } EqdEdgeParams;
 /* P = h W1[:, :d_in]^T, Q = h W1[:, d_in:2 d_in]^T + b1 are node-level inputs ([n_nodes][64]). */
 int eqd_edge_message_fwd(const EqdGraph* g, const EqdEdgeParams* p, const float* P, const float* Q,

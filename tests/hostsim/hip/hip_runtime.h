@@ -64,6 +64,7 @@ void sync_block();
 float shfl_f(float v, int src_lane);
 int shfl_i(int v, int src_lane);
 void mfma16x16x4(float a, float b, const float* c_in, float* d_out);
+void mfma16x16x16bf16(const unsigned short* a, const unsigned short* b, const float* c_in, float* d_out);
 int lane_id();
 void wave_barrier();
 }  // namespace hostsim
@@ -87,6 +88,19 @@ static inline hostsim_f32x4 hostsim_mfma(float a, float b, hostsim_f32x4 c, int,
     return r;
 }
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hostsim_mfma
+typedef short hostsim_s16x4 __attribute__((ext_vector_type(4)));
+static inline hostsim_f32x4 hostsim_mfma_bf16(hostsim_s16x4 a, hostsim_s16x4 b, hostsim_f32x4 c, int, int, int) {
+    unsigned short ai[4], bi[4];
+    for (int i = 0; i < 4; ++i) {
+        ai[i] = (unsigned short)a[i];
+        bi[i] = (unsigned short)b[i];
+    }
+    float ci[4] = {c[0], c[1], c[2], c[3]}, d[4];
+    hostsim::mfma16x16x16bf16(ai, bi, ci, d);
+    hostsim_f32x4 r = {d[0], d[1], d[2], d[3]};
+    return r;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x16bf16_1k hostsim_mfma_bf16
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_wave_barrier() hostsim::wave_barrier()
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)

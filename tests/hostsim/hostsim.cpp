@@ -1,5 +1,7 @@
 // TEST INFRASTRUCTURE ONLY -- fiber scheduler behind tests/hostsim/hip/hip_runtime.h.
 #include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
 #include <sys/mman.h>
 #include <vector>
 
@@ -47,6 +49,7 @@ struct Wave {
     unsigned gen;
     float fa[2][64], fb[2][64];
     int ia[2][64];
+    unsigned short ha[2][64][4], hb[2][64][4];
 };
 
 static Fiber g_fib[kMaxThreads];
@@ -132,6 +135,34 @@ void mfma16x16x4(float a, float b, const float* c, float* d) {
         int row = 4 * grp + r;
         float acc = c[r];
         for (int k = 0; k < 4; ++k) acc = fmaf(w.fa[p][row + 16 * k], w.fb[p][col + 16 * k], acc);
+        d[r] = acc;
+    }
+}
+
+static inline float bf16_to_f32(unsigned short h) {
+    unsigned u = (unsigned)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+// v_mfma_f32_16x16x16_bf16: lane (i = lane & 15, g = lane >> 4) brings A[i][4g..4g+3] and B[4g..4g+3][i] (as 4 bf16),
+// receives D[4g + r][i]; products of bf16 values are exact in fp32, the 16-term sum is accumulated in fp32
+void mfma16x16x16bf16(const unsigned short* a, const unsigned short* b, const float* c, float* d) {
+    Fiber* f = g_cur;
+    Wave& w = g_wave[f->wave];
+    if (w.nlanes != 64) { fprintf(stderr, "hostsim: MFMA in a partial wave\n"); abort(); }
+    int p = (f->ncoll++) & 1;
+    for (int i = 0; i < 4; ++i) {
+        w.ha[p][f->lane][i] = a[i];
+        w.hb[p][f->lane][i] = b[i];
+    }
+    wave_sync();
+    int col = f->lane & 15, grp = f->lane >> 4;
+    for (int r = 0; r < 4; ++r) {
+        int row = 4 * grp + r;
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k)
+            acc = fmaf(bf16_to_f32(w.ha[p][row + 16 * (k >> 2)][k & 3]), bf16_to_f32(w.hb[p][col + 16 * (k >> 2)][k & 3]), acc);
         d[r] = acc;
     }
 }

@@ -32,6 +32,11 @@ def test_edge_message_fwd_bwd(dev):
     pc.check_edge(dev)
 
 
+def test_edge_message_bf16(dev):
+    from tests import parity_common as pc
+    pc.check_edge_bf16(dev)
+
+
 @pytest.mark.parametrize('d', [64, 69])
 def test_cross_attention(dev, d):
     from tests import parity_common as pc
@@ -62,6 +67,12 @@ def test_model_two_row_tiles(dev, name, monkeypatch):
     monkeypatch.setenv('EQD_ROW_TILES', '2')
     pc.check_linear(dev)
     pc.check_model_case(dev, name)
+
+
+@pytest.mark.parametrize('name', ['D_degraded3', 'A_b1_shared5'])
+def test_model_bf16_mode(dev, name):
+    from tests import parity_common as pc
+    pc.check_model_bf16(dev, name)
 
 
 def test_flat_grads(dev):

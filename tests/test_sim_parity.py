@@ -33,6 +33,10 @@ def test_edge_message_fwd_bwd():
     pc.check_edge(DEV)
 
 
+def test_edge_message_bf16():
+    pc.check_edge_bf16(DEV)
+
+
 @pytest.mark.parametrize('d', [64, 69])
 def test_cross_attention(d):
     pc.check_attention(DEV, d)
@@ -57,6 +61,10 @@ def test_model_two_row_tiles(name, monkeypatch):
     monkeypatch.setenv('EQD_ROW_TILES', '2')
     pc.check_linear(DEV)
     pc.check_model_case(DEV, name)
+
+
+def test_model_bf16_mode():
+    pc.check_model_bf16(DEV, 'D_degraded3')
 
 
 def test_flat_grads():
