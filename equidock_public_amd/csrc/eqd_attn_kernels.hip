@@ -43,10 +43,19 @@ __device__ __forceinline__ void tile_load(TileRegs<DB, FAST>& R, const float* __
     const int nvalid = nrows * d;
     const float* __restrict__ base = M + (size_t)r0 * d;
     if (FAST) {
+        // unpredicated (a predicated load is an exec-masked branch with a wait behind it): rows beyond the range are
+        // fetched from its last row and zeroed; a tile entirely beyond the range is not fetched at all (wave-uniform)
+        if (nrows > 0) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int i4 = lane + 64 * j;
-            R.q[j] = (4 * i4 < nvalid) ? ((const float4*)base)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = 0; j < 8; ++j) {
+                const int i4 = lane + 64 * j;
+                const int row = i4 >> 4;
+                const float4 v = ((const float4*)base)[(row < nrows ? row : nrows - 1) * 16 + (i4 & 15)];
+                R.q[j] = row < nrows ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) R.q[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     } else {
 #pragma unroll
@@ -102,6 +111,25 @@ __device__ __forceinline__ void block_tile_stage(const float* __restrict__ M, in
         }
     }
 }
+// d == 64, 16-byte aligned rows: the [32][64] tile is 512 float4, two per thread, unpredicated (rows beyond the block are
+// fetched from its last row and written as zeros).  Columns 64.. of the LDS tile are never read when d == 64.
+__device__ __forceinline__ void block_tile_stage_fast(const float* __restrict__ M, int DS, int r0, int r1,
+                                                      float* __restrict__ L, int t) {
+    int nrows = r1 - r0;
+    nrows = nrows > 32 ? 32 : nrows;
+    const float4* __restrict__ base = (const float4*)(M + (size_t)r0 * 64);
+    float4 v[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int i4 = t + 256 * j, row = i4 >> 4;
+        v[j] = base[(row < nrows ? row : nrows - 1) * 16 + (i4 & 15)];
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int i4 = t + 256 * j, row = i4 >> 4;
+        *(float4*)&L[row * DS + 4 * (i4 & 15)] = row < nrows ? v[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
 __device__ __forceinline__ void zero_fill(float* __restrict__ L, int n, int t, int nthreads) {
     for (int i = t; i < n; i += nthreads) L[i] = 0.f;
 }
@@ -132,12 +160,17 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_fwd(EqdGraph G, int d, const
     int kt = o0 + 32 * wave;
     tile_load<DB, FAST>(rk, k, d, kt, o1, lane);
     tile_load<DB, FAST>(rv, v, d, kt, o1, lane);
-    zero_fill(Qt, C::TILE, t, EQD_BLOCK);
-    zero_fill(Kt[wave], C::TILE, lane, 64);
-    zero_fill(Vt[wave], C::TILE, lane, 64);
-    __syncthreads();
-    EQD_TR(1);
-    block_tile_stage(q, d, DS, b0, b1, Qt, t);
+    if (FAST) {      // every element that is read later is written by the tile stores: no zero fill needed
+        EQD_TR(1);
+        block_tile_stage_fast(q, DS, b0, b1, Qt, t);
+    } else {
+        zero_fill(Qt, C::TILE, t, EQD_BLOCK);
+        zero_fill(Kt[wave], C::TILE, lane, 64);
+        zero_fill(Vt[wave], C::TILE, lane, 64);
+        __syncthreads();
+        EQD_TR(1);
+        block_tile_stage(q, d, DS, b0, b1, Qt, t);
+    }
     __syncthreads();
     EQD_TR(2);
     float qf[2][KS];
@@ -310,27 +343,54 @@ __device__ __forceinline__ void attn_bwd_q_body(AttnBwdSmem<DB>& sm, const EqdGr
     tile_load<DB, FAST>(rk, k, d, kt, o1, lane);
     tile_load<DB, FAST>(rv, v, d, kt, o1, lane);
     float dl[2], lq[2];
+    if (FAST) {
+        // delta partial of the lane: columns 16 q + 4 g .. + 3 of its two rows (unpredicated, clamped rows)
+        float4 a[2][4], b[2][4];
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-        float s = 0.f;
+        for (int nb = 0; nb < 2; ++nb) {
+            const size_t ro = (size_t)(qv[nb] ? rowq[nb] : b1 - 1) * 64;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int kk = 4 * ks + g;
-            if (qv[nb] && kk < d) {
-                const size_t o = (size_t)rowq[nb] * d + kk;
-                s += d_out[o] * out[o];
+            for (int qq = 0; qq < 4; ++qq) {
+                a[nb][qq] = *(const float4*)&d_out[ro + 16 * qq + 4 * g];
+                b[nb][qq] = *(const float4*)&out[ro + 16 * qq + 4 * g];
             }
+            lq[nb] = lse[qv[nb] ? rowq[nb] : b1 - 1];
         }
-        dl[nb] = s;
-        lq[nb] = qv[nb] ? lse[rowq[nb]] : 0.f;
+        block_tile_stage_fast(q, DS, b0, b1, Qt, t);
+        block_tile_stage_fast(d_out, DS, b0, b1, Gt, t);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            float s = 0.f;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+                s += a[nb][qq].x * b[nb][qq].x + a[nb][qq].y * b[nb][qq].y + a[nb][qq].z * b[nb][qq].z +
+                     a[nb][qq].w * b[nb][qq].w;
+            dl[nb] = qv[nb] ? s : 0.f;
+            lq[nb] = qv[nb] ? lq[nb] : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            float s = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int kk = 4 * ks + g;
+                if (qv[nb] && kk < d) {
+                    const size_t o = (size_t)rowq[nb] * d + kk;
+                    s += d_out[o] * out[o];
+                }
+            }
+            dl[nb] = s;
+            lq[nb] = qv[nb] ? lse[rowq[nb]] : 0.f;
+        }
+        zero_fill(Qt, C::TILE, t, EQD_BLOCK);
+        zero_fill(Gt, C::TILE, t, EQD_BLOCK);
+        zero_fill(Kt[wave], C::TILE, lane, 64);
+        zero_fill(Vt[wave], C::TILE, lane, 64);
+        __syncthreads();
+        block_tile_stage(q, d, DS, b0, b1, Qt, t);
+        block_tile_stage(d_out, d, DS, b0, b1, Gt, t);
     }
-    zero_fill(Qt, C::TILE, t, EQD_BLOCK);
-    zero_fill(Gt, C::TILE, t, EQD_BLOCK);
-    zero_fill(Kt[wave], C::TILE, lane, 64);
-    zero_fill(Vt[wave], C::TILE, lane, 64);
-    __syncthreads();
-    block_tile_stage(q, d, DS, b0, b1, Qt, t);
-    block_tile_stage(d_out, d, DS, b0, b1, Gt, t);
     __syncthreads();
     float qf[2][KS], dof[2][KS];
 #pragma unroll
@@ -453,13 +513,18 @@ __device__ __forceinline__ void attn_bwd_kv_body(AttnBwdSmem<DB>& sm, const EqdG
             lr[mb][r] = qr < o1 ? lse[qr] : 0.f;
             dr[mb][r] = (!OWN_DELTA && qr < o1) ? delta[qr] : 0.f;
         }
-    zero_fill(Kb, C::TILE, t, EQD_BLOCK);
-    zero_fill(Vb, C::TILE, t, EQD_BLOCK);
-    zero_fill(Qt[wave], C::TILE, lane, 64);
-    zero_fill(Gt[wave], C::TILE, lane, 64);
-    __syncthreads();
-    block_tile_stage(k, d, DS, b0, b1, Kb, t);
-    block_tile_stage(v, d, DS, b0, b1, Vb, t);
+    if (FAST) {
+        block_tile_stage_fast(k, DS, b0, b1, Kb, t);
+        block_tile_stage_fast(v, DS, b0, b1, Vb, t);
+    } else {
+        zero_fill(Kb, C::TILE, t, EQD_BLOCK);
+        zero_fill(Vb, C::TILE, t, EQD_BLOCK);
+        zero_fill(Qt[wave], C::TILE, lane, 64);
+        zero_fill(Gt[wave], C::TILE, lane, 64);
+        __syncthreads();
+        block_tile_stage(k, d, DS, b0, b1, Kb, t);
+        block_tile_stage(v, d, DS, b0, b1, Vb, t);
+    }
     __syncthreads();
     float kf[2][KS], vf[2][KS];
 #pragma unroll
@@ -661,7 +726,7 @@ extern "C" int eqd_cross_attention_fwd(const EqdGraph* g, int d, const float* q,
     }
     if (g->n_att_items <= 0) return EQD_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (d == 64 && aligned16(k) && aligned16(v)) return attn_launch_fwd<4, true>(g, d, q, k, v, out, lse, st);
+    if (d == 64 && aligned16(q) && aligned16(k) && aligned16(v)) return attn_launch_fwd<4, true>(g, d, q, k, v, out, lse, st);
     if (d <= 64) return attn_launch_fwd<4, false>(g, d, q, k, v, out, lse, st);
     return attn_launch_fwd<5, false>(g, d, q, k, v, out, lse, st);
 }
@@ -679,7 +744,7 @@ extern "C" int eqd_cross_attention_bwd(const EqdGraph* g, int d, const float* q,
     }
     if (g->n_att_items <= 0) return EQD_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (d == 64 && aligned16(q) && aligned16(k) && aligned16(v) && aligned16(d_out))
+    if (d == 64 && aligned16(q) && aligned16(k) && aligned16(v) && aligned16(d_out) && aligned16(out))
         return attn_launch_bwd<4, true>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
     if (d <= 64) return attn_launch_bwd<4, false>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
     return attn_launch_bwd<5, false>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
