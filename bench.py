@@ -198,11 +198,18 @@ def main():
     if a.gpus != world and world == 1 and a.gpus > 1:
         raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     import torch.distributed as dist
-    dev = torch.device('cuda', local_rank)
+    # EQD_BENCH_ONE_DEVICE=1 + EQD_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow (barriers, max over ranks,
+    # rank-0 report, gradient all-reduce) on a box with a single GPU; real runs use one GPU per rank over RCCL
+    one_dev = os.environ.get('EQD_BENCH_ONE_DEVICE') == '1'
+    dev = torch.device('cuda', 0 if one_dev else local_rank)
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        backend = os.environ.get('EQD_BENCH_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from equidock_public_amd import graph, model, parallel, synthetic
     from oracle import iegmn_port as port   # only for default_args/init_state_dict + the cpu_baseline leg
@@ -293,7 +300,7 @@ def main():
             "config": {"workload": desc, "pairs_per_gpu": ppg, "nodes_per_gpu": packed.n_nodes,
                        "edges_per_gpu": packed.n_edges, "layers": L, "parallelism": f"dp{world}",
                        "weights": "PyTorch default init (seed 0), ROT key/query x40 (SURVEY.md section 8c)",
-                       "loss": float(loss), "svd_guard_pairs": svd_bad,
+                       "loss": float(loss.detach()), "svd_guard_pairs": svd_bad,
                        "host_enqueue_ms_per_step": round(host_dt / a.steps * 1e3, 4), "launch_mode": graph_mode},
         }
         if not a.no_roofline:

@@ -58,10 +58,16 @@ __device__ __forceinline__ void tile_load(TileRegs<DB, FAST>& R, const float* __
             for (int j = 0; j < 8; ++j) R.q[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     } else {
+        if (nvalid > 0) {       // unpredicated: clamp the element index, zero afterwards (see the FAST branch)
 #pragma unroll
-        for (int j = 0; j < AttnCfg<DB>::NL; ++j) {
-            const int i = lane + 64 * j;
-            R.v[j] = i < nvalid ? base[i] : 0.f;
+            for (int j = 0; j < AttnCfg<DB>::NL; ++j) {
+                const int i = lane + 64 * j;
+                const float v = base[i < nvalid ? i : nvalid - 1];
+                R.v[j] = i < nvalid ? v : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < AttnCfg<DB>::NL; ++j) R.v[j] = 0.f;
         }
     }
 }
@@ -96,9 +102,10 @@ __device__ __forceinline__ void block_tile_stage(const float* __restrict__ M, in
     const float* __restrict__ base = M + (size_t)r0 * d;
     float v[10];
 #pragma unroll
-    for (int j = 0; j < 10; ++j) {
+    for (int j = 0; j < 10; ++j) {       // unpredicated (nvalid >= 1: a block has at least one row)
         const int i = t + 256 * j;
-        v[j] = i < nvalid ? base[i] : 0.f;
+        const float x = base[i < nvalid ? i : nvalid - 1];
+        v[j] = i < nvalid ? x : 0.f;
     }
     int row = t / d, col = t - row * d;
 #pragma unroll
@@ -371,17 +378,20 @@ __device__ __forceinline__ void attn_bwd_q_body(AttnBwdSmem<DB>& sm, const EqdGr
     } else {
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
+            const size_t ro = (size_t)(qv[nb] ? rowq[nb] : b1 - 1) * d;
+            float a[KS], b[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {       // unpredicated, clamped
+                const int kk = 4 * ks + g;
+                a[ks] = d_out[ro + (kk < d ? kk : d - 1)];
+                b[ks] = out[ro + (kk < d ? kk : d - 1)];
+            }
             float s = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const int kk = 4 * ks + g;
-                if (qv[nb] && kk < d) {
-                    const size_t o = (size_t)rowq[nb] * d + kk;
-                    s += d_out[o] * out[o];
-                }
-            }
+            for (int ks = 0; ks < KS; ++ks) s += (qv[nb] && 4 * ks + g < d) ? a[ks] * b[ks] : 0.f;
             dl[nb] = s;
-            lq[nb] = qv[nb] ? lse[rowq[nb]] : 0.f;
+            const float l = lse[qv[nb] ? rowq[nb] : b1 - 1];
+            lq[nb] = qv[nb] ? l : 0.f;
         }
         zero_fill(Qt, C::TILE, t, EQD_BLOCK);
         zero_fill(Gt, C::TILE, t, EQD_BLOCK);
@@ -510,8 +520,10 @@ __device__ __forceinline__ void attn_bwd_kv_body(AttnBwdSmem<DB>& sm, const EqdG
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int qr = qt + 16 * mb + 4 * g + r;
-            lr[mb][r] = qr < o1 ? lse[qr] : 0.f;
-            dr[mb][r] = (!OWN_DELTA && qr < o1) ? delta[qr] : 0.f;
+            const int qc = o1 > o0 ? (qr < o1 ? qr : o1 - 1) : 0;       // unpredicated, clamped
+            const float lv = lse[qc], dv_ = OWN_DELTA ? 0.f : delta[qc];
+            lr[mb][r] = qr < o1 ? lv : 0.f;
+            dr[mb][r] = qr < o1 ? dv_ : 0.f;
         }
     if (FAST) {
         block_tile_stage_fast(k, DS, b0, b1, Kb, t);
@@ -579,8 +591,10 @@ __device__ __forceinline__ void attn_bwd_kv_body(AttnBwdSmem<DB>& sm, const EqdG
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int qr = qn + 16 * mb + 4 * g + r;
-                lr[mb][r] = qr < o1 ? lse[qr] : 0.f;
-                dr[mb][r] = (!OWN_DELTA && qr < o1) ? delta[qr] : 0.f;
+                const int qc = o1 > o0 ? (qr < o1 ? qr : o1 - 1) : 0;
+                const float lv = lse[qc], dv_ = OWN_DELTA ? 0.f : delta[qc];
+                lr[mb][r] = qr < o1 ? lv : 0.f;
+                dr[mb][r] = qr < o1 ? dv_ : 0.f;
             }
         f32x4 S[2][2], dP[2][2];
 #pragma unroll

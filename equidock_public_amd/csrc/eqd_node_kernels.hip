@@ -429,7 +429,13 @@ __global__ __launch_bounds__(1024) void k_atb_reduce(AtbUnitsArg U, const float*
 // Host side.  Every (job, 64-column block) is a unit; units are packed into launches of at most ATB_MAXUNITS
 // such that no two units of a launch accumulate into the same output (shared-weight layers), and each
 // unit's rows are split over ~ATB_TARGET_WGS / units workgroups.
-#define ATB_TARGET_WGS 1024
+#define ATB_TARGET_WGS_DEFAULT 1024
+static int atb_target_wgs() {
+    const char* f = getenv("EQD_ATB_WGS");      // tuning experiments only
+    const int v = f ? atoi(f) : 0;
+    return v >= 64 && v <= 4096 ? v : ATB_TARGET_WGS_DEFAULT;
+}
+#define ATB_TARGET_WGS atb_target_wgs()
 static int atb_units(const EqdAtbJob* jobs, int njobs, std::vector<AtbUnit>& units) {
     for (int i = 0; i < njobs; ++i) {
         const EqdAtbJob& J = jobs[i];
@@ -480,7 +486,7 @@ static int atb_next_batch(std::vector<AtbUnit>& units, size_t first, long long* 
 // upper bound of the partial workspace of ANY eqd_atb call (independent of the jobs)
 size_t eqd_atb_batch_partial_bytes(int rows) {
     (void)rows;
-    return (size_t)(ATB_TARGET_WGS + ATB_MAXBLOCKS + ATB_MAXUNITS) * ATB_PSTRIDE * sizeof(float) + 256;
+    return (size_t)(4096 + ATB_MAXBLOCKS + ATB_MAXUNITS) * ATB_PSTRIDE * sizeof(float) + 256;
 }
 
 extern "C" size_t eqd_atb_partial_bytes(const EqdAtbJob* jobs, int njobs) {
