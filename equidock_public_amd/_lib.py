@@ -170,8 +170,11 @@ _ctx = {}
 
 
 def exec_ctx(device):
-    """Per-device execution context (auxiliary streams + events) of the C library, created once."""
-    if os.environ.get('EQD_SERIAL') == '1':
+    """Execution context of the C library (an auxiliary stream on which the forward's attention kernel runs beside the
+    edge-message kernel).  Off by default: with the current kernels one stream measured faster at every workload
+    (B 4 274 vs 4 128 pairs/s, C 5 894 vs 5 810, E 440 vs 433) - the event fork/join costs more than the overlap
+    gains.  EQD_FORK=1 turns it on."""
+    if os.environ.get('EQD_FORK') != '1':
         return C.c_void_p(0)
     key = (id(_lib), str(device))
     if key not in _ctx:

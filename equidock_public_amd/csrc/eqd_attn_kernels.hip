@@ -58,16 +58,10 @@ __device__ __forceinline__ void tile_load(TileRegs<DB, FAST>& R, const float* __
             for (int j = 0; j < 8; ++j) R.q[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     } else {
-        if (nvalid > 0) {       // unpredicated: clamp the element index, zero afterwards (see the FAST branch)
 #pragma unroll
-            for (int j = 0; j < AttnCfg<DB>::NL; ++j) {
-                const int i = lane + 64 * j;
-                const float v = base[i < nvalid ? i : nvalid - 1];
-                R.v[j] = i < nvalid ? v : 0.f;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < AttnCfg<DB>::NL; ++j) R.v[j] = 0.f;
+        for (int j = 0; j < AttnCfg<DB>::NL; ++j) {
+            const int i = lane + 64 * j;
+            R.v[j] = i < nvalid ? base[i] : 0.f;
         }
     }
 }
@@ -102,10 +96,9 @@ __device__ __forceinline__ void block_tile_stage(const float* __restrict__ M, in
     const float* __restrict__ base = M + (size_t)r0 * d;
     float v[10];
 #pragma unroll
-    for (int j = 0; j < 10; ++j) {       // unpredicated (nvalid >= 1: a block has at least one row)
+    for (int j = 0; j < 10; ++j) {
         const int i = t + 256 * j;
-        const float x = base[i < nvalid ? i : nvalid - 1];
-        v[j] = i < nvalid ? x : 0.f;
+        v[j] = i < nvalid ? base[i] : 0.f;
     }
     int row = t / d, col = t - row * d;
 #pragma unroll
@@ -378,20 +371,17 @@ __device__ __forceinline__ void attn_bwd_q_body(AttnBwdSmem<DB>& sm, const EqdGr
     } else {
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
-            const size_t ro = (size_t)(qv[nb] ? rowq[nb] : b1 - 1) * d;
-            float a[KS], b[KS];
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {       // unpredicated, clamped
-                const int kk = 4 * ks + g;
-                a[ks] = d_out[ro + (kk < d ? kk : d - 1)];
-                b[ks] = out[ro + (kk < d ? kk : d - 1)];
-            }
             float s = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) s += (qv[nb] && 4 * ks + g < d) ? a[ks] * b[ks] : 0.f;
+            for (int ks = 0; ks < KS; ++ks) {
+                const int kk = 4 * ks + g;
+                if (qv[nb] && kk < d) {
+                    const size_t o = (size_t)rowq[nb] * d + kk;
+                    s += d_out[o] * out[o];
+                }
+            }
             dl[nb] = s;
-            const float l = lse[qv[nb] ? rowq[nb] : b1 - 1];
-            lq[nb] = qv[nb] ? l : 0.f;
+            lq[nb] = qv[nb] ? lse[rowq[nb]] : 0.f;
         }
         zero_fill(Qt, C::TILE, t, EQD_BLOCK);
         zero_fill(Gt, C::TILE, t, EQD_BLOCK);

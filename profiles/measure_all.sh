@@ -10,6 +10,6 @@ DB=$(find /tmp/prof -name "*.db" | head -1)
 python $R/profiles/summarize.py $DB $R/gpurun_out/r01_n.md "round 1 (n): end-of-round state, workload B (8 pairs x 200/200, 8 layers, fp32)" "rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline" > $R/gpurun_out/r01_n.txt 2>&1
 python $R/profiles/timeline.py $DB > $R/gpurun_out/r01_n_tl.txt 2>&1
 for W in B C; do for CNT in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/pmc; EQD_SERIAL=1 rocprofv3 --kernel-trace --pmc $CNT -d /tmp/pmc -o p -- python $R/bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > /tmp/pmc_$W_$CNT.log 2>&1
+  rm -rf /tmp/pmc; rocprofv3 --kernel-trace --pmc $CNT -d /tmp/pmc -o p -- python $R/bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > /tmp/pmc_$W_$CNT.log 2>&1
   python $R/profiles/pmcstats.py $(find /tmp/pmc -name "*.db" | head -1) k_edge > $R/gpurun_out/pmc_${W}_${CNT}.json 2>&1
 done; done

@@ -75,6 +75,13 @@ def test_model_bf16_mode(dev, name):
     pc.check_model_bf16(dev, name)
 
 
+def test_model_forked_attention_stream(dev, monkeypatch):
+    """EQD_FORK=1: the forward's attention kernel on the library's auxiliary stream (off by default)"""
+    from tests import parity_common as pc
+    monkeypatch.setenv('EQD_FORK', '1')
+    pc.check_model_case(dev, 'D_degraded3')
+
+
 def test_flat_grads(dev):
     from tests import parity_common as pc
     pc.check_flat_grads_equal_autograd(dev)

@@ -67,6 +67,11 @@ def test_model_bf16_mode():
     pc.check_model_bf16(DEV, 'D_degraded3')
 
 
+def test_model_forked_attention_stream(monkeypatch):
+    monkeypatch.setenv('EQD_FORK', '1')
+    pc.check_model_case(DEV, 'D_degraded3')
+
+
 def test_flat_grads():
     pc.check_flat_grads_equal_autograd(DEV)
 
