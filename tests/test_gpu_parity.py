@@ -120,6 +120,39 @@ def test_model_vs_oracle_config_b(dev):
         pc.grad_close(p.grad, leaves[k].grad, what=f'config-B grad {k}')
 
 
+def test_big_batch_equals_small_batches(dev):
+    """Config C regime (> 16 384 nodes: 32-row workgroups in the row kernels, several super-tiles per workgroup in the
+    edge backward, capped AtB parts): pairs are independent, so outputs must equal those of the same pairs run in
+    batches of 4 (different kernel decompositions), and the gradient of the summed loss must equal the sum."""
+    from equidock_public_amd import graph as G, synthetic
+    from oracle import iegmn_port as port
+    from tests import parity_common as pc
+    args = port.default_args(iegmn_n_lays=3, skip_weight_h=0.75)
+    sd = port.init_state_dict(args, seed=9)
+    net = pc.build_model(args, sd, dev)
+    sizes = [(180 + 7 * (i % 5), 200 - 3 * (i % 7)) for i in range(46)]
+    pairs = synthetic.make_pairs(sizes, 77)
+    assert sum(a + b for a, b in sizes) > 16384
+
+    def run(ps):
+        g = G.batch_pairs(ps).to(dev)
+        for p in net.parameters():
+            p.grad = None
+        lig, Yl, Yr, T, b = net.forward_batched(g)
+        (lig.square().sum() * 1e-3 + Yl.square().sum() * 1e-3 + Yr.square().sum() * 1e-3).backward()
+        return [t.detach().cpu() for t in (lig, Yl, Yr, T, b)], {k: p.grad.detach().cpu().clone() for k, p in net.named_parameters()}
+    big, gbig = run(pairs)
+    parts, gsum = [], None
+    for i in range(0, len(pairs), 4):
+        o, gr = run(pairs[i:i + 4])
+        parts.append(o)
+        gsum = gr if gsum is None else {k: gsum[k] + gr[k] for k in gr}
+    for j, nm in enumerate(('lig', 'Yl', 'Yr', 'T', 'b')):
+        pc.close(big[j], torch.cat([p[j] for p in parts], 0), tol=1e-4, what=f'big batch vs small batches: {nm}')
+    for k in gbig:
+        pc.grad_close(gbig[k], gsum[k], what=f'big batch vs small batches: grad {k}')
+
+
 def test_large_complex_runs(dev):
     """Stress shape (one 2000 + 2000 residue pair, 2 layers): finite outputs, valid rotation."""
     from equidock_public_amd import graph as G, synthetic
