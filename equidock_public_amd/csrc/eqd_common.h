@@ -208,6 +208,7 @@ struct EqdChainJob {
     int out_local;                // >= 0: keep the result in this LDS tile (0..3)
     int type;                     // 0 linear; 1 LeakyReLU->LayerNorm backward (see chain_lnbwd)
     float* aux;                   // type 1: per-workgroup partial sums [blocks][256]
+    int prefetch_next;            // filled by eqd_launch_rowchain: linear job whose first step is fetched early, or -1
 };
 struct EqdChainArg {
     EqdChainJob j[EQD_CHAIN_MAXJOBS];

@@ -208,9 +208,14 @@ __device__ __forceinline__ void lin_mma(f32x4 (&acc)[RT][2], f32x4 (&acc2)[RT][2
 // One linear job on rows row0 .. row0 + 16 RT - 1.  src_local[i] >= 0: source i is the LDS tile Lb[rt][src_local[i]]
 // ([16][LIN_S], written by an earlier job of the chain; K <= 80); out_local >= 0: the result is also left in
 // Lb[rt][out_local].  Must be called by all 256 threads of the workgroup.
+// RA / have_first / has_next: a row chain hands the registers of this job's first step in already loaded (have_first)
+// and names the next linear job (Jn, its LDS-source flags src_local_n), whose first step is fetched into RA before this
+// job's epilogue - otherwise every job of a chain starts with a fully exposed memory round trip.
 template <int RT>
 __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const int* __restrict__ src_local, int out_local,
-                                            LinSmem<RT>& sm, float (*Lb)[LIN_LOCALS][16 * LIN_S], int row0) {
+                                            LinSmem<RT>& sm, float (*Lb)[LIN_LOCALS][16 * LIN_S], int row0,
+                                            LinRegs<RT>& RA, bool have_first, bool has_next, const EqdLinJob& Jn,
+                                            const int* __restrict__ src_local_n) {
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int l15 = lane & 15, g = lane >> 4;
@@ -242,7 +247,7 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const int* __res
         for (int i = 0; i < 2; ++i) acc[rt][i] = acc2[rt][i] = f4zero();
 
     // ---- pipelined (source, K chunk) steps: the loads of step i + 2 are issued while step i is multiplied ----
-    LinRegs<RT> RA, RB;
+    LinRegs<RT> RB;
     int tr_i = 0;
     (void)tr_i;
     auto is_local = [&](int si) { return src_local && src_local[si] >= 0; };
@@ -277,7 +282,7 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const int* __res
     LinStep cur = lin_first(J);
     LinStep nx = lin_next(J, cur);
     LIN_TR(tr_i++);
-    lin_load<RT>(J, J.s[0], is_local(0), cur, row0, t, RA);
+    if (!have_first) lin_load<RT>(J, J.s[0], is_local(0), cur, row0, t, RA);
     if (nx.s < J.nsrc) lin_load<RT>(J, J.s[nx.s], is_local(nx.s), nx, row0, t, RB);
     LIN_TR(tr_i++);
     while (cur.s < J.nsrc) {
@@ -292,6 +297,7 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const int* __res
         nx = n2;
     }
 
+    if (has_next) lin_load<RT>(Jn, Jn.s[0], src_local_n && src_local_n[0] >= 0, lin_first(Jn), row0, t, RA);
     // ---- epilogue in F-layout: feature f = 16 mb + 4 g + r, row = row0 + 16 rt + l15 -----------------------------
     float4 bs[2], lgv[2], lbv[2];
 #pragma unroll

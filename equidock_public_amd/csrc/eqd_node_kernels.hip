@@ -52,7 +52,8 @@ __global__ __launch_bounds__(EQD_BLOCK, 2) void k_linear(LinJobsArg jobs) {
     const int row0 = (int)blockIdx.x * 16 * RT;
     if (row0 >= J.rows) return;      // uniform for the whole workgroup
     EQD_TR_WG();
-    linear_tile<RT>(J, nullptr, -1, sm, nullptr, row0);
+    LinRegs<RT> RA;
+    linear_tile<RT>(J, nullptr, -1, sm, nullptr, row0, RA, false, false, J, nullptr);
     EQD_TR_WG_END();
 }
 // 16-row tiles per workgroup: one at DB5-sized batches (3 200 rows: latency matters, spread over the CUs), two
@@ -146,16 +147,26 @@ __global__ __launch_bounds__(EQD_BLOCK, 2) void k_rowchain(EqdChainArg A) {
     __shared__ __attribute__((aligned(16))) float Lb[RT][LIN_LOCALS][16 * LIN_S];
     __shared__ float red[EQD_WAVES][256];
     const int row0 = (int)blockIdx.x * 16 * RT;
+    EQD_TR_WG();
+    EQD_TR(200);
     for (int i = threadIdx.x; i < RT * LIN_LOCALS * 16 * LIN_S; i += EQD_BLOCK) (&Lb[0][0][0])[i] = 0.f;
     __syncthreads();
+    LinRegs<RT> RA;
+    bool have = false;
     for (int jj = 0; jj < A.njobs; ++jj) {
         const EqdChainJob& C = A.j[jj];
-        if (C.type == 0)
-            linear_tile<RT>(C.lin, C.src_local, C.out_local, sm, Lb, row0);
-        else
+        if (C.type == 0) {
+            const int nj = C.prefetch_next;      // next linear job whose first step may be fetched early, or -1
+            const EqdChainJob& Cn = A.j[nj >= 0 ? nj : jj];
+            linear_tile<RT>(C.lin, C.src_local, C.out_local, sm, Lb, row0, RA, have, nj >= 0, Cn.lin, Cn.src_local);
+            have = nj >= 0;
+        } else {
             chain_lnbwd<RT>(C, Lb, red, row0);
+        }
         __syncthreads();
+        EQD_TR(201 + jj);      // job boundaries (phase-trace experiments only)
     }
+    EQD_TR_WG_END();
 }
 
 #ifdef EQD_TRACE
@@ -203,6 +214,25 @@ int eqd_launch_rowchain(const EqdChainJob* jobs, int njobs, int rows, hipStream_
             }
     }
     arg.njobs = njobs;
+    // prefetch_next[i]: the next linear job n whose first step may be loaded before job i's epilogue: its first
+    // source is an LDS tile, or global data that none of the jobs i .. n-1 writes
+    for (int i = 0; i < njobs; ++i) {
+        arg.j[i].prefetch_next = -1;
+        if (jobs[i].type != 0) continue;
+        int n = i + 1;
+        while (n < njobs && jobs[n].type != 0) ++n;
+        if (n >= njobs) continue;
+        bool ok = true;
+        if (jobs[n].src_local[0] < 0) {
+            const EqdLinSrc& S0 = jobs[n].lin.s[0];
+            for (int m = i; m < n && ok; ++m) {
+                const float* outs[2] = {jobs[m].lin.Y, jobs[m].lin.pre_ln};
+                for (int q = 0; q < 2; ++q)
+                    if (outs[q] && (outs[q] == S0.X || outs[q] == S0.mask)) ok = false;
+            }
+        }
+        if (ok) arg.j[i].prefetch_next = n;
+    }
     for (int i = 0; i < njobs; ++i)
         if (jobs[i].out_local >= LIN_LOCALS) {
             eqd_set_error("eqd_launch_rowchain: LDS tile index %d >= %d", jobs[i].out_local, LIN_LOCALS);
