@@ -30,8 +30,9 @@ struct AttnCfg {
 
 template <int DB, bool FAST>
 struct TileRegs {
-    float v[FAST ? 1 : 8 * DB];
-    float4 q[FAST ? 8 : 1];
+    float4 q[FAST ? 8 : 1];            // d == 64: row (lane >> 4) + 4 j, columns 4 (lane & 15) ..
+    f32x4 qv[FAST ? 1 : 2 * DB];       // any d: elements 4 (lane + 64 j) .. + 3 of the contiguous [rows][d] slab (raw)
+    int nvalid;
 };
 
 // rows r0 .. r0+31 of M (row stride d), clipped at r1 -> registers (zeros beyond)
@@ -42,6 +43,7 @@ __device__ __forceinline__ void tile_load(TileRegs<DB, FAST>& R, const float* __
     nrows = nrows < 0 ? 0 : (nrows > 32 ? 32 : nrows);
     const int nvalid = nrows * d;
     const float* __restrict__ base = M + (size_t)r0 * d;
+    R.nvalid = nvalid;
     if (FAST) {
         // unpredicated (a predicated load is an exec-masked branch with a wait behind it): rows beyond the range are
         // fetched from its last row and zeroed; a tile entirely beyond the range is not fetched at all (wave-uniform)
@@ -58,10 +60,14 @@ __device__ __forceinline__ void tile_load(TileRegs<DB, FAST>& R, const float* __
             for (int j = 0; j < 8; ++j) R.q[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     } else {
+        // the 32 rows are one contiguous slab of 32 d floats: 16-byte vectors (4-byte alignment is enough), all in
+        // flight at once; tail / beyond-the-range handling in ld4u_raw / ld4u_fix
+        if (nvalid > 0) {
 #pragma unroll
-        for (int j = 0; j < AttnCfg<DB>::NL; ++j) {
-            const int i = lane + 64 * j;
-            R.v[j] = i < nvalid ? base[i] : 0.f;
+            for (int j = 0; j < 2 * DB; ++j) {
+                const int e = 4 * (lane + 64 * j);
+                R.qv[j] = ld4u_raw(base + (e < nvalid ? e : 0), nvalid - e, M);
+            }
         }
     }
 }
@@ -75,14 +81,20 @@ __device__ __forceinline__ void tile_store(const TileRegs<DB, FAST>& R, float* _
             *(float4*)&L[(i4 >> 4) * DS + 4 * (i4 & 15)] = R.q[j];
         }
     } else {
-        int row = lane / d, col = lane - row * d;
 #pragma unroll
-        for (int j = 0; j < AttnCfg<DB>::NL; ++j) {
-            if (row < 32) L[row * DS + col] = R.v[j];
-            col += 64;
-            while (col >= d) {
-                col -= d;
-                ++row;
+        for (int j = 0; j < 2 * DB; ++j) {
+            const int e = 4 * (lane + 64 * j);
+            const float4 f = R.nvalid > 0 ? ld4u_fix(R.qv[j], R.nvalid - e) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float vv[4] = {f.x, f.y, f.z, f.w};
+            int row = e / d, col = e - row * d;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (col >= d) {
+                    col -= d;
+                    ++row;
+                }
+                if (row < 32) L[row * DS + col] = vv[u];
+                ++col;
             }
         }
     }
@@ -92,22 +104,28 @@ __device__ __forceinline__ void block_tile_stage(const float* __restrict__ M, in
                                                  float* __restrict__ L, int t) {
     int nrows = r1 - r0;
     nrows = nrows > 32 ? 32 : nrows;
-    const int nvalid = nrows * d;
+    const int nvalid = nrows * d;       // >= d >= 4: a block has at least one row
     const float* __restrict__ base = M + (size_t)r0 * d;
-    float v[10];
+    f32x4 v[3];                         // 3 x 256 vectors >= 32 x 80 floats
 #pragma unroll
-    for (int j = 0; j < 10; ++j) {
-        const int i = t + 256 * j;
-        v[j] = i < nvalid ? base[i] : 0.f;
+    for (int j = 0; j < 3; ++j) {
+        const int e = 4 * (t + 256 * j);
+        v[j] = ld4u_raw(base + (e < nvalid ? e : 0), nvalid - e, M);
     }
-    int row = t / d, col = t - row * d;
 #pragma unroll
-    for (int j = 0; j < 10; ++j) {
-        if (row < 32) L[row * DS + col] = v[j];
-        col += 256;
-        while (col >= d) {
-            col -= d;
-            ++row;
+    for (int j = 0; j < 3; ++j) {
+        const int e = 4 * (t + 256 * j);
+        const float4 f = ld4u_fix(v[j], nvalid - e);
+        const float vv[4] = {f.x, f.y, f.z, f.w};
+        int row = e / d, col = e - row * d;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (col >= d) {
+                col -= d;
+                ++row;
+            }
+            if (row < 32) L[row * DS + col] = vv[u];
+            ++col;
         }
     }
 }
