@@ -20,7 +20,11 @@
 
 #define LIN_S 84    /* LDS row stride: 21 x 16 B (aligned b128), 20 l15 + g hits 64 different banks */
 #define LIN_LOCALS 3
+#ifdef EQD_TRACE_FINE      /* per-step stamps perturb the pipeline; the chain experiment only stamps job boundaries */
 #define LIN_TR(i) EQD_TR(i)
+#else
+#define LIN_TR(i) do { } while (0)
+#endif
 
 template <int RT>
 struct LinRegs {

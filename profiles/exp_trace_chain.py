@@ -30,8 +30,3 @@ if __name__ == '__main__':
     for i, n in enumerate(names):
         print(f'   {ck[i + 1] - ck[i]:7d}  {n}')
     print(f'   total {ck[6] - ck[0]} ticks')
-    # slots 0.. hold the phase stamps of the LAST linear job of that chain (d h0: K = 69 -> one 64-wide + one 5-wide step)
-    st = [buf[2 * s] for s in range(0, 13)]
-    lab = ['prologue (epilogue operands + first loads issued)'] + [f'step {k}: {n}' for k in range(2) for n in ('wait+top', 'store', 'sync', 'next loads', 'mma')] + ['next-job prefetch + epilogue']
-    for i, n in enumerate(lab):
-        print(f'   {st[i + 1] - st[i]:7d}  {n}')

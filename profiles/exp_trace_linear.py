@@ -7,10 +7,11 @@ sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, 'profiles', '_exp', 'libeqd_trace.so')
 
 
-def build():
+def build(fine='--fine' in sys.argv):
+    """--fine additionally stamps every pipeline step inside linear_tile (this script's own experiment)"""
     srcs = sorted(glob.glob(os.path.join(ROOT, 'equidock_public_amd', 'csrc', '*.hip')))
     cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-DEQD_TRACE', '-fgpu-rdc',
-           '-shared', '-o', OUT] + srcs
+           '-shared', '-o', OUT] + (['-DEQD_TRACE_FINE'] if fine else []) + srcs
     subprocess.run(cmd, check=True)
 
 
