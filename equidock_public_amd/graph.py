@@ -319,9 +319,33 @@ class PackedGraph:
             .to(torch.float32).contiguous()
 
     def to(self, device):
-        for k, v in list(self.__dict__.items()):
-            if torch.is_tensor(v):
-                setattr(self, k, v.to(device))
-        self.device = torch.device(device)
+        """Move the layout to `device`.  All tensors of one dtype travel as ONE buffer (64-byte aligned slices; pinned
+        staging when the source is host memory and the target a GPU), so a batch that was packed in a DataLoader worker
+        (collate_fn: batch_pairs(...).pack()) costs a handful of H->D copies instead of one per field."""
+        device = torch.device(device)
+        items = [(k, v) for k, v in self.__dict__.items() if torch.is_tensor(v)]
+        by_dtype = {}
+        for k, v in items:
+            by_dtype.setdefault(v.dtype, []).append((k, v))
+        for dt, group in by_dtype.items():
+            if len(group) == 1 or any(v.device != group[0][1].device for _, v in group):
+                for k, v in group:
+                    setattr(self, k, v.to(device))
+                continue
+            esz = group[0][1].element_size()
+            align = max(1, 64 // esz)
+            offs, total = [], 0
+            for _, v in group:
+                offs.append(total)
+                total += (v.numel() + align - 1) // align * align
+            flat = torch.empty(total, dtype=dt, device=group[0][1].device)
+            for (k, v), o in zip(group, offs):
+                flat[o:o + v.numel()] = v.reshape(-1)
+            if device.type == 'cuda' and flat.device.type == 'cpu':
+                flat = flat.pin_memory()
+            flat = flat.to(device, non_blocking=True)
+            for (k, v), o in zip(group, offs):
+                setattr(self, k, flat[o:o + v.numel()].view(v.shape))
+        self.device = device
         self._cstruct = None
         return self

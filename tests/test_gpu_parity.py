@@ -153,6 +153,25 @@ def test_big_batch_equals_small_batches(dev):
         pc.grad_close(gbig[k], gsum[k], what=f'big batch vs small batches: grad {k}')
 
 
+def test_pack_on_host_then_move(dev):
+    """collate-in-a-worker pattern: batch + pack on the host, one move to the GPU, same outputs as packing on the GPU"""
+    from equidock_public_amd import graph as G, synthetic
+    from oracle import iegmn_port as port
+    from tests import parity_common as pc
+    args = port.default_args(iegmn_n_lays=2, skip_weight_h=0.5)
+    net = pc.build_model(args, port.init_state_dict(args, seed=5), dev)
+    pairs = synthetic.make_pairs([(50, 61), (33, 47), (80, 20)], 5)
+    g_host = G.batch_pairs(pairs)
+    g_host.pack()                       # CPU layout (what a DataLoader worker would produce)
+    g_moved = g_host.to(dev)
+    assert g_moved.pack().he_bf16.is_cuda and g_moved.pack().he_bf16.data_ptr() % 16 == 0
+    with torch.no_grad():
+        a = net.forward_batched(g_moved)
+        b = net.forward_batched(G.batch_pairs(pairs).to(dev))
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
 def test_large_complex_runs(dev):
     """Stress shape (one 2000 + 2000 residue pair, 2 layers): finite outputs, valid rotation."""
     from equidock_public_amd import graph as G, synthetic
