@@ -257,16 +257,21 @@ class PackedGraph:
         csc_ptr = np.concatenate([[0], np.cumsum(np.bincount(src, minlength=n))]).astype(np.int32)
 
         # node-aligned edge tiles
-        tiles = [0]
-        cur_e, cur_n = 0, 0
-        for i in range(n):
-            di = int(deg[i])
-            if cur_n > 0 and (cur_e + di > TILE_EDGES or cur_n + 1 > TILE_NODES):
+        # greedy: a tile takes nodes while it stays within TILE_EDGES edges and TILE_NODES nodes.  The end of the tile
+        # that starts at node i is computed for every i at once (searchsorted on the edge prefix sums); the tiling is
+        # then the chain 0 -> nxt[0] -> nxt[nxt[0]] ... (one list lookup per tile instead of Python work per node)
+        if n:
+            cs = rowptr.astype(np.int64)
+            nxt = np.searchsorted(cs, cs[:-1] + TILE_EDGES, side='right') - 1
+            idx = np.arange(n, dtype=np.int64)
+            nxt = np.minimum(np.minimum(nxt, idx + TILE_NODES), n)
+            nxt = np.maximum(nxt, idx + 1).tolist()
+            tiles, i = [0], 0
+            while i < n:
+                i = nxt[i]
                 tiles.append(i)
-                cur_e, cur_n = 0, 0
-            cur_e += di
-            cur_n += 1
-        tiles.append(n)
+        else:
+            tiles = [0, 0]
         tile_node = np.asarray(tiles, dtype=np.int32)
         p.n_tiles = len(tiles) - 1
 
