@@ -162,8 +162,11 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_fwd(EqdGraph G, int d, const
     __shared__ __attribute__((aligned(16))) float Qt[C::TILE];
     __shared__ __attribute__((aligned(16))) float Kt[EQD_WAVES][C::TILE];
     __shared__ __attribute__((aligned(16))) float Vt[EQD_WAVES][C::TILE];
-    __shared__ float red[EQD_WAVES][C::RED];
     __shared__ float sm_m[EQD_WAVES][32], sm_l[EQD_WAVES][32];
+    // the merge buffer aliases the waves' own K tiles (C::RED <= C::TILE; written only after the wave's last tile):
+    // 79 KB of LDS instead of 111 KB, i.e. two workgroups per CU, so that one wave's softmax overlaps another's MFMAs
+    float (*red)[C::TILE] = Kt;
+    static_assert(C::RED <= C::TILE, "merge buffer must fit a K tile");
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const int item = blockIdx.x;
@@ -273,6 +276,7 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_fwd(EqdGraph G, int d, const
     }
     EQD_TR(9);
     // ---- merge the 4 waves' partial softmax states -----------------------------------------------
+    wave_lds_fence();       // this wave's reads of its K tile are done before it is overwritten
 #pragma unroll
     for (int db = 0; db < DB; ++db)
 #pragma unroll
