@@ -23,6 +23,14 @@
 // (row stride 16*DB + 4 floats); MFMA operands are read from LDS.  One HBM/L2 round trip per tile.
 #include "eqd_common.h"
 
+// The backward passes recompute p = exp(S - lse) (arguments <= 0 up to rounding) with the hardware exponential
+// (v_exp_f32 on x log2 e: ~4e-6 relative error at |x| ~ 80, far inside the gradient tolerance) - 32 of them per
+// 32 x 32 score tile otherwise cost as many VALU cycles as a third of the tile's MFMAs.  The forward keeps expf.
+#ifndef EQD_NATIVE_EXP
+#define EQD_NATIVE_EXP(x) __expf(x)
+#endif
+__device__ __forceinline__ float bwd_exp(float x) { return EQD_NATIVE_EXP(x); }
+
 template <int DB>
 struct AttnCfg {
     enum { DS = 16 * DB + 4, KS = 4 * DB, NL = 8 * DB, TILE = 32 * (16 * DB + 4), RED = DB * 2 * 4 * 64 };
@@ -435,8 +443,10 @@ __device__ __forceinline__ void attn_bwd_q_body(AttnBwdSmem<DB>& sm, const EqdGr
         tile_store<DB, FAST>(rk, Kt[wave], d, lane);
         tile_store<DB, FAST>(rv, Vt[wave], d, lane);
         wave_lds_fence();
+        EQD_TR(30);
         tile_load<DB, FAST>(rk, k, d, kt + 32 * EQD_WAVES, o1, lane);
         tile_load<DB, FAST>(rv, v, d, kt + 32 * EQD_WAVES, o1, lane);
+        EQD_TR(31);
         f32x4 S[2][2], dP[2][2];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
@@ -454,6 +464,7 @@ __device__ __forceinline__ void attn_bwd_q_body(AttnBwdSmem<DB>& sm, const EqdGr
                 dP[mb][0] = mfma4(b, dof[0][ks], dP[mb][0]);
                 dP[mb][1] = mfma4(b, dof[1][ks], dP[mb][1]);
             }
+        EQD_TR(32);
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -461,9 +472,10 @@ __device__ __forceinline__ void attn_bwd_q_body(AttnBwdSmem<DB>& sm, const EqdGr
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = kt + 16 * mb + 4 * g + r;
-                    const float p = key < o1 ? expf(S[mb][nb][r] - lq[nb]) : 0.f;
+                    const float p = key < o1 ? bwd_exp(S[mb][nb][r] - lq[nb]) : 0.f;
                     S[mb][nb][r] = p * (dP[mb][nb][r] - dl[nb]);
                 }
+        EQD_TR(33);
 #pragma unroll
         for (int mbk = 0; mbk < 2; ++mbk)
 #pragma unroll
@@ -474,6 +486,7 @@ __device__ __forceinline__ void attn_bwd_q_body(AttnBwdSmem<DB>& sm, const EqdGr
                     dQ[db][0] = mfma4(a, S[mbk][0][r], dQ[db][0]);
                     dQ[db][1] = mfma4(a, S[mbk][1][r], dQ[db][1]);
                 }
+        EQD_TR(34);
     }
 #pragma unroll
     for (int db = 0; db < DB; ++db)
@@ -632,7 +645,7 @@ __device__ __forceinline__ void attn_bwd_kv_body(AttnBwdSmem<DB>& sm, const EqdG
                 const bool ok = qt + 16 * mb + 4 * g + r < o1;
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb) {
-                    const float p = ok ? expf(S[mb][nb][r] - lc[mb][r]) : 0.f;
+                    const float p = ok ? bwd_exp(S[mb][nb][r] - lc[mb][r]) : 0.f;
                     S[mb][nb][r] = p;
                     dP[mb][nb][r] = p * (dP[mb][nb][r] - dc[mb][r]);
                 }
