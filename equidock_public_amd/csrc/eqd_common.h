@@ -81,6 +81,18 @@ __device__ __forceinline__ float4 ld4u_fix(f32x4 v, int n) {
     r.w = n > 3 ? v[3] : 0.f;
     return r;
 }
+// Kernels that take a large by-value descriptor (row chains: 3.3 KB of job descriptions) copy it from the kernarg
+// segment into LDS once, with vector loads: reading the fields on demand through scalar loads costs a scalar-cache /
+// L2 round trip (500+ clocks) at every job boundary and pipeline step of a workgroup that has nothing else to do.
+#ifndef EQD_KERNARG_PTR
+#define EQD_KERNARG_PTR(first_param) ((const void*)__builtin_amdgcn_kernarg_segment_ptr())
+#endif
+template <class T>
+__device__ __forceinline__ void kernarg_to_lds(T& dst, const void* kernarg, int byte_offset) {
+    const int* __restrict__ src = (const int*)((const char*)kernarg + byte_offset);
+    for (int i = threadIdx.x; i < (int)(sizeof(T) / 4); i += blockDim.x) ((int*)&dst)[i] = src[i];
+}
+
 // ---- bf16 MFMA path (edge-message kernels, storage_bf16 mode) ---------------------------------------------------
 // v_mfma_f32_16x16x16_bf16: lane (i = lane & 15, g = lane >> 4) supplies A[i][4g..4g+3] and B[4g..4g+3][i] as 4 bf16
 // and receives D[4g + r][i] - the same D layout as the fp32 instruction, so with features on the M axis an output

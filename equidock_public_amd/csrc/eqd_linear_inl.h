@@ -89,9 +89,14 @@ __device__ __forceinline__ void lin_load(const EqdLinJob& J, const EqdLinSrc& S,
             }
         } else {          // transposed: thread: k = tr + 16 j, weight rows m = 4 tc .. (tail / beyond M: ld4u)
             const float* __restrict__ Wb = S.W + (size_t)c.k0 * S.w_cs;
+            if (M >= 64) {                  // every 4-wide row segment below 64 is complete: plain vector loads
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                R.w[j] = ld4u_raw(Wb + (size_t)(tr + 16 * j) * S.w_cs + 4 * tc, M - 4 * tc, S.W);
+                for (int j = 0; j < 4; ++j) R.w[j] = *(const f4v*)(Wb + (size_t)(tr + 16 * j) * S.w_cs + 4 * tc);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    R.w[j] = ld4u_raw(Wb + (size_t)(tr + 16 * j) * S.w_cs + 4 * tc, M - 4 * tc, S.W);
+            }
             if (M > 64) {                   // rows 64 .. 79: k = t >> 2, m = 64 + 4 (t & 3)
                 const int m = 64 + 4 * (t & 3);
                 R.w[4] = ld4u_raw(Wb + (size_t)(t >> 2) * S.w_cs + m, M - m, S.W);
@@ -147,7 +152,11 @@ __device__ __forceinline__ void lin_store(const EqdLinJob& J, const EqdLinSrc& S
         } else {       // the vector runs along m: transpose on the way in (4-way bank conflict, 16 short stores)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float4 v = ld4u_fix(R.w[j], M - 4 * tc);
+                float4 v;
+                if (M >= 64)
+                    v = make_float4(R.w[j][0], R.w[j][1], R.w[j][2], R.w[j][3]);
+                else
+                    v = ld4u_fix(R.w[j], M - 4 * tc);
                 const int k = tr + 16 * j;
                 Wl[(4 * tc + 0) * LIN_S + k] = v.x;
                 Wl[(4 * tc + 1) * LIN_S + k] = v.y;
@@ -219,7 +228,9 @@ template <int RT>
 __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const int* __restrict__ src_local, int out_local,
                                             LinSmem<RT>& sm, float (*Lb)[LIN_LOCALS][16 * LIN_S], int row0,
                                             LinRegs<RT>& RA, bool have_first, bool has_next, const EqdLinJob& Jn,
-                                            const int* __restrict__ src_local_n) {
+                                            const int* __restrict__ src_local_n, int trace_slot = 255) {
+    (void)trace_slot;
+    EQD_TR(trace_slot);
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int l15 = lane & 15, g = lane >> 4;
@@ -285,6 +296,7 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const int* __res
     };
     LinStep cur = lin_first(J);
     LinStep nx = lin_next(J, cur);
+    EQD_TR(trace_slot + 1);
     LIN_TR(tr_i++);
     if (!have_first) lin_load<RT>(J, J.s[0], is_local(0), cur, row0, t, RA);
     if (nx.s < J.nsrc) lin_load<RT>(J, J.s[nx.s], is_local(nx.s), nx, row0, t, RB);
@@ -301,14 +313,24 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const int* __res
         nx = n2;
     }
 
+    EQD_TR(trace_slot + 2);
     if (has_next) lin_load<RT>(Jn, Jn.s[0], src_local_n && src_local_n[0] >= 0, lin_first(Jn), row0, t, RA);
+    EQD_TR(trace_slot + 3);
     // ---- epilogue in F-layout: feature f = 16 mb + 4 g + r, row = row0 + 16 rt + l15 -----------------------------
+    // `plain`: M is a multiple of 4, so an owned 4-feature group is always complete - no tail handling, 16-byte stores
+    const bool plain = (M & 3) == 0;
     float4 bs[2], lgv[2], lbv[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        bs[i] = ld4u_fix(bias[i], nf[i]);
-        lgv[i] = ld4u_fix(lg[i], nf[i]);
-        lbv[i] = ld4u_fix(lb[i], nf[i]);
+        if (plain) {
+            bs[i] = make_float4(bias[i][0], bias[i][1], bias[i][2], bias[i][3]);
+            lgv[i] = make_float4(lg[i][0], lg[i][1], lg[i][2], lg[i][3]);
+            lbv[i] = make_float4(lb[i][0], lb[i][1], lb[i][2], lb[i][3]);
+        } else {
+            bs[i] = ld4u_fix(bias[i], nf[i]);
+            lgv[i] = ld4u_fix(lg[i], nf[i]);
+            lbv[i] = ld4u_fix(lb[i], nf[i]);
+        }
     }
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -355,27 +377,43 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const int* __res
             for (int i = 0; i < 2; ++i) {
                 const float gg[4] = {lgv[i].x, lgv[i].y, lgv[i].z, lgv[i].w};
                 const float be[4] = {lbv[i].x, lbv[i].y, lbv[i].z, lbv[i].w};
+                if (plain && nf[i] > 0 && J.pre_ln && rv)
+                    *(f4v*)&J.pre_ln[(size_t)rowi * J.ld_pre + 16 * mbs[i] + 4 * g] = f32x4{v[i][0], v[i][1], v[i][2], v[i][3]};
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (r < nf[i]) {
                         const int f = 16 * mbs[i] + 4 * g + r;
-                        if (J.pre_ln && rv) J.pre_ln[(size_t)rowi * J.ld_pre + f] = v[i][r];
+                        if (!plain && J.pre_ln && rv) J.pre_ln[(size_t)rowi * J.ld_pre + f] = v[i][r];
                         v[i][r] = (v[i][r] - mean) * rstd * gg[r] + be[r];
                     }
             }
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const float4 rr = ld4u_fix(res[rt][i], nf[i]);
+            float4 rr;
+            if (plain)
+                rr = make_float4(res[rt][i][0], res[rt][i][1], res[rt][i][2], res[rt][i][3]);
+            else
+                rr = ld4u_fix(res[rt][i], nf[i]);
             const float rs[4] = {rr.x, rr.y, rr.z, rr.w};
+            float y[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (r < nf[i]) {
-                    const int f = 16 * mbs[i] + 4 * g + r;
-                    const float y = J.alpha * v[i][r] + J.beta * rs[r];
-                    if (J.Y && rv) J.Y[(size_t)rowi * J.ldy + f] = y;
-                    if (out_local >= 0) Lb[rt][out_local][l15 * LIN_S + f] = y;
+            for (int r = 0; r < 4; ++r) y[r] = J.alpha * v[i][r] + J.beta * rs[r];
+            const int f0 = 16 * mbs[i] + 4 * g;
+            if (plain) {
+                if (nf[i] > 0) {
+                    const f32x4 yv = {y[0], y[1], y[2], y[3]};
+                    if (J.Y && rv) *(f4v*)&J.Y[(size_t)rowi * J.ldy + f0] = yv;
+                    if (out_local >= 0) *(f32x4*)&Lb[rt][out_local][l15 * LIN_S + f0] = yv;
                 }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r < nf[i]) {
+                        if (J.Y && rv) J.Y[(size_t)rowi * J.ldy + f0 + r] = y[r];
+                        if (out_local >= 0) Lb[rt][out_local][l15 * LIN_S + f0 + r] = y[r];
+                    }
+            }
         }
     }
     LIN_TR(tr_i++);

@@ -48,7 +48,10 @@ struct LinJobsArg {
 template <int RT>
 __global__ __launch_bounds__(EQD_BLOCK, 2) void k_linear(LinJobsArg jobs) {
     __shared__ LinSmem<RT> sm;
-    const EqdLinJob& J = jobs.j[blockIdx.y];
+    __shared__ __attribute__((aligned(16))) EqdLinJob Jl;      // this workgroup's job, copied out of the kernarg segment
+    kernarg_to_lds(Jl, EQD_KERNARG_PTR(jobs), (int)(blockIdx.y * sizeof(EqdLinJob)));
+    __syncthreads();
+    const EqdLinJob& J = Jl;
     const int row0 = (int)blockIdx.x * 16 * RT;
     if (row0 >= J.rows) return;      // uniform for the whole workgroup
     EQD_TR_WG();
@@ -142,7 +145,9 @@ __device__ __forceinline__ void chain_lnbwd(const EqdChainJob& C, float (*Lb)[LI
 }
 
 template <int RT>
-__global__ __launch_bounds__(EQD_BLOCK, 2) void k_rowchain(EqdChainArg A) {
+__global__ __launch_bounds__(EQD_BLOCK, 2) void k_rowchain(EqdChainArg A_) {
+    __shared__ __attribute__((aligned(16))) EqdChainArg A;      // job descriptions: kernarg segment -> LDS, once
+    kernarg_to_lds(A, EQD_KERNARG_PTR(A_), 0);
     __shared__ LinSmem<RT> sm;
     __shared__ __attribute__((aligned(16))) float Lb[RT][LIN_LOCALS][16 * LIN_S];
     __shared__ float red[EQD_WAVES][256];
@@ -158,7 +163,8 @@ __global__ __launch_bounds__(EQD_BLOCK, 2) void k_rowchain(EqdChainArg A) {
         if (C.type == 0) {
             const int nj = C.prefetch_next;      // next linear job whose first step may be fetched early, or -1
             const EqdChainJob& Cn = A.j[nj >= 0 ? nj : jj];
-            linear_tile<RT>(C.lin, C.src_local, C.out_local, sm, Lb, row0, RA, have, nj >= 0, Cn.lin, Cn.src_local);
+            linear_tile<RT>(C.lin, C.src_local, C.out_local, sm, Lb, row0, RA, have, nj >= 0, Cn.lin, Cn.src_local,
+                            210 + 4 * jj);
             have = nj >= 0;
         } else {
             chain_lnbwd<RT>(C, Lb, red, row0);

@@ -30,3 +30,7 @@ if __name__ == '__main__':
     for i, n in enumerate(names):
         print(f'   {ck[i + 1] - ck[i]:7d}  {n}')
     print(f'   total {ck[6] - ck[0]} ticks')
+    print('inside the linear jobs: prologue (epilogue operands requested, step list) | steps | next-job prefetch | epilogue + end sync')
+    for jj in (0, 1, 3, 4, 5):
+        b = [buf[2 * (210 + 4 * jj + i)] for i in range(4)]
+        print(f'   job {jj}: {b[1] - b[0]:6d} | {b[2] - b[1]:6d} | {b[3] - b[2]:6d} | {buf[2 * (201 + jj)] - b[3]:6d}')

@@ -73,6 +73,7 @@ void wave_barrier();
     hostsim::launch(dim3(grid), dim3(block), [&]() { kern(__VA_ARGS__); })
 
 static inline void __syncthreads() { hostsim::sync_block(); }
+#define EQD_KERNARG_PTR(first_param) ((const void*)&(first_param))   /* host: the by-value argument itself */
 #define EQD_NATIVE_EXP(x) expf(x)   /* the device build uses __expf (v_exp_f32) */
 static inline float __shfl_xor(float v, int m) { return hostsim::shfl_f(v, hostsim::lane_id() ^ m); }
 static inline int __shfl_xor(int v, int m) { return hostsim::shfl_i(v, hostsim::lane_id() ^ m); }
