@@ -65,12 +65,19 @@ extern __device__ long long eqd_trace_buf[1024];
 #define EQD_TR_WG_END() do { } while (0)
 #endif
 
+// Pointers that were read back from memory (descriptors copied to LDS) are "generic" to the compiler, and generic
+// accesses compile to flat_load / flat_store, which also go through the LDS aperture check and both wait counters.
+// Every such pointer in this library addresses HBM: EQD_GAS marks the access as global.
+#ifndef EQD_GAS
+#define EQD_GAS __attribute__((address_space(1)))
+#endif
+
 // Split in two so that a batch of loads can be issued back to back: ld4u_raw is ONE unconditional load
 // instruction; ld4u_fix (shift + zero fill, selects) runs later, when the data is consumed.
 typedef float f4v __attribute__((ext_vector_type(4), aligned(4)));
 __device__ __forceinline__ f32x4 ld4u_raw(const float* __restrict__ p, int n, const float* __restrict__ safe) {
     const int sh = (n > 0 && n < 4) ? 4 - n : 0;
-    return *(const f4v*)(n > 0 ? p - sh : safe);
+    return *(const EQD_GAS f4v*)(n > 0 ? p - sh : safe);
 }
 __device__ __forceinline__ float4 ld4u_fix(f32x4 v, int n) {
     const int sh = (n > 0 && n < 4) ? 4 - n : 0;
@@ -87,6 +94,25 @@ __device__ __forceinline__ float4 ld4u_fix(f32x4 v, int n) {
 #ifndef EQD_KERNARG_PTR
 #define EQD_KERNARG_PTR(first_param) ((const void*)__builtin_amdgcn_kernarg_segment_ptr())
 #endif
+// Values read back from that LDS copy are wave-uniform but live in VGPRs, which would turn every `if (J.act)` into an
+// exec-masked region; uni() moves them to SGPRs (v_readfirstlane) so that control flow on them is scalar again.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float uni(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+template <class T>
+__device__ __forceinline__ T* uni(T* p) {
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+    return (T*)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ EqdLinSrc uni(const EqdLinSrc& S) {
+    EqdLinSrc U;
+    U.X = uni(S.X); U.mask = uni(S.mask); U.W = uni(S.W);
+    U.ldx = uni(S.ldx); U.K = uni(S.K); U.w_rs = uni(S.w_rs); U.w_cs = uni(S.w_cs);
+    return U;
+}
 template <class T>
 __device__ __forceinline__ void kernarg_to_lds(T& dst, const void* kernarg, int byte_offset) {
     const int* __restrict__ src = (const int*)((const char*)kernarg + byte_offset);

@@ -42,36 +42,38 @@ struct LinStep {
 };
 __device__ __forceinline__ int lin_chunk(int rem) { return rem >= 64 ? 64 : (rem < 16 ? rem : 16); }
 __device__ __forceinline__ LinStep lin_first(const EqdLinJob& J) {
-    LinStep c = {0, 0, lin_chunk(J.s[0].K)};
+    LinStep c = {0, 0, lin_chunk(uni(J.s[0].K))};
     return c;
 }
 __device__ __forceinline__ LinStep lin_next(const EqdLinJob& J, LinStep c) {
-    if (c.s >= J.nsrc) return c;
+    const int nsrc = uni(J.nsrc);
+    if (c.s >= nsrc) return c;
     c.k0 += c.kc;
-    if (c.k0 >= J.s[c.s].K) {
+    if (c.k0 >= uni(J.s[c.s].K)) {
         c.s += 1;
         c.k0 = 0;
     }
-    c.kc = c.s < J.nsrc ? lin_chunk(J.s[c.s].K - c.k0) : 0;
+    c.kc = c.s < nsrc ? lin_chunk(uni(J.s[c.s].K) - c.k0) : 0;
     return c;
 }
 
 // ---- loads of one step into registers (nothing is waited for here) -------------------------------------
 template <int RT>
-__device__ __forceinline__ void lin_load(const EqdLinJob& J, const EqdLinSrc& S, bool local, LinStep c, int row0, int t,
+__device__ __forceinline__ void lin_load(const EqdLinJob& J, const EqdLinSrc& S_, bool local, LinStep c, int row0, int t,
                                          LinRegs<RT>& R) {
     const int tr = t >> 4, tc = t & 15;
+    const EqdLinSrc S = uni(S_);
     const bool kfast = (S.w_cs == 1);
-    const int M = J.M;
+    const int M = uni(J.M), rows = uni(J.rows);
     if (c.kc == 64) {
         if (!local) {
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
                 int row = row0 + 16 * rt + tr;
-                row = row < J.rows ? row : J.rows - 1;
+                row = row < rows ? row : rows - 1;
                 const size_t o = (size_t)row * S.ldx + c.k0 + 4 * tc;
-                R.x[rt] = *(const f4v*)(S.X + o);
-                if (S.mask) R.xm[rt] = *(const f4v*)(S.mask + o);
+                R.x[rt] = *(const EQD_GAS f4v*)(S.X + o);
+                if (S.mask) R.xm[rt] = *(const EQD_GAS f4v*)(S.mask + o);
             }
         }
         if (kfast) {      // thread: weight rows m = tr + 16 j, columns k0 + 4 tc ..
@@ -80,18 +82,18 @@ __device__ __forceinline__ void lin_load(const EqdLinJob& J, const EqdLinSrc& S,
             for (int j = 0; j < 4; ++j) {
                 int m = tr + 16 * j;
                 m = m < M ? m : M - 1;
-                R.w[j] = *(const f4v*)(Wb + (size_t)m * S.w_rs);
+                R.w[j] = *(const EQD_GAS f4v*)(Wb + (size_t)m * S.w_rs);
             }
             if (M > 64) {
                 int m = 64 + tr;
                 m = m < M ? m : M - 1;
-                R.w[4] = *(const f4v*)(Wb + (size_t)m * S.w_rs);
+                R.w[4] = *(const EQD_GAS f4v*)(Wb + (size_t)m * S.w_rs);
             }
         } else {          // transposed: thread: k = tr + 16 j, weight rows m = 4 tc .. (tail / beyond M: ld4u)
             const float* __restrict__ Wb = S.W + (size_t)c.k0 * S.w_cs;
             if (M >= 64) {                  // every 4-wide row segment below 64 is complete: plain vector loads
 #pragma unroll
-                for (int j = 0; j < 4; ++j) R.w[j] = *(const f4v*)(Wb + (size_t)(tr + 16 * j) * S.w_cs + 4 * tc);
+                for (int j = 0; j < 4; ++j) R.w[j] = *(const EQD_GAS f4v*)(Wb + (size_t)(tr + 16 * j) * S.w_cs + 4 * tc);
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -110,17 +112,17 @@ __device__ __forceinline__ void lin_load(const EqdLinJob& J, const EqdLinSrc& S,
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             int row = row0 + 16 * rt + tr;
-            row = row < J.rows ? row : J.rows - 1;
+            row = row < rows ? row : rows - 1;
             const size_t o = (size_t)row * S.ldx + kk;
-            R.x[rt][0] = S.X[o];
-            if (S.mask) R.xm[rt][0] = S.mask[o];
+            R.x[rt][0] = ((const EQD_GAS float*)S.X)[o];
+            if (S.mask) R.xm[rt][0] = ((const EQD_GAS float*)S.mask)[o];
         }
     }
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
         int m = tr + 16 * j;
         m = m < M ? m : M - 1;
-        R.w[j][0] = S.W[(size_t)m * S.w_rs + (size_t)kk * S.w_cs];
+        R.w[j][0] = ((const EQD_GAS float*)S.W)[(size_t)m * S.w_rs + (size_t)kk * S.w_cs];
     }
 }
 
@@ -129,17 +131,19 @@ template <int RT>
 __device__ __forceinline__ void lin_store(const EqdLinJob& J, const EqdLinSrc& S, bool local, LinStep c, int t,
                                           const LinRegs<RT>& R, LinSmem<RT>& sm) {
     const int tr = t >> 4, tc = t & 15;
-    const bool kfast = (S.w_cs == 1);
-    const int M = J.M;
+    const bool kfast = (uni(S.w_cs) == 1);
+    const bool masked = uni(S.mask) != nullptr;
+    const int M = uni(J.M);
+    const float slope = uni(J.slope);
     float* __restrict__ Wl = sm.Wl;
     if (c.kc == 64) {
         if (!local) {
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
                 f32x4 v = R.x[rt];
-                if (S.mask) {
+                if (masked) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] *= lrelu_grad(R.xm[rt][i], J.slope);
+                    for (int i = 0; i < 4; ++i) v[i] *= lrelu_grad(R.xm[rt][i], slope);
                 }
                 *(f32x4*)&sm.Xl[rt][tr * LIN_S + 4 * tc] = v;
             }
@@ -179,7 +183,7 @@ __device__ __forceinline__ void lin_store(const EqdLinJob& J, const EqdLinSrc& S
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             float v = R.x[rt][0];
-            if (S.mask) v *= lrelu_grad(R.xm[rt][0], J.slope);
+            if (masked) v *= lrelu_grad(R.xm[rt][0], slope);
             sm.Xl[rt][tr * LIN_S + tc] = kv ? v : 0.f;
         }
     }
@@ -234,7 +238,16 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const int* __res
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const int M = J.M;
+    // the job header, moved to SGPRs once (see uni())
+    const int M = uni(J.M), rows = uni(J.rows), nsrc = uni(J.nsrc), act = uni(J.act);
+    const float* const jbias = uni(J.bias);
+    const float* const jlng = uni(J.ln_g);
+    const float* const jlnb = uni(J.ln_b);
+    const float* const jR = uni(J.R);
+    float* const jY = uni(J.Y);
+    float* const jpre = uni(J.pre_ln);
+    const int ldr = uni(J.ldr), ldy = uni(J.ldy), ld_pre = uni(J.ld_pre);
+    const float alpha = uni(J.alpha), beta = uni(J.beta), slope = uni(J.slope), ln_eps = uni(J.ln_eps);
     const int mbn = (M + 15) >> 4;
     // this wave's output blocks and their epilogue operands (fetched now: the latency hides under the GEMM)
     const int mbs[2] = {wave, wave + 4};
@@ -245,14 +258,14 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const int* __res
     for (int i = 0; i < 2; ++i) {
         const int f0 = 16 * mbs[i] + 4 * g;
         nf[i] = own[i] ? M - f0 : 0;            // valid features at f0 (<= 0: none)
-        bias[i] = J.bias ? ld4u_raw(J.bias + f0, nf[i], J.bias) : f4zero();
-        lg[i] = J.ln_g ? ld4u_raw(J.ln_g + f0, nf[i], J.ln_g) : f4zero();
-        lb[i] = J.ln_g ? ld4u_raw(J.ln_b + f0, nf[i], J.ln_b) : f4zero();
+        bias[i] = jbias ? ld4u_raw(jbias + f0, nf[i], jbias) : f4zero();
+        lg[i] = jlng ? ld4u_raw(jlng + f0, nf[i], jlng) : f4zero();
+        lb[i] = jlng ? ld4u_raw(jlnb + f0, nf[i], jlnb) : f4zero();
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             int row = row0 + 16 * rt + l15;
-            row = row < J.rows ? row : J.rows - 1;
-            res[rt][i] = J.R ? ld4u_raw(J.R + (size_t)row * J.ldr + f0, nf[i], J.R) : f4zero();
+            row = row < rows ? row : rows - 1;
+            res[rt][i] = jR ? ld4u_raw(jR + (size_t)row * ldr + f0, nf[i], jR) : f4zero();
         }
     }
     f32x4 acc[RT][2], acc2[RT][2];
@@ -265,7 +278,7 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const int* __res
     LinRegs<RT> RB;
     int tr_i = 0;
     (void)tr_i;
-    auto is_local = [&](int si) { return src_local && src_local[si] >= 0; };
+    auto is_local = [&](int si) { return src_local && uni(src_local[si]) >= 0; };
     // one step: RX holds step `c`; after it has been written to LDS it is refilled with step `n2`
     auto step = [&](LinStep c, LinRegs<RT>& RX, LinStep n2) {
         const EqdLinSrc& S = J.s[c.s];
@@ -276,11 +289,12 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const int* __res
         LIN_TR(tr_i++);
         __syncthreads();
         LIN_TR(tr_i++);
-        if (n2.s < J.nsrc) lin_load<RT>(J, J.s[n2.s], is_local(n2.s), n2, row0, t, RX);
+        if (n2.s < nsrc) lin_load<RT>(J, J.s[n2.s], is_local(n2.s), n2, row0, t, RX);
         LIN_TR(tr_i++);
         const float* Xs[RT];
+        const int loc = local ? uni(src_local[c.s]) : 0;
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) Xs[rt] = local ? &Lb[rt][src_local[c.s]][c.k0] : sm.Xl[rt];
+        for (int rt = 0; rt < RT; ++rt) Xs[rt] = local ? &Lb[rt][loc][c.k0] : sm.Xl[rt];
         if (c.kc == 64) {
             if (own[1])
                 lin_mma<RT, 2, 4>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
@@ -299,14 +313,14 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const int* __res
     EQD_TR(trace_slot + 1);
     LIN_TR(tr_i++);
     if (!have_first) lin_load<RT>(J, J.s[0], is_local(0), cur, row0, t, RA);
-    if (nx.s < J.nsrc) lin_load<RT>(J, J.s[nx.s], is_local(nx.s), nx, row0, t, RB);
+    if (nx.s < nsrc) lin_load<RT>(J, J.s[nx.s], is_local(nx.s), nx, row0, t, RB);
     LIN_TR(tr_i++);
-    while (cur.s < J.nsrc) {
+    while (cur.s < nsrc) {
         LinStep n2 = lin_next(J, nx);
         step(cur, RA, n2);
         cur = nx;
         nx = n2;
-        if (cur.s >= J.nsrc) break;
+        if (cur.s >= nsrc) break;
         n2 = lin_next(J, nx);
         step(cur, RB, n2);
         cur = nx;
@@ -314,7 +328,7 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const int* __res
     }
 
     EQD_TR(trace_slot + 2);
-    if (has_next) lin_load<RT>(Jn, Jn.s[0], src_local_n && src_local_n[0] >= 0, lin_first(Jn), row0, t, RA);
+    if (has_next) lin_load<RT>(Jn, Jn.s[0], src_local_n && uni(src_local_n[0]) >= 0, lin_first(Jn), row0, t, RA);
     EQD_TR(trace_slot + 3);
     // ---- epilogue in F-layout: feature f = 16 mb + 4 g + r, row = row0 + 16 rt + l15 -----------------------------
     // `plain`: M is a multiple of 4, so an owned 4-feature group is always complete - no tail handling, 16-byte stores
@@ -335,7 +349,7 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const int* __res
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         const int rowi = row0 + 16 * rt + l15;
-        const bool rv = rowi < J.rows;
+        const bool rv = rowi < rows;
         float v[2][4];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -343,11 +357,11 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const int* __res
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float y = (acc[rt][i][r] + acc2[rt][i][r]) + bb[r];
-                if (J.act) y = lrelu(y, J.slope);
+                if (act) y = lrelu(y, slope);
                 v[i][r] = r < nf[i] ? y : 0.f;
             }
         }
-        if (J.ln_g) {
+        if (jlng) {
             const float invM = 1.f / (float)M;
             float s1 = 0.f;
 #pragma unroll
@@ -372,18 +386,18 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const int* __res
             if (g == 0) sm.stat[rt][wave][l15] = q;
             __syncthreads();
             const float rstd = 1.f / sqrtf((sm.stat[rt][0][l15] + sm.stat[rt][1][l15] + sm.stat[rt][2][l15] +
-                                            sm.stat[rt][3][l15]) * invM + J.ln_eps);
+                                            sm.stat[rt][3][l15]) * invM + ln_eps);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const float gg[4] = {lgv[i].x, lgv[i].y, lgv[i].z, lgv[i].w};
                 const float be[4] = {lbv[i].x, lbv[i].y, lbv[i].z, lbv[i].w};
-                if (plain && nf[i] > 0 && J.pre_ln && rv)
-                    *(f4v*)&J.pre_ln[(size_t)rowi * J.ld_pre + 16 * mbs[i] + 4 * g] = f32x4{v[i][0], v[i][1], v[i][2], v[i][3]};
+                if (plain && nf[i] > 0 && jpre && rv)
+                    *(EQD_GAS f4v*)&jpre[(size_t)rowi * ld_pre + 16 * mbs[i] + 4 * g] = f32x4{v[i][0], v[i][1], v[i][2], v[i][3]};
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (r < nf[i]) {
                         const int f = 16 * mbs[i] + 4 * g + r;
-                        if (!plain && J.pre_ln && rv) J.pre_ln[(size_t)rowi * J.ld_pre + f] = v[i][r];
+                        if (!plain && jpre && rv) ((EQD_GAS float*)jpre)[(size_t)rowi * ld_pre + f] = v[i][r];
                         v[i][r] = (v[i][r] - mean) * rstd * gg[r] + be[r];
                     }
             }
@@ -398,19 +412,19 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const int* __res
             const float rs[4] = {rr.x, rr.y, rr.z, rr.w};
             float y[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) y[r] = J.alpha * v[i][r] + J.beta * rs[r];
+            for (int r = 0; r < 4; ++r) y[r] = alpha * v[i][r] + beta * rs[r];
             const int f0 = 16 * mbs[i] + 4 * g;
             if (plain) {
                 if (nf[i] > 0) {
                     const f32x4 yv = {y[0], y[1], y[2], y[3]};
-                    if (J.Y && rv) *(f4v*)&J.Y[(size_t)rowi * J.ldy + f0] = yv;
+                    if (jY && rv) *(EQD_GAS f4v*)&jY[(size_t)rowi * ldy + f0] = yv;
                     if (out_local >= 0) *(f32x4*)&Lb[rt][out_local][l15 * LIN_S + f0] = yv;
                 }
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (r < nf[i]) {
-                        if (J.Y && rv) J.Y[(size_t)rowi * J.ldy + f0 + r] = y[r];
+                        if (jY && rv) ((EQD_GAS float*)jY)[(size_t)rowi * ldy + f0 + r] = y[r];
                         if (out_local >= 0) Lb[rt][out_local][l15 * LIN_S + f0 + r] = y[r];
                     }
             }

@@ -83,11 +83,18 @@ __device__ __forceinline__ void chain_lnbwd(const EqdChainJob& C, float (*Lb)[LI
     // y_act = LeakyReLU(z) (saved by the forward) is lin.s[0].X; the incoming gradient is the LDS tile
     // src_local[0]; dz goes to LDS tile out_local and to lin.Y; per-workgroup (d gamma | d beta) to aux.
     const EqdLinJob& J = C.lin;
+    // descriptor fields come from the LDS copy: scalarise them, address HBM as global (see uni / EQD_GAS)
+    const EQD_GAS float* const jlng = (const EQD_GAS float*)uni(J.ln_g);
+    const EQD_GAS float* const jX = (const EQD_GAS float*)uni(J.s[0].X);
+    EQD_GAS float* const jY = (EQD_GAS float*)uni(J.Y);
+    EQD_GAS float* const jaux = (EQD_GAS float*)uni(C.aux);
+    const int rows = uni(J.rows), ldx = uni(J.s[0].ldx), ldy = uni(J.ldy), src_l = uni(C.src_local[0]), out_l = uni(C.out_local);
+    const float slope = uni(J.slope), ln_eps = uni(J.ln_eps);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int d = J.M;
+    const int d = uni(J.M);
     const int f0 = lane, f1 = lane + 64;
     const bool v0 = f0 < d, v1 = f1 < d;
-    const float g0 = v0 ? J.ln_g[f0] : 0.f, g1 = v1 ? J.ln_g[f1] : 0.f;
+    const float g0 = v0 ? jlng[f0] : 0.f, g1 = v1 ? jlng[f1] : 0.f;
     const float invd = 1.f / (float)d;
     float dg0 = 0.f, dg1 = 0.f, db0 = 0.f, db1 = 0.f;
     // all y_act rows of the wave first (unpredicated, clamped), then the arithmetic
@@ -97,36 +104,36 @@ __device__ __forceinline__ void chain_lnbwd(const EqdChainJob& C, float (*Lb)[LI
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             int row = row0 + 16 * rt + 4 * wave + rr;
-            row = row < J.rows ? row : J.rows - 1;
-            const size_t o = (size_t)row * J.s[0].ldx;
-            y0s[rt][rr] = J.s[0].X[o + (v0 ? f0 : 0)];
-            y1s[rt][rr] = J.s[0].X[o + (v1 ? f1 : 0)];
+            row = row < rows ? row : rows - 1;
+            const size_t o = (size_t)row * ldx;
+            y0s[rt][rr] = jX[o + (v0 ? f0 : 0)];
+            y1s[rt][rr] = jX[o + (v1 ? f1 : 0)];
         }
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-        const float* __restrict__ din = Lb[rt][C.src_local[0]];
-        float* __restrict__ dout = Lb[rt][C.out_local];
+        const float* __restrict__ din = Lb[rt][src_l];
+        float* __restrict__ dout = Lb[rt][out_l];
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int lr = 4 * wave + rr;
             const int row = row0 + 16 * rt + lr;
-            const bool rv = row < J.rows;
+            const bool rv = row < rows;
             const float y0 = (rv && v0) ? y0s[rt][rr] : 0.f, y1 = (rv && v1) ? y1s[rt][rr] : 0.f;
             const float o0 = (rv && v0) ? din[lr * LIN_S + f0] : 0.f, o1 = (rv && v1) ? din[lr * LIN_S + f1] : 0.f;
             const float mean = wave_sum(y0 + y1) * invd;
             const float c0 = v0 ? y0 - mean : 0.f, c1 = v1 ? y1 - mean : 0.f;
-            const float rstd = 1.f / sqrtf(wave_sum(c0 * c0 + c1 * c1) * invd + J.ln_eps);
+            const float rstd = 1.f / sqrtf(wave_sum(c0 * c0 + c1 * c1) * invd + ln_eps);
             const float xh0 = c0 * rstd, xh1 = c1 * rstd;
             const float dx0 = o0 * g0, dx1 = o1 * g1;
             const float s1 = wave_sum(dx0 + dx1) * invd;
             const float s2 = wave_sum(dx0 * xh0 + dx1 * xh1) * invd;
-            const float z0 = rstd * (dx0 - s1 - xh0 * s2) * lrelu_grad(y0, J.slope);
-            const float z1 = rstd * (dx1 - s1 - xh1 * s2) * lrelu_grad(y1, J.slope);
+            const float z0 = rstd * (dx0 - s1 - xh0 * s2) * lrelu_grad(y0, slope);
+            const float z1 = rstd * (dx1 - s1 - xh1 * s2) * lrelu_grad(y1, slope);
             if (v0) dout[lr * LIN_S + f0] = rv ? z0 : 0.f;
             if (v1) dout[lr * LIN_S + f1] = rv ? z1 : 0.f;
-            if (rv && J.Y) {
-                if (v0) J.Y[(size_t)row * J.ldy + f0] = z0;
-                if (v1) J.Y[(size_t)row * J.ldy + f1] = z1;
+            if (rv && jY) {
+                if (v0) jY[(size_t)row * ldy + f0] = z0;
+                if (v1) jY[(size_t)row * ldy + f1] = z1;
             }
             if (rv) {
                 dg0 += o0 * xh0;
@@ -141,7 +148,7 @@ __device__ __forceinline__ void chain_lnbwd(const EqdChainJob& C, float (*Lb)[LI
     red[wave][128 + lane] = db0;
     red[wave][192 + lane] = db1;
     __syncthreads();
-    C.aux[(size_t)blockIdx.x * 256 + t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+    jaux[(size_t)blockIdx.x * 256 + t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
 }
 
 template <int RT>
@@ -158,12 +165,13 @@ __global__ __launch_bounds__(EQD_BLOCK, 2) void k_rowchain(EqdChainArg A_) {
     __syncthreads();
     LinRegs<RT> RA;
     bool have = false;
-    for (int jj = 0; jj < A.njobs; ++jj) {
+    const int njobs = uni(A.njobs);
+    for (int jj = 0; jj < njobs; ++jj) {
         const EqdChainJob& C = A.j[jj];
-        if (C.type == 0) {
-            const int nj = C.prefetch_next;      // next linear job whose first step may be fetched early, or -1
+        if (uni(C.type) == 0) {
+            const int nj = uni(C.prefetch_next);      // next linear job whose first step may be fetched early, or -1
             const EqdChainJob& Cn = A.j[nj >= 0 ? nj : jj];
-            linear_tile<RT>(C.lin, C.src_local, C.out_local, sm, Lb, row0, RA, have, nj >= 0, Cn.lin, Cn.src_local,
+            linear_tile<RT>(C.lin, C.src_local, uni(C.out_local), sm, Lb, row0, RA, have, nj >= 0, Cn.lin, Cn.src_local,
                             210 + 4 * jj);
             have = nj >= 0;
         } else {

@@ -74,6 +74,7 @@ void wave_barrier();
 
 static inline void __syncthreads() { hostsim::sync_block(); }
 #define EQD_KERNARG_PTR(first_param) ((const void*)&(first_param))   /* host: the by-value argument itself */
+#define EQD_GAS   /* no address spaces on the host */
 #define EQD_NATIVE_EXP(x) expf(x)   /* the device build uses __expf (v_exp_f32) */
 static inline float __shfl_xor(float v, int m) { return hostsim::shfl_f(v, hostsim::lane_id() ^ m); }
 static inline int __shfl_xor(int v, int m) { return hostsim::shfl_i(v, hostsim::lane_id() ^ m); }
@@ -106,3 +107,4 @@ static inline hostsim_f32x4 hostsim_mfma_bf16(hostsim_s16x4 a, hostsim_s16x4 b, 
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_wave_barrier() hostsim::wave_barrier()
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
+#define __builtin_amdgcn_readfirstlane(x) (x)   /* only applied to wave-uniform values */
