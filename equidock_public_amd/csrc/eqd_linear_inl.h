@@ -126,7 +126,7 @@ __device__ __forceinline__ void lin_load(const EqdLinJob& J, const EqdLinSrc& S_
     }
 }
 
-// ---- registers -> LDS: Xl[rt][row][k], Wl[m][k] (always k-contiguous), zero padded ------------------------------
+// ---- registers -> LDS: Xl[rt][row][k]; Wl[m][k], except full steps of transposed sources: Wl[k][m]; zero padded ------------------------------
 template <int RT>
 __device__ __forceinline__ void lin_store(const EqdLinJob& J, const EqdLinSrc& S, bool local, LinStep c, int t,
                                           const LinRegs<RT>& R, LinSmem<RT>& sm) {
@@ -153,27 +153,21 @@ __device__ __forceinline__ void lin_store(const EqdLinJob& J, const EqdLinSrc& S
 #pragma unroll
             for (int j = 0; j < 4; ++j) *(f32x4*)&Wl[(tr + 16 * j) * LIN_S + 4 * tc] = (tr + 16 * j < M) ? R.w[j] : z;
             if (M > 64) *(f32x4*)&Wl[(64 + tr) * LIN_S + 4 * tc] = (64 + tr < M) ? R.w[4] : z;
-        } else {       // the vector runs along m: transpose on the way in (4-way bank conflict, 16 short stores)
+        } else {       // the vector runs along m: stored as Wl[k][m] (conflict-free b128; transposing here would be 16
+                       // scalar stores with an 8-way bank conflict, +770 clocks per step); lin_mma reads it accordingly
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float4 v;
-                if (M >= 64)
-                    v = make_float4(R.w[j][0], R.w[j][1], R.w[j][2], R.w[j][3]);
-                else
-                    v = ld4u_fix(R.w[j], M - 4 * tc);
-                const int k = tr + 16 * j;
-                Wl[(4 * tc + 0) * LIN_S + k] = v.x;
-                Wl[(4 * tc + 1) * LIN_S + k] = v.y;
-                Wl[(4 * tc + 2) * LIN_S + k] = v.z;
-                Wl[(4 * tc + 3) * LIN_S + k] = v.w;
+                f32x4 v = R.w[j];
+                if (M < 64) {
+                    const float4 f = ld4u_fix(R.w[j], M - 4 * tc);
+                    v = f32x4{f.x, f.y, f.z, f.w};
+                }
+                *(f32x4*)&Wl[(tr + 16 * j) * LIN_S + 4 * tc] = v;
             }
             if (M > 64) {
                 const int m = 64 + 4 * (t & 3), k = t >> 2;
-                const float4 v = ld4u_fix(R.w[4], M - m);
-                Wl[(m + 0) * LIN_S + k] = v.x;
-                Wl[(m + 1) * LIN_S + k] = v.y;
-                Wl[(m + 2) * LIN_S + k] = v.z;
-                Wl[(m + 3) * LIN_S + k] = v.w;
+                const float4 f = ld4u_fix(R.w[4], M - m);
+                *(f32x4*)&Wl[k * LIN_S + m] = f32x4{f.x, f.y, f.z, f.w};
             }
         }
         return;
@@ -197,14 +191,22 @@ __device__ __forceinline__ void lin_store(const EqdLinJob& J, const EqdLinSrc& S
 // acc[rt][i] (+)= W-fragment x X-fragment of the chunk for the wave's NOWN output blocks; no per-lane predicates.
 // The weight fragments are read once for the RT row tiles.  MFMAs alternate between two accumulator sets (a single
 // dependent chain leaves the matrix pipe idle).
-template <int RT, int NOWN, int NQ>
+template <int RT, int NOWN, int NQ, bool WT>
 __device__ __forceinline__ void lin_mma(f32x4 (&acc)[RT][2], f32x4 (&acc2)[RT][2], const float* (&Xs)[RT],
                                         const float* __restrict__ Wl, const int (&mb)[2], int l15, int g) {
+    // WT: the weights lie as Wl[k][m] (full steps of transposed sources): the 4 k-values of a lane are 4 scalar reads
     f32x4 a[NOWN][NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
 #pragma unroll
-        for (int i = 0; i < NOWN; ++i) a[i][q] = *(const f32x4*)&Wl[(16 * mb[i] + l15) * LIN_S + 16 * q + 4 * g];
+        for (int i = 0; i < NOWN; ++i) {
+            if (WT) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[i][q][j] = Wl[(16 * q + 4 * g + j) * LIN_S + 16 * mb[i] + l15];
+            } else {
+                a[i][q] = *(const f32x4*)&Wl[(16 * mb[i] + l15) * LIN_S + 16 * q + 4 * g];
+            }
+        }
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         f32x4 b[NQ];
@@ -296,15 +298,22 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const int* __res
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) Xs[rt] = local ? &Lb[rt][loc][c.k0] : sm.Xl[rt];
         if (c.kc == 64) {
-            if (own[1])
-                lin_mma<RT, 2, 4>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
-            else if (own[0])
-                lin_mma<RT, 1, 4>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+            if (uni(S.w_cs) == 1) {
+                if (own[1])
+                    lin_mma<RT, 2, 4, false>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+                else if (own[0])
+                    lin_mma<RT, 1, 4, false>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+            } else {
+                if (own[1])
+                    lin_mma<RT, 2, 4, true>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+                else if (own[0])
+                    lin_mma<RT, 1, 4, true>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+            }
         } else {
             if (own[1])
-                lin_mma<RT, 2, 1>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+                lin_mma<RT, 2, 1, false>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
             else if (own[0])
-                lin_mma<RT, 1, 1>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+                lin_mma<RT, 1, 1, false>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
         }
         LIN_TR(tr_i++);
     };
