@@ -276,66 +276,194 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const int* __res
 #pragma unroll
         for (int i = 0; i < 2; ++i) acc[rt][i] = acc2[rt][i] = f4zero();
 
-    // ---- pipelined (source, K chunk) steps: the loads of step i + 2 are issued while step i is multiplied ----
+    // ---- lean pipeline (M == 64, every source at least 64 wide - all jobs of the layers >= 1 except the 69-wide h0
+    //      gradient): every load address is computed ONCE per job and kept in VGPRs, the source loop is unrolled, and a
+    //      step is: barrier, 5 b128 LDS stores, barrier, 5 loads for the step after next, 8 LDS reads, 16 MFMAs.  The
+    //      generic pipeline below spends ~3 500 clocks per step on descriptor handling and bookkeeping; the floor measured
+    //      with static addressing is 1 350 (profiles/exp_step_floor.hip). ----------------------------------------------------
+    bool lean = (RT == 1) && (M == 64);     // with two row tiles the extra address registers spill (256-VGPR budget)
+#pragma unroll
+    for (int si = 0; si < EQD_MAX_SRC; ++si)
+        if (si < nsrc && uni(J.s[si].K) < 64) lean = false;
     LinRegs<RT> RB;
     int tr_i = 0;
     (void)tr_i;
-    auto is_local = [&](int si) { return src_local && uni(src_local[si]) >= 0; };
-    // one step: RX holds step `c`; after it has been written to LDS it is refilled with step `n2`
-    auto step = [&](LinStep c, LinRegs<RT>& RX, LinStep n2) {
-        const EqdLinSrc& S = J.s[c.s];
-        const bool local = is_local(c.s);
-        __syncthreads();                  // previous chunk's fragment reads are done
-        LIN_TR(tr_i++);
-        lin_store<RT>(J, S, local, c, t, RX, sm);
-        LIN_TR(tr_i++);
-        __syncthreads();
-        LIN_TR(tr_i++);
-        if (n2.s < nsrc) lin_load<RT>(J, J.s[n2.s], is_local(n2.s), n2, row0, t, RX);
-        LIN_TR(tr_i++);
-        const float* Xs[RT];
-        const int loc = local ? uni(src_local[c.s]) : 0;
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) Xs[rt] = local ? &Lb[rt][loc][c.k0] : sm.Xl[rt];
-        if (c.kc == 64) {
-            if (uni(S.w_cs) == 1) {
-                if (own[1])
-                    lin_mma<RT, 2, 4, false>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
-                else if (own[0])
-                    lin_mma<RT, 1, 4, false>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+    auto generic_pipeline = [&]() {
+        // ---- pipelined (source, K chunk) steps: the loads of step i + 2 are issued while step i is multiplied ----
+        auto is_local = [&](int si) { return src_local && uni(src_local[si]) >= 0; };
+        // one step: RX holds step `c`; after it has been written to LDS it is refilled with step `n2`
+        auto step = [&](LinStep c, LinRegs<RT>& RX, LinStep n2) {
+            const EqdLinSrc& S = J.s[c.s];
+            const bool local = is_local(c.s);
+            __syncthreads();                  // previous chunk's fragment reads are done
+            LIN_TR(tr_i++);
+            lin_store<RT>(J, S, local, c, t, RX, sm);
+            LIN_TR(tr_i++);
+            __syncthreads();
+            LIN_TR(tr_i++);
+            if (n2.s < nsrc) lin_load<RT>(J, J.s[n2.s], is_local(n2.s), n2, row0, t, RX);
+            LIN_TR(tr_i++);
+            const float* Xs[RT];
+            const int loc = local ? uni(src_local[c.s]) : 0;
+    #pragma unroll
+            for (int rt = 0; rt < RT; ++rt) Xs[rt] = local ? &Lb[rt][loc][c.k0] : sm.Xl[rt];
+            if (c.kc == 64) {
+                if (uni(S.w_cs) == 1) {
+                    if (own[1])
+                        lin_mma<RT, 2, 4, false>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+                    else if (own[0])
+                        lin_mma<RT, 1, 4, false>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+                } else {
+                    if (own[1])
+                        lin_mma<RT, 2, 4, true>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+                    else if (own[0])
+                        lin_mma<RT, 1, 4, true>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+                }
             } else {
                 if (own[1])
-                    lin_mma<RT, 2, 4, true>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+                    lin_mma<RT, 2, 1, false>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
                 else if (own[0])
-                    lin_mma<RT, 1, 4, true>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+                    lin_mma<RT, 1, 1, false>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+            }
+            LIN_TR(tr_i++);
+        };
+        LinStep cur = lin_first(J);
+        LinStep nx = lin_next(J, cur);
+        EQD_TR(trace_slot + 1);
+        LIN_TR(tr_i++);
+        if (!have_first) lin_load<RT>(J, J.s[0], is_local(0), cur, row0, t, RA);
+        if (nx.s < nsrc) lin_load<RT>(J, J.s[nx.s], is_local(nx.s), nx, row0, t, RB);
+        LIN_TR(tr_i++);
+        while (cur.s < nsrc) {
+            LinStep n2 = lin_next(J, nx);
+            step(cur, RA, n2);
+            cur = nx;
+            nx = n2;
+            if (cur.s >= nsrc) break;
+            n2 = lin_next(J, nx);
+            step(cur, RB, n2);
+            cur = nx;
+            nx = n2;
+        }
+    };
+    if constexpr (RT == 1) {
+        if (lean) {
+            const int tr = t >> 4, tc = t & 15;
+            // addresses of row tile 0; tile rt is drow[rt] rows further (rows beyond the matrix are clamped to its last row)
+            unsigned long long xa[EQD_MAX_SRC], ma[EQD_MAX_SRC], wa[EQD_MAX_SRC];
+            int wst[EQD_MAX_SRC], locs[EQD_MAX_SRC], ldxb[EQD_MAX_SRC];
+            int rowc0 = row0 + tr, drow[RT];
+            rowc0 = rowc0 < rows ? rowc0 : rows - 1;
+    #pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                int r = row0 + 16 * rt + tr;
+                r = r < rows ? r : rows - 1;
+                drow[rt] = r - rowc0;
+            }
+            unsigned kfm = 0u, mkm = 0u, remm = 0u;
+    #pragma unroll
+            for (int si = 0; si < EQD_MAX_SRC; ++si) {
+                wst[si] = 0;
+                locs[si] = -1;
+                ldxb[si] = 0;
+                wa[si] = xa[si] = ma[si] = 0ull;
+                if (si < nsrc) {
+                    const EqdLinSrc S = uni(J.s[si]);
+                    locs[si] = src_local ? uni(src_local[si]) : -1;
+                    const bool kf = (S.w_cs == 1);
+                    const int stride = kf ? S.w_rs : S.w_cs;
+                    if (kf) kfm |= 1u << si;
+                    if (S.mask) mkm |= 1u << si;
+                    if (S.K > 64) remm |= 1u << si;
+                    wa[si] = (unsigned long long)(S.W + (size_t)tr * stride + 4 * tc);
+                    wst[si] = 64 * stride;      // bytes between weight rows tr + 16 j
+                    if (locs[si] < 0) {
+                        ldxb[si] = 4 * S.ldx;
+                        xa[si] = (unsigned long long)(S.X + (size_t)rowc0 * S.ldx + 4 * tc);
+                        ma[si] = S.mask ? (unsigned long long)(S.mask + (size_t)rowc0 * S.ldx + 4 * tc) : 0ull;
+                    }
+                }
+            }
+            auto load = [&](int si, LinRegs<RT>& R) {       // si is a compile-time constant at every call
+                if (locs[si] < 0) {
+    #pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        const unsigned long long off = (unsigned long long)((long long)drow[rt] * ldxb[si]);
+                        R.x[rt] = *(const EQD_GAS f4v*)(xa[si] + off);
+                        if ((mkm >> si) & 1u) R.xm[rt] = *(const EQD_GAS f4v*)(ma[si] + off);
+                    }
+                }
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) R.w[j] = *(const EQD_GAS f4v*)(wa[si] + (unsigned long long)(unsigned)(j * wst[si]));
+            };
+            EQD_TR(trace_slot + 1);
+            LIN_TR(tr_i++);
+            if (!have_first) load(0, RA);
+            if (1 < nsrc) load(1, RB);
+            LIN_TR(tr_i++);
+    #pragma unroll
+            for (int si = 0; si < EQD_MAX_SRC; ++si) {
+                if (si < nsrc) {
+                    LinRegs<RT>& RX = (si & 1) ? RB : RA;
+                    __syncthreads();                  // previous step's fragment reads are done
+                    LIN_TR(tr_i++);
+                    if (locs[si] < 0) {
+    #pragma unroll
+                        for (int rt = 0; rt < RT; ++rt) {
+                            f32x4 v = RX.x[rt];
+                            if ((mkm >> si) & 1u) {
+    #pragma unroll
+                                for (int i = 0; i < 4; ++i) v[i] *= lrelu_grad(RX.xm[rt][i], slope);
+                            }
+                            *(f32x4*)&sm.Xl[rt][tr * LIN_S + 4 * tc] = v;
+                        }
+                    }
+    #pragma unroll
+                    for (int j = 0; j < 4; ++j) *(f32x4*)&sm.Wl[(tr + 16 * j) * LIN_S + 4 * tc] = RX.w[j];   // Wl[m][k] or Wl[k][m]
+                    LIN_TR(tr_i++);
+                    __syncthreads();
+                    LIN_TR(tr_i++);
+                    if (si + 2 < EQD_MAX_SRC) {
+                        if (si + 2 < nsrc) load((si + 2) % EQD_MAX_SRC, RX);
+                    }
+                    LIN_TR(tr_i++);
+                    const float* Xs[RT];
+    #pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) Xs[rt] = locs[si] >= 0 ? &Lb[rt][locs[si]][0] : sm.Xl[rt];
+                    if ((kfm >> si) & 1u)
+                        lin_mma<RT, 1, 4, false>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+                    else
+                        lin_mma<RT, 1, 4, true>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+                    LIN_TR(tr_i++);
+                }
+            }
+            // what is left of sources wider than 64 (the 5 columns beyond 64 of the 69-wide h0): 16-wide steps, not pipelined
+            if (remm) {
+    #pragma unroll
+                for (int si = 0; si < EQD_MAX_SRC; ++si) {
+                    if (si < nsrc && ((remm >> si) & 1u)) {
+                        const EqdLinSrc S = uni(J.s[si]);
+                        for (int k0 = 64; k0 < S.K;) {
+                            const LinStep c = {si, k0, lin_chunk(S.K - k0)};
+                            lin_load<RT>(J, J.s[si], locs[si] >= 0, c, row0, t, RB);
+                            __syncthreads();
+                            lin_store<RT>(J, J.s[si], locs[si] >= 0, c, t, RB, sm);
+                            __syncthreads();
+                            const float* Xs[RT];
+    #pragma unroll
+                            for (int rt = 0; rt < RT; ++rt) Xs[rt] = locs[si] >= 0 ? &Lb[rt][locs[si]][k0] : sm.Xl[rt];
+                            lin_mma<RT, 1, 1, false>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+                            k0 += c.kc;
+                        }
+                    }
+                }
             }
         } else {
-            if (own[1])
-                lin_mma<RT, 2, 1, false>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
-            else if (own[0])
-                lin_mma<RT, 1, 1, false>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+            generic_pipeline();
         }
-        LIN_TR(tr_i++);
-    };
-    LinStep cur = lin_first(J);
-    LinStep nx = lin_next(J, cur);
-    EQD_TR(trace_slot + 1);
-    LIN_TR(tr_i++);
-    if (!have_first) lin_load<RT>(J, J.s[0], is_local(0), cur, row0, t, RA);
-    if (nx.s < nsrc) lin_load<RT>(J, J.s[nx.s], is_local(nx.s), nx, row0, t, RB);
-    LIN_TR(tr_i++);
-    while (cur.s < nsrc) {
-        LinStep n2 = lin_next(J, nx);
-        step(cur, RA, n2);
-        cur = nx;
-        nx = n2;
-        if (cur.s >= nsrc) break;
-        n2 = lin_next(J, nx);
-        step(cur, RB, n2);
-        cur = nx;
-        nx = n2;
+    } else {
+        generic_pipeline();
     }
-
     EQD_TR(trace_slot + 2);
     if (has_next) lin_load<RT>(Jn, Jn.s[0], src_local_n && uni(src_local_n[0]) >= 0, lin_first(Jn), row0, t, RA);
     EQD_TR(trace_slot + 3);

@@ -59,12 +59,15 @@ __global__ __launch_bounds__(EQD_BLOCK, 2) void k_linear(LinJobsArg jobs) {
     linear_tile<RT>(J, nullptr, -1, sm, nullptr, row0, RA, false, false, J, nullptr);
     EQD_TR_WG_END();
 }
-// 16-row tiles per workgroup: one at DB5-sized batches (3 200 rows: latency matters, spread over the CUs), two
-// once there are more tiles than the chip holds at once (the step's weights are then staged once per 32 rows)
+// 16-row tiles per workgroup.  One tile everywhere: with the lean (precomputed-address) step pipeline, which only fits
+// the register budget with one tile, 16-row workgroups at two per CU measured faster than 32-row workgroups at every
+// size (config C: 6 040 vs 5 950 pairs/s).  EQD_ROW_TILES=2 selects the two-tile kernels (kept and tested: they stage a
+// step's weights once per 32 rows, which pays off once weights stop fitting the L2, i.e. for wider models).
 int eqd_row_tiles(int rows) {
-    const char* f = getenv("EQD_ROW_TILES");      // tests force the 2-tile kernels on small inputs
+    (void)rows;
+    const char* f = getenv("EQD_ROW_TILES");
     if (f && (f[0] == '1' || f[0] == '2') && f[1] == 0) return f[0] - '0';
-    return rows > 16 * 1024 ? 2 : 1;
+    return 1;
 }
 int eqd_rowchain_blocks(int rows) {
     const int per = 16 * eqd_row_tiles(rows);

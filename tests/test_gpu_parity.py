@@ -62,7 +62,7 @@ def test_model_vs_golden(dev, name):
 
 @pytest.mark.parametrize('name', ['D_degraded3', 'B_b3_dips8'])
 def test_model_two_row_tiles(dev, name, monkeypatch):
-    """the 32-rows-per-workgroup variants of the row kernels (picked above 16 384 rows) on small golden cases"""
+    """the 32-rows-per-workgroup variants of the row kernels (EQD_ROW_TILES=2) on small golden cases"""
     from tests import parity_common as pc
     monkeypatch.setenv('EQD_ROW_TILES', '2')
     pc.check_linear(dev)

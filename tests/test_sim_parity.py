@@ -57,7 +57,7 @@ def test_model_vs_golden(name):
 
 @pytest.mark.parametrize('name', ['D_degraded3'])
 def test_model_two_row_tiles(name, monkeypatch):
-    """the 32-rows-per-workgroup variants of the row kernels (picked above 16 384 rows) on a small golden case"""
+    """the 32-rows-per-workgroup variants of the row kernels (EQD_ROW_TILES=2) on a small golden case"""
     monkeypatch.setenv('EQD_ROW_TILES', '2')
     pc.check_linear(DEV)
     pc.check_model_case(DEV, name)
