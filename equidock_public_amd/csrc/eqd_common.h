@@ -230,6 +230,8 @@ struct EqdRedSeg {
 struct EqdRedArg {
     EqdRedSeg s[EQD_RED_MAXSEG];
     int chain_first[EQD_RED_MAXSEG], chain_len[EQD_RED_MAXSEG];
+    int chain_blk0[EQD_RED_MAXSEG];   // first workgroup of the chain (one workgroup per 64 output columns)
+    int nchains;
 };
 int eqd_launch_reduce_segments(const EqdRedSeg* segs, int nseg, hipStream_t st);
 // list of pending reductions, flushed in a few launches at the end of the backward pass

@@ -585,39 +585,78 @@ extern "C" int eqd_atb(const EqdAtbJob* jobs, int njobs, void* partial, size_t p
 // ------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------
+// One workgroup per (chain, block of 64 output columns); only blocks that have columns are launched (chain_blk0 is the
+// prefix of the chains' block counts).  Thread = (group of 4 columns, one of 64 part lanes): a part's 64 columns are ONE
+// 256-byte row segment fetched by 16 lanes with 16-byte loads, eight parts per lane in flight at once (a 4-byte-per-lane
+// version of this kernel ran at 1 TB/s on the 90 MB of edge weight-gradient partials of a config-B pass, and chains of
+// 2 000 short partials serialised 8 load round trips in one workgroup).  The summation order is fixed: parts
+// pl, pl + 64, .. in each lane, segments of a chain in list order, then the 64 lanes as 4 x 16 in index order.
 __global__ __launch_bounds__(1024) void k_reduce_segments(EqdRedArg A) {
-    __shared__ float red[16][64];
-    const int first = A.chain_first[blockIdx.y], len = A.chain_len[blockIdx.y];
-    const int c = threadIdx.x & 63, pl = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + c;
+    __shared__ __attribute__((aligned(16))) float red[64][68];
+    __shared__ float red2[4][64];
+    int ch = 0;
+    while (ch + 1 < A.nchains && (int)blockIdx.x >= A.chain_blk0[ch + 1]) ++ch;
+    ch = uni(ch);
+    const int first = A.chain_first[ch], len = A.chain_len[ch];
+    const int t = threadIdx.x, cg = t & 15, pl = t >> 4;
+    const int c0 = ((int)blockIdx.x - A.chain_blk0[ch]) * 64;
     const int n = A.s[first].n;
-    float acc = 0.f;
-    if (i < n) {
+    const int col = c0 + 4 * cg;            // this thread's columns col .. col + 3
+    const int nv = n - col;                 // how many of them exist (<= 0: none)
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n >= 4) {
         for (int j = 0; j < len; ++j) {
             const EqdRedSeg& S = A.s[first + j];
-            // 16 partials per trip and lane, loads unpredicated (clamped) so that they are all in flight at once
-            for (int p0 = pl; p0 < S.nparts; p0 += 256) {
-                float v[16];
+            const float* __restrict__ base = S.partial + (nv > 0 ? col : 0);
+            const int np = S.nparts;
+            const size_t ps = (size_t)S.pstride;
+            for (int p0 = pl; p0 < np; p0 += 8 * 64) {
+                f32x4 v[8];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int p = p0 + 16 * u;
-                    v[u] = S.partial[(size_t)(p < S.nparts ? p : 0) * S.pstride + i];
+                for (int u = 0; u < 8; ++u) {
+                    const int p = p0 + 64 * u;
+                    v[u] = ld4u_raw(base + (size_t)(p < np ? p : 0) * ps, nv, S.partial);
                 }
 #pragma unroll
-                for (int u = 0; u < 16; ++u) acc += p0 + 16 * u < S.nparts ? v[u] : 0.f;
+                for (int u = 0; u < 8; ++u) {
+                    const float4 f = ld4u_fix(v[u], p0 + 64 * u < np ? nv : 0);
+                    acc.x += f.x;
+                    acc.y += f.y;
+                    acc.z += f.z;
+                    acc.w += f.w;
+                }
             }
         }
+    } else if (cg == 0) {                    // 1 .. 3 columns in all (a scalar bias): scalar loads
+        float a3[3] = {0.f, 0.f, 0.f};
+        for (int j = 0; j < len; ++j) {
+            const EqdRedSeg& S = A.s[first + j];
+            for (int p = pl; p < S.nparts; p += 64)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float v = S.partial[(size_t)p * S.pstride + (c < n ? c : 0)];
+                    a3[c] += c < n ? v : 0.f;
+                }
+        }
+        acc = make_float4(a3[0], a3[1], a3[2], 0.f);
     }
-    red[pl][c] = acc;
+    *(float4*)&red[pl][4 * cg] = acc;
     __syncthreads();
-    if (pl == 0 && i < n) {
+    if (t < 256) {
+        const int c = t & 63, qd = t >> 6;
         float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) s += red[j][c];
+        for (int j = 0; j < 16; ++j) s += red[16 * qd + j][c];
+        red2[qd][c] = s;
+    }
+    __syncthreads();
+    const int i = c0 + t;
+    if (t < 64 && i < n) {
+        const float s = (red2[0][t] + red2[1][t]) + (red2[2][t] + red2[3][t]);
         const EqdRedSeg& S0 = A.s[first];
         if (S0.cols > 0) {
-            const int row = i / S0.cols, col = i - row * S0.cols;
-            if (col < S0.cols_valid) S0.out[(size_t)row * S0.ld_out + col] += s;
+            const int row = i / S0.cols, cc = i - row * S0.cols;
+            if (cc < S0.cols_valid) S0.out[(size_t)row * S0.ld_out + cc] += s;
         } else {
             S0.out[i] += s;
         }
@@ -652,17 +691,22 @@ int eqd_launch_reduce_segments(const EqdRedSeg* segs, int nseg, hipStream_t st) 
     while (c0 < nc) {
         EqdRedArg arg;
         memset(&arg, 0, sizeof(arg));
-        int ns = 0, nch = 0, maxn = 0;
+        int ns = 0, nch = 0, nblk = 0;
         while (c0 < nc && ns + clen[c0] <= EQD_RED_MAXSEG) {
-            arg.chain_first[nch] = ns;
-            arg.chain_len[nch] = clen[c0];
-            for (int j = 0; j < clen[c0]; ++j) arg.s[ns++] = segs[order[cfirst[c0] + j]];
-            if (arg.s[arg.chain_first[nch]].n > maxn) maxn = arg.s[arg.chain_first[nch]].n;
-            ++nch;
+            const int n0 = segs[order[cfirst[c0]]].n;
+            if (n0 > 0) {
+                arg.chain_first[nch] = ns;
+                arg.chain_len[nch] = clen[c0];
+                arg.chain_blk0[nch] = nblk;
+                nblk += (n0 + 63) / 64;
+                for (int j = 0; j < clen[c0]; ++j) arg.s[ns++] = segs[order[cfirst[c0] + j]];
+                ++nch;
+            }
             ++c0;
         }
-        if (maxn <= 0 || nch == 0) continue;
-        hipLaunchKernelGGL(k_reduce_segments, dim3((maxn + 63) / 64, nch), dim3(1024), 0, st, arg);
+        if (nblk == 0) continue;
+        arg.nchains = nch;
+        hipLaunchKernelGGL(k_reduce_segments, dim3(nblk), dim3(1024), 0, st, arg);
         int rc = eqd_check_launch("k_reduce_segments");
         if (rc) return rc;
     }

@@ -122,6 +122,13 @@ class _IEGMNFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, packed, desc, table_idx, svd_draws, need_grad, flat_state, *uniq):
+        # Flat-gradient mode: `uniq` is (parameter list, anchor).  The ~160 parameters are then NOT autograd inputs
+        # (apply() only tracks top-level tensors): their gradients are accumulated by the C call straight into the
+        # flat buffer, and the 0-d `anchor` is the one input that makes autograd call backward().  Per-parameter
+        # inputs cost ~0.5 ms of host time per step in torch's Function machinery, as much as all kernel launches.
+        if flat_state is not None:
+            uniq = uniq[0]
+        ctx.set_materialize_grads(False)
         lib = _lib.load_library()
         dev = packed.x0.device
         gs = packed.c_struct()
@@ -172,11 +179,11 @@ class _IEGMNFunction(torch.autograd.Function):
         tensors = ctx.tensors
         ptrs = ctx.ptrs
         if ctx.flat_state is not None:      # accumulate straight into the model's persistent flat buffer
-            flat, offs = ctx.flat_state
+            flat, offs, goffs = ctx.flat_state
         else:
             offs, total = flat_layout(tensors)
             flat = torch.zeros(total, dtype=torch.float32, device=dev)
-        goffs = (C.c_int64 * len(ctx.table_idx))(*[offs[i] for i in ctx.table_idx])
+            goffs = (C.c_int64 * len(ctx.table_idx))(*[offs[i] for i in ctx.table_idx])
         scratch = torch.empty(ctx.wb, dtype=torch.uint8, device=dev)
 
         def prep(t):
@@ -187,7 +194,7 @@ class _IEGMNFunction(torch.autograd.Function):
             _lib.ptr(d_b), _lib.ptr(flat), goffs, _lib.ptr(ctx.saved), C.c_size_t(ctx.sb), _lib.ptr(scratch),
             C.c_size_t(ctx.wb), _lib.stream_ptr(dev), _lib.exec_ctx(dev)))
         if ctx.flat_state is not None:
-            return (None,) * (6 + len(tensors))
+            return (None,) * 8
         grads = tuple(flat[o:o + t.numel()].view(t.shape) for o, t in zip(offs, tensors))
         return (None, None, None, None, None, None) + grads
 
@@ -311,7 +318,10 @@ class IEGMN(nn.Module):
         flat = torch.zeros(total, dtype=torch.float32, device=uniq[0].device)
         for p, o in zip(uniq, offs):
             p.grad = flat[o:o + p.numel()].view(p.shape)
-        self._flat = (flat, offs, [id(p) for p in uniq])
+        _, table_idx = self._param_table()
+        goffs = (C.c_int64 * len(table_idx))(*[offs[i] for i in table_idx])
+        anchor = torch.zeros((), dtype=torch.float32, device=uniq[0].device, requires_grad=True)
+        self._flat = (flat, offs, [id(p) for p in uniq], goffs, anchor)
         return flat
 
     def zero_flat_grads(self):
@@ -334,9 +344,13 @@ class IEGMN(nn.Module):
         if self._flat is not None and need_grad:
             if self._flat[2] != [id(p) for p in uniq] or self._flat[0].device != packed.x0.device:
                 raise _lib.EquidockHipError("parameters changed since enable_flat_grads(); call it again")
-            flat_state = (self._flat[0], self._flat[1])
-        lig, Yl, Yr, T, b, status = _IEGMNFunction.apply(packed, self._desc(), table_idx, self.svd_draws, need_grad,
-                                                         flat_state, *uniq)
+            flat_state = (self._flat[0], self._flat[1], self._flat[3])
+        if flat_state is not None:
+            lig, Yl, Yr, T, b, status = _IEGMNFunction.apply(packed, self._desc(), table_idx, self.svd_draws,
+                                                             need_grad, flat_state, uniq, self._flat[4])
+        else:
+            lig, Yl, Yr, T, b, status = _IEGMNFunction.apply(packed, self._desc(), table_idx, self.svd_draws,
+                                                             need_grad, None, *uniq)
         self.last_svd_status = status
         return packed, lig, Yl, Yr, T, b
 

@@ -121,9 +121,8 @@ def test_model_vs_oracle_config_b(dev):
 
 
 def test_big_batch_equals_small_batches(dev):
-    """Config C regime (> 16 384 nodes: 32-row workgroups in the row kernels, several super-tiles per workgroup in the
-    edge backward, capped AtB parts): pairs are independent, so outputs must equal those of the same pairs run in
-    batches of 4 (different kernel decompositions), and the gradient of the summed loss must equal the sum."""
+    """Config C regime (> 16 384 nodes: several super-tiles per workgroup in the edge backward, capped AtB parts):
+    pairs are independent, so outputs must equal those of the same pairs run in batches of 4 (different kernel decompositions), and the gradient of the summed loss must equal the sum."""
     from equidock_public_amd import graph as G, synthetic
     from oracle import iegmn_port as port
     from tests import parity_common as pc
