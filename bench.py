@@ -43,9 +43,31 @@ EDGE_FWD_FLOP_PER_EDGE = 38272          # SURVEY.md section 8d, layers >= 1, mod
 EDGE_FWD_BYTES = lambda n, e: n * 540 + e * 112   # noqa: E731  SURVEY.md section 8d (fp32)
 
 
+class _BatchedLoss(torch.autograd.Function):
+    """sum over pairs of mean(lig'^2) + mean(Yl^2) + mean(Yr^2) on the batched outputs (lig_w[i] = 1 / (3 n_pair(i))).
+
+    The same scalar as oracle.iegmn_port.scalar_loss, with the backward written out: spelled with torch operators and
+    differentiated by autograd it is 27 elementwise / reduction launches (~100 us of GPU time at workload B, 5 % of
+    the step, none of it the path being measured); this way it is 15."""
+
+    @staticmethod
+    def forward(ctx, lig, Yl, Yr, lig_w):
+        wl = lig * lig_w
+        c = 1.0 / (Yl.shape[1] * Yl.shape[2])
+        ctx.save_for_backward(wl, Yl, Yr)
+        ctx.c = c
+        return (wl * lig).sum() + (Yl.square().sum() + Yr.square().sum()) * c
+
+    @staticmethod
+    def backward(ctx, g):
+        wl, Yl, Yr = ctx.saved_tensors
+        g2 = g * 2.0
+        gc = g2 * ctx.c
+        return wl * g2, Yl * gc, Yr * gc, None
+
+
 def batched_loss(lig, Yl, Yr, lig_w):
-    """sum over pairs of mean(lig'^2) + mean(Yl^2) + mean(Yr^2) on the batched outputs."""
-    return (lig * lig * lig_w).sum() + (Yl * Yl).mean(dim=(1, 2)).sum() + (Yr * Yr).mean(dim=(1, 2)).sum()
+    return _BatchedLoss.apply(lig, Yl, Yr, lig_w)
 
 
 def time_kernel(fn, iters, stream_sync):

@@ -57,14 +57,60 @@ __device__ __forceinline__ LinStep lin_next(const EqdLinJob& J, LinStep c) {
     return c;
 }
 
+// ---- job descriptor access ------------------------------------------------------------------------------
+// The descriptors live in LDS.  Reading a field as an LDS load + v_readfirstlane costs an LDS round trip (>= 64 clocks,
+// in practice serialised by the wait in front of every readfirstlane): the ~40 fields of a one-source job were 2 200
+// clocks of prologue in front of a single pipeline step of 1 800 (profiles/exp_trace_chain.py).  Instead lane i fetches
+// dword i and dword 64 + i of the descriptor ONCE - two LDS loads in flight together - and every field is a v_readlane
+// from those two registers: no memory access, and the next job's words are fetched while the current job runs.
+struct JobW {
+    int w0, w1;
+};
+__device__ __forceinline__ JobW jobw_load(const void* desc, int ndw, int lane) {
+    const int* p = (const int*)desc;
+    JobW W;
+    const int i1 = 64 + lane;
+    W.w0 = p[lane < ndw ? lane : 0];
+    W.w1 = p[i1 < ndw ? i1 : 0];
+    return W;
+}
+__device__ __forceinline__ int jw_i(const JobW& W, int dw) {
+    return __builtin_amdgcn_readlane(dw < 64 ? W.w0 : W.w1, dw & 63);
+}
+__device__ __forceinline__ float jw_f(const JobW& W, int dw) {
+    const int v = jw_i(W, dw);
+    float f;
+    __builtin_memcpy(&f, &v, 4);
+    return f;
+}
+template <class T>
+__device__ __forceinline__ T* jw_p(const JobW& W, int dw) {
+    const unsigned lo = (unsigned)jw_i(W, dw), hi = (unsigned)jw_i(W, dw + 1);
+    return (T*)(((unsigned long long)hi << 32) | (unsigned long long)lo);
+}
+#define JW_OFF(type, field) ((int)(offsetof(type, field) / 4))
+#define JW_SRC_DW ((int)(sizeof(EqdLinSrc) / 4))
+static_assert(sizeof(EqdChainJob) <= 128 * 4, "a job descriptor must fit two dwords per lane");
+static_assert(offsetof(EqdChainJob, lin) == 0, "EqdChainJob starts with its EqdLinJob");
+__device__ __forceinline__ EqdLinSrc jw_src(const JobW& W, int si) {
+    const int b = JW_OFF(EqdLinJob, s) + si * JW_SRC_DW;
+    EqdLinSrc S;
+    S.X = jw_p<const float>(W, b + JW_OFF(EqdLinSrc, X));
+    S.mask = jw_p<const float>(W, b + JW_OFF(EqdLinSrc, mask));
+    S.W = jw_p<const float>(W, b + JW_OFF(EqdLinSrc, W));
+    S.ldx = jw_i(W, b + JW_OFF(EqdLinSrc, ldx));
+    S.K = jw_i(W, b + JW_OFF(EqdLinSrc, K));
+    S.w_rs = jw_i(W, b + JW_OFF(EqdLinSrc, w_rs));
+    S.w_cs = jw_i(W, b + JW_OFF(EqdLinSrc, w_cs));
+    return S;
+}
+
 // ---- loads of one step into registers (nothing is waited for here) -------------------------------------
 template <int RT>
-__device__ __forceinline__ void lin_load(const EqdLinJob& J, const EqdLinSrc& S_, bool local, LinStep c, int row0, int t,
-                                         LinRegs<RT>& R) {
+__device__ __forceinline__ void lin_load_s(const EqdLinSrc S, const int M, const int rows, bool local, LinStep c, int row0,
+                                           int t, LinRegs<RT>& R) {      // S, M, rows: already wave-uniform (SGPRs)
     const int tr = t >> 4, tc = t & 15;
-    const EqdLinSrc S = uni(S_);
     const bool kfast = (S.w_cs == 1);
-    const int M = uni(J.M), rows = uni(J.rows);
     if (c.kc == 64) {
         if (!local) {
 #pragma unroll
@@ -126,15 +172,19 @@ __device__ __forceinline__ void lin_load(const EqdLinJob& J, const EqdLinSrc& S_
     }
 }
 
+template <int RT>
+__device__ __forceinline__ void lin_load(const EqdLinJob& J, const EqdLinSrc& S_, bool local, LinStep c, int row0, int t,
+                                         LinRegs<RT>& R) {
+    lin_load_s<RT>(uni(S_), uni(J.M), uni(J.rows), local, c, row0, t, R);
+}
+
 // ---- registers -> LDS: Xl[rt][row][k]; Wl[m][k], except full steps of transposed sources: Wl[k][m]; zero padded ------------------------------
 template <int RT>
-__device__ __forceinline__ void lin_store(const EqdLinJob& J, const EqdLinSrc& S, bool local, LinStep c, int t,
-                                          const LinRegs<RT>& R, LinSmem<RT>& sm) {
+__device__ __forceinline__ void lin_store_s(const EqdLinSrc S, const int M, const float slope, bool local, LinStep c, int t,
+                                            const LinRegs<RT>& R, LinSmem<RT>& sm) {     // S, M, slope: wave-uniform
     const int tr = t >> 4, tc = t & 15;
-    const bool kfast = (uni(S.w_cs) == 1);
-    const bool masked = uni(S.mask) != nullptr;
-    const int M = uni(J.M);
-    const float slope = uni(J.slope);
+    const bool kfast = (S.w_cs == 1);
+    const bool masked = S.mask != nullptr;
     float* __restrict__ Wl = sm.Wl;
     if (c.kc == 64) {
         if (!local) {
@@ -188,6 +238,12 @@ __device__ __forceinline__ void lin_store(const EqdLinJob& J, const EqdLinSrc& S
     }
 }
 
+template <int RT>
+__device__ __forceinline__ void lin_store(const EqdLinJob& J, const EqdLinSrc& S, bool local, LinStep c, int t,
+                                          const LinRegs<RT>& R, LinSmem<RT>& sm) {
+    lin_store_s<RT>(uni(S), uni(J.M), uni(J.slope), local, c, t, R, sm);
+}
+
 // acc[rt][i] (+)= W-fragment x X-fragment of the chunk for the wave's NOWN output blocks; no per-lane predicates.
 // The weight fragments are read once for the RT row tiles.  MFMAs alternate between two accumulator sets (a single
 // dependent chain leaves the matrix pipe idle).
@@ -224,32 +280,232 @@ __device__ __forceinline__ void lin_mma(f32x4 (&acc)[RT][2], f32x4 (&acc2)[RT][2
     }
 }
 
+// ---- lean job (one row tile, M == 64, every source at least 64 wide: all jobs of the layers >= 1 except the 69-wide h0
+//      gradient).  Everything that the general linear_tile below decides per element is a compile-time fact here (one
+//      complete output block per wave, 16-byte accesses everywhere), every load address is computed ONCE per job and kept
+//      in VGPRs, and the source loop is unrolled; a step is: barrier, 5 b128 LDS stores, barrier, 5 loads for the step
+//      after next, 8 LDS reads, 16 MFMAs.  A workgroup at config B has nothing to overlap a job's bookkeeping with
+//      (one wave per SIMD), so its instruction count is latency: the general path spends ~3 500 clocks per step and
+//      ~2 000 per job on descriptor handling; the floor with static addressing is 1 350 per step
+//      (profiles/exp_step_floor.hip).  Arithmetic (order of every sum) is the same as in linear_tile. -----------------
+__device__ __forceinline__ void linear_tile_lean(const JobW& W, bool chain, int out_local, LinSmem<1>& sm,
+                                                 float (*Lb)[LIN_LOCALS][16 * LIN_S], int row0, LinRegs<1>& RA,
+                                                 bool have_first, bool has_next, const JobW& Wn, int trace_slot) {
+    (void)trace_slot;
+#define LJ(f) JW_OFF(EqdLinJob, f)
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int tr = t >> 4, tc = t & 15;
+    const int rows = jw_i(W, LJ(rows)), nsrc = jw_i(W, LJ(nsrc));
+    const float slope = jw_f(W, LJ(slope));
+    // epilogue operands of this wave's output block (features f0 .. f0 + 3 of row row0 + l15), requested now
+    const int f0 = 16 * wave + 4 * g;
+    const int rowi = row0 + l15;
+    const bool rv = rowi < rows;
+    const int rowe = rv ? rowi : rows - 1;
+    const float* const jbias = jw_p<const float>(W, LJ(bias));
+    const float* const jlng = jw_p<const float>(W, LJ(ln_g));
+    const float* const jR = jw_p<const float>(W, LJ(R));
+    f32x4 bias = f4zero(), lg = f4zero(), lb = f4zero(), res = f4zero();
+    if (jbias) bias = *(const EQD_GAS f4v*)(jbias + f0);
+    if (jlng) {
+        lg = *(const EQD_GAS f4v*)(jlng + f0);
+        lb = *(const EQD_GAS f4v*)(jw_p<const float>(W, LJ(ln_b)) + f0);
+    }
+    if (jR) res = *(const EQD_GAS f4v*)(jR + (size_t)rowe * jw_i(W, LJ(ldr)) + f0);
+    f32x4 acc[1][2], acc2[1][2];
+    acc[0][0] = acc[0][1] = acc2[0][0] = acc2[0][1] = f4zero();
+    const int mbs[2] = {wave, wave + 4};
+
+    // per-source addresses of this thread: X row tr (clamped), columns 4 tc ..; W rows tr + 16 j (or k rows when transposed)
+    unsigned long long xa[EQD_MAX_SRC], ma[EQD_MAX_SRC], wa[EQD_MAX_SRC];
+    int wst[EQD_MAX_SRC], locs[EQD_MAX_SRC];
+    int rowc0 = row0 + tr;
+    rowc0 = rowc0 < rows ? rowc0 : rows - 1;
+    unsigned kfm = 0u, mkm = 0u, remm = 0u;
+#pragma unroll
+    for (int si = 0; si < EQD_MAX_SRC; ++si) {
+        if (si < nsrc) {
+            const EqdLinSrc S = jw_src(W, si);
+            locs[si] = chain ? jw_i(W, JW_OFF(EqdChainJob, src_local) + si) : -1;
+            const bool kf = (S.w_cs == 1);
+            const int stride = kf ? S.w_rs : S.w_cs;
+            if (kf) kfm |= 1u << si;
+            if (S.mask) mkm |= 1u << si;
+            if (S.K > 64) remm |= 1u << si;
+            wa[si] = (unsigned long long)(S.W + (size_t)tr * stride + 4 * tc);
+            wst[si] = 64 * stride;      // bytes between weight rows tr + 16 j
+            if (locs[si] < 0) {
+                xa[si] = (unsigned long long)(S.X + (size_t)rowc0 * S.ldx + 4 * tc);
+                ma[si] = S.mask ? (unsigned long long)(S.mask + (size_t)rowc0 * S.ldx + 4 * tc) : 0ull;
+            }
+        }
+    }
+    auto load = [&](int si, LinRegs<1>& R) {       // si is a compile-time constant at every call
+        if (locs[si] < 0) {
+            R.x[0] = *(const EQD_GAS f4v*)(xa[si]);
+            if ((mkm >> si) & 1u) R.xm[0] = *(const EQD_GAS f4v*)(ma[si]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) R.w[j] = *(const EQD_GAS f4v*)(wa[si] + (unsigned long long)(unsigned)(j * wst[si]));
+    };
+    LinRegs<1> RB;
+    int tr_i = 0;
+    (void)tr_i;
+    EQD_TR(trace_slot + 1);
+    LIN_TR(tr_i++);
+    if (!have_first) load(0, RA);
+    if (1 < nsrc) load(1, RB);
+    LIN_TR(tr_i++);
+#pragma unroll
+    for (int si = 0; si < EQD_MAX_SRC; ++si) {
+        if (si < nsrc) {
+            LinRegs<1>& RX = (si & 1) ? RB : RA;
+            __syncthreads();                  // previous step's fragment reads are done
+            LIN_TR(tr_i++);
+            if (locs[si] < 0) {
+                f32x4 v = RX.x[0];
+                if ((mkm >> si) & 1u) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] *= lrelu_grad(RX.xm[0][i], slope);
+                }
+                *(f32x4*)&sm.Xl[0][tr * LIN_S + 4 * tc] = v;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *(f32x4*)&sm.Wl[(tr + 16 * j) * LIN_S + 4 * tc] = RX.w[j];   // Wl[m][k] or Wl[k][m]
+            LIN_TR(tr_i++);
+            __syncthreads();
+            LIN_TR(tr_i++);
+            if (si + 2 < EQD_MAX_SRC) {
+                if (si + 2 < nsrc) load((si + 2) % EQD_MAX_SRC, RX);
+            }
+            LIN_TR(tr_i++);
+            const float* Xs[1] = {locs[si] >= 0 ? &Lb[0][locs[si]][0] : sm.Xl[0]};
+            if ((kfm >> si) & 1u)
+                lin_mma<1, 1, 4, false>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+            else
+                lin_mma<1, 1, 4, true>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+            LIN_TR(tr_i++);
+        }
+    }
+    // what is left of sources wider than 64 (the 5 columns beyond 64 of the 69-wide h0): 16-wide steps, not pipelined
+    if (remm) {
+        const int M = 64;
+#pragma unroll
+        for (int si = 0; si < EQD_MAX_SRC; ++si) {
+            if (si < nsrc && ((remm >> si) & 1u)) {
+                const EqdLinSrc S = jw_src(W, si);
+                for (int k0 = 64; k0 < S.K;) {
+                    const LinStep c = {si, k0, lin_chunk(S.K - k0)};
+                    lin_load_s<1>(S, M, rows, locs[si] >= 0, c, row0, t, RB);
+                    __syncthreads();
+                    lin_store_s<1>(S, M, slope, locs[si] >= 0, c, t, RB, sm);
+                    __syncthreads();
+                    const float* Xs[1] = {locs[si] >= 0 ? &Lb[0][locs[si]][k0] : sm.Xl[0]};
+                    lin_mma<1, 1, 1, false>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+                    k0 += c.kc;
+                }
+            }
+        }
+    }
+    EQD_TR(trace_slot + 2);
+    if (has_next) {      // the next job's first step (same rows) -> RA
+        const EqdLinSrc Sn = jw_src(Wn, 0);
+        const bool local_n = chain && jw_i(Wn, JW_OFF(EqdChainJob, src_local)) >= 0;
+        const LinStep c0 = {0, 0, lin_chunk(Sn.K)};
+        lin_load_s<1>(Sn, jw_i(Wn, LJ(M)), rows, local_n, c0, row0, t, RA);
+    }
+    EQD_TR(trace_slot + 3);
+    // ---- epilogue: feature f0 + r of row rowi ------------------------------------------------------------------------
+    const int act = jw_i(W, LJ(act));
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float y = (acc[0][0][r] + acc2[0][0][r]) + bias[r];
+        if (act) y = lrelu(y, slope);
+        v[r] = y;
+    }
+    if (jlng) {
+        const float invM = 1.f / 64.f;
+        float s1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s1 += v[r];
+        s1 = group_sum(s1);
+        if (g == 0) sm.stat[0][wave][l15] = s1;
+        __syncthreads();
+        const float mean = (sm.stat[0][0][l15] + sm.stat[0][1][l15] + sm.stat[0][2][l15] + sm.stat[0][3][l15]) * invM;
+        float q = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float dlt = v[r] - mean;
+            q += dlt * dlt;
+        }
+        q = group_sum(q);
+        __syncthreads();
+        if (g == 0) sm.stat[0][wave][l15] = q;
+        __syncthreads();
+        const float rstd = 1.f / sqrtf((sm.stat[0][0][l15] + sm.stat[0][1][l15] + sm.stat[0][2][l15] + sm.stat[0][3][l15]) * invM +
+                                       jw_f(W, LJ(ln_eps)));
+        float* const jpre = jw_p<float>(W, LJ(pre_ln));
+        const int ld_pre = jw_i(W, LJ(ld_pre));
+        if (jpre && rv) *(EQD_GAS f4v*)&jpre[(size_t)rowi * ld_pre + f0] = f32x4{v[0], v[1], v[2], v[3]};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (v[r] - mean) * rstd * lg[r] + lb[r];
+    }
+    const float alpha = jw_f(W, LJ(alpha)), beta = jw_f(W, LJ(beta));
+    f32x4 yv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) yv[r] = alpha * v[r] + beta * res[r];
+    float* const jY = jw_p<float>(W, LJ(Y));
+    const int ldy = jw_i(W, LJ(ldy));
+    if (jY && rv) *(EQD_GAS f4v*)&jY[(size_t)rowi * ldy + f0] = yv;
+    if (out_local >= 0) *(f32x4*)&Lb[0][out_local][l15 * LIN_S + f0] = yv;
+    LIN_TR(tr_i++);
+#undef LJ
+}
+
 // One linear job on rows row0 .. row0 + 16 RT - 1.  src_local[i] >= 0: source i is the LDS tile Lb[rt][src_local[i]]
 // ([16][LIN_S], written by an earlier job of the chain; K <= 80); out_local >= 0: the result is also left in
 // Lb[rt][out_local].  Must be called by all 256 threads of the workgroup.
 // RA / have_first / has_next: a row chain hands the registers of this job's first step in already loaded (have_first)
 // and names the next linear job (Jn, its LDS-source flags src_local_n), whose first step is fetched into RA before this
 // job's epilogue - otherwise every job of a chain starts with a fully exposed memory round trip.
+// W: the descriptor words of J (jobw_load); chain: J is the `lin` of an EqdChainJob, whose src_local / out_local words are
+// in W too; Wn: the words of the next job Jn (only read when has_next).
 template <int RT>
-__device__ __forceinline__ void linear_tile(const EqdLinJob& J, const int* __restrict__ src_local, int out_local,
+__device__ __forceinline__ void linear_tile(const EqdLinJob& J, const JobW& W, bool chain,
+                                            const int* __restrict__ src_local, int out_local,
                                             LinSmem<RT>& sm, float (*Lb)[LIN_LOCALS][16 * LIN_S], int row0,
-                                            LinRegs<RT>& RA, bool have_first, bool has_next, const EqdLinJob& Jn,
-                                            const int* __restrict__ src_local_n, int trace_slot = 255) {
+                                            LinRegs<RT>& RA, bool have_first, bool has_next, const JobW& Wn,
+                                            int trace_slot = 255) {
     (void)trace_slot;
     EQD_TR(trace_slot);
+#define LJ(f) JW_OFF(EqdLinJob, f)
+    const int M = jw_i(W, LJ(M)), nsrc = jw_i(W, LJ(nsrc));
+    if constexpr (RT == 1) {     // with two row tiles the lean job's address registers spill (256-VGPR budget)
+        bool lean = (M == 64);
+#pragma unroll
+        for (int si = 0; si < EQD_MAX_SRC; ++si)
+            if (si < nsrc && jw_i(W, LJ(s) + si * JW_SRC_DW + JW_OFF(EqdLinSrc, K)) < 64) lean = false;
+        if (lean) {
+            linear_tile_lean(W, chain, out_local, sm, Lb, row0, RA, have_first, has_next, Wn, trace_slot);
+            return;
+        }
+    }
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    // the job header, moved to SGPRs once (see uni())
-    const int M = uni(J.M), rows = uni(J.rows), nsrc = uni(J.nsrc), act = uni(J.act);
-    const float* const jbias = uni(J.bias);
-    const float* const jlng = uni(J.ln_g);
-    const float* const jlnb = uni(J.ln_b);
-    const float* const jR = uni(J.R);
-    float* const jY = uni(J.Y);
-    float* const jpre = uni(J.pre_ln);
-    const int ldr = uni(J.ldr), ldy = uni(J.ldy), ld_pre = uni(J.ld_pre);
-    const float alpha = uni(J.alpha), beta = uni(J.beta), slope = uni(J.slope), ln_eps = uni(J.ln_eps);
+    // the job header: SGPRs, read out of the descriptor words
+    const int rows = jw_i(W, LJ(rows)), act = jw_i(W, LJ(act));
+    const float* const jbias = jw_p<const float>(W, LJ(bias));
+    const float* const jlng = jw_p<const float>(W, LJ(ln_g));
+    const float* const jlnb = jw_p<const float>(W, LJ(ln_b));
+    const float* const jR = jw_p<const float>(W, LJ(R));
+    float* const jY = jw_p<float>(W, LJ(Y));
+    float* const jpre = jw_p<float>(W, LJ(pre_ln));
+    const int ldr = jw_i(W, LJ(ldr)), ldy = jw_i(W, LJ(ldy)), ld_pre = jw_i(W, LJ(ld_pre));
+    const float alpha = jw_f(W, LJ(alpha)), beta = jw_f(W, LJ(beta)), slope = jw_f(W, LJ(slope)), ln_eps = jw_f(W, LJ(ln_eps));
     const int mbn = (M + 15) >> 4;
     // this wave's output blocks and their epilogue operands (fetched now: the latency hides under the GEMM)
     const int mbs[2] = {wave, wave + 4};
@@ -276,15 +532,6 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const int* __res
 #pragma unroll
         for (int i = 0; i < 2; ++i) acc[rt][i] = acc2[rt][i] = f4zero();
 
-    // ---- lean pipeline (M == 64, every source at least 64 wide - all jobs of the layers >= 1 except the 69-wide h0
-    //      gradient): every load address is computed ONCE per job and kept in VGPRs, the source loop is unrolled, and a
-    //      step is: barrier, 5 b128 LDS stores, barrier, 5 loads for the step after next, 8 LDS reads, 16 MFMAs.  The
-    //      generic pipeline below spends ~3 500 clocks per step on descriptor handling and bookkeeping; the floor measured
-    //      with static addressing is 1 350 (profiles/exp_step_floor.hip). ----------------------------------------------------
-    bool lean = (RT == 1) && (M == 64);     // with two row tiles the extra address registers spill (256-VGPR budget)
-#pragma unroll
-    for (int si = 0; si < EQD_MAX_SRC; ++si)
-        if (si < nsrc && uni(J.s[si].K) < 64) lean = false;
     LinRegs<RT> RB;
     int tr_i = 0;
     (void)tr_i;
@@ -346,126 +593,14 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const int* __res
             nx = n2;
         }
     };
-    if constexpr (RT == 1) {
-        if (lean) {
-            const int tr = t >> 4, tc = t & 15;
-            // addresses of row tile 0; tile rt is drow[rt] rows further (rows beyond the matrix are clamped to its last row)
-            unsigned long long xa[EQD_MAX_SRC], ma[EQD_MAX_SRC], wa[EQD_MAX_SRC];
-            int wst[EQD_MAX_SRC], locs[EQD_MAX_SRC], ldxb[EQD_MAX_SRC];
-            int rowc0 = row0 + tr, drow[RT];
-            rowc0 = rowc0 < rows ? rowc0 : rows - 1;
-    #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                int r = row0 + 16 * rt + tr;
-                r = r < rows ? r : rows - 1;
-                drow[rt] = r - rowc0;
-            }
-            unsigned kfm = 0u, mkm = 0u, remm = 0u;
-    #pragma unroll
-            for (int si = 0; si < EQD_MAX_SRC; ++si) {
-                wst[si] = 0;
-                locs[si] = -1;
-                ldxb[si] = 0;
-                wa[si] = xa[si] = ma[si] = 0ull;
-                if (si < nsrc) {
-                    const EqdLinSrc S = uni(J.s[si]);
-                    locs[si] = src_local ? uni(src_local[si]) : -1;
-                    const bool kf = (S.w_cs == 1);
-                    const int stride = kf ? S.w_rs : S.w_cs;
-                    if (kf) kfm |= 1u << si;
-                    if (S.mask) mkm |= 1u << si;
-                    if (S.K > 64) remm |= 1u << si;
-                    wa[si] = (unsigned long long)(S.W + (size_t)tr * stride + 4 * tc);
-                    wst[si] = 64 * stride;      // bytes between weight rows tr + 16 j
-                    if (locs[si] < 0) {
-                        ldxb[si] = 4 * S.ldx;
-                        xa[si] = (unsigned long long)(S.X + (size_t)rowc0 * S.ldx + 4 * tc);
-                        ma[si] = S.mask ? (unsigned long long)(S.mask + (size_t)rowc0 * S.ldx + 4 * tc) : 0ull;
-                    }
-                }
-            }
-            auto load = [&](int si, LinRegs<RT>& R) {       // si is a compile-time constant at every call
-                if (locs[si] < 0) {
-    #pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) {
-                        const unsigned long long off = (unsigned long long)((long long)drow[rt] * ldxb[si]);
-                        R.x[rt] = *(const EQD_GAS f4v*)(xa[si] + off);
-                        if ((mkm >> si) & 1u) R.xm[rt] = *(const EQD_GAS f4v*)(ma[si] + off);
-                    }
-                }
-    #pragma unroll
-                for (int j = 0; j < 4; ++j) R.w[j] = *(const EQD_GAS f4v*)(wa[si] + (unsigned long long)(unsigned)(j * wst[si]));
-            };
-            EQD_TR(trace_slot + 1);
-            LIN_TR(tr_i++);
-            if (!have_first) load(0, RA);
-            if (1 < nsrc) load(1, RB);
-            LIN_TR(tr_i++);
-    #pragma unroll
-            for (int si = 0; si < EQD_MAX_SRC; ++si) {
-                if (si < nsrc) {
-                    LinRegs<RT>& RX = (si & 1) ? RB : RA;
-                    __syncthreads();                  // previous step's fragment reads are done
-                    LIN_TR(tr_i++);
-                    if (locs[si] < 0) {
-    #pragma unroll
-                        for (int rt = 0; rt < RT; ++rt) {
-                            f32x4 v = RX.x[rt];
-                            if ((mkm >> si) & 1u) {
-    #pragma unroll
-                                for (int i = 0; i < 4; ++i) v[i] *= lrelu_grad(RX.xm[rt][i], slope);
-                            }
-                            *(f32x4*)&sm.Xl[rt][tr * LIN_S + 4 * tc] = v;
-                        }
-                    }
-    #pragma unroll
-                    for (int j = 0; j < 4; ++j) *(f32x4*)&sm.Wl[(tr + 16 * j) * LIN_S + 4 * tc] = RX.w[j];   // Wl[m][k] or Wl[k][m]
-                    LIN_TR(tr_i++);
-                    __syncthreads();
-                    LIN_TR(tr_i++);
-                    if (si + 2 < EQD_MAX_SRC) {
-                        if (si + 2 < nsrc) load((si + 2) % EQD_MAX_SRC, RX);
-                    }
-                    LIN_TR(tr_i++);
-                    const float* Xs[RT];
-    #pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) Xs[rt] = locs[si] >= 0 ? &Lb[rt][locs[si]][0] : sm.Xl[rt];
-                    if ((kfm >> si) & 1u)
-                        lin_mma<RT, 1, 4, false>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
-                    else
-                        lin_mma<RT, 1, 4, true>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
-                    LIN_TR(tr_i++);
-                }
-            }
-            // what is left of sources wider than 64 (the 5 columns beyond 64 of the 69-wide h0): 16-wide steps, not pipelined
-            if (remm) {
-    #pragma unroll
-                for (int si = 0; si < EQD_MAX_SRC; ++si) {
-                    if (si < nsrc && ((remm >> si) & 1u)) {
-                        const EqdLinSrc S = uni(J.s[si]);
-                        for (int k0 = 64; k0 < S.K;) {
-                            const LinStep c = {si, k0, lin_chunk(S.K - k0)};
-                            lin_load<RT>(J, J.s[si], locs[si] >= 0, c, row0, t, RB);
-                            __syncthreads();
-                            lin_store<RT>(J, J.s[si], locs[si] >= 0, c, t, RB, sm);
-                            __syncthreads();
-                            const float* Xs[RT];
-    #pragma unroll
-                            for (int rt = 0; rt < RT; ++rt) Xs[rt] = locs[si] >= 0 ? &Lb[rt][locs[si]][k0] : sm.Xl[rt];
-                            lin_mma<RT, 1, 1, false>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
-                            k0 += c.kc;
-                        }
-                    }
-                }
-            }
-        } else {
-            generic_pipeline();
-        }
-    } else {
-        generic_pipeline();
-    }
+    generic_pipeline();
     EQD_TR(trace_slot + 2);
-    if (has_next) lin_load<RT>(Jn, Jn.s[0], src_local_n && uni(src_local_n[0]) >= 0, lin_first(Jn), row0, t, RA);
+    if (has_next) {      // the next job's first step (same rows) -> RA
+        const EqdLinSrc Sn = jw_src(Wn, 0);
+        const bool local_n = chain && jw_i(Wn, JW_OFF(EqdChainJob, src_local)) >= 0;
+        const LinStep c0 = {0, 0, lin_chunk(Sn.K)};
+        lin_load_s<RT>(Sn, jw_i(Wn, LJ(M)), rows, local_n, c0, row0, t, RA);
+    }
     EQD_TR(trace_slot + 3);
     // ---- epilogue in F-layout: feature f = 16 mb + 4 g + r, row = row0 + 16 rt + l15 -----------------------------
     // `plain`: M is a multiple of 4, so an owned 4-feature group is always complete - no tail handling, 16-byte stores
@@ -568,4 +703,5 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const int* __res
         }
     }
     LIN_TR(tr_i++);
+#undef LJ
 }

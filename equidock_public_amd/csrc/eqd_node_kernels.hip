@@ -56,7 +56,8 @@ __global__ __launch_bounds__(EQD_BLOCK, 2) void k_linear(LinJobsArg jobs) {
     if (row0 >= J.rows) return;      // uniform for the whole workgroup
     EQD_TR_WG();
     LinRegs<RT> RA;
-    linear_tile<RT>(J, nullptr, -1, sm, nullptr, row0, RA, false, false, J, nullptr);
+    const JobW W = jobw_load(&Jl, (int)(sizeof(EqdLinJob) / 4), threadIdx.x & 63);
+    linear_tile<RT>(J, W, false, nullptr, -1, sm, nullptr, row0, RA, false, false, W);
     EQD_TR_WG_END();
 }
 // 16-row tiles per workgroup.  One tile everywhere: with the lean (precomputed-address) step pipeline, which only fits
@@ -169,17 +170,23 @@ __global__ __launch_bounds__(EQD_BLOCK, 2) void k_rowchain(EqdChainArg A_) {
     LinRegs<RT> RA;
     bool have = false;
     const int njobs = uni(A.njobs);
+    constexpr int CJ_DW = (int)(sizeof(EqdChainJob) / 4);
+    const int lane = threadIdx.x & 63;
+    JobW Wc = jobw_load(&A.j[0], CJ_DW, lane);      // descriptor words of the current job (see JobW)
     for (int jj = 0; jj < njobs; ++jj) {
         const EqdChainJob& C = A.j[jj];
-        if (uni(C.type) == 0) {
-            const int nj = uni(C.prefetch_next);      // next linear job whose first step may be fetched early, or -1
-            const EqdChainJob& Cn = A.j[nj >= 0 ? nj : jj];
-            linear_tile<RT>(C.lin, C.src_local, uni(C.out_local), sm, Lb, row0, RA, have, nj >= 0, Cn.lin, Cn.src_local,
-                            210 + 4 * jj);
+        const JobW Wn = jobw_load(&A.j[jj + 1 < njobs ? jj + 1 : jj], CJ_DW, lane);      // consumed a job later
+        if (jw_i(Wc, JW_OFF(EqdChainJob, type)) == 0) {
+            const int nj = jw_i(Wc, JW_OFF(EqdChainJob, prefetch_next));   // next linear job whose first step may be fetched early, or -1
+            JobW Wp = Wn;
+            if (nj >= 0 && nj != jj + 1) Wp = jobw_load(&A.j[nj], CJ_DW, lane);
+            linear_tile<RT>(C.lin, Wc, true, C.src_local, jw_i(Wc, JW_OFF(EqdChainJob, out_local)), sm, Lb, row0, RA, have,
+                            nj >= 0, Wp, 210 + 4 * jj);
             have = nj >= 0;
         } else {
             chain_lnbwd<RT>(C, Lb, red, row0);
         }
+        Wc = Wn;
         __syncthreads();
         EQD_TR(201 + jj);      // job boundaries (phase-trace experiments only)
     }
@@ -404,7 +411,7 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_atb(AtbUnitsArg U, float* __restr
     const EqdAtbJob& J = u.job;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const int tr = t >> 4, tc = t & 15;
+    (void)t;
     const int mbn = (J.M + 15) >> 4;
     f32x4 acc[5];
 #pragma unroll

@@ -11,7 +11,7 @@ from oracle import iegmn_port as port
 if __name__ == '__main__':
     lib = L.load_library_for_testing(OUT)
     dev = torch.device('cuda:0')
-    args = port.default_args(iegmn_n_lays=8, skip_weight_h=0.75, device=dev)
+    args = port.default_args(iegmn_n_lays=8, skip_weight_h=0.75, device=dev, use_mean_node_features='--d69' in sys.argv)   # default: every layer 64 wide, so that the traced (last) chain is a typical one
     net = model.Rigid_Body_Docking_Net(args).to(dev)
     net.load_state_dict(port.init_state_dict(args, 0))
     g = graph.batch_pairs(synthetic.make_pairs([(200, 200)] * 8, 1000)).to(dev)

@@ -108,3 +108,4 @@ static inline hostsim_f32x4 hostsim_mfma_bf16(hostsim_s16x4 a, hostsim_s16x4 b, 
 #define __builtin_amdgcn_wave_barrier() hostsim::wave_barrier()
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
 #define __builtin_amdgcn_readfirstlane(x) (x)   /* only applied to wave-uniform values */
+#define __builtin_amdgcn_readlane(v, l) hostsim::shfl_i((v), (l))

@@ -155,3 +155,22 @@ def test_bad_inputs_rejected():
     bad['src'][0] = 10 ** 6
     with pytest.raises(ValueError, match='out of range'):
         G.batch_pairs([(bad, rec)])
+
+
+def test_bench_loss_equals_oracle_scalar_loss():
+    """bench.py's batched loss (hand-written backward) against the oracle's per-pair expression under autograd"""
+    import bench
+    from oracle import iegmn_port as port
+    torch.manual_seed(0)
+    counts = [5, 9, 3]
+    lig = torch.randn(sum(counts), 3, dtype=torch.float64, requires_grad=True)
+    Yl = torch.randn(3, 7, 3, dtype=torch.float64, requires_grad=True)
+    Yr = torch.randn(3, 7, 3, dtype=torch.float64, requires_grad=True)
+    lig_w = torch.cat([torch.full((n, 1), 1.0 / (3 * n), dtype=torch.float64) for n in counts])
+    a = bench.batched_loss(lig, Yl, Yr, lig_w)
+    ga = torch.autograd.grad(a * 1.7, (lig, Yl, Yr))
+    b = port.scalar_loss((list(torch.split(lig, counts)), list(Yl), list(Yr), None, None))
+    gb = torch.autograd.grad(b * 1.7, (lig, Yl, Yr))
+    assert abs(float(a) - float(b)) < 1e-12
+    for x, y in zip(ga, gb):
+        assert torch.allclose(x, y, atol=1e-13)
