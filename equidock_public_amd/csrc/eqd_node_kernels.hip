@@ -81,6 +81,92 @@ int eqd_rowchain_blocks(int rows) {
 // (7 jobs, was 3 launches) in the forward, and  node_mlp.4^T -> LeakyReLU/LayerNorm backward ->
 // d aggr_msg / d aggr_cross / d h0  (5 jobs, was 3 launches + a reduction) in the backward.
 // ------------------------------------------------------------------------------------------
+// d == 64, one row tile: the workgroup works in the layout of the linear jobs' epilogue (lane = row l15, features
+// 16 wave + 4 g .. + 3): a row statistic is an in-lane sum of 4, two cross-lane steps and an exchange between the four
+// waves through LDS - three rounds (mean; variance; the two projections) instead of the 16 six-step wave reductions per
+// wave of the one-wave-per-row layout, which ran one after the other (9 800 of the chain's 47 600 clocks).  yp: the
+// job's y_act values, fetched by the caller before the previous job (have_y) or here.
+__device__ __forceinline__ void chain_lnbwd64(const JobW& W, float (*Lb)[LIN_LOCALS][16 * LIN_S], float (*stat)[EQD_WAVES][16],
+                                              int row0, bool have_y, f32x4 yp) {
+#define LJ(f) JW_OFF(EqdLinJob, f)
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, g = lane >> 4;
+    const int rows = jw_i(W, LJ(rows));
+    const int src_l = jw_i(W, JW_OFF(EqdChainJob, src_local)), out_l = jw_i(W, JW_OFF(EqdChainJob, out_local));
+    const float slope = jw_f(W, LJ(slope)), ln_eps = jw_f(W, LJ(ln_eps));
+    const int f0 = 16 * wave + 4 * g;
+    const int rowi = row0 + l15;
+    const bool rv = rowi < rows;
+    const f32x4 gam = *(const EQD_GAS f4v*)(jw_p<const float>(W, LJ(ln_g)) + f0);
+    if (!have_y) {
+        const int ldx = jw_i(W, LJ(s) + JW_OFF(EqdLinSrc, ldx));
+        yp = *(const EQD_GAS f4v*)(jw_p<const float>(W, LJ(s) + JW_OFF(EqdLinSrc, X)) + (size_t)(rv ? rowi : rows - 1) * ldx + f0);
+    }
+    float* const jY = jw_p<float>(W, LJ(Y));
+    const int ldy = jw_i(W, LJ(ldy));
+    float* const jaux = jw_p<float>(W, JW_OFF(EqdChainJob, aux));
+#undef LJ
+    f32x4 o = *(const f32x4*)&Lb[0][src_l][l15 * LIN_S + f0];
+    f32x4 y = yp;
+    if (!rv) {
+        o = f4zero();
+        y = f4zero();
+    }
+    const float invd = 1.f / 64.f;
+    auto row_total = [&](float v, int slot) {      // sum over the row's 64 features; all 256 threads call it
+        v = group_sum(v);
+        if (g == 0) stat[slot][wave][l15] = v;
+        __syncthreads();
+        return (stat[slot][0][l15] + stat[slot][1][l15]) + (stat[slot][2][l15] + stat[slot][3][l15]);
+    };
+    const float mean = row_total((y[0] + y[1]) + (y[2] + y[3]), 0) * invd;
+    f32x4 c;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[r] = y[r] - mean;
+    const float rstd = 1.f / sqrtf(row_total((c[0] * c[0] + c[1] * c[1]) + (c[2] * c[2] + c[3] * c[3]), 1) * invd + ln_eps);
+    f32x4 xh, dx;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        xh[r] = c[r] * rstd;
+        dx[r] = o[r] * gam[r];
+    }
+    // the two projections share one exchange (slots 2 and 3)
+    float p1 = group_sum((dx[0] + dx[1]) + (dx[2] + dx[3]));
+    float p2 = group_sum((dx[0] * xh[0] + dx[1] * xh[1]) + (dx[2] * xh[2] + dx[3] * xh[3]));
+    if (g == 0) {
+        stat[2][wave][l15] = p1;
+        stat[3][wave][l15] = p2;
+    }
+    __syncthreads();
+    const float s1 = ((stat[2][0][l15] + stat[2][1][l15]) + (stat[2][2][l15] + stat[2][3][l15])) * invd;
+    const float s2 = ((stat[3][0][l15] + stat[3][1][l15]) + (stat[3][2][l15] + stat[3][3][l15])) * invd;
+    f32x4 z;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) z[r] = rv ? rstd * (dx[r] - s1 - xh[r] * s2) * lrelu_grad(y[r], slope) : 0.f;
+    *(f32x4*)&Lb[0][out_l][l15 * LIN_S + f0] = z;
+    if (rv && jY) *(EQD_GAS f4v*)&jY[(size_t)rowi * ldy + f0] = z;
+    // d gamma / d beta of the workgroup's 16 rows: 8 values per lane, summed over the 16 lanes of the group by a halving
+    // butterfly (8 exchanges); lane l15 ends with value (l15 >> 1): 0..3 = d gamma of feature f0 + r, 4..7 = d beta
+    float v8[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        v8[r] = o[r] * xh[r];        // rows beyond the matrix carry o = 0
+        v8[4 + r] = o[r];
+    }
+    const bool b3 = (l15 & 8) != 0, b2 = (l15 & 4) != 0, b1 = (l15 & 2) != 0;
+    float w4[4], w2[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w4[i] = (b3 ? v8[i + 4] : v8[i]) + __shfl_xor(b3 ? v8[i] : v8[i + 4], 8);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) w2[i] = (b2 ? w4[i + 2] : w4[i]) + __shfl_xor(b2 ? w4[i] : w4[i + 2], 4);
+    float w1 = (b1 ? w2[1] : w2[0]) + __shfl_xor(b1 ? w2[0] : w2[1], 2);
+    w1 += __shfl_xor(w1, 1);
+    if ((l15 & 1) == 0) {
+        const int idx = l15 >> 1;          // b3 b2 b1
+        jaux[(size_t)blockIdx.x * 256 + (idx < 4 ? 0 : 128) + f0 + (idx & 3)] = w1;
+    }
+    // (the workgroup's partial row is [d gamma 0..127 | d beta 128..255]; columns of features >= 64 are never read)
+}
+
 template <int RT>
 __device__ __forceinline__ void chain_lnbwd(const EqdChainJob& C, float (*Lb)[LIN_LOCALS][16 * LIN_S], float (*red)[256],
                                             int row0) {
@@ -162,6 +248,7 @@ __global__ __launch_bounds__(EQD_BLOCK, 2) void k_rowchain(EqdChainArg A_) {
     __shared__ LinSmem<RT> sm;
     __shared__ __attribute__((aligned(16))) float Lb[RT][LIN_LOCALS][16 * LIN_S];
     __shared__ float red[EQD_WAVES][256];
+    float (*sm4)[EQD_WAVES][16] = (float (*)[EQD_WAVES][16])&red[0][0];     // chain_lnbwd64's exchange slots (4 x 4 x 16)
     const int row0 = (int)blockIdx.x * 16 * RT;
     EQD_TR_WG();
     EQD_TR(200);
@@ -184,7 +271,12 @@ __global__ __launch_bounds__(EQD_BLOCK, 2) void k_rowchain(EqdChainArg A_) {
                             nj >= 0, Wp, 210 + 4 * jj);
             have = nj >= 0;
         } else {
-            chain_lnbwd<RT>(C, Lb, red, row0);
+            bool fast = false;
+            if constexpr (RT == 1) fast = jw_i(Wc, JW_OFF(EqdLinJob, M)) == 64;
+            if constexpr (RT == 1) {
+                if (fast) chain_lnbwd64(Wc, Lb, sm4, row0, false, f4zero());
+            }
+            if (!fast) chain_lnbwd<RT>(C, Lb, red, row0);
         }
         Wc = Wn;
         __syncthreads();
