@@ -410,8 +410,10 @@ extern "C" int eqd_linear(const EqdLinJob* jobs, int njobs, void* stream) {
 struct AtbUnit {
     EqdAtbJob job;
     int n0, nparts, nchunks;
+    int fast;        // M == 64, a full 64-column block of Y, 16-byte aligned rows: see atb_fast
     long long poff;  // float offset of this unit's partials
 };
+static_assert(sizeof(AtbUnit) * 36 <= 4096, "AtbUnitsArg must fit the kernel-argument segment");
 struct AtbUnitsArg {
     AtbUnit u[ATB_MAXUNITS];
 };
@@ -494,12 +496,88 @@ __device__ __forceinline__ void atb_mma(f32x4 (&acc)[5], const float* __restrict
     }
 }
 
+// The common shape (64 x 64 block, aligned): 12 plain 16-byte loads per thread and chunk (rows beyond the matrix are
+// clamped and zeroed when written to LDS) instead of the general path's 20 shifted / fixed-up ones, 8 of which fetch
+// nothing when M <= 64 - the general path is bound by its ~800 VALU instructions per chunk, not by memory (its time
+// does not change between 256 and 1 536 workgroups).  The column sums (bias gradients) are taken by all four waves,
+// 16 rows each, and only when a bias gradient is wanted.
+__device__ __forceinline__ void atb_fast(const AtbUnit& u, int c, float* __restrict__ partial, float* __restrict__ Xl,
+                                         float* __restrict__ Yl) {
+    const EqdAtbJob& J = u.job;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int tr = t >> 4, tc = t & 15;
+    const int rows = J.rows, ldx = J.ldx, ldy = J.ldy, nparts = u.nparts, nchunks = u.nchunks;
+    const bool masked = J.xmask != nullptr;
+    const bool want_bias = J.bias_out != nullptr && u.n0 == 0;
+    const float slope = J.slope;
+    const EQD_GAS float* const X = (const EQD_GAS float*)J.X + 4 * tc;
+    const EQD_GAS float* const Xm = (const EQD_GAS float*)(masked ? J.xmask : J.X) + 4 * tc;
+    const EQD_GAS float* const Y = (const EQD_GAS float*)J.Y + u.n0 + 4 * tc;
+    f32x4 acc[5];
+#pragma unroll
+    for (int mb = 0; mb < 5; ++mb) acc[mb] = f4zero();
+    float bacc = 0.f;
+    f32x4 rx[4], rm[4], ry[4];
+    auto load = [&](int chunk) {
+#pragma unroll
+        for (int jr = 0; jr < 4; ++jr) {
+            int row = chunk * ATB_ROWS + tr + 16 * jr;
+            row = row < rows ? row : rows - 1;
+            rx[jr] = *(const EQD_GAS f4v*)(X + (size_t)row * ldx);
+            if (masked) rm[jr] = *(const EQD_GAS f4v*)(Xm + (size_t)row * ldx);
+            ry[jr] = *(const EQD_GAS f4v*)(Y + (size_t)row * ldy);
+        }
+    };
+    load(c);
+    for (int chunk = c; chunk < nchunks; chunk += nparts) {
+        __syncthreads();             // the previous chunk's LDS reads are done
+#pragma unroll
+        for (int jr = 0; jr < 4; ++jr) {
+            const bool rvalid = chunk * ATB_ROWS + tr + 16 * jr < rows;
+            f32x4 v = rx[jr], y = ry[jr];
+            if (masked) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] *= lrelu_grad(rm[jr][i], slope);
+            }
+            if (!rvalid) {
+                v = f4zero();
+                y = f4zero();
+            }
+            *(f32x4*)&Xl[(tr + 16 * jr) * ATB_LS + 4 * tc] = v;
+            *(f32x4*)&Yl[(tr + 16 * jr) * ATB_LS + 4 * tc] = y;
+        }
+        __syncthreads();
+        if (chunk + nparts < nchunks) load(chunk + nparts);
+        atb_mma<4>(acc, Xl, Yl, wave, l15, g);
+        if (want_bias) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bacc += Xl[(16 * wave + i) * ATB_LS + lane];
+        }
+    }
+    float* P = partial + u.poff + (long long)c * ATB_PSTRIDE;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) P[(16 * mb + 4 * g + r) * 64 + 16 * wave + l15] = acc[mb][r];
+    if (want_bias) {                 // (without one the bias slots of the partial are never read)
+        __syncthreads();
+        Yl[64 * wave + lane] = bacc;
+        __syncthreads();
+        if (t < 64) P[ATB_TILE + t] = (Yl[t] + Yl[64 + t]) + (Yl[128 + t] + Yl[192 + t]);
+    }
+}
+
 __global__ __launch_bounds__(EQD_BLOCK) void k_atb(AtbUnitsArg U, float* __restrict__ partial) {
     __shared__ __attribute__((aligned(16))) float Xl[ATB_ROWS * ATB_LS];
     __shared__ __attribute__((aligned(16))) float Yl[ATB_ROWS * ATB_LS];
     const AtbUnit& u = U.u[blockIdx.y];
     const int c = blockIdx.x;
     if (c >= u.nparts) return;       // uniform per workgroup
+    if (u.fast) {
+        atb_fast(u, c, partial, Xl, Yl);
+        return;
+    }
     const EqdAtbJob& J = u.job;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l15 = lane & 15, g = lane >> 4;
@@ -596,6 +674,9 @@ static int atb_units(const EqdAtbJob* jobs, int njobs, std::vector<AtbUnit>& uni
             u.job = J;
             u.n0 = n0;
             u.nchunks = nchunks;
+            auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+            u.fast = J.M == 64 && J.N - n0 >= 64 && J.rows > 0 && (J.ldx & 3) == 0 && (J.ldy & 3) == 0 && al16(J.X) &&
+                     al16(J.Y) && (!J.xmask || al16(J.xmask));
             units.push_back(u);
         }
     }

@@ -143,6 +143,25 @@ def check_atb(dev):
     sync(dev)
     close(outb, Xb.t() @ Yb, tol=2e-4, what='A^T B, multi-chunk')
     close(bob, Xb.sum(0), tol=2e-4, what='column sums, multi-chunk')
+    # the aligned 64-wide shape of the model's weight gradients (fast path): masked and plain, with and without the
+    # column sums, a ragged last chunk, two 64-column blocks of Y, transposed output
+    for rows, masked, bias in ((333, True, True), (64 * 40 + 1, False, False), (50, True, False)):
+        Xc, Yc, mc = torch.randn(rows, 64), torch.randn(rows, 128), torch.randn(rows, 64)
+        outc, boc = torch.zeros(128, 64, device=dev), torch.zeros(64, device=dev)
+        Xcd, Ycd, mcd = Xc.to(dev), Yc.to(dev), mc.to(dev)
+        Cj = L.EqdAtbJob()
+        Cj.X, Cj.ldx, Cj.M, Cj.Y, Cj.ldy, Cj.N = Xcd.data_ptr(), 64, 64, Ycd.data_ptr(), 128, 128
+        Cj.xmask = mcd.data_ptr() if masked else None
+        Cj.rows, Cj.out, Cj.o_rs, Cj.o_cs, Cj.slope, Cj.scale = rows, outc.data_ptr(), 1, 64, 0.01, 1.0
+        Cj.bias_out = boc.data_ptr() if bias else None
+        nb = lib().eqd_atb_partial_bytes(C.byref(Cj), 1)
+        part = torch.zeros(nb // 4 + 64, device=dev)
+        L.check(lib().eqd_atb(C.byref(Cj), 1, P(part), C.c_size_t(nb), st(dev)))
+        sync(dev)
+        Xe = Xc * torch.where(mc > 0, 1.0, 0.01) if masked else Xc
+        close(outc, (Xe.t() @ Yc).t(), tol=2e-4, what=f'A^T B, aligned 64-wide, rows={rows}')
+        if bias:
+            close(boc, Xe.sum(0), tol=2e-4, what='column sums, aligned 64-wide')
 
 
 def _edge_setup(dev, d_in=64):
