@@ -36,9 +36,11 @@ struct AttnCfg {
     enum { DS = 16 * DB + 4, KS = 4 * DB, NL = 8 * DB, TILE = 32 * (16 * DB + 4), RED = DB * 2 * 4 * 64 };
 };
 
+// FAST: d == 16 DB exactly (64, or the 69-wide first layer zero-padded to 80 by the caller), 16-byte aligned rows
 template <int DB, bool FAST>
 struct TileRegs {
-    float4 q[FAST ? 8 : 1];            // d == 64: row (lane >> 4) + 4 j, columns 4 (lane & 15) ..
+    float4 q[FAST ? 8 : 1];            // FAST: row (lane >> 4) + 4 j, columns 4 (lane & 15) .. (the first 64 columns)
+    float4 qx[(FAST && DB > 4) ? 2 : 1];   // FAST, d == 80: row (lane + 64 j) >> 2, columns 64 + 4 ((lane + 64 j) & 3) ..
     f32x4 qv[FAST ? 1 : 2 * DB];       // any d: elements 4 (lane + 64 j) .. + 3 of the contiguous [rows][d] slab (raw)
     int nvalid;
 };
@@ -60,12 +62,22 @@ __device__ __forceinline__ void tile_load(TileRegs<DB, FAST>& R, const float* __
             for (int j = 0; j < 8; ++j) {
                 const int i4 = lane + 64 * j;
                 const int row = i4 >> 4;
-                const float4 v = ((const float4*)base)[(row < nrows ? row : nrows - 1) * 16 + (i4 & 15)];
+                const float4 v = ((const float4*)base)[(row < nrows ? row : nrows - 1) * (4 * DB) + (i4 & 15)];
                 R.q[j] = row < nrows ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if constexpr (DB > 4) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int i = lane + 64 * j;
+                    const int row = i >> 2;
+                    const float4 v = ((const float4*)base)[(row < nrows ? row : nrows - 1) * (4 * DB) + 16 + (i & 3)];
+                    R.qx[j] = row < nrows ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) R.q[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (DB > 4) R.qx[0] = R.qx[1] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     } else {
         // the 32 rows are one contiguous slab of 32 d floats: 16-byte vectors (4-byte alignment is enough), all in
@@ -87,6 +99,13 @@ __device__ __forceinline__ void tile_store(const TileRegs<DB, FAST>& R, float* _
         for (int j = 0; j < 8; ++j) {
             const int i4 = lane + 64 * j;
             *(float4*)&L[(i4 >> 4) * DS + 4 * (i4 & 15)] = R.q[j];
+        }
+        if constexpr (DB > 4) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int i = lane + 64 * j;
+                *(float4*)&L[(i >> 2) * DS + 64 + 4 * (i & 3)] = R.qx[j];
+            }
         }
     } else {
 #pragma unroll
@@ -139,21 +158,30 @@ __device__ __forceinline__ void block_tile_stage(const float* __restrict__ M, in
 }
 // d == 64, 16-byte aligned rows: the [32][64] tile is 512 float4, two per thread, unpredicated (rows beyond the block are
 // fetched from its last row and written as zeros).  Columns 64.. of the LDS tile are never read when d == 64.
+template <int DB>
 __device__ __forceinline__ void block_tile_stage_fast(const float* __restrict__ M, int DS, int r0, int r1,
                                                       float* __restrict__ L, int t) {
     int nrows = r1 - r0;
     nrows = nrows > 32 ? 32 : nrows;
-    const float4* __restrict__ base = (const float4*)(M + (size_t)r0 * 64);
-    float4 v[2];
+    const float4* __restrict__ base = (const float4*)(M + (size_t)r0 * (16 * DB));
+    float4 v[2], vx = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int i4 = t + 256 * j, row = i4 >> 4;
-        v[j] = base[(row < nrows ? row : nrows - 1) * 16 + (i4 & 15)];
+        v[j] = base[(row < nrows ? row : nrows - 1) * (4 * DB) + (i4 & 15)];
+    }
+    if constexpr (DB > 4) {      // columns 64 .. 79: 32 rows x 4 vectors, threads 0 .. 127
+        const int row = (t & 127) >> 2;
+        vx = base[(row < nrows ? row : nrows - 1) * (4 * DB) + 16 + (t & 3)];
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int i4 = t + 256 * j, row = i4 >> 4;
         *(float4*)&L[row * DS + 4 * (i4 & 15)] = row < nrows ? v[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if constexpr (DB > 4) {
+        const int row = (t & 127) >> 2;
+        if (t < 128) *(float4*)&L[row * DS + 64 + 4 * (t & 3)] = row < nrows ? vx : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 __device__ __forceinline__ void zero_fill(float* __restrict__ L, int n, int t, int nthreads) {
@@ -191,7 +219,7 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_fwd(EqdGraph G, int d, const
     tile_load<DB, FAST>(rv, v, d, kt, o1, lane);
     if (FAST) {      // every element that is read later is written by the tile stores: no zero fill needed
         EQD_TR(1);
-        block_tile_stage_fast(q, DS, b0, b1, Qt, t);
+        block_tile_stage_fast<DB>(q, DS, b0, b1, Qt, t);
     } else {
         zero_fill(Qt, C::TILE, t, EQD_BLOCK);
         zero_fill(Kt[wave], C::TILE, lane, 64);
@@ -375,24 +403,24 @@ __device__ __forceinline__ void attn_bwd_q_body(AttnBwdSmem<DB>& sm, const EqdGr
     float dl[2], lq[2];
     if (FAST) {
         // delta partial of the lane: columns 16 q + 4 g .. + 3 of its two rows (unpredicated, clamped rows)
-        float4 a[2][4], b[2][4];
+        float4 a[2][DB], b[2][DB];
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
-            const size_t ro = (size_t)(qv[nb] ? rowq[nb] : b1 - 1) * 64;
+            const size_t ro = (size_t)(qv[nb] ? rowq[nb] : b1 - 1) * (16 * DB);
 #pragma unroll
-            for (int qq = 0; qq < 4; ++qq) {
+            for (int qq = 0; qq < DB; ++qq) {
                 a[nb][qq] = *(const float4*)&d_out[ro + 16 * qq + 4 * g];
                 b[nb][qq] = *(const float4*)&out[ro + 16 * qq + 4 * g];
             }
             lq[nb] = lse[qv[nb] ? rowq[nb] : b1 - 1];
         }
-        block_tile_stage_fast(q, DS, b0, b1, Qt, t);
-        block_tile_stage_fast(d_out, DS, b0, b1, Gt, t);
+        block_tile_stage_fast<DB>(q, DS, b0, b1, Qt, t);
+        block_tile_stage_fast<DB>(d_out, DS, b0, b1, Gt, t);
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
             float s = 0.f;
 #pragma unroll
-            for (int qq = 0; qq < 4; ++qq)
+            for (int qq = 0; qq < DB; ++qq)
                 s += a[nb][qq].x * b[nb][qq].x + a[nb][qq].y * b[nb][qq].y + a[nb][qq].z * b[nb][qq].z +
                      a[nb][qq].w * b[nb][qq].w;
             dl[nb] = qv[nb] ? s : 0.f;
@@ -551,8 +579,8 @@ __device__ __forceinline__ void attn_bwd_kv_body(AttnBwdSmem<DB>& sm, const EqdG
             dr[mb][r] = qr < o1 ? dv_ : 0.f;
         }
     if (FAST) {
-        block_tile_stage_fast(k, DS, b0, b1, Kb, t);
-        block_tile_stage_fast(v, DS, b0, b1, Vb, t);
+        block_tile_stage_fast<DB>(k, DS, b0, b1, Kb, t);
+        block_tile_stage_fast<DB>(v, DS, b0, b1, Vb, t);
     } else {
         zero_fill(Kb, C::TILE, t, EQD_BLOCK);
         zero_fill(Vb, C::TILE, t, EQD_BLOCK);
@@ -590,6 +618,17 @@ __device__ __forceinline__ void attn_bwd_kv_body(AttnBwdSmem<DB>& sm, const EqdG
                 const float4 a = rg.q[FAST ? j : 0], b = ro.q[FAST && OWN_DELTA ? j : 0];
                 const float p = l16_sum(a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w);
                 if (l15 == 0) sm.dls[wave][g + 4 * j] = p;
+            }
+            if constexpr (DB > 4 && FAST && OWN_DELTA) {      // columns 64 .. 79: 4 lanes per row
+                wave_lds_fence();
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float4 a = rg.qx[j], b = ro.qx[j];
+                    float p = a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+                    p += __shfl_xor(p, 1);
+                    p += __shfl_xor(p, 2);
+                    if ((lane & 3) == 0) sm.dls[wave][(lane + 64 * j) >> 2] += p;
+                }
             }
         }
         float lc[2][4], dc[2][4];
@@ -765,7 +804,9 @@ extern "C" int eqd_cross_attention_fwd(const EqdGraph* g, int d, const float* q,
     }
     if (g->n_att_items <= 0) return EQD_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (d == 64 && aligned16(q) && aligned16(k) && aligned16(v)) return attn_launch_fwd<4, true>(g, d, q, k, v, out, lse, st);
+    const bool al = aligned16(q) && aligned16(k) && aligned16(v);
+    if (d == 64 && al) return attn_launch_fwd<4, true>(g, d, q, k, v, out, lse, st);
+    if (d == 80 && al) return attn_launch_fwd<5, true>(g, d, q, k, v, out, lse, st);
     if (d <= 64) return attn_launch_fwd<4, false>(g, d, q, k, v, out, lse, st);
     return attn_launch_fwd<5, false>(g, d, q, k, v, out, lse, st);
 }
@@ -783,8 +824,9 @@ extern "C" int eqd_cross_attention_bwd(const EqdGraph* g, int d, const float* q,
     }
     if (g->n_att_items <= 0) return EQD_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (d == 64 && aligned16(q) && aligned16(k) && aligned16(v) && aligned16(d_out) && aligned16(out))
-        return attn_launch_bwd<4, true>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
+    const bool al = aligned16(q) && aligned16(k) && aligned16(v) && aligned16(d_out) && aligned16(out);
+    if (d == 64 && al) return attn_launch_bwd<4, true>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
+    if (d == 80 && al) return attn_launch_bwd<5, true>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
     if (d <= 64) return attn_launch_bwd<4, false>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
     return attn_launch_bwd<5, false>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
 }

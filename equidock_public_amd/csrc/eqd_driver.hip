@@ -23,6 +23,11 @@ enum { G_EMB = 0, G_WK, G_WQ, G_WM, G_BM };
 struct Dims {
     int N, E, B, K, L, d0, dh;
     int d_in(int l) const { return l == 0 ? d0 : dh; }
+    // Row stride of the attention operands q / k / v / aggr_cross and of their gradients: the width rounded up to whole
+    // 16-feature blocks (69 -> 80) with zero padding, which is exactly what the attention kernels' LDS tiles hold anyway -
+    // but 16-byte aligned rows of whole blocks take the float4 path and the merged backward launch (the first layer's
+    // attention cost 109 us of a 1 650 us config-B step unpadded, against 34 us for a 64-wide layer).
+    int d_att(int l) const { return (d_in(l) + 15) / 16 * 16; }
     int ldw1(int l) const { return 2 * d_in(l) + 27 + 15; }
     int ldwn(int l) const { return d0 + 2 * d_in(l) + dh; }
 };
@@ -54,11 +59,12 @@ void carve_saved(const Dims& D, const EqdGraph* g, EqdArena& A, Saved& S) {
         LayerSaved& Ls = S.lay[l];
         Ls.P = A.take<float>(N * 64);
         Ls.Q = A.take<float>(N * 64);
-        Ls.qa = A.take<float>(N * d);
-        Ls.ka = A.take<float>(N * d);
-        Ls.va = A.take<float>(N * d);
+        const int da = D.d_att(l);
+        Ls.qa = A.take<float>(N * da);
+        Ls.ka = A.take<float>(N * da);
+        Ls.va = A.take<float>(N * da);
         Ls.aggr_msg = A.take<float>(N * 64);
-        Ls.aggr_cross = A.take<float>(N * d);
+        Ls.aggr_cross = A.take<float>(N * da);
         Ls.lse = A.take<float>(N);
         Ls.y_act = A.take<float>(N * d);
         Ls.a1n = A.take<float>(N * d);
@@ -100,7 +106,7 @@ EqdAtbJob atb_job(const float* X, int ldx, int M, const float* Y, int ldy, int N
 int node_atb_jobs(const Dims& D, int l, const EqdModelDesc* m, const Saved* S, const float* dHout, const float* dz,
                   const float* dP, const float* dQ, const float* dq, const float* dk, const float* dv,
                   float* const* gp, EqdAtbJob* jobs) {
-    const int d = D.d_in(l), N = D.N;
+    const int d = D.d_in(l), da = D.d_att(l), N = D.N;
     const bool skip = (d == D.dh);
     const float alpha = skip ? m->skip_weight_h : 1.f;
     const LayerSaved* Ls = S ? &S->lay[l] : nullptr;
@@ -117,7 +123,7 @@ int node_atb_jobs(const Dims& D, int l, const EqdModelDesc* m, const Saved* S, c
     jobs[n++] = atb_job(dz, d, d, Ls ? Ls->aggr_msg : nullptr, 64, 64, N, gp ? G(P_WN1) + d : nullptr, ldn, nullptr,
                         m->lrelu_slope);
     if (m->cross_msgs)
-        jobs[n++] = atb_job(dz, d, d, Ls ? Ls->aggr_cross : nullptr, d, d, N, gp ? G(P_WN1) + d + 64 : nullptr, ldn,
+        jobs[n++] = atb_job(dz, d, d, Ls ? Ls->aggr_cross : nullptr, da, d, N, gp ? G(P_WN1) + d + 64 : nullptr, ldn,
                             nullptr, m->lrelu_slope);
     jobs[n++] = atb_job(dz, d, d, h0, D.d0, D.d0, N, gp ? G(P_WN1) + 2 * d + 64 : nullptr, ldn, nullptr,
                         m->lrelu_slope);
@@ -126,9 +132,9 @@ int node_atb_jobs(const Dims& D, int l, const EqdModelDesc* m, const Saved* S, c
     jobs[n++] = atb_job(dP, 64, 64, h, d, d, N, G(P_W1), ld1, nullptr, m->lrelu_slope);
     jobs[n++] = atb_job(dQ, 64, 64, h, d, d, N, gp ? G(P_W1) + d : nullptr, ld1, G(P_B1), m->lrelu_slope);
     if (m->cross_msgs) {
-        jobs[n++] = atb_job(dq, d, d, h, d, d, N, G(P_WQ), d, nullptr, m->lrelu_slope, Ls ? Ls->qa : nullptr);
-        jobs[n++] = atb_job(dk, d, d, h, d, d, N, G(P_WK), d, nullptr, m->lrelu_slope, Ls ? Ls->ka : nullptr);
-        jobs[n++] = atb_job(dv, d, d, h, d, d, N, G(P_WV), d, nullptr, m->lrelu_slope);
+        jobs[n++] = atb_job(dq, da, d, h, d, d, N, G(P_WQ), d, nullptr, m->lrelu_slope, Ls ? Ls->qa : nullptr);
+        jobs[n++] = atb_job(dk, da, d, h, d, d, N, G(P_WK), d, nullptr, m->lrelu_slope, Ls ? Ls->ka : nullptr);
+        jobs[n++] = atb_job(dv, da, d, h, d, d, N, G(P_WV), d, nullptr, m->lrelu_slope);
     }
     return n;
 }
@@ -308,22 +314,23 @@ extern "C" int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const
         const int d = D.d_in(l);
         const LayerSaved& Ls = S.lay[l];
         int nj = 0;
-        auto add = [&](float* Y, int M, const float* Wp, int w_rs, const float* bias, int act) {
+        auto add = [&](float* Y, int M, int ldy, const float* Wp, int w_rs, const float* bias, int act) {
             EqdChainJob& C = cj[nj++];
             memset(&C, 0, sizeof(C));
-            C.lin = lin_job(N, M, Y, M, slope, eps);
+            C.lin = lin_job(N, M, Y, ldy, slope, eps);
             lin_src(C.lin, 0, hsrc, d, d, Wp, w_rs, 1);
             C.lin.nsrc = 1; C.lin.bias = bias; C.lin.act = act;
             for (int i = 0; i < EQD_MAX_SRC; ++i) C.src_local[i] = -1;
             C.src_local[0] = loc;
             C.out_local = -1;
         };
-        add(Ls.P, 64, p[P_W1], D.ldw1(l), nullptr, 0);
-        add(Ls.Q, 64, p[P_W1] + d, D.ldw1(l), p[P_B1], 0);
+        add(Ls.P, 64, 64, p[P_W1], D.ldw1(l), nullptr, 0);
+        add(Ls.Q, 64, 64, p[P_W1] + d, D.ldw1(l), p[P_B1], 0);
         if (m->cross_msgs) {
-            add(Ls.qa, d, p[P_WQ], d, nullptr, 1);
-            add(Ls.ka, d, p[P_WK], d, nullptr, 1);
-            add(Ls.va, d, p[P_WV], d, nullptr, 0);
+            const int da = D.d_att(l);
+            add(Ls.qa, d, da, p[P_WQ], d, nullptr, 1);
+            add(Ls.ka, d, da, p[P_WK], d, nullptr, 1);
+            add(Ls.va, d, da, p[P_WV], d, nullptr, 0);
         }
         return nj;
     };
@@ -332,6 +339,12 @@ extern "C" int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const
         const int d = D.d_in(l);
         const LayerSaved& Ls = S.lay[l];
         const float* h = S.h[l];
+        const int da = D.d_att(l);
+        if (m->cross_msgs && da != d) {      // padding columns of q / k / v (the projections write d of da columns)
+            // one fill: the three buffers are consecutive in the saved-state arena (only alignment padding between them)
+            if (!(Ls.qa < Ls.ka && Ls.ka < Ls.va)) return EQD_ERR_WORKSPACE;
+            HIPOK(hipMemsetAsync(Ls.qa, 0, (size_t)((char*)(Ls.va + (size_t)N * da) - (char*)Ls.qa), st));
+        }
         // ---- node projections (5 independent jobs, one launch: they run side by side) ---------------------
         {
             EqdChainJob cj[8];
@@ -347,9 +360,9 @@ extern "C" int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const
             HIPOK(hipStreamWaitEvent(sat, cx->fork, 0));
         }
         if (m->cross_msgs) {
-            RC(eqd_cross_attention_fwd(g, d, Ls.qa, Ls.ka, Ls.va, Ls.aggr_cross, Ls.lse, sat));
+            RC(eqd_cross_attention_fwd(g, da, Ls.qa, Ls.ka, Ls.va, Ls.aggr_cross, Ls.lse, sat));
         } else {
-            if (hipMemsetAsync(Ls.aggr_cross, 0, (size_t)N * d * sizeof(float), st) != hipSuccess) return EQD_ERR_LAUNCH;
+            if (hipMemsetAsync(Ls.aggr_cross, 0, (size_t)N * da * sizeof(float), st) != hipSuccess) return EQD_ERR_LAUNCH;
         }
         if (sat != st) HIPOK(hipEventRecord(cx->join_a, sat));
         EqdEdgeParams ep = edge_params(D, m, l, p);
@@ -362,7 +375,7 @@ extern "C" int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const
         EqdLinJob j1 = lin_job(N, d, Ls.a1n, d, slope, eps);
         lin_src(j1, 0, h, d, d, p[P_WN1], ldn, 1);
         lin_src(j1, 1, Ls.aggr_msg, 64, 64, p[P_WN1] + d, ldn, 1);
-        lin_src(j1, 2, Ls.aggr_cross, d, d, p[P_WN1] + d + 64, ldn, 1);
+        lin_src(j1, 2, Ls.aggr_cross, da, d, p[P_WN1] + d + 64, ldn, 1);
         lin_src(j1, 3, S.h[0], D.d0, D.d0, p[P_WN1] + 2 * d + 64, ldn, 1);
         j1.nsrc = 4; j1.bias = p[P_BN1]; j1.act = 1; j1.ln_g = p[P_NLG]; j1.ln_b = p[P_NLB];
         j1.pre_ln = Ls.y_act; j1.ld_pre = d;
@@ -471,9 +484,10 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
         lin_src(j, ns++, W.dP_all + l * NP, 64, 64, p[P_W1], 1, D.ldw1(l));
         lin_src(j, ns++, W.dQ_all + l * NP, 64, 64, p[P_W1] + d, 1, D.ldw1(l));
         if (m->cross_msgs) {
-            lin_src(j, ns++, W.dq_all + l * NS, d, d, p[P_WQ], 1, d, Ls.qa);
-            lin_src(j, ns++, W.dk_all + l * NS, d, d, p[P_WK], 1, d, Ls.ka);
-            lin_src(j, ns++, W.dv_all + l * NS, d, d, p[P_WV], 1, d);
+            const int da = D.d_att(l);
+            lin_src(j, ns++, W.dq_all + l * NS, da, d, p[P_WQ], 1, d, Ls.qa);
+            lin_src(j, ns++, W.dk_all + l * NS, da, d, p[P_WK], 1, d, Ls.ka);
+            lin_src(j, ns++, W.dv_all + l * NS, da, d, p[P_WV], 1, d);
         }
         j.nsrc = ns;
         if (d == D.dh) { j.R = dHof(l + 1); j.ldr = D.dh; j.beta = 1.f - m->skip_weight_h; }
@@ -488,6 +502,10 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
         const bool skip = (d == D.dh);
         const float alpha = skip ? m->skip_weight_h : 1.f;
         const int ldn = D.ldwn(l);
+        const int da = D.d_att(l);
+        if (m->cross_msgs && da != d)      // padding columns of d aggr_cross (the chain writes d of da columns; they meet
+                                           // zeros in V, but must not be NaN bit patterns left in the scratch buffer)
+            HIPOK(hipMemsetAsync(W.d_aggr_cross, 0, (size_t)N * da * sizeof(float), st));
         float *dz = W.dz_all + l * NS, *dq = W.dq_all + l * NS, *dk = W.dk_all + l * NS, *dv = W.dv_all + l * NS;
         float *dP = W.dP_all + l * NP, *dQ = W.dQ_all + l * NP;
         float* dHout = dHof(l + 1);
@@ -539,7 +557,7 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
                 return C;
             };
             dx_job(W.d_aggr_msg, 64, 64, d);
-            if (m->cross_msgs) dx_job(W.d_aggr_cross, d, d, d + 64);
+            if (m->cross_msgs) dx_job(W.d_aggr_cross, d, da, d + 64);
             EqdChainJob& C5 = dx_job(W.dh0acc, D.d0, D.d0, 2 * d + 64);
             if (l < D.L - 1) {      // the last layer (processed first) initialises the accumulator
                 C5.lin.R = W.dh0acc; C5.lin.ldr = D.d0; C5.lin.beta = 1.f;
@@ -557,7 +575,7 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
         // The backward kernels of a layer each fill the chip (LDS-bound occupancy), so they run back to back
         // on ONE stream: side streams only added event latency here.
         if (m->cross_msgs)
-            RC(eqd_cross_attention_bwd(g, d, Ls.qa, Ls.ka, Ls.va, Ls.aggr_cross, Ls.lse, W.d_aggr_cross, dq, dk, dv,
+            RC(eqd_cross_attention_bwd(g, da, Ls.qa, Ls.ka, Ls.va, Ls.aggr_cross, Ls.lse, W.d_aggr_cross, dq, dk, dv,
                                        W.delta, st));
         {
             EqdEdgeParams ep = edge_params(D, m, l, p);

@@ -37,7 +37,7 @@ def test_edge_message_bf16(dev):
     pc.check_edge_bf16(dev)
 
 
-@pytest.mark.parametrize('d', [64, 69])
+@pytest.mark.parametrize('d', [64, 69, 80])
 def test_cross_attention(dev, d):
     from tests import parity_common as pc
     pc.check_attention(dev, d)

@@ -37,7 +37,7 @@ def test_edge_message_bf16():
     pc.check_edge_bf16(DEV)
 
 
-@pytest.mark.parametrize('d', [64, 69])
+@pytest.mark.parametrize('d', [64, 69, 80])
 def test_cross_attention(d):
     pc.check_attention(DEV, d)
 
