@@ -409,8 +409,7 @@ extern "C" int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const
     RC(eqd_launch_seg_mean(g, S.hm, S.qmean, st));
     RC(eqd_keypoint_pool_fwd_impl(g, D.K, gp[G_WK], gp[G_WQ], S.qmean, H, Z, S.Y, Y_lig, Y_rec, S.scores, S.klse, S.qp,
                                   S.u, st));
-    RC(eqd_kabsch_fwd_impl(D.B, D.K, S.Y, svd_draws, m->svd_seed, S.T, T, b, S.A, svd_status, st));
-    RC(eqd_rigid_apply_fwd(g, S.T, b, lig_out, st));
+    RC(eqd_kabsch_fwd_impl(D.B, D.K, S.Y, svd_draws, m->svd_seed, S.T, T, b, S.A, svd_status, st, g, lig_out));   // + rigid apply
     return EQD_OK;
 }
 
@@ -451,8 +450,7 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
         EqdRedList* p;
         ~DeferGuard() { delete p; }
     } defer_guard{defer};
-    RC(eqd_rigid_apply_bwd_impl(g, d_lig, d_T, d_b, W.dT, W.db, st));
-    RC(eqd_kabsch_bwd_impl(B, K, S.Y, S.A, S.T, W.dT, W.db, d_Ylig, d_Yrec, W.dY, st));
+    RC(eqd_kabsch_bwd_impl(B, K, S.Y, S.A, S.T, d_T, d_b, d_Ylig, d_Yrec, W.dY, st, g, d_lig));   // + rigid apply backward
     const float* H = S.h[D.L];
     const float* Z = S.x[D.L];
     float* dXcur = W.dXa;   // grad wrt x[L]

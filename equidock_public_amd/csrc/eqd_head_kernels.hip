@@ -25,24 +25,37 @@ __device__ __forceinline__ int find_segment(const int32_t* __restrict__ seg_off,
 }
 
 // qmean[s][c] = mean over the nodes of segment s of hm[i][c]   (64 columns)
-__global__ __launch_bounds__(EQD_BLOCK) void k_seg_mean(const int32_t* __restrict__ seg_off,
-                                                        const float* __restrict__ hm, float* __restrict__ qmean) {
-    __shared__ float red[4][64];
+// (1 024 threads: 16 row groups, four rows in flight per thread - with 4 groups and one dependent add per row a
+// 200-node segment was 50 serial load round trips, 13.6 us for 50 KB)
+__global__ __launch_bounds__(1024) void k_seg_mean(const int32_t* __restrict__ seg_off,
+                                                   const float* __restrict__ hm, float* __restrict__ qmean) {
+    __shared__ float red[16][64];
     const int s = blockIdx.x;
     const int n0 = seg_off[s], n1 = seg_off[s + 1];
     const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
     float acc = 0.f;
-    for (int i = n0 + rg; i < n1; i += 4) acc += hm[(size_t)i * 64 + c];
+    for (int i = n0 + rg; i < n1; i += 64) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = i + 16 * u;
+            v[u] = hm[(size_t)(r < n1 ? r : n0) * 64 + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += i + 16 * u < n1 ? v[u] : 0.f;
+    }
     red[rg][c] = acc;
     __syncthreads();
     if (rg == 0) {
-        const float t = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t += red[j][c];
         qmean[(size_t)s * 64 + c] = n1 > n0 ? t / (float)(n1 - n0) : 0.f;
     }
 }
 int eqd_launch_seg_mean(const EqdGraph* g, const float* hm, float* qmean, hipStream_t st) {
     if (g->n_pairs == 0) return EQD_OK;
-    hipLaunchKernelGGL(k_seg_mean, dim3(2 * g->n_pairs), dim3(EQD_BLOCK), 0, st, g->seg_off, hm, qmean);
+    hipLaunchKernelGGL(k_seg_mean, dim3(2 * g->n_pairs), dim3(1024), 0, st, g->seg_off, hm, qmean);
     return eqd_check_launch("k_seg_mean");
 }
 
@@ -322,17 +335,20 @@ int eqd_launch_head_u_bwd(const EqdGraph* g, int K, const float* Wk, const float
 // dqmean[p] = sum_k dqm_part[partner(p)][k]; dhm[i] = dqmean[seg(i)] / n_seg for the nodes of segment p
 __global__ void k_qmean_bwd(const int32_t* __restrict__ seg_off, int B, int K, const float* __restrict__ dqm_part,
                             float* __restrict__ dhm) {
-    const int p = blockIdx.x, t = threadIdx.x;  // 64 threads
+    // 1 024 threads: every 64-lane group sums the K parts of its column (same order everywhere, 10 loads in flight) and
+    // then writes the rows rg, rg + 16, .. of the segment (one group writing all rows one after the other was 17 us)
+    const int p = blockIdx.x, t = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int s = p < B ? p + B : p - B;        // the segment whose keypoints used qmean[p]
     float a = 0.f;
+#pragma unroll 10
     for (int k = 0; k < K; ++k) a += dqm_part[((size_t)s * K + k) * 64 + t];
     const int n0 = seg_off[p], n1 = seg_off[p + 1];
     const float v = n1 > n0 ? a / (float)(n1 - n0) : 0.f;
-    for (int i = n0; i < n1; ++i) dhm[(size_t)i * 64 + t] = v;
+    for (int i = n0 + rg; i < n1; i += 16) dhm[(size_t)i * 64 + t] = v;
 }
 int eqd_launch_qmean_bwd(const EqdGraph* g, int K, const float* dqm_part, float* dhm, hipStream_t st) {
     if (g->n_pairs == 0) return EQD_OK;
-    hipLaunchKernelGGL(k_qmean_bwd, dim3(2 * g->n_pairs), dim3(64), 0, st, g->seg_off, g->n_pairs, K, dqm_part, dhm);
+    hipLaunchKernelGGL(k_qmean_bwd, dim3(2 * g->n_pairs), dim3(1024), 0, st, g->seg_off, g->n_pairs, K, dqm_part, dhm);
     return eqd_check_launch("k_qmean_bwd");
 }
 
@@ -423,9 +439,12 @@ __device__ __forceinline__ float uniform_draw(unsigned seed, unsigned pair, unsi
 __global__ __launch_bounds__(64) void k_kabsch_fwd(int B, int K, const float* __restrict__ Y,
                                                    const float* __restrict__ draws, int seed, float* __restrict__ T,
                                                    float* __restrict__ T2, float* __restrict__ bvec,
-                                                   float* __restrict__ A_out, int32_t* __restrict__ status) {
+                                                   float* __restrict__ A_out, int32_t* __restrict__ status,
+                                                   const int32_t* __restrict__ seg_off, const float* __restrict__ x0,
+                                                   float* __restrict__ lig_out) {
+    // lig_out != NULL: the rigid apply of the pair's ligand nodes (k_apply_fwd's arithmetic) runs here as well
     __shared__ float sy[2][KAB_MAXK * 3];
-    __shared__ float smean[6], sA[9];
+    __shared__ float smean[6], sA[9], sTb[12];
     const int p = blockIdx.x, t = threadIdx.x;
     const float* Yl = Y + (size_t)p * K * 3;
     const float* Yr = Y + (size_t)(B + p) * K * 3;
@@ -448,7 +467,7 @@ __global__ __launch_bounds__(64) void k_kabsch_fwd(int B, int K, const float* __
         sA[t] = a;
     }
     __syncthreads();
-    if (t != 0) return;
+    if (t == 0) {
     float ml[3], mr[3], Af[3][3];
     for (int c = 0; c < 3; ++c) {
         ml[c] = smean[c];
@@ -484,17 +503,33 @@ __global__ __launch_bounds__(64) void k_kabsch_fwd(int B, int K, const float* __
             T[(size_t)p * 9 + i * 3 + j] = (float)tt;
             if (T2) T2[(size_t)p * 9 + i * 3 + j] = (float)tt;
             A_out[(size_t)p * 9 + i * 3 + j] = Af[i][j];
+            sTb[i * 3 + j] = (float)tt;
         }
-    for (int i = 0; i < 3; ++i)
-        bvec[(size_t)p * 3 + i] = mr[i] - (Tm[i][0] * ml[0] + Tm[i][1] * ml[1] + Tm[i][2] * ml[2]);
+    for (int i = 0; i < 3; ++i) {
+        const float bi = mr[i] - (Tm[i][0] * ml[0] + Tm[i][1] * ml[1] + Tm[i][2] * ml[2]);
+        bvec[(size_t)p * 3 + i] = bi;
+        sTb[9 + i] = bi;
+    }
+    }
+    if (!lig_out) return;
+    __syncthreads();
+    const int n0 = seg_off[p], n1 = seg_off[p + 1];      // ligand segments are the first B entries
+    for (int i = n0 + t; i < n1; i += 64) {
+        const float x = x0[(size_t)i * 3], y = x0[(size_t)i * 3 + 1], z = x0[(size_t)i * 3 + 2];
+        for (int r = 0; r < 3; ++r)
+            lig_out[(size_t)i * 3 + r] = sTb[r * 3] * x + sTb[r * 3 + 1] * y + sTb[r * 3 + 2] * z + sTb[9 + r];
+    }
 }
 
 extern "C" int eqd_kabsch_fwd(int n_pairs, int n_heads, const float* Y, const float* svd_draws, int svd_seed, float* T,
                               float* b, float* A_out, int32_t* status, void* stream) {
-    return eqd_kabsch_fwd_impl(n_pairs, n_heads, Y, svd_draws, svd_seed, T, nullptr, b, A_out, status, (hipStream_t)stream);
+    return eqd_kabsch_fwd_impl(n_pairs, n_heads, Y, svd_draws, svd_seed, T, nullptr, b, A_out, status, (hipStream_t)stream,
+                               nullptr, nullptr);
 }
+// g + lig_out: also lig_out = T x0 + b for every ligand node (eqd_rigid_apply_fwd fused in: one launch less)
 int eqd_kabsch_fwd_impl(int n_pairs, int n_heads, const float* Y, const float* svd_draws, int svd_seed, float* T,
-                        float* T2, float* b, float* A_out, int32_t* status, hipStream_t stream) {
+                        float* T2, float* b, float* A_out, int32_t* status, hipStream_t stream, const EqdGraph* g,
+                        float* lig_out) {
     if (!Y || !T || !b || !A_out || !status) {
         eqd_set_error("eqd_kabsch_fwd: NULL argument");
         return EQD_ERR_NULL;
@@ -505,7 +540,8 @@ int eqd_kabsch_fwd_impl(int n_pairs, int n_heads, const float* Y, const float* s
         return EQD_ERR_UNSUPPORTED;
     }
     hipLaunchKernelGGL(k_kabsch_fwd, dim3(n_pairs), dim3(64), 0, (hipStream_t)stream, n_pairs, n_heads, Y, svd_draws,
-                       svd_seed, T, T2, b, A_out, status);
+                       svd_seed, T, T2, b, A_out, status, g ? g->seg_off : (const int32_t*)nullptr,
+                       g ? g->x0 : (const float*)nullptr, g ? lig_out : (float*)nullptr);
     return eqd_check_launch("k_kabsch_fwd");
 }
 
@@ -517,12 +553,35 @@ __global__ __launch_bounds__(64) void k_kabsch_bwd(int B, int K, const float* __
                                                    const float* __restrict__ dT, const float* __restrict__ db,
                                                    const float* __restrict__ dYl_ext,
                                                    const float* __restrict__ dYr_ext, int use_ext,
-                                                   float* __restrict__ dY) {
+                                                   float* __restrict__ dY, const int32_t* __restrict__ seg_off,
+                                                   const float* __restrict__ x0, const float* __restrict__ d_lig) {
     // one 64-thread workgroup per pair; lane 0 does the 3x3 algebra, the per-keypoint work is spread over lanes,
     // every sum over keypoints runs sequentially on one lane (fixed order)
     __shared__ float sy[2][KAB_MAXK * 3];
     __shared__ double smean[6], sdA[9], sdb[3], sdml[3], sg[2][KAB_MAXK * 3], sgm[6];
+    __shared__ float sapp[12];
     const int p = blockIdx.x, t = threadIdx.x;
+    // seg_off != NULL: the backward of the rigid apply (k_apply_bwd: dT += d_lig^T x0, db += colsum d_lig over the pair's
+    // ligand nodes) is taken here, on top of the external dT / db
+    if (seg_off) {
+        float acc[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) acc[i] = 0.f;
+        const int n0 = seg_off[p], n1 = seg_off[p + 1];
+        for (int i = n0 + t; i < n1 && d_lig; i += 64) {
+            const float g0 = d_lig[(size_t)i * 3], g1 = d_lig[(size_t)i * 3 + 1], g2 = d_lig[(size_t)i * 3 + 2];
+            const float x = x0[(size_t)i * 3], y = x0[(size_t)i * 3 + 1], z = x0[(size_t)i * 3 + 2];
+            acc[0] += g0 * x; acc[1] += g0 * y; acc[2] += g0 * z;
+            acc[3] += g1 * x; acc[4] += g1 * y; acc[5] += g1 * z;
+            acc[6] += g2 * x; acc[7] += g2 * y; acc[8] += g2 * z;
+            acc[9] += g0; acc[10] += g1; acc[11] += g2;
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const float sum = wave_sum(acc[i]);
+            if (t == 0) sapp[i] = sum;
+        }
+    }
     const float* Yl = Y + (size_t)p * K * 3;
     const float* Yr = Y + (size_t)(B + p) * K * 3;
     float* dYl = dY + (size_t)p * K * 3;
@@ -543,14 +602,16 @@ __global__ __launch_bounds__(64) void k_kabsch_bwd(int B, int K, const float* __
         double ml[3] = {smean[0], smean[1], smean[2]};
         double A[3][3], U[3][3], S[3], V[3][3], G[3][3], Tm[3][3], dbv[3];
         for (int i = 0; i < 3; ++i) {
-            dbv[i] = db ? (double)db[(size_t)p * 3 + i] : 0.0;
+            dbv[i] = (db ? (double)db[(size_t)p * 3 + i] : 0.0) + (seg_off ? (double)sapp[9 + i] : 0.0);
             for (int j = 0; j < 3; ++j) {
                 A[i][j] = (double)A_in[(size_t)p * 9 + i * 3 + j];
                 Tm[i][j] = (double)T[(size_t)p * 9 + i * 3 + j];
             }
         }
         for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) G[i][j] = (dT ? (double)dT[(size_t)p * 9 + i * 3 + j] : 0.0) - dbv[i] * ml[j];
+            for (int j = 0; j < 3; ++j)
+                G[i][j] = (dT ? (double)dT[(size_t)p * 9 + i * 3 + j] : 0.0) + (seg_off ? (double)sapp[i * 3 + j] : 0.0) -
+                          dbv[i] * ml[j];
         svd3(A, U, S, V);
         const double c[3] = {1.0, 1.0, det3(A) < 0.0 ? -1.0 : 1.0};
         double M[3][3], dP[3][3];
@@ -630,11 +691,14 @@ extern "C" int eqd_kabsch_bwd(int n_pairs, int n_heads, const float* Y, const fl
         return EQD_ERR_UNSUPPORTED;
     }
     hipLaunchKernelGGL(k_kabsch_bwd, dim3(n_pairs), dim3(64), 0, (hipStream_t)stream, n_pairs, n_heads, Y,
-                       A, T, dT, db, (const float*)nullptr, (const float*)nullptr, 0, dY);
+                       A, T, dT, db, (const float*)nullptr, (const float*)nullptr, 0, dY, (const int32_t*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr);
     return eqd_check_launch("k_kabsch_bwd");
 }
+// g != NULL: dT / db are the EXTERNAL gradients (may be NULL) and the rigid apply's backward from d_lig is added inside
 int eqd_kabsch_bwd_impl(int n_pairs, int n_heads, const float* Y, const float* A, const float* T, const float* dT,
-                        const float* db, const float* dYl_ext, const float* dYr_ext, float* dY, hipStream_t stream) {
+                        const float* db, const float* dYl_ext, const float* dYr_ext, float* dY, hipStream_t stream,
+                        const EqdGraph* g, const float* d_lig) {
     if (!Y || !A || !T || !dY) {
         eqd_set_error("eqd_kabsch_bwd: NULL argument");
         return EQD_ERR_NULL;
@@ -645,7 +709,8 @@ int eqd_kabsch_bwd_impl(int n_pairs, int n_heads, const float* Y, const float* A
         return EQD_ERR_UNSUPPORTED;
     }
     hipLaunchKernelGGL(k_kabsch_bwd, dim3(n_pairs), dim3(64), 0, (hipStream_t)stream, n_pairs, n_heads, Y,
-                       A, T, dT, db, dYl_ext, dYr_ext, 1, dY);
+                       A, T, dT, db, dYl_ext, dYr_ext, 1, dY, g ? g->seg_off : (const int32_t*)nullptr,
+                       g ? g->x0 : (const float*)nullptr, g ? d_lig : (const float*)nullptr);
     return eqd_check_launch("k_kabsch_bwd");
 }
 
