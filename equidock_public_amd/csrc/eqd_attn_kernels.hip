@@ -189,7 +189,12 @@ __device__ __forceinline__ void zero_fill(float* __restrict__ L, int n, int t, i
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int DB, bool FAST>
+// NB = 2: one workgroup per work item (a block of up to 32 rows).  NB = 1: TWO workgroups per item, 16 rows each - for
+// small batches, whose 32-row blocks do not give every CU a workgroup (DB5.5: 112 items, 256 CUs): twice the workgroups
+// with half the matrix work and the same loads each; the arithmetic of a row is unchanged (its keys are split over the
+// waves and merged in the same order).  Only the forward: the merged backward launch already has two workgroups per
+// item and 120 KB of LDS each, so halving its blocks makes it a second round of workgroups (measured: 21.5 -> 24 us).
+template <int DB, bool FAST, int NB>
 __global__ __launch_bounds__(EQD_BLOCK) void k_attn_fwd(EqdGraph G, int d, const float* __restrict__ q,
                                                         const float* __restrict__ k, const float* __restrict__ v,
                                                         float* __restrict__ out, float* __restrict__ lse) {
@@ -205,11 +210,21 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_fwd(EqdGraph G, int d, const
     static_assert(C::RED <= C::TILE, "merge buffer must fit a K tile");
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const int item = blockIdx.x;
-    const int b0 = G.att_items[item * 4 + 0], b1 = G.att_items[item * 4 + 1];
+    const int item = NB == 1 ? (int)blockIdx.x >> 1 : (int)blockIdx.x;
+    int b0 = G.att_items[item * 4 + 0], b1 = G.att_items[item * 4 + 1];
     const int o0 = G.att_items[item * 4 + 2], o1 = G.att_items[item * 4 + 3];
-    int rowq[2] = {b0 + l15, b0 + 16 + l15};
-    bool qv[2] = {rowq[0] < b1, rowq[1] < b1};
+    if (NB == 1) {
+        b0 += 16 * ((int)blockIdx.x & 1);
+        b1 = b1 < b0 + 16 ? b1 : b0 + 16;
+        if (b0 >= b1) return;        // the item's block has at most 16 rows (uniform for the workgroup)
+    }
+    int rowq[NB];
+    bool qv[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        rowq[nb] = b0 + 16 * nb + l15;
+        qv[nb] = rowq[nb] < b1;
+    }
 
     EQD_TR_WG();
     EQD_TR(0);
@@ -230,19 +245,21 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_fwd(EqdGraph G, int d, const
     }
     __syncthreads();
     EQD_TR(2);
-    float qf[2][KS];
+    float qf[NB][KS];
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qf[nb][ks] = Qt[(16 * nb + l15) * DS + 4 * ks + g];
 
-    f32x4 O[DB][2];
+    f32x4 O[DB][NB];
+    float mrun[NB], lrun[NB];
 #pragma unroll
-    for (int db = 0; db < DB; ++db) {
-        O[db][0] = f4zero();
-        O[db][1] = f4zero();
+    for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+        for (int db = 0; db < DB; ++db) O[db][nb] = f4zero();
+        mrun[nb] = EQD_NEG_BIG;
+        lrun[nb] = 0.f;
     }
-    float mrun[2] = {EQD_NEG_BIG, EQD_NEG_BIG}, lrun[2] = {0.f, 0.f};
     const float* __restrict__ Kw = Kt[wave];
     const float* __restrict__ Vw = Vt[wave];
     EQD_TR(3);
@@ -255,20 +272,22 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_fwd(EqdGraph G, int d, const
         tile_load<DB, FAST>(rk, k, d, kt + 32 * EQD_WAVES, o1, lane);   // prefetch the wave's next tile
         tile_load<DB, FAST>(rv, v, d, kt + 32 * EQD_WAVES, o1, lane);
         EQD_TR(5);
-        f32x4 S[2][2];
+        f32x4 S[2][NB];
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) S[mb][0] = S[mb][1] = f4zero();
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) S[mb][nb] = f4zero();
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
                 const float a = Kw[(16 * mb + l15) * DS + 4 * ks + g];
-                S[mb][0] = mfma4(a, qf[0][ks], S[mb][0]);
-                S[mb][1] = mfma4(a, qf[1][ks], S[mb][1]);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) S[mb][nb] = mfma4(a, qf[nb][ks], S[mb][nb]);
             }
         EQD_TR(6);
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
+        for (int nb = 0; nb < NB; ++nb) {
             float mx = EQD_NEG_BIG;
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
@@ -305,8 +324,8 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_fwd(EqdGraph G, int d, const
 #pragma unroll
                 for (int db = 0; db < DB; ++db) {
                     const float a = Vw[(16 * mbk + 4 * g + r) * DS + 16 * db + l15];
-                    O[db][0] = mfma4(a, S[mbk][0][r], O[db][0]);
-                    O[db][1] = mfma4(a, S[mbk][1][r], O[db][1]);
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) O[db][nb] = mfma4(a, S[mbk][nb][r], O[db][nb]);
                 }
         EQD_TR(8);
     }
@@ -316,20 +335,20 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_fwd(EqdGraph G, int d, const
 #pragma unroll
     for (int db = 0; db < DB; ++db)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[wave][((db * 2 + nb) * 4 + r) * 64 + lane] = O[db][nb][r];
     if (g == 0) {
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
+        for (int nb = 0; nb < NB; ++nb) {
             sm_m[wave][16 * nb + l15] = mrun[nb];
             sm_l[wave][16 * nb + l15] = lrun[nb];
         }
     }
     __syncthreads();
-    float sc[2][EQD_WAVES], inv[2], mtot[2], ltot[2];
+    float sc[NB][EQD_WAVES], inv[NB], mtot[NB], ltot[NB];
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
+    for (int nb = 0; nb < NB; ++nb) {
         float mm = EQD_NEG_BIG;
 #pragma unroll
         for (int w = 0; w < EQD_WAVES; ++w) mm = fmaxf(mm, sm_m[w][16 * nb + l15]);
@@ -345,7 +364,7 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_fwd(EqdGraph G, int d, const
     }
     for (int db = wave; db < DB; db += EQD_WAVES)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
+        for (int nb = 0; nb < NB; ++nb) {
             if (!qv[nb]) continue;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -358,7 +377,7 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_fwd(EqdGraph G, int d, const
         }
     if (wave == 0 && g == 0) {
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+        for (int nb = 0; nb < NB; ++nb)
             if (qv[nb]) lse[rowq[nb]] = ltot[nb] > 0.f ? mtot[nb] + logf(ltot[nb]) : 0.f;
     }
     EQD_TR(10);
@@ -376,7 +395,7 @@ struct AttnBwdSmem {
     float dls[EQD_WAVES][32];
 };
 
-template <int DB, bool FAST>
+template <int DB, bool FAST, int NB>
 __device__ __forceinline__ void attn_bwd_q_body(AttnBwdSmem<DB>& sm, const EqdGraph& G, int item, int d,
                                                 const float* __restrict__ q, const float* __restrict__ k,
                                                 const float* __restrict__ v, const float* __restrict__ out,
@@ -393,19 +412,24 @@ __device__ __forceinline__ void attn_bwd_q_body(AttnBwdSmem<DB>& sm, const EqdGr
     const int l15 = lane & 15, g = lane >> 4;
     const int b0 = G.att_items[item * 4 + 0], b1 = G.att_items[item * 4 + 1];
     const int o0 = G.att_items[item * 4 + 2], o1 = G.att_items[item * 4 + 3];
-    int rowq[2] = {b0 + l15, b0 + 16 + l15};
-    bool qv[2] = {rowq[0] < b1, rowq[1] < b1};
+    int rowq[NB];
+    bool qv[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        rowq[nb] = b0 + 16 * nb + l15;
+        qv[nb] = rowq[nb] < b1;
+    }
 
     TileRegs<DB, FAST> rk, rv;
     int kt = o0 + 32 * wave;
     tile_load<DB, FAST>(rk, k, d, kt, o1, lane);
     tile_load<DB, FAST>(rv, v, d, kt, o1, lane);
-    float dl[2], lq[2];
+    float dl[NB], lq[NB];
     if (FAST) {
         // delta partial of the lane: columns 16 q + 4 g .. + 3 of its two rows (unpredicated, clamped rows)
-        float4 a[2][DB], b[2][DB];
+        float4 a[NB][DB], b[NB][DB];
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
+        for (int nb = 0; nb < NB; ++nb) {
             const size_t ro = (size_t)(qv[nb] ? rowq[nb] : b1 - 1) * (16 * DB);
 #pragma unroll
             for (int qq = 0; qq < DB; ++qq) {
@@ -417,7 +441,7 @@ __device__ __forceinline__ void attn_bwd_q_body(AttnBwdSmem<DB>& sm, const EqdGr
         block_tile_stage_fast<DB>(q, DS, b0, b1, Qt, t);
         block_tile_stage_fast<DB>(d_out, DS, b0, b1, Gt, t);
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
+        for (int nb = 0; nb < NB; ++nb) {
             float s = 0.f;
 #pragma unroll
             for (int qq = 0; qq < DB; ++qq)
@@ -428,7 +452,7 @@ __device__ __forceinline__ void attn_bwd_q_body(AttnBwdSmem<DB>& sm, const EqdGr
         }
     } else {
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
+        for (int nb = 0; nb < NB; ++nb) {
             float s = 0.f;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -450,9 +474,9 @@ __device__ __forceinline__ void attn_bwd_q_body(AttnBwdSmem<DB>& sm, const EqdGr
         block_tile_stage(d_out, d, DS, b0, b1, Gt, t);
     }
     __syncthreads();
-    float qf[2][KS], dof[2][KS];
+    float qf[NB][KS], dof[NB][KS];
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
+    for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             qf[nb][ks] = Qt[(16 * nb + l15) * DS + 4 * ks + g];
@@ -461,9 +485,11 @@ __device__ __forceinline__ void attn_bwd_q_body(AttnBwdSmem<DB>& sm, const EqdGr
         dl[nb] = group_sum(dl[nb]);
         if (wave == 0 && g == 0 && qv[nb]) delta[rowq[nb]] = dl[nb];
     }
-    f32x4 dQ[DB][2];
+    f32x4 dQ[DB][NB];
 #pragma unroll
-    for (int db = 0; db < DB; ++db) dQ[db][0] = dQ[db][1] = f4zero();
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) dQ[db][nb] = f4zero();
     const float* __restrict__ Kw = Kt[wave];
     const float* __restrict__ Vw = Vt[wave];
     for (; kt < o1; kt += 32 * EQD_WAVES) {
@@ -475,26 +501,26 @@ __device__ __forceinline__ void attn_bwd_q_body(AttnBwdSmem<DB>& sm, const EqdGr
         tile_load<DB, FAST>(rk, k, d, kt + 32 * EQD_WAVES, o1, lane);
         tile_load<DB, FAST>(rv, v, d, kt + 32 * EQD_WAVES, o1, lane);
         EQD_TR(31);
-        f32x4 S[2][2], dP[2][2];
+        f32x4 S[2][NB], dP[2][NB];
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
-            S[mb][0] = S[mb][1] = f4zero();
-            dP[mb][0] = dP[mb][1] = f4zero();
-        }
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) S[mb][nb] = dP[mb][nb] = f4zero();
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
                 const float a = Kw[(16 * mb + l15) * DS + 4 * ks + g];
                 const float b = Vw[(16 * mb + l15) * DS + 4 * ks + g];
-                S[mb][0] = mfma4(a, qf[0][ks], S[mb][0]);
-                S[mb][1] = mfma4(a, qf[1][ks], S[mb][1]);
-                dP[mb][0] = mfma4(b, dof[0][ks], dP[mb][0]);
-                dP[mb][1] = mfma4(b, dof[1][ks], dP[mb][1]);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    S[mb][nb] = mfma4(a, qf[nb][ks], S[mb][nb]);
+                    dP[mb][nb] = mfma4(b, dof[nb][ks], dP[mb][nb]);
+                }
             }
         EQD_TR(32);
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -511,21 +537,21 @@ __device__ __forceinline__ void attn_bwd_q_body(AttnBwdSmem<DB>& sm, const EqdGr
 #pragma unroll
                 for (int db = 0; db < DB; ++db) {
                     const float a = Kw[(16 * mbk + 4 * g + r) * DS + 16 * db + l15];
-                    dQ[db][0] = mfma4(a, S[mbk][0][r], dQ[db][0]);
-                    dQ[db][1] = mfma4(a, S[mbk][1][r], dQ[db][1]);
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) dQ[db][nb] = mfma4(a, S[mbk][nb][r], dQ[db][nb]);
                 }
         EQD_TR(34);
     }
 #pragma unroll
     for (int db = 0; db < DB; ++db)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[wave][((db * 2 + nb) * 4 + r) * 64 + lane] = dQ[db][nb][r];
     __syncthreads();
     for (int db = wave; db < DB; db += EQD_WAVES)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
+        for (int nb = 0; nb < NB; ++nb) {
             if (!qv[nb]) continue;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -539,7 +565,7 @@ __device__ __forceinline__ void attn_bwd_q_body(AttnBwdSmem<DB>& sm, const EqdGr
 // backward pass 2: dk, dv for the block's keys (queries = the partner protein).
 // OWN_DELTA (float4 path only): delta = rowsum(dO * O) of each streamed query tile is recomputed here from the
 // O tile instead of being read from pass 1's output, so that both passes can run in ONE launch.
-template <int DB, bool FAST, bool OWN_DELTA>
+template <int DB, bool FAST, bool OWN_DELTA, int NB>
 __device__ __forceinline__ void attn_bwd_kv_body(AttnBwdSmem<DB>& sm, const EqdGraph& G, int item, int d,
                                                  const float* __restrict__ q, const float* __restrict__ k,
                                                  const float* __restrict__ v, const float* __restrict__ out,
@@ -558,8 +584,13 @@ __device__ __forceinline__ void attn_bwd_kv_body(AttnBwdSmem<DB>& sm, const EqdG
     const int l15 = lane & 15, g = lane >> 4;
     const int b0 = G.att_items[item * 4 + 0], b1 = G.att_items[item * 4 + 1];
     const int o0 = G.att_items[item * 4 + 2], o1 = G.att_items[item * 4 + 3];
-    int rowk[2] = {b0 + l15, b0 + 16 + l15};
-    bool kvd[2] = {rowk[0] < b1, rowk[1] < b1};
+    int rowk[NB];
+    bool kvd[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        rowk[nb] = b0 + 16 * nb + l15;
+        kvd[nb] = rowk[nb] < b1;
+    }
 
     TileRegs<DB, FAST> rq, rg;
     TileRegs<DB, FAST && OWN_DELTA> ro;
@@ -591,20 +622,19 @@ __device__ __forceinline__ void attn_bwd_kv_body(AttnBwdSmem<DB>& sm, const EqdG
         block_tile_stage(v, d, DS, b0, b1, Vb, t);
     }
     __syncthreads();
-    float kf[2][KS], vf[2][KS];
+    float kf[NB][KS], vf[NB][KS];
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             kf[nb][ks] = Kb[(16 * nb + l15) * DS + 4 * ks + g];
             vf[nb][ks] = Vb[(16 * nb + l15) * DS + 4 * ks + g];
         }
-    f32x4 dK[DB][2], dV[DB][2];
+    f32x4 dK[DB][NB], dV[DB][NB];
 #pragma unroll
-    for (int db = 0; db < DB; ++db) {
-        dK[db][0] = dK[db][1] = f4zero();
-        dV[db][0] = dV[db][1] = f4zero();
-    }
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) dK[db][nb] = dV[db][nb] = f4zero();
     const float* __restrict__ Qw = Qt[wave];
     const float* __restrict__ Gw = Gt[wave];
     for (; qt < o1; qt += 32 * EQD_WAVES) {
@@ -660,22 +690,22 @@ __device__ __forceinline__ void attn_bwd_kv_body(AttnBwdSmem<DB>& sm, const EqdG
                 lr[mb][r] = qr < o1 ? lv : 0.f;
                 dr[mb][r] = qr < o1 ? dv_ : 0.f;
             }
-        f32x4 S[2][2], dP[2][2];
+        f32x4 S[2][NB], dP[2][NB];
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
-            S[mb][0] = S[mb][1] = f4zero();
-            dP[mb][0] = dP[mb][1] = f4zero();
-        }
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) S[mb][nb] = dP[mb][nb] = f4zero();
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
                 const float a = Qw[(16 * mb + l15) * DS + 4 * ks + g];
                 const float b = Gw[(16 * mb + l15) * DS + 4 * ks + g];
-                S[mb][0] = mfma4(a, kf[0][ks], S[mb][0]);
-                S[mb][1] = mfma4(a, kf[1][ks], S[mb][1]);
-                dP[mb][0] = mfma4(b, vf[0][ks], dP[mb][0]);
-                dP[mb][1] = mfma4(b, vf[1][ks], dP[mb][1]);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    S[mb][nb] = mfma4(a, kf[nb][ks], S[mb][nb]);
+                    dP[mb][nb] = mfma4(b, vf[nb][ks], dP[mb][nb]);
+                }
             }
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
@@ -683,7 +713,7 @@ __device__ __forceinline__ void attn_bwd_kv_body(AttnBwdSmem<DB>& sm, const EqdG
             for (int r = 0; r < 4; ++r) {
                 const bool ok = qt + 16 * mb + 4 * g + r < o1;
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb) {
+                for (int nb = 0; nb < NB; ++nb) {
                     const float p = ok ? bwd_exp(S[mb][nb][r] - lc[mb][r]) : 0.f;
                     S[mb][nb][r] = p;
                     dP[mb][nb][r] = p * (dP[mb][nb][r] - dc[mb][r]);
@@ -697,10 +727,11 @@ __device__ __forceinline__ void attn_bwd_kv_body(AttnBwdSmem<DB>& sm, const EqdG
                 for (int db = 0; db < DB; ++db) {
                     const float a = Gw[(16 * mbq + 4 * g + r) * DS + 16 * db + l15];
                     const float b = Qw[(16 * mbq + 4 * g + r) * DS + 16 * db + l15];
-                    dV[db][0] = mfma4(a, S[mbq][0][r], dV[db][0]);
-                    dV[db][1] = mfma4(a, S[mbq][1][r], dV[db][1]);
-                    dK[db][0] = mfma4(b, dP[mbq][0][r], dK[db][0]);
-                    dK[db][1] = mfma4(b, dP[mbq][1][r], dK[db][1]);
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        dV[db][nb] = mfma4(a, S[mbq][nb][r], dV[db][nb]);
+                        dK[db][nb] = mfma4(b, dP[mbq][nb][r], dK[db][nb]);
+                    }
                 }
     }
 #pragma unroll
@@ -709,7 +740,7 @@ __device__ __forceinline__ void attn_bwd_kv_body(AttnBwdSmem<DB>& sm, const EqdG
 #pragma unroll
         for (int db = 0; db < DB; ++db)
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
+            for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     red[wave][((db * 2 + nb) * 4 + r) * 64 + lane] = pass ? dV[db][nb][r] : dK[db][nb][r];
@@ -717,7 +748,7 @@ __device__ __forceinline__ void attn_bwd_kv_body(AttnBwdSmem<DB>& sm, const EqdG
         float* __restrict__ dst = pass ? dv : dk;
         for (int db = wave; db < DB; db += EQD_WAVES)
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
+            for (int nb = 0; nb < NB; ++nb) {
                 if (!kvd[nb]) continue;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -729,7 +760,7 @@ __device__ __forceinline__ void attn_bwd_kv_body(AttnBwdSmem<DB>& sm, const EqdG
     }
 }
 
-template <int DB, bool FAST>
+template <int DB, bool FAST, int NB>
 __global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd_q(EqdGraph G, int d, const float* __restrict__ q,
                                                           const float* __restrict__ k, const float* __restrict__ v,
                                                           const float* __restrict__ out,
@@ -737,9 +768,9 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd_q(EqdGraph G, int d, con
                                                           const float* __restrict__ d_out, float* __restrict__ dq,
                                                           float* __restrict__ delta) {
     __shared__ __attribute__((aligned(16))) AttnBwdSmem<DB> sm;
-    attn_bwd_q_body<DB, FAST>(sm, G, blockIdx.x, d, q, k, v, out, lse, d_out, dq, delta);
+    attn_bwd_q_body<DB, FAST, NB>(sm, G, blockIdx.x, d, q, k, v, out, lse, d_out, dq, delta);
 }
-template <int DB, bool FAST>
+template <int DB, bool FAST, int NB>
 __global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd_kv(EqdGraph G, int d, const float* __restrict__ q,
                                                            const float* __restrict__ k, const float* __restrict__ v,
                                                            const float* __restrict__ lse,
@@ -747,10 +778,10 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd_kv(EqdGraph G, int d, co
                                                            const float* __restrict__ delta, float* __restrict__ dk,
                                                            float* __restrict__ dv) {
     __shared__ __attribute__((aligned(16))) AttnBwdSmem<DB> sm;
-    attn_bwd_kv_body<DB, FAST, false>(sm, G, blockIdx.x, d, q, k, v, nullptr, lse, d_out, delta, dk, dv);
+    attn_bwd_kv_body<DB, FAST, false, NB>(sm, G, blockIdx.x, d, q, k, v, nullptr, lse, d_out, delta, dk, dv);
 }
 // both passes in one launch (float4 path): workgroups [0, n_items) run pass 1, [n_items, 2 n_items) pass 2
-template <int DB>
+template <int DB, int NB>
 __global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd(EqdGraph G, int d, const float* __restrict__ q,
                                                         const float* __restrict__ k, const float* __restrict__ v,
                                                         const float* __restrict__ out, const float* __restrict__ lse,
@@ -760,37 +791,44 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd(EqdGraph G, int d, const
     __shared__ __attribute__((aligned(16))) AttnBwdSmem<DB> sm;
     const int item = blockIdx.x;
     if (item < G.n_att_items)
-        attn_bwd_q_body<DB, true>(sm, G, item, d, q, k, v, out, lse, d_out, dq, delta);
+        attn_bwd_q_body<DB, true, NB>(sm, G, item, d, q, k, v, out, lse, d_out, dq, delta);
     else
-        attn_bwd_kv_body<DB, true, true>(sm, G, item - G.n_att_items, d, q, k, v, out, lse, d_out, nullptr, dk, dv);
+        attn_bwd_kv_body<DB, true, true, NB>(sm, G, item - G.n_att_items, d, q, k, v, out, lse, d_out, nullptr, dk, dv);
 }
 
 // ---------------------------------------------------------------------------------------------
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-template <int DB, bool FAST>
+template <int DB, bool FAST, int NB>
 static int attn_launch_fwd(const EqdGraph* g, int d, const float* q, const float* k, const float* v, float* out,
                            float* lse, hipStream_t st) {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_fwd<DB, FAST>), dim3(g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, d, q, k,
-                       v, out, lse);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_fwd<DB, FAST, NB>), dim3(NB == 1 ? 2 * g->n_att_items : g->n_att_items),
+                       dim3(EQD_BLOCK), 0, st, *g, d, q, k, v, out, lse);
     return eqd_check_launch("k_attn_fwd");
 }
-template <int DB, bool FAST>
+template <int DB, bool FAST, int NB>
 static int attn_launch_bwd(const EqdGraph* g, int d, const float* q, const float* k, const float* v, const float* out,
                            const float* lse, const float* d_out, float* dq, float* dk, float* dv, float* delta,
                            hipStream_t st) {
     if constexpr (FAST) if (aligned16(out)) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd<DB>), dim3(2 * g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, d, q, k,
-                           v, out, lse, d_out, dq, dk, dv, delta);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd<DB, NB>), dim3(2 * g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, d, q,
+                           k, v, out, lse, d_out, dq, dk, dv, delta);
         return eqd_check_launch("k_attn_bwd");
     }
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_q<DB, FAST>), dim3(g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, d, q,
-                       k, v, out, lse, d_out, dq, delta);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_q<DB, FAST, NB>), dim3(g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, d,
+                       q, k, v, out, lse, d_out, dq, delta);
     int rc = eqd_check_launch("k_attn_bwd_q");
     if (rc) return rc;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_kv<DB, FAST>), dim3(g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, d, q,
-                       k, v, lse, d_out, delta, dk, dv);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_kv<DB, FAST, NB>), dim3(g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, d,
+                       q, k, v, lse, d_out, delta, dk, dv);
     return eqd_check_launch("k_attn_bwd_kv");
+}
+// forward, float4 path: half blocks while that still fits one round of workgroups (two of them share a CU's LDS);
+// EQD_ATT_SPLIT=0|1 forces either (tests)
+static bool att_half_blocks(const EqdGraph* g) {
+    const char* f = getenv("EQD_ATT_SPLIT");
+    if (f && (f[0] == '0' || f[0] == '1') && f[1] == 0) return f[0] == '1';
+    return g->n_att_items <= 256;
 }
 extern "C" int eqd_cross_attention_fwd(const EqdGraph* g, int d, const float* q, const float* k, const float* v,
                                        float* out, float* lse, void* stream) {
@@ -805,10 +843,13 @@ extern "C" int eqd_cross_attention_fwd(const EqdGraph* g, int d, const float* q,
     if (g->n_att_items <= 0) return EQD_OK;
     hipStream_t st = (hipStream_t)stream;
     const bool al = aligned16(q) && aligned16(k) && aligned16(v);
-    if (d == 64 && al) return attn_launch_fwd<4, true>(g, d, q, k, v, out, lse, st);
-    if (d == 80 && al) return attn_launch_fwd<5, true>(g, d, q, k, v, out, lse, st);
-    if (d <= 64) return attn_launch_fwd<4, false>(g, d, q, k, v, out, lse, st);
-    return attn_launch_fwd<5, false>(g, d, q, k, v, out, lse, st);
+    const bool half = att_half_blocks(g);
+    if (d == 64 && al)
+        return half ? attn_launch_fwd<4, true, 1>(g, d, q, k, v, out, lse, st) : attn_launch_fwd<4, true, 2>(g, d, q, k, v, out, lse, st);
+    if (d == 80 && al)
+        return half ? attn_launch_fwd<5, true, 1>(g, d, q, k, v, out, lse, st) : attn_launch_fwd<5, true, 2>(g, d, q, k, v, out, lse, st);
+    if (d <= 64) return attn_launch_fwd<4, false, 2>(g, d, q, k, v, out, lse, st);
+    return attn_launch_fwd<5, false, 2>(g, d, q, k, v, out, lse, st);
 }
 
 extern "C" int eqd_cross_attention_bwd(const EqdGraph* g, int d, const float* q, const float* k, const float* v,
@@ -825,8 +866,8 @@ extern "C" int eqd_cross_attention_bwd(const EqdGraph* g, int d, const float* q,
     if (g->n_att_items <= 0) return EQD_OK;
     hipStream_t st = (hipStream_t)stream;
     const bool al = aligned16(q) && aligned16(k) && aligned16(v) && aligned16(d_out) && aligned16(out);
-    if (d == 64 && al) return attn_launch_bwd<4, true>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
-    if (d == 80 && al) return attn_launch_bwd<5, true>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
-    if (d <= 64) return attn_launch_bwd<4, false>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
-    return attn_launch_bwd<5, false>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
+    if (d == 64 && al) return attn_launch_bwd<4, true, 2>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
+    if (d == 80 && al) return attn_launch_bwd<5, true, 2>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
+    if (d <= 64) return attn_launch_bwd<4, false, 2>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
+    return attn_launch_bwd<5, false, 2>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
 }

@@ -199,7 +199,17 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_keypoint_bwd_a(const int32_t* __r
     __syncthreads();   // dscores of this (segment, head) are re-read below by other threads of the block
     const int c = t & 63, rg = t >> 6;
     float acc = 0.f;
-    for (int i = n0 + rg; i < n1; i += 4) acc += dscores[(size_t)i * K + k] * H[(size_t)i * 64 + c];
+    for (int i = n0 + rg; i < n1; i += 32) {       // 8 rows in flight per thread (clamped, unpredicated loads)
+        float ds[8], hv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = i + 4 * u < n1 ? i + 4 * u : n0;
+            ds[u] = dscores[(size_t)r * K + k];
+            hv[u] = H[(size_t)r * 64 + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += i + 4 * u < n1 ? ds[u] * hv[u] : 0.f;
+    }
     racc[rg][c] = acc;
     __syncthreads();
     if (rg == 0) du[((size_t)s * K + k) * 64 + c] = racc[0][c] + racc[1][c] + racc[2][c] + racc[3][c];

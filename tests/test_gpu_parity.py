@@ -44,6 +44,18 @@ def test_cross_attention(dev, d):
     pc.check_attention(dev, d, sizes=((300, 257), (129, 64)))
 
 
+@pytest.mark.parametrize('split', ['0', '1'])
+def test_attention_half_blocks(dev, split, monkeypatch):
+    """forward attention with one or two workgroups per 32-row work item (EQD_ATT_SPLIT) on the float4 paths, and a
+    whole model without the split (small batches default to it)"""
+    from tests import parity_common as pc
+    monkeypatch.setenv('EQD_ATT_SPLIT', split)
+    pc.check_attention(dev, 64)
+    pc.check_attention(dev, 80, sizes=((300, 257), (129, 64)))
+    if split == '0':
+        pc.check_model_case(dev, 'D_degraded3')
+
+
 def test_kabsch(dev):
     from tests import parity_common as pc
     pc.check_kabsch(dev)

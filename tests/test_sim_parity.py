@@ -42,6 +42,17 @@ def test_cross_attention(d):
     pc.check_attention(DEV, d)
 
 
+@pytest.mark.parametrize('split', ['0', '1'])
+def test_attention_half_blocks(split, monkeypatch):
+    """forward attention with one or two workgroups per 32-row work item (EQD_ATT_SPLIT) on the float4 paths, and a
+    whole model without the split (small batches default to it)"""
+    monkeypatch.setenv('EQD_ATT_SPLIT', split)
+    pc.check_attention(DEV, 64)
+    pc.check_attention(DEV, 80, sizes=((300, 257), (129, 64)))
+    if split == '0':
+        pc.check_model_case(DEV, 'D_degraded3')
+
+
 def test_kabsch():
     pc.check_kabsch(DEV)
 
