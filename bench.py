@@ -46,24 +46,36 @@ EDGE_FWD_BYTES = lambda n, e: n * 540 + e * 112   # noqa: E731  SURVEY.md sectio
 class _BatchedLoss(torch.autograd.Function):
     """sum over pairs of mean(lig'^2) + mean(Yl^2) + mean(Yr^2) on the batched outputs (lig_w[i] = 1 / (3 n_pair(i))).
 
-    The same scalar as oracle.iegmn_port.scalar_loss, with the backward written out: spelled with torch operators and
-    differentiated by autograd it is 27 elementwise / reduction launches (~100 us of GPU time at workload B, 5 % of
-    the step, none of it the path being measured); this way it is 15."""
+    The same scalar as oracle.iegmn_port.scalar_loss, written as ONE weighted sum of squares over the concatenated
+    outputs with the backward spelled out: differentiated by autograd from the obvious expression it is 27 elementwise /
+    reduction launches (~100 us of GPU time at workload B, 6 % of the step, none of it the path being measured); this
+    way it is 6."""
 
     @staticmethod
     def forward(ctx, lig, Yl, Yr, lig_w):
-        wl = lig * lig_w
         c = 1.0 / (Yl.shape[1] * Yl.shape[2])
-        ctx.save_for_backward(wl, Yl, Yr)
-        ctx.c = c
-        return (wl * lig).sum() + (Yl.square().sum() + Yr.square().sum()) * c
+        key = (lig_w.data_ptr(), Yl.shape, Yr.shape)
+        if _BatchedLoss._wcat is None or _BatchedLoss._wcat[0] != key:      # weights of the concatenation, built once
+            w = torch.cat([lig_w.expand(-1, 3).reshape(-1), torch.full((Yl.numel() + Yr.numel(),), c, dtype=lig_w.dtype,
+                                                                       device=lig_w.device)])
+            _BatchedLoss._wcat = (key, w)
+        w = _BatchedLoss._wcat[1]
+        v = torch.cat([lig.reshape(-1), Yl.reshape(-1), Yr.reshape(-1)])
+        vw = v * w
+        ctx.save_for_backward(vw)
+        ctx.shapes = (lig.shape, Yl.shape, Yr.shape)
+        return (vw * v).sum()
 
     @staticmethod
     def backward(ctx, g):
-        wl, Yl, Yr = ctx.saved_tensors
-        g2 = g * 2.0
-        gc = g2 * ctx.c
-        return wl * g2, Yl * gc, Yr * gc, None
+        (vw,) = ctx.saved_tensors
+        gv = vw * (g * 2.0)
+        sl, syl, syr = ctx.shapes
+        nl, nyl = sl.numel(), syl.numel()
+        return gv[:nl].view(sl), gv[nl:nl + nyl].view(syl), gv[nl + nyl:].view(syr), None
+
+
+_BatchedLoss._wcat = None
 
 
 def batched_loss(lig, Yl, Yr, lig_w):
@@ -211,7 +223,8 @@ def main():
                     help='bf16: edge-message kernels in bf16 mode (he rows + GEMM inputs bf16, fp32 accumulate); the rest of the path stays fp32')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
-    ap.add_argument('--graph', action='store_true', help='replay a captured hipGraph of the whole step (zero-grad, forward, loss, backward) instead of launching eagerly; single GPU only; measured 1.6 %% faster than eager at workload B (1.98 vs 2.01 ms/step)')
+    ap.add_argument('--eager', action='store_true', help='launch every kernel of every step from the host instead of replaying a captured hipGraph of the step (zero-grad, forward, loss, backward; the gradient all-reduce always runs outside the graph).  Same kernels either way; the replay takes the host (torch autograd + ~110 launches, 0.7-1.5 ms depending on the box) off the critical path of a 1.5 ms step')
+    ap.add_argument('--graph', action='store_true', help='(default; kept for older command lines)')
     a = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -257,13 +270,17 @@ def main():
         loss.backward()
         return loss
 
-    # Optional (--graph): capture zero-grad -> forward -> loss -> backward ONCE into a hipGraph (including the
-    # forked attention / weight-gradient streams) and replay it; every kernel still runs every step.
+    # Default: capture zero-grad -> forward -> loss -> backward ONCE into a hipGraph and replay it every step (every
+    # kernel still runs every step; the RCCL all-reduce of the flat gradient stays outside the graph).  --eager launches
+    # from the host instead; a failed capture falls back to that as well.
     graph_mode = 'eager'
     static_loss = None
     cuda_graph = None
-    if a.graph:
+    if not a.eager:
         try:
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()      # no collective in flight while the stream is capturing
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -272,7 +289,7 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             cuda_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(cuda_graph):
+            with torch.cuda.graph(cuda_graph, capture_error_mode='thread_local'):
                 static_loss = compute()
             graph_mode = 'hipGraph replay'
         except Exception as e:   # capture not possible: fall back to eager launches (still the HIP path)

@@ -2,7 +2,7 @@ TAG=${1:-r01_x}
 R=$GRAFT_REPO_ROOT
 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > $R/gpurun_out/pytest_gpu.log
 python bench.py > $R/gpurun_out/${TAG}_bench.log 2>&1
-python bench.py --graph --no-cpu-baseline --no-roofline > $R/gpurun_out/${TAG}_bench_graph.log 2>&1
+python bench.py --eager --no-cpu-baseline --no-roofline > $R/gpurun_out/${TAG}_bench_eager.log 2>&1
 python bench.py --workload C --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/${TAG}_benchC.log 2>&1
 python bench.py --workload E --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/${TAG}_benchE.log 2>&1
 cd /tmp; export TMPDIR=/tmp
