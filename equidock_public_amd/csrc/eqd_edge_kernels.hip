@@ -812,7 +812,6 @@ extern "C" int eqd_edge_message_fwd(const EqdGraph* g, const EqdEdgeParams* p, c
 // dx_rel are written: 272 B/edge.  Weight-gradient blocks are kept in registers across iterations and
 // written once per workgroup; bias / LayerNorm / coordinate-MLP vector gradients go through per-wave
 // LDS accumulators.  Both partial sets are summed in a fixed order by k_reduce_segments.
-#define US 68          /* row stride of the shared operand slabs */
 #define VP 384         /* floats per wave in the vector partial buffer */
 #define V_DLNG 0
 #define V_DLNB 64
@@ -833,36 +832,52 @@ struct EdgeBwdWs {
     float* wpart;  // [nblocks][WP_N]  weight-gradient partials per workgroup
 };
 
-// F-layout tile (16 edges x 64 features) -> rows 16 w .. 16 w + 15 of a shared [128][US] slab
+// The two operand slabs of a weight-gradient GEMM (K axis = the super-tile's 128 edges) are stored TRANSPOSED,
+// [feature][edge] with row stride UST: an MFMA operand of lane (l15, g) - 4 consecutive edges of one feature, used as the
+// k-values of 4 successive MFMAs (any assignment of edges to k-steps is a valid contraction as long as A and B share
+// it) - is then ONE b128 read.  With [edge][feature] slabs and one b32 read per operand and k-step a slab GEMM was 96 LDS
+// reads for 64 MFMAs per wave and ran at 46 % of the MFMA rate (8 960 clocks per GEMM, three per super-tile = 37 % of
+// the kernel); now it is 24 b128 reads.  UST = 132 floats = 33 x 16 B: the 16 lanes of a b128 read phase (l15 = 0..15)
+// hit 16 different 16-byte bank groups, and the scalar stores below (16 g + l15 mod 64) all 64 banks.
+#define UST 132
+// F-layout tile (16 edges x 64 features) -> columns 16 w .. 16 w + 15 of a shared [64][UST] slab
 __device__ __forceinline__ void slab_store(float* __restrict__ slab, int wave, const f32x4 (&v)[4][1], int l15, int g) {
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
-        *(float4*)&slab[(16 * wave + l15) * US + 16 * mb + 4 * g] =
-            make_float4(v[mb][0][0], v[mb][0][1], v[mb][0][2], v[mb][0][3]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab[(16 * mb + 4 * g + r) * UST + 16 * wave + l15] = v[mb][0][r];
 }
 // acc[j] += X^T Y over the 128 edges of the slabs for output block (mb, nb0 + j)
 template <int NJ>
-__device__ __forceinline__ void slab_atb(f32x4 (&acc)[NJ], const float* __restrict__ X, const float* __restrict__ Y,
+__device__ __forceinline__ void slab_atb(f32x4 (&acc)[NJ], const float* __restrict__ Xt, const float* __restrict__ Yt,
                                          int mb, int nb0, int l15, int g) {
-#pragma unroll 4
-    for (int s = 0; s < 32; ++s) {
-        const int row = 4 * s + g;
-        const float a = X[row * US + 16 * mb + l15];
+#pragma unroll 2
+    for (int kc = 0; kc < 8; ++kc) {
+        const f32x4 a = *(const f32x4*)&Xt[(16 * mb + l15) * UST + 16 * kc + 4 * g];
+        f32x4 b[NJ];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[j] = mfma4(a, Y[row * US + 16 * (nb0 + j) + l15], acc[j]);
+        for (int j = 0; j < NJ; ++j) b[j] = *(const f32x4*)&Yt[(16 * (nb0 + j) + l15) * UST + 16 * kc + 4 * g];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[j] = mfma4(a[u], b[j][u], acc[j]);
     }
 }
 
 // acc += X^T F where F = the waves' [16][FS] feature tiles stacked (row = edge within the 128-edge super-tile)
-__device__ __forceinline__ void feat_atb(f32x4 (&acc)[1], const float* __restrict__ X, const float* __restrict__ tiles,
+__device__ __forceinline__ void feat_atb(f32x4 (&acc)[1], const float* __restrict__ Xt, const float* __restrict__ tiles,
                                          int mb, int nb, int l15, int g) {
     const int c = 16 * nb + l15;
     const bool ok = c < FS;
-#pragma unroll 4
-    for (int s = 0; s < 32; ++s) {
-        const int row = 4 * s + g;
-        const float b = ok ? tiles[(row >> 4) * (16 * FS) + (row & 15) * FS + c] : 0.f;
-        acc[0] = mfma4(X[row * US + 16 * mb + l15], b, acc[0]);
+    const int cc = ok ? c : 0;
+#pragma unroll 2
+    for (int kc = 0; kc < 8; ++kc) {
+        const f32x4 a = *(const f32x4*)&Xt[(16 * mb + l15) * UST + 16 * kc + 4 * g];
+        float b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) b[u] = tiles[kc * (16 * FS) + (4 * g + u) * FS + cc];     // edge 16 kc + 4 g + u
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[0] = mfma4(a[u], ok ? b[u] : 0.f, acc[0]);
     }
 }
 
@@ -892,7 +907,7 @@ template <bool BF>
 struct EdgeBwdSmemSel {
     typedef EdgeSmem<BWD_WAVES, 16 * FS> type;
     typedef float slab_t;
-    enum { SLAB = 128 * US };
+    enum { SLAB = 64 * UST };
 };
 template <>
 struct EdgeBwdSmemSel<true> {
