@@ -1174,17 +1174,26 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
         __syncthreads();                 // phase-3 slabs and the feature tiles are free for the next iteration
         EQD_TR(21);
     }
-    // ---- partials: this wave's vector sums and weight-gradient blocks ---------------------------------------
-    float* vp = W.vecp + (size_t)(blockIdx.x * BWD_WAVES + wave) * VP;
+    // ---- partials: the workgroup's vector sums (its 8 waves' sums added in wave order through the free U slab: one
+    //      partial row per workgroup, not per wave, for the later fixed-order reduction) and weight-gradient blocks ----
     {
+        float* vs = (float*)U + wave * VP;      // the slabs are free after the loop's last barrier
         const int fo = 16 * (l15 >> 2) + 4 * g + (l15 & 3);
-        vp[V_DLNG + fo] = r_dlng;
-        vp[V_DLNB + fo] = r_dlnb;
-        vp[V_DWC2 + fo] = r_dwc2;
-        vp[V_DB2 + fo] = r_db2;
-        vp[V_DBC1 + fo] = r_dbc1;
+        vs[V_DLNG + fo] = r_dlng;
+        vs[V_DLNB + fo] = r_dlnb;
+        vs[V_DWC2 + fo] = r_dwc2;
+        vs[V_DB2 + fo] = r_db2;
+        vs[V_DBC1 + fo] = r_dbc1;
         const float t = wave_sum(r_dbc2);
-        if (lane == 0) vp[V_DBC2] = t;
+        if (lane == 0) vs[V_DBC2] = t;
+        __syncthreads();
+        float* vp = W.vecp + (size_t)blockIdx.x * VP;
+        for (int i = threadIdx.x; i < VP; i += 64 * BWD_WAVES) {
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < BWD_WAVES; ++w) a += ((const float*)U)[w * VP + i];
+            vp[i] = a;
+        }
     }
     float* wp = W.wpart + (size_t)blockIdx.x * WP_N;
 #pragma unroll
@@ -1301,7 +1310,7 @@ int eqd_edge_message_bwd_impl(const EqdGraph* g, const EqdEdgeParams* p, const f
         }
         int rc = eqd_check_launch("k_edge_bwd");
         if (rc) return rc;
-        const int nw = blocks * BWD_WAVES;
+        const int nw = blocks;               // one vector partial row per workgroup
         const int koff = 2 * p->d_in;
         EqdRedSeg segs[9] = {
             {W.vecp + V_DLNG, nw, VP, 64, grads->dln_g, 0, 0, 0}, {W.vecp + V_DLNB, nw, VP, 64, grads->dln_b, 0, 0, 0},
@@ -1316,6 +1325,7 @@ int eqd_edge_message_bwd_impl(const EqdGraph* g, const EqdEdgeParams* p, const f
             return rc;
         }
     }
-    // per-node sums: dP (by source), dQ (by destination), dx = (1 - eta) d_xnew + sum_src dx_rel - sum_dst dx_rel
-    return eqd_launch_node_gather(g, W.dz1, W.dxrel, d_xnew, 1.f - p->eta, dP, dQ, dx, st);
+    // per-node sums: dP (by source), dQ (by destination), dx = (1 - eta) d_xnew + sum_src dx_rel - sum_dst dx_rel;
+    // the pending reductions (this layer's partials and whatever the caller had queued) ride in the same launch
+    return eqd_launch_node_gather(g, W.dz1, W.dxrel, d_xnew, 1.f - p->eta, dP, dQ, dx, st, defer);
 }

@@ -771,15 +771,15 @@ extern "C" int eqd_atb(const EqdAtbJob* jobs, int njobs, void* partial, size_t p
 // version of this kernel ran at 1 TB/s on the 90 MB of edge weight-gradient partials of a config-B pass, and chains of
 // 2 000 short partials serialised 8 load round trips in one workgroup).  The summation order is fixed: parts
 // pl, pl + 64, .. in each lane, segments of a chain in list order, then the 64 lanes as 4 x 16 in index order.
-__global__ __launch_bounds__(1024) void k_reduce_segments(EqdRedArg A) {
-    __shared__ __attribute__((aligned(16))) float red[64][68];
-    __shared__ float red2[4][64];
+// PL part lanes (thread = 16 column groups x PL): 64 in k_reduce_segments, 16 when the block rides in k_node_gather
+template <int PL>
+__device__ __forceinline__ void reduce_block(const EqdRedArg& A, int blk, float (*red)[68], float (*red2)[64]) {
     int ch = 0;
-    while (ch + 1 < A.nchains && (int)blockIdx.x >= A.chain_blk0[ch + 1]) ++ch;
+    while (ch + 1 < A.nchains && blk >= A.chain_blk0[ch + 1]) ++ch;
     ch = uni(ch);
     const int first = A.chain_first[ch], len = A.chain_len[ch];
     const int t = threadIdx.x, cg = t & 15, pl = t >> 4;
-    const int c0 = ((int)blockIdx.x - A.chain_blk0[ch]) * 64;
+    const int c0 = (blk - A.chain_blk0[ch]) * 64;
     const int n = A.s[first].n;
     const int col = c0 + 4 * cg;            // this thread's columns col .. col + 3
     const int nv = n - col;                 // how many of them exist (<= 0: none)
@@ -790,16 +790,16 @@ __global__ __launch_bounds__(1024) void k_reduce_segments(EqdRedArg A) {
             const float* __restrict__ base = S.partial + (nv > 0 ? col : 0);
             const int np = S.nparts;
             const size_t ps = (size_t)S.pstride;
-            for (int p0 = pl; p0 < np; p0 += 8 * 64) {
+            for (int p0 = pl; p0 < np; p0 += 8 * PL) {
                 f32x4 v[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int p = p0 + 64 * u;
+                    const int p = p0 + PL * u;
                     v[u] = ld4u_raw(base + (size_t)(p < np ? p : 0) * ps, nv, S.partial);
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const float4 f = ld4u_fix(v[u], p0 + 64 * u < np ? nv : 0);
+                    const float4 f = ld4u_fix(v[u], p0 + PL * u < np ? nv : 0);
                     acc.x += f.x;
                     acc.y += f.y;
                     acc.z += f.z;
@@ -811,7 +811,7 @@ __global__ __launch_bounds__(1024) void k_reduce_segments(EqdRedArg A) {
         float a3[3] = {0.f, 0.f, 0.f};
         for (int j = 0; j < len; ++j) {
             const EqdRedSeg& S = A.s[first + j];
-            for (int p = pl; p < S.nparts; p += 64)
+            for (int p = pl; p < S.nparts; p += PL)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const float v = S.partial[(size_t)p * S.pstride + (c < n ? c : 0)];
@@ -826,7 +826,7 @@ __global__ __launch_bounds__(1024) void k_reduce_segments(EqdRedArg A) {
         const int c = t & 63, qd = t >> 6;
         float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) s += red[16 * qd + j][c];
+        for (int j = 0; j < PL / 4; ++j) s += red[(PL / 4) * qd + j][c];
         red2[qd][c] = s;
     }
     __syncthreads();
@@ -842,50 +842,68 @@ __global__ __launch_bounds__(1024) void k_reduce_segments(EqdRedArg A) {
         }
     }
 }
-int eqd_launch_reduce_segments(const EqdRedSeg* segs, int nseg, hipStream_t st) {
-    // group by output pointer (stable order), then launch whole chains, at most EQD_RED_MAXSEG segments each
-    static thread_local int order[512], cfirst[512], clen[512];
+__global__ __launch_bounds__(1024) void k_reduce_segments(EqdRedArg A) {
+    __shared__ __attribute__((aligned(16))) float red[64][68];
+    __shared__ float red2[4][64];
+    reduce_block<64>(A, (int)blockIdx.x, red, red2);
+}
+// segments -> launch descriptors: chains of segments with the same output (shared-weight layers) are summed by ONE
+// workgroup column.  Fills as many whole chains as fit one EqdRedArg starting at chain *c0; returns the workgroup count.
+struct RedPlan {
+    int order[512], cfirst[512], clen[512], nc;
+};
+static int red_plan(const EqdRedSeg* segs, int nseg, RedPlan& P) {
     static thread_local bool used[512];
     if (nseg > 512) {
         eqd_set_error("eqd_launch_reduce_segments: too many segments");
         return EQD_ERR_SHAPE;
     }
-    int no = 0, nc = 0;
+    int no = 0;
+    P.nc = 0;
     for (int i = 0; i < nseg; ++i) used[i] = false;
     for (int i = 0; i < nseg; ++i) {
         if (used[i]) continue;
-        cfirst[nc] = no;
+        P.cfirst[P.nc] = no;
         for (int j = i; j < nseg; ++j)
             if (!used[j] && segs[j].out == segs[i].out && segs[j].n == segs[i].n) {
                 used[j] = true;
-                order[no++] = j;
+                P.order[no++] = j;
             }
-        clen[nc] = no - cfirst[nc];
-        if (clen[nc] > EQD_RED_MAXSEG) {
+        P.clen[P.nc] = no - P.cfirst[P.nc];
+        if (P.clen[P.nc] > EQD_RED_MAXSEG) {
             eqd_set_error("eqd_launch_reduce_segments: chain too long");
             return EQD_ERR_SHAPE;
         }
-        ++nc;
+        ++P.nc;
     }
-    int c0 = 0;
-    while (c0 < nc) {
-        EqdRedArg arg;
-        memset(&arg, 0, sizeof(arg));
-        int ns = 0, nch = 0, nblk = 0;
-        while (c0 < nc && ns + clen[c0] <= EQD_RED_MAXSEG) {
-            const int n0 = segs[order[cfirst[c0]]].n;
-            if (n0 > 0) {
-                arg.chain_first[nch] = ns;
-                arg.chain_len[nch] = clen[c0];
-                arg.chain_blk0[nch] = nblk;
-                nblk += (n0 + 63) / 64;
-                for (int j = 0; j < clen[c0]; ++j) arg.s[ns++] = segs[order[cfirst[c0] + j]];
-                ++nch;
-            }
-            ++c0;
+    return EQD_OK;
+}
+static int red_fill(const EqdRedSeg* segs, const RedPlan& P, int& c0, EqdRedArg& arg) {
+    memset(&arg, 0, sizeof(arg));
+    int ns = 0, nch = 0, nblk = 0;
+    while (c0 < P.nc && ns + P.clen[c0] <= EQD_RED_MAXSEG) {
+        const int n0 = segs[P.order[P.cfirst[c0]]].n;
+        if (n0 > 0) {
+            arg.chain_first[nch] = ns;
+            arg.chain_len[nch] = P.clen[c0];
+            arg.chain_blk0[nch] = nblk;
+            nblk += (n0 + 63) / 64;
+            for (int j = 0; j < P.clen[c0]; ++j) arg.s[ns++] = segs[P.order[P.cfirst[c0] + j]];
+            ++nch;
         }
+        ++c0;
+    }
+    arg.nchains = nch;
+    return nblk;
+}
+int eqd_launch_reduce_segments(const EqdRedSeg* segs, int nseg, hipStream_t st) {
+    static thread_local RedPlan P;
+    if (int e = red_plan(segs, nseg, P)) return e;
+    int c0 = 0;
+    while (c0 < P.nc) {
+        EqdRedArg arg;
+        const int nblk = red_fill(segs, P, c0, arg);
         if (nblk == 0) continue;
-        arg.nchains = nch;
         hipLaunchKernelGGL(k_reduce_segments, dim3(nblk), dim3(1024), 0, st, arg);
         int rc = eqd_check_launch("k_reduce_segments");
         if (rc) return rc;
@@ -984,10 +1002,21 @@ int eqd_launch_embed_bwd(const EqdGraph* g, const float* dh0, const float* dh0b,
 //   dP[j] = sum over out-edges (CSC, edges with src == j) of dz[e]
 //   dQ[j] = sum over in-edges  (CSR, edges with dst == j) of dz[e]
 //   dx[j] = a * d_xnew[j] + sum_{src == j} dxrel[e] - sum_{dst == j} dxrel[e]      (x_rel = x[src] - x[dst])
-__global__ void k_node_gather(const int32_t* __restrict__ csc_ptr, const int32_t* __restrict__ csc_eid,
-                              const int32_t* __restrict__ rowptr, int n, const float* __restrict__ dz,
-                              const float* __restrict__ dxrel, const float* __restrict__ d_xnew, float a,
-                              float* __restrict__ dP, float* __restrict__ dQ, float* __restrict__ dx) {
+// Workgroups beyond the gather's own (blockIdx.x >= ngather) sum pending partials (EqdRedArg): the layer's edge
+// weight-gradient partials were written by the launch before, are read here while they are still in the memory-side
+// cache, and the workgroups run on CUs the small gather leaves idle - instead of 90 MB of partials of a config-B
+// pass being streamed from HBM by two launches at the end (68 us).
+__global__ __launch_bounds__(256) void k_node_gather(const int32_t* __restrict__ csc_ptr, const int32_t* __restrict__ csc_eid,
+                                                     const int32_t* __restrict__ rowptr, int n, const float* __restrict__ dz,
+                                                     const float* __restrict__ dxrel, const float* __restrict__ d_xnew, float a,
+                                                     float* __restrict__ dP, float* __restrict__ dQ, float* __restrict__ dx,
+                                                     int ngather, EqdRedArg RA) {
+    if ((int)blockIdx.x >= ngather) {
+        __shared__ __attribute__((aligned(16))) float red[16][68];
+        __shared__ float red2[4][64];
+        reduce_block<16>(RA, (int)blockIdx.x - ngather, red, red2);
+        return;
+    }
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int c = threadIdx.x & 63;
     if (j >= n) return;
@@ -1030,12 +1059,35 @@ __global__ void k_node_gather(const int32_t* __restrict__ csc_ptr, const int32_t
     dQ[(size_t)j * 64 + c] = sq;
     if (c < 3) dx[(size_t)j * 3 + c] = a * d_xnew[(size_t)j * 3 + c] + sx;
 }
+// pending: reductions to run in the same launch (emptied on return); what does not fit one descriptor is launched on
+// its own
 int eqd_launch_node_gather(const EqdGraph* g, const float* dz, const float* dxrel, const float* d_xnew, float a,
-                           float* dP, float* dQ, float* dx, hipStream_t st) {
-    if (g->n_nodes == 0) return EQD_OK;
-    hipLaunchKernelGGL(k_node_gather, dim3((g->n_nodes + 3) / 4), dim3(256), 0, st, g->csc_ptr, g->csc_eid, g->rowptr,
-                       g->n_nodes, dz, dxrel, d_xnew, a, dP, dQ, dx);
-    return eqd_check_launch("k_node_gather");
+                           float* dP, float* dQ, float* dx, hipStream_t st, EqdRedList* pending) {
+    static thread_local RedPlan P;
+    static thread_local EqdRedArg arg;
+    int nblk = 0, c0 = 0;
+    memset(&arg, 0, sizeof(arg));
+    if (pending && pending->n > 0) {
+        if (int e = red_plan(pending->seg, pending->n, P)) return e;
+        nblk = red_fill(pending->seg, P, c0, arg);
+    }
+    const int ng = (g->n_nodes + 3) / 4;
+    if (ng + nblk > 0) {
+        hipLaunchKernelGGL(k_node_gather, dim3(ng + nblk), dim3(256), 0, st, g->csc_ptr, g->csc_eid, g->rowptr,
+                           g->n_nodes, dz, dxrel, d_xnew, a, dP, dQ, dx, ng, arg);
+        if (int rc = eqd_check_launch("k_node_gather")) return rc;
+    }
+    if (pending && pending->n > 0) {
+        while (c0 < P.nc) {         // (more than 64 segments or chains: not the case for one layer)
+            EqdRedArg more;
+            const int nb = red_fill(pending->seg, P, c0, more);
+            if (nb == 0) continue;
+            hipLaunchKernelGGL(k_reduce_segments, dim3(nb), dim3(1024), 0, st, more);
+            if (int rc = eqd_check_launch("k_reduce_segments")) return rc;
+        }
+        pending->n = 0;
+    }
+    return EQD_OK;
 }
 
 // Backward of LeakyReLU -> LayerNorm (node_mlp.2/.3): y_act = LeakyReLU(z) is saved by the forward.
