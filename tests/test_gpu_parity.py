@@ -99,6 +99,12 @@ def test_flat_grads(dev):
     pc.check_flat_grads_equal_autograd(dev)
 
 
+def test_model_vs_oracle_ragged(dev):
+    from tests import parity_common as pc
+    pc.check_model_vs_oracle_ragged(dev)
+    pc.check_model_vs_oracle_ragged(dev, sizes=((129, 257), (300, 31), (64, 64), (95, 200)), layers=3, seed=8)
+
+
 def test_properties_small(dev):
     from tests import parity_common as pc
     pc.check_properties(dev)

@@ -87,6 +87,10 @@ def test_flat_grads():
     pc.check_flat_grads_equal_autograd(DEV)
 
 
+def test_model_vs_oracle_ragged():
+    pc.check_model_vs_oracle_ragged(DEV)
+
+
 def test_properties():
     pc.check_properties(DEV, sizes=((30, 41), (52, 27)), layers=2)
 
