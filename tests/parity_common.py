@@ -518,7 +518,8 @@ def check_properties(dev, sizes=((60, 75), (90, 48)), layers=3):
         assert err < 2e-3, f'SE(3) equivariance violated: {err}'
 
 
-def check_model_vs_oracle_ragged(dev, sizes=((4, 4), (17, 5), (33, 64), (1, 40), (48, 1)), layers=2, seed=21):
+def check_model_vs_oracle_ragged(dev, sizes=((4, 4), (17, 5), (33, 64), (1, 40), (48, 1)), layers=2, seed=21,
+                                 check_grads=True):
     """Tiny and ragged proteins (1-node graphs without edges, blocks that end mid-tile, fewer nodes than neighbours):
     outputs and gradients of the HIP path against the oracle on the same inputs.  (2- and 3-node proteins are left
     out on purpose: their keypoints are coplanar, the Kabsch guard loop makes A full rank with a 1e-3-conditioned
@@ -539,4 +540,6 @@ def check_model_vs_oracle_ragged(dev, sizes=((4, 4), (17, 5), (33, 64), (1, 40),
         for x, y in zip(a, b):
             close(x, y, tol=1e-4, what='ragged batch output')
     for k, p in net.named_parameters():
-        grad_close(p.grad, leaves[k].grad, what=f'ragged batch grad {k}')
+        assert torch.isfinite(p.grad).all(), k
+        if check_grads:
+            grad_close(p.grad, leaves[k].grad, what=f'ragged batch grad {k} sizes={sizes}')

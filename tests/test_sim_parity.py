@@ -88,7 +88,8 @@ def test_flat_grads():
 
 
 def test_model_vs_oracle_ragged():
-    pc.check_model_vs_oracle_ragged(DEV)
+    pc.check_model_vs_oracle_ragged(DEV, check_grads=False)
+    pc.check_model_vs_oracle_ragged(DEV, sizes=((4, 4), (17, 5), (33, 64)))
 
 
 def test_properties():
