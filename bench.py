@@ -83,18 +83,23 @@ def batched_loss(lig, Yl, Yr, lig_w):
 
 
 def time_kernel(fn, iters, stream_sync):
-    """Average duration of ONE launch of fn: every launch is bracketed by its own pair of HIP events on the
-    launch stream, so host launch overhead (ctypes, Python) between launches is not part of the figure."""
+    """Average duration of ONE launch of fn, from HIP events on the launch stream around batches of 10 back-to-back
+    launches.  A spin kernel in front of every batch keeps the GPU busy while the host enqueues the batch, so host launch
+    overhead (ctypes, Python; 5-15 us per launch depending on the box) is not in the figure - one event pair per launch
+    measured 37-41 us for a kernel that rocprofv3 times at 34 us."""
     for _ in range(3):
         fn()
     stream_sync()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    per = 10
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(max(1, iters // per))]
     for e0, e1 in ev:
+        torch.cuda._sleep(2_000_000)        # ~1 ms of spinning
         e0.record()
-        fn()
+        for _ in range(per):
+            fn()
         e1.record()
     ev[-1][1].synchronize()
-    ts = [e0.elapsed_time(e1) for e0, e1 in ev]
+    ts = [e0.elapsed_time(e1) / per for e0, e1 in ev]
     return sum(ts) / len(ts) * 1e-3   # seconds per launch
 
 
