@@ -410,7 +410,7 @@ extern "C" int eqd_linear(const EqdLinJob* jobs, int njobs, void* stream) {
 struct AtbUnit {
     EqdAtbJob job;
     int n0, nparts, nchunks;
-    int fast;        // M == 64, a full 64-column block of Y, 16-byte aligned rows: see atb_fast
+    int fast;        // 0 general; 1 / 2: M == 64 with aligned X rows, Y block whole and aligned / through ld4u (atb_fast)
     long long poff;  // float offset of this unit's partials
 };
 static_assert(sizeof(AtbUnit) * 36 <= 4096, "AtbUnitsArg must fit the kernel-argument segment");
@@ -514,6 +514,8 @@ __device__ __forceinline__ void atb_fast(const AtbUnit& u, int c, float* __restr
     const EQD_GAS float* const X = (const EQD_GAS float*)J.X + 4 * tc;
     const EQD_GAS float* const Xm = (const EQD_GAS float*)(masked ? J.xmask : J.X) + 4 * tc;
     const EQD_GAS float* const Y = (const EQD_GAS float*)J.Y + u.n0 + 4 * tc;
+    const int ny = J.N - (u.n0 + 4 * tc);      // columns of Y left at this thread's vector (a narrow last block: < 4, <= 0)
+    const bool yfull = u.fast == 1;            // 1: a whole 64-column block of 16-byte aligned rows
     f32x4 acc[5];
 #pragma unroll
     for (int mb = 0; mb < 5; ++mb) acc[mb] = f4zero();
@@ -526,7 +528,8 @@ __device__ __forceinline__ void atb_fast(const AtbUnit& u, int c, float* __restr
             row = row < rows ? row : rows - 1;
             rx[jr] = *(const EQD_GAS f4v*)(X + (size_t)row * ldx);
             if (masked) rm[jr] = *(const EQD_GAS f4v*)(Xm + (size_t)row * ldx);
-            ry[jr] = *(const EQD_GAS f4v*)(Y + (size_t)row * ldy);
+            ry[jr] = yfull ? *(const EQD_GAS f4v*)(Y + (size_t)row * ldy)
+                           : ld4u_raw((const float*)(Y + (size_t)row * ldy), ny, J.Y);
         }
     };
     load(c);
@@ -536,6 +539,10 @@ __device__ __forceinline__ void atb_fast(const AtbUnit& u, int c, float* __restr
         for (int jr = 0; jr < 4; ++jr) {
             const bool rvalid = chunk * ATB_ROWS + tr + 16 * jr < rows;
             f32x4 v = rx[jr], y = ry[jr];
+            if (!yfull) {
+                const float4 f = ld4u_fix(ry[jr], ny);
+                y = f32x4{f.x, f.y, f.z, f.w};
+            }
             if (masked) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] *= lrelu_grad(rm[jr][i], slope);
@@ -675,8 +682,10 @@ static int atb_units(const EqdAtbJob* jobs, int njobs, std::vector<AtbUnit>& uni
             u.n0 = n0;
             u.nchunks = nchunks;
             auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
-            u.fast = J.M == 64 && J.N - n0 >= 64 && J.rows > 0 && (J.ldx & 3) == 0 && (J.ldy & 3) == 0 && al16(J.X) &&
-                     al16(J.Y) && (!J.xmask || al16(J.xmask));
+            // 1: everything aligned and a whole 64-column block of Y; 2: X as in 1, Y through the shifting loader (the 5
+            // columns left over of the 69-wide h0: a general-path unit costs twice a fast one for 1/13 of the columns)
+            const bool xfast = J.M == 64 && J.rows > 0 && (J.ldx & 3) == 0 && al16(J.X) && (!J.xmask || al16(J.xmask));
+            u.fast = !xfast ? 0 : (J.N - n0 >= 64 && (J.ldy & 3) == 0 && al16(J.Y)) ? 1 : (J.N - n0 >= 4 || n0 >= 4) ? 2 : 0;
             units.push_back(u);
         }
     }

@@ -162,6 +162,19 @@ def check_atb(dev):
         close(outc, (Xe.t() @ Yc).t(), tol=2e-4, what=f'A^T B, aligned 64-wide, rows={rows}')
         if bias:
             close(boc, Xe.sum(0), tol=2e-4, what='column sums, aligned 64-wide')
+    # aligned 64-wide X against the 69-wide h0 (unaligned rows of Y, a 5-column last block)
+    rows = 777
+    Xc, Yc = torch.randn(rows, 64), torch.randn(rows, 69)
+    outc = torch.zeros(64, 69, device=dev)
+    Xcd, Ycd = Xc.to(dev), Yc.to(dev)
+    Dj = L.EqdAtbJob()
+    Dj.X, Dj.ldx, Dj.M, Dj.Y, Dj.ldy, Dj.N = Xcd.data_ptr(), 64, 64, Ycd.data_ptr(), 69, 69
+    Dj.rows, Dj.out, Dj.o_rs, Dj.o_cs, Dj.slope, Dj.scale = rows, outc.data_ptr(), 69, 1, 0.01, 1.0
+    nb = lib().eqd_atb_partial_bytes(C.byref(Dj), 1)
+    part = torch.zeros(nb // 4 + 64, device=dev)
+    L.check(lib().eqd_atb(C.byref(Dj), 1, P(part), C.c_size_t(nb), st(dev)))
+    sync(dev)
+    close(outc, Xc.t() @ Yc, tol=2e-4, what='A^T B, 64 x 69')
 
 
 def _edge_setup(dev, d_in=64):
