@@ -92,7 +92,7 @@ def _declare(lib):
                  'eqd_edge_message_fwd', 'eqd_edge_message_bwd', 'eqd_edge_message_bwd_kernel_only',
                  'eqd_cross_attention_fwd',
                  'eqd_cross_attention_bwd', 'eqd_keypoint_pool_fwd', 'eqd_kabsch_fwd', 'eqd_kabsch_bwd',
-                 'eqd_rigid_apply_fwd', 'eqd_rigid_apply_bwd'):
+                 'eqd_rigid_apply_fwd', 'eqd_rigid_apply_bwd', 'eqd_pair_losses_fwd', 'eqd_pair_losses_bwd'):
         getattr(lib, name).restype = C.c_int
 
 
@@ -101,7 +101,8 @@ EXPORTS = ('eqd_ctx_create', 'eqd_ctx_destroy', 'eqd_abi_version', 'eqd_last_err
            'eqd_atb_partial_bytes', 'eqd_atb', 'eqd_edge_message_fwd', 'eqd_edge_message_bwd_workspace_bytes',
            'eqd_edge_message_bwd', 'eqd_edge_message_bwd_kernel_only', 'eqd_cross_attention_fwd',
            'eqd_cross_attention_bwd', 'eqd_keypoint_pool_fwd',
-           'eqd_kabsch_fwd', 'eqd_kabsch_bwd', 'eqd_rigid_apply_fwd', 'eqd_rigid_apply_bwd')
+           'eqd_kabsch_fwd', 'eqd_kabsch_bwd', 'eqd_rigid_apply_fwd', 'eqd_rigid_apply_bwd', 'eqd_pair_losses_fwd',
+           'eqd_pair_losses_bwd')
 
 
 def load_library():

@@ -245,6 +245,24 @@ int eqd_rigid_apply_fwd(const EqdGraph* g, const float* T, const float* b, float
 /* dT[b] += sum_i d_lig_i x_i^T, db[b] += sum_i d_lig_i (dT, db must be initialised by the caller). */
 int eqd_rigid_apply_bwd(const EqdGraph* g, const float* d_lig, float* dT, float* db, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Loss terms right after the hot path, batched over the pairs of g instead of the
+ * reference's Python loop over the minibatch (src/train.py:112-133):
+ *   mse[p]   = nn.MSELoss(reduction='mean')(lig_pred_p, lig_target_p)                       (src/train.py:114, 274)
+ *   inter[p] = compute_body_intersection_loss(lig_pred_p, rec_p, sigma, surface_ct)          (src/train.py:41-49)
+ * lig_pred / lig_target: [n_lig][3] in the graph's ligand node order; rec: [n_rec][3] bound receptor coordinates in
+ * the graph's receptor node order.  s_lig [n_lig] / s_rec [n_rec] receive the Gaussian sums of every node and are the
+ * only state the backward needs.  The backward writes d lig_pred = d_mse[p] dmse/da + d_inter[p] dinter/da
+ * (d_mse / d_inter: [n_pairs], NULL = zero); no other input carries a gradient in the reference either.
+ * The pocket OT term (ot.emd) is not part of this library.
+ * ------------------------------------------------------------------------------------------- */
+int eqd_pair_losses_fwd(const EqdGraph* g, const float* lig_pred, const float* lig_target, const float* rec,
+                        float sigma, float surface_ct, float* mse, float* inter, float* s_lig, float* s_rec,
+                        void* stream);
+int eqd_pair_losses_bwd(const EqdGraph* g, const float* lig_pred, const float* lig_target, const float* rec,
+                        float sigma, float surface_ct, const float* s_lig, const float* s_rec, const float* d_mse,
+                        const float* d_inter, float* d_lig_pred, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

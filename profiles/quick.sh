@@ -1,4 +1,3 @@
 R=$GRAFT_REPO_ROOT
-python bench.py --dtype bf16 --no-cpu-baseline > $R/gpurun_out/r01_z_benchB_bf16.log 2>&1
-python bench.py --workload C --dtype bf16 --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/r01_z_benchC_bf16.log 2>&1
-python bench.py --workload E --dtype bf16 --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/r01_z_benchE_bf16.log 2>&1
+python -m pytest tests -m gpu -x -q 2>&1 | tail -4 > $R/gpurun_out/pytest_gpu.log
+python profiles/bench_losses.py > $R/gpurun_out/bench_losses.log 2>&1

@@ -556,3 +556,55 @@ def check_model_vs_oracle_ragged(dev, sizes=((4, 4), (17, 5), (33, 64), (1, 40),
         assert torch.isfinite(p.grad).all(), k
         if check_grads:
             grad_close(p.grad, leaves[k].grad, what=f'ragged batch grad {k} sizes={sizes}')
+
+
+def check_pair_losses(dev):
+    """eqd_pair_losses_fwd / _bwd through equidock_public_amd.losses against the golden vectors recorded from the
+    reference's own functions (tests/golden/loss_case.npz, oracle/make_golden_loss.py) and against the oracle port on a
+    second, larger batch."""
+    import os
+    import numpy as np
+    from equidock_public_amd import graph as G, losses, synthetic
+    from oracle import loss_port as lp
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'loss_case.npz'))
+    sizes = [tuple(int(v) for v in r) for r in z['sizes']]
+    sigma, ct = float(z['sigma']), float(z['surface_ct'])
+    g = G.batch_pairs(synthetic.make_pairs(sizes, 3)).to(dev)      # only the segmentation of the batch is used
+    P_ = len(sizes)
+    pred = torch.cat([torch.tensor(z[f'pred{p}']) for p in range(P_)]).to(dev).requires_grad_(True)
+    tgt = torch.cat([torch.tensor(z[f'tgt{p}']) for p in range(P_)]).to(dev)
+    rec = torch.cat([torch.tensor(z[f'rec{p}']) for p in range(P_)]).to(dev)
+    mse, inter = losses.pair_losses(g, pred, tgt, rec, sigma, ct)
+    for p in range(P_):
+        close(mse[p], torch.tensor(z[f'mse{p}']), tol=1e-5, what=f'mse pair {p}')
+        close(inter[p], torch.tensor(z[f'inter{p}']), tol=1e-5, what=f'intersection loss pair {p}')
+    wm = torch.tensor([1.0, 0.5, 2.0, 1.5], device=mse.device)
+    wi = torch.tensor([0.7, 1.0, 1.3, 0.2], device=mse.device)
+    ((mse * wm).sum() + (inter * wi).sum()).backward()
+    off = 0
+    for p, (nl, _) in enumerate(sizes):
+        ref = float(wm[p]) * torch.tensor(z[f'dmse{p}']) + float(wi[p]) * torch.tensor(z[f'dinter{p}'])
+        close(pred.grad[off:off + nl], ref, tol=1e-5, what=f'd lig_pred pair {p}')
+        off += nl
+    # single-pair wrapper with the reference's name and signature
+    a0 = torch.tensor(z['pred0']).to(dev).requires_grad_(True)
+    l0 = losses.compute_body_intersection_loss(a0, torch.tensor(z['rec0']).to(dev), sigma, ct)
+    close(l0, torch.tensor(z['inter0']), tol=1e-5, what='compute_body_intersection_loss')
+    l0.backward()
+    close(a0.grad, torch.tensor(z['dinter0']), tol=1e-5, what='compute_body_intersection_loss grad')
+    # a larger ragged batch (more partner points than one LDS sweep holds) against the oracle port
+    sizes2 = [(300, 1100), (1, 1), (257, 40)]
+    g2 = G.batch_pairs(synthetic.make_pairs(sizes2, 4)).to(dev)
+    gen = torch.Generator().manual_seed(5)
+    preds = [torch.randn(nl, 3, generator=gen) * 8 for nl, _ in sizes2]
+    tgts = [a + torch.randn(a.shape, generator=gen) for a in preds]
+    recs = [torch.randn(nr, 3, generator=gen) * 9 + 3 for _, nr in sizes2]
+    pd = torch.cat(preds).to(dev).requires_grad_(True)
+    mse2, inter2 = losses.pair_losses(g2, pd, torch.cat(tgts).to(dev), torch.cat(recs).to(dev), sigma, ct)
+    (mse2.sum() + inter2.sum()).backward()
+    leaves = [a.clone().requires_grad_(True) for a in preds]
+    m_ref, i_ref = lp.pair_losses(leaves, tgts, recs, sigma, ct)
+    (m_ref.sum() + i_ref.sum()).backward()
+    close(mse2, m_ref, tol=1e-5, what='mse, large batch')
+    close(inter2, i_ref, tol=1e-5, what='intersection, large batch')
+    close(pd.grad, torch.cat([a.grad for a in leaves]), tol=1e-5, what='d lig_pred, large batch')

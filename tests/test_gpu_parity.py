@@ -111,6 +111,11 @@ def test_model_vs_oracle_ragged(dev):
     pc.check_model_vs_oracle_ragged(dev, sizes=((129, 257), (300, 31), (64, 64), (95, 200)), layers=3, seed=10)
 
 
+def test_pair_losses(dev):
+    from tests import parity_common as pc
+    pc.check_pair_losses(dev)
+
+
 def test_properties_small(dev):
     from tests import parity_common as pc
     pc.check_properties(dev)

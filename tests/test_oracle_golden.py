@@ -64,3 +64,25 @@ def test_reference_invariants():
         np.testing.assert_allclose(t @ t.T, np.eye(3), atol=1e-5)
         assert abs(np.linalg.det(t) - 1.0) < 1e-5
     assert z['out_b'].shape == (len(raw['lig_counts']), 3)
+
+
+def test_loss_port_matches_reference_vectors():
+    """oracle/loss_port.py against the numbers recorded from the reference's own G_fn / compute_body_intersection_loss /
+    compute_sq_dist_mat / nn.MSELoss (tests/golden/loss_case.npz, oracle/make_golden_loss.py)"""
+    import os
+    import numpy as np
+    import torch
+    from oracle import loss_port as lp
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'loss_case.npz'))
+    sigma, ct = float(z['sigma']), float(z['surface_ct'])
+    for p in range(len(z['sizes'])):
+        a = torch.tensor(z[f'pred{p}'], requires_grad=True)
+        t, r = torch.tensor(z[f'tgt{p}']), torch.tensor(z[f'rec{p}'])
+        mse, inter = lp.mse_loss(a, t), lp.body_intersection_loss(a, r, sigma, ct)
+        (gm,) = torch.autograd.grad(mse, a, retain_graph=True)
+        (gi,) = torch.autograd.grad(inter, a)
+        assert abs(float(mse) - float(z[f'mse{p}'])) <= 1e-6 * max(1.0, abs(float(mse)))
+        assert abs(float(inter) - float(z[f'inter{p}'])) <= 1e-6 * max(1.0, abs(float(inter)))
+        assert np.allclose(gm.numpy(), z[f'dmse{p}'], atol=1e-6) and np.allclose(gi.numpy(), z[f'dinter{p}'], atol=1e-6)
+        nl = a.shape[0]
+        assert np.allclose(lp.sq_dist_mat(t[: min(nl, 20)], torch.tensor(z[f'kp{p}'])).numpy(), z[f'sq{p}'], rtol=1e-6, atol=1e-5)

@@ -92,6 +92,10 @@ def test_model_vs_oracle_ragged():
     pc.check_model_vs_oracle_ragged(DEV, sizes=((4, 4), (17, 5), (33, 64)))
 
 
+def test_pair_losses():
+    pc.check_pair_losses(DEV)
+
+
 def test_properties():
     pc.check_properties(DEV, sizes=((30, 41), (52, 27)), layers=2)
 
