@@ -9,6 +9,10 @@ from equidock_public_amd import graph as G, synthetic
 
 dev = torch.device('cuda:0')
 torch.zeros(1, device=dev)
+# a DataLoader worker runs with ONE intra-op thread (torch sets that in every worker); with the main process' default
+# (all cores of the box) the dozens of tiny host-side torch.cat calls of a collate spend their time in the thread pool
+torch.set_num_threads(int(os.environ.get('EQD_COLLATE_THREADS', '1')))
+print('intra-op threads', torch.get_num_threads())
 for name, sizes in (('B: 8 x (200,200)', [(200, 200)] * 8), ('C: 64 x (300,300)', [(300, 300)] * 64)):
     pairs = synthetic.make_pairs(sizes, 1)
     n = 10
