@@ -706,7 +706,10 @@ static int atb_next_batch(std::vector<AtbUnit>& units, size_t first, long long* 
         if (clash) break;
         ++n;
     }
-    int per = (ATB_TARGET_WGS + n - 1) / (n > 0 ? n : 1);
+    // ~1024 workgroups per launch; twice that once a unit has more 64-row chunks than that leaves it (config C: +1 %)
+    int target = ATB_TARGET_WGS;
+    if (!getenv("EQD_ATB_WGS") && n > 0 && units[first].nchunks > 8 * (target / n)) target *= 2;
+    int per = (target + n - 1) / (n > 0 ? n : 1);
     per = per > ATB_MAXBLOCKS ? ATB_MAXBLOCKS : per;
     long long off = 0;
     for (int i = 0; i < n; ++i) {
