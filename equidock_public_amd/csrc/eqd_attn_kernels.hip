@@ -192,8 +192,7 @@ __device__ __forceinline__ void zero_fill(float* __restrict__ L, int n, int t, i
 // NB = 2: one workgroup per work item (a block of up to 32 rows).  NB = 1: TWO workgroups per item, 16 rows each - for
 // small batches, whose 32-row blocks do not give every CU a workgroup (DB5.5: 112 items, 256 CUs): twice the workgroups
 // with half the matrix work and the same loads each; the arithmetic of a row is unchanged (its keys are split over the
-// waves and merged in the same order).  Only the forward: the merged backward launch already has two workgroups per
-// item and 120 KB of LDS each, so halving its blocks makes it a second round of workgroups (measured: 21.5 -> 24 us).
+// waves and merged in the same order).  (The backward uses half blocks for another reason: k_attn_bwd.)
 template <int DB, bool FAST, int NB>
 __global__ __launch_bounds__(EQD_BLOCK) void k_attn_fwd(EqdGraph G, int d, const float* __restrict__ q,
                                                         const float* __restrict__ k, const float* __restrict__ v,
@@ -386,32 +385,45 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_fwd(EqdGraph G, int d, const
 
 // backward pass 1: dq for the block's queries; also writes delta[q] = sum_f dO[q][f] O[q][f]
 // LDS of the backward passes: 2 block tiles + 2 x EQD_WAVES streamed tiles + the merge buffer + 32 floats per wave
-template <int DB>
+// ALIAS (the merged float4 launch): the two block tiles are dead once their fragments sit in registers, so they live in
+// the streamed V / dO tiles of waves 2 and 3 (one barrier before the tile loop), and each wave's part of the merge buffer
+// is its own first streamed tile (written after its last tile, as in the forward): 70 KB instead of 120 KB at d = 64,
+// i.e. TWO workgroups per CU - with one, every LDS-read -> MFMA dependency of the single wave per SIMD is exposed.
+template <int DB, bool ALIAS>
 struct AttnBwdSmem {
     typedef AttnCfg<DB> C;
-    float blk[2][C::TILE];
-    float str[2][EQD_WAVES][C::TILE];
-    float red[EQD_WAVES][C::RED];
+    enum { ALIASED = ALIAS ? 1 : 0 };
+    float str_[2][EQD_WAVES][C::TILE];
+    float blk_[2][ALIAS ? 4 : C::TILE];
+    float red_[EQD_WAVES][ALIAS ? 4 : C::RED];
     float dls[EQD_WAVES][32];
+    static_assert(C::RED <= C::TILE, "merge buffer must fit a streamed tile");
+    __device__ __forceinline__ float* blk(int i) { return ALIAS ? str_[1][2 + i] : blk_[i]; }
+    __device__ __forceinline__ float (*str(int i))[C::TILE] { return str_[i]; }
+    __device__ __forceinline__ float* red(int w) { return ALIAS ? str_[0][w] : red_[w]; }
 };
 
-template <int DB, bool FAST, int NB>
-__device__ __forceinline__ void attn_bwd_q_body(AttnBwdSmem<DB>& sm, const EqdGraph& G, int item, int d,
+template <int DB, bool FAST, int NB, class SM>
+__device__ __forceinline__ void attn_bwd_q_body(SM& sm, const EqdGraph& G, int item, int d,
                                                 const float* __restrict__ q, const float* __restrict__ k,
                                                 const float* __restrict__ v, const float* __restrict__ out,
                                                 const float* __restrict__ lse, const float* __restrict__ d_out,
-                                                float* __restrict__ dq, float* __restrict__ delta) {
+                                                float* __restrict__ dq, float* __restrict__ delta, int half = 0) {
     typedef AttnCfg<DB> C;
     constexpr int DS = C::DS, KS = C::KS;
-    float* Qt = sm.blk[0];
-    float* Gt = sm.blk[1];   // dO rows of the block
-    float (*Kt)[C::TILE] = sm.str[0];
-    float (*Vt)[C::TILE] = sm.str[1];
-    float (*red)[C::RED] = sm.red;
+    float* Qt = sm.blk(0);
+    float* Gt = sm.blk(1);   // dO rows of the block
+    float (*Kt)[C::TILE] = sm.str(0);
+    float (*Vt)[C::TILE] = sm.str(1);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const int b0 = G.att_items[item * 4 + 0], b1 = G.att_items[item * 4 + 1];
+    int b0 = G.att_items[item * 4 + 0], b1 = G.att_items[item * 4 + 1];
     const int o0 = G.att_items[item * 4 + 2], o1 = G.att_items[item * 4 + 3];
+    if (NB == 1) {          // half blocks: rows b0 + 16 half .. of the item (see k_attn_fwd)
+        b0 += 16 * half;
+        b1 = b1 < b0 + 16 ? b1 : b0 + 16;
+        if (b0 >= b1) return;
+    }
     int rowq[NB];
     bool qv[NB];
 #pragma unroll
@@ -485,6 +497,7 @@ __device__ __forceinline__ void attn_bwd_q_body(AttnBwdSmem<DB>& sm, const EqdGr
         dl[nb] = group_sum(dl[nb]);
         if (wave == 0 && g == 0 && qv[nb]) delta[rowq[nb]] = dl[nb];
     }
+    if (SM::ALIASED) __syncthreads();      // every wave has its fragments: the block tiles may be overwritten
     f32x4 dQ[DB][NB];
 #pragma unroll
     for (int db = 0; db < DB; ++db)
@@ -542,12 +555,13 @@ __device__ __forceinline__ void attn_bwd_q_body(AttnBwdSmem<DB>& sm, const EqdGr
                 }
         EQD_TR(34);
     }
+    wave_lds_fence();       // (aliased layout) this wave's reads of its K tile are done before it is overwritten
 #pragma unroll
     for (int db = 0; db < DB; ++db)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) red[wave][((db * 2 + nb) * 4 + r) * 64 + lane] = dQ[db][nb][r];
+            for (int r = 0; r < 4; ++r) sm.red(wave)[((db * 2 + nb) * 4 + r) * 64 + lane] = dQ[db][nb][r];
     __syncthreads();
     for (int db = wave; db < DB; db += EQD_WAVES)
 #pragma unroll
@@ -557,7 +571,7 @@ __device__ __forceinline__ void attn_bwd_q_body(AttnBwdSmem<DB>& sm, const EqdGr
             for (int r = 0; r < 4; ++r) {
                 const int o = ((db * 2 + nb) * 4 + r) * 64 + lane;
                 const int f = 16 * db + 4 * g + r;
-                if (f < d) dq[(size_t)rowq[nb] * d + f] = red[0][o] + red[1][o] + red[2][o] + red[3][o];
+                if (f < d) dq[(size_t)rowq[nb] * d + f] = sm.red(0)[o] + sm.red(1)[o] + sm.red(2)[o] + sm.red(3)[o];
             }
         }
 }
@@ -565,25 +579,29 @@ __device__ __forceinline__ void attn_bwd_q_body(AttnBwdSmem<DB>& sm, const EqdGr
 // backward pass 2: dk, dv for the block's keys (queries = the partner protein).
 // OWN_DELTA (float4 path only): delta = rowsum(dO * O) of each streamed query tile is recomputed here from the
 // O tile instead of being read from pass 1's output, so that both passes can run in ONE launch.
-template <int DB, bool FAST, bool OWN_DELTA, int NB>
-__device__ __forceinline__ void attn_bwd_kv_body(AttnBwdSmem<DB>& sm, const EqdGraph& G, int item, int d,
+template <int DB, bool FAST, bool OWN_DELTA, int NB, class SM>
+__device__ __forceinline__ void attn_bwd_kv_body(SM& sm, const EqdGraph& G, int item, int d,
                                                  const float* __restrict__ q, const float* __restrict__ k,
                                                  const float* __restrict__ v, const float* __restrict__ out,
                                                  const float* __restrict__ lse, const float* __restrict__ d_out,
                                                  const float* __restrict__ delta, float* __restrict__ dk,
-                                                 float* __restrict__ dv) {
+                                                 float* __restrict__ dv, int half = 0) {
     static_assert(FAST || !OWN_DELTA, "OWN_DELTA needs the float4 tile layout");
     typedef AttnCfg<DB> C;
     constexpr int DS = C::DS, KS = C::KS;
-    float* Kb = sm.blk[0];   // the block's own key / value rows
-    float* Vb = sm.blk[1];
-    float (*Qt)[C::TILE] = sm.str[0];   // streamed query / dO tiles
-    float (*Gt)[C::TILE] = sm.str[1];
-    float (*red)[C::RED] = sm.red;
+    float* Kb = sm.blk(0);   // the block's own key / value rows
+    float* Vb = sm.blk(1);
+    float (*Qt)[C::TILE] = sm.str(0);   // streamed query / dO tiles
+    float (*Gt)[C::TILE] = sm.str(1);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const int b0 = G.att_items[item * 4 + 0], b1 = G.att_items[item * 4 + 1];
+    int b0 = G.att_items[item * 4 + 0], b1 = G.att_items[item * 4 + 1];
     const int o0 = G.att_items[item * 4 + 2], o1 = G.att_items[item * 4 + 3];
+    if (NB == 1) {
+        b0 += 16 * half;
+        b1 = b1 < b0 + 16 ? b1 : b0 + 16;
+        if (b0 >= b1) return;
+    }
     int rowk[NB];
     bool kvd[NB];
 #pragma unroll
@@ -630,6 +648,7 @@ __device__ __forceinline__ void attn_bwd_kv_body(AttnBwdSmem<DB>& sm, const EqdG
             kf[nb][ks] = Kb[(16 * nb + l15) * DS + 4 * ks + g];
             vf[nb][ks] = Vb[(16 * nb + l15) * DS + 4 * ks + g];
         }
+    if (SM::ALIASED) __syncthreads();      // every wave has its fragments: the block tiles may be overwritten
     f32x4 dK[DB][NB], dV[DB][NB];
 #pragma unroll
     for (int db = 0; db < DB; ++db)
@@ -734,6 +753,7 @@ __device__ __forceinline__ void attn_bwd_kv_body(AttnBwdSmem<DB>& sm, const EqdG
                     }
                 }
     }
+    wave_lds_fence();       // (aliased layout) this wave's reads of its query tile are done before it is overwritten
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {     // dK then dV through the same LDS buffer
         if (pass) __syncthreads();
@@ -743,7 +763,7 @@ __device__ __forceinline__ void attn_bwd_kv_body(AttnBwdSmem<DB>& sm, const EqdG
             for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    red[wave][((db * 2 + nb) * 4 + r) * 64 + lane] = pass ? dV[db][nb][r] : dK[db][nb][r];
+                    sm.red(wave)[((db * 2 + nb) * 4 + r) * 64 + lane] = pass ? dV[db][nb][r] : dK[db][nb][r];
         __syncthreads();
         float* __restrict__ dst = pass ? dv : dk;
         for (int db = wave; db < DB; db += EQD_WAVES)
@@ -754,7 +774,7 @@ __device__ __forceinline__ void attn_bwd_kv_body(AttnBwdSmem<DB>& sm, const EqdG
                 for (int r = 0; r < 4; ++r) {
                     const int o = ((db * 2 + nb) * 4 + r) * 64 + lane;
                     const int f = 16 * db + 4 * g + r;
-                    if (f < d) dst[(size_t)rowk[nb] * d + f] = red[0][o] + red[1][o] + red[2][o] + red[3][o];
+                    if (f < d) dst[(size_t)rowk[nb] * d + f] = sm.red(0)[o] + sm.red(1)[o] + sm.red(2)[o] + sm.red(3)[o];
                 }
             }
     }
@@ -767,7 +787,7 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd_q(EqdGraph G, int d, con
                                                           const float* __restrict__ lse,
                                                           const float* __restrict__ d_out, float* __restrict__ dq,
                                                           float* __restrict__ delta) {
-    __shared__ __attribute__((aligned(16))) AttnBwdSmem<DB> sm;
+    __shared__ __attribute__((aligned(16))) AttnBwdSmem<DB, false> sm;
     attn_bwd_q_body<DB, FAST, NB>(sm, G, blockIdx.x, d, q, k, v, out, lse, d_out, dq, delta);
 }
 template <int DB, bool FAST, int NB>
@@ -777,23 +797,28 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd_kv(EqdGraph G, int d, co
                                                            const float* __restrict__ d_out,
                                                            const float* __restrict__ delta, float* __restrict__ dk,
                                                            float* __restrict__ dv) {
-    __shared__ __attribute__((aligned(16))) AttnBwdSmem<DB> sm;
+    __shared__ __attribute__((aligned(16))) AttnBwdSmem<DB, false> sm;
     attn_bwd_kv_body<DB, FAST, false, NB>(sm, G, blockIdx.x, d, q, k, v, nullptr, lse, d_out, delta, dk, dv);
 }
 // both passes in one launch (float4 path): workgroups [0, n_items) run pass 1, [n_items, 2 n_items) pass 2
+// NB = 1: two workgroups per item and pass (16-row half blocks); with half the accumulators the kernel fits 256
+// registers, i.e. with its 70 KB of LDS two workgroups share a CU (NB = 2 needs 371 registers: one wave per SIMD)
 template <int DB, int NB>
-__global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd(EqdGraph G, int d, const float* __restrict__ q,
+__global__ __launch_bounds__(EQD_BLOCK, NB == 1 ? 2 : 1) void k_attn_bwd(EqdGraph G, int d, const float* __restrict__ q,
                                                         const float* __restrict__ k, const float* __restrict__ v,
                                                         const float* __restrict__ out, const float* __restrict__ lse,
                                                         const float* __restrict__ d_out, float* __restrict__ dq,
                                                         float* __restrict__ dk, float* __restrict__ dv,
                                                         float* __restrict__ delta) {
-    __shared__ __attribute__((aligned(16))) AttnBwdSmem<DB> sm;
-    const int item = blockIdx.x;
-    if (item < G.n_att_items)
-        attn_bwd_q_body<DB, true, NB>(sm, G, item, d, q, k, v, out, lse, d_out, dq, delta);
+    __shared__ __attribute__((aligned(16))) AttnBwdSmem<DB, true> sm;
+    const int per = NB == 1 ? 2 * G.n_att_items : G.n_att_items;      // workgroups per pass
+    const bool kv = (int)blockIdx.x >= per;
+    const int idx = kv ? (int)blockIdx.x - per : (int)blockIdx.x;
+    const int item = NB == 1 ? idx >> 1 : idx, half = NB == 1 ? idx & 1 : 0;
+    if (!kv)
+        attn_bwd_q_body<DB, true, NB>(sm, G, item, d, q, k, v, out, lse, d_out, dq, delta, half);
     else
-        attn_bwd_kv_body<DB, true, true, NB>(sm, G, item - G.n_att_items, d, q, k, v, out, lse, d_out, nullptr, dk, dv);
+        attn_bwd_kv_body<DB, true, true, NB>(sm, G, item, d, q, k, v, out, lse, d_out, nullptr, dk, dv, half);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -811,8 +836,8 @@ static int attn_launch_bwd(const EqdGraph* g, int d, const float* q, const float
                            const float* lse, const float* d_out, float* dq, float* dk, float* dv, float* delta,
                            hipStream_t st) {
     if constexpr (FAST) if (aligned16(out)) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd<DB, NB>), dim3(2 * g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, d, q,
-                           k, v, out, lse, d_out, dq, dk, dv, delta);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd<DB, NB>), dim3((NB == 1 ? 4 : 2) * g->n_att_items), dim3(EQD_BLOCK), 0,
+                           st, *g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta);
         return eqd_check_launch("k_attn_bwd");
     }
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_q<DB, FAST, NB>), dim3(g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, d,
@@ -866,6 +891,11 @@ extern "C" int eqd_cross_attention_bwd(const EqdGraph* g, int d, const float* q,
     if (g->n_att_items <= 0) return EQD_OK;
     hipStream_t st = (hipStream_t)stream;
     const bool al = aligned16(q) && aligned16(k) && aligned16(v) && aligned16(d_out) && aligned16(out);
+    // d = 64: half blocks (two workgroups per CU, see k_attn_bwd) - config C +2.3 %, E +0.9 %, B unchanged;
+    // EQD_ATT_BWD_SPLIT=0 keeps 32-row blocks (tests)
+    const char* hb = getenv("EQD_ATT_BWD_SPLIT");
+    const bool half = !(hb && hb[0] == '0' && hb[1] == 0);
+    if (d == 64 && al && half) return attn_launch_bwd<4, true, 1>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
     if (d == 64 && al) return attn_launch_bwd<4, true, 2>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
     if (d == 80 && al) return attn_launch_bwd<5, true, 2>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
     if (d <= 64) return attn_launch_bwd<4, false, 2>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);

@@ -46,10 +46,11 @@ def test_cross_attention(dev, d):
 
 @pytest.mark.parametrize('split', ['0', '1'])
 def test_attention_half_blocks(dev, split, monkeypatch):
-    """forward attention with one or two workgroups per 32-row work item (EQD_ATT_SPLIT) on the float4 paths, and a
-    whole model without the split (small batches default to it)"""
+    """attention with one or two workgroups per 32-row work item (EQD_ATT_SPLIT forward, EQD_ATT_BWD_SPLIT backward)
+    on the float4 paths, and a whole model without the splits (the defaults use them)"""
     from tests import parity_common as pc
     monkeypatch.setenv('EQD_ATT_SPLIT', split)
+    monkeypatch.setenv('EQD_ATT_BWD_SPLIT', split)
     pc.check_attention(dev, 64)
     pc.check_attention(dev, 80, sizes=((300, 257), (129, 64)))
     if split == '0':

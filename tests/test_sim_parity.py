@@ -44,9 +44,10 @@ def test_cross_attention(d):
 
 @pytest.mark.parametrize('split', ['0', '1'])
 def test_attention_half_blocks(split, monkeypatch):
-    """forward attention with one or two workgroups per 32-row work item (EQD_ATT_SPLIT) on the float4 paths, and a
-    whole model without the split (small batches default to it)"""
+    """attention with one or two workgroups per 32-row work item (EQD_ATT_SPLIT forward, EQD_ATT_BWD_SPLIT backward)
+    on the float4 paths, and a whole model without the splits (the defaults use them)"""
     monkeypatch.setenv('EQD_ATT_SPLIT', split)
+    monkeypatch.setenv('EQD_ATT_BWD_SPLIT', split)
     pc.check_attention(DEV, 64)
     pc.check_attention(DEV, 80, sizes=((300, 257), (129, 64)))
     if split == '0':
