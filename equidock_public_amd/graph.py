@@ -102,6 +102,19 @@ class PairGraph:
             self._packed = self._packed.to(device)
         return self
 
+    def pin_memory(self):
+        """Called by torch.utils.data.DataLoader(pin_memory=True) on the collated batch (in its pin thread): after it,
+        .to('cuda') is a handful of asynchronous copies from page-locked memory."""
+        for store in list(self._ndata.values()) + list(self._edata.values()):
+            for k in list(store):
+                if store[k].device.type == 'cpu':
+                    store[k] = store[k].pin_memory()
+        self._edges = {k: (s.pin_memory() if s.device.type == 'cpu' else s, d.pin_memory() if d.device.type == 'cpu' else d)
+                       for k, (s, d) in self._edges.items()}
+        if self._packed is not None:
+            self._packed.pin_memory()
+        return self
+
     # ---- packing for the HIP path ---------------------------------------------------------------
     def pack(self):
         """Device-resident kernel layout (topology cached; coordinates re-read every call)."""
@@ -317,40 +330,81 @@ class PackedGraph:
         p.device = dev
         p.lig_counts = list(g._batch_nodes['ligand'])
         p.rec_counts = list(g._batch_nodes['receptor'])
-        return p
+        p._flats = None
+        return p.consolidate()
 
     def refresh_coords(self, g):
         self.x0 = torch.cat([g._ndata['ligand']['new_x'], g._ndata['receptor']['x']], 0) \
             .to(torch.float32).contiguous()
 
-    def to(self, device):
-        """Move the layout to `device`.  All tensors of one dtype travel as ONE buffer (64-byte aligned slices; pinned
-        staging when the source is host memory and the target a GPU), so a batch that was packed in a DataLoader worker
-        (collate_fn: batch_pairs(...).pack()) costs a handful of H->D copies instead of one per field."""
-        device = torch.device(device)
-        items = [(k, v) for k, v in self.__dict__.items() if torch.is_tensor(v)]
+    def _tensor_items(self):
+        return [(k, v) for k, v in self.__dict__.items() if torch.is_tensor(v) and k != 'x0']
+
+    def consolidate(self):
+        """Re-home every tensor of the layout as a 64-byte aligned slice of ONE buffer per dtype (done once, where the
+        layout is built - e.g. in a DataLoader worker), so that pinning and the H->D move are one copy per dtype with no
+        re-staging on the consumer's side."""
+        items = self._tensor_items()
+        if not items or any(v.device != items[0][1].device for _, v in items):
+            return self
         by_dtype = {}
         for k, v in items:
             by_dtype.setdefault(v.dtype, []).append((k, v))
+        flats = {}
         for dt, group in by_dtype.items():
-            if len(group) == 1 or any(v.device != group[0][1].device for _, v in group):
-                for k, v in group:
-                    setattr(self, k, v.to(device))
-                continue
             esz = group[0][1].element_size()
             align = max(1, 64 // esz)
             offs, total = [], 0
             for _, v in group:
                 offs.append(total)
                 total += (v.numel() + align - 1) // align * align
-            flat = torch.empty(total, dtype=dt, device=group[0][1].device)
+            flat = torch.empty(max(total, 1), dtype=dt, device=group[0][1].device)
+            layout = []
             for (k, v), o in zip(group, offs):
                 flat[o:o + v.numel()] = v.reshape(-1)
-            if device.type == 'cuda' and flat.device.type == 'cpu':
-                flat = flat.pin_memory()
-            flat = flat.to(device, non_blocking=True)
-            for (k, v), o in zip(group, offs):
                 setattr(self, k, flat[o:o + v.numel()].view(v.shape))
+                layout.append((k, o, tuple(v.shape)))
+            flats[dt] = (flat, layout)
+        self._flats = flats
+        return self
+
+    def _rebind(self, moved):
+        for dt, (flat, layout) in moved.items():
+            for k, o, shape in layout:
+                n = 1
+                for d in shape:
+                    n *= d
+                setattr(self, k, flat[o:o + n].view(shape))
+        self._flats = moved
+        self._cstruct = None
+
+    def pin_memory(self):
+        """torch.utils.data.DataLoader(pin_memory=True) calls this on custom batch objects (in its pin thread)."""
+        if getattr(self, '_flats', None) is None:
+            self.consolidate()
+        if getattr(self, '_flats', None) is not None and self.he.device.type == 'cpu':
+            self._rebind({dt: (flat.pin_memory(), layout) for dt, (flat, layout) in self._flats.items()})
+        return self
+
+    def to(self, device):
+        """Move the layout to `device`: one copy per dtype (see consolidate; pinned staging when the source is pageable
+        host memory and the target a GPU), so a batch that was packed in a DataLoader worker (collate_fn:
+        batch_pairs(...).pack()) costs three H->D copies instead of one per field."""
+        device = torch.device(device)
+        if getattr(self, '_flats', None) is None:
+            self.consolidate()
+        if getattr(self, '_flats', None) is not None:
+            moved = {}
+            for dt, (flat, layout) in self._flats.items():
+                if device.type == 'cuda' and flat.device.type == 'cpu' and not flat.is_pinned():
+                    flat = flat.pin_memory()
+                moved[dt] = (flat.to(device, non_blocking=True), layout)
+            self._rebind(moved)
+        else:
+            for k, v in self._tensor_items():
+                setattr(self, k, v.to(device))
+        if self.x0 is not None:
+            self.x0 = self.x0.to(device)
         self.device = device
         self._cstruct = None
         return self

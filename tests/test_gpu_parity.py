@@ -199,6 +199,22 @@ def test_pack_on_host_then_move(dev):
         b = net.forward_batched(G.batch_pairs(pairs).to(dev))
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+    # through a DataLoader: collate_fn builds and packs the batch, pin_memory=True pins its per-dtype buffers
+    # (PairGraph.pin_memory), .to() is then asynchronous copies from page-locked memory
+    from torch.utils.data import DataLoader
+
+    def collate(items):
+        gb = G.batch_pairs(items)
+        gb.pack()
+        return gb
+    for workers in (0, 2):
+        dl = DataLoader(pairs + pairs, batch_size=3, shuffle=False, collate_fn=collate, pin_memory=True, num_workers=workers)
+        batches = list(dl)
+        assert len(batches) == 2 and batches[0].pack().he.is_pinned()
+        with torch.no_grad():
+            c = net.forward_batched(batches[1].to(dev))
+        for x, y in zip(a, c):
+            assert torch.equal(x, y)
 
 
 def test_large_complex_runs(dev):
