@@ -44,7 +44,24 @@ def build(force=False, verbose=True):
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
         run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs)
+    build_host(force, verbose)
     return LIB
+
+
+HOST_LIB = os.path.join(HERE, 'libequidock_host.so')
+
+
+def build_host(force=False, verbose=True):
+    """libequidock_host.so: host-only helpers for DataLoader workers (csrc_host/, plain g++, no HIP runtime)."""
+    srcs = sorted(glob.glob(os.path.join(HERE, 'csrc_host', '*.cpp')))
+    if force or _stale(HOST_LIB, srcs):
+        cmd = [os.environ.get('CXX', 'g++'), '-O2', '-std=c++17', '-fPIC', '-shared', '-Wall', '-o', HOST_LIB] + srcs
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"g++ failed:\n{r.stdout}\n{r.stderr}")
+    return HOST_LIB
 
 
 if __name__ == '__main__':

@@ -1,0 +1,167 @@
+// Host-side (no GPU, no HIP) construction of the kernel layout of a batch of protein pairs: what
+// equidock_public_amd/graph.py:PackedGraph.build computes with ~60 numpy calls, as one pass of plain loops for the
+// DataLoader workers (the reference spends this time in per-pair DGL heterograph
+// construction and dgl.batch, src/utils/train_utils.py:61-108).  Results are bit-identical to the numpy path
+// (tests/test_abi_and_graph.py::test_native_pack_equals_numpy_pack); that path stays as the fallback when this
+// library has not been built.
+//
+//   edges of each type arrive in block-local node ids; ligand nodes are global ids [0, n_lig), receptor nodes
+//   [n_lig, n_lig + n_rec); edges are stably sorted by destination if they are not already; he rows follow.
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+extern "C" {
+
+enum { EQDH_OK = 0, EQDH_ERR_DEGREE = 1, EQDH_ERR_RANGE = 2, EQDH_ERR_SPACE = 3 };
+
+struct EqdHostPackIn {
+    int32_t n_pairs, n_lig, n_rec;
+    const int64_t* lig_counts;   // [n_pairs]
+    const int64_t* rec_counts;   // [n_pairs]
+    int64_t e_ll, e_rr;
+    const int32_t *src_ll, *dst_ll, *src_rr, *dst_rr;   // block-local ids
+    const float *he_ll, *he_rr;                         // [e][27]
+    int32_t tile_edges, tile_nodes, att_block;
+};
+struct EqdHostPackOut {
+    // caller-allocated: int32 [n_pairs+1] x2, [E] x3 (src, dst, csc_eid), [N+1] x2, [N+2] tile_node, [items_cap][4],
+    // [2 n_pairs + 1] seg_off; int64 [E] edge_perm; float [E][27] he; uint16 [max(E,1)][32] he_bf16
+    int32_t *lig_off, *rec_off, *src, *dst, *rowptr, *csc_ptr, *csc_eid, *tile_node, *att_items, *seg_off;
+    int64_t* edge_perm;
+    float* he;
+    uint16_t* he_bf16;
+    int32_t items_cap;
+    int32_t n_tiles, n_att_items, max_seg, max_degree;   // results
+};
+
+static inline uint16_t f2bf_rne(float f) {      // round to nearest even, like torch's float -> bfloat16
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);    // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+int eqd_host_pack(const EqdHostPackIn* in, EqdHostPackOut* out) {
+    const int B = in->n_pairs, nl = in->n_lig, nr = in->n_rec, n = nl + nr;
+    const int64_t E = in->e_ll + in->e_rr;
+    // per-pair offsets and segments (B ligand segments, then B receptor segments, global ids)
+    out->lig_off[0] = out->rec_off[0] = 0;
+    int max_seg = 0;
+    for (int b = 0; b < B; ++b) {
+        out->lig_off[b + 1] = out->lig_off[b] + (int32_t)in->lig_counts[b];
+        out->rec_off[b + 1] = out->rec_off[b] + (int32_t)in->rec_counts[b];
+        max_seg = std::max<int>(max_seg, (int)std::max(in->lig_counts[b], in->rec_counts[b]));
+    }
+    if (out->lig_off[B] != nl || out->rec_off[B] != nr) return EQDH_ERR_RANGE;
+    for (int b = 0; b < B; ++b) {
+        out->seg_off[b] = out->lig_off[b];
+        out->seg_off[B + b] = nl + out->rec_off[b];
+    }
+    out->seg_off[2 * B] = nl + nr;
+    out->max_seg = max_seg;
+
+    // edges: per type a stable sort by destination (identity when already sorted), then global ids
+    int64_t eoff = 0;
+    const int32_t* srcs[2] = {in->src_ll, in->src_rr};
+    const int32_t* dsts[2] = {in->dst_ll, in->dst_rr};
+    const int64_t es[2] = {in->e_ll, in->e_rr};
+    const int bases[2] = {0, nl}, counts[2] = {nl, nr};
+    std::vector<int64_t> perm;
+    for (int t = 0; t < 2; ++t) {
+        const int64_t e = es[t];
+        const int32_t *s = srcs[t], *d = dsts[t];
+        bool sorted = true;
+        for (int64_t i = 0; i < e; ++i) {
+            if (s[i] < 0 || d[i] < 0 || s[i] >= counts[t] || d[i] >= counts[t]) return EQDH_ERR_RANGE;
+            if (i && d[i] < d[i - 1]) sorted = false;
+        }
+        perm.resize((size_t)e);
+        std::iota(perm.begin(), perm.end(), (int64_t)0);
+        if (!sorted) std::stable_sort(perm.begin(), perm.end(), [d](int64_t a, int64_t b) { return d[a] < d[b]; });
+        for (int64_t i = 0; i < e; ++i) {
+            out->src[eoff + i] = s[perm[(size_t)i]] + bases[t];
+            out->dst[eoff + i] = d[perm[(size_t)i]] + bases[t];
+            out->edge_perm[eoff + i] = perm[(size_t)i] + eoff;
+        }
+        eoff += e;
+    }
+    // CSR by destination, CSC (stable by source) as edge ids
+    std::vector<int64_t> deg((size_t)n + 1, 0), sdeg((size_t)n + 1, 0);
+    for (int64_t i = 0; i < E; ++i) {
+        ++deg[(size_t)out->dst[i]];
+        ++sdeg[(size_t)out->src[i]];
+    }
+    int maxdeg = 0;
+    out->rowptr[0] = out->csc_ptr[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        maxdeg = std::max<int>(maxdeg, (int)deg[(size_t)i]);
+        out->rowptr[i + 1] = out->rowptr[i] + (int32_t)deg[(size_t)i];
+        out->csc_ptr[i + 1] = out->csc_ptr[i] + (int32_t)sdeg[(size_t)i];
+    }
+    out->max_degree = maxdeg;
+    if (E && maxdeg > in->tile_edges) return EQDH_ERR_DEGREE;
+    {
+        std::vector<int32_t> cur(out->csc_ptr, out->csc_ptr + n);
+        for (int64_t i = 0; i < E; ++i) out->csc_eid[cur[(size_t)out->src[i]]++] = (int32_t)i;
+    }
+    // node-aligned edge tiles: greedy, a tile takes nodes while it stays within tile_edges edges and tile_nodes nodes
+    int nt = 0;
+    out->tile_node[0] = 0;
+    if (n) {
+        int i = 0;
+        while (i < n) {
+            int j = i;
+            const int64_t e0 = out->rowptr[i];
+            while (j < n && j - i < in->tile_nodes && (int64_t)out->rowptr[j + 1] - e0 <= in->tile_edges) ++j;
+            if (j == i) j = i + 1;
+            i = j;
+            out->tile_node[++nt] = i;
+        }
+    } else {
+        out->tile_node[1] = 0;
+        nt = 1;
+    }
+    out->n_tiles = nt;
+    // attention work list: blocks of att_block nodes x the partner's node range; biggest partner first (stable)
+    struct Item { int32_t v[4]; };
+    std::vector<Item> items;
+    for (int b = 0; b < B; ++b) {
+        const int32_t l0 = out->lig_off[b], l1 = out->lig_off[b + 1];
+        const int32_t r0 = nl + out->rec_off[b], r1 = nl + out->rec_off[b + 1];
+        const int32_t quad[2][4] = {{l0, l1, r0, r1}, {r0, r1, l0, l1}};
+        for (int q = 0; q < 2; ++q)
+            for (int32_t s0 = quad[q][0]; s0 < quad[q][1]; s0 += in->att_block)
+                items.push_back(Item{{s0, std::min<int32_t>(s0 + in->att_block, quad[q][1]), quad[q][2], quad[q][3]}});
+    }
+    std::stable_sort(items.begin(), items.end(),
+                     [](const Item& a, const Item& b) { return (a.v[3] - a.v[2]) > (b.v[3] - b.v[2]); });
+    if ((int64_t)items.size() > out->items_cap) return EQDH_ERR_SPACE;
+    for (size_t i = 0; i < items.size(); ++i) std::memcpy(out->att_items + 4 * i, items[i].v, 16);
+    out->n_att_items = (int32_t)items.size();
+    // edge features in sorted order + bf16 copy (32 columns per edge, 27 used)
+    const float* hes[2] = {in->he_ll, in->he_rr};
+    eoff = 0;
+    if (E == 0) std::memset(out->he_bf16, 0, 64);
+    for (int t = 0; t < 2; ++t) {
+        for (int64_t i = 0; i < es[t]; ++i) {
+            const float* row = hes[t] + (size_t)(out->edge_perm[eoff + i] - eoff) * 27;
+            float* o = out->he + (size_t)(eoff + i) * 27;
+            uint16_t* ob = out->he_bf16 + (size_t)(eoff + i) * 32;
+            for (int c = 0; c < 27; ++c) {
+                o[c] = row[c];
+                ob[c] = f2bf_rne(row[c]);
+            }
+            for (int c = 27; c < 32; ++c) ob[c] = 0;
+        }
+        eoff += es[t];
+    }
+    return EQDH_OK;
+}
+
+int eqd_host_pack_abi(void) { return 1; }
+
+}  // extern "C"

@@ -23,12 +23,50 @@ and, for the HIP path, `PairBatch.pack()` which lays the batch out for the kerne
 
 All index arrays are int32 (graph indexing is bit-exact with the reference's int32 edges).
 """
+import os
+
 import numpy as np
 import torch
 
 TILE_EDGES = 32      # must equal eqd_tile_edges() of the C-ABI library
 TILE_NODES = 32
 ATT_BLOCK = 32
+
+# ---- native host pack (csrc_host/eqd_host_pack.cpp -> libequidock_host.so; plain C++, safe in DataLoader workers) ----
+import ctypes as _C
+
+
+class _HostPackIn(_C.Structure):
+    _fields_ = [('n_pairs', _C.c_int32), ('n_lig', _C.c_int32), ('n_rec', _C.c_int32), ('lig_counts', _C.c_void_p),
+                ('rec_counts', _C.c_void_p), ('e_ll', _C.c_int64), ('e_rr', _C.c_int64), ('src_ll', _C.c_void_p),
+                ('dst_ll', _C.c_void_p), ('src_rr', _C.c_void_p), ('dst_rr', _C.c_void_p), ('he_ll', _C.c_void_p),
+                ('he_rr', _C.c_void_p), ('tile_edges', _C.c_int32), ('tile_nodes', _C.c_int32), ('att_block', _C.c_int32)]
+
+
+class _HostPackOut(_C.Structure):
+    _fields_ = [(k, _C.c_void_p) for k in ('lig_off', 'rec_off', 'src', 'dst', 'rowptr', 'csc_ptr', 'csc_eid', 'tile_node',
+                                           'att_items', 'seg_off', 'edge_perm', 'he', 'he_bf16')] + \
+               [(k, _C.c_int32) for k in ('items_cap', 'n_tiles', 'n_att_items', 'max_seg', 'max_degree')]
+
+
+_host_lib = None
+
+
+def _native():
+    """libequidock_host.so if it has been built (python -m equidock_public_amd.build), else None (numpy path).
+    EQD_NATIVE_PACK=0 forces the numpy path (tests compare the two)."""
+    global _host_lib
+    if os.environ.get('EQD_NATIVE_PACK') == '0':
+        return None
+    if _host_lib is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libequidock_host.so')
+        if not os.path.exists(path):
+            _host_lib = False
+        else:
+            lib = _C.CDLL(path)
+            lib.eqd_host_pack.restype = _C.c_int
+            _host_lib = lib if lib.eqd_host_pack_abi() == 1 else False
+    return _host_lib or None
 
 
 class _DataView:
@@ -240,6 +278,9 @@ class PackedGraph:
         n = nl + nr
         B = g.batch_size
         p.n_pairs, p.n_lig, p.n_rec, p.n_nodes = B, nl, nr, n
+        native = _native() if (dev.type == 'cpu' and n > 0) else None
+        if native is not None:
+            return PackedGraph._build_native(native, g, p)
         lig_off = np.concatenate([[0], np.cumsum(g._batch_nodes['ligand'])]).astype(np.int32)
         rec_off = np.concatenate([[0], np.cumsum(g._batch_nodes['receptor'])]).astype(np.int32)
 
@@ -332,6 +373,84 @@ class PackedGraph:
         p.rec_counts = list(g._batch_nodes['receptor'])
         p._flats = None
         return p.consolidate()
+
+    @staticmethod
+    def _build_native(lib, g, p):
+        """Same layout through libequidock_host.so: one pass of C++ loops straight into the per-dtype buffers that
+        consolidate() would otherwise assemble from ~25 numpy arrays (bit-identical results)."""
+        B, nl, nr = p.n_pairs, p.n_lig, p.n_rec
+        n = nl + nr
+
+        def c32(t):
+            return t.detach().to(torch.int32).contiguous()
+        s_ll, d_ll = (c32(t) for t in g._edges['ll'])
+        s_rr, d_rr = (c32(t) for t in g._edges['rr'])
+        he_ll = g._edata['ll']['he'].detach().to(torch.float32).contiguous()
+        he_rr = g._edata['rr']['he'].detach().to(torch.float32).contiguous()
+        E = s_ll.numel() + s_rr.numel()
+        lc = torch.tensor(list(g._batch_nodes['ligand']), dtype=torch.int64)
+        rc = torch.tensor(list(g._batch_nodes['receptor']), dtype=torch.int64)
+        res = torch.cat([g._ndata['ligand']['res_feat'].view(-1), g._ndata['receptor']['res_feat'].view(-1)]) \
+            .detach().to(torch.int32)
+        if int(res.min()) < 0 or int(res.max()) > 20:
+            raise ValueError("res_feat must hold residue ids 0..20 (nn.Embedding(21, .), rigid_docking_model.py:382)")
+        mu = torch.cat([g._ndata['ligand']['mu_r_norm'], g._ndata['receptor']['mu_r_norm']], 0).to(torch.float32)
+        if float(mu.min()) <= 0.0:
+            raise ValueError("mu_r_norm must be > 0 (the model takes its log, rigid_docking_model.py:469)")
+        items_cap = sum((int(c) + ATT_BLOCK - 1) // ATT_BLOCK for c in list(lc) + list(rc))
+        # per-dtype buffers with 64-byte aligned slices, laid out here and filled by the library
+        spec = {
+            torch.int32: [('lig_off', (B + 1,)), ('rec_off', (B + 1,)), ('src', (E,)), ('dst', (E,)), ('rowptr', (n + 1,)),
+                          ('csc_ptr', (n + 1,)), ('csc_eid', (E,)), ('tile_node', (n + 2,)), ('att_items', (items_cap, 4)),
+                          ('res_id', (n,)), ('seg_off', (2 * B + 1,))],
+            torch.int64: [('edge_perm', (E,))],
+            torch.float32: [('he', (E, 27)), ('mu_r_norm', (n, 5))],
+            torch.int16: [('he_bf16', (max(E, 1), 32))],
+        }
+        flats, views = {}, {}
+        for dt, fields in spec.items():
+            esz = torch.empty(0, dtype=dt).element_size()
+            align = 64 // esz
+            offs, total = [], 0
+            for _, shape in fields:
+                offs.append(total)
+                total += (int(np.prod(shape)) + align - 1) // align * align
+            flat = torch.empty(max(total, 1), dtype=dt)
+            layout = []
+            for (k, shape), o in zip(fields, offs):
+                views[k] = flat[o:o + int(np.prod(shape))].view(shape)
+                layout.append((k, o, tuple(shape)))
+            flats[dt] = (flat, layout)
+        views['res_id'].copy_(res)
+        views['mu_r_norm'].copy_(mu)
+        hin = _HostPackIn(B, nl, nr, lc.data_ptr(), rc.data_ptr(), s_ll.numel(), s_rr.numel(), s_ll.data_ptr(),
+                          d_ll.data_ptr(), s_rr.data_ptr(), d_rr.data_ptr(), he_ll.data_ptr(), he_rr.data_ptr(), TILE_EDGES,
+                          TILE_NODES, ATT_BLOCK)
+        hout = _HostPackOut()
+        for k in ('lig_off', 'rec_off', 'src', 'dst', 'rowptr', 'csc_ptr', 'csc_eid', 'tile_node', 'att_items', 'seg_off',
+                  'edge_perm', 'he', 'he_bf16'):
+            setattr(hout, k, views[k].data_ptr())
+        hout.items_cap = items_cap
+        rc_ = lib.eqd_host_pack(_C.byref(hin), _C.byref(hout))
+        if rc_ == 1:
+            raise ValueError(f"in-degree {hout.max_degree} exceeds the supported maximum of {TILE_EDGES} "
+                             "(the reference caps it at graph_max_neighbor=10, src/utils/args.py:47)")
+        if rc_ != 0:
+            raise ValueError(f"eqd_host_pack failed ({rc_}): edge endpoint out of range or inconsistent pair sizes")
+        p.n_edges, p.n_tiles, p.n_att_items, p.max_seg = E, hout.n_tiles, hout.n_att_items, hout.max_seg
+        # the two lists with data-dependent lengths are shorter than their upper bounds: re-slice the views
+        for k, shape in (('tile_node', (p.n_tiles + 1,)), ('att_items', (p.n_att_items, 4))):
+            views[k] = views[k].reshape(-1)[:int(np.prod(shape))].view(shape)
+        for dt, (flat, layout) in flats.items():
+            flats[dt] = (flat, [(k, o, tuple(views[k].shape)) for k, o, _ in layout])
+        for k, v in views.items():
+            setattr(p, k, v)
+        p.x0 = None
+        p.device = torch.device('cpu')
+        p.lig_counts = list(g._batch_nodes['ligand'])
+        p.rec_counts = list(g._batch_nodes['receptor'])
+        p._flats = flats
+        return p
 
     def refresh_coords(self, g):
         self.x0 = torch.cat([g._ndata['ligand']['new_x'], g._ndata['receptor']['x']], 0) \

@@ -174,3 +174,31 @@ def test_bench_loss_equals_oracle_scalar_loss():
     assert abs(float(a) - float(b)) < 1e-12
     for x, y in zip(ga, gb):
         assert torch.allclose(x, y, atol=1e-13)
+
+
+def test_native_pack_equals_numpy_pack(monkeypatch):
+    """libequidock_host.so (csrc_host/eqd_host_pack.cpp) against the numpy construction of the same layout: bit-exact
+    on every index array, the permuted edge features and their bf16 copy - sorted and unsorted edges, ragged pairs,
+    1-node proteins without edges"""
+    from equidock_public_amd import build as B
+    B.build_host(verbose=False)
+    rng = np.random.default_rng(5)
+    for sizes, shuffle in ((((40, 57), (1, 9), (130, 33)), False), (((64, 64), (17, 5)), True), (((200, 200),) * 3, False)):
+        pairs = synthetic.make_pairs(list(sizes), 7)
+        if shuffle:      # destination-unsorted edges: both paths must sort them stably
+            for lig, rec in pairs:
+                for d in (lig, rec):
+                    perm = rng.permutation(len(d['src']))
+                    d['src'], d['dst'], d['he'] = d['src'][perm], d['dst'][perm], d['he'][perm]
+        monkeypatch.setenv('EQD_NATIVE_PACK', '0')
+        ref = G.batch_pairs(pairs).pack()
+        monkeypatch.delenv('EQD_NATIVE_PACK')
+        G._host_lib = None
+        nat = G.batch_pairs(pairs).pack()
+        assert G._native() is not None, "libequidock_host.so was not loaded"
+        for k in ('n_pairs', 'n_lig', 'n_rec', 'n_nodes', 'n_edges', 'n_tiles', 'n_att_items', 'max_seg'):
+            assert getattr(ref, k) == getattr(nat, k), k
+        for k in G.PackedGraph.INT_FIELDS + ('edge_perm', 'he', 'he_bf16', 'mu_r_norm'):
+            a, b = getattr(ref, k), getattr(nat, k)
+            assert a.dtype == b.dtype and a.shape == b.shape and torch.equal(a, b), k
+            assert b.data_ptr() % 64 == 0, k
