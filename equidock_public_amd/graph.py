@@ -23,6 +23,7 @@ and, for the HIP path, `PairBatch.pack()` which lays the batch out for the kerne
 
 All index arrays are int32 (graph indexing is bit-exact with the reference's int32 edges).
 """
+import ctypes as _C
 import os
 
 import numpy as np
@@ -33,8 +34,6 @@ TILE_NODES = 32
 ATT_BLOCK = 32
 
 # ---- native host pack (csrc_host/eqd_host_pack.cpp -> libequidock_host.so; plain C++, safe in DataLoader workers) ----
-import ctypes as _C
-
 
 class _HostPackIn(_C.Structure):
     _fields_ = [('n_pairs', _C.c_int32), ('n_lig', _C.c_int32), ('n_rec', _C.c_int32), ('lig_counts', _C.c_void_p),
