@@ -476,7 +476,8 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
         const float* const* p = params + (size_t)EQD_PARAMS_PER_LAYER * l;
         const int d = D.d_in(l);
         const LayerSaved& Ls = S.lay[l];
-        EqdLinJob j = lin_job(N, d, dHof(l), d, slope, eps);
+        // dH(0) only feeds the embedding gradient: its node-feature columns (d_emb .. d0 - 1) are not computed
+        EqdLinJob j = lin_job(N, l == 0 ? m->d_emb : d, dHof(l), d, slope, eps);
         int ns = 0;
         lin_src(j, ns++, W.dz_all + l * NS, d, d, p[P_WN1], 1, D.ldwn(l));
         lin_src(j, ns++, W.dP_all + l * NP, 64, 64, p[P_W1], 1, D.ldw1(l));
@@ -556,7 +557,9 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
             };
             dx_job(W.d_aggr_msg, 64, 64, d);
             if (m->cross_msgs) dx_job(W.d_aggr_cross, d, da, d + 64);
-            EqdChainJob& C5 = dx_job(W.dh0acc, D.d0, D.d0, 2 * d + 64);
+            // only the embedding columns of d h0 are ever read (k_embed_bwd: the trailing node features are inputs), so the
+            // job computes m->d_emb of the D.d0 columns: a 64-wide job instead of a 69-wide one (the general body)
+            EqdChainJob& C5 = dx_job(W.dh0acc, m->d_emb, D.d0, 2 * d + 64);
             if (l < D.L - 1) {      // the last layer (processed first) initialises the accumulator
                 C5.lin.R = W.dh0acc; C5.lin.ldr = D.d0; C5.lin.beta = 1.f;
             }
