@@ -452,8 +452,14 @@ class PackedGraph:
         return p
 
     def refresh_coords(self, g):
-        self.x0 = torch.cat([g._ndata['ligand']['new_x'], g._ndata['receptor']['x']], 0) \
-            .to(torch.float32).contiguous()
+        """x0 = [ligand new_x ; receptor x], re-read at every forward (the training loop re-draws new_x per batch); the
+        concatenation is skipped while both tensors are the ones of the last call and were not written to in between."""
+        lx, rx = g._ndata['ligand']['new_x'], g._ndata['receptor']['x']
+        key = (lx.data_ptr(), lx._version, rx.data_ptr(), rx._version, lx.device)
+        if self.x0 is not None and getattr(self, '_x0_key', None) == key:
+            return
+        self.x0 = torch.cat([lx, rx], 0).to(torch.float32).contiguous()
+        self._x0_key = key
 
     def _tensor_items(self):
         return [(k, v) for k, v in self.__dict__.items() if torch.is_tensor(v) and k != 'x0']

@@ -173,8 +173,9 @@ class _IEGMNFunction(torch.autograd.Function):
         lib = _lib.load_library()
         packed, desc = ctx.packed, ctx.desc
         dev = packed.x0.device
-        if packed.x0 is not ctx.x0:
-            packed.x0 = ctx.x0
+        if packed.x0 is not ctx.x0:      # a later forward re-read the coordinates: use this forward's, and make the
+            packed.x0 = ctx.x0           # next forward re-read them again
+            packed._x0_key = None
         gs = packed.c_struct()
         tensors = ctx.tensors
         ptrs = ctx.ptrs

@@ -117,6 +117,11 @@ def test_pair_losses(dev):
     pc.check_pair_losses(dev)
 
 
+def test_coordinates_are_reread(dev):
+    from tests import parity_common as pc
+    pc.check_coords_reread(dev)
+
+
 def test_properties_small(dev):
     from tests import parity_common as pc
     pc.check_properties(dev)

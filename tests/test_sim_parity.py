@@ -97,6 +97,10 @@ def test_pair_losses():
     pc.check_pair_losses(DEV)
 
 
+def test_coordinates_are_reread():
+    pc.check_coords_reread(DEV)
+
+
 def test_properties():
     pc.check_properties(DEV, sizes=((30, 41), (52, 27)), layers=2)
 
