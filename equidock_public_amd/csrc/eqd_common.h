@@ -281,10 +281,10 @@ int eqd_keypoint_pool_fwd_impl(const EqdGraph* g, int n_heads, const float* Wk, 
                                float* scores, float* lse, float* qp, float* u, hipStream_t st);
 int eqd_kabsch_fwd_impl(int n_pairs, int n_heads, const float* Y, const float* svd_draws, int svd_seed, float* T,
                         float* T2, float* b, float* A_out, int32_t* status, hipStream_t st, const EqdGraph* g = nullptr,
-                        float* lig_out = nullptr);
+                        float* lig_out = nullptr, double* usv = nullptr);
 int eqd_kabsch_bwd_impl(int n_pairs, int n_heads, const float* Y, const float* A, const float* T, const float* dT,
                         const float* db, const float* dYl_ext, const float* dYr_ext, float* dY, hipStream_t st,
-                        const EqdGraph* g = nullptr, const float* d_lig = nullptr);
+                        const EqdGraph* g = nullptr, const float* d_lig = nullptr, const double* usv = nullptr);
 int eqd_rigid_apply_bwd_impl(const EqdGraph* g, const float* d_lig, const float* dT_ext, const float* db_ext, float* dT,
                              float* db, hipStream_t st);
 size_t eqd_ln_act_bwd_partial_floats(int rows, int d);

@@ -48,6 +48,7 @@ struct Saved {
     float* x[64 + 1];
     LayerSaved lay[64];
     float *hm, *qmean, *qp, *u, *scores, *klse, *Y, *A, *T;
+    double* usv;     // [B][21] U, S, V of the Kabsch SVD (fp64), reused by the backward
 };
 
 void carve_saved(const Dims& D, const EqdGraph* g, EqdArena& A, Saved& S) {
@@ -79,6 +80,7 @@ void carve_saved(const Dims& D, const EqdGraph* g, EqdArena& A, Saved& S) {
     S.klse = A.take<float>((size_t)2 * D.B * D.K);
     S.Y = A.take<float>((size_t)2 * D.B * D.K * 3);
     S.A = A.take<float>((size_t)D.B * 9);
+    S.usv = A.take<double>((size_t)D.B * 21);
     S.T = A.take<float>((size_t)D.B * 9);
 }
 
@@ -409,7 +411,8 @@ extern "C" int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const
     RC(eqd_launch_seg_mean(g, S.hm, S.qmean, st));
     RC(eqd_keypoint_pool_fwd_impl(g, D.K, gp[G_WK], gp[G_WQ], S.qmean, H, Z, S.Y, Y_lig, Y_rec, S.scores, S.klse, S.qp,
                                   S.u, st));
-    RC(eqd_kabsch_fwd_impl(D.B, D.K, S.Y, svd_draws, m->svd_seed, S.T, T, b, S.A, svd_status, st, g, lig_out));   // + rigid apply
+    RC(eqd_kabsch_fwd_impl(D.B, D.K, S.Y, svd_draws, m->svd_seed, S.T, T, b, S.A, svd_status, st, g, lig_out,
+                           S.usv));   // + rigid apply
     return EQD_OK;
 }
 
@@ -450,7 +453,7 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
         EqdRedList* p;
         ~DeferGuard() { delete p; }
     } defer_guard{defer};
-    RC(eqd_kabsch_bwd_impl(B, K, S.Y, S.A, S.T, d_T, d_b, d_Ylig, d_Yrec, W.dY, st, g, d_lig));   // + rigid apply backward
+    RC(eqd_kabsch_bwd_impl(B, K, S.Y, S.A, S.T, d_T, d_b, d_Ylig, d_Yrec, W.dY, st, g, d_lig, S.usv));   // + rigid apply backward
     const float* H = S.h[D.L];
     const float* Z = S.x[D.L];
     float* dXcur = W.dXa;   // grad wrt x[L]

@@ -451,7 +451,7 @@ __global__ __launch_bounds__(64) void k_kabsch_fwd(int B, int K, const float* __
                                                    float* __restrict__ T2, float* __restrict__ bvec,
                                                    float* __restrict__ A_out, int32_t* __restrict__ status,
                                                    const int32_t* __restrict__ seg_off, const float* __restrict__ x0,
-                                                   float* __restrict__ lig_out) {
+                                                   float* __restrict__ lig_out, double* __restrict__ usv) {
     // lig_out != NULL: the rigid apply of the pair's ligand nodes (k_apply_fwd's arithmetic) runs here as well
     __shared__ float sy[2][KAB_MAXK * 3];
     __shared__ float smean[6], sA[9], sTb[12];
@@ -504,6 +504,16 @@ __global__ __launch_bounds__(64) void k_kabsch_fwd(int B, int K, const float* __
         ++it;
     }
     status[p] = it;
+    if (usv) {       // U, S, V of the (guarded) A for the backward: the serial fp64 Jacobi SVD is most of that kernel's time
+        double* o = usv + (size_t)p * 21;
+        for (int i = 0; i < 3; ++i) {
+            o[9 + i] = S[i];
+            for (int j = 0; j < 3; ++j) {
+                o[i * 3 + j] = U[i][j];
+                o[12 + i * 3 + j] = V[i][j];
+            }
+        }
+    }
     const double sd = det3(A) < 0.0 ? -1.0 : 1.0;
     float Tm[3][3];
     for (int i = 0; i < 3; ++i)
@@ -534,12 +544,12 @@ __global__ __launch_bounds__(64) void k_kabsch_fwd(int B, int K, const float* __
 extern "C" int eqd_kabsch_fwd(int n_pairs, int n_heads, const float* Y, const float* svd_draws, int svd_seed, float* T,
                               float* b, float* A_out, int32_t* status, void* stream) {
     return eqd_kabsch_fwd_impl(n_pairs, n_heads, Y, svd_draws, svd_seed, T, nullptr, b, A_out, status, (hipStream_t)stream,
-                               nullptr, nullptr);
+                               nullptr, nullptr, nullptr);
 }
 // g + lig_out: also lig_out = T x0 + b for every ligand node (eqd_rigid_apply_fwd fused in: one launch less)
 int eqd_kabsch_fwd_impl(int n_pairs, int n_heads, const float* Y, const float* svd_draws, int svd_seed, float* T,
                         float* T2, float* b, float* A_out, int32_t* status, hipStream_t stream, const EqdGraph* g,
-                        float* lig_out) {
+                        float* lig_out, double* usv) {
     if (!Y || !T || !b || !A_out || !status) {
         eqd_set_error("eqd_kabsch_fwd: NULL argument");
         return EQD_ERR_NULL;
@@ -551,7 +561,7 @@ int eqd_kabsch_fwd_impl(int n_pairs, int n_heads, const float* Y, const float* s
     }
     hipLaunchKernelGGL(k_kabsch_fwd, dim3(n_pairs), dim3(64), 0, (hipStream_t)stream, n_pairs, n_heads, Y, svd_draws,
                        svd_seed, T, T2, b, A_out, status, g ? g->seg_off : (const int32_t*)nullptr,
-                       g ? g->x0 : (const float*)nullptr, g ? lig_out : (float*)nullptr);
+                       g ? g->x0 : (const float*)nullptr, g ? lig_out : (float*)nullptr, usv);
     return eqd_check_launch("k_kabsch_fwd");
 }
 
@@ -564,7 +574,8 @@ __global__ __launch_bounds__(64) void k_kabsch_bwd(int B, int K, const float* __
                                                    const float* __restrict__ dYl_ext,
                                                    const float* __restrict__ dYr_ext, int use_ext,
                                                    float* __restrict__ dY, const int32_t* __restrict__ seg_off,
-                                                   const float* __restrict__ x0, const float* __restrict__ d_lig) {
+                                                   const float* __restrict__ x0, const float* __restrict__ d_lig,
+                                                   const double* __restrict__ usv) {
     // one 64-thread workgroup per pair; lane 0 does the 3x3 algebra, the per-keypoint work is spread over lanes,
     // every sum over keypoints runs sequentially on one lane (fixed order)
     __shared__ float sy[2][KAB_MAXK * 3];
@@ -622,7 +633,18 @@ __global__ __launch_bounds__(64) void k_kabsch_bwd(int B, int K, const float* __
             for (int j = 0; j < 3; ++j)
                 G[i][j] = (dT ? (double)dT[(size_t)p * 9 + i * 3 + j] : 0.0) + (seg_off ? (double)sapp[i * 3 + j] : 0.0) -
                           dbv[i] * ml[j];
-        svd3(A, U, S, V);
+        if (usv) {       // saved by the forward
+            const double* o = usv + (size_t)p * 21;
+            for (int i = 0; i < 3; ++i) {
+                S[i] = o[9 + i];
+                for (int j = 0; j < 3; ++j) {
+                    U[i][j] = o[i * 3 + j];
+                    V[i][j] = o[12 + i * 3 + j];
+                }
+            }
+        } else {
+            svd3(A, U, S, V);
+        }
         const double c[3] = {1.0, 1.0, det3(A) < 0.0 ? -1.0 : 1.0};
         double M[3][3], dP[3][3];
         for (int i = 0; i < 3; ++i)
@@ -702,13 +724,13 @@ extern "C" int eqd_kabsch_bwd(int n_pairs, int n_heads, const float* Y, const fl
     }
     hipLaunchKernelGGL(k_kabsch_bwd, dim3(n_pairs), dim3(64), 0, (hipStream_t)stream, n_pairs, n_heads, Y,
                        A, T, dT, db, (const float*)nullptr, (const float*)nullptr, 0, dY, (const int32_t*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr);
+                       (const float*)nullptr, (const float*)nullptr, (const double*)nullptr);
     return eqd_check_launch("k_kabsch_bwd");
 }
 // g != NULL: dT / db are the EXTERNAL gradients (may be NULL) and the rigid apply's backward from d_lig is added inside
 int eqd_kabsch_bwd_impl(int n_pairs, int n_heads, const float* Y, const float* A, const float* T, const float* dT,
                         const float* db, const float* dYl_ext, const float* dYr_ext, float* dY, hipStream_t stream,
-                        const EqdGraph* g, const float* d_lig) {
+                        const EqdGraph* g, const float* d_lig, const double* usv) {
     if (!Y || !A || !T || !dY) {
         eqd_set_error("eqd_kabsch_bwd: NULL argument");
         return EQD_ERR_NULL;
@@ -720,7 +742,7 @@ int eqd_kabsch_bwd_impl(int n_pairs, int n_heads, const float* Y, const float* A
     }
     hipLaunchKernelGGL(k_kabsch_bwd, dim3(n_pairs), dim3(64), 0, (hipStream_t)stream, n_pairs, n_heads, Y,
                        A, T, dT, db, dYl_ext, dYr_ext, 1, dY, g ? g->seg_off : (const int32_t*)nullptr,
-                       g ? g->x0 : (const float*)nullptr, g ? d_lig : (const float*)nullptr);
+                       g ? g->x0 : (const float*)nullptr, g ? d_lig : (const float*)nullptr, usv);
     return eqd_check_launch("k_kabsch_bwd");
 }
 
