@@ -51,59 +51,66 @@ struct alignas(16) EdgeSmem {
 
 template <int NW, int TF>
 __device__ __forceinline__ void edge_stage_weights(EdgeSmem<NW, TF>& sm, const EqdEdgeParams& P) {
-    // all global loads of a thread are issued before the first LDS store (constant trip counts, fully
-    // unrolled): one L2 round trip per batch instead of one per element
+    // ALL global loads of a thread (W1's feature columns, W2, Wc1, the five vectors) are issued before the first LDS
+    // store (constant trip counts, fully unrolled, unpredicated): ONE L2 round trip for the whole staging - three
+    // batches with their own waits were 4 200 clocks at the head of every workgroup of the backward
     constexpr int NT = 64 * NW;
     constexpr int N1 = (64 * 11 + NT - 1) / NT, N2 = 1024 / NT;
     const int t = threadIdx.x;
     const int koff = 2 * P.d_in;
-    {
-        f32x4 v[N1];
+    f32x4 v[N1];
+    float4 a[N2], b[N2];
+    float vec5[5];
 #pragma unroll
-        for (int j = 0; j < N1; ++j) {       // 64 rows x 42 floats = 64 x 11 16-byte segments (the last holds 2)
-            const int i = t + j * NT;
-            const int r = i / 11, c = 4 * (i - r * 11);
-            v[j] = ld4u_raw(P.W1 + (size_t)(i < 64 * 11 ? r : 0) * P.ldw1 + koff + c, i < 64 * 11 ? 42 - c : 0, P.W1);
-        }
+    for (int j = 0; j < N1; ++j) {       // 64 rows x 42 floats = 64 x 11 16-byte segments (the last holds 2)
+        const int i = t + j * NT;
+        const int r = i / 11, c = 4 * (i - r * 11);
+        v[j] = ld4u_raw(P.W1 + (size_t)(i < 64 * 11 ? r : 0) * P.ldw1 + koff + c, i < 64 * 11 ? 42 - c : 0, P.W1);
+    }
 #pragma unroll
-        for (int j = 0; j < N1; ++j) {
-            const int i = t + j * NT;
-            const int r = i / 11, c = 4 * (i - r * 11);
-            if (i < 64 * 11) {
-                const float4 f = ld4u_fix(v[j], 42 - c);
-                float* o = &sm.w1[r * WS1 + c];
-                o[0] = f.x;
-                if (c + 1 < WS1) o[1] = f.y;      // c = 40: 42, 43, 44 are the zero padding (ld4u_fix zero-fills)
-                if (c + 2 < WS1) o[2] = f.z;
-                if (c + 3 < WS1) o[3] = f.w;
-            }
-        }
-        if (t < 64) sm.w1[t * WS1 + 44] = 0.f;
+    for (int j = 0; j < N2; ++j) {       // 64 x 64 floats = 1024 float4
+        const int i = t + j * NT;
+        a[j] = ((const float4*)P.W2)[i];
+        b[j] = ((const float4*)P.Wc1)[i];
     }
     {
-        float4 a[N2], b[N2];
+        const int tc = t & 63;
+        vec5[0] = P.ln_g[tc];
+        vec5[1] = P.ln_b[tc];
+        vec5[2] = P.b2[tc];
+        vec5[3] = P.bc1[tc];
+        vec5[4] = P.wc2[tc];
+    }
+    const float bc2 = P.bc2[0];
 #pragma unroll
-        for (int j = 0; j < N2; ++j) {       // 64 x 64 floats = 1024 float4
-            const int i = t + j * NT;
-            a[j] = ((const float4*)P.W2)[i];
-            b[j] = ((const float4*)P.Wc1)[i];
+    for (int j = 0; j < N1; ++j) {
+        const int i = t + j * NT;
+        const int r = i / 11, c = 4 * (i - r * 11);
+        if (i < 64 * 11) {
+            const float4 f = ld4u_fix(v[j], 42 - c);
+            float* o = &sm.w1[r * WS1 + c];
+            o[0] = f.x;
+            if (c + 1 < WS1) o[1] = f.y;      // c = 40: 42, 43, 44 are the zero padding (ld4u_fix zero-fills)
+            if (c + 2 < WS1) o[2] = f.z;
+            if (c + 3 < WS1) o[3] = f.w;
         }
+    }
+    if (t < 64) sm.w1[t * WS1 + 44] = 0.f;
 #pragma unroll
-        for (int j = 0; j < N2; ++j) {
-            const int i = t + j * NT;
-            const int r = i >> 4, c = (i & 15) * 4;
-            *(float4*)&sm.w2[r * WS2 + c] = a[j];
-            *(float4*)&sm.wc1[r * WS2 + c] = b[j];
-        }
+    for (int j = 0; j < N2; ++j) {
+        const int i = t + j * NT;
+        const int r = i >> 4, c = (i & 15) * 4;
+        *(float4*)&sm.w2[r * WS2 + c] = a[j];
+        *(float4*)&sm.wc1[r * WS2 + c] = b[j];
     }
     if (t < 64) {
-        sm.vec[VEC_LNG + t] = P.ln_g[t];
-        sm.vec[VEC_LNB + t] = P.ln_b[t];
-        sm.vec[VEC_B2 + t] = P.b2[t];
-        sm.vec[VEC_BC1 + t] = P.bc1[t];
-        sm.vec[VEC_WC2 + t] = P.wc2[t];
+        sm.vec[VEC_LNG + t] = vec5[0];
+        sm.vec[VEC_LNB + t] = vec5[1];
+        sm.vec[VEC_B2 + t] = vec5[2];
+        sm.vec[VEC_BC1 + t] = vec5[3];
+        sm.vec[VEC_WC2 + t] = vec5[4];
     }
-    if (t == 0) sm.vec[VEC_BC2] = P.bc2[0];
+    if (t == 0) sm.vec[VEC_BC2] = bc2;
     __syncthreads();
 }
 
