@@ -88,7 +88,9 @@ def _declare(lib):
     lib.eqd_model_scratch_bytes.restype = C.c_size_t
     lib.eqd_atb_partial_bytes.restype = C.c_size_t
     lib.eqd_edge_message_bwd_workspace_bytes.restype = C.c_size_t
-    for name in ('eqd_ctx_create', 'eqd_ctx_destroy', 'eqd_model_check', 'eqd_model_forward', 'eqd_model_backward', 'eqd_linear', 'eqd_atb',
+    lib.eqd_profile_name.restype = C.c_char_p
+    lib.eqd_profile_us.restype = C.c_float
+    for name in ('eqd_profile_begin', 'eqd_profile_end', 'eqd_ctx_create', 'eqd_ctx_destroy', 'eqd_model_check', 'eqd_model_forward', 'eqd_model_backward', 'eqd_linear', 'eqd_atb',
                  'eqd_edge_message_fwd', 'eqd_edge_message_bwd', 'eqd_edge_message_bwd_kernel_only',
                  'eqd_cross_attention_fwd',
                  'eqd_cross_attention_bwd', 'eqd_keypoint_pool_fwd', 'eqd_kabsch_fwd', 'eqd_kabsch_bwd',
@@ -96,7 +98,7 @@ def _declare(lib):
         getattr(lib, name).restype = C.c_int
 
 
-EXPORTS = ('eqd_ctx_create', 'eqd_ctx_destroy', 'eqd_abi_version', 'eqd_last_error', 'eqd_tile_edges', 'eqd_is_simulator', 'eqd_model_saved_bytes',
+EXPORTS = ('eqd_profile_begin', 'eqd_profile_end', 'eqd_profile_name', 'eqd_profile_us', 'eqd_ctx_create', 'eqd_ctx_destroy', 'eqd_abi_version', 'eqd_last_error', 'eqd_tile_edges', 'eqd_is_simulator', 'eqd_model_saved_bytes',
            'eqd_model_scratch_bytes', 'eqd_model_check', 'eqd_model_forward', 'eqd_model_backward', 'eqd_linear',
            'eqd_atb_partial_bytes', 'eqd_atb', 'eqd_edge_message_fwd', 'eqd_edge_message_bwd_workspace_bytes',
            'eqd_edge_message_bwd', 'eqd_edge_message_bwd_kernel_only', 'eqd_cross_attention_fwd',
@@ -155,6 +157,23 @@ def require_device(t, what='tensor'):
             f"{what} is on {t.device}: the IEGMN hot path runs only on an MI355X through libequidock_hip.so "
             "(no CPU fallback)")
     return t
+
+
+class device_guard:
+    """`with device_guard(dev):` - the tensors' GPU is the current HIP device while the C library enqueues work (it
+    launches on the passed stream, but hipMemsetAsync / kernel launches resolve against the current device)."""
+
+    def __init__(self, device):
+        self._cm = None if (_is_sim or torch.device(device).type != 'cuda') else torch.cuda.device(device)
+
+    def __enter__(self):
+        if self._cm is not None:
+            self._cm.__enter__()
+
+    def __exit__(self, *exc):
+        if self._cm is not None:
+            self._cm.__exit__(*exc)
+        return False
 
 
 def ptr(t):

@@ -853,7 +853,7 @@ static int attn_launch_bwd(const EqdGraph* g, int d, const float* q, const float
 static bool att_half_blocks(const EqdGraph* g) {
     const char* f = getenv("EQD_ATT_SPLIT");
     if (f && (f[0] == '0' || f[0] == '1') && f[1] == 0) return f[0] == '1';
-    return g->n_att_items <= 256;
+    return g->n_att_items <= eqd_num_cus();
 }
 extern "C" int eqd_cross_attention_fwd(const EqdGraph* g, int d, const float* q, const float* k, const float* v,
                                        float* out, float* lse, void* stream) {

@@ -770,14 +770,15 @@ __global__ __launch_bounds__(64 * NW) void k_edge_fwd(EqdGraph G, EqdEdgeParams 
 }
 
 // Smallest grid with the minimal number of tile rounds: with `wg_per_cu` workgroups per CU the makespan is
-// ceil(tiles / (256 * wg_per_cu * waves)) tile times whatever the grid, so use as few CUs as that allows
+// ceil(tiles / (CUs * wg_per_cu * waves)) tile times whatever the grid, so use as few CUs as that allows
 // and leave the rest to the kernels that run concurrently on the auxiliary streams.
 static int edge_grid(int n_tiles, int waves, int wg_per_cu) {
     if (n_tiles <= 0) return 1;
-    const int slots = 256 * waves * wg_per_cu;
+    const int cus = eqd_num_cus();
+    const int slots = cus * waves * wg_per_cu;
     const int rounds = (n_tiles + slots - 1) / slots;
     int blocks = (n_tiles + waves * rounds - 1) / (waves * rounds);
-    if (blocks > 256 * wg_per_cu) blocks = 256 * wg_per_cu;
+    if (blocks > cus * wg_per_cu) blocks = cus * wg_per_cu;
     return blocks < 1 ? 1 : blocks;
 }
 
@@ -1224,7 +1225,8 @@ static int edge_bwd_blocks(const EqdGraph* g) {
     const int n_tiles = (g->n_edges + 15) / 16;
     int n_super = (n_tiles + BWD_WAVES - 1) / BWD_WAVES;
     if (n_super < 1) n_super = 1;
-    return n_super < 256 ? n_super : 256;      // one workgroup per CU (LDS-bound), persistent over super-tiles
+    const int cus = eqd_num_cus();
+    return n_super < cus ? n_super : cus;      // one workgroup per CU (LDS-bound), persistent over super-tiles
 }
 size_t eqd_edge_bwd_vecp_floats(const EqdGraph* g) {
     return (size_t)edge_bwd_blocks(g) * (BWD_WAVES * VP + WP_N);

@@ -24,13 +24,88 @@ void eqd_set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+// ------------------------------------------------------------------------------------------
+// per-launch timing (eqd_profile_*, include/equidock_hip.h): between begin and end every launch of this library on the
+// profiled stream is followed by an event record; the time between consecutive events is that launch's duration.
+// ------------------------------------------------------------------------------------------
+namespace {
+struct EqdProfiler {
+    bool on = false;
+    hipStream_t st = nullptr;
+    std::vector<hipEvent_t> ev;
+    std::vector<const char*> name;
+    std::vector<float> us;
+    int n = 0, cap = 0;
+};
+thread_local EqdProfiler g_prof;
+}  // namespace
+
+extern "C" int eqd_profile_begin(void* stream, int max_launches) {
+    EqdProfiler& P = g_prof;
+    if (P.on || max_launches < 1) {
+        eqd_set_error("eqd_profile_begin: already profiling, or max_launches < 1");
+        return EQD_ERR_SHAPE;
+    }
+    while ((int)P.ev.size() < max_launches + 1) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) {
+            eqd_set_error("eqd_profile_begin: hipEventCreate failed");
+            return EQD_ERR_LAUNCH;
+        }
+        P.ev.push_back(e);
+    }
+    P.name.assign(max_launches, nullptr);
+    P.us.assign(max_launches, 0.f);
+    P.st = (hipStream_t)stream;
+    P.n = 0;
+    P.cap = max_launches;
+    if (hipEventRecord(P.ev[0], P.st) != hipSuccess) return EQD_ERR_LAUNCH;
+    P.on = true;
+    return EQD_OK;
+}
+extern "C" int eqd_profile_end(void) {
+    EqdProfiler& P = g_prof;
+    if (!P.on) return 0;
+    P.on = false;
+    if (P.n > 0 && hipEventSynchronize(P.ev[P.n]) != hipSuccess) return -1;
+    for (int i = 0; i < P.n; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, P.ev[i], P.ev[i + 1]) != hipSuccess) return -1;
+        P.us[i] = ms * 1000.f;
+    }
+    return P.n;
+}
+extern "C" const char* eqd_profile_name(int i) { return (i >= 0 && i < g_prof.n) ? g_prof.name[i] : ""; }
+extern "C" float eqd_profile_us(int i) { return (i >= 0 && i < g_prof.n) ? g_prof.us[i] : 0.f; }
+
 int eqd_check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         eqd_set_error("launch of %s failed: %s", what, hipGetErrorString(e));
         return EQD_ERR_LAUNCH;
     }
+    EqdProfiler& P = g_prof;
+    if (P.on && P.n < P.cap) {
+        P.name[P.n] = what;
+        (void)hipEventRecord(P.ev[P.n + 1], P.st);
+        ++P.n;
+    }
     return EQD_OK;
+}
+int eqd_num_cus() {
+#ifdef EQD_NUM_CUS_FIXED
+    return EQD_NUM_CUS_FIXED;      // host simulator
+#else
+    static int cached[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+    if (!cached[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
+#endif
 }
 extern "C" const char* eqd_last_error(void) { return g_err; }
 extern "C" int eqd_abi_version(void) { return EQD_ABI_VERSION; }

@@ -155,10 +155,19 @@ class PairGraph:
     # ---- packing for the HIP path ---------------------------------------------------------------
     def pack(self):
         """Device-resident kernel layout (topology cached; coordinates re-read every call)."""
-        if self._packed is None or self._packed.device != self.device:
+        if self._packed is None or _canon(self._packed.device) != _canon(self.device):
             self._packed = PackedGraph.build(self)
         self._packed.refresh_coords(self)
         return self._packed
+
+
+def _canon(device):
+    """(type, index) with the index of a bare 'cuda' resolved, so that torch.device('cuda') == cuda:<current>: a layout
+    that was packed on the host and moved with .to('cuda') must not be rebuilt from GPU tensors at the first forward."""
+    device = torch.device(device)
+    if device.type == 'cuda' and device.index is None:
+        return (device.type, torch.cuda.current_device())
+    return (device.type, device.index)
 
 
 def pair_from_arrays(lig, rec):
@@ -178,6 +187,7 @@ def pair_from_arrays(lig, rec):
     edges = {'ll': (t(lig['src'], torch.int32), t(lig['dst'], torch.int32)),
              'rr': (t(rec['src'], torch.int32), t(rec['dst'], torch.int32))}
     nl, nr = ndata['ligand']['x'].shape[0], ndata['receptor']['x'].shape[0]
+    nt_of = PairGraph.ETYPES
     for et, n in (('ll', nl), ('rr', nr)):
         s, d = edges[et]
         if s.numel():
@@ -185,9 +195,23 @@ def pair_from_arrays(lig, rec):
                 raise ValueError(f"edge endpoint out of range for edge type {et}")
         if edata[et]['he'].shape[0] != s.numel():
             raise ValueError(f"'he' has {edata[et]['he'].shape[0]} rows for {s.numel()} {et} edges")
+        _check_feature_widths(edata[et]['he'], ndata[nt_of[et]]['mu_r_norm'], et)
     return PairGraph(ndata, edata, edges,
                      {'ligand': [nl], 'receptor': [nr]},
                      {'ll': [int(edges['ll'][0].numel())], 'rr': [int(edges['rr'][0].numel())]})
+
+
+HE_WIDTH = 27        # 15 distance RBFs + 12 orientation features (src/utils/protein_utils.py:71-86, 380-390)
+MU_WIDTH = 5         # surface-aware features, sigma in {1, 2, 5, 10, 30} (src/utils/protein_utils.py:351-359)
+
+
+def _check_feature_widths(he, mu, et):
+    """The kernels (and the native host pack) address `he` rows as 27 floats and `mu_r_norm` rows as 5."""
+    if he.dim() != 2 or he.shape[1] != HE_WIDTH:
+        raise ValueError(f"'he' of edge type {et} must be [E, {HE_WIDTH}] (input_edge_feats_dim of the HIP path), got "
+                         f"{tuple(he.shape)}")
+    if mu.dim() != 2 or mu.shape[1] != MU_WIDTH:
+        raise ValueError(f"'mu_r_norm' must be [n, {MU_WIDTH}], got {tuple(mu.shape)}")
 
 
 def batch(graphs):
@@ -277,6 +301,8 @@ class PackedGraph:
         n = nl + nr
         B = g.batch_size
         p.n_pairs, p.n_lig, p.n_rec, p.n_nodes = B, nl, nr, n
+        for et, nt in PairGraph.ETYPES.items():
+            _check_feature_widths(g._edata[et]['he'], g._ndata[nt]['mu_r_norm'], et)
         native = _native() if (dev.type == 'cpu' and n > 0) else None
         if native is not None:
             return PackedGraph._build_native(native, g, p)

@@ -145,20 +145,24 @@ class _IEGMNFunction(torch.autograd.Function):
         status = torch.empty(B, dtype=torch.int32, device=dev)
         key = (desc.n_layers, desc.n_heads, desc.d_emb, desc.use_mean_node_features)
         if packed.ws_sizes.get(key) is None:
-            sb = lib.eqd_model_saved_bytes(C.byref(desc), C.byref(gs))
-            wb = lib.eqd_model_scratch_bytes(C.byref(desc), C.byref(gs))
+            with _lib.device_guard(dev):    # workgroup counts (hence partial-sum workspaces) follow the device's CU count
+                sb = lib.eqd_model_saved_bytes(C.byref(desc), C.byref(gs))
+                wb = lib.eqd_model_scratch_bytes(C.byref(desc), C.byref(gs))
             if sb == 0 or wb == 0:
                 _lib.check(lib.eqd_model_check(C.byref(desc), C.byref(gs)))
             packed.ws_sizes[key] = (sb, wb)
         sb, wb = packed.ws_sizes[key]
+        # the forward carves its state from `saved` when a backward will follow and from `scratch` otherwise: only one
+        # of the two is ever touched (the state is hundreds of MB at 64 x (300, 300))
         saved = torch.empty(sb, dtype=torch.uint8, device=dev) if need_grad else None
-        scratch = torch.empty(wb, dtype=torch.uint8, device=dev)
+        scratch = None if need_grad else torch.empty(wb, dtype=torch.uint8, device=dev)
         if svd_draws is not None:
             svd_draws = _lib.require_device(svd_draws.to(torch.float32).contiguous(), 'svd_draws')
-        _lib.check(lib.eqd_model_forward(
-            C.byref(desc), C.byref(gs), ptrs, _lib.ptr(svd_draws), _lib.ptr(lig), _lib.ptr(Yl), _lib.ptr(Yr),
-            _lib.ptr(T), _lib.ptr(b), _lib.ptr(status), _lib.ptr(saved), C.c_size_t(sb if need_grad else 0),
-            _lib.ptr(scratch), C.c_size_t(wb), _lib.stream_ptr(dev), _lib.exec_ctx(dev)))
+        with _lib.device_guard(dev):        # kernels and memsets go to the tensors' device, whatever the current one is
+            _lib.check(lib.eqd_model_forward(
+                C.byref(desc), C.byref(gs), ptrs, _lib.ptr(svd_draws), _lib.ptr(lig), _lib.ptr(Yl), _lib.ptr(Yr),
+                _lib.ptr(T), _lib.ptr(b), _lib.ptr(status), _lib.ptr(saved), C.c_size_t(sb if need_grad else 0),
+                _lib.ptr(scratch), C.c_size_t(0 if need_grad else wb), _lib.stream_ptr(dev), _lib.exec_ctx(dev)))
         ctx.packed, ctx.desc, ctx.table_idx, ctx.saved, ctx.sb, ctx.wb = packed, desc, table_idx, saved, sb, wb
         ctx.tensors, ctx.ptrs = tensors, ptrs
         ctx.flat_state = flat_state
@@ -190,10 +194,11 @@ class _IEGMNFunction(torch.autograd.Function):
         def prep(t):
             return None if t is None else _lib.require_device(t.to(torch.float32).contiguous(), 'output gradient')
         d_lig, d_Yl, d_Yr, d_T, d_b = (prep(t) for t in (d_lig, d_Yl, d_Yr, d_T, d_b))
-        _lib.check(lib.eqd_model_backward(
-            C.byref(desc), C.byref(gs), ptrs, _lib.ptr(d_lig), _lib.ptr(d_Yl), _lib.ptr(d_Yr), _lib.ptr(d_T),
-            _lib.ptr(d_b), _lib.ptr(flat), goffs, _lib.ptr(ctx.saved), C.c_size_t(ctx.sb), _lib.ptr(scratch),
-            C.c_size_t(ctx.wb), _lib.stream_ptr(dev), _lib.exec_ctx(dev)))
+        with _lib.device_guard(dev):
+            _lib.check(lib.eqd_model_backward(
+                C.byref(desc), C.byref(gs), ptrs, _lib.ptr(d_lig), _lib.ptr(d_Yl), _lib.ptr(d_Yr), _lib.ptr(d_T),
+                _lib.ptr(d_b), _lib.ptr(flat), goffs, _lib.ptr(ctx.saved), C.c_size_t(ctx.sb), _lib.ptr(scratch),
+                C.c_size_t(ctx.wb), _lib.stream_ptr(dev), _lib.exec_ctx(dev)))
         if ctx.flat_state is not None:
             return (None,) * 8
         grads = tuple(flat[o:o + t.numel()].view(t.shape) for o, t in zip(offs, tensors))
@@ -313,12 +318,16 @@ class IEGMN(nn.Module):
     def enable_flat_grads(self):
         """Make every parameter's .grad a view into ONE persistent fp32 buffer that the backward C call
         accumulates into directly (no per-parameter autograd work, one all-reduce for data parallel).
-        Use zero_flat_grads() instead of optimizer.zero_grad(set_to_none=True)."""
+        zero_flat_grads() is one fill; optimizer.zero_grad() (either set_to_none) also works: dropped views are zeroed
+        and restored at the next forward (_rebind_flat_views)."""
         uniq, _ = self._param_table()
         offs, total = flat_layout(uniq)
         flat = torch.zeros(total, dtype=torch.float32, device=uniq[0].device)
-        for p, o in zip(uniq, offs):
-            p.grad = flat[o:o + p.numel()].view(p.shape)
+        self._flat_views = [flat[o:o + p.numel()].view(p.shape) for p, o in zip(uniq, offs)]
+        for p, v in zip(uniq, self._flat_views):
+            # frozen parameters keep .grad = None: their slice of the buffer still receives the C call's sums (the
+            # kernels write every weight gradient), it is simply never shown to an optimizer
+            p.grad = v if p.requires_grad else None
         _, table_idx = self._param_table()
         goffs = (C.c_int64 * len(table_idx))(*[offs[i] for i in table_idx])
         anchor = torch.zeros((), dtype=torch.float32, device=uniq[0].device, requires_grad=True)
@@ -327,6 +336,35 @@ class IEGMN(nn.Module):
 
     def zero_flat_grads(self):
         self._flat[0].zero_()
+
+    def _rebind_flat_views(self, uniq):
+        """Keep every trainable parameter's .grad a view into the flat buffer.  The reference's training loop calls
+        optimizer.zero_grad() (src/train.py:88), whose default set_to_none=True drops the views: a dropped view means
+        "this gradient is zero now", so the slice is zeroed and the view restored (otherwise the backward would keep
+        accumulating into a buffer nothing zeroes while the optimizer skips every parameter).  A .grad that was
+        replaced by some other tensor is an error - the C call cannot accumulate into it."""
+        flat, offs, views = self._flat[0], self._flat[1], self._flat_views
+        dropped = []
+        for i, p in enumerate(uniq):
+            gr = p.grad
+            if gr is views[i]:              # identity: the view object itself is still attached (the common case)
+                continue
+            if gr is None:
+                if p.requires_grad:
+                    dropped.append(i)
+            elif gr.data_ptr() != flat.data_ptr() + 4 * offs[i]:
+                raise _lib.EquidockHipError(
+                    "a parameter's .grad no longer aliases the flat gradient buffer (it was replaced, not zeroed): "
+                    "call enable_flat_grads() again, or use zero_flat_grads() / optimizer.zero_grad()")
+        if not dropped:
+            return
+        whole = len(dropped) == sum(1 for p in uniq if p.requires_grad)
+        if whole:
+            flat.zero_()                    # zero_grad() dropped all of them: one fill
+        for i in dropped:
+            if not whole:
+                views[i].zero_()
+            uniq[i].grad = views[i]
 
     @property
     def grad_flat(self):
@@ -345,6 +383,7 @@ class IEGMN(nn.Module):
         if self._flat is not None and need_grad:
             if self._flat[2] != [id(p) for p in uniq] or self._flat[0].device != packed.x0.device:
                 raise _lib.EquidockHipError("parameters changed since enable_flat_grads(); call it again")
+            self._rebind_flat_views(uniq)
             flat_state = (self._flat[0], self._flat[1], self._flat[3])
         if flat_state is not None:
             lig, Yl, Yr, T, b, status = _IEGMNFunction.apply(packed, self._desc(), table_idx, self.svd_draws,

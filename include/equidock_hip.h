@@ -55,6 +55,19 @@ int eqd_tile_edges(void);
 /* 1 when the library is the x86 host simulator built by tests/hostsim (never shipped), else 0 */
 int eqd_is_simulator(void);
 
+/* ---- per-launch timing (measurement aid for bench.py; nothing in the reference corresponds to it) ----
+ * Between eqd_profile_begin(stream, max) and eqd_profile_end() every kernel this library launches FROM THE CALLING
+ * THREAD is followed by a hipEventRecord on `stream` (pass the stream the model runs on; hipMemsetAsync fills are
+ * not recorded and count towards the next launch).  eqd_profile_end() synchronises the last event and returns the
+ * number of launches seen (or -1); eqd_profile_name(i) / eqd_profile_us(i) give launch i's kernel name and the time
+ * between the events before and after it - the kernel's duration when the stream was kept busy (enqueue the work
+ * behind a long-running kernel so that the host is ahead of the GPU), plus one event-record of overhead that the
+ * caller calibrates with an empty interval.  Not usable while the stream is being captured into a hipGraph. */
+int eqd_profile_begin(void* stream, int max_launches);
+int eqd_profile_end(void);
+const char* eqd_profile_name(int i);
+float eqd_profile_us(int i);
+
 /* ---- batched pair graph: kernel-side view of what the reference passes as a batched DGL
  *      heterograph (src/utils/train_utils.py:61-100). Built by equidock_public_amd/graph.py. ---- */
 typedef struct EqdGraph {

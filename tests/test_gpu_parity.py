@@ -106,10 +106,23 @@ def test_model_vs_oracle_ragged(dev):
     # (the closed-form SVD backward divides by singular-value gaps of the random diagonal there)
     pc.check_model_vs_oracle_ragged(dev, check_grads=False)
     pc.check_model_vs_oracle_ragged(dev, sizes=((4, 4), (17, 5), (33, 64)))
-    # (seed chosen free of LeakyReLU kink flips between the GPU's and the host's fp32 rounding: a pre-activation within
-    # rounding of 0 takes the other slope, x100, and moves a weight gradient by up to 1 % - seeds 8, 9, 11 have one each
-    # among the ~1e6 activations of this batch, 10, 12, 13 none)
-    pc.check_model_vs_oracle_ragged(dev, sizes=((129, 257), (300, 31), (64, 64), (95, 200)), layers=3, seed=10)
+    # gradients are compared kink-aware (oracle_reference): seeds 8, 9 and 11 each have a LeakyReLU pre-activation
+    # within fp32 rounding of 0 that takes the other slope on the GPU; no seed is avoided any more
+    for seed in (8, 9, 10, 11):
+        pc.check_model_vs_oracle_ragged(dev, sizes=((129, 257), (300, 31), (64, 64), (95, 200)), layers=3, seed=seed)
+
+
+@pytest.mark.parametrize('over', [dict(cross_msgs=False), dict(use_dist_in_layers=False),
+                                  dict(use_edge_features_in_gmn=False), dict(use_mean_node_features=False),
+                                  dict(x_connection_init=0.25), dict(num_att_heads=13),
+                                  dict(cross_msgs=False, use_mean_node_features=False, x_connection_init=0.25,
+                                       shared_layers=True)],
+                         ids=lambda o: '+'.join(f'{k}={v}' for k, v in o.items()))
+def test_option_toggles_vs_oracle(dev, over):
+    """every `args` switch the HIP path advertises, outputs + all gradients vs the oracle"""
+    from tests import parity_common as pc
+    pc.check_model_vs_oracle(dev, [(23, 31), (40, 17), (130, 77)], layers=3, seed=5, pair_seed=7, args_over=over,
+                             what=str(over))
 
 
 def test_pair_losses(dev):
@@ -133,26 +146,52 @@ def test_properties_baseline_sizes(dev):
     pc.check_properties(dev, sizes=((200, 200), (200, 200), (200, 200), (200, 200)), layers=8)
 
 
+REPORT = []      # one line per BASELINE.json workload, printed at the end of the module (pytest -s) and kept in
+                 # gpurun_out/parity_report.txt when that directory exists
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _parity_report():
+    yield
+    if REPORT:
+        import os
+        text = '\n'.join(REPORT) + '\n'
+        print('\n' + text)
+        if os.path.isdir('gpurun_out'):
+            with open('gpurun_out/parity_report.txt', 'a') as f:
+                f.write(text)
+
+
 def test_model_vs_oracle_config_b(dev):
-    """Config B shapes (8 x 200/200, 8 layers): outputs and gradients vs the oracle on the host."""
-    from equidock_public_amd import graph as G, synthetic
-    from oracle import iegmn_port as port
+    """BASELINE.json configs[1] at its real workload: 8 x (200, 200), 8 layers, fp32 - outputs and every gradient vs
+    the oracle in its faithful mode (the reference's op sequence, dense batch-wide mask)."""
     from tests import parity_common as pc
-    args = port.default_args(iegmn_n_lays=8, skip_weight_h=0.75)
-    sd = port.init_state_dict(args, seed=3)
-    net = pc.build_model(args, sd, dev)
-    pairs = synthetic.make_pairs([(200, 200)] * 4, 33)
-    g = G.batch_pairs(pairs).to(dev)
-    outs = net(g, epoch=0)
-    port.scalar_loss(outs).backward()
-    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    ref = port.forward(leaves, args, port.raw_from_graph(g), faithful=True)
-    port.scalar_loss(ref).backward()
-    for a, b in zip(outs, ref):
-        for x, y in zip(a, b):
-            pc.close(x, y, tol=1e-4, what='config-B output')
-    for k, p in net.named_parameters():
-        pc.grad_close(p.grad, leaves[k].grad, what=f'config-B grad {k}')
+    pc.check_model_vs_oracle(dev, [(200, 200)] * 8, layers=8, seed=3, pair_seed=33, faithful=True, what='config B fp32',
+                             report=REPORT)
+
+
+def test_model_vs_oracle_config_c_fp32(dev):
+    """BASELINE.json configs[2] shapes at the real workload, fp32 arithmetic: 64 x (300, 300), 8 layers.  The dense mask
+    of the faithful oracle would be 19 200^2 per temporary, so the oracle runs its block-diagonal mode (equal to the
+    reference to 0.0 on every golden case, tests/test_oracle_golden.py)."""
+    from tests import parity_common as pc
+    pc.check_model_vs_oracle(dev, [(300, 300)] * 64, layers=8, seed=3, pair_seed=34, faithful=False, what='config C fp32',
+                             report=REPORT)
+
+
+def test_model_vs_oracle_config_e(dev):
+    """BASELINE.json configs[4] at its real workload: 4 x (2000, 2000), 8 layers, fp32, vs the oracle (block-diagonal
+    mode: four 2000 x 2000 attention blocks per direction on the host)."""
+    from tests import parity_common as pc
+    pc.check_model_vs_oracle(dev, [(2000, 2000)] * 4, layers=8, seed=3, pair_seed=35, faithful=False, what='config E fp32',
+                             report=REPORT)
+
+
+def test_model_vs_oracle_config_a(dev):
+    """BASELINE.json configs[0]: one (200, 200) pair, 5-layer shared IEGMN."""
+    from tests import parity_common as pc
+    pc.check_model_vs_oracle(dev, [(200, 200)], layers=5, seed=3, pair_seed=36, faithful=True, what='config A fp32',
+                             args_over=dict(shared_layers=True, skip_weight_h=0.5), report=REPORT)
 
 
 def test_big_batch_equals_small_batches(dev):

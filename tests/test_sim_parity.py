@@ -93,6 +93,17 @@ def test_model_vs_oracle_ragged():
     pc.check_model_vs_oracle_ragged(DEV, sizes=((4, 4), (17, 5), (33, 64)))
 
 
+@pytest.mark.parametrize('over', [dict(cross_msgs=False), dict(use_dist_in_layers=False),
+                                  dict(use_edge_features_in_gmn=False), dict(use_mean_node_features=False),
+                                  dict(x_connection_init=0.25), dict(num_att_heads=13),
+                                  dict(cross_msgs=False, use_mean_node_features=False, x_connection_init=0.25,
+                                       shared_layers=True)],
+                         ids=lambda o: '+'.join(f'{k}={v}' for k, v in o.items()))
+def test_option_toggles_vs_oracle(over):
+    """every `args` switch the HIP path advertises, outputs + all gradients vs the oracle"""
+    pc.check_model_vs_oracle(DEV, [(23, 31), (40, 17)], layers=3, seed=5, pair_seed=7, args_over=over, what=str(over))
+
+
 def test_pair_losses():
     pc.check_pair_losses(DEV)
 
