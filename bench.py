@@ -1,6 +1,6 @@
 """bench.py -- protein-pairs/sec (fwd+bwd) of one IEGMN stack on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload B|A|C|E]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload B|A|C|D|E] [--dtype f32|bf16]
 
 A "step" = zero grads -> Rigid_Body_Docking_Net forward -> fixed scalar loss
 -> backward, on one synthetic batch that is already resident in HBM (the slice
@@ -10,11 +10,17 @@ heads, fp32, on ONE GPU.  With --gpus N (launched by torch.distributed.run, one 
 every rank runs the same per-GPU batch (weak scaling) and the flat gradient buffer is
 all-reduced once per step over RCCL.
 
+The default workload is B for every N, so that the driver's N = 1, 2, 4, 8 runs form one weak-scaling curve;
+`--workload D` is BASELINE.json configs[3] (64 x (300,300) per GPU, bf16).
+
 Rank 0 prints ONE JSON line with the contract fields plus
-  "roofline":     the dominant kernel (edge-message backward/forward), measured live with HIP
-                  events on the launch stream: algorithmic FLOPs|bytes per launch / avg duration;
-  "cpu_baseline": the oracle (oracle/iegmn_port.py, reference op sequence incl. the dense mask)
-                  timed on the host cores on the same batch (N=1 only).
+  "roofline":      the dominant kernel (edge-message backward/forward), measured live with HIP events on the launch
+                   stream: algorithmic FLOPs|bytes per launch / avg duration of batched standalone launches;
+  "roofline_all":  every kernel family >= 3 % of the step, timed inside an eager step with the library's launch
+                   profiler (eqd_profile_*): executed and as-written FLOP rates, algorithmic-bytes HBM rate, PMC MfmaUtil;
+  "whole_step":    as-written FLOPs of the step / ms_per_step against the MFMA peak of the dtype;
+  "cpu_baseline":  the oracle (oracle/iegmn_port.py, the reference's op sequence) on the host's physical cores, plus
+                   its one-thread and one-pair-per-step variants (N=1 only; the only place `oracle` is imported).
 """
 import argparse
 import ctypes as C
@@ -30,17 +36,86 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (pairs per GPU, (n_lig, n_rec), layers, shared, skip_weight_h, description)
-    'A': (1, (200, 200), 5, True, 0.5, 'A: DB5.5 single pair (200,200), k=10, 5-layer shared IEGMN hdim 64, 50 heads, fp32'),
-    'B': (8, (200, 200), 8, False, 0.75, 'B: DB5.5-sized batch of 8 pairs x (200,200) residues, k=10, 8-layer IEGMN hdim 64, 50 heads, fp32'),
-    'C': (64, (300, 300), 8, False, 0.75, 'C-fp32: DIPS-sized batch of 64 pairs x (300,300) residues, k=10, 8-layer IEGMN (fp32 arithmetic)'),
-    'E': (4, (2000, 2000), 8, False, 0.75, 'E: stress, 4 pairs x (2000,2000) residues, k=10, 8-layer IEGMN, fp32'),
+    # name: (pairs per GPU, (n_lig, n_rec), layers, shared, skip_weight_h, default dtype, description)
+    'A': (1, (200, 200), 5, True, 0.5, 'f32', 'A: DB5.5 single pair (200,200), k=10, 5-layer shared IEGMN hdim 64, 50 heads, fp32'),
+    'B': (8, (200, 200), 8, False, 0.75, 'f32', 'B: DB5.5-sized batch of 8 pairs x (200,200) residues, k=10, 8-layer IEGMN hdim 64, 50 heads, fp32'),
+    'C': (64, (300, 300), 8, False, 0.75, 'f32', 'C: DIPS-sized batch of 64 pairs x (300,300) residues, k=10, 8-layer IEGMN'),
+    'D': (64, (300, 300), 8, False, 0.75, 'bf16', 'D: DIPS-sized batch of 64 pairs x (300,300) per GPU (512 pairs on 8 GPUs), k=10, 8-layer IEGMN, data parallel'),
+    'E': (4, (2000, 2000), 8, False, 0.75, 'f32', 'E: stress, 4 pairs x (2000,2000) residues, k=10, 8-layer IEGMN, fp32'),
 }
 PEAK_FP32_TFLOPS = 157.3   # MI355X fp32 vector = fp32-input MFMA peak (MI355X_MICROARCH.md)
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA (MI355X_MICROARCH.md; no sparsity)
 PEAK_HBM_GBS = 8000.0      # HBM3E spec
 EDGE_FWD_FLOP_PER_EDGE = 38272          # SURVEY.md section 8d, layers >= 1, model as written
 EDGE_FWD_BYTES = lambda n, e: n * 540 + e * 112   # noqa: E731  SURVEY.md section 8d (fp32)
+
+
+def step_flops_as_written(sizes, L, d0=69, d=64, K=50):
+    """algorithmic FLOPs of ONE forward of the model as written (2 per MAC) for the given pair
+    sizes; forward + backward = 3x.  k = 10 in-edges per node."""
+    tot = 0.0
+    for nl, nr in sizes:
+        n, e = nl + nr, 10 * (nl + nr)
+        tot += e * 39552 + n * 74796 + 552.0 * nl * nr                       # layer 0 (d_in = 69)
+        tot += (L - 1) * (e * 38272 + n * 66176 + 512.0 * nl * nr)            # layers >= 1
+        tot += n * 424492 + 0.82e6                                            # keypoint head
+    return tot
+
+
+def kernel_work_model(sizes, L, n_nodes, n_edges, cross=True, d0=69, dh=64, d_emb=64, K=50):
+    """Per-STEP work of each kernel family, from the launch structure of eqd_model_forward / eqd_model_backward
+    (csrc/eqd_driver.hip): `flops` = FLOPs the kernel executes on the MFMA pipes for its GEMMs (2 per MAC),
+    `flops_written` = the model-as-written share where SURVEY.md section 8d defines one (edge kernels, attention),
+    `bytes` = algorithmic HBM bytes (every operand read once, every result written once; fp32).  DESIGN.md section 6
+    spells the formulas out."""
+    N, E = float(n_nodes), float(n_edges)
+    pp = sum(float(a) * b for a, b in sizes)              # sum over pairs of n_lig * n_rec
+    W = {k: dict(flops=0.0, flops_written=0.0, bytes=0.0) for k in
+         ('k_linear', 'k_rowchain', 'k_attn_fwd', 'k_attn_bwd', 'k_edge_fwd', 'k_edge_bwd', 'k_node_gather', 'k_atb')}
+    for l in range(L):
+        d = d0 if l == 0 else dh
+        da = (d + 15) // 16 * 16
+        # forward: five node projections (P, Q 64 wide; q, k, v d wide)
+        W['k_linear']['flops'] += N * 2 * d * (128 + 3 * d)
+        W['k_linear']['bytes'] += N * 4 * (d + 128 + 3 * da)
+        # forward row chain: node_mlp.0 (+LeakyReLU, LayerNorm) -> node_mlp.4 (+ skip)
+        W['k_rowchain']['flops'] += N * (2 * (d0 + 2 * d + 64) * d + 2 * d * 64)
+        W['k_rowchain']['bytes'] += N * 4 * (d + 64 + da + d0 + 2 * d + 64)
+        # backward row chain: dh of the layer above (6 transposed GEMMs), d a1n, LN/LReLU backward, 3 input gradients
+        if l < L - 1:
+            W['k_rowchain']['flops'] += N * 2 * 64 * (64 * 3 + 64 * 3)
+            W['k_rowchain']['bytes'] += N * 4 * (64 * 3 + 80 * 3 + 64 + 64)
+        W['k_rowchain']['flops'] += N * (2 * 64 * d + 2 * d * (64 + d + d_emb))
+        W['k_rowchain']['bytes'] += N * 4 * (64 + d + d + 64 + da + d0)
+        # attention (model as written: 8 Nl Nr d forward, 2x that backward; executed backward: S and dP are recomputed by
+        # both the dq and the dk/dv workgroups -> 28 Nl Nr d)
+        if cross:
+            W['k_attn_fwd']['flops'] += 8 * pp * da
+            W['k_attn_fwd']['flops_written'] += 8 * pp * d
+            W['k_attn_fwd']['bytes'] += N * 4 * (4 * da + 1)
+            W['k_attn_bwd']['flops'] += 28 * pp * da
+            W['k_attn_bwd']['flops_written'] += 16 * pp * d
+            W['k_attn_bwd']['bytes'] += N * 4 * (8 * da + 2)
+        # edge kernels (as written: 2 (2 d + 42) 64 + 2 64 64 + 2 64 64 + 2 64 per edge; executed: the P/Q split moves
+        # 2 (2 d) 64 per edge to k_linear - the executed count comes from the PMC file when present)
+        fe = 2 * (2 * d + 42) * 64 + 2 * 64 * 64 + 2 * 64 * 64 + 2 * 64
+        fx = 2 * 42 * 64 + 2 * 64 * 64 + 2 * 64 * 64 + 2 * 64
+        W['k_edge_fwd']['flops_written'] += E * fe
+        W['k_edge_fwd']['flops'] += E * fx
+        W['k_edge_fwd']['bytes'] += N * 540 + E * 112
+        W['k_edge_bwd']['flops_written'] += 2 * E * fe
+        W['k_edge_bwd']['flops'] += E * (3 * fx - 2 * 42 * 64)      # recompute + data gradients + weight gradients
+        W['k_edge_bwd']['bytes'] += 2 * (N * 540 + E * 112)
+        W['k_node_gather']['bytes'] += E * 272 + N * 540
+        # end-of-pass weight-gradient GEMMs of the node-level Linears
+        W['k_atb']['flops'] += N * 2 * (dh * d + d * d + d * 64 + (d * d if cross else 0) + d * d0 + 2 * 64 * d
+                                        + (3 * d * d if cross else 0))
+        W['k_atb']['bytes'] += N * 4 * (dh + d + d + 64 + da + d0 + 128 + d + 3 * da)
+    # head: mlp_h_mean_ROT forward, its data gradient, the final dh job of layer 0
+    W['k_linear']['flops'] += N * (2 * 64 * 64 * 2 + 2 * d_emb * (4 * d0 + 128))
+    W['k_linear']['bytes'] += N * 4 * (64 * 4 + 3 * 80 + 128 + d0 + 64)
+    W['k_atb']['flops'] += N * 2 * 64 * 64
+    return W
 
 
 class _BatchedLoss(torch.autograd.Function):
@@ -191,31 +266,160 @@ def edge_kernel_rooflines(net, packed, dev, workload='B', bf16=False):
     return out
 
 
-def cpu_baseline(args_model, sd, g_cpu, pairs_per_step):
-    """Oracle (reference op sequence, dense mask) fwd+bwd on the host cores."""
-    from oracle import iegmn_port as port
-    raw = port.raw_from_graph(g_cpu)
-    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    cores = torch.get_num_threads()
+def profile_step(compute, dev, reps=4):
+    """Per-kernel durations of ONE eager step, measured live with the library's launch profiler (eqd_profile_*: a HIP
+    event after every launch of the library, on the stream it launches on).  The step is enqueued behind a ~3 ms spin
+    kernel so that the host stays ahead of the GPU and consecutive events bracket kernel execution, not host gaps; the
+    cost of the event record itself is calibrated with empty intervals and subtracted.  Returns
+    ({name: [calls per step, us per step]}, event overhead us, launches per step)."""
+    from equidock_public_amd import _lib
+    lib = _lib.load_library()
+    stream = torch.cuda.current_stream(dev)
+    st = _lib.stream_ptr(dev)
+    compute()
+    torch.cuda.synchronize()
+    # empty-interval calibration: back-to-back event records behind a spin kernel
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(41)]
+    torch.cuda._sleep(4_000_000)
+    for e in evs:
+        e.record(stream)
+    torch.cuda.synchronize()
+    gaps = sorted(a.elapsed_time(b) * 1e3 for a, b in zip(evs[:-1], evs[1:]))
+    overhead = gaps[len(gaps) // 2]
+    acc, n_launch = {}, 0
+    for _ in range(reps):
+        torch.cuda._sleep(8_000_000)        # ~3-4 ms: longer than the host needs to enqueue one eager step
+        _lib.profiling = True
+        _lib.check(lib.eqd_profile_begin(st, 1024))
+        try:
+            compute()
+        finally:
+            n = lib.eqd_profile_end()
+            _lib.profiling = False
+        if n < 0:
+            raise RuntimeError('eqd_profile_end failed')
+        n_launch = n
+        for i in range(n):
+            nm = lib.eqd_profile_name(i).decode()
+            a = acc.setdefault(nm, [0, 0.0])
+            a[0] += 1
+            a[1] += max(0.0, lib.eqd_profile_us(i) - overhead)
+    return {k: [v[0] / reps, v[1] / reps] for k, v in acc.items()}, overhead, n_launch
 
-    def step():
-        for v in leaves.values():
-            v.grad = None
-        outs = port.forward(leaves, args_model, raw, faithful=True)
-        port.scalar_loss(outs).backward()
-    for _ in range(1):
-        step()
-    times = []
-    budget = time.perf_counter() + 25.0
-    while len(times) < 5 and (time.perf_counter() < budget or len(times) < 2):
-        t0 = time.perf_counter()
-        step()
-        times.append(time.perf_counter() - t0)
-    times.sort()
-    med = times[len(times) // 2]
-    return {"value": round(pairs_per_step / med, 3), "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": f"{len(times)} fwd+bwd steps of the same {pairs_per_step}-pair batch (median {med * 1e3:.0f} ms/step), "
-                      f"oracle/iegmn_port.py faithful mode, torch {torch.__version__} CPU"}
+
+def kernel_rooflines(prof, work, bf16, step_us, pmc):
+    """roofline_all: one entry per kernel family that takes >= 3 % of the step (plus the two edge kernels always)."""
+    out = {}
+    total = sum(v[1] for v in prof.values())
+    peak_tf = PEAK_BF16_TFLOPS if bf16 else PEAK_FP32_TFLOPS
+    for name, (calls, us) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
+        share = us / total if total > 0 else 0.0
+        w = work.get(name)
+        if w is None or (share < 0.03 and not name.startswith('k_edge')):
+            continue
+        t = us * 1e-6
+        tf_x = w['flops'] / t / 1e12
+        tf_w = w['flops_written'] / t / 1e12 if w['flops_written'] else None
+        gb = w['bytes'] / t / 1e9
+        e = {"calls_per_step": round(calls, 2), "us_per_step": round(us, 1), "avg_launch_us": round(us / calls, 2),
+             "share_of_kernel_time": round(share, 4),
+             "executed_flops_per_step": w['flops'], "executed_TFLOPs": round(tf_x, 2),
+             "executed_frac_of_mfma_peak": round(tf_x / peak_tf, 4),
+             "algorithmic_bytes_per_step": w['bytes'], "hbm_algorithmic_GBps": round(gb, 1),
+             "hbm_frac_algorithmic": round(gb / PEAK_HBM_GBS, 4)}
+        if tf_w is not None:
+            e["as_written_flops_per_step"] = w['flops_written']
+            e["as_written_TFLOPs"] = round(tf_w, 2)
+            e["as_written_frac_of_mfma_peak"] = round(tf_w / peak_tf, 4)
+        if w['flops'] == 0:
+            e["bound"] = "hbm"
+        else:
+            e["bound"] = "mfma" if tf_x / peak_tf >= gb / PEAK_HBM_GBS else "hbm"
+        for k, v in pmc.items():        # hardware counters of an earlier rocprofv3 --pmc pass (profiles/*.json)
+            if name in k and 'MfmaUtil' in v:
+                e.setdefault("pmc", {})[k] = {"MfmaUtil_pct": v['MfmaUtil'],
+                                              "executed_mfma_gflop_per_launch": v.get('executed_mfma_gflop_per_launch')}
+        out[name] = e
+    return out, total
+
+
+def physical_cores():
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
+
+
+def cpu_baseline(args_model, sd, pairs, budget_s=24.0):
+    """The oracle (oracle/iegmn_port.py: the reference's op sequence, pinned to the reference's golden vectors) timed on
+    the host cores, fwd + bwd of the fixed scalar loss, on a bounded sample of the workload's pairs:
+      value        the workload's batch composition (all pairs of the sample in ONE step, as the reference's DataLoader
+                   would hand them over) on all PHYSICAL cores;
+      one_thread   the same step with torch.set_num_threads(1);
+      b1_per_step  one pair per step on all physical cores - the reference's best case, because its dense batch-wide
+                   attention mask makes the per-pair cost grow with the batch.
+    Batches whose dense (sum n_lig x sum n_rec) mask would not be reasonable on the host (> 4000 x 4000) use the
+    oracle's block-diagonal mode - equal to the reference's result, cheaper than its arithmetic - and say so."""
+    from equidock_public_amd import graph
+    from oracle import iegmn_port as port
+    cores = physical_cores()
+    prev = torch.get_num_threads()
+
+    def run(ps, threads, budget, min_steps=2, max_steps=5):
+        torch.set_num_threads(threads)
+        g = graph.batch_pairs(ps)
+        raw = port.raw_from_graph(g)
+        faithful = sum(raw['lig_counts']) * sum(raw['rec_counts']) <= 16_000_000
+        leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+
+        def step():
+            for v in leaves.values():
+                v.grad = None
+            port.scalar_loss(port.forward(leaves, args_model, raw, faithful=faithful)).backward()
+        step()      # warm-up
+        times, end = [], time.perf_counter() + budget
+        while len(times) < min_steps or (len(times) < max_steps and time.perf_counter() < end):
+            t0 = time.perf_counter()
+            step()
+            times.append(time.perf_counter() - t0)
+        times.sort()
+        return len(ps) / times[len(times) // 2], len(times), faithful
+    try:
+        n = len(pairs)
+        # bounded sample: at most 8 pairs of the batch (and at most ~1600 residues in total per step on one thread)
+        sample = pairs[:min(n, 8)]
+        if sum(len(l['x']) + len(r['x']) for l, r in sample) > 9000:
+            sample = pairs[:1]
+        v_all, k_all, faithful = run(sample, cores, budget_s * 0.4)
+        v_one, k_one, _ = run(sample[:max(1, len(sample) // 4)], 1, budget_s * 0.3, min_steps=1, max_steps=3)
+        v_b1, k_b1, f1 = run(sample[:1], cores, budget_s * 0.3)
+    finally:
+        torch.set_num_threads(prev)
+    mode = "faithful mode (dense batch-wide mask)" if faithful else "block-diagonal mode (dense mask too large for the host)"
+    return {"value": round(v_all, 3), "unit": "pairs/s", "cores": cores, "kind": "port",
+            "one_thread": round(v_one, 3), "b1_per_step": round(v_b1, 3),
+            "sample": f"{len(sample)} of the workload's {n} pairs per GPU; value: {k_all} fwd+bwd steps of the {len(sample)}-pair "
+                      f"batch on {cores} threads (physical cores), {mode}; one_thread: {k_one} steps of "
+                      f"{max(1, len(sample) // 4)} pair(s) on 1 thread; b1_per_step: {k_b1} steps of 1 pair on {cores} "
+                      f"threads ({'faithful' if f1 else 'block-diagonal'}); oracle/iegmn_port.py, torch {torch.__version__} CPU"}
+
+
+def load_pmc(workload):
+    """MFMA utilisation / executed MFMA FLOPs per kernel from the newest committed PMC summary (profiles/*pmc_mfma*.json)."""
+    import glob
+    best = {}
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*pmc_mfma*.json'))):
+        try:
+            d = json.load(open(f)).get(workload)
+            if d:
+                best = {k: dict(v, source=os.path.basename(f)) for k, v in d.items()}
+        except Exception:
+            pass
+    return best
 
 
 def main():
@@ -224,11 +428,12 @@ def main():
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--workload', default='B', choices=sorted(WORKLOADS))
-    ap.add_argument('--dtype', default='f32', choices=('f32', 'bf16'),
-                    help='bf16: edge-message kernels in bf16 mode (he rows + GEMM inputs bf16, fp32 accumulate); the rest of the path stays fp32')
+    ap.add_argument('--dtype', default=None, choices=('f32', 'bf16'),
+                    help="arithmetic of the GEMMs: f32 (default for A, B, C, E) or bf16 inputs with fp32 accumulate "
+                         "(default for D; `--workload C --dtype bf16` is BASELINE.json configs[2])")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
-    ap.add_argument('--eager', action='store_true', help='launch every kernel of every step from the host instead of replaying a captured hipGraph of the step (zero-grad, forward, loss, backward; the gradient all-reduce always runs outside the graph).  Same kernels either way; the replay takes the host (torch autograd + ~110 launches, 0.7-1.5 ms depending on the box) off the critical path of a 1.5 ms step')
+    ap.add_argument('--eager', action='store_true', help='launch every kernel of every step from the host instead of replaying a captured hipGraph of the step (zero-grad, forward, loss, backward; the gradient all-reduce always runs outside the graph).  Same kernels either way; the replay takes the host (torch autograd + the launches, 0.7-1.5 ms depending on the box) off the critical path of a 1.5 ms step')
     ap.add_argument('--graph', action='store_true', help='(default; kept for older command lines)')
     a = ap.parse_args()
 
@@ -251,18 +456,18 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from equidock_public_amd import graph, model, parallel, synthetic
-    from oracle import iegmn_port as port   # only for default_args/init_state_dict + the cpu_baseline leg
+    from equidock_public_amd import config, graph, model, parallel, synthetic
 
-    ppg, (nl, nr), L, shared, skh, desc = WORKLOADS[a.workload]
-    args_model = port.default_args(iegmn_n_lays=L, shared_layers=shared, skip_weight_h=skh, device=dev)
-    if a.dtype == 'bf16':
+    ppg, (nl, nr), L, shared, skh, wl_dtype, desc = WORKLOADS[a.workload]
+    dtype = a.dtype or wl_dtype
+    args_model = config.published_args(iegmn_n_lays=L, shared_layers=shared, skip_weight_h=skh, device=dev)
+    if dtype == 'bf16':
         args_model['hip_storage_dtype'] = 'bf16'
-    sd = port.init_state_dict(args_model, seed=0)
+    sd = config.seeded_state_dict(args_model, seed=0)
     net = model.Rigid_Body_Docking_Net(args_model).to(dev)
     net.load_state_dict(sd)
-    pairs = synthetic.make_pairs([(nl, nr)] * ppg, seed=1000 + rank)
-    g_cpu = graph.batch_pairs(pairs)
+    sizes = [(nl, nr)] * ppg
+    pairs = synthetic.make_pairs(sizes, seed=1000 + rank)
     g = graph.batch_pairs(pairs).to(dev)
     packed = g.pack()
     lig_w = torch.cat([torch.full((n, 1), 1.0 / (3 * n)) for n in packed.lig_counts]).to(dev)
@@ -334,12 +539,13 @@ def main():
     out = None
     if rank == 0:
         total_pairs = ppg * world * a.steps
+        ms_step = dt / a.steps * 1e3
         out = {
             "metric": "protein-pairs/sec (fwd+bwd) per IEGMN stack", "value": round(total_pairs / dt, 2),
             "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if a.dtype == 'f32' else "bf16 edge-message GEMMs (fp32 accumulate) + f32 elsewhere",
+            "dtype": "f32" if dtype == 'f32' else "bf16 (GEMM inputs; fp32 accumulate, fp32 coordinates / statistics / softmax / Kabsch)",
             "data": "synthetic",
             "config": {"workload": desc, "pairs_per_gpu": ppg, "nodes_per_gpu": packed.n_nodes,
                        "edges_per_gpu": packed.n_edges, "layers": L, "parallelism": f"dp{world}",
@@ -347,14 +553,36 @@ def main():
                        "loss": float(loss.detach()), "svd_guard_pairs": svd_bad,
                        "host_enqueue_ms_per_step": round(host_dt / a.steps * 1e3, 4), "launch_mode": graph_mode},
         }
+        flops_step = 3.0 * step_flops_as_written(sizes, L)
+        peak_tf = PEAK_BF16_TFLOPS if dtype == 'bf16' else PEAK_FP32_TFLOPS
+        out["whole_step"] = {"as_written_flops_per_step": flops_step,
+                             "achieved_TFLOPs": round(flops_step / (ms_step * 1e-3) / 1e12, 2), "peak_TFLOPs": peak_tf,
+                             "frac": round(flops_step / (ms_step * 1e-3) / 1e12 / peak_tf, 4),
+                             "note": "SURVEY.md section 8d FLOPs of the model as written, fwd + bwd = 3x fwd, over ms_per_step"}
         if not a.no_roofline:
-            rl = edge_kernel_rooflines(net, packed, dev, a.workload, bf16=(a.dtype == 'bf16'))
+            rl = edge_kernel_rooflines(net, packed, dev, a.workload, bf16=(dtype == 'bf16'))
             dom = max(rl, key=lambda k: rl[k]["avg_launch_us"])
             out["roofline"] = dict(rl[dom], kernel=dom)
-            out["roofline_all"] = rl
+            try:
+                prof, ev_us, n_launch = profile_step(compute, dev)
+                work = kernel_work_model(sizes, L, packed.n_nodes, packed.n_edges)
+                allk, ktot = kernel_rooflines(prof, work, dtype == 'bf16', ms_step * 1e3, load_pmc(a.workload))
+                for k in ('k_edge_fwd', 'k_edge_bwd'):     # keep the standalone batched-launch figures beside the in-step ones
+                    if k in allk:
+                        allk[k]["standalone"] = rl[k]
+                out["roofline_all"] = allk
+                out["step_profile"] = {
+                    "library_launches_per_step": n_launch, "kernel_us_per_step": round(ktot, 1),
+                    "event_overhead_us_subtracted_per_launch": round(ev_us, 2),
+                    "us_per_step_by_kernel": {k: round(v[1], 1) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
+                    "method": "eqd_profile_* (HIP event after every library launch on the launch stream, eager step "
+                              "enqueued behind a spin kernel), mean of 4 steps"}
+            except Exception as e:      # the bench line must not die on the diagnostic part
+                out["roofline_all"] = rl
+                out["step_profile"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(port.default_args(iegmn_n_lays=L, shared_layers=shared,
-                                                                 skip_weight_h=skh), sd, g_cpu, ppg)
+            out["cpu_baseline"] = cpu_baseline(config.published_args(iegmn_n_lays=L, shared_layers=shared,
+                                                                     skip_weight_h=skh), sd, pairs)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

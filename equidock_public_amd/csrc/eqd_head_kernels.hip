@@ -362,6 +362,39 @@ int eqd_launch_qmean_bwd(const EqdGraph* g, int K, const float* dqm_part, float*
     return eqd_check_launch("k_qmean_bwd");
 }
 
+// Operator-level backward of eqd_keypoint_pool_fwd (the three launches the model's backward issues for this stage).
+extern "C" size_t eqd_keypoint_pool_bwd_workspace_bytes(const EqdGraph* g, int n_heads) {
+    if (!g || n_heads < 1) return 0;
+    const size_t N = (size_t)g->n_nodes, S = (size_t)2 * g->n_pairs, K = (size_t)n_heads;
+    return eqd_align_up(N * K * sizeof(float)) + 2 * eqd_align_up(S * K * 64 * sizeof(float)) + 256;
+}
+extern "C" int eqd_keypoint_pool_bwd(const EqdGraph* g, int n_heads, const float* Wk, const float* Wq,
+                                     const float* qmean, const float* qp, const float* u, const float* H, const float* Z,
+                                     const float* scores, const float* lse, const float* dY, float* dH, float* dZ,
+                                     float* dWk, float* dWq, float* d_hm, void* workspace, size_t ws_bytes,
+                                     void* stream) {
+    if (!g || !Wk || !Wq || !qmean || !qp || !u || !H || !Z || !scores || !lse || !dY || !dH || !dZ || !dWk || !dWq ||
+        !d_hm || !workspace) {
+        eqd_set_error("eqd_keypoint_pool_bwd: NULL argument");
+        return EQD_ERR_NULL;
+    }
+    EqdArena A(workspace, ws_bytes);
+    const size_t N = (size_t)g->n_nodes, S = (size_t)2 * g->n_pairs, K = (size_t)n_heads;
+    float* dscores = A.take<float>(N * K);
+    float* du = A.take<float>(S * K * 64);
+    float* dqm_part = A.take<float>(S * K * 64);
+    if (!A.ok) {
+        eqd_set_error("eqd_keypoint_pool_bwd: workspace too small (%zu needed)", A.off);
+        return EQD_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    int rc = eqd_launch_keypoint_bwd(g, n_heads, H, Z, scores, lse, u, dY, dscores, du, dH, dZ, st);
+    if (rc) return rc;
+    rc = eqd_launch_head_u_bwd(g, n_heads, Wk, Wq, qmean, qp, du, dWk, dWq, dqm_part, st);
+    if (rc) return rc;
+    return eqd_launch_qmean_bwd(g, n_heads, dqm_part, d_hm, st);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Kabsch: 3x3 SVD by one-sided Jacobi in fp64 (one thread per pair; singular values descending)
 // ---------------------------------------------------------------------------------------------

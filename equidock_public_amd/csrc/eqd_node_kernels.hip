@@ -75,6 +75,23 @@ extern "C" int eqd_profile_end(void) {
     }
     return P.n;
 }
+extern "C" int eqd_profile_mark(const char* label) {
+    // work of OTHER libraries on the stream since the last event (torch's loss kernels, fills) gets its own interval
+    static thread_local std::vector<char*> interned;
+    EqdProfiler& P = g_prof;
+    if (!P.on || P.n >= P.cap || !label) return EQD_OK;
+    const char* keep = nullptr;
+    for (char* s : interned)
+        if (strcmp(s, label) == 0) keep = s;
+    if (!keep) {
+        interned.push_back(strdup(label));
+        keep = interned.back();
+    }
+    P.name[P.n] = keep;
+    (void)hipEventRecord(P.ev[P.n + 1], P.st);
+    ++P.n;
+    return EQD_OK;
+}
 extern "C" const char* eqd_profile_name(int i) { return (i >= 0 && i < g_prof.n) ? g_prof.name[i] : ""; }
 extern "C" float eqd_profile_us(int i) { return (i >= 0 && i < g_prof.n) ? g_prof.us[i] : 0.f; }
 

@@ -158,6 +158,8 @@ class _IEGMNFunction(torch.autograd.Function):
         scratch = None if need_grad else torch.empty(wb, dtype=torch.uint8, device=dev)
         if svd_draws is not None:
             svd_draws = _lib.require_device(svd_draws.to(torch.float32).contiguous(), 'svd_draws')
+        if _lib.profiling:
+            lib.eqd_profile_mark(b'(before forward: zero-grad fill, allocations)')
         with _lib.device_guard(dev):        # kernels and memsets go to the tensors' device, whatever the current one is
             _lib.check(lib.eqd_model_forward(
                 C.byref(desc), C.byref(gs), ptrs, _lib.ptr(svd_draws), _lib.ptr(lig), _lib.ptr(Yl), _lib.ptr(Yr),
@@ -194,6 +196,8 @@ class _IEGMNFunction(torch.autograd.Function):
         def prep(t):
             return None if t is None else _lib.require_device(t.to(torch.float32).contiguous(), 'output gradient')
         d_lig, d_Yl, d_Yr, d_T, d_b = (prep(t) for t in (d_lig, d_Yl, d_Yr, d_T, d_b))
+        if _lib.profiling:
+            lib.eqd_profile_mark(b'(between forward and backward: the caller\'s loss + its autograd)')
         with _lib.device_guard(dev):
             _lib.check(lib.eqd_model_backward(
                 C.byref(desc), C.byref(gs), ptrs, _lib.ptr(d_lig), _lib.ptr(d_Yl), _lib.ptr(d_Yr), _lib.ptr(d_T),

@@ -62,9 +62,11 @@ int eqd_is_simulator(void);
  * number of launches seen (or -1); eqd_profile_name(i) / eqd_profile_us(i) give launch i's kernel name and the time
  * between the events before and after it - the kernel's duration when the stream was kept busy (enqueue the work
  * behind a long-running kernel so that the host is ahead of the GPU), plus one event-record of overhead that the
- * caller calibrates with an empty interval.  Not usable while the stream is being captured into a hipGraph. */
+ * caller calibrates with an empty interval.  eqd_profile_mark(label) records an event under `label` for work that was
+ * enqueued by someone else since the last event (e.g. the caller's loss kernels).  Not usable while the stream is being captured into a hipGraph. */
 int eqd_profile_begin(void* stream, int max_launches);
 int eqd_profile_end(void);
+int eqd_profile_mark(const char* label);   /* closes an interval for work other libraries enqueued on the stream */
 const char* eqd_profile_name(int i);
 float eqd_profile_us(int i);
 
@@ -243,6 +245,17 @@ int eqd_cross_attention_bwd(const EqdGraph* g, int d, const float* q, const floa
 int eqd_keypoint_pool_fwd(const EqdGraph* g, int n_heads, const float* Wk, const float* Wq, const float* qmean,
                           const float* H, const float* Z, float* Y, float* scores, float* lse,
                           float* qp, float* u, void* stream);
+
+/* Backward of eqd_keypoint_pool_fwd (autograd of rigid_docking_model.py:521-560).  Inputs: the forward's operands and
+ * saved outputs (scores, lse, qp, u) and dY [2B][K][3].  Outputs: dH [n_nodes][64], dZ [n_nodes][3] (written);
+ * d_hm [n_nodes][64] (written) = gradient w.r.t. the ROWS whose per-segment means are `qmean`, i.e.
+ * d qmean[seg(i)] / n_seg(i) for node i (the partner's keypoints consume qmean[seg]); dWk, dWq [K*64][64] are
+ * ACCUMULATED (the caller zeroes them).  Deterministic (no atomics). */
+size_t eqd_keypoint_pool_bwd_workspace_bytes(const EqdGraph* g, int n_heads);
+int eqd_keypoint_pool_bwd(const EqdGraph* g, int n_heads, const float* Wk, const float* Wq, const float* qmean,
+                          const float* qp, const float* u, const float* H, const float* Z, const float* scores,
+                          const float* lse, const float* dY, float* dH, float* dZ, float* dWk, float* dWq, float* d_hm,
+                          void* workspace, size_t ws_bytes, void* stream);
 
 /* Kabsch / 3x3 SVD (rigid_docking_model.py:563-589): per pair A = (Yr - mean)^T (Yl - mean),
  * T = U diag(1,1,sign det A) V^T, b = mean_r - T mean_l.  Y: [2B][K][3].  A_out [B][9] is the

@@ -68,7 +68,8 @@ def oracle_reference(sd, args, raw, faithful=True, loss_fn=None, kink_aware=True
     def run(mode):
         port.Kink.mode, port.Kink.near = mode, 0
         try:
-            leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+            uniq = {}       # shared layers: one leaf per distinct tensor, so that its gradient is the sum over the layers
+            leaves = {k: uniq.setdefault(id(v), v.clone().requires_grad_(True)) for k, v in sd.items()}
             outs = port.forward(leaves, args, raw, faithful=faithful)
             loss_fn(outs).backward()
             return outs, {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaves.items()}, \
@@ -463,6 +464,37 @@ def check_keypoints_and_apply(dev):
             F.linear(H[n0:n1], Wk).view(-1, K, 64).transpose(0, 1) @
             F.linear(qmean[partner:partner + 1], Wq).view(1, K, 64).transpose(0, 1).transpose(1, 2) / 8.0, dim=1).view(K, -1)
         close(Y[s], att @ Z[n0:n1], what=f'keypoints segment {s}')
+    # operator-level backward (eqd_keypoint_pool_bwd) against torch autograd of the as-written 64 -> K*64 projections,
+    # with qmean expressed as the per-segment mean of rows hm so that d_hm is checked too
+    hm = torch.randn(N, 64)
+    leaves = [t.clone().requires_grad_(True) for t in (Wk, Wq, hm, H, Z)]
+    Wk_, Wq_, hm_, H_, Z_ = leaves
+    qm_ = torch.stack([hm_[seg[s]:seg[s + 1]].mean(0) for s in range(2 * B)])
+    dYr = torch.randn(2 * B, K, 3)
+    tot = 0.
+    for s in range(2 * B):
+        partner = s + B if s < B else s - B
+        n0, n1 = seg[s], seg[s + 1]
+        att = torch.softmax(
+            F.linear(H_[n0:n1], Wk_).view(-1, K, 64).transpose(0, 1) @
+            F.linear(qm_[partner:partner + 1], Wq_).view(1, K, 64).transpose(0, 1).transpose(1, 2) / 8.0, dim=1).view(K, -1)
+        tot = tot + ((att @ Z_[n0:n1]) * dYr[s]).sum()
+    tot.backward()
+    qmd = qm_.detach().to(dev).contiguous()
+    L.check(lib().eqd_keypoint_pool_fwd(C.byref(gs), K, P(dd[0]), P(dd[1]), P(qmd), P(dd[3]), P(dd[4]), P(Y), P(scores),
+                                        P(lse), P(qp), P(u), st(dev)))
+    wsb = lib().eqd_keypoint_pool_bwd_workspace_bytes(C.byref(gs), K)
+    ws = torch.zeros(wsb, dtype=torch.uint8, device=dev)
+    dH, dZ, dhm = torch.zeros(N, 64, device=dev), torch.zeros(N, 3, device=dev), torch.zeros(N, 64, device=dev)
+    dWk, dWq = torch.zeros(K * 64, 64, device=dev), torch.zeros(K * 64, 64, device=dev)
+    dYd = dYr.to(dev).contiguous()
+    L.check(lib().eqd_keypoint_pool_bwd(C.byref(gs), K, P(dd[0]), P(dd[1]), P(qmd), P(qp), P(u), P(dd[3]), P(dd[4]),
+                                        P(scores), P(lse), P(dYd), P(dH), P(dZ), P(dWk), P(dWq), P(dhm), P(ws),
+                                        C.c_size_t(wsb), st(dev)))
+    sync(dev)
+    for nm, a, b in (('dWk', dWk, Wk_.grad), ('dWq', dWq, Wq_.grad), ('d_hm', dhm, hm_.grad), ('dH', dH, H_.grad),
+                     ('dZ', dZ, Z_.grad)):
+        grad_close(a, b, what=f'keypoint pool backward {nm}', l2=1e-4, mx=1e-4)
     # rigid apply + its backward
     T = torch.randn(B, 3, 3)
     bb = torch.randn(B, 3)
