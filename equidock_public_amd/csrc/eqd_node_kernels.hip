@@ -6,6 +6,7 @@
 #include "eqd_common.h"
 #include "eqd_linear_inl.h"
 
+#include <mutex>
 #include <vector>
 
 #include <stdarg.h>
@@ -37,10 +38,14 @@ struct EqdProfiler {
     std::vector<float> us;
     int n = 0, cap = 0;
 };
-thread_local EqdProfiler g_prof;
+// process-wide (torch runs the backward on its autograd thread, not on the thread that called eqd_profile_begin);
+// only launches on the profiled stream are recorded
+EqdProfiler g_prof;
+std::mutex g_prof_mu;
 }  // namespace
 
 extern "C" int eqd_profile_begin(void* stream, int max_launches) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     EqdProfiler& P = g_prof;
     if (P.on || max_launches < 1) {
         eqd_set_error("eqd_profile_begin: already profiling, or max_launches < 1");
@@ -64,6 +69,7 @@ extern "C" int eqd_profile_begin(void* stream, int max_launches) {
     return EQD_OK;
 }
 extern "C" int eqd_profile_end(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     EqdProfiler& P = g_prof;
     if (!P.on) return 0;
     P.on = false;
@@ -77,7 +83,8 @@ extern "C" int eqd_profile_end(void) {
 }
 extern "C" int eqd_profile_mark(const char* label) {
     // work of OTHER libraries on the stream since the last event (torch's loss kernels, fills) gets its own interval
-    static thread_local std::vector<char*> interned;
+    static std::vector<char*> interned;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     EqdProfiler& P = g_prof;
     if (!P.on || P.n >= P.cap || !label) return EQD_OK;
     const char* keep = nullptr;
@@ -102,10 +109,13 @@ int eqd_check_launch(const char* what) {
         return EQD_ERR_LAUNCH;
     }
     EqdProfiler& P = g_prof;
-    if (P.on && P.n < P.cap) {
-        P.name[P.n] = what;
-        (void)hipEventRecord(P.ev[P.n + 1], P.st);
-        ++P.n;
+    if (P.on) {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        if (P.on && P.n < P.cap) {
+            P.name[P.n] = what;
+            (void)hipEventRecord(P.ev[P.n + 1], P.st);
+            ++P.n;
+        }
     }
     return EQD_OK;
 }

@@ -14,7 +14,8 @@
  *   - every pointer is a DEVICE pointer (HBM) unless stated otherwise; fp32 is `float`,
  *     indices are int32; row-major, leading dimension given where it is not the width;
  *   - ownership: the caller owns every buffer including workspaces; the library allocates
- *     nothing persistent and keeps no global mutable state except a thread-local error string;
+ *     nothing persistent and keeps no global mutable state except a thread-local error string (and the
+ *     optional launch profiler below);
  *   - every function enqueues its work on `stream` (a hipStream_t passed as void*) and returns
  *     without synchronising; return value 0 = EQD_OK, otherwise an EQD_ERR_* code, and
  *     eqd_last_error() describes it.  Nothing throws or exits across this boundary (the
@@ -56,8 +57,8 @@ int eqd_tile_edges(void);
 int eqd_is_simulator(void);
 
 /* ---- per-launch timing (measurement aid for bench.py; nothing in the reference corresponds to it) ----
- * Between eqd_profile_begin(stream, max) and eqd_profile_end() every kernel this library launches FROM THE CALLING
- * THREAD is followed by a hipEventRecord on `stream` (pass the stream the model runs on; hipMemsetAsync fills are
+ * Between eqd_profile_begin(stream, max) and eqd_profile_end() every kernel this library launches (from any thread:
+ * torch runs the backward on its autograd thread) is followed by a hipEventRecord on `stream` (pass the stream the model runs on; hipMemsetAsync fills are
  * not recorded and count towards the next launch).  eqd_profile_end() synchronises the last event and returns the
  * number of launches seen (or -1); eqd_profile_name(i) / eqd_profile_us(i) give launch i's kernel name and the time
  * between the events before and after it - the kernel's duration when the stream was kept busy (enqueue the work

@@ -25,7 +25,7 @@ prof)
     rocprofv3 --kernel-trace --stats -d /tmp/prof_$W -o h -- python $R/bench.py --workload $W --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > $O/${TAG}_prof_$W.log 2>&1
     DB=$(find /tmp/prof_$W -name "*.db" | head -1)
     python $R/profiles/summarize.py $DB $O/${TAG}_kernels_$W.md "round 2 (${TAG}): workload $W, fp32" "rocprofv3 --kernel-trace --stats -- python bench.py --workload $W --steps 20 --warmup 5 --no-cpu-baseline --no-roofline" > $O/${TAG}_kernels_$W.txt 2>&1
-    python $R/profiles/timeline.py $DB > $O/${TAG}_timeline_$W.txt 2>&1
+    python $R/profiles/timeline.py $DB 130 > $O/${TAG}_timeline_$W.txt 2>&1
   done
   cd $R ;;
 profbf16)

@@ -122,7 +122,7 @@ def test_option_toggles_vs_oracle(dev, over):
     """every `args` switch the HIP path advertises, outputs + all gradients vs the oracle"""
     from tests import parity_common as pc
     pc.check_model_vs_oracle(dev, [(23, 31), (40, 17), (130, 77)], layers=3, seed=5, pair_seed=7, args_over=over,
-                             what=str(over))
+                             what=str(over), l2=pc.GRAD_L2_SMALL, mx=pc.GRAD_MX_SMALL)
 
 
 def test_pair_losses(dev):

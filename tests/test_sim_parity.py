@@ -101,7 +101,8 @@ def test_model_vs_oracle_ragged():
                          ids=lambda o: '+'.join(f'{k}={v}' for k, v in o.items()))
 def test_option_toggles_vs_oracle(over):
     """every `args` switch the HIP path advertises, outputs + all gradients vs the oracle"""
-    pc.check_model_vs_oracle(DEV, [(23, 31), (40, 17)], layers=3, seed=5, pair_seed=7, args_over=over, what=str(over))
+    pc.check_model_vs_oracle(DEV, [(23, 31), (40, 17)], layers=3, seed=5, pair_seed=7, args_over=over, what=str(over),
+                             l2=pc.GRAD_L2_SMALL, mx=pc.GRAD_MX_SMALL)
 
 
 def test_pair_losses():
