@@ -482,13 +482,29 @@ def main():
     packed = g.pack()
     lig_w = torch.cat([torch.full((n, 1), 1.0 / (3 * n)) for n in packed.lig_counts]).to(dev)
     reducer = parallel.FlatGradAllReduce(net)
+    from equidock_public_amd import losses
+    scalar_loss = losses.ScalarLoss(packed, args_model['num_att_heads'])
 
     def compute():
+        # zero grads -> forward -> fixed scalar loss (value + its gradient w.r.t. the outputs: ONE launch, eqd_scalar_loss)
+        # -> backward of the model from those output gradients (== loss.backward())
+        reducer.zero()
+        lig, Yl, Yr, T, b = net.forward_batched(g)
+        loss, grads = scalar_loss(lig, Yl, Yr)
+        torch.autograd.backward([lig, Yl, Yr], list(grads))
+        return loss
+
+    def compute_torch_loss():      # the same step with the loss written in torch ops (cross-check of the fused kernel)
         reducer.zero()
         lig, Yl, Yr, T, b = net.forward_batched(g)
         loss = batched_loss(lig, Yl, Yr, lig_w)
         loss.backward()
         return loss
+    l_ref = float(compute_torch_loss())
+    g_ref = reducer.flat.clone()
+    l_got = float(compute())
+    if abs(l_got - l_ref) > 1e-5 * abs(l_ref) or float((reducer.flat - g_ref).abs().max()) > 1e-5 * float(g_ref.abs().max()):
+        raise SystemExit(f"fused scalar loss disagrees with its torch formulation: {l_got} vs {l_ref}")
 
     # Default: capture zero-grad -> forward -> loss -> backward ONCE into a hipGraph and replay it every step (every
     # kernel still runs every step; the RCCL all-reduce of the flat gradient stays outside the graph).  --eager launches

@@ -181,3 +181,64 @@ extern "C" int eqd_pair_losses_bwd(const EqdGraph* g, const float* lig_pred, con
                        g->n_lig, lig_pred, lig_target, rec, sigma, surface_ct, s_lig, s_rec, d_mse, d_inter, d_lig_pred);
     return eqd_check_launch("k_pair_losses_bwd");
 }
+
+// ---------------------------------------------------------------------------------------------
+// Fixed scalar loss of the measurement harness (oracle.iegmn_port.scalar_loss):
+//   loss = sum_p [ mean(lig_p^2) + mean(Yl_p^2) + mean(Yr_p^2) ]
+// value AND gradients w.r.t. the three outputs in ONE launch (written out from the obvious torch expression it is
+// ~27 elementwise / reduction launches, a visible share of a 1.4 ms step).  One workgroup per pair; the per-pair sums
+// are added in pair order by the last workgroup to finish (deterministic).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(EQD_BLOCK) void k_scalar_loss(const int32_t* __restrict__ seg_off, int B, int K,
+                                                           const float* __restrict__ lig, const float* __restrict__ Yl,
+                                                           const float* __restrict__ Yr, float* __restrict__ d_lig,
+                                                           float* __restrict__ d_Yl, float* __restrict__ d_Yr,
+                                                           float* __restrict__ pair_loss, float* __restrict__ loss,
+                                                           int* __restrict__ counter) {
+    __shared__ float red[EQD_WAVES];
+    __shared__ int last;
+    const int p = blockIdx.x, t = threadIdx.x;
+    const int l0 = 3 * seg_off[p], l1 = 3 * seg_off[p + 1];
+    const float cl = l1 > l0 ? 1.f / (float)(l1 - l0) : 0.f, cy = 1.f / (float)(3 * K);
+    float acc = 0.f;
+    for (int i = l0 + t; i < l1; i += EQD_BLOCK) {
+        const float v = lig[i];
+        acc += v * v * cl;
+        d_lig[i] = 2.f * cl * v;
+    }
+    for (int i = t; i < 3 * K; i += EQD_BLOCK) {
+        const size_t o = (size_t)p * 3 * K + i;
+        const float a = Yl[o], b = Yr[o];
+        acc += (a * a + b * b) * cy;
+        d_Yl[o] = 2.f * cy * a;
+        d_Yr[o] = 2.f * cy * b;
+    }
+    acc = wave_sum(acc);
+    if ((t & 63) == 0) red[t >> 6] = acc;
+    __syncthreads();
+    if (t == 0) {
+        pair_loss[p] = (red[0] + red[1]) + (red[2] + red[3]);
+        __threadfence();
+        last = atomicAdd(counter, 1) == B - 1;
+    }
+    __syncthreads();
+    if (last && t == 0) {
+        __threadfence();
+        float s = 0.f;
+        for (int i = 0; i < B; ++i) s += ((volatile float*)pair_loss)[i];
+        *loss = s;
+        *counter = 0;       // ready for the next launch (hipGraph replays re-run the kernel with the same buffers)
+    }
+}
+extern "C" int eqd_scalar_loss(const EqdGraph* g, int n_heads, const float* lig, const float* Y_lig, const float* Y_rec,
+                               float* d_lig, float* d_Ylig, float* d_Yrec, float* pair_loss, float* loss,
+                               int32_t* counter, void* stream) {
+    if (!g || !lig || !Y_lig || !Y_rec || !d_lig || !d_Ylig || !d_Yrec || !pair_loss || !loss || !counter) {
+        eqd_set_error("eqd_scalar_loss: NULL argument");
+        return EQD_ERR_NULL;
+    }
+    if (g->n_pairs <= 0 || n_heads < 1) return EQD_OK;
+    hipLaunchKernelGGL(k_scalar_loss, dim3(g->n_pairs), dim3(EQD_BLOCK), 0, (hipStream_t)stream, g->seg_off, g->n_pairs,
+                       n_heads, lig, Y_lig, Y_rec, d_lig, d_Ylig, d_Yrec, pair_loss, loss, counter);
+    return eqd_check_launch("k_scalar_loss");
+}

@@ -98,3 +98,41 @@ def compute_body_intersection_loss(model_ligand_coors_deform, bound_receptor_rep
     g = _SegmentsOnly(a.shape[0], r.shape[0], a.device)
     _, inter = _PairLosses.apply(g, a, a.detach(), r, float(sigma), float(surface_ct))
     return inter[0]
+
+
+class ScalarLoss:
+    """Fixed scalar loss of the measurement harness: sum over pairs of mean(lig'^2) + mean(Yl^2) +
+    mean(Yr^2) on the batched model outputs, value AND gradients w.r.t. the outputs in ONE launch (eqd_scalar_loss).
+
+        sl = ScalarLoss(packed, n_heads)
+        loss, grads = sl(lig, Yl, Yr)                       # 0-d tensor, (d_lig, d_Yl, d_Yr)
+        torch.autograd.backward([lig, Yl, Yr], grads)        # == loss.backward() of the torch expression
+
+    Buffers are allocated once, so the call is capturable in a hipGraph."""
+
+    def __init__(self, packed, n_heads):
+        dev = packed.x0.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.packed, self.K = packed, int(n_heads)
+        B = packed.n_pairs
+        self.d_lig = torch.empty(packed.n_lig, 3, **f32)
+        self.d_Yl = torch.empty(B, self.K, 3, **f32)
+        self.d_Yr = torch.empty(B, self.K, 3, **f32)
+        self.pair_loss = torch.empty(B, **f32)
+        self.loss = torch.zeros((), **f32)
+        self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def __call__(self, lig, Yl, Yr):
+        lib = _lib.load_library()
+        dev = self.d_lig.device
+        for t, ref in ((lig, self.d_lig), (Yl, self.d_Yl), (Yr, self.d_Yr)):
+            _lib.require_device(t, 'model output')
+            if t.shape != ref.shape or t.dtype != torch.float32 or not t.is_contiguous():
+                raise _lib.EquidockHipError("ScalarLoss: outputs must be contiguous fp32 tensors of the batch's shapes")
+        gs = self.packed.c_struct()
+        with _lib.device_guard(dev):
+            _lib.check(lib.eqd_scalar_loss(C.byref(gs), self.K, _lib.ptr(lig.detach()), _lib.ptr(Yl.detach()),
+                                           _lib.ptr(Yr.detach()), _lib.ptr(self.d_lig), _lib.ptr(self.d_Yl),
+                                           _lib.ptr(self.d_Yr), _lib.ptr(self.pair_loss), _lib.ptr(self.loss),
+                                           _lib.ptr(self.counter), _lib.stream_ptr(dev)))
+        return self.loss, (self.d_lig, self.d_Yl, self.d_Yr)

@@ -290,6 +290,15 @@ int eqd_pair_losses_bwd(const EqdGraph* g, const float* lig_pred, const float* l
                         float sigma, float surface_ct, const float* s_lig, const float* s_rec, const float* d_mse,
                         const float* d_inter, float* d_lig_pred, void* stream);
 
+/* Fixed scalar loss of the measurement harness (bench.py, __graft_entry__.smoke):
+ *   loss = sum over pairs of mean(lig_p^2) + mean(Y_lig_p^2) + mean(Y_rec_p^2)
+ * together with its gradients w.r.t. the three model outputs, in one launch (deterministic).  lig [n_lig][3],
+ * Y_* [n_pairs][n_heads][3]; pair_loss [n_pairs] scratch; counter: one int32 that must be 0 before the first call
+ * (the kernel resets it).  Nothing in the reference corresponds to it: its training losses are eqd_pair_losses_*. */
+int eqd_scalar_loss(const EqdGraph* g, int n_heads, const float* lig, const float* Y_lig, const float* Y_rec,
+                    float* d_lig, float* d_Ylig, float* d_Yrec, float* pair_loss, float* loss, int32_t* counter,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -782,3 +782,23 @@ def check_coords_reread(dev):
     assert not torch.equal(a[0], b[0])
     for x, y in zip(b, c):
         assert torch.equal(x, y)
+
+
+def check_scalar_loss(dev):
+    """eqd_scalar_loss (value + output gradients in one launch) against the oracle's scalar_loss differentiated by autograd."""
+    from equidock_public_amd import losses
+    g, pk, gs = small_graph(dev, sizes=((40, 33), (25, 61), (1, 7)), degrade=False)
+    torch.manual_seed(12)
+    B, K = pk.n_pairs, 50
+    lig, Yl, Yr = torch.randn(pk.n_lig, 3) * 7, torch.randn(B, K, 3) * 3, torch.randn(B, K, 3) * 4
+    leaves = [t.clone().requires_grad_(True) for t in (lig, Yl, Yr)]
+    ref = port.scalar_loss((list(torch.split(leaves[0], pk.lig_counts)), list(leaves[1]), list(leaves[2]), None, None))
+    ref.backward()
+    sl = losses.ScalarLoss(pk, K)
+    dd = [t.to(dev) for t in (lig, Yl, Yr)]
+    for _ in range(2):          # the second call checks that the completion counter was reset
+        loss, grads = sl(*dd)
+        sync(dev)
+        close(loss, ref, tol=1e-6, what='scalar loss')
+        for a, b, nm in zip(grads, leaves, ('d_lig', 'd_Yl', 'd_Yr')):
+            close(a, b.grad, tol=1e-6, what=f'scalar loss {nm}')
