@@ -64,6 +64,36 @@ def _lrelu(x, slope):
     return torch.where(near, x * (1.0 if Kink.mode == 'pos' else slope), y)
 
 
+class Bf16Mode:
+    """Rounding points of the HIP path's bf16 mode (`hip_storage_dtype='bf16'`), restated so that the
+    whole model can be held to a tight tolerance in that mode too: GEMM INPUTS are rounded to bf16 (round to nearest
+    even), products are accumulated in fp32, everything else (coordinates, RBFs before the GEMM, LayerNorm statistics,
+    softmax, biases, Kabsch) stays fp32 - i.e. the arithmetic of v_mfma_f32_16x16x16_bf16.  Rounding is the identity for
+    autograd (the kernels' backward GEMMs round their own operands, which a CPU autograd cannot mirror: gradients are
+    compared at bf16 resolution).  `edge`: the edge-message MLPs (first Linear split into fp32 node terms P[src] + Q[dst]
+    plus a bf16 GEMM over [he, rbf]; W2 and Wc1 GEMMs with bf16 inputs).  Not a reference option."""
+    edge = False
+
+
+def rb16(t):
+    """bf16 rounding of a GEMM input, identity for autograd"""
+    return t + (t.to(torch.bfloat16).to(torch.float32) - t).detach()
+
+
+def _edge_mlps_bf16(sd, pfx, slope, h, src, dst, he, rbf):
+    """edge_mlp + coors_mlp of one edge type with the bf16 mode's rounding points (see Bf16Mode)."""
+    W1, b1 = sd[pfx + 'edge_mlp.0.weight'], sd[pfx + 'edge_mlp.0.bias']
+    d = h.shape[1]
+    Pn = F.linear(h, W1[:, :d])
+    Qn = F.linear(h, W1[:, d:2 * d], b1)
+    z1 = Pn[src] + Qn[dst] + rb16(torch.cat([he, rbf], 1)) @ rb16(W1[:, 2 * d:]).t()
+    a1 = F.layer_norm(_lrelu(z1, slope), (z1.shape[1],), sd[pfx + 'edge_mlp.3.weight'], sd[pfx + 'edge_mlp.3.bias'], 1e-5)
+    msg = rb16(a1) @ rb16(sd[pfx + 'edge_mlp.4.weight']).t() + sd[pfx + 'edge_mlp.4.bias']
+    ch = rb16(msg) @ rb16(sd[pfx + 'coors_mlp.0.weight']).t() + sd[pfx + 'coors_mlp.0.bias']
+    coef = F.linear(_lrelu(ch, slope), sd[pfx + 'coors_mlp.4.weight'], sd[pfx + 'coors_mlp.4.bias'])
+    return msg, coef
+
+
 def _mlp5(x, sd, prefix, slope, norm):
     """Linear -> Dropout(p=0) -> LeakyReLU -> LayerNorm/Identity -> Linear
     (edge_mlp :119-125, node_mlp :142-148, coors_mlp :153-159)."""
@@ -125,9 +155,12 @@ def iegmn_layer(sd, pfx, args, d_in, raw, x_l, h_l, h0_l, he_l, x0_l, x_r, h_r, 
         rbf = torch.cat([torch.exp(-d2 / s) for s in RBF_SIGMAS], dim=-1)    # :210
         if not args['use_dist_in_layers']:
             rbf = rbf * 0.                                                   # :216-218
-        cat = torch.cat([h[src], h[dst], he, rbf], dim=-1)                   # :226-234
-        msg = _mlp5(cat, sd, pfx + 'edge_mlp', slope, args['layer_norm'])    # :236-237
-        coef = _mlp5(msg, sd, pfx + 'coors_mlp', slope, args['layer_norm_coors'])   # :263-265
+        if Bf16Mode.edge:
+            msg, coef = _edge_mlps_bf16(sd, pfx, slope, h, src, dst, he, rbf)
+        else:
+            cat = torch.cat([h[src], h[dst], he, rbf], dim=-1)               # :226-234
+            msg = _mlp5(cat, sd, pfx + 'edge_mlp', slope, args['layer_norm'])    # :236-237
+            coef = _mlp5(msg, sd, pfx + 'coors_mlp', slope, args['layer_norm_coors'])   # :263-265
         n = x.shape[0]
         msgs[side] = dict(x_update=_mean_by_dst(x_rel * coef, dst, n),       # :274-277
                           aggr_msg=_mean_by_dst(msg, dst, n))                # :280-283

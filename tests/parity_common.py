@@ -59,6 +59,15 @@ def grad_close(got, ref, what='', l2=1e-3, mx=1e-2):
     assert e2 <= l2 and em <= mx, f'{what}: rel-L2 {e2:.3e} (<= {l2}), max-abs/max {em:.3e} (<= {mx})'
 
 
+# bf16 mode (hip_storage_dtype='bf16') against the oracle evaluated with the SAME rounding points (oracle.iegmn_port.Bf16Mode):
+# outputs to 2e-3 of their scale (an input that differs by one fp32 ulp between the two evaluations can round to the OTHER
+# bf16 neighbour, a 2^-9 relative step on one of a dot product's inputs; measured 5e-4 .. 8e-4 on small batches, against
+# 1.5e-2 when compared with the fp32 result); gradients to 1 % rel-L2 / 3 % max-abs - the kernels' backward GEMMs round
+# their own operands to bf16, which the oracle's fp32 autograd of the rounded forward does not mirror (measured 1.2e-3 ..
+# 3.3e-3 / 4.7e-3 .. 1.0e-2).  The previous bounds against the fp32 golden vectors were 3e-2 / 0.2 / 0.5.
+BF16_OUT_TOL, BF16_GRAD_L2, BF16_GRAD_MX = 2e-3, 1e-2, 3e-2
+
+
 def oracle_reference(sd, args, raw, faithful=True, loss_fn=None, kink_aware=True):
     """Oracle outputs + parameter gradients of the fixed scalar loss, plus the element-wise hull [lo, hi] of the gradient
     over the slope choices of LeakyReLU pre-activations that lie within fp32 rounding of 0 (oracle.iegmn_port.Kink).
@@ -112,12 +121,21 @@ def grad_close_hull(got, ref, lo, hi, what='', l2=GRAD_L2, mx=GRAD_MX):
 
 
 def check_model_vs_oracle(dev, sizes, layers=8, seed=3, pair_seed=33, faithful=True, what='', args_over=None,
-                          l2=GRAD_L2, mx=GRAD_MX, tol=1e-4, report=None):
+                          l2=GRAD_L2, mx=GRAD_MX, tol=1e-4, report=None, bf16=False):
     """Whole model (outputs + every parameter gradient of the fixed scalar loss) on seeded synthetic pairs of the given
-    sizes against the oracle on the host; gradients kink-aware (oracle_reference)."""
+    sizes against the oracle on the host; gradients kink-aware (oracle_reference).  bf16=True: the HIP path in its bf16
+    mode against the oracle with the same rounding points."""
     args = port.default_args(**dict(dict(iegmn_n_lays=layers, skip_weight_h=0.75), **(args_over or {})))
     sd = port.init_state_dict(args, seed=seed)
-    net = build_model(args, sd, dev)
+    net = build_model(dict(args, hip_storage_dtype='bf16') if bf16 else args, sd, dev)
+    port.Bf16Mode.edge = bool(bf16)
+    try:
+        return _check_model_vs_oracle(dev, net, args, sd, sizes, layers, pair_seed, faithful, what, l2, mx, tol, report)
+    finally:
+        port.Bf16Mode.edge = False
+
+
+def _check_model_vs_oracle(dev, net, args, sd, sizes, layers, pair_seed, faithful, what, l2, mx, tol, report):
     pairs = synthetic.make_pairs(list(sizes), pair_seed)
     g = G.batch_pairs(pairs).to(dev)
     outs = net(g, epoch=0)
@@ -582,26 +600,25 @@ def check_model_case(dev, name, check_grads=True):
 
 
 def check_model_bf16(dev, name):
-    """hip_storage_dtype='bf16' (edge-message kernels in bf16 mode) against the fp32 golden vectors at bf16-sized
-    tolerances: outputs 3 % of their scale, rotation 2e-2, loss 0.5 %, parameter gradients 20 % rel-L2 (the sharp
-    x40 ROT softmax amplifies the 4e-3 input rounding through the layers; measured 1.5 %, 6e-3, 0.04 %, 10 %)."""
+    """hip_storage_dtype='bf16' on a golden case's inputs against the oracle evaluated with the same rounding points
+    (oracle.iegmn_port.Bf16Mode) at BF16_OUT_TOL / BF16_GRAD_*; and, loosely, against the fp32 golden outputs (3 %)."""
     z, meta, args, raw = load_case(name)
     sd = state_dict_for(meta, args)
     net = build_model(dict(args, hip_storage_dtype='bf16'), sd, dev)
     g = G.batch_pairs(pairs_from_raw(raw)).to(dev)
     outs = net(g, epoch=0)
-    for nm, lst in zip(('lig', 'Yl', 'Yr', 'T', 'b'), outs):
-        ref = torch.from_numpy(z['out_' + nm])
-        got = cat_out(lst).detach().cpu()
-        tol = 2e-2 if nm == 'T' else 3e-2 * max(1.0, float(ref.abs().max()))
-        assert float((got - ref).abs().max()) <= tol, f'{name} bf16 {nm}: {float((got - ref).abs().max()):.3e} > {tol:.1e}'
-    loss = port.scalar_loss(outs)
-    loss.backward()
+    port.scalar_loss(outs).backward()
     sync(dev)
-    assert abs(float(loss) - float(z['loss'])) <= 5e-3 * abs(float(z['loss']))
+    port.Bf16Mode.edge = True
+    try:
+        ref, grads, lo, hi, _ = oracle_reference(sd, args, raw, faithful=True)
+    finally:
+        port.Bf16Mode.edge = False
+    for nm, a, b in zip(('lig', 'Yl', 'Yr', 'T', 'b'), outs, ref):
+        close(cat_out(a), cat_out(b), tol=BF16_OUT_TOL, what=f'{name} bf16 {nm} vs bf16 oracle')
+        close(cat_out(a), torch.from_numpy(z['out_' + nm]), tol=3e-2, what=f'{name} bf16 {nm} vs fp32 golden')
     for k, p in net.named_parameters():
-        if 'grad_' + k in z.files:
-            grad_close(p.grad, torch.from_numpy(z['grad_' + k]), what=f'{name} bf16 grad {k}', l2=0.2, mx=0.5)
+        grad_close_hull(p.grad, grads[k], lo[k], hi[k], what=f'{name} bf16 grad {k}', l2=BF16_GRAD_L2, mx=BF16_GRAD_MX)
 
 
 def check_flat_grads_equal_autograd(dev):
