@@ -96,7 +96,8 @@ def _declare(lib):
                  'eqd_edge_message_fwd', 'eqd_edge_message_bwd', 'eqd_edge_message_bwd_kernel_only',
                  'eqd_cross_attention_fwd',
                  'eqd_cross_attention_bwd', 'eqd_keypoint_pool_fwd', 'eqd_keypoint_pool_bwd', 'eqd_kabsch_fwd', 'eqd_kabsch_bwd',
-                 'eqd_rigid_apply_fwd', 'eqd_rigid_apply_bwd', 'eqd_pair_losses_fwd', 'eqd_pair_losses_bwd', 'eqd_scalar_loss'):
+                 'eqd_rigid_apply_fwd', 'eqd_rigid_apply_bwd', 'eqd_pair_losses_fwd', 'eqd_pair_losses_bwd', 'eqd_scalar_loss', 'eqd_pocket_ot_cost',
+                 'eqd_pocket_ot_fwd', 'eqd_pocket_ot_bwd'):
         getattr(lib, name).restype = C.c_int
 
 
@@ -107,7 +108,7 @@ EXPORTS = ('eqd_profile_begin', 'eqd_profile_end', 'eqd_profile_mark', 'eqd_prof
            'eqd_cross_attention_bwd', 'eqd_keypoint_pool_fwd', 'eqd_keypoint_pool_bwd',
            'eqd_keypoint_pool_bwd_workspace_bytes',
            'eqd_kabsch_fwd', 'eqd_kabsch_bwd', 'eqd_rigid_apply_fwd', 'eqd_rigid_apply_bwd', 'eqd_pair_losses_fwd',
-           'eqd_pair_losses_bwd', 'eqd_scalar_loss')
+           'eqd_pair_losses_bwd', 'eqd_scalar_loss', 'eqd_pocket_ot_cost', 'eqd_pocket_ot_fwd', 'eqd_pocket_ot_bwd')
 
 
 def load_library():

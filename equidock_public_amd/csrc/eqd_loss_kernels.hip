@@ -242,3 +242,102 @@ extern "C" int eqd_scalar_loss(const EqdGraph* g, int n_heads, const float* lig,
                        n_heads, lig, Y_lig, Y_rec, d_lig, d_Ylig, d_Yrec, pair_loss, loss, counter);
     return eqd_check_launch("k_scalar_loss");
 }
+
+// ---------------------------------------------------------------------------------------------
+// Pocket optimal-transport term (src/train.py:117-129, src/utils/ot_utils.py:5-29), device side:
+//   cost[p] = sq_dist(pocket_lig_p, Y_lig_p) + sq_dist(pocket_rec_p, Y_rec_p)      (n_pocket_p x K)
+//   ot[p]   = sum(plan_p * cost[p]),  gradient through cost only (the plan is detached in the reference)
+// The exact plan comes from the host solver (csrc_host/eqd_host_emd.cpp) between the two launches - the reference
+// has the same D->H / H->D round trip around POT's network simplex; here it is ONE round trip per batch instead of
+// one per pair, and the (n_pocket x K) matrices never exist in torch.
+// Layout: pocket rows of all pairs one after the other, pocket_off [B + 1]; cost / plan [sum n_pocket][K].
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(EQD_BLOCK) void k_pocket_cost(const int32_t* __restrict__ pocket_off, int K,
+                                                           const float* __restrict__ pl, const float* __restrict__ pr,
+                                                           const float* __restrict__ Yl, const float* __restrict__ Yr,
+                                                           float* __restrict__ cost) {
+    const int p = blockIdx.x;
+    const int r0 = pocket_off[p], r1 = pocket_off[p + 1];
+    const float* yl = Yl + (size_t)p * K * 3;
+    const float* yr = Yr + (size_t)p * K * 3;
+    for (int e = threadIdx.x; e < (r1 - r0) * K; e += EQD_BLOCK) {
+        const int i = r0 + e / K, k = e % K;
+        const float ax = pl[(size_t)i * 3] - yl[3 * k], ay = pl[(size_t)i * 3 + 1] - yl[3 * k + 1],
+                    az = pl[(size_t)i * 3 + 2] - yl[3 * k + 2];
+        const float bx = pr[(size_t)i * 3] - yr[3 * k], by = pr[(size_t)i * 3 + 1] - yr[3 * k + 1],
+                    bz = pr[(size_t)i * 3 + 2] - yr[3 * k + 2];
+        cost[(size_t)i * K + k] = ((ax * ax + ay * ay) + az * az) + ((bx * bx + by * by) + bz * bz);
+    }
+}
+__global__ __launch_bounds__(EQD_BLOCK) void k_pocket_ot_fwd(const int32_t* __restrict__ pocket_off, int K,
+                                                             const float* __restrict__ plan,
+                                                             const float* __restrict__ cost, float* __restrict__ ot) {
+    __shared__ float red[EQD_WAVES];
+    const int p = blockIdx.x, t = threadIdx.x;
+    const size_t e0 = (size_t)pocket_off[p] * K, e1 = (size_t)pocket_off[p + 1] * K;
+    float acc = 0.f;
+    for (size_t e = e0 + t; e < e1; e += EQD_BLOCK) acc += plan[e] * cost[e];
+    acc = wave_sum(acc);
+    if ((t & 63) == 0) red[t >> 6] = acc;
+    __syncthreads();
+    if (t == 0) ot[p] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+// d Y_lig[p][k] = g[p] sum_i plan[i][k] 2 (Y_lig[p][k] - pocket_lig[i]); same for the receptor side
+__global__ __launch_bounds__(EQD_BLOCK) void k_pocket_ot_bwd(const int32_t* __restrict__ pocket_off, int K,
+                                                             const float* __restrict__ pl, const float* __restrict__ pr,
+                                                             const float* __restrict__ Yl, const float* __restrict__ Yr,
+                                                             const float* __restrict__ plan, const float* __restrict__ d_ot,
+                                                             float* __restrict__ dYl, float* __restrict__ dYr) {
+    const int p = blockIdx.x;
+    const int r0 = pocket_off[p], r1 = pocket_off[p + 1];
+    const float g = d_ot ? d_ot[p] : 0.f;
+    for (int e = threadIdx.x; e < 2 * 3 * K; e += EQD_BLOCK) {
+        const int side = e / (3 * K), kc = e % (3 * K), k = kc / 3, c = kc % 3;
+        const float* __restrict__ pts = side ? pr : pl;
+        const float y = (side ? Yr : Yl)[(size_t)p * K * 3 + kc];
+        float acc = 0.f;
+        for (int i = r0; i < r1; ++i) acc += plan[(size_t)i * K + k] * (y - pts[(size_t)i * 3 + c]);
+        (side ? dYr : dYl)[(size_t)p * K * 3 + kc] = 2.f * g * acc;
+    }
+}
+static int pocket_args_ok(const char* what, int n_pairs, int n_heads, const void* a, const void* b, const void* c) {
+    if (!a || !b || !c) {
+        eqd_set_error("%s: NULL argument", what);
+        return EQD_ERR_NULL;
+    }
+    if (n_pairs < 0 || n_heads < 1) {
+        eqd_set_error("%s: n_pairs = %d, n_heads = %d", what, n_pairs, n_heads);
+        return EQD_ERR_SHAPE;
+    }
+    return EQD_OK;
+}
+extern "C" int eqd_pocket_ot_cost(int n_pairs, int n_heads, const int32_t* pocket_off, const float* pocket_lig,
+                                  const float* pocket_rec, const float* Y_lig, const float* Y_rec, float* cost,
+                                  void* stream) {
+    if (int rc = pocket_args_ok("eqd_pocket_ot_cost", n_pairs, n_heads, pocket_off, pocket_lig, pocket_rec)) return rc;
+    if (!Y_lig || !Y_rec || !cost) return pocket_args_ok("eqd_pocket_ot_cost", n_pairs, n_heads, nullptr, nullptr, nullptr);
+    if (n_pairs == 0) return EQD_OK;
+    hipLaunchKernelGGL(k_pocket_cost, dim3(n_pairs), dim3(EQD_BLOCK), 0, (hipStream_t)stream, pocket_off, n_heads,
+                       pocket_lig, pocket_rec, Y_lig, Y_rec, cost);
+    return eqd_check_launch("k_pocket_cost");
+}
+extern "C" int eqd_pocket_ot_fwd(int n_pairs, int n_heads, const int32_t* pocket_off, const float* plan,
+                                 const float* cost, float* ot, void* stream) {
+    if (int rc = pocket_args_ok("eqd_pocket_ot_fwd", n_pairs, n_heads, pocket_off, plan, cost)) return rc;
+    if (!ot) return pocket_args_ok("eqd_pocket_ot_fwd", n_pairs, n_heads, nullptr, nullptr, nullptr);
+    if (n_pairs == 0) return EQD_OK;
+    hipLaunchKernelGGL(k_pocket_ot_fwd, dim3(n_pairs), dim3(EQD_BLOCK), 0, (hipStream_t)stream, pocket_off, n_heads, plan,
+                       cost, ot);
+    return eqd_check_launch("k_pocket_ot_fwd");
+}
+extern "C" int eqd_pocket_ot_bwd(int n_pairs, int n_heads, const int32_t* pocket_off, const float* pocket_lig,
+                                 const float* pocket_rec, const float* Y_lig, const float* Y_rec, const float* plan,
+                                 const float* d_ot, float* dY_lig, float* dY_rec, void* stream) {
+    if (int rc = pocket_args_ok("eqd_pocket_ot_bwd", n_pairs, n_heads, pocket_off, pocket_lig, pocket_rec)) return rc;
+    if (!Y_lig || !Y_rec || !plan || !dY_lig || !dY_rec)
+        return pocket_args_ok("eqd_pocket_ot_bwd", n_pairs, n_heads, nullptr, nullptr, nullptr);
+    if (n_pairs == 0) return EQD_OK;
+    hipLaunchKernelGGL(k_pocket_ot_bwd, dim3(n_pairs), dim3(EQD_BLOCK), 0, (hipStream_t)stream, pocket_off, n_heads,
+                       pocket_lig, pocket_rec, Y_lig, Y_rec, plan, d_ot, dY_lig, dY_rec);
+    return eqd_check_launch("k_pocket_ot_bwd");
+}

@@ -136,3 +136,116 @@ class ScalarLoss:
                                            _lib.ptr(self.d_Yr), _lib.ptr(self.pair_loss), _lib.ptr(self.loss),
                                            _lib.ptr(self.counter), _lib.stream_ptr(dev)))
         return self.loss, (self.d_lig, self.d_Yl, self.d_Yr)
+
+
+# ---- pocket optimal-transport term (src/train.py:117-129) ------------------------------------------------------------
+_host_emd = None
+
+
+def _emd_lib():
+    """libequidock_host.so's exact solver for transport between uniform measures (csrc_host/eqd_host_emd.cpp).  The
+    product has no other solver: a missing library raises."""
+    global _host_emd
+    if _host_emd is None:
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libequidock_host.so')
+        if not os.path.exists(path):
+            raise _lib.EquidockHipError(f"{path} is missing: build it with `python -m equidock_public_amd.build`")
+        lib = C.CDLL(path)
+        lib.eqd_host_emd_uniform.restype = C.c_int
+        if lib.eqd_host_emd_abi() != 1:
+            raise _lib.EquidockHipError("libequidock_host.so: EMD solver ABI mismatch")
+        _host_emd = lib
+    return _host_emd
+
+
+def emd_uniform_host(cost, counts, n_threads=0):
+    """Exact optimal plans for a ragged batch of transport problems with uniform marginals (a = 1/n, b = 1/K), what the
+    reference gets from POT's ot.emd per pair (src/utils/ot_utils.py:23-26).  cost: HOST float32 [sum(counts), K];
+    returns (plan float32 [sum(counts), K], values float64 [len(counts)])."""
+    lib = _emd_lib()
+    cost = cost.detach().to(torch.float32).contiguous()
+    if cost.device.type != 'cpu':
+        raise _lib.EquidockHipError("emd_uniform_host takes the cost matrices on the host")
+    ns = torch.tensor(list(counts), dtype=torch.int32)
+    if int(ns.sum()) != cost.shape[0]:
+        raise ValueError("counts do not add up to the rows of cost")
+    plan = torch.empty_like(cost)
+    vals = torch.empty(len(counts), dtype=torch.float64)
+    rc = lib.eqd_host_emd_uniform(len(counts), C.c_void_p(ns.data_ptr()), int(cost.shape[1]), C.c_void_p(cost.data_ptr()),
+                                  C.c_void_p(plan.data_ptr()), C.c_void_p(vals.data_ptr()), int(n_threads))
+    if rc != 0:
+        raise _lib.EquidockHipError("exact transport solver failed (non-finite cost matrix?)")
+    return plan, vals
+
+
+class _PocketOT(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, Yl, Yr, pl, pr, off_dev, counts, n_threads):
+        lib = _lib.load_library()
+        dev = Yl.device
+        B, K = Yl.shape[0], Yl.shape[1]
+        f32 = dict(dtype=torch.float32, device=dev)
+        Yl_, Yr_ = (_lib.require_device(t.detach().to(torch.float32).contiguous(), 'keypoints') for t in (Yl, Yr))
+        rows = pl.shape[0]
+        cost = torch.empty(rows, K, **f32)
+        ot = torch.zeros(B, **f32)
+        st = _lib.stream_ptr(dev)
+        with _lib.device_guard(dev):
+            _lib.check(lib.eqd_pocket_ot_cost(B, K, _lib.ptr(off_dev), _lib.ptr(pl), _lib.ptr(pr), _lib.ptr(Yl_),
+                                              _lib.ptr(Yr_), _lib.ptr(cost), st))
+        # the one D->H / H->D round trip of the batch (the reference has one per pair, src/utils/ot_utils.py:23, 27)
+        plan_host, _ = emd_uniform_host(cost.cpu(), counts, n_threads)
+        plan = plan_host.to(dev, non_blocking=False)
+        with _lib.device_guard(dev):
+            _lib.check(lib.eqd_pocket_ot_fwd(B, K, _lib.ptr(off_dev), _lib.ptr(plan), _lib.ptr(cost), _lib.ptr(ot), st))
+        ctx.save_for_backward(Yl_, Yr_, pl, pr, off_dev, plan)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(plan)
+        return ot, plan
+
+    @staticmethod
+    def backward(ctx, d_ot, _d_plan):
+        if d_ot is None:
+            return (None,) * 7
+        lib = _lib.load_library()
+        Yl, Yr, pl, pr, off_dev, plan = ctx.saved_tensors
+        dev = Yl.device
+        B, K = Yl.shape[0], Yl.shape[1]
+        dYl, dYr = torch.empty_like(Yl), torch.empty_like(Yr)
+        g = d_ot.to(torch.float32).contiguous()
+        with _lib.device_guard(dev):
+            _lib.check(lib.eqd_pocket_ot_bwd(B, K, _lib.ptr(off_dev), _lib.ptr(pl), _lib.ptr(pr), _lib.ptr(Yl), _lib.ptr(Yr),
+                                             _lib.ptr(plan), _lib.ptr(g), _lib.ptr(dYl), _lib.ptr(dYr),
+                                             _lib.stream_ptr(dev)))
+        return dYl, dYr, None, None, None, None, None
+
+
+def pocket_ot_loss(keypts_ligand, keypts_receptor, pocket_coors_ligand_list, pocket_coors_receptor_list, n_threads=0,
+                   return_plan=False):
+    """The pocket OT term of every pair of a batch (src/train.py:117-129): ot[p] = compute_ot_emd(
+    compute_sq_dist_mat(pocket_lig_p, Y_lig_p) + compute_sq_dist_mat(pocket_rec_p, Y_rec_p))[0].
+
+    keypts_*: [B, K, 3] device tensors (the model's 2nd / 3rd outputs, stacked; gradients flow to them);
+    pocket_coors_*_list: per pair (n_pocket_p, 3) tensors, matched rows (src/utils/db5_data.py pocket_coors).
+    Cost matrices, sum(plan * cost) and its gradient run on the device for the whole batch; the exact plans come from the
+    host solver on worker threads (ONE device<->host round trip per batch).  Returns ot [B] (and the plans)."""
+    dev = keypts_ligand.device
+    counts = [int(t.shape[0]) for t in pocket_coors_ligand_list]
+    if counts != [int(t.shape[0]) for t in pocket_coors_receptor_list] or len(counts) != keypts_ligand.shape[0]:
+        raise ValueError("pocket lists must have one (n_pocket, 3) tensor per pair, same rows for ligand and receptor")
+    pl = torch.cat([t.reshape(-1, 3) for t in pocket_coors_ligand_list]).to(dev, torch.float32).contiguous()
+    pr = torch.cat([t.reshape(-1, 3) for t in pocket_coors_receptor_list]).to(dev, torch.float32).contiguous()
+    _lib.require_device(pl, 'pocket coordinates')
+    off = torch.tensor([0] + list(torch.tensor(counts).cumsum(0).tolist()), dtype=torch.int32).to(dev)
+    ot, plan = _PocketOT.apply(keypts_ligand, keypts_receptor, pl, pr, off, counts, int(n_threads))
+    return (ot, plan) if return_plan else ot
+
+
+def compute_ot_emd(cost_mat, device=None):
+    """src/utils/ot_utils.py:22-29 for ONE cost matrix, with the host solver in POT's place: returns
+    (sum(plan * cost_mat), plan) with the plan detached, exactly like the reference."""
+    plan, _ = emd_uniform_host(cost_mat.detach().cpu(), [cost_mat.shape[0]])
+    plan = plan.to(cost_mat.device)
+    return torch.sum(plan * cost_mat), plan

@@ -281,7 +281,7 @@ int eqd_rigid_apply_bwd(const EqdGraph* g, const float* d_lig, float* dT, float*
  * the graph's receptor node order.  s_lig [n_lig] / s_rec [n_rec] receive the Gaussian sums of every node and are the
  * only state the backward needs.  The backward writes d lig_pred = d_mse[p] dmse/da + d_inter[p] dinter/da
  * (d_mse / d_inter: [n_pairs], NULL = zero); no other input carries a gradient in the reference either.
- * The pocket OT term (ot.emd) is not part of this library.
+ * The pocket OT term is eqd_pocket_ot_* below (its exact solver runs on the host).
  * ------------------------------------------------------------------------------------------- */
 int eqd_pair_losses_fwd(const EqdGraph* g, const float* lig_pred, const float* lig_target, const float* rec,
                         float sigma, float surface_ct, float* mse, float* inter, float* s_lig, float* s_rec,
@@ -289,6 +289,23 @@ int eqd_pair_losses_fwd(const EqdGraph* g, const float* lig_pred, const float* l
 int eqd_pair_losses_bwd(const EqdGraph* g, const float* lig_pred, const float* lig_target, const float* rec,
                         float sigma, float surface_ct, const float* s_lig, const float* s_rec, const float* d_mse,
                         const float* d_inter, float* d_lig_pred, void* stream);
+
+/* Pocket optimal-transport term of the loss (src/train.py:117-129, src/utils/ot_utils.py:5-29), device side.  Pocket
+ * rows of all pairs are stored one after the other: pocket_lig / pocket_rec [sum n_pocket][3] (matched rows: row i of
+ * both is the same binding-pocket contact), pocket_off [n_pairs + 1] (device, int32); Y_* [n_pairs][n_heads][3].
+ *   eqd_pocket_ot_cost: cost [sum n_pocket][n_heads] = compute_sq_dist_mat(pocket_lig_p, Y_lig_p) + (... rec ...)
+ *   (the caller copies `cost` to the host, solves the exact transport problems with uniform marginals there -
+ *    libequidock_host.so: eqd_host_emd_uniform, replacing POT's ot.emd - and copies `plan` back)
+ *   eqd_pocket_ot_fwd : ot[p] = sum(plan_p * cost_p)
+ *   eqd_pocket_ot_bwd : dY_lig / dY_rec (written) = d_ot[p] * d ot[p] / d Y, the plan being a constant as in the
+ *                       reference (ot_mat_attached has requires_grad=False) */
+int eqd_pocket_ot_cost(int n_pairs, int n_heads, const int32_t* pocket_off, const float* pocket_lig,
+                       const float* pocket_rec, const float* Y_lig, const float* Y_rec, float* cost, void* stream);
+int eqd_pocket_ot_fwd(int n_pairs, int n_heads, const int32_t* pocket_off, const float* plan, const float* cost,
+                      float* ot, void* stream);
+int eqd_pocket_ot_bwd(int n_pairs, int n_heads, const int32_t* pocket_off, const float* pocket_lig,
+                      const float* pocket_rec, const float* Y_lig, const float* Y_rec, const float* plan,
+                      const float* d_ot, float* dY_lig, float* dY_rec, void* stream);
 
 /* Fixed scalar loss of the measurement harness (bench.py, __graft_entry__.smoke):
  *   loss = sum over pairs of mean(lig_p^2) + mean(Y_lig_p^2) + mean(Y_rec_p^2)

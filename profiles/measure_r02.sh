@@ -7,7 +7,7 @@ mkdir -p $O
 cd $R
 for what in "$@"; do case $what in
 tests)
-  python -m pytest tests -m gpu -x -q -s 2>&1 | tail -40 > $O/${TAG}_pytest_gpu.log ;;
+  python -m pytest tests -m gpu -q -s 2>&1 | tail -60 > $O/${TAG}_pytest_gpu.log ;;
 testsfast)   # everything except the three big-workload oracle comparisons
   python -m pytest tests -m gpu -x -q -k "not config_c and not config_e and not ragged" 2>&1 | tail -15 > $O/${TAG}_pytest_gpu_fast.log ;;
 bench)

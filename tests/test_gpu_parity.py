@@ -130,6 +130,11 @@ def test_pair_losses(dev):
     pc.check_pair_losses(dev)
 
 
+def test_pocket_ot(dev):
+    from tests import parity_common as pc
+    pc.check_pocket_ot(dev)
+
+
 def test_scalar_loss(dev):
     from tests import parity_common as pc
     pc.check_scalar_loss(dev)

@@ -109,6 +109,10 @@ def test_pair_losses():
     pc.check_pair_losses(DEV)
 
 
+def test_pocket_ot():
+    pc.check_pocket_ot(DEV)
+
+
 def test_scalar_loss():
     pc.check_scalar_loss(DEV)
 
