@@ -11,6 +11,7 @@
 #include <cstdint>
 #include <cstring>
 #include <numeric>
+#include <thread>
 #include <vector>
 
 extern "C" {
@@ -25,6 +26,13 @@ struct EqdHostPackIn {
     const int32_t *src_ll, *dst_ll, *src_rr, *dst_rr;   // block-local ids
     const float *he_ll, *he_rr;                         // [e][27]
     int32_t tile_edges, tile_nodes, att_block;
+    // optional (eqd_host_collate_pack): the he rows of each edge type as per-pair blocks instead of one array
+    // (he_ll / he_rr are ignored when the tables are given); he_*_cum[p] = first edge of pair p, [n_pairs] = total
+    const float* const* he_ll_parts;
+    const float* const* he_rr_parts;
+    const int64_t* he_ll_cum;
+    const int64_t* he_rr_cum;
+    int32_t n_threads;   // worker threads for the he pass (0 / 1 = caller's thread only)
 };
 struct EqdHostPackOut {
     // caller-allocated: int32 [n_pairs+1] x2, [E] x3 (src, dst, csc_eid), [N+1] x2, [N+2] tile_node, [items_cap][4],
@@ -142,26 +150,147 @@ int eqd_host_pack(const EqdHostPackIn* in, EqdHostPackOut* out) {
     if ((int64_t)items.size() > out->items_cap) return EQDH_ERR_SPACE;
     for (size_t i = 0; i < items.size(); ++i) std::memcpy(out->att_items + 4 * i, items[i].v, 16);
     out->n_att_items = (int32_t)items.size();
-    // edge features in sorted order + bf16 copy (32 columns per edge, 27 used)
+    // edge features in sorted order + bf16 copy (32 columns per edge, 27 used): the only pass over the big array
+    // (41 MB at 64 x (300, 300)), split over worker threads by edge ranges
     const float* hes[2] = {in->he_ll, in->he_rr};
-    eoff = 0;
+    const float* const* parts[2] = {in->he_ll_parts, in->he_rr_parts};
+    const int64_t* cums[2] = {in->he_ll_cum, in->he_rr_cum};
     if (E == 0) std::memset(out->he_bf16, 0, 64);
-    for (int t = 0; t < 2; ++t) {
-        for (int64_t i = 0; i < es[t]; ++i) {
-            const float* row = hes[t] + (size_t)(out->edge_perm[eoff + i] - eoff) * 27;
-            float* o = out->he + (size_t)(eoff + i) * 27;
-            uint16_t* ob = out->he_bf16 + (size_t)(eoff + i) * 32;
+    auto he_range = [&](int t, int64_t base, int64_t i0, int64_t i1) {
+        int part = 0;
+        for (int64_t i = i0; i < i1; ++i) {
+            const int64_t src_row = out->edge_perm[base + i] - base;
+            const float* row;
+            if (parts[t]) {
+                const int64_t* cum = cums[t];
+                if (src_row < cum[part] || src_row >= cum[part + 1])
+                    part = (int)(std::upper_bound(cum, cum + B + 1, src_row) - cum) - 1;
+                row = parts[t][part] + (size_t)(src_row - cum[part]) * 27;
+            } else {
+                row = hes[t] + (size_t)src_row * 27;
+            }
+            float* o = out->he + (size_t)(base + i) * 27;
+            uint16_t* ob = out->he_bf16 + (size_t)(base + i) * 32;
             for (int c = 0; c < 27; ++c) {
                 o[c] = row[c];
                 ob[c] = f2bf_rne(row[c]);
             }
             for (int c = 27; c < 32; ++c) ob[c] = 0;
         }
-        eoff += es[t];
+    };
+    const int nth = std::max(1, std::min<int>(in->n_threads, 16));
+    eoff = 0;
+    for (int t = 0; t < 2; ++t) {
+        const int64_t e = es[t];
+        if (nth == 1 || e < 20000) {
+            he_range(t, eoff, 0, e);
+        } else {
+            std::vector<std::thread> th;
+            const int64_t chunk = (e + nth - 1) / nth;
+            for (int k = 1; k < nth; ++k)
+                th.emplace_back(he_range, t, eoff, std::min(e, k * chunk), std::min(e, (k + 1) * chunk));
+            he_range(t, eoff, 0, std::min(e, chunk));
+            for (auto& x : th) x.join();
+        }
+        eoff += e;
     }
     return EQDH_OK;
 }
 
-int eqd_host_pack_abi(void) { return 1; }
+// ---------------------------------------------------------------------------------------------------------------
+// Collate + pack in one call: what the reference does with one dgl.heterograph per pair + dgl.batch in its
+// DataLoader's collate function (src/utils/train_utils.py:61-100), straight from the per-pair arrays into the batch's
+// node arrays and the kernel layout - no per-pair tensor objects, no concatenated intermediate of the edge features.
+// ---------------------------------------------------------------------------------------------------------------
+struct EqdHostCollateIn {
+    int32_t n_pairs;
+    const int64_t *nl, *nr, *el, *er;                      // [n_pairs] node / edge counts
+    const float* const *lig_x, *const *lig_new_x, *const *lig_res, *const *lig_mu;   // per pair [n][3], [n][3], [n], [n][5]
+    const float* const *rec_x, *const *rec_res, *const *rec_mu;
+    const float* const *he_ll, *const *he_rr;                // per pair [e][27]
+    const int32_t* const *src_ll, *const *dst_ll, *const *src_rr, *const *dst_rr;    // per pair, pair-local node ids
+    int32_t tile_edges, tile_nodes, att_block, n_threads;
+};
+struct EqdHostCollateOut {
+    // caller-allocated batch-level node data: float [nl][3] lig_x, [nl][3] lig_new_x, [nl] lig_res, [nl][5] lig_mu,
+    // [nr][3] rec_x, [nr] rec_res, [nr][5] rec_mu, [nl + nr][5] mu (both types), [nl + nr][3] x0 (new_x rows, then x rows);
+    // int32 [nl + nr] res_id; int32 block-local endpoints with the batch's node offsets: [el_tot] x2, [er_tot] x2
+    float *lig_x, *lig_new_x, *lig_res, *lig_mu, *rec_x, *rec_res, *rec_mu, *mu, *x0;
+    int32_t *res_id, *src_ll, *dst_ll, *src_rr, *dst_rr;
+    int32_t bad_res;   // result: 1 if a residue id is outside 0..20, 2 if a mu_r_norm entry is <= 0
+};
+
+int eqd_host_collate_pack(const EqdHostCollateIn* ci, EqdHostCollateOut* co, EqdHostPackOut* po) {
+    const int B = ci->n_pairs;
+    std::vector<int64_t> lc(B), rc(B), cum_ll(B + 1, 0), cum_rr(B + 1, 0);
+    int64_t nl = 0, nr = 0;
+    for (int b = 0; b < B; ++b) {
+        lc[b] = ci->nl[b];
+        rc[b] = ci->nr[b];
+        nl += lc[b];
+        nr += rc[b];
+        cum_ll[b + 1] = cum_ll[b] + ci->el[b];
+        cum_rr[b + 1] = cum_rr[b] + ci->er[b];
+    }
+    co->bad_res = 0;
+    int64_t lo = 0, ro = 0;
+    for (int b = 0; b < B; ++b) {
+        const int64_t a = lc[b], c = rc[b];
+        std::memcpy(co->lig_x + lo * 3, ci->lig_x[b], (size_t)a * 12);
+        std::memcpy(co->lig_new_x + lo * 3, ci->lig_new_x[b], (size_t)a * 12);
+        std::memcpy(co->x0 + lo * 3, ci->lig_new_x[b], (size_t)a * 12);
+        std::memcpy(co->lig_res + lo, ci->lig_res[b], (size_t)a * 4);
+        std::memcpy(co->lig_mu + lo * 5, ci->lig_mu[b], (size_t)a * 20);
+        std::memcpy(co->mu + lo * 5, ci->lig_mu[b], (size_t)a * 20);
+        std::memcpy(co->rec_x + ro * 3, ci->rec_x[b], (size_t)c * 12);
+        std::memcpy(co->x0 + (nl + ro) * 3, ci->rec_x[b], (size_t)c * 12);
+        std::memcpy(co->rec_res + ro, ci->rec_res[b], (size_t)c * 4);
+        std::memcpy(co->rec_mu + ro * 5, ci->rec_mu[b], (size_t)c * 20);
+        std::memcpy(co->mu + (nl + ro) * 5, ci->rec_mu[b], (size_t)c * 20);
+        for (int64_t i = 0; i < a; ++i) {
+            const float r = ci->lig_res[b][i];
+            co->res_id[lo + i] = (int32_t)r;
+            if (!(r >= 0.f && r <= 20.f)) co->bad_res = 1;
+        }
+        for (int64_t i = 0; i < c; ++i) {
+            const float r = ci->rec_res[b][i];
+            co->res_id[nl + ro + i] = (int32_t)r;
+            if (!(r >= 0.f && r <= 20.f)) co->bad_res = 1;
+        }
+        for (int64_t i = 0; i < ci->el[b]; ++i) {
+            const int32_t s = ci->src_ll[b][i], d = ci->dst_ll[b][i];
+            if (s < 0 || d < 0 || s >= a || d >= a) return EQDH_ERR_RANGE;
+            co->src_ll[cum_ll[b] + i] = s + (int32_t)lo;
+            co->dst_ll[cum_ll[b] + i] = d + (int32_t)lo;
+        }
+        for (int64_t i = 0; i < ci->er[b]; ++i) {
+            const int32_t s = ci->src_rr[b][i], d = ci->dst_rr[b][i];
+            if (s < 0 || d < 0 || s >= c || d >= c) return EQDH_ERR_RANGE;
+            co->src_rr[cum_rr[b] + i] = s + (int32_t)ro;
+            co->dst_rr[cum_rr[b] + i] = d + (int32_t)ro;
+        }
+        lo += a;
+        ro += c;
+    }
+    if (!co->bad_res)
+        for (int64_t i = 0; i < (nl + nr) * 5; ++i)
+            if (!(co->mu[i] > 0.f)) {
+                co->bad_res = 2;
+                break;
+            }
+    EqdHostPackIn pi;
+    std::memset(&pi, 0, sizeof(pi));
+    pi.n_pairs = B; pi.n_lig = (int32_t)nl; pi.n_rec = (int32_t)nr;
+    pi.lig_counts = lc.data(); pi.rec_counts = rc.data();
+    pi.e_ll = cum_ll[B]; pi.e_rr = cum_rr[B];
+    pi.src_ll = co->src_ll; pi.dst_ll = co->dst_ll; pi.src_rr = co->src_rr; pi.dst_rr = co->dst_rr;
+    pi.tile_edges = ci->tile_edges; pi.tile_nodes = ci->tile_nodes; pi.att_block = ci->att_block;
+    pi.he_ll_parts = ci->he_ll; pi.he_rr_parts = ci->he_rr;
+    pi.he_ll_cum = cum_ll.data(); pi.he_rr_cum = cum_rr.data();
+    pi.n_threads = ci->n_threads;
+    return eqd_host_pack(&pi, po);
+}
+
+int eqd_host_pack_abi(void) { return 2; }
 
 }  // extern "C"

@@ -39,7 +39,21 @@ class _HostPackIn(_C.Structure):
     _fields_ = [('n_pairs', _C.c_int32), ('n_lig', _C.c_int32), ('n_rec', _C.c_int32), ('lig_counts', _C.c_void_p),
                 ('rec_counts', _C.c_void_p), ('e_ll', _C.c_int64), ('e_rr', _C.c_int64), ('src_ll', _C.c_void_p),
                 ('dst_ll', _C.c_void_p), ('src_rr', _C.c_void_p), ('dst_rr', _C.c_void_p), ('he_ll', _C.c_void_p),
-                ('he_rr', _C.c_void_p), ('tile_edges', _C.c_int32), ('tile_nodes', _C.c_int32), ('att_block', _C.c_int32)]
+                ('he_rr', _C.c_void_p), ('tile_edges', _C.c_int32), ('tile_nodes', _C.c_int32), ('att_block', _C.c_int32),
+                ('he_ll_parts', _C.c_void_p), ('he_rr_parts', _C.c_void_p), ('he_ll_cum', _C.c_void_p),
+                ('he_rr_cum', _C.c_void_p), ('n_threads', _C.c_int32)]
+
+
+class _HostCollateIn(_C.Structure):
+    _fields_ = [('n_pairs', _C.c_int32)] + [(k, _C.c_void_p) for k in (
+        'nl', 'nr', 'el', 'er', 'lig_x', 'lig_new_x', 'lig_res', 'lig_mu', 'rec_x', 'rec_res', 'rec_mu', 'he_ll', 'he_rr',
+        'src_ll', 'dst_ll', 'src_rr', 'dst_rr')] + [(k, _C.c_int32) for k in ('tile_edges', 'tile_nodes', 'att_block',
+                                                                             'n_threads')]
+
+
+class _HostCollateOut(_C.Structure):
+    _fields_ = [(k, _C.c_void_p) for k in ('lig_x', 'lig_new_x', 'lig_res', 'lig_mu', 'rec_x', 'rec_res', 'rec_mu', 'mu', 'x0',
+                                           'res_id', 'src_ll', 'dst_ll', 'src_rr', 'dst_rr')] + [('bad_res', _C.c_int32)]
 
 
 class _HostPackOut(_C.Structure):
@@ -64,7 +78,8 @@ def _native():
         else:
             lib = _C.CDLL(path)
             lib.eqd_host_pack.restype = _C.c_int
-            _host_lib = lib if lib.eqd_host_pack_abi() == 1 else False
+            lib.eqd_host_collate_pack.restype = _C.c_int
+            _host_lib = lib if lib.eqd_host_pack_abi() == 2 else False
     return _host_lib or None
 
 
@@ -260,9 +275,204 @@ def unbatch(g):
     return outs
 
 
-def batch_pairs(pairs):
-    """Convenience: list of (ligand_dict, receptor_dict) -> batched PairGraph."""
+def uniform_rotation_translation(translation_interval):
+    """src/utils/protein_utils.py:15-23 (UniformRotation_Translation): a uniformly random rotation (scipy) and a translation
+    of uniformly random length in [0, translation_interval) along a random direction, drawn from numpy's GLOBAL generator
+    in the reference's order - the same np.random.seed gives the reference's draws.  Returns float32 (3, 3), (1, 3)."""
+    from scipy.spatial.transform import Rotation
+    rotation_matrix = Rotation.random(num=1).as_matrix().squeeze()
+    t = np.random.randn(1, 3)
+    t = t / np.sqrt(np.sum(t * t))
+    length = np.random.uniform(low=0, high=translation_interval)
+    t = t * length
+    return rotation_matrix.astype(np.float32), t.astype(np.float32)
+
+
+def augment_ligand(batch, rotations, translations, pocket_coors_ligand_list=None):
+    """The reference's per-item random rigid perturbation of the ligand (src/utils/db5_data.py:195-204), for a whole
+    batch in one launch ON THE DEVICE (eqd_rigid_augment): ligand `new_x` <- R_p (x - mean_p) + t_p, written in place, and
+    - when given - the pairs' ligand pocket coordinates under the same maps (returned as a list).  rotations [B, 3, 3],
+    translations [B, 3] (or [B, 1, 3]): host or device, e.g. B draws of uniform_rotation_translation()."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load_library()
+    packed = batch.pack()
+    dev = packed.x0.device
+    B = packed.n_pairs
+    R = torch.as_tensor(np.asarray(rotations) if not torch.is_tensor(rotations) else rotations).to(dev, torch.float32) \
+        .reshape(B, 9).contiguous()
+    t = torch.as_tensor(np.asarray(translations) if not torch.is_tensor(translations) else translations) \
+        .to(dev, torch.float32).reshape(B, 3).contiguous()
+    x = _lib.require_device(batch._ndata['ligand']['x'].to(torch.float32).contiguous(), "ligand 'x'")
+    new_x = batch._ndata['ligand']['new_x']
+    if new_x.dtype != torch.float32 or not new_x.is_contiguous() or new_x.device != x.device:
+        new_x = torch.empty_like(x)
+        batch._ndata['ligand']['new_x'] = new_x
+    off = pin = pout = None
+    if pocket_coors_ligand_list is not None:
+        counts = [int(p.shape[0]) for p in pocket_coors_ligand_list]
+        if len(counts) != B:
+            raise ValueError("one pocket array per pair expected")
+        pin = torch.cat([torch.as_tensor(p).reshape(-1, 3) for p in pocket_coors_ligand_list]).to(dev, torch.float32) \
+            .contiguous()
+        pout = torch.empty_like(pin)
+        off = torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int32).to(dev)
+    gs = packed.c_struct()
+    with _lib.device_guard(dev):
+        _lib.check(lib.eqd_rigid_augment(C.byref(gs), _lib.ptr(x), _lib.ptr(R), _lib.ptr(t), _lib.ptr(new_x), _lib.ptr(off),
+                                         _lib.ptr(pin), _lib.ptr(pout), _lib.stream_ptr(dev)))
+    new_x.add_(0)       # bump the version counter: the packed layout re-reads [new_x ; x] at the next forward
+    if pout is None:
+        return None
+    return list(torch.split(pout, counts))
+
+
+def from_dgl(g):
+    """Adapter from the reference's input object: a (batched) DGL heterograph as built by
+    hetero_graph_from_sg_l_r_pair + dgl.batch (src/utils/train_utils.py:61-100) -> PairGraph.
+
+    Duck-typed - DGL itself is not imported (it is a third-party pin that is absent here): only the accessors the
+    reference's own model file uses are needed, `g.nodes[ntype].data[...]`, `g.edges[canonical_etype].data['he']`,
+    `g.batch_num_nodes(ntype)`, `g.batch_num_edges(etype)` and the endpoint query `g.edges(etype=...)` (DGL's
+    EdgeView is callable; `g.all_edges(etype=...)` is tried as well).  The empty 'cross' edge types of the reference's
+    heterograph are ignored.  Tensors are shared, not copied; the result packs bit-identically to batch_pairs() on the
+    same pairs (tests/test_abi_and_graph.py, through the oracle's DGL stand-in)."""
+    if isinstance(g, PairGraph):
+        return g
+    cet = {'ll': ('ligand', 'll', 'ligand'), 'rr': ('receptor', 'rr', 'receptor')}
+    try:
+        nd = {'ligand': {k: g.nodes['ligand'].data[k] for k in ('res_feat', 'x', 'new_x', 'mu_r_norm')},
+              'receptor': {k: g.nodes['receptor'].data[k] for k in ('res_feat', 'x', 'mu_r_norm')}}
+        ed = {et: {'he': g.edges[c].data['he']} for et, c in cet.items()}
+    except (KeyError, AttributeError, TypeError) as e:
+        raise TypeError("expected a PairGraph or a DGL heterograph with node types ligand/receptor carrying res_feat, x, "
+                        f"mu_r_norm (+ new_x on the ligand) and edge types ll/rr carrying he: {e!r}")
+
+    def endpoints(c):
+        for call in (lambda: g.edges(etype=c), lambda: g.all_edges(etype=c), lambda: g.edges(etype=c[1])):
+            try:
+                s, d = call()[:2]
+                return s, d
+            except (TypeError, AttributeError, KeyError):
+                continue
+        raise TypeError(f"cannot query the endpoints of edge type {c}")
+    edges = {}
+    for et, c in cet.items():
+        s, d = endpoints(c)
+        edges[et] = (torch.as_tensor(s).to(torch.int32).contiguous(), torch.as_tensor(d).to(torch.int32).contiguous())
+        if ed[et]['he'].shape[0] != edges[et][0].numel():
+            raise ValueError(f"'he' has {ed[et]['he'].shape[0]} rows for {edges[et][0].numel()} {et} edges")
+    bn = {nt: [int(v) for v in g.batch_num_nodes(nt)] for nt in PairGraph.NTYPES}
+    be = {et: [int(v) for v in g.batch_num_edges(c)] for et, c in cet.items()}
+    for nt in PairGraph.NTYPES:
+        nd[nt] = {k: (v.to(torch.float32) if v.dtype != torch.float32 else v) for k, v in nd[nt].items()}
+        nd[nt]['res_feat'] = nd[nt]['res_feat'].reshape(-1, 1)
+        if sum(bn[nt]) != nd[nt]['x'].shape[0]:
+            raise ValueError(f"batch_num_nodes('{nt}') does not add up to the node data rows")
+    return PairGraph(nd, ed, edges, bn, be)
+
+
+def batch_pairs(pairs, n_threads=4):
+    """List of (ligand_dict, receptor_dict) of arrays -> batched PairGraph: the collate function of the drop-in (the
+    reference builds one dgl.heterograph per pair and calls dgl.batch, src/utils/train_utils.py:61-100).
+
+    With libequidock_host.so built this is ONE native call (eqd_host_collate_pack) that goes from the per-pair arrays
+    straight to the batch's node arrays AND the packed kernel layout (so `.pack()` afterwards is free); otherwise - or
+    with EQD_NATIVE_PACK=0 - the per-pair construction + batch() below.  Both give bit-identical batches
+    (tests/test_abi_and_graph.py)."""
+    pairs = list(pairs)
+    lib = _native()
+    if lib is not None and pairs:
+        return _batch_pairs_native(lib, pairs, n_threads)
     return batch([pair_from_arrays(l, r) for l, r in pairs])
+
+
+def _np(a, dtype):
+    if torch.is_tensor(a):
+        a = a.detach().cpu().numpy()
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def _batch_pairs_native(lib, pairs, n_threads):
+    B = len(pairs)
+    keep = []           # per-pair arrays must stay alive until the call returns
+    cols = {k: [] for k in ('lig_x', 'lig_new_x', 'lig_res', 'lig_mu', 'rec_x', 'rec_res', 'rec_mu', 'he_ll', 'he_rr',
+                            'src_ll', 'dst_ll', 'src_rr', 'dst_rr')}
+    nl, nr, el, er = [], [], [], []
+    for lig, rec in pairs:
+        a = dict(lig_x=_np(lig['x'], np.float32), lig_new_x=_np(lig['new_x'], np.float32),
+                 lig_res=_np(lig['res_feat'], np.float32).reshape(-1), lig_mu=_np(lig['mu_r_norm'], np.float32),
+                 rec_x=_np(rec['x'], np.float32), rec_res=_np(rec['res_feat'], np.float32).reshape(-1),
+                 rec_mu=_np(rec['mu_r_norm'], np.float32), he_ll=_np(lig['he'], np.float32), he_rr=_np(rec['he'], np.float32),
+                 src_ll=_np(lig['src'], np.int32), dst_ll=_np(lig['dst'], np.int32),
+                 src_rr=_np(rec['src'], np.int32), dst_rr=_np(rec['dst'], np.int32))
+        n_l, n_r, e_l, e_r = a['lig_x'].shape[0], a['rec_x'].shape[0], a['src_ll'].shape[0], a['src_rr'].shape[0]
+        ok = (a['lig_x'].shape == (n_l, 3) and a['lig_new_x'].shape == (n_l, 3) and a['lig_res'].shape == (n_l,)
+              and a['lig_mu'].shape == (n_l, MU_WIDTH) and a['rec_x'].shape == (n_r, 3) and a['rec_res'].shape == (n_r,)
+              and a['rec_mu'].shape == (n_r, MU_WIDTH) and a['he_ll'].shape == (e_l, HE_WIDTH)
+              and a['he_rr'].shape == (e_r, HE_WIDTH) and a['dst_ll'].shape == (e_l,) and a['dst_rr'].shape == (e_r,))
+        if not ok:
+            raise ValueError("inconsistent array shapes in a (ligand, receptor) pair: x / new_x [n, 3], res_feat [n(, 1)], "
+                             f"mu_r_norm [n, {MU_WIDTH}], src / dst [e], he [e, {HE_WIDTH}]")
+        keep.append(a)
+        for k in cols:
+            cols[k].append(a[k].ctypes.data)
+        nl.append(n_l); nr.append(n_r); el.append(e_l); er.append(e_r)
+    NL, NR, EL, ER = sum(nl), sum(nr), sum(el), sum(er)
+    n, E = NL + NR, EL + ER
+    p = PackedGraph()
+    p.n_pairs, p.n_lig, p.n_rec, p.n_nodes = B, NL, NR, n
+    items_cap = sum((c + ATT_BLOCK - 1) // ATT_BLOCK for c in nl + nr)
+    flats, views = PackedGraph._alloc_native_buffers(B, n, E, items_cap)
+    f32, i32 = torch.float32, torch.int32
+    nd = {'ligand': {'res_feat': torch.empty(NL, 1, dtype=f32), 'x': torch.empty(NL, 3, dtype=f32),
+                     'new_x': torch.empty(NL, 3, dtype=f32), 'mu_r_norm': torch.empty(NL, 5, dtype=f32)},
+          'receptor': {'res_feat': torch.empty(NR, 1, dtype=f32), 'x': torch.empty(NR, 3, dtype=f32),
+                       'mu_r_norm': torch.empty(NR, 5, dtype=f32)}}
+    x0 = torch.empty(n, 3, dtype=f32)
+    edges = {'ll': (torch.empty(EL, dtype=i32), torch.empty(EL, dtype=i32)),
+             'rr': (torch.empty(ER, dtype=i32), torch.empty(ER, dtype=i32))}
+    counts = {k: np.asarray(v, dtype=np.int64) for k, v in (('nl', nl), ('nr', nr), ('el', el), ('er', er))}
+    tabs = {k: (_C.c_void_p * B)(*v) for k, v in cols.items()}
+    ci = _HostCollateIn()
+    ci.n_pairs = B
+    for k, v in counts.items():
+        setattr(ci, k, v.ctypes.data)
+    for k, v in tabs.items():
+        setattr(ci, k, _C.cast(v, _C.c_void_p))
+    ci.tile_edges, ci.tile_nodes, ci.att_block, ci.n_threads = TILE_EDGES, TILE_NODES, ATT_BLOCK, int(n_threads)
+    co = _HostCollateOut()
+    co.lig_x, co.lig_new_x = nd['ligand']['x'].data_ptr(), nd['ligand']['new_x'].data_ptr()
+    co.lig_res, co.lig_mu = nd['ligand']['res_feat'].data_ptr(), nd['ligand']['mu_r_norm'].data_ptr()
+    co.rec_x, co.rec_res, co.rec_mu = (nd['receptor'][k].data_ptr() for k in ('x', 'res_feat', 'mu_r_norm'))
+    co.mu, co.x0, co.res_id = views['mu_r_norm'].data_ptr(), x0.data_ptr(), views['res_id'].data_ptr()
+    co.src_ll, co.dst_ll = edges['ll'][0].data_ptr(), edges['ll'][1].data_ptr()
+    co.src_rr, co.dst_rr = edges['rr'][0].data_ptr(), edges['rr'][1].data_ptr()
+    hout = PackedGraph._host_out(views, items_cap)
+    rc_ = lib.eqd_host_collate_pack(_C.byref(ci), _C.byref(co), _C.byref(hout))
+    PackedGraph._check_native_rc(rc_, hout)
+    if co.bad_res == 1:
+        raise ValueError("res_feat must hold residue ids 0..20 (nn.Embedding(21, .), rigid_docking_model.py:382)")
+    if co.bad_res == 2:
+        raise ValueError("mu_r_norm must be > 0 (the model takes its log, rigid_docking_model.py:469)")
+    p._finish_native(flats, views, hout, E, nl, nr)
+    # edge features of the container: views into the packed array when the edges were already destination-sorted (they
+    # are as the reference builds them, src/utils/protein_utils.py:339-346); re-ordered copies otherwise
+    perm = p.edge_perm
+    if E == 0 or bool((perm == torch.arange(E, dtype=perm.dtype)).all()):
+        he_ll, he_rr = p.he[:EL], p.he[EL:]
+    else:
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(E, dtype=perm.dtype)
+        he_all = p.he[inv]
+        he_ll, he_rr = he_all[:EL], he_all[EL:]
+    g = PairGraph(nd, {'ll': {'he': he_ll}, 'rr': {'he': he_rr}}, edges, {'ligand': nl, 'receptor': nr},
+                  {'ll': el, 'rr': er})
+    p.x0 = x0
+    lx, rx = nd['ligand']['new_x'], nd['receptor']['x']
+    p._x0_key = (lx.data_ptr(), lx._version, rx.data_ptr(), rx._version, lx.device)
+    g._packed = p
+    return g
 
 
 class PackedGraph:
@@ -423,7 +633,21 @@ class PackedGraph:
         if float(mu.min()) <= 0.0:
             raise ValueError("mu_r_norm must be > 0 (the model takes its log, rigid_docking_model.py:469)")
         items_cap = sum((int(c) + ATT_BLOCK - 1) // ATT_BLOCK for c in list(lc) + list(rc))
-        # per-dtype buffers with 64-byte aligned slices, laid out here and filled by the library
+        flats, views = PackedGraph._alloc_native_buffers(B, n, E, items_cap)
+        views['res_id'].copy_(res)
+        views['mu_r_norm'].copy_(mu)
+        hin = _HostPackIn(B, nl, nr, lc.data_ptr(), rc.data_ptr(), s_ll.numel(), s_rr.numel(), s_ll.data_ptr(),
+                          d_ll.data_ptr(), s_rr.data_ptr(), d_rr.data_ptr(), he_ll.data_ptr(), he_rr.data_ptr(), TILE_EDGES,
+                          TILE_NODES, ATT_BLOCK, None, None, None, None, 4)
+        hout = PackedGraph._host_out(views, items_cap)
+        rc_ = lib.eqd_host_pack(_C.byref(hin), _C.byref(hout))
+        PackedGraph._check_native_rc(rc_, hout)
+        p._finish_native(flats, views, hout, E, list(g._batch_nodes['ligand']), list(g._batch_nodes['receptor']))
+        return p
+
+    @staticmethod
+    def _alloc_native_buffers(B, n, E, items_cap):
+        """per-dtype buffers with 64-byte aligned slices, laid out here and filled by the host library"""
         spec = {
             torch.int32: [('lig_off', (B + 1,)), ('rec_off', (B + 1,)), ('src', (E,)), ('dst', (E,)), ('rowptr', (n + 1,)),
                           ('csc_ptr', (n + 1,)), ('csc_eid', (E,)), ('tile_node', (n + 2,)), ('att_items', (items_cap, 4)),
@@ -446,22 +670,27 @@ class PackedGraph:
                 views[k] = flat[o:o + int(np.prod(shape))].view(shape)
                 layout.append((k, o, tuple(shape)))
             flats[dt] = (flat, layout)
-        views['res_id'].copy_(res)
-        views['mu_r_norm'].copy_(mu)
-        hin = _HostPackIn(B, nl, nr, lc.data_ptr(), rc.data_ptr(), s_ll.numel(), s_rr.numel(), s_ll.data_ptr(),
-                          d_ll.data_ptr(), s_rr.data_ptr(), d_rr.data_ptr(), he_ll.data_ptr(), he_rr.data_ptr(), TILE_EDGES,
-                          TILE_NODES, ATT_BLOCK)
+        return flats, views
+
+    @staticmethod
+    def _host_out(views, items_cap):
         hout = _HostPackOut()
         for k in ('lig_off', 'rec_off', 'src', 'dst', 'rowptr', 'csc_ptr', 'csc_eid', 'tile_node', 'att_items', 'seg_off',
                   'edge_perm', 'he', 'he_bf16'):
             setattr(hout, k, views[k].data_ptr())
         hout.items_cap = items_cap
-        rc_ = lib.eqd_host_pack(_C.byref(hin), _C.byref(hout))
+        return hout
+
+    @staticmethod
+    def _check_native_rc(rc_, hout):
         if rc_ == 1:
             raise ValueError(f"in-degree {hout.max_degree} exceeds the supported maximum of {TILE_EDGES} "
                              "(the reference caps it at graph_max_neighbor=10, src/utils/args.py:47)")
         if rc_ != 0:
-            raise ValueError(f"eqd_host_pack failed ({rc_}): edge endpoint out of range or inconsistent pair sizes")
+            raise ValueError(f"native pack failed ({rc_}): edge endpoint out of range or inconsistent pair sizes")
+
+    def _finish_native(self, flats, views, hout, E, lig_counts, rec_counts):
+        p = self
         p.n_edges, p.n_tiles, p.n_att_items, p.max_seg = E, hout.n_tiles, hout.n_att_items, hout.max_seg
         # the two lists with data-dependent lengths are shorter than their upper bounds: re-slice the views
         for k, shape in (('tile_node', (p.n_tiles + 1,)), ('att_items', (p.n_att_items, 4))):
@@ -472,10 +701,9 @@ class PackedGraph:
             setattr(p, k, v)
         p.x0 = None
         p.device = torch.device('cpu')
-        p.lig_counts = list(g._batch_nodes['ligand'])
-        p.rec_counts = list(g._batch_nodes['receptor'])
+        p.lig_counts = list(lig_counts)
+        p.rec_counts = list(rec_counts)
         p._flats = flats
-        return p
 
     def refresh_coords(self, g):
         """x0 = [ligand new_x ; receptor x], re-read at every forward (the training loop re-draws new_x per batch); the

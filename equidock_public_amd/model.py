@@ -377,7 +377,17 @@ class IEGMN(nn.Module):
     def run(self, batch_hetero_graph):
         """Returns the raw batched outputs (lig [n_lig,3], Yl, Yr [B,K,3], T [B,3,3], b [B,3])."""
         if not isinstance(batch_hetero_graph, PairGraph):
-            raise TypeError("expected an equidock_public_amd.graph.PairGraph batch (DGL is not used on this path)")
+            # the reference's callers hand over a batched DGL heterograph (src/train.py:94-100): adapt it (duck-typed,
+            # tensors shared) and remember the adaptation on the object so that its packed layout is built once
+            pg = getattr(batch_hetero_graph, '_eqd_pair_graph', None)
+            if pg is None:
+                from .graph import from_dgl
+                pg = from_dgl(batch_hetero_graph)
+                try:
+                    batch_hetero_graph._eqd_pair_graph = pg
+                except AttributeError:
+                    pass
+            batch_hetero_graph = pg
         if self.training and self.args['dropout'] > 0:
             raise NotImplementedError("dropout > 0 in training mode is outside the HIP path")
         packed = batch_hetero_graph.pack()

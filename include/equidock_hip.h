@@ -290,6 +290,14 @@ int eqd_pair_losses_bwd(const EqdGraph* g, const float* lig_pred, const float* l
                         float sigma, float surface_ct, const float* s_lig, const float* s_rec, const float* d_mse,
                         const float* d_inter, float* d_lig_pred, void* stream);
 
+/* Per-item random rigid augmentation of the ligand, for the whole batch (src/utils/db5_data.py:195-204): for pair p
+ *   new_x_i = R_p (x_i - mean_p(x)) + t_p   for the pair's ligand nodes (x_lig / new_x: [n_lig][3], ligand node order),
+ * and the same map for the pair's ligand pocket coordinates when pocket_off [n_pairs + 1] (device) is not NULL
+ * (pocket_in / pocket_out [sum n_pocket][3]).  R [n_pairs][9] row-major, t [n_pairs][3]: drawn by the caller (the
+ * reference draws them with scipy / numpy on the host, src/utils/protein_utils.py:15-23). */
+int eqd_rigid_augment(const EqdGraph* g, const float* x_lig, const float* R, const float* t, float* new_x,
+                      const int32_t* pocket_off, const float* pocket_in, float* pocket_out, void* stream);
+
 /* Pocket optimal-transport term of the loss (src/train.py:117-129, src/utils/ot_utils.py:5-29), device side.  Pocket
  * rows of all pairs are stored one after the other: pocket_lig / pocket_rec [sum n_pocket][3] (matched rows: row i of
  * both is the same binding-pocket contact), pocket_off [n_pairs + 1] (device, int32); Y_* [n_pairs][n_heads][3].

@@ -13,7 +13,7 @@ and executed UNMODIFIED on CPU to generate golden vectors (oracle/make_golden.py
   * g.apply_edges(udf, etype) with edges.src[k] / edges.dst[k] gathers
   * g.update_all(fn.copy_edge(f, 'm'), fn.mean('m', out), etype)
         per-destination mean over in-edges, zeros for in-degree 0
-  * g.batch_num_nodes(ntype), g.batch_num_edges(etype), g.to(device)
+  * g.batch_num_nodes(ntype), g.batch_num_edges(etype), g.to(device), g.edges(etype=...) -> (src, dst)
   * dgl.batch(list) / dgl.unbatch(g)
 
 The three semantics (src - dst, mean with zero fill, concatenating batch order) are the
@@ -47,6 +47,17 @@ class _Indexer:
         return _DataView(self._stores[self._canon(key)])
 
 
+class _EdgeView(_Indexer):
+    """g.edges[etype].data (dict view) and g.edges(etype=...) -> (src, dst), like DGL's EdgeView."""
+
+    def __init__(self, g):
+        super().__init__(g._edata, _canon)
+        self._g = g
+
+    def __call__(self, form='uv', order='eid', etype=None):
+        return self._g._edges[_canon(etype)]
+
+
 class _EdgeBatch:
     def __init__(self, src_data, dst_data, src_idx, dst_idx, edata):
         self.src = {k: v[src_idx] for k, v in src_data.items() if torch.is_tensor(v)}
@@ -74,7 +85,10 @@ class HG:
 
     @property
     def edges(self):
-        return _Indexer(self._edata, _canon)
+        return _EdgeView(self)
+
+    def all_edges(self, form='uv', order='eid', etype=None):
+        return self._edges[_canon(etype)]
 
     def num_nodes(self, ntype):
         return self._num_nodes[ntype]

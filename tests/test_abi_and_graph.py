@@ -202,3 +202,82 @@ def test_native_pack_equals_numpy_pack(monkeypatch):
             a, b = getattr(ref, k), getattr(nat, k)
             assert a.dtype == b.dtype and a.shape == b.shape and torch.equal(a, b), k
             assert b.data_ptr() % 64 == 0, k
+
+
+def _same_batch(a, b):
+    pa, pb = a.pack(), b.pack()
+    for k in G.PackedGraph.INT_FIELDS + ('edge_perm', 'he', 'he_bf16', 'mu_r_norm', 'x0'):
+        assert torch.equal(getattr(pa, k), getattr(pb, k)), k
+    for nt in ('ligand', 'receptor'):
+        assert set(a._ndata[nt]) == set(b._ndata[nt])
+        for k in a._ndata[nt]:
+            assert torch.equal(a._ndata[nt][k], b._ndata[nt][k]), (nt, k)
+    for et in ('ll', 'rr'):
+        assert torch.equal(a._edata[et]['he'], b._edata[et]['he']), et
+        assert torch.equal(a._edges[et][0], b._edges[et][0]) and torch.equal(a._edges[et][1], b._edges[et][1]), et
+    assert a._batch_nodes == b._batch_nodes and a._batch_edges == b._batch_edges
+
+
+def test_native_collate_equals_per_pair_collate(monkeypatch):
+    """batch_pairs through ONE native call (eqd_host_collate_pack: per-pair arrays -> batch arrays + kernel layout)
+    against the per-pair construction + batch() + numpy pack: identical container and identical packed layout; also the
+    intermediate route (python batch(), native pack)."""
+    from equidock_public_amd import build as B
+    B.build_host(verbose=False)
+    rng = np.random.default_rng(11)
+    pairs = synthetic.make_pairs([(41, 57), (66, 38), (1, 40), (30, 1), (200, 180)], 3)
+    for d in pairs[1]:          # one pair with destination-unsorted edges
+        perm = rng.permutation(len(d['dst']))
+        d['src'], d['dst'], d['he'] = d['src'][perm], d['dst'][perm], d['he'][perm]
+    G._host_lib = None
+    nat = G.batch_pairs(pairs)
+    assert G._native() is not None and nat._packed is not None, "native collate did not run"
+    mid = G.batch([G.pair_from_arrays(l, r) for l, r in pairs])      # python batch, native pack
+    monkeypatch.setenv('EQD_NATIVE_PACK', '0')
+    ref = G.batch_pairs(pairs)
+    ref.pack()
+    monkeypatch.delenv('EQD_NATIVE_PACK')
+    _same_batch(nat, ref)
+    _same_batch(mid, ref)
+    # torch tensors as inputs, res_feat as (n, 1)
+    tp = [({k: torch.as_tensor(v) for k, v in l.items()}, {k: torch.as_tensor(v) for k, v in r.items()}) for l, r in pairs]
+    _same_batch(G.batch_pairs(tp), ref)
+    with pytest.raises(ValueError):
+        bad = [(dict(pairs[0][0], he=pairs[0][0]['he'][:, :20]), pairs[0][1])]
+        G.batch_pairs(bad)
+    with pytest.raises(ValueError):
+        bad = [(dict(pairs[0][0], src=pairs[0][0]['src'] + 1000), pairs[0][1])]
+        G.batch_pairs(bad)
+
+
+def test_from_dgl_equals_batch_pairs():
+    """graph.from_dgl on a batched heterograph built the reference's way (hetero_graph_from_sg_l_r_pair + dgl.batch,
+    src/utils/train_utils.py:61-100) - through the oracle's DGL stand-in, DGL itself being absent - packs bit-identically
+    to batch_pairs on the same pairs; and the drop-in module accepts the DGL object directly."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'oracle', '_dgl_standin'))
+    try:
+        import dgl
+    finally:
+        sys.path.pop(0)
+    pairs = synthetic.make_pairs([(41, 57), (66, 38), (1, 40)], 3)
+    hgs = []
+    for lig, rec in pairs:      # the reference's construction, restated: 4 edge types, two empty 'cross' ones
+        nl, nr = len(lig['x']), len(rec['x'])
+        hg = dgl.heterograph({('ligand', 'll', 'ligand'): (torch.as_tensor(lig['src']), torch.as_tensor(lig['dst'])),
+                              ('receptor', 'rr', 'receptor'): (torch.as_tensor(rec['src']), torch.as_tensor(rec['dst'])),
+                              ('ligand', 'cross', 'receptor'): ([], []), ('receptor', 'cross', 'ligand'): ([], [])},
+                             num_nodes_dict={'ligand': nl, 'receptor': nr})
+        for k in ('res_feat', 'x', 'new_x', 'mu_r_norm'):
+            hg.nodes['ligand'].data[k] = torch.as_tensor(lig[k])
+        for k in ('res_feat', 'x', 'mu_r_norm'):
+            hg.nodes['receptor'].data[k] = torch.as_tensor(rec[k])
+        hg.edges['ll'].data['he'] = torch.as_tensor(lig['he'])
+        hg.edges['rr'].data['he'] = torch.as_tensor(rec['he'])
+        hgs.append(hg)
+    batched = dgl.batch(hgs)
+    a = G.from_dgl(batched)
+    _same_batch(a, G.batch_pairs(pairs))
+    assert G.from_dgl(a) is a
+    with pytest.raises(TypeError):
+        G.from_dgl(object())

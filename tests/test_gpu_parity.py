@@ -135,6 +135,11 @@ def test_pocket_ot(dev):
     pc.check_pocket_ot(dev)
 
 
+def test_rigid_augment(dev):
+    from tests import parity_common as pc
+    pc.check_rigid_augment(dev)
+
+
 def test_scalar_loss(dev):
     from tests import parity_common as pc
     pc.check_scalar_loss(dev)

@@ -113,6 +113,10 @@ def test_pocket_ot():
     pc.check_pocket_ot(DEV)
 
 
+def test_rigid_augment():
+    pc.check_rigid_augment(DEV)
+
+
 def test_scalar_loss():
     pc.check_scalar_loss(DEV)
 
