@@ -97,7 +97,8 @@ def _declare(lib):
                  'eqd_cross_attention_fwd',
                  'eqd_cross_attention_bwd', 'eqd_keypoint_pool_fwd', 'eqd_keypoint_pool_bwd', 'eqd_kabsch_fwd', 'eqd_kabsch_bwd',
                  'eqd_rigid_apply_fwd', 'eqd_rigid_apply_bwd', 'eqd_pair_losses_fwd', 'eqd_pair_losses_bwd', 'eqd_scalar_loss', 'eqd_pocket_ot_cost',
-                 'eqd_pocket_ot_fwd', 'eqd_pocket_ot_bwd', 'eqd_rigid_augment'):
+                 'eqd_pocket_ot_fwd', 'eqd_pocket_ot_bwd', 'eqd_rigid_augment', 'eqd_protein_graph_distances',
+                 'eqd_protein_graph_select', 'eqd_protein_graph_edges'):
         getattr(lib, name).restype = C.c_int
 
 
@@ -109,7 +110,7 @@ EXPORTS = ('eqd_profile_begin', 'eqd_profile_end', 'eqd_profile_mark', 'eqd_prof
            'eqd_keypoint_pool_bwd_workspace_bytes',
            'eqd_kabsch_fwd', 'eqd_kabsch_bwd', 'eqd_rigid_apply_fwd', 'eqd_rigid_apply_bwd', 'eqd_pair_losses_fwd',
            'eqd_pair_losses_bwd', 'eqd_scalar_loss', 'eqd_pocket_ot_cost', 'eqd_pocket_ot_fwd', 'eqd_pocket_ot_bwd',
-           'eqd_rigid_augment')
+           'eqd_rigid_augment', 'eqd_protein_graph_distances', 'eqd_protein_graph_select', 'eqd_protein_graph_edges')
 
 
 def load_library():

@@ -298,6 +298,23 @@ int eqd_pair_losses_bwd(const EqdGraph* g, const float* lig_pred, const float* l
 int eqd_rigid_augment(const EqdGraph* g, const float* x_lig, const float* R, const float* t, float* new_x,
                       const int32_t* pocket_off, const float* pocket_in, float* pocket_out, void* stream);
 
+/* Graph construction / featurisation (compute_dig_kNN_graph, src/utils/protein_utils.py:311-397), one protein per call,
+ * fp64 like the reference's numpy code.  atoms [A][3] fp32 + atom_off [n + 1]: the all-atom coordinates of each residue;
+ * x, n_i, u_i, v_i [n][3] fp64: (aligned) representative locations and local frames.
+ *   eqd_protein_graph_distances: D [n][n] fp64 = mean all-atom distance between residues (inf on the diagonal)
+ *   eqd_protein_graph_select   : per residue i its sources: the j with D[i][j] < cutoff in index order, or the
+ *                                max_neighbor nearest in ascending distance when more qualify (np.argsort, :339-343) ->
+ *                                nbr / nbr_dist [n][max_neighbor], deg [n]; and mu_r_norm [n][5] fp32 (:351-359)
+ *   eqd_protein_graph_edges    : edge_off [n + 1] = exclusive prefix sum of deg (by the caller) -> destination-major
+ *                                src / dst [E] int32 and he [E][27] fp32 = 15 RBFs exp(-d^2 / 1.5^k) (:71-86) followed by
+ *                                the orientation features p, q, k, t in the destination's frame (:370-387) */
+int eqd_protein_graph_distances(int n, const float* atoms, const int32_t* atom_off, double* D, void* stream);
+int eqd_protein_graph_select(int n, int max_neighbor, double cutoff, const double* D, const double* x, int32_t* nbr,
+                             double* nbr_dist, int32_t* deg, float* mu_r_norm, void* stream);
+int eqd_protein_graph_edges(int n, int max_neighbor, const int32_t* edge_off, const int32_t* nbr, const double* nbr_dist,
+                            const double* x, const double* n_i, const double* u_i, const double* v_i, int32_t* src,
+                            int32_t* dst, float* he, void* stream);
+
 /* Pocket optimal-transport term of the loss (src/train.py:117-129, src/utils/ot_utils.py:5-29), device side.  Pocket
  * rows of all pairs are stored one after the other: pocket_lig / pocket_rec [sum n_pocket][3] (matched rows: row i of
  * both is the same binding-pocket contact), pocket_off [n_pairs + 1] (device, int32); Y_* [n_pairs][n_heads][3].

@@ -207,3 +207,34 @@ def unbatch(g):
             eoff[et] += g._batch_edges[et][i]
         outs.append(h)
     return outs
+
+
+class _HomoGraph:
+    """dgl.graph(([], []), idtype=...) + add_nodes / add_edges / ndata / edata: what the reference's graph construction
+    (src/utils/protein_utils.py:331-333, 363-394) uses to hold one protein's k-NN graph."""
+
+    def __init__(self):
+        self._n = 0
+        self._src, self._dst = [], []
+        self.ndata, self.edata = {}, {}
+
+    def add_nodes(self, n):
+        self._n += int(n)
+
+    def add_edges(self, u, v):
+        self._src.extend(int(a) for a in u)
+        self._dst.extend(int(a) for a in v)
+
+    def num_nodes(self):
+        return self._n
+
+    def num_edges(self):
+        return len(self._src)
+
+    def edges(self):
+        return torch.tensor(self._src, dtype=torch.int32), torch.tensor(self._dst, dtype=torch.int32)
+
+
+def graph(data, idtype=None):
+    assert len(data[0]) == 0 and len(data[1]) == 0
+    return _HomoGraph()

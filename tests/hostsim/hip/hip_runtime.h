@@ -78,6 +78,7 @@ void wave_barrier();
 
 static inline void __syncthreads() { hostsim::sync_block(); }
 static inline void __threadfence() {}
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 #define EQD_KERNARG_PTR(first_param) ((const void*)&(first_param))   /* host: the by-value argument itself */
 #define EQD_GAS   /* no address spaces on the host */
 #define EQD_NATIVE_EXP(x) expf(x)   /* the device build uses __expf (v_exp_f32) */

@@ -877,3 +877,67 @@ def check_rigid_augment(dev):
         assert abs(np.linalg.det(rot_T) - 1) < 1e-5 and float(np.linalg.norm(rot_b)) < 5.0
         lo += len(x)
     assert torch.equal(g.pack().x0[:g.pack().n_lig].cpu(), new_x)
+
+
+def _residues_from_fixture(z, prefix):
+    from equidock_public_amd import featurize as FZ
+    off = z[prefix + 'atom_off']
+    res = []
+    for i in range(len(off) - 1):
+        a0, a1 = int(off[i]), int(off[i + 1])
+        res.append(FZ.Residue(str(z[prefix + 'chains'][i]), int(z[prefix + 'numbers'][i]), str(z[prefix + 'resnames'][i]),
+                              [str(a) for a in z[prefix + 'atom_names'][a0:a1]],
+                              [str(e) for e in z[prefix + 'elements'][a0:a1]], z[prefix + 'atoms'][a0:a1]))
+    return res
+
+
+def check_protein_graph(dev):
+    """Graph construction / featurisation on the device (equidock_public_amd.featurize -> eqd_protein_graph_*) against the
+    vectors recorded from the reference's own protein_to_graph_unbound_bound_residuesonly on a real DB5.5 complex
+    (tests/golden/graph_case.npz, oracle/make_golden_graph.py): int32 endpoints bit-exact (neighbour sets AND order),
+    features to float32 rounding; then the graphs run through the model."""
+    import os
+    from equidock_public_amd import featurize as FZ
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'graph_case.npz'))
+    lig_all, rec_all = _residues_from_fixture(z, 'lig_in_'), _residues_from_fixture(z, 'rec_in_')
+    lig, rec, lig_ca, rec_ca, pocket = FZ.preprocess_unbound_bound(lig_all, rec_all)
+    assert np.array_equal(lig_ca, z['lig_ca']) and np.array_equal(rec_ca, z['rec_ca'])
+    np.testing.assert_allclose(pocket, z['pocket'], rtol=0, atol=1e-6)
+    gl, gr = FZ.protein_to_graph_unbound_bound(lig, rec, lig_ca, rec_ca, cutoff=float(z['cutoff']),
+                                               max_neighbor=int(z['max_neighbor']), device=dev)
+    sync(dev)
+    for nm, g in (('lig', gl), ('rec', gr)):
+        assert g['src'].dtype == torch.int32 and g['dst'].dtype == torch.int32
+        assert np.array_equal(g['src'].cpu().numpy(), z[nm + '_src']), f'{nm}: source indices differ from the reference'
+        assert np.array_equal(g['dst'].cpu().numpy(), z[nm + '_dst']), f'{nm}: destination indices differ'
+        assert np.array_equal(g['res_feat'].cpu().numpy(), z[nm + '_res'])
+        close(g['he'], torch.from_numpy(z[nm + '_he']), tol=1e-6, what=f'{nm} edge features')
+        close(g['x'], torch.from_numpy(z[nm + '_x']), tol=1e-6, what=f'{nm} x')
+        close(g['mu_r_norm'], torch.from_numpy(z[nm + '_mu']), tol=1e-6, what=f'{nm} mu_r_norm')
+    # fewer candidates than max_neighbor (np.where order) and a cut-off that empties some rows' tails
+    g2 = FZ.protein_graph(lig, lig_ca, 9.0, 10, dev)
+    sync(dev)
+    D = None
+    loc = np.stack([r.coords[r.atom('CA')[0]] for r in lig])
+    import scipy.spatial as spa
+    n = len(lig)
+    D = np.full((n, n), np.inf)
+    for i in range(n - 1):
+        for j in range(i + 1, n):
+            D[i, j] = D[j, i] = np.mean(spa.distance.cdist(lig[i].coords, lig[j].coords))
+    src, dst = [], []
+    for i in range(n):
+        valid = list(np.where(D[i, :] < 9.0)[0])
+        if len(valid) > 10:
+            valid = list(np.argsort(D[i, :]))[0:10]
+        src.extend(valid)
+        dst.extend([i] * len(valid))
+    assert np.array_equal(g2['src'].cpu().numpy(), np.asarray(src, dtype=np.int32))
+    assert np.array_equal(g2['dst'].cpu().numpy(), np.asarray(dst, dtype=np.int32))
+    # the featurised pair goes through the drop-in like any other batch (src/inference_rigid.py:186-196)
+    args = port.default_args(iegmn_n_lays=2, skip_weight_h=0.5)
+    net = build_model(args, port.init_state_dict(args, seed=2), dev)
+    batch = G.batch_pairs([(dict(gl, new_x=gl['x']), gr)]).to(dev)
+    with torch.no_grad():
+        outs = net(batch, epoch=0)
+    assert outs[0][0].shape == (len(lig), 3) and torch.isfinite(outs[0][0]).all()

@@ -140,6 +140,11 @@ def test_rigid_augment(dev):
     pc.check_rigid_augment(dev)
 
 
+def test_protein_graph_vs_reference_golden(dev):
+    from tests import parity_common as pc
+    pc.check_protein_graph(dev)
+
+
 def test_scalar_loss(dev):
     from tests import parity_common as pc
     pc.check_scalar_loss(dev)

@@ -117,6 +117,10 @@ def test_rigid_augment():
     pc.check_rigid_augment(DEV)
 
 
+def test_protein_graph_vs_reference_golden():
+    pc.check_protein_graph(DEV)
+
+
 def test_scalar_loss():
     pc.check_scalar_loss(DEV)
 
