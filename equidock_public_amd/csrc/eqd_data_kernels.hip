@@ -291,3 +291,252 @@ extern "C" int eqd_protein_graph_edges(int n, int max_neighbor, const int32_t* e
                        (hipStream_t)stream, n, max_neighbor, edge_off, nbr, nbr_dist, x, n_i, u_i, v_i, src, dst, he);
     return eqd_check_launch("k_pg_edges");
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Inference post-processing: the clash-removal loop of src/inference_rigid.py:207-234 -
+// gradient descent on 3 Euler angles + a translation of the docked ligand (ALL atoms) against the receptor (all atoms)
+// under compute_body_intersection_loss(sigma = 8, surface_ct = 8), up to 2000 iterations, which the reference runs as
+// torch autograd over an (n_lig x n_rec) matrix per iteration on the host.  Here: four small launches per iteration
+// with the whole state on the device (angles, translation, iteration counter, stop flag); once the stop rule
+// (loss <= loss_stop or it >= max_it) fires, the remaining launches of a chunk return immediately, so the host only
+// looks at the flag every few dozen iterations.  float32 like the reference.
+//   ligand_th_i = R(euler) p_i + t,   R = RZ(yaw) RY(pitch) RX(roll),  euler = (roll, yaw, pitch)        (:46-73, :213)
+//   loss = mean_i max(0, ct - G_r(a_i)) + mean_k max(0, ct - G_l(b_k)),  G(x) = -sigma log(1e-3 + sum exp(-|x - c|^2 / sigma))
+//   eta = 1e-3; 1e-4 if loss < 2; 1e-2 if it > 1500                                                      (:219-224)
+// ---------------------------------------------------------------------------------------------------------------
+#define CL_TILE 1024
+struct EqdClashWs {
+    float* lig_th;     // [n_lig][3] current ligand positions
+    float* s_lig;      // [n_lig]
+    float* w_rec;      // [n_rec]  [ct - G_l(b_k) >= 0] / (n_rec (1e-3 + S_k))
+    float* part1;      // [nb_lig] term-1 partial sums
+    float* part2;      // [nb_rec] term-2 partial sums
+    float* gpart;      // [nb_lig][6] partial (d trans, d euler)
+};
+__device__ __forceinline__ void euler_rot(const float* e, float R[9]) {
+    const float cr = cosf(e[0]), sr = sinf(e[0]), cy = cosf(e[1]), sy = sinf(e[1]), cp = cosf(e[2]), sp = sinf(e[2]);
+    // RZ(yaw) RY(pitch) RX(roll)
+    R[0] = cy * cp; R[1] = cy * sp * sr - sy * cr; R[2] = cy * sp * cr + sy * sr;
+    R[3] = sy * cp; R[4] = sy * sp * sr + cy * cr; R[5] = sy * sp * cr - cy * sr;
+    R[6] = -sp;     R[7] = cp * sr;                R[8] = cp * cr;
+}
+__device__ __forceinline__ float block_sum256(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+// pass 1: positions + Gaussian sums of every ligand atom against the receptor
+__global__ __launch_bounds__(EQD_BLOCK) void k_clash_lig(int n_lig, int n_rec, const float* __restrict__ lig0,
+                                                         const float* __restrict__ rec, float sigma, float ct,
+                                                         const EqdClashState* __restrict__ st, EqdClashWs W) {
+    __shared__ float pts[CL_TILE][3];
+    __shared__ float red[EQD_WAVES];
+    if (st->done) return;
+    float R[9];
+    const float e[3] = {st->euler[0], st->euler[1], st->euler[2]};
+    euler_rot(e, R);
+    const int i = blockIdx.x * EQD_BLOCK + threadIdx.x;
+    const int ic = i < n_lig ? i : n_lig - 1;
+    const float px = lig0[(size_t)ic * 3], py = lig0[(size_t)ic * 3 + 1], pz = lig0[(size_t)ic * 3 + 2];
+    const float ax = (R[0] * px + R[1] * py) + R[2] * pz + st->trans[0];
+    const float ay = (R[3] * px + R[4] * py) + R[5] * pz + st->trans[1];
+    const float az = (R[6] * px + R[7] * py) + R[8] * pz + st->trans[2];
+    const float inv = 1.f / sigma;
+    float S = 0.f;
+    for (int c0 = 0; c0 < n_rec; c0 += CL_TILE) {
+        const int nc = n_rec - c0 < CL_TILE ? n_rec - c0 : CL_TILE;
+        __syncthreads();
+        for (int k = threadIdx.x; k < 3 * nc; k += EQD_BLOCK) pts[k / 3][k % 3] = rec[(size_t)c0 * 3 + k];
+        __syncthreads();
+        for (int k = 0; k < nc; ++k) {
+            const float dx = pts[k][0] - ax, dy = pts[k][1] - ay, dz = pts[k][2] - az;
+            S += expf(-((dx * dx + dy * dy) + dz * dz) * inv);
+        }
+    }
+    float term = 0.f;
+    if (i < n_lig) {
+        W.lig_th[(size_t)i * 3] = ax; W.lig_th[(size_t)i * 3 + 1] = ay; W.lig_th[(size_t)i * 3 + 2] = az;
+        W.s_lig[i] = S;
+        const float G = -sigma * logf(1e-3f + S);
+        term = ct - G > 0.f ? ct - G : 0.f;
+    }
+    const float tot = block_sum256(term, red);
+    if (threadIdx.x == 0) W.part1[blockIdx.x] = tot;
+}
+// pass 2: Gaussian sums of every receptor atom against the moved ligand -> weights of the backward, term-2 partials
+__global__ __launch_bounds__(EQD_BLOCK) void k_clash_rec(int n_lig, int n_rec, const float* __restrict__ rec, float sigma,
+                                                         float ct, const EqdClashState* __restrict__ st, EqdClashWs W) {
+    __shared__ float pts[CL_TILE][3];
+    __shared__ float red[EQD_WAVES];
+    if (st->done) return;
+    const int k = blockIdx.x * EQD_BLOCK + threadIdx.x;
+    const int kc = k < n_rec ? k : n_rec - 1;
+    const float bx = rec[(size_t)kc * 3], by = rec[(size_t)kc * 3 + 1], bz = rec[(size_t)kc * 3 + 2];
+    const float inv = 1.f / sigma;
+    float S = 0.f;
+    for (int c0 = 0; c0 < n_lig; c0 += CL_TILE) {
+        const int nc = n_lig - c0 < CL_TILE ? n_lig - c0 : CL_TILE;
+        __syncthreads();
+        for (int q = threadIdx.x; q < 3 * nc; q += EQD_BLOCK) pts[q / 3][q % 3] = W.lig_th[(size_t)c0 * 3 + q];
+        __syncthreads();
+        for (int q = 0; q < nc; ++q) {
+            const float dx = pts[q][0] - bx, dy = pts[q][1] - by, dz = pts[q][2] - bz;
+            S += expf(-((dx * dx + dy * dy) + dz * dz) * inv);
+        }
+    }
+    float term = 0.f;
+    if (k < n_rec) {
+        const float G = -sigma * logf(1e-3f + S);
+        term = ct - G > 0.f ? ct - G : 0.f;
+        W.w_rec[k] = ct - G >= 0.f ? 1.f / ((float)n_rec * (1e-3f + S)) : 0.f;
+    }
+    const float tot = block_sum256(term, red);
+    if (threadIdx.x == 0) W.part2[blockIdx.x] = tot;
+}
+__device__ __forceinline__ float clash_loss(int n_lig, int n_rec, const EqdClashWs& W) {
+    const int nb1 = (n_lig + EQD_BLOCK - 1) / EQD_BLOCK, nb2 = (n_rec + EQD_BLOCK - 1) / EQD_BLOCK;
+    float a = 0.f, b = 0.f;
+    for (int q = 0; q < nb1; ++q) a += W.part1[q];
+    for (int q = 0; q < nb2; ++q) b += W.part2[q];
+    return a / (float)n_lig + b / (float)n_rec;
+}
+// pass 3: gradient w.r.t. every ligand atom, chained to (translation, Euler angles); per-block partial sums
+__global__ __launch_bounds__(EQD_BLOCK) void k_clash_grad(int n_lig, int n_rec, const float* __restrict__ lig0,
+                                                          const float* __restrict__ rec, float sigma, float ct,
+                                                          float loss_stop, int max_it,
+                                                          const EqdClashState* __restrict__ st, EqdClashWs W) {
+    __shared__ float pts[CL_TILE][4];
+    __shared__ float red[EQD_WAVES];
+    if (st->done) return;
+    const float loss = clash_loss(n_lig, n_rec, W);          // every thread: same fixed-order sum
+    if (!(loss > loss_stop && st->it < max_it)) return;     // converged: k_clash_step raises the flag
+    const float e[3] = {st->euler[0], st->euler[1], st->euler[2]};
+    const int i = blockIdx.x * EQD_BLOCK + threadIdx.x;
+    const int ic = i < n_lig ? i : n_lig - 1;
+    const float ax = W.lig_th[(size_t)ic * 3], ay = W.lig_th[(size_t)ic * 3 + 1], az = W.lig_th[(size_t)ic * 3 + 2];
+    const float Si = W.s_lig[ic];
+    const float Gi = -sigma * logf(1e-3f + Si);
+    const float wi = (ct - Gi >= 0.f) ? 1.f / ((float)n_lig * (1e-3f + Si)) : 0.f;
+    const float inv = 1.f / sigma;
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    for (int c0 = 0; c0 < n_rec; c0 += CL_TILE) {
+        const int nc = n_rec - c0 < CL_TILE ? n_rec - c0 : CL_TILE;
+        __syncthreads();
+        for (int k = threadIdx.x; k < nc; k += EQD_BLOCK) {
+            pts[k][0] = rec[(size_t)(c0 + k) * 3]; pts[k][1] = rec[(size_t)(c0 + k) * 3 + 1];
+            pts[k][2] = rec[(size_t)(c0 + k) * 3 + 2]; pts[k][3] = W.w_rec[c0 + k];
+        }
+        __syncthreads();
+        for (int k = 0; k < nc; ++k) {
+            const float dx = ax - pts[k][0], dy = ay - pts[k][1], dz = az - pts[k][2];
+            const float w = expf(-((dx * dx + dy * dy) + dz * dz) * inv) * (wi + pts[k][3]);
+            gx += w * dx; gy += w * dy; gz += w * dz;
+        }
+    }
+    // d loss / d a_i = -2 (gx, gy, gz); a_i = R(euler) p_i + t
+    float g[3] = {i < n_lig ? -2.f * gx : 0.f, i < n_lig ? -2.f * gy : 0.f, i < n_lig ? -2.f * gz : 0.f};
+    const float px = lig0[(size_t)ic * 3], py = lig0[(size_t)ic * 3 + 1], pz = lig0[(size_t)ic * 3 + 2];
+    const float cr = cosf(e[0]), sr = sinf(e[0]), cy = cosf(e[1]), sy = sinf(e[1]), cp = cosf(e[2]), sp = sinf(e[2]);
+    // dR/droll, dR/dyaw, dR/dpitch of R = RZ(yaw) RY(pitch) RX(roll)
+    const float dRr[9] = {0.f, cy * sp * cr + sy * sr, -cy * sp * sr + sy * cr,
+                          0.f, sy * sp * cr - cy * sr, -sy * sp * sr - cy * cr,
+                          0.f, cp * cr, -cp * sr};
+    const float dRy[9] = {-sy * cp, -sy * sp * sr - cy * cr, -sy * sp * cr + cy * sr,
+                          cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr,
+                          0.f, 0.f, 0.f};
+    const float dRp[9] = {-cy * sp, cy * cp * sr, cy * cp * cr,
+                          -sy * sp, sy * cp * sr, sy * cp * cr,
+                          -cp, -sp * sr, -sp * cr};
+    float out[6];
+    out[0] = g[0]; out[1] = g[1]; out[2] = g[2];
+    const float* dRs[3] = {dRr, dRy, dRp};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float* d = dRs[j];
+        out[3 + j] = g[0] * ((d[0] * px + d[1] * py) + d[2] * pz) + g[1] * ((d[3] * px + d[4] * py) + d[5] * pz) +
+                     g[2] * ((d[6] * px + d[7] * py) + d[8] * pz);
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const float tot = block_sum256(out[j], red);
+        if (threadIdx.x == 0) W.gpart[(size_t)blockIdx.x * 6 + j] = tot;
+    }
+}
+// pass 4 (one wave): stop rule, step size, update
+__global__ void k_clash_step(int n_lig, int n_rec, float loss_stop, int max_it, EqdClashState* __restrict__ st,
+                             EqdClashWs W) {
+    if (st->done) return;
+    if (threadIdx.x != 0) return;
+    const float loss = clash_loss(n_lig, n_rec, W);
+    st->loss = loss;
+    if (!(loss > loss_stop && st->it < max_it)) {
+        st->done = 1;
+        return;
+    }
+    float eta = 1e-3f;
+    if (loss < 2.f) eta = 1e-4f;
+    if (st->it > 1500) eta = 1e-2f;
+    const int nb = (n_lig + EQD_BLOCK - 1) / EQD_BLOCK;
+    float g[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < nb; ++q)
+        for (int j = 0; j < 6; ++j) g[j] += W.gpart[(size_t)q * 6 + j];
+    for (int j = 0; j < 3; ++j) {
+        st->trans[j] -= eta * g[j];
+        st->euler[j] -= eta * g[3 + j];
+    }
+    st->it += 1;
+}
+
+static size_t clash_carve(int n_lig, int n_rec, EqdArena& A, EqdClashWs* W) {
+    const size_t nb1 = (size_t)(n_lig + EQD_BLOCK - 1) / EQD_BLOCK, nb2 = (size_t)(n_rec + EQD_BLOCK - 1) / EQD_BLOCK;
+    EqdClashWs w;
+    w.lig_th = A.take<float>((size_t)n_lig * 3);
+    w.s_lig = A.take<float>((size_t)n_lig);
+    w.w_rec = A.take<float>((size_t)n_rec);
+    w.part1 = A.take<float>(nb1);
+    w.part2 = A.take<float>(nb2);
+    w.gpart = A.take<float>(nb1 * 6);
+    if (W) *W = w;
+    return A.off;
+}
+extern "C" size_t eqd_clash_workspace_bytes(int n_lig, int n_rec) {
+    if (n_lig < 1 || n_rec < 1) return 0;
+    EqdArena A(nullptr, 0);
+    return clash_carve(n_lig, n_rec, A, nullptr) + 256;
+}
+extern "C" int eqd_clash_iterations(int n_iter, int n_lig, int n_rec, const float* lig0, const float* rec, float sigma,
+                                    float surface_ct, float loss_stop, int max_it, EqdClashState* state, void* workspace,
+                                    size_t ws_bytes, void* stream) {
+    if (!lig0 || !rec || !state || !workspace) {
+        eqd_set_error("eqd_clash_iterations: NULL argument");
+        return EQD_ERR_NULL;
+    }
+    if (n_lig < 1 || n_rec < 1 || !(sigma > 0.f) || n_iter < 0) {
+        eqd_set_error("eqd_clash_iterations: n_lig = %d, n_rec = %d, sigma = %g", n_lig, n_rec, sigma);
+        return EQD_ERR_SHAPE;
+    }
+    EqdArena A(workspace, ws_bytes);
+    EqdClashWs W;
+    clash_carve(n_lig, n_rec, A, &W);
+    if (!A.ok) {
+        eqd_set_error("eqd_clash_iterations: workspace too small (%zu needed)", A.off);
+        return EQD_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int nb1 = (n_lig + EQD_BLOCK - 1) / EQD_BLOCK, nb2 = (n_rec + EQD_BLOCK - 1) / EQD_BLOCK;
+    for (int it = 0; it < n_iter; ++it) {
+        hipLaunchKernelGGL(k_clash_lig, dim3(nb1), dim3(EQD_BLOCK), 0, st, n_lig, n_rec, lig0, rec, sigma, surface_ct, state, W);
+        if (int rc = eqd_check_launch("k_clash_lig")) return rc;
+        hipLaunchKernelGGL(k_clash_rec, dim3(nb2), dim3(EQD_BLOCK), 0, st, n_lig, n_rec, rec, sigma, surface_ct, state, W);
+        if (int rc = eqd_check_launch("k_clash_rec")) return rc;
+        hipLaunchKernelGGL(k_clash_grad, dim3(nb1), dim3(EQD_BLOCK), 0, st, n_lig, n_rec, lig0, rec, sigma, surface_ct,
+                           loss_stop, max_it, state, W);
+        if (int rc = eqd_check_launch("k_clash_grad")) return rc;
+        hipLaunchKernelGGL(k_clash_step, dim3(1), dim3(64), 0, st, n_lig, n_rec, loss_stop, max_it, state, W);
+        if (int rc = eqd_check_launch("k_clash_step")) return rc;
+    }
+    return EQD_OK;
+}
+/* lig_th of the last evaluated iteration lives at the start of the workspace ([n_lig][3] floats) */

@@ -315,6 +315,26 @@ int eqd_protein_graph_edges(int n, int max_neighbor, const int32_t* edge_off, co
                             const double* x, const double* n_i, const double* u_i, const double* v_i, int32_t* src,
                             int32_t* dst, float* he, void* stream);
 
+/* Clash removal after docking (src/inference_rigid.py:207-234): gradient descent on 3 Euler angles (roll, yaw, pitch;
+ * R = RZ RY RX, :46-73) and a translation applied to the docked ligand's atoms `lig0` [n_lig][3] against the receptor
+ * atoms `rec` [n_rec][3] under compute_body_intersection_loss (reference: sigma = 8, surface_ct = 8), while
+ * loss > loss_stop (0.5) and it < max_it (2000), with the reference's step sizes.  All state lives on the device:
+ * `state` (zero-initialised by the caller: angles, translation, iteration counter, last loss, stop flag).  One call
+ * enqueues n_iter iterations (4 launches each; they return immediately once the flag is up) - the caller reads
+ * state->done every few dozen iterations.  The ligand positions of the last evaluated iteration are the first
+ * n_lig * 3 floats of `workspace`.  float32 like the reference. */
+typedef struct EqdClashState {
+    float euler[3];
+    float trans[3];
+    float loss;
+    int32_t it;
+    int32_t done;
+    int32_t reserved;
+} EqdClashState;
+size_t eqd_clash_workspace_bytes(int n_lig, int n_rec);
+int eqd_clash_iterations(int n_iter, int n_lig, int n_rec, const float* lig0, const float* rec, float sigma, float surface_ct,
+                         float loss_stop, int max_it, EqdClashState* state, void* workspace, size_t ws_bytes, void* stream);
+
 /* Pocket optimal-transport term of the loss (src/train.py:117-129, src/utils/ot_utils.py:5-29), device side.  Pocket
  * rows of all pairs are stored one after the other: pocket_lig / pocket_rec [sum n_pocket][3] (matched rows: row i of
  * both is the same binding-pocket contact), pocket_off [n_pairs + 1] (device, int32); Y_* [n_pairs][n_heads][3].

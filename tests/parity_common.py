@@ -941,3 +941,42 @@ def check_protein_graph(dev):
     with torch.no_grad():
         outs = net(batch, epoch=0)
     assert outs[0][0].shape == (len(lig), 3) and torch.isfinite(outs[0][0]).all()
+
+
+def check_inference_postprocessing(dev):
+    """Clash removal on the device (equidock_public_amd.inference.remove_clashes -> eqd_clash_iterations), get_rot_mat,
+    apply_rigid and the RMSD meter against vectors recorded from the reference's own functions
+    (tests/golden/inference_case.npz, oracle/make_golden_inference.py)."""
+    import os
+    from equidock_public_amd import inference as INF
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'inference_case.npz'))
+    close(INF.get_rot_mat(torch.from_numpy(z['rot_euler'])), torch.from_numpy(z['rot_mat']), tol=1e-6, what='get_rot_mat')
+    for tag in ('a', 'b', 'c'):
+        lig, rec = torch.from_numpy(z[tag + '_lig']).to(dev), torch.from_numpy(z[tag + '_rec']).to(dev)
+        cap, it_ref, losses = int(z[tag + '_max_it']), int(z[tag + '_it']), z[tag + '_losses']
+        out = INF.remove_clashes(lig, rec, max_it=cap, check_every=100)
+        # float32 gradient descent on a non-convex loss: trajectories with re-ordered sums agree to 1e-6 for hundreds of
+        # iterations and drift apart over thousands (0.2 A after 2000, a third of them at the 1e-2 step size), and the
+        # threshold crossing can move by a few iterations
+        if tag == 'a':
+            assert out['iterations'] == it_ref == cap
+            close(out['positions'], torch.from_numpy(z[tag + '_pos']), tol=1e-4, what='clash removal a: ligand atoms after 300 iterations')
+            close(torch.from_numpy(out['euler']), torch.from_numpy(z['a_euler']), tol=1e-4, what='euler angles')
+            close(torch.from_numpy(out['translation']), torch.from_numpy(z['a_trans']), tol=1e-4, what='translation')
+        elif tag == 'b':
+            assert it_ref < cap and abs(out['iterations'] - it_ref) <= 25, (out['iterations'], it_ref)
+            assert out['loss'] <= 0.5
+            close(out['positions'], torch.from_numpy(z[tag + '_pos']), tol=2e-3, what='clash removal b: converged ligand atoms')
+        else:
+            assert out['iterations'] == it_ref == cap
+            assert abs(out['loss'] - float(losses[-1])) <= 3e-2 * float(losses[-1]), (out['loss'], float(losses[-1]))
+        # the returned parameters reproduce the returned positions (the reference's parametrisation, :213)
+        R = INF.get_rot_mat(torch.from_numpy(out['euler']))
+        close(out['positions'], INF.apply_rigid(R, out['translation'], lig.cpu()), tol=1e-5, what='positions vs (euler, t)')
+    lig, rmsd_rec, cpx = INF.rmsd_metrics(z['m_lp'], z['m_rp'], z['m_lt'], z['m_rt'])
+    assert abs(lig - float(z['m_ligand'])) < 1e-5 and abs(rmsd_rec - float(z['m_receptor'])) < 1e-5
+    assert abs(cpx - float(z['m_complex'])) < 1e-5
+    m = INF.Meter_Unbound_Bound()
+    m.update_rmsd(torch.from_numpy(z['m_lp']), torch.from_numpy(z['m_rp']), torch.from_numpy(z['m_lt']),
+                  torch.from_numpy(z['m_rt']))
+    assert abs(m.summarize('median')[2] - float(z['m_complex'])) < 1e-5

@@ -145,6 +145,11 @@ def test_protein_graph_vs_reference_golden(dev):
     pc.check_protein_graph(dev)
 
 
+def test_inference_postprocessing(dev):
+    from tests import parity_common as pc
+    pc.check_inference_postprocessing(dev)
+
+
 def test_scalar_loss(dev):
     from tests import parity_common as pc
     pc.check_scalar_loss(dev)

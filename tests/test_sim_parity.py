@@ -121,6 +121,10 @@ def test_protein_graph_vs_reference_golden():
     pc.check_protein_graph(DEV)
 
 
+def test_inference_postprocessing():
+    pc.check_inference_postprocessing(DEV)
+
+
 def test_scalar_loss():
     pc.check_scalar_loss(DEV)
 
