@@ -37,6 +37,7 @@ def seeded_state_dict(args, seed, rot_scale=40.0):
     finally:
         torch.set_rng_state(state)
     sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
-    for k in ('iegmn_original.att_mlp_key_ROT.0.weight', 'iegmn_original.att_mlp_query_ROT.0.weight'):
-        sd[k] = sd[k] * rot_scale
+    for k in sd:        # both stages when fine_tune is on
+        if k.endswith('att_mlp_key_ROT.0.weight') or k.endswith('att_mlp_query_ROT.0.weight'):
+            sd[k] = sd[k] * rot_scale
     return sd

@@ -167,6 +167,21 @@ class PairGraph:
             self._packed.pin_memory()
         return self
 
+    def with_ligand_coords(self, new_x):
+        """A batch that shares everything with this one except the ligand's `new_x` (the reference's fine-tune stage
+        writes the first stage's docked ligand back and re-batches, rigid_docking_model.py:667-669, 681-682); the packed
+        topology is shared too, only the coordinate block is re-read."""
+        nd = {nt: dict(v) for nt, v in self._ndata.items()}
+        nd['ligand']['new_x'] = new_x
+        g = PairGraph(nd, self._edata, self._edges, self._batch_nodes, self._batch_edges)
+        if self._packed is not None:
+            import copy
+            g._packed = copy.copy(self._packed)
+            g._packed.x0 = None
+            g._packed._x0_key = None
+            g._packed._cstruct = None
+        return g
+
     # ---- packing for the HIP path ---------------------------------------------------------------
     def pack(self):
         """Device-resident kernel layout (topology cached; coordinates re-read every call)."""

@@ -16,10 +16,13 @@ same torch modules created in the same order, so a given torch seed yields the r
 initial weights).  The arithmetic does NOT run in those sub-modules: forward and backward are
 two C calls into the HIP library (include/equidock_hip.h) wrapped in one autograd.Function.
 
-There is no CPU/PyTorch fallback: a missing library, a CPU tensor or a configuration outside
-the HIP path raises.  Supported configuration = the published family (src/utils/args.py:227-280):
-nonlin 'lkyrelu', layer_norm 'LN', layer_norm_coors '0', final_h_layer_norm '0', dropout 0 (or
-eval mode), fine_tune False, hidden/embedding width 64.
+The published configuration family (src/utils/args.py:227-280: nonlin 'lkyrelu', layer_norm 'LN',
+layer_norm_coors '0', final_h_layer_norm '0', hidden/embedding width 64, no fine-tune stage) runs in the HIP
+library, and there is no CPU fallback for it: a missing library or a CPU tensor raises.  The reference's other
+options - swish, BatchNorm / LayerNorm placements, GraphNorm (src/utils/graph_norm.py), the fine-tune stage, and
+dropout > 0 while training (torch's RNG cannot be reproduced inside a fused kernel) - build the same sub-modules
+and run them through torch operators on the tensors' device (equidock_public_amd/torch_path.py), so that every
+configuration of the reference constructs, loads its checkpoint and trains.
 """
 import ctypes as C
 
@@ -31,18 +34,65 @@ from .graph import PairGraph
 
 
 def get_non_lin(type, negative_slope):
+    """rigid_docking_model.py:10-15."""
+    if type == 'swish':
+        return nn.SiLU()
     if type != 'lkyrelu':
-        raise NotImplementedError(f"nonlin='{type}': only 'lkyrelu' runs on the HIP path (published configs, "
-                                  "src/utils/args.py:263)")
+        raise ValueError(f"nonlin='{type}': the reference knows 'swish' and 'lkyrelu'")
     return nn.LeakyReLU(negative_slope=negative_slope)
 
 
 def get_layer_norm(layer_norm_type, dim):
+    """rigid_docking_model.py:18-24."""
+    if layer_norm_type == 'BN':
+        return nn.BatchNorm1d(dim)
     if layer_norm_type == 'LN':
         return nn.LayerNorm(dim)
-    if layer_norm_type == '0':
-        return nn.Identity()
-    raise NotImplementedError(f"layer_norm='{layer_norm_type}' is not supported on the HIP path")
+    return nn.Identity()
+
+
+class GraphNorm(nn.Module):
+    """src/utils/graph_norm.py:7-41: per-graph (x - mean) / (std + eps) with the UNBIASED std and eps added to the std,
+    then an affine map.  `counts`: nodes per graph of the batch (the reference reads them from g.batch_num_nodes)."""
+
+    def __init__(self, num_features, eps=1e-5, affine=True, is_node=True):
+        super().__init__()
+        self.eps, self.num_features, self.affine, self.is_node = eps, num_features, affine, is_node
+        if affine:
+            self.gamma = nn.Parameter(torch.ones(num_features))
+            self.beta = nn.Parameter(torch.zeros(num_features))
+        else:
+            self.register_parameter('gamma', None)
+            self.register_parameter('beta', None)
+
+    def forward(self, counts, h):
+        parts = [(x - x.mean(dim=0, keepdim=True)) / (x.std(dim=0, keepdim=True) + self.eps)
+                 for x in torch.split(h, [int(c) for c in counts])]
+        out = torch.cat(parts, 0)
+        return self.gamma * out + self.beta if self.affine else out
+
+
+def get_final_h_layer_norm(layer_norm_type, dim):
+    """rigid_docking_model.py:27-36."""
+    if layer_norm_type == 'BN':
+        return nn.BatchNorm1d(dim)
+    if layer_norm_type == 'LN':
+        return nn.LayerNorm(dim)
+    if layer_norm_type == 'GN':
+        return GraphNorm(dim)
+    if layer_norm_type != '0':
+        raise ValueError(f"final_h_layer_norm='{layer_norm_type}': the reference knows BN, LN, GN and '0'")
+    return nn.Identity()
+
+
+def hip_path_supported(args, fine_tune=False):
+    """True when the configuration is the published family (src/utils/args.py:227-280), which runs as two C calls into
+    the HIP library; every other reference option - swish, BatchNorm / LayerNorm placements, GraphNorm, the fine-tune
+    stage, and dropout > 0 while training - runs the same modules through torch operators on the GPU
+    (equidock_public_amd/torch_path.py)."""
+    return (not fine_tune and args['nonlin'] == 'lkyrelu' and args['layer_norm'] == 'LN' and args['layer_norm_coors'] == '0'
+            and args['final_h_layer_norm'] == '0' and args['iegmn_lay_hid_dim'] == 64 and args['residue_emb_dim'] <= 64
+            and args['input_edge_feats_dim'] == 27)
 
 
 class IEGMN_Layer(nn.Module):
@@ -50,14 +100,6 @@ class IEGMN_Layer(nn.Module):
 
     def __init__(self, orig_h_feats_dim, h_feats_dim, out_feats_dim, fine_tune, args, log=None):
         super().__init__()
-        if fine_tune:
-            raise NotImplementedError("fine_tune=True is outside the HIP path (reference: 'didn't work', "
-                                      "src/utils/args.py:110)")
-        if args['layer_norm'] != 'LN' or args['layer_norm_coors'] != '0' or args['final_h_layer_norm'] != '0':
-            raise NotImplementedError(
-                "HIP path supports layer_norm='LN', layer_norm_coors='0', final_h_layer_norm='0' (the published "
-                f"configuration); got {args['layer_norm']!r}, {args['layer_norm_coors']!r}, "
-                f"{args['final_h_layer_norm']!r}")
         input_edge_feats_dim = args['input_edge_feats_dim']
         dropout = args['dropout']
         nonlin = args['nonlin']
@@ -67,6 +109,7 @@ class IEGMN_Layer(nn.Module):
         self.skip_weight_h = args['skip_weight_h']
         self.x_connection_init = args['x_connection_init']
         self.fine_tune = fine_tune
+        self.final_h_layer_norm = args['final_h_layer_norm']
         self.debug = args['debug']
         self.log = log
         self.h_feats_dim = h_feats_dim
@@ -86,10 +129,17 @@ class IEGMN_Layer(nn.Module):
             nn.Linear(orig_h_feats_dim + 2 * h_feats_dim + out_feats_dim, h_feats_dim), nn.Dropout(dropout),
             get_non_lin(nonlin, slope), get_layer_norm(args['layer_norm'], h_feats_dim),
             nn.Linear(h_feats_dim, out_feats_dim))
-        self.final_h_layernorm_layer = nn.Identity()
+        self.final_h_layernorm_layer = get_final_h_layer_norm(self.final_h_layer_norm, out_feats_dim)
         self.coors_mlp = nn.Sequential(
             nn.Linear(out_feats_dim, out_feats_dim), nn.Dropout(dropout), get_non_lin(nonlin, slope),
             get_layer_norm(args['layer_norm_coors'], out_feats_dim), nn.Linear(out_feats_dim, 1))
+        if self.fine_tune:      # rigid_docking_model.py:161-174
+            self.att_mlp_cross_coors_Q = nn.Sequential(nn.Linear(h_feats_dim, h_feats_dim, bias=False),
+                                                       get_non_lin(nonlin, slope))
+            self.att_mlp_cross_coors_K = nn.Sequential(nn.Linear(h_feats_dim, h_feats_dim, bias=False),
+                                                       get_non_lin(nonlin, slope))
+            self.att_mlp_cross_coors_V = nn.Sequential(nn.Linear(h_feats_dim, h_feats_dim), get_non_lin(nonlin, slope),
+                                                       nn.Linear(h_feats_dim, 1))
 
     def param_table(self):
         """The 19 tensors in the order of include/equidock_hip.h's parameter table."""
@@ -99,10 +149,19 @@ class IEGMN_Layer(nn.Module):
                 self.node_mlp[3].bias, self.node_mlp[4].weight, self.node_mlp[4].bias, self.coors_mlp[0].weight,
                 self.coors_mlp[0].bias, self.coors_mlp[4].weight, self.coors_mlp[4].bias]
 
-    def forward(self, *a, **k):
-        raise NotImplementedError(
-            "IEGMN_Layer is a parameter container here: the layer loop runs inside eqd_model_forward "
-            "(include/equidock_hip.h). Call IEGMN / Rigid_Body_Docking_Net instead.")
+    def forward(self, hetero_graph, coors_ligand, h_feats_ligand, original_ligand_node_features,
+                original_edge_feats_ligand, orig_coors_ligand, coors_receptor, h_feats_receptor,
+                original_receptor_node_features, original_edge_feats_receptor, orig_coors_receptor):
+        """One layer on its own, with the reference's signature (rigid_docking_model.py:189-352).  Inside IEGMN the layer
+        loop of the published configuration never comes through here - it runs as one C call (eqd_model_forward); a
+        layer called by itself composes the same arithmetic from torch operators on the tensors' device
+        (equidock_public_amd/torch_path.py), differentiable w.r.t. every input."""
+        from . import torch_path
+        from .graph import from_dgl
+        return torch_path.layer_forward(self, from_dgl(hetero_graph), coors_ligand, h_feats_ligand,
+                                        original_ligand_node_features, original_edge_feats_ligand, orig_coors_ligand,
+                                        coors_receptor, h_feats_receptor, original_receptor_node_features,
+                                        original_edge_feats_receptor, orig_coors_receptor)
 
     def __repr__(self):
         return f"IEGMN Layer (HIP) h_feats_dim={self.h_feats_dim} out_feats_dim={self.out_feats_dim}"
@@ -213,8 +272,7 @@ class IEGMN(nn.Module):
 
     def __init__(self, args, n_lays, fine_tune, log=None):
         super().__init__()
-        if fine_tune:
-            raise NotImplementedError("fine_tune IEGMN stage is outside the HIP path")
+        self.fine_tune = fine_tune
         self.debug = args['debug']
         self.log = log
         self.device = args['device']
@@ -388,8 +446,11 @@ class IEGMN(nn.Module):
                 except AttributeError:
                     pass
             batch_hetero_graph = pg
-        if self.training and self.args['dropout'] > 0:
-            raise NotImplementedError("dropout > 0 in training mode is outside the HIP path")
+        if not self.uses_hip_path():
+            from . import torch_path
+            T, b, Yl, Yr, lig = torch_path.iegmn_forward(self, batch_hetero_graph)
+            self.last_svd_status = None
+            return batch_hetero_graph.pack(), lig, Yl, Yr, T, b
         packed = batch_hetero_graph.pack()
         uniq, table_idx = self._param_table()
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in uniq)
@@ -407,6 +468,11 @@ class IEGMN(nn.Module):
                                                              need_grad, None, *uniq)
         self.last_svd_status = status
         return packed, lig, Yl, Yr, T, b
+
+    def uses_hip_path(self):
+        """The published family runs in the HIP library; other reference options (and dropout > 0 while training) run
+        through torch operators on the same device (hip_path_supported)."""
+        return hip_path_supported(self.args, self.fine_tune) and not (self.training and self.args['dropout'] > 0)
 
     def forward(self, batch_hetero_graph, epoch):
         """[T_align list, b_align list, Y_ligand list, Y_receptor list] like the reference (:602)."""
@@ -426,22 +492,34 @@ class Rigid_Body_Docking_Net(nn.Module):
         self.debug = args['debug']
         self.log = log
         self.device = args['device']
-        if args['fine_tune']:
-            raise NotImplementedError("fine_tune=True is outside the HIP path (src/utils/args.py:110)")
         self.iegmn_original = IEGMN(args, n_lays=args['iegmn_n_lays'], fine_tune=False, log=log)
-        self.list_iegmns = [('finetune', self.iegmn_original)]
-
-    def forward(self, batch_hetero_graph, epoch):
-        packed, lig, Yl, Yr, T, b = self.iegmn_original.run(batch_hetero_graph)
-        B = packed.n_pairs
-        ligs = list(torch.split(lig, packed.lig_counts, dim=0))
-        return ligs, [Yl[i] for i in range(B)], [Yr[i] for i in range(B)], [T[i] for i in range(B)], \
-            [b[i].view(1, 3) for i in range(B)]
+        if args['fine_tune']:      # rigid_docking_model.py:622-627: a second, 2-layer stage on the moved ligand
+            self.iegmn_fine_tune = IEGMN(args, n_lays=2, fine_tune=True, log=log)
+            self.list_iegmns = [('original', self.iegmn_original), ('finetune', self.iegmn_fine_tune)]
+        else:
+            self.list_iegmns = [('finetune', self.iegmn_original)]
 
     def forward_batched(self, batch_hetero_graph):
-        """Same computation, batched tensors instead of per-pair lists (no Python loop over pairs)."""
-        _, lig, Yl, Yr, T, b = self.iegmn_original.run(batch_hetero_graph)
-        return lig, Yl, Yr, T, b
+        """Batched tensors instead of per-pair lists (no Python loop over pairs): lig [n_lig, 3], Yl, Yr [B, K, 3],
+        T [B, 3, 3], b [B, 3]."""
+        if not isinstance(batch_hetero_graph, PairGraph):
+            from .graph import from_dgl
+            batch_hetero_graph = from_dgl(batch_hetero_graph)
+        out = None
+        for stage, iegmn in self.list_iegmns:      # rigid_docking_model.py:646-682
+            _, lig, Yl, Yr, T, b = iegmn.run(batch_hetero_graph)
+            out = (lig, Yl, Yr, T, b)
+            if stage == 'original':                # the fine-tune stage starts from the moved ligand (:667-669, 681-682)
+                batch_hetero_graph = batch_hetero_graph.with_ligand_coords(lig)
+        return out
+
+    def forward(self, batch_hetero_graph, epoch):
+        lig, Yl, Yr, T, b = self.forward_batched(batch_hetero_graph)
+        B = Yl.shape[0]
+        counts = [int(c) for c in (batch_hetero_graph.batch_num_nodes('ligand'))]
+        ligs = list(torch.split(lig, counts, dim=0))
+        return ligs, [Yl[i] for i in range(B)], [Yr[i] for i in range(B)], [T[i] for i in range(B)], \
+            [b[i].view(1, 3) for i in range(B)]
 
     def __repr__(self):
         return "Rigid_Body_Docking_Net (HIP)"

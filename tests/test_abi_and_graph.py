@@ -40,13 +40,28 @@ def test_product_refuses_cpu_tensors():
     _lib.unload_for_testing()
 
 
-def test_unsupported_configs_raise():
+def test_every_reference_config_constructs_and_routes():
+    """Every option of the reference constructs (rigid_docking_model.py:10-42, 95-175, 622-627); the published family is
+    routed to the HIP library, everything else - and dropout > 0 while training - to the torch-operator path; 212 state_dict
+    keys with the fine-tune stage; unknown option values raise."""
     from equidock_public_amd import model as M
     from oracle import iegmn_port as port
-    for over in (dict(nonlin='swish'), dict(layer_norm='BN'), dict(final_h_layer_norm='GN'), dict(fine_tune=True),
-                 dict(layer_norm_coors='LN')):
-        with pytest.raises(NotImplementedError):
-            M.Rigid_Body_Docking_Net(port.default_args(**over))
+    for over, hip in ((dict(), True), (dict(nonlin='swish'), False), (dict(layer_norm='BN'), False),
+                      (dict(layer_norm='0'), False), (dict(final_h_layer_norm='GN'), False),
+                      (dict(final_h_layer_norm='LN'), False), (dict(layer_norm_coors='LN'), False),
+                      (dict(x_connection_init=0.25, shared_layers=True, iegmn_n_lays=5), True)):
+        net = M.Rigid_Body_Docking_Net(port.default_args(**over))
+        assert net.iegmn_original.uses_hip_path() == hip, over
+    net = M.Rigid_Body_Docking_Net(port.default_args(dropout=0.25))
+    assert not net.iegmn_original.uses_hip_path()          # training mode: torch's dropout masks
+    net.eval()
+    assert net.iegmn_original.uses_hip_path()              # inference: dropout is the identity
+    ft = M.Rigid_Body_Docking_Net(port.default_args(fine_tune=True))
+    assert len(ft.state_dict()) == 212 and not ft.iegmn_fine_tune.uses_hip_path() and ft.iegmn_original.uses_hip_path()
+    with pytest.raises(ValueError):
+        M.Rigid_Body_Docking_Net(port.default_args(nonlin='gelu'))
+    with pytest.raises(ValueError):
+        M.Rigid_Body_Docking_Net(port.default_args(final_h_layer_norm='XN'))
 
 
 def test_state_dict_keys_match_reference_layout():

@@ -1,0 +1,103 @@
+"""The reference's NON-published model options (swish, BatchNorm / LayerNorm placements, GraphNorm, dropout > 0 while
+training, the two-stage fine-tune model) through the drop-in's torch-operator path (equidock_public_amd/torch_path.py)
+against vectors recorded from the real reference module (tests/golden/variants.npz, oracle/make_golden_variants.py):
+same seeded initial parameters (the constructors mirror the reference's module order), same outputs, same loss, same
+parameter-gradient norms - including torch's dropout masks, i.e. the RNG consumption order."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from equidock_public_amd import config, graph as G, model as M
+from oracle import iegmn_port as port
+from tests.util import cat_out, pairs_from_raw
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+Z = np.load(os.path.join(ROOT, 'tests', 'golden', 'variants.npz'), allow_pickle=False)
+META = json.loads(str(Z['meta']))
+
+
+def _raw():
+    raw = {k[3:]: torch.from_numpy(Z[k]) for k in Z.files if k.startswith('in_')}
+    raw['lig_counts'] = [int(v) for v in Z['in_lig_counts']]
+    raw['rec_counts'] = [int(v) for v in Z['in_rec_counts']]
+    return raw
+
+
+def _model(name, device='cpu'):
+    v = META['variants'][name]
+    args = dict(v['args'], device=torch.device(device))
+    sd = config.seeded_state_dict(args, META['init_seed'], META['rot_scale'])
+    for k, (s, a) in v['fingerprint'].items():
+        t = sd[k].double()
+        assert abs(float(t.sum()) - s) <= 1e-9 * max(1.0, abs(a)) and abs(float(t.abs().sum()) - a) <= 1e-9 * max(1.0, abs(a)), \
+            f'{name}: seeded initial parameter {k} differs from the reference\'s'
+    net = M.Rigid_Body_Docking_Net(args)
+    net.load_state_dict(sd)
+    net.train(v['train'])
+    return net, v
+
+
+@pytest.fixture
+def simulator():
+    """stage 1 of the fine-tune model is the published configuration, i.e. the HIP path: on the CPU it runs through the
+    x86 build of the kernels (tests/hostsim), like tests/test_sim_parity.py"""
+    from equidock_public_amd import _lib
+    from tests.hostsim import build as hs
+    _lib.load_library_for_testing(hs.build())
+    yield
+    _lib.unload_for_testing()
+
+
+@pytest.mark.parametrize('name', sorted(META['variants']))
+def test_variant_vs_reference_golden(name, simulator):
+    net, v = _model(name)
+    assert not net.iegmn_original.uses_hip_path() or name == 'fine_tune'
+    g = G.batch_pairs(pairs_from_raw(_raw()))
+    torch.manual_seed(META['fwd_seed'])
+    outs = net(g, epoch=0)
+    for nm, lst in zip(('lig', 'Yl', 'Yr', 'T', 'b'), outs):
+        got, ref = cat_out(lst).detach(), torch.from_numpy(Z[f'{name}_{nm}'])
+        err = float((got - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+        # (fine_tune: stage 1 is the HIP path - its kernels sum in another order than torch: the 1e-4 of the north_star)
+        assert err <= (1e-4 if name == 'fine_tune' else 2e-5), f'{name} {nm}: {err:.2e}'
+    loss = port.scalar_loss(outs)
+    loss.backward()
+    assert abs(float(loss) - float(Z[f'{name}_loss'])) <= 1e-5 * abs(float(Z[f'{name}_loss']))
+    for k, p in net.named_parameters():
+        ref = v['grad_norms'][k]
+        got = float(p.grad.double().norm()) if p.grad is not None else 0.0
+        # (a bias in front of a BatchNorm has a mathematically zero gradient: its computed value is rounding noise)
+        assert abs(got - ref) <= (2e-3 if name == 'fine_tune' else 2e-4) * ref + 1e-5, f'{name}: gradient norm of {k}: {got} vs {ref}'
+
+
+def test_state_dict_keys_of_variants():
+    """BatchNorm buffers, GraphNorm gamma / beta and the fine-tune stage's parameters carry the reference's names."""
+    net, v = _model('swish_bn_gn')
+    keys = set(net.state_dict())
+    assert 'iegmn_original.iegmn_layers.0.final_h_layernorm_layer.gamma' in keys
+    assert 'iegmn_original.iegmn_layers.0.edge_mlp.3.running_mean' in keys
+    assert {k for k in v['fingerprint']} <= keys
+    net, v = _model('fine_tune')
+    keys = set(net.state_dict())
+    assert 'iegmn_fine_tune.iegmn_layers.1.att_mlp_cross_coors_V.2.weight' in keys and set(v['fingerprint']) <= keys
+
+
+def test_standalone_layer_forward_matches_model_layers():
+    """IEGMN_Layer.forward with the reference's signature: chaining the layers by hand reproduces the layer loop."""
+    from equidock_public_amd import torch_path
+    net, _ = _model('swish_bn_gn_eval')
+    g = G.batch_pairs(pairs_from_raw(_raw()))
+    ie = net.iegmn_original
+    nl, nr = g.nodes['ligand'].data, g.nodes['receptor'].data
+    h_l = torch.cat([ie.residue_emb_layer(nl['res_feat'].view(-1).long()), torch.log(nl['mu_r_norm'])], 1)
+    h_r = torch.cat([ie.residue_emb_layer(nr['res_feat'].view(-1).long()), torch.log(nr['mu_r_norm'])], 1)
+    x_l, x_r = nl['new_x'], nr['x']
+    a = ie.iegmn_layers[0](g, x_l, h_l, h_l, g.edges['ll'].data['he'], x_l, x_r, h_r, h_r, g.edges['rr'].data['he'], x_r)
+    b = torch_path.layer_forward(ie.iegmn_layers[0], g, x_l, h_l, h_l, g.edges['ll'].data['he'], x_l, x_r, h_r, h_r,
+                                 g.edges['rr'].data['he'], x_r)
+    for u, w in zip(a, b):
+        assert torch.equal(u, w)
+    assert a[1].shape == (x_l.shape[0], 64)
