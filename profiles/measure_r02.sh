@@ -7,9 +7,11 @@ mkdir -p $O
 cd $R
 for what in "$@"; do case $what in
 tests)
-  python -m pytest tests -m gpu -q -s 2>&1 | tail -60 > $O/${TAG}_pytest_gpu.log ;;
-testsfast)   # everything except the three big-workload oracle comparisons
-  python -m pytest tests -m gpu -x -q -k "not config_c and not config_e and not ragged" 2>&1 | tail -15 > $O/${TAG}_pytest_gpu_fast.log ;;
+  python -m pytest tests -m gpu -q -s --tb=line 2>&1 | grep -v Warning > $O/${TAG}_pytest_gpu.log ;;
+testsfast)   # everything except the big-workload oracle comparisons
+  python -m pytest tests -m gpu -q -s --tb=line -k "not config_c and not config_e and not config_b" 2>&1 | grep -v Warning > $O/${TAG}_pytest_gpu_fast.log ;;
+testsbig)
+  python -m pytest tests -m gpu -q -s --tb=line -k "config_c or config_e or config_b or ragged" 2>&1 | grep -v Warning > $O/${TAG}_pytest_gpu_big.log ;;
 bench)
   python bench.py > $O/${TAG}_bench.log 2>&1
   python bench.py --eager --no-cpu-baseline --no-roofline > $O/${TAG}_bench_eager.log 2>&1
@@ -35,6 +37,11 @@ profbf16)
   DB=$(find /tmp/prof_Cb -name "*.db" | head -1)
   python $R/profiles/summarize.py $DB $O/${TAG}_kernels_C_bf16.md "round 2 (${TAG}): workload C, bf16" "rocprofv3 --kernel-trace --stats -- python bench.py --workload C --dtype bf16 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline" > $O/${TAG}_kernels_C_bf16.txt 2>&1
   cd $R ;;
+dprehearsal)   # N = 2 control flow of bench.py on ONE GPU (gloo; real runs: one GPU per rank over RCCL)
+  EQD_BENCH_ONE_DEVICE=1 EQD_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 10 --warmup 3 > $O/${TAG}_bench_dp2_rehearsal.log 2>&1
+  EQD_BENCH_ONE_DEVICE=1 EQD_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 2 --workload D --steps 5 --warmup 2 > $O/${TAG}_bench_dp2_rehearsal_D.log 2>&1 ;;
+collate)
+  python profiles/bench_collate.py > $O/${TAG}_collate.txt 2>&1 ;;
 pmc)
   cd /tmp; export TMPDIR=/tmp
   for W in B C E; do for CNT in MfmaUtil SQ_INSTS_VALU_MFMA_MOPS_F32 FETCH_SIZE WRITE_SIZE; do

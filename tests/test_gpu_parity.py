@@ -315,3 +315,29 @@ def test_large_complex_runs(dev):
 def test_smoke_entry(dev):
     import __graft_entry__ as ge
     ge.smoke()
+
+
+def test_flat_grad_allreduce_on_rccl_world_of_one(dev):
+    """The data-parallel exchange (parallel.FlatGradAllReduce: ONE all-reduce of the flat gradient buffer) on backend
+    'nccl' (= RCCL) in a world of one: the collective runs on the GPU buffer and leaves the gradient unchanged."""
+    import torch.distributed as dist
+    from equidock_public_amd import graph as G, parallel, synthetic
+    from oracle import iegmn_port as port
+    from tests import parity_common as pc
+    if dist.is_initialized():
+        pytest.skip('a process group already exists in this process')
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29517', rank=0, world_size=1, device_id=dev)
+    try:
+        args = port.default_args(iegmn_n_lays=2, skip_weight_h=0.5)
+        net = pc.build_model(args, port.init_state_dict(args, seed=5), dev)
+        red = parallel.FlatGradAllReduce(net)
+        g = G.batch_pairs(synthetic.make_pairs([(50, 61), (33, 47)], 5)).to(dev)
+        red.zero()
+        port.scalar_loss(net(g, epoch=0)).backward()
+        before = red.flat.clone()
+        red.reduce(force=True)
+        torch.cuda.synchronize()
+        assert float(before.abs().sum()) > 0 and torch.equal(before, red.flat)
+        parallel.broadcast_parameters(net)
+    finally:
+        dist.destroy_process_group()
