@@ -22,366 +22,7 @@
 // registers while it multiplies the previous tile, then writes them to its private LDS tile
 // (row stride 16*DB + 4 floats); MFMA operands are read from LDS.  One HBM/L2 round trip per tile.
 #include "eqd_common.h"
-
-// The backward passes recompute p = exp(S - lse) (arguments <= 0 up to rounding) with the hardware exponential
-// (v_exp_f32 on x log2 e: ~4e-6 relative error at |x| ~ 80, far inside the gradient tolerance) - 32 of them per
-// 32 x 32 score tile otherwise cost as many VALU cycles as a third of the tile's MFMAs.  The forward keeps expf.
-#ifndef EQD_NATIVE_EXP
-#define EQD_NATIVE_EXP(x) __expf(x)
-#endif
-__device__ __forceinline__ float bwd_exp(float x) { return EQD_NATIVE_EXP(x); }
-
-template <int DB>
-struct AttnCfg {
-    enum { DS = 16 * DB + 4, KS = 4 * DB, NL = 8 * DB, TILE = 32 * (16 * DB + 4), RED = DB * 2 * 4 * 64 };
-};
-
-// FAST: d == 16 DB exactly (64, or the 69-wide first layer zero-padded to 80 by the caller), 16-byte aligned rows
-template <int DB, bool FAST>
-struct TileRegs {
-    float4 q[FAST ? 8 : 1];            // FAST: row (lane >> 4) + 4 j, columns 4 (lane & 15) .. (the first 64 columns)
-    float4 qx[(FAST && DB > 4) ? 2 : 1];   // FAST, d == 80: row (lane + 64 j) >> 2, columns 64 + 4 ((lane + 64 j) & 3) ..
-    f32x4 qv[FAST ? 1 : 2 * DB];       // any d: elements 4 (lane + 64 j) .. + 3 of the contiguous [rows][d] slab (raw)
-    int nvalid;
-};
-
-// rows r0 .. r0+31 of M (row stride d), clipped at r1 -> registers (zeros beyond)
-template <int DB, bool FAST>
-__device__ __forceinline__ void tile_load(TileRegs<DB, FAST>& R, const float* __restrict__ M, int d, int r0, int r1,
-                                          int lane) {
-    int nrows = r1 - r0;
-    nrows = nrows < 0 ? 0 : (nrows > 32 ? 32 : nrows);
-    const int nvalid = nrows * d;
-    const float* __restrict__ base = M + (size_t)r0 * d;
-    R.nvalid = nvalid;
-    if (FAST) {
-        // unpredicated (a predicated load is an exec-masked branch with a wait behind it): rows beyond the range are
-        // fetched from its last row and zeroed; a tile entirely beyond the range is not fetched at all (wave-uniform)
-        if (nrows > 0) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int i4 = lane + 64 * j;
-                const int row = i4 >> 4;
-                const float4 v = ((const float4*)base)[(row < nrows ? row : nrows - 1) * (4 * DB) + (i4 & 15)];
-                R.q[j] = row < nrows ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            if constexpr (DB > 4) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int i = lane + 64 * j;
-                    const int row = i >> 2;
-                    const float4 v = ((const float4*)base)[(row < nrows ? row : nrows - 1) * (4 * DB) + 16 + (i & 3)];
-                    R.qx[j] = row < nrows ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) R.q[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if constexpr (DB > 4) R.qx[0] = R.qx[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    } else {
-        // the 32 rows are one contiguous slab of 32 d floats: 16-byte vectors (4-byte alignment is enough), all in
-        // flight at once; tail / beyond-the-range handling in ld4u_raw / ld4u_fix
-        if (nvalid > 0) {
-#pragma unroll
-            for (int j = 0; j < 2 * DB; ++j) {
-                const int e = 4 * (lane + 64 * j);
-                R.qv[j] = ld4u_raw(base + (e < nvalid ? e : 0), nvalid - e, M);
-            }
-        }
-    }
-}
-template <int DB, bool FAST>
-__device__ __forceinline__ void tile_store(const TileRegs<DB, FAST>& R, float* __restrict__ L, int d, int lane) {
-    constexpr int DS = AttnCfg<DB>::DS;
-    if (FAST) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int i4 = lane + 64 * j;
-            *(float4*)&L[(i4 >> 4) * DS + 4 * (i4 & 15)] = R.q[j];
-        }
-        if constexpr (DB > 4) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int i = lane + 64 * j;
-                *(float4*)&L[(i >> 2) * DS + 64 + 4 * (i & 3)] = R.qx[j];
-            }
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 2 * DB; ++j) {
-            const int e = 4 * (lane + 64 * j);
-            const float4 f = R.nvalid > 0 ? ld4u_fix(R.qv[j], R.nvalid - e) : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float vv[4] = {f.x, f.y, f.z, f.w};
-            int row = e / d, col = e - row * d;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (col >= d) {
-                    col -= d;
-                    ++row;
-                }
-                if (row < 32) L[row * DS + col] = vv[u];
-                ++col;
-            }
-        }
-    }
-}
-// cooperative (256 threads) [32][d] tile -> LDS, used once per workgroup for the block's own rows
-__device__ __forceinline__ void block_tile_stage(const float* __restrict__ M, int d, int DS, int r0, int r1,
-                                                 float* __restrict__ L, int t) {
-    int nrows = r1 - r0;
-    nrows = nrows > 32 ? 32 : nrows;
-    const int nvalid = nrows * d;       // >= d >= 4: a block has at least one row
-    const float* __restrict__ base = M + (size_t)r0 * d;
-    f32x4 v[3];                         // 3 x 256 vectors >= 32 x 80 floats
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int e = 4 * (t + 256 * j);
-        v[j] = ld4u_raw(base + (e < nvalid ? e : 0), nvalid - e, M);
-    }
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int e = 4 * (t + 256 * j);
-        const float4 f = ld4u_fix(v[j], nvalid - e);
-        const float vv[4] = {f.x, f.y, f.z, f.w};
-        int row = e / d, col = e - row * d;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (col >= d) {
-                col -= d;
-                ++row;
-            }
-            if (row < 32) L[row * DS + col] = vv[u];
-            ++col;
-        }
-    }
-}
-// d == 64, 16-byte aligned rows: the [32][64] tile is 512 float4, two per thread, unpredicated (rows beyond the block are
-// fetched from its last row and written as zeros).  Columns 64.. of the LDS tile are never read when d == 64.
-template <int DB>
-__device__ __forceinline__ void block_tile_stage_fast(const float* __restrict__ M, int DS, int r0, int r1,
-                                                      float* __restrict__ L, int t) {
-    int nrows = r1 - r0;
-    nrows = nrows > 32 ? 32 : nrows;
-    const float4* __restrict__ base = (const float4*)(M + (size_t)r0 * (16 * DB));
-    float4 v[2], vx = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int i4 = t + 256 * j, row = i4 >> 4;
-        v[j] = base[(row < nrows ? row : nrows - 1) * (4 * DB) + (i4 & 15)];
-    }
-    if constexpr (DB > 4) {      // columns 64 .. 79: 32 rows x 4 vectors, threads 0 .. 127
-        const int row = (t & 127) >> 2;
-        vx = base[(row < nrows ? row : nrows - 1) * (4 * DB) + 16 + (t & 3)];
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int i4 = t + 256 * j, row = i4 >> 4;
-        *(float4*)&L[row * DS + 4 * (i4 & 15)] = row < nrows ? v[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    if constexpr (DB > 4) {
-        const int row = (t & 127) >> 2;
-        if (t < 128) *(float4*)&L[row * DS + 64 + 4 * (t & 3)] = row < nrows ? vx : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-}
-__device__ __forceinline__ void zero_fill(float* __restrict__ L, int n, int t, int nthreads) {
-    for (int i = t; i < n; i += nthreads) L[i] = 0.f;
-}
-
-// ---------------------------------------------------------------------------------------------
-// NB = 2: one workgroup per work item (a block of up to 32 rows).  NB = 1: TWO workgroups per item, 16 rows each - for
-// small batches, whose 32-row blocks do not give every CU a workgroup (DB5.5: 112 items, 256 CUs): twice the workgroups
-// with half the matrix work and the same loads each; the arithmetic of a row is unchanged (its keys are split over the
-// waves and merged in the same order).  (The backward uses half blocks for another reason: k_attn_bwd.)
-template <int DB, bool FAST, int NB>
-__global__ __launch_bounds__(EQD_BLOCK) void k_attn_fwd(EqdGraph G, int d, const float* __restrict__ q,
-                                                        const float* __restrict__ k, const float* __restrict__ v,
-                                                        float* __restrict__ out, float* __restrict__ lse) {
-    typedef AttnCfg<DB> C;
-    constexpr int DS = C::DS, KS = C::KS;
-    __shared__ __attribute__((aligned(16))) float Qt[C::TILE];
-    __shared__ __attribute__((aligned(16))) float Kt[EQD_WAVES][C::TILE];
-    __shared__ __attribute__((aligned(16))) float Vt[EQD_WAVES][C::TILE];
-    __shared__ float sm_m[EQD_WAVES][32], sm_l[EQD_WAVES][32];
-    // the merge buffer aliases the waves' own K tiles (C::RED <= C::TILE; written only after the wave's last tile):
-    // 79 KB of LDS instead of 111 KB, i.e. two workgroups per CU, so that one wave's softmax overlaps another's MFMAs
-    float (*red)[C::TILE] = Kt;
-    static_assert(C::RED <= C::TILE, "merge buffer must fit a K tile");
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int l15 = lane & 15, g = lane >> 4;
-    const int item = NB == 1 ? (int)blockIdx.x >> 1 : (int)blockIdx.x;
-    int b0 = G.att_items[item * 4 + 0], b1 = G.att_items[item * 4 + 1];
-    const int o0 = G.att_items[item * 4 + 2], o1 = G.att_items[item * 4 + 3];
-    if (NB == 1) {
-        b0 += 16 * ((int)blockIdx.x & 1);
-        b1 = b1 < b0 + 16 ? b1 : b0 + 16;
-        if (b0 >= b1) return;        // the item's block has at most 16 rows (uniform for the workgroup)
-    }
-    int rowq[NB];
-    bool qv[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        rowq[nb] = b0 + 16 * nb + l15;
-        qv[nb] = rowq[nb] < b1;
-    }
-
-    EQD_TR_WG();
-    EQD_TR(0);
-    TileRegs<DB, FAST> rk, rv;
-    int kt = o0 + 32 * wave;
-    tile_load<DB, FAST>(rk, k, d, kt, o1, lane);
-    tile_load<DB, FAST>(rv, v, d, kt, o1, lane);
-    if (FAST) {      // every element that is read later is written by the tile stores: no zero fill needed
-        EQD_TR(1);
-        block_tile_stage_fast<DB>(q, DS, b0, b1, Qt, t);
-    } else {
-        zero_fill(Qt, C::TILE, t, EQD_BLOCK);
-        zero_fill(Kt[wave], C::TILE, lane, 64);
-        zero_fill(Vt[wave], C::TILE, lane, 64);
-        __syncthreads();
-        EQD_TR(1);
-        block_tile_stage(q, d, DS, b0, b1, Qt, t);
-    }
-    __syncthreads();
-    EQD_TR(2);
-    float qf[NB][KS];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[nb][ks] = Qt[(16 * nb + l15) * DS + 4 * ks + g];
-
-    f32x4 O[DB][NB];
-    float mrun[NB], lrun[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-#pragma unroll
-        for (int db = 0; db < DB; ++db) O[db][nb] = f4zero();
-        mrun[nb] = EQD_NEG_BIG;
-        lrun[nb] = 0.f;
-    }
-    const float* __restrict__ Kw = Kt[wave];
-    const float* __restrict__ Vw = Vt[wave];
-    EQD_TR(3);
-    for (; kt < o1; kt += 32 * EQD_WAVES) {
-        wave_lds_fence();
-        tile_store<DB, FAST>(rk, Kt[wave], d, lane);
-        tile_store<DB, FAST>(rv, Vt[wave], d, lane);
-        wave_lds_fence();
-        EQD_TR(4);
-        tile_load<DB, FAST>(rk, k, d, kt + 32 * EQD_WAVES, o1, lane);   // prefetch the wave's next tile
-        tile_load<DB, FAST>(rv, v, d, kt + 32 * EQD_WAVES, o1, lane);
-        EQD_TR(5);
-        f32x4 S[2][NB];
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) S[mb][nb] = f4zero();
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                const float a = Kw[(16 * mb + l15) * DS + 4 * ks + g];
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) S[mb][nb] = mfma4(a, qf[nb][ks], S[mb][nb]);
-            }
-        EQD_TR(6);
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            float mx = EQD_NEG_BIG;
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = kt + 16 * mb + 4 * g + r;
-                    const float s = key < o1 ? S[mb][nb][r] : EQD_NEG_BIG;
-                    S[mb][nb][r] = s;
-                    mx = fmaxf(mx, s);
-                }
-            mx = group_max(mx);
-            const float mnew = fmaxf(mrun[nb], mx);
-            const float alpha = expf(mrun[nb] - mnew);
-            float ps = 0.f;
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = kt + 16 * mb + 4 * g + r;
-                    const float p = key < o1 ? expf(S[mb][nb][r] - mnew) : 0.f;
-                    S[mb][nb][r] = p;
-                    ps += p;
-                }
-            lrun[nb] = lrun[nb] * alpha + group_sum(ps);
-            mrun[nb] = mnew;
-#pragma unroll
-            for (int db = 0; db < DB; ++db) O[db][nb] *= alpha;
-        }
-        EQD_TR(7);
-#pragma unroll
-        for (int mbk = 0; mbk < 2; ++mbk)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int db = 0; db < DB; ++db) {
-                    const float a = Vw[(16 * mbk + 4 * g + r) * DS + 16 * db + l15];
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) O[db][nb] = mfma4(a, S[mbk][nb][r], O[db][nb]);
-                }
-        EQD_TR(8);
-    }
-    EQD_TR(9);
-    // ---- merge the 4 waves' partial softmax states -----------------------------------------------
-    wave_lds_fence();       // this wave's reads of its K tile are done before it is overwritten
-#pragma unroll
-    for (int db = 0; db < DB; ++db)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) red[wave][((db * 2 + nb) * 4 + r) * 64 + lane] = O[db][nb][r];
-    if (g == 0) {
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            sm_m[wave][16 * nb + l15] = mrun[nb];
-            sm_l[wave][16 * nb + l15] = lrun[nb];
-        }
-    }
-    __syncthreads();
-    float sc[NB][EQD_WAVES], inv[NB], mtot[NB], ltot[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        float mm = EQD_NEG_BIG;
-#pragma unroll
-        for (int w = 0; w < EQD_WAVES; ++w) mm = fmaxf(mm, sm_m[w][16 * nb + l15]);
-        float ll = 0.f;
-#pragma unroll
-        for (int w = 0; w < EQD_WAVES; ++w) {
-            sc[nb][w] = expf(sm_m[w][16 * nb + l15] - mm);
-            ll += sm_l[w][16 * nb + l15] * sc[nb][w];
-        }
-        mtot[nb] = mm;
-        ltot[nb] = ll;
-        inv[nb] = ll > 0.f ? 1.f / ll : 0.f;
-    }
-    for (int db = wave; db < DB; db += EQD_WAVES)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            if (!qv[nb]) continue;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float o = 0.f;
-#pragma unroll
-                for (int w = 0; w < EQD_WAVES; ++w) o += red[w][((db * 2 + nb) * 4 + r) * 64 + lane] * sc[nb][w];
-                const int f = 16 * db + 4 * g + r;
-                if (f < d) out[(size_t)rowq[nb] * d + f] = o * inv[nb];
-            }
-        }
-    if (wave == 0 && g == 0) {
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-            if (qv[nb]) lse[rowq[nb]] = ltot[nb] > 0.f ? mtot[nb] + logf(ltot[nb]) : 0.f;
-    }
-    EQD_TR(10);
-    EQD_TR_WG_END();
-}
+#include "eqd_attn_fwd_inl.h"
 
 // backward pass 1: dq for the block's queries; also writes delta[q] = sum_f dO[q][f] O[q][f]
 // LDS of the backward passes: 2 block tiles + 2 x EQD_WAVES streamed tiles + the merge buffer + 32 floats per wave

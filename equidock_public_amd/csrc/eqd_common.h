@@ -277,6 +277,9 @@ int eqd_edge_message_bwd_impl(const EqdGraph* g, const EqdEdgeParams* p, const f
                               const EqdEdgeGrads* grads, void* workspace, size_t ws_bytes, hipStream_t st,
                               float* part_override, EqdRedList* defer);
 size_t eqd_edge_bwd_vecp_floats(const EqdGraph* g);
+int eqd_edge_attn_fwd(const EqdGraph* g, const EqdEdgeParams* p, const float* P, const float* Q, const float* x,
+                      float* aggr_msg, float* x_new, int d_att, const float* q, const float* k, const float* v,
+                      float* att_out, float* lse, hipStream_t st);
 int eqd_keypoint_pool_fwd_impl(const EqdGraph* g, int n_heads, const float* Wk, const float* Wq, const float* qmean,
                                const float* H, const float* Z, float* Y, float* Y_lig_out, float* Y_rec_out,
                                float* scores, float* lse, float* qp, float* u, hipStream_t st);

@@ -361,15 +361,21 @@ extern "C" int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const
             HIPOK(hipEventRecord(cx->fork, st));
             HIPOK(hipStreamWaitEvent(sat, cx->fork, 0));
         }
-        if (m->cross_msgs) {
-            RC(eqd_cross_attention_fwd(g, da, Ls.qa, Ls.ka, Ls.va, Ls.aggr_cross, Ls.lse, sat));
-        } else {
-            if (hipMemsetAsync(Ls.aggr_cross, 0, (size_t)N * da * sizeof(float), st) != hipSuccess) return EQD_ERR_LAUNCH;
-        }
-        if (sat != st) HIPOK(hipEventRecord(cx->join_a, sat));
         EqdEdgeParams ep = edge_params(D, m, l, p);
-        RC(eqd_edge_message_fwd(g, &ep, Ls.P, Ls.Q, S.x[l], Ls.aggr_msg, S.x[l + 1], st));
-        if (sat != st) HIPOK(hipStreamWaitEvent(st, cx->join_a, 0));
+        if (m->cross_msgs && sat == st) {
+            // the two independent halves of the layer: ONE launch when both fit the chip at once (small batches)
+            RC(eqd_edge_attn_fwd(g, &ep, Ls.P, Ls.Q, S.x[l], Ls.aggr_msg, S.x[l + 1], da, Ls.qa, Ls.ka, Ls.va, Ls.aggr_cross,
+                                 Ls.lse, st));
+        } else {
+            if (m->cross_msgs) {
+                RC(eqd_cross_attention_fwd(g, da, Ls.qa, Ls.ka, Ls.va, Ls.aggr_cross, Ls.lse, sat));
+            } else {
+                if (hipMemsetAsync(Ls.aggr_cross, 0, (size_t)N * da * sizeof(float), st) != hipSuccess) return EQD_ERR_LAUNCH;
+            }
+            if (sat != st) HIPOK(hipEventRecord(cx->join_a, sat));
+            RC(eqd_edge_message_fwd(g, &ep, Ls.P, Ls.Q, S.x[l], Ls.aggr_msg, S.x[l + 1], st));
+            if (sat != st) HIPOK(hipStreamWaitEvent(st, cx->join_a, 0));
+        }
         // ---- node update: node_mlp([h, aggr_msg, aggr_cross, h0]) -> LayerNorm, then node_mlp.4 (+ skip).
         //      (A fused row chain of these + the next layer's projections measured SLOWER: 46 vs 33 us,
         //       because the five projections then run one after the other instead of side by side.) -----------

@@ -23,7 +23,9 @@
 //     over the chip at DB5 sizes.  It recomputes the tile forward and writes the five per-edge operands
 //     of the weight-gradient GEMMs (a1, m, d_chid, dm, dz1) for k_atb.
 #include "eqd_common.h"
+#include "eqd_attn_fwd_inl.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 #define WS1 45   /* row stride of the staged W1[:, 2d_in:] block (42 used + 3 zero) */
@@ -674,14 +676,18 @@ struct EdgeSmemSel<NW, TF, true> {
 // forward: node-aligned 32-edge tiles
 // ---------------------------------------------------------------------------------------------
 template <int NW, bool BF>
-__global__ __launch_bounds__(64 * NW) void k_edge_fwd(EqdGraph G, EqdEdgeParams P, const float* __restrict__ Pn,
-                                                              const float* __restrict__ Qn,
-                                                              const float* __restrict__ x,
-                                                              float* __restrict__ aggr_msg,
-                                                              float* __restrict__ x_new) {
-    typedef typename EdgeSmemSel<NW, 32 * TS, BF>::type Smem;
-    __shared__ Smem sm;
-    __shared__ float sxw[NW][96];      // per-node mean of x_rel * coef of the wave's tile
+struct EdgeFwdSmem {
+    typename EdgeSmemSel<NW, 32 * TS, BF>::type sm;
+    float sxw[NW][96];      // per-node mean of x_rel * coef of the wave's tile
+};
+// forward of the tiles blk * NW + wave, + nblk * NW, ... (blk of nblk workgroups of NW waves)
+template <int NW, bool BF>
+__device__ __forceinline__ void edge_fwd_body(EdgeFwdSmem<NW, BF>& S_, const EqdGraph& G, const EqdEdgeParams& P, int blk,
+                                              int nblk, const float* __restrict__ Pn, const float* __restrict__ Qn,
+                                              const float* __restrict__ x, float* __restrict__ aggr_msg,
+                                              float* __restrict__ x_new) {
+    auto& sm = S_.sm;
+    float (*sxw)[96] = S_.sxw;
     EQD_TR_WG();
     EQD_TR(0);
     if constexpr (BF)
@@ -692,7 +698,7 @@ __global__ __launch_bounds__(64 * NW) void k_edge_fwd(EqdGraph G, EqdEdgeParams 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     float* tile = sm.tile[wave];
-    for (int t = blockIdx.x * NW + wave; t < G.n_tiles; t += gridDim.x * NW) {
+    for (int t = blk * NW + wave; t < G.n_tiles; t += nblk * NW) {
         EdgeTileState<2> S;
         S.n0 = G.tile_node[t];
         S.n1 = G.tile_node[t + 1];
@@ -768,6 +774,51 @@ __global__ __launch_bounds__(64 * NW) void k_edge_fwd(EqdGraph G, EqdEdgeParams 
     }
     EQD_TR_WG_END();
 }
+template <int NW, bool BF>
+__global__ __launch_bounds__(64 * NW) void k_edge_fwd(EqdGraph G, EqdEdgeParams P, const float* __restrict__ Pn,
+                                                              const float* __restrict__ Qn,
+                                                              const float* __restrict__ x,
+                                                              float* __restrict__ aggr_msg,
+                                                              float* __restrict__ x_new) {
+    __shared__ EdgeFwdSmem<NW, BF> S;
+    edge_fwd_body<NW, BF>(S, G, P, (int)blockIdx.x, (int)gridDim.x, Pn, Qn, x, aggr_msg, x_new);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Small batches (DB5.5-sized: 8 pairs x 200 + 200 residues): the edge-message forward needs 134 workgroups and the
+// cross-attention forward 112 - each leaves half of the 256 CUs idle, and the two are independent (both read the
+// layer's node projections, neither reads the other's output).  ONE launch runs them side by side: workgroups
+// [0, n_edge) are edge-forward workgroups (8 waves, one 32-edge tile per wave), workgroups [n_edge, n_edge + n_items)
+// each run one 32-row attention work item as two 4-wave groups (its two 16-row halves: same partner range, hence the
+// same number of barriers).  LDS is a union of the two layouts (the attention side is the bigger one: 2 x 79 KB), so
+// one workgroup per CU; taken when n_edge + n_items <= CUs, i.e. when everything is resident at once and the launch
+// lasts as long as its longer half (23 us at config B instead of 23 + 9.5).  Same arithmetic as the separate launches.
+// ---------------------------------------------------------------------------------------------
+union alignas(16) EdgeAttnFwdSmem {
+    EdgeFwdSmem<FWD_WAVES, false> edge;
+    AttnFwdSmem<4> att[2];
+    __device__ EdgeAttnFwdSmem() {}
+};
+__global__ __launch_bounds__(64 * FWD_WAVES) void k_edge_attn_fwd(EqdGraph G, EqdEdgeParams P, int n_edge,
+                                                                   const float* __restrict__ Pn,
+                                                                   const float* __restrict__ Qn,
+                                                                   const float* __restrict__ x,
+                                                                   float* __restrict__ aggr_msg,
+                                                                   float* __restrict__ x_new,
+                                                                   const float* __restrict__ q,
+                                                                   const float* __restrict__ k,
+                                                                   const float* __restrict__ v,
+                                                                   float* __restrict__ att_out,
+                                                                   float* __restrict__ lse) {
+    __shared__ EdgeAttnFwdSmem S;
+    if ((int)blockIdx.x < n_edge) {
+        edge_fwd_body<FWD_WAVES, false>(S.edge, G, P, (int)blockIdx.x, n_edge, Pn, Qn, x, aggr_msg, x_new);
+    } else {
+        const int half = (int)threadIdx.x >> 8;
+        attn_fwd_body<4, true, 1>(S.att[half], G, (int)blockIdx.x - n_edge, half, (int)threadIdx.x & 255, 64, q, k, v,
+                                  att_out, lse, true);
+    }
+}
 
 // Smallest grid with the minimal number of tile rounds: with `wg_per_cu` workgroups per CU the makespan is
 // ceil(tiles / (CUs * wg_per_cu * waves)) tile times whatever the grid, so use as few CUs as that allows
@@ -805,6 +856,31 @@ extern "C" int eqd_edge_message_fwd(const EqdGraph* g, const EqdEdgeParams* p, c
                            (hipStream_t)stream, *g, *p, P, Q, x, aggr_msg, x_new);
     }
     return eqd_check_launch("k_edge_fwd");
+}
+
+// 1 if eqd_edge_attn_fwd will take the fused launch for this graph / width / mode (else it issues the two launches)
+int eqd_edge_attn_fused(const EqdGraph* g, const EqdEdgeParams* p, int d_att, const float* q, const float* k, const float* v) {
+    const char* f = getenv("EQD_FUSE_FWD");
+    if (f && f[0] == '0' && f[1] == 0) return 0;
+    if (p->bf16 || d_att != 64 || g->n_tiles <= 0 || g->n_att_items <= 0) return 0;
+    if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) != 0) return 0;
+    const int n_edge = edge_grid(g->n_tiles, FWD_WAVES, 1);
+    return n_edge + g->n_att_items <= eqd_num_cus();
+}
+// edge-message forward + cross-attention forward of one layer (independent of each other): one launch when both fit
+// the chip at once (eqd_edge_attn_fused), the two separate launches otherwise
+int eqd_edge_attn_fwd(const EqdGraph* g, const EqdEdgeParams* p, const float* P, const float* Q, const float* x,
+                      float* aggr_msg, float* x_new, int d_att, const float* q, const float* k, const float* v,
+                      float* att_out, float* lse, hipStream_t st) {
+    if (!eqd_edge_attn_fused(g, p, d_att, q, k, v)) {
+        int rc = eqd_cross_attention_fwd(g, d_att, q, k, v, att_out, lse, st);
+        if (rc) return rc;
+        return eqd_edge_message_fwd(g, p, P, Q, x, aggr_msg, x_new, st);
+    }
+    const int n_edge = edge_grid(g->n_tiles, FWD_WAVES, 1);
+    hipLaunchKernelGGL(k_edge_attn_fwd, dim3(n_edge + g->n_att_items), dim3(64 * FWD_WAVES), 0, st, *g, *p, n_edge, P, Q, x,
+                       aggr_msg, x_new, q, k, v, att_out, lse);
+    return eqd_check_launch("k_edge_attn_fwd");
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -985,3 +985,27 @@ def check_inference_postprocessing(dev):
     m.update_rmsd(torch.from_numpy(z['m_lp']), torch.from_numpy(z['m_rp']), torch.from_numpy(z['m_lt']),
                   torch.from_numpy(z['m_rt']))
     assert abs(m.summarize('median')[2] - float(z['m_complex'])) < 1e-5
+
+
+def check_fused_forward(dev):
+    """The one-launch edge-message + cross-attention forward of small batches (k_edge_attn_fwd, csrc/eqd_edge_kernels.hip)
+    against the two separate launches (EQD_FUSE_FWD=0): the same arithmetic, so bit-identical outputs and gradients -
+    including items whose second 16-row half is empty and proteins smaller than one block."""
+    import os
+    args = port.default_args(iegmn_n_lays=3, skip_weight_h=0.75)
+    sd = port.init_state_dict(args, seed=4)
+    pairs = synthetic.make_pairs([(60, 75), (90, 48), (7, 130), (33, 16)], 21)
+    res = {}
+    for mode in ('1', '0'):
+        os.environ['EQD_FUSE_FWD'] = mode
+        try:
+            net = build_model(args, sd, dev)
+            g = G.batch_pairs(pairs).to(dev)
+            outs = net.forward_batched(g)
+            (outs[0].square().sum() + outs[1].square().sum() + outs[2].square().sum()).backward()
+            sync(dev)
+            res[mode] = ([t.detach().cpu().clone() for t in outs], [p.grad.detach().cpu().clone() for p in net.parameters()])
+        finally:
+            del os.environ['EQD_FUSE_FWD']
+    for a, b in zip(res['1'][0] + res['1'][1], res['0'][0] + res['0'][1]):
+        assert torch.equal(a, b)

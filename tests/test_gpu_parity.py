@@ -150,6 +150,11 @@ def test_inference_postprocessing(dev):
     pc.check_inference_postprocessing(dev)
 
 
+def test_fused_forward_launch_is_bit_identical(dev):
+    from tests import parity_common as pc
+    pc.check_fused_forward(dev)
+
+
 def test_scalar_loss(dev):
     from tests import parity_common as pc
     pc.check_scalar_loss(dev)

@@ -125,6 +125,10 @@ def test_inference_postprocessing():
     pc.check_inference_postprocessing(DEV)
 
 
+def test_fused_forward_launch_is_bit_identical():
+    pc.check_fused_forward(DEV)
+
+
 def test_scalar_loss():
     pc.check_scalar_loss(DEV)
 
