@@ -62,7 +62,7 @@ def step_flops_as_written(sizes, L, d0=69, d=64, K=50):
     return tot
 
 
-def kernel_work_model(sizes, L, n_nodes, n_edges, cross=True, d0=69, dh=64, d_emb=64, K=50):
+def kernel_work_model(sizes, L, n_nodes, n_edges, cross=True, d0=69, dh=64, d_emb=64, K=50, fused_fwd=False):
     """Per-STEP work of each kernel family, from the launch structure of eqd_model_forward / eqd_model_backward
     (csrc/eqd_driver.hip): `flops` = FLOPs the kernel executes on the MFMA pipes for its GEMMs (2 per MAC),
     `flops_written` = the model-as-written share where SURVEY.md section 8d defines one (edge kernels, attention),
@@ -71,7 +71,8 @@ def kernel_work_model(sizes, L, n_nodes, n_edges, cross=True, d0=69, dh=64, d_em
     N, E = float(n_nodes), float(n_edges)
     pp = sum(float(a) * b for a, b in sizes)              # sum over pairs of n_lig * n_rec
     W = {k: dict(flops=0.0, flops_written=0.0, bytes=0.0) for k in
-         ('k_linear', 'k_rowchain', 'k_attn_fwd', 'k_attn_bwd', 'k_edge_fwd', 'k_edge_bwd', 'k_node_gather', 'k_atb')}
+         ('k_linear', 'k_rowchain', 'k_attn_fwd', 'k_attn_bwd', 'k_edge_fwd', 'k_edge_bwd', 'k_node_gather', 'k_atb',
+          'k_edge_attn_fwd')}      # k_edge_attn_fwd: the 64-wide layers' edge + attention forward in one launch (small batches)
     for l in range(L):
         d = d0 if l == 0 else dh
         da = (d + 15) // 16 * 16
@@ -89,10 +90,12 @@ def kernel_work_model(sizes, L, n_nodes, n_edges, cross=True, d0=69, dh=64, d_em
         W['k_rowchain']['bytes'] += N * 4 * (64 + d + d + 64 + da + d0)
         # attention (model as written: 8 Nl Nr d forward, 2x that backward; executed backward: S and dP are recomputed by
         # both the dq and the dk/dv workgroups -> 28 Nl Nr d)
+        fa = 'k_edge_attn_fwd' if (fused_fwd and d == 64) else 'k_attn_fwd'
+        fe_ = 'k_edge_attn_fwd' if (fused_fwd and d == 64) else 'k_edge_fwd'
         if cross:
-            W['k_attn_fwd']['flops'] += 8 * pp * da
-            W['k_attn_fwd']['flops_written'] += 8 * pp * d
-            W['k_attn_fwd']['bytes'] += N * 4 * (4 * da + 1)
+            W[fa]['flops'] += 8 * pp * da
+            W[fa]['flops_written'] += 8 * pp * d
+            W[fa]['bytes'] += N * 4 * (4 * da + 1)
             W['k_attn_bwd']['flops'] += 28 * pp * da
             W['k_attn_bwd']['flops_written'] += 16 * pp * d
             W['k_attn_bwd']['bytes'] += N * 4 * (8 * da + 2)
@@ -100,9 +103,9 @@ def kernel_work_model(sizes, L, n_nodes, n_edges, cross=True, d0=69, dh=64, d_em
         # 2 (2 d) 64 per edge to k_linear - the executed count comes from the PMC file when present)
         fe = 2 * (2 * d + 42) * 64 + 2 * 64 * 64 + 2 * 64 * 64 + 2 * 64
         fx = 2 * 42 * 64 + 2 * 64 * 64 + 2 * 64 * 64 + 2 * 64
-        W['k_edge_fwd']['flops_written'] += E * fe
-        W['k_edge_fwd']['flops'] += E * fx
-        W['k_edge_fwd']['bytes'] += N * 540 + E * 112
+        W[fe_]['flops_written'] += E * fe
+        W[fe_]['flops'] += E * fx
+        W[fe_]['bytes'] += N * 540 + E * 112
         W['k_edge_bwd']['flops_written'] += 2 * E * fe
         W['k_edge_bwd']['flops'] += E * (3 * fx - 2 * 42 * 64)      # recompute + data gradients + weight gradients
         W['k_edge_bwd']['bytes'] += 2 * (N * 540 + E * 112)
@@ -315,7 +318,7 @@ def kernel_rooflines(prof, work, bf16, step_us, pmc):
     for name, (calls, us) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
         share = us / total if total > 0 else 0.0
         w = work.get(name)
-        if w is None or (share < 0.03 and not name.startswith('k_edge')):
+        if w is None or (w['flops'] == 0 and w['bytes'] == 0) or (share < 0.03 and not name.startswith('k_edge')):
             continue
         t = us * 1e-6
         tf_x = w['flops'] / t / 1e12
@@ -591,7 +594,7 @@ def main():
             out["roofline"] = dict(rl[dom], kernel=dom)
             try:
                 prof, ev_us, n_launch = profile_step(compute, dev)
-                work = kernel_work_model(sizes, L, packed.n_nodes, packed.n_edges)
+                work = kernel_work_model(sizes, L, packed.n_nodes, packed.n_edges, fused_fwd='k_edge_attn_fwd' in prof)
                 allk, ktot = kernel_rooflines(prof, work, dtype == 'bf16', ms_step * 1e3, load_pmc(a.workload))
                 for k in ('k_edge_fwd', 'k_edge_bwd'):     # keep the standalone batched-launch figures beside the in-step ones
                     if k in allk:
