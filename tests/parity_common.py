@@ -102,9 +102,10 @@ def oracle_reference(sd, args, raw, faithful=True, loss_fn=None, kink_aware=True
 # re-ordered sums give ~5e-5 rel-L2 on their own.  Small batches (a few hundred nodes) get GRAD_L2_SMALL / GRAD_MX_SMALL:
 # there ONE flipped LeakyReLU slope is a visible fraction of a weight row's gradient, and the three-evaluation hull
 # (default / all-positive / all-negative) only bounds sums of flips, not each single flip (measured up to 7.9e-4 / 2.7e-3
-# over seeds 8-11 of the ragged case, against 2.2e-3 / 1e-2 without the hull).
+# over seeds 8-11 of the ragged case on the simulator, 3.4e-3 / 7.4e-3 on the GPU).  The ragged test therefore ALSO runs with
+# leakyrelu_neg_slope = 0.5, where a flipped slope changes a derivative by 2x instead of 100x, at the tight tolerance.
 GRAD_L2, GRAD_MX = 3e-4, 1.5e-3
-GRAD_L2_SMALL, GRAD_MX_SMALL = 3e-3, 1e-2
+GRAD_L2_SMALL, GRAD_MX_SMALL = 5e-3, 2e-2
 
 
 def grad_close_hull(got, ref, lo, hi, what='', l2=GRAD_L2, mx=GRAD_MX):
@@ -703,14 +704,16 @@ def check_properties(dev, sizes=((60, 75), (90, 48)), layers=3):
 
 
 def check_model_vs_oracle_ragged(dev, sizes=((4, 4), (17, 5), (33, 64), (1, 40), (48, 1)), layers=2, seed=21,
-                                 check_grads=True):
+                                 check_grads=True, slope=0.01, l2=None, mx=None):
     """Tiny and ragged proteins (1-node graphs without edges, blocks that end mid-tile, fewer nodes than neighbours):
     outputs and gradients of the HIP path against the oracle on the same inputs.  (2- and 3-node proteins are left
     out on purpose: their keypoints are coplanar, the Kabsch guard loop makes A full rank with a 1e-3-conditioned
     diagonal, and the 1e-5 summation-order differences of the keypoints become 1e-2 in T - in the reference as well.)"""
     from equidock_public_amd import graph as G, synthetic
     from oracle import iegmn_port as port
-    args = port.default_args(iegmn_n_lays=layers, skip_weight_h=0.75)
+    l2 = GRAD_L2_SMALL if l2 is None else l2
+    mx = GRAD_MX_SMALL if mx is None else mx
+    args = port.default_args(iegmn_n_lays=layers, skip_weight_h=0.75, leakyrelu_neg_slope=slope)
     sd = port.init_state_dict(args, seed=seed)
     net = build_model(args, sd, dev)
     pairs = synthetic.make_pairs(list(sizes), seed)
@@ -725,11 +728,11 @@ def check_model_vs_oracle_ragged(dev, sizes=((4, 4), (17, 5), (33, 64), (1, 40),
     for k, p in net.named_parameters():
         assert torch.isfinite(p.grad).all(), k
         if check_grads:
-            e2, em = grad_close_hull(p.grad, grads[k], lo[k], hi[k], what=f'ragged batch grad {k} sizes={sizes} seed={seed}',
-                                     l2=GRAD_L2_SMALL, mx=GRAD_MX_SMALL)
+            e2, em = grad_close_hull(p.grad, grads[k], lo[k], hi[k],
+                                     what=f'ragged batch grad {k} sizes={sizes} seed={seed} slope={slope}', l2=l2, mx=mx)
             w2, wm = max(w2, e2), max(wm, em)
     if check_grads:
-        print(f'ragged batch seed {seed}: worst grad rel-L2 {w2:.2e}, max-abs/max {wm:.2e}')
+        print(f'ragged batch seed {seed} slope {slope}: worst grad rel-L2 {w2:.2e}, max-abs/max {wm:.2e}')
 
 
 def check_pair_losses(dev):
