@@ -173,6 +173,76 @@ __device__ __forceinline__ void zero_fill(float* __restrict__ L, int n, int t, i
 // small batches, whose 32-row blocks do not give every CU a workgroup (DB5.5: 112 items, 256 CUs): twice the workgroups
 // with half the matrix work and the same loads each; the arithmetic of a row is unchanged (its keys are split over the
 // waves and merged in the same order).  (The backward uses half blocks for another reason: k_attn_bwd.)
+// ---- MFMA steps shared by the forward and backward bodies, fp32 (BF = false) or bf16 inputs (BF = true) ----------------
+// A bf16 MFMA (v_mfma_f32_16x16x16_bf16, fp32 accumulate) contracts 16 k per instruction, 4 per lane; which 4 a lane
+// supplies does not matter as long as A and B agree, so four consecutive fp32 steps (lane group g supplying k = 4 ks + g,
+// ks = 4 c .. 4 c + 3) become ONE bf16 instruction on the same operand loads, packed (v_cvt_pk_bf16_f32).
+template <bool BF, int KS>
+struct KFrag {                       // a lane's B-operand values for KS k-steps: floats, or bf16 packed four steps at a time
+    float v[BF ? 1 : KS];
+    s16x4 p[BF ? KS / 4 : 1];
+};
+// fragment of row `row` of an LDS tile (row stride DS): element ks = T[row * DS + 4 ks + g]
+template <bool BF, int KS>
+__device__ __forceinline__ void kfrag_load(KFrag<BF, KS>& F, const float* __restrict__ T, int row, int DS, int g) {
+    if constexpr (BF) {
+#pragma unroll
+        for (int c = 0; c < KS / 4; ++c)
+            F.p[c] = pack_bf4(T[row * DS + 16 * c + g], T[row * DS + 16 * c + 4 + g], T[row * DS + 16 * c + 8 + g],
+                              T[row * DS + 16 * c + 12 + g]);
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) F.v[ks] = T[row * DS + 4 * ks + g];
+    }
+}
+// acc[nb] += sum_ks A[arow * DS + 4 ks + g] * F[nb][ks]   (A: a streamed LDS tile, one row per lane)
+template <bool BF, int KS, int NB>
+__device__ __forceinline__ void mma_k(f32x4 (&acc)[NB], const float* __restrict__ A, int arow, int DS, int g,
+                                      const KFrag<BF, KS> (&F)[NB]) {
+    if constexpr (BF) {
+#pragma unroll
+        for (int c = 0; c < KS / 4; ++c) {
+            const s16x4 a = pack_bf4(A[arow * DS + 16 * c + g], A[arow * DS + 16 * c + 4 + g], A[arow * DS + 16 * c + 8 + g],
+                                     A[arow * DS + 16 * c + 12 + g]);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma_bf(a, F[nb].p[c], acc[nb]);
+        }
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const float a = A[arow * DS + 4 * ks + g];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma4(a, F[nb].v[ks], acc[nb]);
+        }
+    }
+}
+// acc[db][nb] += sum_r A[(row0 + r) * DS + 16 db + l15] * B[nb][r]   (B: an F-layout tile, e.g. softmax weights)
+template <bool BF, int DB, int NB>
+__device__ __forceinline__ void mma_r(f32x4 (&acc)[DB][NB], const float* __restrict__ A, int row0, int DS, int l15,
+                                      const f32x4 (&B)[NB]) {
+    if constexpr (BF) {
+        s16x4 b[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) b[nb] = pack_bf4(B[nb][0], B[nb][1], B[nb][2], B[nb][3]);
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+            const s16x4 a = pack_bf4(A[row0 * DS + 16 * db + l15], A[(row0 + 1) * DS + 16 * db + l15],
+                                     A[(row0 + 2) * DS + 16 * db + l15], A[(row0 + 3) * DS + 16 * db + l15]);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[db][nb] = mfma_bf(a, b[nb], acc[db][nb]);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                const float a = A[(row0 + r) * DS + 16 * db + l15];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[db][nb] = mfma4(a, B[nb][r], acc[db][nb]);
+            }
+    }
+}
+
 // LDS of one 4-wave attention-forward group.  The merge buffer aliases the waves' own K tiles (C::RED <= C::TILE; written
 // only after the wave's last tile): 79 KB instead of 111 KB, i.e. two groups per CU, so that one wave's softmax overlaps
 // another's MFMAs.
@@ -190,7 +260,7 @@ struct alignas(16) AttnFwdSmem {
 // t = the thread's index within the group (0..255).  `group_barriers`: the group shares its workgroup with other groups
 // that execute the same number of __syncthreads() (k_edge_attn_fwd: the two halves of one item) - an empty half then
 // still has to pass them.
-template <int DB, bool FAST, int NB>
+template <int DB, bool FAST, int NB, bool BF = false>
 __device__ __forceinline__ void attn_fwd_body(AttnFwdSmem<DB>& sm, const EqdGraph& G, int item, int half, int t, int d,
                                               const float* __restrict__ q, const float* __restrict__ k,
                                               const float* __restrict__ v, float* __restrict__ out,
@@ -246,11 +316,9 @@ __device__ __forceinline__ void attn_fwd_body(AttnFwdSmem<DB>& sm, const EqdGrap
     }
     __syncthreads();
     EQD_TR(2);
-    float qf[NB][KS];
+    KFrag<BF, KS> qf[NB];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[nb][ks] = Qt[(16 * nb + l15) * DS + 4 * ks + g];
+    for (int nb = 0; nb < NB; ++nb) kfrag_load<BF, KS>(qf[nb], Qt, 16 * nb + l15, DS, g);
 
     f32x4 O[DB][NB];
     float mrun[NB], lrun[NB];
@@ -279,13 +347,7 @@ __device__ __forceinline__ void attn_fwd_body(AttnFwdSmem<DB>& sm, const EqdGrap
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) S[mb][nb] = f4zero();
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                const float a = Kw[(16 * mb + l15) * DS + 4 * ks + g];
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) S[mb][nb] = mfma4(a, qf[nb][ks], S[mb][nb]);
-            }
+        for (int mb = 0; mb < 2; ++mb) mma_k<BF, KS, NB>(S[mb], Kw, 16 * mb + l15, DS, g, qf);
         EQD_TR(6);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
@@ -319,15 +381,7 @@ __device__ __forceinline__ void attn_fwd_body(AttnFwdSmem<DB>& sm, const EqdGrap
         }
         EQD_TR(7);
 #pragma unroll
-        for (int mbk = 0; mbk < 2; ++mbk)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int db = 0; db < DB; ++db) {
-                    const float a = Vw[(16 * mbk + 4 * g + r) * DS + 16 * db + l15];
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) O[db][nb] = mfma4(a, S[mbk][nb][r], O[db][nb]);
-                }
+        for (int mbk = 0; mbk < 2; ++mbk) mma_r<BF, DB, NB>(O, Vw, 16 * mbk + 4 * g, DS, l15, S[mbk]);
         EQD_TR(8);
     }
     EQD_TR(9);
@@ -385,11 +439,11 @@ __device__ __forceinline__ void attn_fwd_body(AttnFwdSmem<DB>& sm, const EqdGrap
     EQD_TR_WG_END();
 }
 
-template <int DB, bool FAST, int NB>
+template <int DB, bool FAST, int NB, bool BF = false>
 __global__ __launch_bounds__(EQD_BLOCK) void k_attn_fwd(EqdGraph G, int d, const float* __restrict__ q,
                                                         const float* __restrict__ k, const float* __restrict__ v,
                                                         float* __restrict__ out, float* __restrict__ lse) {
     __shared__ AttnFwdSmem<DB> sm;
     const int item = NB == 1 ? (int)blockIdx.x >> 1 : (int)blockIdx.x;
-    attn_fwd_body<DB, FAST, NB>(sm, G, item, (int)blockIdx.x & 1, (int)threadIdx.x, d, q, k, v, out, lse);
+    attn_fwd_body<DB, FAST, NB, BF>(sm, G, item, (int)blockIdx.x & 1, (int)threadIdx.x, d, q, k, v, out, lse);
 }

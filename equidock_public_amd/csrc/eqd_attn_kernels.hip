@@ -44,7 +44,7 @@ struct AttnBwdSmem {
     __device__ __forceinline__ float* red(int w) { return ALIAS ? str_[0][w] : red_[w]; }
 };
 
-template <int DB, bool FAST, int NB, class SM>
+template <int DB, bool FAST, int NB, class SM, bool BF = false>
 __device__ __forceinline__ void attn_bwd_q_body(SM& sm, const EqdGraph& G, int item, int d,
                                                 const float* __restrict__ q, const float* __restrict__ k,
                                                 const float* __restrict__ v, const float* __restrict__ out,
@@ -127,14 +127,11 @@ __device__ __forceinline__ void attn_bwd_q_body(SM& sm, const EqdGraph& G, int i
         block_tile_stage(d_out, d, DS, b0, b1, Gt, t);
     }
     __syncthreads();
-    float qf[NB][KS], dof[NB][KS];
+    KFrag<BF, KS> qf[NB], dof[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            qf[nb][ks] = Qt[(16 * nb + l15) * DS + 4 * ks + g];
-            dof[nb][ks] = Gt[(16 * nb + l15) * DS + 4 * ks + g];
-        }
+        kfrag_load<BF, KS>(qf[nb], Qt, 16 * nb + l15, DS, g);
+        kfrag_load<BF, KS>(dof[nb], Gt, 16 * nb + l15, DS, g);
         dl[nb] = group_sum(dl[nb]);
         if (wave == 0 && g == 0 && qv[nb]) delta[rowq[nb]] = dl[nb];
     }
@@ -161,17 +158,10 @@ __device__ __forceinline__ void attn_bwd_q_body(SM& sm, const EqdGraph& G, int i
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) S[mb][nb] = dP[mb][nb] = f4zero();
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                const float a = Kw[(16 * mb + l15) * DS + 4 * ks + g];
-                const float b = Vw[(16 * mb + l15) * DS + 4 * ks + g];
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    S[mb][nb] = mfma4(a, qf[nb][ks], S[mb][nb]);
-                    dP[mb][nb] = mfma4(b, dof[nb][ks], dP[mb][nb]);
-                }
-            }
+        for (int mb = 0; mb < 2; ++mb) {
+            mma_k<BF, KS, NB>(S[mb], Kw, 16 * mb + l15, DS, g, qf);
+            mma_k<BF, KS, NB>(dP[mb], Vw, 16 * mb + l15, DS, g, dof);
+        }
         EQD_TR(32);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
@@ -185,15 +175,7 @@ __device__ __forceinline__ void attn_bwd_q_body(SM& sm, const EqdGraph& G, int i
                 }
         EQD_TR(33);
 #pragma unroll
-        for (int mbk = 0; mbk < 2; ++mbk)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int db = 0; db < DB; ++db) {
-                    const float a = Kw[(16 * mbk + 4 * g + r) * DS + 16 * db + l15];
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) dQ[db][nb] = mfma4(a, S[mbk][nb][r], dQ[db][nb]);
-                }
+        for (int mbk = 0; mbk < 2; ++mbk) mma_r<BF, DB, NB>(dQ, Kw, 16 * mbk + 4 * g, DS, l15, S[mbk]);
         EQD_TR(34);
     }
     wave_lds_fence();       // (aliased layout) this wave's reads of its K tile are done before it is overwritten
@@ -220,7 +202,7 @@ __device__ __forceinline__ void attn_bwd_q_body(SM& sm, const EqdGraph& G, int i
 // backward pass 2: dk, dv for the block's keys (queries = the partner protein).
 // OWN_DELTA (float4 path only): delta = rowsum(dO * O) of each streamed query tile is recomputed here from the
 // O tile instead of being read from pass 1's output, so that both passes can run in ONE launch.
-template <int DB, bool FAST, bool OWN_DELTA, int NB, class SM>
+template <int DB, bool FAST, bool OWN_DELTA, int NB, class SM, bool BF = false>
 __device__ __forceinline__ void attn_bwd_kv_body(SM& sm, const EqdGraph& G, int item, int d,
                                                  const float* __restrict__ q, const float* __restrict__ k,
                                                  const float* __restrict__ v, const float* __restrict__ out,
@@ -281,14 +263,12 @@ __device__ __forceinline__ void attn_bwd_kv_body(SM& sm, const EqdGraph& G, int 
         block_tile_stage(v, d, DS, b0, b1, Vb, t);
     }
     __syncthreads();
-    float kf[NB][KS], vf[NB][KS];
+    KFrag<BF, KS> kf[NB], vf[NB];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            kf[nb][ks] = Kb[(16 * nb + l15) * DS + 4 * ks + g];
-            vf[nb][ks] = Vb[(16 * nb + l15) * DS + 4 * ks + g];
-        }
+    for (int nb = 0; nb < NB; ++nb) {
+        kfrag_load<BF, KS>(kf[nb], Kb, 16 * nb + l15, DS, g);
+        kfrag_load<BF, KS>(vf[nb], Vb, 16 * nb + l15, DS, g);
+    }
     if (SM::ALIASED) __syncthreads();      // every wave has its fragments: the block tiles may be overwritten
     f32x4 dK[DB][NB], dV[DB][NB];
 #pragma unroll
@@ -356,17 +336,10 @@ __device__ __forceinline__ void attn_bwd_kv_body(SM& sm, const EqdGraph& G, int 
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) S[mb][nb] = dP[mb][nb] = f4zero();
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                const float a = Qw[(16 * mb + l15) * DS + 4 * ks + g];
-                const float b = Gw[(16 * mb + l15) * DS + 4 * ks + g];
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    S[mb][nb] = mfma4(a, kf[nb][ks], S[mb][nb]);
-                    dP[mb][nb] = mfma4(b, vf[nb][ks], dP[mb][nb]);
-                }
-            }
+        for (int mb = 0; mb < 2; ++mb) {
+            mma_k<BF, KS, NB>(S[mb], Qw, 16 * mb + l15, DS, g, kf);
+            mma_k<BF, KS, NB>(dP[mb], Gw, 16 * mb + l15, DS, g, vf);
+        }
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -380,19 +353,10 @@ __device__ __forceinline__ void attn_bwd_kv_body(SM& sm, const EqdGraph& G, int 
                 }
             }
 #pragma unroll
-        for (int mbq = 0; mbq < 2; ++mbq)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int db = 0; db < DB; ++db) {
-                    const float a = Gw[(16 * mbq + 4 * g + r) * DS + 16 * db + l15];
-                    const float b = Qw[(16 * mbq + 4 * g + r) * DS + 16 * db + l15];
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) {
-                        dV[db][nb] = mfma4(a, S[mbq][nb][r], dV[db][nb]);
-                        dK[db][nb] = mfma4(b, dP[mbq][nb][r], dK[db][nb]);
-                    }
-                }
+        for (int mbq = 0; mbq < 2; ++mbq) {
+            mma_r<BF, DB, NB>(dV, Gw, 16 * mbq + 4 * g, DS, l15, S[mbq]);
+            mma_r<BF, DB, NB>(dK, Qw, 16 * mbq + 4 * g, DS, l15, dP[mbq]);
+        }
     }
     wave_lds_fence();       // (aliased layout) this wave's reads of its query tile are done before it is overwritten
 #pragma unroll
@@ -444,7 +408,7 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd_kv(EqdGraph G, int d, co
 // both passes in one launch (float4 path): workgroups [0, n_items) run pass 1, [n_items, 2 n_items) pass 2
 // NB = 1: two workgroups per item and pass (16-row half blocks); with half the accumulators the kernel fits 256
 // registers, i.e. with its 70 KB of LDS two workgroups share a CU (NB = 2 needs 371 registers: one wave per SIMD)
-template <int DB, int NB>
+template <int DB, int NB, bool BF = false>
 __global__ __launch_bounds__(EQD_BLOCK, NB == 1 ? 2 : 1) void k_attn_bwd(EqdGraph G, int d, const float* __restrict__ q,
                                                         const float* __restrict__ k, const float* __restrict__ v,
                                                         const float* __restrict__ out, const float* __restrict__ lse,
@@ -457,20 +421,29 @@ __global__ __launch_bounds__(EQD_BLOCK, NB == 1 ? 2 : 1) void k_attn_bwd(EqdGrap
     const int idx = kv ? (int)blockIdx.x - per : (int)blockIdx.x;
     const int item = NB == 1 ? idx >> 1 : idx, half = NB == 1 ? idx & 1 : 0;
     if (!kv)
-        attn_bwd_q_body<DB, true, NB>(sm, G, item, d, q, k, v, out, lse, d_out, dq, delta, half);
+        attn_bwd_q_body<DB, true, NB, AttnBwdSmem<DB, true>, BF>(sm, G, item, d, q, k, v, out, lse, d_out, dq, delta, half);
     else
-        attn_bwd_kv_body<DB, true, true, NB>(sm, G, item, d, q, k, v, out, lse, d_out, nullptr, dk, dv, half);
+        attn_bwd_kv_body<DB, true, true, NB, AttnBwdSmem<DB, true>, BF>(sm, G, item, d, q, k, v, out, lse, d_out, nullptr, dk,
+                                                                        dv, half);
 }
 
 // ---------------------------------------------------------------------------------------------
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-template <int DB, bool FAST, int NB>
+template <int DB, bool FAST, int NB, bool BF = false>
 static int attn_launch_fwd(const EqdGraph* g, int d, const float* q, const float* k, const float* v, float* out,
                            float* lse, hipStream_t st) {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_fwd<DB, FAST, NB>), dim3(NB == 1 ? 2 * g->n_att_items : g->n_att_items),
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_fwd<DB, FAST, NB, BF>), dim3(NB == 1 ? 2 * g->n_att_items : g->n_att_items),
                        dim3(EQD_BLOCK), 0, st, *g, d, q, k, v, out, lse);
     return eqd_check_launch("k_attn_fwd");
+}
+template <int DB, int NB>
+static int attn_launch_bwd_bf(const EqdGraph* g, int d, const float* q, const float* k, const float* v, const float* out,
+                              const float* lse, const float* d_out, float* dq, float* dk, float* dv, float* delta,
+                              hipStream_t st) {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd<DB, NB, true>), dim3((NB == 1 ? 4 : 2) * g->n_att_items), dim3(EQD_BLOCK), 0,
+                       st, *g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta);
+    return eqd_check_launch("k_attn_bwd");
 }
 template <int DB, bool FAST, int NB>
 static int attn_launch_bwd(const EqdGraph* g, int d, const float* q, const float* k, const float* v, const float* out,
@@ -541,4 +514,44 @@ extern "C" int eqd_cross_attention_bwd(const EqdGraph* g, int d, const float* q,
     if (d == 80 && al) return attn_launch_bwd<5, true, 2>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
     if (d <= 64) return attn_launch_bwd<4, false, 2>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
     return attn_launch_bwd<5, false, 2>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
+}
+
+// ---- bf16 mode: the four contractions of the forward (Q K^T, P V) and the ten of the backward run on
+// v_mfma_f32_16x16x16_bf16 - inputs rounded to bf16 when the MFMA operands are formed, fp32 accumulate; logits, softmax
+// statistics, exponentials, delta and all outputs stay fp32.  Float4 tile path only (d = 64, or 80 = the zero-padded
+// first layer, 16-byte aligned operands), which is what the model always presents; anything else is an error here.
+extern "C" int eqd_cross_attention_fwd_bf16(const EqdGraph* g, int d, const float* q, const float* k, const float* v,
+                                            float* out, float* lse, void* stream) {
+    if (!g || !q || !k || !v || !out || !lse) {
+        eqd_set_error("eqd_cross_attention_fwd_bf16: NULL argument");
+        return EQD_ERR_NULL;
+    }
+    if ((d != 64 && d != 80) || !(aligned16(q) && aligned16(k) && aligned16(v))) {
+        eqd_set_error("eqd_cross_attention_fwd_bf16: needs d = 64 or 80 and 16-byte aligned operands (d = %d)", d);
+        return EQD_ERR_UNSUPPORTED;
+    }
+    if (g->n_att_items <= 0) return EQD_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const bool half = att_half_blocks(g);
+    if (d == 64)
+        return half ? attn_launch_fwd<4, true, 1, true>(g, d, q, k, v, out, lse, st)
+                    : attn_launch_fwd<4, true, 2, true>(g, d, q, k, v, out, lse, st);
+    return half ? attn_launch_fwd<5, true, 1, true>(g, d, q, k, v, out, lse, st)
+                : attn_launch_fwd<5, true, 2, true>(g, d, q, k, v, out, lse, st);
+}
+extern "C" int eqd_cross_attention_bwd_bf16(const EqdGraph* g, int d, const float* q, const float* k, const float* v,
+                                            const float* out, const float* lse, const float* d_out, float* dq, float* dk,
+                                            float* dv, float* delta, void* stream) {
+    if (!g || !q || !k || !v || !out || !lse || !d_out || !dq || !dk || !dv || !delta) {
+        eqd_set_error("eqd_cross_attention_bwd_bf16: NULL argument");
+        return EQD_ERR_NULL;
+    }
+    if ((d != 64 && d != 80) || !(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(d_out) && aligned16(out))) {
+        eqd_set_error("eqd_cross_attention_bwd_bf16: needs d = 64 or 80 and 16-byte aligned operands (d = %d)", d);
+        return EQD_ERR_UNSUPPORTED;
+    }
+    if (g->n_att_items <= 0) return EQD_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (d == 64) return attn_launch_bwd_bf<4, 1>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
+    return attn_launch_bwd_bf<5, 2>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
 }

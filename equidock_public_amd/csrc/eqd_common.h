@@ -125,16 +125,34 @@ __device__ __forceinline__ void kernarg_to_lds(T& dst, const void* kernarg, int 
 // tile (4 fp32 per 16-feature block and lane) packed to bf16 IS the B operand of the next GEMM's k-chunk.
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ unsigned short f2bf(float f) {      // round to nearest even (finite inputs)
+#ifdef EQD_HOSTSIM
     unsigned u = __builtin_bit_cast(unsigned, f);
     u += 0x7fffu + ((u >> 16) & 1u);
     return (unsigned short)(u >> 16);
+#else
+    return __builtin_bit_cast(unsigned short, (__bf16)f);      // v_cvt_pk_bf16_f32
+#endif
 }
 __device__ __forceinline__ float bf2f(unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
+#ifdef EQD_HOSTSIM
 __device__ __forceinline__ s16x4 pack_bf4(float a, float b, float c, float d) {
     s16x4 r;
     r[0] = (short)f2bf(a); r[1] = (short)f2bf(b); r[2] = (short)f2bf(c); r[3] = (short)f2bf(d);
     return r;
 }
+#else
+// gfx950: v_cvt_pk_bf16_f32 rounds two floats to nearest-even bf16 in ONE instruction (the shift-and-add form above is
+// 4 VALU operations per value - more than the bf16 MFMA they feed); same results for finite inputs
+typedef float eqd_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 eqd_bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned eqd_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x4 pack_bf4(float a, float b, float c, float d) {
+    const eqd_f32x2 lo = {a, b}, hi = {c, d};
+    const eqd_bf16x2 l = __builtin_convertvector(lo, eqd_bf16x2), h = __builtin_convertvector(hi, eqd_bf16x2);
+    const eqd_u32x2 r = {__builtin_bit_cast(unsigned, l), __builtin_bit_cast(unsigned, h)};
+    return __builtin_bit_cast(s16x4, r);
+}
+#endif
 __device__ __forceinline__ f32x4 mfma_bf(s16x4 a, s16x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
 }

@@ -239,6 +239,16 @@ int eqd_cross_attention_bwd(const EqdGraph* g, int d, const float* q, const floa
                             const float* out, const float* lse, const float* d_out,
                             float* dq, float* dk, float* dv, float* delta /* [n_nodes] scratch */, void* stream);
 
+/* bf16 mode of the two calls above: every contraction (Q K^T, P V; dS K, dS^T Q, P^T dO, dO V^T) on
+ * v_mfma_f32_16x16x16_bf16 - inputs rounded to bf16 (round to nearest even) when the MFMA operands are formed, fp32
+ * accumulate; logits, softmax statistics, exponentials and outputs fp32.  d = 64 or 80 (zero-padded), 16-byte aligned
+ * operands (what the model presents); otherwise EQD_ERR_UNSUPPORTED. */
+int eqd_cross_attention_fwd_bf16(const EqdGraph* g, int d, const float* q, const float* k, const float* v,
+                                 float* out, float* lse, void* stream);
+int eqd_cross_attention_bwd_bf16(const EqdGraph* g, int d, const float* q, const float* k, const float* v,
+                                 const float* out, const float* lse, const float* d_out,
+                                 float* dq, float* dk, float* dv, float* delta, void* stream);
+
 /* K-head attention keypoint pooling (rigid_docking_model.py:521-560) with collapsed heads:
  * u[s][k] = W_K^(k)T (W_Q^(k) qmean[partner(s)]) / sqrt(d);  scores = H u^T; softmax over the
  * segment's nodes; Y = att^T Z.  qmean: [2B][64]; H [n_nodes][64]; Z [n_nodes][3];

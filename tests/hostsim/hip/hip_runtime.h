@@ -45,6 +45,7 @@ static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMem
 }
 
 #define EQD_NUM_CUS_FIXED 256   /* the simulated device: MI355X */
+#define EQD_HOSTSIM 1
 typedef void* hipEvent_t;
 enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }

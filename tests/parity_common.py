@@ -1012,3 +1012,43 @@ def check_fused_forward(dev):
             del os.environ['EQD_FUSE_FWD']
     for a, b in zip(res['1'][0] + res['1'][1], res['0'][0] + res['0'][1]):
         assert torch.equal(a, b)
+
+
+def check_attention_bf16(dev, d, sizes=((70, 45), (33, 101))):
+    """bf16 mode of the cross-attention op (every contraction on the bf16 MFMA, fp32 accumulate / softmax) against the
+    torch restatement with bf16-rounded GEMM inputs.  The kernels round the UN-normalised softmax weights of each tile
+    (relative to that tile's running maximum) and, in the backward, dS and the recomputed P: comparison at bf16 resolution."""
+    g, pk, gs = small_graph(dev, sizes=sizes, degrade=False)
+    N = pk.n_nodes
+    torch.manual_seed(4)
+    q, k, v = torch.randn(N, d) * 0.5, torch.randn(N, d) * 0.5, torch.randn(N, d)
+    if d == 80:     # the zero-padded first layer: columns 69.. are zero
+        q[:, 69:], k[:, 69:], v[:, 69:] = 0, 0, 0
+    qd, kd, vd = (t.to(dev) for t in (q, k, v))
+    out, lse = torch.zeros(N, d, device=dev), torch.zeros(N, device=dev)
+    L.check(lib().eqd_cross_attention_fwd_bf16(C.byref(gs), d, P(qd), P(kd), P(vd), P(out), P(lse), st(dev)))
+    sync(dev)
+    ql, kl, vl = (t.clone().requires_grad_(True) for t in (q, k, v))
+    nl = pk.n_lig
+    o_l, o_r, lo, ro = [], [], 0, 0
+    for a, b in zip(pk.lig_counts, pk.rec_counts):
+        L0, L1, R0, R1 = lo, lo + a, nl + ro, nl + ro + b
+        for (q0, q1, k0, k1), acc in (((L0, L1, R0, R1), o_l), ((R0, R1, L0, L1), o_r)):
+            pr = torch.softmax(port.rb16(ql[q0:q1]) @ port.rb16(kl[k0:k1]).t(), 1)
+            acc.append(port.rb16(pr) @ port.rb16(vl[k0:k1]))
+        lo += a
+        ro += b
+    ref = torch.cat(o_l + o_r, 0)
+    close(out, ref, tol=6e-3, what=f'bf16 attention out d={d}')
+    do = torch.randn(N, d)
+    if d == 80:
+        do[:, 69:] = 0
+    (ref * do).sum().backward()
+    dq, dk, dv = (torch.zeros(N, d, device=dev) for _ in range(3))
+    delta = torch.zeros(N, device=dev)
+    dod = do.to(dev)
+    L.check(lib().eqd_cross_attention_bwd_bf16(C.byref(gs), d, P(qd), P(kd), P(vd), P(out), P(lse), P(dod), P(dq), P(dk),
+                                               P(dv), P(delta), st(dev)))
+    sync(dev)
+    for n, a, b in (('dq', dq, ql.grad), ('dk', dk, kl.grad), ('dv', dv, vl.grad)):
+        grad_close(a, b, what=f'bf16 attention {n} d={d}', l2=1e-2, mx=3e-2)

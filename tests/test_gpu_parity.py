@@ -160,6 +160,13 @@ def test_fused_forward_launch_is_bit_identical(dev):
     pc.check_fused_forward(dev)
 
 
+@pytest.mark.parametrize('d', [64, 80])
+def test_cross_attention_bf16(dev, d):
+    from tests import parity_common as pc
+    pc.check_attention_bf16(dev, d)
+    pc.check_attention_bf16(dev, d, sizes=((300, 257), (129, 64)))
+
+
 def test_scalar_loss(dev):
     from tests import parity_common as pc
     pc.check_scalar_loss(dev)

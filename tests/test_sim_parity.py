@@ -129,6 +129,11 @@ def test_fused_forward_launch_is_bit_identical():
     pc.check_fused_forward(DEV)
 
 
+@pytest.mark.parametrize('d', [64, 80])
+def test_cross_attention_bf16(d):
+    pc.check_attention_bf16(DEV, d)
+
+
 def test_scalar_loss():
     pc.check_scalar_loss(DEV)
 
