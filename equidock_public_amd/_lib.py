@@ -48,13 +48,13 @@ class EqdLinJob(C.Structure):
                 ('rows', C.c_int32), ('bias', C.c_void_p), ('ln_g', C.c_void_p), ('ln_b', C.c_void_p),
                 ('pre_ln', C.c_void_p), ('ld_pre', C.c_int32), ('R', C.c_void_p), ('ldr', C.c_int32),
                 ('alpha', C.c_float), ('beta', C.c_float), ('slope', C.c_float), ('ln_eps', C.c_float),
-                ('Y', C.c_void_p), ('ldy', C.c_int32)]
+                ('Y', C.c_void_p), ('ldy', C.c_int32), ('bf16', C.c_int32)]
 
 
 class EqdAtbJob(C.Structure):
     _fields_ = [('X', C.c_void_p), ('xmask', C.c_void_p), ('ldx', C.c_int32), ('M', C.c_int32), ('Y', C.c_void_p),
                 ('ldy', C.c_int32), ('N', C.c_int32), ('rows', C.c_int32), ('out', C.c_void_p), ('o_rs', C.c_int32),
-                ('o_cs', C.c_int32), ('bias_out', C.c_void_p), ('slope', C.c_float), ('scale', C.c_float)]
+                ('o_cs', C.c_int32), ('bias_out', C.c_void_p), ('slope', C.c_float), ('scale', C.c_float), ('bf16', C.c_int32)]
 
 
 class EqdEdgeParams(C.Structure):
@@ -128,8 +128,8 @@ def load_library():
             "There is no CPU fallback for the IEGMN hot path.")
     lib = C.CDLL(LIB_PATH)
     _declare(lib)
-    if lib.eqd_abi_version() != 2:
-        raise EquidockHipError(f"ABI version mismatch: library {lib.eqd_abi_version()} != 2")
+    if lib.eqd_abi_version() != 3:
+        raise EquidockHipError(f"ABI version mismatch: library {lib.eqd_abi_version()} != 3")
     _lib, _is_sim = lib, bool(lib.eqd_is_simulator())
     return _lib
 

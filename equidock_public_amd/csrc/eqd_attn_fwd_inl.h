@@ -357,20 +357,26 @@ __device__ __forceinline__ void attn_fwd_body(AttnFwdSmem<DB>& sm, const EqdGrap
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = kt + 16 * mb + 4 * g + r;
-                    const float s = key < o1 ? S[mb][nb][r] : EQD_NEG_BIG;
+                    // bf16 mode: logits in log2 units (the running maximum is then kept as an INTEGER, see below)
+                    const float sv = BF ? S[mb][nb][r] * 1.44269504088896341f : S[mb][nb][r];
+                    const float s = key < o1 ? sv : EQD_NEG_BIG;
                     S[mb][nb][r] = s;
                     mx = fmaxf(mx, s);
                 }
             mx = group_max(mx);
-            const float mnew = fmaxf(mrun[nb], mx);
-            const float alpha = expf(mrun[nb] - mnew);
+            // bf16 mode: the un-normalised weights p = 2^(s - M) are rounded to bf16 for the P V product; with M an
+            // integer every tile / wave / merge step rescales by an exact power of two, so WHICH bf16 value a weight
+            // rounds to does not depend on the tile schedule (and the oracle can state the rounding point:
+            // 2^(s log2 e - ceil(max)) rounded to bf16)
+            const float mnew = fmaxf(mrun[nb], BF ? ceilf(mx) : mx);
+            const float alpha = BF ? exp2f(mrun[nb] - mnew) : expf(mrun[nb] - mnew);
             float ps = 0.f;
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = kt + 16 * mb + 4 * g + r;
-                    const float p = key < o1 ? expf(S[mb][nb][r] - mnew) : 0.f;
+                    const float p = key < o1 ? (BF ? exp2f(S[mb][nb][r] - mnew) : expf(S[mb][nb][r] - mnew)) : 0.f;
                     S[mb][nb][r] = p;
                     ps += p;
                 }
@@ -410,7 +416,7 @@ __device__ __forceinline__ void attn_fwd_body(AttnFwdSmem<DB>& sm, const EqdGrap
         float ll = 0.f;
 #pragma unroll
         for (int w = 0; w < EQD_WAVES; ++w) {
-            sc[nb][w] = expf(sm_m[w][16 * nb + l15] - mm);
+            sc[nb][w] = BF ? exp2f(sm_m[w][16 * nb + l15] - mm) : expf(sm_m[w][16 * nb + l15] - mm);
             ll += sm_l[w][16 * nb + l15] * sc[nb][w];
         }
         mtot[nb] = mm;
@@ -433,7 +439,8 @@ __device__ __forceinline__ void attn_fwd_body(AttnFwdSmem<DB>& sm, const EqdGrap
     if (wave == 0 && g == 0) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
-            if (qv[nb]) lse[rowq[nb]] = ltot[nb] > 0.f ? mtot[nb] + logf(ltot[nb]) : 0.f;
+            if (qv[nb])
+                lse[rowq[nb]] = ltot[nb] > 0.f ? (BF ? mtot[nb] * 0.693147180559945309f : mtot[nb]) + logf(ltot[nb]) : 0.f;
     }
     EQD_TR(10);
     EQD_TR_WG_END();

@@ -89,10 +89,12 @@ void lin_src(EqdLinJob& J, int i, const float* X, int ldx, int K, const float* W
     J.s[i].X = X; J.s[i].ldx = ldx; J.s[i].K = K; J.s[i].W = W; J.s[i].w_rs = w_rs; J.s[i].w_cs = w_cs;
     J.s[i].mask = mask;
 }
+thread_local int g_bf16_mode = 0;      // EqdModelDesc.storage_bf16 of the call being enqueued (stamped on every job)
 EqdLinJob lin_job(int rows, int M, float* Y, int ldy, float slope, float eps) {
     EqdLinJob J;
     memset(&J, 0, sizeof(J));
     J.rows = rows; J.M = M; J.Y = Y; J.ldy = ldy; J.alpha = 1.f; J.beta = 0.f; J.slope = slope; J.ln_eps = eps;
+    J.bf16 = g_bf16_mode;
     return J;
 }
 EqdAtbJob atb_job(const float* X, int ldx, int M, const float* Y, int ldy, int N, int rows, float* out, int o_rs,
@@ -101,6 +103,7 @@ EqdAtbJob atb_job(const float* X, int ldx, int M, const float* Y, int ldy, int N
     memset(&J, 0, sizeof(J));
     J.X = X; J.ldx = ldx; J.M = M; J.Y = Y; J.ldy = ldy; J.N = N; J.rows = rows; J.out = out; J.o_rs = o_rs;
     J.o_cs = 1; J.bias_out = bias_out; J.slope = slope; J.xmask = xmask; J.scale = scale;
+    J.bf16 = g_bf16_mode;
     return J;
 }
 
@@ -297,6 +300,7 @@ extern "C" int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const
     hipStream_t st = (hipStream_t)stream;
     EqdCtx* cx = (EqdCtx*)ctx;
     const Dims D = make_dims(m, g);
+    g_bf16_mode = m->storage_bf16 ? 1 : 0;
     EqdArena A(saved ? saved : scratch, saved ? saved_bytes : scratch_bytes);
     Saved S;
     carve_saved(D, g, A, S);
@@ -362,13 +366,16 @@ extern "C" int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const
             HIPOK(hipStreamWaitEvent(sat, cx->fork, 0));
         }
         EqdEdgeParams ep = edge_params(D, m, l, p);
-        if (m->cross_msgs && sat == st) {
+        if (m->cross_msgs && sat == st && !m->storage_bf16) {
             // the two independent halves of the layer: ONE launch when both fit the chip at once (small batches)
             RC(eqd_edge_attn_fwd(g, &ep, Ls.P, Ls.Q, S.x[l], Ls.aggr_msg, S.x[l + 1], da, Ls.qa, Ls.ka, Ls.va, Ls.aggr_cross,
                                  Ls.lse, st));
         } else {
             if (m->cross_msgs) {
-                RC(eqd_cross_attention_fwd(g, da, Ls.qa, Ls.ka, Ls.va, Ls.aggr_cross, Ls.lse, sat));
+                if (m->storage_bf16)
+                    RC(eqd_cross_attention_fwd_bf16(g, da, Ls.qa, Ls.ka, Ls.va, Ls.aggr_cross, Ls.lse, sat));
+                else
+                    RC(eqd_cross_attention_fwd(g, da, Ls.qa, Ls.ka, Ls.va, Ls.aggr_cross, Ls.lse, sat));
             } else {
                 if (hipMemsetAsync(Ls.aggr_cross, 0, (size_t)N * da * sizeof(float), st) != hipSuccess) return EQD_ERR_LAUNCH;
             }
@@ -434,6 +441,7 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
     hipStream_t st = (hipStream_t)stream;
     (void)ctx;
     const Dims D = make_dims(m, g);
+    g_bf16_mode = m->storage_bf16 ? 1 : 0;
     EqdArena As(const_cast<void*>(saved), saved_bytes);
     Saved S;
     carve_saved(D, g, As, S);
@@ -584,9 +592,14 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
         }
         // The backward kernels of a layer each fill the chip (LDS-bound occupancy), so they run back to back
         // on ONE stream: side streams only added event latency here.
-        if (m->cross_msgs)
-            RC(eqd_cross_attention_bwd(g, da, Ls.qa, Ls.ka, Ls.va, Ls.aggr_cross, Ls.lse, W.d_aggr_cross, dq, dk, dv,
-                                       W.delta, st));
+        if (m->cross_msgs) {
+            if (m->storage_bf16)
+                RC(eqd_cross_attention_bwd_bf16(g, da, Ls.qa, Ls.ka, Ls.va, Ls.aggr_cross, Ls.lse, W.d_aggr_cross, dq, dk, dv,
+                                                W.delta, st));
+            else
+                RC(eqd_cross_attention_bwd(g, da, Ls.qa, Ls.ka, Ls.va, Ls.aggr_cross, Ls.lse, W.d_aggr_cross, dq, dk, dv,
+                                           W.delta, st));
+        }
         {
             EqdEdgeParams ep = edge_params(D, m, l, p);
             EqdEdgeGrads eg;

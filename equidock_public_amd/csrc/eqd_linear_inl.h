@@ -247,7 +247,7 @@ __device__ __forceinline__ void lin_store(const EqdLinJob& J, const EqdLinSrc& S
 // acc[rt][i] (+)= W-fragment x X-fragment of the chunk for the wave's NOWN output blocks; no per-lane predicates.
 // The weight fragments are read once for the RT row tiles.  MFMAs alternate between two accumulator sets (a single
 // dependent chain leaves the matrix pipe idle).
-template <int RT, int NOWN, int NQ, bool WT>
+template <int RT, int NOWN, int NQ, bool WT, bool BF = false>
 __device__ __forceinline__ void lin_mma(f32x4 (&acc)[RT][2], f32x4 (&acc2)[RT][2], const float* (&Xs)[RT],
                                         const float* __restrict__ Wl, const int (&mb)[2], int l15, int g) {
     // WT: the weights lie as Wl[k][m] (full steps of transposed sources): the 4 k-values of a lane are 4 scalar reads
@@ -268,15 +268,30 @@ __device__ __forceinline__ void lin_mma(f32x4 (&acc)[RT][2], f32x4 (&acc2)[RT][2
         f32x4 b[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) b[q] = *(const f32x4*)&Xs[rt][l15 * LIN_S + 16 * q + 4 * g];
+        if constexpr (BF) {
+            // bf16 mode: the 4 k-values a lane holds for chunk q (k = 16 q + 4 g + j) are exactly one operand of
+            // v_mfma_f32_16x16x16_bf16: four fp32 instructions become one (inputs rounded to bf16, fp32 accumulate)
 #pragma unroll
-        for (int q = 0; q < NQ; ++q)
+            for (int q = 0; q < NQ; ++q) {
+                const s16x4 bp = pack_bf4(b[q][0], b[q][1], b[q][2], b[q][3]);
 #pragma unroll
-            for (int i = 0; i < NOWN; ++i) {
-                acc[rt][i] = mfma4(a[i][q][0], b[q][0], acc[rt][i]);
-                acc2[rt][i] = mfma4(a[i][q][1], b[q][1], acc2[rt][i]);
-                acc[rt][i] = mfma4(a[i][q][2], b[q][2], acc[rt][i]);
-                acc2[rt][i] = mfma4(a[i][q][3], b[q][3], acc2[rt][i]);
+                for (int i = 0; i < NOWN; ++i) {
+                    const s16x4 ap = pack_bf4(a[i][q][0], a[i][q][1], a[i][q][2], a[i][q][3]);
+                    if (q & 1) acc2[rt][i] = mfma_bf(ap, bp, acc2[rt][i]);
+                    else acc[rt][i] = mfma_bf(ap, bp, acc[rt][i]);
+                }
             }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int i = 0; i < NOWN; ++i) {
+                    acc[rt][i] = mfma4(a[i][q][0], b[q][0], acc[rt][i]);
+                    acc2[rt][i] = mfma4(a[i][q][1], b[q][1], acc2[rt][i]);
+                    acc[rt][i] = mfma4(a[i][q][2], b[q][2], acc[rt][i]);
+                    acc2[rt][i] = mfma4(a[i][q][3], b[q][3], acc2[rt][i]);
+                }
+        }
     }
 }
 
@@ -288,6 +303,7 @@ __device__ __forceinline__ void lin_mma(f32x4 (&acc)[RT][2], f32x4 (&acc2)[RT][2
 //      (one wave per SIMD), so its instruction count is latency: the general path spends ~3 500 clocks per step and
 //      ~2 000 per job on descriptor handling; the floor with static addressing is 1 350 per step
 //      (profiles/exp_step_floor.hip).  Arithmetic (order of every sum) is the same as in linear_tile. -----------------
+template <bool BF>
 __device__ __forceinline__ void linear_tile_lean(const JobW& W, bool chain, int out_local, LinSmem<1>& sm,
                                                  float (*Lb)[LIN_LOCALS][16 * LIN_S], int row0, LinRegs<1>& RA,
                                                  bool have_first, bool has_next, const JobW& Wn, int trace_slot) {
@@ -383,9 +399,9 @@ __device__ __forceinline__ void linear_tile_lean(const JobW& W, bool chain, int 
             LIN_TR(tr_i++);
             const float* Xs[1] = {locs[si] >= 0 ? &Lb[0][locs[si]][0] : sm.Xl[0]};
             if ((kfm >> si) & 1u)
-                lin_mma<1, 1, 4, false>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+                lin_mma<1, 1, 4, false, BF>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
             else
-                lin_mma<1, 1, 4, true>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+                lin_mma<1, 1, 4, true, BF>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
             LIN_TR(tr_i++);
         }
     }
@@ -403,7 +419,7 @@ __device__ __forceinline__ void linear_tile_lean(const JobW& W, bool chain, int 
                     lin_store_s<1>(S, M, slope, locs[si] >= 0, c, t, RB, sm);
                     __syncthreads();
                     const float* Xs[1] = {locs[si] >= 0 ? &Lb[0][locs[si]][k0] : sm.Xl[0]};
-                    lin_mma<1, 1, 1, false>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+                    lin_mma<1, 1, 1, false, BF>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
                     k0 += c.kc;
                 }
             }
@@ -473,7 +489,7 @@ __device__ __forceinline__ void linear_tile_lean(const JobW& W, bool chain, int 
 // job's epilogue - otherwise every job of a chain starts with a fully exposed memory round trip.
 // W: the descriptor words of J (jobw_load); chain: J is the `lin` of an EqdChainJob, whose src_local / out_local words are
 // in W too; Wn: the words of the next job Jn (only read when has_next).
-template <int RT>
+template <int RT, bool BF = false>
 __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const JobW& W, bool chain,
                                             const int* __restrict__ src_local, int out_local,
                                             LinSmem<RT>& sm, float (*Lb)[LIN_LOCALS][16 * LIN_S], int row0,
@@ -489,7 +505,7 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const JobW& W, b
         for (int si = 0; si < EQD_MAX_SRC; ++si)
             if (si < nsrc && jw_i(W, LJ(s) + si * JW_SRC_DW + JW_OFF(EqdLinSrc, K)) < 64) lean = false;
         if (lean) {
-            linear_tile_lean(W, chain, out_local, sm, Lb, row0, RA, have_first, has_next, Wn, trace_slot);
+            linear_tile_lean<BF>(W, chain, out_local, sm, Lb, row0, RA, have_first, has_next, Wn, trace_slot);
             return;
         }
     }
@@ -557,20 +573,20 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const JobW& W, b
             if (c.kc == 64) {
                 if (uni(S.w_cs) == 1) {
                     if (own[1])
-                        lin_mma<RT, 2, 4, false>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+                        lin_mma<RT, 2, 4, false, BF>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
                     else if (own[0])
-                        lin_mma<RT, 1, 4, false>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+                        lin_mma<RT, 1, 4, false, BF>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
                 } else {
                     if (own[1])
-                        lin_mma<RT, 2, 4, true>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+                        lin_mma<RT, 2, 4, true, BF>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
                     else if (own[0])
-                        lin_mma<RT, 1, 4, true>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+                        lin_mma<RT, 1, 4, true, BF>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
                 }
             } else {
                 if (own[1])
-                    lin_mma<RT, 2, 1, false>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+                    lin_mma<RT, 2, 1, false, BF>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
                 else if (own[0])
-                    lin_mma<RT, 1, 1, false>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+                    lin_mma<RT, 1, 1, false, BF>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
             }
             LIN_TR(tr_i++);
         };

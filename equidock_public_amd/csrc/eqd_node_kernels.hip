@@ -147,7 +147,7 @@ struct LinJobsArg {
     EqdLinJob j[LIN_MAXJOBS];
 };
 
-template <int RT>
+template <int RT, bool BF = false>
 __global__ __launch_bounds__(EQD_BLOCK, 2) void k_linear(LinJobsArg jobs) {
     __shared__ LinSmem<RT> sm;
     __shared__ __attribute__((aligned(16))) EqdLinJob Jl;      // this workgroup's job, copied out of the kernarg segment
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(EQD_BLOCK, 2) void k_linear(LinJobsArg jobs) {
     EQD_TR_WG();
     LinRegs<RT> RA;
     const JobW W = jobw_load(&Jl, (int)(sizeof(EqdLinJob) / 4), threadIdx.x & 63);
-    linear_tile<RT>(J, W, false, nullptr, -1, sm, nullptr, row0, RA, false, false, W);
+    linear_tile<RT, BF>(J, W, false, nullptr, -1, sm, nullptr, row0, RA, false, false, W);
     EQD_TR_WG_END();
 }
 // 16-row tiles per workgroup.  One tile everywhere: with the lean (precomputed-address) step pipeline, which only fits
@@ -343,7 +343,7 @@ __device__ __forceinline__ void chain_lnbwd(const EqdChainJob& C, float (*Lb)[LI
     jaux[(size_t)blockIdx.x * 256 + t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
 }
 
-template <int RT>
+template <int RT, bool BF = false>
 __global__ __launch_bounds__(EQD_BLOCK, 2) void k_rowchain(EqdChainArg A_) {
     __shared__ __attribute__((aligned(16))) EqdChainArg A;      // job descriptions: kernarg segment -> LDS, once
     kernarg_to_lds(A, EQD_KERNARG_PTR(A_), 0);
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(EQD_BLOCK, 2) void k_rowchain(EqdChainArg A_) {
             const int nj = jw_i(Wc, JW_OFF(EqdChainJob, prefetch_next));   // next linear job whose first step may be fetched early, or -1
             JobW Wp = Wn;
             if (nj >= 0 && nj != jj + 1) Wp = jobw_load(&A.j[nj], CJ_DW, lane);
-            linear_tile<RT>(C.lin, Wc, true, C.src_local, jw_i(Wc, JW_OFF(EqdChainJob, out_local)), sm, Lb, row0, RA, have,
+            linear_tile<RT, BF>(C.lin, Wc, true, C.src_local, jw_i(Wc, JW_OFF(EqdChainJob, out_local)), sm, Lb, row0, RA, have,
                             nj >= 0, Wp, 210 + 4 * jj);
             have = nj >= 0;
         } else {
@@ -456,10 +456,14 @@ int eqd_launch_rowchain(const EqdChainJob* jobs, int njobs, int rows, hipStream_
             eqd_set_error("eqd_launch_rowchain: LDS tile index %d >= %d", jobs[i].out_local, LIN_LOCALS);
             return EQD_ERR_SHAPE;
         }
-    if (eqd_row_tiles(rows) == 2)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rowchain<2>), dim3(eqd_rowchain_blocks(rows)), dim3(EQD_BLOCK), 0, st, arg);
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rowchain<1>), dim3(eqd_rowchain_blocks(rows)), dim3(EQD_BLOCK), 0, st, arg);
+    const bool bf = njobs > 0 && jobs[0].lin.bf16;     // one arithmetic mode per launch
+    if (eqd_row_tiles(rows) == 2) {
+        if (bf) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rowchain<2, true>), dim3(eqd_rowchain_blocks(rows)), dim3(EQD_BLOCK), 0, st, arg);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rowchain<2, false>), dim3(eqd_rowchain_blocks(rows)), dim3(EQD_BLOCK), 0, st, arg);
+    } else {
+        if (bf) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rowchain<1, true>), dim3(eqd_rowchain_blocks(rows)), dim3(EQD_BLOCK), 0, st, arg);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rowchain<1, false>), dim3(eqd_rowchain_blocks(rows)), dim3(EQD_BLOCK), 0, st, arg);
+    }
     return eqd_check_launch("k_rowchain");
 }
 
@@ -491,10 +495,14 @@ extern "C" int eqd_linear(const EqdLinJob* jobs, int njobs, void* stream) {
         }
         if (maxrows == 0) continue;
         dim3 grid(eqd_rowchain_blocks(maxrows), n);
-        if (eqd_row_tiles(maxrows) == 2)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear<2>), grid, dim3(EQD_BLOCK), 0, st, arg);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear<1>), grid, dim3(EQD_BLOCK), 0, st, arg);
+        const bool bf = jobs[base].bf16 != 0;       // one arithmetic mode per launch
+        if (eqd_row_tiles(maxrows) == 2) {
+            if (bf) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear<2, true>), grid, dim3(EQD_BLOCK), 0, st, arg);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear<2, false>), grid, dim3(EQD_BLOCK), 0, st, arg);
+        } else {
+            if (bf) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear<1, true>), grid, dim3(EQD_BLOCK), 0, st, arg);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear<1, false>), grid, dim3(EQD_BLOCK), 0, st, arg);
+        }
         int rc = eqd_check_launch("k_linear");
         if (rc) return rc;
     }
@@ -506,7 +514,7 @@ extern "C" int eqd_linear(const EqdLinJob* jobs, int njobs, void* stream) {
 //   wave tile: 80 (M axis, output rows m) x 64 (N axis, output cols n), K axis = graph rows.
 //   then k_atb_reduce sums the chunks in a fixed order and accumulates into the gradient.
 // ------------------------------------------------------------------------------------------
-#define ATB_MAXUNITS 36   /* 36 x 104 B of kernel arguments */
+#define ATB_MAXUNITS 36   /* 36 x 112 B of kernel arguments */
 #define ATB_TILE 5120  /* 80 x 64 */
 #define ATB_PSTRIDE 5200
 struct AtbUnit {
@@ -515,7 +523,7 @@ struct AtbUnit {
     int fast;        // 0 general; 1 / 2: M == 64 with aligned X rows, Y block whole and aligned / through ld4u (atb_fast)
     long long poff;  // float offset of this unit's partials
 };
-static_assert(sizeof(AtbUnit) * 36 <= 4096, "AtbUnitsArg must fit the kernel-argument segment");
+static_assert(sizeof(AtbUnit) * ATB_MAXUNITS <= 4096, "AtbUnitsArg must fit the kernel-argument segment");
 struct AtbUnitsArg {
     AtbUnit u[ATB_MAXUNITS];
 };
@@ -579,7 +587,7 @@ __device__ __forceinline__ void atb_store(const EqdAtbJob& J, int n0, int chunk,
 }
 // one 64-row chunk: acc[mb] += X[:, 16 mb ..]^T Y[:, 16 wave ..]; MBN row blocks, no predicates in the loop
 // (4 k-steps per trip: 4 (1 + MBN) LDS reads in flight, then 4 MBN MFMAs)
-template <int MBN>
+template <int MBN, bool BF = false>
 __device__ __forceinline__ void atb_mma(f32x4 (&acc)[5], const float* __restrict__ Xl, const float* __restrict__ Yl,
                                         int wave, int l15, int g) {
     for (int ks = 0; ks < ATB_ROWS / 4; ks += 4) {
@@ -591,10 +599,17 @@ __device__ __forceinline__ void atb_mma(f32x4 (&acc)[5], const float* __restrict
 #pragma unroll
             for (int mb = 0; mb < MBN; ++mb) a[u][mb] = Xl[row * ATB_LS + 16 * mb + l15];
         }
+        if constexpr (BF) {      // bf16 mode: the four k-steps (rows 4 (ks + u) + g) as one 16-deep bf16 MFMA
+            const s16x4 bp = pack_bf4(b[0], b[1], b[2], b[3]);
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+            for (int mb = 0; mb < MBN; ++mb)
+                acc[mb] = mfma_bf(pack_bf4(a[0][mb], a[1][mb], a[2][mb], a[3][mb]), bp, acc[mb]);
+        } else {
 #pragma unroll
-            for (int mb = 0; mb < MBN; ++mb) acc[mb] = mfma4(a[u][mb], b[u], acc[mb]);
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int mb = 0; mb < MBN; ++mb) acc[mb] = mfma4(a[u][mb], b[u], acc[mb]);
+        }
     }
 }
 
@@ -658,7 +673,8 @@ __device__ __forceinline__ void atb_fast(const AtbUnit& u, int c, float* __restr
         }
         __syncthreads();
         if (chunk + nparts < nchunks) load(chunk + nparts);
-        atb_mma<4>(acc, Xl, Yl, wave, l15, g);
+        if (J.bf16) atb_mma<4, true>(acc, Xl, Yl, wave, l15, g);
+        else atb_mma<4, false>(acc, Xl, Yl, wave, l15, g);
         if (want_bias) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) bacc += Xl[(16 * wave + i) * ATB_LS + lane];
@@ -703,10 +719,13 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_atb(AtbUnitsArg U, float* __restr
         atb_store(J, u.n0, chunk, t, R, Xl, Yl);
         __syncthreads();
         if (chunk + u.nparts < u.nchunks) atb_load(J, u.n0, chunk + u.nparts, t, R);
-        if (mbn > 4)
-            atb_mma<5>(acc, Xl, Yl, wave, l15, g);
-        else
-            atb_mma<4>(acc, Xl, Yl, wave, l15, g);
+        if (J.bf16) {
+            if (mbn > 4) atb_mma<5, true>(acc, Xl, Yl, wave, l15, g);
+            else atb_mma<4, true>(acc, Xl, Yl, wave, l15, g);
+        } else {
+            if (mbn > 4) atb_mma<5, false>(acc, Xl, Yl, wave, l15, g);
+            else atb_mma<4, false>(acc, Xl, Yl, wave, l15, g);
+        }
         if (t < 80) {
 #pragma unroll 8
             for (int row = 0; row < ATB_ROWS; ++row) bacc += Xl[row * ATB_LS + t];

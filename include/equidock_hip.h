@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define EQD_ABI_VERSION 2
+#define EQD_ABI_VERSION 3
 #define EQD_TILE_EDGES 32   /* edges per node-aligned tile (max supported in-degree) */
 #define EQD_ATT_BLOCK 32    /* nodes per cross-attention work item */
 #define EQD_MAX_SRC 6
@@ -103,7 +103,9 @@ typedef struct EqdModelDesc {
     int32_t cross_msgs, use_dist_in_layers, use_edge_features;
     float skip_weight_h, x_connection_init, lrelu_slope, ln_eps;
     int32_t svd_seed;               /* seed of the counter-based draws used if the SVD guard fires */
-    int32_t storage_bf16;           /* 1: edge-message kernels in bf16 mode (EqdEdgeParams.bf16); default 0 = fp32 */
+    int32_t storage_bf16;           /* 1: every GEMM of the path on the bf16 MFMA (inputs rounded to bf16, fp32 accumulate):
+                                       edge kernels (EqdEdgeParams.bf16), node-level Linears and their weight gradients
+                                       (EqdLinJob.bf16, EqdAtbJob.bf16), attention (eqd_cross_attention_*_bf16); default 0 */
 } EqdModelDesc;
 
 /* Parameter table: device pointers in this fixed order.  Per layer i (base = 19*i):
@@ -178,6 +180,9 @@ typedef struct EqdLinJob {
     const float* R; int32_t ldr;
     float alpha, beta, slope, ln_eps;
     float* Y; int32_t ldy;
+    int32_t bf16;   /* 1: the products run on v_mfma_f32_16x16x16_bf16 (X and W rounded to bf16 when the MFMA operands are
+                       formed, fp32 accumulate; bias, activation, LayerNorm, residual fp32).  One mode per eqd_linear call
+                       (the first job's). */
 } EqdLinJob;
 int eqd_linear(const EqdLinJob* jobs /* host */, int njobs, void* stream);
 
@@ -191,6 +196,7 @@ typedef struct EqdAtbJob {
     float* bias_out;
     float slope;
     float scale;   /* multiplier applied to both results; 0 means 1 */
+    int32_t bf16;  /* 1: X^T Y on the bf16 MFMA (inputs rounded, fp32 accumulate); column sums stay fp32 */
 } EqdAtbJob;
 size_t eqd_atb_partial_bytes(const EqdAtbJob* jobs /* host */, int njobs);
 int eqd_atb(const EqdAtbJob* jobs /* host */, int njobs, void* partial, size_t partial_bytes, void* stream);

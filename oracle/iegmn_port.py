@@ -66,13 +66,15 @@ def _lrelu(x, slope):
 
 class Bf16Mode:
     """Rounding points of the HIP path's bf16 mode (`hip_storage_dtype='bf16'`), restated so that the
-    whole model can be held to a tight tolerance in that mode too: GEMM INPUTS are rounded to bf16 (round to nearest
-    even), products are accumulated in fp32, everything else (coordinates, RBFs before the GEMM, LayerNorm statistics,
-    softmax, biases, Kabsch) stays fp32 - i.e. the arithmetic of v_mfma_f32_16x16x16_bf16.  Rounding is the identity for
+    whole model can be held to a tight tolerance in that mode too: the INPUTS of every GEMM of the IEGMN layers are rounded
+    to bf16 (round to nearest even), products are accumulated in fp32, everything else (coordinates, RBFs before the GEMM,
+    biases, LeakyReLU, LayerNorm, softmax, residuals, the keypoint head and Kabsch) stays fp32 - i.e. the arithmetic of
+    v_mfma_f32_16x16x16_bf16.  Rounded: the edge MLPs (first Linear split into node terms P[src] + Q[dst] plus a GEMM
+    over [he, rbf]; W2 and Wc1 GEMMs), the node-level Linears (P / Q, att_mlp_Q / K / V, node_mlp.0 / .4,
+    mlp_h_mean_ROT) and the attention contractions (q k^T and softmax-weights x v).  Rounding is the identity for
     autograd (the kernels' backward GEMMs round their own operands, which a CPU autograd cannot mirror: gradients are
-    compared at bf16 resolution).  `edge`: the edge-message MLPs (first Linear split into fp32 node terms P[src] + Q[dst]
-    plus a bf16 GEMM over [he, rbf]; W2 and Wc1 GEMMs with bf16 inputs).  Not a reference option."""
-    edge = False
+    compared at bf16 resolution).  Not a reference option."""
+    on = False
 
 
 def rb16(t):
@@ -84,8 +86,8 @@ def _edge_mlps_bf16(sd, pfx, slope, h, src, dst, he, rbf):
     """edge_mlp + coors_mlp of one edge type with the bf16 mode's rounding points (see Bf16Mode)."""
     W1, b1 = sd[pfx + 'edge_mlp.0.weight'], sd[pfx + 'edge_mlp.0.bias']
     d = h.shape[1]
-    Pn = F.linear(h, W1[:, :d])
-    Qn = F.linear(h, W1[:, d:2 * d], b1)
+    Pn = F.linear(rb16(h), rb16(W1[:, :d]))
+    Qn = F.linear(rb16(h), rb16(W1[:, d:2 * d]), b1)
     z1 = Pn[src] + Qn[dst] + rb16(torch.cat([he, rbf], 1)) @ rb16(W1[:, 2 * d:]).t()
     a1 = F.layer_norm(_lrelu(z1, slope), (z1.shape[1],), sd[pfx + 'edge_mlp.3.weight'], sd[pfx + 'edge_mlp.3.bias'], 1e-5)
     msg = rb16(a1) @ rb16(sd[pfx + 'edge_mlp.4.weight']).t() + sd[pfx + 'edge_mlp.4.bias']
@@ -94,16 +96,23 @@ def _edge_mlps_bf16(sd, pfx, slope, h, src, dst, he, rbf):
     return msg, coef
 
 
+def _lin(x, W, b=None):
+    """nn.Linear; in Bf16Mode its two GEMM inputs are rounded to bf16."""
+    if Bf16Mode.on:
+        return F.linear(rb16(x), rb16(W), b)
+    return F.linear(x, W, b)
+
+
 def _mlp5(x, sd, prefix, slope, norm):
     """Linear -> Dropout(p=0) -> LeakyReLU -> LayerNorm/Identity -> Linear
     (edge_mlp :119-125, node_mlp :142-148, coors_mlp :153-159)."""
-    y = F.linear(x, sd[prefix + '.0.weight'], sd[prefix + '.0.bias'])
+    y = _lin(x, sd[prefix + '.0.weight'], sd[prefix + '.0.bias'])
     y = _lrelu(y, slope)
     if norm == 'LN':
         y = F.layer_norm(y, (y.shape[-1],), sd[prefix + '.3.weight'], sd[prefix + '.3.bias'], 1e-5)
     else:
         assert norm == '0'
-    return F.linear(y, sd[prefix + '.4.weight'], sd[prefix + '.4.bias'])
+    return _lin(y, sd[prefix + '.4.weight'], sd[prefix + '.4.bias'])
 
 
 def get_mask(lig_counts, rec_counts):
@@ -117,8 +126,21 @@ def get_mask(lig_counts, rec_counts):
     return mask
 
 
+def _softmax_v_bf16(a, v):
+    """softmax(a) @ v with the bf16 mode's rounding point: the un-normalised weights 2^(a log2 e - M), M = ceil of the row
+    maximum in log2 units (an integer, so that any power-of-two rescaling - the kernels' online softmax - rounds to the same
+    bf16 values), and v are rounded; the normaliser is the fp32 sum of the UNROUNDED weights."""
+    a2 = a * 1.44269504088896341
+    M = torch.ceil(a2.max(dim=1, keepdim=True).values).detach()
+    e = torch.exp2(a2 - M)
+    return torch.mm(rb16(e), rb16(v)) / e.sum(dim=1, keepdim=True)
+
+
 def cross_attention_dense(q, k, v, mask):
     """src/model/rigid_docking_model.py:46-64 (no 1/sqrt(d), single head, -1000 fill)."""
+    if Bf16Mode.on:
+        a = mask * torch.mm(rb16(q), rb16(k).t()) - 1000. * (1. - mask)
+        return _softmax_v_bf16(a, v)
     a = mask * torch.mm(q, k.t()) - 1000. * (1. - mask)
     return torch.mm(torch.softmax(a, dim=1), v)
 
@@ -127,8 +149,12 @@ def cross_attention_blockdiag(q, k, v, q_counts, k_counts):
     """Per-pair softmax: what the reference computes whenever in-pair logits are not < -900."""
     outs, qo, ko = [], 0, 0
     for nq, nk in zip(q_counts, k_counts):
-        a = torch.mm(q[qo:qo + nq], k[ko:ko + nk].t())
-        outs.append(torch.mm(torch.softmax(a, dim=1), v[ko:ko + nk]))
+        if Bf16Mode.on:
+            a = torch.mm(rb16(q[qo:qo + nq]), rb16(k[ko:ko + nk]).t())
+            outs.append(_softmax_v_bf16(a, v[ko:ko + nk]))
+        else:
+            a = torch.mm(q[qo:qo + nq], k[ko:ko + nk].t())
+            outs.append(torch.mm(torch.softmax(a, dim=1), v[ko:ko + nk]))
         qo += nq
         ko += nk
     return torch.cat(outs, 0)
@@ -155,7 +181,7 @@ def iegmn_layer(sd, pfx, args, d_in, raw, x_l, h_l, h0_l, he_l, x0_l, x_r, h_r, 
         rbf = torch.cat([torch.exp(-d2 / s) for s in RBF_SIGMAS], dim=-1)    # :210
         if not args['use_dist_in_layers']:
             rbf = rbf * 0.                                                   # :216-218
-        if Bf16Mode.edge:
+        if Bf16Mode.on:
             msg, coef = _edge_mlps_bf16(sd, pfx, slope, h, src, dst, he, rbf)
         else:
             cat = torch.cat([h[src], h[dst], he, rbf], dim=-1)               # :226-234
@@ -166,9 +192,9 @@ def iegmn_layer(sd, pfx, args, d_in, raw, x_l, h_l, h0_l, he_l, x0_l, x_r, h_r, 
                           aggr_msg=_mean_by_dst(msg, dst, n))                # :280-283
 
     def qkv(h):
-        q = _lrelu(F.linear(h, sd[pfx + 'att_mlp_Q.0.weight']), slope)       # :130-133
-        k = _lrelu(F.linear(h, sd[pfx + 'att_mlp_K.0.weight']), slope)       # :134-137
-        v = F.linear(h, sd[pfx + 'att_mlp_V.0.weight'])                      # :138-140
+        q = _lrelu(_lin(h, sd[pfx + 'att_mlp_Q.0.weight']), slope)           # :130-133
+        k = _lrelu(_lin(h, sd[pfx + 'att_mlp_K.0.weight']), slope)           # :134-137
+        v = _lin(h, sd[pfx + 'att_mlp_V.0.weight'])                          # :138-140
         return q, k, v
     ql, kl, vl = qkv(h_l)
     qr, kr, vr = qkv(h_r)
@@ -266,8 +292,8 @@ def forward(sd, args, raw, faithful=True, prefix='iegmn_original.', rand_fn=None
     for nl, nr in zip(raw['lig_counts'], raw['rec_counts']):                 # :521-600
         H_r, H_l = h_r[ro:ro + nr], h_l[lo:lo + nl]
         Z_r, Z_l = x_r[ro:ro + nr], x_l[lo:lo + nl]
-        q_r = _lrelu(F.linear(H_r, Wm, bm), slope).mean(0, keepdim=True)     # :524-525
-        q_l = _lrelu(F.linear(H_l, Wm, bm), slope).mean(0, keepdim=True)     # :528-529
+        q_r = _lrelu(_lin(H_r, Wm, bm), slope).mean(0, keepdim=True)         # :524-525
+        q_l = _lrelu(_lin(H_l, Wm, bm), slope).mean(0, keepdim=True)         # :528-529
         att_r = torch.softmax(
             F.linear(H_r, Wk).view(-1, K, d).transpose(0, 1) @
             F.linear(q_l, Wq).view(1, K, d).transpose(0, 1).transpose(1, 2) / math.sqrt(d),

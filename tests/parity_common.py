@@ -59,13 +59,20 @@ def grad_close(got, ref, what='', l2=1e-3, mx=1e-2):
     assert e2 <= l2 and em <= mx, f'{what}: rel-L2 {e2:.3e} (<= {l2}), max-abs/max {em:.3e} (<= {mx})'
 
 
-# bf16 mode (hip_storage_dtype='bf16') against the oracle evaluated with the SAME rounding points (oracle.iegmn_port.Bf16Mode):
-# outputs to 1e-2 of their scale - 3.1e-3 measured at config C, where the flips compound over 8 layers (an input that differs by one fp32 ulp between the two evaluations can round to the OTHER
-# bf16 neighbour, a 2^-9 relative step on one of a dot product's inputs; measured 5e-4 .. 8e-4 on small batches, against
-# 1.5e-2 when compared with the fp32 result); gradients to 1 % rel-L2 / 3 % max-abs - the kernels' backward GEMMs round
-# their own operands to bf16, which the oracle's fp32 autograd of the rounded forward does not mirror (measured 1.2e-3 ..
-# 3.3e-3 / 4.7e-3 .. 1.0e-2).  The previous bounds against the fp32 golden vectors were 3e-2 / 0.2 / 0.5.
-BF16_OUT_TOL, BF16_GRAD_L2, BF16_GRAD_MX = 1e-2, 2e-2, 6e-2
+# bf16 mode (hip_storage_dtype='bf16': every GEMM of the IEGMN layers on the bf16 MFMA) against the oracle evaluated with the
+# SAME rounding points (oracle.iegmn_port.Bf16Mode).  Per OPERATOR the agreement is fp32-summation-order tight (linear 2e-6,
+# A^T B 2e-5, attention 2e-5, edge messages 5e-5: check_linear_atb_bf16, check_attention_bf16, check_edge_bf16).  The
+# WHOLE model cannot be: a value that differs by one fp32 ulp between two evaluations can round to the OTHER bf16 neighbour
+# (a 2^-9 relative step), a few hundred such flips per layer put 4e-3 of noise on the last layer's h whatever the
+# implementation - the oracle ALONE moves by that much when its weights are perturbed by 1e-6 - and the keypoint softmax
+# (sharp by construction: its key / query weights are scaled x40 to keep the SVD guard silent)
+# amplifies it 18-fold (oracle alone: 1.6 % .. 6.6 % on the outputs).  The whole-model bf16 comparison therefore runs with
+# that scale at 10 (guard still silent, amplification ~1.3), where HIP and oracle agree to 3e-4 .. 5e-3 on the outputs and
+# 0.8 % .. 2.8 % rel-L2 on the gradients (the kernels' backward GEMMs round their own operands, which the oracle's fp32
+# autograd of the rounded forward does not mirror).  Bounds: 2e-2 / 6e-2 / 1.2e-1 (the previous round compared against the
+# fp32 golden vectors at 3e-2 / 0.2 / 0.5).
+BF16_OUT_TOL, BF16_GRAD_L2, BF16_GRAD_MX = 2e-2, 6e-2, 1.2e-1
+BF16_ROT_SCALE = 10.0
 
 
 def oracle_reference(sd, args, raw, faithful=True, loss_fn=None, kink_aware=True):
@@ -123,18 +130,18 @@ def grad_close_hull(got, ref, lo, hi, what='', l2=GRAD_L2, mx=GRAD_MX):
 
 
 def check_model_vs_oracle(dev, sizes, layers=8, seed=3, pair_seed=33, faithful=True, what='', args_over=None,
-                          l2=GRAD_L2, mx=GRAD_MX, tol=1e-4, report=None, bf16=False):
+                          l2=GRAD_L2, mx=GRAD_MX, tol=1e-4, report=None, bf16=False, rot_scale=40.0):
     """Whole model (outputs + every parameter gradient of the fixed scalar loss) on seeded synthetic pairs of the given
     sizes against the oracle on the host; gradients kink-aware (oracle_reference).  bf16=True: the HIP path in its bf16
     mode against the oracle with the same rounding points."""
     args = port.default_args(**dict(dict(iegmn_n_lays=layers, skip_weight_h=0.75), **(args_over or {})))
-    sd = port.init_state_dict(args, seed=seed)
+    sd = port.init_state_dict(args, seed=seed, rot_scale=rot_scale)
     net = build_model(dict(args, hip_storage_dtype='bf16') if bf16 else args, sd, dev)
-    port.Bf16Mode.edge = bool(bf16)
+    port.Bf16Mode.on = bool(bf16)
     try:
         return _check_model_vs_oracle(dev, net, args, sd, sizes, layers, pair_seed, faithful, what, l2, mx, tol, report)
     finally:
-        port.Bf16Mode.edge = False
+        port.Bf16Mode.on = False
 
 
 def _check_model_vs_oracle(dev, net, args, sd, sizes, layers, pair_seed, faithful, what, l2, mx, tol, report):
@@ -603,22 +610,22 @@ def check_model_case(dev, name, check_grads=True):
 
 def check_model_bf16(dev, name):
     """hip_storage_dtype='bf16' on a golden case's inputs against the oracle evaluated with the same rounding points
-    (oracle.iegmn_port.Bf16Mode) at BF16_OUT_TOL / BF16_GRAD_*; and, loosely, against the fp32 golden outputs (3 %)."""
+    (oracle.iegmn_port.Bf16Mode) at BF16_OUT_TOL / BF16_GRAD_* (see there for why the ROT scale is 10 in bf16 comparisons)."""
     z, meta, args, raw = load_case(name)
-    sd = state_dict_for(meta, args)
+    sd = port.init_state_dict(args, meta['seed'], BF16_ROT_SCALE)      # the case's inputs, its weights with ROT scale 10
     net = build_model(dict(args, hip_storage_dtype='bf16'), sd, dev)
     g = G.batch_pairs(pairs_from_raw(raw)).to(dev)
     outs = net(g, epoch=0)
     port.scalar_loss(outs).backward()
     sync(dev)
-    port.Bf16Mode.edge = True
+    assert net.iegmn_original.last_svd_status.cpu().tolist() == [0] * len(raw['lig_counts'])
+    port.Bf16Mode.on = True
     try:
         ref, grads, lo, hi, _ = oracle_reference(sd, args, raw, faithful=True)
     finally:
-        port.Bf16Mode.edge = False
+        port.Bf16Mode.on = False
     for nm, a, b in zip(('lig', 'Yl', 'Yr', 'T', 'b'), outs, ref):
         close(cat_out(a), cat_out(b), tol=BF16_OUT_TOL, what=f'{name} bf16 {nm} vs bf16 oracle')
-        close(cat_out(a), torch.from_numpy(z['out_' + nm]), tol=3e-2, what=f'{name} bf16 {nm} vs fp32 golden')
     for k, p in net.named_parameters():
         grad_close_hull(p.grad, grads[k], lo[k], hi[k], what=f'{name} bf16 grad {k}', l2=BF16_GRAD_L2, mx=BF16_GRAD_MX)
 
@@ -1034,12 +1041,11 @@ def check_attention_bf16(dev, d, sizes=((70, 45), (33, 101))):
     for a, b in zip(pk.lig_counts, pk.rec_counts):
         L0, L1, R0, R1 = lo, lo + a, nl + ro, nl + ro + b
         for (q0, q1, k0, k1), acc in (((L0, L1, R0, R1), o_l), ((R0, R1, L0, L1), o_r)):
-            pr = torch.softmax(port.rb16(ql[q0:q1]) @ port.rb16(kl[k0:k1]).t(), 1)
-            acc.append(port.rb16(pr) @ port.rb16(vl[k0:k1]))
+            acc.append(port._softmax_v_bf16(port.rb16(ql[q0:q1]) @ port.rb16(kl[k0:k1]).t(), vl[k0:k1]))
         lo += a
         ro += b
     ref = torch.cat(o_l + o_r, 0)
-    close(out, ref, tol=6e-3, what=f'bf16 attention out d={d}')
+    close(out, ref, tol=2e-5, what=f'bf16 attention out d={d}')       # same rounding points: fp32 summation order only
     do = torch.randn(N, d)
     if d == 80:
         do[:, 69:] = 0
@@ -1052,3 +1058,60 @@ def check_attention_bf16(dev, d, sizes=((70, 45), (33, 101))):
     sync(dev)
     for n, a, b in (('dq', dq, ql.grad), ('dk', dk, kl.grad), ('dv', dv, vl.grad)):
         grad_close(a, b, what=f'bf16 attention {n} d={d}', l2=1e-2, mx=3e-2)
+
+
+def check_linear_atb_bf16(dev):
+    """bf16 mode of the node-level GEMMs (EqdLinJob.bf16 / EqdAtbJob.bf16: inputs rounded to bf16 when the MFMA operands
+    are formed, fp32 accumulate) against torch with the same rounding points: fp32 summation order only."""
+    torch.manual_seed(0)
+    for rows, K1, K2, Mo in ((77, 69, 64, 69), (77, 64, 64, 64), (40, 64, 69, 64)):
+        X1, X2 = torch.randn(rows, K1), torch.randn(rows, K2)
+        W, b = torch.randn(Mo, K1 + K2) * 0.2, torch.randn(Mo)
+        g_, be = torch.randn(Mo), torch.randn(Mo)
+        d = [t.to(dev) for t in (X1, X2, W, b, g_, be)]
+        Y, pre = torch.zeros(rows, Mo, device=dev), torch.zeros(rows, Mo, device=dev)
+        J = L.EqdLinJob()
+        J.nsrc = 2
+        for i, (X, K, off) in enumerate(((d[0], K1, 0), (d[1], K2, K1))):
+            J.s[i].X, J.s[i].W, J.s[i].ldx, J.s[i].K = X.data_ptr(), d[2].data_ptr() + 4 * off, K, K
+            J.s[i].w_rs, J.s[i].w_cs = K1 + K2, 1
+        J.M, J.act, J.rows, J.bias = Mo, 1, rows, d[3].data_ptr()
+        J.ln_g, J.ln_b, J.pre_ln, J.ld_pre = d[4].data_ptr(), d[5].data_ptr(), pre.data_ptr(), Mo
+        J.alpha, J.beta, J.slope, J.ln_eps = 1.0, 0.0, 0.01, 1e-5
+        J.Y, J.ldy, J.bf16 = Y.data_ptr(), Mo, 1
+        L.check(lib().eqd_linear(C.byref(J), 1, st(dev)))
+        sync(dev)
+        z = F.leaky_relu(port.rb16(torch.cat([X1, X2], 1)) @ port.rb16(W).t() + b, 0.01)
+        close(pre, z, tol=1e-5, what='bf16 linear pre-LN')
+        close(Y, F.layer_norm(z, (Mo,), g_, be, 1e-5), tol=2e-5, what='bf16 linear + LN')
+        z32 = F.leaky_relu(torch.cat([X1, X2], 1) @ W.t() + b, 0.01)
+        assert float((pre.cpu() - z32).abs().max()) > 1e-4, 'bf16 mode did not round anything'
+    for rows, masked in ((333, True), (64 * 40 + 1, False)):
+        Xc, Yc, mc = torch.randn(rows, 64), torch.randn(rows, 128), torch.randn(rows, 64)
+        outc, boc = torch.zeros(128, 64, device=dev), torch.zeros(64, device=dev)
+        Xcd, Ycd, mcd = Xc.to(dev), Yc.to(dev), mc.to(dev)
+        Cj = L.EqdAtbJob()
+        Cj.X, Cj.ldx, Cj.M, Cj.Y, Cj.ldy, Cj.N = Xcd.data_ptr(), 64, 64, Ycd.data_ptr(), 128, 128
+        Cj.xmask = mcd.data_ptr() if masked else None
+        Cj.rows, Cj.out, Cj.o_rs, Cj.o_cs, Cj.slope, Cj.scale = rows, outc.data_ptr(), 1, 64, 0.01, 1.0
+        Cj.bias_out, Cj.bf16 = boc.data_ptr(), 1
+        nb = lib().eqd_atb_partial_bytes(C.byref(Cj), 1)
+        part = torch.zeros(nb // 4 + 64, device=dev)
+        L.check(lib().eqd_atb(C.byref(Cj), 1, P(part), C.c_size_t(nb), st(dev)))
+        sync(dev)
+        Xe = Xc * torch.where(mc > 0, 1.0, 0.01) if masked else Xc
+        close(outc, (port.rb16(Xe).t() @ port.rb16(Yc)).t(), tol=2e-5, what=f'bf16 A^T B rows={rows}')
+        close(boc, Xe.sum(0), tol=2e-4, what='bf16 A^T B: column sums stay fp32')
+    # general (non-aligned) A^T B path
+    rows = 500
+    Xa, Ya = torch.randn(rows, 69), torch.randn(rows, 271)
+    out = torch.zeros(69, 271, device=dev)
+    Xd, Yd = Xa.to(dev), Ya.to(dev)
+    A = L.EqdAtbJob()
+    A.X, A.ldx, A.M, A.Y, A.ldy, A.N = Xd.data_ptr(), 69, 69, Yd.data_ptr(), 271, 271
+    A.rows, A.out, A.o_rs, A.o_cs, A.slope, A.scale, A.bf16 = rows, out.data_ptr(), 271, 1, 0.01, 1.0, 1
+    nb = lib().eqd_atb_partial_bytes(C.byref(A), 1)
+    part = torch.zeros(nb // 4 + 64, device=dev)
+    L.check(lib().eqd_atb(C.byref(A), 1, P(part), C.c_size_t(nb), st(dev)))
+    sync(dev)
+    close(out, port.rb16(Xa).t() @ port.rb16(Ya), tol=2e-5, what='bf16 A^T B, general path')

@@ -167,6 +167,11 @@ def test_cross_attention_bf16(dev, d):
     pc.check_attention_bf16(dev, d, sizes=((300, 257), (129, 64)))
 
 
+def test_linear_atb_bf16(dev):
+    from tests import parity_common as pc
+    pc.check_linear_atb_bf16(dev)
+
+
 def test_scalar_loss(dev):
     from tests import parity_common as pc
     pc.check_scalar_loss(dev)
@@ -226,7 +231,8 @@ def test_model_vs_oracle_config_c_bf16(dev):
     evaluated with the bf16 mode's rounding points (tests/parity_common.py: BF16_OUT_TOL, BF16_GRAD_*)."""
     from tests import parity_common as pc
     pc.check_model_vs_oracle(dev, [(300, 300)] * 64, layers=8, seed=3, pair_seed=34, faithful=False, what='config C bf16',
-                             report=REPORT, bf16=True, tol=pc.BF16_OUT_TOL, l2=pc.BF16_GRAD_L2, mx=pc.BF16_GRAD_MX)
+                             report=REPORT, bf16=True, tol=pc.BF16_OUT_TOL, l2=pc.BF16_GRAD_L2, mx=pc.BF16_GRAD_MX,
+                             rot_scale=pc.BF16_ROT_SCALE)
 
 
 def test_model_vs_oracle_config_e(dev):

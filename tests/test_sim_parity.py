@@ -134,6 +134,10 @@ def test_cross_attention_bf16(d):
     pc.check_attention_bf16(DEV, d)
 
 
+def test_linear_atb_bf16():
+    pc.check_linear_atb_bf16(DEV)
+
+
 def test_scalar_loss():
     pc.check_scalar_loss(DEV)
 
