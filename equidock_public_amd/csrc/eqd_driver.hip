@@ -246,6 +246,32 @@ extern "C" size_t eqd_model_scratch_bytes(const EqdModelDesc* m, const EqdGraph*
     return bwd > sv ? bwd : sv;
 }
 
+// Debug / test aid: where the state after `layer` layers (0 = the embedding) lives inside a forward's `saved` buffer.
+extern "C" int eqd_model_layer_state(const EqdModelDesc* m, const EqdGraph* g, const void* saved, size_t saved_bytes,
+                                     int layer, const float** h, int* h_width, const float** x) {
+    if (int rc = eqd_model_check(m, g)) return rc;
+    if (!saved || !h || !h_width || !x) {
+        eqd_set_error("eqd_model_layer_state: NULL argument");
+        return EQD_ERR_NULL;
+    }
+    const Dims D = make_dims(m, g);
+    if (layer < 0 || layer > D.L) {
+        eqd_set_error("eqd_model_layer_state: layer %d outside 0..%d", layer, D.L);
+        return EQD_ERR_SHAPE;
+    }
+    EqdArena A(const_cast<void*>(saved), saved_bytes);
+    Saved S;
+    carve_saved(D, g, A, S);
+    if (!A.ok) {
+        eqd_set_error("eqd_model_layer_state: saved buffer too small");
+        return EQD_ERR_WORKSPACE;
+    }
+    *h = S.h[layer];
+    *h_width = layer == 0 ? D.d0 : D.dh;
+    *x = S.x[layer];
+    return EQD_OK;
+}
+
 // ---- execution context: auxiliary streams + events -----------------------------------------------------
 struct EqdCtx {
     hipStream_t sa;              // attention branch of the forward (runs beside the edge-message kernel)

@@ -224,6 +224,7 @@ class _IEGMNFunction(torch.autograd.Function):
                 C.byref(desc), C.byref(gs), ptrs, _lib.ptr(svd_draws), _lib.ptr(lig), _lib.ptr(Yl), _lib.ptr(Yr),
                 _lib.ptr(T), _lib.ptr(b), _lib.ptr(status), _lib.ptr(saved), C.c_size_t(sb if need_grad else 0),
                 _lib.ptr(scratch), C.c_size_t(0 if need_grad else wb), _lib.stream_ptr(dev), _lib.exec_ctx(dev)))
+        packed._last_saved = (saved, sb) if need_grad else None     # for IEGMN.layer_state (tests); freed with the batch
         ctx.packed, ctx.desc, ctx.table_idx, ctx.saved, ctx.sb, ctx.wb = packed, desc, table_idx, saved, sb, wb
         ctx.tensors, ctx.ptrs = tensors, ptrs
         ctx.flat_state = flat_state
@@ -468,6 +469,30 @@ class IEGMN(nn.Module):
                                                              need_grad, None, *uniq)
         self.last_svd_status = status
         return packed, lig, Yl, Yr, T, b
+
+    def layer_state(self, batch_hetero_graph, layer):
+        """(h [n_nodes, width], x [n_nodes, 3]) after `layer` layers of the LAST forward of this batch that kept its state
+        (a forward with gradients enabled): ligand nodes first, then receptor nodes - what the reference keeps as
+        'hv_iegmn_out' / 'x_iegmn_out' for layer == n_lays (rigid_docking_model.py:507-510).  Copies; a test / debug aid."""
+        packed = batch_hetero_graph.pack()
+        last = getattr(packed, '_last_saved', None)
+        if last is None:
+            raise _lib.EquidockHipError("no saved forward state for this batch (run a forward with gradients enabled)")
+        saved, sb = last
+        lib = _lib.load_library()
+        desc, gs = self._desc(), packed.c_struct()
+        hp, xp, w = C.c_void_p(), C.c_void_p(), C.c_int(0)
+        _lib.check(lib.eqd_model_layer_state(C.byref(desc), C.byref(gs), _lib.ptr(saved), C.c_size_t(sb), int(layer),
+                                             C.byref(hp), C.byref(w), C.byref(xp)))
+        n = packed.n_nodes
+        base = saved.data_ptr()
+        f = saved.view(torch.float32) if saved.numel() % 4 == 0 else saved[:saved.numel() // 4 * 4].view(torch.float32)
+        h = f[(hp.value - base) // 4:(hp.value - base) // 4 + n * w.value].view(n, w.value).clone()
+        if layer == 0:
+            x = packed.x0.clone()
+        else:
+            x = f[(xp.value - base) // 4:(xp.value - base) // 4 + n * 3].view(n, 3).clone()
+        return h, x
 
     def uses_hip_path(self):
         """The published family runs in the HIP library; other reference options (and dropout > 0 while training) run

@@ -136,6 +136,12 @@ size_t eqd_model_saved_bytes(const EqdModelDesc* m, const EqdGraph* g);    /* fo
 size_t eqd_model_scratch_bytes(const EqdModelDesc* m, const EqdGraph* g);  /* transient, either pass */
 int eqd_model_check(const EqdModelDesc* m, const EqdGraph* g);
 
+/* Test / debug aid: pointers to the node features h [n_nodes][*h_width] and coordinates x [n_nodes][3] after `layer`
+ * layers (0 = embedding output and input coordinates, n_layers = what the keypoint head consumes; the reference stores the
+ * latter as 'hv_iegmn_out' / 'x_iegmn_out', rigid_docking_model.py:507-510) inside the `saved` buffer of a forward. */
+int eqd_model_layer_state(const EqdModelDesc* m, const EqdGraph* g, const void* saved, size_t saved_bytes, int layer,
+                          const float** h, int* h_width, const float** x);
+
 /* Rigid_Body_Docking_Net.forward (rigid_docking_model.py:642-692) for the single-stage model:
  * embedding + L IEGMN layers + keypoint attention + Kabsch + rigid apply.
  * Outputs: lig_out [n_lig][3], Y_lig / Y_rec [n_pairs][n_heads][3], T [n_pairs][9], b [n_pairs][3],

@@ -138,6 +138,10 @@ def test_linear_atb_bf16():
     pc.check_linear_atb_bf16(DEV)
 
 
+def test_model_bf16_layer_states():
+    pc.check_model_bf16_states(DEV, [(60, 75), (90, 48), (120, 100)], layers=4, seed=5, pair_seed=7, faithful=True, what='sim')
+
+
 def test_scalar_loss():
     pc.check_scalar_loss(DEV)
 
