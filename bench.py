@@ -259,11 +259,14 @@ def edge_kernel_rooflines(net, packed, dev, workload='B', bf16=False):
     # HBM bytes per launch from the committed PMC passes (profiles/r01_traffic.json; counters cannot be read
     # from inside the process): (2 * FETCH_SIZE + WRITE_SIZE) KB, see the file's comment for the correction
     try:
-        tr = {} if bf16 else json.load(open(os.path.join(ROOT, 'profiles', 'r01_traffic.json'))).get(workload, {})
+        import glob
+        files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*traffic.json')))      # newest round last
+        tr = {} if (bf16 or not files) else json.load(open(files[-1])).get(workload, {})
         for k, v in tr.items():
             if k in out:
                 out[k]['traffic'] = int((2 * v['FETCH_SIZE_KB'] + v['WRITE_SIZE_KB']) * 1024)
-                out[k]['traffic_source'] = 'profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)'
+                out[k]['traffic_source'] = (f'profiles/{os.path.basename(files[-1])} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
+                                            'separate passes)')
     except Exception:
         pass
     return out

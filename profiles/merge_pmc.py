@@ -1,0 +1,59 @@
+"""Merge the per-counter JSONs written by `profiles/measure_r02.sh TAG pmc` (rocprofv3 --kernel-trace --pmc <counter>, one
+counter per pass, averaged per kernel by profiles/pmcstats.py) into the two summaries bench.py reads:
+  profiles/<TAG>_pmc_mfma.json   per workload and kernel: MfmaUtil (%), executed MFMA FLOPs per launch
+  profiles/<TAG>_traffic.json    per workload and kernel family: FETCH_SIZE_KB, WRITE_SIZE_KB per launch
+usage: python profiles/merge_pmc.py TAG [dir=gpurun_out]"""
+import json, os, sys
+
+tag = sys.argv[1]
+src = sys.argv[2] if len(sys.argv) > 2 else 'gpurun_out'
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FAM = ('k_edge_attn_fwd', 'k_edge_fwd', 'k_edge_bwd', 'k_attn_fwd', 'k_attn_bwd', 'k_rowchain', 'k_linear', 'k_atb_reduce', 'k_atb',
+       'k_node_gather')
+
+
+def load(w, cnt):
+    f = os.path.join(root, src, f'{tag}_pmc_{w}_{cnt}.json')
+    try:
+        txt = open(f).read()
+        return json.loads(txt[txt.index('{'):])
+    except Exception:
+        return {}
+
+
+mfma = {'_comment': "rocprofv3 --kernel-trace --pmc <counter> -- python bench.py --eager --workload W --steps 3 --warmup 1 (one counter per "
+                    "pass, profiles/measure_r02.sh pmc), averaged over the dispatches of each kernel.  MfmaUtil in %, measured while the "
+                    "counters serialise the kernels; executed MFMA FLOP = SQ_INSTS_VALU_MFMA_MOPS_F32 x 512."}
+traffic = {'_comment': "FETCH_SIZE / WRITE_SIZE in KB per launch from separate rocprofv3 --pmc passes (summed over counter instances, "
+                       "averaged over dispatches, dispatch-weighted over the template variants of a kernel family).  bench.py reports "
+                       "traffic = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 bytes: FETCH_SIZE counts 128-B requests as 64 B on gfx950 "
+                       "(MI355X_MICROARCH.md, HBM section) - an upper bound on the fetch side for mixed access sizes."}
+for w in ('B', 'C', 'E'):
+    mu, mops = load(w, 'MfmaUtil'), load(w, 'SQ_INSTS_VALU_MFMA_MOPS_F32')
+    if mu:
+        mfma[w] = {}
+        for k, v in mu.items():
+            e = {'MfmaUtil': round(v['MfmaUtil']['avg'], 1) if 'MfmaUtil' in v else None}
+            mo = mops.get(k, {}).get('SQ_INSTS_VALU_MFMA_MOPS_F32')
+            if mo:
+                e['SQ_INSTS_VALU_MFMA_MOPS_F32'] = mo['avg']
+                e['executed_mfma_gflop_per_launch'] = round(mo['avg'] * 512 / 1e9, 3)
+            mfma[w][k] = e
+    fe, wr = load(w, 'FETCH_SIZE'), load(w, 'WRITE_SIZE')
+    if fe:
+        traffic[w] = {}
+        for fam in FAM:
+            tot = {'FETCH_SIZE': [0.0, 0], 'WRITE_SIZE': [0.0, 0]}
+            for cnt, d in (('FETCH_SIZE', fe), ('WRITE_SIZE', wr)):
+                for k, v in d.items():
+                    owner = next((f for f in FAM if f in k), None)      # first family whose name is contained (longest first)
+                    if owner == fam and cnt in v:
+                        tot[cnt][0] += v[cnt]['avg'] * v[cnt]['n']
+                        tot[cnt][1] += v[cnt]['n']
+            if tot['FETCH_SIZE'][1]:
+                traffic[w][fam] = {'FETCH_SIZE_KB': round(tot['FETCH_SIZE'][0] / tot['FETCH_SIZE'][1], 1),
+                                   'WRITE_SIZE_KB': round(tot['WRITE_SIZE'][0] / max(1, tot['WRITE_SIZE'][1]), 1),
+                                   'dispatches': tot['FETCH_SIZE'][1]}
+json.dump(mfma, open(os.path.join(root, 'profiles', f'{tag}_pmc_mfma.json'), 'w'), indent=1)
+json.dump(traffic, open(os.path.join(root, 'profiles', f'{tag}_traffic.json'), 'w'), indent=1)
+print('written', [k for k in mfma if not k.startswith('_')], [k for k in traffic if not k.startswith('_')])
