@@ -1155,37 +1155,72 @@ __global__ __launch_bounds__(256) void k_node_gather(const int32_t* __restrict__
     if (j >= n) return;
     const int s0 = csc_ptr[j], s1 = csc_ptr[j + 1];
     const int d0 = rowptr[j], d1 = rowptr[j + 1];
+    const int nout = s1 - s0, nin = d1 - d0;
     float sp = 0.f, sq = 0.f, sx = 0.f;
-    // batches of 8 edges: all indices, then all rows, are in flight together (2 dependent round trips per
-    // batch instead of 2 per edge)
-    for (int q0 = s0; q0 < s1; q0 += 8) {
+    // First 16 edges of both directions in TWO dependent round trips: the 16 by-source edge ids (CSC) and the 16
+    // by-destination rows (CSR: consecutive edge ids, no index needed) are issued together, then the 16 by-source rows.
+    // Every load is unconditional on a clamped index and masked afterwards (a predicated load is an exec-masked branch
+    // with its own wait: the previous form was 8 dependent round trips per node at in / out degree 10).  Sums are taken
+    // in edge order, as before.
+    constexpr int GB = 16;
+    if (nout > 0 || nin > 0) {       // (a node without any edge reads nothing: dz may be empty)
+        const int so = nout > 0 ? s0 : 0, no1 = nout > 0 ? nout - 1 : 0;
+        const int di = nin > 0 ? d0 : (nout > 0 ? csc_eid[s0] : 0), ni1 = nin > 0 ? nin - 1 : 0;
+        int e[GB];
+        float vq[GB], wq[GB], vp[GB], wp[GB];
+#pragma unroll
+        for (int i = 0; i < GB; ++i) e[i] = nout > 0 ? csc_eid[so + (i < no1 ? i : no1)] : di;
+#pragma unroll
+        for (int i = 0; i < GB; ++i) {
+            const size_t ee = (size_t)(di + (i < ni1 ? i : ni1));
+            vq[i] = dz[ee * 64 + c];
+            wq[i] = dxrel[ee * 4 + (c & 3)];
+        }
+#pragma unroll
+        for (int i = 0; i < GB; ++i) {
+            vp[i] = dz[(size_t)e[i] * 64 + c];
+            wp[i] = dxrel[(size_t)e[i] * 4 + (c & 3)];
+        }
+#pragma unroll
+        for (int i = 0; i < GB; ++i) {
+            sp += i < nout ? vp[i] : 0.f;
+            sx += (i < nout && c < 3) ? wp[i] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < GB; ++i) {
+            sq += i < nin ? vq[i] : 0.f;
+            sx -= (i < nin && c < 3) ? wq[i] : 0.f;
+        }
+    }
+    // degrees beyond 16 (out-degree is unbounded; in-degree <= 32): the remaining edges, 8 at a time
+    for (int q0 = s0 + GB; q0 < s1; q0 += 8) {
         int e[8];
         float v[8], w[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) e[i] = (q0 + i < s1) ? csc_eid[q0 + i] : -1;
+        for (int i = 0; i < 8; ++i) e[i] = csc_eid[q0 + i < s1 ? q0 + i : s1 - 1];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            v[i] = e[i] >= 0 ? dz[(size_t)e[i] * 64 + c] : 0.f;
-            w[i] = (e[i] >= 0 && c < 3) ? dxrel[(size_t)e[i] * 4 + c] : 0.f;
+            v[i] = dz[(size_t)e[i] * 64 + c];
+            w[i] = dxrel[(size_t)e[i] * 4 + (c & 3)];
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            sp += v[i];
-            sx += w[i];
+            sp += q0 + i < s1 ? v[i] : 0.f;
+            sx += (q0 + i < s1 && c < 3) ? w[i] : 0.f;
         }
     }
-    for (int e0 = d0; e0 < d1; e0 += 8) {
+    for (int e0 = d0 + GB; e0 < d1; e0 += 8) {
         float v[8], w[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const bool ok = e0 + i < d1;
-            v[i] = ok ? dz[(size_t)(e0 + i) * 64 + c] : 0.f;
-            w[i] = (ok && c < 3) ? dxrel[(size_t)(e0 + i) * 4 + c] : 0.f;
+            const size_t ee = (size_t)(e0 + i < d1 ? e0 + i : d1 - 1);
+            v[i] = dz[ee * 64 + c];
+            w[i] = dxrel[ee * 4 + (c & 3)];
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            sq += v[i];
-            sx -= w[i];
+            sq += e0 + i < d1 ? v[i] : 0.f;
+            sx -= (e0 + i < d1 && c < 3) ? w[i] : 0.f;
         }
     }
     dP[(size_t)j * 64 + c] = sp;
