@@ -286,7 +286,8 @@ int eqd_launch_embed_bwd(const EqdGraph* g, const float* dh0, const float* dh0b,
                          float* partial, hipStream_t st, EqdRedList* defer = nullptr);
 size_t eqd_embed_bwd_partial_floats(const EqdGraph* g, int d_emb);
 int eqd_launch_node_gather(const EqdGraph* g, const float* dz, const float* dxrel, const float* d_xnew, float a,
-                           float* dP, float* dQ, float* dx, hipStream_t st, EqdRedList* pending = nullptr);
+                           float* dP, float* dQ, float* dx, hipStream_t st, EqdRedList* pending = nullptr,
+                           bool dz_bf16 = false);
 int eqd_launch_ln_act_bwd(const float* y_act, const float* d_out, const float* gamma, int rows, int d, int ld,
                           float slope, float eps, float* dz, float* dgamma, float* dbeta, float* partial,
                           hipStream_t st, EqdRedList* defer = nullptr);

@@ -1202,7 +1202,18 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
                 }
         }
         EQD_TR(19);
-        hbm_store<1>(W.dz1, dz, S, l15, g);
+        if constexpr (BF) {
+            // bf16 mode: dz1 goes to HBM as bf16 rows (128 B per edge instead of 256): it is the largest stream of the
+            // backward (98 MB per launch at 64 x (300, 300)), written here and gathered twice by k_node_gather
+            if (S.ev[0]) {
+                unsigned short* row = (unsigned short*)W.dz1 + (size_t)(S.e0 + l15) * 64;
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+                    *(s16x4*)&row[16 * mb + 4 * g] = pack_bf4(dz[mb][0][0], dz[mb][0][1], dz[mb][0][2], dz[mb][0][3]);
+            }
+        } else {
+            hbm_store<1>(W.dz1, dz, S, l15, g);
+        }
         // ---- phase 3: dW1[:, 2d:] += dz1^T [he | rbf] ------------------------------------------------------
         __syncthreads();                 // phase-2 slabs are free
         if constexpr (BF) {
@@ -1412,5 +1423,5 @@ int eqd_edge_message_bwd_impl(const EqdGraph* g, const EqdEdgeParams* p, const f
     }
     // per-node sums: dP (by source), dQ (by destination), dx = (1 - eta) d_xnew + sum_src dx_rel - sum_dst dx_rel;
     // the pending reductions (this layer's partials and whatever the caller had queued) ride in the same launch
-    return eqd_launch_node_gather(g, W.dz1, W.dxrel, d_xnew, 1.f - p->eta, dP, dQ, dx, st, defer);
+    return eqd_launch_node_gather(g, W.dz1, W.dxrel, d_xnew, 1.f - p->eta, dP, dQ, dx, st, defer, p->bf16 != 0);
 }

@@ -1139,6 +1139,13 @@ int eqd_launch_embed_bwd(const EqdGraph* g, const float* dh0, const float* dh0b,
 // weight-gradient partials were written by the launch before, are read here while they are still in the memory-side
 // cache, and the workgroups run on CUs the small gather leaves idle - instead of 90 MB of partials of a config-B
 // pass being streamed from HBM by two launches at the end (68 us).
+// BF: dz holds bf16 rows ([E][64] unsigned short; the edge backward's bf16 mode), sums are fp32
+template <bool BF>
+__device__ __forceinline__ float gather_dz(const float* __restrict__ dz, size_t e, int c) {
+    if constexpr (BF) return bf2f(((const unsigned short*)dz)[e * 64 + c]);
+    else return dz[e * 64 + c];
+}
+template <bool BF>
 __global__ __launch_bounds__(256) void k_node_gather(const int32_t* __restrict__ csc_ptr, const int32_t* __restrict__ csc_eid,
                                                      const int32_t* __restrict__ rowptr, int n, const float* __restrict__ dz,
                                                      const float* __restrict__ dxrel, const float* __restrict__ d_xnew, float a,
@@ -1173,12 +1180,12 @@ __global__ __launch_bounds__(256) void k_node_gather(const int32_t* __restrict__
 #pragma unroll
         for (int i = 0; i < GB; ++i) {
             const size_t ee = (size_t)(di + (i < ni1 ? i : ni1));
-            vq[i] = dz[ee * 64 + c];
+            vq[i] = gather_dz<BF>(dz, ee, c);
             wq[i] = dxrel[ee * 4 + (c & 3)];
         }
 #pragma unroll
         for (int i = 0; i < GB; ++i) {
-            vp[i] = dz[(size_t)e[i] * 64 + c];
+            vp[i] = gather_dz<BF>(dz, (size_t)e[i], c);
             wp[i] = dxrel[(size_t)e[i] * 4 + (c & 3)];
         }
 #pragma unroll
@@ -1200,7 +1207,7 @@ __global__ __launch_bounds__(256) void k_node_gather(const int32_t* __restrict__
         for (int i = 0; i < 8; ++i) e[i] = csc_eid[q0 + i < s1 ? q0 + i : s1 - 1];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            v[i] = dz[(size_t)e[i] * 64 + c];
+            v[i] = gather_dz<BF>(dz, (size_t)e[i], c);
             w[i] = dxrel[(size_t)e[i] * 4 + (c & 3)];
         }
 #pragma unroll
@@ -1214,7 +1221,7 @@ __global__ __launch_bounds__(256) void k_node_gather(const int32_t* __restrict__
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const size_t ee = (size_t)(e0 + i < d1 ? e0 + i : d1 - 1);
-            v[i] = dz[ee * 64 + c];
+            v[i] = gather_dz<BF>(dz, ee, c);
             w[i] = dxrel[ee * 4 + (c & 3)];
         }
 #pragma unroll
@@ -1230,7 +1237,7 @@ __global__ __launch_bounds__(256) void k_node_gather(const int32_t* __restrict__
 // pending: reductions to run in the same launch (emptied on return); what does not fit one descriptor is launched on
 // its own
 int eqd_launch_node_gather(const EqdGraph* g, const float* dz, const float* dxrel, const float* d_xnew, float a,
-                           float* dP, float* dQ, float* dx, hipStream_t st, EqdRedList* pending) {
+                           float* dP, float* dQ, float* dx, hipStream_t st, EqdRedList* pending, bool dz_bf16) {
     static thread_local RedPlan P;
     static thread_local EqdRedArg arg;
     int nblk = 0, c0 = 0;
@@ -1241,8 +1248,12 @@ int eqd_launch_node_gather(const EqdGraph* g, const float* dz, const float* dxre
     }
     const int ng = (g->n_nodes + 3) / 4;
     if (ng + nblk > 0) {
-        hipLaunchKernelGGL(k_node_gather, dim3(ng + nblk), dim3(256), 0, st, g->csc_ptr, g->csc_eid, g->rowptr,
-                           g->n_nodes, dz, dxrel, d_xnew, a, dP, dQ, dx, ng, arg);
+        if (dz_bf16)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_node_gather<true>), dim3(ng + nblk), dim3(256), 0, st, g->csc_ptr, g->csc_eid,
+                               g->rowptr, g->n_nodes, dz, dxrel, d_xnew, a, dP, dQ, dx, ng, arg);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_node_gather<false>), dim3(ng + nblk), dim3(256), 0, st, g->csc_ptr, g->csc_eid,
+                               g->rowptr, g->n_nodes, dz, dxrel, d_xnew, a, dP, dQ, dx, ng, arg);
         if (int rc = eqd_check_launch("k_node_gather")) return rc;
     }
     if (pending && pending->n > 0) {
