@@ -1161,3 +1161,32 @@ def check_linear_atb_bf16(dev):
     L.check(lib().eqd_atb(C.byref(A), 1, P(part), C.c_size_t(nb), st(dev)))
     sync(dev)
     close(out, port.rb16(Xa).t() @ port.rb16(Ya), tol=2e-5, what='bf16 A^T B, general path')
+
+
+def check_inference_pipeline(dev):
+    """src/inference_rigid.py:146-239 end to end with the drop-in's pieces on a real complex (the residues recorded in
+    tests/golden/graph_case.npz): PDB residues -> graphs (device) -> model -> (R, t) applied to all ligand atoms -> clash
+    removal (device) -> the identities the reference asserts (:188, :202-203)."""
+    import os
+    from equidock_public_amd import featurize as FZ, inference as INF
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'graph_case.npz'))
+    lig_all, rec_all = _residues_from_fixture(z, 'lig_in_'), _residues_from_fixture(z, 'rec_in_')
+    lig, rec, lig_ca, rec_ca = FZ.preprocess_unbound_bound(lig_all, rec_all, inference=True)
+    gl, gr = FZ.protein_to_graph_unbound_bound(lig, rec, lig_ca, rec_ca, cutoff=30.0, max_neighbor=10, device=dev)
+    assert np.linalg.norm(lig_ca - gl['x'].cpu().numpy()) < 1e-1                                   # :188
+    args = port.default_args(iegmn_n_lays=5, shared_layers=True, skip_weight_h=0.5)
+    net = build_model(args, port.init_state_dict(args, seed=1), dev).eval()
+    batch = G.batch_pairs([(dict(gl, new_x=gl['x']), gr)]).to(dev)
+    with torch.no_grad():
+        ligs, _, _, rot, tr = net(batch, epoch=0)
+    rotation, translation = rot[0].cpu().numpy(), tr[0].cpu().numpy()
+    new_residues = (rotation @ lig_ca.T).T + translation
+    assert np.linalg.norm(new_residues - ligs[0].cpu().numpy()) < 1e-1                             # :202-203
+    atoms, _ = FZ.atoms_ragged(lig)
+    rec_atoms, _ = FZ.atoms_ragged(rec)
+    new_pos = INF.apply_rigid(rot[0], tr[0], torch.from_numpy(atoms).to(dev))
+    close(new_pos, torch.from_numpy((rotation @ atoms.T).T + translation), tol=1e-5, what='rigid apply to all atoms')
+    out = INF.remove_clashes(new_pos, torch.from_numpy(rec_atoms).to(dev), max_it=30, check_every=10)
+    assert out['iterations'] <= 30 and torch.isfinite(out['positions']).all() and out['positions'].shape == new_pos.shape
+    R = INF.get_rot_mat(torch.from_numpy(out['euler']))
+    close(out['positions'], INF.apply_rigid(R, out['translation'], new_pos.cpu()), tol=1e-5, what='clash removal: (euler, t)')

@@ -172,6 +172,11 @@ def test_linear_atb_bf16(dev):
     pc.check_linear_atb_bf16(dev)
 
 
+def test_inference_pipeline_end_to_end(dev):
+    from tests import parity_common as pc
+    pc.check_inference_pipeline(dev)
+
+
 def test_scalar_loss(dev):
     from tests import parity_common as pc
     pc.check_scalar_loss(dev)

@@ -142,6 +142,10 @@ def test_model_bf16_layer_states():
     pc.check_model_bf16_states(DEV, [(60, 75), (90, 48), (120, 100)], layers=4, seed=5, pair_seed=7, faithful=True, what='sim')
 
 
+def test_inference_pipeline_end_to_end():
+    pc.check_inference_pipeline(DEV)
+
+
 def test_scalar_loss():
     pc.check_scalar_loss(DEV)
 
