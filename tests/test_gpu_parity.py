@@ -368,3 +368,36 @@ def test_flat_grad_allreduce_on_rccl_world_of_one(dev):
         parallel.broadcast_parameters(net)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('name', ['swish_bn_gn_eval', 'fine_tune'])
+def test_non_published_options_on_gpu(dev, name):
+    """The torch-operator path of the reference's non-published options (tests/test_torch_path.py pins it on the CPU) on the
+    GPU: same vectors from the real reference module; the fine-tune model runs its first stage in the HIP library and hands
+    the docked ligand, with its gradient, to the torch-path second stage."""
+    import json
+    import os
+    from equidock_public_amd import config, graph as G, model as M
+    from oracle import iegmn_port as port
+    from tests.util import cat_out, pairs_from_raw
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'variants.npz'), allow_pickle=False)
+    meta = json.loads(str(z['meta']))
+    v = meta['variants'][name]
+    args = dict(v['args'], device=dev)
+    net = M.Rigid_Body_Docking_Net(args).to(dev)
+    net.load_state_dict(config.seeded_state_dict(args, meta['init_seed'], meta['rot_scale']))
+    net.train(v['train'])
+    raw = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('in_')}
+    raw['lig_counts'], raw['rec_counts'] = [int(c) for c in z['in_lig_counts']], [int(c) for c in z['in_rec_counts']]
+    g = G.batch_pairs(pairs_from_raw(raw)).to(dev)
+    outs = net(g, epoch=0)
+    for nm, lst in zip(('lig', 'Yl', 'Yr', 'T', 'b'), outs):
+        got, ref = cat_out(lst).detach().cpu(), torch.from_numpy(z[f'{name}_{nm}'])
+        assert float((got - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max())), (name, nm)
+    loss = port.scalar_loss(outs)
+    loss.backward()
+    assert abs(float(loss) - float(z[f'{name}_loss'])) <= 1e-4 * abs(float(z[f'{name}_loss']))
+    for k, p in net.named_parameters():
+        ref = v['grad_norms'][k]
+        got = float(p.grad.double().norm()) if p.grad is not None else 0.0
+        assert abs(got - ref) <= 2e-3 * ref + 1e-5, f'{name}: gradient norm of {k}: {got} vs {ref}'
