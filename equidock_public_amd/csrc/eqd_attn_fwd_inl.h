@@ -256,6 +256,12 @@ struct alignas(16) AttnFwdSmem {
     static_assert(C::RED <= C::TILE, "merge buffer must fit a K tile");
 };
 
+// Half-block launches (two workgroups per item): workgroup b runs on XCD b % 8 and the work list is laid out so that item
+// i belongs to XCD class i % 8 (graph.py: _xcd_interleave; n_att_items is a multiple of 8).  Both halves of an item must
+// therefore sit at workgroup ids with the item's residue: b = 16 (i / 8) + 8 half + i % 8.
+__device__ __forceinline__ int att_half_item(int b) { return ((b >> 4) << 3) + (b & 7); }
+__device__ __forceinline__ int att_half_of(int b) { return (b >> 3) & 1; }
+
 // The forward of one work item (NB = 2) or of one 16-row half of it (NB = 1, half = 0 | 1) by a group of 4 waves;
 // t = the thread's index within the group (0..255).  `group_barriers`: the group shares its workgroup with other groups
 // that execute the same number of __syncthreads() (k_edge_attn_fwd: the two halves of one item) - an empty half then
@@ -280,14 +286,14 @@ __device__ __forceinline__ void attn_fwd_body(AttnFwdSmem<DB>& sm, const EqdGrap
     if (NB == 1) {
         b0 += 16 * half;
         b1 = b1 < b0 + 16 ? b1 : b0 + 16;
-        if (b0 >= b1) {              // the item's block has at most 16 rows (uniform for the group)
-            if (group_barriers) {
-                static_assert(!(NB == 1) || FAST, "half blocks exist on the float4 path only");
-                __syncthreads();
-                __syncthreads();
-            }
-            return;
+    }
+    if (b0 >= b1) {   // at most 16 rows in the item's block, or a padding item of the XCD-interleaved list (uniform)
+        if (group_barriers) {
+            static_assert(!(NB == 1) || FAST, "half blocks exist on the float4 path only");
+            __syncthreads();
+            __syncthreads();
         }
+        return;
     }
     int rowq[NB];
     bool qv[NB];
@@ -451,6 +457,6 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_fwd(EqdGraph G, int d, const
                                                         const float* __restrict__ k, const float* __restrict__ v,
                                                         float* __restrict__ out, float* __restrict__ lse) {
     __shared__ AttnFwdSmem<DB> sm;
-    const int item = NB == 1 ? (int)blockIdx.x >> 1 : (int)blockIdx.x;
-    attn_fwd_body<DB, FAST, NB, BF>(sm, G, item, (int)blockIdx.x & 1, (int)threadIdx.x, d, q, k, v, out, lse);
+    const int item = NB == 1 ? att_half_item((int)blockIdx.x) : (int)blockIdx.x;
+    attn_fwd_body<DB, FAST, NB, BF>(sm, G, item, att_half_of((int)blockIdx.x), (int)threadIdx.x, d, q, k, v, out, lse);
 }

@@ -63,8 +63,8 @@ __device__ __forceinline__ void attn_bwd_q_body(SM& sm, const EqdGraph& G, int i
     if (NB == 1) {          // half blocks: rows b0 + 16 half .. of the item (see k_attn_fwd)
         b0 += 16 * half;
         b1 = b1 < b0 + 16 ? b1 : b0 + 16;
-        if (b0 >= b1) return;
     }
+    if (b0 >= b1) return;   // short half block, or a padding item of the XCD-interleaved work list
     int rowq[NB];
     bool qv[NB];
 #pragma unroll
@@ -223,8 +223,8 @@ __device__ __forceinline__ void attn_bwd_kv_body(SM& sm, const EqdGraph& G, int 
     if (NB == 1) {
         b0 += 16 * half;
         b1 = b1 < b0 + 16 ? b1 : b0 + 16;
-        if (b0 >= b1) return;
     }
+    if (b0 >= b1) return;
     int rowk[NB];
     bool kvd[NB];
 #pragma unroll
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(EQD_BLOCK, NB == 1 ? 2 : 1) void k_attn_bwd(EqdGrap
     const int per = NB == 1 ? 2 * G.n_att_items : G.n_att_items;      // workgroups per pass
     const bool kv = (int)blockIdx.x >= per;
     const int idx = kv ? (int)blockIdx.x - per : (int)blockIdx.x;
-    const int item = NB == 1 ? idx >> 1 : idx, half = NB == 1 ? idx & 1 : 0;
+    const int item = NB == 1 ? att_half_item(idx) : idx, half = NB == 1 ? att_half_of(idx) : 0;
     if (!kv)
         attn_bwd_q_body<DB, true, NB, AttnBwdSmem<DB, true>, BF>(sm, G, item, d, q, k, v, out, lse, d_out, dq, delta, half);
     else
@@ -465,6 +465,7 @@ static int attn_launch_bwd(const EqdGraph* g, int d, const float* q, const float
 // forward, float4 path: half blocks while that still fits one round of workgroups (two of them share a CU's LDS);
 // EQD_ATT_SPLIT=0|1 forces either (tests)
 static bool att_half_blocks(const EqdGraph* g) {
+    if (g->n_att_items % 8) return false;   // the half-block workgroup map needs the 8-way interleaved list (header)
     const char* f = getenv("EQD_ATT_SPLIT");
     if (f && (f[0] == '0' || f[0] == '1') && f[1] == 0) return f[0] == '1';
     return g->n_att_items <= eqd_num_cus();
@@ -508,7 +509,7 @@ extern "C" int eqd_cross_attention_bwd(const EqdGraph* g, int d, const float* q,
     // d = 64: half blocks (two workgroups per CU, see k_attn_bwd) - config C +2.3 %, E +0.9 %, B unchanged;
     // EQD_ATT_BWD_SPLIT=0 keeps 32-row blocks (tests)
     const char* hb = getenv("EQD_ATT_BWD_SPLIT");
-    const bool half = !(hb && hb[0] == '0' && hb[1] == 0);
+    const bool half = !(hb && hb[0] == '0' && hb[1] == 0) && g->n_att_items % 8 == 0;
     if (d == 64 && al && half) return attn_launch_bwd<4, true, 1>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
     if (d == 64 && al) return attn_launch_bwd<4, true, 2>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
     if (d == 80 && al) return attn_launch_bwd<5, true, 2>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
@@ -552,6 +553,7 @@ extern "C" int eqd_cross_attention_bwd_bf16(const EqdGraph* g, int d, const floa
     }
     if (g->n_att_items <= 0) return EQD_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (d == 64) return attn_launch_bwd_bf<4, 1>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
+    if (d == 64 && g->n_att_items % 8 == 0) return attn_launch_bwd_bf<4, 1>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
+    if (d == 64) return attn_launch_bwd_bf<4, 2>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
     return attn_launch_bwd_bf<5, 2>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
 }

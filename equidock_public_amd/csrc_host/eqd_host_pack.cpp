@@ -147,9 +147,26 @@ int eqd_host_pack(const EqdHostPackIn* in, EqdHostPackOut* out) {
     }
     std::stable_sort(items.begin(), items.end(),
                      [](const Item& a, const Item& b) { return (a.v[3] - a.v[2]) > (b.v[3] - b.v[2]); });
-    if ((int64_t)items.size() > out->items_cap) return EQDH_ERR_SPACE;
-    for (size_t i = 0; i < items.size(); ++i) std::memcpy(out->att_items + 4 * i, items[i].v, 16);
-    out->n_att_items = (int32_t)items.size();
+    // XCD-aware order (graph.py: _xcd_interleave): 8 queues of equal cost, slot 8 k + c = k-th item of queue c, so the
+    // blocks that stream the same partner rows share one XCD's L2 (workgroup b runs on XCD b % 8)
+    constexpr int XCD = 8;
+    int64_t total = 0;
+    for (const Item& it : items) total += it.v[3] - it.v[2];
+    std::vector<int32_t> qlen(XCD, 0), slot(items.size());
+    {
+        int c = 0;
+        int64_t acc = 0;
+        for (size_t i = 0; i < items.size(); ++i) {
+            slot[i] = XCD * qlen[c]++ + c;
+            acc += items[i].v[3] - items[i].v[2];
+            if (c < XCD - 1 && acc * XCD >= total * (c + 1)) ++c;
+        }
+    }
+    const int32_t depth = *std::max_element(qlen.begin(), qlen.end());
+    if ((int64_t)depth * XCD > out->items_cap) return EQDH_ERR_SPACE;
+    std::memset(out->att_items, 0, (size_t)depth * XCD * 16);
+    for (size_t i = 0; i < items.size(); ++i) std::memcpy(out->att_items + 4 * (size_t)slot[i], items[i].v, 16);
+    out->n_att_items = depth * XCD;
     // edge features in sorted order + bf16 copy (32 columns per edge, 27 used): the only pass over the big array
     // (41 MB at 64 x (300, 300)), split over worker threads by edge ranges
     const float* hes[2] = {in->he_ll, in->he_rr};

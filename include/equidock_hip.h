@@ -82,7 +82,11 @@ typedef struct EqdGraph {
     const int32_t* csc_ptr;    /* [n_nodes+1] edges grouped by source ... */
     const int32_t* csc_eid;    /* [n_edges]   ... as edge ids */
     const int32_t* tile_node;  /* [n_tiles+1] node ranges; each tile has <= EQD_TILE_EDGES in-edges */
-    const int32_t* att_items;  /* [n_att_items][4] = {blk_begin, blk_end, other_begin, other_end} */
+    const int32_t* att_items;  /* [n_att_items][4] = {blk_begin, blk_end, other_begin, other_end}; blk_begin == blk_end
+                                * marks an empty (padding) item.  Workgroup b of a launch runs on XCD b % 8, so the packers
+                                * place the items that stream the same partner rows at indices of one residue mod 8 and
+                                * pad n_att_items to a multiple of 8 (graph.py: _xcd_interleave); any order is CORRECT,
+                                * a count that is not a multiple of 8 merely disables the half-block kernels */
     const int32_t* res_id;     /* [n_nodes] residue type 0..20 */
     const float* mu_r_norm;    /* [n_nodes][5] */
     const float* he;           /* [n_edges][27] */

@@ -18,6 +18,18 @@ bench)
   python bench.py --workload C --steps 20 --warmup 5 > $O/${TAG}_benchC.log 2>&1
   python bench.py --workload C --dtype bf16 --steps 20 --warmup 5 --no-cpu-baseline > $O/${TAG}_benchC_bf16.log 2>&1
   python bench.py --workload E --steps 20 --warmup 5 > $O/${TAG}_benchE.log 2>&1 ;;
+benchq)      # the four bench lines without the CPU baseline
+  python bench.py --no-cpu-baseline > $O/${TAG}_bench.log 2>&1
+  python bench.py --workload C --steps 20 --warmup 5 --no-cpu-baseline > $O/${TAG}_benchC.log 2>&1
+  python bench.py --workload C --dtype bf16 --steps 20 --warmup 5 --no-cpu-baseline > $O/${TAG}_benchC_bf16.log 2>&1
+  python bench.py --workload E --steps 20 --warmup 5 --no-cpu-baseline > $O/${TAG}_benchE.log 2>&1 ;;
+pmctraffic)
+  cd /tmp; export TMPDIR=/tmp
+  for W in B C E; do for CNT in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/pmc2; rocprofv3 --kernel-trace --pmc $CNT -d /tmp/pmc2 -o p -- python $R/bench.py --eager --workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > /tmp/pmc2_${W}_$CNT.log 2>&1
+    python $R/profiles/pmcstats.py $(find /tmp/pmc2 -name "*.db" | head -1) k_edge k_attn k_rowchain k_atb k_linear k_node k_layer > $O/${TAG}_pmc_${W}_${CNT}.json 2>&1
+  done; done
+  cd $R ;;
 benchB)
   python bench.py --no-cpu-baseline > $O/${TAG}_bench.log 2>&1 ;;
 prof)

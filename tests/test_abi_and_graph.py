@@ -121,13 +121,51 @@ def test_pack_invariants():
     items = p.att_items.numpy()
     covered = np.zeros(N, int)
     seg = p.seg_off.numpy()
+    assert len(items) % G.XCD_CLASSES == 0 and p.n_att_items == len(items)
     for b0, b1, o0, o1 in items:
+        if b0 == b1:                      # padding item of the XCD-interleaved list
+            assert (b0, b1, o0, o1) == (0, 0, 0, 0)
+            continue
         covered[b0:b1] += 1
         assert b1 - b0 <= G.ATT_BLOCK
         s = np.searchsorted(seg, b0, side='right') - 1
         partner = s + p.n_pairs if s < p.n_pairs else s - p.n_pairs
         assert (o0, o1) == (seg[partner], seg[partner + 1])
     assert np.all(covered == 1)
+
+
+def test_attention_work_list_is_xcd_interleaved():
+    """graph._xcd_interleave: slot 8 k + c holds the k-th item of queue c; the queues carry equal cost (block x partner
+    rows), are filled in order of decreasing partner size, and one (pair, direction) spans as few queues as its cost
+    allows - so its partner rows are fetched into one XCD's L2 (workgroup b runs on XCD b % 8)."""
+    rng = np.random.default_rng(5)
+    for sizes in ([(300, 300)] * 64, [(200, 200)] * 8, [(2000, 2000)] * 4, [(40, 40)],
+                  [(int(a), int(b)) for a, b in rng.integers(20, 500, size=(13, 2))]):
+        items = []
+        off = 0
+        nl = sum(a for a, _ in sizes)
+        lo, ro = 0, nl
+        for a, b in sizes:
+            for (a0, a1, o0, o1) in ((lo, lo + a, ro, ro + b), (ro, ro + b, lo, lo + a)):
+                items += [(s0, min(s0 + G.ATT_BLOCK, a1), o0, o1) for s0 in range(a0, a1, G.ATT_BLOCK)]
+            lo, ro = lo + a, ro + b
+        out = G._xcd_interleave(items)
+        assert out.shape[0] % 8 == 0
+        real = [tuple(r) for r in out.tolist() if r[0] != r[1]]
+        assert sorted(real) == sorted(items)
+        cost = [sum(r[3] - r[2] for r in out[c::8].tolist()) for c in range(8)]
+        total, biggest = sum(cost), max(it[3] - it[2] for it in items)
+        assert max(cost) <= total / 8 + biggest and (len(items) < 8 or min(cost) >= total / 8 - 2 * biggest), (sizes[:2], cost)
+        # a direction's items sit in consecutive queues, and no more of them than its share of the cost needs (+1 spill)
+        by_unit = {}
+        for c in range(8):
+            for r in out[c::8].tolist():
+                if r[0] != r[1]:
+                    by_unit.setdefault((r[2], r[3]), set()).add(c)
+        for (o0, o1), cs in by_unit.items():
+            n_items = sum(1 for it in items if (it[2], it[3]) == (o0, o1))
+            assert max(cs) - min(cs) + 1 == len(cs)
+            assert len(cs) <= int(np.ceil(n_items * (o1 - o0) * 8 / total)) + 1, (sizes[:2], o0, o1, cs)
 
 
 def test_unsorted_edges_are_sorted_stably():

@@ -397,7 +397,10 @@ def test_non_published_options_on_gpu(dev, name):
     loss = port.scalar_loss(outs)
     loss.backward()
     assert abs(float(loss) - float(z[f'{name}_loss'])) <= 1e-4 * abs(float(z[f'{name}_loss']))
+    # (biases in front of a BatchNorm / GraphNorm: mathematically zero gradient, computed value = rounding noise of the
+    # device's summation order - hence the floor relative to the largest gradient norm, as in tests/test_torch_path.py)
+    floor = 1e-6 * max(v['grad_norms'].values()) + 1e-5
     for k, p in net.named_parameters():
         ref = v['grad_norms'][k]
         got = float(p.grad.double().norm()) if p.grad is not None else 0.0
-        assert abs(got - ref) <= 2e-3 * ref + 1e-5, f'{name}: gradient norm of {k}: {got} vs {ref}'
+        assert abs(got - ref) <= 2e-3 * ref + floor, f'{name}: gradient norm of {k}: {got} vs {ref}'

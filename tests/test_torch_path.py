@@ -62,15 +62,18 @@ def test_variant_vs_reference_golden(name, simulator):
         got, ref = cat_out(lst).detach(), torch.from_numpy(Z[f'{name}_{nm}'])
         err = float((got - ref).abs().max()) / max(1.0, float(ref.abs().max()))
         # (fine_tune: stage 1 is the HIP path - its kernels sum in another order than torch: the 1e-4 of the north_star)
-        assert err <= (1e-4 if name == 'fine_tune' else 2e-5), f'{name} {nm}: {err:.2e}'
+        assert err <= (1e-4 if name == 'fine_tune' else 5e-5), f'{name} {nm}: {err:.2e}'
     loss = port.scalar_loss(outs)
     loss.backward()
     assert abs(float(loss) - float(Z[f'{name}_loss'])) <= 1e-5 * abs(float(Z[f'{name}_loss']))
+    # a bias in front of a BatchNorm / GraphNorm has a mathematically zero gradient: its computed value (~1e-4 here, next
+    # to norms of up to ~8e2) is rounding noise that changes with torch's thread count, hence a floor relative to the
+    # largest gradient norm instead of an absolute one
+    floor = 1e-7 * max(v['grad_norms'].values()) + 1e-5
     for k, p in net.named_parameters():
         ref = v['grad_norms'][k]
         got = float(p.grad.double().norm()) if p.grad is not None else 0.0
-        # (a bias in front of a BatchNorm has a mathematically zero gradient: its computed value is rounding noise)
-        assert abs(got - ref) <= (2e-3 if name == 'fine_tune' else 2e-4) * ref + 1e-5, f'{name}: gradient norm of {k}: {got} vs {ref}'
+        assert abs(got - ref) <= (2e-3 if name == 'fine_tune' else 2e-4) * ref + floor, f'{name}: gradient norm of {k}: {got} vs {ref}'
 
 
 def test_state_dict_keys_of_variants():
