@@ -268,12 +268,14 @@ struct EqdChainJob {
     int type;                     // 0 linear; 1 LeakyReLU->LayerNorm backward (see chain_lnbwd)
     float* aux;                   // type 1: per-workgroup partial sums [blocks][256]
     int prefetch_next;            // filled by eqd_launch_rowchain: linear job whose first step is fetched early, or -1
+    int next_lin;                 // filled by eqd_launch_rowchain: the next linear job of the chain, or -1 (k_rowwave)
 };
 struct EqdChainArg {
     EqdChainJob j[EQD_CHAIN_MAXJOBS];
     int njobs;
 };
-int eqd_launch_rowchain(const EqdChainJob* jobs, int njobs, int rows, hipStream_t st);
+// partial_rows (optional): rows of LayerNorm-backward partial sums the launch wrote (= its workgroups)
+int eqd_launch_rowchain(const EqdChainJob* jobs, int njobs, int rows, hipStream_t st, int* partial_rows = nullptr);
 size_t eqd_atb_batch_partial_bytes(int rows);
 int eqd_row_tiles(int rows);          // 16-row tiles per workgroup of the row kernels
 int eqd_rowchain_blocks(int rows);    // = workgroups of a row-chain launch = LayerNorm-backward partial rows

@@ -606,8 +606,8 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
             if (l < D.L - 1) {      // the last layer (processed first) initialises the accumulator
                 C5.lin.R = W.dh0acc; C5.lin.ldr = D.d0; C5.lin.beta = 1.f;
             }
-            RC(eqd_launch_rowchain(cj, nj, N, st));
-            const int nb = eqd_rowchain_blocks(N);
+            int nb = 0;      // partial rows of the LayerNorm-backward sums = workgroups of whichever kernel took the chain
+            RC(eqd_launch_rowchain(cj, nj, N, st, &nb));
             if (defer->n + 2 <= 512) {
                 defer->seg[defer->n++] = EqdRedSeg{lnp, nb, 256, d, gp[P_NLG], 0, 0, 0};
                 defer->seg[defer->n++] = EqdRedSeg{lnp + 128, nb, 256, d, gp[P_NLB], 0, 0, 0};

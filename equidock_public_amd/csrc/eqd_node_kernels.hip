@@ -5,6 +5,7 @@
 // (src/model/rigid_docking_model.py:119-159, 382, 427-438) and their autograd backward.
 #include "eqd_common.h"
 #include "eqd_linear_inl.h"
+#include "eqd_rowwave_inl.h"
 
 #include <mutex>
 #include <vector>
@@ -408,7 +409,74 @@ static int lin_check_sources(const EqdLinJob& J) {
     return EQD_OK;
 }
 
-int eqd_launch_rowchain(const EqdChainJob* jobs, int njobs, int rows, hipStream_t st) {
+// ---- k_rowwave (eqd_rowwave_inl.h): which chains it takes ---------------------------------------------------------
+// EQD_ROWWAVE=0 keeps every chain on k_rowchain / k_linear, =1 (default) uses k_rowwave for every eligible chain.
+static bool rw_enabled() {
+    const char* f = getenv("EQD_ROWWAVE");
+    return !(f && f[0] == '0' && f[1] == 0);
+}
+static bool rw_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+static bool rw_eligible(const EqdChainJob* jobs, int njobs, int rows) {
+    if (!rw_enabled() || njobs <= 0 || rows <= 0) return false;
+    for (int i = 0; i < njobs; ++i) {
+        const EqdChainJob& C = jobs[i];
+        const EqdLinJob& J = C.lin;
+        if (J.M != 64 || J.rows != rows || C.out_local >= LIN_LOCALS) return false;
+        if ((J.bf16 != 0) != (jobs[0].lin.bf16 != 0)) return false;
+        // 16-byte row accesses: every leading dimension a multiple of 4 floats would be too strict (69-wide h0 rows are
+        // read through unaligned-tolerant loads: gfx950 global memory runs in unaligned-access mode), bases 4-byte
+        if (C.type != 0) {
+            if (C.src_local[0] < 0 || C.src_local[0] >= LIN_LOCALS || !J.s[0].X || !J.ln_g || !C.aux) return false;
+            continue;
+        }
+        if (J.nsrc <= 0 || J.nsrc > EQD_MAX_SRC) return false;
+        if (J.ln_g && !J.ln_b) return false;
+        const bool tp = J.s[0].w_cs != 1;
+        for (int s = 0; s < J.nsrc; ++s) {
+            const EqdLinSrc& S = J.s[s];
+            const bool local = C.src_local[s] >= 0;
+            if (!S.W || (S.w_cs != 1) != tp) return false;
+            if (tp ? S.w_rs != 1 : S.w_cs != 1) return false;
+            if (local && (C.src_local[s] >= LIN_LOCALS || S.K != 64 || S.mask)) return false;
+            if (!local && !S.X) return false;
+            if (S.K == 64) continue;
+            if (S.K < 64 || S.K > 80 || tp || local || S.mask) return false;
+        }
+    }
+    (void)rw_aligned16;
+    return true;
+}
+static void chain_links(EqdChainArg& arg, const EqdChainJob* jobs, int njobs) {
+    // prefetch_next[i]: the next linear job n whose first step may be loaded before job i's epilogue: its first
+    // source is an LDS tile, or global data that none of the jobs i .. n-1 writes
+    for (int i = 0; i < njobs; ++i) {
+        arg.j[i].prefetch_next = -1;
+        arg.j[i].next_lin = -1;
+        if (jobs[i].type != 0) continue;
+        int n = i + 1;
+        while (n < njobs && jobs[n].type != 0) ++n;
+        if (n >= njobs) continue;
+        arg.j[i].next_lin = n;
+        bool ok = true;
+        if (jobs[n].src_local[0] < 0) {
+            const EqdLinSrc& S0 = jobs[n].lin.s[0];
+            for (int m = i; m < n && ok; ++m) {
+                const float* outs[2] = {jobs[m].lin.Y, jobs[m].lin.pre_ln};
+                for (int q = 0; q < 2; ++q)
+                    if (outs[q] && (outs[q] == S0.X || outs[q] == S0.mask)) ok = false;
+            }
+        }
+        if (ok) arg.j[i].prefetch_next = n;
+    }
+}
+static int rw_blocks(int rows) { return ((rows + 15) / 16 + RW_WAVES - 1) / RW_WAVES; }
+static int launch_rowwave(const EqdChainArg& arg, int rows, bool bf, hipStream_t st) {
+    if (bf) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rowwave<true>), dim3(rw_blocks(rows)), dim3(64 * RW_WAVES), 0, st, arg);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rowwave<false>), dim3(rw_blocks(rows)), dim3(64 * RW_WAVES), 0, st, arg);
+    return eqd_check_launch("k_rowwave");
+}
+
+int eqd_launch_rowchain(const EqdChainJob* jobs, int njobs, int rows, hipStream_t st, int* partial_rows) {
     if (njobs <= 0 || njobs > EQD_CHAIN_MAXJOBS) {
         eqd_set_error("eqd_launch_rowchain: %d jobs (1..%d)", njobs, EQD_CHAIN_MAXJOBS);
         return EQD_ERR_SHAPE;
@@ -432,31 +500,18 @@ int eqd_launch_rowchain(const EqdChainJob* jobs, int njobs, int rows, hipStream_
             }
     }
     arg.njobs = njobs;
-    // prefetch_next[i]: the next linear job n whose first step may be loaded before job i's epilogue: its first
-    // source is an LDS tile, or global data that none of the jobs i .. n-1 writes
-    for (int i = 0; i < njobs; ++i) {
-        arg.j[i].prefetch_next = -1;
-        if (jobs[i].type != 0) continue;
-        int n = i + 1;
-        while (n < njobs && jobs[n].type != 0) ++n;
-        if (n >= njobs) continue;
-        bool ok = true;
-        if (jobs[n].src_local[0] < 0) {
-            const EqdLinSrc& S0 = jobs[n].lin.s[0];
-            for (int m = i; m < n && ok; ++m) {
-                const float* outs[2] = {jobs[m].lin.Y, jobs[m].lin.pre_ln};
-                for (int q = 0; q < 2; ++q)
-                    if (outs[q] && (outs[q] == S0.X || outs[q] == S0.mask)) ok = false;
-            }
-        }
-        if (ok) arg.j[i].prefetch_next = n;
-    }
+    chain_links(arg, jobs, njobs);
     for (int i = 0; i < njobs; ++i)
         if (jobs[i].out_local >= LIN_LOCALS) {
             eqd_set_error("eqd_launch_rowchain: LDS tile index %d >= %d", jobs[i].out_local, LIN_LOCALS);
             return EQD_ERR_SHAPE;
         }
     const bool bf = njobs > 0 && jobs[0].lin.bf16;     // one arithmetic mode per launch
+    if (rw_eligible(jobs, njobs, rows)) {
+        if (partial_rows) *partial_rows = rw_blocks(rows);
+        return launch_rowwave(arg, rows, bf, st);
+    }
+    if (partial_rows) *partial_rows = eqd_rowchain_blocks(rows);
     if (eqd_row_tiles(rows) == 2) {
         if (bf) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rowchain<2, true>), dim3(eqd_rowchain_blocks(rows)), dim3(EQD_BLOCK), 0, st, arg);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rowchain<2, false>), dim3(eqd_rowchain_blocks(rows)), dim3(EQD_BLOCK), 0, st, arg);
@@ -473,6 +528,29 @@ extern "C" int eqd_linear(const EqdLinJob* jobs, int njobs, void* stream) {
         return EQD_ERR_NULL;
     }
     hipStream_t st = (hipStream_t)stream;
+    // jobs on the same rows that k_rowwave takes: one launch, a wave walks the jobs of its 16 rows one after the other
+    // (k_linear runs them side by side on four-wave workgroups; per row tile the same MFMA work without the barriers)
+    if (njobs <= EQD_CHAIN_MAXJOBS) {
+        EqdChainArg carg;
+        memset(&carg, 0, sizeof(carg));
+        bool ok = true;
+        for (int i = 0; i < njobs && ok; ++i) {
+            EqdChainJob& C = carg.j[i];
+            C.lin = jobs[i];
+            for (int s = 0; s < EQD_MAX_SRC; ++s) C.src_local[s] = -1;
+            C.out_local = -1;
+            ok = jobs[i].Y != nullptr && jobs[i].rows == jobs[0].rows;
+        }
+        if (ok && rw_eligible(carg.j, njobs, jobs[0].rows)) {
+            for (int i = 0; i < njobs; ++i)
+                if (int e = lin_check_sources(jobs[i])) return e;
+            carg.njobs = njobs;
+            EqdChainJob tmp[EQD_CHAIN_MAXJOBS];
+            for (int i = 0; i < njobs; ++i) tmp[i] = carg.j[i];
+            chain_links(carg, tmp, njobs);
+            return launch_rowwave(carg, jobs[0].rows, jobs[0].bf16 != 0, st);
+        }
+    }
     for (int base = 0; base < njobs; base += LIN_MAXJOBS) {
         LinJobsArg arg;
         memset(&arg, 0, sizeof(arg));

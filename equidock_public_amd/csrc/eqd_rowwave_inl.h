@@ -1,0 +1,428 @@
+// k_rowwave: the row-local job chains (EqdChainJob, eqd_common.h) with ONE WAVE per 16-row tile and the whole chain in
+// registers - the throughput form of k_rowchain, which spreads a tile over four waves and pays two workgroup barriers
+// and an LDS staging of the weights per 64-wide K step (1 350 clocks of step overhead around 512 clocks of fp32 MFMA
+// work, 32 in bf16 mode: MfmaUtil 4 % at config B, 15 % at config C).
+//
+// Transposed formulation, as everywhere in this library: features on the MFMA M axis, the tile's 16 rows on the N axis.
+// A wave owns all 64 output features of its rows, so
+//   * nothing is shared between waves: no barrier, no staging - the A operand (weights) is loaded from global memory
+//     (L2 / L1 resident: <= 170 KB per chain) straight into the lanes that feed the MFMA, 16 x 16-byte loads per 64-wide
+//     K step, issued one step ahead of the 64 (fp32) / 16 (bf16) MFMAs that consume them;
+//   * the D layout of one job is the B layout of the next: lane (l15, g) holds, of row l15, 16 features v[a][b],
+//       S layout: feature 16 a + 4 g + b      (weights W[m][k], k contiguous:  acc[mb][r] = v[mb][r])
+//       P layout: feature 16 g + 4 a + b      (weights W[k][m], m contiguous:  acc[j][r]  = v[r][j])
+//     and MFMA (a, b) contracts k = feature(a) + b, whichever layout the producer left.  With k-contiguous weights the
+//     lane loads W[16 mb + l15][feature(a) ..+3] (4 MFMAs b = 0..3 per load and output block mb); with m-contiguous
+//     weights (the backward's dX = dY W) it loads W[feature(a) + b][4 l15 ..+3] and MFMA j of the four uses component j:
+//     output block j then holds features 4 i + j on its M index i, i.e. the P layout.  No transposes anywhere;
+//   * tiles that later jobs of the chain read (EqdChainJob.out_local) go to a wave-private LDS tile in [row][feature]
+//     order; LayerNorm statistics are 16 in-lane values + two cross-lane steps.
+// Arithmetic: the same products as k_rowchain, summed in another order (fp32: within the north-star tolerance, and
+// checked against the same oracle; bf16: inputs rounded at the same points).
+//
+// Eligible chains (rw_eligible, host): every job 64 outputs wide; sources 64 wide, or 65..80 wide with k-contiguous
+// weights, read from global memory and without mask (the 69-wide h0 of node_mlp.0); one weight orientation per job.
+// Everything else - layer 0 with its 69-wide features - stays on k_rowchain / k_linear.
+#pragma once
+#include "eqd_linear_inl.h"
+
+#define RW_S 68          /* LDS row stride of a wave-private tile: 4 l15 + c covers the 64 banks once per 16 lanes */
+#define RW_WAVES 4
+
+struct RwBuf {           // operands of one SUB-step as loaded (nothing is waited for at load time).  A source is walked in
+                         // sub-steps h = 0, 1: features a = 2 h, 2 h + 1 (32 columns each); h = 2: columns 64 .. K - 1
+    f32x4 w[8];          // k-contiguous weights: w[4 i + mb] for a = 2 h + i; m-contiguous: w[4 i + b]; h = 2: w[mb] raw
+    f32x4 x[2], xm[2];   // global source row, S layout (features 16 a + 4 g ..), and its LeakyReLU mask row; h = 2: x[0] raw
+};
+
+struct RwSmem {
+    float tile[RW_WAVES][LIN_LOCALS][16 * RW_S];
+    float red[RW_WAVES][256];      // LayerNorm-backward partial sums of the wave's rows: [d gamma 0..127 | d beta 128..255]
+};
+
+__device__ __forceinline__ void rw_load(const JobW& W, int si, int h, bool local, int rowc, int l15, int g, RwBuf& R) {
+    const EqdLinSrc S = jw_src(W, si);
+    if (h == 2) {        // k-contiguous weights, global source (rw_eligible)
+        const int n = S.K - 64 - 4 * g;
+        R.x[0] = ld4u_raw(S.X + (size_t)rowc * S.ldx + 64 + 4 * g, n, S.X);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) R.w[mb] = ld4u_raw(S.W + (size_t)(16 * mb + l15) * S.w_rs + 64 + 4 * g, n, S.W);
+        return;
+    }
+    if (!local) {
+        const float* xp = S.X + (size_t)rowc * S.ldx + 4 * g + 32 * h;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) R.x[i] = *(const EQD_GAS f4v*)(xp + 16 * i);
+        if (S.mask) {
+            const float* mp = S.mask + (size_t)rowc * S.ldx + 4 * g + 32 * h;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) R.xm[i] = *(const EQD_GAS f4v*)(mp + 16 * i);
+        }
+    }
+    if (S.w_cs == 1) {
+        const float* wp = S.W + (size_t)l15 * S.w_rs + 4 * g + 32 * h;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) R.w[4 * i + mb] = *(const EQD_GAS f4v*)(wp + (size_t)(16 * mb) * S.w_rs + 16 * i);
+    } else {
+        const float* wp = S.W + (size_t)(4 * g + 32 * h) * S.w_cs + 4 * l15;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) R.w[4 * i + b] = *(const EQD_GAS f4v*)(wp + (size_t)(16 * i + b) * S.w_cs);
+    }
+}
+
+// the 32 (fp32) / 8 (bf16) MFMAs of a sub-step h < 2; Bv[i]: the lane's 4 features of a = 2 h + i
+template <bool BF>
+__device__ __forceinline__ void rw_mma(const RwBuf& R, const f32x4 (&Bv)[2], bool tp, f32x4 (&acc)[4]) {
+    if (!tp) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if constexpr (BF) {
+                const s16x4 bp = pack_bf4(Bv[i][0], Bv[i][1], Bv[i][2], Bv[i][3]);
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    const f32x4 w = R.w[4 * i + mb];
+                    acc[mb] = mfma_bf(pack_bf4(w[0], w[1], w[2], w[3]), bp, acc[mb]);
+                }
+            } else {
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb) acc[mb] = mfma4(R.w[4 * i + mb][b], Bv[i][b], acc[mb]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if constexpr (BF) {
+                const s16x4 bp = pack_bf4(Bv[i][0], Bv[i][1], Bv[i][2], Bv[i][3]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[j] = mfma_bf(pack_bf4(R.w[4 * i][j], R.w[4 * i + 1][j], R.w[4 * i + 2][j], R.w[4 * i + 3][j]), bp, acc[j]);
+            } else {
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] = mfma4(R.w[4 * i + b][j], Bv[i][b], acc[j]);
+            }
+        }
+    }
+}
+
+// sub-step h = 2, columns 64 .. K - 1 of a wide source: lane group g contributes k = 64 + 4 g + b (zeros beyond K)
+template <bool BF>
+__device__ __forceinline__ void rw_mma_rest(const RwBuf& R, int K, int g, f32x4 (&acc)[4]) {
+    const int n = K - 64 - 4 * g;
+    const float4 xf = ld4u_fix(R.x[0], n);
+    const float xv[4] = {xf.x, xf.y, xf.z, xf.w};
+    float wv[4][4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        const float4 wf = ld4u_fix(R.w[mb], n);
+        wv[mb][0] = wf.x; wv[mb][1] = wf.y; wv[mb][2] = wf.z; wv[mb][3] = wf.w;
+    }
+    if constexpr (BF) {
+        const s16x4 bp = pack_bf4(xv[0], xv[1], xv[2], xv[3]);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) acc[mb] = mfma_bf(pack_bf4(wv[mb][0], wv[mb][1], wv[mb][2], wv[mb][3]), bp, acc[mb]);
+    } else {
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) acc[mb] = mfma4(wv[mb][b], xv[b], acc[mb]);
+    }
+}
+
+// Y = alpha * f(acc + bias) + beta * R of one job for the wave's rows (EqdLinJob semantics, see equidock_hip.h)
+__device__ __forceinline__ void rw_epilogue(const JobW& W, bool tp, const f32x4 (&acc)[4], float* tiles, int row0, int l15,
+                                            int g) {
+#define LJ(f) JW_OFF(EqdLinJob, f)
+    const int rows = jw_i(W, LJ(rows));
+    const int rowi = row0 + l15;
+    const bool rv = rowi < rows;
+    const int rowe = rv ? rowi : rows - 1;
+    int ft[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) ft[a] = tp ? 16 * g + 4 * a : 16 * a + 4 * g;
+    const float* const jbias = jw_p<const float>(W, LJ(bias));
+    const float* const jlng = jw_p<const float>(W, LJ(ln_g));
+    const float* const jR = jw_p<const float>(W, LJ(R));
+    const float slope = jw_f(W, LJ(slope));
+    f32x4 res[4];
+    const int ldr = jw_i(W, LJ(ldr));
+    if (jR) {
+        const float* rp = jR + (size_t)rowe * ldr;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) res[a] = *(const EQD_GAS f4v*)(rp + ft[a]);
+    }
+    f32x4 v[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) v[a][b] = tp ? acc[b][a] : acc[a][b];
+    if (jbias) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const f32x4 bv = *(const EQD_GAS f4v*)(jbias + ft[a]);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) v[a][b] += bv[b];
+        }
+    }
+    if (jw_i(W, LJ(act))) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) v[a][b] = lrelu(v[a][b], slope);
+    }
+    if (jlng) {
+        const float* const jlnb = jw_p<const float>(W, LJ(ln_b));
+        f32x4 lg[4], lb[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            lg[a] = *(const EQD_GAS f4v*)(jlng + ft[a]);
+            lb[a] = *(const EQD_GAS f4v*)(jlnb + ft[a]);
+        }
+        float* const jpre = jw_p<float>(W, LJ(pre_ln));
+        const int ld_pre = jw_i(W, LJ(ld_pre));      // (descriptor reads are wave operations: never under a lane predicate)
+        if (jpre && rv) {
+            float* pp = jpre + (size_t)rowi * ld_pre;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) *(EQD_GAS f4v*)(pp + ft[a]) = v[a];
+        }
+        float s1 = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) s1 += (v[a][0] + v[a][1]) + (v[a][2] + v[a][3]);
+        const float mean = group_sum(s1) * (1.f / 64.f);
+        float q = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const float dlt = v[a][b] - mean;
+                q += dlt * dlt;
+            }
+        const float rstd = 1.f / sqrtf(group_sum(q) * (1.f / 64.f) + jw_f(W, LJ(ln_eps)));
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) v[a][b] = (v[a][b] - mean) * rstd * lg[a][b] + lb[a][b];
+    }
+    const float alpha = jw_f(W, LJ(alpha)), beta = jw_f(W, LJ(beta));
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) v[a][b] = alpha * v[a][b] + (jR ? beta * res[a][b] : 0.f);
+    float* const jY = jw_p<float>(W, LJ(Y));
+    const int ldy = jw_i(W, LJ(ldy));
+    if (jY && rv) {
+        float* yp = jY + (size_t)rowi * ldy;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) *(EQD_GAS f4v*)(yp + ft[a]) = v[a];
+    }
+    const int out_l = jw_i(W, JW_OFF(EqdChainJob, out_local));
+    if (out_l >= 0) {
+        float* T = tiles + out_l * (16 * RW_S) + l15 * RW_S;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) *(f32x4*)(T + ft[a]) = v[a];
+        wave_lds_fence();
+    }
+#undef LJ
+}
+
+// LeakyReLU -> LayerNorm backward of the wave's rows (EqdChainJob.type 1; same mathematics as chain_lnbwd64)
+__device__ __forceinline__ void rw_lnbwd(const JobW& W, float* tiles, float* red, int row0, int l15, int g) {
+#define LJ(f) JW_OFF(EqdLinJob, f)
+    const int rows = jw_i(W, LJ(rows));
+    const int src_l = jw_i(W, JW_OFF(EqdChainJob, src_local)), out_l = jw_i(W, JW_OFF(EqdChainJob, out_local));
+    const float slope = jw_f(W, LJ(slope)), ln_eps = jw_f(W, LJ(ln_eps));
+    const int rowi = row0 + l15;
+    const bool rv = rowi < rows;
+    const float* const jg = jw_p<const float>(W, LJ(ln_g));
+    const float* yp = jw_p<const float>(W, LJ(s) + JW_OFF(EqdLinSrc, X)) +
+                      (size_t)(rv ? rowi : rows - 1) * jw_i(W, LJ(s) + JW_OFF(EqdLinSrc, ldx)) + 4 * g;
+    f32x4 y[4], gam[4], o[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        y[a] = *(const EQD_GAS f4v*)(yp + 16 * a);
+        gam[a] = *(const EQD_GAS f4v*)(jg + 16 * a + 4 * g);
+    }
+    const float* T = tiles + src_l * (16 * RW_S) + l15 * RW_S + 4 * g;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) o[a] = *(const f32x4*)(T + 16 * a);
+    if (!rv) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) o[a] = y[a] = f4zero();
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) s += (y[a][0] + y[a][1]) + (y[a][2] + y[a][3]);
+    const float mean = group_sum(s) * (1.f / 64.f);
+    float q = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const float c = y[a][b] - mean;
+            q += c * c;
+        }
+    const float rstd = 1.f / sqrtf(group_sum(q) * (1.f / 64.f) + ln_eps);
+    float p1 = 0.f, p2 = 0.f;
+    f32x4 xh[4], dx[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            xh[a][b] = (y[a][b] - mean) * rstd;
+            dx[a][b] = o[a][b] * gam[a][b];
+            p1 += dx[a][b];
+            p2 += dx[a][b] * xh[a][b];
+        }
+    const float s1 = group_sum(p1) * (1.f / 64.f), s2 = group_sum(p2) * (1.f / 64.f);
+    f32x4 z[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            z[a][b] = rv ? rstd * (dx[a][b] - s1 - xh[a][b] * s2) * lrelu_grad(y[a][b], slope) : 0.f;
+    float* const jY = jw_p<float>(W, LJ(Y));
+    const int ldy = jw_i(W, LJ(ldy));
+    if (jY && rv) {
+        float* zp = jY + (size_t)rowi * ldy + 4 * g;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) *(EQD_GAS f4v*)(zp + 16 * a) = z[a];
+    }
+    if (out_l >= 0) {
+        float* To = tiles + out_l * (16 * RW_S) + l15 * RW_S + 4 * g;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) *(f32x4*)(To + 16 * a) = z[a];
+        wave_lds_fence();
+    }
+    // d gamma / d beta over the wave's 16 rows: lane l15 ends with the sum of entry l15 = 4 a + b (feature 16 a + 4 g + b)
+    float vg[16], vb[16];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            vg[4 * a + b] = o[a][b] * xh[a][b];      // rows beyond the matrix carry o = 0
+            vb[4 * a + b] = o[a][b];
+        }
+    const float dg = reduce16x16(vg, l15), db = reduce16x16(vb, l15);
+    const int f = 16 * (l15 >> 2) + 4 * g + (l15 & 3);
+    red[f] += dg;
+    red[128 + f] += db;
+#undef LJ
+}
+
+// One wave per 16-row tile; workgroup = RW_WAVES independent waves (they only meet to add their LayerNorm-backward
+// partial sums: one row of `aux` per workgroup, like k_rowchain).
+template <bool BF>
+__global__ __launch_bounds__(64 * RW_WAVES, 2) void k_rowwave(EqdChainArg A_) {
+    __shared__ __attribute__((aligned(16))) EqdChainArg A;
+    __shared__ __attribute__((aligned(16))) RwSmem sm;
+    kernarg_to_lds(A, EQD_KERNARG_PTR(A_), 0);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, g = lane >> 4;
+    float* const red = sm.red[wave];
+    for (int i = lane; i < 256; i += 64) red[i] = 0.f;
+    __syncthreads();
+    constexpr int CJ_DW = (int)(sizeof(EqdChainJob) / 4);
+    const int njobs = uni(A.njobs);
+    const int row0 = ((int)blockIdx.x * RW_WAVES + wave) * 16;
+    float* const tiles = &sm.tile[wave][0][0];
+    float* aux = nullptr;
+    JobW Wc = jobw_load(&A.j[0], CJ_DW, lane);
+    const int rows = jw_i(Wc, JW_OFF(EqdLinJob, rows));
+    if (row0 < rows) {      // wave-uniform
+        int rowc = row0 + l15;
+        rowc = rowc < rows ? rowc : rows - 1;
+        int jj = 0;
+        // LayerNorm-backward jobs in front of the first linear job
+        while (jj < njobs && jw_i(Wc, JW_OFF(EqdChainJob, type)) != 0) {
+            rw_lnbwd(Wc, tiles, red, row0, l15, g);
+            aux = jw_p<float>(Wc, JW_OFF(EqdChainJob, aux));
+            ++jj;
+            if (jj < njobs) Wc = jobw_load(&A.j[jj], CJ_DW, lane);
+        }
+        if (jj < njobs) {
+            RwBuf RA, RB;
+            int si = 0, h = 0;
+            f32x4 acc[4] = {f4zero(), f4zero(), f4zero(), f4zero()};
+            rw_load(Wc, 0, 0, jw_i(Wc, JW_OFF(EqdChainJob, src_local)) >= 0, rowc, l15, g, RA);
+            bool done = false;
+            // One sub-step: issue the loads of the NEXT sub-step (the next job's first one included, unless it reads global
+            // data this chain writes: EqdChainJob.prefetch_next), multiply the current one; after a job's last sub-step
+            // its epilogue and the LayerNorm-backward jobs that follow it.
+#define RW_STEP(CUR, NXT)                                                                                              \
+    {                                                                                                                  \
+        const int nsrc = jw_i(Wc, JW_OFF(EqdLinJob, nsrc));                                                            \
+        const int sb = JW_OFF(EqdLinJob, s) + si * JW_SRC_DW;                                                          \
+        const int Ks = jw_i(Wc, sb + JW_OFF(EqdLinSrc, K));                                                            \
+        const bool src_end = h == 2 || (h == 1 && Ks <= 64);                                                           \
+        const bool last = src_end && si + 1 >= nsrc;                                                                   \
+        int njj = jj, nsi = src_end ? si + 1 : si, nh = src_end ? 0 : h + 1;                                           \
+        bool have_next = true, early = true;                                                                           \
+        JobW Wn = Wc;                                                                                                  \
+        if (last) {                                                                                                    \
+            njj = jw_i(Wc, JW_OFF(EqdChainJob, next_lin));                                                             \
+            nsi = 0;                                                                                                   \
+            have_next = njj >= 0;                                                                                      \
+            early = jw_i(Wc, JW_OFF(EqdChainJob, prefetch_next)) >= 0;                                                 \
+            if (have_next) Wn = jobw_load(&A.j[njj], CJ_DW, lane);                                                     \
+        }                                                                                                              \
+        const bool nloc = have_next && jw_i(Wn, JW_OFF(EqdChainJob, src_local) + nsi) >= 0;                            \
+        if (have_next && early) rw_load(Wn, nsi, nh, nloc, rowc, l15, g, NXT);                                         \
+        const bool tp = jw_i(Wc, JW_OFF(EqdLinJob, s) + JW_OFF(EqdLinSrc, w_cs)) != 1;                                 \
+        if (h == 2) {                                                                                                  \
+            rw_mma_rest<BF>(CUR, Ks, g, acc);                                                                          \
+        } else {                                                                                                       \
+            const int loc = jw_i(Wc, JW_OFF(EqdChainJob, src_local) + si);                                             \
+            f32x4 Bv[2];                                                                                               \
+            if (loc >= 0) {                                                                                            \
+                const float* T = tiles + loc * (16 * RW_S) + l15 * RW_S + 4 * g + 32 * h;                              \
+                _Pragma("unroll") for (int i = 0; i < 2; ++i) Bv[i] = *(const f32x4*)(T + 16 * i);                     \
+            } else {                                                                                                   \
+                const bool masked = jw_p<const float>(Wc, sb + JW_OFF(EqdLinSrc, mask)) != nullptr;                    \
+                const float slope = jw_f(Wc, JW_OFF(EqdLinJob, slope));                                                \
+                _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                        \
+                    Bv[i] = CUR.x[i];                                                                                  \
+                    if (masked) {                                                                                      \
+                        _Pragma("unroll") for (int b = 0; b < 4; ++b) Bv[i][b] *= lrelu_grad(CUR.xm[i][b], slope);     \
+                    }                                                                                                  \
+                }                                                                                                      \
+            }                                                                                                          \
+            rw_mma<BF>(CUR, Bv, tp, acc);                                                                              \
+        }                                                                                                              \
+        if (last) {                                                                                                    \
+            rw_epilogue(Wc, tp, acc, tiles, row0, l15, g);                                                             \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) acc[i] = f4zero();                                           \
+            const int stop = have_next ? njj : njobs;                                                                  \
+            for (int tj = jj + 1; tj < stop; ++tj) {                                                                   \
+                const JobW Wt = jobw_load(&A.j[tj], CJ_DW, lane);                                                      \
+                rw_lnbwd(Wt, tiles, red, row0, l15, g);                                                                \
+                aux = jw_p<float>(Wt, JW_OFF(EqdChainJob, aux));                                                       \
+            }                                                                                                          \
+        }                                                                                                              \
+        if (have_next && !early) rw_load(Wn, nsi, nh, nloc, rowc, l15, g, NXT);                                        \
+        if (!have_next) done = true;                                                                                   \
+        jj = njj;                                                                                                      \
+        si = nsi;                                                                                                      \
+        h = nh;                                                                                                        \
+        Wc = Wn;                                                                                                       \
+    }
+            while (!done) {
+                RW_STEP(RA, RB)
+                if (done) break;
+                RW_STEP(RB, RA)
+            }
+#undef RW_STEP
+        }
+    }
+    __syncthreads();
+    // (wave 0 always has rows: its tile index is 4 blockIdx.x < number of tiles)
+    if (wave == 0 && aux) {
+        float* ap = aux + (size_t)blockIdx.x * 256;
+        for (int i = lane; i < 256; i += 64) ap[i] = (sm.red[0][i] + sm.red[1][i]) + (sm.red[2][i] + sm.red[3][i]);
+    }
+}

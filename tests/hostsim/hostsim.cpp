@@ -223,6 +223,18 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
             }
             if (g_progress == before && remaining > 0) {
                 fprintf(stderr, "hostsim: deadlock (divergent barrier/collective) in block %u,%u\n", bx, by);
+                fprintf(stderr, "  block barrier: %d of %d threads arrived\n", g_blk_arrived, g_nthreads);
+                for (int w = 0; w < (nt + 63) / 64; ++w) {
+                    unsigned lo = ~0u, hi = 0;
+                    int ndone = 0;
+                    for (int t = 64 * w; t < nt && t < 64 * w + 64; ++t) {
+                        lo = g_fib[t].ncoll < lo ? g_fib[t].ncoll : lo;
+                        hi = g_fib[t].ncoll > hi ? g_fib[t].ncoll : hi;
+                        ndone += g_fib[t].done;
+                    }
+                    fprintf(stderr, "  wave %d: %d lanes waiting at a wave collective, collectives executed %u..%u, %d lanes finished\n",
+                            w, g_wave[w].arrived, lo, hi, ndone);
+                }
                 abort();
             }
         }

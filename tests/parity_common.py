@@ -604,6 +604,24 @@ def build_model(args, sd, dev):
     return net
 
 
+def launch_names_of_a_step(dev, name):
+    """kernel names of one forward + backward of a golden case, from the library's launch profiler"""
+    z, meta, args, raw = load_case(name)
+    net = build_model(args, state_dict_for(meta, args), dev)
+    g = G.batch_pairs(pairs_from_raw(raw)).to(dev)
+    lib_ = lib()
+    L.profiling = True
+    L.check(lib_.eqd_profile_begin(st(dev), 1024))
+    try:
+        port.scalar_loss(net(g, epoch=0)).backward()
+        sync(dev)
+    finally:
+        n = lib_.eqd_profile_end()
+        L.profiling = False
+    assert n > 0
+    return [lib_.eqd_profile_name(i).decode() for i in range(n)]
+
+
 def check_model_case(dev, name, check_grads=True):
     """Whole model vs the golden vectors captured from the imported reference."""
     z, meta, args, raw = load_case(name)

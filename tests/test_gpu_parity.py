@@ -78,8 +78,26 @@ def test_model_two_row_tiles(dev, name, monkeypatch):
     """the 32-rows-per-workgroup variants of the row kernels (EQD_ROW_TILES=2) on small golden cases"""
     from tests import parity_common as pc
     monkeypatch.setenv('EQD_ROW_TILES', '2')
+    monkeypatch.setenv('EQD_ROWWAVE', '0')
     pc.check_linear(dev)
     pc.check_model_case(dev, name)
+
+
+@pytest.mark.parametrize('rowwave', ['0', '1'])
+def test_row_kernels_both_forms(dev, rowwave, monkeypatch):
+    """k_rowwave (one wave per 16-row tile, chain in registers: every node-level chain of the 64-wide layers) and
+    k_rowchain / k_linear (four waves per tile: layer 0, and everything under EQD_ROWWAVE=0) against the golden vectors
+    and the oracle; the switch must really select the kernel."""
+    from tests import parity_common as pc
+    monkeypatch.setenv('EQD_ROWWAVE', rowwave)
+    pc.check_linear(dev)
+    pc.check_linear_atb_bf16(dev)
+    for name in ('D_degraded3', 'B_b3_dips8'):
+        pc.check_model_case(dev, name)
+    pc.check_model_bf16(dev, 'D_degraded3')
+    names = pc.launch_names_of_a_step(dev, 'D_degraded3')
+    assert ('k_rowwave' in names) == (rowwave == '1'), sorted(set(names))
+    assert 'k_rowchain' in names
 
 
 @pytest.mark.parametrize('name', ['D_degraded3', 'A_b1_shared5'])

@@ -71,8 +71,22 @@ def test_model_vs_golden(name):
 def test_model_two_row_tiles(name, monkeypatch):
     """the 32-rows-per-workgroup variants of the row kernels (EQD_ROW_TILES=2) on a small golden case"""
     monkeypatch.setenv('EQD_ROW_TILES', '2')
+    monkeypatch.setenv('EQD_ROWWAVE', '0')
     pc.check_linear(DEV)
     pc.check_model_case(DEV, name)
+
+
+@pytest.mark.parametrize('rowwave', ['0', '1'])
+def test_row_kernels_both_forms(rowwave, monkeypatch):
+    """The node-level chains have two kernels: k_rowwave (one wave per 16-row tile, chain in registers; every chain of the
+    layers >= 1) and k_rowchain / k_linear (four waves per tile, for layer 0's 69-wide jobs and under EQD_ROWWAVE=0).  Both
+    must reproduce the golden vectors, and the switch must really select the kernel."""
+    monkeypatch.setenv('EQD_ROWWAVE', rowwave)
+    pc.check_linear(DEV)
+    pc.check_model_case(DEV, 'D_degraded3')
+    names = pc.launch_names_of_a_step(DEV, 'D_degraded3')
+    assert ('k_rowwave' in names) == (rowwave == '1'), sorted(set(names))
+    assert 'k_rowchain' in names            # layer 0 (and everything under EQD_ROWWAVE=0)
 
 
 def test_model_bf16_mode():
