@@ -410,14 +410,19 @@ static int lin_check_sources(const EqdLinJob& J) {
 }
 
 // ---- k_rowwave (eqd_rowwave_inl.h): which chains it takes ---------------------------------------------------------
-// EQD_ROWWAVE=0 keeps every chain on k_rowchain / k_linear, =1 (default) uses k_rowwave for every eligible chain.
-static bool rw_enabled() {
+// Which kernel: k_rowwave streams every weight through each wave's own loads, k_rowchain stages a step's weights once
+// per four-wave workgroup.  A CU pulls ~10-12 B/clock from L2 either way (profiles/r02_exp_trace_rowwave_*.txt), so with
+// one tile per CU (config B: 200 tiles) the four waves that share a tile's weights finish sooner (B 6 337 vs 5 011
+// pairs/s), while with many tiles per CU the barrier-free wave-per-tile form wins (C fp32 +3 %, bf16 +5.7 %).
+// Default: k_rowwave from 4 tiles per CU; EQD_ROWWAVE=0 / 1 forces k_rowchain + k_linear / k_rowwave (tests).
+static bool rw_enabled(int rows) {
     const char* f = getenv("EQD_ROWWAVE");
-    return !(f && f[0] == '0' && f[1] == 0);
+    if (f && (f[0] == '0' || f[0] == '1') && f[1] == 0) return f[0] == '1';
+    return (rows + 15) / 16 >= 4 * eqd_num_cus();
 }
 static bool rw_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 static bool rw_eligible(const EqdChainJob* jobs, int njobs, int rows) {
-    if (!rw_enabled() || njobs <= 0 || rows <= 0) return false;
+    if (njobs <= 0 || rows <= 0 || !rw_enabled(rows)) return false;
     for (int i = 0; i < njobs; ++i) {
         const EqdChainJob& C = jobs[i];
         const EqdLinJob& J = C.lin;
@@ -440,10 +445,21 @@ static bool rw_eligible(const EqdChainJob* jobs, int njobs, int rows) {
             if (local && (C.src_local[s] >= LIN_LOCALS || S.K != 64 || S.mask)) return false;
             if (!local && !S.X) return false;
             if (S.K == 64) continue;
-            if (S.K < 64 || S.K > 80 || tp || local || S.mask) return false;
+            if (S.K < 64 || S.K > 80 || local || S.mask) return false;
         }
     }
     (void)rw_aligned16;
+    // the kernel fetches a job's first operands while the previous job is still being multiplied: every job's first
+    // source must be an LDS tile or global data that no earlier job of the chain writes (chain_links: prefetch_next)
+    for (int i = 0; i < njobs; ++i) {
+        if (jobs[i].type != 0 || jobs[i].src_local[0] >= 0) continue;
+        const EqdLinSrc& S0 = jobs[i].lin.s[0];
+        for (int m = 0; m < i; ++m) {
+            const float* outs[2] = {jobs[m].lin.Y, jobs[m].lin.pre_ln};
+            for (int q = 0; q < 2; ++q)
+                if (outs[q] && (outs[q] == S0.X || outs[q] == S0.mask)) return false;
+        }
+    }
     return true;
 }
 static void chain_links(EqdChainArg& arg, const EqdChainJob* jobs, int njobs) {

@@ -40,99 +40,161 @@ struct RwSmem {
     float red[RW_WAVES][256];      // LayerNorm-backward partial sums of the wave's rows: [d gamma 0..127 | d beta 128..255]
 };
 
-__device__ __forceinline__ void rw_load(const JobW& W, int si, int h, bool local, int rowc, int l15, int g, RwBuf& R) {
-    const EqdLinSrc S = jw_src(W, si);
-    if (h == 2) {        // k-contiguous weights, global source (rw_eligible)
-        const int n = S.K - 64 - 4 * g;
-        R.x[0] = ld4u_raw(S.X + (size_t)rowc * S.ldx + 64 + 4 * g, n, S.X);
+// Loads of one sub-step.  ALWAYS the same 12 instructions in the same register order - 8 weight vectors, 2 source-row
+// vectors, 2 mask-row vectors - whatever the source looks like: what a sub-step does not need (rows of an LDS-resident
+// source, an absent mask, the second half of the columns 64 .. K - 1, everything when the chain has no further sub-step)
+// is fetched from a harmless address (the start of the weight matrix: a cache hit).  With a load count that depends on
+// the descriptor the compiler cannot tell how many loads are in flight when the PREVIOUS buffer is consumed and waits
+// for all of them (s_waitcnt vmcnt(0)): the prefetch would be serialised behind the MFMAs it is meant to overlap
+// (measured: 2 000-3 500 clocks of issue stall per sub-step, profiles/r02_exp_trace_rowwave_*.txt).  Every address is a
+// wave-uniform base (SGPR pair) + a 32-bit per-lane byte offset, so a load costs one scalar add and no 64-bit VALU work.
+__device__ __forceinline__ f32x4 rw_ld(const char* base, unsigned off) { return *(const EQD_GAS f4v*)(base + off); }
+
+__device__ __forceinline__ void rw_load(const JobW& W, int si, int h, bool local, bool valid, int rowc, int l15, int g,
+                                        RwBuf& R) {
+    const EqdLinSrc S = jw_src(W, valid ? si : 0);
+    const bool tp = S.w_cs != 1;
+    const char* const wb = (const char*)S.W;
+    const unsigned lane16 = 16u * (unsigned)(l15 + 16 * g);
+    const bool xreal = valid && !local;
+    const char* const xb = xreal ? (const char*)S.X : wb;
+    const char* const mb_ = (xreal && S.mask) ? (const char*)S.mask : xb;
+    if (valid && h == 2) {        // columns 64 .. K - 1: k = 64 + 4 g + b of lane group g, zeros beyond K (rw_mma_rest)
+        const int n = S.K - 64 - 4 * g;         // valid columns of this lane's 4
+        if (tp) {                 // W[k][4 l15 ..]: whole vectors; rows beyond K are read at row K - 1 and dropped later
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) R.w[mb] = ld4u_raw(S.W + (size_t)(16 * mb + l15) * S.w_rs + 64 + 4 * g, n, S.W);
+            for (int b = 0; b < 4; ++b) {
+                int k = 64 + 4 * g + b;
+                k = k < S.K ? k : S.K - 1;
+                R.w[b] = rw_ld(wb, 4u * (unsigned)(k * S.w_cs + 4 * l15));
+            }
+        } else {                  // W[16 mb + l15][64 + 4 g ..]: unaligned-tail loads (ld4u_raw: vector ENDING at the last column)
+            const int sh = (n > 0 && n < 4) ? 4 - n : 0;
+            const unsigned wl = n > 0 ? 4u * (unsigned)(l15 * S.w_rs + 64 + 4 * g - sh) : 4u * (unsigned)(l15 * S.w_rs);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) R.w[mb] = rw_ld(wb + (size_t)(16 * mb) * S.w_rs * 4, wl);
+        }
+#pragma unroll
+        for (int q = 4; q < 8; ++q) R.w[q] = rw_ld(wb, lane16);
+        {
+            const int sh = (n > 0 && n < 4) ? 4 - n : 0;
+            const unsigned xl = n > 0 ? 4u * (unsigned)(rowc * S.ldx + 64 + 4 * g - sh) : 4u * (unsigned)(rowc * S.ldx);
+            R.x[0] = rw_ld(xb, xreal ? xl : lane16);
+        }
+        R.x[1] = rw_ld(wb, lane16);
+        R.xm[0] = rw_ld(wb, lane16);
+        R.xm[1] = rw_ld(wb, lane16);
         return;
     }
-    if (!local) {
-        const float* xp = S.X + (size_t)rowc * S.ldx + 4 * g + 32 * h;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) R.x[i] = *(const EQD_GAS f4v*)(xp + 16 * i);
-        if (S.mask) {
-            const float* mp = S.mask + (size_t)rowc * S.ldx + 4 * g + 32 * h;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) R.xm[i] = *(const EQD_GAS f4v*)(mp + 16 * i);
-        }
-    }
-    if (S.w_cs == 1) {
-        const float* wp = S.W + (size_t)l15 * S.w_rs + 4 * g + 32 * h;
+    const int hh = valid ? h : 0;
+    if (tp) {
+        const unsigned wl = 4u * (unsigned)(4 * g * S.w_cs + 4 * l15);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) R.w[4 * i + mb] = *(const EQD_GAS f4v*)(wp + (size_t)(16 * mb) * S.w_rs + 16 * i);
+            for (int b = 0; b < 4; ++b) R.w[4 * i + b] = rw_ld(wb + (size_t)(32 * hh + 16 * i + b) * S.w_cs * 4, wl);
     } else {
-        const float* wp = S.W + (size_t)(4 * g + 32 * h) * S.w_cs + 4 * l15;
+        const unsigned wl = 4u * (unsigned)(l15 * S.w_rs + 4 * g);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) R.w[4 * i + b] = *(const EQD_GAS f4v*)(wp + (size_t)(16 * i + b) * S.w_cs);
+            for (int mb = 0; mb < 4; ++mb)
+                R.w[4 * i + mb] = rw_ld(wb + ((size_t)(16 * mb) * S.w_rs + 32 * hh + 16 * i) * 4, wl);
     }
+    const unsigned xl = xreal ? 4u * (unsigned)(rowc * S.ldx + 4 * g) : lane16;
+    const size_t xu = xreal ? (size_t)(32 * hh) * 4 : 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) R.x[i] = rw_ld(xb + xu + (xreal ? 64 * i : 0), xl);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) R.xm[i] = rw_ld(mb_ + xu + (xreal ? 64 * i : 0), xl);
 }
 
-// the 32 (fp32) / 8 (bf16) MFMAs of a sub-step h < 2; Bv[i]: the lane's 4 features of a = 2 h + i
+// MFMA operands of one sub-step, COPIED out of the load buffer (RwBuf) once its loads have landed: the copy is what
+// decouples the matrix instructions from the loads in flight - they read registers no load ever targets, so the compiler
+// has nothing to wait for in front of them, whatever the control flow around the prefetch looks like (with the MFMAs
+// reading the load buffers directly it waited for the NEXT sub-step's loads as well: 4 800 clocks per sub-step instead of
+// ~1 400, profiles/r02_exp_trace_rowwave_*.txt).  The mask product and, in bf16 mode, the rounding happen in the copy.
 template <bool BF>
-__device__ __forceinline__ void rw_mma(const RwBuf& R, const f32x4 (&Bv)[2], bool tp, f32x4 (&acc)[4]) {
-    if (!tp) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if constexpr (BF) {
-                const s16x4 bp = pack_bf4(Bv[i][0], Bv[i][1], Bv[i][2], Bv[i][3]);
-#pragma unroll
-                for (int mb = 0; mb < 4; ++mb) {
-                    const f32x4 w = R.w[4 * i + mb];
-                    acc[mb] = mfma_bf(pack_bf4(w[0], w[1], w[2], w[3]), bp, acc[mb]);
-                }
-            } else {
-#pragma unroll
-                for (int b = 0; b < 4; ++b)
-#pragma unroll
-                    for (int mb = 0; mb < 4; ++mb) acc[mb] = mfma4(R.w[4 * i + mb][b], Bv[i][b], acc[mb]);
-            }
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if constexpr (BF) {
-                const s16x4 bp = pack_bf4(Bv[i][0], Bv[i][1], Bv[i][2], Bv[i][3]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[j] = mfma_bf(pack_bf4(R.w[4 * i][j], R.w[4 * i + 1][j], R.w[4 * i + 2][j], R.w[4 * i + 3][j]), bp, acc[j]);
-            } else {
-#pragma unroll
-                for (int b = 0; b < 4; ++b)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[j] = mfma4(R.w[4 * i + b][j], Bv[i][b], acc[j]);
-            }
-        }
-    }
-}
+struct RwOps;
+template <>
+struct RwOps<false> {
+    f32x4 w[8], x[2];
+};
+template <>
+struct RwOps<true> {
+    s16x4 w[8], x[2];      // non-transposed: w[4 i + mb] = the lane's 4 k-values; transposed: w[4 i + j] gathered over b
+};
 
-// sub-step h = 2, columns 64 .. K - 1 of a wide source: lane group g contributes k = 64 + 4 g + b (zeros beyond K)
 template <bool BF>
-__device__ __forceinline__ void rw_mma_rest(const RwBuf& R, int K, int g, f32x4 (&acc)[4]) {
-    const int n = K - 64 - 4 * g;
-    const float4 xf = ld4u_fix(R.x[0], n);
-    const float xv[4] = {xf.x, xf.y, xf.z, xf.w};
-    float wv[4][4];
+__device__ __forceinline__ void rw_take(const RwBuf& R, bool tp, bool masked, float slope, bool rest, int n_rest,
+                                        RwOps<BF>& O) {
+    f32x4 x[2] = {R.x[0], R.x[1]};
+    f32x4 w[8];
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
-        const float4 wf = ld4u_fix(R.w[mb], n);
-        wv[mb][0] = wf.x; wv[mb][1] = wf.y; wv[mb][2] = wf.z; wv[mb][3] = wf.w;
+    for (int q = 0; q < 8; ++q) w[q] = R.w[q];
+    if (rest) {      // columns 64 .. K - 1: zeros beyond K; non-transposed weights arrive as unaligned-tail vectors
+        const float4 xf = ld4u_fix(R.x[0], n_rest);
+        x[0] = f32x4{xf.x, xf.y, xf.z, xf.w};
+        x[1] = f4zero();
+        if (!tp) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const float4 wf = ld4u_fix(R.w[mb], n_rest);
+                w[mb] = f32x4{wf.x, wf.y, wf.z, wf.w};
+            }
+        }
+    } else if (masked) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) x[i][b] *= lrelu_grad(R.xm[i][b], slope);
     }
     if constexpr (BF) {
-        const s16x4 bp = pack_bf4(xv[0], xv[1], xv[2], xv[3]);
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) acc[mb] = mfma_bf(pack_bf4(wv[mb][0], wv[mb][1], wv[mb][2], wv[mb][3]), bp, acc[mb]);
+        for (int i = 0; i < 2; ++i) O.x[i] = pack_bf4(x[i][0], x[i][1], x[i][2], x[i][3]);
+        if (!tp) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) O.w[q] = pack_bf4(w[q][0], w[q][1], w[q][2], w[q][3]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) O.w[4 * i + j] = pack_bf4(w[4 * i][j], w[4 * i + 1][j], w[4 * i + 2][j], w[4 * i + 3][j]);
+        }
     } else {
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int i = 0; i < 2; ++i) O.x[i] = x[i];
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) acc[mb] = mfma4(wv[mb][b], xv[b], acc[mb]);
+        for (int q = 0; q < 8; ++q) O.w[q] = w[q];
+    }
+}
+
+// the 32 (fp32) / 8 (bf16) MFMAs of a sub-step; Bl: B operand of an LDS-resident source (fp32), else O.x.  ni: 2, or 1
+// for the columns 64 .. K - 1 (only a = 4 exists)
+template <bool BF>
+__device__ __forceinline__ void rw_mma(const RwOps<BF>& O, bool local, const f32x4 (&Bl)[2], bool tp, int ni, f32x4 (&acc)[4]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (i < ni) {
+            if constexpr (BF) {
+                const s16x4 bp = local ? pack_bf4(Bl[i][0], Bl[i][1], Bl[i][2], Bl[i][3]) : O.x[i];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = mfma_bf(O.w[4 * i + q], bp, acc[q]);
+            } else {
+                const f32x4 bv = local ? Bl[i] : O.x[i];
+                if (!tp) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+#pragma unroll
+                        for (int mb = 0; mb < 4; ++mb) acc[mb] = mfma4(O.w[4 * i + mb][b], bv[b], acc[mb]);
+                } else {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[j] = mfma4(O.w[4 * i + b][j], bv[b], acc[j]);
+                }
+            }
+        }
     }
 }
 
@@ -345,78 +407,54 @@ __global__ __launch_bounds__(64 * RW_WAVES, 2) void k_rowwave(EqdChainArg A_) {
             ++jj;
             if (jj < njobs) Wc = jobw_load(&A.j[jj], CJ_DW, lane);
         }
-        if (jj < njobs) {
-            RwBuf RA, RB;
-            int si = 0, h = 0;
+        int trc = 0;      // sub-step counter of the phase-trace experiments (profiles/exp_trace_rowwave.py)
+        (void)trc;
+        // linear jobs, one after the other; per job a two-stage pipeline over its sub-steps (32 source columns each):
+        // the loads of sub-step s + 1 are in flight while sub-step s is multiplied
+        while (jj < njobs) {
+            const int nsrc = jw_i(Wc, JW_OFF(EqdLinJob, nsrc));
+            const bool tp = jw_i(Wc, JW_OFF(EqdLinJob, s) + JW_OFF(EqdLinSrc, w_cs)) != 1;
+            const float slope = jw_f(Wc, JW_OFF(EqdLinJob, slope));
             f32x4 acc[4] = {f4zero(), f4zero(), f4zero(), f4zero()};
-            rw_load(Wc, 0, 0, jw_i(Wc, JW_OFF(EqdChainJob, src_local)) >= 0, rowc, l15, g, RA);
-            bool done = false;
-            // One sub-step: issue the loads of the NEXT sub-step (the next job's first one included, unless it reads global
-            // data this chain writes: EqdChainJob.prefetch_next), multiply the current one; after a job's last sub-step
-            // its epilogue and the LayerNorm-backward jobs that follow it.
-#define RW_STEP(CUR, NXT)                                                                                              \
-    {                                                                                                                  \
-        const int nsrc = jw_i(Wc, JW_OFF(EqdLinJob, nsrc));                                                            \
-        const int sb = JW_OFF(EqdLinJob, s) + si * JW_SRC_DW;                                                          \
-        const int Ks = jw_i(Wc, sb + JW_OFF(EqdLinSrc, K));                                                            \
-        const bool src_end = h == 2 || (h == 1 && Ks <= 64);                                                           \
-        const bool last = src_end && si + 1 >= nsrc;                                                                   \
-        int njj = jj, nsi = src_end ? si + 1 : si, nh = src_end ? 0 : h + 1;                                           \
-        bool have_next = true, early = true;                                                                           \
-        JobW Wn = Wc;                                                                                                  \
-        if (last) {                                                                                                    \
-            njj = jw_i(Wc, JW_OFF(EqdChainJob, next_lin));                                                             \
-            nsi = 0;                                                                                                   \
-            have_next = njj >= 0;                                                                                      \
-            early = jw_i(Wc, JW_OFF(EqdChainJob, prefetch_next)) >= 0;                                                 \
-            if (have_next) Wn = jobw_load(&A.j[njj], CJ_DW, lane);                                                     \
-        }                                                                                                              \
-        const bool nloc = have_next && jw_i(Wn, JW_OFF(EqdChainJob, src_local) + nsi) >= 0;                            \
-        if (have_next && early) rw_load(Wn, nsi, nh, nloc, rowc, l15, g, NXT);                                         \
-        const bool tp = jw_i(Wc, JW_OFF(EqdLinJob, s) + JW_OFF(EqdLinSrc, w_cs)) != 1;                                 \
-        if (h == 2) {                                                                                                  \
-            rw_mma_rest<BF>(CUR, Ks, g, acc);                                                                          \
-        } else {                                                                                                       \
-            const int loc = jw_i(Wc, JW_OFF(EqdChainJob, src_local) + si);                                             \
-            f32x4 Bv[2];                                                                                               \
-            if (loc >= 0) {                                                                                            \
-                const float* T = tiles + loc * (16 * RW_S) + l15 * RW_S + 4 * g + 32 * h;                              \
-                _Pragma("unroll") for (int i = 0; i < 2; ++i) Bv[i] = *(const f32x4*)(T + 16 * i);                     \
-            } else {                                                                                                   \
-                const bool masked = jw_p<const float>(Wc, sb + JW_OFF(EqdLinSrc, mask)) != nullptr;                    \
-                const float slope = jw_f(Wc, JW_OFF(EqdLinJob, slope));                                                \
-                _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                        \
-                    Bv[i] = CUR.x[i];                                                                                  \
-                    if (masked) {                                                                                      \
-                        _Pragma("unroll") for (int b = 0; b < 4; ++b) Bv[i][b] *= lrelu_grad(CUR.xm[i][b], slope);     \
-                    }                                                                                                  \
-                }                                                                                                      \
-            }                                                                                                          \
-            rw_mma<BF>(CUR, Bv, tp, acc);                                                                              \
-        }                                                                                                              \
-        if (last) {                                                                                                    \
-            rw_epilogue(Wc, tp, acc, tiles, row0, l15, g);                                                             \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) acc[i] = f4zero();                                           \
-            const int stop = have_next ? njj : njobs;                                                                  \
-            for (int tj = jj + 1; tj < stop; ++tj) {                                                                   \
-                const JobW Wt = jobw_load(&A.j[tj], CJ_DW, lane);                                                      \
-                rw_lnbwd(Wt, tiles, red, row0, l15, g);                                                                \
-                aux = jw_p<float>(Wt, JW_OFF(EqdChainJob, aux));                                                       \
-            }                                                                                                          \
-        }                                                                                                              \
-        if (have_next && !early) rw_load(Wn, nsi, nh, nloc, rowc, l15, g, NXT);                                        \
-        if (!have_next) done = true;                                                                                   \
-        jj = njj;                                                                                                      \
-        si = nsi;                                                                                                      \
-        h = nh;                                                                                                        \
-        Wc = Wn;                                                                                                       \
-    }
-            while (!done) {
-                RW_STEP(RA, RB)
-                if (done) break;
-                RW_STEP(RB, RA)
+            RwBuf R;
+            RwOps<BF> O;
+            int si = 0, h = 0;
+            rw_load(Wc, 0, 0, jw_i(Wc, JW_OFF(EqdChainJob, src_local)) >= 0, true, rowc, l15, g, R);
+            for (;;) {
+                EQD_TR(100 + 3 * trc);
+                const int sb = JW_OFF(EqdLinJob, s) + si * JW_SRC_DW;
+                const int Ks = jw_i(Wc, sb + JW_OFF(EqdLinSrc, K));
+                const int loc = jw_i(Wc, JW_OFF(EqdChainJob, src_local) + si);
+                const bool masked = jw_p<const float>(Wc, sb + JW_OFF(EqdLinSrc, mask)) != nullptr;
+                rw_take<BF>(R, tp, masked && loc < 0, slope, h == 2, Ks - 64 - 4 * g, O);      // waits for the loads
+                const bool src_end = h == 2 || (h == 1 && Ks <= 64);
+                const bool more = !(src_end && si + 1 >= nsrc);
+                const int nsi = src_end ? si + 1 : si, nh = src_end ? 0 : h + 1;
+                if (more) rw_load(Wc, nsi, nh, jw_i(Wc, JW_OFF(EqdChainJob, src_local) + nsi) >= 0, true, rowc, l15, g, R);
+                EQD_TR(101 + 3 * trc);
+                f32x4 Bl[2] = {f4zero(), f4zero()};
+                if (loc >= 0) {
+                    const float* T = tiles + loc * (16 * RW_S) + l15 * RW_S + 4 * g + 32 * h;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) Bl[i] = *(const f32x4*)(T + 16 * i);
+                }
+                rw_mma<BF>(O, loc >= 0, Bl, tp, h == 2 ? 1 : 2, acc);
+                EQD_TR(102 + 3 * trc);
+                ++trc;
+                if (!more) break;
+                si = nsi;
+                h = nh;
             }
-#undef RW_STEP
+            rw_epilogue(Wc, tp, acc, tiles, row0, l15, g);
+            // the LayerNorm-backward jobs behind it, then the next linear job
+            ++jj;
+            while (jj < njobs) {
+                Wc = jobw_load(&A.j[jj], CJ_DW, lane);
+                if (jw_i(Wc, JW_OFF(EqdChainJob, type)) == 0) break;
+                rw_lnbwd(Wc, tiles, red, row0, l15, g);
+                aux = jw_p<float>(Wc, JW_OFF(EqdChainJob, aux));
+                ++jj;
+            }
         }
     }
     __syncthreads();
