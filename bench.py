@@ -62,7 +62,7 @@ def step_flops_as_written(sizes, L, d0=69, d=64, K=50):
     return tot
 
 
-def kernel_work_model(sizes, L, n_nodes, n_edges, cross=True, d0=69, dh=64, d_emb=64, K=50, fused_fwd=False, rowwave=True):
+def kernel_work_model(sizes, L, n_nodes, n_edges, cross=True, d0=69, dh=64, d_emb=64, K=50, fused_fwd=False, rowwave='k_rowres'):
     """Per-STEP work of each kernel family, from the launch structure of eqd_model_forward / eqd_model_backward
     (csrc/eqd_driver.hip): `flops` = FLOPs the kernel executes on the MFMA pipes for its GEMMs (2 per MAC),
     `flops_written` = the model-as-written share where SURVEY.md section 8d defines one (edge kernels, attention),
@@ -71,15 +71,16 @@ def kernel_work_model(sizes, L, n_nodes, n_edges, cross=True, d0=69, dh=64, d_em
     N, E = float(n_nodes), float(n_edges)
     pp = sum(float(a) * b for a, b in sizes)              # sum over pairs of n_lig * n_rec
     W = {k: dict(flops=0.0, flops_written=0.0, bytes=0.0) for k in
-         ('k_linear', 'k_rowchain', 'k_rowwave', 'k_attn_fwd', 'k_attn_bwd', 'k_edge_fwd', 'k_edge_bwd', 'k_node_gather',
+         ('k_linear', 'k_rowchain', 'k_rowwave', 'k_rowres', 'k_attn_fwd', 'k_attn_bwd', 'k_edge_fwd', 'k_edge_bwd', 'k_node_gather',
           'k_atb', 'k_edge_attn_fwd')}   # k_edge_attn_fwd: the 64-wide layers' edge + attention forward in one launch (small batches)
     for l in range(L):
         d = d0 if l == 0 else dh
         da = (d + 15) // 16 * 16
-        # the node-level jobs of the 64-wide layers run on k_rowwave (one wave per 16-row tile), layer 0's 69-wide ones on
-        # k_linear / k_rowchain (csrc/eqd_node_kernels.hip: rw_eligible)
-        lin = 'k_rowwave' if (rowwave and d == 64) else 'k_linear'
-        chain = 'k_rowwave' if (rowwave and d == 64) else 'k_rowchain'
+        # from 4 tiles per CU the node-level jobs of the 64-wide layers run on k_rowres (weights resident in LDS; `rowwave`
+        # = the name seen in the profile, k_rowwave when forced), layer 0's 69-wide ones and small batches on k_linear /
+        # k_rowchain (csrc/eqd_node_kernels.hip: rw_mode, rw_eligible)
+        lin = rowwave if (rowwave and d == 64) else 'k_linear'
+        chain = rowwave if (rowwave and d == 64) else 'k_rowchain'
         # forward: five node projections (P, Q 64 wide; q, k, v d wide)
         W[lin]['flops'] += N * 2 * d * (128 + 3 * d)
         W[lin]['bytes'] += N * 4 * (d + 128 + 3 * da)
@@ -119,8 +120,8 @@ def kernel_work_model(sizes, L, n_nodes, n_edges, cross=True, d0=69, dh=64, d_em
                                         + (3 * d * d if cross else 0))
         W['k_atb']['bytes'] += N * 4 * (dh + d + d + 64 + da + d0 + 128 + d + 3 * da)
     # head: mlp_h_mean_ROT forward, its data gradient (64 wide), the final dh job of layer 0 (69-wide sources)
-    W['k_rowwave' if rowwave else 'k_linear']['flops'] += N * (2 * 64 * 64 * 2)
-    W['k_rowwave' if rowwave else 'k_linear']['bytes'] += N * 4 * (64 * 4 + 64)
+    W[rowwave or 'k_linear']['flops'] += N * (2 * 64 * 64 * 2)
+    W[rowwave or 'k_linear']['bytes'] += N * 4 * (64 * 4 + 64)
     W['k_linear']['flops'] += N * (2 * d_emb * (4 * d0 + 128))
     W['k_linear']['bytes'] += N * 4 * (3 * 80 + 128 + d0)
     W['k_atb']['flops'] += N * 2 * 64 * 64
@@ -604,7 +605,7 @@ def main():
             try:
                 prof, ev_us, n_launch = profile_step(compute, dev)
                 work = kernel_work_model(sizes, L, packed.n_nodes, packed.n_edges, fused_fwd='k_edge_attn_fwd' in prof,
-                                         rowwave='k_rowwave' in prof)
+                                         rowwave=next((k for k in ('k_rowres', 'k_rowwave') if k in prof), None))
                 allk, ktot = kernel_rooflines(prof, work, dtype == 'bf16', ms_step * 1e3, load_pmc(a.workload))
                 for k in ('k_edge_fwd', 'k_edge_bwd'):     # keep the standalone batched-launch figures beside the in-step ones
                     if k in allk:

@@ -6,6 +6,7 @@
 #include "eqd_common.h"
 #include "eqd_linear_inl.h"
 #include "eqd_rowwave_inl.h"
+#include "eqd_rowres_inl.h"
 
 #include <mutex>
 #include <vector>
@@ -410,19 +411,20 @@ static int lin_check_sources(const EqdLinJob& J) {
 }
 
 // ---- k_rowwave (eqd_rowwave_inl.h): which chains it takes ---------------------------------------------------------
-// Which kernel: k_rowwave streams every weight through each wave's own loads, k_rowchain stages a step's weights once
-// per four-wave workgroup.  A CU pulls ~10-12 B/clock from L2 either way (profiles/r02_exp_trace_rowwave_*.txt), so with
-// one tile per CU (config B: 200 tiles) the four waves that share a tile's weights finish sooner (B 6 337 vs 5 011
-// pairs/s), while with many tiles per CU the barrier-free wave-per-tile form wins (C fp32 +3 %, bf16 +5.7 %).
-// Default: k_rowwave from 4 tiles per CU; EQD_ROWWAVE=0 / 1 forces k_rowchain + k_linear / k_rowwave (tests).
-static bool rw_enabled(int rows) {
+// Which kernel.  k_rowchain / k_linear: four waves per 16-row tile, a step's weights staged per workgroup; k_rowwave:
+// one wave per tile, every wave loads its own weights; k_rowres: persistent 8-wave workgroups, weights resident in LDS.
+// A CU pulls ~10-12 B/clock from L2 whatever the pattern (profiles/r02_exp_trace_rowwave_*.txt), so with about one tile
+// per CU (config B: 200 tiles) the four waves that share a tile's weights finish first, and with many tiles per CU the
+// kernel that fetches the weights once per CU does.  Default: k_rowres from 4 tiles per CU, k_rowchain / k_linear
+// below; EQD_ROWWAVE = 0 / 1 / 2 forces k_rowchain + k_linear / k_rowwave / k_rowres for every eligible chain (tests).
+static int rw_mode(int rows) {
     const char* f = getenv("EQD_ROWWAVE");
-    if (f && (f[0] == '0' || f[0] == '1') && f[1] == 0) return f[0] == '1';
-    return (rows + 15) / 16 >= 4 * eqd_num_cus();
+    if (f && f[0] >= '0' && f[0] <= '2' && f[1] == 0) return f[0] - '0';
+    return (rows + 15) / 16 >= 4 * eqd_num_cus() ? 2 : 0;
 }
 static bool rw_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 static bool rw_eligible(const EqdChainJob* jobs, int njobs, int rows) {
-    if (njobs <= 0 || rows <= 0 || !rw_enabled(rows)) return false;
+    if (njobs <= 0 || rows <= 0 || rw_mode(rows) == 0) return false;
     for (int i = 0; i < njobs; ++i) {
         const EqdChainJob& C = jobs[i];
         const EqdLinJob& J = C.lin;
@@ -485,8 +487,45 @@ static void chain_links(EqdChainArg& arg, const EqdChainJob* jobs, int njobs) {
         if (ok) arg.j[i].prefetch_next = n;
     }
 }
+// k_rowres keeps ONE intermediate tile per (wave, tile slot): every LDS-resident source must be the tile written last
+static bool rr_single_tile(const EqdChainJob* jobs, int njobs) {
+    int cur = -1;
+    for (int i = 0; i < njobs; ++i) {
+        const EqdChainJob& C = jobs[i];
+        const int ns = C.type != 0 ? 1 : C.lin.nsrc;
+        for (int s = 0; s < ns; ++s)
+            if (C.src_local[s] >= 0 && C.src_local[s] != cur) return false;
+        if (C.out_local >= 0) cur = C.out_local;
+    }
+    return true;
+}
+static int rr_tiles_per_wg(int rows) {
+    const char* f = getenv("EQD_ROWRES_TPS");      // tests: force the tiles per workgroup (1..16) to reach the two-slot paths
+    if (f && f[0]) {
+        const int v = atoi(f);
+        if (v >= 1 && v <= RR_WAVES * RR_TMAX) return v;
+    }
+    const int nt = (rows + 15) / 16, cus = eqd_num_cus();
+    int tps = (nt + cus - 1) / cus;
+    tps = tps < 1 ? 1 : tps;
+    return tps > RR_WAVES * RR_TMAX ? RR_WAVES * RR_TMAX : tps;
+}
+static int rr_blocks(int rows) {
+    const int tps = rr_tiles_per_wg(rows);
+    return ((rows + 15) / 16 + tps - 1) / tps;
+}
 static int rw_blocks(int rows) { return ((rows + 15) / 16 + RW_WAVES - 1) / RW_WAVES; }
+// workgroups (= LayerNorm-backward partial rows) of the launch rw_launch would make
+static int rw_launch_blocks(const EqdChainJob* jobs, int njobs, int rows) {
+    return (rw_mode(rows) == 2 && rr_single_tile(jobs, njobs)) ? rr_blocks(rows) : rw_blocks(rows);
+}
 static int launch_rowwave(const EqdChainArg& arg, int rows, bool bf, hipStream_t st) {
+    if (rw_mode(rows) == 2 && rr_single_tile(arg.j, arg.njobs)) {
+        const int tps = rr_tiles_per_wg(rows);
+        if (bf) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rowres<true>), dim3(rr_blocks(rows)), dim3(64 * RR_WAVES), 0, st, arg, tps);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rowres<false>), dim3(rr_blocks(rows)), dim3(64 * RR_WAVES), 0, st, arg, tps);
+        return eqd_check_launch("k_rowres");
+    }
     if (bf) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rowwave<true>), dim3(rw_blocks(rows)), dim3(64 * RW_WAVES), 0, st, arg);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rowwave<false>), dim3(rw_blocks(rows)), dim3(64 * RW_WAVES), 0, st, arg);
     return eqd_check_launch("k_rowwave");
@@ -524,7 +563,7 @@ int eqd_launch_rowchain(const EqdChainJob* jobs, int njobs, int rows, hipStream_
         }
     const bool bf = njobs > 0 && jobs[0].lin.bf16;     // one arithmetic mode per launch
     if (rw_eligible(jobs, njobs, rows)) {
-        if (partial_rows) *partial_rows = rw_blocks(rows);
+        if (partial_rows) *partial_rows = rw_launch_blocks(jobs, njobs, rows);
         return launch_rowwave(arg, rows, bf, st);
     }
     if (partial_rows) *partial_rows = eqd_rowchain_blocks(rows);

@@ -1,0 +1,275 @@
+// k_rowres: the row-local job chains with the weights RESIDENT in LDS - the form for many tiles per CU.
+//
+// k_rowwave (one wave per 16-row tile, weights loaded by every wave for itself) showed where the node-level chains are
+// bound once the barriers are gone: a CU pulls ~10-12 B/clock through its vector-memory path whatever the pattern
+// (profiles/r02_exp_trace_rowwave_*.txt: ~2 000-5 000 clocks to issue the 12 KB of a 32-column sub-step), and a chain
+// needs 86-168 KB of weights PER TILE that way.  Here a persistent 8-wave workgroup per CU stages each source's weights
+// (<= 21 KB) into LDS ONCE for all the tiles it owns - double buffered, the next source's weights are in flight while
+// the current one is multiplied - and the waves read their MFMA A operands from LDS (128 B/clock per CU).  Global
+// traffic per CU drops to the rows themselves (~1.5 KB per row and chain) + one copy of the weights.
+//
+// Work split: workgroup b owns `tps` consecutive tiles, wave w of it the tiles w, w + 8 (<= RR_TMAX per wave: two
+// accumulator sets).  Loop order: job -> source -> the wave's tiles, so the job's accumulators live in registers across
+// its sources; the chain's intermediate tile (EqdChainJob.out_local) lives in one LDS tile per (wave, tile slot) - the
+// chains this kernel takes (rr_eligible, host) only ever read the tile written last, so every local id names that tile.
+// One workgroup barrier per source (the weight hand-over), none inside.  Arithmetic, layouts (S / P), epilogue and
+// LayerNorm backward are k_rowwave's (eqd_rowwave_inl.h).
+#pragma once
+#include "eqd_rowwave_inl.h"
+
+#define RR_WAVES 8
+#define RR_TMAX 2
+#define RR_WFLOATS (64 * 84)      /* one source: [64][KP] (k-contiguous weights, KP = 68 or 84) or [80][64] (m-contiguous) */
+
+struct RrSmem {
+    float Wl[2][RR_WFLOATS];
+    float tile[RR_WAVES][RR_TMAX][16 * RW_S];
+    float red[RR_WAVES][256];
+};
+
+// global -> registers of one source's weights (all 512 threads; 16-byte vectors, coalesced along the contiguous axis)
+struct RrStage {
+    f32x4 v[3];
+};
+__device__ __forceinline__ int rr_kp(int K) { return K > 64 ? 84 : 68; }      // 4 x odd: conflict-free b128 fragment reads
+
+__device__ __forceinline__ void rr_stage_load(const EqdLinSrc S, int t, RrStage& R) {
+    const bool tp = S.w_cs != 1;
+    if (!tp) {          // W[m][k]: idx -> (m, 4-column group c4); tails of a 69-wide row through the unaligned-tail load
+        const int nc4 = S.K > 64 ? 20 : 16;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int idx = t + 64 * RR_WAVES * j;
+            const int m = idx / nc4, c4 = idx - m * nc4;
+            const int mm = m < 64 ? m : 63;
+            R.v[j] = ld4u_raw(S.W + (size_t)mm * S.w_rs + 4 * c4, S.K - 4 * c4, S.W);
+        }
+    } else {            // W[k][m] (m contiguous): idx -> (k, 4-column group of m); rows k >= K become zeros in LDS
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int idx = t + 64 * RR_WAVES * j;
+            const int k = idx >> 4, c4 = idx & 15;
+            const int kk = k < S.K ? k : S.K - 1;
+            R.v[j] = *(const EQD_GAS f4v*)(S.W + (size_t)kk * S.w_cs + 4 * c4);
+        }
+    }
+}
+__device__ __forceinline__ void rr_stage_store(const EqdLinSrc S, int t, const RrStage& R, float* Wl) {
+    const bool tp = S.w_cs != 1;
+    if (!tp) {
+        const int nc4 = S.K > 64 ? 20 : 16, KP = rr_kp(S.K);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int idx = t + 64 * RR_WAVES * j;
+            const int m = idx / nc4, c4 = idx - m * nc4;
+            if (m < 64) {
+                const float4 f = ld4u_fix(R.v[j], S.K - 4 * c4);
+                *(f32x4*)&Wl[m * KP + 4 * c4] = f32x4{f.x, f.y, f.z, f.w};
+            }
+        }
+    } else {
+        const int nk = S.K > 64 ? 80 : 64;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int idx = t + 64 * RR_WAVES * j;
+            const int k = idx >> 4, c4 = idx & 15;
+            if (k < nk) *(f32x4*)&Wl[k * 64 + 4 * c4] = k < S.K ? R.v[j] : f4zero();
+        }
+    }
+}
+
+// rows of one (source, tile) item as loaded: 64 columns + the 4 columns 64 + 4 g .. of a wide source, and the mask rows
+struct RrRows {
+    f32x4 x[4], xm[4], xr;
+};
+__device__ __forceinline__ void rr_rows_load(const EqdLinSrc S, bool local, int rowc, int g, RrRows& R) {
+    // always 9 loads (see rw_load): what an item does not need comes from the start of the weight matrix
+    const char* const wb = (const char*)S.W;
+    const bool real = !local;
+    const char* const xb = real ? (const char*)S.X : wb;
+    const char* const mb = (real && S.mask) ? (const char*)S.mask : xb;
+    const unsigned xl = real ? 4u * (unsigned)(rowc * S.ldx + 4 * g) : 16u * (unsigned)g;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) R.x[a] = rw_ld(xb + (real ? 64 * a : 0), xl);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) R.xm[a] = rw_ld(mb + (real ? 64 * a : 0), xl);
+    const int n = S.K - 64 - 4 * g;
+    const int sh = (n > 0 && n < 4) ? 4 - n : 0;
+    const unsigned rl = (real && n > 0) ? 4u * (unsigned)(rowc * S.ldx + 64 + 4 * g - sh) : xl;
+    R.xr = rw_ld(xb, rl);
+}
+
+// one (source, tile) item: B operands from the item's rows (global source) or the LDS tile, A operands from the staged
+// weights; 64 (fp32) / 16 (bf16) MFMAs per 64 columns
+template <bool BF>
+__device__ __forceinline__ void rr_item(const float* __restrict__ Wl, int K, bool tp, bool local, const float* T,
+                                        const RrRows& R, bool masked, float slope, int l15, int g, f32x4 (&acc)[4]) {
+    const int KP = rr_kp(K);
+    const int na = K > 64 ? 5 : 4;
+#pragma unroll
+    for (int a = 0; a < 5; ++a) {
+        if (a < na) {
+            f32x4 bv;
+            if (a == 4) {
+                const float4 xf = ld4u_fix(R.xr, K - 64 - 4 * g);
+                bv = f32x4{xf.x, xf.y, xf.z, xf.w};
+            } else if (local) {
+                bv = *(const f32x4*)(T + l15 * RW_S + 16 * a + 4 * g);
+            } else {
+                bv = R.x[a < 4 ? a : 0];
+                if (masked) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) bv[b] *= lrelu_grad(R.xm[a < 4 ? a : 0][b], slope);
+                }
+            }
+            f32x4 w[4];
+            if (!tp) {
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) w[mb] = *(const f32x4*)&Wl[(16 * mb + l15) * KP + 16 * a + 4 * g];
+            } else {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) w[b] = *(const f32x4*)&Wl[(16 * a + 4 * g + b) * 64 + 4 * l15];
+            }
+            if constexpr (BF) {
+                const s16x4 bp = pack_bf4(bv[0], bv[1], bv[2], bv[3]);
+                if (!tp) {
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb) acc[mb] = mfma_bf(pack_bf4(w[mb][0], w[mb][1], w[mb][2], w[mb][3]), bp, acc[mb]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] = mfma_bf(pack_bf4(w[0][j], w[1][j], w[2][j], w[3][j]), bp, acc[j]);
+                }
+            } else {
+                if (!tp) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+#pragma unroll
+                        for (int mb = 0; mb < 4; ++mb) acc[mb] = mfma4(w[mb][b], bv[b], acc[mb]);
+                } else {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[j] = mfma4(w[b][j], bv[b], acc[j]);
+                }
+            }
+        }
+    }
+}
+
+template <bool BF>
+__global__ __launch_bounds__(64 * RR_WAVES, 1) void k_rowres(EqdChainArg A_, int tps) {
+    __shared__ __attribute__((aligned(16))) EqdChainArg A;
+    __shared__ __attribute__((aligned(16))) RrSmem sm;
+    kernarg_to_lds(A, EQD_KERNARG_PTR(A_), 0);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, g = lane >> 4;
+    float* const red = sm.red[wave];
+    for (int i = lane; i < 256; i += 64) red[i] = 0.f;
+    __syncthreads();
+    constexpr int CJ_DW = (int)(sizeof(EqdChainJob) / 4);
+    const int njobs = uni(A.njobs);
+    JobW Wc = jobw_load(&A.j[0], CJ_DW, lane);
+    const int rows = jw_i(Wc, JW_OFF(EqdLinJob, rows));
+    const int ntiles = (rows + 15) >> 4;
+    const int tile0 = (int)blockIdx.x * tps;
+    int nt_wg = ntiles - tile0;
+    nt_wg = nt_wg < tps ? nt_wg : tps;
+    // this wave's tiles: slot s -> tile tile0 + wave + RR_WAVES s
+    int nslots = 0;
+    int row0s[RR_TMAX], rowcs[RR_TMAX];
+#pragma unroll
+    for (int s = 0; s < RR_TMAX; ++s) {
+        const bool has = wave + RR_WAVES * s < nt_wg;
+        nslots += has ? 1 : 0;
+        row0s[s] = (tile0 + wave + RR_WAVES * s) * 16;
+        int rc = row0s[s] + l15;
+        rowcs[s] = has ? (rc < rows ? rc : rows - 1) : 0;
+    }
+    nslots = uni(nslots);
+    float* aux = nullptr;
+    int jj = 0;
+    // LayerNorm-backward jobs in front of the first linear job
+    while (jj < njobs && jw_i(Wc, JW_OFF(EqdChainJob, type)) != 0) {
+#pragma unroll
+        for (int s = 0; s < RR_TMAX; ++s)
+            if (s < nslots) rw_lnbwd(Wc, sm.tile[wave][s], red, row0s[s], l15, g, 0);
+        aux = jw_p<float>(Wc, JW_OFF(EqdChainJob, aux));
+        ++jj;
+        if (jj < njobs) Wc = jobw_load(&A.j[jj], CJ_DW, lane);
+    }
+    int buf = 0;
+    RrStage WS;
+    if (jj < njobs) {      // the first source's weights
+        const EqdLinSrc S0 = jw_src(Wc, 0);
+        rr_stage_load(S0, t, WS);
+        rr_stage_store(S0, t, WS, sm.Wl[0]);
+    }
+    __syncthreads();
+    while (jj < njobs) {
+        const int nsrc = jw_i(Wc, JW_OFF(EqdLinJob, nsrc));
+        const bool tp = jw_i(Wc, JW_OFF(EqdLinJob, s) + JW_OFF(EqdLinSrc, w_cs)) != 1;
+        const float slope = jw_f(Wc, JW_OFF(EqdLinJob, slope));
+        const int next_lin = jw_i(Wc, JW_OFF(EqdChainJob, next_lin));
+        JobW Wnl = Wc;
+        if (next_lin >= 0) Wnl = jobw_load(&A.j[next_lin], CJ_DW, lane);
+        f32x4 acc[RR_TMAX][4];
+#pragma unroll
+        for (int s = 0; s < RR_TMAX; ++s)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[s][q] = f4zero();
+        RrRows XR;
+        {
+            const EqdLinSrc S0 = jw_src(Wc, 0);
+            rr_rows_load(S0, jw_i(Wc, JW_OFF(EqdChainJob, src_local)) >= 0 || nslots == 0, rowcs[0], g, XR);
+        }
+        for (int si = 0; si < nsrc; ++si) {
+            const EqdLinSrc S = jw_src(Wc, si);
+            const int loc = jw_i(Wc, JW_OFF(EqdChainJob, src_local) + si);
+            // weights of the next source (of this job, or the first one of the next linear job): in flight during the items
+            const bool last_src = si + 1 >= nsrc;
+            const bool have_next = !last_src || next_lin >= 0;
+            const EqdLinSrc Sn = last_src ? jw_src(Wnl, 0) : jw_src(Wc, si + 1);
+            const int nloc = last_src ? -1 : jw_i(Wc, JW_OFF(EqdChainJob, src_local) + si + 1);
+            if (nslots == 0 && have_next) rr_stage_load(Sn, t, WS);
+#pragma unroll
+            for (int s = 0; s < RR_TMAX; ++s) {
+                if (s < nslots) {
+                    RrRows XC = XR;          // copy: the MFMAs below never read a register a load in flight targets
+                    // (the weight loads are issued behind the copy: in front of it the copy would wait for them too)
+                    if (s == 0 && have_next) rr_stage_load(Sn, t, WS);
+                    // rows of the next item: the next tile of this source, or the first tile of the next source
+                    const bool more_slots = s + 1 < nslots;
+                    if (more_slots) rr_rows_load(S, loc >= 0, rowcs[s + 1 < RR_TMAX ? s + 1 : 0], g, XR);
+                    else if (!last_src) rr_rows_load(Sn, nloc >= 0, rowcs[0], g, XR);
+                    rr_item<BF>(sm.Wl[buf], S.K, tp, loc >= 0, sm.tile[wave][s], XC, S.mask != nullptr, slope, l15, g, acc[s]);
+                }
+            }
+            if (have_next) rr_stage_store(Sn, t, WS, sm.Wl[buf ^ 1]);
+            __syncthreads();      // every wave is done with Wl[buf]; Wl[buf ^ 1] is complete
+            buf ^= 1;
+        }
+#pragma unroll
+        for (int s = 0; s < RR_TMAX; ++s)
+            if (s < nslots) rw_epilogue(Wc, tp, acc[s], sm.tile[wave][s], row0s[s], l15, g, 0);
+        // the LayerNorm-backward jobs behind it, then the next linear job
+        ++jj;
+        while (jj < njobs) {
+            Wc = jobw_load(&A.j[jj], CJ_DW, lane);
+            if (jw_i(Wc, JW_OFF(EqdChainJob, type)) == 0) break;
+#pragma unroll
+            for (int s = 0; s < RR_TMAX; ++s)
+                if (s < nslots) rw_lnbwd(Wc, sm.tile[wave][s], red, row0s[s], l15, g, 0);
+            aux = jw_p<float>(Wc, JW_OFF(EqdChainJob, aux));
+            ++jj;
+        }
+    }
+    __syncthreads();
+    if (aux) {      // (every wave walks the whole job list, so every wave knows aux)
+        float* ap = aux + (size_t)blockIdx.x * 256;
+        if (t < 256) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int w = 0; w < RR_WAVES; ++w) sacc += sm.red[w][t];
+            ap[t] = sacc;
+        }
+    }
+}

@@ -199,8 +199,9 @@ __device__ __forceinline__ void rw_mma(const RwOps<BF>& O, bool local, const f32
 }
 
 // Y = alpha * f(acc + bias) + beta * R of one job for the wave's rows (EqdLinJob semantics, see equidock_hip.h)
+// tstride: floats between the LDS tiles of consecutive local ids (0: every id names the same tile, k_rowres)
 __device__ __forceinline__ void rw_epilogue(const JobW& W, bool tp, const f32x4 (&acc)[4], float* tiles, int row0, int l15,
-                                            int g) {
+                                            int g, int tstride = 16 * RW_S) {
 #define LJ(f) JW_OFF(EqdLinJob, f)
     const int rows = jw_i(W, LJ(rows));
     const int rowi = row0 + l15;
@@ -286,7 +287,7 @@ __device__ __forceinline__ void rw_epilogue(const JobW& W, bool tp, const f32x4 
     }
     const int out_l = jw_i(W, JW_OFF(EqdChainJob, out_local));
     if (out_l >= 0) {
-        float* T = tiles + out_l * (16 * RW_S) + l15 * RW_S;
+        float* T = tiles + out_l * tstride + l15 * RW_S;
 #pragma unroll
         for (int a = 0; a < 4; ++a) *(f32x4*)(T + ft[a]) = v[a];
         wave_lds_fence();
@@ -295,7 +296,8 @@ __device__ __forceinline__ void rw_epilogue(const JobW& W, bool tp, const f32x4 
 }
 
 // LeakyReLU -> LayerNorm backward of the wave's rows (EqdChainJob.type 1; same mathematics as chain_lnbwd64)
-__device__ __forceinline__ void rw_lnbwd(const JobW& W, float* tiles, float* red, int row0, int l15, int g) {
+__device__ __forceinline__ void rw_lnbwd(const JobW& W, float* tiles, float* red, int row0, int l15, int g,
+                                         int tstride = 16 * RW_S) {
 #define LJ(f) JW_OFF(EqdLinJob, f)
     const int rows = jw_i(W, LJ(rows));
     const int src_l = jw_i(W, JW_OFF(EqdChainJob, src_local)), out_l = jw_i(W, JW_OFF(EqdChainJob, out_local));
@@ -311,7 +313,7 @@ __device__ __forceinline__ void rw_lnbwd(const JobW& W, float* tiles, float* red
         y[a] = *(const EQD_GAS f4v*)(yp + 16 * a);
         gam[a] = *(const EQD_GAS f4v*)(jg + 16 * a + 4 * g);
     }
-    const float* T = tiles + src_l * (16 * RW_S) + l15 * RW_S + 4 * g;
+    const float* T = tiles + src_l * tstride + l15 * RW_S + 4 * g;
 #pragma unroll
     for (int a = 0; a < 4; ++a) o[a] = *(const f32x4*)(T + 16 * a);
     if (!rv) {
@@ -357,7 +359,7 @@ __device__ __forceinline__ void rw_lnbwd(const JobW& W, float* tiles, float* red
         for (int a = 0; a < 4; ++a) *(EQD_GAS f4v*)(zp + 16 * a) = z[a];
     }
     if (out_l >= 0) {
-        float* To = tiles + out_l * (16 * RW_S) + l15 * RW_S + 4 * g;
+        float* To = tiles + out_l * tstride + l15 * RW_S + 4 * g;
 #pragma unroll
         for (int a = 0; a < 4; ++a) *(f32x4*)(To + 16 * a) = z[a];
         wave_lds_fence();

@@ -27,7 +27,7 @@ pmctraffic)
   cd /tmp; export TMPDIR=/tmp
   for W in B C E; do for CNT in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pmc2; rocprofv3 --kernel-trace --pmc $CNT -d /tmp/pmc2 -o p -- python $R/bench.py --eager --workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > /tmp/pmc2_${W}_$CNT.log 2>&1
-    python $R/profiles/pmcstats.py $(find /tmp/pmc2 -name "*.db" | head -1) k_edge k_attn k_rowwave k_rowchain k_atb k_linear k_node k_layer > $O/${TAG}_pmc_${W}_${CNT}.json 2>&1
+    python $R/profiles/pmcstats.py $(find /tmp/pmc2 -name "*.db" | head -1) k_edge k_attn k_rowres k_rowwave k_rowchain k_atb k_linear k_node k_layer > $O/${TAG}_pmc_${W}_${CNT}.json 2>&1
   done; done
   cd $R ;;
 benchB)
@@ -58,7 +58,7 @@ pmc)
   cd /tmp; export TMPDIR=/tmp
   for W in B C E; do for CNT in MfmaUtil SQ_INSTS_VALU_MFMA_MOPS_F32 FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pmc2; rocprofv3 --kernel-trace --pmc $CNT -d /tmp/pmc2 -o p -- python $R/bench.py --eager --workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > /tmp/pmc2_${W}_$CNT.log 2>&1
-    python $R/profiles/pmcstats.py $(find /tmp/pmc2 -name "*.db" | head -1) k_edge k_attn k_rowwave k_rowchain k_atb k_linear k_node k_layer > $O/${TAG}_pmc_${W}_${CNT}.json 2>&1
+    python $R/profiles/pmcstats.py $(find /tmp/pmc2 -name "*.db" | head -1) k_edge k_attn k_rowres k_rowwave k_rowchain k_atb k_linear k_node k_layer > $O/${TAG}_pmc_${W}_${CNT}.json 2>&1
   done; done
   cd $R ;;
 esac; done

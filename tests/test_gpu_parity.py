@@ -83,7 +83,7 @@ def test_model_two_row_tiles(dev, name, monkeypatch):
     pc.check_model_case(dev, name)
 
 
-@pytest.mark.parametrize('rowwave', ['0', '1'])
+@pytest.mark.parametrize('rowwave', ['0', '1', '2'])
 def test_row_kernels_both_forms(dev, rowwave, monkeypatch):
     """k_rowwave (one wave per 16-row tile, chain in registers: every node-level chain of the 64-wide layers) and
     k_rowchain / k_linear (four waves per tile: layer 0, and everything under EQD_ROWWAVE=0) against the golden vectors
@@ -96,8 +96,21 @@ def test_row_kernels_both_forms(dev, rowwave, monkeypatch):
         pc.check_model_case(dev, name)
     pc.check_model_bf16(dev, 'D_degraded3')
     names = pc.launch_names_of_a_step(dev, 'D_degraded3')
-    assert ('k_rowwave' in names) == (rowwave == '1'), sorted(set(names))
+    assert ('k_rowwave' in names) == (rowwave == '1') and ('k_rowres' in names) == (rowwave == '2'), sorted(set(names))
     assert 'k_rowchain' in names
+
+
+@pytest.mark.parametrize('tps', ['3', '11', '16'])
+def test_rowres_tiles_per_workgroup(dev, tps, monkeypatch):
+    """k_rowres with several tiles per workgroup (one and two tile slots per wave, idle waves, ragged last workgroup)"""
+    from tests import parity_common as pc
+    monkeypatch.setenv('EQD_ROWWAVE', '2')
+    monkeypatch.setenv('EQD_ROWRES_TPS', tps)
+    pc.check_linear(dev)
+    pc.check_linear_atb_bf16(dev)
+    for name in ('D_degraded3', 'B_b3_dips8'):
+        pc.check_model_case(dev, name)
+    pc.check_model_bf16(dev, 'D_degraded3')
 
 
 @pytest.mark.parametrize('name', ['D_degraded3', 'A_b1_shared5'])

@@ -76,7 +76,7 @@ def test_model_two_row_tiles(name, monkeypatch):
     pc.check_model_case(DEV, name)
 
 
-@pytest.mark.parametrize('rowwave', ['0', '1'])
+@pytest.mark.parametrize('rowwave', ['0', '1', '2'])
 def test_row_kernels_both_forms(rowwave, monkeypatch):
     """The node-level chains have two kernels: k_rowwave (one wave per 16-row tile, chain in registers; every chain of the
     layers >= 1) and k_rowchain / k_linear (four waves per tile, for layer 0's 69-wide jobs and under EQD_ROWWAVE=0).  Both
@@ -85,8 +85,18 @@ def test_row_kernels_both_forms(rowwave, monkeypatch):
     pc.check_linear(DEV)
     pc.check_model_case(DEV, 'D_degraded3')
     names = pc.launch_names_of_a_step(DEV, 'D_degraded3')
-    assert ('k_rowwave' in names) == (rowwave == '1'), sorted(set(names))
+    assert ('k_rowwave' in names) == (rowwave == '1') and ('k_rowres' in names) == (rowwave == '2'), sorted(set(names))
     assert 'k_rowchain' in names            # layer 0 (and everything under EQD_ROWWAVE=0)
+
+
+@pytest.mark.parametrize('tps', ['3', '11', '16'])
+def test_rowres_tiles_per_workgroup(tps, monkeypatch):
+    """k_rowres with several tiles per workgroup (one and two tile slots per wave, idle waves, ragged last workgroup)"""
+    monkeypatch.setenv('EQD_ROWWAVE', '2')
+    monkeypatch.setenv('EQD_ROWRES_TPS', tps)
+    pc.check_linear(DEV)
+    pc.check_linear_atb_bf16(DEV)
+    pc.check_model_case(DEV, 'D_degraded3')
 
 
 def test_model_bf16_mode():
