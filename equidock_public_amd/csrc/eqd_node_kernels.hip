@@ -414,13 +414,15 @@ static int lin_check_sources(const EqdLinJob& J) {
 // Which kernel.  k_rowchain / k_linear: four waves per 16-row tile, a step's weights staged per workgroup; k_rowwave:
 // one wave per tile, every wave loads its own weights; k_rowres: persistent 8-wave workgroups, weights resident in LDS.
 // A CU pulls ~10-12 B/clock from L2 whatever the pattern (profiles/r02_exp_trace_rowwave_*.txt), so with about one tile
-// per CU (config B: 200 tiles) the four waves that share a tile's weights finish first, and with many tiles per CU the
-// kernel that fetches the weights once per CU does.  Default: k_rowres from 4 tiles per CU, k_rowchain / k_linear
-// below; EQD_ROWWAVE = 0 / 1 / 2 forces k_rowchain + k_linear / k_rowwave / k_rowres for every eligible chain (tests).
+// per CU (config B: 200 tiles) the four waves that share a tile's weights finish first (B 6 337 pairs/s against 5 011
+// with k_rowwave and 4 422 with k_rowres), and with many tiles per CU the kernel that fetches the weights once per CU
+// does (C fp32 7 107 -> 7 329 k_rowwave -> 7 607 k_rowres, C bf16 9 971 -> 10 537 -> 11 390, E 551 -> 552 -> 562).
+// Default: k_rowres from 3 tiles per CU, k_rowchain / k_linear below; EQD_ROWWAVE = 0 / 1 / 2 forces k_rowchain +
+// k_linear / k_rowwave / k_rowres for every eligible chain (tests, experiments).
 static int rw_mode(int rows) {
     const char* f = getenv("EQD_ROWWAVE");
     if (f && f[0] >= '0' && f[0] <= '2' && f[1] == 0) return f[0] - '0';
-    return (rows + 15) / 16 >= 4 * eqd_num_cus() ? 2 : 0;
+    return (rows + 15) / 16 >= 3 * eqd_num_cus() ? 2 : 0;
 }
 static bool rw_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 static bool rw_eligible(const EqdChainJob* jobs, int njobs, int rows) {

@@ -78,32 +78,44 @@ __device__ __forceinline__ void rr_stage_store(const EqdLinSrc S, int t, const R
     }
 }
 
-// rows of one (source, tile) item as loaded: 64 columns + the 4 columns 64 + 4 g .. of a wide source, and the mask rows
+// rows of one (source, tile) item as loaded: 64 columns + the 4 columns 64 + 4 g .. of a wide source
 struct RrRows {
-    f32x4 x[4], xm[4], xr;
+    f32x4 x[4], xr;
 };
-__device__ __forceinline__ void rr_rows_load(const EqdLinSrc S, bool local, int rowc, int g, RrRows& R) {
-    // always 9 loads (see rw_load): what an item does not need comes from the start of the weight matrix
-    const char* const wb = (const char*)S.W;
-    const bool real = !local;
-    const char* const xb = real ? (const char*)S.X : wb;
-    const char* const mb = (real && S.mask) ? (const char*)S.mask : xb;
-    const unsigned xl = real ? 4u * (unsigned)(rowc * S.ldx + 4 * g) : 16u * (unsigned)g;
+__device__ __forceinline__ void rr_rows_load(const EqdLinSrc S, int rowc, int g, RrRows& R) {
+    const char* const xb = (const char*)S.X;
+    const unsigned xl = 4u * (unsigned)(rowc * S.ldx + 4 * g);
 #pragma unroll
-    for (int a = 0; a < 4; ++a) R.x[a] = rw_ld(xb + (real ? 64 * a : 0), xl);
+    for (int a = 0; a < 4; ++a) R.x[a] = rw_ld(xb + 64 * a, xl);
+    if (S.K > 64) {
+        const int n = S.K - 64 - 4 * g;
+        const int sh = (n > 0 && n < 4) ? 4 - n : 0;
+        R.xr = rw_ld(xb, n > 0 ? 4u * (unsigned)(rowc * S.ldx + 64 + 4 * g - sh) : xl);
+    }
+}
+// the copy the MFMAs read (they never read a register a load in flight targets: eqd_rowwave_inl.h), with the LeakyReLU
+// mask applied - mask rows are fetched here, not ahead (two of the ten sources of the backward chain carry one)
+__device__ __forceinline__ void rr_rows_take(const EqdLinSrc S, float slope, int rowc, int g, const RrRows& R, RrRows& C) {
 #pragma unroll
-    for (int a = 0; a < 4; ++a) R.xm[a] = rw_ld(mb + (real ? 64 * a : 0), xl);
-    const int n = S.K - 64 - 4 * g;
-    const int sh = (n > 0 && n < 4) ? 4 - n : 0;
-    const unsigned rl = (real && n > 0) ? 4u * (unsigned)(rowc * S.ldx + 64 + 4 * g - sh) : xl;
-    R.xr = rw_ld(xb, rl);
+    for (int a = 0; a < 4; ++a) C.x[a] = R.x[a];
+    C.xr = R.xr;
+    if (S.mask) {
+        const char* const mb = (const char*)S.mask;
+        const unsigned xl = 4u * (unsigned)(rowc * S.ldx + 4 * g);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const f32x4 m = rw_ld(mb + 64 * a, xl);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) C.x[a][b] *= lrelu_grad(m[b], slope);
+        }
+    }
 }
 
 // one (source, tile) item: B operands from the item's rows (global source) or the LDS tile, A operands from the staged
 // weights; 64 (fp32) / 16 (bf16) MFMAs per 64 columns
 template <bool BF>
 __device__ __forceinline__ void rr_item(const float* __restrict__ Wl, int K, bool tp, bool local, const float* T,
-                                        const RrRows& R, bool masked, float slope, int l15, int g, f32x4 (&acc)[4]) {
+                                        const RrRows& R, int l15, int g, f32x4 (&acc)[4]) {
     const int KP = rr_kp(K);
     const int na = K > 64 ? 5 : 4;
 #pragma unroll
@@ -117,10 +129,6 @@ __device__ __forceinline__ void rr_item(const float* __restrict__ Wl, int K, boo
                 bv = *(const f32x4*)(T + l15 * RW_S + 16 * a + 4 * g);
             } else {
                 bv = R.x[a < 4 ? a : 0];
-                if (masked) {
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) bv[b] *= lrelu_grad(R.xm[a < 4 ? a : 0][b], slope);
-                }
             }
             f32x4 w[4];
             if (!tp) {
@@ -216,33 +224,41 @@ __global__ __launch_bounds__(64 * RR_WAVES, 1) void k_rowres(EqdChainArg A_, int
         for (int s = 0; s < RR_TMAX; ++s)
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[s][q] = f4zero();
-        RrRows XR;
+        // rows of the job's first source for every tile slot (global sources only); from then on the rows of source
+        // si + 1 are fetched while source si is multiplied
+        RrRows XR[RR_TMAX];
         {
             const EqdLinSrc S0 = jw_src(Wc, 0);
-            rr_rows_load(S0, jw_i(Wc, JW_OFF(EqdChainJob, src_local)) >= 0 || nslots == 0, rowcs[0], g, XR);
+            if (jw_i(Wc, JW_OFF(EqdChainJob, src_local)) < 0) {
+#pragma unroll
+                for (int s = 0; s < RR_TMAX; ++s)
+                    if (s < nslots) rr_rows_load(S0, rowcs[s], g, XR[s]);
+            }
         }
         for (int si = 0; si < nsrc; ++si) {
             const EqdLinSrc S = jw_src(Wc, si);
             const int loc = jw_i(Wc, JW_OFF(EqdChainJob, src_local) + si);
-            // weights of the next source (of this job, or the first one of the next linear job): in flight during the items
             const bool last_src = si + 1 >= nsrc;
             const bool have_next = !last_src || next_lin >= 0;
             const EqdLinSrc Sn = last_src ? jw_src(Wnl, 0) : jw_src(Wc, si + 1);
-            const int nloc = last_src ? -1 : jw_i(Wc, JW_OFF(EqdChainJob, src_local) + si + 1);
-            if (nslots == 0 && have_next) rr_stage_load(Sn, t, WS);
+            const int nloc = last_src ? 0 : jw_i(Wc, JW_OFF(EqdChainJob, src_local) + si + 1);
+            RrRows XC[RR_TMAX];
+            if (loc < 0) {
 #pragma unroll
-            for (int s = 0; s < RR_TMAX; ++s) {
-                if (s < nslots) {
-                    RrRows XC = XR;          // copy: the MFMAs below never read a register a load in flight targets
-                    // (the weight loads are issued behind the copy: in front of it the copy would wait for them too)
-                    if (s == 0 && have_next) rr_stage_load(Sn, t, WS);
-                    // rows of the next item: the next tile of this source, or the first tile of the next source
-                    const bool more_slots = s + 1 < nslots;
-                    if (more_slots) rr_rows_load(S, loc >= 0, rowcs[s + 1 < RR_TMAX ? s + 1 : 0], g, XR);
-                    else if (!last_src) rr_rows_load(Sn, nloc >= 0, rowcs[0], g, XR);
-                    rr_item<BF>(sm.Wl[buf], S.K, tp, loc >= 0, sm.tile[wave][s], XC, S.mask != nullptr, slope, l15, g, acc[s]);
-                }
+                for (int s = 0; s < RR_TMAX; ++s)
+                    if (s < nslots) rr_rows_take(S, slope, rowcs[s], g, XR[s], XC[s]);      // waits for the rows
             }
+            // behind the copies (in front of them the copies would wait for these loads too): the next source's weights
+            // and, within the job, its rows
+            if (have_next) rr_stage_load(Sn, t, WS);
+            if (!last_src && nloc < 0) {
+#pragma unroll
+                for (int s = 0; s < RR_TMAX; ++s)
+                    if (s < nslots) rr_rows_load(Sn, rowcs[s], g, XR[s]);
+            }
+#pragma unroll
+            for (int s = 0; s < RR_TMAX; ++s)
+                if (s < nslots) rr_item<BF>(sm.Wl[buf], S.K, tp, loc >= 0, sm.tile[wave][s], XC[s], l15, g, acc[s]);
             if (have_next) rr_stage_store(Sn, t, WS, sm.Wl[buf ^ 1]);
             __syncthreads();      // every wave is done with Wl[buf]; Wl[buf ^ 1] is complete
             buf ^= 1;
