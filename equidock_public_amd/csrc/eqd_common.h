@@ -316,8 +316,11 @@ size_t eqd_ln_act_bwd_partial_floats(int rows, int d);
 int eqd_launch_fill(float* p, float v, size_t n, hipStream_t st);
 int eqd_launch_axpy(float* y, const float* x, float a, size_t n, hipStream_t st);
 int eqd_launch_seg_mean(const EqdGraph* g, const float* hm, float* qmean, hipStream_t st);
+size_t eqd_head_u_bwd_partial_floats(int n_pairs, int K);      // 0 when the batch is not split over segment groups
+// part / defer: partial buffer of that size and the pass's pending-reduction list (both or neither)
 int eqd_launch_head_u_bwd(const EqdGraph* g, int K, const float* Wk, const float* Wq, const float* qmean,
-                          const float* qp, const float* du, float* dWk, float* dWq, float* dqm_part, hipStream_t st);
+                          const float* qp, const float* du, float* dWk, float* dWq, float* dqm_part, hipStream_t st,
+                          float* part, EqdRedList* defer);
 int eqd_launch_qmean_bwd(const EqdGraph* g, int K, const float* dqm_part, float* dhm, hipStream_t st);
 int eqd_launch_keypoint_bwd(const EqdGraph* g, int K, const float* H, const float* Z, const float* scores,
                             const float* lse, const float* u, const float* dY, float* dscores, float* du,

@@ -150,7 +150,7 @@ struct Scratch {
     float* dH_all;   // [L + 1][N][80]: entry i = grad wrt h[i]
     float *dz_all, *dq_all, *dk_all, *dv_all;   // [L][N][80]
     float *dP_all, *dQ_all;                     // [L][N][64]
-    float *dY, *dT, *db, *dscores, *du, *dHk, *dqm_part, *dhm;
+    float *dY, *dT, *db, *dscores, *du, *dHk, *dqm_part, *dhm, *head_part;
     void* edge_ws; size_t edge_ws_bytes;
     float* atb_part; size_t atb_bytes;
     float* ln_part; size_t ln_part_stride;     // per layer (reductions are deferred to the end of the pass)
@@ -180,6 +180,7 @@ void carve_scratch(const Dims& D, const EqdModelDesc* m, const EqdGraph* g, EqdA
     W.du = A.take<float>((size_t)2 * D.B * D.K * 64);
     W.dHk = A.take<float>(N * 64);
     W.dqm_part = A.take<float>((size_t)2 * D.B * D.K * 64);
+    W.head_part = A.take<float>(eqd_head_u_bwd_partial_floats(D.B, D.K));
     W.dhm = A.take<float>(N * 64);
     W.edge_ws_bytes = eqd_edge_message_bwd_workspace_bytes(g);
     W.edge_ws = A.take<char>(W.edge_ws_bytes);
@@ -500,7 +501,7 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
     float* dXnext = W.dXb;
     RC(eqd_launch_keypoint_bwd(g, K, H, Z, S.scores, S.klse, S.u, W.dY, W.dscores, W.du, W.dHk, dXcur, st));
     RC(eqd_launch_head_u_bwd(g, K, gpar[G_WK], gpar[G_WQ], S.qmean, S.qp, W.du, ggrad[G_WK], ggrad[G_WQ], W.dqm_part,
-                             st));
+                             st, W.head_part, defer));
     RC(eqd_launch_qmean_bwd(g, K, W.dqm_part, W.dhm, st));
     const size_t NS = (size_t)N * 80, NP = (size_t)N * 64;
     auto dHof = [&](int i) -> float* { return W.dH_all + (size_t)i * NS; };   // grad wrt h[i]

@@ -256,7 +256,10 @@ int eqd_launch_keypoint_bwd(const EqdGraph* g, int K, const float* H, const floa
     return eqd_check_launch("k_keypoint_bwd_b");
 }
 
-// backward of k_head_u: one block per head, sequential over segments (deterministic):
+// backward of k_head_u: one block per (head, group of HU_GROUP segments), sequential over its segments (deterministic):
+// with one group the block adds its sums to dWk / dWq itself; with several (large batches: 128 segments at 64 pairs
+// were 93 us on 50 of the 256 CUs) every block writes a partial [group][Wk | Wq][head][64 x 64] that the pass's
+// fixed-order reduction adds up (EqdRedSeg).
 //   dWk^(k) += qp (x) du / 8,  dqp = W_K^(k) du / 8,  dWq^(k) += dqp (x) qmean[partner],
 //   dqm_part[s][k] = W_Q^(k)T dqp   (gradient wrt qmean[partner(s)], reduced over k later)
 __global__ __launch_bounds__(EQD_BLOCK) void k_head_u_bwd(int B, int K, const float* __restrict__ Wk,
@@ -264,7 +267,8 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_head_u_bwd(int B, int K, const fl
                                                           const float* __restrict__ qmean,
                                                           const float* __restrict__ qp, const float* __restrict__ du,
                                                           float* __restrict__ dWk, float* __restrict__ dWq,
-                                                          float* __restrict__ dqm_part) {
+                                                          float* __restrict__ dqm_part, float* __restrict__ part,
+                                                          int segs_per_group) {
     // The head's two 64 x 64 matrices and 16 segments' vectors at a time live in LDS (one coalesced fetch
     // each); all products then run out of LDS.  Sums over segments stay sequential (deterministic).
     __shared__ float wk[64 * 65], wq[64 * 65];
@@ -288,8 +292,9 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_head_u_bwd(int B, int K, const fl
     float accK[16], accQ[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) accK[i] = accQ[i] = 0.f;
-    const int S2 = 2 * B;
-    for (int s0 = 0; s0 < S2; s0 += 16) {
+    const int Sbeg = (int)blockIdx.y * segs_per_group;
+    const int S2 = 2 * B < Sbeg + segs_per_group ? 2 * B : Sbeg + segs_per_group;
+    for (int s0 = Sbeg; s0 < S2; s0 += 16) {
         const int ns = S2 - s0 < 16 ? S2 - s0 : 16;
         __syncthreads();
 #pragma unroll
@@ -327,18 +332,44 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_head_u_bwd(int B, int K, const fl
             }
         }
     }
+    if (!part) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int j = j0 + 4 * i;
-        dWk[((size_t)k * 64 + j) * 64 + c] += accK[i];
-        dWq[((size_t)k * 64 + j) * 64 + c] += accQ[i];
+        for (int i = 0; i < 16; ++i) {
+            const int j = j0 + 4 * i;
+            dWk[((size_t)k * 64 + j) * 64 + c] += accK[i];
+            dWq[((size_t)k * 64 + j) * 64 + c] += accQ[i];
+        }
+    } else {
+        float* pk = part + ((size_t)blockIdx.y * 2 * K + k) * 4096;
+        float* pq = pk + (size_t)K * 4096;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int j = j0 + 4 * i;
+            pk[j * 64 + c] = accK[i];
+            pq[j * 64 + c] = accQ[i];
+        }
     }
 }
+#define HU_GROUP 32      /* segments per block of k_head_u_bwd when the batch is split */
+size_t eqd_head_u_bwd_partial_floats(int n_pairs, int K) {
+    const int groups = (2 * n_pairs + HU_GROUP - 1) / HU_GROUP;
+    return groups > 1 ? (size_t)groups * 2 * K * 4096 : 0;
+}
 int eqd_launch_head_u_bwd(const EqdGraph* g, int K, const float* Wk, const float* Wq, const float* qmean,
-                          const float* qp, const float* du, float* dWk, float* dWq, float* dqm_part, hipStream_t st) {
+                          const float* qp, const float* du, float* dWk, float* dWq, float* dqm_part, hipStream_t st,
+                          float* part, EqdRedList* defer) {
     if (g->n_pairs == 0) return EQD_OK;
-    hipLaunchKernelGGL(k_head_u_bwd, dim3(K), dim3(EQD_BLOCK), 0, st, g->n_pairs, K, Wk, Wq, qmean, qp, du, dWk, dWq,
-                       dqm_part);
+    const int groups = (2 * g->n_pairs + HU_GROUP - 1) / HU_GROUP;
+    if (groups <= 1 || !part || !defer || defer->n + 2 > 512) {      // small batch (or no partial buffer): one block per head
+        hipLaunchKernelGGL(k_head_u_bwd, dim3(K), dim3(EQD_BLOCK), 0, st, g->n_pairs, K, Wk, Wq, qmean, qp, du, dWk, dWq,
+                           dqm_part, (float*)nullptr, 2 * g->n_pairs);
+        return eqd_check_launch("k_head_u_bwd");
+    }
+    hipLaunchKernelGGL(k_head_u_bwd, dim3(K, groups), dim3(EQD_BLOCK), 0, st, g->n_pairs, K, Wk, Wq, qmean, qp, du, dWk,
+                       dWq, dqm_part, part, HU_GROUP);
+    const int n = K * 4096, stride = 2 * K * 4096;
+    defer->seg[defer->n++] = EqdRedSeg{part, groups, stride, n, dWk, 0, 0, 0};
+    defer->seg[defer->n++] = EqdRedSeg{part + n, groups, stride, n, dWq, 0, 0, 0};
     return eqd_check_launch("k_head_u_bwd");
 }
 
@@ -390,7 +421,7 @@ extern "C" int eqd_keypoint_pool_bwd(const EqdGraph* g, int n_heads, const float
     hipStream_t st = (hipStream_t)stream;
     int rc = eqd_launch_keypoint_bwd(g, n_heads, H, Z, scores, lse, u, dY, dscores, du, dH, dZ, st);
     if (rc) return rc;
-    rc = eqd_launch_head_u_bwd(g, n_heads, Wk, Wq, qmean, qp, du, dWk, dWq, dqm_part, st);
+    rc = eqd_launch_head_u_bwd(g, n_heads, Wk, Wq, qmean, qp, du, dWk, dWq, dqm_part, st, nullptr, nullptr);
     if (rc) return rc;
     return eqd_launch_qmean_bwd(g, n_heads, dqm_part, d_hm, st);
 }

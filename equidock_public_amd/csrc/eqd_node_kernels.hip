@@ -453,15 +453,18 @@ static bool rw_eligible(const EqdChainJob* jobs, int njobs, int rows) {
         }
     }
     (void)rw_aligned16;
-    // the kernel fetches a job's first operands while the previous job is still being multiplied: every job's first
-    // source must be an LDS tile or global data that no earlier job of the chain writes (chain_links: prefetch_next)
+    // the kernels fetch a job's rows ahead (k_rowres: across job boundaries, and it keeps rows that several jobs share):
+    // no global source may be data that an earlier job of the chain writes - such chains pass it on as an LDS tile
     for (int i = 0; i < njobs; ++i) {
-        if (jobs[i].type != 0 || jobs[i].src_local[0] >= 0) continue;
-        const EqdLinSrc& S0 = jobs[i].lin.s[0];
-        for (int m = 0; m < i; ++m) {
-            const float* outs[2] = {jobs[m].lin.Y, jobs[m].lin.pre_ln};
-            for (int q = 0; q < 2; ++q)
-                if (outs[q] && (outs[q] == S0.X || outs[q] == S0.mask)) return false;
+        if (jobs[i].type != 0) continue;
+        for (int s = 0; s < jobs[i].lin.nsrc; ++s) {
+            if (jobs[i].src_local[s] >= 0) continue;
+            const EqdLinSrc& S0 = jobs[i].lin.s[s];
+            for (int m = 0; m < i; ++m) {
+                const float* outs[2] = {jobs[m].lin.Y, jobs[m].lin.pre_ln};
+                for (int q = 0; q < 2; ++q)
+                    if (outs[q] && (outs[q] == S0.X || outs[q] == S0.mask)) return false;
+            }
         }
     }
     return true;

@@ -206,6 +206,9 @@ __global__ __launch_bounds__(64 * RR_WAVES, 1) void k_rowres(EqdChainArg A_, int
     }
     int buf = 0;
     RrStage WS;
+    RrRows XR[RR_TMAX];
+    const float* held_x = nullptr;      // the global source whose rows XR holds (wave-uniform)
+    int held_ld = 0, held_k = 0;
     if (jj < njobs) {      // the first source's weights
         const EqdLinSrc S0 = jw_src(Wc, 0);
         rr_stage_load(S0, t, WS);
@@ -226,13 +229,15 @@ __global__ __launch_bounds__(64 * RR_WAVES, 1) void k_rowres(EqdChainArg A_, int
             for (int q = 0; q < 4; ++q) acc[s][q] = f4zero();
         // rows of the job's first source for every tile slot (global sources only); from then on the rows of source
         // si + 1 are fetched while source si is multiplied
-        RrRows XR[RR_TMAX];
+        // (XR lives across jobs: `held` names the rows it holds, so the five projection jobs of a layer - same h rows -
+        // fetch them once, and a job whose first source is global finds its rows already requested by the job before)
         {
             const EqdLinSrc S0 = jw_src(Wc, 0);
-            if (jw_i(Wc, JW_OFF(EqdChainJob, src_local)) < 0) {
+            if (jw_i(Wc, JW_OFF(EqdChainJob, src_local)) < 0 && !(held_x == S0.X && held_ld == S0.ldx && held_k == S0.K)) {
 #pragma unroll
                 for (int s = 0; s < RR_TMAX; ++s)
                     if (s < nslots) rr_rows_load(S0, rowcs[s], g, XR[s]);
+                held_x = S0.X; held_ld = S0.ldx; held_k = S0.K;
             }
         }
         for (int si = 0; si < nsrc; ++si) {
@@ -251,10 +256,12 @@ __global__ __launch_bounds__(64 * RR_WAVES, 1) void k_rowres(EqdChainArg A_, int
             // behind the copies (in front of them the copies would wait for these loads too): the next source's weights
             // and, within the job, its rows
             if (have_next) rr_stage_load(Sn, t, WS);
-            if (!last_src && nloc < 0) {
+            const bool next_rows = last_src ? (next_lin >= 0 && jw_i(Wnl, JW_OFF(EqdChainJob, src_local)) < 0) : nloc < 0;
+            if (next_rows && !(held_x == Sn.X && held_ld == Sn.ldx && held_k == Sn.K)) {
 #pragma unroll
                 for (int s = 0; s < RR_TMAX; ++s)
                     if (s < nslots) rr_rows_load(Sn, rowcs[s], g, XR[s]);
+                held_x = Sn.X; held_ld = Sn.ldx; held_k = Sn.K;
             }
 #pragma unroll
             for (int s = 0; s < RR_TMAX; ++s)

@@ -161,6 +161,15 @@ def test_option_toggles_vs_oracle(dev, over):
                              what=str(over), l2=pc.GRAD_L2_SMALL, mx=pc.GRAD_MX_SMALL)
 
 
+def test_many_pairs_split_head_backward(dev):
+    """more than 16 pairs: k_head_u_bwd on (head, segment group) blocks + fixed-order reduction of the group partials"""
+    from tests import parity_common as pc
+    pc.check_model_vs_oracle(dev, [(9 + i % 5, 12 - i % 4) for i in range(19)], layers=2, seed=4, pair_seed=11,
+                             what='19 pairs', l2=pc.GRAD_L2_SMALL, mx=pc.GRAD_MX_SMALL)
+    pc.check_model_vs_oracle(dev, [(40 + i % 7, 35 + i % 3) for i in range(40)], layers=3, seed=5, pair_seed=12,
+                             what='40 pairs', l2=pc.GRAD_L2_SMALL, mx=pc.GRAD_MX_SMALL)
+
+
 def test_pair_losses(dev):
     from tests import parity_common as pc
     pc.check_pair_losses(dev)

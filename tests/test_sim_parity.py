@@ -129,6 +129,13 @@ def test_option_toggles_vs_oracle(over):
                              l2=pc.GRAD_L2_SMALL, mx=pc.GRAD_MX_SMALL)
 
 
+def test_many_pairs_split_head_backward():
+    """more than 16 pairs: the keypoint head's weight-gradient kernel (k_head_u_bwd) runs one block per (head, group of 32
+    segments) and its per-group partials go through the pass's fixed-order reduction"""
+    pc.check_model_vs_oracle(DEV, [(9 + i % 5, 12 - i % 4) for i in range(19)], layers=2, seed=4, pair_seed=11,
+                             what='19 pairs', l2=pc.GRAD_L2_SMALL, mx=pc.GRAD_MX_SMALL)
+
+
 def test_pair_losses():
     pc.check_pair_losses(DEV)
 
