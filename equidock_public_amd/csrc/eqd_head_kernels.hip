@@ -96,98 +96,53 @@ __device__ __forceinline__ float block_reduce_max(float v, float* red) {
     return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
-// per (segment, group of KP_HEADS heads): scores over the segment's nodes, softmax, Y = att^T Z.  A workgroup per
-// (segment, head) read the segment's H rows once per head - 50 x 77 KB per 300-residue segment, 490 MB per launch at
-// 64 pairs (71 us, bandwidth-bound on re-reads).  With a group of heads per workgroup every thread loads its node's H
-// row ONCE and takes the dot products with the group's u vectors (LDS, broadcast reads).  Per head the arithmetic and
-// the order of every sum are those of the one-head kernel (node order per thread, wave sums, four waves in index order).
-#define KP_HEADS 10
+// per (segment, head): scores over the segment's nodes, softmax, Y = att^T Z
 __global__ __launch_bounds__(EQD_BLOCK) void k_keypoint(const int32_t* __restrict__ seg_off, int K,
                                                         const float* __restrict__ u, const float* __restrict__ H,
                                                         const float* __restrict__ Z, float* __restrict__ Y,
                                                         float* __restrict__ Yl_out, float* __restrict__ Yr_out,
                                                         int B, float* __restrict__ scores, float* __restrict__ lse) {
-    __shared__ __attribute__((aligned(16))) float su[KP_HEADS][64];
-    __shared__ float redm[4][KP_HEADS];
-    __shared__ float reds[4][KP_HEADS][4];
-    const int s = blockIdx.x, k0 = (int)blockIdx.y * KP_HEADS, t = threadIdx.x;
-    const int nk = K - k0 < KP_HEADS ? K - k0 : KP_HEADS;
+    __shared__ float su[64];
+    __shared__ float red[4];
+    const int s = blockIdx.x, k = blockIdx.y, t = threadIdx.x;
     const int n0 = seg_off[s], n1 = seg_off[s + 1];
-    for (int idx = t; idx < KP_HEADS * 64; idx += EQD_BLOCK) {
-        const int kk = idx >> 6;
-        su[kk][idx & 63] = kk < nk ? u[((size_t)s * K + k0 + kk) * 64 + (idx & 63)] : 0.f;
-    }
+    if (t < 64) su[t] = u[((size_t)s * K + k) * 64 + t];
     __syncthreads();
-    float mx[KP_HEADS];
-#pragma unroll
-    for (int kk = 0; kk < KP_HEADS; ++kk) mx[kk] = EQD_NEG_BIG;
+    float mx = EQD_NEG_BIG;
     for (int i = n0 + t; i < n1; i += EQD_BLOCK) {
-        float4 hv[16];
         const float4* h = (const float4*)&H[(size_t)i * 64];
+        float a = 0.f;
 #pragma unroll
-        for (int c = 0; c < 16; ++c) hv[c] = h[c];
-#pragma unroll
-        for (int kk = 0; kk < KP_HEADS; ++kk) {
-            float a = 0.f;
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                const float4 uv = *(const float4*)&su[kk][4 * c];
-                a += hv[c].x * uv.x + hv[c].y * uv.y + hv[c].z * uv.z + hv[c].w * uv.w;
-            }
-            if (kk < nk) scores[(size_t)i * K + k0 + kk] = a;
-            mx[kk] = fmaxf(mx[kk], a);
+        for (int c = 0; c < 16; ++c) {
+            const float4 hv = h[c];
+            a += hv.x * su[4 * c] + hv.y * su[4 * c + 1] + hv.z * su[4 * c + 2] + hv.w * su[4 * c + 3];
         }
+        scores[(size_t)i * K + k] = a;
+        mx = fmaxf(mx, a);
     }
-    const int wave = t >> 6, lane = t & 63;
-#pragma unroll
-    for (int kk = 0; kk < KP_HEADS; ++kk) {
-        float v = mx[kk];
-        v = fmaxf(v, __shfl_xor(v, 1)); v = fmaxf(v, __shfl_xor(v, 2)); v = fmaxf(v, __shfl_xor(v, 4));
-        v = fmaxf(v, __shfl_xor(v, 8)); v = fmaxf(v, __shfl_xor(v, 16)); v = fmaxf(v, __shfl_xor(v, 32));
-        if (lane == 0) redm[wave][kk] = v;
+    mx = block_reduce_max(mx, red);
+    float se = 0.f, y0 = 0.f, y1 = 0.f, y2 = 0.f;
+    for (int i = n0 + t; i < n1; i += EQD_BLOCK) {
+        const float p = expf(scores[(size_t)i * K + k] - mx);
+        se += p;
+        y0 += p * Z[(size_t)i * 3 + 0];
+        y1 += p * Z[(size_t)i * 3 + 1];
+        y2 += p * Z[(size_t)i * 3 + 2];
     }
-    __syncthreads();
-#pragma unroll
-    for (int kk = 0; kk < KP_HEADS; ++kk) mx[kk] = fmaxf(fmaxf(redm[0][kk], redm[1][kk]), fmaxf(redm[2][kk], redm[3][kk]));
-    float se[KP_HEADS], y0[KP_HEADS], y1[KP_HEADS], y2[KP_HEADS];
-#pragma unroll
-    for (int kk = 0; kk < KP_HEADS; ++kk) se[kk] = y0[kk] = y1[kk] = y2[kk] = 0.f;
-    for (int i = n0 + t; i < n1; i += EQD_BLOCK) {      // (a thread re-reads the scores it stored itself)
-        const float z0 = Z[(size_t)i * 3 + 0], z1 = Z[(size_t)i * 3 + 1], z2 = Z[(size_t)i * 3 + 2];
-#pragma unroll
-        for (int kk = 0; kk < KP_HEADS; ++kk) {
-            if (kk < nk) {
-                const float p = expf(scores[(size_t)i * K + k0 + kk] - mx[kk]);
-                se[kk] += p;
-                y0[kk] += p * z0;
-                y1[kk] += p * z1;
-                y2[kk] += p * z2;
-            }
-        }
-    }
-#pragma unroll
-    for (int kk = 0; kk < KP_HEADS; ++kk) {
-        const float a = wave_sum(se[kk]), b = wave_sum(y0[kk]), c = wave_sum(y1[kk]), d = wave_sum(y2[kk]);
-        if (lane == 0) {
-            reds[wave][kk][0] = a; reds[wave][kk][1] = b; reds[wave][kk][2] = c; reds[wave][kk][3] = d;
-        }
-    }
-    __syncthreads();
-    if (t < nk) {
-        const int k = k0 + t;
-        float r[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) r[q] = reds[0][t][q] + reds[1][t][q] + reds[2][t][q] + reds[3][t][q];
-        const float sev = r[0], m = fmaxf(fmaxf(redm[0][t], redm[1][t]), fmaxf(redm[2][t], redm[3][t]));
-        const float inv = sev > 0.f ? 1.f / sev : 0.f;
+    se = block_reduce_sum(se, red);
+    y0 = block_reduce_sum(y0, red);
+    y1 = block_reduce_sum(y1, red);
+    y2 = block_reduce_sum(y2, red);
+    if (t == 0) {
+        const float inv = se > 0.f ? 1.f / se : 0.f;
         float* y = Y + ((size_t)s * K + k) * 3;
-        y[0] = r[1] * inv; y[1] = r[2] * inv; y[2] = r[3] * inv;
+        y[0] = y0 * inv; y[1] = y1 * inv; y[2] = y2 * inv;
         float* yo = s < B ? (Yl_out ? Yl_out + ((size_t)s * K + k) * 3 : nullptr)
                           : (Yr_out ? Yr_out + ((size_t)(s - B) * K + k) * 3 : nullptr);
         if (yo) {
-            yo[0] = r[1] * inv; yo[1] = r[2] * inv; yo[2] = r[3] * inv;
+            yo[0] = y0 * inv; yo[1] = y1 * inv; yo[2] = y2 * inv;
         }
-        lse[(size_t)s * K + k] = sev > 0.f ? m + logf(sev) : 0.f;
+        lse[(size_t)s * K + k] = se > 0.f ? mx + logf(se) : 0.f;
     }
 }
 
@@ -209,14 +164,12 @@ int eqd_keypoint_pool_fwd_impl(const EqdGraph* g, int n_heads, const float* Wk, 
                        u);
     int rc = eqd_check_launch("k_head_u");
     if (rc) return rc;
-    hipLaunchKernelGGL(k_keypoint, dim3(2 * g->n_pairs, (n_heads + KP_HEADS - 1) / KP_HEADS), dim3(EQD_BLOCK), 0, st, g->seg_off, n_heads, u, H, Z,
+    hipLaunchKernelGGL(k_keypoint, dim3(2 * g->n_pairs, n_heads), dim3(EQD_BLOCK), 0, st, g->seg_off, n_heads, u, H, Z,
                        Y, Y_lig_out, Y_rec_out, g->n_pairs, scores, lse);
     return eqd_check_launch("k_keypoint");
 }
 
-// backward of k_keypoint, part a: per (segment, group of KP_HEADS heads): dscores (written), du (reduced over nodes).
-// Same grouping as the forward: the H rows of the du products are read once per group of heads instead of once per head;
-// per head the sums run in the order of the one-head kernel.
+// backward of k_keypoint, part a: per (segment, head): dscores (written), du (reduced over nodes)
 __global__ __launch_bounds__(EQD_BLOCK) void k_keypoint_bwd_a(const int32_t* __restrict__ seg_off, int K,
                                                               const float* __restrict__ H,
                                                               const float* __restrict__ Z,
@@ -224,131 +177,65 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_keypoint_bwd_a(const int32_t* __r
                                                               const float* __restrict__ lse,
                                                               const float* __restrict__ dY,
                                                               float* __restrict__ dscores, float* __restrict__ du) {
-    __shared__ float red[4][KP_HEADS];
-    __shared__ float racc[KP_HEADS][4][64];
-    __shared__ float sdy[KP_HEADS][4];
-    const int s = blockIdx.x, k0 = (int)blockIdx.y * KP_HEADS, t = threadIdx.x;
-    const int nk = K - k0 < KP_HEADS ? K - k0 : KP_HEADS;
+    __shared__ float red[4];
+    __shared__ float racc[4][64];
+    const int s = blockIdx.x, k = blockIdx.y, t = threadIdx.x;
     const int n0 = seg_off[s], n1 = seg_off[s + 1];
-    if (t < KP_HEADS) {
-        const int k = k0 + (t < nk ? t : 0);
-        sdy[t][0] = dY[((size_t)s * K + k) * 3 + 0];
-        sdy[t][1] = dY[((size_t)s * K + k) * 3 + 1];
-        sdy[t][2] = dY[((size_t)s * K + k) * 3 + 2];
-        sdy[t][3] = lse[(size_t)s * K + k];
-    }
-    __syncthreads();
-    float dot[KP_HEADS];
-#pragma unroll
-    for (int kk = 0; kk < KP_HEADS; ++kk) dot[kk] = 0.f;
+    const float* dy = dY + ((size_t)s * K + k) * 3;
+    const float d0 = dy[0], d1 = dy[1], d2 = dy[2];
+    const float L = lse[(size_t)s * K + k];
+    float dot = 0.f;
     for (int i = n0 + t; i < n1; i += EQD_BLOCK) {
-        const float z0 = Z[(size_t)i * 3], z1 = Z[(size_t)i * 3 + 1], z2 = Z[(size_t)i * 3 + 2];
-#pragma unroll
-        for (int kk = 0; kk < KP_HEADS; ++kk) {
-            if (kk < nk) {
-                const float a = expf(scores[(size_t)i * K + k0 + kk] - sdy[kk][3]);
-                const float da = sdy[kk][0] * z0 + sdy[kk][1] * z1 + sdy[kk][2] * z2;
-                dot[kk] += a * da;
-            }
-        }
+        const float a = expf(scores[(size_t)i * K + k] - L);
+        const float da = d0 * Z[(size_t)i * 3] + d1 * Z[(size_t)i * 3 + 1] + d2 * Z[(size_t)i * 3 + 2];
+        dot += a * da;
     }
-    const int wave = t >> 6, lane = t & 63;
-#pragma unroll
-    for (int kk = 0; kk < KP_HEADS; ++kk) {
-        const float v = wave_sum(dot[kk]);
-        if (lane == 0) red[wave][kk] = v;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int kk = 0; kk < KP_HEADS; ++kk) dot[kk] = red[0][kk] + red[1][kk] + red[2][kk] + red[3][kk];
+    dot = block_reduce_sum(dot, red);
     for (int i = n0 + t; i < n1; i += EQD_BLOCK) {
-        const float z0 = Z[(size_t)i * 3], z1 = Z[(size_t)i * 3 + 1], z2 = Z[(size_t)i * 3 + 2];
-#pragma unroll
-        for (int kk = 0; kk < KP_HEADS; ++kk) {
-            if (kk < nk) {
-                const float a = expf(scores[(size_t)i * K + k0 + kk] - sdy[kk][3]);
-                const float da = sdy[kk][0] * z0 + sdy[kk][1] * z1 + sdy[kk][2] * z2;
-                dscores[(size_t)i * K + k0 + kk] = a * (da - dot[kk]);
-            }
-        }
+        const float a = expf(scores[(size_t)i * K + k] - L);
+        const float da = d0 * Z[(size_t)i * 3] + d1 * Z[(size_t)i * 3 + 1] + d2 * Z[(size_t)i * 3 + 2];
+        dscores[(size_t)i * K + k] = a * (da - dot);
     }
-    __syncthreads();   // dscores of this (segment, head group) are re-read below by other threads of the block
+    __syncthreads();   // dscores of this (segment, head) are re-read below by other threads of the block
     const int c = t & 63, rg = t >> 6;
-    float acc[KP_HEADS];
+    float acc = 0.f;
+    for (int i = n0 + rg; i < n1; i += 32) {       // 8 rows in flight per thread (clamped, unpredicated loads)
+        float ds[8], hv[8];
 #pragma unroll
-    for (int kk = 0; kk < KP_HEADS; ++kk) acc[kk] = 0.f;
-    for (int i = n0 + rg; i < n1; i += 32) {       // rows i, i + 4, .. i + 28 (clamped, unpredicated loads), four at a time
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            float ds[4][KP_HEADS], hv[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int r = i + 4 * (4 * half + u) < n1 ? i + 4 * (4 * half + u) : n0;
-                hv[u] = H[(size_t)r * 64 + c];
-#pragma unroll
-                for (int kk = 0; kk < KP_HEADS; ++kk) ds[u][kk] = dscores[(size_t)r * K + k0 + (kk < nk ? kk : 0)];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const bool ok = i + 4 * (4 * half + u) < n1;
-#pragma unroll
-                for (int kk = 0; kk < KP_HEADS; ++kk) acc[kk] += ok ? ds[u][kk] * hv[u] : 0.f;
-            }
+        for (int u = 0; u < 8; ++u) {
+            const int r = i + 4 * u < n1 ? i + 4 * u : n0;
+            ds[u] = dscores[(size_t)r * K + k];
+            hv[u] = H[(size_t)r * 64 + c];
         }
-    }
 #pragma unroll
-    for (int kk = 0; kk < KP_HEADS; ++kk) racc[kk][rg][c] = acc[kk];
+        for (int u = 0; u < 8; ++u) acc += i + 4 * u < n1 ? ds[u] * hv[u] : 0.f;
+    }
+    racc[rg][c] = acc;
     __syncthreads();
-    for (int kk = rg; kk < nk; kk += 4)
-        du[((size_t)s * K + k0 + kk) * 64 + c] = racc[kk][0][c] + racc[kk][1][c] + racc[kk][2][c] + racc[kk][3][c];
+    if (rg == 0) du[((size_t)s * K + k) * 64 + c] = racc[0][c] + racc[1][c] + racc[2][c] + racc[3][c];
 }
 
-// part b: per node: dH[i] = sum_k dscores[i][k] u[seg][k];  dZ[i] = sum_k att[i][k] dY[seg][k].  One workgroup per
-// (segment, chunk of KPB_NODES nodes): the segment's u (K x 64) and dY are staged in LDS once per chunk (a workgroup per
-// node read the 12.8 KB of u for itself: 490 MB per launch at 64 pairs); thread = (node slot, feature), sums over the
-// heads in index order as before.
-#define KPB_NODES 64
-__global__ __launch_bounds__(EQD_BLOCK) void k_keypoint_bwd_b(const int32_t* __restrict__ seg_off, int K,
-                                                              const float* __restrict__ scores,
-                                                              const float* __restrict__ lse,
-                                                              const float* __restrict__ u, const float* __restrict__ dY,
-                                                              const float* __restrict__ dscores,
-                                                              float* __restrict__ dH, float* __restrict__ dZ) {
-    __shared__ float su[128 * 64];
-    __shared__ float sdy[128][4];
-    __shared__ float sds[4][128], sal[4][128];
-    const int s = blockIdx.x, t = threadIdx.x;
-    const int n0 = seg_off[s] + (int)blockIdx.y * KPB_NODES, nend = seg_off[s + 1];
-    if (n0 >= nend) return;      // uniform
-    const int n1 = n0 + KPB_NODES < nend ? n0 + KPB_NODES : nend;
-    for (int idx = t; idx < K * 64; idx += EQD_BLOCK) su[idx] = u[(size_t)s * K * 64 + idx];
-    for (int k = t; k < K; k += EQD_BLOCK) {
-        sdy[k][0] = dY[((size_t)s * K + k) * 3 + 0];
-        sdy[k][1] = dY[((size_t)s * K + k) * 3 + 1];
-        sdy[k][2] = dY[((size_t)s * K + k) * 3 + 2];
-        sdy[k][3] = lse[(size_t)s * K + k];
+// part b: per node: dH[i] = sum_k dscores[i][k] u[seg][k];  dZ[i] = sum_k att[i][k] dY[seg][k]
+__global__ void k_keypoint_bwd_b(const int32_t* __restrict__ seg_off, int nseg, int n, int K,
+                                 const float* __restrict__ scores, const float* __restrict__ lse,
+                                 const float* __restrict__ u, const float* __restrict__ dY,
+                                 const float* __restrict__ dscores, float* __restrict__ dH, float* __restrict__ dZ) {
+    __shared__ float sds[128], sal[128];
+    const int i = blockIdx.x, t = threadIdx.x;  // 64 threads
+    if (i >= n) return;
+    const int s = find_segment(seg_off, nseg, i);
+    for (int k = t; k < K; k += 64) {
+        sds[k] = dscores[(size_t)i * K + k];
+        sal[k] = expf(scores[(size_t)i * K + k] - lse[(size_t)s * K + k]);
     }
-    const int c = t & 63, rg = t >> 6;
-    for (int ib = n0; ib < n1; ib += 4) {
-        const int i = ib + rg;
-        __syncthreads();      // su / sdy staged (first pass); the previous pass's sds / sal are consumed
-        if (i < n1) {
-            for (int k = c; k < K; k += 64) {
-                sds[rg][k] = dscores[(size_t)i * K + k];
-                sal[rg][k] = expf(scores[(size_t)i * K + k] - sdy[k][3]);
-            }
-        }
-        __syncthreads();
-        if (i < n1) {
-            float a = 0.f;
-            for (int k = 0; k < K; ++k) a += sds[rg][k] * su[k * 64 + c];
-            dH[(size_t)i * 64 + c] = a;
-            if (c < 3) {
-                float z = 0.f;
-                for (int k = 0; k < K; ++k) z += sal[rg][k] * sdy[k][c];
-                dZ[(size_t)i * 3 + c] = z;
-            }
-        }
+    __syncthreads();
+    float a = 0.f;
+    for (int k = 0; k < K; ++k) a += sds[k] * u[((size_t)s * K + k) * 64 + t];
+    dH[(size_t)i * 64 + t] = a;
+    if (t < 3) {
+        float z = 0.f;
+        for (int k = 0; k < K; ++k) z += sal[k] * dY[((size_t)s * K + k) * 3 + t];
+        dZ[(size_t)i * 3 + t] = z;
     }
 }
 
@@ -360,12 +247,11 @@ int eqd_launch_keypoint_bwd(const EqdGraph* g, int K, const float* H, const floa
         eqd_set_error("num_att_heads %d > 128 unsupported", K);
         return EQD_ERR_UNSUPPORTED;
     }
-    hipLaunchKernelGGL(k_keypoint_bwd_a, dim3(2 * g->n_pairs, (K + KP_HEADS - 1) / KP_HEADS), dim3(EQD_BLOCK), 0, st,
-                       g->seg_off, K, H, Z, scores, lse, dY, dscores, du);
+    hipLaunchKernelGGL(k_keypoint_bwd_a, dim3(2 * g->n_pairs, K), dim3(EQD_BLOCK), 0, st, g->seg_off, K, H, Z, scores,
+                       lse, dY, dscores, du);
     int rc = eqd_check_launch("k_keypoint_bwd_a");
     if (rc) return rc;
-    const int chunks = (g->max_seg + KPB_NODES - 1) / KPB_NODES;
-    hipLaunchKernelGGL(k_keypoint_bwd_b, dim3(2 * g->n_pairs, chunks > 0 ? chunks : 1), dim3(EQD_BLOCK), 0, st, g->seg_off, K,
+    hipLaunchKernelGGL(k_keypoint_bwd_b, dim3(g->n_nodes), dim3(64), 0, st, g->seg_off, 2 * g->n_pairs, g->n_nodes, K,
                        scores, lse, u, dY, dscores, dH, dZ);
     return eqd_check_launch("k_keypoint_bwd_b");
 }
