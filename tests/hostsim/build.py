@@ -1,5 +1,6 @@
 """TEST INFRASTRUCTURE: compile the product's kernel sources for x86 against the host
 simulator (tests/hostsim/hip/hip_runtime.h) -> tests/hostsim/build/libeqd_hostsim.so."""
+import fcntl
 import glob
 import os
 import subprocess
@@ -16,7 +17,18 @@ FLAGS = ['-O2', '-g', '-std=c++17', '-fPIC', '-ffp-contract=off', '-I', HERE, '-
 
 
 def build(force=False):
+    """(Re)build the simulator library if a source is newer than its object.  Serialised with a file lock: pytest-xdist
+    workers call this at the same time, and two of them compiling into the same objects corrupt the link."""
     os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, '.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build(force)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build(force):
     srcs = [s for s in sorted(glob.glob(os.path.join(CSRC, '*.hip'))) if not s.endswith('eqd_target_gfx950.hip')]
     deps = sorted(glob.glob(os.path.join(CSRC, '*.h'))) + [os.path.join(HERE, 'hip', 'hip_runtime.h'),
                                                            os.path.join(ROOT, 'include', 'equidock_hip.h')]
