@@ -424,7 +424,6 @@ static int rw_mode(int rows) {
     if (f && f[0] >= '0' && f[0] <= '2' && f[1] == 0) return f[0] - '0';
     return (rows + 15) / 16 >= 3 * eqd_num_cus() ? 2 : 0;
 }
-static bool rw_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 static bool rw_eligible(const EqdChainJob* jobs, int njobs, int rows) {
     if (njobs <= 0 || rows <= 0 || rw_mode(rows) == 0) return false;
     for (int i = 0; i < njobs; ++i) {
@@ -432,8 +431,8 @@ static bool rw_eligible(const EqdChainJob* jobs, int njobs, int rows) {
         const EqdLinJob& J = C.lin;
         if (J.M != 64 || J.rows != rows || C.out_local >= LIN_LOCALS) return false;
         if ((J.bf16 != 0) != (jobs[0].lin.bf16 != 0)) return false;
-        // 16-byte row accesses: every leading dimension a multiple of 4 floats would be too strict (69-wide h0 rows are
-        // read through unaligned-tolerant loads: gfx950 global memory runs in unaligned-access mode), bases 4-byte
+        // (no alignment condition: rows are read with 16-byte loads at 4-byte alignment - gfx950 runs global memory in
+        // unaligned-access mode - which is what the 69-wide h0 rows need anyway)
         if (C.type != 0) {
             if (C.src_local[0] < 0 || C.src_local[0] >= LIN_LOCALS || !J.s[0].X || !J.ln_g || !C.aux) return false;
             continue;
@@ -452,7 +451,6 @@ static bool rw_eligible(const EqdChainJob* jobs, int njobs, int rows) {
             if (S.K < 64 || S.K > 80 || local || S.mask) return false;
         }
     }
-    (void)rw_aligned16;
     // the kernels fetch a job's rows ahead (k_rowres: across job boundaries, and it keeps rows that several jobs share):
     // no global source may be data that an earlier job of the chain writes - such chains pass it on as an LDS tile
     for (int i = 0; i < njobs; ++i) {
@@ -1278,11 +1276,22 @@ int eqd_launch_embed_bwd(const EqdGraph* g, const float* dh0, const float* dh0b,
 // cache, and the workgroups run on CUs the small gather leaves idle - instead of 90 MB of partials of a config-B
 // pass being streamed from HBM by two launches at the end (68 us).
 // BF: dz holds bf16 rows ([E][64] unsigned short; the edge backward's bf16 mode), sums are fp32
+// A node is handled by 16 lanes with 16-byte vectors (lane c4 owns features 4 c4 .. 4 c4 + 3; four nodes per wave): a row
+// of dz is ONE 256-byte request of 16 lanes.  With one lane per feature (a wave per node, 4-byte loads) the kernel issued
+// 4 x as many load instructions for the same bytes, and the vector-memory path accepts instructions, not bytes, at a
+// fixed rate (profiles/r02_exp_trace_rowwave_*.txt).  Sums per feature run over the edges in the same order as before.
 template <bool BF>
-__device__ __forceinline__ float gather_dz(const float* __restrict__ dz, size_t e, int c) {
-    if constexpr (BF) return bf2f(((const unsigned short*)dz)[e * 64 + c]);
-    else return dz[e * 64 + c];
+__device__ __forceinline__ f32x4 gather_dz4(const float* __restrict__ dz, size_t e, int c4) {
+    if constexpr (BF) {
+        typedef unsigned gather_u32x2 __attribute__((ext_vector_type(2)));
+        const gather_u32x2 h = *(const gather_u32x2*)((const unsigned short*)dz + e * 64 + 4 * c4);      // 4 bf16
+        return f32x4{__builtin_bit_cast(float, h[0] << 16), __builtin_bit_cast(float, h[0] & 0xffff0000u),
+                     __builtin_bit_cast(float, h[1] << 16), __builtin_bit_cast(float, h[1] & 0xffff0000u)};
+    } else {
+        return *(const f32x4*)(dz + e * 64 + 4 * c4);
+    }
 }
+#define GATHER_NODES 16      /* nodes per workgroup: 4 waves x 4 */
 template <bool BF>
 __global__ __launch_bounds__(256) void k_node_gather(const int32_t* __restrict__ csc_ptr, const int32_t* __restrict__ csc_eid,
                                                      const int32_t* __restrict__ rowptr, int n, const float* __restrict__ dz,
@@ -1295,82 +1304,96 @@ __global__ __launch_bounds__(256) void k_node_gather(const int32_t* __restrict__
         reduce_block<16>(RA, (int)blockIdx.x - ngather, red, red2);
         return;
     }
-    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int c = threadIdx.x & 63;
-    if (j >= n) return;
+    const int jr = blockIdx.x * GATHER_NODES + (threadIdx.x >> 4);
+    const int c4 = threadIdx.x & 15;
+    const bool live = jr < n;
+    const int j = live ? jr : n - 1;      // lanes beyond the last node repeat it (unconditional loads) and store nothing
     const int s0 = csc_ptr[j], s1 = csc_ptr[j + 1];
     const int d0 = rowptr[j], d1 = rowptr[j + 1];
     const int nout = s1 - s0, nin = d1 - d0;
-    float sp = 0.f, sq = 0.f, sx = 0.f;
+    f32x4 sp = f4zero(), sq = f4zero();
+    float sx = 0.f;                       // component c4 & 3 of the dx sum (lanes c4 < 3 store it)
     // First 16 edges of both directions in TWO dependent round trips: the 16 by-source edge ids (CSC) and the 16
     // by-destination rows (CSR: consecutive edge ids, no index needed) are issued together, then the 16 by-source rows.
     // Every load is unconditional on a clamped index and masked afterwards (a predicated load is an exec-masked branch
-    // with its own wait: the previous form was 8 dependent round trips per node at in / out degree 10).  Sums are taken
-    // in edge order, as before.
+    // with its own wait).  Sums are taken in edge order.
     constexpr int GB = 16;
     if (nout > 0 || nin > 0) {       // (a node without any edge reads nothing: dz may be empty)
         const int so = nout > 0 ? s0 : 0, no1 = nout > 0 ? nout - 1 : 0;
         const int di = nin > 0 ? d0 : (nout > 0 ? csc_eid[s0] : 0), ni1 = nin > 0 ? nin - 1 : 0;
         int e[GB];
-        float vq[GB], wq[GB], vp[GB], wp[GB];
+        f32x4 vq[GB], vp[GB];
+        float wq[GB], wp[GB];
 #pragma unroll
         for (int i = 0; i < GB; ++i) e[i] = nout > 0 ? csc_eid[so + (i < no1 ? i : no1)] : di;
 #pragma unroll
         for (int i = 0; i < GB; ++i) {
             const size_t ee = (size_t)(di + (i < ni1 ? i : ni1));
-            vq[i] = gather_dz<BF>(dz, ee, c);
-            wq[i] = dxrel[ee * 4 + (c & 3)];
+            vq[i] = gather_dz4<BF>(dz, ee, c4);
+            wq[i] = dxrel[ee * 4 + (c4 & 3)];
         }
 #pragma unroll
         for (int i = 0; i < GB; ++i) {
-            vp[i] = gather_dz<BF>(dz, (size_t)e[i], c);
-            wp[i] = dxrel[(size_t)e[i] * 4 + (c & 3)];
+            vp[i] = gather_dz4<BF>(dz, (size_t)e[i], c4);
+            wp[i] = dxrel[(size_t)e[i] * 4 + (c4 & 3)];
         }
 #pragma unroll
         for (int i = 0; i < GB; ++i) {
-            sp += i < nout ? vp[i] : 0.f;
-            sx += (i < nout && c < 3) ? wp[i] : 0.f;
+            if (i < nout) {
+                sp += vp[i];
+                sx += wp[i];
+            }
         }
 #pragma unroll
         for (int i = 0; i < GB; ++i) {
-            sq += i < nin ? vq[i] : 0.f;
-            sx -= (i < nin && c < 3) ? wq[i] : 0.f;
+            if (i < nin) {
+                sq += vq[i];
+                sx -= wq[i];
+            }
         }
     }
     // degrees beyond 16 (out-degree is unbounded; in-degree <= 32): the remaining edges, 8 at a time
     for (int q0 = s0 + GB; q0 < s1; q0 += 8) {
         int e[8];
-        float v[8], w[8];
+        f32x4 v[8];
+        float w[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) e[i] = csc_eid[q0 + i < s1 ? q0 + i : s1 - 1];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            v[i] = gather_dz<BF>(dz, (size_t)e[i], c);
-            w[i] = dxrel[(size_t)e[i] * 4 + (c & 3)];
+            v[i] = gather_dz4<BF>(dz, (size_t)e[i], c4);
+            w[i] = dxrel[(size_t)e[i] * 4 + (c4 & 3)];
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            sp += q0 + i < s1 ? v[i] : 0.f;
-            sx += (q0 + i < s1 && c < 3) ? w[i] : 0.f;
+            if (q0 + i < s1) {
+                sp += v[i];
+                sx += w[i];
+            }
         }
     }
     for (int e0 = d0 + GB; e0 < d1; e0 += 8) {
-        float v[8], w[8];
+        f32x4 v[8];
+        float w[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const size_t ee = (size_t)(e0 + i < d1 ? e0 + i : d1 - 1);
-            v[i] = gather_dz<BF>(dz, ee, c);
-            w[i] = dxrel[ee * 4 + (c & 3)];
+            v[i] = gather_dz4<BF>(dz, ee, c4);
+            w[i] = dxrel[ee * 4 + (c4 & 3)];
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            sq += e0 + i < d1 ? v[i] : 0.f;
-            sx -= (e0 + i < d1 && c < 3) ? w[i] : 0.f;
+            if (e0 + i < d1) {
+                sq += v[i];
+                sx -= w[i];
+            }
         }
     }
-    dP[(size_t)j * 64 + c] = sp;
-    dQ[(size_t)j * 64 + c] = sq;
-    if (c < 3) dx[(size_t)j * 3 + c] = a * d_xnew[(size_t)j * 3 + c] + sx;
+    if (live) {
+        *(f32x4*)(dP + (size_t)j * 64 + 4 * c4) = sp;
+        *(f32x4*)(dQ + (size_t)j * 64 + 4 * c4) = sq;
+        if (c4 < 3) dx[(size_t)j * 3 + c4] = a * d_xnew[(size_t)j * 3 + c4] + sx;
+    }
 }
 // pending: reductions to run in the same launch (emptied on return); what does not fit one descriptor is launched on
 // its own
@@ -1384,7 +1407,7 @@ int eqd_launch_node_gather(const EqdGraph* g, const float* dz, const float* dxre
         if (int e = red_plan(pending->seg, pending->n, P)) return e;
         nblk = red_fill(pending->seg, P, c0, arg);
     }
-    const int ng = (g->n_nodes + 3) / 4;
+    const int ng = (g->n_nodes + GATHER_NODES - 1) / GATHER_NODES;
     if (ng + nblk > 0) {
         if (dz_bf16)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_node_gather<true>), dim3(ng + nblk), dim3(256), 0, st, g->csc_ptr, g->csc_eid,
