@@ -178,6 +178,14 @@ int eqd_rowchain_blocks(int rows) {
     const int per = 16 * eqd_row_tiles(rows);
     return (rows + per - 1) / per;
 }
+// k_linear (what is left on it at large sizes: layer 0's 69-wide projection group and dh job, on the general body):
+// two tiles from 3 tiles per CU - the general body's ~3 500 clocks per step are then paid once per 32 rows (C bf16:
+// 156 -> 129 us per step, E: 78 -> 67; k_rowchain does not gain and keeps one tile)
+static int linear_row_tiles(int rows) {
+    const char* f = getenv("EQD_ROW_TILES");
+    if (f && (f[0] == '1' || f[0] == '2') && f[1] == 0) return f[0] - '0';
+    return (rows + 15) / 16 >= 3 * eqd_num_cus() ? 2 : 1;
+}
 
 // ------------------------------------------------------------------------------------------
 // k_rowchain: a sequence of row-local jobs on the same 16 rows in ONE launch; intermediate tiles stay
@@ -630,9 +638,10 @@ extern "C" int eqd_linear(const EqdLinJob* jobs, int njobs, void* stream) {
             if (J.rows > maxrows) maxrows = J.rows;
         }
         if (maxrows == 0) continue;
-        dim3 grid(eqd_rowchain_blocks(maxrows), n);
+        const int rt = linear_row_tiles(maxrows);
+        dim3 grid((maxrows + 16 * rt - 1) / (16 * rt), n);
         const bool bf = jobs[base].bf16 != 0;       // one arithmetic mode per launch
-        if (eqd_row_tiles(maxrows) == 2) {
+        if (rt == 2) {
             if (bf) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear<2, true>), grid, dim3(EQD_BLOCK), 0, st, arg);
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear<2, false>), grid, dim3(EQD_BLOCK), 0, st, arg);
         } else {
