@@ -205,6 +205,8 @@ __global__ __launch_bounds__(64 * RR_WAVES, 1) void k_rowres(EqdChainArg A_, int
         if (jj < njobs) Wc = jobw_load(&A.j[jj], CJ_DW, lane);
     }
     int buf = 0;
+    int trc = 0;      // source counter of the phase-trace experiments (profiles/exp_trace_rowwave.py)
+    (void)trc;
     RrStage WS;
     RrRows XR[RR_TMAX];
     const float* held_x = nullptr;      // the global source whose rows XR holds (wave-uniform)
@@ -241,6 +243,7 @@ __global__ __launch_bounds__(64 * RR_WAVES, 1) void k_rowres(EqdChainArg A_, int
             }
         }
         for (int si = 0; si < nsrc; ++si) {
+            EQD_TR(100 + 5 * trc);
             const EqdLinSrc S = jw_src(Wc, si);
             const int loc = jw_i(Wc, JW_OFF(EqdChainJob, src_local) + si);
             const bool last_src = si + 1 >= nsrc;
@@ -253,6 +256,7 @@ __global__ __launch_bounds__(64 * RR_WAVES, 1) void k_rowres(EqdChainArg A_, int
                 for (int s = 0; s < RR_TMAX; ++s)
                     if (s < nslots) rr_rows_take(S, slope, rowcs[s], g, XR[s], XC[s]);      // waits for the rows
             }
+            EQD_TR(101 + 5 * trc);
             // behind the copies (in front of them the copies would wait for these loads too): the next source's weights
             // and, within the job, its rows
             if (have_next) rr_stage_load(Sn, t, WS);
@@ -263,13 +267,20 @@ __global__ __launch_bounds__(64 * RR_WAVES, 1) void k_rowres(EqdChainArg A_, int
                     if (s < nslots) rr_rows_load(Sn, rowcs[s], g, XR[s]);
                 held_x = Sn.X; held_ld = Sn.ldx; held_k = Sn.K;
             }
+            EQD_TR(102 + 5 * trc);
 #pragma unroll
             for (int s = 0; s < RR_TMAX; ++s)
                 if (s < nslots) rr_item<BF>(sm.Wl[buf], S.K, tp, loc >= 0, sm.tile[wave][s], XC[s], l15, g, acc[s]);
+            EQD_TR(103 + 5 * trc);
             if (have_next) rr_stage_store(Sn, t, WS, sm.Wl[buf ^ 1]);
+            EQD_TR(104 + 5 * trc);
             __syncthreads();      // every wave is done with Wl[buf]; Wl[buf ^ 1] is complete
             buf ^= 1;
+            ++trc;
         }
+        // (fetching both tiles' residual rows and the parameter vectors ahead of the arithmetic - the epilogues and job
+        // transitions are 24-31 % of a launch, profiles/r02_exp_trace_rowres_C*.txt - was measured SLOWER: the kernel is at
+        // its register limit and the extra live values spill, k_rowres 975 -> 1 213 us per step at C)
 #pragma unroll
         for (int s = 0; s < RR_TMAX; ++s)
             if (s < nslots) rw_epilogue(Wc, tp, acc[s], sm.tile[wave][s], row0s[s], l15, g, 0);

@@ -198,38 +198,78 @@ __device__ __forceinline__ void rw_mma(const RwOps<BF>& O, bool local, const f32
     }
 }
 
-// Y = alpha * f(acc + bias) + beta * R of one job for the wave's rows (EqdLinJob semantics, see equidock_hip.h)
-// tstride: floats between the LDS tiles of consecutive local ids (0: every id names the same tile, k_rowres)
-__device__ __forceinline__ void rw_epilogue(const JobW& W, bool tp, const f32x4 (&acc)[4], float* tiles, int row0, int l15,
-                                            int g, int tstride = 16 * RW_S) {
+// Y = alpha * f(acc + bias) + beta * R of one job for the wave's rows (EqdLinJob semantics, see equidock_hip.h).
+// In two steps so that a caller with several tiles (k_rowres) can put ALL the epilogue's loads in flight first: the
+// job's parameter vectors once (RwEpiParams), each tile's residual rows (rw_epi_rows), then the arithmetic per tile -
+// one load latency per job instead of two or three per tile (they were 24-31 % of a k_rowres launch,
+// profiles/r02_exp_trace_rowres_C*.txt).
+struct RwEpiParams {
+    f32x4 bias[4], lg[4], lb[4];
+};
+__device__ __forceinline__ void rw_epi_feat(bool tp, int g, int (&ft)[4]) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) ft[a] = tp ? 16 * g + 4 * a : 16 * a + 4 * g;
+}
+__device__ __forceinline__ void rw_epi_params(const JobW& W, bool tp, int g, RwEpiParams& P) {
+#define LJ(f) JW_OFF(EqdLinJob, f)
+    int ft[4];
+    rw_epi_feat(tp, g, ft);
+    const float* const jbias = jw_p<const float>(W, LJ(bias));
+    const float* const jlng = jw_p<const float>(W, LJ(ln_g));
+    const float* const jlnb = jw_p<const float>(W, LJ(ln_b));
+    if (jbias) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) P.bias[a] = *(const EQD_GAS f4v*)(jbias + ft[a]);
+    }
+    if (jlng) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            P.lg[a] = *(const EQD_GAS f4v*)(jlng + ft[a]);
+            P.lb[a] = *(const EQD_GAS f4v*)(jlnb + ft[a]);
+        }
+    }
+#undef LJ
+}
+__device__ __forceinline__ void rw_epi_rows(const JobW& W, bool tp, int row0, int l15, int g, f32x4 (&res)[4]) {
 #define LJ(f) JW_OFF(EqdLinJob, f)
     const int rows = jw_i(W, LJ(rows));
     const int rowi = row0 + l15;
-    const bool rv = rowi < rows;
-    const int rowe = rv ? rowi : rows - 1;
+    const int rowe = rowi < rows ? rowi : rows - 1;
     int ft[4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) ft[a] = tp ? 16 * g + 4 * a : 16 * a + 4 * g;
-    const float* const jbias = jw_p<const float>(W, LJ(bias));
-    const float* const jlng = jw_p<const float>(W, LJ(ln_g));
+    rw_epi_feat(tp, g, ft);
     const float* const jR = jw_p<const float>(W, LJ(R));
-    const float slope = jw_f(W, LJ(slope));
-    f32x4 res[4];
     const int ldr = jw_i(W, LJ(ldr));
     if (jR) {
         const float* rp = jR + (size_t)rowe * ldr;
 #pragma unroll
         for (int a = 0; a < 4; ++a) res[a] = *(const EQD_GAS f4v*)(rp + ft[a]);
     }
+#undef LJ
+}
+// tstride: floats between the LDS tiles of consecutive local ids (0: every id names the same tile, k_rowres)
+// epl (k_rowres): the job's parameter vectors in LDS ([bias | ln_g | ln_b] x 64 floats) instead of P
+__device__ __forceinline__ void rw_epi_finish(const JobW& W, bool tp, const f32x4 (&acc)[4], const RwEpiParams& P,
+                                              const f32x4 (&res)[4], float* tiles, int row0, int l15, int g, int tstride,
+                                              const float* epl = nullptr) {
+#define LJ(f) JW_OFF(EqdLinJob, f)
+    const int rows = jw_i(W, LJ(rows));
+    const int rowi = row0 + l15;
+    const bool rv = rowi < rows;
+    int ft[4];
+    rw_epi_feat(tp, g, ft);
+    const bool has_bias = jw_p<const float>(W, LJ(bias)) != nullptr;
+    const bool has_ln = jw_p<const float>(W, LJ(ln_g)) != nullptr;
+    const bool has_res = jw_p<const float>(W, LJ(R)) != nullptr;
+    const float slope = jw_f(W, LJ(slope));
     f32x4 v[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) v[a][b] = tp ? acc[b][a] : acc[a][b];
-    if (jbias) {
+    if (has_bias) {
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-            const f32x4 bv = *(const EQD_GAS f4v*)(jbias + ft[a]);
+            const f32x4 bv = epl ? *(const f32x4*)(epl + ft[a]) : P.bias[a];
 #pragma unroll
             for (int b = 0; b < 4; ++b) v[a][b] += bv[b];
         }
@@ -240,14 +280,7 @@ __device__ __forceinline__ void rw_epilogue(const JobW& W, bool tp, const f32x4 
 #pragma unroll
             for (int b = 0; b < 4; ++b) v[a][b] = lrelu(v[a][b], slope);
     }
-    if (jlng) {
-        const float* const jlnb = jw_p<const float>(W, LJ(ln_b));
-        f32x4 lg[4], lb[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            lg[a] = *(const EQD_GAS f4v*)(jlng + ft[a]);
-            lb[a] = *(const EQD_GAS f4v*)(jlnb + ft[a]);
-        }
+    if (has_ln) {
         float* const jpre = jw_p<float>(W, LJ(pre_ln));
         const int ld_pre = jw_i(W, LJ(ld_pre));      // (descriptor reads are wave operations: never under a lane predicate)
         if (jpre && rv) {
@@ -269,15 +302,18 @@ __device__ __forceinline__ void rw_epilogue(const JobW& W, bool tp, const f32x4 
             }
         const float rstd = 1.f / sqrtf(group_sum(q) * (1.f / 64.f) + jw_f(W, LJ(ln_eps)));
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 4; ++a) {
+            const f32x4 lg = epl ? *(const f32x4*)(epl + 64 + ft[a]) : P.lg[a];
+            const f32x4 lb = epl ? *(const f32x4*)(epl + 128 + ft[a]) : P.lb[a];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) v[a][b] = (v[a][b] - mean) * rstd * lg[a][b] + lb[a][b];
+            for (int b = 0; b < 4; ++b) v[a][b] = (v[a][b] - mean) * rstd * lg[b] + lb[b];
+        }
     }
     const float alpha = jw_f(W, LJ(alpha)), beta = jw_f(W, LJ(beta));
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) v[a][b] = alpha * v[a][b] + (jR ? beta * res[a][b] : 0.f);
+        for (int b = 0; b < 4; ++b) v[a][b] = alpha * v[a][b] + (has_res ? beta * res[a][b] : 0.f);
     float* const jY = jw_p<float>(W, LJ(Y));
     const int ldy = jw_i(W, LJ(ldy));
     if (jY && rv) {
@@ -294,28 +330,42 @@ __device__ __forceinline__ void rw_epilogue(const JobW& W, bool tp, const f32x4 
     }
 #undef LJ
 }
+__device__ __forceinline__ void rw_epilogue(const JobW& W, bool tp, const f32x4 (&acc)[4], float* tiles, int row0, int l15,
+                                            int g, int tstride = 16 * RW_S) {
+    RwEpiParams P;
+    f32x4 res[4];
+    rw_epi_rows(W, tp, row0, l15, g, res);
+    rw_epi_params(W, tp, g, P);
+    rw_epi_finish(W, tp, acc, P, res, tiles, row0, l15, g, tstride);
+}
 
-// LeakyReLU -> LayerNorm backward of the wave's rows (EqdChainJob.type 1; same mathematics as chain_lnbwd64)
-__device__ __forceinline__ void rw_lnbwd(const JobW& W, float* tiles, float* red, int row0, int l15, int g,
-                                         int tstride = 16 * RW_S) {
+// LeakyReLU -> LayerNorm backward of the wave's rows (EqdChainJob.type 1; same mathematics as chain_lnbwd64); the loads
+// of a tile's saved activations (rw_lnbwd_rows) apart from the arithmetic, for the same reason as in the epilogue
+__device__ __forceinline__ void rw_lnbwd_rows(const JobW& W, int row0, int l15, int g, f32x4 (&y)[4]) {
+#define LJ(f) JW_OFF(EqdLinJob, f)
+    const int rows = jw_i(W, LJ(rows));
+    const int rowi = row0 + l15;
+    const float* yp = jw_p<const float>(W, LJ(s) + JW_OFF(EqdLinSrc, X)) +
+                      (size_t)(rowi < rows ? rowi : rows - 1) * jw_i(W, LJ(s) + JW_OFF(EqdLinSrc, ldx)) + 4 * g;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) y[a] = *(const EQD_GAS f4v*)(yp + 16 * a);
+#undef LJ
+}
+__device__ __forceinline__ void rw_lnbwd_finish(const JobW& W, const f32x4 (&yin)[4], const f32x4 (&gam)[4], float* tiles,
+                                                float* red, int row0, int l15, int g, int tstride) {
 #define LJ(f) JW_OFF(EqdLinJob, f)
     const int rows = jw_i(W, LJ(rows));
     const int src_l = jw_i(W, JW_OFF(EqdChainJob, src_local)), out_l = jw_i(W, JW_OFF(EqdChainJob, out_local));
     const float slope = jw_f(W, LJ(slope)), ln_eps = jw_f(W, LJ(ln_eps));
     const int rowi = row0 + l15;
     const bool rv = rowi < rows;
-    const float* const jg = jw_p<const float>(W, LJ(ln_g));
-    const float* yp = jw_p<const float>(W, LJ(s) + JW_OFF(EqdLinSrc, X)) +
-                      (size_t)(rv ? rowi : rows - 1) * jw_i(W, LJ(s) + JW_OFF(EqdLinSrc, ldx)) + 4 * g;
-    f32x4 y[4], gam[4], o[4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        y[a] = *(const EQD_GAS f4v*)(yp + 16 * a);
-        gam[a] = *(const EQD_GAS f4v*)(jg + 16 * a + 4 * g);
-    }
+    f32x4 y[4], o[4];
     const float* T = tiles + src_l * tstride + l15 * RW_S + 4 * g;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) o[a] = *(const f32x4*)(T + 16 * a);
+    for (int a = 0; a < 4; ++a) {
+        o[a] = *(const f32x4*)(T + 16 * a);
+        y[a] = yin[a];
+    }
     if (!rv) {
 #pragma unroll
         for (int a = 0; a < 4; ++a) o[a] = y[a] = f4zero();
@@ -378,6 +428,18 @@ __device__ __forceinline__ void rw_lnbwd(const JobW& W, float* tiles, float* red
     red[f] += dg;
     red[128 + f] += db;
 #undef LJ
+}
+__device__ __forceinline__ void rw_lnbwd_gamma(const JobW& W, int g, f32x4 (&gam)[4]) {
+    const float* const jg = jw_p<const float>(W, JW_OFF(EqdLinJob, ln_g));
+#pragma unroll
+    for (int a = 0; a < 4; ++a) gam[a] = *(const EQD_GAS f4v*)(jg + 16 * a + 4 * g);
+}
+__device__ __forceinline__ void rw_lnbwd(const JobW& W, float* tiles, float* red, int row0, int l15, int g,
+                                         int tstride = 16 * RW_S) {
+    f32x4 y[4], gam[4];
+    rw_lnbwd_rows(W, row0, l15, g, y);
+    rw_lnbwd_gamma(W, g, gam);
+    rw_lnbwd_finish(W, y, gam, tiles, red, row0, l15, g, tstride);
 }
 
 // One wave per 16-row tile; workgroup = RW_WAVES independent waves (they only meet to add their LayerNorm-backward
