@@ -277,6 +277,7 @@ struct EqdChainArg {
 // partial_rows (optional): rows of LayerNorm-backward partial sums the launch wrote (= its workgroups)
 int eqd_launch_rowchain(const EqdChainJob* jobs, int njobs, int rows, hipStream_t st, int* partial_rows = nullptr);
 size_t eqd_atb_batch_partial_bytes(int rows);
+int eqd_rows_resident(int rows);      // 1: row chains of this size run on k_rowres (eqd_node_kernels.hip)
 int eqd_row_tiles(int rows);          // 16-row tiles per workgroup of the row kernels
 int eqd_rowchain_blocks(int rows);    // = workgroups of a row-chain launch = LayerNorm-backward partial rows
 

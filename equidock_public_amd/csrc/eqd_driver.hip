@@ -367,6 +367,7 @@ extern "C" int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const
         }
         return nj;
     };
+    bool proj_in_chain = false;      // layer l's projections were computed by layer l - 1's node-update chain
     for (int l = 0; l < D.L; ++l) {
         const float* const* p = params + (size_t)EQD_PARAMS_PER_LAYER * l;
         const int d = D.d_in(l);
@@ -378,8 +379,9 @@ extern "C" int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const
             if (!(Ls.qa < Ls.ka && Ls.ka < Ls.va)) return EQD_ERR_WORKSPACE;
             HIPOK(hipMemsetAsync(Ls.qa, 0, (size_t)((char*)(Ls.va + (size_t)N * da) - (char*)Ls.qa), st));
         }
-        // ---- node projections (5 independent jobs, one launch: they run side by side) ---------------------
-        {
+        // ---- node projections (5 independent jobs, one launch: they run side by side) - unless the previous
+        //      layer's node-update chain already carried them (large batches, see below) ---------------------
+        if (!proj_in_chain) {
             EqdChainJob cj[8];
             const int nj = node_pre_jobs(l, h, -1, cj);
             EqdLinJob jobs[8];
@@ -428,7 +430,7 @@ extern "C" int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const
             j2.alpha = m->skip_weight_h; j2.beta = 1.f - m->skip_weight_h; j2.R = h; j2.ldr = d;
         }
         {   // one launch: the LayerNorm output stays in LDS for node_mlp.4
-            EqdChainJob cj[2];
+            EqdChainJob cj[EQD_CHAIN_MAXJOBS];
             memset(cj, 0, sizeof(cj));
             for (int k = 0; k < 2; ++k) {
                 for (int i = 0; i < EQD_MAX_SRC; ++i) cj[k].src_local[i] = -1;
@@ -436,7 +438,19 @@ extern "C" int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const
             }
             cj[0].lin = j1; cj[0].out_local = 0;
             cj[1].lin = j2; cj[1].src_local[0] = 0;
-            RC(eqd_launch_rowchain(cj, 2, N, st));
+            int nj = 2;
+            // Large batches (row chains on k_rowres, where a wave runs a chain's jobs one after the other anyway): the
+            // next layer's projections ride in this chain, reading h(l+1) from the LDS tile - one launch, and one
+            // pass over the h rows, less per layer.  (With the four-wave kernels of small batches this was measured
+            // slower: 46 vs 33 us, the five projections then run one after the other instead of side by side; layer 0's
+            // 69-wide chain stays on those kernels at every size, so it never carries projections.)
+            proj_in_chain = l + 1 < D.L && d == 64 && D.d_in(l + 1) == 64 && D.dh == 64 && eqd_rows_resident(N) &&
+                            2 + (m->cross_msgs ? 5 : 2) <= EQD_CHAIN_MAXJOBS;
+            if (proj_in_chain) {
+                cj[1].out_local = 1;
+                nj += node_pre_jobs(l + 1, S.h[l + 1], 1, cj + 2);
+            }
+            RC(eqd_launch_rowchain(cj, nj, N, st));
         }
     }
     {

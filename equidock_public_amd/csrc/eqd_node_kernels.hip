@@ -427,6 +427,11 @@ static int lin_check_sources(const EqdLinJob& J) {
 // does (C fp32 7 107 -> 7 329 k_rowwave -> 7 607 k_rowres, C bf16 9 971 -> 10 537 -> 11 390, E 551 -> 552 -> 562).
 // Default: k_rowres from 3 tiles per CU, k_rowchain / k_linear below; EQD_ROWWAVE = 0 / 1 / 2 forces k_rowchain +
 // k_linear / k_rowwave / k_rowres for every eligible chain (tests, experiments).
+static int rw_mode(int rows);
+// 1 when chains over `rows` rows run on k_rowres: a wave walks a chain's jobs one after the other there, so the driver
+// appends the next layer's five projection jobs to the node-update chain (they read its result from the LDS tile)
+// instead of launching them on their own - below that size they run side by side on k_linear, which is faster
+int eqd_rows_resident(int rows) { return rows > 0 && rw_mode(rows) == 2; }
 static int rw_mode(int rows) {
     const char* f = getenv("EQD_ROWWAVE");
     if (f && f[0] >= '0' && f[0] <= '2' && f[1] == 0) return f[0] - '0';
