@@ -6,8 +6,10 @@
 // Transposed formulation, as everywhere in this library: features on the MFMA M axis, the tile's 16 rows on the N axis.
 // A wave owns all 64 output features of its rows, so
 //   * nothing is shared between waves: no barrier, no staging - the A operand (weights) is loaded from global memory
-//     (L2 / L1 resident: <= 170 KB per chain) straight into the lanes that feed the MFMA, 16 x 16-byte loads per 64-wide
-//     K step, issued one step ahead of the 64 (fp32) / 16 (bf16) MFMAs that consume them;
+//     (L2 resident: <= 170 KB per chain) straight into the lanes that feed the MFMA.  A source is walked in sub-steps of
+//     32 columns: 12 x 16-byte loads (8 weight vectors, 2 row vectors, 2 mask vectors - always 12, see rw_load) issued
+//     one sub-step ahead of the 32 (fp32) / 8 (bf16) MFMAs that consume them, through a copy into MFMA-only registers
+//     (rw_take) so that the matrix instructions never wait for loads in flight;
 //   * the D layout of one job is the B layout of the next: lane (l15, g) holds, of row l15, 16 features v[a][b],
 //       S layout: feature 16 a + 4 g + b      (weights W[m][k], k contiguous:  acc[mb][r] = v[mb][r])
 //       P layout: feature 16 g + 4 a + b      (weights W[k][m], m contiguous:  acc[j][r]  = v[r][j])
@@ -20,9 +22,14 @@
 // Arithmetic: the same products as k_rowchain, summed in another order (fp32: within the north-star tolerance, and
 // checked against the same oracle; bf16: inputs rounded at the same points).
 //
-// Eligible chains (rw_eligible, host): every job 64 outputs wide; sources 64 wide, or 65..80 wide with k-contiguous
-// weights, read from global memory and without mask (the 69-wide h0 of node_mlp.0); one weight orientation per job.
-// Everything else - layer 0 with its 69-wide features - stays on k_rowchain / k_linear.
+// Eligible chains (rw_eligible, host): every job 64 outputs wide; sources 64 wide, or 65..80 wide when read from global
+// memory without mask (the 69-wide h0 of node_mlp.0); one weight orientation per job; no global source that an earlier
+// job of the chain writes.  Everything else - layer 0 with its 69-wide features - stays on k_rowchain / k_linear.
+// This kernel is the middle form: measured faster than the four-wave kernels only from a few tiles per CU, and slower
+// than k_rowres (weights resident in LDS, eqd_rowres_inl.h) there, because every wave streams the chain's weights for
+// itself and a CU accepts only ~10-12 B/clock of loads.  It stays selectable (EQD_ROWWAVE=1), it takes the chains
+// k_rowres cannot (more than one live intermediate tile), and its helpers (layouts, epilogue, LayerNorm backward) are
+// k_rowres's.
 #pragma once
 #include "eqd_linear_inl.h"
 
