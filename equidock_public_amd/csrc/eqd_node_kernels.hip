@@ -664,7 +664,9 @@ extern "C" int eqd_linear(const EqdLinJob* jobs, int njobs, void* stream) {
 //   wave tile: 80 (M axis, output rows m) x 64 (N axis, output cols n), K axis = graph rows.
 //   then k_atb_reduce sums the chunks in a fixed order and accumulates into the gradient.
 // ------------------------------------------------------------------------------------------
-#define ATB_MAXUNITS 36   /* 36 x 112 B of kernel arguments */
+#define ATB_MAXUNITS 128  /* 128 x 112 B = 14 KB of kernel arguments: every weight-gradient GEMM of an 8-layer backward pass
+                             (~100 units) in ONE launch + ONE reduction (36 units = 4 KB meant three of each: -25 us per
+                             config-B step).  HIP passes kernel arguments of this size (checked with 12 KB on gfx950) */
 #define ATB_TILE 5120  /* 80 x 64 */
 #define ATB_PSTRIDE 5200
 struct AtbUnit {
@@ -673,7 +675,7 @@ struct AtbUnit {
     int fast;        // 0 general; 1 / 2: M == 64 with aligned X rows, Y block whole and aligned / through ld4u (atb_fast)
     long long poff;  // float offset of this unit's partials
 };
-static_assert(sizeof(AtbUnit) * ATB_MAXUNITS <= 4096, "AtbUnitsArg must fit the kernel-argument segment");
+static_assert(sizeof(AtbUnit) * ATB_MAXUNITS <= 16384, "AtbUnitsArg: keep the kernel-argument segment moderate");
 struct AtbUnitsArg {
     AtbUnit u[ATB_MAXUNITS];
 };
@@ -977,9 +979,11 @@ static int atb_next_batch(std::vector<AtbUnit>& units, size_t first, long long* 
         if (clash) break;
         ++n;
     }
-    // ~1024 workgroups per launch; twice that once a unit has more 64-row chunks than that leaves it (config C: +1 %)
-    int target = ATB_TARGET_WGS;
+    // ~1024 workgroups per 36 units (the launch size this was tuned at); twice that once a unit has more 64-row chunks
+    // than that leaves it (config C: +1 %); at most 4096 (eqd_atb_batch_partial_bytes)
+    int target = ATB_TARGET_WGS * ((n + 35) / 36 > 0 ? (n + 35) / 36 : 1);
     if (!getenv("EQD_ATB_WGS") && n > 0 && units[first].nchunks > 8 * (target / n)) target *= 2;
+    target = target > 4096 ? 4096 : target;
     int per = (target + n - 1) / (n > 0 ? n : 1);
     per = per > ATB_MAXBLOCKS ? ATB_MAXBLOCKS : per;
     long long off = 0;
