@@ -891,42 +891,39 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_atb(AtbUnitsArg U, float* __restr
     if (t < 80) P[ATB_TILE + t] = bacc;
 }
 
+// Sums a unit's partial tiles in a fixed order and accumulates into the gradient.  Thread = (group of 4 elements, one
+// of 16 part lanes): 16-byte loads, a workgroup covers 256 elements of the 5 200-element partial (80 x 64 tile + 80
+// column sums); lane pl sums parts pl, pl + 16, .., then the 16 lanes are added in index order - the order of the
+// earlier one-element-per-thread kernel, which issued 4 x the load instructions (26.9 us for the ~100 units of a
+// config-B pass in one launch).
+#define ATB_RED_ELEMS 256
 __global__ __launch_bounds__(1024) void k_atb_reduce(AtbUnitsArg U, const float* __restrict__ partial) {
-    __shared__ float red[16][64];
+    __shared__ __attribute__((aligned(16))) float red[16][ATB_RED_ELEMS + 4];
     const AtbUnit& u = U.u[blockIdx.y];
     const EqdAtbJob& J = u.job;
-    const int c = threadIdx.x & 63, pl = threadIdx.x >> 6;
-    const int e = blockIdx.x * 64 + c;
-    int m = 0, n = 0;
-    bool ok = e < ATB_PSTRIDE;
-    const bool is_bias = e >= ATB_TILE;
-    if (ok) {
-        if (is_bias) {
-            m = e - ATB_TILE;
-            ok = J.bias_out && u.n0 == 0 && m < J.M;
-        } else {
-            m = e >> 6;
-            n = u.n0 + (e & 63);
-            ok = m < J.M && n < J.N;
-        }
-    }
-    float acc = 0.f;
-    if (ok) {
-        const float* P = partial + u.poff + e;
+    const int t = threadIdx.x, cg = t & 63, pl = t >> 6;       // element group cg (4 elements), part lane pl
+    const int e0 = blockIdx.x * ATB_RED_ELEMS + 4 * cg;
+    f32x4 acc = f4zero();
+    if (e0 < ATB_PSTRIDE) {
+        const float* P = partial + u.poff + e0;
 #pragma unroll 4
-        for (int p = pl; p < u.nparts; p += 16) acc += P[(long long)p * ATB_PSTRIDE];
+        for (int p = pl; p < u.nparts; p += 16) acc += *(const f32x4*)(P + (long long)p * ATB_PSTRIDE);
     }
-    red[pl][c] = acc;
+    *(f32x4*)&red[pl][4 * cg] = acc;
     __syncthreads();
-    if (pl == 0 && ok) {
+    if (t < ATB_RED_ELEMS) {
+        const int e = blockIdx.x * ATB_RED_ELEMS + t;
         float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) s += red[j][c];
+        for (int j = 0; j < 16; ++j) s += red[j][t];
         if (J.scale != 0.f) s *= J.scale;
-        if (is_bias)
-            J.bias_out[m] += s;
-        else
-            J.out[(size_t)m * J.o_rs + (size_t)n * J.o_cs] += s;
+        if (e < ATB_TILE) {
+            const int m = e >> 6, n = u.n0 + (e & 63);
+            if (m < J.M && n < J.N) J.out[(size_t)m * J.o_rs + (size_t)n * J.o_cs] += s;
+        } else if (e < ATB_PSTRIDE) {
+            const int m = e - ATB_TILE;
+            if (J.bias_out && u.n0 == 0 && m < J.M) J.bias_out[m] += s;
+        }
     }
 }
 
@@ -1040,7 +1037,7 @@ extern "C" int eqd_atb(const EqdAtbJob* jobs, int njobs, void* partial, size_t p
             rc = eqd_check_launch("k_atb");
             if (rc) return rc;
         }
-        hipLaunchKernelGGL(k_atb_reduce, dim3((ATB_PSTRIDE + 63) / 64, n), dim3(1024), 0, st, arg,
+        hipLaunchKernelGGL(k_atb_reduce, dim3((ATB_PSTRIDE + ATB_RED_ELEMS - 1) / ATB_RED_ELEMS, n), dim3(1024), 0, st, arg,
                            (const float*)partial);
         rc = eqd_check_launch("k_atb_reduce");
         if (rc) return rc;
