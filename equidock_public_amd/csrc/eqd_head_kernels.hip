@@ -215,33 +215,27 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_keypoint_bwd_a(const int32_t* __r
     if (rg == 0) du[((size_t)s * K + k) * 64 + c] = racc[0][c] + racc[1][c] + racc[2][c] + racc[3][c];
 }
 
-// part b: per node: dH[i] = sum_k dscores[i][k] u[seg][k];  dZ[i] = sum_k att[i][k] dY[seg][k].
-// 16 lanes per node with 16-byte loads of the u rows (lane c4 owns features 4 c4 ..; four nodes per wave): a quarter of
-// the load instructions of the one-lane-per-feature form; sums over the heads in index order, as before.
-#define KPB_NODES 16
-__global__ __launch_bounds__(256) void k_keypoint_bwd_b(const int32_t* __restrict__ seg_off, int nseg, int n, int K,
-                                                        const float* __restrict__ scores, const float* __restrict__ lse,
-                                                        const float* __restrict__ u, const float* __restrict__ dY,
-                                                        const float* __restrict__ dscores, float* __restrict__ dH,
-                                                        float* __restrict__ dZ) {
-    const int ir = blockIdx.x * KPB_NODES + (threadIdx.x >> 4), c4 = threadIdx.x & 15;
-    const bool live = ir < n;
-    const int i = live ? ir : n - 1;
+// part b: per node: dH[i] = sum_k dscores[i][k] u[seg][k];  dZ[i] = sum_k att[i][k] dY[seg][k]
+__global__ void k_keypoint_bwd_b(const int32_t* __restrict__ seg_off, int nseg, int n, int K,
+                                 const float* __restrict__ scores, const float* __restrict__ lse,
+                                 const float* __restrict__ u, const float* __restrict__ dY,
+                                 const float* __restrict__ dscores, float* __restrict__ dH, float* __restrict__ dZ) {
+    __shared__ float sds[128], sal[128];
+    const int i = blockIdx.x, t = threadIdx.x;  // 64 threads
+    if (i >= n) return;
     const int s = find_segment(seg_off, nseg, i);
-    const float* __restrict__ us = u + (size_t)s * K * 64 + 4 * c4;
-    const float* __restrict__ ds = dscores + (size_t)i * K;
-    f32x4 a = f4zero();
-    for (int k = 0; k < K; ++k) {
-        const float d = ds[k];
-        const f32x4 uv = *(const f32x4*)(us + (size_t)k * 64);
-        a[0] += d * uv[0]; a[1] += d * uv[1]; a[2] += d * uv[2]; a[3] += d * uv[3];
+    for (int k = t; k < K; k += 64) {
+        sds[k] = dscores[(size_t)i * K + k];
+        sal[k] = expf(scores[(size_t)i * K + k] - lse[(size_t)s * K + k]);
     }
-    if (live) *(f32x4*)(dH + (size_t)i * 64 + 4 * c4) = a;
-    if (live && c4 < 3) {
+    __syncthreads();
+    float a = 0.f;
+    for (int k = 0; k < K; ++k) a += sds[k] * u[((size_t)s * K + k) * 64 + t];
+    dH[(size_t)i * 64 + t] = a;
+    if (t < 3) {
         float z = 0.f;
-        for (int k = 0; k < K; ++k)
-            z += expf(scores[(size_t)i * K + k] - lse[(size_t)s * K + k]) * dY[((size_t)s * K + k) * 3 + c4];
-        dZ[(size_t)i * 3 + c4] = z;
+        for (int k = 0; k < K; ++k) z += sal[k] * dY[((size_t)s * K + k) * 3 + t];
+        dZ[(size_t)i * 3 + t] = z;
     }
 }
 
@@ -257,8 +251,8 @@ int eqd_launch_keypoint_bwd(const EqdGraph* g, int K, const float* H, const floa
                        lse, dY, dscores, du);
     int rc = eqd_check_launch("k_keypoint_bwd_a");
     if (rc) return rc;
-    hipLaunchKernelGGL(k_keypoint_bwd_b, dim3((g->n_nodes + KPB_NODES - 1) / KPB_NODES), dim3(256), 0, st, g->seg_off,
-                       2 * g->n_pairs, g->n_nodes, K, scores, lse, u, dY, dscores, dH, dZ);
+    hipLaunchKernelGGL(k_keypoint_bwd_b, dim3(g->n_nodes), dim3(64), 0, st, g->seg_off, 2 * g->n_pairs, g->n_nodes, K,
+                       scores, lse, u, dY, dscores, dH, dZ);
     return eqd_check_launch("k_keypoint_bwd_b");
 }
 
