@@ -513,7 +513,7 @@ def main():
         loss = batched_loss(lig, Yl, Yr, lig_w)
         loss.backward()
         return loss
-    l_ref = float(compute_torch_loss())
+    l_ref = float(compute_torch_loss().detach())
     g_ref = reducer.flat.clone()
     l_got = float(compute())
     if abs(l_got - l_ref) > 1e-5 * abs(l_ref) or float((reducer.flat - g_ref).abs().max()) > 1e-5 * float(g_ref.abs().max()):
