@@ -175,12 +175,12 @@ def check_model_bf16_states(dev, sizes, layers=8, seed=3, pair_seed=34, faithful
     ex = float((x.cpu() - x_ref).abs().max()) / float(x_ref.abs().max())
     ref_loss = float(port.scalar_loss(ref))
     line = (f'{what}: {len(sizes)} pairs, {layers} layers, bf16: last-layer h rel err {eh:.2e}, x rel err {ex:.2e}; '
-            f'loss {float(loss):.4f} vs oracle {ref_loss:.4f}')
+            f'loss {float(loss.detach()):.4f} vs oracle {ref_loss:.4f}')
     print(line)
     if report is not None:
         report.append(line)
     assert eh <= 2e-2 and ex <= 2e-3, line
-    assert abs(float(loss) - ref_loss) <= 0.3 * abs(ref_loss), line
+    assert abs(float(loss.detach()) - ref_loss) <= 0.3 * abs(ref_loss), line
     for T in outs[3]:
         t = T.detach().cpu()
         close(t @ t.t(), torch.eye(3), tol=1e-4, what='bf16 T T^T')
@@ -200,7 +200,7 @@ def _check_model_vs_oracle(dev, net, args, sd, sizes, layers, pair_seed, faithfu
     for nm, a, b in zip(('lig', 'Yl', 'Yr', 'T', 'b'), outs, ref):
         got, exp = cat_out(a), cat_out(b)
         close(got, exp, tol=tol, what=f'{what} output {nm}')
-        worst = max(worst, float((got.detach().cpu() - exp.detach()).abs().max()) / max(1.0, float(exp.abs().max())))
+        worst = max(worst, float((got.detach().cpu() - exp.detach()).abs().max()) / max(1.0, float(exp.detach().abs().max())))
     w2 = wm = 0.0
     for k, p in net.named_parameters():
         got = p.grad if p.grad is not None else torch.zeros_like(p)
@@ -505,7 +505,7 @@ def check_kabsch(dev):
         t, bb, a = port.kabsch(Yl[B + p], Yl[p])
         Ts.append(t)
         bs.append(bb.view(3))
-        dets.append(float(torch.det(a)))
+        dets.append(float(torch.det(a.detach())))
     assert min(dets) < 0 < max(dets)
     Tr, br = torch.stack(Ts), torch.stack(bs)
     close(T.view(B, 3, 3), Tr, tol=2e-5, what='Kabsch T')
@@ -650,7 +650,7 @@ def check_model_case(dev, name, check_grads=True):
     loss = port.scalar_loss(outs)
     loss.backward()
     sync(dev)
-    assert abs(float(loss) - float(z['loss'])) <= 1e-4 * abs(float(z['loss']))
+    assert abs(float(loss.detach()) - float(z['loss'])) <= 1e-4 * abs(float(z['loss']))
     gf = meta['grad_fingerprint']
     # the golden gradient is the reference's; the hull over near-kink LeakyReLU slopes comes from the oracle port (which
     # reproduces the golden gradient to <= 1.2e-6) on the same inputs.  The guard case draws from torch's RNG: no hull.
@@ -724,7 +724,7 @@ def check_flat_grads_equal_autograd(dev):
         assert torch.equal(a, b), f'flat-gradient mode diverged from autograd mode after optimizer steps: {k}'
         assert b.grad is not None and b.grad.data_ptr() >= flat.data_ptr() and \
             b.grad.data_ptr() < flat.data_ptr() + 4 * flat.numel(), k
-        moved = max(moved, float((a - c).abs().max()))
+        moved = max(moved, float((a.detach() - c.detach()).abs().max()))
     assert moved > 0
     # a replaced (not dropped) .grad cannot be accumulated into: loud error
     first = next(iter(n2.parameters()))

@@ -224,7 +224,7 @@ def test_bench_loss_equals_oracle_scalar_loss():
     ga = torch.autograd.grad(a * 1.7, (lig, Yl, Yr))
     b = port.scalar_loss((list(torch.split(lig, counts)), list(Yl), list(Yr), None, None))
     gb = torch.autograd.grad(b * 1.7, (lig, Yl, Yr))
-    assert abs(float(a) - float(b)) < 1e-12
+    assert abs(float(a.detach()) - float(b.detach())) < 1e-12
     for x, y in zip(ga, gb):
         assert torch.allclose(x, y, atol=1e-13)
 

@@ -46,7 +46,7 @@ def test_port_gradients_match_reference(name):
     outs = port.forward(sdp, args, raw, faithful=True)
     loss = port.scalar_loss(outs)
     loss.backward()
-    assert abs(float(loss) - float(z['loss'])) <= 1e-5 * abs(float(z['loss']))
+    assert abs(float(loss.detach()) - float(z['loss'])) <= 1e-5 * abs(float(z['loss']))
     for k in z.files:
         if not k.startswith('grad_'):
             continue
@@ -81,8 +81,8 @@ def test_loss_port_matches_reference_vectors():
         mse, inter = lp.mse_loss(a, t), lp.body_intersection_loss(a, r, sigma, ct)
         (gm,) = torch.autograd.grad(mse, a, retain_graph=True)
         (gi,) = torch.autograd.grad(inter, a)
-        assert abs(float(mse) - float(z[f'mse{p}'])) <= 1e-6 * max(1.0, abs(float(mse)))
-        assert abs(float(inter) - float(z[f'inter{p}'])) <= 1e-6 * max(1.0, abs(float(inter)))
+        assert abs(float(mse.detach()) - float(z[f'mse{p}'])) <= 1e-6 * max(1.0, abs(float(mse.detach())))
+        assert abs(float(inter.detach()) - float(z[f'inter{p}'])) <= 1e-6 * max(1.0, abs(float(inter.detach())))
         assert np.allclose(gm.numpy(), z[f'dmse{p}'], atol=1e-6) and np.allclose(gi.numpy(), z[f'dinter{p}'], atol=1e-6)
         nl = a.shape[0]
         assert np.allclose(lp.sq_dist_mat(t[: min(nl, 20)], torch.tensor(z[f'kp{p}'])).numpy(), z[f'sq{p}'], rtol=1e-6, atol=1e-5)
