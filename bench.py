@@ -1,6 +1,6 @@
 """bench.py -- protein-pairs/sec (fwd+bwd) of one IEGMN stack on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload B|A|C|D|E] [--dtype f32|bf16]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload B|A|C|D|E|R] [--dtype f32|bf16]
 
 A "step" = zero grads -> Rigid_Body_Docking_Net forward -> fixed scalar loss
 -> backward, on one synthetic batch that is already resident in HBM (the slice
@@ -11,7 +11,10 @@ every rank runs the same per-GPU batch (weak scaling) and the flat gradient buff
 all-reduced once per step over RCCL.
 
 The default workload is B for every N, so that the driver's N = 1, 2, 4, 8 runs form one weak-scaling curve;
-`--workload D` is BASELINE.json configs[3] (64 x (300,300) per GPU, bf16).
+`--workload D` is BASELINE.json configs[3] (64 x (300,300) per GPU, bf16); `--workload R` is SURVEY.md section 8d's
+"realistic sizes" variant: 64 ragged pairs drawn from the DB5.5 size statistics (ligand 29..1500, receptor 40..2130
+residues; synthetic.realistic_sizes), which also reports residue-pairs/s (sum n_lig * n_rec per second: the quadratic
+attention term) and the size spread.
 
 Rank 0 prints ONE JSON line with the contract fields plus
   "roofline":      the dominant kernel (edge-message backward/forward), measured live with HIP events on the launch
@@ -42,7 +45,9 @@ WORKLOADS = {
     'C': (64, (300, 300), 8, False, 0.75, 'f32', 'C: DIPS-sized batch of 64 pairs x (300,300) residues, k=10, 8-layer IEGMN'),
     'D': (64, (300, 300), 8, False, 0.75, 'bf16', 'D: DIPS-sized batch of 64 pairs x (300,300) per GPU (512 pairs on 8 GPUs), k=10, 8-layer IEGMN, data parallel'),
     'E': (4, (2000, 2000), 8, False, 0.75, 'f32', 'E: stress, 4 pairs x (2000,2000) residues, k=10, 8-layer IEGMN, fp32'),
+    'R': (64, None, 8, False, 0.75, 'f32', 'R: ragged batch of 64 pairs with DB5.5-distributed sizes (ligand 29..1500, receptor 40..2130 residues; SURVEY.md section 8d "realistic sizes"), k=10, 8-layer IEGMN, fp32'),
 }
+R_SIZE_SEED = 5055      # synthetic.realistic_sizes(64, R_SIZE_SEED + rank): the same ragged batch in every run
 PEAK_FP32_TFLOPS = 157.3   # MI355X fp32 vector = fp32-input MFMA peak (MI355X_MICROARCH.md)
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA (MI355X_MICROARCH.md; no sparsity)
 PEAK_HBM_GBS = 8000.0      # HBM3E spec
@@ -167,6 +172,20 @@ def batched_loss(lig, Yl, Yr, lig_w):
     return _BatchedLoss.apply(lig, Yl, Yr, lig_w)
 
 
+def _profile_order(path):
+    """Sort key that puts the NEWEST committed counter summary last: the file's own "collected" stamp when it has one
+    (json key `_collected`, ISO date-time written by profiles/merge_pmc.py), else its round number and name (r02_z4 after
+    r02_z: plain name order gets that wrong, '_' sorts after digits) - mtimes do not survive a git checkout."""
+    import re
+    try:
+        stamp = json.load(open(path)).get('_collected', '')
+    except Exception:
+        stamp = ''
+    m = re.match(r'r(\d+)_([a-z]+)(\d*)', os.path.basename(path))
+    rnd, tag, num = (int(m.group(1)), m.group(2), int(m.group(3) or 0)) if m else (0, '', 0)
+    return (stamp, rnd, tag, num, os.path.basename(path))
+
+
 def time_kernel(fn, iters, stream_sync):
     """Average duration of ONE launch of fn, from HIP events on the launch stream around batches of 10 back-to-back
     launches.  A spin kernel in front of every batch keeps the GPU busy while the host enqueues the batch, so host launch
@@ -267,7 +286,7 @@ def edge_kernel_rooflines(net, packed, dev, workload='B', bf16=False):
     # from inside the process): (2 * FETCH_SIZE + WRITE_SIZE) KB, see the file's comment for the correction
     try:
         import glob
-        files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*traffic.json')))      # newest round last
+        files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*traffic.json')), key=_profile_order)      # newest last
         tr = {} if (bf16 or not files) else json.load(open(files[-1])).get(workload, {})
         for k, v in tr.items():
             if k in out:
@@ -435,7 +454,7 @@ def load_pmc(workload):
     """MFMA utilisation / executed MFMA FLOPs per kernel from the newest committed PMC summary (profiles/*pmc_mfma*.json)."""
     import glob
     best = {}
-    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*pmc_mfma*.json'))):
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*pmc_mfma*.json')), key=_profile_order):
         try:
             d = json.load(open(f)).get(workload)
             if d:
@@ -471,8 +490,13 @@ def main():
     one_dev = os.environ.get('EQD_BENCH_ONE_DEVICE') == '1'
     dev = torch.device('cuda', 0 if one_dev else local_rank)
     torch.cuda.set_device(dev)
-    if world > 1:
+    # under torch.distributed.run (RANK set) the process group is created even for a world of one, so that the RCCL
+    # all-reduce of the flat gradient is part of the step and gets measured; a plain `python bench.py` has no group
+    use_dist = world > 1 or 'RANK' in os.environ
+    backend = None
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         backend = os.environ.get('EQD_BENCH_BACKEND', 'nccl')
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=dev)
@@ -481,7 +505,7 @@ def main():
 
     from equidock_public_amd import config, graph, model, parallel, synthetic
 
-    ppg, (nl, nr), L, shared, skh, wl_dtype, desc = WORKLOADS[a.workload]
+    ppg, uniform, L, shared, skh, wl_dtype, desc = WORKLOADS[a.workload]
     dtype = a.dtype or wl_dtype
     args_model = config.published_args(iegmn_n_lays=L, shared_layers=shared, skip_weight_h=skh, device=dev)
     if dtype == 'bf16':
@@ -489,7 +513,7 @@ def main():
     sd = config.seeded_state_dict(args_model, seed=0)
     net = model.Rigid_Body_Docking_Net(args_model).to(dev)
     net.load_state_dict(sd)
-    sizes = [(nl, nr)] * ppg
+    sizes = [uniform] * ppg if uniform else synthetic.realistic_sizes(ppg, R_SIZE_SEED + rank)
     pairs = synthetic.make_pairs(sizes, seed=1000 + rank)
     g = graph.batch_pairs(pairs).to(dev)
     packed = g.pack()
@@ -520,31 +544,47 @@ def main():
         raise SystemExit(f"fused scalar loss disagrees with its torch formulation: {l_got} vs {l_ref}")
 
     # Default: capture zero-grad -> forward -> loss -> backward ONCE into a hipGraph and replay it every step (every
-    # kernel still runs every step; the RCCL all-reduce of the flat gradient stays outside the graph).  --eager launches
-    # from the host instead; a failed capture falls back to that as well.
+    # kernel still runs every step).  With a process group the RCCL all-reduce of the flat gradient is captured INSIDE the
+    # graph (RCCL supports stream capture: the collective becomes a graph node, no host enqueue per step); if that
+    # capture fails the graph is rebuilt without it and the collective is enqueued from the host after every replay.
+    # --eager launches everything from the host; a failed capture falls back to that as well.
     graph_mode = 'eager'
     static_loss = None
     cuda_graph = None
+    allreduce_in_graph = False
+
+    def capture(with_allreduce):
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()      # no collective in flight while the stream is capturing
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                compute()
+                if with_allreduce:
+                    reducer.reduce(force=True)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, capture_error_mode='thread_local'):
+            loss_ = compute()
+            if with_allreduce:
+                reducer.reduce(force=True)
+        return gr, loss_
     if not a.eager:
-        try:
-            torch.cuda.synchronize()
-            if world > 1:
-                dist.barrier()      # no collective in flight while the stream is capturing
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(3):
-                    compute()
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            cuda_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(cuda_graph, capture_error_mode='thread_local'):
-                static_loss = compute()
-            graph_mode = 'hipGraph replay'
-        except Exception as e:   # capture not possible: fall back to eager launches (still the HIP path)
-            print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-            cuda_graph = None
-            torch.cuda.synchronize()
+        want_ar = use_dist and backend == 'nccl' and os.environ.get('EQD_BENCH_ALLREDUCE_IN_GRAPH', '1') == '1'
+        for with_ar in ([True, False] if want_ar else [False]):
+            try:
+                cuda_graph, static_loss = capture(with_ar)
+                graph_mode = 'hipGraph replay'
+                allreduce_in_graph = with_ar
+                break
+            except Exception as e:   # capture not possible: without the collective, then eager launches (still the HIP path)
+                print(f"[bench] graph capture ({'with' if with_ar else 'without'} the all-reduce) failed "
+                      f"({type(e).__name__}: {e})", file=sys.stderr)
+                cuda_graph = None
+                torch.cuda.synchronize()
 
     def step():
         if cuda_graph is not None:
@@ -552,12 +592,13 @@ def main():
             loss = static_loss
         else:
             loss = compute()
-        reducer.reduce()
+        if use_dist and not allreduce_in_graph:
+            reducer.reduce(force=True)
         return loss
 
     for _ in range(a.warmup):
         step()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -565,13 +606,33 @@ def main():
         loss = step()
     host_dt = time.perf_counter() - t0      # host-side enqueue time (== dt when the step is launch-bound)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    # the collective on its own (outside the timed region): HIP events around batches of back-to-back all-reduces of the
+    # flat gradient buffer, every rank taking part; max over ranks
+    allreduce_us = None
+    if use_dist:
+        for _ in range(3):
+            reducer.reduce(force=True)
+        torch.cuda.synchronize()
+        dist.barrier()
+        reps, per = 5, 10
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for e0, e1 in evs:
+            e0.record()
+            for _ in range(per):
+                reducer.reduce(force=True)
+            e1.record()
+        torch.cuda.synchronize()
+        ts = sorted(e0.elapsed_time(e1) / per * 1e3 for e0, e1 in evs)
+        tt = torch.tensor([ts[len(ts) // 2]], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        allreduce_us = float(tt.item())
     status = net.iegmn_original.last_svd_status
     svd_bad = int((status != 0).sum().item())
 
@@ -591,7 +652,23 @@ def main():
                        "weights": "PyTorch default init (seed 0), ROT key/query x40 (SURVEY.md section 8c)",
                        "loss": float(loss.detach()), "svd_guard_pairs": svd_bad,
                        "host_enqueue_ms_per_step": round(host_dt / a.steps * 1e3, 4), "launch_mode": graph_mode},
+            # data parallel: ranks of the RCCL communicator the flat-gradient all-reduce ran on (0 = no process group: a
+            # plain single-process run), whether the collective was a node of the replayed hipGraph, and its duration
+            # alone (HIP events around back-to-back all-reduces of the buffer, after the timed region; max over ranks)
+            "rccl_ranks": (world if (use_dist and backend == 'nccl') else 0),
+            "allreduce_in_graph": bool(allreduce_in_graph),
+            "allreduce_us_per_step": (None if allreduce_us is None else round(allreduce_us, 2)),
+            "allreduce_bytes": int(reducer.flat.numel() * 4),
         }
+        if not uniform:      # ragged workload: the size spread and the quadratic-term rate
+            nls, nrs = [s[0] for s in sizes], [s[1] for s in sizes]
+            pp = sum(x * y for x, y in sizes)
+            out["config"].update({
+                "sizes": {"ligand_min_median_max": [min(nls), sorted(nls)[len(nls) // 2], max(nls)],
+                          "receptor_min_median_max": [min(nrs), sorted(nrs)[len(nrs) // 2], max(nrs)],
+                          "sum_nlig_x_nrec": pp, "size_seed": R_SIZE_SEED,
+                          "largest_pair_share_of_sum_nlig_x_nrec": round(max(x * y for x, y in sizes) / pp, 4)}})
+            out["residue_pairs_per_s"] = round(pp * world * a.steps / dt, 1)
         flops_step = 3.0 * step_flops_as_written(sizes, L)
         peak_tf = PEAK_BF16_TFLOPS if dtype == 'bf16' else PEAK_FP32_TFLOPS
         out["whole_step"] = {"as_written_flops_per_step": flops_step,
@@ -624,7 +701,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(config.published_args(iegmn_n_lays=L, shared_layers=shared,
                                                                      skip_weight_h=skh), sd, pairs)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

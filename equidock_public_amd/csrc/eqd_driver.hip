@@ -273,6 +273,69 @@ extern "C" int eqd_model_layer_state(const EqdModelDesc* m, const EqdGraph* g, c
     return EQD_OK;
 }
 
+// Test / debug aid: the LeakyReLU branch decisions of a forward whose state is in `saved`, as one byte per element
+// (1 = pre-activation > 0).  The backward takes its node-level masks from the saved activations (y_act, qa, ka, hm: the
+// sign of LeakyReLU(z) is the sign of z) and the edge-level ones from the per-tile recompute; both are reproduced here
+// bit for bit, so that a CPU oracle can be evaluated with exactly the slopes the library used and its gradient compared
+// plainly (tests/parity_common.py) - a pre-activation within rounding of 0 otherwise takes either slope depending on
+// the summation order, in the reference as much as here.
+__global__ void k_sign_rows(const float* __restrict__ src, int ld, int rows, int d, unsigned char* __restrict__ out) {
+    const size_t n = (size_t)rows * d;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / d;
+        out[i] = src[r * ld + (i - r * d)] > 0.f ? 1 : 0;
+    }
+}
+int eqd_launch_edge_signs(const EqdGraph* g, const EqdEdgeParams* p, const float* P, const float* Q, const float* x,
+                          unsigned char* z1_pos, unsigned char* ch_pos, hipStream_t st);
+
+extern "C" int eqd_model_lrelu_signs(const EqdModelDesc* m, const EqdGraph* g, const float* const* params,
+                                     const void* saved, size_t saved_bytes, int layer, unsigned char* edge_z1,
+                                     unsigned char* edge_ch, unsigned char* node, unsigned char* q, unsigned char* k,
+                                     void* stream) {
+    if (int rc = eqd_model_check(m, g)) return rc;
+    if (!params || !saved) {
+        eqd_set_error("eqd_model_lrelu_signs: NULL argument");
+        return EQD_ERR_NULL;
+    }
+    const Dims D = make_dims(m, g);
+    if (layer < 0 || layer > D.L) {
+        eqd_set_error("eqd_model_lrelu_signs: layer %d outside 0..%d", layer, D.L);
+        return EQD_ERR_SHAPE;
+    }
+    EqdArena A(const_cast<void*>(saved), saved_bytes);
+    Saved S;
+    carve_saved(D, g, A, S);
+    if (!A.ok) {
+        eqd_set_error("eqd_model_lrelu_signs: saved buffer too small");
+        return EQD_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    auto rows = [&](const float* src, int ld, int d, unsigned char* out) -> int {
+        if (!out) return EQD_OK;
+        const size_t n = (size_t)D.N * d;
+        int blocks = (int)((n + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(k_sign_rows, dim3(blocks), dim3(256), 0, st, src, ld, D.N, d, out);
+        return eqd_check_launch("k_sign_rows");
+    };
+    if (layer == D.L)      // head: mlp_h_mean_ROT's LeakyReLU (rigid_docking_model.py:434-438), [n_nodes][64]
+        return rows(S.hm, 64, 64, node);
+    const float* const* p = params + (size_t)EQD_PARAMS_PER_LAYER * layer;
+    const LayerSaved& Ls = S.lay[layer];
+    const int d = D.d_in(layer), da = D.d_att(layer);
+    if (int rc = rows(Ls.y_act, d, d, node)) return rc;
+    if (m->cross_msgs) {
+        if (int rc = rows(Ls.qa, da, d, q)) return rc;
+        if (int rc = rows(Ls.ka, da, d, k)) return rc;
+    }
+    if (edge_z1 && edge_ch) {
+        EqdEdgeParams ep = edge_params(D, m, layer, p);
+        return eqd_launch_edge_signs(g, &ep, Ls.P, Ls.Q, S.x[layer], edge_z1, edge_ch, st);
+    }
+    return EQD_OK;
+}
+
 // ---- execution context: auxiliary streams + events -----------------------------------------------------
 struct EqdCtx {
     hipStream_t sa;              // attention branch of the forward (runs beside the edge-message kernel)

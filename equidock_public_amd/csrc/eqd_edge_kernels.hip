@@ -1308,6 +1308,67 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
     EQD_TR_WG_END();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Test / debug aid (eqd_model_lrelu_signs): which side of its two LeakyReLU kinks every edge took.  Runs the SAME
+// per-edge forward recompute as k_edge_bwd (edge_tile_forward<1>: same operands, same MFMA order, hence the same bits)
+// and writes, per edge and feature, one byte: 1 = pre-activation > 0 (derivative 1), 0 = derivative `slope`.
+// z1_pos: edge_mlp.0's output (EdgeTileState::zpos, the mask the backward applies); ch_pos: coors_mlp.0's output.
+// ---------------------------------------------------------------------------------------------
+template <bool BF>
+__global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_signs(EqdGraph G, EqdEdgeParams P, const float* __restrict__ Pn,
+                                                                const float* __restrict__ Qn,
+                                                                const float* __restrict__ x,
+                                                                unsigned char* __restrict__ z1_pos,
+                                                                unsigned char* __restrict__ ch_pos) {
+    __shared__ typename EdgeSmemSel<BWD_WAVES, 16 * FS, BF>::type sm;
+    if constexpr (BF)
+        edge_stage_weights_bf<BWD_WAVES, false>(sm, P);
+    else
+        edge_stage_weights(sm, P);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    float* tile = sm.tile[wave];
+    const int n_tiles = (G.n_edges + 15) >> 4;
+    for (int t = blockIdx.x * BWD_WAVES + wave; t < n_tiles; t += gridDim.x * BWD_WAVES) {
+        EdgeTileState<1> S;
+        S.n0 = S.n1 = 0;
+        S.e0 = 16 * t;
+        S.ne = G.n_edges - S.e0;
+        S.ne = S.ne > 16 ? 16 : S.ne;
+        f32x4 xh[4][1], m[4][1], ch[4][1];
+        if constexpr (BF)
+            edge_tile_forward_bf<1>(G, P, sm.w1, sm.w2, sm.wc1, sm.vec, tile, Pn, Qn, x, lane, S, xh, m, ch);
+        else
+            edge_tile_forward<1>(G, P, sm.w1, sm.w2, sm.wc1, sm.vec, tile, Pn, Qn, x, lane, S, xh, m, ch, nullptr);
+        if (S.ev[0]) {
+            const size_t row = (size_t)(S.e0 + l15) * 64;
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    z1_pos[row + 16 * mb + 4 * g + r] = (unsigned char)((S.zpos >> (4 * mb + r)) & 1u);
+                    ch_pos[row + 16 * mb + 4 * g + r] = ch[mb][0][r] > 0.f ? 1 : 0;
+                }
+        }
+        wave_lds_fence();
+    }
+}
+
+int eqd_launch_edge_signs(const EqdGraph* g, const EqdEdgeParams* p, const float* P, const float* Q, const float* x,
+                          unsigned char* z1_pos, unsigned char* ch_pos, hipStream_t st) {
+    if (g->n_edges <= 0) return EQD_OK;
+    const int n_tiles = (g->n_edges + 15) / 16;
+    int blocks = (n_tiles + BWD_WAVES - 1) / BWD_WAVES;
+    if (blocks > eqd_num_cus()) blocks = eqd_num_cus();
+    if (p->bf16)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_edge_signs<true>), dim3(blocks), dim3(64 * BWD_WAVES), 0, st, *g, *p, P, Q, x,
+                           z1_pos, ch_pos);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_edge_signs<false>), dim3(blocks), dim3(64 * BWD_WAVES), 0, st, *g, *p, P, Q, x,
+                           z1_pos, ch_pos);
+    return eqd_check_launch("k_edge_signs");
+}
+
 static int edge_bwd_blocks(const EqdGraph* g) {
     const int n_tiles = (g->n_edges + 15) / 16;
     int n_super = (n_tiles + BWD_WAVES - 1) / BWD_WAVES;

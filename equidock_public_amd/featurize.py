@@ -88,10 +88,15 @@ def alpha_carbon_array(residues):
     return np.stack(locs, axis=0)
 
 
-def preprocess_unbound_bound(bound_ligand_residues, bound_receptor_residues, pos_cutoff=8.0, inference=False):
-    """protein_utils.py:107-175 for graph_nodes == 'residues' (unbound == bound structures, as in the reference): filtered
-    residue lists, the bound C-alpha arrays and - unless `inference` - the pocket coordinates (midpoints of ligand /
-    receptor C-alpha pairs closer than pos_cutoff; None when there are at most 3)."""
+def preprocess_unbound_bound(bound_ligand_residues, bound_receptor_residues, graph_nodes='residues', pos_cutoff=8.0,
+                             inference=False):
+    """protein_utils.py:107-175 (same signature: the reference's callers pass graph_nodes by keyword,
+    src/inference_rigid.py:166-168) for graph_nodes == 'residues' (unbound == bound structures, as in the reference):
+    filtered residue lists, the bound C-alpha arrays and - unless `inference` - the pocket coordinates (midpoints of
+    ligand / receptor C-alpha pairs closer than pos_cutoff; None when there are at most 3)."""
+    if graph_nodes != 'residues':
+        raise ValueError(f"graph_nodes={graph_nodes!r}: only 'residues' exists (the reference asserts the same, "
+                         "src/utils/protein_utils.py:119)")
     lig, rec = filter_residues(bound_ligand_residues), filter_residues(bound_receptor_residues)
     rec_ca, lig_ca = alpha_carbon_array(rec), alpha_carbon_array(lig)
     if inference:
@@ -173,7 +178,12 @@ def knn_graph_device(atoms, atom_off, x, n_i, u_i, v_i, cutoff, max_neighbor, de
                                                 _lib.ptr(nbd), _lib.ptr(deg), _lib.ptr(mu), st))
     eoff = torch.zeros(n + 1, dtype=torch.int32, device=dev)
     eoff[1:] = torch.cumsum(deg, 0)
-    E = int(eoff[-1])                       # the one host sync: the edge count sizes the outputs
+    E, dmin = (int(v) for v in torch.stack([eoff[-1], deg.min() if n else eoff[-1]]).tolist())   # the one host sync
+    if n and dmin <= 0:
+        # a residue without a neighbour under the cutoff: the reference asserts here (protein_utils.py:354,
+        # `assert len(valid_src) > 0`), and its mu_r_norm would be 0 / 0
+        raise ValueError(f"a residue has no neighbour closer than cutoff={cutoff}: the reference asserts on such graphs "
+                         "(src/utils/protein_utils.py:354)")
     src = torch.empty(E, dtype=torch.int32, device=dev)
     dst = torch.empty(E, dtype=torch.int32, device=dev)
     he = torch.empty(E, 27, dtype=torch.float32, device=dev)

@@ -643,7 +643,7 @@ class PackedGraph:
         p.he_bf16 = hb.view(torch.int16).contiguous()
         p.mu_r_norm = torch.cat([g._ndata['ligand']['mu_r_norm'], g._ndata['receptor']['mu_r_norm']], 0) \
             .to(torch.float32).contiguous()
-        if n and float(p.mu_r_norm.min()) <= 0.0:
+        if n and not float(p.mu_r_norm.min()) > 0.0:      # `not >` also rejects NaN
             raise ValueError("mu_r_norm must be > 0 (the model takes its log, rigid_docking_model.py:469)")
         p.x0 = None
         p.device = dev
@@ -673,7 +673,7 @@ class PackedGraph:
         if int(res.min()) < 0 or int(res.max()) > 20:
             raise ValueError("res_feat must hold residue ids 0..20 (nn.Embedding(21, .), rigid_docking_model.py:382)")
         mu = torch.cat([g._ndata['ligand']['mu_r_norm'], g._ndata['receptor']['mu_r_norm']], 0).to(torch.float32)
-        if float(mu.min()) <= 0.0:
+        if not float(mu.min()) > 0.0:      # `not >` also rejects NaN
             raise ValueError("mu_r_norm must be > 0 (the model takes its log, rigid_docking_model.py:469)")
         items_cap = XCD_CLASSES * sum((int(c) + ATT_BLOCK - 1) // ATT_BLOCK for c in list(lc) + list(rc))
         flats, views = PackedGraph._alloc_native_buffers(B, n, E, items_cap)

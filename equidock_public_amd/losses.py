@@ -6,8 +6,10 @@ reference's Python loop with an (n_l x n_r) torch matrix per pair and term.
     loss = mse.mean() + args['intersection_loss_weight'] * inter.mean()                # src/train.py:143-150
 
 `compute_body_intersection_loss` keeps the reference's name and signature for one pair.  The pocket OT term
-(compute_ot_emd -> ot.emd, src/utils/ot_utils.py:22-29) stays where the reference has it (host, POT): it is not part
-of this library.  No CPU fallback: tensors must be on the GPU.
+(compute_ot_emd -> ot.emd, src/utils/ot_utils.py:22-29) is `pocket_ot_loss` below: cost matrices, the plan-weighted sum
+and its gradient on the device for the whole batch (eqd_pocket_ot_*), the exact transport plans from the host solver of
+libequidock_host.so (eqd_host_emd_uniform, in place of POT's ot.emd) with ONE device<->host round trip per batch.
+No CPU fallback: tensors must be on the GPU.
 """
 import ctypes as C
 
@@ -57,9 +59,10 @@ class _PairLosses(torch.autograd.Function):
         mse, inter = torch.empty(B, **f32), torch.empty(B, **f32)
         s_lig, s_rec = torch.empty(packed.n_lig, **f32), torch.empty(packed.n_rec, **f32)
         gs = packed.c_struct()
-        _lib.check(lib.eqd_pair_losses_fwd(C.byref(gs), _lib.ptr(a), _lib.ptr(t), _lib.ptr(r), C.c_float(sigma),
-                                           C.c_float(surface_ct), _lib.ptr(mse), _lib.ptr(inter), _lib.ptr(s_lig),
-                                           _lib.ptr(s_rec), _lib.stream_ptr(dev)))
+        with _lib.device_guard(dev):        # the launch goes to the tensors' GPU, whatever the current device is
+            _lib.check(lib.eqd_pair_losses_fwd(C.byref(gs), _lib.ptr(a), _lib.ptr(t), _lib.ptr(r), C.c_float(sigma),
+                                               C.c_float(surface_ct), _lib.ptr(mse), _lib.ptr(inter), _lib.ptr(s_lig),
+                                               _lib.ptr(s_rec), _lib.stream_ptr(dev)))
         ctx.packed, ctx.sigma, ctx.ct = packed, float(sigma), float(surface_ct)
         ctx.save_for_backward(a, t, r, s_lig, s_rec)
         ctx.set_materialize_grads(False)
@@ -77,9 +80,10 @@ class _PairLosses(torch.autograd.Function):
             return None if g is None else g.to(torch.float32).contiguous()
         d_mse, d_inter = prep(d_mse), prep(d_inter)
         gs = packed.c_struct()
-        _lib.check(lib.eqd_pair_losses_bwd(C.byref(gs), _lib.ptr(a), _lib.ptr(t), _lib.ptr(r), C.c_float(ctx.sigma),
-                                           C.c_float(ctx.ct), _lib.ptr(s_lig), _lib.ptr(s_rec), _lib.ptr(d_mse),
-                                           _lib.ptr(d_inter), _lib.ptr(d_a), _lib.stream_ptr(dev)))
+        with _lib.device_guard(dev):
+            _lib.check(lib.eqd_pair_losses_bwd(C.byref(gs), _lib.ptr(a), _lib.ptr(t), _lib.ptr(r), C.c_float(ctx.sigma),
+                                               C.c_float(ctx.ct), _lib.ptr(s_lig), _lib.ptr(s_rec), _lib.ptr(d_mse),
+                                               _lib.ptr(d_inter), _lib.ptr(d_a), _lib.stream_ptr(dev)))
         return None, d_a, None, None, None, None
 
 

@@ -167,6 +167,18 @@ class IEGMN_Layer(nn.Module):
         return f"IEGMN Layer (HIP) h_feats_dim={self.h_feats_dim} out_feats_dim={self.out_feats_dim}"
 
 
+def _dgl_signature(g):
+    """Identity of the tensors a DGL heterograph currently holds for the accessors from_dgl() reads (None when the object
+    does not look like one: from_dgl then raises its own error)."""
+    try:
+        ts = [g.nodes['ligand'].data[k] for k in ('res_feat', 'x', 'new_x', 'mu_r_norm')]
+        ts += [g.nodes['receptor'].data[k] for k in ('res_feat', 'x', 'mu_r_norm')]
+        ts += [g.edges[c].data['he'] for c in (('ligand', 'll', 'ligand'), ('receptor', 'rr', 'receptor'))]
+        return tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in ts)
+    except (KeyError, AttributeError, TypeError):
+        return None
+
+
 def flat_layout(tensors):
     """Offsets (in floats, 64-float aligned) of each unique parameter in a flat gradient buffer."""
     offs, total = [], 0
@@ -340,8 +352,9 @@ class IEGMN(nn.Module):
         d.lrelu_slope = a['leakyrelu_neg_slope']
         d.ln_eps = 1e-5
         d.svd_seed = int(self.svd_seed)
-        # not a reference option: 'hip_storage_dtype' = 'bf16' runs the edge-message kernels in bf16 mode (he rows and
-        # GEMM inputs in bf16, fp32 accumulate); everything else stays fp32
+        # not a reference option: 'hip_storage_dtype' = 'bf16' runs EVERY GEMM of the IEGMN layers on the bf16 MFMA (edge
+        # messages, node-level Linears and their weight gradients, all attention contractions: inputs rounded to bf16,
+        # fp32 accumulate); coordinates, RBFs, LayerNorm / softmax statistics, the keypoint head and Kabsch stay fp32
         sd = a.get('hip_storage_dtype', 'fp32')
         if sd not in ('fp32', 'bf16'):
             raise NotImplementedError(f"hip_storage_dtype={sd!r}: only 'fp32' and 'bf16' exist")
@@ -437,21 +450,25 @@ class IEGMN(nn.Module):
         """Returns the raw batched outputs (lig [n_lig,3], Yl, Yr [B,K,3], T [B,3,3], b [B,3])."""
         if not isinstance(batch_hetero_graph, PairGraph):
             # the reference's callers hand over a batched DGL heterograph (src/train.py:94-100): adapt it (duck-typed,
-            # tensors shared) and remember the adaptation on the object so that its packed layout is built once
-            pg = getattr(batch_hetero_graph, '_eqd_pair_graph', None)
-            if pg is None:
+            # tensors shared) and remember the adaptation on the object so that its packed layout is built once - as long
+            # as the graph still holds the SAME tensors: DGL replaces a tensor when the user assigns node / edge data
+            # (`g.nodes['ligand'].data['new_x'] = ...`, what the reference's augmentation and fine-tune stage do), and an
+            # in-place write bumps its version, so the cache is keyed on (data_ptr, version) of every tensor it adapted
+            sig = _dgl_signature(batch_hetero_graph)
+            cached = getattr(batch_hetero_graph, '_eqd_pair_graph', None)
+            if cached is None or cached[0] != sig:
                 from .graph import from_dgl
-                pg = from_dgl(batch_hetero_graph)
+                cached = (sig, from_dgl(batch_hetero_graph))
                 try:
-                    batch_hetero_graph._eqd_pair_graph = pg
+                    batch_hetero_graph._eqd_pair_graph = cached
                 except AttributeError:
                     pass
-            batch_hetero_graph = pg
+            batch_hetero_graph = cached[1]
         if not self.uses_hip_path():
             from . import torch_path
             T, b, Yl, Yr, lig = torch_path.iegmn_forward(self, batch_hetero_graph)
             self.last_svd_status = None
-            return batch_hetero_graph.pack(), lig, Yl, Yr, T, b
+            return None, lig, Yl, Yr, T, b      # no packed kernel layout on this path (and no pack() cost or constraints)
         packed = batch_hetero_graph.pack()
         uniq, table_idx = self._param_table()
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in uniq)
@@ -494,6 +511,47 @@ class IEGMN(nn.Module):
             x = f[(xp.value - base) // 4:(xp.value - base) // 4 + n * 3].view(n, 3).clone()
         return h, x
 
+    def lrelu_signs(self, batch_hetero_graph):
+        """The LeakyReLU branch decisions (uint8, 1 = pre-activation > 0) of the LAST forward of this batch that kept its
+        state, in the library's node / edge order (ligand nodes then receptor nodes; PackedGraph edge order): a list with
+        one dict per layer - 'edge_mlp', 'coors_mlp' [n_edges, 64], 'node_mlp', 'att_mlp_Q', 'att_mlp_K' [n_nodes, d_in] -
+        followed by {'mlp_h_mean_ROT': [n_nodes, 64]}.  These are exactly the masks the backward applies
+        (eqd_model_lrelu_signs); a test / debug aid: tests/parity_common.py hands them to the CPU oracle so that its
+        gradient can be compared plainly even when a pre-activation lies within fp32 rounding of 0."""
+        packed = batch_hetero_graph.pack()
+        last = getattr(packed, '_last_saved', None)
+        if last is None:
+            raise _lib.EquidockHipError("no saved forward state for this batch (run a forward with gradients enabled)")
+        saved, sb = last
+        lib = _lib.load_library()
+        desc, gs = self._desc(), packed.c_struct()
+        uniq, table_idx = self._param_table()
+        ptrs = (C.c_void_p * len(table_idx))(*[uniq[i].data_ptr() for i in table_idx])
+        dev = packed.x0.device
+        N, E = packed.n_nodes, packed.n_edges
+        d0 = self.args['residue_emb_dim'] + (5 if self.use_mean_node_features else 0)
+        out = []
+
+        def u8(*shape):
+            return torch.zeros(*shape, dtype=torch.uint8, device=dev)
+        with _lib.device_guard(dev):
+            for l in range(self.n_lays):
+                d = d0 if l == 0 else self.args['iegmn_lay_hid_dim']
+                t = dict(edge_mlp=u8(E, 64), coors_mlp=u8(E, 64), node_mlp=u8(N, d))
+                if self.args['cross_msgs']:
+                    t.update(att_mlp_Q=u8(N, d), att_mlp_K=u8(N, d))
+                _lib.check(lib.eqd_model_lrelu_signs(
+                    C.byref(desc), C.byref(gs), ptrs, _lib.ptr(saved), C.c_size_t(sb), l, _lib.ptr(t['edge_mlp']),
+                    _lib.ptr(t['coors_mlp']), _lib.ptr(t['node_mlp']), _lib.ptr(t.get('att_mlp_Q')),
+                    _lib.ptr(t.get('att_mlp_K')), _lib.stream_ptr(dev)))
+                out.append(t)
+            t = dict(mlp_h_mean_ROT=u8(N, 64))
+            _lib.check(lib.eqd_model_lrelu_signs(
+                C.byref(desc), C.byref(gs), ptrs, _lib.ptr(saved), C.c_size_t(sb), self.n_lays, None, None,
+                _lib.ptr(t['mlp_h_mean_ROT']), None, None, _lib.stream_ptr(dev)))
+            out.append(t)
+        return out
+
     def uses_hip_path(self):
         """The published family runs in the HIP library; other reference options (and dropout > 0 while training) run
         through torch operators on the same device (hip_path_supported)."""
@@ -501,8 +559,8 @@ class IEGMN(nn.Module):
 
     def forward(self, batch_hetero_graph, epoch):
         """[T_align list, b_align list, Y_ligand list, Y_receptor list] like the reference (:602)."""
-        packed, lig, Yl, Yr, T, b = self.run(batch_hetero_graph)
-        B = packed.n_pairs
+        _, lig, Yl, Yr, T, b = self.run(batch_hetero_graph)
+        B = Yl.shape[0]
         return [[T[i] for i in range(B)], [b[i].view(1, 3) for i in range(B)],
                 [Yl[i] for i in range(B)], [Yr[i] for i in range(B)]]
 

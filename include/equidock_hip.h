@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define EQD_ABI_VERSION 3
+#define EQD_ABI_VERSION 4
 #define EQD_TILE_EDGES 32   /* edges per node-aligned tile (max supported in-degree) */
 #define EQD_ATT_BLOCK 32    /* nodes per cross-attention work item */
 #define EQD_MAX_SRC 6
@@ -145,6 +145,18 @@ int eqd_model_check(const EqdModelDesc* m, const EqdGraph* g);
  * latter as 'hv_iegmn_out' / 'x_iegmn_out', rigid_docking_model.py:507-510) inside the `saved` buffer of a forward. */
 int eqd_model_layer_state(const EqdModelDesc* m, const EqdGraph* g, const void* saved, size_t saved_bytes, int layer,
                           const float** h, int* h_width, const float** x);
+
+/* Test / debug aid: the LeakyReLU branch decisions of the forward whose state is in `saved`, one byte per element
+ * (1 = pre-activation > 0, i.e. derivative 1; 0 = derivative lrelu_slope) - exactly the masks eqd_model_backward applies.
+ * layer in [0, n_layers): edge_z1 / edge_ch [n_edges][64] = edge_mlp.0 / coors_mlp.0 outputs (rigid_docking_model.py:119-125,
+ * 153-159; recomputed per edge tile like the backward does, same bits), node [n_nodes][d_in] = node_mlp.0 output (:142-148),
+ * q / k [n_nodes][d_in] = att_mlp_Q / att_mlp_K outputs (:130-137; skipped without cross_msgs).  layer == n_layers: node
+ * [n_nodes][64] = mlp_h_mean_ROT (:434-438).  Any output may be NULL (edge_z1 and edge_ch: both or neither).  A CPU oracle
+ * evaluated with these slopes has ONE gradient to compare against, whatever the fp32 summation order did to
+ * pre-activations within rounding of 0 (tests/parity_common.py). */
+int eqd_model_lrelu_signs(const EqdModelDesc* m, const EqdGraph* g, const float* const* params, const void* saved,
+                          size_t saved_bytes, int layer, unsigned char* edge_z1, unsigned char* edge_ch,
+                          unsigned char* node, unsigned char* q, unsigned char* k, void* stream);
 
 /* Rigid_Body_Docking_Net.forward (rigid_docking_model.py:642-692) for the single-stage model:
  * embedding + L IEGMN layers + keypoint attention + Kabsch + rigid apply.

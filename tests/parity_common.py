@@ -75,44 +75,109 @@ BF16_OUT_TOL, BF16_GRAD_L2, BF16_GRAD_MX = 2e-2, 6e-2, 1.2e-1
 BF16_ROT_SCALE = 10.0
 
 
+def _oracle_run(sd, args, raw, faithful, loss_fn, mode, given=None):
+    """One oracle evaluation (outputs, parameter gradients of `loss_fn`) under a Kink mode."""
+    port.Kink.mode, port.Kink.near, port.Kink.given, port.Kink.flips = mode, 0, given, []
+    try:
+        uniq = {}       # shared layers: one leaf per distinct tensor, so that its gradient is the sum over the layers
+        leaves = {k: uniq.setdefault(id(v), v.clone().requires_grad_(True)) for k, v in sd.items()}
+        outs = port.forward(leaves, args, raw, faithful=faithful)
+        loss_fn(outs).backward()
+        grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaves.items()}
+        return outs, grads, port.Kink.near, port.Kink.flips
+    finally:
+        port.Kink.mode, port.Kink.given, port.Kink.flips = None, None, None
+
+
 def oracle_reference(sd, args, raw, faithful=True, loss_fn=None, kink_aware=True):
     """Oracle outputs + parameter gradients of the fixed scalar loss, plus the element-wise hull [lo, hi] of the gradient
-    over the slope choices of LeakyReLU pre-activations that lie within fp32 rounding of 0 (oracle.iegmn_port.Kink).
+    over the slope choices of LeakyReLU pre-activations within Kink.eps (ulp scale: 3e-7 of the largest pre-activation)
+    of 0.  A diagnostic since round 3 - the asserted comparison is oracle_given().
     Returns (outs, grads, lo, hi, n_near); lo/hi are `grads` themselves when no pre-activation is near a kink."""
     loss_fn = loss_fn or port.scalar_loss
-
-    def run(mode):
-        port.Kink.mode, port.Kink.near = mode, 0
-        try:
-            uniq = {}       # shared layers: one leaf per distinct tensor, so that its gradient is the sum over the layers
-            leaves = {k: uniq.setdefault(id(v), v.clone().requires_grad_(True)) for k, v in sd.items()}
-            outs = port.forward(leaves, args, raw, faithful=faithful)
-            loss_fn(outs).backward()
-            return outs, {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaves.items()}, \
-                port.Kink.near
-        finally:
-            port.Kink.mode = None
-    outs, grads, near = run('count' if kink_aware else None)
+    outs, grads, near, _ = _oracle_run(sd, args, raw, faithful, loss_fn, 'count' if kink_aware else None)
     if not kink_aware or near == 0:
         return outs, grads, grads, grads, 0
-    _, gp, _ = run('pos')
-    _, gn, _ = run('neg')
+    _, gp, _, _ = _oracle_run(sd, args, raw, faithful, loss_fn, 'pos')
+    _, gn, _, _ = _oracle_run(sd, args, raw, faithful, loss_fn, 'neg')
     lo = {k: torch.minimum(torch.minimum(gp[k], gn[k]), grads[k]) for k in grads}
     hi = {k: torch.maximum(torch.maximum(gp[k], gn[k]), grads[k]) for k in grads}
     return outs, grads, lo, hi, near
 
 
-# Gradient tolerance of the whole model against the oracle (north_star: 1e-4 fp32): the distance to the kink hull must be
-# <= 3e-4 of the gradient's norm (relative L2) and <= 1.5e-3 of its largest element (max-abs) at the BASELINE workloads
-# (measured on MI355X: A 3.4e-5 / 6.1e-5, B 1.3e-4 / 2.5e-4 (simulator), C 1.3e-4 / 5.5e-4, E 6.0e-5 / 2.9e-4;
-# gpurun_out/parity_report.txt -> profiles/r02_parity_report.txt).  8 layers of fp32 forward + backward with
-# re-ordered sums give ~5e-5 rel-L2 on their own.  Small batches (a few hundred nodes) get GRAD_L2_SMALL / GRAD_MX_SMALL:
-# there ONE flipped LeakyReLU slope is a visible fraction of a weight row's gradient, and the three-evaluation hull
-# (default / all-positive / all-negative) only bounds sums of flips, not each single flip (measured up to 7.9e-4 / 2.7e-3
-# over seeds 8-11 of the ragged case on the simulator, 3.4e-3 / 7.4e-3 on the GPU).  The ragged test therefore ALSO runs with
-# leakyrelu_neg_slope = 0.5, where a flipped slope changes a derivative by 2x instead of 100x, at the tight tolerance.
+def library_signs(net, g, prefix='iegmn_original.'):
+    """The LeakyReLU branch decisions the HIP library took in its last forward of `g` (IEGMN.lrelu_signs ->
+    eqd_model_lrelu_signs: the masks its backward applies), re-keyed and re-ordered for the oracle: {oracle tag: bool
+    tensor in the oracle's row order}.  Edges go back from the packed (destination-sorted) order to the raw order."""
+    ie = net.iegmn_original
+    dumps = ie.lrelu_signs(g)
+    sync(g.device)
+    packed = g.pack()
+    lc = [int(v) for v in g.batch_num_nodes('ligand')]
+    rc = [int(v) for v in g.batch_num_nodes('receptor')]
+    nl = sum(lc)
+    e_ll = int(g.num_edges('ll'))
+    perm = packed.edge_perm.cpu().long()
+    given = {}
+    for l, t in enumerate(dumps[:-1]):
+        pfx = f'{prefix}iegmn_layers.{l}.'
+        for name in ('edge_mlp', 'coors_mlp'):
+            a = t[name].cpu().bool()
+            rawo = torch.empty_like(a)
+            rawo[perm] = a
+            given[pfx + name + '.l'], given[pfx + name + '.r'] = rawo[:e_ll], rawo[e_ll:]
+        for name in ('node_mlp', 'att_mlp_Q', 'att_mlp_K'):
+            if name in t:
+                a = t[name].cpu().bool()
+                given[pfx + name + '.l'], given[pfx + name + '.r'] = a[:nl], a[nl:]
+            else:       # without cross_msgs the library never evaluates q / k (the reference does, then multiplies by 0)
+                given[pfx + name + '.l'] = given[pfx + name + '.r'] = None
+    hm = dumps[-1]['mlp_h_mean_ROT'].cpu().bool()
+    lo, ro = 0, nl
+    for i, (a, b) in enumerate(zip(lc, rc)):
+        given[f'{prefix}mlp_h_mean_ROT.l.{i}'] = hm[lo:lo + a]
+        given[f'{prefix}mlp_h_mean_ROT.r.{i}'] = hm[ro:ro + b]
+        lo += a
+        ro += b
+    return given
+
+
+# A decision of the library that differs from the oracle's own must sit on a pre-activation at rounding level: relative to the
+# largest pre-activation of its tensor, fp32 sums of ~200 terms differ by <~1e-6 between summation orders (bf16 mode: the
+# library's bf16 roundings of GEMM inputs are restated by the oracle, but fp32 values one ulp apart can round to different
+# bf16 neighbours upstream: 2^-9 relative steps).  Anything larger is a wrong mask, not a rounding flip.
+FLIP_REL_MAX = 1e-5
+FLIP_REL_MAX_BF16 = 2e-2
+
+
+def oracle_given(net, g, sd, args, raw, faithful=True, loss_fn=None, flip_rel_max=FLIP_REL_MAX):
+    """Oracle outputs + gradients evaluated with the library's own LeakyReLU decisions (oracle.iegmn_port.Kink 'given'):
+    ONE gradient, compared plainly.  Returns (outs, grads, flips) - flips = [(tag, count, largest |z| / max|z|)] where the
+    library's decision differs from the oracle's own sign; asserted to be at rounding level."""
+    given = library_signs(net, g)
+    outs, grads, _, flips = _oracle_run(sd, args, raw, faithful, loss_fn or port.scalar_loss, 'given', given)
+    for tag, n, rel in flips:
+        assert rel <= flip_rel_max, f'LeakyReLU mask differs from the oracle at a pre-activation of relative size {rel:.2e}: {tag} ({n})'
+    return outs, grads, flips
+
+
+# Gradient tolerance of the whole model against the oracle evaluated with the library's own LeakyReLU decisions (round 3:
+# a PLAIN comparison - no hull): relative L2 error <= 3e-4 of every parameter gradient's norm and max-abs error <= 1.5e-3
+# of its largest element, at every size (8 layers of fp32 forward + backward with re-ordered sums give ~5e-5 rel-L2 on
+# their own).  Until round 2 the comparison was the distance to a three-evaluation hull whose width at config B turned
+# out to be ~2 % (VERDICT r02 weak 1); that hull, now at ulp scale (Kink.eps = 3e-7), is only reported as a diagnostic
+# together with the plain error against the oracle's OWN decisions (which contains the library's rounding-level flips).
 GRAD_L2, GRAD_MX = 3e-4, 1.5e-3
-GRAD_L2_SMALL, GRAD_MX_SMALL = 5e-3, 2e-2
+GRAD_L2_SMALL, GRAD_MX_SMALL = GRAD_L2, GRAD_MX      # kept as names: small batches need no looser bound any more
+
+
+def grad_err(got, ref):
+    """(relative L2 error, max-abs error / max|ref|)"""
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    n = float(ref.norm())
+    if n < 1e-12:
+        return float(got.norm()), float(got.abs().max())
+    return float((got - ref).norm()) / n, float((got - ref).abs().max()) / float(ref.abs().max())
 
 
 def grad_close_hull(got, ref, lo, hi, what='', l2=GRAD_L2, mx=GRAD_MX):
@@ -129,17 +194,54 @@ def grad_close_hull(got, ref, lo, hi, what='', l2=GRAD_L2, mx=GRAD_MX):
     return e2, em
 
 
+def compare_grads(net, grads, what, l2, mx):
+    """every parameter gradient of `net` against `grads` (plain); returns the worst (rel-L2, max-abs/max)"""
+    w2 = wm = 0.0
+    for k, p in net.named_parameters():
+        got = p.grad if p.grad is not None else torch.zeros_like(p)
+        assert torch.isfinite(got).all(), k
+        e2, em = grad_err(got, grads[k])
+        if float(grads[k].double().norm()) < 1e-12:
+            assert e2 < 1e-6, f'{what} grad {k}'
+            continue
+        assert e2 <= l2 and em <= mx, f'{what} grad {k}: rel-L2 {e2:.3e} (<= {l2}), max-abs/max {em:.3e} (<= {mx})'
+        w2, wm = max(w2, e2), max(wm, em)
+    return w2, wm
+
+
+def hull_diagnostics(net, sd, args, raw, faithful):
+    """(plain worst errors against the oracle's own decisions, median / max relative width of the ulp-scale hull over the
+    parameter tensors, worst distance to that hull, near-kink count) - reported, never asserted."""
+    _, grads, lo, hi, near = oracle_reference(sd, args, raw, faithful=faithful)
+    p2 = pm = d2 = dm = 0.0
+    widths = []
+    for k, p in net.named_parameters():
+        got = p.grad.detach().cpu().double()
+        ref = grads[k].double()
+        n = float(ref.norm())
+        if n < 1e-12:
+            continue
+        e2, em = grad_err(got, ref)
+        p2, pm = max(p2, e2), max(pm, em)
+        widths.append(float((hi[k].double() - lo[k].double()).norm()) / n)
+        err = torch.clamp(lo[k].double() - got, min=0) + torch.clamp(got - hi[k].double(), min=0)
+        d2, dm = max(d2, float(err.norm()) / n), max(dm, float(err.abs().max()) / float(ref.abs().max()))
+    w = torch.tensor(widths)
+    return dict(plain=(p2, pm), width=(float(w.median()), float(w.max())), dist=(d2, dm), near=near)
+
+
 def check_model_vs_oracle(dev, sizes, layers=8, seed=3, pair_seed=33, faithful=True, what='', args_over=None,
                           l2=GRAD_L2, mx=GRAD_MX, tol=1e-4, report=None, bf16=False, rot_scale=40.0):
     """Whole model (outputs + every parameter gradient of the fixed scalar loss) on seeded synthetic pairs of the given
-    sizes against the oracle on the host; gradients kink-aware (oracle_reference).  bf16=True: the HIP path in its bf16
+    sizes against the oracle on the host evaluated with the library's own LeakyReLU decisions (oracle_given).  bf16=True: the HIP path in its bf16
     mode against the oracle with the same rounding points."""
     args = port.default_args(**dict(dict(iegmn_n_lays=layers, skip_weight_h=0.75), **(args_over or {})))
     sd = port.init_state_dict(args, seed=seed, rot_scale=rot_scale)
     net = build_model(dict(args, hip_storage_dtype='bf16') if bf16 else args, sd, dev)
     port.Bf16Mode.on = bool(bf16)
     try:
-        return _check_model_vs_oracle(dev, net, args, sd, sizes, layers, pair_seed, faithful, what, l2, mx, tol, report)
+        return _check_model_vs_oracle(dev, net, args, sd, sizes, layers, pair_seed, faithful, what, l2, mx, tol, report,
+                                      FLIP_REL_MAX_BF16 if bf16 else FLIP_REL_MAX)
     finally:
         port.Bf16Mode.on = False
 
@@ -188,29 +290,35 @@ def check_model_bf16_states(dev, sizes, layers=8, seed=3, pair_seed=34, faithful
         assert torch.isfinite(p.grad).all()
 
 
-def _check_model_vs_oracle(dev, net, args, sd, sizes, layers, pair_seed, faithful, what, l2, mx, tol, report):
+def _check_model_vs_oracle(dev, net, args, sd, sizes, layers, pair_seed, faithful, what, l2, mx, tol, report,
+                           flip_rel_max=FLIP_REL_MAX):
     pairs = synthetic.make_pairs(list(sizes), pair_seed)
     g = G.batch_pairs(pairs).to(dev)
     outs = net(g, epoch=0)
     port.scalar_loss(outs).backward()
     sync(dev)
     assert net.iegmn_original.last_svd_status.cpu().tolist() == [0] * len(sizes), 'SVD guard fired'
-    ref, grads, lo, hi, near = oracle_reference(sd, args, port.raw_from_graph(g), faithful=faithful)
+    raw = port.raw_from_graph(g)
+    # the oracle with the library's own LeakyReLU decisions: one gradient, compared plainly
+    ref, grads, flips = oracle_given(net, g, sd, args, raw, faithful=faithful, flip_rel_max=flip_rel_max)
     worst = 0.0
     for nm, a, b in zip(('lig', 'Yl', 'Yr', 'T', 'b'), outs, ref):
         got, exp = cat_out(a), cat_out(b)
         close(got, exp, tol=tol, what=f'{what} output {nm}')
         worst = max(worst, float((got.detach().cpu() - exp.detach()).abs().max()) / max(1.0, float(exp.detach().abs().max())))
-    w2 = wm = 0.0
-    for k, p in net.named_parameters():
-        got = p.grad if p.grad is not None else torch.zeros_like(p)
-        e2, em = grad_close_hull(got, grads[k], lo[k], hi[k], what=f'{what} grad {k}', l2=l2, mx=mx)
-        w2, wm = max(w2, e2), max(wm, em)
-    line = (f'{what}: {len(sizes)} pairs, {layers} layers: max rel output err {worst:.2e}, worst grad rel-L2 {w2:.2e}, '
-            f'max-abs/max {wm:.2e}, near-kink pre-activations {near}')
-    print(line)
-    if report is not None:
+    w2, wm = compare_grads(net, grads, what, l2, mx)
+    nfl = sum(n for _, n, _ in flips)
+    rfl = max([r for _, _, r in flips], default=0.0)
+    line = (f'{what}: {len(sizes)} pairs, {layers} layers: max rel output err {worst:.2e}; gradients vs the oracle with the '
+            f"library's LeakyReLU decisions (plain): worst rel-L2 {w2:.2e}, max-abs/max {wm:.2e}; decisions that differ from "
+            f"the oracle's own: {nfl} (largest |z|/max|z| {rfl:.1e})")
+    if report is not None:      # diagnostics of the BASELINE workloads (three more oracle evaluations)
+        dg = hull_diagnostics(net, sd, args, raw, faithful)
+        line += (f"; vs the oracle's own decisions (plain): rel-L2 {dg['plain'][0]:.2e}, max-abs/max {dg['plain'][1]:.2e}; "
+                 f"ulp-scale hull (eps {port.Kink.eps:.0e}, {dg['near']} near-kink): width rel-L2 median {dg['width'][0]:.2e} "
+                 f"max {dg['width'][1]:.2e}, distance to it rel-L2 {dg['dist'][0]:.2e}, max-abs/max {dg['dist'][1]:.2e}")
         report.append(line)
+    print(line)
     return net, g
 
 
@@ -652,19 +760,27 @@ def check_model_case(dev, name, check_grads=True):
     sync(dev)
     assert abs(float(loss.detach()) - float(z['loss'])) <= 1e-4 * abs(float(z['loss']))
     gf = meta['grad_fingerprint']
-    # the golden gradient is the reference's; the hull over near-kink LeakyReLU slopes comes from the oracle port (which
-    # reproduces the golden gradient to <= 1.2e-6) on the same inputs.  The guard case draws from torch's RNG: no hull.
-    lo = hi = None
+    # (1) the library against the oracle port evaluated with the library's own LeakyReLU decisions: plain, tight.
+    # (2) the library against the REFERENCE's golden gradient: plain 1e-3 / 1e-2.  The golden gradient has the reference's
+    #     own decisions baked in; where the library decided a rounding-level pre-activation the other way (`flips`, asserted
+    #     to be at |z| / max|z| <= 1e-5), the golden gradient is corrected by the oracle's own estimate of those flips'
+    #     effect (oracle_given - oracle_default; the port reproduces the golden gradient to <= 1.2e-6).
+    # The guard case draws its perturbation from recorded torch draws the port cannot replay here: (2) only, uncorrected.
+    delta = None
     if 'svd_draws' not in z.files:
-        _, gport, lo, hi, _ = oracle_reference(sd, args, raw, faithful=True)
+        _, ggiven, flips = oracle_given(net, g, sd, args, raw, faithful=True)
+        compare_grads(net, ggiven, f'{name} (vs oracle, library decisions)', GRAD_L2, GRAD_MX)
+        if flips:
+            _, gdef, _, _ = _oracle_run(sd, args, raw, True, port.scalar_loss, None)
+            delta = {k: ggiven[k] - gdef[k] for k in ggiven}
+            print(f'{name}: {sum(n for _, n, _ in flips)} LeakyReLU decisions differ from the reference at rounding level '
+                  f'(largest |z|/max|z| {max(r for _, _, r in flips):.1e})')
     for k, p in net.named_parameters():
         if 'grad_' + k in z.files:
             ref = torch.from_numpy(z['grad_' + k])
-            if lo is not None:
-                grad_close_hull(p.grad, ref, torch.minimum(lo[k], ref), torch.maximum(hi[k], ref),
-                                what=f'{name} grad {k}', l2=GRAD_L2_SMALL, mx=GRAD_MX_SMALL)
-            else:
-                grad_close(p.grad, ref, what=f'{name} grad {k}')
+            if delta is not None:
+                ref = ref + delta[k]
+            grad_close(p.grad, ref, what=f'{name} grad {k}')
         else:
             nrm = gf[k][1]
             assert abs(float(p.grad.double().norm().cpu()) - nrm) <= 2e-3 * max(nrm, 1e-6), f'{name} grad norm {k}'
@@ -683,13 +799,12 @@ def check_model_bf16(dev, name):
     assert net.iegmn_original.last_svd_status.cpu().tolist() == [0] * len(raw['lig_counts'])
     port.Bf16Mode.on = True
     try:
-        ref, grads, lo, hi, _ = oracle_reference(sd, args, raw, faithful=True)
+        ref, grads, _ = oracle_given(net, g, sd, args, raw, faithful=True, flip_rel_max=FLIP_REL_MAX_BF16)
     finally:
         port.Bf16Mode.on = False
     for nm, a, b in zip(('lig', 'Yl', 'Yr', 'T', 'b'), outs, ref):
         close(cat_out(a), cat_out(b), tol=BF16_OUT_TOL, what=f'{name} bf16 {nm} vs bf16 oracle')
-    for k, p in net.named_parameters():
-        grad_close_hull(p.grad, grads[k], lo[k], hi[k], what=f'{name} bf16 grad {k}', l2=BF16_GRAD_L2, mx=BF16_GRAD_MX)
+    compare_grads(net, grads, f'{name} bf16', BF16_GRAD_L2, BF16_GRAD_MX)
 
 
 def check_flat_grads_equal_autograd(dev):
@@ -789,19 +904,21 @@ def check_model_vs_oracle_ragged(dev, sizes=((4, 4), (17, 5), (33, 64), (1, 40),
     g = G.batch_pairs(pairs).to(dev)
     outs = net(g, epoch=0)
     port.scalar_loss(outs).backward()
-    ref, grads, lo, hi, _ = oracle_reference(sd, args, port.raw_from_graph(g), faithful=True, kink_aware=check_grads)
+    sync(dev)
+    raw = port.raw_from_graph(g)
+    if check_grads:
+        ref, grads, flips = oracle_given(net, g, sd, args, raw, faithful=True)
+    else:
+        ref, grads, _, _ = _oracle_run(sd, args, raw, True, port.scalar_loss, None)
     for a, b in zip(outs, ref):
         for x, y in zip(a, b):
             close(x, y, tol=1e-4, what='ragged batch output')
-    w2 = wm = 0.0
     for k, p in net.named_parameters():
         assert torch.isfinite(p.grad).all(), k
-        if check_grads:
-            e2, em = grad_close_hull(p.grad, grads[k], lo[k], hi[k],
-                                     what=f'ragged batch grad {k} sizes={sizes} seed={seed} slope={slope}', l2=l2, mx=mx)
-            w2, wm = max(w2, e2), max(wm, em)
     if check_grads:
-        print(f'ragged batch seed {seed} slope {slope}: worst grad rel-L2 {w2:.2e}, max-abs/max {wm:.2e}')
+        w2, wm = compare_grads(net, grads, f'ragged batch sizes={sizes} seed={seed} slope={slope}', l2, mx)
+        print(f'ragged batch seed {seed} slope {slope}: worst grad rel-L2 {w2:.2e}, max-abs/max {wm:.2e} (plain, vs the '
+              f"oracle with the library's decisions; {sum(n for _, n, _ in flips)} differ from the oracle's own)")
 
 
 def check_pair_losses(dev):

@@ -137,15 +137,13 @@ def test_model_vs_oracle_ragged(dev):
     # (the closed-form SVD backward divides by singular-value gaps of the random diagonal there)
     pc.check_model_vs_oracle_ragged(dev, check_grads=False)
     pc.check_model_vs_oracle_ragged(dev, sizes=((4, 4), (17, 5), (33, 64)))
-    # gradients are compared kink-aware (oracle_reference): seeds 8, 9 and 11 each have a LeakyReLU pre-activation
-    # within fp32 rounding of 0 that takes the other slope on the GPU; no seed is avoided any more
-    # A flipped LeakyReLU slope changes a derivative 100-fold at the reference's slope 0.01, and in a batch of a thousand
-    # nodes ONE flip is visible in a weight row's gradient: these runs are compared at the small-batch tolerance
-    # (parity_common.GRAD_*_SMALL).  The same shapes with slope 0.5 (a flip is a factor 2) are held to the tight one.
+    # seeds 8, 9 and 11 each have a LeakyReLU pre-activation within fp32 rounding of 0 that takes the other slope on the
+    # GPU than in the oracle's own evaluation (x100 on that derivative at the reference's slope 0.01).  Since round 3 the
+    # oracle is evaluated with the library's own decisions (parity_common.oracle_given), so these runs are held to the
+    # same plain tolerance as everything else (until round 2: 5e-3 / 2e-2 against a hull); one more run with slope 0.5.
     for seed in (8, 9, 10, 11):
         pc.check_model_vs_oracle_ragged(dev, sizes=((129, 257), (300, 31), (64, 64), (95, 200)), layers=3, seed=seed)
-        pc.check_model_vs_oracle_ragged(dev, sizes=((129, 257), (300, 31), (64, 64), (95, 200)), layers=3, seed=seed,
-                                        slope=0.5, l2=pc.GRAD_L2, mx=pc.GRAD_MX)
+    pc.check_model_vs_oracle_ragged(dev, sizes=((129, 257), (300, 31), (64, 64), (95, 200)), layers=3, seed=8, slope=0.5)
 
 
 @pytest.mark.parametrize('over', [dict(cross_msgs=False), dict(use_dist_in_layers=False),
@@ -292,6 +290,43 @@ def test_model_vs_oracle_config_a(dev):
     from tests import parity_common as pc
     pc.check_model_vs_oracle(dev, [(200, 200)], layers=5, seed=3, pair_seed=36, faithful=True, what='config A fp32',
                              args_over=dict(shared_layers=True, skip_weight_h=0.5), report=REPORT)
+
+
+def test_model_vs_oracle_workload_r(dev):
+    """`bench.py --workload R` (SURVEY.md section 8d "realistic sizes": 64 ragged pairs, ligand 29..1500 / receptor 40..2130
+    residues): the first 16 of those pairs (56..856 residues per protein) at 8 layers against the oracle."""
+    import bench
+    from equidock_public_amd import synthetic
+    from tests import parity_common as pc
+    sizes = synthetic.realistic_sizes(64, bench.R_SIZE_SEED)[:16]
+    pc.check_model_vs_oracle(dev, sizes, layers=8, seed=3, pair_seed=37, faithful=False, what='workload R (16 of 64 pairs)',
+                             report=REPORT)
+
+
+def test_bench_workload_d_on_rccl_world_of_one(dev):
+    """`bench.py --workload D` (BASELINE.json configs[3]: 64 x (300, 300) per GPU, bf16, data parallel) launched the way the
+    driver launches N > 1 - torch.distributed.run, backend nccl (= RCCL) - with one rank: the flat-gradient all-reduce runs
+    on RCCL every step (inside the replayed hipGraph when RCCL accepts the capture) and its cost is in the JSON line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', '29541', os.path.join(root, 'bench.py'), '--gpus', '1', '--workload', 'D', '--steps', '3',
+           '--warmup', '2', '--no-cpu-baseline', '--no-roofline']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
+    out = json.loads(line)
+    assert out['rccl_ranks'] == 1 and out['n_gpus'] == 1 and out['scaling'] == 'weak'
+    assert out['allreduce_us_per_step'] is not None and out['allreduce_us_per_step'] > 0
+    assert out['allreduce_bytes'] > 3_000_000 and out['value'] > 0
+    assert 'bf16' in out['dtype'] and out['config']['pairs_per_gpu'] == 64
+    REPORT.append(f"bench.py --workload D under torch.distributed.run (nccl, 1 rank): {out['value']} pairs/s, "
+                  f"all-reduce of {out['allreduce_bytes']} B: {out['allreduce_us_per_step']} us per step, "
+                  f"in the replayed hipGraph: {out['allreduce_in_graph']}")
 
 
 def test_big_batch_equals_small_batches(dev):
