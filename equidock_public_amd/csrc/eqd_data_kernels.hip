@@ -409,9 +409,8 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_clash_grad(int n_lig, int n_rec, 
                                                           const EqdClashState* __restrict__ st, EqdClashWs W) {
     __shared__ float pts[CL_TILE][4];
     __shared__ float red[EQD_WAVES];
-    if (st->done) return;
-    const float loss = clash_loss(n_lig, n_rec, W);          // every thread: same fixed-order sum
-    if (!(loss > loss_stop && st->it < max_it)) return;     // converged: k_clash_step raises the flag
+    if (st->done || st->it >= max_it) return;               // (k_clash_step raises the flag at it == max_it)
+    // the iteration whose loss comes out <= loss_stop still steps (the reference's loop), so its gradient is needed too
     const float e[3] = {st->euler[0], st->euler[1], st->euler[2]};
     const int i = blockIdx.x * EQD_BLOCK + threadIdx.x;
     const int ic = i < n_lig ? i : n_lig - 1;
@@ -469,12 +468,17 @@ __global__ void k_clash_step(int n_lig, int n_rec, float loss_stop, int max_it, 
                              EqdClashWs W) {
     if (st->done) return;
     if (threadIdx.x != 0) return;
-    const float loss = clash_loss(n_lig, n_rec, W);
-    st->loss = loss;
-    if (!(loss > loss_stop && st->it < max_it)) {
+    // The reference's loop (src/inference_rigid.py:213-232) tests `loss > 0.5 and it < 2000` with the loss of the PREVIOUS
+    // evaluation, then evaluates, steps and increments unconditionally: the iteration whose loss comes out <= loss_stop
+    // still applies its gradient step (the returned parameters are one step past the converged evaluation, `it` counts
+    // that step), and at it == max_it nothing is evaluated any more (the reported loss stays the last one).
+    if (st->it >= max_it) {
         st->done = 1;
         return;
     }
+    const float loss = clash_loss(n_lig, n_rec, W);
+    st->loss = loss;
+    if (!(loss > loss_stop)) st->done = 1;
     float eta = 1e-3f;
     if (loss < 2.f) eta = 1e-4f;
     if (st->it > 1500) eta = 1e-2f;

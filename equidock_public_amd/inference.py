@@ -48,7 +48,9 @@ def apply_rigid(rotation, translation, coords):
 def remove_clashes(ligand_atoms, receptor_atoms, sigma=8.0, surface_ct=8.0, loss_stop=0.5, max_it=2000, check_every=50):
     """src/inference_rigid.py:207-234 on the device.  ligand_atoms [n, 3]: the docked ligand (all atoms, after
     apply_rigid); receptor_atoms [m, 3].  Returns dict(positions [n, 3] device tensor, euler (3,), translation (3,),
-    iterations, loss) - `positions` = get_rot_mat(euler) @ ligand_atoms + translation at the last evaluated iteration."""
+    iterations, loss) - `positions` = get_rot_mat(euler) @ ligand_atoms + translation with the FINAL parameters, i.e. like
+    the reference's `ligand_th` one gradient step past the evaluation that met the stop rule (:226-232); `loss` is the last
+    evaluated loss (`non_int_loss_item`), `iterations` the reference's `it`."""
     lib = _lib.load_library()
     lig = _lib.require_device(ligand_atoms.detach().to(torch.float32).contiguous(), 'ligand atoms')
     rec = _lib.require_device(receptor_atoms.detach().to(torch.float32).contiguous(), 'receptor atoms')
@@ -68,9 +70,9 @@ def remove_clashes(ligand_atoms, receptor_atoms, sigma=8.0, surface_ct=8.0, loss
         C.memmove(C.byref(host), raw, C.sizeof(EqdClashState))
         if host.done:
             break
-    pos = ws[:n * 12].view(torch.float32).view(n, 3).clone()
-    return {'positions': pos, 'euler': np.asarray(host.euler[:], dtype=np.float32),
-            'translation': np.asarray(host.trans[:], dtype=np.float32), 'iterations': int(host.it), 'loss': float(host.loss)}
+    euler, trans = np.asarray(host.euler[:], dtype=np.float32), np.asarray(host.trans[:], dtype=np.float32)
+    pos = apply_rigid(get_rot_mat(torch.from_numpy(euler)).to(dev), trans, lig)      # :230
+    return {'positions': pos, 'euler': euler, 'translation': trans, 'iterations': int(host.it), 'loss': float(host.loss)}
 
 
 def write_pdb_coordinates(src_pdb, coords, out_pdb):

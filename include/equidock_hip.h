@@ -359,8 +359,10 @@ int eqd_protein_graph_edges(int n, int max_neighbor, const int32_t* edge_off, co
  * loss > loss_stop (0.5) and it < max_it (2000), with the reference's step sizes.  All state lives on the device:
  * `state` (zero-initialised by the caller: angles, translation, iteration counter, last loss, stop flag).  One call
  * enqueues n_iter iterations (4 launches each; they return immediately once the flag is up) - the caller reads
- * state->done every few dozen iterations.  The ligand positions of the last evaluated iteration are the first
- * n_lig * 3 floats of `workspace`.  float32 like the reference. */
+ * state->done every few dozen iterations.  Like the reference's loop, the iteration whose loss evaluates <= loss_stop
+ * still applies its step (state->euler / trans are one step past that evaluation and state->it counts it; the final
+ * ligand is R(euler) lig0 + trans); state->loss is the last EVALUATED loss.  The ligand positions of the last evaluated
+ * iteration are the first n_lig * 3 floats of `workspace`.  float32 like the reference. */
 typedef struct EqdClashState {
     float euler[3];
     float trans[3];

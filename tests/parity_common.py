@@ -1158,9 +1158,14 @@ def check_inference_postprocessing(dev):
             close(torch.from_numpy(out['euler']), torch.from_numpy(z['a_euler']), tol=1e-4, what='euler angles')
             close(torch.from_numpy(out['translation']), torch.from_numpy(z['a_trans']), tol=1e-4, what='translation')
         elif tag == 'b':
-            assert it_ref < cap and abs(out['iterations'] - it_ref) <= 25, (out['iterations'], it_ref)
+            # converging case: the reference's stop rule exactly (the iteration whose loss evaluates <= 0.5 still steps and
+            # counts).  On the simulator the iteration count equals the reference's 1 199 and the positions agree to 2e-6;
+            # a device's expf may move the threshold crossing by an iteration (until round 2: +-25 and 2e-3)
+            print(f"clash removal b: {out['iterations']} iterations (reference {it_ref}), final loss {out['loss']:.6f} "
+                  f"(reference {float(losses[-1]):.6f})")
+            assert it_ref < cap and abs(out['iterations'] - it_ref) <= 3, (out['iterations'], it_ref)
             assert out['loss'] <= 0.5
-            close(out['positions'], torch.from_numpy(z[tag + '_pos']), tol=2e-3, what='clash removal b: converged ligand atoms')
+            close(out['positions'], torch.from_numpy(z[tag + '_pos']), tol=5e-4, what='clash removal b: converged ligand atoms')
         else:
             assert out['iterations'] == it_ref == cap
             assert abs(out['loss'] - float(losses[-1])) <= 3e-2 * float(losses[-1]), (out['loss'], float(losses[-1]))
