@@ -39,6 +39,11 @@ class EqdModelDesc(C.Structure):
                 ('ln_eps', C.c_float), ('svd_seed', C.c_int32), ('storage_bf16', C.c_int32)]
 
 
+class EqdDropout(C.Structure):
+    _fields_ = [('p', C.c_float), ('edge_z1', C.c_void_p), ('edge_ch', C.c_void_p), ('node', C.c_void_p),
+                ('head', C.c_void_p)]
+
+
 class EqdLinSrc(C.Structure):
     _fields_ = [('X', C.c_void_p), ('mask', C.c_void_p), ('W', C.c_void_p), ('ldx', C.c_int32), ('K', C.c_int32),
                 ('w_rs', C.c_int32), ('w_cs', C.c_int32)]
@@ -49,7 +54,7 @@ class EqdLinJob(C.Structure):
                 ('rows', C.c_int32), ('bias', C.c_void_p), ('ln_g', C.c_void_p), ('ln_b', C.c_void_p),
                 ('pre_ln', C.c_void_p), ('ld_pre', C.c_int32), ('R', C.c_void_p), ('ldr', C.c_int32),
                 ('alpha', C.c_float), ('beta', C.c_float), ('slope', C.c_float), ('ln_eps', C.c_float),
-                ('Y', C.c_void_p), ('ldy', C.c_int32), ('bf16', C.c_int32)]
+                ('Y', C.c_void_p), ('ldy', C.c_int32), ('bf16', C.c_int32), ('mul', C.c_void_p), ('ld_mul', C.c_int32)]
 
 
 class EqdAtbJob(C.Structure):
@@ -63,7 +68,7 @@ class EqdEdgeParams(C.Structure):
                 ('ln_b', C.c_void_p), ('W2', C.c_void_p), ('b2', C.c_void_p), ('Wc1', C.c_void_p),
                 ('bc1', C.c_void_p), ('wc2', C.c_void_p), ('bc2', C.c_void_p), ('slope', C.c_float),
                 ('ln_eps', C.c_float), ('eta', C.c_float), ('use_dist', C.c_int32), ('use_he', C.c_int32),
-                ('bf16', C.c_int32)]
+                ('bf16', C.c_int32), ('drop_z1', C.c_void_p), ('drop_ch', C.c_void_p), ('drop_scale', C.c_float)]
 
 
 class EqdEdgeGrads(C.Structure):

@@ -193,9 +193,33 @@ void carve_scratch(const Dims& D, const EqdModelDesc* m, const EqdGraph* g, EqdA
     W.emb_part = A.take<float>(eqd_embed_bwd_partial_floats(g, m->d_emb));
 }
 
-EqdEdgeParams edge_params(const Dims& D, const EqdModelDesc* m, int l, const float* const* p) {
+// dropout factors of node_mlp.1 of layer l inside EqdDropout.node (layer 0 is d0 wide, the others dh)
+const float* drop_node(const Dims& D, const EqdDropout* drop, int l) {
+    if (!drop) return nullptr;
+    return drop->node + (l == 0 ? (size_t)0 : (size_t)D.N * D.d0 + (size_t)(l - 1) * D.N * D.dh);
+}
+int drop_check(const EqdDropout* drop) {
+    if (!drop) return EQD_OK;
+    if (!(drop->p > 0.f && drop->p < 1.f) || !drop->edge_z1 || !drop->edge_ch || !drop->node || !drop->head) {
+        eqd_set_error("EqdDropout: need 0 < p < 1 and all four mask arrays (p = %g)", drop->p);
+        return EQD_ERR_NULL;
+    }
+    return EQD_OK;
+}
+
+__global__ void k_mul_inplace(float* __restrict__ y, const float* __restrict__ m, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] *= m[i];
+}
+
+EqdEdgeParams edge_params(const Dims& D, const EqdModelDesc* m, int l, const float* const* p,
+                          const EqdDropout* drop = nullptr) {
     EqdEdgeParams e;
     memset(&e, 0, sizeof(e));
+    if (drop) {
+        e.drop_z1 = drop->edge_z1 + (size_t)l * D.E * 2;
+        e.drop_ch = drop->edge_ch + (size_t)l * D.E * 2;
+        e.drop_scale = 1.f / (1.f - drop->p);
+    }
     e.W1 = p[P_W1]; e.ldw1 = D.ldw1(l); e.d_in = D.d_in(l);
     e.ln_g = p[P_LNG]; e.ln_b = p[P_LNB]; e.W2 = p[P_W2]; e.b2 = p[P_B2];
     e.Wc1 = p[P_WC1]; e.bc1 = p[P_BC1]; e.wc2 = p[P_WC2]; e.bc2 = p[P_BC2];
@@ -290,7 +314,8 @@ int eqd_launch_edge_signs(const EqdGraph* g, const EqdEdgeParams* p, const float
                           unsigned char* z1_pos, unsigned char* ch_pos, hipStream_t st);
 
 extern "C" int eqd_model_lrelu_signs(const EqdModelDesc* m, const EqdGraph* g, const float* const* params,
-                                     const void* saved, size_t saved_bytes, int layer, unsigned char* edge_z1,
+                                     const EqdDropout* drop, const void* saved, size_t saved_bytes, int layer,
+                                     unsigned char* edge_z1,
                                      unsigned char* edge_ch, unsigned char* node, unsigned char* q, unsigned char* k,
                                      void* stream) {
     if (int rc = eqd_model_check(m, g)) return rc;
@@ -330,7 +355,8 @@ extern "C" int eqd_model_lrelu_signs(const EqdModelDesc* m, const EqdGraph* g, c
         if (int rc = rows(Ls.ka, da, d, k)) return rc;
     }
     if (edge_z1 && edge_ch) {
-        EqdEdgeParams ep = edge_params(D, m, layer, p);
+        if (int rc = drop_check(drop)) return rc;
+        EqdEdgeParams ep = edge_params(D, m, layer, p, drop);
         return eqd_launch_edge_signs(g, &ep, Ls.P, Ls.Q, S.x[layer], edge_z1, edge_ch, st);
     }
     return EQD_OK;
@@ -379,7 +405,7 @@ extern "C" int eqd_ctx_destroy(void* ctx) {
     } while (0)
 
 extern "C" int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const float* const* params,
-                                 const float* svd_draws, float* lig_out, float* Y_lig, float* Y_rec, float* T,
+                                 const EqdDropout* drop, const float* svd_draws, float* lig_out, float* Y_lig, float* Y_rec, float* T,
                                  float* b, int32_t* svd_status, void* saved, size_t saved_bytes, void* scratch,
                                  size_t scratch_bytes, void* stream, void* ctx) {
     RC(eqd_model_check(m, g));
@@ -387,6 +413,7 @@ extern "C" int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const
         eqd_set_error("eqd_model_forward: NULL argument");
         return EQD_ERR_NULL;
     }
+    RC(drop_check(drop));
     hipStream_t st = (hipStream_t)stream;
     EqdCtx* cx = (EqdCtx*)ctx;
     const Dims D = make_dims(m, g);
@@ -457,7 +484,7 @@ extern "C" int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const
             HIPOK(hipEventRecord(cx->fork, st));
             HIPOK(hipStreamWaitEvent(sat, cx->fork, 0));
         }
-        EqdEdgeParams ep = edge_params(D, m, l, p);
+        EqdEdgeParams ep = edge_params(D, m, l, p, drop);
         if (m->cross_msgs && sat == st && !m->storage_bf16) {
             // the two independent halves of the layer: ONE launch when both fit the chip at once (small batches)
             RC(eqd_edge_attn_fwd(g, &ep, Ls.P, Ls.Q, S.x[l], Ls.aggr_msg, S.x[l + 1], da, Ls.qa, Ls.ka, Ls.va, Ls.aggr_cross,
@@ -486,6 +513,7 @@ extern "C" int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const
         lin_src(j1, 3, S.h[0], D.d0, D.d0, p[P_WN1] + 2 * d + 64, ldn, 1);
         j1.nsrc = 4; j1.bias = p[P_BN1]; j1.act = 1; j1.ln_g = p[P_NLG]; j1.ln_b = p[P_NLB];
         j1.pre_ln = Ls.y_act; j1.ld_pre = d;
+        j1.mul = drop_node(D, drop, l); j1.ld_mul = d;       // node_mlp.1 (Dropout) in training mode
         EqdLinJob j2 = lin_job(N, D.dh, S.h[l + 1], D.dh, slope, eps);
         lin_src(j2, 0, Ls.a1n, d, d, p[P_WN2], d, 1);
         j2.nsrc = 1; j2.bias = p[P_BN2];
@@ -507,7 +535,7 @@ extern "C" int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const
             // pass over the h rows, less per layer.  (With the four-wave kernels of small batches this was measured
             // slower: 46 vs 33 us, the five projections then run one after the other instead of side by side; layer 0's
             // 69-wide chain stays on those kernels at every size, so it never carries projections.)
-            proj_in_chain = l + 1 < D.L && d == 64 && D.d_in(l + 1) == 64 && D.dh == 64 && eqd_rows_resident(N) &&
+            proj_in_chain = l + 1 < D.L && d == 64 && D.d_in(l + 1) == 64 && D.dh == 64 && eqd_rows_resident(N) && !drop &&
                             2 + (m->cross_msgs ? 5 : 2) <= EQD_CHAIN_MAXJOBS;
             if (proj_in_chain) {
                 cj[1].out_local = 1;
@@ -520,6 +548,7 @@ extern "C" int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const
         EqdLinJob jm = lin_job(N, 64, S.hm, 64, slope, eps);
         lin_src(jm, 0, S.h[D.L], D.dh, D.dh, gp[G_WM], D.dh, 1);
         jm.nsrc = 1; jm.bias = gp[G_BM]; jm.act = 1;
+        if (drop) { jm.mul = drop->head; jm.ld_mul = 64; }      // mlp_h_mean_ROT.1 (Dropout) in training mode
         RC(eqd_linear(&jm, 1, st));
     }
     // ---- keypoint head ----------------------------------------------------------------------------------
@@ -534,7 +563,7 @@ extern "C" int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const
 }
 
 extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, const float* const* params,
-                                  const float* d_lig, const float* d_Ylig, const float* d_Yrec, const float* d_T,
+                                  const EqdDropout* drop, const float* d_lig, const float* d_Ylig, const float* d_Yrec, const float* d_T,
                                   const float* d_b, float* grad_flat, const int64_t* grad_offsets, const void* saved,
                                   size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream, void* ctx) {
     RC(eqd_model_check(m, g));
@@ -544,6 +573,7 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
     }
     hipStream_t st = (hipStream_t)stream;
     (void)ctx;
+    RC(drop_check(drop));
     const Dims D = make_dims(m, g);
     g_bf16_mode = m->storage_bf16 ? 1 : 0;
     EqdArena As(const_cast<void*>(saved), saved_bytes);
@@ -580,6 +610,13 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
     RC(eqd_launch_head_u_bwd(g, K, gpar[G_WK], gpar[G_WQ], S.qmean, S.qp, W.du, ggrad[G_WK], ggrad[G_WQ], W.dqm_part,
                              st, W.head_part, defer));
     RC(eqd_launch_qmean_bwd(g, K, W.dqm_part, W.dhm, st));
+    if (drop) {      // d(keep * s * LeakyReLU(z)): the dropout factor rides on the incoming gradient, the LeakyReLU
+                     // derivative comes from the saved activation's sign as without dropout
+        const size_t n = (size_t)N * 64;
+        hipLaunchKernelGGL(k_mul_inplace, dim3((unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)), dim3(256), 0, st,
+                           W.dhm, drop->head, n);
+        RC(eqd_check_launch("k_mul_inplace"));
+    }
     const size_t NS = (size_t)N * 80, NP = (size_t)N * 64;
     auto dHof = [&](int i) -> float* { return W.dH_all + (size_t)i * NS; };   // grad wrt h[i]
     std::vector<EqdAtbJob> wjobs;   // weight-gradient GEMMs of the whole pass, launched together at the end
@@ -663,6 +700,7 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
                 C.lin = lin_job(N, d, dz, d, slope, eps);
                 lin_src(C.lin, 0, Ls.y_act, d, d, nullptr, 0, 0);
                 C.lin.nsrc = 1; C.lin.ln_g = p[P_NLG];
+                C.lin.mul = drop_node(D, drop, l); C.lin.ld_mul = d;
                 C.src_local[0] = 0;
                 C.out_local = 1;
                 C.aux = lnp;
@@ -705,7 +743,7 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
                                            W.delta, st));
         }
         {
-            EqdEdgeParams ep = edge_params(D, m, l, p);
+            EqdEdgeParams ep = edge_params(D, m, l, p, drop);
             EqdEdgeGrads eg;
             memset(&eg, 0, sizeof(eg));
             eg.dW1 = gp[P_W1]; eg.ldw1 = D.ldw1(l); eg.dln_g = gp[P_LNG]; eg.dln_b = gp[P_LNB]; eg.dW2 = gp[P_W2];

@@ -182,12 +182,37 @@ struct EdgeTileState {
     float mean[NB], rstd[NB];
     float coef[NB];
     unsigned zpos;   // bit (16 nb + 4 mb + r): edge_mlp.0 pre-activation > 0 (exact LeakyReLU mask for the backward)
+    unsigned keepz, keepc;   // dropout (training): bit (16 nb + 4 mb + r) = the element of edge_mlp.1 / coors_mlp.1 is kept
 };
+
+// Dropout of the two edge MLPs (rigid_docking_model.py:119-125 edge_mlp.1, :153-159 coors_mlp.1; active while training with
+// args['dropout'] > 0).  The masks are drawn by the CALLER with torch's generator in the reference's consumption order
+// (model.py: _draw_dropout) and arrive bit-packed: two 32-bit words per edge, bit f of the pair = feature f kept.
+// Dropout sits between the Linear and the LeakyReLU; LeakyReLU is positively homogeneous, so
+// LeakyReLU(keep * s * z) = keep * s * LeakyReLU(z): the kernels apply the factor to the activation, and the backward
+// multiplies the LeakyReLU derivative by the same factor.  This lane's 16 bits of edge `e`: features 16 mb + 4 g + r.
+__device__ __forceinline__ unsigned drop_bits16(const uint32_t* __restrict__ words, int e, int g) {
+    const uint32_t w0 = words[(size_t)e * 2], w1 = words[(size_t)e * 2 + 1];
+    unsigned b = 0u;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) b |= (((mb < 2 ? w0 : w1) >> (16 * (mb & 1) + 4 * g)) & 0xfu) << (4 * mb);
+    return b;
+}
+template <int NB>
+__device__ __forceinline__ void drop_load(const EqdEdgeParams& P, EdgeTileState<NB>& S, int l15, int g) {
+    S.keepz = S.keepc = 0u;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int e = S.e0 + ((16 * nb + l15) < S.ne ? 16 * nb + l15 : 0);
+        S.keepz |= drop_bits16(P.drop_z1, e, g) << (16 * nb);
+        S.keepc |= drop_bits16(P.drop_ch, e, g) << (16 * nb);
+    }
+}
 
 // Forward of one tile of 16*NB edges up to (and including) the coefficient. On return:
 //   xh = LayerNorm-normalised hidden (before the affine), m = msg, ch = coors_mlp hidden pre-activation.
 // If rbf_out != nullptr the 15 RBFs of each edge are also written there ([E][16]).
-template <int NB>
+template <int NB, bool DROP = false>
 __device__ __forceinline__ void edge_tile_forward(const EqdGraph& G, const EqdEdgeParams& P, const float* __restrict__ w1,
                                                   const float* __restrict__ w2, const float* __restrict__ wc1,
                                                   const float* __restrict__ vec, float* __restrict__ tile,
@@ -308,6 +333,7 @@ __device__ __forceinline__ void edge_tile_forward(const EqdGraph& G, const EqdEd
     EQD_TR(6);
     // ---- LeakyReLU + LayerNorm statistics (two-pass like torch) ------------------------------------
     S.zpos = 0u;
+    if constexpr (DROP) drop_load<NB>(P, S, l15, g);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         float s = 0.f;
@@ -317,7 +343,8 @@ __device__ __forceinline__ void edge_tile_forward(const EqdGraph& G, const EqdEd
             for (int r = 0; r < 4; ++r) {
                 const float z = xh[mb][nb][r];
                 if (z > 0.f) S.zpos |= 1u << (16 * nb + 4 * mb + r);
-                const float v = lrelu(z, P.slope);
+                float v = lrelu(z, P.slope);
+                if constexpr (DROP) v *= ((S.keepz >> (16 * nb + 4 * mb + r)) & 1u) ? P.drop_scale : 0.f;
                 xh[mb][nb][r] = v;
                 s += v;
             }
@@ -364,8 +391,16 @@ __device__ __forceinline__ void edge_tile_forward(const EqdGraph& G, const EqdEd
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
             const float4 w = *(const float4*)&vec[VEC_WC2 + 16 * mb + 4 * g];
-            s += lrelu(ch[mb][nb][0], P.slope) * w.x + lrelu(ch[mb][nb][1], P.slope) * w.y +
-                 lrelu(ch[mb][nb][2], P.slope) * w.z + lrelu(ch[mb][nb][3], P.slope) * w.w;
+            if constexpr (DROP) {
+                const float wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    s += lrelu(ch[mb][nb][r], P.slope) *
+                         (((S.keepc >> (16 * nb + 4 * mb + r)) & 1u) ? P.drop_scale : 0.f) * wv[r];
+            } else {
+                s += lrelu(ch[mb][nb][0], P.slope) * w.x + lrelu(ch[mb][nb][1], P.slope) * w.y +
+                     lrelu(ch[mb][nb][2], P.slope) * w.z + lrelu(ch[mb][nb][3], P.slope) * w.w;
+            }
         }
         S.coef[nb] = group_sum(s) + vec[VEC_BC2];
     }
@@ -497,7 +532,7 @@ __device__ __forceinline__ void chain64_bf(f32x4 (&out)[4][NB], const f32x4 (&in
 }
 
 // bf16 counterpart of edge_tile_forward (same outputs, same EdgeTileState)
-template <int NB>
+template <int NB, bool DROP = false>
 __device__ __forceinline__ void edge_tile_forward_bf(const EqdGraph& G, const EqdEdgeParams& P,
                                                      const unsigned short* __restrict__ w1,
                                                      const unsigned short* __restrict__ w2,
@@ -592,6 +627,7 @@ __device__ __forceinline__ void edge_tile_forward_bf(const EqdGraph& G, const Eq
     }
     // ---- LeakyReLU + LayerNorm statistics (fp32, two-pass like torch) ------------------------------------------------
     S.zpos = 0u;
+    if constexpr (DROP) drop_load<NB>(P, S, l15, g);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         float s = 0.f;
@@ -601,7 +637,8 @@ __device__ __forceinline__ void edge_tile_forward_bf(const EqdGraph& G, const Eq
             for (int r = 0; r < 4; ++r) {
                 const float z = xh[mb][nb][r];
                 if (z > 0.f) S.zpos |= 1u << (16 * nb + 4 * mb + r);
-                const float v = lrelu(z, P.slope);
+                float v = lrelu(z, P.slope);
+                if constexpr (DROP) v *= ((S.keepz >> (16 * nb + 4 * mb + r)) & 1u) ? P.drop_scale : 0.f;
                 xh[mb][nb][r] = v;
                 s += v;
             }
@@ -642,8 +679,16 @@ __device__ __forceinline__ void edge_tile_forward_bf(const EqdGraph& G, const Eq
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
             const float4 w = *(const float4*)&vec[VEC_WC2 + 16 * mb + 4 * g];
-            s += lrelu(ch[mb][nb][0], P.slope) * w.x + lrelu(ch[mb][nb][1], P.slope) * w.y +
-                 lrelu(ch[mb][nb][2], P.slope) * w.z + lrelu(ch[mb][nb][3], P.slope) * w.w;
+            if constexpr (DROP) {
+                const float wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    s += lrelu(ch[mb][nb][r], P.slope) *
+                         (((S.keepc >> (16 * nb + 4 * mb + r)) & 1u) ? P.drop_scale : 0.f) * wv[r];
+            } else {
+                s += lrelu(ch[mb][nb][0], P.slope) * w.x + lrelu(ch[mb][nb][1], P.slope) * w.y +
+                     lrelu(ch[mb][nb][2], P.slope) * w.z + lrelu(ch[mb][nb][3], P.slope) * w.w;
+            }
         }
         S.coef[nb] = group_sum(s) + vec[VEC_BC2];
     }
@@ -681,7 +726,7 @@ struct EdgeFwdSmem {
     float sxw[NW][96];      // per-node mean of x_rel * coef of the wave's tile
 };
 // forward of the tiles blk * NW + wave, + nblk * NW, ... (blk of nblk workgroups of NW waves)
-template <int NW, bool BF>
+template <int NW, bool BF, bool DROP = false>
 __device__ __forceinline__ void edge_fwd_body(EdgeFwdSmem<NW, BF>& S_, const EqdGraph& G, const EqdEdgeParams& P, int blk,
                                               int nblk, const float* __restrict__ Pn, const float* __restrict__ Qn,
                                               const float* __restrict__ x, float* __restrict__ aggr_msg,
@@ -714,9 +759,9 @@ __device__ __forceinline__ void edge_fwd_body(EdgeFwdSmem<NW, BF>& S_, const Eqd
         const float x0a = G.x0[xo + (c0 < 3 * nn_pre ? c0 : 0)], xa = x[xo + (c0 < 3 * nn_pre ? c0 : 0)];
         const float x0b = G.x0[xo + (c1 < 3 * nn_pre ? c1 : 0)], xb = x[xo + (c1 < 3 * nn_pre ? c1 : 0)];
         if constexpr (BF)
-            edge_tile_forward_bf<2>(G, P, sm.w1, sm.w2, sm.wc1, sm.vec, tile, Pn, Qn, x, lane, S, xh, m, ch);
+            edge_tile_forward_bf<2, DROP>(G, P, sm.w1, sm.w2, sm.wc1, sm.vec, tile, Pn, Qn, x, lane, S, xh, m, ch);
         else
-            edge_tile_forward<2>(G, P, sm.w1, sm.w2, sm.wc1, sm.vec, tile, Pn, Qn, x, lane, S, xh, m, ch, nullptr);
+            edge_tile_forward<2, DROP>(G, P, sm.w1, sm.w2, sm.wc1, sm.vec, tile, Pn, Qn, x, lane, S, xh, m, ch, nullptr);
         wave_lds_fence();   // feature tile is dead: reuse as the message tile [edge][64 + x_moment]
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
@@ -774,14 +819,22 @@ __device__ __forceinline__ void edge_fwd_body(EdgeFwdSmem<NW, BF>& S_, const Eqd
     }
     EQD_TR_WG_END();
 }
-template <int NW, bool BF>
+template <int NW, bool BF, bool DROP = false>
 __global__ __launch_bounds__(64 * NW) void k_edge_fwd(EqdGraph G, EqdEdgeParams P, const float* __restrict__ Pn,
                                                               const float* __restrict__ Qn,
                                                               const float* __restrict__ x,
                                                               float* __restrict__ aggr_msg,
                                                               float* __restrict__ x_new) {
     __shared__ EdgeFwdSmem<NW, BF> S;
-    edge_fwd_body<NW, BF>(S, G, P, (int)blockIdx.x, (int)gridDim.x, Pn, Qn, x, aggr_msg, x_new);
+    edge_fwd_body<NW, BF, DROP>(S, G, P, (int)blockIdx.x, (int)gridDim.x, Pn, Qn, x, aggr_msg, x_new);
+}
+// NULL-ness of the two dropout masks must agree; returns 1 when dropout is active
+static int edge_drop_mode(const EqdEdgeParams* p, const char* who) {
+    if ((p->drop_z1 == nullptr) != (p->drop_ch == nullptr) || (p->drop_z1 && !(p->drop_scale > 0.f))) {
+        eqd_set_error("%s: dropout needs both masks (drop_z1, drop_ch) and drop_scale > 0", who);
+        return -1;
+    }
+    return p->drop_z1 ? 1 : 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -844,17 +897,21 @@ extern "C" int eqd_edge_message_fwd(const EqdGraph* g, const EqdEdgeParams* p, c
     // leaves room for the attention kernel that runs beside this one on the auxiliary stream.  (Dealing the 1067
     // tiles over all 256 CUs measured no faster - 4 % of the SIMDs still get two tiles - and serialised the two.)
     const int blocks = edge_grid(g->n_tiles, FWD_WAVES, 1);
-    if (p->bf16) {
-        if (p->use_he && !g->he_bf16) {
-            eqd_set_error("eqd_edge_message_fwd: bf16 mode needs EqdGraph.he_bf16");
-            return EQD_ERR_NULL;
-        }
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_edge_fwd<FWD_WAVES, true>), dim3(blocks), dim3(64 * FWD_WAVES), 0,
-                           (hipStream_t)stream, *g, *p, P, Q, x, aggr_msg, x_new);
-    } else {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_edge_fwd<FWD_WAVES, false>), dim3(blocks), dim3(64 * FWD_WAVES), 0,
-                           (hipStream_t)stream, *g, *p, P, Q, x, aggr_msg, x_new);
+    const int drop = edge_drop_mode(p, "eqd_edge_message_fwd");
+    if (drop < 0) return EQD_ERR_NULL;
+    if (p->bf16 && p->use_he && !g->he_bf16) {
+        eqd_set_error("eqd_edge_message_fwd: bf16 mode needs EqdGraph.he_bf16");
+        return EQD_ERR_NULL;
     }
+#define EQD_EDGE_FWD_LAUNCH(BF_, DROP_)                                                                                   \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_edge_fwd<FWD_WAVES, BF_, DROP_>), dim3(blocks), dim3(64 * FWD_WAVES), 0,         \
+                       (hipStream_t)stream, *g, *p, P, Q, x, aggr_msg, x_new)
+    if (p->bf16) {
+        if (drop) EQD_EDGE_FWD_LAUNCH(true, true); else EQD_EDGE_FWD_LAUNCH(true, false);
+    } else {
+        if (drop) EQD_EDGE_FWD_LAUNCH(false, true); else EQD_EDGE_FWD_LAUNCH(false, false);
+    }
+#undef EQD_EDGE_FWD_LAUNCH
     return eqd_check_launch("k_edge_fwd");
 }
 
@@ -862,7 +919,7 @@ extern "C" int eqd_edge_message_fwd(const EqdGraph* g, const EqdEdgeParams* p, c
 int eqd_edge_attn_fused(const EqdGraph* g, const EqdEdgeParams* p, int d_att, const float* q, const float* k, const float* v) {
     const char* f = getenv("EQD_FUSE_FWD");
     if (f && f[0] == '0' && f[1] == 0) return 0;
-    if (p->bf16 || d_att != 64 || g->n_tiles <= 0 || g->n_att_items <= 0) return 0;
+    if (p->bf16 || p->drop_z1 || d_att != 64 || g->n_tiles <= 0 || g->n_att_items <= 0) return 0;
     if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) != 0) return 0;
     const int n_edge = edge_grid(g->n_tiles, FWD_WAVES, 1);
     return n_edge + g->n_att_items <= eqd_num_cus();
@@ -1000,7 +1057,7 @@ struct EdgeBwdSmemSel<true> {
     enum { SLAB = 64 * USB };
 };
 
-template <bool BF>
+template <bool BF, bool DROP = false>
 __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdgeParams P, const float* __restrict__ Pn,
                                                               const float* __restrict__ Qn,
                                                               const float* __restrict__ x,
@@ -1053,9 +1110,9 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
             for (int mb = 0; mb < 4; ++mb) dag[mb] = *(const float4*)&d_aggr[(size_t)d * 64 + 16 * mb + 4 * g];
         }
         if constexpr (BF)
-            edge_tile_forward_bf<1>(G, P, sm.w1, sm.w2, sm.wc1, sm.vec, tile, Pn, Qn, x, lane, S, xh, m, ch);
+            edge_tile_forward_bf<1, DROP>(G, P, sm.w1, sm.w2, sm.wc1, sm.vec, tile, Pn, Qn, x, lane, S, xh, m, ch);
         else
-            edge_tile_forward<1>(G, P, sm.w1, sm.w2, sm.wc1, sm.vec, tile, Pn, Qn, x, lane, S, xh, m, ch, nullptr);
+            edge_tile_forward<1, DROP>(G, P, sm.w1, sm.w2, sm.wc1, sm.vec, tile, Pn, Qn, x, lane, S, xh, m, ch, nullptr);
         // ---- coordinate path ---------------------------------------------------------------------
         float invdeg = 0.f, dcoef = 0.f, dxr[3] = {0.f, 0.f, 0.f};
         {
@@ -1077,8 +1134,10 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float c = ch[mb][0][r];
-                    const float dch = wv[r] * dcoef * lrelu_grad(c, P.slope);
-                    va[4 * mb + r] = lrelu(c, P.slope) * dcoef;
+                    float keep = 1.f;       // dropout of coors_mlp.1: factor on the activation and on its derivative
+                    if constexpr (DROP) keep = ((S.keepc >> (4 * mb + r)) & 1u) ? P.drop_scale : 0.f;
+                    const float dch = wv[r] * dcoef * (lrelu_grad(c, P.slope) * keep);
+                    va[4 * mb + r] = (lrelu(c, P.slope) * keep) * dcoef;
                     vb[4 * mb + r] = dch;
                     ch[mb][0][r] = dch;
                 }
@@ -1196,7 +1255,8 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float xhv = xh[mb][0][r];
-                    const float lg = ((S.zpos >> (4 * mb + r)) & 1u) ? 1.f : P.slope;
+                    float lg = ((S.zpos >> (4 * mb + r)) & 1u) ? 1.f : P.slope;
+                    if constexpr (DROP) lg *= ((S.keepz >> (4 * mb + r)) & 1u) ? P.drop_scale : 0.f;
                     const float v = S.ev[0] ? S.rstd[0] * (dz[mb][0][r] - s1 - xhv * s2) * lg : 0.f;
                     dz[mb][0][r] = v;
                 }
@@ -1314,7 +1374,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
 // and writes, per edge and feature, one byte: 1 = pre-activation > 0 (derivative 1), 0 = derivative `slope`.
 // z1_pos: edge_mlp.0's output (EdgeTileState::zpos, the mask the backward applies); ch_pos: coors_mlp.0's output.
 // ---------------------------------------------------------------------------------------------
-template <bool BF>
+template <bool BF, bool DROP>
 __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_signs(EqdGraph G, EqdEdgeParams P, const float* __restrict__ Pn,
                                                                 const float* __restrict__ Qn,
                                                                 const float* __restrict__ x,
@@ -1337,9 +1397,9 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_signs(EqdGraph G, EqdEd
         S.ne = S.ne > 16 ? 16 : S.ne;
         f32x4 xh[4][1], m[4][1], ch[4][1];
         if constexpr (BF)
-            edge_tile_forward_bf<1>(G, P, sm.w1, sm.w2, sm.wc1, sm.vec, tile, Pn, Qn, x, lane, S, xh, m, ch);
+            edge_tile_forward_bf<1, DROP>(G, P, sm.w1, sm.w2, sm.wc1, sm.vec, tile, Pn, Qn, x, lane, S, xh, m, ch);
         else
-            edge_tile_forward<1>(G, P, sm.w1, sm.w2, sm.wc1, sm.vec, tile, Pn, Qn, x, lane, S, xh, m, ch, nullptr);
+            edge_tile_forward<1, DROP>(G, P, sm.w1, sm.w2, sm.wc1, sm.vec, tile, Pn, Qn, x, lane, S, xh, m, ch, nullptr);
         if (S.ev[0]) {
             const size_t row = (size_t)(S.e0 + l15) * 64;
 #pragma unroll
@@ -1360,12 +1420,15 @@ int eqd_launch_edge_signs(const EqdGraph* g, const EqdEdgeParams* p, const float
     const int n_tiles = (g->n_edges + 15) / 16;
     int blocks = (n_tiles + BWD_WAVES - 1) / BWD_WAVES;
     if (blocks > eqd_num_cus()) blocks = eqd_num_cus();
-    if (p->bf16)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_edge_signs<true>), dim3(blocks), dim3(64 * BWD_WAVES), 0, st, *g, *p, P, Q, x,
-                           z1_pos, ch_pos);
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_edge_signs<false>), dim3(blocks), dim3(64 * BWD_WAVES), 0, st, *g, *p, P, Q, x,
-                           z1_pos, ch_pos);
+#define EQD_EDGE_SIGNS_LAUNCH(BF_, DROP_)                                                                                 \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_edge_signs<BF_, DROP_>), dim3(blocks), dim3(64 * BWD_WAVES), 0, st, *g, *p, P, Q, x, \
+                       z1_pos, ch_pos)
+    if (p->bf16) {
+        if (p->drop_z1) EQD_EDGE_SIGNS_LAUNCH(true, true); else EQD_EDGE_SIGNS_LAUNCH(true, false);
+    } else {
+        if (p->drop_z1) EQD_EDGE_SIGNS_LAUNCH(false, true); else EQD_EDGE_SIGNS_LAUNCH(false, false);
+    }
+#undef EQD_EDGE_SIGNS_LAUNCH
     return eqd_check_launch("k_edge_signs");
 }
 
@@ -1454,17 +1517,21 @@ int eqd_edge_message_bwd_impl(const EqdGraph* g, const EqdEdgeParams* p, const f
         W.wpart = part_override + (size_t)blocks * BWD_WAVES * VP;
     }
     if (g->n_edges > 0) {
-        if (p->bf16) {
-            if (p->use_he && !g->he_bf16) {
-                eqd_set_error("eqd_edge_message_bwd: bf16 mode needs EqdGraph.he_bf16");
-                return EQD_ERR_NULL;
-            }
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_edge_bwd<true>), dim3(blocks), dim3(64 * BWD_WAVES), 0, st, *g, *p, P, Q, x,
-                               d_aggr_msg, d_xnew, W);
-        } else {
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_edge_bwd<false>), dim3(blocks), dim3(64 * BWD_WAVES), 0, st, *g, *p, P, Q, x,
-                               d_aggr_msg, d_xnew, W);
+        const int drop = edge_drop_mode(p, "eqd_edge_message_bwd");
+        if (drop < 0) return EQD_ERR_NULL;
+        if (p->bf16 && p->use_he && !g->he_bf16) {
+            eqd_set_error("eqd_edge_message_bwd: bf16 mode needs EqdGraph.he_bf16");
+            return EQD_ERR_NULL;
         }
+#define EQD_EDGE_BWD_LAUNCH(BF_, DROP_)                                                                                  \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_edge_bwd<BF_, DROP_>), dim3(blocks), dim3(64 * BWD_WAVES), 0, st, *g, *p, P, Q, x, \
+                       d_aggr_msg, d_xnew, W)
+        if (p->bf16) {
+            if (drop) EQD_EDGE_BWD_LAUNCH(true, true); else EQD_EDGE_BWD_LAUNCH(true, false);
+        } else {
+            if (drop) EQD_EDGE_BWD_LAUNCH(false, true); else EQD_EDGE_BWD_LAUNCH(false, false);
+        }
+#undef EQD_EDGE_BWD_LAUNCH
         int rc = eqd_check_launch("k_edge_bwd");
         if (rc) return rc;
         const int nw = blocks;               // one vector partial row per workgroup

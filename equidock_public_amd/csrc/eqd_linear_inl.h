@@ -442,6 +442,11 @@ __device__ __forceinline__ void linear_tile_lean(const JobW& W, bool chain, int 
         if (act) y = lrelu(y, slope);
         v[r] = y;
     }
+    if (const float* const jmul = jw_p<const float>(W, LJ(mul))) {      // dropout factors (training mode only)
+        const f32x4 mm = *(const EQD_GAS f4v*)(jmul + (size_t)rowe * jw_i(W, LJ(ld_mul)) + f0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= mm[r];
+    }
     if (jlng) {
         const float invM = 1.f / 64.f;
         float s1 = 0.f;
@@ -647,6 +652,15 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const JobW& W, b
                 float y = (acc[rt][i][r] + acc2[rt][i][r]) + bb[r];
                 if (act) y = lrelu(y, slope);
                 v[i][r] = r < nf[i] ? y : 0.f;
+            }
+        }
+        if (const float* const jmul = jw_p<const float>(W, LJ(mul))) {      // dropout factors (training mode only)
+            const int ld_mul = jw_i(W, LJ(ld_mul));
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float4 mm = ld4u_fix(ld4u_raw(jmul + (size_t)(rv ? rowi : rows - 1) * ld_mul + 16 * mbs[i] + 4 * g, nf[i], jmul),
+                                           nf[i]);
+                v[i][0] *= mm.x; v[i][1] *= mm.y; v[i][2] *= mm.z; v[i][3] *= mm.w;
             }
         }
         if (jlng) {

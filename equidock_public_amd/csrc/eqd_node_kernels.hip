@@ -216,6 +216,9 @@ __device__ __forceinline__ void chain_lnbwd64(const JobW& W, float (*Lb)[LIN_LOC
     float* const jY = jw_p<float>(W, LJ(Y));
     const int ldy = jw_i(W, LJ(ldy));
     float* const jaux = jw_p<float>(W, JW_OFF(EqdChainJob, aux));
+    f32x4 mulv = {1.f, 1.f, 1.f, 1.f};       // dropout factors of the forward (training mode): d LeakyReLU * keep * s
+    if (const float* const jmul = jw_p<const float>(W, LJ(mul)))
+        mulv = *(const EQD_GAS f4v*)(jmul + (size_t)(rv ? rowi : rows - 1) * jw_i(W, LJ(ld_mul)) + f0);
 #undef LJ
     f32x4 o = *(const f32x4*)&Lb[0][src_l][l15 * LIN_S + f0];
     f32x4 y = yp;
@@ -253,7 +256,7 @@ __device__ __forceinline__ void chain_lnbwd64(const JobW& W, float (*Lb)[LIN_LOC
     const float s2 = ((stat[3][0][l15] + stat[3][1][l15]) + (stat[3][2][l15] + stat[3][3][l15])) * invd;
     f32x4 z;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) z[r] = rv ? rstd * (dx[r] - s1 - xh[r] * s2) * lrelu_grad(y[r], slope) : 0.f;
+    for (int r = 0; r < 4; ++r) z[r] = rv ? rstd * (dx[r] - s1 - xh[r] * s2) * (lrelu_grad(y[r], slope) * mulv[r]) : 0.f;
     *(f32x4*)&Lb[0][out_l][l15 * LIN_S + f0] = z;
     if (rv && jY) *(EQD_GAS f4v*)&jY[(size_t)rowi * ldy + f0] = z;
     // d gamma / d beta of the workgroup's 16 rows: 8 values per lane, summed over the 16 lanes of the group by a halving
@@ -290,6 +293,8 @@ __device__ __forceinline__ void chain_lnbwd(const EqdChainJob& C, float (*Lb)[LI
     const EQD_GAS float* const jX = (const EQD_GAS float*)uni(J.s[0].X);
     EQD_GAS float* const jY = (EQD_GAS float*)uni(J.Y);
     EQD_GAS float* const jaux = (EQD_GAS float*)uni(C.aux);
+    const EQD_GAS float* const jmul = (const EQD_GAS float*)uni(J.mul);      // dropout factors of the forward, or NULL
+    const int ld_mul = uni(J.ld_mul);
     const int rows = uni(J.rows), ldx = uni(J.s[0].ldx), ldy = uni(J.ldy), src_l = uni(C.src_local[0]), out_l = uni(C.out_local);
     const float slope = uni(J.slope), ln_eps = uni(J.ln_eps);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -329,8 +334,13 @@ __device__ __forceinline__ void chain_lnbwd(const EqdChainJob& C, float (*Lb)[LI
             const float dx0 = o0 * g0, dx1 = o1 * g1;
             const float s1 = wave_sum(dx0 + dx1) * invd;
             const float s2 = wave_sum(dx0 * xh0 + dx1 * xh1) * invd;
-            const float z0 = rstd * (dx0 - s1 - xh0 * s2) * lrelu_grad(y0, slope);
-            const float z1 = rstd * (dx1 - s1 - xh1 * s2) * lrelu_grad(y1, slope);
+            float z0 = rstd * (dx0 - s1 - xh0 * s2) * lrelu_grad(y0, slope);
+            float z1 = rstd * (dx1 - s1 - xh1 * s2) * lrelu_grad(y1, slope);
+            if (jmul) {
+                const size_t mo = (size_t)(rv ? row : rows - 1) * ld_mul;
+                z0 *= jmul[mo + (v0 ? f0 : 0)];
+                z1 *= jmul[mo + (v1 ? f1 : 0)];
+            }
             if (v0) dout[lr * LIN_S + f0] = rv ? z0 : 0.f;
             if (v1) dout[lr * LIN_S + f1] = rv ? z1 : 0.f;
             if (rv && jY) {
@@ -443,6 +453,7 @@ static bool rw_eligible(const EqdChainJob* jobs, int njobs, int rows) {
         const EqdChainJob& C = jobs[i];
         const EqdLinJob& J = C.lin;
         if (J.M != 64 || J.rows != rows || C.out_local >= LIN_LOCALS) return false;
+        if (J.mul) return false;      // dropout factors (training mode): only the four-wave kernels apply them
         if ((J.bf16 != 0) != (jobs[0].lin.bf16 != 0)) return false;
         // (no alignment condition: rows are read with 16-byte loads at 4-byte alignment - gfx950 runs global memory in
         // unaligned-access mode - which is what the 69-wide h0 rows need anyway)

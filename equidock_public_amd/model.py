@@ -18,11 +18,12 @@ two C calls into the HIP library (include/equidock_hip.h) wrapped in one autogra
 
 The published configuration family (src/utils/args.py:227-280: nonlin 'lkyrelu', layer_norm 'LN',
 layer_norm_coors '0', final_h_layer_norm '0', hidden/embedding width 64, no fine-tune stage) runs in the HIP
-library, and there is no CPU fallback for it: a missing library or a CPU tensor raises.  The reference's other
-options - swish, BatchNorm / LayerNorm placements, GraphNorm (src/utils/graph_norm.py), the fine-tune stage, and
-dropout > 0 while training (torch's RNG cannot be reproduced inside a fused kernel) - build the same sub-modules
-and run them through torch operators on the tensors' device (equidock_public_amd/torch_path.py), so that every
-configuration of the reference constructs, loads its checkpoint and trains.
+library - in eval and in training mode, with or without dropout: nn.Dropout's masks are drawn with torch's generator in
+the reference's consumption order (DropoutMasks) and applied inside the kernels - and there is no CPU fallback for it: a
+missing library or a CPU tensor raises.  The reference's other options - swish, BatchNorm / LayerNorm placements,
+GraphNorm (src/utils/graph_norm.py), the fine-tune stage - build the same sub-modules and run them through torch
+operators on the tensors' device (equidock_public_amd/torch_path.py), so that every configuration of the reference
+constructs, loads its checkpoint and trains.
 """
 import ctypes as C
 
@@ -87,8 +88,8 @@ def get_final_h_layer_norm(layer_norm_type, dim):
 
 def hip_path_supported(args, fine_tune=False):
     """True when the configuration is the published family (src/utils/args.py:227-280), which runs as two C calls into
-    the HIP library; every other reference option - swish, BatchNorm / LayerNorm placements, GraphNorm, the fine-tune
-    stage, and dropout > 0 while training - runs the same modules through torch operators on the GPU
+    the HIP library (any dropout, training or eval mode); every other reference option - swish, BatchNorm / LayerNorm
+    placements, GraphNorm, the fine-tune stage - runs the same modules through torch operators on the GPU
     (equidock_public_amd/torch_path.py)."""
     return (not fine_tune and args['nonlin'] == 'lkyrelu' and args['layer_norm'] == 'LN' and args['layer_norm_coors'] == '0'
             and args['final_h_layer_norm'] == '0' and args['iegmn_lay_hid_dim'] == 64 and args['residue_emb_dim'] <= 64
@@ -188,11 +189,74 @@ def flat_layout(tensors):
     return offs, total
 
 
+class DropoutMasks:
+    """The nn.Dropout keep masks of ONE training-mode forward (include/equidock_hip.h: EqdDropout).
+
+    Drawn with torch's own dropout on tensors of the reference's shapes, in the reference's consumption order - per layer
+    edge_mlp.1 on the ll then the rr edges, coors_mlp.1 ll / rr, node_mlp.1 ligand / receptor
+    (rigid_docking_model.py:236-237, 263-265, 319-337), then mlp_h_mean_ROT.1 per pair, receptor before ligand (:524-529) -
+    so that for a given torch seed the masks are the ones the reference's nn.Dropout modules would draw on the same
+    device (a mask depends on the generator state and the tensor's shape, not on its values).  `device`: where the draws
+    happen - the tensors' device by default; 'cpu' reproduces a CPU run of the reference (that is how the recorded
+    `dropout_train` vectors of tests/golden/variants.npz are matched on a GPU).  The masks are then re-ordered to the
+    library's edge order and bit-packed (edges) / kept as 0 | 1/(1-p) factors (nodes)."""
+
+    def __init__(self, p, edge_z1, edge_ch, node, head):
+        self.p, self.edge_z1, self.edge_ch, self.node, self.head = float(p), edge_z1, edge_ch, node, head
+
+    def c_struct(self):
+        d = _lib.EqdDropout()
+        d.p = self.p
+        d.edge_z1, d.edge_ch = self.edge_z1.data_ptr(), self.edge_ch.data_ptr()
+        d.node, d.head = self.node.data_ptr(), self.head.data_ptr()
+        return d
+
+    @staticmethod
+    def draw(iegmn, g, packed):
+        import torch.nn.functional as F
+        p = float(iegmn.args['dropout'])
+        dev = packed.x0.device
+        mdev = torch.device(getattr(iegmn, 'dropout_mask_device', None) or dev)
+        lc, rc = g._batch_nodes['ligand'], g._batch_nodes['receptor']
+        nl, nr = sum(lc), sum(rc)
+        e_ll, e_rr = int(g._edges['ll'][0].numel()), int(g._edges['rr'][0].numel())
+        d0 = iegmn.args['residue_emb_dim'] + (5 if iegmn.use_mean_node_features else 0)
+        dh = iegmn.args['iegmn_lay_hid_dim']
+
+        def factors(rows, width):        # what nn.Dropout multiplies a [rows, width] activation by: 0 or 1 / (1 - p)
+            return F.dropout(torch.ones(rows, width, dtype=torch.float32, device=mdev), p, True)
+        weights = (2 ** torch.arange(32, dtype=torch.int64, device=mdev)).view(1, 1, 32)
+
+        def bits(fl, fr):                # two [E, 64] factor tensors (ll, rr edges) -> [E_ll + E_rr, 2] packed words
+            keep = (torch.cat([fl, fr], 0) > 0).view(-1, 2, 32).to(torch.int64)
+            return (keep * weights).sum(-1).to(torch.int32)      # (int64 -> int32 wraps: the bit pattern of the uint32)
+        ez, ec, nodes = [], [], []
+        for l in range(iegmn.n_lays):
+            d = d0 if l == 0 else dh
+            zl, zr = factors(e_ll, 64), factors(e_rr, 64)            # edge_mlp.1: ligand edges first
+            cl, cr = factors(e_ll, 64), factors(e_rr, 64)            # coors_mlp.1
+            ml, mr = factors(nl, d), factors(nr, d)                  # node_mlp.1
+            ez.append(bits(zl, zr))
+            ec.append(bits(cl, cr))
+            nodes.append(torch.cat([ml, mr], 0).reshape(-1))
+        head = torch.empty(nl + nr, 64, dtype=torch.float32, device=mdev)
+        lo, ro = 0, nl
+        for a, b in zip(lc, rc):                                       # per pair: receptor rows, then ligand rows
+            head[ro:ro + b] = factors(b, 64)
+            head[lo:lo + a] = factors(a, 64)
+            lo += a
+            ro += b
+        perm = packed.edge_perm.to(mdev).long()                        # packed edge i = raw edge perm[i]
+        edge_z1 = torch.stack([t[perm] for t in ez]).to(dev).contiguous()
+        edge_ch = torch.stack([t[perm] for t in ec]).to(dev).contiguous()
+        return DropoutMasks(p, edge_z1, edge_ch, torch.cat(nodes).to(dev).contiguous(), head.to(dev).contiguous())
+
+
 class _IEGMNFunction(torch.autograd.Function):
     """forward = eqd_model_forward, backward = eqd_model_backward (one C call each)."""
 
     @staticmethod
-    def forward(ctx, packed, desc, table_idx, svd_draws, need_grad, flat_state, *uniq):
+    def forward(ctx, packed, desc, table_idx, svd_draws, need_grad, flat_state, drop, *uniq):
         # Flat-gradient mode: `uniq` is (parameter list, anchor).  The ~160 parameters are then NOT autograd inputs
         # (apply() only tracks top-level tensors): their gradients are accumulated by the C call straight into the
         # flat buffer, and the 0-d `anchor` is the one input that makes autograd call backward().  Per-parameter
@@ -231,12 +295,15 @@ class _IEGMNFunction(torch.autograd.Function):
             svd_draws = _lib.require_device(svd_draws.to(torch.float32).contiguous(), 'svd_draws')
         if _lib.profiling:
             lib.eqd_profile_mark(b'(before forward: zero-grad fill, allocations)')
+        dstruct = None if drop is None else drop.c_struct()
         with _lib.device_guard(dev):        # kernels and memsets go to the tensors' device, whatever the current one is
             _lib.check(lib.eqd_model_forward(
-                C.byref(desc), C.byref(gs), ptrs, _lib.ptr(svd_draws), _lib.ptr(lig), _lib.ptr(Yl), _lib.ptr(Yr),
+                C.byref(desc), C.byref(gs), ptrs, None if dstruct is None else C.byref(dstruct),
+                _lib.ptr(svd_draws), _lib.ptr(lig), _lib.ptr(Yl), _lib.ptr(Yr),
                 _lib.ptr(T), _lib.ptr(b), _lib.ptr(status), _lib.ptr(saved), C.c_size_t(sb if need_grad else 0),
                 _lib.ptr(scratch), C.c_size_t(0 if need_grad else wb), _lib.stream_ptr(dev), _lib.exec_ctx(dev)))
-        packed._last_saved = (saved, sb) if need_grad else None     # for IEGMN.layer_state (tests); freed with the batch
+        packed._last_saved = (saved, sb, drop) if need_grad else None     # for IEGMN.layer_state (tests); freed with the batch
+        ctx.drop = drop                 # the masks of THIS forward: the backward applies the same ones
         ctx.packed, ctx.desc, ctx.table_idx, ctx.saved, ctx.sb, ctx.wb = packed, desc, table_idx, saved, sb, wb
         ctx.tensors, ctx.ptrs = tensors, ptrs
         ctx.flat_state = flat_state
@@ -270,15 +337,17 @@ class _IEGMNFunction(torch.autograd.Function):
         d_lig, d_Yl, d_Yr, d_T, d_b = (prep(t) for t in (d_lig, d_Yl, d_Yr, d_T, d_b))
         if _lib.profiling:
             lib.eqd_profile_mark(b'(between forward and backward: the caller\'s loss + its autograd)')
+        dstruct = None if ctx.drop is None else ctx.drop.c_struct()
         with _lib.device_guard(dev):
             _lib.check(lib.eqd_model_backward(
-                C.byref(desc), C.byref(gs), ptrs, _lib.ptr(d_lig), _lib.ptr(d_Yl), _lib.ptr(d_Yr), _lib.ptr(d_T),
+                C.byref(desc), C.byref(gs), ptrs, None if dstruct is None else C.byref(dstruct),
+                _lib.ptr(d_lig), _lib.ptr(d_Yl), _lib.ptr(d_Yr), _lib.ptr(d_T),
                 _lib.ptr(d_b), _lib.ptr(flat), goffs, _lib.ptr(ctx.saved), C.c_size_t(ctx.sb), _lib.ptr(scratch),
                 C.c_size_t(ctx.wb), _lib.stream_ptr(dev), _lib.exec_ctx(dev)))
         if ctx.flat_state is not None:
-            return (None,) * 8
+            return (None,) * 9
         grads = tuple(flat[o:o + t.numel()].view(t.shape) for o, t in zip(offs, tensors))
-        return (None, None, None, None, None, None) + grads
+        return (None, None, None, None, None, None, None) + grads
 
 
 class IEGMN(nn.Module):
@@ -478,12 +547,18 @@ class IEGMN(nn.Module):
                 raise _lib.EquidockHipError("parameters changed since enable_flat_grads(); call it again")
             self._rebind_flat_views(uniq)
             flat_state = (self._flat[0], self._flat[1], self._flat[3])
+        # nn.Dropout is active while training with args['dropout'] > 0 (half of the published family's hyper-parameter
+        # draws, src/utils/args.py:240): the masks come from torch's generator in the reference's order, the kernels
+        # apply them (no torch-operator detour any more)
+        drop = None
+        if self.training and self.args['dropout'] > 0:
+            drop = DropoutMasks.draw(self, batch_hetero_graph, packed)
         if flat_state is not None:
             lig, Yl, Yr, T, b, status = _IEGMNFunction.apply(packed, self._desc(), table_idx, self.svd_draws,
-                                                             need_grad, flat_state, uniq, self._flat[4])
+                                                             need_grad, flat_state, drop, uniq, self._flat[4])
         else:
             lig, Yl, Yr, T, b, status = _IEGMNFunction.apply(packed, self._desc(), table_idx, self.svd_draws,
-                                                             need_grad, None, *uniq)
+                                                             need_grad, None, drop, *uniq)
         self.last_svd_status = status
         return packed, lig, Yl, Yr, T, b
 
@@ -495,7 +570,7 @@ class IEGMN(nn.Module):
         last = getattr(packed, '_last_saved', None)
         if last is None:
             raise _lib.EquidockHipError("no saved forward state for this batch (run a forward with gradients enabled)")
-        saved, sb = last
+        saved, sb = last[0], last[1]
         lib = _lib.load_library()
         desc, gs = self._desc(), packed.c_struct()
         hp, xp, w = C.c_void_p(), C.c_void_p(), C.c_int(0)
@@ -522,7 +597,9 @@ class IEGMN(nn.Module):
         last = getattr(packed, '_last_saved', None)
         if last is None:
             raise _lib.EquidockHipError("no saved forward state for this batch (run a forward with gradients enabled)")
-        saved, sb = last
+        saved, sb, drop = last
+        dstruct = None if drop is None else drop.c_struct()
+        dref = None if dstruct is None else C.byref(dstruct)
         lib = _lib.load_library()
         desc, gs = self._desc(), packed.c_struct()
         uniq, table_idx = self._param_table()
@@ -541,21 +618,22 @@ class IEGMN(nn.Module):
                 if self.args['cross_msgs']:
                     t.update(att_mlp_Q=u8(N, d), att_mlp_K=u8(N, d))
                 _lib.check(lib.eqd_model_lrelu_signs(
-                    C.byref(desc), C.byref(gs), ptrs, _lib.ptr(saved), C.c_size_t(sb), l, _lib.ptr(t['edge_mlp']),
+                    C.byref(desc), C.byref(gs), ptrs, dref, _lib.ptr(saved), C.c_size_t(sb), l, _lib.ptr(t['edge_mlp']),
                     _lib.ptr(t['coors_mlp']), _lib.ptr(t['node_mlp']), _lib.ptr(t.get('att_mlp_Q')),
                     _lib.ptr(t.get('att_mlp_K')), _lib.stream_ptr(dev)))
                 out.append(t)
             t = dict(mlp_h_mean_ROT=u8(N, 64))
             _lib.check(lib.eqd_model_lrelu_signs(
-                C.byref(desc), C.byref(gs), ptrs, _lib.ptr(saved), C.c_size_t(sb), self.n_lays, None, None,
+                C.byref(desc), C.byref(gs), ptrs, dref, _lib.ptr(saved), C.c_size_t(sb), self.n_lays, None, None,
                 _lib.ptr(t['mlp_h_mean_ROT']), None, None, _lib.stream_ptr(dev)))
             out.append(t)
         return out
 
     def uses_hip_path(self):
-        """The published family runs in the HIP library; other reference options (and dropout > 0 while training) run
-        through torch operators on the same device (hip_path_supported)."""
-        return hip_path_supported(self.args, self.fine_tune) and not (self.training and self.args['dropout'] > 0)
+        """The published family runs in the HIP library - in eval AND in training mode, with or without dropout; the
+        reference's other options run through torch operators on the same device (hip_path_supported).  Decided by the
+        configuration alone (`_force_torch_path` is a test aid: the torch-operator restatement of the same configuration)."""
+        return hip_path_supported(self.args, self.fine_tune) and not getattr(self, '_force_torch_path', False)
 
     def forward(self, batch_hetero_graph, epoch):
         """[T_align list, b_align list, Y_ligand list, Y_receptor list] like the reference (:602)."""

@@ -112,6 +112,19 @@ typedef struct EqdModelDesc {
                                        (EqdLinJob.bf16, EqdAtbJob.bf16), attention (eqd_cross_attention_*_bf16); default 0 */
 } EqdModelDesc;
 
+/* nn.Dropout in training mode (args['dropout'] > 0; src/utils/args.py:240 draws 0 or 0.25 for the published family): the
+ * keep masks of ONE forward, drawn by the caller with torch's generator in the reference's consumption order (per layer:
+ * edge_mlp.1 on the ll then the rr edges, coors_mlp.1 ll / rr, node_mlp.1 ligand / receptor; then mlp_h_mean_ROT.1 per pair,
+ * receptor before ligand - rigid_docking_model.py:236-237, 263-265, 319-337, 524-529), re-ordered to the library's node /
+ * edge order.  The same struct must be passed to the backward of that forward.  NULL = no dropout (eval mode, p = 0). */
+typedef struct EqdDropout {
+    float p;                   /* kept elements are scaled by 1 / (1 - p) */
+    const uint32_t* edge_z1;   /* [n_layers][n_edges][2] bit f of the 64-bit pair = feature f of edge_mlp.1 is kept */
+    const uint32_t* edge_ch;   /* [n_layers][n_edges][2] the same for coors_mlp.1 */
+    const float* node;         /* layer 0: [n_nodes][d0], then layers 1..: [n_nodes][64] each; entries 0 or 1 / (1 - p) */
+    const float* head;         /* [n_nodes][64] mlp_h_mean_ROT.1; entries 0 or 1 / (1 - p) */
+} EqdDropout;
+
 /* Parameter table: device pointers in this fixed order.  Per layer i (base = 19*i):
  *   0 edge_mlp.0.weight [64, 2*d_in+42]   1 edge_mlp.0.bias [64]
  *   2 edge_mlp.3.weight [64] (LayerNorm)  3 edge_mlp.3.bias [64]
@@ -154,8 +167,8 @@ int eqd_model_layer_state(const EqdModelDesc* m, const EqdGraph* g, const void* 
  * [n_nodes][64] = mlp_h_mean_ROT (:434-438).  Any output may be NULL (edge_z1 and edge_ch: both or neither).  A CPU oracle
  * evaluated with these slopes has ONE gradient to compare against, whatever the fp32 summation order did to
  * pre-activations within rounding of 0 (tests/parity_common.py). */
-int eqd_model_lrelu_signs(const EqdModelDesc* m, const EqdGraph* g, const float* const* params, const void* saved,
-                          size_t saved_bytes, int layer, unsigned char* edge_z1, unsigned char* edge_ch,
+int eqd_model_lrelu_signs(const EqdModelDesc* m, const EqdGraph* g, const float* const* params, const EqdDropout* drop,
+                          const void* saved, size_t saved_bytes, int layer, unsigned char* edge_z1, unsigned char* edge_ch,
                           unsigned char* node, unsigned char* q, unsigned char* k, void* stream);
 
 /* Rigid_Body_Docking_Net.forward (rigid_docking_model.py:642-692) for the single-stage model:
@@ -163,8 +176,9 @@ int eqd_model_lrelu_signs(const EqdModelDesc* m, const EqdGraph* g, const float*
  * Outputs: lig_out [n_lig][3], Y_lig / Y_rec [n_pairs][n_heads][3], T [n_pairs][9], b [n_pairs][3],
  * svd_status [n_pairs] int32 (number of guard perturbations, 11 = "consistently unstable").
  * `svd_draws` may be NULL, or [n_pairs][10][3] diagonal perturbations to use when the guard
- * (:574) fires.  `saved` may be NULL for inference (no backward possible). */
-int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const float* const* params,
+ * (:574) fires.  `saved` may be NULL for inference (no backward possible).  `drop`: the dropout masks of a training-mode
+ * forward (EqdDropout), NULL otherwise. */
+int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const float* const* params, const EqdDropout* drop,
                       const float* svd_draws,
                       float* lig_out, float* Y_lig, float* Y_rec, float* T, float* b, int32_t* svd_status,
                       void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream, void* ctx);
@@ -173,7 +187,7 @@ int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const float* con
  * d_* are gradients w.r.t. the five outputs (any may be NULL = zero).  Parameter gradients are
  * ACCUMULATED into grad_flat at grad_offsets[i] (in floats, same order as the parameter table;
  * shared entries share offsets); the caller zeroes grad_flat. */
-int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, const float* const* params,
+int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, const float* const* params, const EqdDropout* drop,
                        const float* d_lig, const float* d_Ylig, const float* d_Yrec, const float* d_T,
                        const float* d_b,
                        float* grad_flat, const int64_t* grad_offsets,
@@ -205,6 +219,10 @@ typedef struct EqdLinJob {
     int32_t bf16;   /* 1: the products run on v_mfma_f32_16x16x16_bf16 (X and W rounded to bf16 when the MFMA operands are
                        formed, fp32 accumulate; bias, activation, LayerNorm, residual fp32).  One mode per eqd_linear call
                        (the first job's). */
+    const float* mul; int32_t ld_mul;   /* optional [rows][ld_mul]: the activation output is multiplied element-wise by it
+                       before the LayerNorm - nn.Dropout between a Linear and its LeakyReLU in training mode
+                       (rigid_docking_model.py:129, 435: LeakyReLU(keep * s * z) = keep * s * LeakyReLU(z)), entries are
+                       0 or 1 / (1 - p), drawn by the caller.  NULL = none.  Jobs with `mul` run on the four-wave kernels. */
 } EqdLinJob;
 int eqd_linear(const EqdLinJob* jobs /* host */, int njobs, void* stream);
 
@@ -235,6 +253,10 @@ typedef struct EqdEdgeParams {
     float slope, ln_eps, eta;
     int32_t use_dist, use_he;
     int32_t bf16;   /* 1: he from EqdGraph.he_bf16, GEMM inputs rounded to bf16, fp32 accumulate (bf16 MFMA) */
+    /* nn.Dropout of edge_mlp.1 / coors_mlp.1 (rigid_docking_model.py:121,154) in training mode: keep masks drawn by the
+     * caller, bit-packed [n_edges][2] uint32 in the graph's edge order (bit f of the 64-bit pair = feature f is kept),
+     * kept elements are scaled by drop_scale = 1 / (1 - p).  Both NULL = no dropout (eval mode / p = 0). */
+    const uint32_t* drop_z1; const uint32_t* drop_ch; float drop_scale;
 } EqdEdgeParams;
 /* P = h W1[:, :d_in]^T, Q = h W1[:, d_in:2 d_in]^T + b1 are node-level inputs ([n_nodes][64]). */
 int eqd_edge_message_fwd(const EqdGraph* g, const EqdEdgeParams* p, const float* P, const float* Q,

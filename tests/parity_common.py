@@ -360,6 +360,21 @@ def check_linear(dev):
     z = F.leaky_relu(torch.cat([X1, X2], 1) @ W.t() + b, 0.01)
     close(pre, z, what='pre-LN')
     close(Y, 0.75 * F.layer_norm(z, (Mo,), g, be, 1e-5) + 0.25 * R, what='linear+LN+residual')
+    # EqdLinJob.mul: dropout factors between the Linear and its LeakyReLU (applied to the activation: LeakyReLU is
+    # positively homogeneous), 69-wide (general body) and 64-wide (lean body)
+    for Mo2 in (69, 64):
+        fac = ((torch.rand(rows, Mo2) >= 0.25).float() / 0.75)
+        facd = fac.to(dev).contiguous()
+        Y2, pre2 = torch.zeros(rows, Mo2, device=dev), torch.zeros(rows, Mo2, device=dev)
+        J.M, J.mul, J.ld_mul, J.Y, J.ldy, J.pre_ln, J.ld_pre = Mo2, facd.data_ptr(), Mo2, Y2.data_ptr(), Mo2, pre2.data_ptr(), Mo2
+        J.R, J.ldr = d[6].data_ptr(), Mo
+        L.check(lib().eqd_linear(C.byref(J), 1, st(dev)))
+        sync(dev)
+        z2 = F.leaky_relu((torch.cat([X1, X2], 1) @ W[:Mo2].t() + b[:Mo2]) * fac, 0.01)
+        close(pre2, z2, what=f'pre-LN with dropout factors (M = {Mo2})')
+        close(Y2, 0.75 * F.layer_norm(z2, (Mo2,), g[:Mo2], be[:Mo2], 1e-5) + 0.25 * R[:, :Mo2],
+              what=f'linear + dropout + LN + residual (M = {Mo2})')
+    J.mul = None
     # transposed-weight / masked mode (dX = (dY * lrelu'(mask)) W)
     dY, mask = torch.randn(rows, Mo), torch.randn(rows, Mo)
     dYd, md = dY.to(dev), mask.to(dev)
@@ -463,8 +478,16 @@ def _rb(t):
     return t + (t.to(torch.bfloat16).to(torch.float32) - t).detach()
 
 
-def _edge_ref(pk, eta, Pn, Qn, x, W1cd, lng, lnb, W2, b2, Wc1, bc1, wc2, bc2, bf16=False):
-    """bf16=True: the rounding points of the kernels' bf16 mode (GEMM inputs and staged weights), fp32 accumulate"""
+def pack_keep_bits(keep):
+    """[E, 64] bool -> [E, 2] int32: bit f of the 64-bit pair = feature f kept (EqdEdgeParams.drop_z1 / drop_ch layout)"""
+    w = (2 ** torch.arange(32, dtype=torch.int64)).view(1, 1, 32)
+    return (keep.view(-1, 2, 32).to(torch.int64) * w).sum(-1).to(torch.int32).contiguous()
+
+
+def _edge_ref(pk, eta, Pn, Qn, x, W1cd, lng, lnb, W2, b2, Wc1, bc1, wc2, bc2, bf16=False, fz=None, fc=None):
+    """bf16=True: the rounding points of the kernels' bf16 mode (GEMM inputs and staged weights), fp32 accumulate.
+    fz / fc: dropout factors (0 or 1 / (1 - p)) on the outputs of edge_mlp.0 / coors_mlp.0, i.e. nn.Dropout between
+    the Linear and the LeakyReLU (rigid_docking_model.py:121, 154) in training mode."""
     rb = _rb if bf16 else (lambda t: t)
     N, E = pk.n_nodes, pk.n_edges
     src, dst = pk.src.cpu().long(), pk.dst.cpu().long()
@@ -473,18 +496,38 @@ def _edge_ref(pk, eta, Pn, Qn, x, W1cd, lng, lnb, W2, b2, Wc1, bc1, wc2, bc2, bf
     d2 = (xrel ** 2).sum(1, keepdim=True)
     rbf = torch.cat([torch.exp(-d2 / (1.5 ** k)) for k in range(15)], 1)
     z1 = Pn[src] + Qn[dst] + rb(torch.cat([he, rbf], 1)) @ rb(W1cd).t()
-    a1 = F.layer_norm(F.leaky_relu(z1, 0.01), (64,), lng, lnb, 1e-5)
+    # (dropout: LeakyReLU(f * z) = f * LeakyReLU(z) for f >= 0; written the way the kernels evaluate it, so that the
+    # bf16 mode's rounding points see bit-identical fp32 values)
+    y1 = F.leaky_relu(z1, 0.01)
+    if fz is not None:
+        y1 = y1 * fz
+    a1 = F.layer_norm(y1, (64,), lng, lnb, 1e-5)
     m = rb(a1) @ rb(W2).t() + b2
-    coef = F.leaky_relu(rb(m) @ rb(Wc1).t() + bc1, 0.01) @ wc2.t() + bc2
+    yc = F.leaky_relu(rb(m) @ rb(Wc1).t() + bc1, 0.01)
+    if fc is not None:
+        yc = yc * fc
+    coef = yc @ wc2.t() + bc2
     deg = torch.zeros(N).index_add(0, dst, torch.ones(E)).clamp(min=1)
     am = torch.zeros(N, 64).index_add(0, dst, m) / deg[:, None]
     xu = torch.zeros(N, 3).index_add(0, dst, xrel * coef) / deg[:, None]
     return am, eta * x0 + (1 - eta) * x + xu
 
 
-def check_edge(dev):
+def check_edge(dev, drop=False, bf16=False):
+    """eqd_edge_message_fwd / _bwd against torch; drop=True: with nn.Dropout masks (training mode) on both edge MLPs;
+    bf16=True (with drop): the bf16 kernels with masks, at bf16 resolution in the backward"""
     g, pk, gs, host, d, ep, ldw1, d_in = _edge_setup(dev)
     N = pk.n_nodes
+    fz = fc = None
+    if drop:
+        torch.manual_seed(17)
+        pdrop = 0.25
+        kz, kc = torch.rand(pk.n_edges, 64) >= pdrop, torch.rand(pk.n_edges, 64) >= pdrop
+        fz, fc = kz.float() / (1 - pdrop), kc.float() / (1 - pdrop)
+        bz, bc = pack_keep_bits(kz).to(dev), pack_keep_bits(kc).to(dev)
+        ep.drop_z1, ep.drop_ch, ep.drop_scale = bz.data_ptr(), bc.data_ptr(), 1.0 / (1 - pdrop)
+    ep.bf16 = int(bf16)
+    fwd_tol, l2, mx = (5e-5, 5e-3, 1e-2) if bf16 else (1e-4, 1e-4, 1e-4)
     aggr, xnew = torch.zeros(N, 64, device=dev), torch.zeros(N, 3, device=dev)
     L.check(lib().eqd_edge_message_fwd(C.byref(gs), C.byref(ep), P(d['Pn']), P(d['Qn']), P(d['x']), P(aggr), P(xnew),
                                        st(dev)))
@@ -492,9 +535,9 @@ def check_edge(dev):
     names = ('Pn', 'Qn', 'x', 'W1cd', 'lng', 'lnb', 'W2', 'b2', 'Wc1', 'bc1', 'wc2', 'bc2')
     host = dict(host, W1cd=host['W1'][:, 2 * d_in:].contiguous())
     leaves = [host[k].clone().requires_grad_(True) for k in names]
-    am, xn = _edge_ref(pk, 0.25, *leaves)
-    close(aggr, am, what='aggr_msg')
-    close(xnew, xn, what='x_new')
+    am, xn = _edge_ref(pk, 0.25, *leaves, bf16=bf16, fz=fz, fc=fc)
+    close(aggr, am, tol=fwd_tol, what='aggr_msg')
+    close(xnew, xn, tol=fwd_tol, what='x_new')
     torch.manual_seed(3)
     dag, dxn = torch.randn(N, 64), torch.randn(N, 3)
     ((am * dag).sum() + (xn * dxn).sum()).backward()
@@ -513,7 +556,7 @@ def check_edge(dev):
     got = [dP, dQ, dx, gr['W1'][:, 2 * d_in:], gr['lng'], gr['lnb'], gr['W2'], gr['b2'], gr['Wc1'], gr['bc1'],
            gr['wc2'], gr['bc2']]
     for n, a, l in zip(names, got, leaves):
-        grad_close(a, l.grad, what='edge d' + n, l2=1e-4, mx=1e-4)
+        grad_close(a, l.grad, what=('dropout ' if drop else '') + 'edge d' + n, l2=l2, mx=mx)
     assert float(gr['W1'][:, :2 * d_in].abs().max()) == 0.0
 
 
@@ -805,6 +848,78 @@ def check_model_bf16(dev, name):
     for nm, a, b in zip(('lig', 'Yl', 'Yr', 'T', 'b'), outs, ref):
         close(cat_out(a), cat_out(b), tol=BF16_OUT_TOL, what=f'{name} bf16 {nm} vs bf16 oracle')
     compare_grads(net, grads, f'{name} bf16', BF16_GRAD_L2, BF16_GRAD_MX)
+
+
+def check_dropout_training(dev):
+    """Dropout > 0 in TRAINING mode through the HIP library (masks from torch's generator in the reference's order, applied by
+    the kernels; model.DropoutMasks):
+      (a) the `dropout_train` vectors recorded from the real reference module (tests/golden/variants.npz: seeded CPU
+          generator) - masks drawn on the CPU, everything else on `dev`;
+      (b) masks drawn on `dev` (what a training run does): the HIP path equals the torch-operator restatement of the same
+          configuration (torch_path.py: the reference's nn.Dropout modules on `dev`, same seed -> same masks), outputs and
+          every parameter gradient;
+      (c) the same in bf16 mode runs and is finite; eval mode ignores dropout."""
+    import json
+    import os
+    from equidock_public_amd import config
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'variants.npz'), allow_pickle=False)
+    meta = json.loads(str(z['meta']))
+    v = meta['variants']['dropout_train']
+    args = dict(v['args'], device=torch.device(dev))
+    sd = config.seeded_state_dict(args, meta['init_seed'], meta['rot_scale'])
+    raw = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('in_')}
+    raw['lig_counts'], raw['rec_counts'] = [int(c) for c in z['in_lig_counts']], [int(c) for c in z['in_rec_counts']]
+    g = G.batch_pairs(pairs_from_raw(raw)).to(dev)
+
+    def run(force_torch=False, mask_dev=None, over=None):
+        net = build_model(dict(args, **(over or {})), sd, dev)
+        net.train(True)
+        ie = net.iegmn_original
+        ie._force_torch_path, ie.dropout_mask_device = force_torch, mask_dev
+        assert ie.uses_hip_path() == (not force_torch)
+        torch.manual_seed(meta['fwd_seed'])
+        if torch.device(dev).type == 'cuda':
+            torch.cuda.manual_seed(meta['fwd_seed'])
+        outs = net(g, epoch=0)
+        loss = port.scalar_loss(outs)
+        loss.backward()
+        sync(dev)
+        return net, outs, loss
+    # (a)
+    net, outs, loss = run(mask_dev='cpu')
+    for nm, lst in zip(('lig', 'Yl', 'Yr', 'T', 'b'), outs):
+        close(cat_out(lst), torch.from_numpy(z[f'dropout_train_{nm}']), what=f'dropout_train {nm} vs the reference')
+    assert abs(float(loss.detach()) - float(z['dropout_train_loss'])) <= 1e-4 * abs(float(z['dropout_train_loss']))
+    for k, p in net.named_parameters():
+        ref = v['grad_norms'][k]
+        got = float(p.grad.double().norm())
+        assert abs(got - ref) <= 2e-3 * ref + 1e-5, f'dropout_train: gradient norm of {k}: {got} vs {ref}'
+    # (b)
+    n_hip, o_hip, _ = run()
+    n_ref, o_ref, _ = run(force_torch=True)
+    for nm, a, b in zip(('lig', 'Yl', 'Yr', 'T', 'b'), o_hip, o_ref):
+        close(cat_out(a), cat_out(b), what=f'dropout on {dev}: HIP path vs torch operators, {nm}')
+    gr = dict(n_ref.named_parameters())
+    w2 = wm = 0.0
+    for k, p in n_hip.named_parameters():
+        e2, em = grad_err(p.grad, gr[k].grad)
+        w2, wm = max(w2, e2), max(wm, em)
+    print(f'dropout training on {dev}: HIP path vs torch operators: worst grad rel-L2 {w2:.2e}, max-abs/max {wm:.2e}')
+    # (a LeakyReLU pre-activation within rounding of 0 may take the other slope in one of the two evaluations: the bound
+    # leaves room for one such flip in this 111-node batch; typical agreement is ~3e-5)
+    assert w2 <= 5e-3 and wm <= 2e-2
+    # (c)
+    n_bf, o_bf, l_bf = run(over=dict(hip_storage_dtype='bf16'))
+    assert all(torch.isfinite(p.grad).all() for p in n_bf.parameters()) and torch.isfinite(l_bf)
+    n_hip.eval()
+    with torch.no_grad():
+        ev = n_hip(g, epoch=0)
+    n_ev = build_model(dict(args, dropout=0.0), sd, dev)
+    n_ev.eval()
+    with torch.no_grad():
+        ev0 = n_ev(g, epoch=0)
+    for a, b in zip(ev, ev0):
+        assert torch.equal(cat_out(a), cat_out(b))
 
 
 def check_flat_grads_equal_autograd(dev):

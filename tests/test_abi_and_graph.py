@@ -42,7 +42,8 @@ def test_product_refuses_cpu_tensors():
 
 def test_every_reference_config_constructs_and_routes():
     """Every option of the reference constructs (rigid_docking_model.py:10-42, 95-175, 622-627); the published family is
-    routed to the HIP library, everything else - and dropout > 0 while training - to the torch-operator path; 212 state_dict
+    routed to the HIP library - in training mode too, with or without dropout (round 3) -, everything else to the
+    torch-operator path; 212 state_dict
     keys with the fine-tune stage; unknown option values raise."""
     from equidock_public_amd import model as M
     from oracle import iegmn_port as port
@@ -53,7 +54,7 @@ def test_every_reference_config_constructs_and_routes():
         net = M.Rigid_Body_Docking_Net(port.default_args(**over))
         assert net.iegmn_original.uses_hip_path() == hip, over
     net = M.Rigid_Body_Docking_Net(port.default_args(dropout=0.25))
-    assert not net.iegmn_original.uses_hip_path()          # training mode: torch's dropout masks
+    assert net.training and net.iegmn_original.uses_hip_path()      # training mode: the kernels apply torch-drawn masks
     net.eval()
     assert net.iegmn_original.uses_hip_path()              # inference: dropout is the identity
     ft = M.Rigid_Body_Docking_Net(port.default_args(fine_tune=True))

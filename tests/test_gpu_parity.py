@@ -37,6 +37,18 @@ def test_edge_message_bf16(dev):
     pc.check_edge_bf16(dev)
 
 
+def test_edge_message_with_dropout_masks(dev):
+    from tests import parity_common as pc
+    pc.check_edge(dev, drop=True)
+    pc.check_edge(dev, drop=True, bf16=True)
+
+
+def test_dropout_training_through_the_kernels(dev):
+    """dropout > 0 while training: HIP path vs the reference's recorded vectors and vs the torch-operator restatement"""
+    from tests import parity_common as pc
+    pc.check_dropout_training(dev)
+
+
 @pytest.mark.parametrize('d', [64, 69, 80])
 def test_cross_attention(dev, d):
     from tests import parity_common as pc

@@ -37,6 +37,15 @@ def test_edge_message_bf16():
     pc.check_edge_bf16(DEV)
 
 
+def test_edge_message_with_dropout_masks():
+    pc.check_edge(DEV, drop=True)
+    pc.check_edge(DEV, drop=True, bf16=True)
+
+
+def test_dropout_training_through_the_kernels():
+    pc.check_dropout_training(DEV)
+
+
 @pytest.mark.parametrize('d', [64, 69, 80])
 def test_cross_attention(d):
     pc.check_attention(DEV, d)
