@@ -564,7 +564,7 @@ extern "C" int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const
 
 extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, const float* const* params,
                                   const EqdDropout* drop, const float* d_lig, const float* d_Ylig, const float* d_Yrec, const float* d_T,
-                                  const float* d_b, float* grad_flat, const int64_t* grad_offsets, const void* saved,
+                                  const float* d_b, const float* d_h_last, const float* d_x_last, float* grad_flat, const int64_t* grad_offsets, const void* saved,
                                   size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream, void* ctx) {
     RC(eqd_model_check(m, g));
     if (!params || !grad_flat || !grad_offsets || !saved || !scratch) {
@@ -607,6 +607,8 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
     float* dXcur = W.dXa;   // grad wrt x[L]
     float* dXnext = W.dXb;
     RC(eqd_launch_keypoint_bwd(g, K, H, Z, S.scores, S.klse, S.u, W.dY, W.dscores, W.du, W.dHk, dXcur, st));
+    if (d_h_last) RC(eqd_launch_axpy(W.dHk, d_h_last, 1.f, (size_t)N * 64, st));      // a loss on the last layer's node data
+    if (d_x_last) RC(eqd_launch_axpy(dXcur, d_x_last, 1.f, (size_t)N * 3, st));
     RC(eqd_launch_head_u_bwd(g, K, gpar[G_WK], gpar[G_WQ], S.qmean, S.qp, W.du, ggrad[G_WK], ggrad[G_WQ], W.dqm_part,
                              st, W.head_part, defer));
     RC(eqd_launch_qmean_bwd(g, K, W.dqm_part, W.dhm, st));

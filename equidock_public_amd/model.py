@@ -342,7 +342,7 @@ class _IEGMNFunction(torch.autograd.Function):
             _lib.check(lib.eqd_model_backward(
                 C.byref(desc), C.byref(gs), ptrs, None if dstruct is None else C.byref(dstruct),
                 _lib.ptr(d_lig), _lib.ptr(d_Yl), _lib.ptr(d_Yr), _lib.ptr(d_T),
-                _lib.ptr(d_b), _lib.ptr(flat), goffs, _lib.ptr(ctx.saved), C.c_size_t(ctx.sb), _lib.ptr(scratch),
+                _lib.ptr(d_b), None, None, _lib.ptr(flat), goffs, _lib.ptr(ctx.saved), C.c_size_t(ctx.sb), _lib.ptr(scratch),
                 C.c_size_t(ctx.wb), _lib.stream_ptr(dev), _lib.exec_ctx(dev)))
         if ctx.flat_state is not None:
             return (None,) * 9
@@ -585,6 +585,41 @@ class IEGMN(nn.Module):
         else:
             x = f[(xp.value - base) // 4:(xp.value - base) // 4 + n * 3].view(n, 3).clone()
         return h, x
+
+    def stack_backward(self, batch_hetero_graph, d_h_last, d_x_last):
+        """Backward of the IEGMN layer stack alone, from a given gradient w.r.t. the state after the last layer (d_h_last
+        [n_nodes, 64], d_x_last [n_nodes, 3]; ligand nodes first): {parameter name: gradient} of
+        sum(h_L * d_h_last) + sum(x_L * d_x_last) for the LAST forward of this batch that kept its state.  The keypoint /
+        Kabsch head receives zero output gradients and contributes nothing.  A test aid (eqd_model_backward's d_h_last /
+        d_x_last): in bf16 mode the head amplifies rounding flips erratically, the stack does not."""
+        packed = batch_hetero_graph.pack()
+        last = getattr(packed, '_last_saved', None)
+        if last is None:
+            raise _lib.EquidockHipError("no saved forward state for this batch (run a forward with gradients enabled)")
+        saved, sb, drop = last
+        lib = _lib.load_library()
+        desc, gs = self._desc(), packed.c_struct()
+        uniq, table_idx = self._param_table()
+        dev = packed.x0.device
+        ptrs = (C.c_void_p * len(table_idx))(*[uniq[i].data_ptr() for i in table_idx])
+        offs, total = flat_layout(uniq)
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        goffs = (C.c_int64 * len(table_idx))(*[offs[i] for i in table_idx])
+        with _lib.device_guard(dev):
+            wb = lib.eqd_model_scratch_bytes(C.byref(desc), C.byref(gs))
+        scratch = torch.empty(wb, dtype=torch.uint8, device=dev)
+        dh = _lib.require_device(d_h_last.to(torch.float32).contiguous(), 'd_h_last')
+        dx = _lib.require_device(d_x_last.to(torch.float32).contiguous(), 'd_x_last')
+        if tuple(dh.shape) != (packed.n_nodes, 64) or tuple(dx.shape) != (packed.n_nodes, 3):
+            raise _lib.EquidockHipError("stack_backward: d_h_last must be [n_nodes, 64] and d_x_last [n_nodes, 3]")
+        dstruct = None if drop is None else drop.c_struct()
+        with _lib.device_guard(dev):
+            _lib.check(lib.eqd_model_backward(
+                C.byref(desc), C.byref(gs), ptrs, None if dstruct is None else C.byref(dstruct), None, None, None, None,
+                None, _lib.ptr(dh), _lib.ptr(dx), _lib.ptr(flat), goffs, _lib.ptr(saved), C.c_size_t(sb),
+                _lib.ptr(scratch), C.c_size_t(wb), _lib.stream_ptr(dev), _lib.exec_ctx(dev)))
+        names = {id(p): k for k, p in self.named_parameters()}
+        return {names[id(p)]: flat[o:o + p.numel()].view(p.shape).clone() for p, o in zip(uniq, offs)}
 
     def lrelu_signs(self, batch_hetero_graph):
         """The LeakyReLU branch decisions (uint8, 1 = pre-activation > 0) of the LAST forward of this batch that kept its

@@ -184,12 +184,15 @@ int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const float* con
                       void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream, void* ctx);
 
 /* Backward of the above (the autograd the reference gets from loss.backward(), src/train.py:154).
- * d_* are gradients w.r.t. the five outputs (any may be NULL = zero).  Parameter gradients are
+ * d_* are gradients w.r.t. the five outputs (any may be NULL = zero).  d_h_last [n_nodes][64] / d_x_last [n_nodes][3]
+ * (usually NULL) are ADDED to the gradient w.r.t. the state after the last IEGMN layer (what the reference keeps as
+ * 'hv_iegmn_out' / 'x_iegmn_out', rigid_docking_model.py:507-510): a loss on those node data, and the tests' way of
+ * driving the backward of the layer stack with a fixed gradient, without the keypoint / Kabsch head.  Parameter gradients are
  * ACCUMULATED into grad_flat at grad_offsets[i] (in floats, same order as the parameter table;
  * shared entries share offsets); the caller zeroes grad_flat. */
 int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, const float* const* params, const EqdDropout* drop,
                        const float* d_lig, const float* d_Ylig, const float* d_Yrec, const float* d_T,
-                       const float* d_b,
+                       const float* d_b, const float* d_h_last, const float* d_x_last,
                        float* grad_flat, const int64_t* grad_offsets,
                        const void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream,
                        void* ctx);

@@ -289,6 +289,20 @@ def test_model_vs_oracle_config_c_bf16(dev):
     pc.check_model_bf16_states(dev, [(300, 300)] * 64, layers=8, seed=3, pair_seed=34, what='config C bf16', report=REPORT)
 
 
+def test_stack_backward_config_c_bf16(dev):
+    """BASELINE.json configs[2] as stated (bf16, 64 x (300, 300), 8 layers, ROT scale 40 like the bench): the backward of the
+    layer stack from a fixed gradient w.r.t. the last layer's state - every layer parameter's gradient against the oracle
+    with the bf16 mode's rounding points and the library's LeakyReLU decisions (parity_common.check_stack_backward)."""
+    from tests import parity_common as pc
+    pc.check_stack_backward(dev, [(300, 300)] * 64, layers=8, seed=3, pair_seed=34, bf16=True, what='config C bf16', report=REPORT)
+
+
+def test_stack_backward_config_b_fp32(dev):
+    from tests import parity_common as pc
+    pc.check_stack_backward(dev, [(200, 200)] * 8, layers=8, seed=3, pair_seed=33, faithful=True, what='config B fp32',
+                            report=REPORT)
+
+
 def test_model_vs_oracle_config_e(dev):
     """BASELINE.json configs[4] at its real workload: 4 x (2000, 2000), 8 layers, fp32, vs the oracle (block-diagonal
     mode: four 2000 x 2000 attention blocks per direction on the host)."""

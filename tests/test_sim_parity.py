@@ -178,6 +178,12 @@ def test_linear_atb_bf16():
     pc.check_linear_atb_bf16(DEV)
 
 
+def test_stack_backward_fp32_and_bf16():
+    """backward of the layer stack from a fixed d(h_L, x_L): every layer parameter's gradient vs the oracle, plain"""
+    pc.check_stack_backward(DEV, [(60, 75), (90, 48)], layers=4, seed=5, pair_seed=7, faithful=True, what='sim fp32')
+    pc.check_stack_backward(DEV, [(60, 75), (90, 48)], layers=4, seed=5, pair_seed=7, faithful=True, bf16=True, what='sim bf16')
+
+
 def test_model_bf16_layer_states():
     pc.check_model_bf16_states(DEV, [(60, 75), (90, 48), (120, 100)], layers=4, seed=5, pair_seed=7, faithful=True, what='sim')
 
