@@ -543,6 +543,7 @@ __device__ __forceinline__ void edge_tile_forward_bf(const EqdGraph& G, const Eq
                                                      f32x4 (&xh)[4][NB], f32x4 (&m)[4][NB], f32x4 (&ch)[4][NB]) {
     const int l15 = lane & 15, g = lane >> 4;
     unsigned short* __restrict__ ft = (unsigned short*)tile;
+    EQD_TR(2);
     // ---- he rows: 64 B per edge, four 16-byte parts; lane -> (edge, part), all loads up front, unpredicated ------
     f32x4 hv[NB];
 #pragma unroll
@@ -574,6 +575,7 @@ __device__ __forceinline__ void edge_tile_forward_bf(const EqdGraph& G, const Eq
         }
     }
     // ---- feature tile [16 NB][48] bf16: he (27) | rbf (15) | 0 (6) -------------------------------------------------
+    EQD_TR(3);
     {
         const f32x4 z = f4zero();
         if (lane < 32 * NB) *(f32x4*)&ft[(lane >> 1) * FSB + 32 + 8 * (lane & 1)] = z;      // columns 32..47
@@ -602,6 +604,7 @@ __device__ __forceinline__ void edge_tile_forward_bf(const EqdGraph& G, const Eq
         }
     }
     wave_lds_fence();
+    EQD_TR(4);
     // ---- stage 1: z1 = P[src] + Q[dst] (fp32) + W1cd feat (3 k-chunks of 16) ------------------------------------------
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
@@ -613,6 +616,7 @@ __device__ __forceinline__ void edge_tile_forward_bf(const EqdGraph& G, const Eq
             a[2] = S.ev[nb] ? p.z + q.z : 0.f; a[3] = S.ev[nb] ? p.w + q.w : 0.f;
             xh[mb][nb] = a;
         }
+    EQD_TR(5);
 #pragma unroll
     for (int kc = 0; kc < 3; ++kc) {
         s16x4 b[NB];
@@ -625,6 +629,7 @@ __device__ __forceinline__ void edge_tile_forward_bf(const EqdGraph& G, const Eq
             for (int nb = 0; nb < NB; ++nb) xh[mb][nb] = mfma_bf(a, b[nb], xh[mb][nb]);
         }
     }
+    EQD_TR(6);
     // ---- LeakyReLU + LayerNorm statistics (fp32, two-pass like torch) ------------------------------------------------
     S.zpos = 0u;
     if constexpr (DROP) drop_load<NB>(P, S, l15, g);
@@ -659,6 +664,7 @@ __device__ __forceinline__ void edge_tile_forward_bf(const EqdGraph& G, const Eq
         S.mean[nb] = mean;
         S.rstd[nb] = rstd;
     }
+    EQD_TR(7);
     // ---- stage 2: m = W2 bf16(xh * gamma + beta) + b2;  stage 3: ch = Wc1 bf16(m) + bc1 -----------------------------
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
@@ -672,6 +678,7 @@ __device__ __forceinline__ void edge_tile_forward_bf(const EqdGraph& G, const Eq
         }
     }
     chain64_bf<true, NB>(m, xh, w2, &vec[VEC_LNG], &vec[VEC_LNB], l15, g);
+    EQD_TR(8);
     chain64_bf<false, NB>(ch, m, wc1, nullptr, nullptr, l15, g);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
@@ -692,6 +699,7 @@ __device__ __forceinline__ void edge_tile_forward_bf(const EqdGraph& G, const Eq
         }
         S.coef[nb] = group_sum(s) + vec[VEC_BC2];
     }
+    EQD_TR(9);
 }
 
 // store an F-layout tile to HBM as [edge][64]

@@ -107,5 +107,74 @@ def main():
     print('written', os.path.getsize(os.path.join(ROOT, 'tests', 'golden', 'graph_case.npz')), 'bytes')
 
 
+# Round 3: three more complexes of the reference's DB5.5 copy, each through the reference's own
+# function as above.  To keep the fixtures small the edge features are stored for every `he_stride`-th edge only (the
+# int32 endpoints - the "bit-exact graph indexing" claim - are complete), and the partner protein that is not the point of
+# the case is cut short.  The reference call is timed: that is the CPU baseline of the graph-construction row.
+EXTRA = {
+    # name: (pdb id, ligand residue cut, receptor residue cut, he stride, what the case pins)
+    'big': ('1DE4', None, 40, 8, '1 270-residue ligand (the >= 1 000-residue regime: argsort over 1 269 candidates per row)'),
+    'pair300': ('2J7P', None, None, 4, 'a DIPS-sized pair, 271 + 298 residues'),
+    'tiny': ('1PPE', 8, 30, 1, 'fewer residues than max_neighbor: every row keeps all its candidates in np.where order'),
+}
+
+
+def main_extra():
+    import time
+    ns = reference_functions()
+    lines = []
+    for name, (pid, lcut, rcut, stride, what) in EXTRA.items():
+        pdb = '/root/reference/data/benchmark5.5/structures/' + pid + '_%s_b.pdb'
+        lig_all, rec_all = F.read_pdb_residues(pdb % 'l'), F.read_pdb_residues(pdb % 'r')
+        lig_all = lig_all[:lcut] if lcut else lig_all
+        rec_all = rec_all[:rcut] if rcut else rec_all
+        lig_f, rec_f, lig_ca, rec_ca = ns['preprocess_unbound_bound'](as_groups(lig_all), as_groups(rec_all), 'residues',
+                                                                      pos_cutoff=8.0, inference=True)
+        t0 = time.perf_counter()
+        gl, gr = ns['protein_to_graph_unbound_bound_residuesonly'](lig_f, rec_f, lig_ca, rec_ca, cutoff=CUTOFF,
+                                                                   max_neighbor=MAX_NEIGHBOR, one_hot=False,
+                                                                   residue_loc_is_alphaC=True)
+        dt = time.perf_counter() - t0
+        p = F.preprocess_unbound_bound(lig_all, rec_all, inference=True)
+        assert len(p[0]) == len(lig_f) and len(p[1]) == len(rec_f)
+        assert np.array_equal(p[2], lig_ca) and np.array_equal(p[3], rec_ca)
+        out = {'cutoff': CUTOFF, 'max_neighbor': MAX_NEIGHBOR, 'he_stride': stride, 'lig_ca': lig_ca.astype(np.float32),
+               'rec_ca': rec_ca.astype(np.float32), 'what': what, 'pdb': pid, 'reference_seconds': dt}
+        pack_residues(lig_all, 'lig_in_', out)
+        pack_residues(rec_all, 'rec_in_', out)
+        for nm, g in (('lig', gl), ('rec', gr)):
+            s, d = g.edges()
+            out[nm + '_src'], out[nm + '_dst'] = s.numpy().astype(np.int32), d.numpy().astype(np.int32)
+            out[nm + '_he'] = g.edata['he'].numpy()[::stride].copy()
+            out[nm + '_x'] = g.ndata['x'].numpy()
+            out[nm + '_mu'] = g.ndata['mu_r_norm'].numpy()
+            out[nm + '_res'] = g.ndata['res_feat'].numpy()
+        path = os.path.join(ROOT, 'tests', 'golden', f'graph_case_{name}.npz')
+        np.savez_compressed(path, **out)
+        line = (f'{name}: {pid} ligand {gl.num_nodes()} residues / {gl.num_edges()} edges, receptor {gr.num_nodes()} / '
+                f'{gr.num_edges()}; reference protein_to_graph_unbound_bound_residuesonly (this container, 1 thread): '
+                f'{dt:.2f} s; fixture {os.path.getsize(path)} bytes')
+        print(line)
+        lines.append(line)
+    # reference timing alone at the sizes of the measurement table (no fixture): 200 / 1 000 / 2 000-residue proteins
+    for pid, side, cut in (('1N2C', 'r', 200), ('1N2C', 'r', 1000), ('1N2C', 'r', 2000)):
+        pdb = '/root/reference/data/benchmark5.5/structures/' + pid + '_%s_b.pdb'
+        big = F.read_pdb_residues(pdb % side)[:cut]
+        small = F.read_pdb_residues(pdb % 'l')[:20]
+        a, b, a_ca, b_ca = ns['preprocess_unbound_bound'](as_groups(big), as_groups(small), 'residues', pos_cutoff=8.0, inference=True)
+        t0 = time.perf_counter()
+        ns['protein_to_graph_unbound_bound_residuesonly'](a, b, a_ca, b_ca, cutoff=CUTOFF, max_neighbor=MAX_NEIGHBOR,
+                                                          one_hot=False, residue_loc_is_alphaC=True)
+        line = (f'reference graph construction, {len(a)} + {len(b)} residues ({pid}): {time.perf_counter() - t0:.2f} s '
+                f'(this container, 1 thread)')
+        print(line)
+        lines.append(line)
+    with open(os.path.join(ROOT, 'profiles', 'r03_graph_reference_cpu.txt'), 'w') as f:
+        f.write('\n'.join(lines) + '\n')
+
+
 if __name__ == '__main__':
-    main()
+    if '--extra' in sys.argv:
+        main_extra()
+    else:
+        main()

@@ -1,5 +1,6 @@
-"""Latency experiment: phase timestamps inside k_edge_fwd / k_edge_bwd on the workload-B graph.  Needs the
--DEQD_TRACE library (python profiles/exp_trace_linear.py --build).  usage (GPU box): python profiles/exp_trace_edge.py"""
+"""Latency experiment: phase timestamps inside k_edge_fwd / k_edge_bwd on the workload-B graph (or `--workload C`: 64 x
+(300, 300); `--bf16`: the bf16 kernels).  Needs the -DEQD_TRACE library (python profiles/exp_trace_linear.py --build).
+usage (GPU box): python profiles/exp_trace_edge.py [--workload C] [--bf16]"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -19,7 +20,8 @@ del BWD[10], BWD[11]
 if __name__ == '__main__':
     lib = L.load_library_for_testing(OUT)
     dev = torch.device('cuda:0')
-    g = graph.batch_pairs(synthetic.make_pairs([(200, 200)] * 8, 1000)).to(dev)
+    sizes = [(300, 300)] * 64 if 'C' in sys.argv else [(200, 200)] * 8
+    g = graph.batch_pairs(synthetic.make_pairs(sizes, 1000)).to(dev)
     packed = g.pack()
     gs = L.graph_struct(packed)
     N, E = packed.n_nodes, packed.n_edges
@@ -33,6 +35,7 @@ if __name__ == '__main__':
     ep.ln_g, ep.ln_b, ep.W2, ep.b2 = vecs[0].data_ptr(), vecs[1].data_ptr(), W2.data_ptr(), vecs[2].data_ptr()
     ep.Wc1, ep.bc1, ep.wc2, ep.bc2 = Wc1.data_ptr(), vecs[3].data_ptr(), vecs[4].data_ptr(), bc2.data_ptr()
     ep.slope, ep.ln_eps, ep.eta, ep.use_dist, ep.use_he = 0.01, 1e-5, 0.0, 1, 1
+    ep.bf16 = int('--bf16' in sys.argv)
     P, Q = torch.randn(N, 64, **f), torch.randn(N, 64, **f)
     x = packed.x0.clone()
     aggr, xnew = torch.empty(N, 64, **f), torch.empty(N, 3, **f)

@@ -1321,6 +1321,33 @@ def check_protein_graph(dev):
     assert outs[0][0].shape == (len(lig), 3) and torch.isfinite(outs[0][0]).all()
 
 
+def check_protein_graph_case(dev, name):
+    """More complexes of the reference's DB5.5 copy through its own protein_to_graph_unbound_bound_residuesonly
+    (tests/golden/graph_case_<name>.npz, `oracle/make_golden_graph.py --extra`): 'big' = a 1 270-residue protein, 'pair300' = a
+    DIPS-sized pair, 'tiny' = fewer residues than max_neighbor.  int32 endpoints bit-exact and complete; the edge features
+    were recorded for every he_stride-th edge."""
+    import os
+    from equidock_public_amd import featurize as FZ
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', f'graph_case_{name}.npz'))
+    lig_all, rec_all = _residues_from_fixture(z, 'lig_in_'), _residues_from_fixture(z, 'rec_in_')
+    lig, rec, lig_ca, rec_ca = FZ.preprocess_unbound_bound(lig_all, rec_all, inference=True)
+    assert np.array_equal(lig_ca, z['lig_ca']) and np.array_equal(rec_ca, z['rec_ca'])
+    gl, gr = FZ.protein_to_graph_unbound_bound(lig, rec, lig_ca, rec_ca, cutoff=float(z['cutoff']),
+                                               max_neighbor=int(z['max_neighbor']), device=dev)
+    sync(dev)
+    stride = int(z['he_stride'])
+    for nm, g in (('lig', gl), ('rec', gr)):
+        assert np.array_equal(g['src'].cpu().numpy(), z[nm + '_src']), f'{name} {nm}: source indices differ from the reference'
+        assert np.array_equal(g['dst'].cpu().numpy(), z[nm + '_dst']), f'{name} {nm}: destination indices differ'
+        assert np.array_equal(g['res_feat'].cpu().numpy(), z[nm + '_res'])
+        close(g['he'][::stride], torch.from_numpy(z[nm + '_he']), tol=1e-6, what=f'{name} {nm} edge features')
+        close(g['x'], torch.from_numpy(z[nm + '_x']), tol=1e-6, what=f'{name} {nm} x')
+        close(g['mu_r_norm'], torch.from_numpy(z[nm + '_mu']), tol=1e-6, what=f'{name} {nm} mu_r_norm')
+    if name == 'tiny':
+        n = len(lig)
+        assert n < int(z['max_neighbor']) and int(gl['src'].numel()) == n * (n - 1)
+
+
 def check_inference_postprocessing(dev):
     """Clash removal on the device (equidock_public_amd.inference.remove_clashes -> eqd_clash_iterations), get_rot_mat,
     apply_rigid and the RMSD meter against vectors recorded from the reference's own functions

@@ -200,6 +200,14 @@ def test_protein_graph_vs_reference_golden(dev):
     pc.check_protein_graph(dev)
 
 
+@pytest.mark.parametrize('name', ['tiny', 'pair300', 'big'])
+def test_protein_graph_more_reference_complexes(dev, name):
+    """graph construction on three more DB5.5 complexes (a 1 270-residue protein, a DIPS-sized pair, fewer residues than
+    max_neighbor) against the reference's own function: bit-exact int32 endpoints"""
+    from tests import parity_common as pc
+    pc.check_protein_graph_case(dev, name)
+
+
 def test_inference_postprocessing(dev):
     from tests import parity_common as pc
     pc.check_inference_postprocessing(dev)

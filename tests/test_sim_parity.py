@@ -161,6 +161,11 @@ def test_protein_graph_vs_reference_golden():
     pc.check_protein_graph(DEV)
 
 
+@pytest.mark.parametrize('name', ['tiny', 'pair300'])
+def test_protein_graph_more_reference_complexes(name):
+    pc.check_protein_graph_case(DEV, name)
+
+
 def test_inference_postprocessing():
     pc.check_inference_postprocessing(DEV)
 
