@@ -23,6 +23,9 @@
 // (row stride 16*DB + 4 floats); MFMA operands are read from LDS.  One HBM/L2 round trip per tile.
 #include "eqd_common.h"
 #include "eqd_attn_fwd_inl.h"
+#include "eqd_attn_lb_inl.h"
+
+#include <stdlib.h>
 
 // backward pass 1: dq for the block's queries; also writes delta[q] = sum_f dO[q][f] O[q][f]
 // LDS of the backward passes: 2 block tiles + 2 x EQD_WAVES streamed tiles + the merge buffer + 32 floats per wave
@@ -517,6 +520,13 @@ extern "C" int eqd_cross_attention_bwd(const EqdGraph* g, int d, const float* q,
     return attn_launch_bwd<5, false, 2>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
 }
 
+// bf16 mode, d = 64: the streamed tiles live in LDS as bf16 (eqd_attn_lb_inl.h) unless EQD_ATT_LB=0 (the first bf16 version:
+// fp32 tiles in LDS, rounded per MFMA operand; kept for the 80-wide first layer, tests and A/B measurements)
+static bool att_lds_bf16() {
+    const char* f = getenv("EQD_ATT_LB");
+    return !(f && f[0] == '0' && f[1] == 0);
+}
+
 // ---- bf16 mode: the four contractions of the forward (Q K^T, P V) and the ten of the backward run on
 // v_mfma_f32_16x16x16_bf16 - inputs rounded to bf16 when the MFMA operands are formed, fp32 accumulate; logits, softmax
 // statistics, exponentials, delta and all outputs stay fp32.  Float4 tile path only (d = 64, or 80 = the zero-padded
@@ -534,6 +544,13 @@ extern "C" int eqd_cross_attention_fwd_bf16(const EqdGraph* g, int d, const floa
     if (g->n_att_items <= 0) return EQD_OK;
     hipStream_t st = (hipStream_t)stream;
     const bool half = att_half_blocks(g);
+    if (d == 64 && att_lds_bf16()) {      // streamed tiles held in LDS as bf16 (eqd_attn_lb_inl.h)
+        if (half)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_fwd_lb<1>), dim3(2 * g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, q, k, v, out, lse);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_fwd_lb<2>), dim3(g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, q, k, v, out, lse);
+        return eqd_check_launch("k_attn_fwd");
+    }
     if (d == 64)
         return half ? attn_launch_fwd<4, true, 1, true>(g, d, q, k, v, out, lse, st)
                     : attn_launch_fwd<4, true, 2, true>(g, d, q, k, v, out, lse, st);
@@ -553,6 +570,16 @@ extern "C" int eqd_cross_attention_bwd_bf16(const EqdGraph* g, int d, const floa
     }
     if (g->n_att_items <= 0) return EQD_OK;
     hipStream_t st = (hipStream_t)stream;
+    if (d == 64 && att_lds_bf16()) {      // streamed tiles held in LDS as bf16 (eqd_attn_lb_inl.h)
+        const char* nb2 = getenv("EQD_ATT_LB_NB");      // experiments: 2 = 32-row blocks in the backward
+        if (g->n_att_items % 8 == 0 && !(nb2 && nb2[0] == '2'))
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_lb<1>), dim3(4 * g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, q, k, v, out,
+                               lse, d_out, dq, dk, dv, delta);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_lb<2>), dim3(2 * g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, q, k, v, out,
+                               lse, d_out, dq, dk, dv, delta);
+        return eqd_check_launch("k_attn_bwd");
+    }
     if (d == 64 && g->n_att_items % 8 == 0) return attn_launch_bwd_bf<4, 1>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
     if (d == 64) return attn_launch_bwd_bf<4, 2>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
     return attn_launch_bwd_bf<5, 2>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);

@@ -225,6 +225,18 @@ def test_cross_attention_bf16(dev, d):
     pc.check_attention_bf16(dev, d, sizes=((300, 257), (129, 64)))
 
 
+@pytest.mark.parametrize('env', [dict(EQD_ATT_LB='0'), dict(EQD_ATT_SPLIT='0'), dict(EQD_ATT_SPLIT='1'),
+                                 dict(EQD_ATT_LB_NB='2', EQD_ATT_SPLIT='0')], ids=str)
+def test_cross_attention_bf16_kernel_forms(dev, env, monkeypatch):
+    """bf16 attention, d = 64: tiles held in LDS as bf16 (default; 16- and 32-row blocks, forward and backward) and the first
+    version with fp32 tiles in LDS (EQD_ATT_LB=0) - same rounding points, same tolerance"""
+    from tests import parity_common as pc
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    pc.check_attention_bf16(dev, 64)
+    pc.check_attention_bf16(dev, 64, sizes=((300, 257), (129, 64)))
+
+
 def test_linear_atb_bf16(dev):
     from tests import parity_common as pc
     pc.check_linear_atb_bf16(dev)
