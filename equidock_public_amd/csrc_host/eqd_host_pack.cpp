@@ -145,21 +145,52 @@ int eqd_host_pack(const EqdHostPackIn* in, EqdHostPackOut* out) {
             for (int32_t s0 = quad[q][0]; s0 < quad[q][1]; s0 += in->att_block)
                 items.push_back(Item{{s0, std::min<int32_t>(s0 + in->att_block, quad[q][1]), quad[q][2], quad[q][3]}});
     }
-    std::stable_sort(items.begin(), items.end(),
-                     [](const Item& a, const Item& b) { return (a.v[3] - a.v[2]) > (b.v[3] - b.v[2]); });
-    // XCD-aware order (graph.py: _xcd_interleave): 8 queues of equal cost, slot 8 k + c = k-th item of queue c, so the
-    // blocks that stream the same partner rows share one XCD's L2 (workgroup b runs on XCD b % 8)
+    // XCD-aware order (graph.py: _xcd_interleave, same algorithm bit for bit): the groups (blocks of one (pair, direction),
+    // consecutive in `items`) sorted by decreasing partner size and dealt in snake order into 8 lists, the lists
+    // concatenated and cut into 8 queues of equal cost, each queue with its biggest partners first; slot 8 k + c = k-th
+    // item of queue c, so the blocks that stream the same partner rows share one XCD's L2 (workgroup b runs on XCD b % 8)
     constexpr int XCD = 8;
+    {
+        struct Group { size_t first, count; int32_t partner; };
+        std::vector<Group> groups;
+        for (size_t i = 0; i < items.size(); ++i) {
+            if (groups.empty() || items[i].v[2] != items[groups.back().first].v[2] || items[i].v[3] != items[groups.back().first].v[3])
+                groups.push_back(Group{i, 0, items[i].v[3] - items[i].v[2]});
+            ++groups.back().count;
+        }
+        std::stable_sort(groups.begin(), groups.end(), [](const Group& a, const Group& b) { return a.partner > b.partner; });
+        std::vector<std::vector<size_t>> lists(XCD);
+        for (size_t i = 0; i < groups.size(); ++i) {
+            const size_t r = i % (2 * XCD);
+            lists[r < (size_t)XCD ? r : 2 * XCD - 1 - r].push_back(i);
+        }
+        std::vector<Item> seq;
+        seq.reserve(items.size());
+        for (const auto& lst : lists)
+            for (size_t gi : lst)
+                for (size_t k = 0; k < groups[gi].count; ++k) seq.push_back(items[groups[gi].first + k]);
+        items.swap(seq);
+    }
     int64_t total = 0;
     for (const Item& it : items) total += it.v[3] - it.v[2];
     std::vector<int32_t> qlen(XCD, 0), slot(items.size());
     {
+        std::vector<std::vector<Item>> queues(XCD);
         int c = 0;
         int64_t acc = 0;
         for (size_t i = 0; i < items.size(); ++i) {
-            slot[i] = XCD * qlen[c]++ + c;
+            queues[c].push_back(items[i]);
             acc += items[i].v[3] - items[i].v[2];
             if (c < XCD - 1 && acc * XCD >= total * (c + 1)) ++c;
+        }
+        size_t i = 0;
+        for (int q = 0; q < XCD; ++q) {
+            std::stable_sort(queues[q].begin(), queues[q].end(),
+                             [](const Item& a, const Item& b) { return (a.v[3] - a.v[2]) > (b.v[3] - b.v[2]); });
+            for (const Item& it : queues[q]) {
+                items[i] = it;
+                slot[i++] = XCD * qlen[q]++ + q;
+            }
         }
     }
     const int32_t depth = *std::max_element(qlen.begin(), qlen.end());

@@ -500,10 +500,28 @@ def _xcd_interleave(items):
     shared by all of that direction's items.  Workgroup b lands on XCD b % 8 (observed dispatch rule, a speed matter only),
     so the list is laid out as 8 interleaved queues, slot 8 k + c = k-th item of queue c: the partner rows are then fetched
     from HBM into ONE L2 instead of up to eight (measured 5.7-6.3 x the algorithmic bytes before, profiles/r02_z_traffic).
-    Queues are filled in order of decreasing partner size (cost ~ block x partner) to equal COST, a unit spilling into
-    the next queue where it must, and padded with empty items (0, 0, 0, 0) to equal length.  The native packer
-    (csrc_host/eqd_host_pack.cpp) does the same in integers, bit for bit."""
-    items = sorted(items, key=lambda it: -(it[3] - it[2]))      # stable
+    The GROUPS (all blocks of one (pair, direction): same partner range) are sorted by decreasing partner size and dealt
+    into 8 lists in snake order (0..7, 7..0, ...), so that every list holds big and small partners alike; the lists are
+    concatenated and cut into 8 queues of equal COST (cost ~ block x partner rows; a group spills into the next queue
+    where it must - one pair still spreads over all XCDs), each queue then runs its biggest partners first, and the
+    queues are padded with empty items (0, 0, 0, 0) to equal length.  (Round 2 cut the size-sorted list directly: with
+    ragged sizes one XCD then got only the biggest partners - few long work items, the last round of its 64 workgroup
+    slots mostly idle - and another only the smallest; 77 % -> 93 % of the ideal makespan for the DB5.5 size
+    distribution in a slot model, profiles/r03_attention_schedule.txt.  Uniform batches are unchanged.)  The native
+    packer (csrc_host/eqd_host_pack.cpp) does the same in integers, bit for bit."""
+    groups, order = {}, []
+    for it in items:
+        key = (it[2], it[3])
+        if key not in groups:
+            groups[key] = []
+            order.append(key)
+        groups[key].append(it)
+    order = sorted(order, key=lambda k: -(k[1] - k[0]))      # stable
+    lists = [[] for _ in range(XCD_CLASSES)]
+    for i, key in enumerate(order):
+        r = i % (2 * XCD_CLASSES)
+        lists[r if r < XCD_CLASSES else 2 * XCD_CLASSES - 1 - r].append(key)
+    items = [it for lst in lists for key in lst for it in groups[key]]
     total = sum(it[3] - it[2] for it in items)
     queues = [[] for _ in range(XCD_CLASSES)]
     c, acc = 0, 0
@@ -512,6 +530,7 @@ def _xcd_interleave(items):
         acc += it[3] - it[2]
         if c < XCD_CLASSES - 1 and acc * XCD_CLASSES >= total * (c + 1):
             c += 1
+    queues = [sorted(q, key=lambda it: -(it[3] - it[2])) for q in queues]      # stable: biggest partner first
     depth = max(len(q) for q in queues) if items else 0
     out = np.zeros((depth * XCD_CLASSES, 4), dtype=np.int32)
     for c, q in enumerate(queues):
