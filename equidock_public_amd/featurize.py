@@ -122,26 +122,38 @@ def rigid_transform_kabsch_3d(A, B):
 
 def local_frames(residues, residue_loc_is_alphaC=True):
     """protein_utils.py:213-262: per residue the representative location (C-alpha, or the mean of the heavy atoms), and the
-    orthonormal frame n_i, u_i, v_i from its N, CA, C atoms - float32 arithmetic like the reference."""
-    locs, ns, us, vs = [], [], [], []
-    for r in residues:
-        iN, iCA, iC = r.atom('N'), r.atom('CA'), r.atom('C')
-        if len(iN) != 1 or len(iCA) != 1 or len(iC) != 1:
-            raise ValueError("protein_to_graph: a residue without exactly one N / CA / C atom (filter_residues first)")
-        N_loc, ca, C_loc = r.coords[iN[0]], r.coords[iCA[0]], r.coords[iC[0]]
-        u = (N_loc - ca) / np.linalg.norm(N_loc - ca)
-        t = (C_loc - ca) / np.linalg.norm(C_loc - ca)
-        n = np.cross(u, t) / np.linalg.norm(np.cross(u, t))
-        v = np.cross(n, u)
-        ns.append(n); us.append(u); vs.append(v)
-        if residue_loc_is_alphaC:
-            locs.append(ca)
-        else:
-            heavy = np.asarray([e != 'H' for e in r.elements])
-            locs.append(r.coords[heavy].astype(np.float64).mean(axis=0).astype(np.float32))
+    orthonormal frame n_i, u_i, v_i from its N, CA, C atoms - float32 arithmetic like the reference, for all residues at once
+    (the reference loops over residues in Python; one residue costs ~35 us that way, the whole protein ~1 ms here)."""
     if len(residues) <= 1:
         raise ValueError("l_or_r contains only 1 residue!")
-    return np.stack(locs, 0), np.stack(ns, 0), np.stack(us, 0), np.stack(vs, 0)
+    counts = np.fromiter((len(r.atom_names) for r in residues), dtype=np.int64, count=len(residues))
+    off = np.zeros(len(residues) + 1, dtype=np.int64)
+    off[1:] = np.cumsum(counts)
+    names = np.asarray([a for r in residues for a in r.atom_names])
+    coords = np.concatenate([r.coords for r in residues], 0)
+    owner = np.repeat(np.arange(len(residues)), counts)
+
+    def unique_atom(name):
+        idx = np.nonzero(names == name)[0]
+        if len(idx) != len(residues) or not np.array_equal(owner[idx], np.arange(len(residues))):
+            raise ValueError("protein_to_graph: a residue without exactly one N / CA / C atom (filter_residues first)")
+        return coords[idx]
+    N_loc, ca, C_loc = unique_atom('N'), unique_atom('CA'), unique_atom('C')
+
+    def unit(d):
+        return d / np.sqrt((d * d).sum(axis=1, keepdims=True, dtype=np.float32))
+    u = unit(N_loc - ca)
+    t = unit(C_loc - ca)
+    n = unit(np.cross(u, t))
+    v = np.cross(n, u)
+    if residue_loc_is_alphaC:
+        loc = ca
+    else:
+        heavy = np.asarray([e != 'H' for r in residues for e in r.elements])
+        sums = np.zeros((len(residues), 3), dtype=np.float64)
+        np.add.at(sums, owner[heavy], coords[heavy].astype(np.float64))
+        loc = (sums / np.bincount(owner[heavy], minlength=len(residues))[:, None]).astype(np.float32)
+    return loc, n.astype(np.float32), u.astype(np.float32), v.astype(np.float32)
 
 
 def atoms_ragged(residues):
