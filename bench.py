@@ -287,7 +287,8 @@ def edge_kernel_rooflines(net, packed, dev, workload='B', bf16=False):
     try:
         import glob
         files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*traffic.json')), key=_profile_order)      # newest last
-        tr = {} if (bf16 or not files) else json.load(open(files[-1])).get(workload, {})
+        # (bf16 runs have their own counter passes: key '<workload>_bf16')
+        tr = {} if not files else json.load(open(files[-1])).get(workload + ('_bf16' if bf16 else ''), {})
         for k, v in tr.items():
             if k in out:
                 out[k]['traffic'] = int((2 * v['FETCH_SIZE_KB'] + v['WRITE_SIZE_KB']) * 1024)
@@ -683,7 +684,8 @@ def main():
                 prof, ev_us, n_launch = profile_step(compute, dev)
                 work = kernel_work_model(sizes, L, packed.n_nodes, packed.n_edges, fused_fwd='k_edge_attn_fwd' in prof,
                                          rowwave=next((k for k in ('k_rowres', 'k_rowwave') if k in prof), None))
-                allk, ktot = kernel_rooflines(prof, work, dtype == 'bf16', ms_step * 1e3, load_pmc(a.workload))
+                allk, ktot = kernel_rooflines(prof, work, dtype == 'bf16', ms_step * 1e3,
+                                              load_pmc(a.workload + ('_bf16' if dtype == 'bf16' else '')))
                 for k in ('k_edge_fwd', 'k_edge_bwd'):     # keep the standalone batched-launch figures beside the in-step ones
                     if k in allk:
                         allk[k]["standalone"] = rl[k]

@@ -2,10 +2,14 @@
 counter per pass, averaged per kernel by profiles/pmcstats.py) into the two summaries bench.py reads:
   profiles/<TAG>_pmc_mfma.json   per workload and kernel: MfmaUtil (%), executed MFMA FLOPs per launch
   profiles/<TAG>_traffic.json    per workload and kernel family: FETCH_SIZE_KB, WRITE_SIZE_KB per launch
-usage: python profiles/merge_pmc.py TAG [dir=gpurun_out]"""
-import json, os, sys
+usage: python profiles/merge_pmc.py TAG [dir=gpurun_out] [workloads, comma separated: B,C,E,C_bf16,R ...]
+(round 3: the per-counter files of different gpurun calls may carry different tags: `TAG` may be a comma-separated list, the
+first tag names the output; bf16 workloads count MFMA ops with SQ_INSTS_VALU_MFMA_MOPS_BF16; a `_collected` stamp lets
+bench.py pick the newest summary)"""
+import datetime, json, os, sys
 
-tag = sys.argv[1]
+tags = sys.argv[1].split(',')
+tag = tags[0]
 src = sys.argv[2] if len(sys.argv) > 2 else 'gpurun_out'
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FAM = ('k_edge_attn_fwd', 'k_edge_fwd', 'k_edge_bwd', 'k_attn_fwd', 'k_attn_bwd', 'k_rowres', 'k_rowwave', 'k_rowchain', 'k_linear', 'k_atb_reduce', 'k_atb',
@@ -13,12 +17,14 @@ FAM = ('k_edge_attn_fwd', 'k_edge_fwd', 'k_edge_bwd', 'k_attn_fwd', 'k_attn_bwd'
 
 
 def load(w, cnt):
-    f = os.path.join(root, src, f'{tag}_pmc_{w}_{cnt}.json')
-    try:
-        txt = open(f).read()
-        return json.loads(txt[txt.index('{'):])
-    except Exception:
-        return {}
+    for tg in tags:
+        f = os.path.join(root, src, f'{tg}_pmc_{w}_{cnt}.json')
+        try:
+            txt = open(f).read()
+            return json.loads(txt[txt.index('{'):])
+        except Exception:
+            continue
+    return {}
 
 
 mfma = {'_comment': "rocprofv3 --kernel-trace --pmc <counter> -- python bench.py --eager --workload W --steps 3 --warmup 1 (one counter per "
@@ -28,16 +34,27 @@ traffic = {'_comment': "FETCH_SIZE / WRITE_SIZE in KB per launch from separate r
                        "averaged over dispatches, dispatch-weighted over the template variants of a kernel family).  bench.py reports "
                        "traffic = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 bytes: FETCH_SIZE counts 128-B requests as 64 B on gfx950 "
                        "(MI355X_MICROARCH.md, HBM section) - an upper bound on the fetch side for mixed access sizes."}
-for w in ('B', 'C', 'E'):
-    mu, mops = load(w, 'MfmaUtil'), load(w, 'SQ_INSTS_VALU_MFMA_MOPS_F32')
+stamp = datetime.datetime.now().isoformat(timespec='seconds')
+mfma['_collected'] = traffic['_collected'] = stamp
+for w in (sys.argv[3].split(',') if len(sys.argv) > 3 else ('B', 'C', 'E')):
+    mu = load(w, 'MfmaUtil')
+    mops = load(w, 'SQ_INSTS_VALU_MFMA_MOPS_F32')
+    mops16 = load(w, 'SQ_INSTS_VALU_MFMA_MOPS_BF16')
     if mu:
         mfma[w] = {}
         for k, v in mu.items():
             e = {'MfmaUtil': round(v['MfmaUtil']['avg'], 1) if 'MfmaUtil' in v else None}
             mo = mops.get(k, {}).get('SQ_INSTS_VALU_MFMA_MOPS_F32')
+            m16 = mops16.get(k, {}).get('SQ_INSTS_VALU_MFMA_MOPS_BF16')
+            gf = 0.0
             if mo:
                 e['SQ_INSTS_VALU_MFMA_MOPS_F32'] = mo['avg']
-                e['executed_mfma_gflop_per_launch'] = round(mo['avg'] * 512 / 1e9, 3)
+                gf += mo['avg'] * 512 / 1e9
+            if m16:
+                e['SQ_INSTS_VALU_MFMA_MOPS_BF16'] = m16['avg']
+                gf += m16['avg'] * 512 / 1e9
+            if mo or m16:
+                e['executed_mfma_gflop_per_launch'] = round(gf, 3)
             mfma[w][k] = e
     fe, wr = load(w, 'FETCH_SIZE'), load(w, 'WRITE_SIZE')
     if fe:
