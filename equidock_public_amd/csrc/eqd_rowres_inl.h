@@ -78,6 +78,41 @@ __device__ __forceinline__ void rr_stage_store(const EqdLinSrc S, int t, const R
     }
 }
 
+// bf16 mode: the staged weights are rounded ONCE, when they are written to LDS, as bf16 [m][k] (k contiguous, row stride
+// 72 / 88 bf16) whatever the orientation in memory - an MFMA A operand is then one ds_read_b64 and the inner loop has no
+// weight conversions (round 2 staged fp32 and converted per use: 4 ds_read_b128 + 8 v_cvt_pk_bf16_f32 per 4 MFMAs and
+// tile, the LDS pipe busy ~4x longer than the MFMA pipes).  m-contiguous weights (the backward's dX = dY W) are transposed
+// by the staging stores (12 two-byte stores per thread and source, once per workgroup), so that every job runs the
+// k-contiguous form and leaves its result in the S layout.
+__device__ __forceinline__ int rr_kp16(int K) { return K > 64 ? 88 : 72; }
+__device__ __forceinline__ void rr_stage_store_bf(const EqdLinSrc S, int t, const RrStage& R, unsigned short* Wl) {
+    const bool tp = S.w_cs != 1;
+    const int KP = rr_kp16(S.K);
+    if (!tp) {
+        const int nc4 = S.K > 64 ? 20 : 16;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int idx = t + 64 * RR_WAVES * j;
+            const int m = idx / nc4, c4 = idx - m * nc4;
+            if (m < 64) {
+                const float4 f = ld4u_fix(R.v[j], S.K - 4 * c4);
+                *(s16x4*)&Wl[m * KP + 4 * c4] = pack_bf4(f.x, f.y, f.z, f.w);
+            }
+        }
+    } else {
+        const int nk = S.K > 64 ? 80 : 64;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int idx = t + 64 * RR_WAVES * j;
+            const int k = idx >> 4, c4 = idx & 15;
+            if (k < nk) {
+                const f32x4 v = k < S.K ? R.v[j] : f4zero();
+#pragma unroll
+                for (int u = 0; u < 4; ++u) Wl[(4 * c4 + u) * KP + k] = f2bf(v[u]);
+            }
+        }
+    }
+}
 // rows of one (source, tile) item as loaded: 64 columns + the 4 columns 64 + 4 g .. of a wide source
 struct RrRows {
     f32x4 x[4], xr;
@@ -164,6 +199,31 @@ __device__ __forceinline__ void rr_item(const float* __restrict__ Wl, int K, boo
     }
 }
 
+// one (source, tile) item with bf16 weights in LDS: 4 MFMAs per 16 columns, A operands straight from LDS
+__device__ __forceinline__ void rr_item_bf(const unsigned short* __restrict__ Wl, int K, bool local, const float* T,
+                                           const RrRows& R, int l15, int g, f32x4 (&acc)[4]) {
+    const int KP = rr_kp16(K);
+    const int na = K > 64 ? 5 : 4;
+#pragma unroll
+    for (int a = 0; a < 5; ++a) {
+        if (a < na) {
+            f32x4 bv;
+            if (a == 4) {
+                const float4 xf = ld4u_fix(R.xr, K - 64 - 4 * g);
+                bv = f32x4{xf.x, xf.y, xf.z, xf.w};
+            } else if (local) {
+                bv = *(const f32x4*)(T + l15 * RW_S + 16 * a + 4 * g);
+            } else {
+                bv = R.x[a < 4 ? a : 0];
+            }
+            const s16x4 bp = pack_bf4(bv[0], bv[1], bv[2], bv[3]);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+                acc[mb] = mfma_bf(*(const s16x4*)&Wl[(16 * mb + l15) * KP + 16 * a + 4 * g], bp, acc[mb]);
+        }
+    }
+}
+
 template <bool BF>
 __global__ __launch_bounds__(64 * RR_WAVES, 1) void k_rowres(EqdChainArg A_, int tps) {
     __shared__ __attribute__((aligned(16))) EqdChainArg A;
@@ -214,7 +274,8 @@ __global__ __launch_bounds__(64 * RR_WAVES, 1) void k_rowres(EqdChainArg A_, int
     if (jj < njobs) {      // the first source's weights
         const EqdLinSrc S0 = jw_src(Wc, 0);
         rr_stage_load(S0, t, WS);
-        rr_stage_store(S0, t, WS, sm.Wl[0]);
+        if constexpr (BF) rr_stage_store_bf(S0, t, WS, (unsigned short*)sm.Wl[0]);
+        else rr_stage_store(S0, t, WS, sm.Wl[0]);
     }
     __syncthreads();
     while (jj < njobs) {
@@ -270,9 +331,17 @@ __global__ __launch_bounds__(64 * RR_WAVES, 1) void k_rowres(EqdChainArg A_, int
             EQD_TR(102 + 5 * trc);
 #pragma unroll
             for (int s = 0; s < RR_TMAX; ++s)
-                if (s < nslots) rr_item<BF>(sm.Wl[buf], S.K, tp, loc >= 0, sm.tile[wave][s], XC[s], l15, g, acc[s]);
+                if (s < nslots) {
+                    if constexpr (BF)
+                        rr_item_bf((const unsigned short*)sm.Wl[buf], S.K, loc >= 0, sm.tile[wave][s], XC[s], l15, g, acc[s]);
+                    else
+                        rr_item<BF>(sm.Wl[buf], S.K, tp, loc >= 0, sm.tile[wave][s], XC[s], l15, g, acc[s]);
+                }
             EQD_TR(103 + 5 * trc);
-            if (have_next) rr_stage_store(Sn, t, WS, sm.Wl[buf ^ 1]);
+            if (have_next) {
+                if constexpr (BF) rr_stage_store_bf(Sn, t, WS, (unsigned short*)sm.Wl[buf ^ 1]);
+                else rr_stage_store(Sn, t, WS, sm.Wl[buf ^ 1]);
+            }
             EQD_TR(104 + 5 * trc);
             __syncthreads();      // every wave is done with Wl[buf]; Wl[buf ^ 1] is complete
             buf ^= 1;
@@ -283,7 +352,7 @@ __global__ __launch_bounds__(64 * RR_WAVES, 1) void k_rowres(EqdChainArg A_, int
         // its register limit and the extra live values spill, k_rowres 975 -> 1 213 us per step at C)
 #pragma unroll
         for (int s = 0; s < RR_TMAX; ++s)
-            if (s < nslots) rw_epilogue(Wc, tp, acc[s], sm.tile[wave][s], row0s[s], l15, g, 0);
+            if (s < nslots) rw_epilogue(Wc, BF ? false : tp, acc[s], sm.tile[wave][s], row0s[s], l15, g, 0);      // (bf16: S layout always)
         // the LayerNorm-backward jobs behind it, then the next linear job
         ++jj;
         while (jj < njobs) {
