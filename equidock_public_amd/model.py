@@ -154,15 +154,19 @@ class IEGMN_Layer(nn.Module):
                 original_edge_feats_ligand, orig_coors_ligand, coors_receptor, h_feats_receptor,
                 original_receptor_node_features, original_edge_feats_receptor, orig_coors_receptor):
         """One layer on its own, with the reference's signature (rigid_docking_model.py:189-352).  Inside IEGMN the layer
-        loop of the published configuration never comes through here - it runs as one C call (eqd_model_forward); a
-        layer called by itself composes the same arithmetic from torch operators on the tensors' device
-        (equidock_public_amd/torch_path.py), differentiable w.r.t. every input."""
-        from . import torch_path
+        loop of the published configuration never comes through here - it runs as one C call (eqd_model_forward).  A
+        layer called by itself runs its two heavy operators - edge messages + coordinate update, cross attention - in the
+        HIP library, forward and backward (equidock_public_amd/ops.py: eqd_edge_message_*, eqd_cross_attention_*), and its
+        node-level Linears through its own torch sub-modules, for the published configuration; the reference's other
+        options (and dropout > 0 while training) compose everything from torch operators (torch_path.py).
+        Differentiable w.r.t. coordinates, node features and parameters either way."""
+        from . import ops, torch_path
         from .graph import from_dgl
-        return torch_path.layer_forward(self, from_dgl(hetero_graph), coors_ligand, h_feats_ligand,
-                                        original_ligand_node_features, original_edge_feats_ligand, orig_coors_ligand,
-                                        coors_receptor, h_feats_receptor, original_receptor_node_features,
-                                        original_edge_feats_receptor, orig_coors_receptor)
+        fn = ops.layer_forward if ops.layer_supported(self) else torch_path.layer_forward
+        return fn(self, from_dgl(hetero_graph), coors_ligand, h_feats_ligand,
+                  original_ligand_node_features, original_edge_feats_ligand, orig_coors_ligand,
+                  coors_receptor, h_feats_receptor, original_receptor_node_features,
+                  original_edge_feats_receptor, orig_coors_receptor)
 
     def __repr__(self):
         return f"IEGMN Layer (HIP) h_feats_dim={self.h_feats_dim} out_feats_dim={self.out_feats_dim}"

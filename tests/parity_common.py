@@ -991,6 +991,56 @@ def check_dropout_training(dev):
         assert torch.equal(cat_out(a), cat_out(b))
 
 
+def check_standalone_layer(dev):
+    """IEGMN_Layer.forward on its own (reference signature, rigid_docking_model.py:189-352): the HIP composition
+    (equidock_public_amd/ops.py: edge messages + cross attention in the library, forward and backward) against the
+    torch-operator restatement of the same layer (torch_path.layer_forward) - outputs, gradients w.r.t. node features and
+    coordinates (incl. the original coordinates), and every parameter gradient; the 69-wide first layer and a 64-wide one,
+    x_connection_init != 0."""
+    from equidock_public_amd import ops, torch_path
+    args = port.default_args(iegmn_n_lays=2, skip_weight_h=0.75, x_connection_init=0.25, device=torch.device(dev))
+    sd = port.init_state_dict(args, seed=6)
+    net = build_model(args, sd, dev)
+    g = G.batch_pairs(synthetic.make_pairs([(23, 31), (40, 17), (64, 50)], 9)).to(dev)
+    nl_, nr_ = g.nodes['ligand'].data, g.nodes['receptor'].data
+    ie = net.iegmn_original
+    gen = torch.Generator().manual_seed(3)
+    for li, width in ((0, 69), (1, 64)):
+        layer = ie.iegmn_layers[li]
+        assert ops.layer_supported(layer)
+        n_l, n_r = nl_['x'].shape[0], nr_['x'].shape[0]
+
+        def leaves():
+            torch.manual_seed(11)
+            mk = lambda *s: (torch.randn(*s, generator=gen) * 0.5).to(dev).requires_grad_(True)       # noqa: E731
+            return dict(h_l=mk(n_l, width), h_r=mk(n_r, width), h0_l=mk(n_l, 69), h0_r=mk(n_r, 69),
+                        x_l=(nl_['new_x'].detach().clone() + 0.0).requires_grad_(True),
+                        x_r=(nr_['x'].detach().clone() + 0.0).requires_grad_(True),
+                        x0_l=nl_['new_x'].detach().clone().requires_grad_(True), x0_r=nr_['x'].detach().clone().requires_grad_(True))
+        state = gen.get_state()
+        res = {}
+        for name, fn in (('hip', ops.layer_forward), ('torch', torch_path.layer_forward)):
+            gen.set_state(state)
+            L_ = leaves()
+            for p_ in layer.parameters():
+                p_.grad = None
+            outs = fn(layer, g, L_['x_l'], L_['h_l'], L_['h0_l'], g.edges['ll'].data['he'], L_['x0_l'], L_['x_r'], L_['h_r'],
+                      L_['h0_r'], g.edges['rr'].data['he'], L_['x0_r'])
+            wgen = torch.Generator().manual_seed(5)
+            loss = sum((o * torch.randn(o.shape, generator=wgen).to(dev)).sum() for o in outs)
+            loss.backward()
+            sync(dev)
+            res[name] = ([o.detach().cpu() for o in outs], {k: v.grad.detach().cpu() for k, v in L_.items()},
+                         {k: p_.grad.detach().cpu().clone() for k, p_ in layer.named_parameters() if p_.grad is not None})
+        for a, b, nm in zip(res['hip'][0], res['torch'][0], ('x_l', 'h_l', 'x_r', 'h_r')):
+            close(a, b, what=f'standalone layer {li} output {nm}')
+        for k in res['torch'][1]:
+            grad_close(res['hip'][1][k], res['torch'][1][k], what=f'standalone layer {li} d {k}', l2=2e-4, mx=1e-3)
+        assert set(res['hip'][2]) == set(res['torch'][2])
+        for k in res['torch'][2]:
+            grad_close(res['hip'][2][k], res['torch'][2][k], what=f'standalone layer {li} grad {k}', l2=2e-4, mx=1e-3)
+
+
 def check_flat_grads_equal_autograd(dev):
     z, meta, args, raw = load_case('D_degraded3')
     sd = state_dict_for(meta, args)

@@ -138,6 +138,12 @@ def test_model_forked_attention_stream(dev, monkeypatch):
     pc.check_model_case(dev, 'D_degraded3')
 
 
+def test_standalone_layer_through_the_library(dev):
+    """IEGMN_Layer.forward on its own: edge messages + cross attention in the HIP library vs the torch-operator restatement"""
+    from tests import parity_common as pc
+    pc.check_standalone_layer(dev)
+
+
 def test_flat_grads(dev):
     from tests import parity_common as pc
     pc.check_flat_grads_equal_autograd(dev)

@@ -117,6 +117,10 @@ def test_model_forked_attention_stream(monkeypatch):
     pc.check_model_case(DEV, 'D_degraded3')
 
 
+def test_standalone_layer_through_the_library():
+    pc.check_standalone_layer(DEV)
+
+
 def test_flat_grads():
     pc.check_flat_grads_equal_autograd(DEV)
 
