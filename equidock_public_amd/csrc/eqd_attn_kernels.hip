@@ -52,7 +52,12 @@ __device__ __forceinline__ void attn_bwd_q_body(SM& sm, const EqdGraph& G, int i
                                                 const float* __restrict__ q, const float* __restrict__ k,
                                                 const float* __restrict__ v, const float* __restrict__ out,
                                                 const float* __restrict__ lse, const float* __restrict__ d_out,
-                                                float* __restrict__ dq, float* __restrict__ delta, int half = 0) {
+                                                float* __restrict__ dq, float* __restrict__ delta, int half = 0,
+                                                float qk_slope = 1.f) {
+    // qk_slope: q is LeakyReLU(z) (att_mlp_Q, rigid_docking_model.py:130-133) - the stored gradient is multiplied by
+    // LeakyReLU'(q) (1 | qk_slope), i.e. it is the gradient w.r.t. the pre-activation.  Both consumers (the dh job and
+    // the weight-gradient GEMM) applied that mask themselves until round 3, each from a second stream of rows (the q rows:
+    // +1.0 % / +1.4 % of the fp32 / bf16 step at 64 x (300, 300)); 1 = off (the operator-level entry points)
     typedef AttnCfg<DB> C;
     constexpr int DS = C::DS, KS = C::KS;
     float* Qt = sm.blk(0);
@@ -197,7 +202,9 @@ __device__ __forceinline__ void attn_bwd_q_body(SM& sm, const EqdGraph& G, int i
             for (int r = 0; r < 4; ++r) {
                 const int o = ((db * 2 + nb) * 4 + r) * 64 + lane;
                 const int f = 16 * db + 4 * g + r;
-                if (f < d) dq[(size_t)rowq[nb] * d + f] = sm.red(0)[o] + sm.red(1)[o] + sm.red(2)[o] + sm.red(3)[o];
+                if (f < d)
+                    dq[(size_t)rowq[nb] * d + f] = (sm.red(0)[o] + sm.red(1)[o] + sm.red(2)[o] + sm.red(3)[o]) *
+                                                   lrelu_grad(q[(size_t)rowq[nb] * d + f], qk_slope);
             }
         }
 }
@@ -211,7 +218,7 @@ __device__ __forceinline__ void attn_bwd_kv_body(SM& sm, const EqdGraph& G, int 
                                                  const float* __restrict__ v, const float* __restrict__ out,
                                                  const float* __restrict__ lse, const float* __restrict__ d_out,
                                                  const float* __restrict__ delta, float* __restrict__ dk,
-                                                 float* __restrict__ dv, int half = 0) {
+                                                 float* __restrict__ dv, int half = 0, float qk_slope = 1.f) {
     static_assert(FAST || !OWN_DELTA, "OWN_DELTA needs the float4 tile layout");
     typedef AttnCfg<DB> C;
     constexpr int DS = C::DS, KS = C::KS;
@@ -382,7 +389,10 @@ __device__ __forceinline__ void attn_bwd_kv_body(SM& sm, const EqdGraph& G, int 
                 for (int r = 0; r < 4; ++r) {
                     const int o = ((db * 2 + nb) * 4 + r) * 64 + lane;
                     const int f = 16 * db + 4 * g + r;
-                    if (f < d) dst[(size_t)rowk[nb] * d + f] = sm.red(0)[o] + sm.red(1)[o] + sm.red(2)[o] + sm.red(3)[o];
+                    if (f < d) {      // dK carries LeakyReLU'(k) (see attn_bwd_q_body), dV does not (att_mlp_V is linear)
+                        const float s = sm.red(0)[o] + sm.red(1)[o] + sm.red(2)[o] + sm.red(3)[o];
+                        dst[(size_t)rowk[nb] * d + f] = pass ? s : s * lrelu_grad(k[(size_t)rowk[nb] * d + f], qk_slope);
+                    }
                 }
             }
     }
@@ -394,9 +404,9 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd_q(EqdGraph G, int d, con
                                                           const float* __restrict__ out,
                                                           const float* __restrict__ lse,
                                                           const float* __restrict__ d_out, float* __restrict__ dq,
-                                                          float* __restrict__ delta) {
+                                                          float* __restrict__ delta, float qk_slope) {
     __shared__ __attribute__((aligned(16))) AttnBwdSmem<DB, false> sm;
-    attn_bwd_q_body<DB, FAST, NB>(sm, G, blockIdx.x, d, q, k, v, out, lse, d_out, dq, delta);
+    attn_bwd_q_body<DB, FAST, NB>(sm, G, blockIdx.x, d, q, k, v, out, lse, d_out, dq, delta, 0, qk_slope);
 }
 template <int DB, bool FAST, int NB>
 __global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd_kv(EqdGraph G, int d, const float* __restrict__ q,
@@ -404,9 +414,9 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd_kv(EqdGraph G, int d, co
                                                            const float* __restrict__ lse,
                                                            const float* __restrict__ d_out,
                                                            const float* __restrict__ delta, float* __restrict__ dk,
-                                                           float* __restrict__ dv) {
+                                                           float* __restrict__ dv, float qk_slope) {
     __shared__ __attribute__((aligned(16))) AttnBwdSmem<DB, false> sm;
-    attn_bwd_kv_body<DB, FAST, false, NB>(sm, G, blockIdx.x, d, q, k, v, nullptr, lse, d_out, delta, dk, dv);
+    attn_bwd_kv_body<DB, FAST, false, NB>(sm, G, blockIdx.x, d, q, k, v, nullptr, lse, d_out, delta, dk, dv, 0, qk_slope);
 }
 // both passes in one launch (float4 path): workgroups [0, n_items) run pass 1, [n_items, 2 n_items) pass 2
 // NB = 1: two workgroups per item and pass (16-row half blocks); with half the accumulators the kernel fits 256
@@ -417,17 +427,18 @@ __global__ __launch_bounds__(EQD_BLOCK, NB == 1 ? 2 : 1) void k_attn_bwd(EqdGrap
                                                         const float* __restrict__ out, const float* __restrict__ lse,
                                                         const float* __restrict__ d_out, float* __restrict__ dq,
                                                         float* __restrict__ dk, float* __restrict__ dv,
-                                                        float* __restrict__ delta) {
+                                                        float* __restrict__ delta, float qk_slope) {
     __shared__ __attribute__((aligned(16))) AttnBwdSmem<DB, true> sm;
     const int per = NB == 1 ? 2 * G.n_att_items : G.n_att_items;      // workgroups per pass
     const bool kv = (int)blockIdx.x >= per;
     const int idx = kv ? (int)blockIdx.x - per : (int)blockIdx.x;
     const int item = NB == 1 ? att_half_item(idx) : idx, half = NB == 1 ? att_half_of(idx) : 0;
     if (!kv)
-        attn_bwd_q_body<DB, true, NB, AttnBwdSmem<DB, true>, BF>(sm, G, item, d, q, k, v, out, lse, d_out, dq, delta, half);
+        attn_bwd_q_body<DB, true, NB, AttnBwdSmem<DB, true>, BF>(sm, G, item, d, q, k, v, out, lse, d_out, dq, delta, half,
+                                                                 qk_slope);
     else
         attn_bwd_kv_body<DB, true, true, NB, AttnBwdSmem<DB, true>, BF>(sm, G, item, d, q, k, v, out, lse, d_out, nullptr, dk,
-                                                                        dv, half);
+                                                                        dv, half, qk_slope);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -443,26 +454,26 @@ static int attn_launch_fwd(const EqdGraph* g, int d, const float* q, const float
 template <int DB, int NB>
 static int attn_launch_bwd_bf(const EqdGraph* g, int d, const float* q, const float* k, const float* v, const float* out,
                               const float* lse, const float* d_out, float* dq, float* dk, float* dv, float* delta,
-                              hipStream_t st) {
+                              hipStream_t st, float qk_slope) {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd<DB, NB, true>), dim3((NB == 1 ? 4 : 2) * g->n_att_items), dim3(EQD_BLOCK), 0,
-                       st, *g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta);
+                       st, *g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, qk_slope);
     return eqd_check_launch("k_attn_bwd");
 }
 template <int DB, bool FAST, int NB>
 static int attn_launch_bwd(const EqdGraph* g, int d, const float* q, const float* k, const float* v, const float* out,
                            const float* lse, const float* d_out, float* dq, float* dk, float* dv, float* delta,
-                           hipStream_t st) {
+                           hipStream_t st, float qk_slope) {
     if constexpr (FAST) if (aligned16(out)) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd<DB, NB>), dim3((NB == 1 ? 4 : 2) * g->n_att_items), dim3(EQD_BLOCK), 0,
-                           st, *g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta);
+                           st, *g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, qk_slope);
         return eqd_check_launch("k_attn_bwd");
     }
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_q<DB, FAST, NB>), dim3(g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, d,
-                       q, k, v, out, lse, d_out, dq, delta);
+                       q, k, v, out, lse, d_out, dq, delta, qk_slope);
     int rc = eqd_check_launch("k_attn_bwd_q");
     if (rc) return rc;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_kv<DB, FAST, NB>), dim3(g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, d,
-                       q, k, v, lse, d_out, delta, dk, dv);
+                       q, k, v, lse, d_out, delta, dk, dv, qk_slope);
     return eqd_check_launch("k_attn_bwd_kv");
 }
 // forward, float4 path: half blocks while that still fits one round of workgroups (two of them share a CU's LDS);
@@ -495,9 +506,12 @@ extern "C" int eqd_cross_attention_fwd(const EqdGraph* g, int d, const float* q,
     return attn_launch_fwd<5, false, 2>(g, d, q, k, v, out, lse, st);
 }
 
-extern "C" int eqd_cross_attention_bwd(const EqdGraph* g, int d, const float* q, const float* k, const float* v,
-                                       const float* out, const float* lse, const float* d_out, float* dq, float* dk,
-                                       float* dv, float* delta, void* stream) {
+// The backward with the LeakyReLU derivative of att_mlp_Q / att_mlp_K folded in (qk_slope = the activation's negative slope;
+// 1 = the plain operator): dq, dk are then gradients w.r.t. the PRE-activations - what eqd_model_backward's dh job and
+// weight-gradient GEMMs consume.
+static int attention_bwd_f32(const EqdGraph* g, int d, const float* q, const float* k, const float* v, const float* out,
+                             const float* lse, const float* d_out, float* dq, float* dk, float* dv, float* delta,
+                             float qk_slope, hipStream_t stream) {
     if (!g || !q || !k || !v || !out || !lse || !d_out || !dq || !dk || !dv || !delta) {
         eqd_set_error("eqd_cross_attention_bwd: NULL argument");
         return EQD_ERR_NULL;
@@ -507,17 +521,17 @@ extern "C" int eqd_cross_attention_bwd(const EqdGraph* g, int d, const float* q,
         return EQD_ERR_UNSUPPORTED;
     }
     if (g->n_att_items <= 0) return EQD_OK;
-    hipStream_t st = (hipStream_t)stream;
+    hipStream_t st = stream;
     const bool al = aligned16(q) && aligned16(k) && aligned16(v) && aligned16(d_out) && aligned16(out);
     // d = 64: half blocks (two workgroups per CU, see k_attn_bwd) - config C +2.3 %, E +0.9 %, B unchanged;
     // EQD_ATT_BWD_SPLIT=0 keeps 32-row blocks (tests)
     const char* hb = getenv("EQD_ATT_BWD_SPLIT");
     const bool half = !(hb && hb[0] == '0' && hb[1] == 0) && g->n_att_items % 8 == 0;
-    if (d == 64 && al && half) return attn_launch_bwd<4, true, 1>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
-    if (d == 64 && al) return attn_launch_bwd<4, true, 2>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
-    if (d == 80 && al) return attn_launch_bwd<5, true, 2>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
-    if (d <= 64) return attn_launch_bwd<4, false, 2>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
-    return attn_launch_bwd<5, false, 2>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
+    if (d == 64 && al && half) return attn_launch_bwd<4, true, 1>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st, qk_slope);
+    if (d == 64 && al) return attn_launch_bwd<4, true, 2>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st, qk_slope);
+    if (d == 80 && al) return attn_launch_bwd<5, true, 2>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st, qk_slope);
+    if (d <= 64) return attn_launch_bwd<4, false, 2>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st, qk_slope);
+    return attn_launch_bwd<5, false, 2>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st, qk_slope);
 }
 
 // bf16 mode, d = 64: the streamed tiles live in LDS as bf16 (eqd_attn_lb_inl.h) unless EQD_ATT_LB=0 (the first bf16 version:
@@ -557,9 +571,9 @@ extern "C" int eqd_cross_attention_fwd_bf16(const EqdGraph* g, int d, const floa
     return half ? attn_launch_fwd<5, true, 1, true>(g, d, q, k, v, out, lse, st)
                 : attn_launch_fwd<5, true, 2, true>(g, d, q, k, v, out, lse, st);
 }
-extern "C" int eqd_cross_attention_bwd_bf16(const EqdGraph* g, int d, const float* q, const float* k, const float* v,
-                                            const float* out, const float* lse, const float* d_out, float* dq, float* dk,
-                                            float* dv, float* delta, void* stream) {
+static int attention_bwd_bf16(const EqdGraph* g, int d, const float* q, const float* k, const float* v, const float* out,
+                              const float* lse, const float* d_out, float* dq, float* dk, float* dv, float* delta,
+                              float qk_slope, hipStream_t stream) {
     if (!g || !q || !k || !v || !out || !lse || !d_out || !dq || !dk || !dv || !delta) {
         eqd_set_error("eqd_cross_attention_bwd_bf16: NULL argument");
         return EQD_ERR_NULL;
@@ -574,13 +588,31 @@ extern "C" int eqd_cross_attention_bwd_bf16(const EqdGraph* g, int d, const floa
         const char* nb2 = getenv("EQD_ATT_LB_NB");      // experiments: 2 = 32-row blocks in the backward
         if (g->n_att_items % 8 == 0 && !(nb2 && nb2[0] == '2'))
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_lb<1>), dim3(4 * g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, q, k, v, out,
-                               lse, d_out, dq, dk, dv, delta);
+                               lse, d_out, dq, dk, dv, delta, qk_slope);
         else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_lb<2>), dim3(2 * g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, q, k, v, out,
-                               lse, d_out, dq, dk, dv, delta);
+                               lse, d_out, dq, dk, dv, delta, qk_slope);
         return eqd_check_launch("k_attn_bwd");
     }
-    if (d == 64 && g->n_att_items % 8 == 0) return attn_launch_bwd_bf<4, 1>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
-    if (d == 64) return attn_launch_bwd_bf<4, 2>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
-    return attn_launch_bwd_bf<5, 2>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st);
+    if (d == 64 && g->n_att_items % 8 == 0)
+        return attn_launch_bwd_bf<4, 1>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st, qk_slope);
+    if (d == 64) return attn_launch_bwd_bf<4, 2>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st, qk_slope);
+    return attn_launch_bwd_bf<5, 2>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st, qk_slope);
+}
+
+extern "C" int eqd_cross_attention_bwd(const EqdGraph* g, int d, const float* q, const float* k, const float* v,
+                                       const float* out, const float* lse, const float* d_out, float* dq, float* dk,
+                                       float* dv, float* delta, void* stream) {
+    return attention_bwd_f32(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, 1.f, (hipStream_t)stream);
+}
+extern "C" int eqd_cross_attention_bwd_bf16(const EqdGraph* g, int d, const float* q, const float* k, const float* v,
+                                            const float* out, const float* lse, const float* d_out, float* dq, float* dk,
+                                            float* dv, float* delta, void* stream) {
+    return attention_bwd_bf16(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, 1.f, (hipStream_t)stream);
+}
+int eqd_launch_attention_bwd_act(const EqdGraph* g, int d, const float* q, const float* k, const float* v, const float* out,
+                                 const float* lse, const float* d_out, float* dq, float* dk, float* dv, float* delta,
+                                 float qk_slope, bool bf16, hipStream_t st) {
+    return bf16 ? attention_bwd_bf16(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, qk_slope, st)
+                : attention_bwd_f32(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, qk_slope, st);
 }

@@ -306,7 +306,8 @@ __device__ __forceinline__ void attn_bwd_q_body_lb(AttnBwdSmemLb& sm, const EqdG
                                                    const float* __restrict__ q, const float* __restrict__ k,
                                                    const float* __restrict__ v, const float* __restrict__ out,
                                                    const float* __restrict__ lse, const float* __restrict__ d_out,
-                                                   float* __restrict__ dq, float* __restrict__ delta, int half) {
+                                                   float* __restrict__ dq, float* __restrict__ delta, int half,
+                                                   float qk_slope) {
     typedef AttnCfg<4> C;
     constexpr int DS = C::DS, d = 64;
     float* Qt = sm.blk(0);
@@ -419,7 +420,8 @@ __device__ __forceinline__ void attn_bwd_q_body_lb(AttnBwdSmemLb& sm, const EqdG
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int o = ((db * 2 + nb) * 4 + r) * 64 + lane;
-                dq[(size_t)rowq[nb] * d + 16 * db + 4 * g + r] = sm.red(0)[o] + sm.red(1)[o] + sm.red(2)[o] + sm.red(3)[o];
+                const size_t at = (size_t)rowq[nb] * d + 16 * db + 4 * g + r;      // x LeakyReLU'(q): see attn_bwd_q_body
+                dq[at] = (sm.red(0)[o] + sm.red(1)[o] + sm.red(2)[o] + sm.red(3)[o]) * lrelu_grad(q[at], qk_slope);
             }
         }
 }
@@ -429,7 +431,8 @@ __device__ __forceinline__ void attn_bwd_kv_body_lb(AttnBwdSmemLb& sm, const Eqd
                                                     const float* __restrict__ q, const float* __restrict__ k,
                                                     const float* __restrict__ v, const float* __restrict__ out,
                                                     const float* __restrict__ lse, const float* __restrict__ d_out,
-                                                    float* __restrict__ dk, float* __restrict__ dv, int half) {
+                                                    float* __restrict__ dk, float* __restrict__ dv, int half,
+                                                    float qk_slope) {
     typedef AttnCfg<4> C;
     constexpr int DS = C::DS, d = 64;
     float* Kb = sm.blk(0);
@@ -569,7 +572,9 @@ __device__ __forceinline__ void attn_bwd_kv_body_lb(AttnBwdSmemLb& sm, const Eqd
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int o = ((db * 2 + nb) * 4 + r) * 64 + lane;
-                    dst[(size_t)rowk[nb] * d + 16 * db + 4 * g + r] = sm.red(0)[o] + sm.red(1)[o] + sm.red(2)[o] + sm.red(3)[o];
+                    const size_t at = (size_t)rowk[nb] * d + 16 * db + 4 * g + r;
+                    const float s = sm.red(0)[o] + sm.red(1)[o] + sm.red(2)[o] + sm.red(3)[o];
+                    dst[at] = pass ? s : s * lrelu_grad(k[at], qk_slope);
                 }
             }
     }
@@ -581,14 +586,14 @@ __global__ __launch_bounds__(EQD_BLOCK, NB == 1 ? 2 : 1) void k_attn_bwd_lb(EqdG
                                                         const float* __restrict__ out, const float* __restrict__ lse,
                                                         const float* __restrict__ d_out, float* __restrict__ dq,
                                                         float* __restrict__ dk, float* __restrict__ dv,
-                                                        float* __restrict__ delta) {
+                                                        float* __restrict__ delta, float qk_slope) {
     __shared__ AttnBwdSmemLb sm;
     const int per = NB == 1 ? 2 * G.n_att_items : G.n_att_items;      // workgroups per pass
     const bool kv = (int)blockIdx.x >= per;
     const int idx = kv ? (int)blockIdx.x - per : (int)blockIdx.x;
     const int item = NB == 1 ? att_half_item(idx) : idx, half = NB == 1 ? att_half_of(idx) : 0;
     if (!kv)
-        attn_bwd_q_body_lb<NB>(sm, G, item, q, k, v, out, lse, d_out, dq, delta, half);
+        attn_bwd_q_body_lb<NB>(sm, G, item, q, k, v, out, lse, d_out, dq, delta, half, qk_slope);
     else
-        attn_bwd_kv_body_lb<NB>(sm, G, item, q, k, v, out, lse, d_out, dk, dv, half);
+        attn_bwd_kv_body_lb<NB>(sm, G, item, q, k, v, out, lse, d_out, dk, dv, half, qk_slope);
 }

@@ -316,6 +316,10 @@ int eqd_rigid_apply_bwd_impl(const EqdGraph* g, const float* d_lig, const float*
 size_t eqd_ln_act_bwd_partial_floats(int rows, int d);
 int eqd_launch_fill(float* p, float v, size_t n, hipStream_t st);
 int eqd_launch_axpy(float* y, const float* x, float a, size_t n, hipStream_t st);
+// eqd_cross_attention_bwd[_bf16] with dq, dk multiplied by LeakyReLU'(q), LeakyReLU'(k) (eqd_attn_kernels.hip)
+int eqd_launch_attention_bwd_act(const EqdGraph* g, int d, const float* q, const float* k, const float* v, const float* out,
+                                 const float* lse, const float* d_out, float* dq, float* dk, float* dv, float* delta,
+                                 float qk_slope, bool bf16, hipStream_t st);
 int eqd_launch_seg_mean(const EqdGraph* g, const float* hm, float* qmean, hipStream_t st);
 size_t eqd_head_u_bwd_partial_floats(int n_pairs, int K);      // 0 when the batch is not split over segment groups
 // part / defer: partial buffer of that size and the pass's pending-reduction list (both or neither)

@@ -137,8 +137,9 @@ int node_atb_jobs(const Dims& D, int l, const EqdModelDesc* m, const Saved* S, c
     jobs[n++] = atb_job(dP, 64, 64, h, d, d, N, G(P_W1), ld1, nullptr, m->lrelu_slope);
     jobs[n++] = atb_job(dQ, 64, 64, h, d, d, N, gp ? G(P_W1) + d : nullptr, ld1, G(P_B1), m->lrelu_slope);
     if (m->cross_msgs) {
-        jobs[n++] = atb_job(dq, da, d, h, d, d, N, G(P_WQ), d, nullptr, m->lrelu_slope, Ls ? Ls->qa : nullptr);
-        jobs[n++] = atb_job(dk, da, d, h, d, d, N, G(P_WK), d, nullptr, m->lrelu_slope, Ls ? Ls->ka : nullptr);
+        // dq, dk arrive multiplied by LeakyReLU'(q), LeakyReLU'(k) (eqd_launch_attention_bwd_act)
+        jobs[n++] = atb_job(dq, da, d, h, d, d, N, G(P_WQ), d, nullptr, m->lrelu_slope);
+        jobs[n++] = atb_job(dk, da, d, h, d, d, N, G(P_WK), d, nullptr, m->lrelu_slope);
         jobs[n++] = atb_job(dv, da, d, h, d, d, N, G(P_WV), d, nullptr, m->lrelu_slope);
     }
     return n;
@@ -630,7 +631,7 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
         RC(eqd_linear(&j, 1, st));
         wjobs.push_back(atb_job(W.dhm, 64, 64, H, D.dh, D.dh, N, ggrad[G_WM], D.dh, ggrad[G_BM], slope, S.hm));
     }
-    // dh(l) = dz Wn1[:, :d] + dP W1a + dQ W1b + (dq . lrelu'(qa)) Wq + (dk . lrelu'(ka)) Wk + dv Wv + (1-s) dH:
+    // dh(l) = dz Wn1[:, :d] + dP W1a + dQ W1b + dq Wq + dk Wk + dv Wv + (1-s) dH   (dq, dk w.r.t. the pre-activations):
     // the gradient wrt h[l] once layer l's attention and edge backward are done
     auto dh_job = [&](int l) -> EqdLinJob {
         const float* const* p = params + (size_t)EQD_PARAMS_PER_LAYER * l;
@@ -644,8 +645,8 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
         lin_src(j, ns++, W.dQ_all + l * NP, 64, 64, p[P_W1] + d, 1, D.ldw1(l));
         if (m->cross_msgs) {
             const int da = D.d_att(l);
-            lin_src(j, ns++, W.dq_all + l * NS, da, d, p[P_WQ], 1, d, Ls.qa);
-            lin_src(j, ns++, W.dk_all + l * NS, da, d, p[P_WK], 1, d, Ls.ka);
+            lin_src(j, ns++, W.dq_all + l * NS, da, d, p[P_WQ], 1, d);      // already w.r.t. the pre-activations
+            lin_src(j, ns++, W.dk_all + l * NS, da, d, p[P_WK], 1, d);
             lin_src(j, ns++, W.dv_all + l * NS, da, d, p[P_WV], 1, d);
         }
         j.nsrc = ns;
@@ -737,12 +738,8 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
         // The backward kernels of a layer each fill the chip (LDS-bound occupancy), so they run back to back
         // on ONE stream: side streams only added event latency here.
         if (m->cross_msgs) {
-            if (m->storage_bf16)
-                RC(eqd_cross_attention_bwd_bf16(g, da, Ls.qa, Ls.ka, Ls.va, Ls.aggr_cross, Ls.lse, W.d_aggr_cross, dq, dk, dv,
-                                                W.delta, st));
-            else
-                RC(eqd_cross_attention_bwd(g, da, Ls.qa, Ls.ka, Ls.va, Ls.aggr_cross, Ls.lse, W.d_aggr_cross, dq, dk, dv,
-                                           W.delta, st));
+            RC(eqd_launch_attention_bwd_act(g, da, Ls.qa, Ls.ka, Ls.va, Ls.aggr_cross, Ls.lse, W.d_aggr_cross, dq, dk, dv,
+                                            W.delta, m->lrelu_slope, m->storage_bf16 != 0, st));
         }
         {
             EqdEdgeParams ep = edge_params(D, m, l, p, drop);
