@@ -474,6 +474,14 @@ def main():
     ap.add_argument('--dtype', default=None, choices=('f32', 'bf16'),
                     help="arithmetic of the GEMMs: f32 (default for A, B, C, E) or bf16 inputs with fp32 accumulate "
                          "(default for D; `--workload C --dtype bf16` is BASELINE.json configs[2])")
+    ap.add_argument('--dropout', type=float, default=0.0,
+                    help="args['dropout'] of the model, in training mode (src/utils/args.py:240 draws 0 or 0.25): every step "
+                         "then draws fresh nn.Dropout masks with torch's device generator in the reference's order (inside "
+                         "the replayed graph) and the kernels apply them; reported WITHOUT the roofline / CPU-baseline parts")
+    ap.add_argument('--dropout-masks', default='torch', choices=('torch', 'library'),
+                    help="with --dropout: 'torch' = nn.Dropout's own random stream (torch's dropout on [E, 64] tensors of "
+                         "ones, bit-packed by eqd_dropout_pack_edges); 'library' = eqd_dropout_draw (counter-based, one launch, "
+                         "no [E, 64] tensors; args['hip_dropout_masks'])")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--eager', action='store_true', help='launch every kernel of every step from the host instead of replaying a captured hipGraph of the step (zero-grad, forward, loss, backward; the gradient all-reduce always runs outside the graph).  Same kernels either way; the replay takes the host (torch autograd + the launches, 0.7-1.5 ms depending on the box) off the critical path of a 1.5 ms step')
@@ -511,9 +519,16 @@ def main():
     args_model = config.published_args(iegmn_n_lays=L, shared_layers=shared, skip_weight_h=skh, device=dev)
     if dtype == 'bf16':
         args_model['hip_storage_dtype'] = 'bf16'
+    if a.dropout > 0:
+        args_model['dropout'] = a.dropout
+        args_model['hip_dropout_masks'] = a.dropout_masks
+        a.no_cpu_baseline = a.no_roofline = True
     sd = config.seeded_state_dict(args_model, seed=0)
     net = model.Rigid_Body_Docking_Net(args_model).to(dev)
     net.load_state_dict(sd)
+    net.train(True)      # the step is a TRAINING step (forward + backward); with --dropout the masks are live
+    if os.environ.get('EQD_BENCH_DROPOUT_PACK'):      # 'torch': the mask packing in torch operators (comparison runs)
+        net.iegmn_original.dropout_pack = os.environ['EQD_BENCH_DROPOUT_PACK']
     sizes = [uniform] * ppg if uniform else synthetic.realistic_sizes(ppg, R_SIZE_SEED + rank)
     pairs = synthetic.make_pairs(sizes, seed=1000 + rank)
     g = graph.batch_pairs(pairs).to(dev)
@@ -538,8 +553,10 @@ def main():
         loss = batched_loss(lig, Yl, Yr, lig_w)
         loss.backward()
         return loss
+    torch.manual_seed(4242)     # (same dropout masks in both evaluations)
     l_ref = float(compute_torch_loss().detach())
     g_ref = reducer.flat.clone()
+    torch.manual_seed(4242)
     l_got = float(compute())
     if abs(l_got - l_ref) > 1e-5 * abs(l_ref) or float((reducer.flat - g_ref).abs().max()) > 1e-5 * float(g_ref.abs().max()):
         raise SystemExit(f"fused scalar loss disagrees with its torch formulation: {l_got} vs {l_ref}")
@@ -652,7 +669,8 @@ def main():
                        "edges_per_gpu": packed.n_edges, "layers": L, "parallelism": f"dp{world}",
                        "weights": "PyTorch default init (seed 0), ROT key/query x40 (SURVEY.md section 8c)",
                        "loss": float(loss.detach()), "svd_guard_pairs": svd_bad,
-                       "host_enqueue_ms_per_step": round(host_dt / a.steps * 1e3, 4), "launch_mode": graph_mode},
+                       "host_enqueue_ms_per_step": round(host_dt / a.steps * 1e3, 4), "launch_mode": graph_mode,
+                       "dropout": a.dropout, "dropout_masks": (a.dropout_masks if a.dropout > 0 else None)},
             # data parallel: ranks of the RCCL communicator the flat-gradient all-reduce ran on (0 = no process group: a
             # plain single-process run), whether the collective was a node of the replayed hipGraph, and its duration
             # alone (HIP events around back-to-back all-reduces of the buffer, after the timed region; max over ranks)

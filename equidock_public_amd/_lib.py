@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libequidock_hip.so')
 
 EQD_MAX_SRC = 6
-ABI_VERSION = 4
+ABI_VERSION = 5
 PARAMS_PER_LAYER = 19
 GLOBAL_PARAMS = 5
 
@@ -106,7 +106,7 @@ def _declare(lib):
            'eqd_keypoint_pool_fwd', 'eqd_keypoint_pool_bwd', 'eqd_kabsch_fwd', 'eqd_kabsch_bwd',
                  'eqd_rigid_apply_fwd', 'eqd_rigid_apply_bwd', 'eqd_pair_losses_fwd', 'eqd_pair_losses_bwd', 'eqd_scalar_loss', 'eqd_pocket_ot_cost',
                  'eqd_pocket_ot_fwd', 'eqd_pocket_ot_bwd', 'eqd_rigid_augment', 'eqd_protein_graph_distances',
-                 'eqd_protein_graph_select', 'eqd_protein_graph_edges', 'eqd_clash_iterations'):
+                 'eqd_protein_graph_select', 'eqd_protein_graph_edges', 'eqd_clash_iterations', 'eqd_dropout_pack_edges', 'eqd_dropout_draw'):
         getattr(lib, name).restype = C.c_int
 
 
@@ -120,7 +120,7 @@ EXPORTS = ('eqd_model_layer_state', 'eqd_model_lrelu_signs', 'eqd_profile_begin'
            'eqd_kabsch_fwd', 'eqd_kabsch_bwd', 'eqd_rigid_apply_fwd', 'eqd_rigid_apply_bwd', 'eqd_pair_losses_fwd',
            'eqd_pair_losses_bwd', 'eqd_scalar_loss', 'eqd_pocket_ot_cost', 'eqd_pocket_ot_fwd', 'eqd_pocket_ot_bwd',
            'eqd_rigid_augment', 'eqd_protein_graph_distances', 'eqd_protein_graph_select', 'eqd_protein_graph_edges',
-           'eqd_clash_workspace_bytes', 'eqd_clash_iterations')
+           'eqd_clash_workspace_bytes', 'eqd_clash_iterations', 'eqd_dropout_pack_edges', 'eqd_dropout_draw')
 
 
 def load_library():

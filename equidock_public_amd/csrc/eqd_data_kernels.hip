@@ -64,6 +64,49 @@ extern "C" int eqd_rigid_augment(const EqdGraph* g, const float* x_lig, const fl
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// nn.Dropout keep masks of the edge MLPs (EqdDropout.edge_z1 / edge_ch): the caller draws them with torch's dropout on
+// [E_ll][64] and [E_rr][64] tensors of ones (the reference's shapes and consumption order, rigid_docking_model.py:236-237,
+// 263-265); this kernel turns the two factor tensors (0 | 1 / (1 - p)) into the packed words the edge kernels read, in the
+// library's edge order.  16 lanes per edge (one float4 each), 4 edges per wave; a torch formulation of the same packing
+// moved ~1 GB per mask pair and layer at 64 x (300, 300) (int64 intermediates), this one reads the factors once.
+__global__ __launch_bounds__(EQD_BLOCK) void k_dropout_pack(int n_edges, int e_ll, const float* __restrict__ f_ll,
+                                                            const float* __restrict__ f_rr,
+                                                            const int64_t* __restrict__ perm,
+                                                            uint32_t* __restrict__ words) {
+    const int lane = threadIdx.x & 63, sub = lane >> 4, l15 = lane & 15;
+    const int e = (int)((blockIdx.x * (size_t)EQD_BLOCK + threadIdx.x) >> 6) * 4 + sub;
+    const bool live = e < n_edges;
+    const int raw = perm ? (int)perm[live ? e : 0] : (live ? e : 0);
+    const float* row = raw < e_ll ? f_ll + (size_t)raw * 64 : f_rr + (size_t)(raw - e_ll) * 64;
+    const float4 v = *(const float4*)&row[4 * l15];
+    int bits = ((v.x > 0.f ? 1 : 0) | (v.y > 0.f ? 2 : 0) | (v.z > 0.f ? 4 : 0) | (v.w > 0.f ? 8 : 0)) << (4 * (l15 & 7));
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) bits |= __shfl_xor(bits, m);
+    if (live && (l15 & 7) == 0) words[(size_t)e * 2 + (l15 >> 3)] = (uint32_t)bits;
+}
+
+extern "C" int eqd_dropout_pack_edges(int n_edges, int e_ll, const float* factors_ll, const float* factors_rr,
+                                      const int64_t* perm, uint32_t* words, void* stream) {
+    if (n_edges < 0 || e_ll < 0 || e_ll > n_edges) {
+        eqd_set_error("eqd_dropout_pack_edges: bad edge counts (%d edges, %d ligand)", n_edges, e_ll);
+        return EQD_ERR_SHAPE;
+    }
+    if (n_edges == 0) return EQD_OK;
+    if (!words || (e_ll > 0 && !factors_ll) || (e_ll < n_edges && !factors_rr)) {
+        eqd_set_error("eqd_dropout_pack_edges: NULL argument");
+        return EQD_ERR_NULL;
+    }
+    if (((uintptr_t)factors_ll | (uintptr_t)factors_rr) & 15) {
+        eqd_set_error("eqd_dropout_pack_edges: factor tensors must be 16-byte aligned");
+        return EQD_ERR_UNSUPPORTED;
+    }
+    const int per_block = 4 * (EQD_BLOCK / 64);
+    hipLaunchKernelGGL(k_dropout_pack, dim3((n_edges + per_block - 1) / per_block), dim3(EQD_BLOCK), 0, (hipStream_t)stream,
+                       n_edges, e_ll, factors_ll, factors_rr, perm, words);
+    return eqd_check_launch("k_dropout_pack");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Graph construction / featurisation: compute_dig_kNN_graph of the reference
 // (src/utils/protein_utils.py:311-397), which is an O(N^2) Python double loop over scipy cdist calls plus per-node and
 // per-edge Python loops.  fp64 like the reference's numpy code, so that the neighbour sets and their order - the graph's

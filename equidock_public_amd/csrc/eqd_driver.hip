@@ -208,6 +208,88 @@ int drop_check(const EqdDropout* drop) {
     return EQD_OK;
 }
 
+// ---- library-drawn dropout masks (eqd_dropout_draw) ------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11), counter-based: element block i of array a under key *seed is
+// philox(counter = (lo(i), hi(i), j, a), key = (lo(seed), hi(seed))) - no state, any launch shape gives the same masks.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t* out) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// work items: [0, n_words) edge_z1 words, [n_words, 2 n_words) edge_ch words (4 Philox calls of 8 elements each), then
+// the groups of 8 floats of node and of head (one call each).  A call's four 32-bit words are eight 16-bit draws (low half
+// first); an element is KEPT when its draw >= thr = round(p * 2^16) (p = 0.25, the published family's value, is exact).
+// (32-bit draws - twice the calls - cost 190 us per step at 64 x (300, 300), 2 % of it: the integer multiplies of the ten
+// rounds are quarter rate.)
+__global__ __launch_bounds__(EQD_BLOCK) void k_dropout_draw(const unsigned long long* __restrict__ seed, uint32_t thr,
+                                                            float scale, size_t n_words, uint32_t* __restrict__ edge_z1,
+                                                            uint32_t* __restrict__ edge_ch, size_t n_node,
+                                                            float* __restrict__ node, size_t n_head,
+                                                            float* __restrict__ head) {
+    const unsigned long long s = seed[0];
+    const uint32_t k0 = (uint32_t)s, k1 = (uint32_t)(s >> 32);
+    const size_t gn = (n_node + 7) >> 3, gh = (n_head + 7) >> 3;
+    const size_t total = 2 * n_words + gn + gh;
+    for (size_t w = (size_t)blockIdx.x * EQD_BLOCK + threadIdx.x; w < total; w += (size_t)gridDim.x * EQD_BLOCK) {
+        uint32_t r[4];
+        if (w < 2 * n_words) {
+            const uint32_t arr = w < n_words ? 0u : 1u;
+            const size_t i = arr ? w - n_words : w;
+            uint32_t bits = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                philox4x32_10((uint32_t)i, (uint32_t)((unsigned long long)i >> 32), (uint32_t)j, arr, k0, k1, r);
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    bits |= (((r[b] & 0xffffu) >= thr ? 1u : 0u) | ((r[b] >> 16) >= thr ? 2u : 0u)) << (8 * j + 2 * b);
+            }
+            (arr ? edge_ch : edge_z1)[i] = bits;
+        } else {
+            const bool hd = w >= 2 * n_words + gn;
+            const size_t i = w - 2 * n_words - (hd ? gn : 0), n = hd ? n_head : n_node;
+            float* __restrict__ dst = hd ? head : node;
+            philox4x32_10((uint32_t)i, (uint32_t)((unsigned long long)i >> 32), 0u, hd ? 3u : 2u, k0, k1, r);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (8 * i + 2 * b < n) dst[8 * i + 2 * b] = (r[b] & 0xffffu) >= thr ? scale : 0.f;
+                if (8 * i + 2 * b + 1 < n) dst[8 * i + 2 * b + 1] = (r[b] >> 16) >= thr ? scale : 0.f;
+            }
+        }
+    }
+}
+
+extern "C" int eqd_dropout_draw(const EqdModelDesc* m, const EqdGraph* g, float p, const uint64_t* seed, uint32_t* edge_z1,
+                                uint32_t* edge_ch, float* node, float* head, void* stream) {
+    if (!m || !g || !seed || !edge_z1 || !edge_ch || !node || !head) {
+        eqd_set_error("eqd_dropout_draw: NULL argument");
+        return EQD_ERR_NULL;
+    }
+    if (!(p > 0.f && p < 1.f)) {
+        eqd_set_error("eqd_dropout_draw: need 0 < p < 1 (p = %g)", p);
+        return EQD_ERR_UNSUPPORTED;
+    }
+    const Dims D = make_dims(m, g);
+    const size_t n_words = (size_t)D.L * D.E * 2;
+    const size_t n_node = (size_t)D.N * D.d0 + (size_t)(D.L - 1) * D.N * D.dh, n_head = (size_t)D.N * 64;
+    const size_t total = 2 * n_words + (n_node + 7) / 8 + (n_head + 7) / 8;
+    if (total == 0) return EQD_OK;
+    uint32_t thr = (uint32_t)((double)p * 65536.0 + 0.5);
+    thr = thr < 1 ? 1 : (thr > 65535 ? 65535 : thr);
+    size_t blocks = (total + EQD_BLOCK - 1) / EQD_BLOCK;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(k_dropout_draw, dim3((unsigned)blocks), dim3(EQD_BLOCK), 0, (hipStream_t)stream,
+                       (const unsigned long long*)seed, thr, 1.f / (1.f - p), n_words, edge_z1, edge_ch, n_node, node, n_head,
+                       head);
+    return eqd_check_launch("k_dropout_draw");
+}
+
 __global__ void k_mul_inplace(float* __restrict__ y, const float* __restrict__ m, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] *= m[i];
 }
@@ -536,7 +618,7 @@ extern "C" int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const
             // pass over the h rows, less per layer.  (With the four-wave kernels of small batches this was measured
             // slower: 46 vs 33 us, the five projections then run one after the other instead of side by side; layer 0's
             // 69-wide chain stays on those kernels at every size, so it never carries projections.)
-            proj_in_chain = l + 1 < D.L && d == 64 && D.d_in(l + 1) == 64 && D.dh == 64 && eqd_rows_resident(N) && !drop &&
+            proj_in_chain = l + 1 < D.L && d == 64 && D.d_in(l + 1) == 64 && D.dh == 64 && eqd_rows_resident(N) &&
                             2 + (m->cross_msgs ? 5 : 2) <= EQD_CHAIN_MAXJOBS;
             if (proj_in_chain) {
                 cj[1].out_local = 1;
@@ -636,7 +718,6 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
     auto dh_job = [&](int l) -> EqdLinJob {
         const float* const* p = params + (size_t)EQD_PARAMS_PER_LAYER * l;
         const int d = D.d_in(l);
-        const LayerSaved& Ls = S.lay[l];
         // dH(0) only feeds the embedding gradient: its node-feature columns (d_emb .. d0 - 1) are not computed
         EqdLinJob j = lin_job(N, l == 0 ? m->d_emb : d, dHof(l), d, slope, eps);
         int ns = 0;

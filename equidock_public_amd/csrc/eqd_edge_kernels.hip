@@ -860,6 +860,7 @@ union alignas(16) EdgeAttnFwdSmem {
     AttnFwdSmem<4> att[2];
     __device__ EdgeAttnFwdSmem() {}
 };
+template <bool DROP>
 __global__ __launch_bounds__(64 * FWD_WAVES) void k_edge_attn_fwd(EqdGraph G, EqdEdgeParams P, int n_edge,
                                                                    const float* __restrict__ Pn,
                                                                    const float* __restrict__ Qn,
@@ -873,7 +874,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void k_edge_attn_fwd(EqdGraph G, Eq
                                                                    float* __restrict__ lse) {
     __shared__ EdgeAttnFwdSmem S;
     if ((int)blockIdx.x < n_edge) {
-        edge_fwd_body<FWD_WAVES, false>(S.edge, G, P, (int)blockIdx.x, n_edge, Pn, Qn, x, aggr_msg, x_new);
+        edge_fwd_body<FWD_WAVES, false, DROP>(S.edge, G, P, (int)blockIdx.x, n_edge, Pn, Qn, x, aggr_msg, x_new);
     } else {
         const int half = (int)threadIdx.x >> 8;
         attn_fwd_body<4, true, 1>(S.att[half], G, (int)blockIdx.x - n_edge, half, (int)threadIdx.x & 255, 64, q, k, v,
@@ -927,7 +928,7 @@ extern "C" int eqd_edge_message_fwd(const EqdGraph* g, const EqdEdgeParams* p, c
 int eqd_edge_attn_fused(const EqdGraph* g, const EqdEdgeParams* p, int d_att, const float* q, const float* k, const float* v) {
     const char* f = getenv("EQD_FUSE_FWD");
     if (f && f[0] == '0' && f[1] == 0) return 0;
-    if (p->bf16 || p->drop_z1 || d_att != 64 || g->n_tiles <= 0 || g->n_att_items <= 0) return 0;
+    if (p->bf16 || d_att != 64 || g->n_tiles <= 0 || g->n_att_items <= 0) return 0;
     if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) != 0) return 0;
     const int n_edge = edge_grid(g->n_tiles, FWD_WAVES, 1);
     return n_edge + g->n_att_items <= eqd_num_cus();
@@ -943,8 +944,14 @@ int eqd_edge_attn_fwd(const EqdGraph* g, const EqdEdgeParams* p, const float* P,
         return eqd_edge_message_fwd(g, p, P, Q, x, aggr_msg, x_new, st);
     }
     const int n_edge = edge_grid(g->n_tiles, FWD_WAVES, 1);
-    hipLaunchKernelGGL(k_edge_attn_fwd, dim3(n_edge + g->n_att_items), dim3(64 * FWD_WAVES), 0, st, *g, *p, n_edge, P, Q, x,
-                       aggr_msg, x_new, q, k, v, att_out, lse);
+    const int drop = edge_drop_mode(p, "eqd_edge_attn_fwd");
+    if (drop < 0) return EQD_ERR_NULL;
+    if (drop)
+        hipLaunchKernelGGL(k_edge_attn_fwd<true>, dim3(n_edge + g->n_att_items), dim3(64 * FWD_WAVES), 0, st, *g, *p, n_edge, P,
+                           Q, x, aggr_msg, x_new, q, k, v, att_out, lse);
+    else
+        hipLaunchKernelGGL(k_edge_attn_fwd<false>, dim3(n_edge + g->n_att_items), dim3(64 * FWD_WAVES), 0, st, *g, *p, n_edge, P,
+                           Q, x, aggr_msg, x_new, q, k, v, att_out, lse);
     return eqd_check_launch("k_edge_attn_fwd");
 }
 

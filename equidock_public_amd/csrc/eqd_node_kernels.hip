@@ -453,7 +453,6 @@ static bool rw_eligible(const EqdChainJob* jobs, int njobs, int rows) {
         const EqdChainJob& C = jobs[i];
         const EqdLinJob& J = C.lin;
         if (J.M != 64 || J.rows != rows || C.out_local >= LIN_LOCALS) return false;
-        if (J.mul) return false;      // dropout factors (training mode): only the four-wave kernels apply them
         if ((J.bf16 != 0) != (jobs[0].lin.bf16 != 0)) return false;
         // (no alignment condition: rows are read with 16-byte loads at 4-byte alignment - gfx950 runs global memory in
         // unaligned-access mode - which is what the 69-wide h0 rows need anyway)

@@ -287,6 +287,15 @@ __device__ __forceinline__ void rw_epi_finish(const JobW& W, bool tp, const f32x
 #pragma unroll
             for (int b = 0; b < 4; ++b) v[a][b] = lrelu(v[a][b], slope);
     }
+    if (const float* const jmul = jw_p<const float>(W, LJ(mul))) {      // dropout factors (training mode only)
+        const float* mp = jmul + (size_t)(rv ? rowi : rows - 1) * jw_i(W, LJ(ld_mul));
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const f32x4 mm = *(const EQD_GAS f4v*)(mp + ft[a]);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) v[a][b] *= mm[b];
+        }
+    }
     if (has_ln) {
         float* const jpre = jw_p<float>(W, LJ(pre_ln));
         const int ld_pre = jw_i(W, LJ(ld_pre));      // (descriptor reads are wave operations: never under a lane predicate)
@@ -407,7 +416,21 @@ __device__ __forceinline__ void rw_lnbwd_finish(const JobW& W, const f32x4 (&yin
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b)
-            z[a][b] = rv ? rstd * (dx[a][b] - s1 - xh[a][b] * s2) * lrelu_grad(y[a][b], slope) : 0.f;
+            z[a][b] = rv ? rstd * (dx[a][b] - s1 - xh[a][b] * s2) : 0.f;
+    if (const float* const jmul = jw_p<const float>(W, LJ(mul))) {      // dropout factors of the forward (training mode):
+        const float* mp = jmul + (size_t)(rv ? rowi : rows - 1) * jw_i(W, LJ(ld_mul)) + 4 * g;      // d LeakyReLU * keep * s
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const f32x4 mm = *(const EQD_GAS f4v*)(mp + 16 * a);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) z[a][b] *= lrelu_grad(y[a][b], slope) * mm[b];
+        }
+    } else {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) z[a][b] *= lrelu_grad(y[a][b], slope);
+    }
     float* const jY = jw_p<float>(W, LJ(Y));
     const int ldy = jw_i(W, LJ(ldy));
     if (jY && rv) {

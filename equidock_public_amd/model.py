@@ -216,8 +216,39 @@ class DropoutMasks:
         return d
 
     @staticmethod
+    def draw_library(iegmn, packed):
+        """args['hip_dropout_masks'] = 'library' (not a reference option): the masks of one forward from ONE launch of
+        eqd_dropout_draw - counter-based (Philox4x32-10), keyed by a 64-bit word drawn on the device from torch's generator
+        (so torch.manual_seed still fixes the run, and a replayed hipGraph of the step sees fresh masks every replay).
+        Same Bernoulli law as nn.Dropout, not torch's random stream; no [E, 64] tensors are materialised (the default
+        'torch' source moves ~9 GB per step through HBM for them at 64 x (300, 300))."""
+        p = float(iegmn.args['dropout'])
+        dev = packed.x0.device
+        desc, gs = iegmn._desc(), packed.c_struct()
+        L, E, N = iegmn.n_lays, packed.n_edges, packed.n_nodes
+        d0 = iegmn.args['residue_emb_dim'] + (5 if iegmn.use_mean_node_features else 0)
+        dh = iegmn.args['iegmn_lay_hid_dim']
+        seed = torch.randint(-2 ** 63, 2 ** 63 - 1, (1,), dtype=torch.int64, device=dev)
+        edge_z1 = torch.empty(L, E, 2, dtype=torch.int32, device=dev)
+        edge_ch = torch.empty(L, E, 2, dtype=torch.int32, device=dev)
+        node = torch.empty(N * d0 + (L - 1) * N * dh, dtype=torch.float32, device=dev)
+        head = torch.empty(N, 64, dtype=torch.float32, device=dev)
+        lib = _lib.load_library()
+        with _lib.device_guard(dev):
+            _lib.check(lib.eqd_dropout_draw(C.byref(desc), C.byref(gs), C.c_float(p), _lib.ptr(seed), _lib.ptr(edge_z1),
+                                            _lib.ptr(edge_ch), _lib.ptr(node), _lib.ptr(head), _lib.stream_ptr(dev)))
+        out = DropoutMasks(p, edge_z1, edge_ch, node, head)
+        out.seed = seed
+        return out
+
+    @staticmethod
     def draw(iegmn, g, packed):
         import torch.nn.functional as F
+        src = iegmn.args.get('hip_dropout_masks', 'torch')
+        if src == 'library':
+            return DropoutMasks.draw_library(iegmn, packed)
+        if src != 'torch':
+            raise NotImplementedError(f"hip_dropout_masks={src!r}: 'torch' (nn.Dropout's stream) or 'library' (eqd_dropout_draw)")
         p = float(iegmn.args['dropout'])
         dev = packed.x0.device
         mdev = torch.device(getattr(iegmn, 'dropout_mask_device', None) or dev)
@@ -227,32 +258,55 @@ class DropoutMasks:
         d0 = iegmn.args['residue_emb_dim'] + (5 if iegmn.use_mean_node_features else 0)
         dh = iegmn.args['iegmn_lay_hid_dim']
 
-        def factors(rows, width):        # what nn.Dropout multiplies a [rows, width] activation by: 0 or 1 / (1 - p)
-            return F.dropout(torch.ones(rows, width, dtype=torch.float32, device=mdev), p, True)
-        weights = (2 ** torch.arange(32, dtype=torch.int64, device=mdev)).view(1, 1, 32)
+        # one tensor of ones serves every draw (a mask depends on the generator state and the SHAPE only)
+        n_ones = max(e_ll, e_rr, 1) * 64
+        n_ones = max(n_ones, max(nl, nr, 1) * max(d0, dh))
+        ones = getattr(packed, '_dropout_ones', None)
+        if ones is None or ones.device != mdev or ones.numel() < n_ones:
+            ones = packed._dropout_ones = torch.ones(n_ones, dtype=torch.float32, device=mdev)
 
-        def bits(fl, fr):                # two [E, 64] factor tensors (ll, rr edges) -> [E_ll + E_rr, 2] packed words
-            keep = (torch.cat([fl, fr], 0) > 0).view(-1, 2, 32).to(torch.int64)
-            return (keep * weights).sum(-1).to(torch.int32)      # (int64 -> int32 wraps: the bit pattern of the uint32)
-        ez, ec, nodes = [], [], []
-        for l in range(iegmn.n_lays):
+        def factors(rows, width):        # what nn.Dropout multiplies a [rows, width] activation by: 0 or 1 / (1 - p)
+            return F.dropout(ones[:rows * width].view(rows, width), p, True)
+        E, L = e_ll + e_rr, iegmn.n_lays
+        on_dev = mdev == dev and getattr(iegmn, 'dropout_pack', 'kernel') == 'kernel'
+        if on_dev:                       # packed straight into the library's edge order by eqd_dropout_pack_edges
+            edge_z1 = torch.empty(L, E, 2, dtype=torch.int32, device=dev)
+            edge_ch = torch.empty(L, E, 2, dtype=torch.int32, device=dev)
+            lib = _lib.load_library()
+            stream = _lib.stream_ptr(dev)
+            perm = packed.edge_perm
+            assert perm.dtype == torch.int64 and perm.is_contiguous() and perm.numel() == E
+
+            def pack(fl, fr, out):
+                with _lib.device_guard(dev):
+                    _lib.check(lib.eqd_dropout_pack_edges(E, e_ll, _lib.ptr(fl), _lib.ptr(fr), _lib.ptr(perm), _lib.ptr(out),
+                                                          stream))
+        else:                            # the same packing in torch operators (any device; what the tests compare against)
+            weights = (2 ** torch.arange(32, dtype=torch.int64, device=mdev)).view(1, 1, 32)
+            ez, ec = [], []
+
+            def pack(fl, fr, out):       # two [E, 64] factor tensors (ll, rr edges) -> [E_ll + E_rr, 2] packed words
+                keep = (torch.cat([fl, fr], 0) > 0).view(-1, 2, 32).to(torch.int64)
+                out.append((keep * weights).sum(-1).to(torch.int32))      # (int64 -> int32 wraps: the uint32's bit pattern)
+        nodes = []
+        for l in range(L):
             d = d0 if l == 0 else dh
             zl, zr = factors(e_ll, 64), factors(e_rr, 64)            # edge_mlp.1: ligand edges first
+            pack(zl, zr, edge_z1[l] if on_dev else ez)
+            del zl, zr
             cl, cr = factors(e_ll, 64), factors(e_rr, 64)            # coors_mlp.1
-            ml, mr = factors(nl, d), factors(nr, d)                  # node_mlp.1
-            ez.append(bits(zl, zr))
-            ec.append(bits(cl, cr))
-            nodes.append(torch.cat([ml, mr], 0).reshape(-1))
-        head = torch.empty(nl + nr, 64, dtype=torch.float32, device=mdev)
-        lo, ro = 0, nl
+            pack(cl, cr, edge_ch[l] if on_dev else ec)
+            del cl, cr
+            nodes += [factors(nl, d).reshape(-1), factors(nr, d).reshape(-1)]      # node_mlp.1
+        head_l, head_r = [], []
         for a, b in zip(lc, rc):                                       # per pair: receptor rows, then ligand rows
-            head[ro:ro + b] = factors(b, 64)
-            head[lo:lo + a] = factors(a, 64)
-            lo += a
-            ro += b
-        perm = packed.edge_perm.to(mdev).long()                        # packed edge i = raw edge perm[i]
-        edge_z1 = torch.stack([t[perm] for t in ez]).to(dev).contiguous()
-        edge_ch = torch.stack([t[perm] for t in ec]).to(dev).contiguous()
+            head_r.append(factors(b, 64))
+            head_l.append(factors(a, 64))
+        head = torch.cat(head_l + head_r, 0)
+        if not on_dev:
+            perm = packed.edge_perm.to(mdev).long()                    # packed edge i = raw edge perm[i]
+            edge_z1 = torch.stack([t[perm] for t in ez]).to(dev).contiguous()
+            edge_ch = torch.stack([t[perm] for t in ec]).to(dev).contiguous()
         return DropoutMasks(p, edge_z1, edge_ch, torch.cat(nodes).to(dev).contiguous(), head.to(dev).contiguous())
 
 

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define EQD_ABI_VERSION 4
+#define EQD_ABI_VERSION 5
 #define EQD_TILE_EDGES 32   /* edges per node-aligned tile (max supported in-degree) */
 #define EQD_ATT_BLOCK 32    /* nodes per cross-attention work item */
 #define EQD_MAX_SRC 6
@@ -124,6 +124,26 @@ typedef struct EqdDropout {
     const float* node;         /* layer 0: [n_nodes][d0], then layers 1..: [n_nodes][64] each; entries 0 or 1 / (1 - p) */
     const float* head;         /* [n_nodes][64] mlp_h_mean_ROT.1; entries 0 or 1 / (1 - p) */
 } EqdDropout;
+
+/* Packs the edge-level keep masks of one layer: factors_ll [e_ll][64], factors_rr [n_edges - e_ll][64] are what
+ * nn.Dropout multiplies the ligand-edge / receptor-edge activations by (0 or 1 / (1 - p); torch's dropout applied to ones in
+ * the reference's order, ligand edges first: rigid_docking_model.py:236-237, 263-265), in the RAW edge order of the two
+ * graphs; perm [n_edges] (device, int64 - a torch index tensor; NULL = identity): library edge i = raw edge perm[i], raw edges numbered ligand graph first.
+ * words [n_edges][2]: one layer of EqdDropout.edge_z1 / edge_ch.  Factor tensors 16-byte aligned. */
+/* Library-drawn masks - the alternative to masks drawn by the caller with torch's generator (above): fills the four arrays
+ * of an EqdDropout for model `m` on graph `g` in ONE launch, counter-based (Philox4x32-10 keyed by *seed, a DEVICE word the
+ * caller draws from its own generator: the step stays capturable in a hipGraph and every replay sees fresh masks).  A Philox
+ * call yields eight 16-bit draws (word 0 low half, word 0 high half, word 1 low half, ...); an element is kept when its draw
+ * >= round(p 2^16).  Float arrays (a = 2 node, 3 head; kept entries = 1 / (1 - p)): element i takes draw (i mod 8) of
+ * philox(counter = (i / 8 [lo, hi], 0, a), key = *seed); bit b of packed word w of the edge arrays (a = 0 edge_z1, 1 edge_ch)
+ * takes draw (b mod 8) of philox(counter = (w [lo, hi], b / 8, a)).  The Bernoulli(1 - p) law of nn.Dropout (p quantised to
+ * 2^-16), NOT torch's random stream: parity with the reference is statistical for these masks and exact for any masks passed
+ * in (tests: the masks drawn here, handed to the torch restatement).  No [E][64] tensor is materialised. */
+int eqd_dropout_draw(const EqdModelDesc* m, const EqdGraph* g, float p, const uint64_t* seed, uint32_t* edge_z1,
+                     uint32_t* edge_ch, float* node, float* head, void* stream);
+
+int eqd_dropout_pack_edges(int n_edges, int e_ll, const float* factors_ll, const float* factors_rr,
+                           const int64_t* perm, uint32_t* words, void* stream);
 
 /* Parameter table: device pointers in this fixed order.  Per layer i (base = 19*i):
  *   0 edge_mlp.0.weight [64, 2*d_in+42]   1 edge_mlp.0.bias [64]

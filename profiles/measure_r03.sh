@@ -3,6 +3,8 @@
 # steps:  tests | testsfast | testsbig | test:<pytest -k expression>
 #         bench:<W>[:bf16][:full]     bench.py line of workload W (":full" keeps the CPU baseline and the roofline part)
 #         eager:<W>[:bf16]            the same line with --eager
+#         drop:<W>[:bf16][:torchpack|:lib]  the line with --dropout 0.25 (training-mode masks drawn every step;
+#                                     lib = --dropout-masks library, torchpack = mask packing in torch operators)
 #         prof:<W>[:bf16]             rocprofv3 --kernel-trace --stats table + timeline
 #         pmc:<W>[:bf16]              MfmaUtil, MFMA ops, FETCH_SIZE, WRITE_SIZE (one counter per rocprofv3 pass)
 #         traffic:<W>[:bf16]          FETCH_SIZE, WRITE_SIZE only
@@ -32,6 +34,10 @@ for what in "$@"; do
     python -m pytest tests -m gpu -q -s --tb=short -k "$W" 2>&1 | grep -v Warning > $O/${TAG}_pytest_gpu_sel.log ;;
   bench)
     python bench.py --workload $W $DT $ST $FULL > $O/${TAG}_bench_${W}${SUF}.log 2>&1 ;;
+  drop)      # training with dropout 0.25 (masks drawn per step inside the graph); drop:<W>:torchpack = packing in torch ops
+    PK=""; MS="torch"; [ "$opt1" = "torchpack" -o "$opt2" = "torchpack" ] && PK="torch"
+    [ "$opt1" = "lib" -o "$opt2" = "lib" ] && MS="library" && PK="lib"
+    EQD_BENCH_DROPOUT_PACK=${PK/lib/} python bench.py --workload $W $DT $ST --dropout 0.25 --dropout-masks $MS > $O/${TAG}_bench_${W}${SUF}_dropout${PK}.log 2>&1 ;;
   eager)
     python bench.py --eager --workload $W $DT $ST --no-cpu-baseline --no-roofline > $O/${TAG}_bench_${W}${SUF}_eager.log 2>&1 ;;
   prof)
@@ -41,6 +47,14 @@ for what in "$@"; do
     DB=$(find /tmp/prof_$W$SUF -name "*.db" | head -1)
     python $R/profiles/summarize.py $DB $O/${TAG}_kernels_$W$SUF.md "round 3 (${TAG}): workload $W${SUF}" "rocprofv3 --kernel-trace --stats -- python bench.py --workload $W $DT --steps 20 --warmup 5 --no-cpu-baseline --no-roofline" > $O/${TAG}_kernels_$W$SUF.txt 2>&1
     python $R/profiles/timeline.py $DB 130 > $O/${TAG}_timeline_$W$SUF.txt 2>&1
+    cd $R ;;
+  profdrop)      # the kernel table of a training step with dropout 0.25; profdrop:<W>[:bf16][:lib]
+    MS="torch"; [ "$opt1" = "lib" -o "$opt2" = "lib" ] && MS="library"
+    cd /tmp; export TMPDIR=/tmp
+    rm -rf /tmp/profd_$W$SUF
+    rocprofv3 --kernel-trace --stats -d /tmp/profd_$W$SUF -o h -- python $R/bench.py --workload $W $DT --steps 20 --warmup 5 --dropout 0.25 --dropout-masks $MS > $O/${TAG}_profdrop_$W$SUF.log 2>&1
+    DB=$(find /tmp/profd_$W$SUF -name "*.db" | head -1)
+    python $R/profiles/summarize.py $DB $O/${TAG}_kernels_${W}${SUF}_dropout_$MS.md "round 3 (${TAG}): workload $W${SUF}, dropout 0.25, masks: $MS" "rocprofv3 --kernel-trace --stats -- python bench.py --workload $W $DT --steps 20 --warmup 5 --dropout 0.25 --dropout-masks $MS" > /dev/null 2>&1
     cd $R ;;
   pmc|traffic)
     cd /tmp; export TMPDIR=/tmp

@@ -989,6 +989,190 @@ def check_dropout_training(dev):
         ev0 = n_ev(g, epoch=0)
     for a, b in zip(ev, ev0):
         assert torch.equal(cat_out(a), cat_out(b))
+    # (d) the packing kernel (eqd_dropout_pack_edges: factors -> keep bits in the library's edge order) against the same
+    # packing written in torch operators, same generator state
+    from equidock_public_amd.model import DropoutMasks
+    ie = n_hip.iegmn_original
+    packed = g.pack()
+    masks = []
+    for how in ('kernel', 'torch'):
+        ie.dropout_pack = how
+        torch.manual_seed(77)
+        if torch.device(dev).type == 'cuda':
+            torch.cuda.manual_seed(77)
+        masks.append(DropoutMasks.draw(ie, g, packed))
+    sync(dev)
+    for nm in ('edge_z1', 'edge_ch', 'node', 'head'):
+        assert torch.equal(getattr(masks[0], nm), getattr(masks[1], nm)), f'dropout masks: {nm} differs between the packings'
+    kept = np.unpackbits(masks[0].edge_z1.cpu().numpy().view(np.uint8)).mean()
+    assert abs(kept - (1.0 - float(args['dropout']))) < 0.02, kept
+
+
+def philox4x32_10(ctr, key):
+    """Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11), vectorised:
+    ctr [n, 4] uint32, key [2] or [n, 2] uint32 -> [n, 4] uint32.  The restatement eqd_dropout_draw is checked against."""
+    c = [np.asarray(ctr, dtype=np.uint64)[:, i].copy() for i in range(4)]
+    key = np.asarray(key, dtype=np.uint64)
+    k0, k1 = (key[..., 0].copy(), key[..., 1].copy())
+    m32 = np.uint64(0xffffffff)
+    for _ in range(10):
+        p0, p1 = np.uint64(0xD2511F53) * c[0], np.uint64(0xCD9E8D57) * c[2]
+        c = [(p1 >> np.uint64(32)) ^ c[1] ^ k0, p1 & m32, (p0 >> np.uint64(32)) ^ c[3] ^ k1, p0 & m32]
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & m32, (k1 + np.uint64(0xBB67AE85)) & m32
+    return np.stack(c, 1).astype(np.uint32)
+
+
+def library_dropout_masks(seed, p, L, E, n_node, n_head):
+    """What eqd_dropout_draw must produce (include/equidock_hip.h): (edge_z1 [L*E*2] uint32, edge_ch, node floats, head)."""
+    seed = int(seed) & (2 ** 64 - 1)
+    key = np.array([seed & 0xffffffff, seed >> 32], dtype=np.uint64)
+    thr = min(max(int(float(np.float32(p)) * 65536.0 + 0.5), 1), 65535)
+    scale = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
+    out = []
+    nw = L * E * 2
+
+    def halves(r):                       # [n, 4] uint32 -> [n, 8] 16-bit draws: word 0 low, word 0 high, word 1 low, ...
+        return np.stack([r & np.uint32(0xffff), r >> np.uint32(16)], 2).reshape(r.shape[0], 8)
+    for arr in (0, 1):
+        w = np.repeat(np.arange(nw, dtype=np.uint64), 4)
+        j = np.tile(np.arange(4, dtype=np.uint64), nw)
+        ctr = np.stack([w & np.uint64(0xffffffff), w >> np.uint64(32), j, np.full_like(w, arr)], 1)
+        keep = (halves(philox4x32_10(ctr, key)) >= thr).reshape(nw, 32)      # bit 8 j + 2 b + h = half h of word b of call j
+        out.append((keep.astype(np.uint64) << np.arange(32, dtype=np.uint64)).sum(1).astype(np.uint32))
+    for arr, n in ((2, n_node), (3, n_head)):
+        q = np.arange((n + 7) // 8, dtype=np.uint64)
+        ctr = np.stack([q & np.uint64(0xffffffff), q >> np.uint64(32), np.zeros_like(q), np.full_like(q, arr)], 1)
+        keep = (halves(philox4x32_10(ctr, key)) >= thr).reshape(-1)[:n]
+        out.append(np.where(keep, scale, np.float32(0)).astype(np.float32))
+    return out
+
+
+def check_dropout_library(dev):
+    """args['hip_dropout_masks'] = 'library': masks drawn by eqd_dropout_draw.
+      (a) Philox4x32-10 known answers (Random123's kat_vectors) for the restatement above;
+      (b) the kernel's four arrays are bit-identical to the restatement; the same torch seed gives the same masks, the next
+          draw different ones; keep rates are 1 - p;
+      (c) whole model, training mode: the HIP path with library-drawn masks against the torch-operator restatement fed the
+          SAME masks (nn.Dropout's functional patched to hand them out in the reference's consumption order) - outputs and
+          every parameter gradient."""
+    import json
+    import os
+    from equidock_public_amd import config
+    from equidock_public_amd.model import DropoutMasks
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for c, k, want in kat:
+        got = philox4x32_10(np.array([c], dtype=np.uint64), np.array(k, dtype=np.uint64))[0]
+        assert tuple(int(v) for v in got) == want, (c, k, [hex(int(v)) for v in got])
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'variants.npz'), allow_pickle=False)
+    meta = json.loads(str(z['meta']))
+    v = meta['variants']['dropout_train']
+    args = dict(v['args'], device=torch.device(dev), hip_dropout_masks='library')
+    p = float(args['dropout'])
+    sd = config.seeded_state_dict(args, meta['init_seed'], meta['rot_scale'])
+    raw = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('in_')}
+    raw['lig_counts'], raw['rec_counts'] = [int(c) for c in z['in_lig_counts']], [int(c) for c in z['in_rec_counts']]
+    g = G.batch_pairs(pairs_from_raw(raw)).to(dev)
+    packed = g.pack()
+
+    def seed_all(s):
+        torch.manual_seed(s)
+        if torch.device(dev).type == 'cuda':
+            torch.cuda.manual_seed(s)
+    # (b)
+    net = build_model(args, sd, dev)
+    net.train(True)
+    ie = net.iegmn_original
+    seed_all(31)
+    m1 = DropoutMasks.draw(ie, g, packed)
+    m2 = DropoutMasks.draw(ie, g, packed)
+    seed_all(31)
+    m3 = DropoutMasks.draw(ie, g, packed)
+    sync(dev)
+    L, E, N = ie.n_lays, packed.n_edges, packed.n_nodes
+    want = library_dropout_masks(int(m1.seed.item()), p, L, E, m1.node.numel(), N * 64)
+    for nm, w in zip(('edge_z1', 'edge_ch', 'node', 'head'), want):
+        got = getattr(m1, nm).cpu().numpy().reshape(-1)
+        assert np.array_equal(got.view(w.dtype), w), f'eqd_dropout_draw: {nm} differs from the Philox restatement'
+        assert torch.equal(getattr(m1, nm), getattr(m3, nm)), f'{nm}: same seed, different masks'
+        assert not torch.equal(getattr(m1, nm), getattr(m2, nm)), f'{nm}: consecutive draws gave the same masks'
+    for nm in ('edge_z1', 'edge_ch'):
+        kept = np.unpackbits(getattr(m1, nm).cpu().numpy().view(np.uint8)).mean()
+        assert abs(kept - (1 - p)) < 0.01, (nm, kept)
+    for nm in ('node', 'head'):
+        a = getattr(m1, nm).cpu().numpy().reshape(-1)
+        assert set(np.unique(a)) <= {np.float32(0), np.float32(1) / (np.float32(1) - np.float32(p))}
+        assert abs((a > 0).mean() - (1 - p)) < 0.02, (nm, (a > 0).mean())
+    assert not torch.equal(m1.edge_z1, m1.edge_ch)
+
+    # (c) the masks in the order / layout nn.Dropout meets them in the reference (raw edge order, ligand graph first)
+    def reference_order(m):
+        e_ll = int(g._edges['ll'][0].numel())
+        perm = packed.edge_perm.cpu().numpy()
+        lc, rc = g._batch_nodes['ligand'], g._batch_nodes['receptor']
+        nl = sum(lc)
+        scale = 1.0 / (1.0 - p)
+        d0 = m.node.numel() // N - (L - 1) * 64
+        q, off = [], 0
+        for l in range(L):
+            d = d0 if l == 0 else 64
+            for arr in (m.edge_z1, m.edge_ch):
+                words = arr[l].cpu().numpy().view(np.uint32)                                    # [E, 2], library edge order
+                keep = ((words[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(E, 64).astype(np.float32)
+                rawk = np.empty_like(keep)
+                rawk[perm] = keep                                                               # library edge i = raw perm[i]
+                q += [torch.from_numpy(rawk[:e_ll] * scale).to(dev), torch.from_numpy(rawk[e_ll:] * scale).to(dev)]
+            nm_ = m.node[off:off + N * d].view(N, d)
+            off += N * d
+            q += [nm_[:nl], nm_[nl:]]
+        lo, ro = 0, nl
+        for a, b in zip(lc, rc):
+            q += [m.head[ro:ro + b], m.head[lo:lo + a]]
+            lo += a
+            ro += b
+        return q
+
+    def run(force_torch, queue=None):
+        net = build_model(args, sd, dev)
+        net.train(True)
+        ie = net.iegmn_original
+        ie._force_torch_path = force_torch
+        seed_all(meta['fwd_seed'])
+        if queue is None:
+            outs = net(g, epoch=0)
+        else:
+            import torch.nn.functional as F
+            real = F.dropout
+
+            def handed_out(x, p_=0.5, training=True, inplace=False):
+                mk = queue.pop(0)
+                assert training and mk.shape == x.shape, (mk.shape, x.shape)
+                return x * mk
+            F.dropout = handed_out
+            try:
+                outs = net(g, epoch=0)
+            finally:
+                F.dropout = real
+            assert not queue, f'{len(queue)} masks left over'
+        port.scalar_loss(outs).backward()
+        sync(dev)
+        return net, outs
+    n_hip, o_hip = run(False)
+    seed_all(meta['fwd_seed'])
+    masks = DropoutMasks.draw(n_hip.iegmn_original, g, packed)          # same generator state -> the masks of that forward
+    n_ref, o_ref = run(True, reference_order(masks))
+    for nm, a, b in zip(('lig', 'Yl', 'Yr', 'T', 'b'), o_hip, o_ref):
+        close(cat_out(a), cat_out(b), what=f'library-drawn dropout on {dev}: HIP path vs torch operators, {nm}')
+    gr = dict(n_ref.named_parameters())
+    w2 = wm = 0.0
+    for k, prm in n_hip.named_parameters():
+        e2, em = grad_err(prm.grad, gr[k].grad)
+        w2, wm = max(w2, e2), max(wm, em)
+    print(f'library-drawn dropout on {dev}: HIP path vs torch operators with the same masks: worst grad rel-L2 {w2:.2e}, '
+          f'max-abs/max {wm:.2e}')
+    assert w2 <= 5e-3 and wm <= 2e-2
 
 
 def check_standalone_layer(dev):

@@ -49,6 +49,13 @@ def test_dropout_training_through_the_kernels(dev):
     pc.check_dropout_training(dev)
 
 
+def test_dropout_masks_drawn_by_the_library(dev):
+    """hip_dropout_masks='library': eqd_dropout_draw vs its Philox restatement (bit-exact), then the model with those masks
+    vs the torch-operator restatement handed the same masks"""
+    from tests import parity_common as pc
+    pc.check_dropout_library(dev)
+
+
 @pytest.mark.parametrize('d', [64, 69, 80])
 def test_cross_attention(dev, d):
     from tests import parity_common as pc
@@ -107,6 +114,7 @@ def test_row_kernels_both_forms(dev, rowwave, monkeypatch):
     for name in ('D_degraded3', 'B_b3_dips8'):
         pc.check_model_case(dev, name)
     pc.check_model_bf16(dev, 'D_degraded3')
+    pc.check_dropout_library(dev)           # the dropout factors in each form's epilogue and LayerNorm backward
     names = pc.launch_names_of_a_step(dev, 'D_degraded3')
     assert ('k_rowwave' in names) == (rowwave == '1') and ('k_rowres' in names) == (rowwave == '2'), sorted(set(names))
     assert 'k_rowchain' in names

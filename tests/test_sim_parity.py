@@ -46,6 +46,10 @@ def test_dropout_training_through_the_kernels():
     pc.check_dropout_training(DEV)
 
 
+def test_dropout_masks_drawn_by_the_library():
+    pc.check_dropout_library(DEV)
+
+
 @pytest.mark.parametrize('d', [64, 69, 80])
 def test_cross_attention(d):
     pc.check_attention(DEV, d)
@@ -93,6 +97,7 @@ def test_row_kernels_both_forms(rowwave, monkeypatch):
     monkeypatch.setenv('EQD_ROWWAVE', rowwave)
     pc.check_linear(DEV)
     pc.check_model_case(DEV, 'D_degraded3')
+    pc.check_dropout_library(DEV)           # the dropout factors in each form's epilogue and LayerNorm backward
     names = pc.launch_names_of_a_step(DEV, 'D_degraded3')
     assert ('k_rowwave' in names) == (rowwave == '1') and ('k_rowres' in names) == (rowwave == '2'), sorted(set(names))
     assert 'k_rowchain' in names            # layer 0 (and everything under EQD_ROWWAVE=0)
