@@ -212,7 +212,8 @@ __device__ __forceinline__ void drop_load(const EqdEdgeParams& P, EdgeTileState<
 // Forward of one tile of 16*NB edges up to (and including) the coefficient. On return:
 //   xh = LayerNorm-normalised hidden (before the affine), m = msg, ch = coors_mlp hidden pre-activation.
 // If rbf_out != nullptr the 15 RBFs of each edge are also written there ([E][16]).
-template <int NB, bool DROP = false>
+// PRE: S.src / S.dst hold the tile's endpoints already (k_edge_bwd fetches them one tile ahead)
+template <int NB, bool DROP = false, bool PRE = false>
 __device__ __forceinline__ void edge_tile_forward(const EqdGraph& G, const EqdEdgeParams& P, const float* __restrict__ w1,
                                                   const float* __restrict__ w2, const float* __restrict__ wc1,
                                                   const float* __restrict__ vec, float* __restrict__ tile,
@@ -240,9 +241,11 @@ __device__ __forceinline__ void edge_tile_forward(const EqdGraph& G, const EqdEd
     for (int nb = 0; nb < NB; ++nb) {
         const int el = 16 * nb + l15;
         S.ev[nb] = el < S.ne;
-        const int ei = S.e0 + (S.ev[nb] ? el : 0);
-        S.src[nb] = G.src[ei];
-        S.dst[nb] = G.dst[ei];
+        if constexpr (!PRE) {
+            const int ei = S.e0 + (S.ev[nb] ? el : 0);
+            S.src[nb] = G.src[ei];
+            S.dst[nb] = G.dst[ei];
+        }
     }
     float xs[NB][3], xd[NB][3];
     float4 pv[NB][4], qv[NB][4];
@@ -532,7 +535,8 @@ __device__ __forceinline__ void chain64_bf(f32x4 (&out)[4][NB], const f32x4 (&in
 }
 
 // bf16 counterpart of edge_tile_forward (same outputs, same EdgeTileState)
-template <int NB, bool DROP = false>
+// PRE: S.src / S.dst hold the tile's endpoints already (k_edge_bwd fetches them one tile ahead)
+template <int NB, bool DROP = false, bool PRE = false>
 __device__ __forceinline__ void edge_tile_forward_bf(const EqdGraph& G, const EqdEdgeParams& P,
                                                      const unsigned short* __restrict__ w1,
                                                      const unsigned short* __restrict__ w2,
@@ -555,9 +559,11 @@ __device__ __forceinline__ void edge_tile_forward_bf(const EqdGraph& G, const Eq
     for (int nb = 0; nb < NB; ++nb) {
         const int el = 16 * nb + l15;
         S.ev[nb] = el < S.ne;
-        const int ei = S.e0 + (S.ev[nb] ? el : 0);
-        S.src[nb] = G.src[ei];
-        S.dst[nb] = G.dst[ei];
+        if constexpr (!PRE) {
+            const int ei = S.e0 + (S.ev[nb] ? el : 0);
+            S.src[nb] = G.src[ei];
+            S.dst[nb] = G.dst[ei];
+        }
     }
     float xs[NB][3], xd[NB][3];
     float4 pv[NB][4], qv[NB][4];
@@ -1101,6 +1107,19 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
     f32x4 gW2[2] = {f4zero(), f4zero()}, gWc1[2] = {f4zero(), f4zero()}, gW1a[1] = {f4zero()}, gW1b[1] = {f4zero()};
     const int n_tiles = (G.n_edges + 15) >> 4;
     const int n_super = (n_tiles + BWD_WAVES - 1) / BWD_WAVES;
+    // The endpoints of a tile's edges are fetched ONE ITERATION AHEAD: everything else the tile loads (coordinates, P / Q
+    // rows, the destination's incoming gradients) hangs off them, so an iteration starts with one round trip to memory
+    // instead of two (lanes beyond the tile read the tile's first edge, an empty tile edge 0 - like the tile forward).
+    int nx_src = 0, nx_dst = 0;
+    auto endpoints = [&](int it_) {
+        int e0 = 16 * (it_ * BWD_WAVES + wave), ne = G.n_edges - e0;
+        ne = ne < 0 ? 0 : (ne > 16 ? 16 : ne);
+        if (ne == 0) e0 = 0;
+        const int ei = e0 + (l15 < ne ? l15 : 0);
+        nx_src = G.src[ei];
+        nx_dst = G.dst[ei];
+    };
+    if ((int)blockIdx.x < n_super) endpoints((int)blockIdx.x);
     for (int it = blockIdx.x; it < n_super; it += gridDim.x) {
         const int t = it * BWD_WAVES + wave;
         EdgeTileState<1> S;
@@ -1109,6 +1128,9 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
         S.ne = G.n_edges - S.e0;
         S.ne = S.ne < 0 ? 0 : (S.ne > 16 ? 16 : S.ne);
         if (S.ne == 0) S.e0 = 0;
+        S.src[0] = nx_src;
+        S.dst[0] = nx_dst;
+        if (it + (int)gridDim.x < n_super) endpoints(it + (int)gridDim.x);
         f32x4 xh[4][1], m[4][1], ch[4][1];
         // incoming gradients of the tile's destination nodes: fetched before the forward recompute (unpredicated;
         // lanes beyond the tile use the clamped edge e0), consumed after it
@@ -1116,7 +1138,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
         float gxn[3];
         int r0, r1;
         {
-            const int d = G.dst[S.e0 + (l15 < S.ne ? l15 : 0)];
+            const int d = S.dst[0];
             r0 = G.rowptr[d];
             r1 = G.rowptr[d + 1];
 #pragma unroll
@@ -1125,9 +1147,9 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
             for (int mb = 0; mb < 4; ++mb) dag[mb] = *(const float4*)&d_aggr[(size_t)d * 64 + 16 * mb + 4 * g];
         }
         if constexpr (BF)
-            edge_tile_forward_bf<1, DROP>(G, P, sm.w1, sm.w2, sm.wc1, sm.vec, tile, Pn, Qn, x, lane, S, xh, m, ch);
+            edge_tile_forward_bf<1, DROP, true>(G, P, sm.w1, sm.w2, sm.wc1, sm.vec, tile, Pn, Qn, x, lane, S, xh, m, ch);
         else
-            edge_tile_forward<1, DROP>(G, P, sm.w1, sm.w2, sm.wc1, sm.vec, tile, Pn, Qn, x, lane, S, xh, m, ch, nullptr);
+            edge_tile_forward<1, DROP, true>(G, P, sm.w1, sm.w2, sm.wc1, sm.vec, tile, Pn, Qn, x, lane, S, xh, m, ch, nullptr);
         // ---- coordinate path ---------------------------------------------------------------------
         float invdeg = 0.f, dcoef = 0.f, dxr[3] = {0.f, 0.f, 0.f};
         {

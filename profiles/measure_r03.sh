@@ -8,6 +8,7 @@
 #         prof:<W>[:bf16]             rocprofv3 --kernel-trace --stats table + timeline
 #         pmc:<W>[:bf16]              MfmaUtil, MFMA ops, FETCH_SIZE, WRITE_SIZE (one counter per rocprofv3 pass)
 #         traffic:<W>[:bf16]          FETCH_SIZE, WRITE_SIZE only
+#         sq:<W>[:bf16]               SQ issue / stall counters per kernel (two passes of 8)
 #         collate | dprehearsal | frows
 TAG=${1:-r03_a}; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -63,6 +64,15 @@ for what in "$@"; do
     for CNT in $CNTS; do
       rm -rf /tmp/pmc2; rocprofv3 --kernel-trace --pmc $CNT -d /tmp/pmc2 -o p -- python $R/bench.py --eager --workload $W $DT --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > /tmp/pmc2_${W}_$CNT.log 2>&1
       python $R/profiles/pmcstats.py $(find /tmp/pmc2 -name "*.db" | head -1) k_edge k_attn k_rowres k_rowwave k_rowchain k_atb k_linear k_node k_layer k_head k_keypoint > $O/${TAG}_pmc_${W}${SUF}_${CNT}.json 2>&1
+    done
+    cd $R ;;
+  sq)      # issue / stall breakdown of every kernel: two passes of 8 SQ counters (quad-cycles; see MI355X_MICROARCH.md)
+    cd /tmp; export TMPDIR=/tmp
+    P=0
+    for CNT in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" "SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU"; do
+      P=$((P+1))
+      rm -rf /tmp/pmc3; rocprofv3 --kernel-trace --pmc $CNT -d /tmp/pmc3 -o p -- python $R/bench.py --eager --workload $W $DT --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > /tmp/pmc3_${W}_$P.log 2>&1
+      python $R/profiles/pmcstats.py $(find /tmp/pmc3 -name "*.db" | head -1) k_edge k_attn k_rowres k_rowchain k_atb k_linear k_node > $O/${TAG}_sq_${W}${SUF}_pass$P.json 2>&1
     done
     cd $R ;;
   dprehearsal)   # the driver's N > 1 launch line with one rank on RCCL (world of one)
