@@ -1131,8 +1131,16 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
                                                               const float* __restrict__ d_xnew, EdgeBwdWs W) {
     typedef EdgeBwdSmemSel<BF> Sel;
     __shared__ typename Sel::type sm;
-    __shared__ __attribute__((aligned(16))) typename Sel::slab_t U[Sel::SLAB];
-    __shared__ __attribute__((aligned(16))) typename Sel::slab_t V[Sel::SLAB];
+    // bf16: TWO slab pairs, used alternately by the three phases of an iteration (and on across iterations).  A phase's
+    // stores then only have to wait for the readers of two phases back, and those are behind the barrier of the phase in
+    // between - ONE barrier per phase (stores -> reads) instead of two, none at the end of the iteration (the phase-3 B
+    // operand is a copy of the feature tiles in the slab): 7 -> 3 barriers per 128 edges (the kernel's waves are parked at
+    // barriers / s_waitcnt 48 % of their cycles at 64 x (300, 300), profiles/r03_l_sq_C_bf16_pass1.json).  The fp32 slabs
+    // (2 x 33.8 KB) have no room for a second pair.
+    constexpr bool DBUF = BF;
+    __shared__ __attribute__((aligned(16))) typename Sel::slab_t Ubuf[(DBUF ? 2 : 1) * Sel::SLAB];
+    __shared__ __attribute__((aligned(16))) typename Sel::slab_t Vbuf[(DBUF ? 2 : 1) * Sel::SLAB];
+    int slab_par = 0;
     EQD_TR_WG();
     EQD_TR(0);
     if constexpr (BF)
@@ -1230,6 +1238,9 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
         }
         EQD_TR(12);
         // ---- phase 1: dWc1 += d_chid^T m -------------------------------------------------------------
+        typename Sel::slab_t* U = Ubuf + slab_par * Sel::SLAB;
+        typename Sel::slab_t* V = Vbuf + slab_par * Sel::SLAB;
+        if constexpr (DBUF) slab_par ^= 1;
         if constexpr (BF) {
             slab_store_bf(U, wave, ch, l15, g);
             slab_store_bf(V, wave, m, l15, g);
@@ -1266,7 +1277,10 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
         }
         EQD_TR(15);
         // ---- phase 2: dW2 += dm^T a1 ---------------------------------------------------------------------
-        __syncthreads();                 // every wave is done reading the phase-1 slabs
+        if constexpr (!DBUF) __syncthreads();      // every wave is done reading the phase-1 slabs
+        U = Ubuf + slab_par * Sel::SLAB;
+        V = Vbuf + slab_par * Sel::SLAB;
+        if constexpr (DBUF) slab_par ^= 1;
         if constexpr (BF)
             slab_store_bf(U, wave, m, l15, g);
         else
@@ -1357,7 +1371,10 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
             hbm_store<1>(W.dz1, dz, S, l15, g);
         }
         // ---- phase 3: dW1[:, 2d:] += dz1^T [he | rbf] ------------------------------------------------------
-        __syncthreads();                 // phase-2 slabs are free
+        if constexpr (!DBUF) __syncthreads();      // phase-2 slabs are free
+        U = Ubuf + slab_par * Sel::SLAB;
+        V = Vbuf + slab_par * Sel::SLAB;
+        if constexpr (DBUF) slab_par ^= 1;
         if constexpr (BF) {
             slab_store_bf(U, wave, dz, l15, g);
             // this wave's [16][48] feature tile, transposed, is rows 0..47 x columns 16 w .. of V
@@ -1408,13 +1425,15 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
             float* o = W.dxrel + (size_t)(S.e0 + l15) * 4;
             o[0] = dxr[0]; o[1] = dxr[1]; o[2] = dxr[2]; o[3] = 0.f;
         }
-        __syncthreads();                 // phase-3 slabs and the feature tiles are free for the next iteration
+        if constexpr (!DBUF) __syncthreads();      // phase-3 slabs and the feature tiles are free for the next iteration
         EQD_TR(21);
     }
     // ---- partials: the workgroup's vector sums (its 8 waves' sums added in wave order through the free U slab: one
     //      partial row per workgroup, not per wave, for the later fixed-order reduction) and weight-gradient blocks ----
     {
-        float* vs = (float*)U + wave * VP;      // the slabs are free after the loop's last barrier
+        if constexpr (DBUF) __syncthreads();    // (no barrier at the end of an iteration in this form)
+        float* const U = (float*)Ubuf;
+        float* vs = U + wave * VP;              // the slabs are free after the loop's last barrier
         const int fo = 16 * (l15 >> 2) + 4 * g + (l15 & 3);
         vs[V_DLNG + fo] = r_dlng;
         vs[V_DLNB + fo] = r_dlnb;
