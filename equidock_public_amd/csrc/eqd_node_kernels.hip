@@ -855,6 +855,111 @@ __device__ __forceinline__ void atb_fast(const AtbUnit& u, int c, float* __restr
     }
 }
 
+// atb_fast in bf16 mode: the chunk's operands are rounded ONCE, when they are written to LDS, and stored in the layout the
+// bf16 MFMA reads - [column][k-group] of four bf16, the four rows of a group being the ones the loader thread holds anyway
+// (rows tr, tr + 16, tr + 32, tr + 48 of the chunk: the order of a contraction is free as long as X and Y agree), so a thread
+// packs its 4 x 4 block column by column and an MFMA operand is one ds_read_b64.  The fp32 tiles cost 20 ds_read_b32 + 5
+// packs per 4 MFMAs (the LDS pipe, not the MFMA, set the kernel's time: MfmaUtil 7 %); at 8.7 KB per operand two chunks fit the
+// same LDS, so the "previous chunk's reads are done" barrier goes as well (a chunk's stores only have to wait for the reads
+// of two chunks back, which are behind the barrier in between).  Column sums (bias gradients) are taken from the fp32
+// registers, as before from the fp32 tile.
+#define ATB_KG 17      /* k-groups per column row: 16 + 1 (34 dwords: the 16 lanes of a b64 read phase hit distinct banks) */
+__device__ __forceinline__ void atb_fast_bf(const AtbUnit& u, int c, float* __restrict__ partial, float* __restrict__ Xl_,
+                                            float* __restrict__ Yl_) {
+    const EqdAtbJob& J = u.job;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int tr = t >> 4, tc = t & 15;
+    const int rows = J.rows, ldx = J.ldx, ldy = J.ldy, nparts = u.nparts, nchunks = u.nchunks;
+    const bool masked = J.xmask != nullptr;
+    const bool want_bias = J.bias_out != nullptr && u.n0 == 0;
+    const float slope = J.slope;
+    const EQD_GAS float* const X = (const EQD_GAS float*)J.X + 4 * tc;
+    const EQD_GAS float* const Xm = (const EQD_GAS float*)(masked ? J.xmask : J.X) + 4 * tc;
+    const EQD_GAS float* const Y = (const EQD_GAS float*)J.Y + u.n0 + 4 * tc;
+    const int ny = J.N - (u.n0 + 4 * tc);
+    const bool yfull = u.fast == 1;
+    static_assert(2 * 64 * ATB_KG * 8 <= ATB_ROWS * ATB_LS * 4, "two bf16 chunks must fit one fp32 tile");
+    s16x4* const Xb = (s16x4*)Xl_;      // [2][64 columns][ATB_KG]
+    s16x4* const Yb = (s16x4*)Yl_;
+    f32x4 acc[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) acc[mb] = f4zero();
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 rx[4], rm[4], ry[4];
+    auto load = [&](int chunk) {
+#pragma unroll
+        for (int jr = 0; jr < 4; ++jr) {
+            int row = chunk * ATB_ROWS + tr + 16 * jr;
+            row = row < rows ? row : rows - 1;
+            rx[jr] = *(const EQD_GAS f4v*)(X + (size_t)row * ldx);
+            if (masked) rm[jr] = *(const EQD_GAS f4v*)(Xm + (size_t)row * ldx);
+            ry[jr] = yfull ? *(const EQD_GAS f4v*)(Y + (size_t)row * ldy)
+                           : ld4u_raw((const float*)(Y + (size_t)row * ldy), ny, J.Y);
+        }
+    };
+    load(c);
+    int buf = 0;
+    for (int chunk = c; chunk < nchunks; chunk += nparts) {
+        f32x4 xv[4], yv[4];
+#pragma unroll
+        for (int jr = 0; jr < 4; ++jr) {
+            const bool rvalid = chunk * ATB_ROWS + tr + 16 * jr < rows;
+            f32x4 v = rx[jr], y = ry[jr];
+            if (!yfull) {
+                const float4 f = ld4u_fix(ry[jr], ny);
+                y = f32x4{f.x, f.y, f.z, f.w};
+            }
+            if (masked) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] *= lrelu_grad(rm[jr][i], slope);
+            }
+            if (!rvalid) {
+                v = f4zero();
+                y = f4zero();
+            }
+            xv[jr] = v;
+            yv[jr] = y;
+        }
+        s16x4* const Xc = Xb + buf * 64 * ATB_KG;
+        s16x4* const Yc = Yb + buf * 64 * ATB_KG;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {      // column 4 tc + i, k-group tr = this thread's four rows
+            Xc[(4 * tc + i) * ATB_KG + tr] = pack_bf4(xv[0][i], xv[1][i], xv[2][i], xv[3][i]);
+            Yc[(4 * tc + i) * ATB_KG + tr] = pack_bf4(yv[0][i], yv[1][i], yv[2][i], yv[3][i]);
+            if (want_bias) bs[i] += (xv[0][i] + xv[1][i]) + (xv[2][i] + xv[3][i]);
+        }
+        __syncthreads();             // the chunk is in LDS (and every wave is past its reads of the chunk before the last)
+        if (chunk + nparts < nchunks) load(chunk + nparts);
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            const s16x4 b = Yc[(16 * wave + l15) * ATB_KG + 4 * kc + g];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) acc[mb] = mfma_bf(Xc[(16 * mb + l15) * ATB_KG + 4 * kc + g], b, acc[mb]);
+        }
+        buf ^= 1;
+    }
+    float* P = partial + u.poff + (long long)c * ATB_PSTRIDE;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) P[(16 * mb + 4 * g + r) * 64 + 16 * wave + l15] = acc[mb][r];
+    if (want_bias) {                 // the wave's 4 row groups (lanes 16 apart), then the 4 waves through LDS
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bs[i] += __shfl_xor(bs[i], 16);
+            bs[i] += __shfl_xor(bs[i], 32);
+        }
+        __syncthreads();
+        if (lane < 16) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Yl_[64 * wave + 4 * tc + i] = bs[i];
+        }
+        __syncthreads();
+        if (t < 64) P[ATB_TILE + t] = (Yl_[t] + Yl_[64 + t]) + (Yl_[128 + t] + Yl_[192 + t]);
+    }
+}
+
 __global__ __launch_bounds__(EQD_BLOCK) void k_atb(AtbUnitsArg U, float* __restrict__ partial) {
     __shared__ __attribute__((aligned(16))) float Xl[ATB_ROWS * ATB_LS];
     __shared__ __attribute__((aligned(16))) float Yl[ATB_ROWS * ATB_LS];
@@ -862,7 +967,8 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_atb(AtbUnitsArg U, float* __restr
     const int c = blockIdx.x;
     if (c >= u.nparts) return;       // uniform per workgroup
     if (u.fast) {
-        atb_fast(u, c, partial, Xl, Yl);
+        if (u.job.bf16) atb_fast_bf(u, c, partial, Xl, Yl);
+        else atb_fast(u, c, partial, Xl, Yl);
         return;
     }
     const EqdAtbJob& J = u.job;
