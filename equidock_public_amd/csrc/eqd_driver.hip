@@ -122,9 +122,10 @@ int node_atb_jobs(const Dims& D, int l, const EqdModelDesc* m, const Saved* S, c
     // node_mlp.4: dWn2 = alpha dH^T a1n, dbn2 = alpha colsum(dH)
     jobs[n++] = atb_job(dHout, D.dh, D.dh, Ls ? Ls->a1n : nullptr, d, d, N, G(P_WN2), d, G(P_BN2), m->lrelu_slope,
                         nullptr, alpha);
+    // (order: the jobs that share dz back to back, then the six that share h - eqd_atb runs units that are neighbours in
+    // the list on the same XCD at about the same time, so a shared operand's rows are fetched into that L2 once)
     // node_mlp.0: four column segments [h | aggr_msg | aggr_cross | h0]
     const int ldn = D.ldwn(l);
-    jobs[n++] = atb_job(dz, d, d, h, d, d, N, G(P_WN1), ldn, G(P_BN1), m->lrelu_slope);
     jobs[n++] = atb_job(dz, d, d, Ls ? Ls->aggr_msg : nullptr, 64, 64, N, gp ? G(P_WN1) + d : nullptr, ldn, nullptr,
                         m->lrelu_slope);
     if (m->cross_msgs)
@@ -132,6 +133,7 @@ int node_atb_jobs(const Dims& D, int l, const EqdModelDesc* m, const Saved* S, c
                             nullptr, m->lrelu_slope);
     jobs[n++] = atb_job(dz, d, d, h0, D.d0, D.d0, N, gp ? G(P_WN1) + 2 * d + 64 : nullptr, ldn, nullptr,
                         m->lrelu_slope);
+    jobs[n++] = atb_job(dz, d, d, h, d, d, N, G(P_WN1), ldn, G(P_BN1), m->lrelu_slope);
     // edge_mlp.0 node part: dW1a = dP^T h, dW1b = dQ^T h, db1 = colsum dQ
     const int ld1 = D.ldw1(l);
     jobs[n++] = atb_job(dP, 64, 64, h, d, d, N, G(P_W1), ld1, nullptr, m->lrelu_slope);

@@ -1098,6 +1098,12 @@ static int atb_next_batch(std::vector<AtbUnit>& units, size_t first, long long* 
     if (!getenv("EQD_ATB_WGS") && n > 0 && units[first].nchunks > 8 * (target / n)) target *= 2;
     target = target > 4096 ? 4096 : target;
     int per = (target + n - 1) / (n > 0 ? n : 1);
+    // a multiple of 8: the launch's grid is (parts, units), so part c of EVERY unit runs on XCD c % 8 - the units of a layer
+    // that share an operand (h with six of them, dz with four: the caller lists them back to back) fetch a part's rows of
+    // it into the same L2 at about the same time - and every XCD gets the same number of parts (a grid merely padded to a
+    // multiple of 8 measured k_atb 443 -> 487 us in fp32 at 64 x (300, 300): three XCDs a part short per unit)
+    const char* xa = getenv("EQD_ATB_XCD_ALIGN");      // experiments: 0 = any count
+    if (!(xa && xa[0] == '0' && xa[1] == 0) && per >= 8) per = (per + 7) / 8 * 8;
     per = per > ATB_MAXBLOCKS ? ATB_MAXBLOCKS : per;
     long long off = 0;
     for (int i = 0; i < n; ++i) {
@@ -1113,7 +1119,8 @@ static int atb_next_batch(std::vector<AtbUnit>& units, size_t first, long long* 
 // upper bound of the partial workspace of ANY eqd_atb call (independent of the jobs)
 size_t eqd_atb_batch_partial_bytes(int rows) {
     (void)rows;
-    return (size_t)(4096 + ATB_MAXBLOCKS + ATB_MAXUNITS) * ATB_PSTRIDE * sizeof(float) + 256;
+    // (parts of a launch: units x per, per <= target / units + 1 rounded up to a multiple of 8, target <= 4096)
+    return (size_t)(4096 + ATB_MAXBLOCKS + 8 * ATB_MAXUNITS) * ATB_PSTRIDE * sizeof(float) + 256;
 }
 
 extern "C" size_t eqd_atb_partial_bytes(const EqdAtbJob* jobs, int njobs) {
