@@ -26,7 +26,7 @@ for what in "$@"; do
   ST="--steps 20 --warmup 5"; [ "$W" = "B" ] && ST=""; [ "$W" = "A" ] && ST=""
   case $cmd in
   tests)
-    python -m pytest tests -m gpu -q -s --tb=short 2>&1 | grep -v Warning > $O/${TAG}_pytest_gpu.log ;;
+    EQD_PARITY_DIAGNOSTICS=1 python -m pytest tests -m gpu -q -s --tb=short --durations=15 2>&1 | grep -v Warning > $O/${TAG}_pytest_gpu.log ;;
   testsfast)   # everything except the big-workload oracle comparisons
     python -m pytest tests -m gpu -q -s --tb=short -k "not config_c and not config_e and not config_b and not workload_r" 2>&1 | grep -v Warning > $O/${TAG}_pytest_gpu_fast.log ;;
   testsbig)
