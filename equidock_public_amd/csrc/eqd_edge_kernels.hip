@@ -749,11 +749,6 @@ __device__ __forceinline__ void edge_fwd_body(EdgeFwdSmem<NW, BF>& S_, const Eqd
     float (*sxw)[96] = S_.sxw;
     EQD_TR_WG();
     EQD_TR(0);
-    if constexpr (BF)
-        edge_stage_weights_bf<NW, false>(sm, P);
-    else
-        edge_stage_weights(sm, P);
-    EQD_TR(1);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     float* tile = sm.tile[wave];
@@ -780,12 +775,19 @@ __device__ __forceinline__ void edge_fwd_body(EdgeFwdSmem<NW, BF>& S_, const Eqd
             nx_dst[nb] = G.dst[ei];
         }
     };
+    // The FIRST tile's chain is walked before the weights are staged (both forms: at DB5.5 sizes a wave has one tile, and
+    // the staging - 2 400 clocks - hides the two or three round trips).
     const int t_first = blk * NW + wave, t_step = nblk * NW;
-    if (AHEAD && t_first < G.n_tiles) {
+    if (t_first < G.n_tiles) {
         link_nodes(t_first);
         link_range();
-        link_endpoints();
+        if constexpr (AHEAD) link_endpoints();
     }
+    if constexpr (BF)
+        edge_stage_weights_bf<NW, false>(sm, P);
+    else
+        edge_stage_weights(sm, P);
+    EQD_TR(1);
     for (int t = t_first; t < G.n_tiles; t += t_step) {
         EdgeTileState<2> S;
         if constexpr (AHEAD) {
@@ -798,6 +800,11 @@ __device__ __forceinline__ void edge_fwd_body(EdgeFwdSmem<NW, BF>& S_, const Eqd
                 S.src[nb] = nx_src[nb];
                 S.dst[nb] = nx_dst[nb];
             }
+        } else if (t == t_first) {      // (wave-uniform)
+            S.n0 = nx_n0;
+            S.n1 = nx_n1;
+            S.e0 = nx_e0;
+            S.ne = nx_ne;
         } else {
             S.n0 = G.tile_node[t];
             S.n1 = G.tile_node[t + 1];
@@ -1143,26 +1150,14 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
     int slab_par = 0;
     EQD_TR_WG();
     EQD_TR(0);
-    if constexpr (BF)
-        edge_stage_weights_bf<BWD_WAVES, true>(sm, P);
-    else
-        edge_stage_weights(sm, P);
-    EQD_TR(1);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    float* tile = sm.tile[wave];
-    // vector-gradient sums of this lane's feature fo = 16 (l15 >> 2) + 4 g + (l15 & 3) (see reduce16x16), kept in
-    // registers over all tiles of the wave; r_dbc2 is a plain per-lane partial
-    float r_dlng = 0.f, r_dlnb = 0.f, r_dwc2 = 0.f, r_dbc1 = 0.f, r_db2 = 0.f, r_dbc2 = 0.f;
-    // this wave's blocks of the weight gradients: rows 16*wmb.., columns 16*(2*(wave&1)) + {0,16} of the 64x64
-    // matrices; for dW1[:, 2d:] (3 column blocks) block (wmb, wave&1) and, for waves 0..3, block (wave, 2)
-    const int wmb = wave >> 1, wnb = 2 * (wave & 1);
-    f32x4 gW2[2] = {f4zero(), f4zero()}, gWc1[2] = {f4zero(), f4zero()}, gW1a[1] = {f4zero()}, gW1b[1] = {f4zero()};
     const int n_tiles = (G.n_edges + 15) >> 4;
     const int n_super = (n_tiles + BWD_WAVES - 1) / BWD_WAVES;
     // The endpoints of a tile's edges are fetched ONE ITERATION AHEAD: everything else the tile loads (coordinates, P / Q
     // rows, the destination's incoming gradients) hangs off them, so an iteration starts with one round trip to memory
     // instead of two (lanes beyond the tile read the tile's first edge, an empty tile edge 0 - like the tile forward).
+    // The first tile's are requested before the weights are staged (they land behind the staging barrier).
     int nx_src = 0, nx_dst = 0;
     auto endpoints = [&](int it_) {
         int e0 = 16 * (it_ * BWD_WAVES + wave), ne = G.n_edges - e0;
@@ -1173,6 +1168,19 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
         nx_dst = G.dst[ei];
     };
     if ((int)blockIdx.x < n_super) endpoints((int)blockIdx.x);
+    if constexpr (BF)
+        edge_stage_weights_bf<BWD_WAVES, true>(sm, P);
+    else
+        edge_stage_weights(sm, P);
+    EQD_TR(1);
+    float* tile = sm.tile[wave];
+    // vector-gradient sums of this lane's feature fo = 16 (l15 >> 2) + 4 g + (l15 & 3) (see reduce16x16), kept in
+    // registers over all tiles of the wave; r_dbc2 is a plain per-lane partial
+    float r_dlng = 0.f, r_dlnb = 0.f, r_dwc2 = 0.f, r_dbc1 = 0.f, r_db2 = 0.f, r_dbc2 = 0.f;
+    // this wave's blocks of the weight gradients: rows 16*wmb.., columns 16*(2*(wave&1)) + {0,16} of the 64x64
+    // matrices; for dW1[:, 2d:] (3 column blocks) block (wmb, wave&1) and, for waves 0..3, block (wave, 2)
+    const int wmb = wave >> 1, wnb = 2 * (wave & 1);
+    f32x4 gW2[2] = {f4zero(), f4zero()}, gWc1[2] = {f4zero(), f4zero()}, gW1a[1] = {f4zero()}, gW1b[1] = {f4zero()};
     for (int it = blockIdx.x; it < n_super; it += gridDim.x) {
         const int t = it * BWD_WAVES + wave;
         EdgeTileState<1> S;
