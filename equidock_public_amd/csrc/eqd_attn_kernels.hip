@@ -23,6 +23,7 @@
 // (row stride 16*DB + 4 floats); MFMA operands are read from LDS.  One HBM/L2 round trip per tile.
 #include "eqd_common.h"
 #include "eqd_attn_fwd_inl.h"
+#include "eqd_gather_inl.h"
 #include "eqd_attn_lb_inl.h"
 
 #include <stdlib.h>
@@ -441,6 +442,46 @@ __global__ __launch_bounds__(EQD_BLOCK, NB == 1 ? 2 : 1) void k_attn_bwd(EqdGrap
                                                                         dv, half, qk_slope);
 }
 
+// k_attn_bwd<4, 1> with the layer's node gather (and the partial reductions that ride with it) as the LAST workgroups of the
+// same launch: the two are independent - the gather reads what the edge backward wrote, the attention backward what the row
+// chain wrote - and at DB5.5 sizes neither fills the chip: the 448 attention workgroups take 448 of the 512 slots (two per
+// CU: the gather's 5 KB of LDS ride on the attention's 70 KB) for ~20 us, the ~240 short gather / reduction workgroups flow
+// through the other 64 meanwhile (as the FIRST workgroups they ran before the attention instead of beside it: 27.4 us per
+// launch against 20.4 + 9.6 apart).
+template <bool BF_DZ>
+__global__ __launch_bounds__(EQD_BLOCK, 2) void k_attn_bwd_gather(EqdGraph G, int d, const float* __restrict__ q,
+                                                        const float* __restrict__ k, const float* __restrict__ v,
+                                                        const float* __restrict__ out, const float* __restrict__ lse,
+                                                        const float* __restrict__ d_out, float* __restrict__ dq,
+                                                        float* __restrict__ dk, float* __restrict__ dv,
+                                                        float* __restrict__ delta, float qk_slope, int n_attn, int nred,
+                                                        EqdGatherArgs GA, EqdRedArg RA) {
+    static_assert(EQD_BLOCK == 256, "the gather body is written for 256-thread workgroups");
+    if ((int)blockIdx.x >= n_attn) {
+        const int b = (int)blockIdx.x - n_attn;
+        if (b < GA.ngather) {
+            node_gather_body<BF_DZ>(GA, b);
+        } else if (b < GA.ngather + nred) {
+            __shared__ __attribute__((aligned(16))) float red[16][68];
+            __shared__ float red2[4][64];
+            reduce_block<16>(RA, b - GA.ngather, red, red2);
+        }
+        return;
+    }
+    __shared__ __attribute__((aligned(16))) AttnBwdSmem<4, true> sm;
+    const int b = (int)blockIdx.x;
+    const int per = 2 * G.n_att_items;      // workgroups per pass
+    const bool kv = b >= per;
+    const int idx = kv ? b - per : b;
+    const int item = att_half_item(idx), half = att_half_of(idx);
+    if (!kv)
+        attn_bwd_q_body<4, true, 1, AttnBwdSmem<4, true>, false>(sm, G, item, d, q, k, v, out, lse, d_out, dq, delta, half,
+                                                                 qk_slope);
+    else
+        attn_bwd_kv_body<4, true, true, 1, AttnBwdSmem<4, true>, false>(sm, G, item, d, q, k, v, out, lse, d_out, nullptr, dk,
+                                                                        dv, half, qk_slope);
+}
+
 // ---------------------------------------------------------------------------------------------
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
@@ -615,4 +656,43 @@ int eqd_launch_attention_bwd_act(const EqdGraph* g, int d, const float* q, const
                                  float qk_slope, bool bf16, hipStream_t st) {
     return bf16 ? attention_bwd_bf16(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, qk_slope, st)
                 : attention_bwd_f32(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, qk_slope, st);
+}
+// 1 if eqd_launch_attention_bwd_gather will take the fused launch (fp32 attention of a 64-wide layer on the half-block
+// path - what every layer but the first runs at every size); otherwise it issues the two launches one after the other
+int eqd_attention_bwd_gather_fused(const EqdGraph* g, int d, const float* q, const float* k, const float* v, const float* out,
+                                   const float* d_out, bool bf16) {
+    const char* f = getenv("EQD_FUSE_GATHER");
+    if (f && f[0] == '0' && f[1] == 0) return 0;
+    const char* hb = getenv("EQD_ATT_BWD_SPLIT");
+    if (hb && hb[0] == '0' && hb[1] == 0) return 0;
+    if (bf16 || d != 64 || g->n_att_items <= 0 || g->n_att_items % 8 != 0) return 0;
+    return aligned16(q) && aligned16(k) && aligned16(v) && aligned16(d_out) && aligned16(out);
+}
+int eqd_launch_attention_bwd_gather(const EqdGraph* g, int d, const float* q, const float* k, const float* v, const float* out,
+                                    const float* lse, const float* d_out, float* dq, float* dk, float* dv, float* delta,
+                                    float qk_slope, bool bf16, const EqdGatherCall* gc, EqdRedList* pending, hipStream_t st) {
+    if (!eqd_attention_bwd_gather_fused(g, d, q, k, v, out, d_out, bf16)) {
+        int rc = eqd_launch_attention_bwd_act(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, qk_slope, bf16, st);
+        if (rc) return rc;
+        return eqd_launch_node_gather(g, gc->dz, gc->dxrel, gc->d_xnew, gc->a, gc->dP, gc->dQ, gc->dx, st, pending,
+                                      gc->dz_bf16 != 0);
+    }
+    if (!q || !k || !v || !out || !lse || !d_out || !dq || !dk || !dv || !delta) {
+        eqd_set_error("eqd_launch_attention_bwd_gather: NULL argument");
+        return EQD_ERR_NULL;
+    }
+    static thread_local EqdRedArg RA;
+    EqdGatherArgs GA;
+    int nred = 0;
+    if (int e = eqd_gather_plan(g, gc, pending, &GA, &RA, &nred)) return e;
+    const int n_attn = 4 * g->n_att_items;
+    const dim3 grid(n_attn + GA.ngather + nred);
+    if (gc->dz_bf16)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_gather<true>), grid, dim3(EQD_BLOCK), 0, st, *g, d, q, k, v, out, lse, d_out,
+                           dq, dk, dv, delta, qk_slope, n_attn, nred, GA, RA);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_gather<false>), grid, dim3(EQD_BLOCK), 0, st, *g, d, q, k, v, out, lse, d_out,
+                           dq, dk, dv, delta, qk_slope, n_attn, nred, GA, RA);
+    if (int rc = eqd_check_launch("k_attn_bwd_gather")) return rc;
+    return eqd_gather_rest(pending, st);
 }

@@ -288,6 +288,21 @@ struct EqdRedList;
 int eqd_launch_embed_bwd(const EqdGraph* g, const float* dh0, const float* dh0b, int ld, int d_emb, float* demb,
                          float* partial, hipStream_t st, EqdRedList* defer = nullptr);
 size_t eqd_embed_bwd_partial_floats(const EqdGraph* g, int d_emb);
+// one pending gather (the edge backward's per-edge outputs -> per-node sums), for whoever launches it
+struct EqdGatherCall {
+    const float *dz, *dxrel, *d_xnew;
+    float a;
+    float *dP, *dQ, *dx;
+    int dz_bf16;
+};
+struct EqdGatherArgs;      // eqd_gather_inl.h
+int eqd_gather_plan(const EqdGraph* g, const EqdGatherCall* c, EqdRedList* pending, EqdGatherArgs* GA, EqdRedArg* RA, int* nblk);
+int eqd_gather_rest(EqdRedList* pending, hipStream_t st);
+int eqd_attention_bwd_gather_fused(const EqdGraph* g, int d, const float* q, const float* k, const float* v, const float* out,
+                                   const float* d_out, bool bf16);
+int eqd_launch_attention_bwd_gather(const EqdGraph* g, int d, const float* q, const float* k, const float* v, const float* out,
+                                    const float* lse, const float* d_out, float* dq, float* dk, float* dv, float* delta,
+                                    float qk_slope, bool bf16, const EqdGatherCall* gc, EqdRedList* pending, hipStream_t st);
 int eqd_launch_node_gather(const EqdGraph* g, const float* dz, const float* dxrel, const float* d_xnew, float a,
                            float* dP, float* dQ, float* dx, hipStream_t st, EqdRedList* pending = nullptr,
                            bool dz_bf16 = false);
@@ -297,7 +312,7 @@ int eqd_launch_ln_act_bwd(const float* y_act, const float* d_out, const float* g
 int eqd_edge_message_bwd_impl(const EqdGraph* g, const EqdEdgeParams* p, const float* P, const float* Q, const float* x,
                               const float* d_aggr_msg, const float* d_xnew, float* dP, float* dQ, float* dx,
                               const EqdEdgeGrads* grads, void* workspace, size_t ws_bytes, hipStream_t st,
-                              float* part_override, EqdRedList* defer);
+                              float* part_override, EqdRedList* defer, EqdGatherCall* hold_gather = nullptr);
 size_t eqd_edge_bwd_vecp_floats(const EqdGraph* g);
 int eqd_edge_attn_fwd(const EqdGraph* g, const EqdEdgeParams* p, const float* P, const float* Q, const float* x,
                       float* aggr_msg, float* x_new, int d_att, const float* q, const float* k, const float* v,

@@ -819,19 +819,22 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
             }
         }
         // The backward kernels of a layer each fill the chip (LDS-bound occupancy), so they run back to back
-        // on ONE stream: side streams only added event latency here.
-        if (m->cross_msgs) {
-            RC(eqd_launch_attention_bwd_act(g, da, Ls.qa, Ls.ka, Ls.va, Ls.aggr_cross, Ls.lse, W.d_aggr_cross, dq, dk, dv,
-                                            W.delta, m->lrelu_slope, m->storage_bf16 != 0, st));
-        }
+        // on ONE stream: side streams only added event latency here.  Order: edge backward, then the attention backward
+        // with the edge backward's node gather riding in the same launch where that form exists (the two are independent;
+        // eqd_launch_attention_bwd_gather issues them one after the other otherwise).
         {
             EqdEdgeParams ep = edge_params(D, m, l, p, drop);
             EqdEdgeGrads eg;
             memset(&eg, 0, sizeof(eg));
             eg.dW1 = gp[P_W1]; eg.ldw1 = D.ldw1(l); eg.dln_g = gp[P_LNG]; eg.dln_b = gp[P_LNB]; eg.dW2 = gp[P_W2];
             eg.db2 = gp[P_B2]; eg.dWc1 = gp[P_WC1]; eg.dbc1 = gp[P_BC1]; eg.dwc2 = gp[P_WC2]; eg.dbc2 = gp[P_BC2];
+            EqdGatherCall gc;
             RC(eqd_edge_message_bwd_impl(g, &ep, Ls.P, Ls.Q, S.x[l], W.d_aggr_msg, dXcur, dP, dQ, dXnext, &eg, W.edge_ws,
-                                         W.edge_ws_bytes, st, W.vecp_all + (size_t)l * W.vecp_stride, defer));
+                                         W.edge_ws_bytes, st, W.vecp_all + (size_t)l * W.vecp_stride, defer,
+                                         m->cross_msgs ? &gc : nullptr));
+            if (m->cross_msgs)
+                RC(eqd_launch_attention_bwd_gather(g, da, Ls.qa, Ls.ka, Ls.va, Ls.aggr_cross, Ls.lse, W.d_aggr_cross, dq, dk,
+                                                   dv, W.delta, m->lrelu_slope, m->storage_bf16 != 0, &gc, defer, st));
         }
         {
             EqdAtbJob ajobs[16];

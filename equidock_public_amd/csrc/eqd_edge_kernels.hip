@@ -1602,13 +1602,13 @@ extern "C" int eqd_edge_message_bwd(const EqdGraph* g, const EqdEdgeParams* p, c
                                     float* dQ, float* dx, const EqdEdgeGrads* grads, void* workspace,
                                     size_t ws_bytes, void* stream) {
     return eqd_edge_message_bwd_impl(g, p, P, Q, x, d_aggr_msg, d_xnew, dP, dQ, dx, grads, workspace, ws_bytes,
-                                     (hipStream_t)stream, nullptr, nullptr);
+                                     (hipStream_t)stream, nullptr, nullptr, nullptr);
 }
 
 int eqd_edge_message_bwd_impl(const EqdGraph* g, const EqdEdgeParams* p, const float* P, const float* Q, const float* x,
                               const float* d_aggr_msg, const float* d_xnew, float* dP, float* dQ, float* dx,
                               const EqdEdgeGrads* grads, void* workspace, size_t ws_bytes, hipStream_t st,
-                              float* part_override, EqdRedList* defer) {
+                              float* part_override, EqdRedList* defer, EqdGatherCall* hold_gather) {
     if (!g || !p || !P || !Q || !x || !d_aggr_msg || !d_xnew || !dP || !dQ || !dx || !grads) {
         eqd_set_error("eqd_edge_message_bwd: NULL argument");
         return EQD_ERR_NULL;
@@ -1660,5 +1660,10 @@ int eqd_edge_message_bwd_impl(const EqdGraph* g, const EqdEdgeParams* p, const f
     }
     // per-node sums: dP (by source), dQ (by destination), dx = (1 - eta) d_xnew + sum_src dx_rel - sum_dst dx_rel;
     // the pending reductions (this layer's partials and whatever the caller had queued) ride in the same launch
+    // (hold_gather: the caller launches it - beside the layer's attention backward, eqd_launch_attention_bwd_gather)
+    if (hold_gather) {
+        *hold_gather = EqdGatherCall{W.dz1, W.dxrel, d_xnew, 1.f - p->eta, dP, dQ, dx, p->bf16 != 0 ? 1 : 0};
+        return EQD_OK;
+    }
     return eqd_launch_node_gather(g, W.dz1, W.dxrel, d_xnew, 1.f - p->eta, dP, dQ, dx, st, defer, p->bf16 != 0);
 }

@@ -7,6 +7,7 @@
 #include "eqd_linear_inl.h"
 #include "eqd_rowwave_inl.h"
 #include "eqd_rowres_inl.h"
+#include "eqd_gather_inl.h"
 
 #include <mutex>
 #include <vector>
@@ -1179,76 +1180,6 @@ extern "C" int eqd_atb(const EqdAtbJob* jobs, int njobs, void* partial, size_t p
 // 2 000 short partials serialised 8 load round trips in one workgroup).  The summation order is fixed: parts
 // pl, pl + 64, .. in each lane, segments of a chain in list order, then the 64 lanes as 4 x 16 in index order.
 // PL part lanes (thread = 16 column groups x PL): 64 in k_reduce_segments, 16 when the block rides in k_node_gather
-template <int PL>
-__device__ __forceinline__ void reduce_block(const EqdRedArg& A, int blk, float (*red)[68], float (*red2)[64]) {
-    int ch = 0;
-    while (ch + 1 < A.nchains && blk >= A.chain_blk0[ch + 1]) ++ch;
-    ch = uni(ch);
-    const int first = A.chain_first[ch], len = A.chain_len[ch];
-    const int t = threadIdx.x, cg = t & 15, pl = t >> 4;
-    const int c0 = (blk - A.chain_blk0[ch]) * 64;
-    const int n = A.s[first].n;
-    const int col = c0 + 4 * cg;            // this thread's columns col .. col + 3
-    const int nv = n - col;                 // how many of them exist (<= 0: none)
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (n >= 4) {
-        for (int j = 0; j < len; ++j) {
-            const EqdRedSeg& S = A.s[first + j];
-            const float* __restrict__ base = S.partial + (nv > 0 ? col : 0);
-            const int np = S.nparts;
-            const size_t ps = (size_t)S.pstride;
-            for (int p0 = pl; p0 < np; p0 += 8 * PL) {
-                f32x4 v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int p = p0 + PL * u;
-                    v[u] = ld4u_raw(base + (size_t)(p < np ? p : 0) * ps, nv, S.partial);
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const float4 f = ld4u_fix(v[u], p0 + PL * u < np ? nv : 0);
-                    acc.x += f.x;
-                    acc.y += f.y;
-                    acc.z += f.z;
-                    acc.w += f.w;
-                }
-            }
-        }
-    } else if (cg == 0) {                    // 1 .. 3 columns in all (a scalar bias): scalar loads
-        float a3[3] = {0.f, 0.f, 0.f};
-        for (int j = 0; j < len; ++j) {
-            const EqdRedSeg& S = A.s[first + j];
-            for (int p = pl; p < S.nparts; p += PL)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float v = S.partial[(size_t)p * S.pstride + (c < n ? c : 0)];
-                    a3[c] += c < n ? v : 0.f;
-                }
-        }
-        acc = make_float4(a3[0], a3[1], a3[2], 0.f);
-    }
-    *(float4*)&red[pl][4 * cg] = acc;
-    __syncthreads();
-    if (t < 256) {
-        const int c = t & 63, qd = t >> 6;
-        float s = 0.f;
-#pragma unroll
-        for (int j = 0; j < PL / 4; ++j) s += red[(PL / 4) * qd + j][c];
-        red2[qd][c] = s;
-    }
-    __syncthreads();
-    const int i = c0 + t;
-    if (t < 64 && i < n) {
-        const float s = (red2[0][t] + red2[1][t]) + (red2[2][t] + red2[3][t]);
-        const EqdRedSeg& S0 = A.s[first];
-        if (S0.cols > 0) {
-            const int row = i / S0.cols, cc = i - row * S0.cols;
-            if (cc < S0.cols_valid) S0.out[(size_t)row * S0.ld_out + cc] += s;
-        } else {
-            S0.out[i] += s;
-        }
-    }
-}
 __global__ __launch_bounds__(1024) void k_reduce_segments(EqdRedArg A) {
     __shared__ __attribute__((aligned(16))) float red[64][68];
     __shared__ float red2[4][64];
@@ -1419,146 +1350,42 @@ int eqd_launch_embed_bwd(const EqdGraph* g, const float* dh0, const float* dh0b,
 // 4 x as many load instructions for the same bytes, and the vector-memory path accepts instructions, not bytes, at a
 // fixed rate (profiles/r02_exp_trace_rowwave_*.txt).  Sums per feature run over the edges in the same order as before.
 template <bool BF>
-__device__ __forceinline__ f32x4 gather_dz4(const float* __restrict__ dz, size_t e, int c4) {
-    if constexpr (BF) {
-        typedef unsigned gather_u32x2 __attribute__((ext_vector_type(2)));
-        const gather_u32x2 h = *(const gather_u32x2*)((const unsigned short*)dz + e * 64 + 4 * c4);      // 4 bf16
-        return f32x4{__builtin_bit_cast(float, h[0] << 16), __builtin_bit_cast(float, h[0] & 0xffff0000u),
-                     __builtin_bit_cast(float, h[1] << 16), __builtin_bit_cast(float, h[1] & 0xffff0000u)};
-    } else {
-        return *(const f32x4*)(dz + e * 64 + 4 * c4);
-    }
-}
-#define GATHER_NODES 16      /* nodes per workgroup: 4 waves x 4 */
-template <bool BF>
-__global__ __launch_bounds__(256) void k_node_gather(const int32_t* __restrict__ csc_ptr, const int32_t* __restrict__ csc_eid,
-                                                     const int32_t* __restrict__ rowptr, int n, const float* __restrict__ dz,
-                                                     const float* __restrict__ dxrel, const float* __restrict__ d_xnew, float a,
-                                                     float* __restrict__ dP, float* __restrict__ dQ, float* __restrict__ dx,
-                                                     int ngather, EqdRedArg RA) {
-    if ((int)blockIdx.x >= ngather) {
+__global__ __launch_bounds__(256) void k_node_gather(EqdGatherArgs GA, EqdRedArg RA) {
+    if ((int)blockIdx.x >= GA.ngather) {
         __shared__ __attribute__((aligned(16))) float red[16][68];
         __shared__ float red2[4][64];
-        reduce_block<16>(RA, (int)blockIdx.x - ngather, red, red2);
+        reduce_block<16>(RA, (int)blockIdx.x - GA.ngather, red, red2);
         return;
     }
-    const int jr = blockIdx.x * GATHER_NODES + (threadIdx.x >> 4);
-    const int c4 = threadIdx.x & 15;
-    const bool live = jr < n;
-    const int j = live ? jr : n - 1;      // lanes beyond the last node repeat it (unconditional loads) and store nothing
-    const int s0 = csc_ptr[j], s1 = csc_ptr[j + 1];
-    const int d0 = rowptr[j], d1 = rowptr[j + 1];
-    const int nout = s1 - s0, nin = d1 - d0;
-    f32x4 sp = f4zero(), sq = f4zero();
-    float sx = 0.f;                       // component c4 & 3 of the dx sum (lanes c4 < 3 store it)
-    // First 16 edges of both directions in TWO dependent round trips: the 16 by-source edge ids (CSC) and the 16
-    // by-destination rows (CSR: consecutive edge ids, no index needed) are issued together, then the 16 by-source rows.
-    // Every load is unconditional on a clamped index and masked afterwards (a predicated load is an exec-masked branch
-    // with its own wait).  Sums are taken in edge order.
-    constexpr int GB = 16;
-    if (nout > 0 || nin > 0) {       // (a node without any edge reads nothing: dz may be empty)
-        const int so = nout > 0 ? s0 : 0, no1 = nout > 0 ? nout - 1 : 0;
-        const int di = nin > 0 ? d0 : (nout > 0 ? csc_eid[s0] : 0), ni1 = nin > 0 ? nin - 1 : 0;
-        int e[GB];
-        f32x4 vq[GB], vp[GB];
-        float wq[GB], wp[GB];
-#pragma unroll
-        for (int i = 0; i < GB; ++i) e[i] = nout > 0 ? csc_eid[so + (i < no1 ? i : no1)] : di;
-#pragma unroll
-        for (int i = 0; i < GB; ++i) {
-            const size_t ee = (size_t)(di + (i < ni1 ? i : ni1));
-            vq[i] = gather_dz4<BF>(dz, ee, c4);
-            wq[i] = dxrel[ee * 4 + (c4 & 3)];
-        }
-#pragma unroll
-        for (int i = 0; i < GB; ++i) {
-            vp[i] = gather_dz4<BF>(dz, (size_t)e[i], c4);
-            wp[i] = dxrel[(size_t)e[i] * 4 + (c4 & 3)];
-        }
-#pragma unroll
-        for (int i = 0; i < GB; ++i) {
-            if (i < nout) {
-                sp += vp[i];
-                sx += wp[i];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < GB; ++i) {
-            if (i < nin) {
-                sq += vq[i];
-                sx -= wq[i];
-            }
-        }
-    }
-    // degrees beyond 16 (out-degree is unbounded; in-degree <= 32): the remaining edges, 8 at a time
-    for (int q0 = s0 + GB; q0 < s1; q0 += 8) {
-        int e[8];
-        f32x4 v[8];
-        float w[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) e[i] = csc_eid[q0 + i < s1 ? q0 + i : s1 - 1];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            v[i] = gather_dz4<BF>(dz, (size_t)e[i], c4);
-            w[i] = dxrel[(size_t)e[i] * 4 + (c4 & 3)];
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (q0 + i < s1) {
-                sp += v[i];
-                sx += w[i];
-            }
-        }
-    }
-    for (int e0 = d0 + GB; e0 < d1; e0 += 8) {
-        f32x4 v[8];
-        float w[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const size_t ee = (size_t)(e0 + i < d1 ? e0 + i : d1 - 1);
-            v[i] = gather_dz4<BF>(dz, ee, c4);
-            w[i] = dxrel[ee * 4 + (c4 & 3)];
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (e0 + i < d1) {
-                sq += v[i];
-                sx -= w[i];
-            }
-        }
-    }
-    if (live) {
-        *(f32x4*)(dP + (size_t)j * 64 + 4 * c4) = sp;
-        *(f32x4*)(dQ + (size_t)j * 64 + 4 * c4) = sq;
-        if (c4 < 3) dx[(size_t)j * 3 + c4] = a * d_xnew[(size_t)j * 3 + c4] + sx;
-    }
+    node_gather_body<BF>(GA, (int)blockIdx.x);
 }
 // pending: reductions to run in the same launch (emptied on return); what does not fit one descriptor is launched on
-// its own
-int eqd_launch_node_gather(const EqdGraph* g, const float* dz, const float* dxrel, const float* d_xnew, float a,
-                           float* dP, float* dQ, float* dx, hipStream_t st, EqdRedList* pending, bool dz_bf16) {
-    static thread_local RedPlan P;
-    static thread_local EqdRedArg arg;
-    int nblk = 0, c0 = 0;
-    memset(&arg, 0, sizeof(arg));
+// its own.  Two steps, so that the launch itself can be someone else's (eqd_launch_attention_bwd_gather):
+//   eqd_gather_plan: fills the kernel's arguments (GA.ngather, the first reduction descriptor RA, its workgroup count nblk)
+//   eqd_gather_rest: launches whatever of `pending` did not fit RA and empties the list
+static thread_local RedPlan g_gather_plan;
+static thread_local int g_gather_c0;
+int eqd_gather_plan(const EqdGraph* g, const EqdGatherCall* c, EqdRedList* pending, EqdGatherArgs* GA, EqdRedArg* RA,
+                    int* nblk) {
+    *nblk = 0;
+    g_gather_c0 = 0;
+    memset(RA, 0, sizeof(*RA));
     if (pending && pending->n > 0) {
-        if (int e = red_plan(pending->seg, pending->n, P)) return e;
-        nblk = red_fill(pending->seg, P, c0, arg);
+        if (int e = red_plan(pending->seg, pending->n, g_gather_plan)) return e;
+        *nblk = red_fill(pending->seg, g_gather_plan, g_gather_c0, *RA);
     }
-    const int ng = (g->n_nodes + GATHER_NODES - 1) / GATHER_NODES;
-    if (ng + nblk > 0) {
-        if (dz_bf16)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_node_gather<true>), dim3(ng + nblk), dim3(256), 0, st, g->csc_ptr, g->csc_eid,
-                               g->rowptr, g->n_nodes, dz, dxrel, d_xnew, a, dP, dQ, dx, ng, arg);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_node_gather<false>), dim3(ng + nblk), dim3(256), 0, st, g->csc_ptr, g->csc_eid,
-                               g->rowptr, g->n_nodes, dz, dxrel, d_xnew, a, dP, dQ, dx, ng, arg);
-        if (int rc = eqd_check_launch("k_node_gather")) return rc;
-    }
+    GA->csc_ptr = g->csc_ptr; GA->csc_eid = g->csc_eid; GA->rowptr = g->rowptr; GA->n = g->n_nodes;
+    GA->dz = c->dz; GA->dxrel = c->dxrel; GA->d_xnew = c->d_xnew; GA->a = c->a;
+    GA->dP = c->dP; GA->dQ = c->dQ; GA->dx = c->dx;
+    GA->ngather = (g->n_nodes + GATHER_NODES - 1) / GATHER_NODES;
+    GA->bf16 = c->dz_bf16;
+    return EQD_OK;
+}
+int eqd_gather_rest(EqdRedList* pending, hipStream_t st) {
     if (pending && pending->n > 0) {
-        while (c0 < P.nc) {         // (more than 64 segments or chains: not the case for one layer)
+        while (g_gather_c0 < g_gather_plan.nc) {         // (more than 64 segments or chains: not the case for one layer)
             EqdRedArg more;
-            const int nb = red_fill(pending->seg, P, c0, more);
+            const int nb = red_fill(pending->seg, g_gather_plan, g_gather_c0, more);
             if (nb == 0) continue;
             hipLaunchKernelGGL(k_reduce_segments, dim3(nb), dim3(1024), 0, st, more);
             if (int rc = eqd_check_launch("k_reduce_segments")) return rc;
@@ -1566,6 +1393,22 @@ int eqd_launch_node_gather(const EqdGraph* g, const float* dz, const float* dxre
         pending->n = 0;
     }
     return EQD_OK;
+}
+int eqd_launch_node_gather(const EqdGraph* g, const float* dz, const float* dxrel, const float* d_xnew, float a,
+                           float* dP, float* dQ, float* dx, hipStream_t st, EqdRedList* pending, bool dz_bf16) {
+    const EqdGatherCall c = {dz, dxrel, d_xnew, a, dP, dQ, dx, dz_bf16 ? 1 : 0};
+    static thread_local EqdRedArg arg;
+    EqdGatherArgs GA;
+    int nblk = 0;
+    if (int e = eqd_gather_plan(g, &c, pending, &GA, &arg, &nblk)) return e;
+    if (GA.ngather + nblk > 0) {
+        if (dz_bf16)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_node_gather<true>), dim3(GA.ngather + nblk), dim3(256), 0, st, GA, arg);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_node_gather<false>), dim3(GA.ngather + nblk), dim3(256), 0, st, GA, arg);
+        if (int rc = eqd_check_launch("k_node_gather")) return rc;
+    }
+    return eqd_gather_rest(pending, st);
 }
 
 // Backward of LeakyReLU -> LayerNorm (node_mlp.2/.3): y_act = LeakyReLU(z) is saved by the forward.
