@@ -448,7 +448,8 @@ __global__ __launch_bounds__(EQD_BLOCK, NB == 1 ? 2 : 1) void k_attn_bwd(EqdGrap
 // CU: the gather's 5 KB of LDS ride on the attention's 70 KB) for ~20 us, the ~240 short gather / reduction workgroups flow
 // through the other 64 meanwhile (as the FIRST workgroups they ran before the attention instead of beside it: 27.4 us per
 // launch against 20.4 + 9.6 apart).
-template <bool BF_DZ>
+// LB: the bf16 attention with bf16 tiles in LDS (k_attn_bwd_lb<1>: 74 KB + the gather's 5 KB, still two per CU)
+template <bool BF_DZ, bool LB>
 __global__ __launch_bounds__(EQD_BLOCK, 2) void k_attn_bwd_gather(EqdGraph G, int d, const float* __restrict__ q,
                                                         const float* __restrict__ k, const float* __restrict__ v,
                                                         const float* __restrict__ out, const float* __restrict__ lse,
@@ -468,18 +469,26 @@ __global__ __launch_bounds__(EQD_BLOCK, 2) void k_attn_bwd_gather(EqdGraph G, in
         }
         return;
     }
-    __shared__ __attribute__((aligned(16))) AttnBwdSmem<4, true> sm;
     const int b = (int)blockIdx.x;
     const int per = 2 * G.n_att_items;      // workgroups per pass
     const bool kv = b >= per;
     const int idx = kv ? b - per : b;
     const int item = att_half_item(idx), half = att_half_of(idx);
-    if (!kv)
-        attn_bwd_q_body<4, true, 1, AttnBwdSmem<4, true>, false>(sm, G, item, d, q, k, v, out, lse, d_out, dq, delta, half,
-                                                                 qk_slope);
-    else
-        attn_bwd_kv_body<4, true, true, 1, AttnBwdSmem<4, true>, false>(sm, G, item, d, q, k, v, out, lse, d_out, nullptr, dk,
-                                                                        dv, half, qk_slope);
+    if constexpr (LB) {
+        __shared__ AttnBwdSmemLb sm;
+        if (!kv)
+            attn_bwd_q_body_lb<1>(sm, G, item, q, k, v, out, lse, d_out, dq, delta, half, qk_slope);
+        else
+            attn_bwd_kv_body_lb<1>(sm, G, item, q, k, v, out, lse, d_out, dk, dv, half, qk_slope);
+    } else {
+        __shared__ __attribute__((aligned(16))) AttnBwdSmem<4, true> sm;
+        if (!kv)
+            attn_bwd_q_body<4, true, 1, AttnBwdSmem<4, true>, false>(sm, G, item, d, q, k, v, out, lse, d_out, dq, delta, half,
+                                                                     qk_slope);
+        else
+            attn_bwd_kv_body<4, true, true, 1, AttnBwdSmem<4, true>, false>(sm, G, item, d, q, k, v, out, lse, d_out, nullptr,
+                                                                            dk, dv, half, qk_slope);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -657,15 +666,20 @@ int eqd_launch_attention_bwd_act(const EqdGraph* g, int d, const float* q, const
     return bf16 ? attention_bwd_bf16(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, qk_slope, st)
                 : attention_bwd_f32(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, qk_slope, st);
 }
-// 1 if eqd_launch_attention_bwd_gather will take the fused launch (fp32 attention of a 64-wide layer on the half-block
-// path - what every layer but the first runs at every size); otherwise it issues the two launches one after the other
+// 1 if eqd_launch_attention_bwd_gather will take the fused launch (the attention of a 64-wide layer on the half-block path,
+// fp32 or with bf16 tiles in LDS - what every layer but the first runs at every size); otherwise it issues the two launches
+// one after the other
 int eqd_attention_bwd_gather_fused(const EqdGraph* g, int d, const float* q, const float* k, const float* v, const float* out,
                                    const float* d_out, bool bf16) {
     const char* f = getenv("EQD_FUSE_GATHER");
     if (f && f[0] == '0' && f[1] == 0) return 0;
     const char* hb = getenv("EQD_ATT_BWD_SPLIT");
     if (hb && hb[0] == '0' && hb[1] == 0) return 0;
-    if (bf16 || d != 64 || g->n_att_items <= 0 || g->n_att_items % 8 != 0) return 0;
+    if (d != 64 || g->n_att_items <= 0 || g->n_att_items % 8 != 0) return 0;
+    if (bf16) {
+        const char* nb2 = getenv("EQD_ATT_LB_NB");
+        if (!att_lds_bf16() || (nb2 && nb2[0] == '2')) return 0;
+    }
     return aligned16(q) && aligned16(k) && aligned16(v) && aligned16(d_out) && aligned16(out);
 }
 int eqd_launch_attention_bwd_gather(const EqdGraph* g, int d, const float* q, const float* k, const float* v, const float* out,
@@ -687,12 +701,15 @@ int eqd_launch_attention_bwd_gather(const EqdGraph* g, int d, const float* q, co
     if (int e = eqd_gather_plan(g, gc, pending, &GA, &RA, &nred)) return e;
     const int n_attn = 4 * g->n_att_items;
     const dim3 grid(n_attn + GA.ngather + nred);
-    if (gc->dz_bf16)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_gather<true>), grid, dim3(EQD_BLOCK), 0, st, *g, d, q, k, v, out, lse, d_out,
-                           dq, dk, dv, delta, qk_slope, n_attn, nred, GA, RA);
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_gather<false>), grid, dim3(EQD_BLOCK), 0, st, *g, d, q, k, v, out, lse, d_out,
-                           dq, dk, dv, delta, qk_slope, n_attn, nred, GA, RA);
+#define EQD_ABG_LAUNCH(BFDZ_, LB_)                                                                                          \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_gather<BFDZ_, LB_>), grid, dim3(EQD_BLOCK), 0, st, *g, d, q, k, v, out, lse,     \
+                       d_out, dq, dk, dv, delta, qk_slope, n_attn, nred, GA, RA)
+    if (bf16) {
+        if (gc->dz_bf16) EQD_ABG_LAUNCH(true, true); else EQD_ABG_LAUNCH(false, true);
+    } else {
+        if (gc->dz_bf16) EQD_ABG_LAUNCH(true, false); else EQD_ABG_LAUNCH(false, false);
+    }
+#undef EQD_ABG_LAUNCH
     if (int rc = eqd_check_launch("k_attn_bwd_gather")) return rc;
     return eqd_gather_rest(pending, st);
 }
