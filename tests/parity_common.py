@@ -1658,6 +1658,42 @@ def check_fused_forward(dev):
         assert torch.equal(a, b)
 
 
+def check_gather_rides_in_attention_backward(dev):
+    """The node gather + pending reductions as trailing workgroups of the attention-backward launch (k_attn_bwd_gather,
+    csrc/eqd_attn_kernels.hip) against the separate launches (EQD_FUSE_GATHER=0): the same device bodies, so bit-identical
+    outputs and gradients, fp32 and bf16 mode; and the switch really selects the launch (64-wide layers only: the 69-wide
+    first layer keeps k_attn_bwd + k_node_gather)."""
+    import os
+    pairs = synthetic.make_pairs([(60, 75), (90, 48), (7, 130), (33, 16)], 21)
+    for over in ({}, {'hip_storage_dtype': 'bf16'}):
+        args = dict(port.default_args(iegmn_n_lays=3, skip_weight_h=0.75), **over)
+        sd = port.init_state_dict(args, seed=4)
+        res, names = {}, {}
+        for mode in ('1', '0'):
+            os.environ['EQD_FUSE_GATHER'] = mode
+            try:
+                net = build_model(args, sd, dev)
+                g = G.batch_pairs(pairs).to(dev)
+                lib_ = lib()
+                L.profiling = True
+                L.check(lib_.eqd_profile_begin(st(dev), 1024))
+                try:
+                    outs = net.forward_batched(g)
+                    (outs[0].square().sum() + outs[1].square().sum() + outs[2].square().sum()).backward()
+                    sync(dev)
+                finally:
+                    n = lib_.eqd_profile_end()
+                    L.profiling = False
+                names[mode] = [lib_.eqd_profile_name(i).decode() for i in range(n)]
+                res[mode] = ([t.detach().cpu().clone() for t in outs], [p.grad.detach().cpu().clone() for p in net.parameters()])
+            finally:
+                del os.environ['EQD_FUSE_GATHER']
+        for a, b in zip(res['1'][0] + res['1'][1], res['0'][0] + res['0'][1]):
+            assert torch.equal(a, b), f'fused vs separate gather launch differ ({over})'
+        assert names['1'].count('k_attn_bwd_gather') == 2 and names['1'].count('k_node_gather') == 1, sorted(set(names['1']))
+        assert names['0'].count('k_attn_bwd_gather') == 0 and names['0'].count('k_node_gather') == 3, sorted(set(names['0']))
+
+
 def check_attention_bf16(dev, d, sizes=((70, 45), (33, 101))):
     """bf16 mode of the cross-attention op (every contraction on the bf16 MFMA, fp32 accumulate / softmax) against the
     torch restatement with bf16-rounded GEMM inputs.  The kernels round the UN-normalised softmax weights of each tile

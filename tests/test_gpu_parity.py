@@ -232,6 +232,12 @@ def test_fused_forward_launch_is_bit_identical(dev):
     pc.check_fused_forward(dev)
 
 
+def test_gather_rides_in_the_attention_backward_launch(dev):
+    """k_attn_bwd_gather (attention backward + node gather + reductions in one launch) vs the separate launches: bit-identical"""
+    from tests import parity_common as pc
+    pc.check_gather_rides_in_attention_backward(dev)
+
+
 @pytest.mark.parametrize('d', [64, 80])
 def test_cross_attention_bf16(dev, d):
     from tests import parity_common as pc

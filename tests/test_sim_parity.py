@@ -183,6 +183,10 @@ def test_fused_forward_launch_is_bit_identical():
     pc.check_fused_forward(DEV)
 
 
+def test_gather_rides_in_the_attention_backward_launch():
+    pc.check_gather_rides_in_attention_backward(DEV)
+
+
 @pytest.mark.parametrize('d', [64, 80])
 def test_cross_attention_bf16(d):
     pc.check_attention_bf16(DEV, d)
