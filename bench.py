@@ -67,7 +67,8 @@ def step_flops_as_written(sizes, L, d0=69, d=64, K=50):
     return tot
 
 
-def kernel_work_model(sizes, L, n_nodes, n_edges, cross=True, d0=69, dh=64, d_emb=64, K=50, fused_fwd=False, rowwave='k_rowres'):
+def kernel_work_model(sizes, L, n_nodes, n_edges, cross=True, d0=69, dh=64, d_emb=64, K=50, fused_fwd=False, rowwave='k_rowres',
+                      fused_gather=False):
     """Per-STEP work of each kernel family, from the launch structure of eqd_model_forward / eqd_model_backward
     (csrc/eqd_driver.hip): `flops` = FLOPs the kernel executes on the MFMA pipes for its GEMMs (2 per MAC),
     `flops_written` = the model-as-written share where SURVEY.md section 8d defines one (edge kernels, attention),
@@ -77,7 +78,10 @@ def kernel_work_model(sizes, L, n_nodes, n_edges, cross=True, d0=69, dh=64, d_em
     pp = sum(float(a) * b for a, b in sizes)              # sum over pairs of n_lig * n_rec
     W = {k: dict(flops=0.0, flops_written=0.0, bytes=0.0) for k in
          ('k_linear', 'k_rowchain', 'k_rowwave', 'k_rowres', 'k_attn_fwd', 'k_attn_bwd', 'k_edge_fwd', 'k_edge_bwd', 'k_node_gather',
-          'k_atb', 'k_edge_attn_fwd')}   # k_edge_attn_fwd: the 64-wide layers' edge + attention forward in one launch (small batches)
+          'k_atb', 'k_atb_reduce', 'k_edge_attn_fwd', 'k_attn_bwd_gather', 'k_keypoint', 'k_keypoint_bwd_a', 'k_keypoint_bwd_b',
+          'k_head_u', 'k_head_u_bwd')}
+    # k_edge_attn_fwd: the 64-wide layers' edge + attention forward in one launch (small batches); k_attn_bwd_gather: the
+    # 64-wide layers' attention backward with the edge backward's node gather (+ the partial reductions) in the same launch
     for l in range(L):
         d = d0 if l == 0 else dh
         da = (d + 15) // 16 * 16
@@ -106,9 +110,10 @@ def kernel_work_model(sizes, L, n_nodes, n_edges, cross=True, d0=69, dh=64, d_em
             W[fa]['flops'] += 8 * pp * da
             W[fa]['flops_written'] += 8 * pp * d
             W[fa]['bytes'] += N * 4 * (4 * da + 1)
-            W['k_attn_bwd']['flops'] += 28 * pp * da
-            W['k_attn_bwd']['flops_written'] += 16 * pp * d
-            W['k_attn_bwd']['bytes'] += N * 4 * (8 * da + 2)
+            ab = 'k_attn_bwd_gather' if (fused_gather and d == 64) else 'k_attn_bwd'
+            W[ab]['flops'] += 28 * pp * da
+            W[ab]['flops_written'] += 16 * pp * d
+            W[ab]['bytes'] += N * 4 * (8 * da + 2)
         # edge kernels (as written: 2 (2 d + 42) 64 + 2 64 64 + 2 64 64 + 2 64 per edge; executed: the P/Q split moves
         # 2 (2 d) 64 per edge to k_linear - the executed count comes from the PMC file when present)
         fe = 2 * (2 * d + 42) * 64 + 2 * 64 * 64 + 2 * 64 * 64 + 2 * 64
@@ -119,7 +124,7 @@ def kernel_work_model(sizes, L, n_nodes, n_edges, cross=True, d0=69, dh=64, d_em
         W['k_edge_bwd']['flops_written'] += 2 * E * fe
         W['k_edge_bwd']['flops'] += E * (3 * fx - 2 * 42 * 64)      # recompute + data gradients + weight gradients
         W['k_edge_bwd']['bytes'] += 2 * (N * 540 + E * 112)
-        W['k_node_gather']['bytes'] += E * 272 + N * 540
+        W['k_attn_bwd_gather' if (fused_gather and cross and d == 64) else 'k_node_gather']['bytes'] += E * 272 + N * 540
         # end-of-pass weight-gradient GEMMs of the node-level Linears
         W['k_atb']['flops'] += N * 2 * (dh * d + d * d + d * 64 + (d * d if cross else 0) + d * d0 + 2 * 64 * d
                                         + (3 * d * d if cross else 0))
@@ -130,6 +135,21 @@ def kernel_work_model(sizes, L, n_nodes, n_edges, cross=True, d0=69, dh=64, d_em
     W['k_linear']['flops'] += N * (2 * d_emb * (4 * d0 + 128))
     W['k_linear']['bytes'] += N * 4 * (3 * 80 + 128 + d0)
     W['k_atb']['flops'] += N * 2 * 64 * 64
+    # second stage of the weight-gradient GEMMs: the per-part partial outputs summed (bytes = what the first stage wrote,
+    # taken from the PMC passes only - the part count is a launch-shape choice, no algorithmic figure exists for it)
+    # keypoint head (6.4 kFLOP / node; N (64 + K + 3) 4 bytes): scores of K heads per node, softmax
+    # over the protein's nodes, keypoints; backward twice that
+    W['k_keypoint']['flops'] += N * 2 * 64 * K
+    W['k_keypoint']['bytes'] += N * 4 * (64 + K + 3)
+    W['k_keypoint_bwd_a']['flops'] += N * 2 * 64 * K
+    W['k_keypoint_bwd_a']['bytes'] += N * 4 * (64 + 2 * K + 3)
+    W['k_keypoint_bwd_b']['flops'] += N * 2 * 64 * K
+    W['k_keypoint_bwd_b']['bytes'] += N * 4 * (64 + K + 64)
+    nb2 = 2.0 * len(sizes)
+    W['k_head_u']['flops'] += nb2 * K * 2 * 2 * 64 * 64
+    W['k_head_u']['bytes'] += K * 2 * 64 * 64 * 4 + nb2 * K * 64 * 4 * 2
+    W['k_head_u_bwd']['flops'] += nb2 * K * 2 * 4 * 64 * 64
+    W['k_head_u_bwd']['bytes'] += K * 2 * 64 * 64 * 4 * 2 + nb2 * K * 64 * 4 * 3
     return W
 
 
@@ -340,15 +360,16 @@ def profile_step(compute, dev, reps=4):
     return {k: [v[0] / reps, v[1] / reps] for k, v in acc.items()}, overhead, n_launch
 
 
-def kernel_rooflines(prof, work, bf16, step_us, pmc):
-    """roofline_all: one entry per kernel family that takes >= 3 % of the step (plus the two edge kernels always)."""
+def kernel_rooflines(prof, work, bf16, step_us, pmc, traffic=None):
+    """roofline_all: one entry per kernel family that takes >= 2 % of the step's kernel time (plus the two edge kernels
+    always); `traffic` = per-family {FETCH_SIZE_KB, WRITE_SIZE_KB} per launch of the newest committed PMC summary."""
     out = {}
     total = sum(v[1] for v in prof.values())
     peak_tf = PEAK_BF16_TFLOPS if bf16 else PEAK_FP32_TFLOPS
     for name, (calls, us) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
         share = us / total if total > 0 else 0.0
         w = work.get(name)
-        if w is None or (w['flops'] == 0 and w['bytes'] == 0) or (share < 0.03 and not name.startswith('k_edge')):
+        if w is None or (w['flops'] == 0 and w['bytes'] == 0) or (share < 0.02 and not name.startswith('k_edge')):
             continue
         t = us * 1e-6
         tf_x = w['flops'] / t / 1e12
@@ -368,12 +389,21 @@ def kernel_rooflines(prof, work, bf16, step_us, pmc):
             e["bound"] = "hbm"
         else:
             e["bound"] = "mfma" if tf_x / peak_tf >= gb / PEAK_HBM_GBS else "hbm"
+        tr = (traffic or {}).get(name)
+        if tr and w['bytes'] > 0 and calls > 0:
+            # measured HBM-side bytes per launch, (2 FETCH_SIZE + WRITE_SIZE) KB (MI355X_MICROARCH.md: FETCH_SIZE counts
+            # 128-B requests as 64 B on gfx950), over the algorithmic bytes per launch of the work model
+            meas = (2 * tr['FETCH_SIZE_KB'] + tr['WRITE_SIZE_KB']) * 1024
+            e["traffic_bytes_per_launch"] = int(meas)
+            e["algorithmic_bytes_per_launch"] = int(w['bytes'] / calls)
+            e["traffic_ratio"] = round(meas / (w['bytes'] / calls), 2)
         for k, v in pmc.items():        # hardware counters of an earlier rocprofv3 --pmc pass (profiles/*.json)
             if name in k and 'MfmaUtil' in v:
                 e.setdefault("pmc", {})[k] = {"MfmaUtil_pct": v['MfmaUtil'],
                                               "executed_mfma_gflop_per_launch": v.get('executed_mfma_gflop_per_launch')}
         out[name] = e
-    return out, total
+    covered = sum(e["share_of_kernel_time"] for e in out.values())
+    return out, total, covered
 
 
 def physical_cores():
@@ -451,6 +481,24 @@ def cpu_baseline(args_model, sd, pairs, budget_s=26.0):
                       f"{torch.__version__} CPU"}
 
 
+def load_traffic(workload):
+    """Per-family FETCH_SIZE / WRITE_SIZE (KB per launch) of `workload` from the newest committed PMC summary, and where it
+    came from (file, the workload's own collection stamp and git hash when the summary carries them)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*traffic.json')), key=_profile_order)      # newest last
+    for f in reversed(files):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if workload in d:
+            meta = d.get('_workloads', {}).get(workload, {})
+            src = {"file": 'profiles/' + os.path.basename(f), "collected": meta.get('collected', d.get('_collected')),
+                   "git_head": meta.get('git_head')}
+            return d[workload], src
+    return {}, None
+
+
 def load_pmc(workload):
     """MFMA utilisation / executed MFMA FLOPs per kernel from the newest committed PMC summary (profiles/*pmc_mfma*.json)."""
     import glob
@@ -465,64 +513,27 @@ def load_pmc(workload):
     return best
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--workload', default='B', choices=sorted(WORKLOADS))
-    ap.add_argument('--dtype', default=None, choices=('f32', 'bf16'),
-                    help="arithmetic of the GEMMs: f32 (default for A, B, C, E) or bf16 inputs with fp32 accumulate "
-                         "(default for D; `--workload C --dtype bf16` is BASELINE.json configs[2])")
-    ap.add_argument('--dropout', type=float, default=0.0,
-                    help="args['dropout'] of the model, in training mode (src/utils/args.py:240 draws 0 or 0.25): every step "
-                         "then draws fresh nn.Dropout masks with torch's device generator in the reference's order (inside "
-                         "the replayed graph) and the kernels apply them; reported WITHOUT the roofline / CPU-baseline parts")
-    ap.add_argument('--dropout-masks', default='torch', choices=('torch', 'library'),
-                    help="with --dropout: 'torch' = nn.Dropout's own random stream (torch's dropout on [E, 64] tensors of "
-                         "ones, bit-packed by eqd_dropout_pack_edges); 'library' = eqd_dropout_draw (counter-based, one launch, "
-                         "no [E, 64] tensors; args['hip_dropout_masks'])")
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-roofline', action='store_true')
-    ap.add_argument('--eager', action='store_true', help='launch every kernel of every step from the host instead of replaying a captured hipGraph of the step (zero-grad, forward, loss, backward; the gradient all-reduce always runs outside the graph).  Same kernels either way; the replay takes the host (torch autograd + the launches, 0.7-1.5 ms depending on the box) off the critical path of a 1.5 ms step')
-    ap.add_argument('--graph', action='store_true', help='(default; kept for older command lines)')
-    a = ap.parse_args()
+class _Run:
+    """One timed workload: everything main() needs to report it."""
 
-    rank = int(os.environ.get('RANK', 0))
-    local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
-    if a.gpus != world and world == 1 and a.gpus > 1:
-        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+
+def run_workload(workload, dtype, steps, warmup, dev, rank, world, use_dist, backend, dropout=0.0, dropout_masks='torch',
+                 eager=False, time_allreduce=True):
+    """Build the model + the synthetic batch of `workload`, capture zero-grad -> forward -> loss -> backward (+ the RCCL
+    all-reduce under a process group) into a hipGraph, run `warmup` untimed and `steps` timed steps bracketed by
+    barrier + synchronize, max over ranks.  Returns a _Run (seconds for the timed steps in .dt)."""
     import torch.distributed as dist
-    # EQD_BENCH_ONE_DEVICE=1 + EQD_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow (barriers, max over ranks,
-    # rank-0 report, gradient all-reduce) on a box with a single GPU; real runs use one GPU per rank over RCCL
-    one_dev = os.environ.get('EQD_BENCH_ONE_DEVICE') == '1'
-    dev = torch.device('cuda', 0 if one_dev else local_rank)
-    torch.cuda.set_device(dev)
-    # under torch.distributed.run (RANK set) the process group is created even for a world of one, so that the RCCL
-    # all-reduce of the flat gradient is part of the step and gets measured; a plain `python bench.py` has no group
-    use_dist = world > 1 or 'RANK' in os.environ
-    backend = None
-    if use_dist:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29533')
-        backend = os.environ.get('EQD_BENCH_BACKEND', 'nccl')
-        if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=dev)
-        else:
-            dist.init_process_group(backend)
-
     from equidock_public_amd import config, graph, model, parallel, synthetic
-
-    ppg, uniform, L, shared, skh, wl_dtype, desc = WORKLOADS[a.workload]
-    dtype = a.dtype or wl_dtype
+    from equidock_public_amd import losses
+    R = _Run()
+    ppg, uniform, L, shared, skh, wl_dtype, desc = WORKLOADS[workload]
+    dtype = dtype or wl_dtype
     args_model = config.published_args(iegmn_n_lays=L, shared_layers=shared, skip_weight_h=skh, device=dev)
     if dtype == 'bf16':
         args_model['hip_storage_dtype'] = 'bf16'
-    if a.dropout > 0:
-        args_model['dropout'] = a.dropout
-        args_model['hip_dropout_masks'] = a.dropout_masks
-        a.no_cpu_baseline = a.no_roofline = True
+    if dropout > 0:
+        args_model['dropout'] = dropout
+        args_model['hip_dropout_masks'] = dropout_masks
     sd = config.seeded_state_dict(args_model, seed=0)
     net = model.Rigid_Body_Docking_Net(args_model).to(dev)
     net.load_state_dict(sd)
@@ -535,7 +546,6 @@ def main():
     packed = g.pack()
     lig_w = torch.cat([torch.full((n, 1), 1.0 / (3 * n)) for n in packed.lig_counts]).to(dev)
     reducer = parallel.FlatGradAllReduce(net)
-    from equidock_public_amd import losses
     scalar_loss = losses.ScalarLoss(packed, args_model['num_att_heads'])
 
     def compute():
@@ -590,7 +600,7 @@ def main():
             if with_allreduce:
                 reducer.reduce(force=True)
         return gr, loss_
-    if not a.eager:
+    if not eager:
         want_ar = use_dist and backend == 'nccl' and os.environ.get('EQD_BENCH_ALLREDUCE_IN_GRAPH', '1') == '1'
         for with_ar in ([True, False] if want_ar else [False]):
             try:
@@ -614,13 +624,13 @@ def main():
             reducer.reduce(force=True)
         return loss
 
-    for _ in range(a.warmup):
+    for _ in range(warmup):
         step()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         loss = step()
     host_dt = time.perf_counter() - t0      # host-side enqueue time (== dt when the step is launch-bound)
     torch.cuda.synchronize()
@@ -634,7 +644,7 @@ def main():
     # the collective on its own (outside the timed region): HIP events around batches of back-to-back all-reduces of the
     # flat gradient buffer, every rank taking part; max over ranks
     allreduce_us = None
-    if use_dist:
+    if use_dist and time_allreduce:
         for _ in range(3):
             reducer.reduce(force=True)
         torch.cuda.synchronize()
@@ -652,8 +662,110 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         allreduce_us = float(tt.item())
     status = net.iegmn_original.last_svd_status
-    svd_bad = int((status != 0).sum().item())
+    R.svd_bad = int((status != 0).sum().item())
+    R.workload, R.dtype, R.desc, R.ppg, R.L, R.shared, R.skh = workload, dtype, desc, ppg, L, shared, skh
+    R.uniform, R.sizes, R.pairs, R.sd, R.args_model = uniform, sizes, pairs, sd, args_model
+    R.net, R.packed, R.reducer, R.compute = net, packed, reducer, compute
+    R.dt, R.host_dt, R.loss, R.steps, R.warmup = dt, host_dt, float(loss.detach()), steps, warmup
+    R.graph_mode, R.allreduce_in_graph, R.allreduce_us = graph_mode, allreduce_in_graph, allreduce_us
+    R.launches = None
+    return R
 
+
+def secondary_line(R, world):
+    """The short form of a workload's result for the bench line's "secondary" block."""
+    ms_step = R.dt / R.steps * 1e3
+    flops_step = 3.0 * step_flops_as_written(R.sizes, R.L)
+    peak_tf = PEAK_BF16_TFLOPS if R.dtype == 'bf16' else PEAK_FP32_TFLOPS
+    out = {"workload": R.desc, "value": round(R.ppg * world * R.steps / R.dt, 2), "unit": "pairs/s",
+           "ms_per_step": round(ms_step, 4), "steps": R.steps, "warmup": R.warmup,
+           "dtype": "f32" if R.dtype == 'f32' else "bf16 GEMM inputs, fp32 accumulate",
+           "pairs_per_gpu": R.ppg, "nodes_per_gpu": R.packed.n_nodes, "edges_per_gpu": R.packed.n_edges,
+           "launch_mode": R.graph_mode, "loss": R.loss, "svd_guard_pairs": R.svd_bad,
+           "whole_step_frac_of_mfma_peak": round(flops_step / (ms_step * 1e-3) / 1e12 / peak_tf, 4)}
+    if not R.uniform:
+        pp = sum(x * y for x, y in R.sizes)
+        out["residue_pairs_per_s"] = round(pp * world * R.steps / R.dt, 1)
+    if R.allreduce_us is not None:
+        out["allreduce_in_graph"] = bool(R.allreduce_in_graph)
+        out["allreduce_us_per_step"] = round(R.allreduce_us, 2)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--workload', default='B', choices=sorted(WORKLOADS))
+    ap.add_argument('--dtype', default=None, choices=('f32', 'bf16'),
+                    help="arithmetic of the GEMMs: f32 (default for A, B, C, E) or bf16 inputs with fp32 accumulate "
+                         "(default for D; `--workload C --dtype bf16` is BASELINE.json configs[2])")
+    ap.add_argument('--dropout', type=float, default=0.0,
+                    help="args['dropout'] of the model, in training mode (src/utils/args.py:240 draws 0 or 0.25): every step "
+                         "then draws fresh nn.Dropout masks with torch's device generator in the reference's order (inside "
+                         "the replayed graph) and the kernels apply them; reported WITHOUT the roofline / CPU-baseline parts")
+    ap.add_argument('--dropout-masks', default='torch', choices=('torch', 'library'),
+                    help="with --dropout: 'torch' = nn.Dropout's own random stream (torch's dropout on [E, 64] tensors of "
+                         "ones, bit-packed by eqd_dropout_pack_edges); 'library' = eqd_dropout_draw (counter-based, one launch, "
+                         "no [E, 64] tensors; args['hip_dropout_masks'])")
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true',
+                    help="skip the \"secondary\" block of the default (workload B) line: short timed runs of the other BASELINE "
+                         "configs - C in bf16 (configs[2]), E (configs[4]) and the ragged workload R on one GPU; D (configs[3], "
+                         "64 x (300,300) per GPU in bf16 with the RCCL all-reduce) under torch.distributed.run")
+    ap.add_argument('--eager', action='store_true', help='launch every kernel of every step from the host instead of replaying a captured hipGraph of the step (zero-grad, forward, loss, backward; the gradient all-reduce always runs outside the graph).  Same kernels either way; the replay takes the host (torch autograd + the launches, 0.7-1.5 ms depending on the box) off the critical path of a 1.5 ms step')
+    ap.add_argument('--graph', action='store_true', help='(default; kept for older command lines)')
+    a = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if a.gpus != world and world == 1 and a.gpus > 1:
+        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    import torch.distributed as dist
+    # EQD_BENCH_ONE_DEVICE=1 + EQD_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow (barriers, max over ranks,
+    # rank-0 report, gradient all-reduce) on a box with a single GPU; real runs use one GPU per rank over RCCL
+    one_dev = os.environ.get('EQD_BENCH_ONE_DEVICE') == '1'
+    dev = torch.device('cuda', 0 if one_dev else local_rank)
+    torch.cuda.set_device(dev)
+    # under torch.distributed.run (RANK set) the process group is created even for a world of one, so that the RCCL
+    # all-reduce of the flat gradient is part of the step and gets measured; a plain `python bench.py` has no group
+    use_dist = world > 1 or 'RANK' in os.environ
+    backend = None
+    if use_dist:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        backend = os.environ.get('EQD_BENCH_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
+
+    R = run_workload(a.workload, a.dtype, a.steps, a.warmup, dev, rank, world, use_dist, backend, dropout=a.dropout,
+                     dropout_masks=a.dropout_masks, eager=a.eager)
+    if a.dropout > 0:
+        a.no_cpu_baseline = a.no_roofline = True
+    dtype, desc, ppg, L, shared, skh = R.dtype, R.desc, R.ppg, R.L, R.shared, R.skh
+    uniform, sizes, pairs, sd, net, packed, reducer, compute = R.uniform, R.sizes, R.pairs, R.sd, R.net, R.packed, R.reducer, R.compute
+    dt, host_dt, graph_mode, allreduce_in_graph, allreduce_us = R.dt, R.host_dt, R.graph_mode, R.allreduce_in_graph, R.allreduce_us
+    svd_bad = R.svd_bad
+    # the other BASELINE configs, timed the same way (graph replay, barrier + synchronize on both sides, max over ranks) with
+    # fewer steps, so that the driver's default run carries a number for each of them (VERDICT r03 items 2c, 8)
+    secondary = {}
+    if a.workload == 'B' and a.dropout == 0 and not a.eager and not a.no_secondary:
+        todo = [('D', 'D', None)] if use_dist else [('C_bf16', 'C', 'bf16'), ('E', 'E', None), ('R', 'R', None)]
+        for key, wl, dt_ in todo:
+            t_sec = time.perf_counter()
+            try:
+                R2 = run_workload(wl, dt_, 10, 3, dev, rank, world, use_dist, backend)
+                secondary[key] = secondary_line(R2, world)
+                secondary[key]["wall_s_incl_setup"] = round(time.perf_counter() - t_sec, 2)
+                del R2
+            except Exception as e:      # the primary line must not die on a secondary workload
+                secondary[key] = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.empty_cache()
     out = None
     if rank == 0:
         total_pairs = ppg * world * a.steps
@@ -668,7 +780,7 @@ def main():
             "config": {"workload": desc, "pairs_per_gpu": ppg, "nodes_per_gpu": packed.n_nodes,
                        "edges_per_gpu": packed.n_edges, "layers": L, "parallelism": f"dp{world}",
                        "weights": "PyTorch default init (seed 0), ROT key/query x40 (SURVEY.md section 8c)",
-                       "loss": float(loss.detach()), "svd_guard_pairs": svd_bad,
+                       "loss": R.loss, "svd_guard_pairs": svd_bad,
                        "host_enqueue_ms_per_step": round(host_dt / a.steps * 1e3, 4), "launch_mode": graph_mode,
                        "dropout": a.dropout, "dropout_masks": (a.dropout_masks if a.dropout > 0 else None)},
             # data parallel: ranks of the RCCL communicator the flat-gradient all-reduce ran on (0 = no process group: a
@@ -701,15 +813,18 @@ def main():
             try:
                 prof, ev_us, n_launch = profile_step(compute, dev)
                 work = kernel_work_model(sizes, L, packed.n_nodes, packed.n_edges, fused_fwd='k_edge_attn_fwd' in prof,
-                                         rowwave=next((k for k in ('k_rowres', 'k_rowwave') if k in prof), None))
-                allk, ktot = kernel_rooflines(prof, work, dtype == 'bf16', ms_step * 1e3,
-                                              load_pmc(a.workload + ('_bf16' if dtype == 'bf16' else '')))
+                                         rowwave=next((k for k in ('k_rowres', 'k_rowwave') if k in prof), None),
+                                         fused_gather='k_attn_bwd_gather' in prof)
+                wkey = a.workload + ('_bf16' if dtype == 'bf16' else '')
+                traffic, traffic_src = load_traffic(wkey)
+                allk, ktot, covered = kernel_rooflines(prof, work, dtype == 'bf16', ms_step * 1e3, load_pmc(wkey), traffic)
                 for k in ('k_edge_fwd', 'k_edge_bwd'):     # keep the standalone batched-launch figures beside the in-step ones
                     if k in allk:
                         allk[k]["standalone"] = rl[k]
                 out["roofline_all"] = allk
                 out["step_profile"] = {
                     "library_launches_per_step": n_launch, "kernel_us_per_step": round(ktot, 1),
+                    "share_of_kernel_time_in_roofline_all": round(covered, 4), "traffic_source": traffic_src,
                     "event_overhead_us_subtracted_per_launch": round(ev_us, 2),
                     "us_per_step_by_kernel": {k: round(v[1], 1) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
                     "method": "eqd_profile_* (HIP event after every library launch on the launch stream, eager step "
@@ -717,7 +832,10 @@ def main():
             except Exception as e:      # the bench line must not die on the diagnostic part
                 out["roofline_all"] = rl
                 out["step_profile"] = {"error": f"{type(e).__name__}: {e}"}
+        if secondary:
+            out["secondary"] = secondary
         if world == 1 and not a.no_cpu_baseline:
+            from equidock_public_amd import config
             out["cpu_baseline"] = cpu_baseline(config.published_args(iegmn_n_lays=L, shared_layers=shared,
                                                                      skip_weight_h=skh), sd, pairs)
         print(json.dumps(out), flush=True)

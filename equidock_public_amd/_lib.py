@@ -99,6 +99,7 @@ def _declare(lib):
     lib.eqd_clash_workspace_bytes.restype = C.c_size_t
     lib.eqd_profile_name.restype = C.c_char_p
     lib.eqd_profile_us.restype = C.c_float
+    lib.eqd_tunables_reload.restype = None
     for name in ('eqd_model_layer_state', 'eqd_model_lrelu_signs', 'eqd_profile_begin', 'eqd_profile_end', 'eqd_profile_mark', 'eqd_ctx_create', 'eqd_ctx_destroy', 'eqd_model_check', 'eqd_model_forward', 'eqd_model_backward', 'eqd_linear', 'eqd_atb',
                  'eqd_edge_message_fwd', 'eqd_edge_message_bwd', 'eqd_edge_message_bwd_kernel_only',
                  'eqd_cross_attention_fwd', 'eqd_cross_attention_fwd_bf16', 'eqd_cross_attention_bwd_bf16',
@@ -120,7 +121,8 @@ EXPORTS = ('eqd_model_layer_state', 'eqd_model_lrelu_signs', 'eqd_profile_begin'
            'eqd_kabsch_fwd', 'eqd_kabsch_bwd', 'eqd_rigid_apply_fwd', 'eqd_rigid_apply_bwd', 'eqd_pair_losses_fwd',
            'eqd_pair_losses_bwd', 'eqd_scalar_loss', 'eqd_pocket_ot_cost', 'eqd_pocket_ot_fwd', 'eqd_pocket_ot_bwd',
            'eqd_rigid_augment', 'eqd_protein_graph_distances', 'eqd_protein_graph_select', 'eqd_protein_graph_edges',
-           'eqd_clash_workspace_bytes', 'eqd_clash_iterations', 'eqd_dropout_pack_edges', 'eqd_dropout_draw')
+           'eqd_clash_workspace_bytes', 'eqd_clash_iterations', 'eqd_dropout_pack_edges', 'eqd_dropout_draw',
+           'eqd_tunables_reload')
 
 
 def load_library():
@@ -152,6 +154,13 @@ def load_library_for_testing(path):
 def unload_for_testing():
     global _lib, _is_sim
     _lib, _is_sim = None, False
+
+
+def reload_tunables():
+    """Make the loaded library re-read its EQD_* experiment switches (it snapshots them once per process; tests and A/B
+    measurements that change the environment afterwards call this).  No-op when no library is loaded yet."""
+    if _lib is not None:
+        _lib.eqd_tunables_reload()
 
 
 def is_simulator():

@@ -530,7 +530,7 @@ static int attn_launch_bwd(const EqdGraph* g, int d, const float* q, const float
 // EQD_ATT_SPLIT=0|1 forces either (tests)
 static bool att_half_blocks(const EqdGraph* g) {
     if (g->n_att_items % 8) return false;   // the half-block workgroup map needs the 8-way interleaved list (header)
-    const char* f = getenv("EQD_ATT_SPLIT");
+    const char* f = eqd_tunable("EQD_ATT_SPLIT");
     if (f && (f[0] == '0' || f[0] == '1') && f[1] == 0) return f[0] == '1';
     return g->n_att_items <= eqd_num_cus();
 }
@@ -575,7 +575,7 @@ static int attention_bwd_f32(const EqdGraph* g, int d, const float* q, const flo
     const bool al = aligned16(q) && aligned16(k) && aligned16(v) && aligned16(d_out) && aligned16(out);
     // d = 64: half blocks (two workgroups per CU, see k_attn_bwd) - config C +2.3 %, E +0.9 %, B unchanged;
     // EQD_ATT_BWD_SPLIT=0 keeps 32-row blocks (tests)
-    const char* hb = getenv("EQD_ATT_BWD_SPLIT");
+    const char* hb = eqd_tunable("EQD_ATT_BWD_SPLIT");
     const bool half = !(hb && hb[0] == '0' && hb[1] == 0) && g->n_att_items % 8 == 0;
     if (d == 64 && al && half) return attn_launch_bwd<4, true, 1>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st, qk_slope);
     if (d == 64 && al) return attn_launch_bwd<4, true, 2>(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, st, qk_slope);
@@ -587,7 +587,7 @@ static int attention_bwd_f32(const EqdGraph* g, int d, const float* q, const flo
 // bf16 mode, d = 64: the streamed tiles live in LDS as bf16 (eqd_attn_lb_inl.h) unless EQD_ATT_LB=0 (the first bf16 version:
 // fp32 tiles in LDS, rounded per MFMA operand; kept for the 80-wide first layer, tests and A/B measurements)
 static bool att_lds_bf16() {
-    const char* f = getenv("EQD_ATT_LB");
+    const char* f = eqd_tunable("EQD_ATT_LB");
     return !(f && f[0] == '0' && f[1] == 0);
 }
 
@@ -635,7 +635,7 @@ static int attention_bwd_bf16(const EqdGraph* g, int d, const float* q, const fl
     if (g->n_att_items <= 0) return EQD_OK;
     hipStream_t st = (hipStream_t)stream;
     if (d == 64 && att_lds_bf16()) {      // streamed tiles held in LDS as bf16 (eqd_attn_lb_inl.h)
-        const char* nb2 = getenv("EQD_ATT_LB_NB");      // experiments: 2 = 32-row blocks in the backward
+        const char* nb2 = eqd_tunable("EQD_ATT_LB_NB");      // experiments: 2 = 32-row blocks in the backward
         if (g->n_att_items % 8 == 0 && !(nb2 && nb2[0] == '2'))
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_lb<1>), dim3(4 * g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, q, k, v, out,
                                lse, d_out, dq, dk, dv, delta, qk_slope);
@@ -671,13 +671,13 @@ int eqd_launch_attention_bwd_act(const EqdGraph* g, int d, const float* q, const
 // one after the other
 int eqd_attention_bwd_gather_fused(const EqdGraph* g, int d, const float* q, const float* k, const float* v, const float* out,
                                    const float* d_out, bool bf16) {
-    const char* f = getenv("EQD_FUSE_GATHER");
+    const char* f = eqd_tunable("EQD_FUSE_GATHER");
     if (f && f[0] == '0' && f[1] == 0) return 0;
-    const char* hb = getenv("EQD_ATT_BWD_SPLIT");
+    const char* hb = eqd_tunable("EQD_ATT_BWD_SPLIT");
     if (hb && hb[0] == '0' && hb[1] == 0) return 0;
     if (d != 64 || g->n_att_items <= 0 || g->n_att_items % 8 != 0) return 0;
     if (bf16) {
-        const char* nb2 = getenv("EQD_ATT_LB_NB");
+        const char* nb2 = eqd_tunable("EQD_ATT_LB_NB");
         if (!att_lds_bf16() || (nb2 && nb2[0] == '2')) return 0;
     }
     return aligned16(q) && aligned16(k) && aligned16(v) && aligned16(d_out) && aligned16(out);

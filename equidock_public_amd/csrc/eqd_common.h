@@ -211,6 +211,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 // ---------------------------------------------------------------------------------------------
 void eqd_set_error(const char* fmt, ...);
 int eqd_check_launch(const char* what);
+const char* eqd_tunable(const char* name);   // EQD_* experiment switch, snapshotted once per process (eqd_tunables_reload)
 int eqd_num_cus();   // compute units of the current HIP device (256 on MI355X; queried once per device)
 
 static inline size_t eqd_align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }

@@ -984,7 +984,7 @@ extern "C" int eqd_edge_message_fwd(const EqdGraph* g, const EqdEdgeParams* p, c
 
 // 1 if eqd_edge_attn_fwd will take the fused launch for this graph / width / mode (else it issues the two launches)
 int eqd_edge_attn_fused(const EqdGraph* g, const EqdEdgeParams* p, int d_att, const float* q, const float* k, const float* v) {
-    const char* f = getenv("EQD_FUSE_FWD");
+    const char* f = eqd_tunable("EQD_FUSE_FWD");
     if (f && f[0] == '0' && f[1] == 0) return 0;
     if (p->bf16 || d_att != 64 || g->n_tiles <= 0 || g->n_att_items <= 0) return 0;
     if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) != 0) return 0;

@@ -29,6 +29,39 @@ void eqd_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 // ------------------------------------------------------------------------------------------
+// experiment / test switches (EQD_* environment variables): read ONCE per process and kept, so that a process that
+// changes its environment between a forward and its backward - or between a graph capture and an eager fallback - cannot
+// silently switch kernel forms in the middle of a step.  eqd_tunables_reload() (tests, A/B measurements) forgets the
+// snapshot; the next launch re-reads the environment.
+// ------------------------------------------------------------------------------------------
+namespace {
+struct EqdTunable {
+    char name[32];
+    char value[32];
+    bool set;
+};
+EqdTunable g_tun[32];
+int g_tun_n = 0;
+std::mutex g_tun_mu;
+}  // namespace
+const char* eqd_tunable(const char* name) {
+    std::lock_guard<std::mutex> lk(g_tun_mu);
+    for (int i = 0; i < g_tun_n; ++i)
+        if (strcmp(g_tun[i].name, name) == 0) return g_tun[i].set ? g_tun[i].value : nullptr;
+    const char* v = getenv(name);
+    if (g_tun_n >= 32 || strlen(name) >= sizeof(g_tun[0].name)) return v;      // (table full: uncached, never wrong)
+    EqdTunable& t = g_tun[g_tun_n++];
+    snprintf(t.name, sizeof(t.name), "%s", name);
+    t.set = v != nullptr;
+    snprintf(t.value, sizeof(t.value), "%s", v ? v : "");
+    return t.set ? t.value : nullptr;
+}
+extern "C" void eqd_tunables_reload(void) {
+    std::lock_guard<std::mutex> lk(g_tun_mu);
+    g_tun_n = 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // per-launch timing (eqd_profile_*, include/equidock_hip.h): between begin and end every launch of this library on the
 // profiled stream is followed by an event record; the time between consecutive events is that launch's duration.
 // ------------------------------------------------------------------------------------------
@@ -171,7 +204,7 @@ __global__ __launch_bounds__(EQD_BLOCK, 2) void k_linear(LinJobsArg jobs) {
 // step's weights once per 32 rows, which pays off once weights stop fitting the L2, i.e. for wider models).
 int eqd_row_tiles(int rows) {
     (void)rows;
-    const char* f = getenv("EQD_ROW_TILES");
+    const char* f = eqd_tunable("EQD_ROW_TILES");
     if (f && (f[0] == '1' || f[0] == '2') && f[1] == 0) return f[0] - '0';
     return 1;
 }
@@ -183,7 +216,7 @@ int eqd_rowchain_blocks(int rows) {
 // two tiles from 3 tiles per CU - the general body's ~3 500 clocks per step are then paid once per 32 rows (C bf16:
 // 156 -> 129 us per step, E: 78 -> 67; k_rowchain does not gain and keeps one tile)
 static int linear_row_tiles(int rows) {
-    const char* f = getenv("EQD_ROW_TILES");
+    const char* f = eqd_tunable("EQD_ROW_TILES");
     if (f && (f[0] == '1' || f[0] == '2') && f[1] == 0) return f[0] - '0';
     return (rows + 15) / 16 >= 3 * eqd_num_cus() ? 2 : 1;
 }
@@ -444,7 +477,7 @@ static int rw_mode(int rows);
 // instead of launching them on their own - below that size they run side by side on k_linear, which is faster
 int eqd_rows_resident(int rows) { return rows > 0 && rw_mode(rows) == 2; }
 static int rw_mode(int rows) {
-    const char* f = getenv("EQD_ROWWAVE");
+    const char* f = eqd_tunable("EQD_ROWWAVE");
     if (f && f[0] >= '0' && f[0] <= '2' && f[1] == 0) return f[0] - '0';
     return (rows + 15) / 16 >= 3 * eqd_num_cus() ? 2 : 0;
 }
@@ -527,7 +560,7 @@ static bool rr_single_tile(const EqdChainJob* jobs, int njobs) {
     return true;
 }
 static int rr_tiles_per_wg(int rows) {
-    const char* f = getenv("EQD_ROWRES_TPS");      // tests: force the tiles per workgroup (1..16) to reach the two-slot paths
+    const char* f = eqd_tunable("EQD_ROWRES_TPS");      // tests: force the tiles per workgroup (1..16) to reach the two-slot paths
     if (f && f[0]) {
         const int v = atoi(f);
         if (v >= 1 && v <= RR_WAVES * RR_TMAX) return v;
@@ -1049,7 +1082,7 @@ __global__ __launch_bounds__(1024) void k_atb_reduce(AtbUnitsArg U, const float*
 // unit's rows are split over ~ATB_TARGET_WGS / units workgroups.
 #define ATB_TARGET_WGS_DEFAULT 1024
 static int atb_target_wgs() {
-    const char* f = getenv("EQD_ATB_WGS");      // tuning experiments only
+    const char* f = eqd_tunable("EQD_ATB_WGS");      // tuning experiments only
     const int v = f ? atoi(f) : 0;
     return v >= 64 && v <= 4096 ? v : ATB_TARGET_WGS_DEFAULT;
 }
@@ -1096,14 +1129,14 @@ static int atb_next_batch(std::vector<AtbUnit>& units, size_t first, long long* 
     // ~1024 workgroups per 36 units (the launch size this was tuned at); twice that once a unit has more 64-row chunks
     // than that leaves it (config C: +1 %); at most 4096 (eqd_atb_batch_partial_bytes)
     int target = ATB_TARGET_WGS * ((n + 35) / 36 > 0 ? (n + 35) / 36 : 1);
-    if (!getenv("EQD_ATB_WGS") && n > 0 && units[first].nchunks > 8 * (target / n)) target *= 2;
+    if (!eqd_tunable("EQD_ATB_WGS") && n > 0 && units[first].nchunks > 8 * (target / n)) target *= 2;
     target = target > 4096 ? 4096 : target;
     int per = (target + n - 1) / (n > 0 ? n : 1);
     // a multiple of 8: the launch's grid is (parts, units), so part c of EVERY unit runs on XCD c % 8 - the units of a layer
     // that share an operand (h with six of them, dz with four: the caller lists them back to back) fetch a part's rows of
     // it into the same L2 at about the same time - and every XCD gets the same number of parts (a grid merely padded to a
     // multiple of 8 measured k_atb 443 -> 487 us in fp32 at 64 x (300, 300): three XCDs a part short per unit)
-    const char* xa = getenv("EQD_ATB_XCD_ALIGN");      // experiments: 0 = any count
+    const char* xa = eqd_tunable("EQD_ATB_XCD_ALIGN");      // experiments: 0 = any count
     if (!(xa && xa[0] == '0' && xa[1] == 0) && per >= 8) per = (per + 7) / 8 * 8;
     per = per > ATB_MAXBLOCKS ? ATB_MAXBLOCKS : per;
     long long off = 0;
@@ -1240,7 +1273,12 @@ int eqd_launch_reduce_segments(const EqdRedSeg* segs, int nseg, hipStream_t st) 
     int c0 = 0;
     while (c0 < P.nc) {
         EqdRedArg arg;
+        const int before = c0;
         const int nblk = red_fill(segs, P, c0, arg);
+        if (c0 == before) {      // cannot happen while red_plan rejects chains longer than one descriptor; never spin on it
+            eqd_set_error("eqd_launch_reduce_segments: reduction chain does not fit one descriptor");
+            return EQD_ERR_SHAPE;
+        }
         if (nblk == 0) continue;
         hipLaunchKernelGGL(k_reduce_segments, dim3(nblk), dim3(1024), 0, st, arg);
         int rc = eqd_check_launch("k_reduce_segments");
@@ -1385,7 +1423,12 @@ int eqd_gather_rest(EqdRedList* pending, hipStream_t st) {
     if (pending && pending->n > 0) {
         while (g_gather_c0 < g_gather_plan.nc) {         // (more than 64 segments or chains: not the case for one layer)
             EqdRedArg more;
+            const int before = g_gather_c0;
             const int nb = red_fill(pending->seg, g_gather_plan, g_gather_c0, more);
+            if (g_gather_c0 == before) {      // (see eqd_launch_reduce_segments)
+                eqd_set_error("eqd_gather_rest: reduction chain does not fit one descriptor");
+                return EQD_ERR_SHAPE;
+            }
             if (nb == 0) continue;
             hipLaunchKernelGGL(k_reduce_segments, dim3(nb), dim3(1024), 0, st, more);
             if (int rc = eqd_check_launch("k_reduce_segments")) return rc;

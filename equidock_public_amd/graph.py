@@ -509,13 +509,14 @@ def _xcd_interleave(items):
     slots mostly idle - and another only the smallest; 77 % -> 93 % of the ideal makespan for the DB5.5 size
     distribution in a slot model, profiles/r03_attention_schedule.txt.  Uniform batches are unchanged.)  The native
     packer (csrc_host/eqd_host_pack.cpp) does the same in integers, bit for bit."""
+    # groups = runs of CONSECUTIVE items with the same partner range, exactly as the native packer forms them (two
+    # degenerate segments with equal ranges that are not neighbours stay two groups in both)
     groups, order = {}, []
     for it in items:
-        key = (it[2], it[3])
-        if key not in groups:
-            groups[key] = []
-            order.append(key)
-        groups[key].append(it)
+        if not order or (order[-1][0], order[-1][1]) != (it[2], it[3]):
+            order.append((it[2], it[3], len(order)))
+            groups[order[-1]] = []
+        groups[order[-1]].append(it)
     order = sorted(order, key=lambda k: -(k[1] - k[0]))      # stable
     lists = [[] for _ in range(XCD_CLASSES)]
     for i, key in enumerate(order):

@@ -184,6 +184,29 @@ def _dgl_signature(g):
         return None
 
 
+def adapt_graph(batch_hetero_graph):
+    """The PairGraph of whatever the caller handed over.  The reference's callers pass a batched DGL heterograph
+    (src/train.py:94-100): it is adapted (duck-typed, tensors shared) and the adaptation is remembered on the object so that
+    its packed layout is built once - as long as the graph still holds the SAME tensors: DGL replaces a tensor when the user
+    assigns node / edge data (`g.nodes['ligand'].data['new_x'] = ...`, what the reference's augmentation and fine-tune stage
+    do), and an in-place write bumps its version, so the cache is keyed on (data_ptr, version, shape) of every tensor it
+    adapted.  Shared by Rigid_Body_Docking_Net.forward_batched and IEGMN.run, so that `model(batched_dgl_graph, epoch)` -
+    the reference's call - re-uses the adaptation and the PairGraph-side caches (packed layout, saved state, dropout ones)
+    from step to step as well."""
+    if isinstance(batch_hetero_graph, PairGraph):
+        return batch_hetero_graph
+    sig = _dgl_signature(batch_hetero_graph)
+    cached = getattr(batch_hetero_graph, '_eqd_pair_graph', None)
+    if cached is None or sig is None or cached[0] != sig:
+        from .graph import from_dgl
+        cached = (sig, from_dgl(batch_hetero_graph))
+        try:
+            batch_hetero_graph._eqd_pair_graph = cached
+        except AttributeError:
+            pass
+    return cached[1]
+
+
 def flat_layout(tensors):
     """Offsets (in floats, 64-float aligned) of each unique parameter in a flat gradient buffer."""
     offs, total = [], 0
@@ -275,7 +298,10 @@ class DropoutMasks:
             lib = _lib.load_library()
             stream = _lib.stream_ptr(dev)
             perm = packed.edge_perm
-            assert perm.dtype == torch.int64 and perm.is_contiguous() and perm.numel() == E
+            if perm.dtype != torch.int64 or not perm.is_contiguous() or perm.numel() != E or perm.device != dev:
+                # k_dropout_pack reads E int64 entries through the raw pointer: anything else would be an out-of-bounds read
+                raise _lib.EquidockHipError(f"edge_perm must be a contiguous int64 tensor of {E} entries on {dev} "
+                                            f"(got {perm.dtype}, {tuple(perm.shape)}, {perm.device})")
 
             def pack(fl, fr, out):
                 with _lib.device_guard(dev):
@@ -575,22 +601,7 @@ class IEGMN(nn.Module):
 
     def run(self, batch_hetero_graph):
         """Returns the raw batched outputs (lig [n_lig,3], Yl, Yr [B,K,3], T [B,3,3], b [B,3])."""
-        if not isinstance(batch_hetero_graph, PairGraph):
-            # the reference's callers hand over a batched DGL heterograph (src/train.py:94-100): adapt it (duck-typed,
-            # tensors shared) and remember the adaptation on the object so that its packed layout is built once - as long
-            # as the graph still holds the SAME tensors: DGL replaces a tensor when the user assigns node / edge data
-            # (`g.nodes['ligand'].data['new_x'] = ...`, what the reference's augmentation and fine-tune stage do), and an
-            # in-place write bumps its version, so the cache is keyed on (data_ptr, version) of every tensor it adapted
-            sig = _dgl_signature(batch_hetero_graph)
-            cached = getattr(batch_hetero_graph, '_eqd_pair_graph', None)
-            if cached is None or cached[0] != sig:
-                from .graph import from_dgl
-                cached = (sig, from_dgl(batch_hetero_graph))
-                try:
-                    batch_hetero_graph._eqd_pair_graph = cached
-                except AttributeError:
-                    pass
-            batch_hetero_graph = cached[1]
+        batch_hetero_graph = adapt_graph(batch_hetero_graph)
         if not self.uses_hip_path():
             from . import torch_path
             T, b, Yl, Yr, lig = torch_path.iegmn_forward(self, batch_hetero_graph)
@@ -756,9 +767,7 @@ class Rigid_Body_Docking_Net(nn.Module):
     def forward_batched(self, batch_hetero_graph):
         """Batched tensors instead of per-pair lists (no Python loop over pairs): lig [n_lig, 3], Yl, Yr [B, K, 3],
         T [B, 3, 3], b [B, 3]."""
-        if not isinstance(batch_hetero_graph, PairGraph):
-            from .graph import from_dgl
-            batch_hetero_graph = from_dgl(batch_hetero_graph)
+        batch_hetero_graph = adapt_graph(batch_hetero_graph)
         out = None
         for stage, iegmn in self.list_iegmns:      # rigid_docking_model.py:646-682
             _, lig, Yl, Yr, T, b = iegmn.run(batch_hetero_graph)

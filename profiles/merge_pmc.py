@@ -12,7 +12,7 @@ tags = sys.argv[1].split(',')
 tag = tags[0]
 src = sys.argv[2] if len(sys.argv) > 2 else 'gpurun_out'
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FAM = ('k_edge_attn_fwd', 'k_edge_fwd', 'k_edge_bwd', 'k_attn_fwd', 'k_attn_bwd', 'k_rowres', 'k_rowwave', 'k_rowchain', 'k_linear', 'k_atb_reduce', 'k_atb',
+FAM = ('k_edge_attn_fwd', 'k_edge_fwd', 'k_edge_bwd', 'k_attn_fwd', 'k_attn_bwd_gather', 'k_attn_bwd', 'k_rowres', 'k_rowwave', 'k_rowchain', 'k_linear', 'k_atb_reduce', 'k_atb',
        'k_node_gather')
 
 
@@ -21,10 +21,28 @@ def load(w, cnt):
         f = os.path.join(root, src, f'{tg}_pmc_{w}_{cnt}.json')
         try:
             txt = open(f).read()
-            return json.loads(txt[txt.index('{'):])
+            d = json.loads(txt[txt.index('{'):])
+            when[w] = max(when.get(w, 0.0), os.path.getmtime(f))
+            return d
         except Exception:
             continue
     return {}
+
+
+when = {}      # workload -> newest mtime of the per-counter files it was merged from (= when that gpurun call came back)
+
+
+def git_head():
+    """HEAD of the tree the counters were collected on (the gpurun snapshot is the working tree: commit before measuring);
+    '+dirty' when kernel sources differ from HEAD at merge time."""
+    import subprocess
+    try:
+        h = subprocess.run(['git', 'rev-parse', '--short=12', 'HEAD'], cwd=root, capture_output=True, text=True).stdout.strip()
+        d = subprocess.run(['git', 'status', '--porcelain', '--', 'equidock_public_amd', 'bench.py'], cwd=root,
+                           capture_output=True, text=True).stdout.strip()
+        return h + ('+dirty' if d else '')
+    except Exception:
+        return None
 
 
 mfma = {'_comment': "rocprofv3 --kernel-trace --pmc <counter> -- python bench.py --eager --workload W --steps 3 --warmup 1 (one counter per "
@@ -71,6 +89,12 @@ for w in (sys.argv[3].split(',') if len(sys.argv) > 3 else ('B', 'C', 'E')):
                 traffic[w][fam] = {'FETCH_SIZE_KB': round(tot['FETCH_SIZE'][0] / tot['FETCH_SIZE'][1], 1),
                                    'WRITE_SIZE_KB': round(tot['WRITE_SIZE'][0] / max(1, tot['WRITE_SIZE'][1]), 1),
                                    'dispatches': tot['FETCH_SIZE'][1]}
+# every workload carries its own stamp: nothing is carried over from an older summary, and a reader can tell which
+# code state each entry was measured on
+head = git_head()
+stamps = {w: {'collected': datetime.datetime.fromtimestamp(t).isoformat(timespec='seconds'), 'git_head': head}
+          for w, t in when.items() if w in mfma or w in traffic}
+mfma['_workloads'] = traffic['_workloads'] = stamps
 json.dump(mfma, open(os.path.join(root, 'profiles', f'{tag}_pmc_mfma.json'), 'w'), indent=1)
 json.dump(traffic, open(os.path.join(root, 'profiles', f'{tag}_traffic.json'), 'w'), indent=1)
 print('written', [k for k in mfma if not k.startswith('_')], [k for k in traffic if not k.startswith('_')])

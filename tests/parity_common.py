@@ -1645,6 +1645,7 @@ def check_fused_forward(dev):
     res = {}
     for mode in ('1', '0'):
         os.environ['EQD_FUSE_FWD'] = mode
+        L.reload_tunables()
         try:
             net = build_model(args, sd, dev)
             g = G.batch_pairs(pairs).to(dev)
@@ -1654,6 +1655,7 @@ def check_fused_forward(dev):
             res[mode] = ([t.detach().cpu().clone() for t in outs], [p.grad.detach().cpu().clone() for p in net.parameters()])
         finally:
             del os.environ['EQD_FUSE_FWD']
+            L.reload_tunables()
     for a, b in zip(res['1'][0] + res['1'][1], res['0'][0] + res['0'][1]):
         assert torch.equal(a, b)
 
@@ -1671,6 +1673,7 @@ def check_gather_rides_in_attention_backward(dev):
         res, names = {}, {}
         for mode in ('1', '0'):
             os.environ['EQD_FUSE_GATHER'] = mode
+            L.reload_tunables()
             try:
                 net = build_model(args, sd, dev)
                 g = G.batch_pairs(pairs).to(dev)
@@ -1688,6 +1691,7 @@ def check_gather_rides_in_attention_backward(dev):
                 res[mode] = ([t.detach().cpu().clone() for t in outs], [p.grad.detach().cpu().clone() for p in net.parameters()])
             finally:
                 del os.environ['EQD_FUSE_GATHER']
+                L.reload_tunables()
         for a, b in zip(res['1'][0] + res['1'][1], res['0'][0] + res['0'][1]):
             assert torch.equal(a, b), f'fused vs separate gather launch differ ({over})'
         assert names['1'].count('k_attn_bwd_gather') == 2 and names['1'].count('k_node_gather') == 1, sorted(set(names['1']))
