@@ -100,7 +100,7 @@ def _declare(lib):
     lib.eqd_profile_name.restype = C.c_char_p
     lib.eqd_profile_us.restype = C.c_float
     lib.eqd_tunables_reload.restype = None
-    for name in ('eqd_model_layer_state', 'eqd_model_lrelu_signs', 'eqd_profile_begin', 'eqd_profile_end', 'eqd_profile_mark', 'eqd_ctx_create', 'eqd_ctx_destroy', 'eqd_model_check', 'eqd_model_forward', 'eqd_model_backward', 'eqd_linear', 'eqd_atb',
+    for name in ('eqd_model_layer_state', 'eqd_model_lrelu_signs', 'eqd_model_head_backward', 'eqd_profile_begin', 'eqd_profile_end', 'eqd_profile_mark', 'eqd_ctx_create', 'eqd_ctx_destroy', 'eqd_model_check', 'eqd_model_forward', 'eqd_model_backward', 'eqd_linear', 'eqd_atb',
                  'eqd_edge_message_fwd', 'eqd_edge_message_bwd', 'eqd_edge_message_bwd_kernel_only',
                  'eqd_cross_attention_fwd', 'eqd_cross_attention_fwd_bf16', 'eqd_cross_attention_bwd_bf16',
                  'eqd_cross_attention_bwd',
@@ -111,7 +111,7 @@ def _declare(lib):
         getattr(lib, name).restype = C.c_int
 
 
-EXPORTS = ('eqd_model_layer_state', 'eqd_model_lrelu_signs', 'eqd_profile_begin', 'eqd_profile_end', 'eqd_profile_mark', 'eqd_profile_name', 'eqd_profile_us', 'eqd_ctx_create', 'eqd_ctx_destroy', 'eqd_abi_version', 'eqd_last_error', 'eqd_tile_edges', 'eqd_is_simulator', 'eqd_model_saved_bytes',
+EXPORTS = ('eqd_model_layer_state', 'eqd_model_lrelu_signs', 'eqd_model_head_backward', 'eqd_profile_begin', 'eqd_profile_end', 'eqd_profile_mark', 'eqd_profile_name', 'eqd_profile_us', 'eqd_ctx_create', 'eqd_ctx_destroy', 'eqd_abi_version', 'eqd_last_error', 'eqd_tile_edges', 'eqd_is_simulator', 'eqd_model_saved_bytes',
            'eqd_model_scratch_bytes', 'eqd_model_check', 'eqd_model_forward', 'eqd_model_backward', 'eqd_linear',
            'eqd_atb_partial_bytes', 'eqd_atb', 'eqd_edge_message_fwd', 'eqd_edge_message_bwd_workspace_bytes',
            'eqd_edge_message_bwd', 'eqd_edge_message_bwd_kernel_only', 'eqd_cross_attention_fwd',

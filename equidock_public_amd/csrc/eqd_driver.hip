@@ -647,6 +647,90 @@ extern "C" int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const
     return EQD_OK;
 }
 
+// Backward of the keypoint / Kabsch head (rigid_docking_model.py:521-600, 665): Kabsch + rigid apply -> keypoints -> per-head
+// key / query maps -> segment means -> mlp_h_mean_ROT.  Leaves d h_L in dH_L ([N][d_hid]) and d x_L in dX_L ([N][3]), adds
+// the head parameters' gradients (att_mlp_key / query_ROT directly, partial sums on `defer`; mlp_h_mean_ROT as a job on
+// `wjobs`).  The first stage of eqd_model_backward, and all of eqd_model_head_backward.
+static int head_backward(const EqdModelDesc* m, const EqdGraph* g, const Dims& D, const Saved& S, const Scratch& W,
+                         const float* const* gpar, float* const* ggrad, const EqdDropout* drop, const float* d_lig,
+                         const float* d_Ylig, const float* d_Yrec, const float* d_T, const float* d_b, const float* d_h_last,
+                         const float* d_x_last, float* dH_L, float* dX_L, hipStream_t st, EqdRedList* defer,
+                         std::vector<EqdAtbJob>& wjobs) {
+    const int N = D.N, B = D.B, K = D.K;
+    const float slope = m->lrelu_slope, eps = m->ln_eps;
+    RC(eqd_kabsch_bwd_impl(B, K, S.Y, S.A, S.T, d_T, d_b, d_Ylig, d_Yrec, W.dY, st, g, d_lig, S.usv));   // + rigid apply backward
+    const float* H = S.h[D.L];
+    const float* Z = S.x[D.L];
+    RC(eqd_launch_keypoint_bwd(g, K, H, Z, S.scores, S.klse, S.u, W.dY, W.dscores, W.du, W.dHk, dX_L, st));
+    if (d_h_last) RC(eqd_launch_axpy(W.dHk, d_h_last, 1.f, (size_t)N * 64, st));      // a loss on the last layer's node data
+    if (d_x_last) RC(eqd_launch_axpy(dX_L, d_x_last, 1.f, (size_t)N * 3, st));
+    RC(eqd_launch_head_u_bwd(g, K, gpar[G_WK], gpar[G_WQ], S.qmean, S.qp, W.du, ggrad[G_WK], ggrad[G_WQ], W.dqm_part,
+                             st, W.head_part, defer));
+    RC(eqd_launch_qmean_bwd(g, K, W.dqm_part, W.dhm, st));
+    if (drop) {      // d(keep * s * LeakyReLU(z)): the dropout factor rides on the incoming gradient, the LeakyReLU
+                     // derivative comes from the saved activation's sign as without dropout
+        const size_t n = (size_t)N * 64;
+        hipLaunchKernelGGL(k_mul_inplace, dim3((unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)), dim3(256), 0, st,
+                           W.dhm, drop->head, n);
+        RC(eqd_check_launch("k_mul_inplace"));
+    }
+    EqdLinJob j = lin_job(N, D.dh, dH_L, D.dh, slope, eps);
+    lin_src(j, 0, W.dhm, 64, 64, gpar[G_WM], 1, D.dh, S.hm);
+    j.nsrc = 1; j.R = W.dHk; j.ldr = 64; j.beta = 1.f;
+    RC(eqd_linear(&j, 1, st));
+    wjobs.push_back(atb_job(W.dhm, 64, 64, H, D.dh, D.dh, N, ggrad[G_WM], D.dh, ggrad[G_BM], slope, S.hm));
+    return EQD_OK;
+}
+
+// Test / single-op entry point: the head's backward alone, from the state a forward left in `saved`.  d_h_L [N][d_hid],
+// d_x_L [N][3] receive the gradient w.r.t. the last layer's node state; the head parameters' gradients are accumulated
+// into grad_flat (the layer parameters' entries are not touched).
+extern "C" int eqd_model_head_backward(const EqdModelDesc* m, const EqdGraph* g, const float* const* params,
+                                       const EqdDropout* drop, const float* d_lig, const float* d_Ylig, const float* d_Yrec,
+                                       const float* d_T, const float* d_b, float* grad_flat, const int64_t* grad_offsets,
+                                       const void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
+                                       float* d_h_L, float* d_x_L, void* stream) {
+    RC(eqd_model_check(m, g));
+    if (!params || !grad_flat || !grad_offsets || !saved || !scratch || !d_h_L || !d_x_L) {
+        eqd_set_error("eqd_model_head_backward: NULL argument");
+        return EQD_ERR_NULL;
+    }
+    RC(drop_check(drop));
+    hipStream_t st = (hipStream_t)stream;
+    const Dims D = make_dims(m, g);
+    g_bf16_mode = m->storage_bf16 ? 1 : 0;
+    EqdArena As(const_cast<void*>(saved), saved_bytes);
+    Saved S;
+    carve_saved(D, g, As, S);
+    EqdArena Aw(scratch, scratch_bytes);
+    Scratch W;
+    carve_scratch(D, m, g, Aw, W);
+    if (!As.ok || !Aw.ok) {
+        eqd_set_error("eqd_model_head_backward: workspace too small (saved %zu, scratch %zu needed)", As.off, Aw.off);
+        return EQD_ERR_WORKSPACE;
+    }
+    const int nparams = EQD_PARAMS_PER_LAYER * D.L + EQD_GLOBAL_PARAMS;
+    float* gptr[EQD_PARAMS_PER_LAYER * 64 + EQD_GLOBAL_PARAMS];
+    for (int i = 0; i < nparams; ++i) gptr[i] = grad_flat + grad_offsets[i];
+    const float* const* gpar = params + (size_t)EQD_PARAMS_PER_LAYER * D.L;
+    float* const* ggrad = gptr + (size_t)EQD_PARAMS_PER_LAYER * D.L;
+    EqdRedList* defer = new EqdRedList();
+    defer->n = 0;
+    struct DeferGuard {
+        EqdRedList* p;
+        ~DeferGuard() { delete p; }
+    } defer_guard{defer};
+    std::vector<EqdAtbJob> wjobs;
+    float* dH = W.dH_all + (size_t)D.L * D.N * 80;
+    RC(head_backward(m, g, D, S, W, gpar, ggrad, drop, d_lig, d_Ylig, d_Yrec, d_T, d_b, nullptr, nullptr, dH, W.dXa, st, defer,
+                     wjobs));
+    RC(eqd_atb(wjobs.data(), (int)wjobs.size(), W.atb_part, W.atb_bytes, st));
+    RC(eqd_launch_reduce_segments(defer->seg, defer->n, st));
+    HIPOK(hipMemcpyAsync(d_h_L, dH, (size_t)D.N * D.dh * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIPOK(hipMemcpyAsync(d_x_L, W.dXa, (size_t)D.N * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return EQD_OK;
+}
+
 extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, const float* const* params,
                                   const EqdDropout* drop, const float* d_lig, const float* d_Ylig, const float* d_Yrec, const float* d_T,
                                   const float* d_b, const float* d_h_last, const float* d_x_last, float* grad_flat, const int64_t* grad_offsets, const void* saved,
@@ -686,35 +770,16 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
         EqdRedList* p;
         ~DeferGuard() { delete p; }
     } defer_guard{defer};
-    RC(eqd_kabsch_bwd_impl(B, K, S.Y, S.A, S.T, d_T, d_b, d_Ylig, d_Yrec, W.dY, st, g, d_lig, S.usv));   // + rigid apply backward
     const float* H = S.h[D.L];
-    const float* Z = S.x[D.L];
     float* dXcur = W.dXa;   // grad wrt x[L]
     float* dXnext = W.dXb;
-    RC(eqd_launch_keypoint_bwd(g, K, H, Z, S.scores, S.klse, S.u, W.dY, W.dscores, W.du, W.dHk, dXcur, st));
-    if (d_h_last) RC(eqd_launch_axpy(W.dHk, d_h_last, 1.f, (size_t)N * 64, st));      // a loss on the last layer's node data
-    if (d_x_last) RC(eqd_launch_axpy(dXcur, d_x_last, 1.f, (size_t)N * 3, st));
-    RC(eqd_launch_head_u_bwd(g, K, gpar[G_WK], gpar[G_WQ], S.qmean, S.qp, W.du, ggrad[G_WK], ggrad[G_WQ], W.dqm_part,
-                             st, W.head_part, defer));
-    RC(eqd_launch_qmean_bwd(g, K, W.dqm_part, W.dhm, st));
-    if (drop) {      // d(keep * s * LeakyReLU(z)): the dropout factor rides on the incoming gradient, the LeakyReLU
-                     // derivative comes from the saved activation's sign as without dropout
-        const size_t n = (size_t)N * 64;
-        hipLaunchKernelGGL(k_mul_inplace, dim3((unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)), dim3(256), 0, st,
-                           W.dhm, drop->head, n);
-        RC(eqd_check_launch("k_mul_inplace"));
-    }
     const size_t NS = (size_t)N * 80, NP = (size_t)N * 64;
     auto dHof = [&](int i) -> float* { return W.dH_all + (size_t)i * NS; };   // grad wrt h[i]
     std::vector<EqdAtbJob> wjobs;   // weight-gradient GEMMs of the whole pass, launched together at the end
     wjobs.reserve((size_t)D.L * 10 + 1);
-    {
-        EqdLinJob j = lin_job(N, D.dh, dHof(D.L), D.dh, slope, eps);
-        lin_src(j, 0, W.dhm, 64, 64, gpar[G_WM], 1, D.dh, S.hm);
-        j.nsrc = 1; j.R = W.dHk; j.ldr = 64; j.beta = 1.f;
-        RC(eqd_linear(&j, 1, st));
-        wjobs.push_back(atb_job(W.dhm, 64, 64, H, D.dh, D.dh, N, ggrad[G_WM], D.dh, ggrad[G_BM], slope, S.hm));
-    }
+    RC(head_backward(m, g, D, S, W, gpar, ggrad, drop, d_lig, d_Ylig, d_Yrec, d_T, d_b, d_h_last, d_x_last, dHof(D.L), dXcur,
+                     st, defer, wjobs));
+    (void)H; (void)B; (void)K;
     // dh(l) = dz Wn1[:, :d] + dP W1a + dQ W1b + dq Wq + dk Wk + dv Wv + (1-s) dH   (dq, dk w.r.t. the pre-activations):
     // the gradient wrt h[l] once layer l's attention and edge backward are done
     auto dh_job = [&](int l) -> EqdLinJob {

@@ -690,6 +690,49 @@ class IEGMN(nn.Module):
         names = {id(p): k for k, p in self.named_parameters()}
         return {names[id(p)]: flat[o:o + p.numel()].view(p.shape).clone() for p, o in zip(uniq, offs)}
 
+    def head_backward(self, batch_hetero_graph, d_lig=None, d_Yl=None, d_Yr=None, d_T=None, d_b=None):
+        """Backward of the keypoint / Kabsch head alone (eqd_model_head_backward) for the LAST forward of this batch that
+        kept its state, from gradients w.r.t. the batched outputs (lig [n_lig, 3], Yl, Yr [B, K, 3], T [B, 3, 3], b [B, 3];
+        None = zero): returns (d_h_L [n_nodes, 64], d_x_L [n_nodes, 3], {head parameter name: gradient}).  A test aid: with
+        stack_backward it splits the whole-model gradient at the last layer's state, so that the head - fp32 in every mode -
+        can be compared plainly in bf16 mode too."""
+        packed = batch_hetero_graph.pack()
+        last = getattr(packed, '_last_saved', None)
+        if last is None:
+            raise _lib.EquidockHipError("no saved forward state for this batch (run a forward with gradients enabled)")
+        saved, sb, drop = last
+        lib = _lib.load_library()
+        desc, gs = self._desc(), packed.c_struct()
+        uniq, table_idx = self._param_table()
+        dev = packed.x0.device
+        ptrs = (C.c_void_p * len(table_idx))(*[uniq[i].data_ptr() for i in table_idx])
+        offs, total = flat_layout(uniq)
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        goffs = (C.c_int64 * len(table_idx))(*[offs[i] for i in table_idx])
+        with _lib.device_guard(dev):
+            wb = lib.eqd_model_scratch_bytes(C.byref(desc), C.byref(gs))
+        scratch = torch.empty(wb, dtype=torch.uint8, device=dev)
+
+        def prep(t, what):
+            return None if t is None else _lib.require_device(t.to(torch.float32).contiguous(), what)
+        gl, gyl, gyr, gt, gb = (prep(t, w) for t, w in ((d_lig, 'd_lig'), (d_Yl, 'd_Yl'), (d_Yr, 'd_Yr'), (d_T, 'd_T'), (d_b, 'd_b')))
+        n = packed.n_nodes
+        d_h = torch.empty(n, 64, dtype=torch.float32, device=dev)
+        d_x = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        dstruct = None if drop is None else drop.c_struct()
+
+        def p(t):
+            return None if t is None else _lib.ptr(t)
+        with _lib.device_guard(dev):
+            _lib.check(lib.eqd_model_head_backward(
+                C.byref(desc), C.byref(gs), ptrs, None if dstruct is None else C.byref(dstruct), p(gl), p(gyl), p(gyr), p(gt),
+                p(gb), _lib.ptr(flat), goffs, _lib.ptr(saved), C.c_size_t(sb), _lib.ptr(scratch), C.c_size_t(wb),
+                _lib.ptr(d_h), _lib.ptr(d_x), _lib.stream_ptr(dev)))
+        names = {id(q): k for k, q in self.named_parameters()}
+        grads = {names[id(q)]: flat[o:o + q.numel()].view(q.shape).clone() for q, o in zip(uniq, offs)
+                 if 'iegmn_layers' not in names[id(q)] and 'residue_emb_layer' not in names[id(q)]}
+        return d_h, d_x, grads
+
     def lrelu_signs(self, batch_hetero_graph):
         """The LeakyReLU branch decisions (uint8, 1 = pre-activation > 0) of the LAST forward of this batch that kept its
         state, in the library's node / edge order (ligand nodes then receptor nodes; PackedGraph edge order): a list with

@@ -223,6 +223,18 @@ int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, const float* co
                        const void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream,
                        void* ctx);
 
+/* The first stage of the backward on its own: the keypoint / Kabsch head (rigid_docking_model.py:521-600 and the rigid apply
+ * :665) differentiated from the state a forward left in `saved`.  d_h_L [n_nodes][64] and d_x_L [n_nodes][3] RECEIVE the
+ * gradient w.r.t. the state after the last IEGMN layer; the gradients of att_mlp_key_ROT / att_mlp_query_ROT /
+ * mlp_h_mean_ROT are accumulated into grad_flat (the layer parameters' entries are not touched).  Together with
+ * eqd_model_backward's d_h_last / d_x_last this splits the whole-model gradient at (h_L, x_L): the head is fp32 in every
+ * mode, so the tests compare it plainly in bf16 mode too (tests/parity_common.py: check_head_backward). */
+int eqd_model_head_backward(const EqdModelDesc* m, const EqdGraph* g, const float* const* params, const EqdDropout* drop,
+                            const float* d_lig, const float* d_Ylig, const float* d_Yrec, const float* d_T,
+                            const float* d_b, float* grad_flat, const int64_t* grad_offsets,
+                            const void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
+                            float* d_h_L, float* d_x_L, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Operator-level entry points (used by the model functions above; exported for unit parity
  * tests and for callers that want a single IEGMN_Layer).

@@ -58,6 +58,8 @@ class Kink:
     near = 0
     given = None
     flips = None
+    flip_rels = None      # when a list: |z| / max|z| of EVERY differing decision (one tensor per tag), for distribution checks
+    decisions = 0         # LeakyReLU decisions evaluated in 'given' mode (the denominator of a flip rate)
 
 
 def _lrelu(x, slope, tag=None):
@@ -72,8 +74,12 @@ def _lrelu(x, slope, tag=None):
         with torch.no_grad():
             diff = pos != (x > 0)
             n = int(diff.sum())
+            Kink.decisions += x.numel()
             if n:
-                Kink.flips.append((tag, n, float(x[diff].abs().max()) / max(float(x.abs().max()), 1e-30)))
+                zmax = max(float(x.abs().max()), 1e-30)
+                Kink.flips.append((tag, n, float(x[diff].abs().max()) / zmax))
+                if Kink.flip_rels is not None:
+                    Kink.flip_rels.append((x[diff].abs() / zmax).reshape(-1))
         if n == 0:
             return y
         return torch.where(diff, x * torch.where(pos, 1.0, slope), y)
@@ -272,6 +278,42 @@ def kabsch(Yr, Yl, rand_fn=None, status=None):
     return T, b, A
 
 
+def head(sd, args, raw, h_l, x_l, h_r, x_r, prefix='iegmn_original.', rand_fn=None):
+    """The keypoint / Kabsch head of IEGMN.forward (:521-600) + the rigid apply of Rigid_Body_Docking_Net.forward (:665) on a
+    given last-layer state (h, x of the ligand and the receptor nodes of the whole batch).  forward() ends with it; the
+    tests also call it on the HIP library's own (h_L, x_L) to compare the head's backward on its own.
+    Returns (ligs, Yls, Yrs, Ts, bs, As, svd_iterations)."""
+    slope = args['leakyrelu_neg_slope']
+    K = args['num_att_heads']
+    d = args['iegmn_lay_hid_dim']
+    Wk = sd[prefix + 'att_mlp_key_ROT.0.weight']
+    Wq = sd[prefix + 'att_mlp_query_ROT.0.weight']
+    Wm, bm = sd[prefix + 'mlp_h_mean_ROT.0.weight'], sd[prefix + 'mlp_h_mean_ROT.0.bias']
+    Ts, bs, Yls, Yrs, As, ligs, status = [], [], [], [], [], [], []
+    lo = ro = 0
+    for pi, (nl, nr) in enumerate(zip(raw['lig_counts'], raw['rec_counts'])):    # :521-600
+        H_r, H_l = h_r[ro:ro + nr], h_l[lo:lo + nl]
+        Z_r, Z_l = x_r[ro:ro + nr], x_l[lo:lo + nl]
+        q_r = _lrelu(_lin(H_r, Wm, bm), slope, f'{prefix}mlp_h_mean_ROT.r.{pi}').mean(0, keepdim=True)   # :524-525
+        q_l = _lrelu(_lin(H_l, Wm, bm), slope, f'{prefix}mlp_h_mean_ROT.l.{pi}').mean(0, keepdim=True)   # :528-529
+        att_r = torch.softmax(
+            F.linear(H_r, Wk).view(-1, K, d).transpose(0, 1) @
+            F.linear(q_l, Wq).view(1, K, d).transpose(0, 1).transpose(1, 2) / math.sqrt(d),
+            dim=1).view(K, -1)                                               # :542-546
+        Y_r = att_r @ Z_r                                                    # :548
+        att_l = torch.softmax(
+            F.linear(H_l, Wk).view(-1, K, d).transpose(0, 1) @
+            F.linear(q_r, Wq).view(1, K, d).transpose(0, 1).transpose(1, 2) / math.sqrt(d),
+            dim=1).view(K, -1)                                               # :553-557
+        Y_l = att_l @ Z_l                                                    # :559
+        T, b, A = kabsch(Y_r, Y_l, rand_fn, status)
+        Ts.append(T); bs.append(b); Yls.append(Y_l); Yrs.append(Y_r); As.append(A)
+        ligs.append((T @ raw['lig_x'][lo:lo + nl].t()).t() + b)              # :665
+        lo += nl
+        ro += nr
+    return ligs, Yls, Yrs, Ts, bs, As, status
+
+
 def forward(sd, args, raw, faithful=True, prefix='iegmn_original.', rand_fn=None, return_inter=False):
     """Rigid_Body_Docking_Net.forward (:642-692) for the single-stage (fine_tune=False) model.
 
@@ -305,33 +347,7 @@ def forward(sd, args, raw, faithful=True, prefix='iegmn_original.', rand_fn=None
             li.update(x_l=x_l, h_l=h_l, x_r=x_r, h_r=h_r)
             inter['layers'].append(li)
 
-    K = args['num_att_heads']
-    d = args['iegmn_lay_hid_dim']
-    Wk = sd[prefix + 'att_mlp_key_ROT.0.weight']
-    Wq = sd[prefix + 'att_mlp_query_ROT.0.weight']
-    Wm, bm = sd[prefix + 'mlp_h_mean_ROT.0.weight'], sd[prefix + 'mlp_h_mean_ROT.0.bias']
-    Ts, bs, Yls, Yrs, As, ligs, status = [], [], [], [], [], [], []
-    lo = ro = 0
-    for pi, (nl, nr) in enumerate(zip(raw['lig_counts'], raw['rec_counts'])):    # :521-600
-        H_r, H_l = h_r[ro:ro + nr], h_l[lo:lo + nl]
-        Z_r, Z_l = x_r[ro:ro + nr], x_l[lo:lo + nl]
-        q_r = _lrelu(_lin(H_r, Wm, bm), slope, f'{prefix}mlp_h_mean_ROT.r.{pi}').mean(0, keepdim=True)   # :524-525
-        q_l = _lrelu(_lin(H_l, Wm, bm), slope, f'{prefix}mlp_h_mean_ROT.l.{pi}').mean(0, keepdim=True)   # :528-529
-        att_r = torch.softmax(
-            F.linear(H_r, Wk).view(-1, K, d).transpose(0, 1) @
-            F.linear(q_l, Wq).view(1, K, d).transpose(0, 1).transpose(1, 2) / math.sqrt(d),
-            dim=1).view(K, -1)                                               # :542-546
-        Y_r = att_r @ Z_r                                                    # :548
-        att_l = torch.softmax(
-            F.linear(H_l, Wk).view(-1, K, d).transpose(0, 1) @
-            F.linear(q_r, Wq).view(1, K, d).transpose(0, 1).transpose(1, 2) / math.sqrt(d),
-            dim=1).view(K, -1)                                               # :553-557
-        Y_l = att_l @ Z_l                                                    # :559
-        T, b, A = kabsch(Y_r, Y_l, rand_fn, status)
-        Ts.append(T); bs.append(b); Yls.append(Y_l); Yrs.append(Y_r); As.append(A)
-        ligs.append((T @ raw['lig_x'][lo:lo + nl].t()).t() + b)              # :665
-        lo += nl
-        ro += nr
+    ligs, Yls, Yrs, Ts, bs, As, status = head(sd, args, raw, h_l, x_l, h_r, x_r, prefix, rand_fn)
     outs = (ligs, Yls, Yrs, Ts, bs)
     if return_inter:
         inter.update(A=As, svd_iters=status)

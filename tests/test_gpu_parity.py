@@ -337,6 +337,19 @@ def test_stack_backward_config_c_bf16(dev):
     pc.check_stack_backward(dev, [(300, 300)] * 64, layers=8, seed=3, pair_seed=34, bf16=True, what='config C bf16', report=REPORT)
 
 
+def test_head_backward_config_c_bf16(dev):
+    """BASELINE.json configs[2] (bf16, 64 x (300, 300), 8 layers, ROT scale 40): the keypoint / Kabsch head differentiated on
+    its own from the library's (h_L, x_L) - d(h_L, x_L) and the head parameters' gradients against the oracle's head,
+    plainly.  With the stack test above it covers the whole bf16 model."""
+    from tests import parity_common as pc
+    pc.check_head_backward(dev, [(300, 300)] * 64, layers=8, seed=3, pair_seed=34, bf16=True, what='config C bf16', report=REPORT)
+
+
+def test_head_backward_config_b_fp32(dev):
+    from tests import parity_common as pc
+    pc.check_head_backward(dev, [(200, 200)] * 8, layers=8, seed=3, pair_seed=33, what='config B fp32', report=REPORT)
+
+
 def test_stack_backward_config_b_fp32(dev):
     from tests import parity_common as pc
     pc.check_stack_backward(dev, [(200, 200)] * 8, layers=8, seed=3, pair_seed=33, faithful=True, what='config B fp32',

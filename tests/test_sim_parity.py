@@ -213,6 +213,13 @@ def test_stack_backward_fp32_and_bf16():
     pc.check_stack_backward(DEV, [(60, 75), (90, 48)], layers=4, seed=5, pair_seed=7, faithful=True, bf16=True, what='sim bf16')
 
 
+def test_head_backward_fp32_and_bf16():
+    """the keypoint / Kabsch head alone, from the library's own last-layer state: outputs and d(h_L, x_L) + head parameter
+    gradients vs the oracle's head, plain (eqd_model_head_backward)"""
+    pc.check_head_backward(DEV, [(60, 75), (90, 48)], layers=3, seed=5, pair_seed=7, what='sim fp32')
+    pc.check_head_backward(DEV, [(60, 75), (90, 48)], layers=3, seed=5, pair_seed=7, bf16=True, what='sim bf16')
+
+
 def test_model_bf16_layer_states():
     pc.check_model_bf16_states(DEV, [(60, 75), (90, 48), (120, 100)], layers=4, seed=5, pair_seed=7, faithful=True, what='sim')
 
