@@ -200,12 +200,20 @@ template <bool BF, int KS, int NB>
 __device__ __forceinline__ void mma_k(f32x4 (&acc)[NB], const float* __restrict__ A, int arow, int DS, int g,
                                       const KFrag<BF, KS> (&F)[NB]) {
     if constexpr (BF) {
+        auto chunk = [&](int c) {
+            return pack_bf4(A[arow * DS + 16 * c + g], A[arow * DS + 16 * c + 4 + g], A[arow * DS + 16 * c + 8 + g],
+                            A[arow * DS + 16 * c + 12 + g]);
+        };
 #pragma unroll
-        for (int c = 0; c < KS / 4; ++c) {
-            const s16x4 a = pack_bf4(A[arow * DS + 16 * c + g], A[arow * DS + 16 * c + 4 + g], A[arow * DS + 16 * c + 8 + g],
-                                     A[arow * DS + 16 * c + 12 + g]);
+        for (int cp = 0; cp < KS / 8; ++cp) {      // pairs of 16-deep chunks: v_mfma_f32_16x16x32_bf16
+            const s16x8 a = cat_bf(chunk(2 * cp), chunk(2 * cp + 1));
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma_bf(a, F[nb].p[c], acc[nb]);
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma_bf32(a, cat_bf(F[nb].p[2 * cp], F[nb].p[2 * cp + 1]), acc[nb]);
+        }
+        if constexpr ((KS / 4) % 2 == 1) {          // the 80-wide first layer: five chunks
+            const s16x4 a = chunk(KS / 4 - 1);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma_bf(a, F[nb].p[KS / 4 - 1], acc[nb]);
         }
     } else {
 #pragma unroll
@@ -217,6 +225,11 @@ __device__ __forceinline__ void mma_k(f32x4 (&acc)[NB], const float* __restrict_
     }
 }
 // acc[db][nb] += sum_r A[(row0 + r) * DS + 16 db + l15] * B[nb][r]   (B: an F-layout tile, e.g. softmax weights)
+// both 16-row halves of a 32-row tile at once (bf16: ONE 32-deep chunk of v_mfma_f32_16x16x32_bf16):
+// acc[db][nb] += sum over h, r of A[(16 h + 4 g + r) * DS + 16 db + l15] * B[h][nb][r]
+template <bool BF, int DB, int NB>
+__device__ __forceinline__ void mma_r2(f32x4 (&acc)[DB][NB], const float* __restrict__ A, int g, int DS, int l15,
+                                       const f32x4 (&B)[2][NB]);
 template <bool BF, int DB, int NB>
 __device__ __forceinline__ void mma_r(f32x4 (&acc)[DB][NB], const float* __restrict__ A, int row0, int DS, int l15,
                                       const f32x4 (&B)[NB]) {
@@ -240,6 +253,30 @@ __device__ __forceinline__ void mma_r(f32x4 (&acc)[DB][NB], const float* __restr
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) acc[db][nb] = mfma4(a, B[nb][r], acc[db][nb]);
             }
+    }
+}
+template <bool BF, int DB, int NB>
+__device__ __forceinline__ void mma_r2(f32x4 (&acc)[DB][NB], const float* __restrict__ A, int g, int DS, int l15,
+                                       const f32x4 (&B)[2][NB]) {
+    if constexpr (BF) {
+        s16x8 b[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+            b[nb] = cat_bf(pack_bf4(B[0][nb][0], B[0][nb][1], B[0][nb][2], B[0][nb][3]),
+                           pack_bf4(B[1][nb][0], B[1][nb][1], B[1][nb][2], B[1][nb][3]));
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+            const int r0 = 4 * g, r1 = 16 + 4 * g;
+            const s16x8 a = cat_bf(pack_bf4(A[r0 * DS + 16 * db + l15], A[(r0 + 1) * DS + 16 * db + l15],
+                                            A[(r0 + 2) * DS + 16 * db + l15], A[(r0 + 3) * DS + 16 * db + l15]),
+                                   pack_bf4(A[r1 * DS + 16 * db + l15], A[(r1 + 1) * DS + 16 * db + l15],
+                                            A[(r1 + 2) * DS + 16 * db + l15], A[(r1 + 3) * DS + 16 * db + l15]));
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[db][nb] = mfma_bf32(a, b[nb], acc[db][nb]);
+        }
+    } else {
+        mma_r<false, DB, NB>(acc, A, 4 * g, DS, l15, B[0]);
+        mma_r<false, DB, NB>(acc, A, 16 + 4 * g, DS, l15, B[1]);
     }
 }
 
@@ -392,8 +429,7 @@ __device__ __forceinline__ void attn_fwd_body(AttnFwdSmem<DB>& sm, const EqdGrap
             for (int db = 0; db < DB; ++db) O[db][nb] *= alpha;
         }
         EQD_TR(7);
-#pragma unroll
-        for (int mbk = 0; mbk < 2; ++mbk) mma_r<BF, DB, NB>(O, Vw, 16 * mbk + 4 * g, DS, l15, S[mbk]);
+        mma_r2<BF, DB, NB>(O, Vw, g, DS, l15, S);
         EQD_TR(8);
     }
     EQD_TR(9);

@@ -183,8 +183,7 @@ __device__ __forceinline__ void attn_bwd_q_body(SM& sm, const EqdGraph& G, int i
                     S[mb][nb][r] = p * (dP[mb][nb][r] - dl[nb]);
                 }
         EQD_TR(33);
-#pragma unroll
-        for (int mbk = 0; mbk < 2; ++mbk) mma_r<BF, DB, NB>(dQ, Kw, 16 * mbk + 4 * g, DS, l15, S[mbk]);
+        mma_r2<BF, DB, NB>(dQ, Kw, g, DS, l15, S);
         EQD_TR(34);
     }
     wave_lds_fence();       // (aliased layout) this wave's reads of its K tile are done before it is overwritten
@@ -363,11 +362,8 @@ __device__ __forceinline__ void attn_bwd_kv_body(SM& sm, const EqdGraph& G, int 
                     dP[mb][nb][r] = p * (dP[mb][nb][r] - dc[mb][r]);
                 }
             }
-#pragma unroll
-        for (int mbq = 0; mbq < 2; ++mbq) {
-            mma_r<BF, DB, NB>(dV, Gw, 16 * mbq + 4 * g, DS, l15, S[mbq]);
-            mma_r<BF, DB, NB>(dK, Qw, 16 * mbq + 4 * g, DS, l15, dP[mbq]);
-        }
+        mma_r2<BF, DB, NB>(dV, Gw, g, DS, l15, S);
+        mma_r2<BF, DB, NB>(dK, Qw, g, DS, l15, dP);
     }
     wave_lds_fence();       // (aliased layout) this wave's reads of its query tile are done before it is overwritten
 #pragma unroll

@@ -95,24 +95,27 @@ template <int NB>
 __device__ __forceinline__ void lb_mma_k(f32x4 (&acc)[NB], const unsigned short* __restrict__ rm, int arow, int g,
                                          const s16x4 (&F)[NB][4]) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const s16x4 a = *(const s16x4*)&rm[arow * LB_RS + 16 * c + 4 * g];
+    for (int cp = 0; cp < 2; ++cp) {      // 64 features = two 32-deep chunks of v_mfma_f32_16x16x32_bf16
+        const s16x8 a = cat_bf(*(const s16x4*)&rm[arow * LB_RS + 32 * cp + 4 * g], *(const s16x4*)&rm[arow * LB_RS + 32 * cp + 16 + 4 * g]);
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma_bf(a, F[nb][c], acc[nb]);
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma_bf32(a, cat_bf(F[nb][2 * cp], F[nb][2 * cp + 1]), acc[nb]);
     }
 }
 // acc[db][nb] += sum_r A[row0 + r][16 db + l15] * B[nb][r]   (A: the transposed bf16 copy of the tile; row0 = 16 mb + 4 g)
+// (the tile's 32 rows are ONE 32-deep chunk of v_mfma_f32_16x16x32_bf16: B[h] = the F-layout block of rows 16 h + 4 g .. + 3)
 template <int NB>
-__device__ __forceinline__ void lb_mma_r(f32x4 (&acc)[4][NB], const unsigned short* __restrict__ tr, int row0, int l15,
-                                         const f32x4 (&B)[NB]) {
-    s16x4 b[NB];
+__device__ __forceinline__ void lb_mma_r(f32x4 (&acc)[4][NB], const unsigned short* __restrict__ tr, int g, int l15,
+                                         const f32x4 (&B)[2][NB]) {
+    s16x8 b[NB];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) b[nb] = pack_bf4(B[nb][0], B[nb][1], B[nb][2], B[nb][3]);
+    for (int nb = 0; nb < NB; ++nb)
+        b[nb] = cat_bf(pack_bf4(B[0][nb][0], B[0][nb][1], B[0][nb][2], B[0][nb][3]),
+                       pack_bf4(B[1][nb][0], B[1][nb][1], B[1][nb][2], B[1][nb][3]));
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
-        const s16x4 a = *(const s16x4*)&tr[(16 * db + l15) * LB_TS + row0];
+        const s16x8 a = cat_bf(*(const s16x4*)&tr[(16 * db + l15) * LB_TS + 4 * g], *(const s16x4*)&tr[(16 * db + l15) * LB_TS + 16 + 4 * g]);
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[db][nb] = mfma_bf(a, b[nb], acc[db][nb]);
+        for (int nb = 0; nb < NB; ++nb) acc[db][nb] = mfma_bf32(a, b[nb], acc[db][nb]);
     }
 }
 
@@ -217,8 +220,7 @@ __device__ __forceinline__ void attn_fwd_body_lb(AttnFwdSmemLb& sm, const EqdGra
 #pragma unroll
             for (int db = 0; db < 4; ++db) O[db][nb] *= alpha;
         }
-#pragma unroll
-        for (int mbk = 0; mbk < 2; ++mbk) lb_mma_r<NB>(O, Vw, 16 * mbk + 4 * g, l15, S[mbk]);
+        lb_mma_r<NB>(O, Vw, g, l15, S);
     }
     // ---- merge the 4 waves' partial softmax states (as attn_fwd_body) ------------------------------------------------
     wave_lds_fence();
@@ -402,8 +404,7 @@ __device__ __forceinline__ void attn_bwd_q_body_lb(AttnBwdSmemLb& sm, const EqdG
                     const float p = key < o1 ? bwd_exp(S[mb][nb][r] - lq[nb]) : 0.f;
                     S[mb][nb][r] = p * (dP[mb][nb][r] - dl[nb]);
                 }
-#pragma unroll
-        for (int mbk = 0; mbk < 2; ++mbk) lb_mma_r<NB>(dQ, W.a_tr, 16 * mbk + 4 * g, l15, S[mbk]);
+        lb_mma_r<NB>(dQ, W.a_tr, g, l15, S);
     }
     wave_lds_fence();
 #pragma unroll
@@ -546,11 +547,8 @@ __device__ __forceinline__ void attn_bwd_kv_body_lb(AttnBwdSmemLb& sm, const Eqd
                     dP[mb][nb][r] = p * (dP[mb][nb][r] - dc[mb][r]);
                 }
             }
-#pragma unroll
-        for (int mbq = 0; mbq < 2; ++mbq) {
-            lb_mma_r<NB>(dV, W.b_tr, 16 * mbq + 4 * g, l15, S[mbq]);
-            lb_mma_r<NB>(dK, W.a_tr, 16 * mbq + 4 * g, l15, dP[mbq]);
-        }
+        lb_mma_r<NB>(dV, W.b_tr, g, l15, S);
+        lb_mma_r<NB>(dK, W.a_tr, g, l15, dP);
     }
     wave_lds_fence();
 #pragma unroll

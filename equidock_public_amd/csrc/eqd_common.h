@@ -156,6 +156,29 @@ __device__ __forceinline__ s16x4 pack_bf4(float a, float b, float c, float d) {
 __device__ __forceinline__ f32x4 mfma_bf(s16x4 a, s16x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
 }
+// v_mfma_f32_16x16x32_bf16 - the gfx950 shape (2 x K per instruction at the issue cost of the 16x16x16 one): a lane supplies
+// 8 bf16 of its A row and 8 of its B column, D as above.  WHICH eight k a lane supplies is free as long as A and B agree, so
+// two consecutive k-chunks of the 16x16x16 formulation - lane group g holding k = 16 c + 4 g .. + 3 of chunk c - are ONE
+// instruction on the concatenated operands: slots 0..3 = chunk c, slots 4..7 = chunk c + 1, for A and B alike.  Same
+// products, fp32 accumulate (the hardware's summation order inside an instruction differs: rounding level).
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ s16x8 cat_bf(s16x4 lo, s16x4 hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
+__device__ __forceinline__ f32x4 mfma_bf32(s16x8 a, s16x8 b, f32x4 c) {
+#if defined(EQD_HOSTSIM) || defined(EQD_MFMA_K16)
+    const s16x4 a0 = __builtin_shufflevector(a, a, 0, 1, 2, 3), a1 = __builtin_shufflevector(a, a, 4, 5, 6, 7);
+    const s16x4 b0 = __builtin_shufflevector(b, b, 0, 1, 2, 3), b1 = __builtin_shufflevector(b, b, 4, 5, 6, 7);
+    return mfma_bf(a1, b1, mfma_bf(a0, b0, c));
+#else
+    typedef __bf16 eqd_bf16x8 __attribute__((ext_vector_type(8)));
+    const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(eqd_bf16x8, a), __builtin_bit_cast(eqd_bf16x8, b), c, 0, 0, 0);
+    // MEASURED on MI355X (profiles/_exp/mfma32b.hip, profiles/r04_h_mfma_overlap.txt): with vdst == srcA this instruction
+    // returns wrong values (vdst == srcB, and either overlap of the 16x16x16 form, are fine), and hipcc (ROCm 7.2) does
+    // allocate vdst onto a dead A operand - k_edge_bwd<bf16, DROP> came out 29 % wrong, run-to-run different, on the GPU
+    // only.  Keeping A live past the instruction costs no instruction and makes the overlap impossible.
+    asm volatile("" ::"v"(a));
+    return d;
+#endif
+}
 
 __device__ __forceinline__ f32x4 f4zero() {
     f32x4 z = {0.f, 0.f, 0.f, 0.f};

@@ -512,24 +512,32 @@ template <bool AFF, int NB>
 __device__ __forceinline__ void chain64_bf(f32x4 (&out)[4][NB], const f32x4 (&in)[4][NB], const unsigned short* __restrict__ w,
                                            const float* __restrict__ ga, const float* __restrict__ be, int l15, int g) {
 #pragma unroll
-    for (int mbi = 0; mbi < 4; ++mbi) {
-        s16x4 b[NB];
-        float gg[4] = {1.f, 1.f, 1.f, 1.f}, bb[4] = {0.f, 0.f, 0.f, 0.f};
-        if (AFF) {
-            const float4 gv = *(const float4*)&ga[16 * mbi + 4 * g];
-            const float4 bv = *(const float4*)&be[16 * mbi + 4 * g];
-            gg[0] = gv.x; gg[1] = gv.y; gg[2] = gv.z; gg[3] = gv.w;
-            bb[0] = bv.x; bb[1] = bv.y; bb[2] = bv.z; bb[3] = bv.w;
+    for (int mp = 0; mp < 2; ++mp) {      // two 16-feature blocks of `in` = one 32-deep k-chunk of v_mfma_f32_16x16x32_bf16
+        s16x8 b[NB];
+        s16x4 bh[2][NB];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int mbi = 2 * mp + h;
+            float gg[4] = {1.f, 1.f, 1.f, 1.f}, bb[4] = {0.f, 0.f, 0.f, 0.f};
+            if (AFF) {
+                const float4 gv = *(const float4*)&ga[16 * mbi + 4 * g];
+                const float4 bv = *(const float4*)&be[16 * mbi + 4 * g];
+                gg[0] = gv.x; gg[1] = gv.y; gg[2] = gv.z; gg[3] = gv.w;
+                bb[0] = bv.x; bb[1] = bv.y; bb[2] = bv.z; bb[3] = bv.w;
+            }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+                bh[h][nb] = pack_bf4(in[mbi][nb][0] * gg[0] + bb[0], in[mbi][nb][1] * gg[1] + bb[1],
+                                     in[mbi][nb][2] * gg[2] + bb[2], in[mbi][nb][3] * gg[3] + bb[3]);
         }
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-            b[nb] = pack_bf4(in[mbi][nb][0] * gg[0] + bb[0], in[mbi][nb][1] * gg[1] + bb[1], in[mbi][nb][2] * gg[2] + bb[2],
-                             in[mbi][nb][3] * gg[3] + bb[3]);
+        for (int nb = 0; nb < NB; ++nb) b[nb] = cat_bf(bh[0][nb], bh[1][nb]);
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
-            const s16x4 a = *(const s16x4*)&w[(16 * mb + l15) * WSB + 16 * mbi + 4 * g];
+            const s16x8 a = cat_bf(*(const s16x4*)&w[(16 * mb + l15) * WSB + 32 * mp + 4 * g],
+                                   *(const s16x4*)&w[(16 * mb + l15) * WSB + 32 * mp + 16 + 4 * g]);
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) out[mb][nb] = mfma_bf(a, b[nb], out[mb][nb]);
+            for (int nb = 0; nb < NB; ++nb) out[mb][nb] = mfma_bf32(a, b[nb], out[mb][nb]);
         }
     }
 }
@@ -623,14 +631,25 @@ __device__ __forceinline__ void edge_tile_forward_bf(const EqdGraph& G, const Eq
             xh[mb][nb] = a;
         }
     EQD_TR(5);
+    {      // 48 feature columns = one 32-deep chunk (v_mfma_f32_16x16x32_bf16) + one 16-deep one
+        s16x8 b[NB];
 #pragma unroll
-    for (int kc = 0; kc < 3; ++kc) {
-        s16x4 b[NB];
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) b[nb] = *(const s16x4*)&ft[(16 * nb + l15) * FSB + 16 * kc + 4 * g];
+        for (int nb = 0; nb < NB; ++nb)
+            b[nb] = cat_bf(*(const s16x4*)&ft[(16 * nb + l15) * FSB + 4 * g], *(const s16x4*)&ft[(16 * nb + l15) * FSB + 16 + 4 * g]);
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
-            const s16x4 a = *(const s16x4*)&w1[(16 * mb + l15) * WSB + 16 * kc + 4 * g];
+            const s16x8 a = cat_bf(*(const s16x4*)&w1[(16 * mb + l15) * WSB + 4 * g], *(const s16x4*)&w1[(16 * mb + l15) * WSB + 16 + 4 * g]);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) xh[mb][nb] = mfma_bf32(a, b[nb], xh[mb][nb]);
+        }
+    }
+    {
+        s16x4 b[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) b[nb] = *(const s16x4*)&ft[(16 * nb + l15) * FSB + 32 + 4 * g];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const s16x4 a = *(const s16x4*)&w1[(16 * mb + l15) * WSB + 32 + 4 * g];
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) xh[mb][nb] = mfma_bf(a, b[nb], xh[mb][nb]);
         }
@@ -1109,11 +1128,13 @@ template <int NJ>
 __device__ __forceinline__ void slab_atb_bf(f32x4 (&acc)[NJ], const unsigned short* __restrict__ Xt,
                                             const unsigned short* __restrict__ Yt, int mb, int nb0, int l15, int g) {
 #pragma unroll
-    for (int kc = 0; kc < 8; ++kc) {
-        const s16x4 a = *(const s16x4*)&Xt[(16 * mb + l15) * USB + 16 * kc + 4 * g];
+    for (int kp = 0; kp < 4; ++kp) {      // 128 edges = four 32-deep chunks of v_mfma_f32_16x16x32_bf16
+        const s16x8 a = cat_bf(*(const s16x4*)&Xt[(16 * mb + l15) * USB + 32 * kp + 4 * g],
+                               *(const s16x4*)&Xt[(16 * mb + l15) * USB + 32 * kp + 16 + 4 * g]);
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-            acc[j] = mfma_bf(a, *(const s16x4*)&Yt[(16 * (nb0 + j) + l15) * USB + 16 * kc + 4 * g], acc[j]);
+            acc[j] = mfma_bf32(a, cat_bf(*(const s16x4*)&Yt[(16 * (nb0 + j) + l15) * USB + 32 * kp + 4 * g],
+                                         *(const s16x4*)&Yt[(16 * (nb0 + j) + l15) * USB + 32 * kp + 16 + 4 * g]), acc[j]);
     }
 }
 
@@ -1404,9 +1425,12 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
             f32x4 dr = f4zero();
             if constexpr (BF) {
 #pragma unroll
-                for (int mbi = 0; mbi < 4; ++mbi)
-                    dr = mfma_bf(*(const s16x4*)&sm.w1rT[l15 * WSB + 16 * mbi + 4 * g],
-                                 pack_bf4(dz[mbi][0][0], dz[mbi][0][1], dz[mbi][0][2], dz[mbi][0][3]), dr);
+                for (int mp = 0; mp < 2; ++mp)
+                    dr = mfma_bf32(cat_bf(*(const s16x4*)&sm.w1rT[l15 * WSB + 32 * mp + 4 * g],
+                                          *(const s16x4*)&sm.w1rT[l15 * WSB + 32 * mp + 16 + 4 * g]),
+                                   cat_bf(pack_bf4(dz[2 * mp][0][0], dz[2 * mp][0][1], dz[2 * mp][0][2], dz[2 * mp][0][3]),
+                                          pack_bf4(dz[2 * mp + 1][0][0], dz[2 * mp + 1][0][1], dz[2 * mp + 1][0][2],
+                                                   dz[2 * mp + 1][0][3])), dr);
             } else {
 #pragma unroll
                 for (int mbi = 0; mbi < 4; ++mbi)

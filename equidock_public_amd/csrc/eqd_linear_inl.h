@@ -271,13 +271,26 @@ __device__ __forceinline__ void lin_mma(f32x4 (&acc)[RT][2], f32x4 (&acc2)[RT][2
         if constexpr (BF) {
             // bf16 mode: the 4 k-values a lane holds for chunk q (k = 16 q + 4 g + j) are exactly one operand of
             // v_mfma_f32_16x16x16_bf16: four fp32 instructions become one (inputs rounded to bf16, fp32 accumulate)
+            // ... and two consecutive chunks one v_mfma_f32_16x16x32_bf16 (gfx950: 2 x K at the same issue cost)
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
+            for (int qp = 0; qp < NQ / 2; ++qp) {
+                const s16x8 bp = cat_bf(pack_bf4(b[2 * qp][0], b[2 * qp][1], b[2 * qp][2], b[2 * qp][3]),
+                                        pack_bf4(b[2 * qp + 1][0], b[2 * qp + 1][1], b[2 * qp + 1][2], b[2 * qp + 1][3]));
+#pragma unroll
+                for (int i = 0; i < NOWN; ++i) {
+                    const s16x8 ap = cat_bf(pack_bf4(a[i][2 * qp][0], a[i][2 * qp][1], a[i][2 * qp][2], a[i][2 * qp][3]),
+                                            pack_bf4(a[i][2 * qp + 1][0], a[i][2 * qp + 1][1], a[i][2 * qp + 1][2], a[i][2 * qp + 1][3]));
+                    if (qp & 1) acc2[rt][i] = mfma_bf32(ap, bp, acc2[rt][i]);
+                    else acc[rt][i] = mfma_bf32(ap, bp, acc[rt][i]);
+                }
+            }
+            if constexpr (NQ % 2 == 1) {
+                constexpr int q = NQ - 1;
                 const s16x4 bp = pack_bf4(b[q][0], b[q][1], b[q][2], b[q][3]);
 #pragma unroll
                 for (int i = 0; i < NOWN; ++i) {
                     const s16x4 ap = pack_bf4(a[i][q][0], a[i][q][1], a[i][q][2], a[i][q][3]);
-                    if (q & 1) acc2[rt][i] = mfma_bf(ap, bp, acc2[rt][i]);
+                    if ((NQ / 2) & 1) acc2[rt][i] = mfma_bf(ap, bp, acc2[rt][i]);
                     else acc[rt][i] = mfma_bf(ap, bp, acc[rt][i]);
                 }
             }

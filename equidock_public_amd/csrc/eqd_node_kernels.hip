@@ -397,8 +397,12 @@ __device__ __forceinline__ void chain_lnbwd(const EqdChainJob& C, float (*Lb)[LI
     jaux[(size_t)blockIdx.x * 256 + t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
 }
 
-template <int RT, bool BF = false>
-__global__ __launch_bounds__(EQD_BLOCK, 2) void k_rowchain(EqdChainArg A_) {
+// OCC: workgroups per CU the register budget is sized for.  2 (256 registers) wherever a launch has more 16-row tiles than
+// the chip has CUs; 1 (up to 512) for DB5.5-sized batches - 200 tiles on 256 CUs run one workgroup per CU whatever the
+// budget, so the cap would only cost spills (RT = 2: 46 - 59 spilled registers at 256) and a shallower load pipeline.
+// Same instructions in the same order per output element: bit-identical results.
+template <int RT, bool BF = false, int OCC = 2>
+__global__ __launch_bounds__(EQD_BLOCK, OCC) void k_rowchain(EqdChainArg A_) {
     __shared__ __attribute__((aligned(16))) EqdChainArg A;      // job descriptions: kernarg segment -> LDS, once
     kernarg_to_lds(A, EQD_KERNARG_PTR(A_), 0);
     __shared__ LinSmem<RT> sm;
@@ -628,11 +632,16 @@ int eqd_launch_rowchain(const EqdChainJob* jobs, int njobs, int rows, hipStream_
     }
     if (partial_rows) *partial_rows = eqd_rowchain_blocks(rows);
     if (eqd_row_tiles(rows) == 2) {
-        if (bf) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rowchain<2, true>), dim3(eqd_rowchain_blocks(rows)), dim3(EQD_BLOCK), 0, st, arg);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rowchain<2, false>), dim3(eqd_rowchain_blocks(rows)), dim3(EQD_BLOCK), 0, st, arg);
+        // (the two-tile forms need more than 256 registers: one workgroup per CU at every size)
+        if (bf) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rowchain<2, true, 1>), dim3(eqd_rowchain_blocks(rows)), dim3(EQD_BLOCK), 0, st, arg);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rowchain<2, false, 1>), dim3(eqd_rowchain_blocks(rows)), dim3(EQD_BLOCK), 0, st, arg);
     } else {
-        if (bf) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rowchain<1, true>), dim3(eqd_rowchain_blocks(rows)), dim3(EQD_BLOCK), 0, st, arg);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rowchain<1, false>), dim3(eqd_rowchain_blocks(rows)), dim3(EQD_BLOCK), 0, st, arg);
+        const char* oc = eqd_tunable("EQD_ROWCHAIN_OCC");      // experiments: 1 / 2 forces a register budget
+        const bool one = oc && (oc[0] == '1' || oc[0] == '2') && oc[1] == 0 ? oc[0] == '1' : eqd_rowchain_blocks(rows) <= eqd_num_cus();
+        if (bf && one) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rowchain<1, true, 1>), dim3(eqd_rowchain_blocks(rows)), dim3(EQD_BLOCK), 0, st, arg);
+        else if (bf) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rowchain<1, true, 2>), dim3(eqd_rowchain_blocks(rows)), dim3(EQD_BLOCK), 0, st, arg);
+        else if (one) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rowchain<1, false, 1>), dim3(eqd_rowchain_blocks(rows)), dim3(EQD_BLOCK), 0, st, arg);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rowchain<1, false, 2>), dim3(eqd_rowchain_blocks(rows)), dim3(EQD_BLOCK), 0, st, arg);
     }
     return eqd_check_launch("k_rowchain");
 }
@@ -786,6 +795,25 @@ __device__ __forceinline__ void atb_store(const EqdAtbJob& J, int n0, int chunk,
 template <int MBN, bool BF = false>
 __device__ __forceinline__ void atb_mma(f32x4 (&acc)[5], const float* __restrict__ Xl, const float* __restrict__ Yl,
                                         int wave, int l15, int g) {
+    if constexpr (BF) {      // bf16 mode: eight k-steps (rows 4 (ks + u) + g) as one 32-deep v_mfma_f32_16x16x32_bf16
+        static_assert((ATB_ROWS / 4) % 8 == 0, "whole 32-deep chunks");
+        for (int ks = 0; ks < ATB_ROWS / 4; ks += 8) {
+            float b[8], a[8][MBN];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int row = 4 * (ks + u) + g;
+                b[u] = Yl[row * ATB_LS + 16 * wave + l15];
+#pragma unroll
+                for (int mb = 0; mb < MBN; ++mb) a[u][mb] = Xl[row * ATB_LS + 16 * mb + l15];
+            }
+            const s16x8 bp = cat_bf(pack_bf4(b[0], b[1], b[2], b[3]), pack_bf4(b[4], b[5], b[6], b[7]));
+#pragma unroll
+            for (int mb = 0; mb < MBN; ++mb)
+                acc[mb] = mfma_bf32(cat_bf(pack_bf4(a[0][mb], a[1][mb], a[2][mb], a[3][mb]), pack_bf4(a[4][mb], a[5][mb], a[6][mb], a[7][mb])),
+                                    bp, acc[mb]);
+        }
+        return;
+    }
     for (int ks = 0; ks < ATB_ROWS / 4; ks += 4) {
         float b[4], a[4][MBN];
 #pragma unroll
@@ -795,11 +823,7 @@ __device__ __forceinline__ void atb_mma(f32x4 (&acc)[5], const float* __restrict
 #pragma unroll
             for (int mb = 0; mb < MBN; ++mb) a[u][mb] = Xl[row * ATB_LS + 16 * mb + l15];
         }
-        if constexpr (BF) {      // bf16 mode: the four k-steps (rows 4 (ks + u) + g) as one 16-deep bf16 MFMA
-            const s16x4 bp = pack_bf4(b[0], b[1], b[2], b[3]);
-#pragma unroll
-            for (int mb = 0; mb < MBN; ++mb)
-                acc[mb] = mfma_bf(pack_bf4(a[0][mb], a[1][mb], a[2][mb], a[3][mb]), bp, acc[mb]);
+        if constexpr (BF) {
         } else {
 #pragma unroll
             for (int u = 0; u < 4; ++u)
@@ -966,10 +990,12 @@ __device__ __forceinline__ void atb_fast_bf(const AtbUnit& u, int c, float* __re
         __syncthreads();             // the chunk is in LDS (and every wave is past its reads of the chunk before the last)
         if (chunk + nparts < nchunks) load(chunk + nparts);
 #pragma unroll
-        for (int kc = 0; kc < 4; ++kc) {
-            const s16x4 b = Yc[(16 * wave + l15) * ATB_KG + 4 * kc + g];
+        for (int kp = 0; kp < 2; ++kp) {      // 64 rows = two 32-deep chunks of v_mfma_f32_16x16x32_bf16
+            const s16x8 b = cat_bf(Yc[(16 * wave + l15) * ATB_KG + 8 * kp + g], Yc[(16 * wave + l15) * ATB_KG + 8 * kp + 4 + g]);
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) acc[mb] = mfma_bf(Xc[(16 * mb + l15) * ATB_KG + 4 * kc + g], b, acc[mb]);
+            for (int mb = 0; mb < 4; ++mb)
+                acc[mb] = mfma_bf32(cat_bf(Xc[(16 * mb + l15) * ATB_KG + 8 * kp + g], Xc[(16 * mb + l15) * ATB_KG + 8 * kp + 4 + g]), b,
+                                    acc[mb]);
         }
         buf ^= 1;
     }

@@ -203,24 +203,29 @@ __device__ __forceinline__ void rr_item(const float* __restrict__ Wl, int K, boo
 __device__ __forceinline__ void rr_item_bf(const unsigned short* __restrict__ Wl, int K, bool local, const float* T,
                                            const RrRows& R, int l15, int g, f32x4 (&acc)[4]) {
     const int KP = rr_kp16(K);
-    const int na = K > 64 ? 5 : 4;
+    // columns 0..63: two 32-deep chunks of v_mfma_f32_16x16x32_bf16 (two of the lane's 16-column blocks each)
 #pragma unroll
-    for (int a = 0; a < 5; ++a) {
-        if (a < na) {
-            f32x4 bv;
-            if (a == 4) {
-                const float4 xf = ld4u_fix(R.xr, K - 64 - 4 * g);
-                bv = f32x4{xf.x, xf.y, xf.z, xf.w};
-            } else if (local) {
-                bv = *(const f32x4*)(T + l15 * RW_S + 16 * a + 4 * g);
-            } else {
-                bv = R.x[a < 4 ? a : 0];
-            }
-            const s16x4 bp = pack_bf4(bv[0], bv[1], bv[2], bv[3]);
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
-                acc[mb] = mfma_bf(*(const s16x4*)&Wl[(16 * mb + l15) * KP + 16 * a + 4 * g], bp, acc[mb]);
+    for (int ap = 0; ap < 2; ++ap) {
+        f32x4 b0, b1;
+        if (local) {
+            b0 = *(const f32x4*)(T + l15 * RW_S + 32 * ap + 4 * g);
+            b1 = *(const f32x4*)(T + l15 * RW_S + 32 * ap + 16 + 4 * g);
+        } else {
+            b0 = R.x[2 * ap];
+            b1 = R.x[2 * ap + 1];
         }
+        const s16x8 bp = cat_bf(pack_bf4(b0[0], b0[1], b0[2], b0[3]), pack_bf4(b1[0], b1[1], b1[2], b1[3]));
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+            acc[mb] = mfma_bf32(cat_bf(*(const s16x4*)&Wl[(16 * mb + l15) * KP + 32 * ap + 4 * g],
+                                       *(const s16x4*)&Wl[(16 * mb + l15) * KP + 32 * ap + 16 + 4 * g]), bp, acc[mb]);
+    }
+    if (K > 64) {      // the 69-wide sources' remainder columns: one 16-deep chunk
+        const float4 xf = ld4u_fix(R.xr, K - 64 - 4 * g);
+        const s16x4 bp = pack_bf4(xf.x, xf.y, xf.z, xf.w);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+            acc[mb] = mfma_bf(*(const s16x4*)&Wl[(16 * mb + l15) * KP + 64 + 4 * g], bp, acc[mb]);
     }
 }
 

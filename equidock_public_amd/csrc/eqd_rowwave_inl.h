@@ -180,6 +180,16 @@ __device__ __forceinline__ void rw_take(const RwBuf& R, bool tp, bool masked, fl
 // for the columns 64 .. K - 1 (only a = 4 exists)
 template <bool BF>
 __device__ __forceinline__ void rw_mma(const RwOps<BF>& O, bool local, const f32x4 (&Bl)[2], bool tp, int ni, f32x4 (&acc)[4]) {
+    if constexpr (BF) {
+        if (ni == 2) {      // both 16-deep halves of the sub-step at once: v_mfma_f32_16x16x32_bf16
+            const s16x4 b0 = local ? pack_bf4(Bl[0][0], Bl[0][1], Bl[0][2], Bl[0][3]) : O.x[0];
+            const s16x4 b1 = local ? pack_bf4(Bl[1][0], Bl[1][1], Bl[1][2], Bl[1][3]) : O.x[1];
+            const s16x8 bp = cat_bf(b0, b1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = mfma_bf32(cat_bf(O.w[q], O.w[4 + q]), bp, acc[q]);
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         if (i < ni) {
