@@ -68,7 +68,7 @@ def step_flops_as_written(sizes, L, d0=69, d=64, K=50):
 
 
 def kernel_work_model(sizes, L, n_nodes, n_edges, cross=True, d0=69, dh=64, d_emb=64, K=50, fused_fwd=False, rowwave='k_rowres',
-                      fused_gather=False):
+                      fused_gather=False, ds_handoff=False):
     """Per-STEP work of each kernel family, from the launch structure of eqd_model_forward / eqd_model_backward
     (csrc/eqd_driver.hip): `flops` = FLOPs the kernel executes on the MFMA pipes for its GEMMs (2 per MAC),
     `flops_written` = the model-as-written share where SURVEY.md section 8d defines one (edge kernels, attention),
@@ -79,7 +79,7 @@ def kernel_work_model(sizes, L, n_nodes, n_edges, cross=True, d0=69, dh=64, d_em
     W = {k: dict(flops=0.0, flops_written=0.0, bytes=0.0) for k in
          ('k_linear', 'k_rowchain', 'k_rowwave', 'k_rowres', 'k_attn_fwd', 'k_attn_bwd', 'k_edge_fwd', 'k_edge_bwd', 'k_node_gather',
           'k_atb', 'k_atb_reduce', 'k_edge_attn_fwd', 'k_attn_bwd_gather', 'k_keypoint', 'k_keypoint_bwd_a', 'k_keypoint_bwd_b',
-          'k_head_u', 'k_head_u_bwd')}
+          'k_head_u', 'k_head_u_bwd', 'k_attn_bwd_kvds', 'k_attn_bwd_qds')}
     # k_edge_attn_fwd: the 64-wide layers' edge + attention forward in one launch (small batches); k_attn_bwd_gather: the
     # 64-wide layers' attention backward with the edge backward's node gather (+ the partial reductions) in the same launch
     for l in range(L):
@@ -110,10 +110,20 @@ def kernel_work_model(sizes, L, n_nodes, n_edges, cross=True, d0=69, dh=64, d_em
             W[fa]['flops'] += 8 * pp * da
             W[fa]['flops_written'] += 8 * pp * d
             W[fa]['bytes'] += N * 4 * (4 * da + 1)
-            ab = 'k_attn_bwd_gather' if (fused_gather and d == 64) else 'k_attn_bwd'
-            W[ab]['flops'] += 28 * pp * da
-            W[ab]['flops_written'] += 16 * pp * d
-            W[ab]['bytes'] += N * 4 * (8 * da + 2)
+            if ds_handoff and d == 64:
+                # dS hand-off (large batches): the key / value pass executes S, dP, dV, dK (4 units of 4 pp d) and writes dS
+                # (2 pp floats), the dq pass contracts it with K (1 unit): 20 pp d executed for 16 as written
+                W['k_attn_bwd_kvds']['flops'] += 16 * pp * da
+                W['k_attn_bwd_kvds']['flops_written'] += 12 * pp * d
+                W['k_attn_bwd_kvds']['bytes'] += N * 4 * (7 * da + 2) + 8 * pp
+                W['k_attn_bwd_qds']['flops'] += 4 * pp * da
+                W['k_attn_bwd_qds']['flops_written'] += 4 * pp * d
+                W['k_attn_bwd_qds']['bytes'] += N * 4 * (3 * da) + 8 * pp
+            else:
+                ab = 'k_attn_bwd_gather' if (fused_gather and d == 64) else 'k_attn_bwd'
+                W[ab]['flops'] += 28 * pp * da
+                W[ab]['flops_written'] += 16 * pp * d
+                W[ab]['bytes'] += N * 4 * (8 * da + 2)
         # edge kernels (as written: 2 (2 d + 42) 64 + 2 64 64 + 2 64 64 + 2 64 per edge; executed: the P/Q split moves
         # 2 (2 d) 64 per edge to k_linear - the executed count comes from the PMC file when present)
         fe = 2 * (2 * d + 42) * 64 + 2 * 64 * 64 + 2 * 64 * 64 + 2 * 64
@@ -124,7 +134,9 @@ def kernel_work_model(sizes, L, n_nodes, n_edges, cross=True, d0=69, dh=64, d_em
         W['k_edge_bwd']['flops_written'] += 2 * E * fe
         W['k_edge_bwd']['flops'] += E * (3 * fx - 2 * 42 * 64)      # recompute + data gradients + weight gradients
         W['k_edge_bwd']['bytes'] += 2 * (N * 540 + E * 112)
-        W['k_attn_bwd_gather' if (fused_gather and cross and d == 64) else 'k_node_gather']['bytes'] += E * 272 + N * 540
+        gk = 'k_attn_bwd_kvds' if (ds_handoff and cross and d == 64) else \
+            ('k_attn_bwd_gather' if (fused_gather and cross and d == 64) else 'k_node_gather')
+        W[gk]['bytes'] += E * 272 + N * 540      # (the layer's node gather rides in that launch)
         # end-of-pass weight-gradient GEMMs of the node-level Linears
         W['k_atb']['flops'] += N * 2 * (dh * d + d * d + d * 64 + (d * d if cross else 0) + d * d0 + 2 * 64 * d
                                         + (3 * d * d if cross else 0))
@@ -814,7 +826,7 @@ def main():
                 prof, ev_us, n_launch = profile_step(compute, dev)
                 work = kernel_work_model(sizes, L, packed.n_nodes, packed.n_edges, fused_fwd='k_edge_attn_fwd' in prof,
                                          rowwave=next((k for k in ('k_rowres', 'k_rowwave') if k in prof), None),
-                                         fused_gather='k_attn_bwd_gather' in prof)
+                                         fused_gather='k_attn_bwd_gather' in prof, ds_handoff='k_attn_bwd_kvds' in prof)
                 wkey = a.workload + ('_bf16' if dtype == 'bf16' else '')
                 traffic, traffic_src = load_traffic(wkey)
                 allk, ktot, covered = kernel_rooflines(prof, work, dtype == 'bf16', ms_step * 1e3, load_pmc(wkey), traffic)

@@ -97,13 +97,14 @@ def _declare(lib):
     lib.eqd_edge_message_bwd_workspace_bytes.restype = C.c_size_t
     lib.eqd_keypoint_pool_bwd_workspace_bytes.restype = C.c_size_t
     lib.eqd_clash_workspace_bytes.restype = C.c_size_t
+    lib.eqd_cross_attention_bwd_ds_workspace_bytes.restype = C.c_size_t
     lib.eqd_profile_name.restype = C.c_char_p
     lib.eqd_profile_us.restype = C.c_float
     lib.eqd_tunables_reload.restype = None
     for name in ('eqd_model_layer_state', 'eqd_model_lrelu_signs', 'eqd_model_head_backward', 'eqd_profile_begin', 'eqd_profile_end', 'eqd_profile_mark', 'eqd_ctx_create', 'eqd_ctx_destroy', 'eqd_model_check', 'eqd_model_forward', 'eqd_model_backward', 'eqd_linear', 'eqd_atb',
                  'eqd_edge_message_fwd', 'eqd_edge_message_bwd', 'eqd_edge_message_bwd_kernel_only',
                  'eqd_cross_attention_fwd', 'eqd_cross_attention_fwd_bf16', 'eqd_cross_attention_bwd_bf16',
-                 'eqd_cross_attention_bwd',
+                 'eqd_cross_attention_bwd', 'eqd_cross_attention_bwd_ds',
            'eqd_keypoint_pool_fwd', 'eqd_keypoint_pool_bwd', 'eqd_kabsch_fwd', 'eqd_kabsch_bwd',
                  'eqd_rigid_apply_fwd', 'eqd_rigid_apply_bwd', 'eqd_pair_losses_fwd', 'eqd_pair_losses_bwd', 'eqd_scalar_loss', 'eqd_pocket_ot_cost',
                  'eqd_pocket_ot_fwd', 'eqd_pocket_ot_bwd', 'eqd_rigid_augment', 'eqd_protein_graph_distances',
@@ -115,7 +116,7 @@ EXPORTS = ('eqd_model_layer_state', 'eqd_model_lrelu_signs', 'eqd_model_head_bac
            'eqd_model_scratch_bytes', 'eqd_model_check', 'eqd_model_forward', 'eqd_model_backward', 'eqd_linear',
            'eqd_atb_partial_bytes', 'eqd_atb', 'eqd_edge_message_fwd', 'eqd_edge_message_bwd_workspace_bytes',
            'eqd_edge_message_bwd', 'eqd_edge_message_bwd_kernel_only', 'eqd_cross_attention_fwd',
-           'eqd_cross_attention_bwd', 'eqd_cross_attention_fwd_bf16', 'eqd_cross_attention_bwd_bf16',
+           'eqd_cross_attention_bwd', 'eqd_cross_attention_bwd_ds', 'eqd_cross_attention_bwd_ds_workspace_bytes', 'eqd_cross_attention_fwd_bf16', 'eqd_cross_attention_bwd_bf16',
            'eqd_keypoint_pool_fwd', 'eqd_keypoint_pool_bwd',
            'eqd_keypoint_pool_bwd_workspace_bytes',
            'eqd_kabsch_fwd', 'eqd_kabsch_bwd', 'eqd_rigid_apply_fwd', 'eqd_rigid_apply_bwd', 'eqd_pair_losses_fwd',

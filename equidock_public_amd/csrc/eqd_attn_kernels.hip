@@ -27,6 +27,7 @@
 #include "eqd_attn_lb_inl.h"
 
 #include <stdlib.h>
+#include <string.h>
 
 // backward pass 1: dq for the block's queries; also writes delta[q] = sum_f dO[q][f] O[q][f]
 // LDS of the backward passes: 2 block tiles + 2 x EQD_WAVES streamed tiles + the merge buffer + 32 floats per wave
@@ -212,13 +213,19 @@ __device__ __forceinline__ void attn_bwd_q_body(SM& sm, const EqdGraph& G, int i
 // backward pass 2: dk, dv for the block's keys (queries = the partner protein).
 // OWN_DELTA (float4 path only): delta = rowsum(dO * O) of each streamed query tile is recomputed here from the
 // O tile instead of being read from pass 1's output, so that both passes can run in ONE launch.
-template <int DB, bool FAST, bool OWN_DELTA, int NB, class SM, bool BF = false>
+// WDS (the dS hand-off, large batches): the pass also WRITES its dS = P o (dP - delta) tiles - element (query, key) at
+// ds[query * ds_stride + (key - first node of the key's protein)] - and the dq pass becomes ONE contraction over them
+// (attn_bwd_qds_body) instead of recomputing S and dP: 5 executed GEMM units per (query tile, key tile) instead of 7 (4 as
+// written, rigid_docking_model.py:46-64 backward).  seg_start[node] = first node of the node's protein.
+template <int DB, bool FAST, bool OWN_DELTA, int NB, class SM, bool BF = false, bool WDS = false>
 __device__ __forceinline__ void attn_bwd_kv_body(SM& sm, const EqdGraph& G, int item, int d,
                                                  const float* __restrict__ q, const float* __restrict__ k,
                                                  const float* __restrict__ v, const float* __restrict__ out,
                                                  const float* __restrict__ lse, const float* __restrict__ d_out,
                                                  const float* __restrict__ delta, float* __restrict__ dk,
-                                                 float* __restrict__ dv, int half = 0, float qk_slope = 1.f) {
+                                                 float* __restrict__ dv, int half = 0, float qk_slope = 1.f,
+                                                 float* __restrict__ ds = nullptr, int ds_stride = 0,
+                                                 const int32_t* __restrict__ seg_start = nullptr) {
     static_assert(FAST || !OWN_DELTA, "OWN_DELTA needs the float4 tile layout");
     typedef AttnCfg<DB> C;
     constexpr int DS = C::DS, KS = C::KS;
@@ -243,6 +250,12 @@ __device__ __forceinline__ void attn_bwd_kv_body(SM& sm, const EqdGraph& G, int 
         kvd[nb] = rowk[nb] < b1;
     }
 
+    int kcol[NB];      // WDS: this lane's key columns inside a dS row
+    if constexpr (WDS) {
+        const int y0 = seg_start[b0];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) kcol[nb] = rowk[nb] - y0;
+    }
     TileRegs<DB, FAST> rq, rg;
     TileRegs<DB, FAST && OWN_DELTA> ro;
     int qt = o0 + 32 * wave;
@@ -362,6 +375,20 @@ __device__ __forceinline__ void attn_bwd_kv_body(SM& sm, const EqdGraph& G, int 
                     dP[mb][nb][r] = p * (dP[mb][nb][r] - dc[mb][r]);
                 }
             }
+        if constexpr (WDS) {      // rows = the tile's queries, 16 consecutive keys per lane group: 64-byte segments
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qr = qt + 16 * mb + 4 * g + r;
+                    if (qr < o1) {
+                        float* __restrict__ row = ds + (size_t)qr * ds_stride;
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            if (kvd[nb]) row[kcol[nb]] = dP[mb][nb][r];
+                    }
+                }
+        }
         mma_r2<BF, DB, NB>(dV, Gw, g, DS, l15, S);
         mma_r2<BF, DB, NB>(dK, Qw, g, DS, l15, dP);
     }
@@ -392,6 +419,160 @@ __device__ __forceinline__ void attn_bwd_kv_body(SM& sm, const EqdGraph& G, int 
                     }
                 }
             }
+    }
+}
+
+// backward pass 1 over the dS tiles the key / value pass left (d = 64, 16-byte aligned rows): dq[query] = sum over the
+// partner's keys of dS[query][key] K[key], times LeakyReLU'(q).  The workgroup's 4 waves split the partner's 32-key tiles as
+// in attn_bwd_q_body and merge in the same order; a lane's B operand - 4 consecutive keys of its query row - is ONE
+// 16-byte load from the dS row (rows are ds_stride floats, a multiple of 32, so a tile never leaves its row; keys beyond the
+// partner are whatever the buffer holds and are selected away).
+template <int DB>
+struct AttnQdsSmem {
+    typedef AttnCfg<DB> C;
+    float str_[EQD_WAVES][C::TILE];
+    __device__ __forceinline__ float* red(int w) { return str_[w]; }      // merge buffer = each wave's own tile, as in the alias layout
+    static_assert(C::RED <= C::TILE, "merge buffer must fit a streamed tile");
+};
+template <int DB, int NB>
+__device__ __forceinline__ void attn_bwd_qds_body(AttnQdsSmem<DB>& sm, const EqdGraph& G, int item, const float* __restrict__ q,
+                                                  const float* __restrict__ k, const float* __restrict__ ds, int ds_stride,
+                                                  float* __restrict__ dq, int half, float qk_slope) {
+    typedef AttnCfg<DB> C;
+    constexpr int DS = C::DS, d = 16 * DB;      // (80 = the 69-wide first layer, zero-padded by the caller)
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    int b0 = G.att_items[item * 4 + 0], b1 = G.att_items[item * 4 + 1];
+    const int o0 = G.att_items[item * 4 + 2], o1 = G.att_items[item * 4 + 3];
+    if (NB == 1) {
+        b0 += 16 * half;
+        b1 = b1 < b0 + 16 ? b1 : b0 + 16;
+    }
+    if (b0 >= b1) return;
+    int rowq[NB];
+    bool qv[NB];
+    const float* __restrict__ dsr[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        rowq[nb] = b0 + 16 * nb + l15;
+        qv[nb] = rowq[nb] < b1;
+        dsr[nb] = ds + (size_t)(qv[nb] ? rowq[nb] : b1 - 1) * ds_stride;      // + (key - o0)
+    }
+    TileRegs<DB, true> rk;
+    int kt = o0 + 32 * wave;
+    tile_load<DB, true>(rk, k, d, kt, o1, lane);
+    f32x4 sv[2][NB];
+    auto ds_load = [&](int kt_) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int col = kt_ < o1 ? kt_ - o0 + 16 * mb + 4 * g : 0;      // (a tile beyond the partner: any valid address)
+                sv[mb][nb] = *(const f32x4*)(dsr[nb] + col);
+            }
+    };
+    ds_load(kt);
+    f32x4 dQ[DB][NB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) dQ[db][nb] = f4zero();
+    float* __restrict__ Kw = sm.str_[wave];
+    for (; kt < o1; kt += 32 * EQD_WAVES) {
+        wave_lds_fence();
+        tile_store<DB, true>(rk, Kw, d, lane);
+        wave_lds_fence();
+        f32x4 S[2][NB];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) S[mb][nb][r] = kt + 16 * mb + 4 * g + r < o1 ? sv[mb][nb][r] : 0.f;
+        tile_load<DB, true>(rk, k, d, kt + 32 * EQD_WAVES, o1, lane);
+        ds_load(kt + 32 * EQD_WAVES);
+        mma_r2<false, DB, NB>(dQ, Kw, g, DS, l15, S);
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sm.red(wave)[((db * 2 + nb) * 4 + r) * 64 + lane] = dQ[db][nb][r];
+    __syncthreads();
+    for (int db = wave; db < DB; db += EQD_WAVES)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            if (!qv[nb]) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = ((db * 2 + nb) * 4 + r) * 64 + lane;
+                const int f = 16 * db + 4 * g + r;
+                dq[(size_t)rowq[nb] * d + f] = (sm.red(0)[o] + sm.red(1)[o] + sm.red(2)[o] + sm.red(3)[o]) *
+                                               lrelu_grad(q[(size_t)rowq[nb] * d + f], qk_slope);
+            }
+        }
+}
+// (half blocks like the kernels around it: workgroup b -> item 8 (b / 16) + b % 8, half (b / 8) % 2, so a direction's blocks
+// and the dS rows they read stay on the XCD whose L2 the key / value pass left them in)
+template <int DB, int NB>
+__global__ __launch_bounds__(EQD_BLOCK, 2) void k_attn_bwd_qds(EqdGraph G, const float* __restrict__ q, const float* __restrict__ k,
+                                                               const float* __restrict__ ds, int ds_stride,
+                                                               float* __restrict__ dq, float qk_slope) {
+    __shared__ __attribute__((aligned(16))) AttnQdsSmem<DB> sm;
+    const int item = NB == 1 ? att_half_item((int)blockIdx.x) : (int)blockIdx.x;
+    attn_bwd_qds_body<DB, NB>(sm, G, item, q, k, ds, ds_stride, dq, NB == 1 ? att_half_of((int)blockIdx.x) : 0, qk_slope);
+}
+// the 80-wide (zero-padded 69) first layer: 32-row blocks, one workgroup per item, no gather riding (its gather is launched
+// on its own, as with the recompute form of that layer)
+__global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd_kvds80(EqdGraph G, const float* __restrict__ q, const float* __restrict__ k,
+                                                               const float* __restrict__ v, const float* __restrict__ out,
+                                                               const float* __restrict__ lse, const float* __restrict__ d_out,
+                                                               float* __restrict__ dk, float* __restrict__ dv, float qk_slope,
+                                                               float* __restrict__ ds, int ds_stride,
+                                                               const int32_t* __restrict__ seg_start) {
+    __shared__ __attribute__((aligned(16))) AttnBwdSmem<5, true> sm;
+    attn_bwd_kv_body<5, true, true, 2, AttnBwdSmem<5, true>, false, true>(sm, G, (int)blockIdx.x, 80, q, k, v, out, lse, d_out, nullptr,
+                                                                          dk, dv, 0, qk_slope, ds, ds_stride, seg_start);
+}
+// the key / value pass with the dS hand-off (half blocks), optionally with a layer's node gather + pending reductions as
+// trailing workgroups (k_attn_bwd_gather's arrangement)
+template <bool BF_DZ>
+__global__ __launch_bounds__(EQD_BLOCK, 2) void k_attn_bwd_kvds(EqdGraph G, const float* __restrict__ q, const float* __restrict__ k,
+                                                                const float* __restrict__ v, const float* __restrict__ out,
+                                                                const float* __restrict__ lse, const float* __restrict__ d_out,
+                                                                float* __restrict__ dk, float* __restrict__ dv, float qk_slope,
+                                                                float* __restrict__ ds, int ds_stride,
+                                                                const int32_t* __restrict__ seg_start, int n_attn, int nred,
+                                                                EqdGatherArgs GA, EqdRedArg RA) {
+    static_assert(EQD_BLOCK == 256, "the gather body is written for 256-thread workgroups");
+    if ((int)blockIdx.x >= n_attn) {
+        const int b = (int)blockIdx.x - n_attn;
+        if (b < GA.ngather) {
+            node_gather_body<BF_DZ>(GA, b);
+        } else if (b < GA.ngather + nred) {
+            __shared__ __attribute__((aligned(16))) float red[16][68];
+            __shared__ float red2[4][64];
+            reduce_block<16>(RA, b - GA.ngather, red, red2);
+        }
+        return;
+    }
+    __shared__ __attribute__((aligned(16))) AttnBwdSmem<4, true> sm;
+    const int b = (int)blockIdx.x;
+    attn_bwd_kv_body<4, true, true, 1, AttnBwdSmem<4, true>, false, true>(sm, G, att_half_item(b), 64, q, k, v, out, lse, d_out,
+                                                                          nullptr, dk, dv, att_half_of(b), qk_slope, ds, ds_stride,
+                                                                          seg_start);
+}
+// seg_start[node] = first node of the node's protein (EqdGraph.seg_off: ligand segments, then receptor segments)
+__global__ void k_seg_start(const int32_t* __restrict__ seg_off, int nseg, int n, int32_t* __restrict__ out) {
+    for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < n; i += (int)(gridDim.x * blockDim.x)) {
+        int lo = 0, hi = nseg;      // last segment with seg_off[s] <= i
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (seg_off[mid] <= i) lo = mid; else hi = mid;
+        }
+        out[i] = seg_off[lo];
     }
 }
 
@@ -678,9 +859,107 @@ int eqd_attention_bwd_gather_fused(const EqdGraph* g, int d, const float* q, con
     }
     return aligned16(q) && aligned16(k) && aligned16(v) && aligned16(d_out) && aligned16(out);
 }
+// ---- the dS hand-off form of the backward (fp32, d = 64, half-block work list) ------------------------------------------
+// Workspace: dS [n_nodes][stride] floats (stride = the longest protein rounded up to whole 32-key tiles: element (query, key)
+// at query * stride + key's index inside its protein) followed by seg_start [n_nodes] int32.
+int eqd_attention_ds_stride(const EqdGraph* g) { return (g->max_seg + 31) / 32 * 32; }
+size_t eqd_attention_ds_bytes(const EqdGraph* g) {
+    return eqd_align_up((size_t)g->n_nodes * eqd_attention_ds_stride(g) * sizeof(float)) +
+           eqd_align_up((size_t)g->n_nodes * sizeof(int32_t));
+}
+// Taken when the batch gives every CU more than one attention item (64 x (300, 300): 1 280; 4 x (2000, 2000): 504): there
+// the backward is arithmetic-bound and 5 / 7 of the MFMA work wins; a DB5.5-sized batch (112 items) is one latency-bound
+// round of workgroups either way and keeps the single launch.  EQD_ATT_DS=0|1 forces either (tests, A/B runs).
+int eqd_attention_ds_wanted(const EqdGraph* g, int d, bool bf16) {
+    if (bf16 || (d != 64 && d != 80) || g->n_att_items <= 0 || g->n_att_items % 8 != 0 || g->max_seg <= 0) return 0;
+    const char* hb = eqd_tunable("EQD_ATT_BWD_SPLIT");
+    if (hb && hb[0] == '0' && hb[1] == 0) return 0;
+    const char* f = eqd_tunable("EQD_ATT_DS");
+    if (f && (f[0] == '0' || f[0] == '1') && f[1] == 0) return f[0] == '1';
+    return g->n_att_items > eqd_num_cus();
+}
+int eqd_launch_seg_start(const EqdGraph* g, int32_t* seg_start, hipStream_t st) {
+    int blocks = (g->n_nodes + 255) / 256;
+    blocks = blocks > 1024 ? 1024 : blocks;
+    hipLaunchKernelGGL(k_seg_start, dim3(blocks), dim3(256), 0, st, g->seg_off, 2 * g->n_pairs, g->n_nodes, seg_start);
+    return eqd_check_launch("k_seg_start");
+}
+// key / value pass (+ the gather `gc` and the pending reductions as trailing workgroups when gc != NULL), then the dq pass
+static int attention_bwd_ds(const EqdGraph* g, int d, const float* q, const float* k, const float* v, const float* out, const float* lse,
+                            const float* d_out, float* dq, float* dk, float* dv, float qk_slope, float* ds,
+                            const int32_t* seg_start, const EqdGatherCall* gc, EqdRedList* pending, hipStream_t st) {
+    if (d == 80) {
+        const int stride = eqd_attention_ds_stride(g);
+        hipLaunchKernelGGL(k_attn_bwd_kvds80, dim3(g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, q, k, v, out, lse, d_out, dk, dv,
+                           qk_slope, ds, stride, seg_start);
+        if (int rc = eqd_check_launch("k_attn_bwd_kvds")) return rc;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_qds<5, 2>), dim3(g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, q, k,
+                           (const float*)ds, stride, dq, qk_slope);
+        if (int rc = eqd_check_launch("k_attn_bwd_qds")) return rc;
+        return gc ? eqd_launch_node_gather(g, gc->dz, gc->dxrel, gc->d_xnew, gc->a, gc->dP, gc->dQ, gc->dx, st, pending,
+                                           gc->dz_bf16 != 0)
+                  : EQD_OK;
+    }
+    static thread_local EqdRedArg RA;
+    EqdGatherArgs GA;
+    memset(&GA, 0, sizeof(GA));
+    memset(&RA, 0, sizeof(RA));
+    int nred = 0;
+    if (gc) {
+        if (int e = eqd_gather_plan(g, gc, pending, &GA, &RA, &nred)) return e;
+    }
+    const int n_attn = 2 * g->n_att_items, stride = eqd_attention_ds_stride(g);
+    const dim3 grid(n_attn + GA.ngather + nred);
+    if (gc && gc->dz_bf16)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_kvds<true>), grid, dim3(EQD_BLOCK), 0, st, *g, q, k, v, out, lse, d_out, dk, dv,
+                           qk_slope, ds, stride, seg_start, n_attn, nred, GA, RA);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_kvds<false>), grid, dim3(EQD_BLOCK), 0, st, *g, q, k, v, out, lse, d_out, dk, dv,
+                           qk_slope, ds, stride, seg_start, n_attn, nred, GA, RA);
+    if (int rc = eqd_check_launch("k_attn_bwd_kvds")) return rc;
+    // dq pass on 32-row blocks (one workgroup per item: half the K-tile traffic per dS byte; C + 0.5 %, E + 0.6 %, R equal
+    // against half blocks, profiles/r04_k_*); EQD_ATT_QDS_NB=1 keeps half blocks (A/B runs)
+    const char* qn = eqd_tunable("EQD_ATT_QDS_NB");
+    if (!(qn && qn[0] == '1' && qn[1] == 0))
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_qds<4, 2>), dim3(g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, q, k,
+                           (const float*)ds, stride, dq, qk_slope);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_qds<4, 1>), dim3(n_attn), dim3(EQD_BLOCK), 0, st, *g, q, k, (const float*)ds,
+                           stride, dq, qk_slope);
+    if (int rc = eqd_check_launch("k_attn_bwd_qds")) return rc;
+    return gc ? eqd_gather_rest(pending, st) : EQD_OK;
+}
+extern "C" size_t eqd_cross_attention_bwd_ds_workspace_bytes(const EqdGraph* g) { return g ? eqd_attention_ds_bytes(g) : 0; }
+extern "C" int eqd_cross_attention_bwd_ds(const EqdGraph* g, int d, const float* q, const float* k, const float* v, const float* out,
+                                          const float* lse, const float* d_out, float* dq, float* dk, float* dv, void* ws,
+                                          size_t ws_bytes, void* stream) {
+    if (!g || !q || !k || !v || !out || !lse || !d_out || !dq || !dk || !dv || !ws) {
+        eqd_set_error("eqd_cross_attention_bwd_ds: NULL argument");
+        return EQD_ERR_NULL;
+    }
+    if ((d != 64 && d != 80) || g->n_att_items % 8 != 0 || g->max_seg <= 0 ||
+        !(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(d_out) && aligned16(out) && aligned16(ws))) {
+        eqd_set_error("eqd_cross_attention_bwd_ds: needs d = 64 or 80, 16-byte aligned operands and the 8-way interleaved work list");
+        return EQD_ERR_UNSUPPORTED;
+    }
+    if (ws_bytes < eqd_attention_ds_bytes(g)) {
+        eqd_set_error("eqd_cross_attention_bwd_ds: workspace too small (%zu needed)", eqd_attention_ds_bytes(g));
+        return EQD_ERR_WORKSPACE;
+    }
+    if (g->n_att_items <= 0) return EQD_OK;
+    float* ds = (float*)ws;
+    int32_t* seg = (int32_t*)((char*)ws + eqd_align_up((size_t)g->n_nodes * eqd_attention_ds_stride(g) * sizeof(float)));
+    if (int rc = eqd_launch_seg_start(g, seg, (hipStream_t)stream)) return rc;
+    return attention_bwd_ds(g, d, q, k, v, out, lse, d_out, dq, dk, dv, 1.f, ds, seg, nullptr, nullptr, (hipStream_t)stream);
+}
+
 int eqd_launch_attention_bwd_gather(const EqdGraph* g, int d, const float* q, const float* k, const float* v, const float* out,
                                     const float* lse, const float* d_out, float* dq, float* dk, float* dv, float* delta,
-                                    float qk_slope, bool bf16, const EqdGatherCall* gc, EqdRedList* pending, hipStream_t st) {
+                                    float qk_slope, bool bf16, const EqdGatherCall* gc, EqdRedList* pending, hipStream_t st,
+                                    float* ds, const int32_t* seg_start) {
+    if (ds && seg_start && eqd_attention_ds_wanted(g, d, bf16) && aligned16(q) && aligned16(k) && aligned16(v) &&
+        aligned16(d_out) && aligned16(out) && aligned16(ds))
+        return attention_bwd_ds(g, d, q, k, v, out, lse, d_out, dq, dk, dv, qk_slope, ds, seg_start, gc, pending, st);
     if (!eqd_attention_bwd_gather_fused(g, d, q, k, v, out, d_out, bf16)) {
         int rc = eqd_launch_attention_bwd_act(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, qk_slope, bf16, st);
         if (rc) return rc;

@@ -324,9 +324,15 @@ int eqd_gather_plan(const EqdGraph* g, const EqdGatherCall* c, EqdRedList* pendi
 int eqd_gather_rest(EqdRedList* pending, hipStream_t st);
 int eqd_attention_bwd_gather_fused(const EqdGraph* g, int d, const float* q, const float* k, const float* v, const float* out,
                                    const float* d_out, bool bf16);
+// dS hand-off form of the attention backward (eqd_attn_kernels.hip): workspace layout and when it is taken
+int eqd_attention_ds_stride(const EqdGraph* g);
+size_t eqd_attention_ds_bytes(const EqdGraph* g);
+int eqd_attention_ds_wanted(const EqdGraph* g, int d, bool bf16);
+int eqd_launch_seg_start(const EqdGraph* g, int32_t* seg_start, hipStream_t st);
 int eqd_launch_attention_bwd_gather(const EqdGraph* g, int d, const float* q, const float* k, const float* v, const float* out,
                                     const float* lse, const float* d_out, float* dq, float* dk, float* dv, float* delta,
-                                    float qk_slope, bool bf16, const EqdGatherCall* gc, EqdRedList* pending, hipStream_t st);
+                                    float qk_slope, bool bf16, const EqdGatherCall* gc, EqdRedList* pending, hipStream_t st,
+                                    float* ds = nullptr, const int32_t* seg_start = nullptr);
 int eqd_launch_node_gather(const EqdGraph* g, const float* dz, const float* dxrel, const float* d_xnew, float a,
                            float* dP, float* dQ, float* dx, hipStream_t st, EqdRedList* pending = nullptr,
                            bool dz_bf16 = false);

@@ -159,6 +159,7 @@ struct Scratch {
     float* ln_part; size_t ln_part_stride;     // per layer (reductions are deferred to the end of the pass)
     float* vecp_all; size_t vecp_stride;
     float* emb_part;
+    float* att_ds; int32_t* att_seg_start;      // dS hand-off workspace of the attention backward (large batches), else NULL
 };
 
 void carve_scratch(const Dims& D, const EqdModelDesc* m, const EqdGraph* g, EqdArena& A, Scratch& W) {
@@ -194,6 +195,12 @@ void carve_scratch(const Dims& D, const EqdModelDesc* m, const EqdGraph* g, EqdA
     W.vecp_stride = eqd_align_up(eqd_edge_bwd_vecp_floats(g) * sizeof(float)) / sizeof(float);
     W.vecp_all = A.take<float>(W.vecp_stride * D.L);
     W.emb_part = A.take<float>(eqd_embed_bwd_partial_floats(g, m->d_emb));
+    W.att_ds = nullptr;
+    W.att_seg_start = nullptr;
+    if (m->cross_msgs && D.dh == 64 && eqd_attention_ds_wanted(g, 64, m->storage_bf16 != 0)) {
+        W.att_ds = A.take<float>((size_t)D.N * eqd_attention_ds_stride(g));
+        W.att_seg_start = A.take<int32_t>((size_t)D.N);
+    }
 }
 
 // dropout factors of node_mlp.1 of layer l inside EqdDropout.node (layer 0 is d0 wide, the others dh)
@@ -801,6 +808,7 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
         if (d == D.dh) { j.R = dHof(l + 1); j.ldr = D.dh; j.beta = 1.f - m->skip_weight_h; }
         return j;
     };
+    if (W.att_ds) RC(eqd_launch_seg_start(g, W.att_seg_start, st));      // (the dS hand-off form of the attention backward)
     // ---- layers, last to first ----------------------------------------------------------------------------
     for (int l = D.L - 1; l >= 0; --l) {
         const float* const* p = params + (size_t)EQD_PARAMS_PER_LAYER * l;
@@ -899,7 +907,8 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
                                          m->cross_msgs ? &gc : nullptr));
             if (m->cross_msgs)
                 RC(eqd_launch_attention_bwd_gather(g, da, Ls.qa, Ls.ka, Ls.va, Ls.aggr_cross, Ls.lse, W.d_aggr_cross, dq, dk,
-                                                   dv, W.delta, m->lrelu_slope, m->storage_bf16 != 0, &gc, defer, st));
+                                                   dv, W.delta, m->lrelu_slope, m->storage_bf16 != 0, &gc, defer, st, W.att_ds,
+                                                   W.att_seg_start));
         }
         {
             EqdAtbJob ajobs[16];

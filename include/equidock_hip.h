@@ -329,6 +329,15 @@ int eqd_cross_attention_fwd(const EqdGraph* g, int d, const float* q, const floa
 int eqd_cross_attention_bwd(const EqdGraph* g, int d, const float* q, const float* k, const float* v,
                             const float* out, const float* lse, const float* d_out,
                             float* dq, float* dk, float* dv, float* delta /* [n_nodes] scratch */, void* stream);
+/* The same backward in the form eqd_model_backward takes for large batches (more attention work items than CUs; fp32,
+ * d = 64): the key / value pass also writes its dS = P o (dP - delta) tiles into `ws` ([n_nodes][stride] floats, stride =
+ * the longest protein rounded up to 32) and the dq pass is ONE contraction over them instead of a recompute of S and dP -
+ * 5 GEMM units executed per (query tile, key tile) instead of 7, for 4 as written.  Same results up to fp32 summation
+ * order.  Needs 16-byte aligned operands and an att_items count that is a multiple of 8 (the packers' interleaved list). */
+size_t eqd_cross_attention_bwd_ds_workspace_bytes(const EqdGraph* g);
+int eqd_cross_attention_bwd_ds(const EqdGraph* g, int d, const float* q, const float* k, const float* v,
+                               const float* out, const float* lse, const float* d_out,
+                               float* dq, float* dk, float* dv, void* ws, size_t ws_bytes, void* stream);
 
 /* bf16 mode of the two calls above: every contraction (Q K^T, P V; dS K, dS^T Q, P^T dO, dO V^T) on
  * v_mfma_f32_16x16x16_bf16 - inputs rounded to bf16 (round to nearest even) when the MFMA operands are formed, fp32

@@ -12,7 +12,7 @@ tags = sys.argv[1].split(',')
 tag = tags[0]
 src = sys.argv[2] if len(sys.argv) > 2 else 'gpurun_out'
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FAM = ('k_edge_attn_fwd', 'k_edge_fwd', 'k_edge_bwd', 'k_attn_fwd', 'k_attn_bwd_gather', 'k_attn_bwd', 'k_rowres', 'k_rowwave', 'k_rowchain', 'k_linear', 'k_atb_reduce', 'k_atb',
+FAM = ('k_edge_attn_fwd', 'k_edge_fwd', 'k_edge_bwd', 'k_attn_fwd', 'k_attn_bwd_kvds', 'k_attn_bwd_qds', 'k_attn_bwd_gather', 'k_attn_bwd', 'k_rowres', 'k_rowwave', 'k_rowchain', 'k_linear', 'k_atb_reduce', 'k_atb',
        'k_node_gather')
 
 

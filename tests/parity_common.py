@@ -801,6 +801,61 @@ def check_attention(dev, d, sizes=((70, 45), (33, 101))):
     sync(dev)
     for n, a, b in (('dq', dq, ql.grad), ('dk', dk, kl.grad), ('dv', dv, vl.grad)):
         grad_close(a, b, what=f'attention {n} d={d}', l2=1e-4, mx=1e-4)
+    if d in (64, 80) and pk.n_att_items % 8 == 0:
+        # the dS hand-off form (what eqd_model_backward runs for large batches): the key / value pass writes its dS tiles, the
+        # dq pass contracts them with K - against torch like the recompute form, and against that form at fp32 summation level
+        wsb = lib().eqd_cross_attention_bwd_ds_workspace_bytes(C.byref(gs))
+        ws = torch.full((wsb // 4 + 16,), float('nan'), device=dev)      # (stale workspace contents must not leak into dq)
+        dq2, dk2, dv2 = (torch.zeros(N, d, device=dev) for _ in range(3))
+        L.check(lib().eqd_cross_attention_bwd_ds(C.byref(gs), d, P(qd), P(kd), P(vd), P(out), P(lse), P(dod), P(dq2), P(dk2),
+                                                 P(dv2), P(ws), C.c_size_t(wsb), st(dev)))
+        sync(dev)
+        for n, a, b, c in (('dq', dq2, ql.grad, dq), ('dk', dk2, kl.grad, dk), ('dv', dv2, vl.grad, dv)):
+            grad_close(a, b, what=f'attention (dS hand-off) {n} d={d}', l2=1e-4, mx=1e-4)
+            grad_close(a, c, what=f'attention {n}: dS hand-off vs recompute form', l2=2e-6, mx=1e-5)
+        assert torch.equal(dk2, dk) and torch.equal(dv2, dv), 'the key / value pass must not depend on whether it writes dS'
+
+
+def check_attention_ds_in_model(dev, bf16=False):
+    """The whole model with the dS hand-off form of the attention backward forced on (EQD_ATT_DS=1: what large batches run)
+    against the recompute form (EQD_ATT_DS=0): same outputs bit for bit (the forward is untouched), gradients equal up to fp32
+    summation order; and the switch really selects the launches."""
+    import os
+    args = port.default_args(iegmn_n_lays=3, skip_weight_h=0.75)
+    sd = port.init_state_dict(args, seed=4)
+    pairs = synthetic.make_pairs([(60, 75), (90, 48), (7, 130), (33, 16)], 21)
+    res, names = {}, {}
+    for mode in ('1', '0'):
+        os.environ['EQD_ATT_DS'] = mode
+        L.reload_tunables()
+        try:
+            net = build_model(args, sd, dev)
+            g = G.batch_pairs(pairs).to(dev)
+            lib_ = lib()
+            L.profiling = True
+            L.check(lib_.eqd_profile_begin(st(dev), 1024))
+            try:
+                outs = net.forward_batched(g)
+                (outs[0].square().sum() + outs[1].square().sum() + outs[2].square().sum()).backward()
+                sync(dev)
+            finally:
+                n = lib_.eqd_profile_end()
+                L.profiling = False
+            names[mode] = [lib_.eqd_profile_name(i).decode() for i in range(n)]
+            res[mode] = ([t.detach().cpu().clone() for t in outs], {k: p.grad.detach().cpu().clone() for k, p in net.named_parameters()})
+        finally:
+            del os.environ['EQD_ATT_DS']
+            L.reload_tunables()
+    for a, b in zip(res['1'][0], res['0'][0]):
+        assert torch.equal(a, b)
+    worst = 0.0
+    for k in res['1'][1]:
+        e2, em = grad_err(res['1'][1][k], res['0'][1][k])
+        assert e2 <= 2e-5 and em <= 5e-5, f'dS hand-off vs recompute, grad {k}: rel-L2 {e2:.2e}, max-abs/max {em:.2e}'
+        worst = max(worst, e2)
+    assert names['1'].count('k_attn_bwd_kvds') == 3 and names['1'].count('k_attn_bwd_qds') == 3, sorted(set(names['1']))
+    assert names['0'].count('k_attn_bwd_kvds') == 0 and names['0'].count('k_attn_bwd_gather') == 2, sorted(set(names['0']))
+    print(f'dS hand-off vs recompute form of the attention backward on {dev}: worst parameter-gradient rel-L2 {worst:.2e}')
 
 
 def check_kabsch(dev):

@@ -329,6 +329,12 @@ def test_model_vs_oracle_config_c_bf16(dev):
     pc.check_model_bf16_states(dev, [(300, 300)] * 64, layers=8, seed=3, pair_seed=34, what='config C bf16', report=REPORT)
 
 
+def test_attention_backward_ds_handoff_in_model(dev):
+    """the dS hand-off form of the attention backward (large batches) against the recompute form, whole model"""
+    from tests import parity_common as pc
+    pc.check_attention_ds_in_model(dev)
+
+
 def test_stack_backward_config_c_bf16(dev):
     """BASELINE.json configs[2] as stated (bf16, 64 x (300, 300), 8 layers, ROT scale 40 like the bench): the backward of the
     layer stack from a fixed gradient w.r.t. the last layer's state - every layer parameter's gradient against the oracle
