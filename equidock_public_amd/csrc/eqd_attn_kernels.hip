@@ -564,6 +564,39 @@ __global__ __launch_bounds__(EQD_BLOCK, 2) void k_attn_bwd_kvds(EqdGraph G, cons
                                                                           nullptr, dk, dv, att_half_of(b), qk_slope, ds, ds_stride,
                                                                           seg_start);
 }
+// bf16 mode (bf16 tiles in LDS), d = 64: the same two launches
+template <bool BF_DZ>
+__global__ __launch_bounds__(EQD_BLOCK, 2) void k_attn_bwd_kvds_lb(EqdGraph G, const float* __restrict__ q, const float* __restrict__ k,
+                                                                   const float* __restrict__ v, const float* __restrict__ out,
+                                                                   const float* __restrict__ lse, const float* __restrict__ d_out,
+                                                                   float* __restrict__ dk, float* __restrict__ dv, float qk_slope,
+                                                                   float* __restrict__ ds, int ds_stride,
+                                                                   const int32_t* __restrict__ seg_start, int n_attn, int nred,
+                                                                   EqdGatherArgs GA, EqdRedArg RA) {
+    if ((int)blockIdx.x >= n_attn) {
+        const int b = (int)blockIdx.x - n_attn;
+        if (b < GA.ngather) {
+            node_gather_body<BF_DZ>(GA, b);
+        } else if (b < GA.ngather + nred) {
+            __shared__ __attribute__((aligned(16))) float red[16][68];
+            __shared__ float red2[4][64];
+            reduce_block<16>(RA, b - GA.ngather, red, red2);
+        }
+        return;
+    }
+    __shared__ AttnBwdSmemLb sm;
+    const int b = (int)blockIdx.x;
+    attn_bwd_kv_body_lb<1, true>(sm, G, att_half_item(b), q, k, v, out, lse, d_out, dk, dv, att_half_of(b), qk_slope, ds, ds_stride,
+                                 seg_start);
+}
+template <int NB>
+__global__ __launch_bounds__(EQD_BLOCK, 2) void k_attn_bwd_qds_lb(EqdGraph G, const float* __restrict__ q, const float* __restrict__ k,
+                                                                  const float* __restrict__ ds, int ds_stride,
+                                                                  float* __restrict__ dq, float qk_slope) {
+    __shared__ AttnQdsSmemLb sm;
+    const int item = NB == 1 ? att_half_item((int)blockIdx.x) : (int)blockIdx.x;
+    attn_bwd_qds_body_lb<NB>(sm, G, item, q, k, ds, ds_stride, dq, NB == 1 ? att_half_of((int)blockIdx.x) : 0, qk_slope);
+}
 // seg_start[node] = first node of the node's protein (EqdGraph.seg_off: ligand segments, then receptor segments)
 __global__ void k_seg_start(const int32_t* __restrict__ seg_off, int nseg, int n, int32_t* __restrict__ out) {
     for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < n; i += (int)(gridDim.x * blockDim.x)) {
@@ -862,6 +895,7 @@ int eqd_attention_bwd_gather_fused(const EqdGraph* g, int d, const float* q, con
 // ---- the dS hand-off form of the backward (fp32, d = 64, half-block work list) ------------------------------------------
 // Workspace: dS [n_nodes][stride] floats (stride = the longest protein rounded up to whole 32-key tiles: element (query, key)
 // at query * stride + key's index inside its protein) followed by seg_start [n_nodes] int32.
+static bool att_lds_bf16();
 int eqd_attention_ds_stride(const EqdGraph* g) { return (g->max_seg + 31) / 32 * 32; }
 size_t eqd_attention_ds_bytes(const EqdGraph* g) {
     return eqd_align_up((size_t)g->n_nodes * eqd_attention_ds_stride(g) * sizeof(float)) +
@@ -871,7 +905,11 @@ size_t eqd_attention_ds_bytes(const EqdGraph* g) {
 // the backward is arithmetic-bound and 5 / 7 of the MFMA work wins; a DB5.5-sized batch (112 items) is one latency-bound
 // round of workgroups either way and keeps the single launch.  EQD_ATT_DS=0|1 forces either (tests, A/B runs).
 int eqd_attention_ds_wanted(const EqdGraph* g, int d, bool bf16) {
-    if (bf16 || (d != 64 && d != 80) || g->n_att_items <= 0 || g->n_att_items % 8 != 0 || g->max_seg <= 0) return 0;
+    if ((d != 64 && d != 80) || g->n_att_items <= 0 || g->n_att_items % 8 != 0 || g->max_seg <= 0) return 0;
+    if (bf16) {      // bf16 mode: the LDS-bf16 kernels of the 64-wide layers (the 80-wide first layer keeps its recompute form)
+        const char* nb2 = eqd_tunable("EQD_ATT_LB_NB");
+        if (d != 64 || !att_lds_bf16() || (nb2 && nb2[0] == '2')) return 0;
+    }
     const char* hb = eqd_tunable("EQD_ATT_BWD_SPLIT");
     if (hb && hb[0] == '0' && hb[1] == 0) return 0;
     const char* f = eqd_tunable("EQD_ATT_DS");
@@ -887,7 +925,8 @@ int eqd_launch_seg_start(const EqdGraph* g, int32_t* seg_start, hipStream_t st) 
 // key / value pass (+ the gather `gc` and the pending reductions as trailing workgroups when gc != NULL), then the dq pass
 static int attention_bwd_ds(const EqdGraph* g, int d, const float* q, const float* k, const float* v, const float* out, const float* lse,
                             const float* d_out, float* dq, float* dk, float* dv, float qk_slope, float* ds,
-                            const int32_t* seg_start, const EqdGatherCall* gc, EqdRedList* pending, hipStream_t st) {
+                            const int32_t* seg_start, const EqdGatherCall* gc, EqdRedList* pending, hipStream_t st,
+                            bool bf16 = false) {
     if (d == 80) {
         const int stride = eqd_attention_ds_stride(g);
         hipLaunchKernelGGL(k_attn_bwd_kvds80, dim3(g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, q, k, v, out, lse, d_out, dk, dv,
@@ -910,6 +949,19 @@ static int attention_bwd_ds(const EqdGraph* g, int d, const float* q, const floa
     }
     const int n_attn = 2 * g->n_att_items, stride = eqd_attention_ds_stride(g);
     const dim3 grid(n_attn + GA.ngather + nred);
+    if (bf16) {
+        if (gc && gc->dz_bf16)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_kvds_lb<true>), grid, dim3(EQD_BLOCK), 0, st, *g, q, k, v, out, lse, d_out, dk,
+                               dv, qk_slope, ds, stride, seg_start, n_attn, nred, GA, RA);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_kvds_lb<false>), grid, dim3(EQD_BLOCK), 0, st, *g, q, k, v, out, lse, d_out, dk,
+                               dv, qk_slope, ds, stride, seg_start, n_attn, nred, GA, RA);
+        if (int rc = eqd_check_launch("k_attn_bwd_kvds")) return rc;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_qds_lb<2>), dim3(g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, q, k,
+                           (const float*)ds, stride, dq, qk_slope);
+        if (int rc = eqd_check_launch("k_attn_bwd_qds")) return rc;
+        return gc ? eqd_gather_rest(pending, st) : EQD_OK;
+    }
     if (gc && gc->dz_bf16)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_kvds<true>), grid, dim3(EQD_BLOCK), 0, st, *g, q, k, v, out, lse, d_out, dk, dv,
                            qk_slope, ds, stride, seg_start, n_attn, nred, GA, RA);
@@ -959,7 +1011,7 @@ int eqd_launch_attention_bwd_gather(const EqdGraph* g, int d, const float* q, co
                                     float* ds, const int32_t* seg_start) {
     if (ds && seg_start && eqd_attention_ds_wanted(g, d, bf16) && aligned16(q) && aligned16(k) && aligned16(v) &&
         aligned16(d_out) && aligned16(out) && aligned16(ds))
-        return attention_bwd_ds(g, d, q, k, v, out, lse, d_out, dq, dk, dv, qk_slope, ds, seg_start, gc, pending, st);
+        return attention_bwd_ds(g, d, q, k, v, out, lse, d_out, dq, dk, dv, qk_slope, ds, seg_start, gc, pending, st, bf16);
     if (!eqd_attention_bwd_gather_fused(g, d, q, k, v, out, d_out, bf16)) {
         int rc = eqd_launch_attention_bwd_act(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, qk_slope, bf16, st);
         if (rc) return rc;

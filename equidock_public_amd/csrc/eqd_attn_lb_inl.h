@@ -427,13 +427,15 @@ __device__ __forceinline__ void attn_bwd_q_body_lb(AttnBwdSmemLb& sm, const EqdG
         }
 }
 
-template <int NB>
+// WDS: the dS hand-off (eqd_attn_kernels.hip: attn_bwd_kv_body) - the pass also writes its dS tiles (fp32) for the dq pass
+template <int NB, bool WDS = false>
 __device__ __forceinline__ void attn_bwd_kv_body_lb(AttnBwdSmemLb& sm, const EqdGraph& G, int item,
                                                     const float* __restrict__ q, const float* __restrict__ k,
                                                     const float* __restrict__ v, const float* __restrict__ out,
                                                     const float* __restrict__ lse, const float* __restrict__ d_out,
                                                     float* __restrict__ dk, float* __restrict__ dv, int half,
-                                                    float qk_slope) {
+                                                    float qk_slope, float* __restrict__ ds = nullptr, int ds_stride = 0,
+                                                    const int32_t* __restrict__ seg_start = nullptr) {
     typedef AttnCfg<4> C;
     constexpr int DS = C::DS, d = 64;
     float* Kb = sm.blk(0);
@@ -453,6 +455,12 @@ __device__ __forceinline__ void attn_bwd_kv_body_lb(AttnBwdSmemLb& sm, const Eqd
     for (int nb = 0; nb < NB; ++nb) {
         rowk[nb] = b0 + 16 * nb + l15;
         kvd[nb] = rowk[nb] < b1;
+    }
+    int kcol[NB];      // WDS: this lane's key columns inside a dS row
+    if constexpr (WDS) {
+        const int y0 = seg_start[b0];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) kcol[nb] = rowk[nb] - y0;
     }
     LbRegs rq, rg, ro;
     int qt = o0 + 32 * wave;
@@ -547,6 +555,20 @@ __device__ __forceinline__ void attn_bwd_kv_body_lb(AttnBwdSmemLb& sm, const Eqd
                     dP[mb][nb][r] = p * (dP[mb][nb][r] - dc[mb][r]);
                 }
             }
+        if constexpr (WDS) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qr = qt + 16 * mb + 4 * g + r;
+                    if (qr < o1) {
+                        float* __restrict__ row = ds + (size_t)qr * ds_stride;
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            if (kvd[nb]) row[kcol[nb]] = dP[mb][nb][r];
+                    }
+                }
+        }
         lb_mma_r<NB>(dV, W.b_tr, g, l15, S);
         lb_mma_r<NB>(dK, W.a_tr, g, l15, dP);
     }
@@ -576,6 +598,96 @@ __device__ __forceinline__ void attn_bwd_kv_body_lb(AttnBwdSmemLb& sm, const Eqd
                 }
             }
     }
+}
+
+// dq pass of the dS hand-off in bf16 mode: dq[query] = sum over the partner's keys of dS[query][key] K[key] with K tiles
+// parked transposed in LDS as bf16 and dS rounded to bf16 when the MFMA operand is formed (what the recompute form does
+// with the dS it computes itself); structure of attn_bwd_qds_body (eqd_attn_kernels.hip)
+struct alignas(16) AttnQdsSmemLb {
+    struct alignas(16) Wave {
+        unsigned short a_tr[64 * LB_TS];
+        float pad[(AttnCfg<4>::RED * 4 > 64 * LB_TS * 2 ? (AttnCfg<4>::RED * 4 - 64 * LB_TS * 2) / 4 : 0)];      // the merge buffer must fit
+    } w[EQD_WAVES];
+    __device__ __forceinline__ float* red(int wv) { return (float*)&w[wv]; }
+};
+template <int NB>
+__device__ __forceinline__ void attn_bwd_qds_body_lb(AttnQdsSmemLb& sm, const EqdGraph& G, int item, const float* __restrict__ q,
+                                                     const float* __restrict__ k, const float* __restrict__ ds, int ds_stride,
+                                                     float* __restrict__ dq, int half, float qk_slope) {
+    constexpr int d = 64;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    int b0 = G.att_items[item * 4 + 0], b1 = G.att_items[item * 4 + 1];
+    const int o0 = G.att_items[item * 4 + 2], o1 = G.att_items[item * 4 + 3];
+    if (NB == 1) {
+        b0 += 16 * half;
+        b1 = b1 < b0 + 16 ? b1 : b0 + 16;
+    }
+    if (b0 >= b1) return;
+    int rowq[NB];
+    bool qv[NB];
+    const float* __restrict__ dsr[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        rowq[nb] = b0 + 16 * nb + l15;
+        qv[nb] = rowq[nb] < b1;
+        dsr[nb] = ds + (size_t)(qv[nb] ? rowq[nb] : b1 - 1) * ds_stride;      // + (key - o0)
+    }
+    LbRegs rk;
+    int kt = o0 + 32 * wave;
+    lb_load(rk, k, kt, o1, lane);
+    f32x4 sv[2][NB];
+    auto ds_load = [&](int kt_) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int col = kt_ < o1 ? kt_ - o0 + 16 * mb + 4 * g : 0;
+                sv[mb][nb] = *(const f32x4*)(dsr[nb] + col);
+            }
+    };
+    ds_load(kt);
+    f32x4 dQ[4][NB];
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) dQ[db][nb] = f4zero();
+    unsigned short* __restrict__ Kt = sm.w[wave].a_tr;
+    for (; kt < o1; kt += 32 * EQD_WAVES) {
+        wave_lds_fence();
+        lb_store_tr(rk, Kt, lane);
+        wave_lds_fence();
+        f32x4 S[2][NB];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) S[mb][nb][r] = kt + 16 * mb + 4 * g + r < o1 ? sv[mb][nb][r] : 0.f;
+        lb_load(rk, k, kt + 32 * EQD_WAVES, o1, lane);
+        ds_load(kt + 32 * EQD_WAVES);
+        lb_mma_r<NB>(dQ, Kt, g, l15, S);
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sm.red(wave)[((db * 2 + nb) * 4 + r) * 64 + lane] = dQ[db][nb][r];
+    __syncthreads();
+    for (int db = wave; db < 4; db += EQD_WAVES)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            if (!qv[nb]) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = ((db * 2 + nb) * 4 + r) * 64 + lane;
+                const int f = 16 * db + 4 * g + r;
+                dq[(size_t)rowq[nb] * d + f] = (sm.red(0)[o] + sm.red(1)[o] + sm.red(2)[o] + sm.red(3)[o]) *
+                                               lrelu_grad(q[(size_t)rowq[nb] * d + f], qk_slope);
+            }
+        }
 }
 
 template <int NB>

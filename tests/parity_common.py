@@ -823,6 +823,8 @@ def check_attention_ds_in_model(dev, bf16=False):
     import os
     args = port.default_args(iegmn_n_lays=3, skip_weight_h=0.75)
     sd = port.init_state_dict(args, seed=4)
+    if bf16:      # bf16 mode: the 64-wide layers' LDS-bf16 kernels take the hand-off, the 80-wide first layer keeps its recompute form
+        args = dict(args, hip_storage_dtype='bf16')
     pairs = synthetic.make_pairs([(60, 75), (90, 48), (7, 130), (33, 16)], 21)
     res, names = {}, {}
     for mode in ('1', '0'):
@@ -851,11 +853,16 @@ def check_attention_ds_in_model(dev, bf16=False):
     worst = 0.0
     for k in res['1'][1]:
         e2, em = grad_err(res['1'][1][k], res['0'][1][k])
-        assert e2 <= 2e-5 and em <= 5e-5, f'dS hand-off vs recompute, grad {k}: rel-L2 {e2:.2e}, max-abs/max {em:.2e}'
+        # fp32: summation order only.  bf16 mode: the two forms compute S in different operand roles, so a dS value can round
+        # to the other bf16 neighbour when the dq contraction's operand is formed (2^-9 relative per element)
+        b2, bm = (1e-2, 2e-2) if bf16 else (2e-5, 5e-5)
+        assert e2 <= b2 and em <= bm, f'dS hand-off vs recompute, grad {k}: rel-L2 {e2:.2e}, max-abs/max {em:.2e}'
         worst = max(worst, e2)
-    assert names['1'].count('k_attn_bwd_kvds') == 3 and names['1'].count('k_attn_bwd_qds') == 3, sorted(set(names['1']))
+    nds = 2 if bf16 else 3
+    assert names['1'].count('k_attn_bwd_kvds') == nds and names['1'].count('k_attn_bwd_qds') == nds, sorted(set(names['1']))
     assert names['0'].count('k_attn_bwd_kvds') == 0 and names['0'].count('k_attn_bwd_gather') == 2, sorted(set(names['0']))
-    print(f'dS hand-off vs recompute form of the attention backward on {dev}: worst parameter-gradient rel-L2 {worst:.2e}')
+    print(f"dS hand-off vs recompute form of the attention backward on {dev}{' (bf16)' if bf16 else ''}: worst parameter-gradient "
+          f'rel-L2 {worst:.2e}')
 
 
 def check_kabsch(dev):

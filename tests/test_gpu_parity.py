@@ -333,6 +333,7 @@ def test_attention_backward_ds_handoff_in_model(dev):
     """the dS hand-off form of the attention backward (large batches) against the recompute form, whole model"""
     from tests import parity_common as pc
     pc.check_attention_ds_in_model(dev)
+    pc.check_attention_ds_in_model(dev, bf16=True)
 
 
 def test_stack_backward_config_c_bf16(dev):

@@ -205,6 +205,7 @@ def test_cross_attention_bf16_kernel_forms(env, monkeypatch):
 
 def test_attention_backward_ds_handoff_in_model():
     pc.check_attention_ds_in_model(DEV)
+    pc.check_attention_ds_in_model(DEV, bf16=True)
 
 
 def test_linear_atb_bf16():
