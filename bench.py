@@ -23,7 +23,10 @@ Rank 0 prints ONE JSON line with the contract fields plus
                    profiler (eqd_profile_*): executed and as-written FLOP rates, algorithmic-bytes HBM rate, PMC MfmaUtil;
   "whole_step":    as-written FLOPs of the step / ms_per_step against the MFMA peak of the dtype;
   "cpu_baseline":  the oracle (oracle/iegmn_port.py, the reference's op sequence) on the host's physical cores, plus
-                   its one-thread and one-pair-per-step variants (N=1 only; the only place `oracle` is imported).
+                   its one-thread and one-pair-per-step variants (N=1 only; the only place `oracle` is imported);
+  "secondary":     (default workload B only) the other BASELINE.json configs timed the same way with 3 + 10 steps:
+                   C in bf16 (configs[2]), E (configs[4]) and the ragged workload R on one GPU; D (configs[3]: 64 x (300,300)
+                   per GPU in bf16, RCCL all-reduce inside the step graph) when launched by torch.distributed.run.
 """
 import argparse
 import ctypes as C

@@ -434,7 +434,7 @@ struct AttnQdsSmem {
     __device__ __forceinline__ float* red(int w) { return str_[w]; }      // merge buffer = each wave's own tile, as in the alias layout
     static_assert(C::RED <= C::TILE, "merge buffer must fit a streamed tile");
 };
-template <int DB, int NB>
+template <int DB, int NB, bool BF = false>
 __device__ __forceinline__ void attn_bwd_qds_body(AttnQdsSmem<DB>& sm, const EqdGraph& G, int item, const float* __restrict__ q,
                                                   const float* __restrict__ k, const float* __restrict__ ds, int ds_stride,
                                                   float* __restrict__ dq, int half, float qk_slope) {
@@ -491,7 +491,7 @@ __device__ __forceinline__ void attn_bwd_qds_body(AttnQdsSmem<DB>& sm, const Eqd
                 for (int r = 0; r < 4; ++r) S[mb][nb][r] = kt + 16 * mb + 4 * g + r < o1 ? sv[mb][nb][r] : 0.f;
         tile_load<DB, true>(rk, k, d, kt + 32 * EQD_WAVES, o1, lane);
         ds_load(kt + 32 * EQD_WAVES);
-        mma_r2<false, DB, NB>(dQ, Kw, g, DS, l15, S);
+        mma_r2<BF, DB, NB>(dQ, Kw, g, DS, l15, S);      // (BF: K tile and dS rounded to bf16 as the operands are formed)
     }
     wave_lds_fence();
 #pragma unroll
@@ -516,16 +516,17 @@ __device__ __forceinline__ void attn_bwd_qds_body(AttnQdsSmem<DB>& sm, const Eqd
 }
 // (half blocks like the kernels around it: workgroup b -> item 8 (b / 16) + b % 8, half (b / 8) % 2, so a direction's blocks
 // and the dS rows they read stay on the XCD whose L2 the key / value pass left them in)
-template <int DB, int NB>
+template <int DB, int NB, bool BF = false>
 __global__ __launch_bounds__(EQD_BLOCK, 2) void k_attn_bwd_qds(EqdGraph G, const float* __restrict__ q, const float* __restrict__ k,
                                                                const float* __restrict__ ds, int ds_stride,
                                                                float* __restrict__ dq, float qk_slope) {
     __shared__ __attribute__((aligned(16))) AttnQdsSmem<DB> sm;
     const int item = NB == 1 ? att_half_item((int)blockIdx.x) : (int)blockIdx.x;
-    attn_bwd_qds_body<DB, NB>(sm, G, item, q, k, ds, ds_stride, dq, NB == 1 ? att_half_of((int)blockIdx.x) : 0, qk_slope);
+    attn_bwd_qds_body<DB, NB, BF>(sm, G, item, q, k, ds, ds_stride, dq, NB == 1 ? att_half_of((int)blockIdx.x) : 0, qk_slope);
 }
 // the 80-wide (zero-padded 69) first layer: 32-row blocks, one workgroup per item, no gather riding (its gather is launched
 // on its own, as with the recompute form of that layer)
+template <bool BF>
 __global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd_kvds80(EqdGraph G, const float* __restrict__ q, const float* __restrict__ k,
                                                                const float* __restrict__ v, const float* __restrict__ out,
                                                                const float* __restrict__ lse, const float* __restrict__ d_out,
@@ -533,7 +534,7 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd_kvds80(EqdGraph G, const
                                                                float* __restrict__ ds, int ds_stride,
                                                                const int32_t* __restrict__ seg_start) {
     __shared__ __attribute__((aligned(16))) AttnBwdSmem<5, true> sm;
-    attn_bwd_kv_body<5, true, true, 2, AttnBwdSmem<5, true>, false, true>(sm, G, (int)blockIdx.x, 80, q, k, v, out, lse, d_out, nullptr,
+    attn_bwd_kv_body<5, true, true, 2, AttnBwdSmem<5, true>, BF, true>(sm, G, (int)blockIdx.x, 80, q, k, v, out, lse, d_out, nullptr,
                                                                           dk, dv, 0, qk_slope, ds, ds_stride, seg_start);
 }
 // the key / value pass with the dS hand-off (half blocks), optionally with a layer's node gather + pending reductions as
@@ -906,9 +907,9 @@ size_t eqd_attention_ds_bytes(const EqdGraph* g) {
 // round of workgroups either way and keeps the single launch.  EQD_ATT_DS=0|1 forces either (tests, A/B runs).
 int eqd_attention_ds_wanted(const EqdGraph* g, int d, bool bf16) {
     if ((d != 64 && d != 80) || g->n_att_items <= 0 || g->n_att_items % 8 != 0 || g->max_seg <= 0) return 0;
-    if (bf16) {      // bf16 mode: the LDS-bf16 kernels of the 64-wide layers (the 80-wide first layer keeps its recompute form)
+    if (bf16 && d == 64) {      // bf16 mode: the LDS-bf16 kernels of the 64-wide layers (the 80-wide first layer: fp32 tiles, bf16 operands)
         const char* nb2 = eqd_tunable("EQD_ATT_LB_NB");
-        if (d != 64 || !att_lds_bf16() || (nb2 && nb2[0] == '2')) return 0;
+        if (!att_lds_bf16() || (nb2 && nb2[0] == '2')) return 0;
     }
     const char* hb = eqd_tunable("EQD_ATT_BWD_SPLIT");
     if (hb && hb[0] == '0' && hb[1] == 0) return 0;
@@ -929,11 +930,19 @@ static int attention_bwd_ds(const EqdGraph* g, int d, const float* q, const floa
                             bool bf16 = false) {
     if (d == 80) {
         const int stride = eqd_attention_ds_stride(g);
-        hipLaunchKernelGGL(k_attn_bwd_kvds80, dim3(g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, q, k, v, out, lse, d_out, dk, dv,
-                           qk_slope, ds, stride, seg_start);
-        if (int rc = eqd_check_launch("k_attn_bwd_kvds")) return rc;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_qds<5, 2>), dim3(g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, q, k,
-                           (const float*)ds, stride, dq, qk_slope);
+        if (bf16) {      // bf16 mode: the first layer's fp32-tile kernels with bf16 MFMA operands
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_kvds80<true>), dim3(g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, q, k, v, out,
+                               lse, d_out, dk, dv, qk_slope, ds, stride, seg_start);
+            if (int rc = eqd_check_launch("k_attn_bwd_kvds")) return rc;
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_qds<5, 2, true>), dim3(g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, q, k,
+                               (const float*)ds, stride, dq, qk_slope);
+        } else {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_kvds80<false>), dim3(g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, q, k, v, out,
+                               lse, d_out, dk, dv, qk_slope, ds, stride, seg_start);
+            if (int rc = eqd_check_launch("k_attn_bwd_kvds")) return rc;
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_qds<5, 2>), dim3(g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, q, k,
+                               (const float*)ds, stride, dq, qk_slope);
+        }
         if (int rc = eqd_check_launch("k_attn_bwd_qds")) return rc;
         return gc ? eqd_launch_node_gather(g, gc->dz, gc->dxrel, gc->d_xnew, gc->a, gc->dP, gc->dQ, gc->dx, st, pending,
                                            gc->dz_bf16 != 0)

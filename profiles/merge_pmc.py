@@ -36,6 +36,8 @@ def git_head():
     """HEAD of the tree the counters were collected on (the gpurun snapshot is the working tree: commit before measuring);
     '+dirty' when kernel sources differ from HEAD at merge time."""
     import subprocess
+    if os.environ.get('EQD_PMC_HEAD'):      # (merging later than measuring: name the measured commit explicitly)
+        return os.environ['EQD_PMC_HEAD']
     try:
         h = subprocess.run(['git', 'rev-parse', '--short=12', 'HEAD'], cwd=root, capture_output=True, text=True).stdout.strip()
         d = subprocess.run(['git', 'status', '--porcelain', '--', 'equidock_public_amd', 'bench.py'], cwd=root,
