@@ -82,7 +82,8 @@ def kernel_work_model(sizes, L, n_nodes, n_edges, cross=True, d0=69, dh=64, d_em
     W = {k: dict(flops=0.0, flops_written=0.0, bytes=0.0) for k in
          ('k_linear', 'k_rowchain', 'k_rowwave', 'k_rowres', 'k_attn_fwd', 'k_attn_bwd', 'k_edge_fwd', 'k_edge_bwd', 'k_node_gather',
           'k_atb', 'k_atb_reduce', 'k_edge_attn_fwd', 'k_attn_bwd_gather', 'k_keypoint', 'k_keypoint_bwd_a', 'k_keypoint_bwd_b',
-          'k_head_u', 'k_head_u_bwd', 'k_attn_bwd_kvds', 'k_attn_bwd_qds')}
+          'k_head_u', 'k_head_u_bwd', 'k_attn_bwd_kvds', 'k_attn_bwd_qds', 'k_kabsch_fwd', 'k_kabsch_bwd', 'k_embed_fwd',
+          'k_embed_bwd', 'k_seg_mean', 'k_qmean_bwd', 'k_reduce_segments')}
     # k_edge_attn_fwd: the 64-wide layers' edge + attention forward in one launch (small batches); k_attn_bwd_gather: the
     # 64-wide layers' attention backward with the edge backward's node gather (+ the partial reductions) in the same launch
     for l in range(L):
@@ -165,6 +166,20 @@ def kernel_work_model(sizes, L, n_nodes, n_edges, cross=True, d0=69, dh=64, d_em
     W['k_head_u']['bytes'] += K * 2 * 64 * 64 * 4 + nb2 * K * 64 * 4 * 2
     W['k_head_u_bwd']['flops'] += nb2 * K * 2 * 4 * 64 * 64
     W['k_head_u_bwd']['bytes'] += K * 2 * 64 * 64 * 4 * 2 + nb2 * K * 64 * 4 * 3
+    # the small per-pair / per-node kernels around the head (bytes only: they are launch-latency-bound at every size)
+    nlig = float(sum(a for a, _ in sizes))
+    W['k_kabsch_fwd']['bytes'] += nb2 * K * 3 * 4 + nlig * 3 * 4 * 2 + len(sizes) * (9 + 3 + 9 + 21 * 2) * 4
+    W['k_kabsch_bwd']['bytes'] += nb2 * K * 3 * 4 * 2 + nlig * 3 * 4 * 2 + len(sizes) * (9 + 3 + 9 + 21 * 2) * 4
+    W['k_embed_fwd']['bytes'] += N * 4 * (1 + 5 + d0)
+    W['k_embed_bwd']['bytes'] += N * 4 * (1 + 2 * d_emb) + 21 * d_emb * 4
+    W['k_seg_mean']['bytes'] += N * 4 * 64 + nb2 * 64 * 4
+    W['k_qmean_bwd']['bytes'] += nb2 * K * 64 * 4 + N * 64 * 4
+    # deferred partial sums (LayerNorm / bias / coordinate-MLP vectors, embedding table): what the row chains and the edge
+    # backward wrote per workgroup that did not ride in a gather launch
+    W['k_reduce_segments']['bytes'] += L * (N / 16.0) * 256 * 4
+    # second stage of the weight-gradient GEMMs: ~10 units per layer, each split over ~1024 / 36 row parts (more from 16 k
+    # rows: csrc/eqd_node_kernels.hip, atb_units) whose 64 x 64 partial outputs it sums - a launch-shape figure, nominal
+    W['k_atb_reduce']['bytes'] += (10 * L + 1) * max(28.0, N / 1024.0) * 64 * 64 * 4
     return W
 
 
@@ -376,7 +391,7 @@ def profile_step(compute, dev, reps=4):
 
 
 def kernel_rooflines(prof, work, bf16, step_us, pmc, traffic=None):
-    """roofline_all: one entry per kernel family that takes >= 2 % of the step's kernel time (plus the two edge kernels
+    """roofline_all: one entry per kernel family that takes >= 0.5 % of the step's kernel time (plus the two edge kernels
     always); `traffic` = per-family {FETCH_SIZE_KB, WRITE_SIZE_KB} per launch of the newest committed PMC summary."""
     out = {}
     total = sum(v[1] for v in prof.values())
@@ -384,7 +399,7 @@ def kernel_rooflines(prof, work, bf16, step_us, pmc, traffic=None):
     for name, (calls, us) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
         share = us / total if total > 0 else 0.0
         w = work.get(name)
-        if w is None or (w['flops'] == 0 and w['bytes'] == 0) or (share < 0.02 and not name.startswith('k_edge')):
+        if w is None or (w['flops'] == 0 and w['bytes'] == 0) or (share < 0.005 and not name.startswith('k_edge')):
             continue
         t = us * 1e-6
         tf_x = w['flops'] / t / 1e12
