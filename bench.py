@@ -695,11 +695,42 @@ def run_workload(workload, dtype, steps, warmup, dev, rank, world, use_dist, bac
     R.svd_bad = int((status != 0).sum().item())
     R.workload, R.dtype, R.desc, R.ppg, R.L, R.shared, R.skh = workload, dtype, desc, ppg, L, shared, skh
     R.uniform, R.sizes, R.pairs, R.sd, R.args_model = uniform, sizes, pairs, sd, args_model
-    R.net, R.packed, R.reducer, R.compute = net, packed, reducer, compute
+    R.net, R.packed, R.reducer, R.compute, R.g = net, packed, reducer, compute, g
     R.dt, R.host_dt, R.loss, R.steps, R.warmup = dt, host_dt, float(loss.detach()), steps, warmup
     R.graph_mode, R.allreduce_in_graph, R.allreduce_us = graph_mode, allreduce_in_graph, allreduce_us
     R.launches = None
     return R
+
+
+def time_inference(net, g, ppg, dev, steps=30, warmup=5):
+    """Forward-only throughput (eval mode, torch.no_grad(): eqd_model_forward without a saved-state buffer), hipGraph replay."""
+    was_training = net.training
+    net.eval()
+    try:
+        with torch.no_grad():
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    net.forward_batched(g)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, capture_error_mode='thread_local'):
+                outs = net.forward_batched(g)
+            for _ in range(warmup):
+                gr.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                gr.replay()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        del outs
+    finally:
+        net.train(was_training)
+    return {"metric": "protein-pairs/sec, forward only (inference)", "value": round(ppg * steps / dt, 2), "unit": "pairs/s",
+            "ms_per_forward": round(dt / steps * 1e3, 4), "steps": steps, "warmup": warmup, "launch_mode": "hipGraph replay"}
 
 
 def secondary_line(R, world):
@@ -796,6 +827,14 @@ def main():
             except Exception as e:      # the primary line must not die on a secondary workload
                 secondary[key] = {"error": f"{type(e).__name__}: {e}"}
             torch.cuda.empty_cache()
+    # inference (src/inference_rigid.py:194: the forward alone, no state kept): the primary workload's batch under
+    # torch.no_grad(), replayed from its own hipGraph, timed like the step
+    inference = None
+    if a.workload == 'B' and a.dropout == 0 and not a.eager and not a.no_secondary and world == 1:
+        try:
+            inference = time_inference(R.net, R.g, ppg, dev)
+        except Exception as e:
+            inference = {"error": f"{type(e).__name__}: {e}"}
     out = None
     if rank == 0:
         total_pairs = ppg * world * a.steps
@@ -864,6 +903,8 @@ def main():
                 out["step_profile"] = {"error": f"{type(e).__name__}: {e}"}
         if secondary:
             out["secondary"] = secondary
+        if inference is not None:
+            out["inference"] = inference
         if world == 1 and not a.no_cpu_baseline:
             from equidock_public_amd import config
             out["cpu_baseline"] = cpu_baseline(config.published_args(iegmn_n_lays=L, shared_layers=shared,

@@ -54,7 +54,7 @@ class EqdLinJob(C.Structure):
                 ('rows', C.c_int32), ('bias', C.c_void_p), ('ln_g', C.c_void_p), ('ln_b', C.c_void_p),
                 ('pre_ln', C.c_void_p), ('ld_pre', C.c_int32), ('R', C.c_void_p), ('ldr', C.c_int32),
                 ('alpha', C.c_float), ('beta', C.c_float), ('slope', C.c_float), ('ln_eps', C.c_float),
-                ('Y', C.c_void_p), ('ldy', C.c_int32), ('bf16', C.c_int32), ('mul', C.c_void_p), ('ld_mul', C.c_int32)]
+                ('Y', C.c_void_p), ('ldy', C.c_int32), ('bf16', C.c_int32), ('mul', C.c_void_p), ('ld_mul', C.c_int32), ('pad_to', C.c_int32)]
 
 
 class EqdAtbJob(C.Structure):

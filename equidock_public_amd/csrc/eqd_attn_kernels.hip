@@ -526,13 +526,25 @@ __global__ __launch_bounds__(EQD_BLOCK, 2) void k_attn_bwd_qds(EqdGraph G, const
 }
 // the 80-wide (zero-padded 69) first layer: 32-row blocks, one workgroup per item, no gather riding (its gather is launched
 // on its own, as with the recompute form of that layer)
-template <bool BF>
+template <bool BF, bool BF_DZ>
 __global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd_kvds80(EqdGraph G, const float* __restrict__ q, const float* __restrict__ k,
                                                                const float* __restrict__ v, const float* __restrict__ out,
                                                                const float* __restrict__ lse, const float* __restrict__ d_out,
                                                                float* __restrict__ dk, float* __restrict__ dv, float qk_slope,
                                                                float* __restrict__ ds, int ds_stride,
-                                                               const int32_t* __restrict__ seg_start) {
+                                                               const int32_t* __restrict__ seg_start, int n_attn, int nred,
+                                                               EqdGatherArgs GA, EqdRedArg RA) {
+    if ((int)blockIdx.x >= n_attn) {      // the layer's node gather + pending reductions (k_attn_bwd_gather's arrangement)
+        const int b = (int)blockIdx.x - n_attn;
+        if (b < GA.ngather) {
+            node_gather_body<BF_DZ>(GA, b);
+        } else if (b < GA.ngather + nred) {
+            __shared__ __attribute__((aligned(16))) float red[16][68];
+            __shared__ float red2[4][64];
+            reduce_block<16>(RA, b - GA.ngather, red, red2);
+        }
+        return;
+    }
     __shared__ __attribute__((aligned(16))) AttnBwdSmem<5, true> sm;
     attn_bwd_kv_body<5, true, true, 2, AttnBwdSmem<5, true>, BF, true>(sm, G, (int)blockIdx.x, 80, q, k, v, out, lse, d_out, nullptr,
                                                                           dk, dv, 0, qk_slope, ds, ds_stride, seg_start);
@@ -700,6 +712,38 @@ __global__ __launch_bounds__(EQD_BLOCK, 2) void k_attn_bwd_gather(EqdGraph G, in
             attn_bwd_kv_body<4, true, true, 1, AttnBwdSmem<4, true>, false>(sm, G, item, d, q, k, v, out, lse, d_out, nullptr,
                                                                             dk, dv, half, qk_slope);
     }
+}
+
+// the 80-wide (zero-padded 69) first layer's merged backward (k_attn_bwd<5, 2>: one workgroup per CU, 224 of them for a
+// DB5.5-sized batch) with that layer's node gather and pending reductions as trailing workgroups: they run on the CUs the
+// attention leaves free instead of as a launch of their own behind it
+template <bool BF, bool BF_DZ>
+__global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd80_gather(EqdGraph G, const float* __restrict__ q, const float* __restrict__ k,
+                                                                 const float* __restrict__ v, const float* __restrict__ out,
+                                                                 const float* __restrict__ lse, const float* __restrict__ d_out,
+                                                                 float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv,
+                                                                 float* __restrict__ delta, float qk_slope, int n_attn, int nred,
+                                                                 EqdGatherArgs GA, EqdRedArg RA) {
+    if ((int)blockIdx.x >= n_attn) {
+        const int b = (int)blockIdx.x - n_attn;
+        if (b < GA.ngather) {
+            node_gather_body<BF_DZ>(GA, b);
+        } else if (b < GA.ngather + nred) {
+            __shared__ __attribute__((aligned(16))) float red[16][68];
+            __shared__ float red2[4][64];
+            reduce_block<16>(RA, b - GA.ngather, red, red2);
+        }
+        return;
+    }
+    __shared__ __attribute__((aligned(16))) AttnBwdSmem<5, true> sm;
+    const int per = G.n_att_items;
+    const bool kv = (int)blockIdx.x >= per;
+    const int item = kv ? (int)blockIdx.x - per : (int)blockIdx.x;
+    if (!kv)
+        attn_bwd_q_body<5, true, 2, AttnBwdSmem<5, true>, BF>(sm, G, item, 80, q, k, v, out, lse, d_out, dq, delta, 0, qk_slope);
+    else
+        attn_bwd_kv_body<5, true, true, 2, AttnBwdSmem<5, true>, BF>(sm, G, item, 80, q, k, v, out, lse, d_out, nullptr, dk, dv, 0,
+                                                                     qk_slope);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -886,6 +930,8 @@ int eqd_attention_bwd_gather_fused(const EqdGraph* g, int d, const float* q, con
     if (f && f[0] == '0' && f[1] == 0) return 0;
     const char* hb = eqd_tunable("EQD_ATT_BWD_SPLIT");
     if (hb && hb[0] == '0' && hb[1] == 0) return 0;
+    if (d == 80 && g->n_att_items > 0)      // the first layer's merged backward (one workgroup per item and pass)
+        return aligned16(q) && aligned16(k) && aligned16(v) && aligned16(d_out) && aligned16(out);
     if (d != 64 || g->n_att_items <= 0 || g->n_att_items % 8 != 0) return 0;
     if (bf16) {
         const char* nb2 = eqd_tunable("EQD_ATT_LB_NB");
@@ -929,24 +975,32 @@ static int attention_bwd_ds(const EqdGraph* g, int d, const float* q, const floa
                             const int32_t* seg_start, const EqdGatherCall* gc, EqdRedList* pending, hipStream_t st,
                             bool bf16 = false) {
     if (d == 80) {
-        const int stride = eqd_attention_ds_stride(g);
-        if (bf16) {      // bf16 mode: the first layer's fp32-tile kernels with bf16 MFMA operands
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_kvds80<true>), dim3(g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, q, k, v, out,
-                               lse, d_out, dk, dv, qk_slope, ds, stride, seg_start);
-            if (int rc = eqd_check_launch("k_attn_bwd_kvds")) return rc;
+        static thread_local EqdRedArg RA8;
+        EqdGatherArgs GA8;
+        memset(&GA8, 0, sizeof(GA8));
+        memset(&RA8, 0, sizeof(RA8));
+        int nred8 = 0;
+        if (gc) {
+            if (int e = eqd_gather_plan(g, gc, pending, &GA8, &RA8, &nred8)) return e;
+        }
+        const int stride = eqd_attention_ds_stride(g), n_attn = g->n_att_items;
+        const dim3 grid(n_attn + GA8.ngather + nred8);
+        const bool dzb = gc && gc->dz_bf16;
+#define EQD_KV80(BF_, DZ_)                                                                                                          \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_kvds80<BF_, DZ_>), grid, dim3(EQD_BLOCK), 0, st, *g, q, k, v, out, lse, d_out, dk, dv, \
+                       qk_slope, ds, stride, seg_start, n_attn, nred8, GA8, RA8)
+        if (bf16) { if (dzb) EQD_KV80(true, true); else EQD_KV80(true, false); }
+        else { if (dzb) EQD_KV80(false, true); else EQD_KV80(false, false); }
+#undef EQD_KV80
+        if (int rc = eqd_check_launch("k_attn_bwd_kvds")) return rc;
+        if (bf16)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_qds<5, 2, true>), dim3(g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, q, k,
                                (const float*)ds, stride, dq, qk_slope);
-        } else {
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_kvds80<false>), dim3(g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, q, k, v, out,
-                               lse, d_out, dk, dv, qk_slope, ds, stride, seg_start);
-            if (int rc = eqd_check_launch("k_attn_bwd_kvds")) return rc;
+        else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_qds<5, 2>), dim3(g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, q, k,
                                (const float*)ds, stride, dq, qk_slope);
-        }
         if (int rc = eqd_check_launch("k_attn_bwd_qds")) return rc;
-        return gc ? eqd_launch_node_gather(g, gc->dz, gc->dxrel, gc->d_xnew, gc->a, gc->dP, gc->dQ, gc->dx, st, pending,
-                                           gc->dz_bf16 != 0)
-                  : EQD_OK;
+        return gc ? eqd_gather_rest(pending, st) : EQD_OK;
     }
     static thread_local EqdRedArg RA;
     EqdGatherArgs GA;
@@ -1035,6 +1089,18 @@ int eqd_launch_attention_bwd_gather(const EqdGraph* g, int d, const float* q, co
     EqdGatherArgs GA;
     int nred = 0;
     if (int e = eqd_gather_plan(g, gc, pending, &GA, &RA, &nred)) return e;
+    if (d == 80) {
+        const int n_attn80 = 2 * g->n_att_items;
+        const dim3 grid80(n_attn80 + GA.ngather + nred);
+#define EQD_AB80(BF_, DZ_)                                                                                                         \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd80_gather<BF_, DZ_>), grid80, dim3(EQD_BLOCK), 0, st, *g, q, k, v, out, lse, d_out, dq, \
+                       dk, dv, delta, qk_slope, n_attn80, nred, GA, RA)
+        if (bf16) { if (gc->dz_bf16) EQD_AB80(true, true); else EQD_AB80(true, false); }
+        else { if (gc->dz_bf16) EQD_AB80(false, true); else EQD_AB80(false, false); }
+#undef EQD_AB80
+        if (int rc = eqd_check_launch("k_attn_bwd_gather")) return rc;
+        return eqd_gather_rest(pending, st);
+    }
     const int n_attn = 4 * g->n_att_items;
     const dim3 grid(n_attn + GA.ngather + nred);
 #define EQD_ABG_LAUNCH(BFDZ_, LB_)                                                                                          \

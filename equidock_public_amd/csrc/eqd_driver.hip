@@ -546,6 +546,8 @@ extern "C" int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const
             add(Ls.qa, d, da, p[P_WQ], d, nullptr, 1);
             add(Ls.ka, d, da, p[P_WK], d, nullptr, 1);
             add(Ls.va, d, da, p[P_WV], d, nullptr, 0);
+            if (da != d)
+                for (int i = nj - 3; i < nj; ++i) cj[i].lin.pad_to = da;
         }
         return nj;
     };
@@ -556,11 +558,8 @@ extern "C" int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const
         const LayerSaved& Ls = S.lay[l];
         const float* h = S.h[l];
         const int da = D.d_att(l);
-        if (m->cross_msgs && da != d) {      // padding columns of q / k / v (the projections write d of da columns)
-            // one fill: the three buffers are consecutive in the saved-state arena (only alignment padding between them)
-            if (!(Ls.qa < Ls.ka && Ls.ka < Ls.va)) return EQD_ERR_WORKSPACE;
-            HIPOK(hipMemsetAsync(Ls.qa, 0, (size_t)((char*)(Ls.va + (size_t)N * da) - (char*)Ls.qa), st));
-        }
+        // (padding columns of q / k / v when da != d - the 69-wide first layer's 80-float attention rows -: written as zeros by
+        //  the projection jobs themselves, EqdLinJob.pad_to; until round 3 a fill of the three buffers in front of them)
         // ---- node projections (5 independent jobs, one launch: they run side by side) - unless the previous
         //      layer's node-update chain already carried them (large batches, see below) ---------------------
         if (!proj_in_chain) {
@@ -819,9 +818,8 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
         const float alpha = skip ? m->skip_weight_h : 1.f;
         const int ldn = D.ldwn(l);
         const int da = D.d_att(l);
-        if (m->cross_msgs && da != d)      // padding columns of d aggr_cross (the chain writes d of da columns; they meet
-                                           // zeros in V, but must not be NaN bit patterns left in the scratch buffer)
-            HIPOK(hipMemsetAsync(W.d_aggr_cross, 0, (size_t)N * da * sizeof(float), st));
+        // (padding columns of d aggr_cross when da != d: the chain's job writes them as zeros, EqdLinJob.pad_to - they meet
+        //  zeros in V, but must not be NaN bit patterns left in the scratch buffer)
         float *dz = W.dz_all + l * NS, *dq = W.dq_all + l * NS, *dk = W.dk_all + l * NS, *dv = W.dv_all + l * NS;
         float *dP = W.dP_all + l * NP, *dQ = W.dQ_all + l * NP;
         float* dHout = dHof(l + 1);
@@ -874,7 +872,7 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
                 return C;
             };
             dx_job(W.d_aggr_msg, 64, 64, d);
-            if (m->cross_msgs) dx_job(W.d_aggr_cross, d, da, d + 64);
+            if (m->cross_msgs) dx_job(W.d_aggr_cross, d, da, d + 64).lin.pad_to = da != d ? da : 0;
             // only the embedding columns of d h0 are ever read (k_embed_bwd: the trailing node features are inputs), so the
             // job computes m->d_emb of the D.d0 columns: a 64-wide job instead of a 69-wide one (the general body)
             EqdChainJob& C5 = dx_job(W.dh0acc, m->d_emb, D.d0, 2 * d + 64);

@@ -538,7 +538,7 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const JobW& W, b
     const float* const jR = jw_p<const float>(W, LJ(R));
     float* const jY = jw_p<float>(W, LJ(Y));
     float* const jpre = jw_p<float>(W, LJ(pre_ln));
-    const int ldr = jw_i(W, LJ(ldr)), ldy = jw_i(W, LJ(ldy)), ld_pre = jw_i(W, LJ(ld_pre));
+    const int ldr = jw_i(W, LJ(ldr)), ldy = jw_i(W, LJ(ldy)), ld_pre = jw_i(W, LJ(ld_pre)), pad_to = jw_i(W, LJ(pad_to));
     const float alpha = jw_f(W, LJ(alpha)), beta = jw_f(W, LJ(beta)), slope = jw_f(W, LJ(slope)), ln_eps = jw_f(W, LJ(ln_eps));
     const int mbn = (M + 15) >> 4;
     // this wave's output blocks and their epilogue operands (fetched now: the latency hides under the GEMM)
@@ -734,6 +734,8 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const JobW& W, b
                     const f32x4 yv = {y[0], y[1], y[2], y[3]};
                     if (jY && rv) *(EQD_GAS f4v*)&jY[(size_t)rowi * ldy + f0] = yv;
                     if (out_local >= 0) *(f32x4*)&Lb[rt][out_local][l15 * LIN_S + f0] = yv;
+                } else if (own[i] && f0 < pad_to) {      // zero padding of the row (EqdLinJob.pad_to; pad_to is a multiple of 16)
+                    if (jY && rv) *(EQD_GAS f4v*)&jY[(size_t)rowi * ldy + f0] = f4zero();
                 }
             } else {
 #pragma unroll
@@ -741,6 +743,8 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const JobW& W, b
                     if (r < nf[i]) {
                         if (jY && rv) ((EQD_GAS float*)jY)[(size_t)rowi * ldy + f0 + r] = y[r];
                         if (out_local >= 0) Lb[rt][out_local][l15 * LIN_S + f0 + r] = y[r];
+                    } else if (f0 + r < pad_to) {      // zero padding of the row (EqdLinJob.pad_to)
+                        if (jY && rv) ((EQD_GAS float*)jY)[(size_t)rowi * ldy + f0 + r] = 0.f;
                     }
             }
         }

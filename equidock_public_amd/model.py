@@ -336,6 +336,17 @@ class DropoutMasks:
         return DropoutMasks(p, edge_z1, edge_ch, torch.cat(nodes).to(dev).contiguous(), head.to(dev).contiguous())
 
 
+POISON_WORKSPACES = False      # tests: hand the library workspaces full of NaN bit patterns instead of whatever torch.empty holds
+
+
+def _workspace(nbytes, dev):
+    """Caller-owned scratch / saved-state buffer for the C calls.  Nothing may depend on its contents: with POISON_WORKSPACES
+    (tests) every byte is 0xFF, so that a padding column or partial buffer the kernels forgot to write shows up as NaN."""
+    if POISON_WORKSPACES:
+        return torch.full((nbytes,), 255, dtype=torch.uint8, device=dev)
+    return torch.empty(nbytes, dtype=torch.uint8, device=dev)
+
+
 class _IEGMNFunction(torch.autograd.Function):
     """forward = eqd_model_forward, backward = eqd_model_backward (one C call each)."""
 
@@ -373,8 +384,8 @@ class _IEGMNFunction(torch.autograd.Function):
         sb, wb = packed.ws_sizes[key]
         # the forward carves its state from `saved` when a backward will follow and from `scratch` otherwise: only one
         # of the two is ever touched (the state is hundreds of MB at 64 x (300, 300))
-        saved = torch.empty(sb, dtype=torch.uint8, device=dev) if need_grad else None
-        scratch = None if need_grad else torch.empty(wb, dtype=torch.uint8, device=dev)
+        saved = _workspace(sb, dev) if need_grad else None
+        scratch = None if need_grad else _workspace(wb, dev)
         if svd_draws is not None:
             svd_draws = _lib.require_device(svd_draws.to(torch.float32).contiguous(), 'svd_draws')
         if _lib.profiling:
@@ -414,7 +425,7 @@ class _IEGMNFunction(torch.autograd.Function):
             offs, total = flat_layout(tensors)
             flat = torch.zeros(total, dtype=torch.float32, device=dev)
             goffs = (C.c_int64 * len(ctx.table_idx))(*[offs[i] for i in ctx.table_idx])
-        scratch = torch.empty(ctx.wb, dtype=torch.uint8, device=dev)
+        scratch = _workspace(ctx.wb, dev)
 
         def prep(t):
             return None if t is None else _lib.require_device(t.to(torch.float32).contiguous(), 'output gradient')

@@ -264,6 +264,9 @@ typedef struct EqdLinJob {
                        before the LayerNorm - nn.Dropout between a Linear and its LeakyReLU in training mode
                        (rigid_docking_model.py:129, 435: LeakyReLU(keep * s * z) = keep * s * LeakyReLU(z)), entries are
                        0 or 1 / (1 - p), drawn by the caller.  NULL = none.  Jobs with `mul` run on the four-wave kernels. */
+    int32_t pad_to;   /* > M: columns M .. pad_to - 1 of every output row are written as zeros (the zero padding of a
+                         69-wide layer's 80-float attention rows, without a separate fill); 0 = none.  Honoured by the
+                         general (M % 4 != 0) epilogue - the only place such widths occur. */
 } EqdLinJob;
 int eqd_linear(const EqdLinJob* jobs /* host */, int njobs, void* stream);
 

@@ -816,6 +816,41 @@ def check_attention(dev, d, sizes=((70, 45), (33, 101))):
         assert torch.equal(dk2, dk) and torch.equal(dv2, dv), 'the key / value pass must not depend on whether it writes dS'
 
 
+def check_poisoned_workspaces(dev):
+    """Nothing the kernels read may come from a workspace they did not write: the model with its saved-state / scratch buffers
+    pre-filled with NaN bit patterns gives bit-identical outputs and gradients (zero padding of the first layer's attention
+    rows - written by the projection jobs themselves since round 4, EqdLinJob.pad_to, in both epilogue forms: 69-wide and
+    68-wide first layers -, partial buffers, the dS hand-off's rows beyond the partner)."""
+    import os
+    pairs = synthetic.make_pairs([(60, 75), (90, 48), (7, 130), (33, 16)], 21)
+    for over, env in (({}, None), ({'residue_emb_dim': 63}, None), ({}, '1'), ({'hip_storage_dtype': 'bf16'}, '1')):
+        args = dict(port.default_args(iegmn_n_lays=2, skip_weight_h=0.75), **over)
+        sd = port.init_state_dict(args, seed=4)
+        res = {}
+        if env is not None:
+            os.environ['EQD_ATT_DS'] = env
+            L.reload_tunables()
+        try:
+            for poison in (False, True):
+                M.POISON_WORKSPACES = poison
+                try:
+                    net = build_model(args, sd, dev)
+                    g = G.batch_pairs(pairs).to(dev)
+                    outs = net.forward_batched(g)
+                    (outs[0].square().sum() + outs[1].square().sum() + outs[2].square().sum()).backward()
+                    sync(dev)
+                    res[poison] = [t.detach().cpu().clone() for t in outs] + [p.grad.detach().cpu().clone() for p in net.parameters()]
+                finally:
+                    M.POISON_WORKSPACES = False
+        finally:
+            if env is not None:
+                del os.environ['EQD_ATT_DS']
+                L.reload_tunables()
+        for a, b in zip(res[True], res[False]):
+            assert torch.isfinite(a).all(), f'NaN from a poisoned workspace ({over}, EQD_ATT_DS={env})'
+            assert torch.equal(a, b), f'result depends on stale workspace contents ({over}, EQD_ATT_DS={env})'
+
+
 def check_attention_ds_in_model(dev, bf16=False):
     """The whole model with the dS hand-off form of the attention backward forced on (EQD_ATT_DS=1: what large batches run)
     against the recompute form (EQD_ATT_DS=0): same outputs bit for bit (the forward is untouched), gradients equal up to fp32
@@ -860,7 +895,7 @@ def check_attention_ds_in_model(dev, bf16=False):
         worst = max(worst, e2)
     nds = 3
     assert names['1'].count('k_attn_bwd_kvds') == nds and names['1'].count('k_attn_bwd_qds') == nds, sorted(set(names['1']))
-    assert names['0'].count('k_attn_bwd_kvds') == 0 and names['0'].count('k_attn_bwd_gather') == 2, sorted(set(names['0']))
+    assert names['0'].count('k_attn_bwd_kvds') == 0 and names['0'].count('k_attn_bwd_gather') == 3, sorted(set(names['0']))
     print(f"dS hand-off vs recompute form of the attention backward on {dev}{' (bf16)' if bf16 else ''}: worst parameter-gradient "
           f'rel-L2 {worst:.2e}')
 
@@ -1813,8 +1848,8 @@ def check_fused_forward(dev):
 def check_gather_rides_in_attention_backward(dev):
     """The node gather + pending reductions as trailing workgroups of the attention-backward launch (k_attn_bwd_gather,
     csrc/eqd_attn_kernels.hip) against the separate launches (EQD_FUSE_GATHER=0): the same device bodies, so bit-identical
-    outputs and gradients, fp32 and bf16 mode; and the switch really selects the launch (64-wide layers only: the 69-wide
-    first layer keeps k_attn_bwd + k_node_gather)."""
+    outputs and gradients, fp32 and bf16 mode; and the switch really selects the launch (every layer since round 4: the
+    69-wide first layer's merged backward carries its gather as well)."""
     import os
     pairs = synthetic.make_pairs([(60, 75), (90, 48), (7, 130), (33, 16)], 21)
     for over in ({}, {'hip_storage_dtype': 'bf16'}):
@@ -1844,7 +1879,8 @@ def check_gather_rides_in_attention_backward(dev):
                 L.reload_tunables()
         for a, b in zip(res['1'][0] + res['1'][1], res['0'][0] + res['0'][1]):
             assert torch.equal(a, b), f'fused vs separate gather launch differ ({over})'
-        assert names['1'].count('k_attn_bwd_gather') == 2 and names['1'].count('k_node_gather') == 1, sorted(set(names['1']))
+        # (round 4: the 80-wide first layer's merged backward carries its gather too)
+        assert names['1'].count('k_attn_bwd_gather') == 3 and names['1'].count('k_node_gather') == 0, sorted(set(names['1']))
         assert names['0'].count('k_attn_bwd_gather') == 0 and names['0'].count('k_node_gather') == 3, sorted(set(names['0']))
 
 

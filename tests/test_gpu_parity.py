@@ -329,6 +329,11 @@ def test_model_vs_oracle_config_c_bf16(dev):
     pc.check_model_bf16_states(dev, [(300, 300)] * 64, layers=8, seed=3, pair_seed=34, what='config C bf16', report=REPORT)
 
 
+def test_results_do_not_depend_on_workspace_contents(dev):
+    from tests import parity_common as pc
+    pc.check_poisoned_workspaces(dev)
+
+
 def test_attention_backward_ds_handoff_in_model(dev):
     """the dS hand-off form of the attention backward (large batches) against the recompute form, whole model"""
     from tests import parity_common as pc

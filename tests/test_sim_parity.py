@@ -203,6 +203,10 @@ def test_cross_attention_bf16_kernel_forms(env, monkeypatch):
     pc.check_attention_bf16(DEV, 64, sizes=((300, 257), (129, 64)))
 
 
+def test_results_do_not_depend_on_workspace_contents():
+    pc.check_poisoned_workspaces(DEV)
+
+
 def test_attention_backward_ds_handoff_in_model():
     pc.check_attention_ds_in_model(DEV)
     pc.check_attention_ds_in_model(DEV, bf16=True)
