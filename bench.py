@@ -547,7 +547,7 @@ class _Run:
     """One timed workload: everything main() needs to report it."""
 
 
-def run_workload(workload, dtype, steps, warmup, dev, rank, world, use_dist, backend, dropout=0.0, dropout_masks='torch',
+def run_workload(workload, dtype, steps, warmup, dev, rank, world, use_dist, backend, dropout=0.0, dropout_masks='library',
                  eager=False, time_allreduce=True):
     """Build the model + the synthetic batch of `workload`, capture zero-grad -> forward -> loss -> backward (+ the RCCL
     all-reduce under a process group) into a hipGraph, run `warmup` untimed and `steps` timed steps bracketed by
@@ -766,7 +766,7 @@ def main():
                     help="args['dropout'] of the model, in training mode (src/utils/args.py:240 draws 0 or 0.25): every step "
                          "then draws fresh nn.Dropout masks with torch's device generator in the reference's order (inside "
                          "the replayed graph) and the kernels apply them; reported WITHOUT the roofline / CPU-baseline parts")
-    ap.add_argument('--dropout-masks', default='torch', choices=('torch', 'library'),
+    ap.add_argument('--dropout-masks', default='library', choices=('torch', 'library'),
                     help="with --dropout: 'torch' = nn.Dropout's own random stream (torch's dropout on [E, 64] tensors of "
                          "ones, bit-packed by eqd_dropout_pack_edges); 'library' = eqd_dropout_draw (counter-based, one launch, "
                          "no [E, 64] tensors; args['hip_dropout_masks'])")

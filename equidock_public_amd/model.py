@@ -243,8 +243,8 @@ class DropoutMasks:
         """args['hip_dropout_masks'] = 'library' (not a reference option): the masks of one forward from ONE launch of
         eqd_dropout_draw - counter-based (Philox4x32-10), keyed by a 64-bit word drawn on the device from torch's generator
         (so torch.manual_seed still fixes the run, and a replayed hipGraph of the step sees fresh masks every replay).
-        Same Bernoulli law as nn.Dropout, not torch's random stream; no [E, 64] tensors are materialised (the default
-        'torch' source moves ~9 GB per step through HBM for them at 64 x (300, 300))."""
+        Same Bernoulli law as nn.Dropout, not torch's random stream; no [E, 64] tensors are materialised (the 'torch'
+        source moves ~9 GB per step through HBM for them at 64 x (300, 300)).  The default since round 4."""
         p = float(iegmn.args['dropout'])
         dev = packed.x0.device
         desc, gs = iegmn._desc(), packed.c_struct()
@@ -267,7 +267,7 @@ class DropoutMasks:
     @staticmethod
     def draw(iegmn, g, packed):
         import torch.nn.functional as F
-        src = iegmn.args.get('hip_dropout_masks', 'torch')
+        src = iegmn.args.get('hip_dropout_masks', DEFAULT_DROPOUT_MASKS)
         if src == 'library':
             return DropoutMasks.draw_library(iegmn, packed)
         if src != 'torch':
@@ -335,6 +335,13 @@ class DropoutMasks:
             edge_ch = torch.stack([t[perm] for t in ec]).to(dev).contiguous()
         return DropoutMasks(p, edge_z1, edge_ch, torch.cat(nodes).to(dev).contiguous(), head.to(dev).contiguous())
 
+
+# Source of the nn.Dropout keep masks in training mode (args['hip_dropout_masks']).  'library' (default since round 4):
+# eqd_dropout_draw - one launch, counter-based, keyed by a word torch's generator draws on the device, so torch.manual_seed
+# still fixes a run; the same Bernoulli(1 - p) law as nn.Dropout but NOT torch's random stream.  'torch': nn.Dropout's own
+# stream (torch's dropout on [E, 64] tensors of ones, in the reference's consumption order) - what a bit-for-bit comparison
+# with a reference run on the same device and seed needs, at +22 % of a step at 8 x (200, 200) and +17 % at 64 x (300, 300).
+DEFAULT_DROPOUT_MASKS = 'library'
 
 POISON_WORKSPACES = False      # tests: hand the library workspaces full of NaN bit patterns instead of whatever torch.empty holds
 

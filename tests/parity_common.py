@@ -1127,7 +1127,7 @@ def check_dropout_training(dev):
     z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'variants.npz'), allow_pickle=False)
     meta = json.loads(str(z['meta']))
     v = meta['variants']['dropout_train']
-    args = dict(v['args'], device=torch.device(dev))
+    args = dict(v['args'], device=torch.device(dev), hip_dropout_masks='torch')      # (nn.Dropout's own stream: what was recorded)
     sd = config.seeded_state_dict(args, meta['init_seed'], meta['rot_scale'])
     raw = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('in_')}
     raw['lig_counts'], raw['rec_counts'] = [int(c) for c in z['in_lig_counts']], [int(c) for c in z['in_rec_counts']]

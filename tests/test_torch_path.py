@@ -28,7 +28,8 @@ def _raw():
 
 def _model(name, device='cpu'):
     v = META['variants'][name]
-    args = dict(v['args'], device=torch.device(device))
+    # (the recorded vectors carry nn.Dropout's own random stream: the 'torch' mask source, not the library-drawn default)
+    args = dict(v['args'], device=torch.device(device), hip_dropout_masks='torch')
     sd = config.seeded_state_dict(args, META['init_seed'], META['rot_scale'])
     for k, (s, a) in v['fingerprint'].items():
         t = sd[k].double()
