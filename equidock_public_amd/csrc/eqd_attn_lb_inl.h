@@ -119,6 +119,27 @@ __device__ __forceinline__ void lb_mma_r(f32x4 (&acc)[4][NB], const unsigned sho
     }
 }
 
+// the same contraction with the A operand read out of the ROW-MAJOR copy of the tile by the transposing LDS read
+// (lds_tr16, eqd_common.h): lane (l15, g) points at features 16 db + 4 (l15 & 3) .. + 3 of row 4 g + (l15 >> 2) and receives
+// rows 4 g .. 4 g + 3 of feature 16 db + l15 - what lb_mma_r reads from a transposed copy that then need not be written
+// (8 packs + 8 ds_write_b64 per tile and operand).  Same operand values, same instruction.
+template <int NB>
+__device__ __forceinline__ void lb_mma_rt(f32x4 (&acc)[4][NB], const unsigned short* __restrict__ rm, int g, int l15,
+                                          const f32x4 (&B)[2][NB]) {
+    s16x8 b[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+        b[nb] = cat_bf(pack_bf4(B[0][nb][0], B[0][nb][1], B[0][nb][2], B[0][nb][3]),
+                       pack_bf4(B[1][nb][0], B[1][nb][1], B[1][nb][2], B[1][nb][3]));
+    const unsigned short* const p0 = rm + (4 * g + (l15 >> 2)) * LB_RS + 4 * (l15 & 3);
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+        const s16x8 a = cat_bf(lds_tr16(p0 + 16 * db), lds_tr16(p0 + 16 * LB_RS + 16 * db));
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[db][nb] = mfma_bf32(a, b[nb], acc[db][nb]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward (same schedule as attn_fwd_body: the 4 waves split the partner's 32-row tiles, online softmax, LDS merge)
 // ---------------------------------------------------------------------------------------------
@@ -288,9 +309,9 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_fwd_lb(EqdGraph G, const flo
 // ---------------------------------------------------------------------------------------------
 struct alignas(16) LbBwdWave {
     unsigned short a_rm[32 * LB_RS];    // dq pass: K row-major   | kv pass: Q row-major
-    unsigned short a_tr[64 * LB_TS];    //          K transposed  |          Q transposed
     unsigned short b_rm[32 * LB_RS];    //          V row-major   |          dO row-major
-    unsigned short b_tr[64 * LB_TS];    //          (unused)      |          dO transposed
+    // (until round 3 also transposed copies of K | Q and dO for the contractions over the tile's rows: they are read out of
+    //  the row-major copies by the transposing LDS read now, lb_mma_rt)
 };
 struct alignas(16) AttnBwdSmemLb {
     LbBwdWave w[EQD_WAVES];
@@ -379,7 +400,6 @@ __device__ __forceinline__ void attn_bwd_q_body_lb(AttnBwdSmemLb& sm, const EqdG
     for (; kt < o1; kt += 32 * EQD_WAVES) {
         wave_lds_fence();
         lb_store_rm(rk, W.a_rm, lane);
-        lb_store_tr(rk, W.a_tr, lane);
         lb_store_rm(rv, W.b_rm, lane);
         wave_lds_fence();
         lb_load(rk, k, kt + 32 * EQD_WAVES, o1, lane);
@@ -404,7 +424,7 @@ __device__ __forceinline__ void attn_bwd_q_body_lb(AttnBwdSmemLb& sm, const EqdG
                     const float p = key < o1 ? bwd_exp(S[mb][nb][r] - lq[nb]) : 0.f;
                     S[mb][nb][r] = p * (dP[mb][nb][r] - dl[nb]);
                 }
-        lb_mma_r<NB>(dQ, W.a_tr, g, l15, S);
+        lb_mma_rt<NB>(dQ, W.a_rm, g, l15, S);
     }
     wave_lds_fence();
 #pragma unroll
@@ -497,9 +517,7 @@ __device__ __forceinline__ void attn_bwd_kv_body_lb(AttnBwdSmemLb& sm, const Eqd
     for (; qt < o1; qt += 32 * EQD_WAVES) {
         wave_lds_fence();
         lb_store_rm(rq, W.a_rm, lane);
-        lb_store_tr(rq, W.a_tr, lane);
         lb_store_rm(rg, W.b_rm, lane);
-        lb_store_tr(rg, W.b_tr, lane);
         // delta = rowsum(dO * O) of the streamed query rows (fp32, from the rows as loaded): the lane's 8 columns of its
         // rows 4 a + r, summed over the 8 lanes that share a row group
 #pragma unroll
@@ -569,8 +587,8 @@ __device__ __forceinline__ void attn_bwd_kv_body_lb(AttnBwdSmemLb& sm, const Eqd
                     }
                 }
         }
-        lb_mma_r<NB>(dV, W.b_tr, g, l15, S);
-        lb_mma_r<NB>(dK, W.a_tr, g, l15, dP);
+        lb_mma_rt<NB>(dV, W.b_rm, g, l15, S);
+        lb_mma_rt<NB>(dK, W.a_rm, g, l15, dP);
     }
     wave_lds_fence();
 #pragma unroll

@@ -180,6 +180,29 @@ __device__ __forceinline__ f32x4 mfma_bf32(s16x8 a, s16x8 b, f32x4 c) {
 #endif
 }
 
+// ds_read_b64_tr_b16 (gfx950): a transposing LDS read.  Every lane supplies the address of 4 consecutive bf16 (8-byte
+// aligned); inside each group of 16 lanes, lane i receives element (i & 3) of the reads of lanes (i >> 2), 4 + (i >> 2),
+// 8 + (i >> 2), 12 + (i >> 2) - MEASURED on MI355X (profiles/exp_r04/trb16.hip, profiles/r04_p_trb16.txt: three address
+// patterns, every lane and element).  With lanes 4 j .. 4 j + 3 pointing at 16 consecutive features of row j of a row-major
+// tile, lane i therefore gets rows 0 .. 3 of feature column i: an MFMA operand of a contraction over the tile's ROWS comes
+// straight out of the row-major copy, and the second, transposed copy of the tile need not exist.
+__device__ __forceinline__ s16x4 lds_tr16(const unsigned short* p) {
+#ifdef EQD_HOSTSIM
+    const unsigned long long a = (unsigned long long)p;
+    const int lane = (int)(threadIdx.x & 63), grp = lane & ~15, i = lane & 15;
+    s16x4 r;
+    for (int j = 0; j < 4; ++j) {
+        const int src = grp + 4 * j + (i >> 2);
+        const unsigned lo = (unsigned)__shfl((int)(unsigned)a, src), hi = (unsigned)__shfl((int)(unsigned)(a >> 32), src);
+        const unsigned short* q = (const unsigned short*)(((unsigned long long)hi << 32) | lo);
+        r[j] = (short)q[i & 3];
+    }
+    return r;
+#else
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+#endif
+}
+
 __device__ __forceinline__ f32x4 f4zero() {
     f32x4 z = {0.f, 0.f, 0.f, 0.f};
     return z;
