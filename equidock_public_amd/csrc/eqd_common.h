@@ -210,23 +210,75 @@ __device__ __forceinline__ f32x4 f4zero() {
 __device__ __forceinline__ float lrelu(float v, float s) { return v > 0.f ? v : v * s; }
 __device__ __forceinline__ float lrelu_grad(float y, float s) { return y > 0.f ? 1.f : s; }
 
+// ---- lane exchanges without the LDS pipe (round 4) -------------------------------------------------------------------
+// __shfl_xor compiles to ds_bpermute_b32: an address computation, a trip through the LDS pipe (~50+ clocks) and an
+// s_waitcnt per exchange - 93 of them per 16-edge tile of k_edge_bwd.  Inside a row of 16 lanes the same exchange is a DPP
+// move (VALU, no wait): lane ^ 1 / ^ 2 = quad_perm, lane ^ 8 = row_ror:8, lane ^ 4 = row_half_mirror followed by a quad
+// reverse; across rows v_permlane16_swap / v_permlane32_swap (gfx950) return (even rows | odd rows) resp. (lower | upper
+// half) duplicated, so that v[l] + v[l ^ 16] is the sum of the two results.  All checked on MI355X against __shfl_xor
+// (profiles/exp_r04/dpp.hip, profiles/r04_t_dpp.txt).  Pure data movement, and the sums are commutative: same results.
+template <int M>
+__device__ __forceinline__ float lane_xor(float v) {
+    static_assert(M == 1 || M == 2 || M == 4 || M == 8, "inside a row of 16 lanes");
+#if defined(EQD_HOSTSIM) || defined(EQD_NO_DPP)
+    return __shfl_xor(v, M);
+#else
+    const int i = __builtin_bit_cast(int, v);
+    int r;
+    if constexpr (M == 1) r = __builtin_amdgcn_update_dpp(0, i, 0xB1, 0xf, 0xf, false);           // quad_perm [1,0,3,2]
+    else if constexpr (M == 2) r = __builtin_amdgcn_update_dpp(0, i, 0x4E, 0xf, 0xf, false);      // quad_perm [2,3,0,1]
+    else if constexpr (M == 8) r = __builtin_amdgcn_update_dpp(0, i, 0x128, 0xf, 0xf, false);     // row_ror:8
+    else r = __builtin_amdgcn_update_dpp(0, __builtin_amdgcn_update_dpp(0, i, 0x141, 0xf, 0xf, false), 0x1B, 0xf, 0xf,
+                                         false);                                                   // half mirror, quad reverse
+    return __builtin_bit_cast(float, r);
+#endif
+}
+// v[l] (+ | max) v[l ^ M], M = 16 | 32, through v_permlane{16,32}_swap: with both operands holding v, the instruction leaves
+// (even rows | odd rows) resp. (lower | upper half) of v duplicated in the two registers.
+// The instruction is written as inline assembly: through __builtin_amdgcn_permlane{16,32}_swap hipcc (ROCm 7.2) used the FIRST
+// result for both elements of the returned pair in these kernels (v + v instead of v_even + v_odd in the code object; 15 of
+// 16 operator tests failed on the GPU, profiles/r04_v_bisect.txt), with or without an opaque copy of the second operand.
+template <int M>
+__device__ __forceinline__ float lane_swap_sum(float v, int want_max) {
+#if defined(EQD_HOSTSIM) || defined(EQD_NO_PLSWAP)
+    const float o = __shfl_xor(v, M);
+    return want_max ? fmaxf(v, o) : v + o;
+#else
+    // (inline assembly: the instruction rewrites BOTH registers; s_nop 1 = the wait states hipcc itself puts between a VALU
+    //  write of an operand and the swap)
+    float x = v, y = v;
+    if constexpr (M == 16) asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    else asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    return want_max ? fmaxf(x, y) : x + y;
+#endif
+}
 // sum / max over the 4 lane groups (same l15): after this every lane of the column has the total
 __device__ __forceinline__ float group_sum(float v) {
+#if defined(EQD_HOSTSIM) || defined(EQD_NO_PLSWAP)
     v += __shfl_xor(v, 16);
     v += __shfl_xor(v, 32);
     return v;
+#else
+    const float s = lane_swap_sum<16>(v, 0);
+    return lane_swap_sum<32>(s, 0);
+#endif
 }
 __device__ __forceinline__ float group_max(float v) {
+#if defined(EQD_HOSTSIM) || defined(EQD_NO_PLSWAP)
     v = fmaxf(v, __shfl_xor(v, 16));
     v = fmaxf(v, __shfl_xor(v, 32));
     return v;
+#else
+    const float s = lane_swap_sum<16>(v, 1);
+    return lane_swap_sum<32>(s, 1);
+#endif
 }
 // sum over the 16 lanes of a lane group (same g)
 __device__ __forceinline__ float l16_sum(float v) {
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8);
+    v += lane_xor<1>(v);
+    v += lane_xor<2>(v);
+    v += lane_xor<4>(v);
+    v += lane_xor<8>(v);
     return v;
 }
 __device__ __forceinline__ float wave_sum(float v) { return group_sum(l16_sum(v)); }
@@ -236,12 +288,12 @@ __device__ __forceinline__ float reduce16x16(const float (&v)[16], int l15) {
     const bool b3 = (l15 & 8) != 0, b2 = (l15 & 4) != 0, b1 = (l15 & 2) != 0, b0 = (l15 & 1) != 0;
     float w8[8], w4[4], w2[2];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) w8[i] = (b3 ? v[i + 8] : v[i]) + __shfl_xor(b3 ? v[i] : v[i + 8], 8);
+    for (int i = 0; i < 8; ++i) w8[i] = (b3 ? v[i + 8] : v[i]) + lane_xor<8>(b3 ? v[i] : v[i + 8]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) w4[i] = (b2 ? w8[i + 4] : w8[i]) + __shfl_xor(b2 ? w8[i] : w8[i + 4], 4);
+    for (int i = 0; i < 4; ++i) w4[i] = (b2 ? w8[i + 4] : w8[i]) + lane_xor<4>(b2 ? w8[i] : w8[i + 4]);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) w2[i] = (b1 ? w4[i + 2] : w4[i]) + __shfl_xor(b1 ? w4[i] : w4[i + 2], 2);
-    return (b0 ? w2[1] : w2[0]) + __shfl_xor(b0 ? w2[0] : w2[1], 1);
+    for (int i = 0; i < 2; ++i) w2[i] = (b1 ? w4[i + 2] : w4[i]) + lane_xor<2>(b1 ? w4[i] : w4[i + 2]);
+    return (b0 ? w2[1] : w2[0]) + lane_xor<1>(b0 ? w2[0] : w2[1]);
 }
 
 // Ordering point for wave-private LDS traffic (one wave writes, other lanes of the SAME wave

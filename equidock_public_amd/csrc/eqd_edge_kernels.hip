@@ -1114,27 +1114,42 @@ __device__ __forceinline__ void feat_atb(f32x4 (&acc)[1], const float* __restric
     }
 }
 
-// bf16 mode: the slabs are stored TRANSPOSED ([feature][128 edges], bf16) so that an MFMA operand - 4 consecutive
-// edges (the K axis) of one feature - is one b64 read
-#define USB 136        /* bf16 row stride of the transposed slabs: 68 dwords = 4 mod 32 */
+// bf16 mode: the slabs are stored ROW-MAJOR ([128 edges][64 features], bf16 - a lane's four consecutive features of its
+// edge are ONE 8-byte store) and an MFMA operand - 4 consecutive edges (the K axis) of one feature - comes out of them
+// through the transposing LDS read (lds_tr16, eqd_common.h; round 4).  Until then the slabs were stored transposed
+// ([feature][128 edges]) with one 2-byte store per element: 111 ds_write_b16 per 16-edge tile, the largest group of LDS
+// instructions of the kernel.  Same operand values in the same k-slots: bit-identical results.
+#define USB 72         /* bf16 row stride of the row-major slabs: 144-byte rows keep every 4-feature group 8-byte aligned */
 __device__ __forceinline__ void slab_store_bf(unsigned short* __restrict__ slab, int wave, const f32x4 (&v)[4][1], int l15,
                                               int g) {
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) slab[(16 * mb + 4 * g + r) * USB + 16 * wave + l15] = f2bf(v[mb][0][r]);
+        *(s16x4*)&slab[(16 * wave + l15) * USB + 16 * mb + 4 * g] = pack_bf4(v[mb][0][0], v[mb][0][1], v[mb][0][2], v[mb][0][3]);
 }
-template <int NJ>
-__device__ __forceinline__ void slab_atb_bf(f32x4 (&acc)[NJ], const unsigned short* __restrict__ Xt,
-                                            const unsigned short* __restrict__ Yt, int mb, int nb0, int l15, int g) {
+// acc[j] += X[:, 16 mb ..]^T Y[:, 16 (nb0 + j) ..] over the slabs' 128 edges: lane (l15, g) points at features
+// 16 mb + 4 (l15 & 3) .. + 3 of edge 4 g + (l15 >> 2) of a 16-edge chunk and receives edges 4 g .. 4 g + 3 of feature
+// 16 mb + l15
+// (FULL: all four chunks unrolled - 1.6 % faster per launch at 64 x (300, 300); the dropout instances, which carry the keep
+//  masks as well, spill 9 registers to scratch that way and unroll by two instead: no scratch in any instance)
+template <int NJ, bool FULL>
+__device__ __forceinline__ void slab_atb_bf(f32x4 (&acc)[NJ], const unsigned short* __restrict__ Xr,
+                                            const unsigned short* __restrict__ Yr, int mb, int nb0, int l15, int g) {
+    const int lo = (4 * g + (l15 >> 2)) * USB + 4 * (l15 & 3);
+    const unsigned short* const px = Xr + lo + 16 * mb;
+    auto chunk = [&](int kp) {      // 32 edges: one v_mfma_f32_16x16x32_bf16 per output block
+        const s16x8 a = cat_bf(lds_tr16(px + 32 * kp * USB), lds_tr16(px + (32 * kp + 16) * USB));
 #pragma unroll
-    for (int kp = 0; kp < 4; ++kp) {      // 128 edges = four 32-deep chunks of v_mfma_f32_16x16x32_bf16
-        const s16x8 a = cat_bf(*(const s16x4*)&Xt[(16 * mb + l15) * USB + 32 * kp + 4 * g],
-                               *(const s16x4*)&Xt[(16 * mb + l15) * USB + 32 * kp + 16 + 4 * g]);
+        for (int j = 0; j < NJ; ++j) {
+            const unsigned short* const py = Yr + lo + 16 * (nb0 + j);
+            acc[j] = mfma_bf32(a, cat_bf(lds_tr16(py + 32 * kp * USB), lds_tr16(py + (32 * kp + 16) * USB)), acc[j]);
+        }
+    };
+    if constexpr (FULL) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
-            acc[j] = mfma_bf32(a, cat_bf(*(const s16x4*)&Yt[(16 * (nb0 + j) + l15) * USB + 32 * kp + 4 * g],
-                                         *(const s16x4*)&Yt[(16 * (nb0 + j) + l15) * USB + 32 * kp + 16 + 4 * g]), acc[j]);
+        for (int kp = 0; kp < 4; ++kp) chunk(kp);
+    } else {
+#pragma unroll 2
+        for (int kp = 0; kp < 4; ++kp) chunk(kp);
     }
 }
 
@@ -1148,7 +1163,7 @@ template <>
 struct EdgeBwdSmemSel<true> {
     typedef EdgeSmemBfBwd<BWD_WAVES, 16 * FS> type;
     typedef unsigned short slab_t;
-    enum { SLAB = 64 * USB };
+    enum { SLAB = 128 * USB };
 };
 
 template <bool BF, bool DROP = false>
@@ -1280,7 +1295,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
         __syncthreads();
         EQD_TR(13);
         if constexpr (BF)
-            slab_atb_bf<2>(gWc1, U, V, wmb, wnb, l15, g);
+            slab_atb_bf<2, !DROP>(gWc1, U, V, wmb, wnb, l15, g);
         else
             slab_atb<2>(gWc1, U, V, wmb, wnb, l15, g);
         EQD_TR(14);
@@ -1333,7 +1348,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
         __syncthreads();
         EQD_TR(16);
         if constexpr (BF)
-            slab_atb_bf<2>(gW2, U, V, wmb, wnb, l15, g);
+            slab_atb_bf<2, !DROP>(gW2, U, V, wmb, wnb, l15, g);
         else
             slab_atb<2>(gW2, U, V, wmb, wnb, l15, g);
         EQD_TR(17);
@@ -1406,13 +1421,15 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
         if constexpr (DBUF) slab_par ^= 1;
         if constexpr (BF) {
             slab_store_bf(U, wave, dz, l15, g);
-            // this wave's [16][48] feature tile, transposed, is rows 0..47 x columns 16 w .. of V
+            // this wave's [16][48] feature tile is rows 16 w .. of V (a copy: the tile is overwritten by the next iteration's
+            // recompute while other waves may still be in this phase)
             const unsigned short* __restrict__ ft = (const unsigned short*)tile;
 #pragma unroll
-            for (int i = 0; i < 12; ++i) V[(12 * g + i) * USB + 16 * wave + l15] = ft[l15 * FSB + 12 * g + i];
+            for (int i = 0; i < 3; ++i)
+                *(s16x4*)&V[(16 * wave + l15) * USB + 12 * g + 4 * i] = *(const s16x4*)&ft[l15 * FSB + 12 * g + 4 * i];
             __syncthreads();
-            slab_atb_bf<1>(gW1a, U, V, wmb, wave & 1, l15, g);
-            if (wave < 4) slab_atb_bf<1>(gW1b, U, V, wave, 2, l15, g);
+            slab_atb_bf<1, !DROP>(gW1a, U, V, wmb, wave & 1, l15, g);
+            if (wave < 4) slab_atb_bf<1, !DROP>(gW1b, U, V, wave, 2, l15, g);
         } else {
             slab_store(U, wave, dz, l15, g);
             __syncthreads();
