@@ -318,8 +318,8 @@ __device__ __forceinline__ void attn_bwd_kv_body(SM& sm, const EqdGraph& G, int 
                 for (int j = 0; j < 2; ++j) {
                     const float4 a = rg.qx[j], b = ro.qx[j];
                     float p = a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
-                    p += __shfl_xor(p, 1);
-                    p += __shfl_xor(p, 2);
+                    p += lane_xor<1>(p);
+                    p += lane_xor<2>(p);
                     if ((lane & 3) == 0) sm.dls[wave][(lane + 64 * j) >> 2] += p;
                 }
             }

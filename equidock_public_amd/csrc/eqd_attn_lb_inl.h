@@ -523,9 +523,9 @@ __device__ __forceinline__ void attn_bwd_kv_body_lb(AttnBwdSmemLb& sm, const Eqd
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float p = lb_rowdot(rg, ro, r, lane);
-            p += __shfl_xor(p, 1);
-            p += __shfl_xor(p, 2);
-            p += __shfl_xor(p, 4);
+            p += lane_xor<1>(p);
+            p += lane_xor<2>(p);
+            p += lane_xor<4>(p);
             if ((lane & 7) == 0) sm.dls[wave][4 * a8 + r] = p;
         }
         float lc[2][4], dc[2][4];

@@ -87,8 +87,9 @@ __device__ __forceinline__ float block_reduce_sum(float v, float* red) {
     return red[0] + red[1] + red[2] + red[3];
 }
 __device__ __forceinline__ float block_reduce_max(float v, float* red) {
-    v = fmaxf(v, __shfl_xor(v, 1)); v = fmaxf(v, __shfl_xor(v, 2)); v = fmaxf(v, __shfl_xor(v, 4));
-    v = fmaxf(v, __shfl_xor(v, 8)); v = fmaxf(v, __shfl_xor(v, 16)); v = fmaxf(v, __shfl_xor(v, 32));
+    v = fmaxf(v, lane_xor<1>(v)); v = fmaxf(v, lane_xor<2>(v)); v = fmaxf(v, lane_xor<4>(v));
+    v = fmaxf(v, lane_xor<8>(v));
+    v = group_max(v);
     const int wave = threadIdx.x >> 6;
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[wave] = v;

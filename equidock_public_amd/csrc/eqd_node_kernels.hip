@@ -304,11 +304,11 @@ __device__ __forceinline__ void chain_lnbwd64(const JobW& W, float (*Lb)[LIN_LOC
     const bool b3 = (l15 & 8) != 0, b2 = (l15 & 4) != 0, b1 = (l15 & 2) != 0;
     float w4[4], w2[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) w4[i] = (b3 ? v8[i + 4] : v8[i]) + __shfl_xor(b3 ? v8[i] : v8[i + 4], 8);
+    for (int i = 0; i < 4; ++i) w4[i] = (b3 ? v8[i + 4] : v8[i]) + lane_xor<8>(b3 ? v8[i] : v8[i + 4]);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) w2[i] = (b2 ? w4[i + 2] : w4[i]) + __shfl_xor(b2 ? w4[i] : w4[i + 2], 4);
-    float w1 = (b1 ? w2[1] : w2[0]) + __shfl_xor(b1 ? w2[0] : w2[1], 2);
-    w1 += __shfl_xor(w1, 1);
+    for (int i = 0; i < 2; ++i) w2[i] = (b2 ? w4[i + 2] : w4[i]) + lane_xor<4>(b2 ? w4[i] : w4[i + 2]);
+    float w1 = (b1 ? w2[1] : w2[0]) + lane_xor<2>(b1 ? w2[0] : w2[1]);
+    w1 += lane_xor<1>(w1);
     if ((l15 & 1) == 0) {
         const int idx = l15 >> 1;          // b3 b2 b1
         jaux[(size_t)blockIdx.x * 256 + (idx < 4 ? 0 : 128) + f0 + (idx & 3)] = w1;
@@ -1007,8 +1007,7 @@ __device__ __forceinline__ void atb_fast_bf(const AtbUnit& u, int c, float* __re
     if (want_bias) {                 // the wave's 4 row groups (lanes 16 apart), then the 4 waves through LDS
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            bs[i] += __shfl_xor(bs[i], 16);
-            bs[i] += __shfl_xor(bs[i], 32);
+            bs[i] = group_sum(bs[i]);
         }
         __syncthreads();
         if (lane < 16) {
