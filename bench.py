@@ -81,7 +81,7 @@ def kernel_work_model(sizes, L, n_nodes, n_edges, cross=True, d0=69, dh=64, d_em
     pp = sum(float(a) * b for a, b in sizes)              # sum over pairs of n_lig * n_rec
     W = {k: dict(flops=0.0, flops_written=0.0, bytes=0.0) for k in
          ('k_linear', 'k_rowchain', 'k_rowwave', 'k_rowres', 'k_attn_fwd', 'k_attn_bwd', 'k_edge_fwd', 'k_edge_bwd', 'k_node_gather',
-          'k_atb', 'k_atb_reduce', 'k_edge_attn_fwd', 'k_attn_bwd_gather', 'k_keypoint', 'k_keypoint_bwd_a', 'k_keypoint_bwd_b',
+          'k_atb', 'k_atb_reduce', 'k_edge_attn_fwd', 'k_attn_bwd_gather', 'k_keypoint', 'k_keypoint_bwd', 'k_keypoint_bwd_a', 'k_keypoint_bwd_b',
           'k_head_u', 'k_head_u_bwd', 'k_attn_bwd_kvds', 'k_attn_bwd_qds', 'k_kabsch_fwd', 'k_kabsch_bwd', 'k_embed_fwd',
           'k_embed_bwd', 'k_seg_mean', 'k_qmean_bwd', 'k_reduce_segments')}
     # k_edge_attn_fwd: the 64-wide layers' edge + attention forward in one launch (small batches); k_attn_bwd_gather: the
@@ -157,6 +157,9 @@ def kernel_work_model(sizes, L, n_nodes, n_edges, cross=True, d0=69, dh=64, d_em
     # over the protein's nodes, keypoints; backward twice that
     W['k_keypoint']['flops'] += N * 2 * 64 * K
     W['k_keypoint']['bytes'] += N * 4 * (64 + K + 3)
+    # (the matrix-product backward, one launch: du and dH products; reads h, scores, z, writes dH, dz - no dscores array)
+    W['k_keypoint_bwd']['flops'] += 2 * N * 2 * 64 * K
+    W['k_keypoint_bwd']['bytes'] += N * 4 * (64 + K + 3 + 64 + 3)
     W['k_keypoint_bwd_a']['flops'] += N * 2 * 64 * K
     W['k_keypoint_bwd_a']['bytes'] += N * 4 * (64 + 2 * K + 3)
     W['k_keypoint_bwd_b']['flops'] += N * 2 * 64 * K

@@ -449,4 +449,4 @@ int eqd_launch_head_u_bwd(const EqdGraph* g, int K, const float* Wk, const float
 int eqd_launch_qmean_bwd(const EqdGraph* g, int K, const float* dqm_part, float* dhm, hipStream_t st);
 int eqd_launch_keypoint_bwd(const EqdGraph* g, int K, const float* H, const float* Z, const float* scores,
                             const float* lse, const float* u, const float* dY, float* dscores, float* du,
-                            float* dH, float* dZ, hipStream_t st);
+                            float* dH, float* dZ, hipStream_t st, const float* Y = nullptr);      // Y: the forward's keypoints, or NULL

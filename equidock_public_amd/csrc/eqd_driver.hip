@@ -667,7 +667,7 @@ static int head_backward(const EqdModelDesc* m, const EqdGraph* g, const Dims& D
     RC(eqd_kabsch_bwd_impl(B, K, S.Y, S.A, S.T, d_T, d_b, d_Ylig, d_Yrec, W.dY, st, g, d_lig, S.usv));   // + rigid apply backward
     const float* H = S.h[D.L];
     const float* Z = S.x[D.L];
-    RC(eqd_launch_keypoint_bwd(g, K, H, Z, S.scores, S.klse, S.u, W.dY, W.dscores, W.du, W.dHk, dX_L, st));
+    RC(eqd_launch_keypoint_bwd(g, K, H, Z, S.scores, S.klse, S.u, W.dY, W.dscores, W.du, W.dHk, dX_L, st, S.Y));
     if (d_h_last) RC(eqd_launch_axpy(W.dHk, d_h_last, 1.f, (size_t)N * 64, st));      // a loss on the last layer's node data
     if (d_x_last) RC(eqd_launch_axpy(dX_L, d_x_last, 1.f, (size_t)N * 3, st));
     RC(eqd_launch_head_u_bwd(g, K, gpar[G_WK], gpar[G_WQ], S.qmean, S.qp, W.du, ggrad[G_WK], ggrad[G_WQ], W.dqm_part,

@@ -78,6 +78,33 @@ __global__ void k_head_u(int B, int K, const float* __restrict__ Wk, const float
     u[((size_t)s * K + k) * 64 + t] = b * 0.125f;
 }
 
+#include "eqd_keypoint_mm_inl.h"
+// EQD_KEYPOINT_MM: 0 = the first kernels (one workgroup per (segment, head)), 1 = the matrix-product forms everywhere,
+// unset = the product forward everywhere, the product backward where it has enough workgroups (keypoint_bwd_chunks)
+static int keypoint_mm_mode() {
+    const char* f = eqd_tunable("EQD_KEYPOINT_MM");
+    if (f && (f[0] == '0' || f[0] == '1') && f[1] == 0) return f[0] - '0';
+    return 2;
+}
+// row chunks per segment of the product backward (0: use the first kernels).  A workgroup spends ~2 000 clocks per 16-row
+// tile: enough chunks to fill the chip, of at least four tiles, as long as the partial du blocks fit the dscores workspace
+// ([N][K] floats, unused by this form: S NC K 64 <= N K) - EQD_KEYPOINT_NC forces a count (tests, experiments)
+static int keypoint_bwd_chunks(const EqdGraph* g, int K) {
+    const int mode = keypoint_mm_mode();
+    if (mode == 0 || K > 64) return 0;
+    const int S = 2 * g->n_pairs;
+    const int cap = g->n_nodes / (64 * S);      // partial blocks that fit
+    const int nt = (g->max_seg + 15) / 16;
+    int nc = (eqd_num_cus() + S - 1) / S;
+    if (nc > (nt + 3) / 4) nc = (nt + 3) / 4;
+    const char* f = eqd_tunable("EQD_KEYPOINT_NC");
+    if (f && f[0]) nc = atoi(f);
+    if (nc > cap) nc = cap;
+    if (nc < 1) nc = 1;
+    if (mode == 2 && S * nc < 32) return 0;      // too few workgroups: the (segment, head) kernels fill the chip better
+    return nc;
+}
+
 __device__ __forceinline__ float block_reduce_sum(float v, float* red) {
     v = wave_sum(v);
     const int wave = threadIdx.x >> 6;
@@ -97,7 +124,8 @@ __device__ __forceinline__ float block_reduce_max(float v, float* red) {
     return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
-// per (segment, head): scores over the segment's nodes, softmax, Y = att^T Z
+// per (segment, head): scores over the segment's nodes, softmax, Y = att^T Z   (the first form; k_keypoint_mm replaces it,
+// EQD_KEYPOINT_MM=0 selects it)
 __global__ __launch_bounds__(EQD_BLOCK) void k_keypoint(const int32_t* __restrict__ seg_off, int K,
                                                         const float* __restrict__ u, const float* __restrict__ H,
                                                         const float* __restrict__ Z, float* __restrict__ Y,
@@ -165,8 +193,17 @@ int eqd_keypoint_pool_fwd_impl(const EqdGraph* g, int n_heads, const float* Wk, 
                        u);
     int rc = eqd_check_launch("k_head_u");
     if (rc) return rc;
-    hipLaunchKernelGGL(k_keypoint, dim3(2 * g->n_pairs, n_heads), dim3(EQD_BLOCK), 0, st, g->seg_off, n_heads, u, H, Z,
-                       Y, Y_lig_out, Y_rec_out, g->n_pairs, scores, lse);
+    if (keypoint_mm_mode() != 0) {
+        const dim3 grid(2 * g->n_pairs, (n_heads + 15) / 16);
+        if ((g->max_seg + 15) / 16 >= 64 && (int)(grid.x * grid.y) < eqd_num_cus())      // few long segments: 16 waves per workgroup
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_keypoint_mm<16>), grid, dim3(1024), 0, st, g->seg_off, n_heads, u, H, Z, Y,
+                               Y_lig_out, Y_rec_out, g->n_pairs, scores, lse);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_keypoint_mm<4>), grid, dim3(EQD_BLOCK), 0, st, g->seg_off, n_heads, u, H, Z, Y,
+                               Y_lig_out, Y_rec_out, g->n_pairs, scores, lse);
+    } else
+        hipLaunchKernelGGL(k_keypoint, dim3(2 * g->n_pairs, n_heads), dim3(EQD_BLOCK), 0, st, g->seg_off, n_heads, u, H, Z,
+                           Y, Y_lig_out, Y_rec_out, g->n_pairs, scores, lse);
     return eqd_check_launch("k_keypoint");
 }
 
@@ -242,11 +279,20 @@ __global__ void k_keypoint_bwd_b(const int32_t* __restrict__ seg_off, int nseg, 
 
 int eqd_launch_keypoint_bwd(const EqdGraph* g, int K, const float* H, const float* Z, const float* scores,
                             const float* lse, const float* u, const float* dY, float* dscores, float* du, float* dH,
-                            float* dZ, hipStream_t st) {
+                            float* dZ, hipStream_t st, const float* Y) {
     if (g->n_pairs == 0 || g->n_nodes == 0) return EQD_OK;
     if (K > 128) {
         eqd_set_error("num_att_heads %d > 128 unsupported", K);
         return EQD_ERR_UNSUPPORTED;
+    }
+    if (const int nc = keypoint_bwd_chunks(g, K)) {
+        // (dscores: the workspace of the first kernels holds the chunks' partial du blocks here)
+        hipLaunchKernelGGL(k_keypoint_bwd_mm, dim3(2 * g->n_pairs, nc), dim3(EQD_BLOCK), 0, st, g->seg_off, K, H, Z, scores, lse,
+                           u, dY, Y, nc == 1 ? du : dscores, dH, dZ);
+        int rc = eqd_check_launch("k_keypoint_bwd");
+        if (rc || nc == 1) return rc;
+        hipLaunchKernelGGL(k_keypoint_du_reduce, dim3(2 * g->n_pairs), dim3(256), 0, st, nc, K, dscores, du);
+        return eqd_check_launch("k_keypoint_du_reduce");
     }
     hipLaunchKernelGGL(k_keypoint_bwd_a, dim3(2 * g->n_pairs, K), dim3(EQD_BLOCK), 0, st, g->seg_off, K, H, Z, scores,
                        lse, dY, dscores, du);
@@ -420,7 +466,7 @@ extern "C" int eqd_keypoint_pool_bwd(const EqdGraph* g, int n_heads, const float
         return EQD_ERR_WORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
-    int rc = eqd_launch_keypoint_bwd(g, n_heads, H, Z, scores, lse, u, dY, dscores, du, dH, dZ, st);
+    int rc = eqd_launch_keypoint_bwd(g, n_heads, H, Z, scores, lse, u, dY, dscores, du, dH, dZ, st, nullptr);
     if (rc) return rc;
     rc = eqd_launch_head_u_bwd(g, n_heads, Wk, Wq, qmean, qp, du, dWk, dWq, dqm_part, st, nullptr, nullptr);
     if (rc) return rc;

@@ -933,8 +933,8 @@ def check_kabsch(dev):
     grad_close(dY, Yl.grad, what='Kabsch dY', l2=2e-4, mx=2e-4)
 
 
-def check_keypoints_and_apply(dev):
-    g, pk, gs = small_graph(dev, sizes=((40, 33), (25, 61)), degrade=False)
+def check_keypoints_and_apply(dev, sizes=((40, 33), (25, 61))):
+    g, pk, gs = small_graph(dev, sizes=sizes, degrade=False)
     torch.manual_seed(7)
     N, B, K = pk.n_nodes, pk.n_pairs, 50
     Wk, Wq = torch.randn(K * 64, 64) * 0.3, torch.randn(K * 64, 64) * 0.3

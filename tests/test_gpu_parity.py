@@ -86,6 +86,27 @@ def test_keypoints_and_apply(dev):
     pc.check_keypoints_and_apply(dev)
 
 
+@pytest.mark.parametrize('form', ['first', 'mm', 'mm_chunks', 'mm_long'])
+def test_keypoint_kernel_forms(dev, form, monkeypatch):
+    """both sets of keypoint-pooling kernels (one workgroup per (segment, head); the matrix-product forms with one / several
+    row chunks per segment) against torch, the golden vectors and the oracle's head backward"""
+    from tests import parity_common as pc
+    monkeypatch.setenv('EQD_KEYPOINT_MM', '0' if form == 'first' else '1')
+    if form == 'mm_long':      # one long segment: the forward's 16-wave workgroups, a backward of 8 chunks (some of them empty)
+        pc.check_keypoints_and_apply(dev, sizes=((1030, 40),))
+        return
+    if form == 'mm_chunks':
+        monkeypatch.setenv('EQD_KEYPOINT_NC', '2')
+        pc.check_keypoints_and_apply(dev, sizes=((150, 130), (140, 161)))
+        pc.check_head_backward(dev, [(300, 280), (290, 310)], layers=3, what=f'keypoint kernels: {form}')
+    else:
+        pc.check_keypoints_and_apply(dev)
+        pc.check_head_backward(dev, [(41, 57), (66, 38)], layers=3, what=f'keypoint kernels: {form}')
+    pc.check_model_case(dev, 'D_degraded3')
+    names = pc.launch_names_of_a_step(dev, 'D_degraded3')
+    assert ('k_keypoint_bwd' in names) == (form != 'first') and ('k_keypoint_bwd_a' in names) == (form == 'first'), sorted(set(names))
+
+
 @pytest.mark.parametrize('name', ['A_b1_shared5', 'B_b3_dips8', 'C_b2_200', 'D_degraded3', 'E_svd_guard'])
 def test_model_vs_golden(dev, name):
     from tests import parity_common as pc

@@ -75,6 +75,26 @@ def test_keypoints_and_apply():
     pc.check_keypoints_and_apply(DEV)
 
 
+@pytest.mark.parametrize('form', ['first', 'mm', 'mm_chunks', 'mm_long'])
+def test_keypoint_kernel_forms(form, monkeypatch):
+    """Keypoint pooling has two sets of kernels: one workgroup per (segment, head) (EQD_KEYPOINT_MM=0) and the matrix-product
+    forms (eqd_keypoint_mm_inl.h; the backward with one or several row chunks per segment, and with the per-head dot taken
+    from the forward's Y - the model path - or from a pass over the rows - the operator entry point)."""
+    monkeypatch.setenv('EQD_KEYPOINT_MM', '0' if form == 'first' else '1')
+    if form == 'mm_long':      # one long segment: the forward's 16-wave workgroups, a backward of 8 chunks (some of them empty)
+        pc.check_keypoints_and_apply(DEV, sizes=((1030, 40),))
+        return
+    if form == 'mm_chunks':
+        monkeypatch.setenv('EQD_KEYPOINT_NC', '2')
+        pc.check_keypoints_and_apply(DEV, sizes=((150, 130), (140, 161)))      # 581 nodes: two partial du blocks per segment fit
+    else:
+        pc.check_keypoints_and_apply(DEV)
+    pc.check_model_case(DEV, 'D_degraded3')
+    pc.check_head_backward(DEV, [(41, 57), (66, 38)], layers=3, what=f'keypoint kernels: {form}')
+    names = pc.launch_names_of_a_step(DEV, 'D_degraded3')
+    assert ('k_keypoint_bwd' in names) == (form != 'first') and ('k_keypoint_bwd_a' in names) == (form == 'first'), sorted(set(names))
+
+
 @pytest.mark.parametrize('name', ['A_b1_shared5', 'D_degraded3', 'E_svd_guard'])
 def test_model_vs_golden(name):
     pc.check_model_case(DEV, name)
