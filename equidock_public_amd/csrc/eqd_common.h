@@ -445,8 +445,9 @@ size_t eqd_head_u_bwd_partial_floats(int n_pairs, int K);      // 0 when the bat
 // part / defer: partial buffer of that size and the pass's pending-reduction list (both or neither)
 int eqd_launch_head_u_bwd(const EqdGraph* g, int K, const float* Wk, const float* Wq, const float* qmean,
                           const float* qp, const float* du, float* dWk, float* dWq, float* dqm_part, hipStream_t st,
-                          float* part, EqdRedList* defer);
+                          float* part, EqdRedList* defer, int du_chunks = 1);      // du_chunks > 1: du = partial blocks (k_keypoint_bwd_mm)
 int eqd_launch_qmean_bwd(const EqdGraph* g, int K, const float* dqm_part, float* dhm, hipStream_t st);
 int eqd_launch_keypoint_bwd(const EqdGraph* g, int K, const float* H, const float* Z, const float* scores,
                             const float* lse, const float* u, const float* dY, float* dscores, float* du,
-                            float* dH, float* dZ, hipStream_t st, const float* Y = nullptr);      // Y: the forward's keypoints, or NULL
+                            float* dH, float* dZ, hipStream_t st, const float* Y = nullptr,      // Y: the forward's keypoints, or NULL
+                            int* du_chunks = nullptr);

@@ -667,11 +667,12 @@ static int head_backward(const EqdModelDesc* m, const EqdGraph* g, const Dims& D
     RC(eqd_kabsch_bwd_impl(B, K, S.Y, S.A, S.T, d_T, d_b, d_Ylig, d_Yrec, W.dY, st, g, d_lig, S.usv));   // + rigid apply backward
     const float* H = S.h[D.L];
     const float* Z = S.x[D.L];
-    RC(eqd_launch_keypoint_bwd(g, K, H, Z, S.scores, S.klse, S.u, W.dY, W.dscores, W.du, W.dHk, dX_L, st, S.Y));
+    int du_chunks = 1;      // > 1: the keypoint backward left partial du blocks in W.dscores for k_head_u_bwd to sum
+    RC(eqd_launch_keypoint_bwd(g, K, H, Z, S.scores, S.klse, S.u, W.dY, W.dscores, W.du, W.dHk, dX_L, st, S.Y, &du_chunks));
     if (d_h_last) RC(eqd_launch_axpy(W.dHk, d_h_last, 1.f, (size_t)N * 64, st));      // a loss on the last layer's node data
     if (d_x_last) RC(eqd_launch_axpy(dX_L, d_x_last, 1.f, (size_t)N * 3, st));
-    RC(eqd_launch_head_u_bwd(g, K, gpar[G_WK], gpar[G_WQ], S.qmean, S.qp, W.du, ggrad[G_WK], ggrad[G_WQ], W.dqm_part,
-                             st, W.head_part, defer));
+    RC(eqd_launch_head_u_bwd(g, K, gpar[G_WK], gpar[G_WQ], S.qmean, S.qp, du_chunks > 1 ? W.dscores : W.du, ggrad[G_WK],
+                             ggrad[G_WQ], W.dqm_part, st, W.head_part, defer, du_chunks));
     RC(eqd_launch_qmean_bwd(g, K, W.dqm_part, W.dhm, st));
     if (drop) {      // d(keep * s * LeakyReLU(z)): the dropout factor rides on the incoming gradient, the LeakyReLU
                      // derivative comes from the saved activation's sign as without dropout

@@ -279,20 +279,22 @@ __global__ void k_keypoint_bwd_b(const int32_t* __restrict__ seg_off, int nseg, 
 
 int eqd_launch_keypoint_bwd(const EqdGraph* g, int K, const float* H, const float* Z, const float* scores,
                             const float* lse, const float* u, const float* dY, float* dscores, float* du, float* dH,
-                            float* dZ, hipStream_t st, const float* Y) {
+                            float* dZ, hipStream_t st, const float* Y, int* du_chunks) {
+    // du_chunks (optional): the caller's k_head_u_bwd sums the chunks' partial du blocks (they stay in `dscores`,
+    // *du_chunks = their count per segment); without it the segments are not split
+    if (du_chunks) *du_chunks = 1;
     if (g->n_pairs == 0 || g->n_nodes == 0) return EQD_OK;
     if (K > 128) {
         eqd_set_error("num_att_heads %d > 128 unsupported", K);
         return EQD_ERR_UNSUPPORTED;
     }
-    if (const int nc = keypoint_bwd_chunks(g, K)) {
+    if (int nc = keypoint_bwd_chunks(g, K)) {
+        if (!du_chunks) nc = 1;
         // (dscores: the workspace of the first kernels holds the chunks' partial du blocks here)
         hipLaunchKernelGGL(k_keypoint_bwd_mm, dim3(2 * g->n_pairs, nc), dim3(EQD_BLOCK), 0, st, g->seg_off, K, H, Z, scores, lse,
                            u, dY, Y, nc == 1 ? du : dscores, dH, dZ);
-        int rc = eqd_check_launch("k_keypoint_bwd");
-        if (rc || nc == 1) return rc;
-        hipLaunchKernelGGL(k_keypoint_du_reduce, dim3(2 * g->n_pairs), dim3(256), 0, st, nc, K, dscores, du);
-        return eqd_check_launch("k_keypoint_du_reduce");
+        if (du_chunks) *du_chunks = nc;
+        return eqd_check_launch("k_keypoint_bwd");
     }
     hipLaunchKernelGGL(k_keypoint_bwd_a, dim3(2 * g->n_pairs, K), dim3(EQD_BLOCK), 0, st, g->seg_off, K, H, Z, scores,
                        lse, dY, dscores, du);
@@ -313,15 +315,47 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_head_u_bwd(int B, int K, const fl
                                                           const float* __restrict__ Wq,
                                                           const float* __restrict__ qmean,
                                                           const float* __restrict__ qp, const float* __restrict__ du,
-                                                          float* __restrict__ dWk, float* __restrict__ dWq,
+                                                          int du_chunks, float* __restrict__ dWk, float* __restrict__ dWq,
                                                           float* __restrict__ dqm_part, float* __restrict__ part,
                                                           int segs_per_group) {
     // The head's two 64 x 64 matrices and 16 segments' vectors at a time live in LDS (one coalesced fetch
     // each); all products then run out of LDS.  Sums over segments stay sequential (deterministic).
-    __shared__ float wk[64 * 65], wq[64 * 65];
-    __shared__ float sqp[16 * 64], sdu[16 * 64], sqm[16 * 64], sdq[16 * 64];
+    // LDS traffic is the kernel's time (15 us for 16 segments with 4-byte reads): every operand is laid out so that the
+    // contraction index is contiguous and read 16 bytes at a time - wk[j][c] rows, Wq transposed (wqT[c][j]), the
+    // segments' vectors - and a thread's 16 outputs of the outer products are CONSECUTIVE j (4 broadcast b128 reads per
+    // segment).  Every sum runs in the order it always did: same bits.
+    // du_chunks > 1: du is the product backward's partial blocks [(s NC + chunk) K + k][64] (k_keypoint_bwd_mm), summed
+    // here in chunk order instead of by a launch of their own.
+    constexpr int WS = 68;      // row stride: 16-byte aligned, 4 c mod 64 banks - conflict-free b128 reads for 16 lanes
+    __shared__ __attribute__((aligned(16))) float wk[64 * WS], wqT[64 * WS];
+    __shared__ __attribute__((aligned(16))) float sqp[16 * 64], sdu[16 * 64], sqm[16 * 64], sdq[16 * 64];
     const int k = blockIdx.x, t = threadIdx.x;
-    const int c = t & 63, j0 = t >> 6;  // thread owns elements (j, c) for j = j0, j0+4, ...
+    const int c = t & 63, j0 = t >> 6;  // thread owns elements (j, c) for j = 16 j0 .. 16 j0 + 15
+    const int Sbeg0 = (int)blockIdx.y * segs_per_group;
+    const int Send = 2 * B < Sbeg0 + segs_per_group ? 2 * B : Sbeg0 + segs_per_group;
+    float pv[4][3];      // [i]: qp, du / 8, qmean[partner] of element t + 256 i of a 16-segment slab
+    auto fetch_vectors = [&](int s0, float (&v)[4][3]) {
+        const int ns = Send - s0 < 16 ? Send - s0 : 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = t + 256 * i, sl = idx >> 6, cc = idx & 63;
+            const int s = s0 + sl;
+            const bool ok = sl < ns;
+            const int partner = s < B ? s + B : s - B;
+            v[i][0] = ok ? qp[((size_t)s * K + k) * 64 + cc] : 0.f;
+            float d = 0.f;
+            if (ok) {
+                if (du_chunks <= 1) {
+                    d = du[((size_t)s * K + k) * 64 + cc];
+                } else {
+                    for (int ch = 0; ch < du_chunks; ++ch) d += du[(((size_t)s * du_chunks + ch) * K + k) * 64 + cc];
+                }
+            }
+            v[i][1] = d * 0.125f;
+            v[i][2] = ok ? qmean[(size_t)partner * 64 + cc] : 0.f;
+        }
+    };
+    float oldK[16], oldQ[16];
     {
         float4 a[4], b[4];
 #pragma unroll
@@ -329,69 +363,95 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_head_u_bwd(int B, int K, const fl
             a[i] = ((const float4*)(Wk + (size_t)k * 4096))[t + 256 * i];
             b[i] = ((const float4*)(Wq + (size_t)k * 4096))[t + 256 * i];
         }
+        // the first 16 segments' vectors and (single group) the gradients this block adds to are requested behind the
+        // weights, not after them: one memory round trip in front of the arithmetic instead of three
+        fetch_vectors(Sbeg0, pv);
+        if (!part) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                oldK[i] = dWk[((size_t)k * 64 + 16 * j0 + i) * 64 + c];
+                oldQ[i] = dWq[((size_t)k * 64 + 16 * j0 + i) * 64 + c];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int idx = t + 256 * i, r = idx >> 4, c4 = (idx & 15) * 4;
-            wk[r * 65 + c4] = a[i].x; wk[r * 65 + c4 + 1] = a[i].y; wk[r * 65 + c4 + 2] = a[i].z; wk[r * 65 + c4 + 3] = a[i].w;
-            wq[r * 65 + c4] = b[i].x; wq[r * 65 + c4 + 1] = b[i].y; wq[r * 65 + c4 + 2] = b[i].z; wq[r * 65 + c4 + 3] = b[i].w;
+            *(float4*)&wk[r * WS + c4] = a[i];
+            wqT[c4 * WS + r] = b[i].x; wqT[(c4 + 1) * WS + r] = b[i].y; wqT[(c4 + 2) * WS + r] = b[i].z; wqT[(c4 + 3) * WS + r] = b[i].w;
         }
     }
     float accK[16], accQ[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) accK[i] = accQ[i] = 0.f;
-    const int Sbeg = (int)blockIdx.y * segs_per_group;
-    const int S2 = 2 * B < Sbeg + segs_per_group ? 2 * B : Sbeg + segs_per_group;
+    const int Sbeg = Sbeg0, S2 = Send;
     for (int s0 = Sbeg; s0 < S2; s0 += 16) {
         const int ns = S2 - s0 < 16 ? S2 - s0 : 16;
+        if (s0 != Sbeg) fetch_vectors(s0, pv);
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int idx = t + 256 * i, sl = idx >> 6, cc = idx & 63;
-            const int s = s0 + sl;
-            const bool ok = sl < ns;
-            const int partner = s < B ? s + B : s - B;
-            sqp[idx] = ok ? qp[((size_t)s * K + k) * 64 + cc] : 0.f;
-            sdu[idx] = ok ? du[((size_t)s * K + k) * 64 + cc] * 0.125f : 0.f;
-            sqm[idx] = ok ? qmean[(size_t)partner * 64 + cc] : 0.f;
+            const int idx = t + 256 * i;
+            sqp[idx] = pv[i][0];
+            sdu[idx] = pv[i][1];
+            sqm[idx] = pv[i][2];
         }
         __syncthreads();
+        {          // dqp[s][j] = sum_c Wk[j][c] du[s][c]   (this thread: j = c, segments j0 + 4 i)
+            float a[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {          // dqp[s][j] = sum_c Wk[j][c] du[s][c]
-            const int sl = j0 + 4 * i;
-            float a = 0.f;
-            for (int cc = 0; cc < 64; ++cc) a += wk[c * 65 + cc] * sdu[sl * 64 + cc];
-            sdq[sl * 64 + c] = a;
+            for (int q = 0; q < 16; ++q) {
+                const float4 w = *(const float4*)&wk[c * WS + 4 * q];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 d = *(const float4*)&sdu[(j0 + 4 * i) * 64 + 4 * q];
+                    a[i] += w.x * d.x; a[i] += w.y * d.y; a[i] += w.z * d.z; a[i] += w.w * d.w;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sdq[(j0 + 4 * i) * 64 + c] = a[i];
         }
         __syncthreads();
+        {          // d qmean[partner(s)] part = Wq^T dqp[s]
+            float a[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {          // d qmean[partner(s)] part = Wq^T dqp[s]
-            const int sl = j0 + 4 * i;
-            float a = 0.f;
-            for (int j = 0; j < 64; ++j) a += wq[j * 65 + c] * sdq[sl * 64 + j];
-            if (sl < ns) dqm_part[((size_t)(s0 + sl) * K + k) * 64 + c] = a;
+            for (int q = 0; q < 16; ++q) {
+                const float4 w = *(const float4*)&wqT[c * WS + 4 * q];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 d = *(const float4*)&sdq[(j0 + 4 * i) * 64 + 4 * q];
+                    a[i] += w.x * d.x; a[i] += w.y * d.y; a[i] += w.z * d.z; a[i] += w.w * d.w;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int sl = j0 + 4 * i;
+                if (sl < ns) dqm_part[((size_t)(s0 + sl) * K + k) * 64 + c] = a[i];
+            }
         }
         for (int sl = 0; sl < ns; ++sl) {
+            const float dc = sdu[sl * 64 + c], mc = sqm[sl * 64 + c];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int j = j0 + 4 * i;
-                accK[i] += sqp[sl * 64 + j] * sdu[sl * 64 + c];
-                accQ[i] += sdq[sl * 64 + j] * sqm[sl * 64 + c];
+            for (int q = 0; q < 4; ++q) {
+                const float4 pq = *(const float4*)&sqp[sl * 64 + 16 * j0 + 4 * q];
+                const float4 dq = *(const float4*)&sdq[sl * 64 + 16 * j0 + 4 * q];
+                accK[4 * q] += pq.x * dc; accK[4 * q + 1] += pq.y * dc; accK[4 * q + 2] += pq.z * dc; accK[4 * q + 3] += pq.w * dc;
+                accQ[4 * q] += dq.x * mc; accQ[4 * q + 1] += dq.y * mc; accQ[4 * q + 2] += dq.z * mc; accQ[4 * q + 3] += dq.w * mc;
             }
         }
     }
     if (!part) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int j = j0 + 4 * i;
-            dWk[((size_t)k * 64 + j) * 64 + c] += accK[i];
-            dWq[((size_t)k * 64 + j) * 64 + c] += accQ[i];
+            const int j = 16 * j0 + i;
+            dWk[((size_t)k * 64 + j) * 64 + c] = oldK[i] + accK[i];
+            dWq[((size_t)k * 64 + j) * 64 + c] = oldQ[i] + accQ[i];
         }
     } else {
         float* pk = part + ((size_t)blockIdx.y * 2 * K + k) * 4096;
         float* pq = pk + (size_t)K * 4096;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int j = j0 + 4 * i;
+            const int j = 16 * j0 + i;
             pk[j * 64 + c] = accK[i];
             pq[j * 64 + c] = accQ[i];
         }
@@ -404,16 +464,16 @@ size_t eqd_head_u_bwd_partial_floats(int n_pairs, int K) {
 }
 int eqd_launch_head_u_bwd(const EqdGraph* g, int K, const float* Wk, const float* Wq, const float* qmean,
                           const float* qp, const float* du, float* dWk, float* dWq, float* dqm_part, hipStream_t st,
-                          float* part, EqdRedList* defer) {
+                          float* part, EqdRedList* defer, int du_chunks) {
     if (g->n_pairs == 0) return EQD_OK;
     const int groups = (2 * g->n_pairs + HU_GROUP - 1) / HU_GROUP;
     if (groups <= 1 || !part || !defer || defer->n + 2 > 512) {      // small batch (or no partial buffer): one block per head
-        hipLaunchKernelGGL(k_head_u_bwd, dim3(K), dim3(EQD_BLOCK), 0, st, g->n_pairs, K, Wk, Wq, qmean, qp, du, dWk, dWq,
-                           dqm_part, (float*)nullptr, 2 * g->n_pairs);
+        hipLaunchKernelGGL(k_head_u_bwd, dim3(K), dim3(EQD_BLOCK), 0, st, g->n_pairs, K, Wk, Wq, qmean, qp, du, du_chunks, dWk,
+                           dWq, dqm_part, (float*)nullptr, 2 * g->n_pairs);
         return eqd_check_launch("k_head_u_bwd");
     }
-    hipLaunchKernelGGL(k_head_u_bwd, dim3(K, groups), dim3(EQD_BLOCK), 0, st, g->n_pairs, K, Wk, Wq, qmean, qp, du, dWk,
-                       dWq, dqm_part, part, HU_GROUP);
+    hipLaunchKernelGGL(k_head_u_bwd, dim3(K, groups), dim3(EQD_BLOCK), 0, st, g->n_pairs, K, Wk, Wq, qmean, qp, du, du_chunks,
+                       dWk, dWq, dqm_part, part, HU_GROUP);
     const int n = K * 4096, stride = 2 * K * 4096;
     defer->seg[defer->n++] = EqdRedSeg{part, groups, stride, n, dWk, 0, 0, 0};
     defer->seg[defer->n++] = EqdRedSeg{part + n, groups, stride, n, dWq, 0, 0, 0};
@@ -466,9 +526,10 @@ extern "C" int eqd_keypoint_pool_bwd(const EqdGraph* g, int n_heads, const float
         return EQD_ERR_WORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
-    int rc = eqd_launch_keypoint_bwd(g, n_heads, H, Z, scores, lse, u, dY, dscores, du, dH, dZ, st, nullptr);
+    int nch = 1;
+    int rc = eqd_launch_keypoint_bwd(g, n_heads, H, Z, scores, lse, u, dY, dscores, du, dH, dZ, st, nullptr, &nch);
     if (rc) return rc;
-    rc = eqd_launch_head_u_bwd(g, n_heads, Wk, Wq, qmean, qp, du, dWk, dWq, dqm_part, st, nullptr, nullptr);
+    rc = eqd_launch_head_u_bwd(g, n_heads, Wk, Wq, qmean, qp, nch > 1 ? dscores : du, dWk, dWq, dqm_part, st, nullptr, nullptr, nch);
     if (rc) return rc;
     return eqd_launch_qmean_bwd(g, n_heads, dqm_part, d_hm, st);
 }

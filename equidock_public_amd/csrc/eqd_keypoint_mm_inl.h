@@ -167,7 +167,7 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_keypoint_bwd_mm(const int32_t* __
                                                                float* __restrict__ du, float* __restrict__ dH,
                                                                float* __restrict__ dZ) {
     // gridDim.y = NC row chunks per segment: chunk c takes the segment's tiles [c tpc, (c + 1) tpc) and writes its du to
-    // du[(s NC + c) K + k][:] (NC == 1: the result itself, else partial sums for k_keypoint_du_reduce)
+    // du[(s NC + c) K + k][:] (NC == 1: the result itself, else partial sums that k_head_u_bwd adds up in chunk order)
     __shared__ __attribute__((aligned(16))) float xh[2][EQD_WAVES][4][16 * KPB_RS];      // dH partials [buffer][wave][c block][row][16 c]
     __shared__ float xz[2][EQD_WAVES][16][4];
     __shared__ float tr[EQD_WAVES][16][17];                                                // wave-private [head][row]
@@ -322,17 +322,4 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_keypoint_bwd_mm(const int32_t* __
             const f32x4 o = {accU[0][r], accU[1][r], accU[2][r], accU[3][r]};
             *(EQD_GAS f4v*)(du + (((size_t)s * NC + chunk) * K + hB + r) * 64 + 4 * l15) = o;
         }
-}
-// du[s][k][:] = sum over the chunks, in chunk order
-__global__ void k_keypoint_du_reduce(int NC, int K, const float* __restrict__ part, float* __restrict__ du) {
-    const int s = blockIdx.x, t = threadIdx.x;      // 256 threads x float4 = 16 heads x 64 columns per step
-    for (int i = t; i < K * 16; i += 256) {
-        f32x4 a = f4zero();
-        for (int c = 0; c < NC; ++c) {
-            const f32x4 v = *(const EQD_GAS f4v*)(part + (((size_t)s * NC + c) * K) * 64 + 4 * i);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) a[r] += v[r];
-        }
-        *(EQD_GAS f4v*)(du + (size_t)s * K * 64 + 4 * i) = a;
-    }
 }
