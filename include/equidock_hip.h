@@ -56,8 +56,8 @@ int eqd_tile_edges(void);
 /* 1 when the library is the x86 host simulator built by tests/hostsim (never shipped), else 0 */
 int eqd_is_simulator(void);
 /* The EQD_* environment switches that select kernel forms for tests and A/B measurements (EQD_FUSE_FWD, EQD_FUSE_GATHER,
- * EQD_ATT_SPLIT, EQD_ATT_BWD_SPLIT, EQD_ATT_LB, EQD_ATT_LB_NB, EQD_ROWWAVE, EQD_ROW_TILES, EQD_ROWRES_TPS, EQD_ATB_WGS,
- * EQD_ATB_XCD_ALIGN) are read ONCE per process, at their first use, so that the forward and the backward of a step always
+ * EQD_ATT_SPLIT, EQD_ATT_BWD_SPLIT, EQD_ATT_LB, EQD_ATT_LB_NB, EQD_ATT_DS, EQD_ATT_QDS_NB, EQD_ROWWAVE, EQD_ROW_TILES,
+ * EQD_ROWRES_TPS, EQD_ROWCHAIN_OCC, EQD_ATB_WGS, EQD_ATB_XCD_ALIGN, EQD_KEYPOINT_MM, EQD_KEYPOINT_NC) are read ONCE per process, at their first use, so that the forward and the backward of a step always
  * agree on the forms they run.  A caller that changes one of them afterwards calls this to make the library forget its
  * snapshot (nothing in the reference corresponds to it). */
 void eqd_tunables_reload(void);
