@@ -933,10 +933,10 @@ def check_kabsch(dev):
     grad_close(dY, Yl.grad, what='Kabsch dY', l2=2e-4, mx=2e-4)
 
 
-def check_keypoints_and_apply(dev, sizes=((40, 33), (25, 61))):
+def check_keypoints_and_apply(dev, sizes=((40, 33), (25, 61)), K=50):
     g, pk, gs = small_graph(dev, sizes=sizes, degrade=False)
     torch.manual_seed(7)
-    N, B, K = pk.n_nodes, pk.n_pairs, 50
+    N, B = pk.n_nodes, pk.n_pairs
     Wk, Wq = torch.randn(K * 64, 64) * 0.3, torch.randn(K * 64, 64) * 0.3
     qmean, H, Z = torch.randn(2 * B, 64), torch.randn(N, 64), torch.randn(N, 3) * 5
     dd = [t.to(dev) for t in (Wk, Wq, qmean, H, Z)]

@@ -86,6 +86,15 @@ def test_keypoints_and_apply(dev):
     pc.check_keypoints_and_apply(dev)
 
 
+@pytest.mark.parametrize('K', [3, 16, 37, 64, 70])
+def test_keypoint_head_counts(dev, K, monkeypatch):
+    """num_att_heads other than 50: fewer heads than a lane group holds, whole 16-head blocks, a ragged last block, the
+    largest count of the product backward (64) and one beyond it (the backward falls back to the one-head kernels)"""
+    from tests import parity_common as pc
+    monkeypatch.setenv('EQD_KEYPOINT_MM', '1')
+    pc.check_keypoints_and_apply(dev, K=K)
+
+
 @pytest.mark.parametrize('form', ['first', 'mm', 'mm_chunks', 'mm_long'])
 def test_keypoint_kernel_forms(dev, form, monkeypatch):
     """both sets of keypoint-pooling kernels (one workgroup per (segment, head); the matrix-product forms with one / several

@@ -75,6 +75,14 @@ def test_keypoints_and_apply():
     pc.check_keypoints_and_apply(DEV)
 
 
+@pytest.mark.parametrize('K', [3, 16, 37, 64, 70])
+def test_keypoint_head_counts(K, monkeypatch):
+    """num_att_heads other than 50: fewer heads than a lane group holds, whole 16-head blocks, a ragged last block, the
+    largest count of the product backward (64) and one beyond it (the backward falls back to the one-head kernels)"""
+    monkeypatch.setenv('EQD_KEYPOINT_MM', '1')
+    pc.check_keypoints_and_apply(DEV, K=K)
+
+
 @pytest.mark.parametrize('form', ['first', 'mm', 'mm_chunks', 'mm_long'])
 def test_keypoint_kernel_forms(form, monkeypatch):
     """Keypoint pooling has two sets of kernels: one workgroup per (segment, head) (EQD_KEYPOINT_MM=0) and the matrix-product
