@@ -79,6 +79,7 @@ __global__ void k_head_u(int B, int K, const float* __restrict__ Wk, const float
 }
 
 #include "eqd_keypoint_mm_inl.h"
+#include "eqd_headu_mm_inl.h"
 // EQD_KEYPOINT_MM: 0 = the first kernels (one workgroup per (segment, head)), 1 = the matrix-product forms everywhere,
 // unset = the product forward everywhere, the product backward where it has enough workgroups (keypoint_bwd_chunks)
 static int keypoint_mm_mode() {
@@ -189,8 +190,12 @@ int eqd_keypoint_pool_fwd_impl(const EqdGraph* g, int n_heads, const float* Wk, 
         return EQD_ERR_NULL;
     }
     if (g->n_pairs == 0) return EQD_OK;
-    hipLaunchKernelGGL(k_head_u, dim3(2 * g->n_pairs, n_heads), dim3(64), 0, st, g->n_pairs, n_heads, Wk, Wq, qmean, qp,
-                       u);
+    if (keypoint_mm_mode() != 0)
+        hipLaunchKernelGGL(k_head_u_mm, dim3(n_heads, (2 * g->n_pairs + 15) / 16), dim3(EQD_BLOCK), 0, st, g->n_pairs, n_heads, Wk,
+                           Wq, qmean, qp, u, 16);
+    else
+        hipLaunchKernelGGL(k_head_u, dim3(2 * g->n_pairs, n_heads), dim3(64), 0, st, g->n_pairs, n_heads, Wk, Wq, qmean, qp,
+                           u);
     int rc = eqd_check_launch("k_head_u");
     if (rc) return rc;
     if (keypoint_mm_mode() != 0) {
@@ -398,7 +403,7 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_head_u_bwd(int B, int K, const fl
         __syncthreads();
         {          // dqp[s][j] = sum_c Wk[j][c] du[s][c]   (this thread: j = c, segments j0 + 4 i)
             float a[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+#pragma unroll 2
             for (int q = 0; q < 16; ++q) {
                 const float4 w = *(const float4*)&wk[c * WS + 4 * q];
 #pragma unroll
@@ -413,7 +418,7 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_head_u_bwd(int B, int K, const fl
         __syncthreads();
         {          // d qmean[partner(s)] part = Wq^T dqp[s]
             float a[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+#pragma unroll 2
             for (int q = 0; q < 16; ++q) {
                 const float4 w = *(const float4*)&wqT[c * WS + 4 * q];
 #pragma unroll
@@ -467,13 +472,22 @@ int eqd_launch_head_u_bwd(const EqdGraph* g, int K, const float* Wk, const float
                           float* part, EqdRedList* defer, int du_chunks) {
     if (g->n_pairs == 0) return EQD_OK;
     const int groups = (2 * g->n_pairs + HU_GROUP - 1) / HU_GROUP;
+    const bool mm = keypoint_mm_mode() != 0;      // the matrix-product form (eqd_headu_mm_inl.h) or the first kernel
     if (groups <= 1 || !part || !defer || defer->n + 2 > 512) {      // small batch (or no partial buffer): one block per head
-        hipLaunchKernelGGL(k_head_u_bwd, dim3(K), dim3(EQD_BLOCK), 0, st, g->n_pairs, K, Wk, Wq, qmean, qp, du, du_chunks, dWk,
-                           dWq, dqm_part, (float*)nullptr, 2 * g->n_pairs);
+        if (mm)
+            hipLaunchKernelGGL(k_head_u_bwd_mm, dim3(K), dim3(EQD_BLOCK), 0, st, g->n_pairs, K, Wk, Wq, qmean, qp, du, du_chunks,
+                               dWk, dWq, dqm_part, (float*)nullptr, 2 * g->n_pairs);
+        else
+            hipLaunchKernelGGL(k_head_u_bwd, dim3(K), dim3(EQD_BLOCK), 0, st, g->n_pairs, K, Wk, Wq, qmean, qp, du, du_chunks, dWk,
+                               dWq, dqm_part, (float*)nullptr, 2 * g->n_pairs);
         return eqd_check_launch("k_head_u_bwd");
     }
-    hipLaunchKernelGGL(k_head_u_bwd, dim3(K, groups), dim3(EQD_BLOCK), 0, st, g->n_pairs, K, Wk, Wq, qmean, qp, du, du_chunks,
-                       dWk, dWq, dqm_part, part, HU_GROUP);
+    if (mm)
+        hipLaunchKernelGGL(k_head_u_bwd_mm, dim3(K, groups), dim3(EQD_BLOCK), 0, st, g->n_pairs, K, Wk, Wq, qmean, qp, du,
+                           du_chunks, dWk, dWq, dqm_part, part, HU_GROUP);
+    else
+        hipLaunchKernelGGL(k_head_u_bwd, dim3(K, groups), dim3(EQD_BLOCK), 0, st, g->n_pairs, K, Wk, Wq, qmean, qp, du, du_chunks,
+                           dWk, dWq, dqm_part, part, HU_GROUP);
     const int n = K * 4096, stride = 2 * K * 4096;
     defer->seg[defer->n++] = EqdRedSeg{part, groups, stride, n, dWk, 0, 0, 0};
     defer->seg[defer->n++] = EqdRedSeg{part + n, groups, stride, n, dWq, 0, 0, 0};
