@@ -112,7 +112,8 @@ def test_keypoint_kernel_forms(dev, form, monkeypatch):
         pc.check_keypoints_and_apply(dev)
         pc.check_head_backward(dev, [(41, 57), (66, 38)], layers=3, what=f'keypoint kernels: {form}')
     pc.check_model_case(dev, 'D_degraded3')
-    if form != 'mm_chunks':      # 18 pairs = 36 segments: the key / query maps' backward in two segment groups (partial sums)
+    if form == 'first':      # 18 pairs = 36 segments: the key / query maps' backward in two segment groups (partial sums); the
+                             # product kernels' groups: test_many_pairs_split_head_backward
         pc.check_keypoints_and_apply(dev, sizes=tuple((12 + i, 30 - i) for i in range(18)))
         pc.check_head_backward(dev, [(12 + i, 30 - i) for i in range(18)], layers=2, what=f'keypoint kernels, 18 pairs: {form}')
     names = pc.launch_names_of_a_step(dev, 'D_degraded3')
