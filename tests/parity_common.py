@@ -816,13 +816,13 @@ def check_attention(dev, d, sizes=((70, 45), (33, 101))):
         assert torch.equal(dk2, dk) and torch.equal(dv2, dv), 'the key / value pass must not depend on whether it writes dS'
 
 
-def check_poisoned_workspaces(dev):
+def check_poisoned_workspaces(dev, sizes=((60, 75), (90, 48), (7, 130), (33, 16))):
     """Nothing the kernels read may come from a workspace they did not write: the model with its saved-state / scratch buffers
     pre-filled with NaN bit patterns gives bit-identical outputs and gradients (zero padding of the first layer's attention
     rows - written by the projection jobs themselves since round 4, EqdLinJob.pad_to, in both epilogue forms: 69-wide and
     68-wide first layers -, partial buffers, the dS hand-off's rows beyond the partner)."""
     import os
-    pairs = synthetic.make_pairs([(60, 75), (90, 48), (7, 130), (33, 16)], 21)
+    pairs = synthetic.make_pairs(list(sizes), 21)
     for over, env in (({}, None), ({'residue_emb_dim': 63}, None), ({}, '1'), ({'hip_storage_dtype': 'bf16'}, '1')):
         args = dict(port.default_args(iegmn_n_lays=2, skip_weight_h=0.75), **over)
         sd = port.init_state_dict(args, seed=4)

@@ -236,7 +236,7 @@ def test_cross_attention_bf16_kernel_forms(env, monkeypatch):
 
 
 def test_results_do_not_depend_on_workspace_contents():
-    pc.check_poisoned_workspaces(DEV)
+    pc.check_poisoned_workspaces(DEV, sizes=((36, 41), (50, 23), (7, 70), (33, 16)))      # (the GPU test runs larger pairs)
 
 
 def test_attention_backward_ds_handoff_in_model():
