@@ -346,7 +346,10 @@ def edge_kernel_rooflines(net, packed, dev, workload='B', bf16=False):
             if k in out:
                 out[k]['traffic'] = int((2 * v['FETCH_SIZE_KB'] + v['WRITE_SIZE_KB']) * 1024)
                 out[k]['traffic_source'] = (f'profiles/{os.path.basename(files[-1])} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
-                                            'separate passes)')
+                                            'separate passes; NOT measured in this run - hardware counters cannot be read '
+                                            'from inside the process)')
+                out[k]['hbm_measured_traffic_GBps'] = round(out[k]['traffic'] / (out[k]['avg_launch_us'] * 1e-6) / 1e9, 1)
+                out[k]['hbm_frac_measured_traffic'] = round(out[k]['hbm_measured_traffic_GBps'] / PEAK_HBM_GBS, 4)
     except Exception:
         pass
     return out
@@ -736,6 +739,17 @@ def time_inference(net, g, ppg, dev, steps=30, warmup=5):
             "ms_per_forward": round(dt / steps * 1e3, 4), "steps": steps, "warmup": warmup, "launch_mode": "hipGraph replay"}
 
 
+def north_star_hbm_entry(rl):
+    """north_star's "achieved HBM bandwidth on the IEGMN message kernel": per edge kernel the live launch time of THIS run
+    with (i) the algorithmic bytes and (ii) the rocprofv3-measured bytes of the committed PMC pass."""
+    out = {}
+    for k, v in rl.items():
+        out[k] = {"avg_launch_us": v["avg_launch_us"], "algorithmic_bytes_per_launch": v["algorithmic_bytes_per_launch"],
+                  "hbm_frac_algorithmic": v["hbm_frac_algorithmic"], "measured_bytes_per_launch": v.get("traffic"),
+                  "hbm_frac_measured_traffic": v.get("hbm_frac_measured_traffic")}
+    return out
+
+
 def secondary_line(R, world):
     """The short form of a workload's result for the bench line's "secondary" block."""
     ms_step = R.dt / R.steps * 1e3
@@ -756,12 +770,32 @@ def secondary_line(R, world):
     return out
 
 
+def relaunch_under_torchrun(n):
+    """Run this command line again as `python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <same
+    arguments>` on a free local port; stdout / stderr pass through (rank 0 prints the JSON line), the launcher's exit code
+    is returned."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print('[bench] --gpus %d without a launcher: %s' % (n, ' '.join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--workload', default='B', choices=sorted(WORKLOADS))
+    ap.add_argument('--workload', default=None, choices=sorted(WORKLOADS),
+                    help="default B (BASELINE.json configs[1]) WITH the \"secondary\" / \"inference\" blocks; an explicitly "
+                         "named workload (also `--workload B`) runs that workload alone, so that a profiler around the "
+                         "command sees one workload's kernels only")
     ap.add_argument('--dtype', default=None, choices=('f32', 'bf16'),
                     help="arithmetic of the GEMMs: f32 (default for A, B, C, E) or bf16 inputs with fp32 accumulate "
                          "(default for D; `--workload C --dtype bf16` is BASELINE.json configs[2])")
@@ -782,13 +816,40 @@ def main():
     ap.add_argument('--eager', action='store_true', help='launch every kernel of every step from the host instead of replaying a captured hipGraph of the step (zero-grad, forward, loss, backward; the gradient all-reduce always runs outside the graph).  Same kernels either way; the replay takes the host (torch autograd + the launches, 0.7-1.5 ms depending on the box) off the critical path of a 1.5 ms step')
     ap.add_argument('--graph', action='store_true', help='(default; kept for older command lines)')
     a = ap.parse_args()
+    if a.workload is not None:      # a named workload is measured alone (profiles: one workload per kernel table)
+        a.no_secondary = True
+    else:
+        a.workload = 'B'
 
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    if a.gpus != world and world == 1 and a.gpus > 1:
-        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if a.gpus > 1 and 'RANK' not in os.environ:
+        # `python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU (the
+        # driver's N > 1 command line is the launcher form; this makes the plain form give the same single JSON line)
+        raise SystemExit(relaunch_under_torchrun(a.gpus))
+    if a.gpus != world:
+        print(f"[bench] --gpus {a.gpus} but WORLD_SIZE={world}: reporting n_gpus={world}", file=sys.stderr)
     import torch.distributed as dist
+    if os.environ.get('EQD_BENCH_DRY_RUN') == '1':
+        # launcher rehearsal for boxes without a GPU (tests/test_data_parallel.py): rendezvous over gloo, the barrier +
+        # max-over-ranks reduction of the timing, ONE line from rank 0, clean shutdown - no workload, not a measurement
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        if 'RANK' in os.environ:
+            dist.init_process_group('gloo')
+            dist.barrier()
+            tt = torch.tensor([float(rank + 1)], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dist.barrier()
+            dist.destroy_process_group()
+            assert int(tt.item()) == world
+            if os.environ.get('EQD_BENCH_DRY_RUN_FAIL') == '1' and rank == world - 1:
+                raise SystemExit(3)
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "workload": a.workload}),
+                  flush=True)
+        return
     # EQD_BENCH_ONE_DEVICE=1 + EQD_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow (barriers, max over ranks,
     # rank-0 report, gradient all-reduce) on a box with a single GPU; real runs use one GPU per rank over RCCL
     one_dev = os.environ.get('EQD_BENCH_ONE_DEVICE') == '1'
@@ -817,14 +878,19 @@ def main():
     svd_bad = R.svd_bad
     # the other BASELINE configs, timed the same way (graph replay, barrier + synchronize on both sides, max over ranks) with
     # fewer steps, so that the driver's default run carries a number for each of them
-    secondary = {}
+    secondary, ns_hbm = {}, {}
     if a.workload == 'B' and a.dropout == 0 and not a.eager and not a.no_secondary:
-        todo = [('D', 'D', None)] if use_dist else [('C_bf16', 'C', 'bf16'), ('E', 'E', None), ('R', 'R', None)]
+        todo = [('D', 'D', None)] if use_dist else [('C_bf16', 'C', 'bf16'), ('C_f32', 'C', 'f32'), ('E', 'E', None),
+                                                    ('R', 'R', None)]
         for key, wl, dt_ in todo:
             t_sec = time.perf_counter()
             try:
                 R2 = run_workload(wl, dt_, 10, 3, dev, rank, world, use_dist, backend)
                 secondary[key] = secondary_line(R2, world)
+                if rank == 0 and not a.no_roofline and R2.uniform:
+                    # the message kernels of this workload, timed standalone like the primary "roofline" (north_star_hbm)
+                    ns_hbm[key] = north_star_hbm_entry(edge_kernel_rooflines(R2.net, R2.packed, dev, wl,
+                                                                             bf16=(R2.dtype == 'bf16')))
                 secondary[key]["wall_s_incl_setup"] = round(time.perf_counter() - t_sec, 2)
                 del R2
             except Exception as e:      # the primary line must not die on a secondary workload
@@ -882,6 +948,13 @@ def main():
             rl = edge_kernel_rooflines(net, packed, dev, a.workload, bf16=(dtype == 'bf16'))
             dom = max(rl, key=lambda k: rl[k]["avg_launch_us"])
             out["roofline"] = dict(rl[dom], kernel=dom)
+            out["north_star_hbm"] = dict({a.workload + ('_bf16' if dtype == 'bf16' else ''): north_star_hbm_entry(rl)}, **ns_hbm)
+            out["north_star_hbm"]["note"] = ("north_star: >= 50 % achieved HBM bandwidth on the IEGMN message kernel.  Per edge "
+                                             "kernel and workload: launch time of this run (HIP events, standalone launches) "
+                                             "against algorithmic bytes and against the rocprofv3-measured bytes of the newest "
+                                             "committed PMC pass (profiles/*traffic.json), as fractions of 8 TB/s.  The fused "
+                                             "fp32 kernel is MFMA-bound (SURVEY.md section 8d: 230 FLOP/B against a ridge of "
+                                             "20), so neither fraction can reach 0.5 there")
             try:
                 prof, ev_us, n_launch = profile_step(compute, dev)
                 work = kernel_work_model(sizes, L, packed.n_nodes, packed.n_edges, fused_fwd='k_edge_attn_fwd' in prof,

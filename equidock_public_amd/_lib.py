@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libequidock_hip.so')
 
 EQD_MAX_SRC = 6
-ABI_VERSION = 6
+ABI_VERSION = 7
 PARAMS_PER_LAYER = 19
 GLOBAL_PARAMS = 5
 
@@ -71,6 +71,18 @@ class EqdEdgeParams(C.Structure):
                 ('bf16', C.c_int32), ('drop_z1', C.c_void_p), ('drop_ch', C.c_void_p), ('drop_scale', C.c_float)]
 
 
+class EqdNodeUpdateParams(C.Structure):
+    _fields_ = [('d_in', C.c_int32), ('d0', C.c_int32), ('d_out', C.c_int32), ('ld_cross', C.c_int32), ('Wn1', C.c_void_p),
+                ('bn1', C.c_void_p), ('ln_g', C.c_void_p), ('ln_b', C.c_void_p), ('Wn2', C.c_void_p), ('bn2', C.c_void_p),
+                ('skip_weight_h', C.c_float), ('slope', C.c_float), ('ln_eps', C.c_float), ('bf16', C.c_int32),
+                ('drop_mul', C.c_void_p)]
+
+
+class EqdNodeUpdateGrads(C.Structure):
+    _fields_ = [('dWn1', C.c_void_p), ('dbn1', C.c_void_p), ('dln_g', C.c_void_p), ('dln_b', C.c_void_p),
+                ('dWn2', C.c_void_p), ('dbn2', C.c_void_p)]
+
+
 class EqdEdgeGrads(C.Structure):
     _fields_ = [('dW1', C.c_void_p), ('ldw1', C.c_int32), ('db1_unused', C.c_void_p), ('dln_g', C.c_void_p),
                 ('dln_b', C.c_void_p), ('dW2', C.c_void_p), ('db2', C.c_void_p), ('dWc1', C.c_void_p),
@@ -97,6 +109,7 @@ def _declare(lib):
     lib.eqd_edge_message_bwd_workspace_bytes.restype = C.c_size_t
     lib.eqd_keypoint_pool_bwd_workspace_bytes.restype = C.c_size_t
     lib.eqd_clash_workspace_bytes.restype = C.c_size_t
+    lib.eqd_node_update_bwd_workspace_bytes.restype = C.c_size_t
     lib.eqd_cross_attention_bwd_ds_workspace_bytes.restype = C.c_size_t
     lib.eqd_profile_name.restype = C.c_char_p
     lib.eqd_profile_us.restype = C.c_float
@@ -108,7 +121,8 @@ def _declare(lib):
            'eqd_keypoint_pool_fwd', 'eqd_keypoint_pool_bwd', 'eqd_kabsch_fwd', 'eqd_kabsch_bwd',
                  'eqd_rigid_apply_fwd', 'eqd_rigid_apply_bwd', 'eqd_pair_losses_fwd', 'eqd_pair_losses_bwd', 'eqd_scalar_loss', 'eqd_pocket_ot_cost',
                  'eqd_pocket_ot_fwd', 'eqd_pocket_ot_bwd', 'eqd_rigid_augment', 'eqd_protein_graph_distances',
-                 'eqd_protein_graph_select', 'eqd_protein_graph_edges', 'eqd_clash_iterations', 'eqd_dropout_pack_edges', 'eqd_dropout_draw'):
+                 'eqd_protein_graph_select', 'eqd_protein_graph_edges', 'eqd_clash_iterations', 'eqd_dropout_pack_edges', 'eqd_dropout_draw',
+                 'eqd_node_update_fwd', 'eqd_node_update_bwd'):
         getattr(lib, name).restype = C.c_int
 
 
@@ -123,7 +137,7 @@ EXPORTS = ('eqd_model_layer_state', 'eqd_model_lrelu_signs', 'eqd_model_head_bac
            'eqd_pair_losses_bwd', 'eqd_scalar_loss', 'eqd_pocket_ot_cost', 'eqd_pocket_ot_fwd', 'eqd_pocket_ot_bwd',
            'eqd_rigid_augment', 'eqd_protein_graph_distances', 'eqd_protein_graph_select', 'eqd_protein_graph_edges',
            'eqd_clash_workspace_bytes', 'eqd_clash_iterations', 'eqd_dropout_pack_edges', 'eqd_dropout_draw',
-           'eqd_tunables_reload')
+           'eqd_tunables_reload', 'eqd_node_update_fwd', 'eqd_node_update_bwd_workspace_bytes', 'eqd_node_update_bwd')
 
 
 def load_library():

@@ -927,3 +927,182 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
     RC(eqd_launch_reduce_segments(defer->seg, defer->n, st));
     return EQD_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Node update of ONE IEGMN layer as an operator pair (rigid_docking_model.py:319-337):
+//   a1n  = LayerNorm(mul * LeakyReLU([h | aggr_msg | aggr_cross | h0] Wn1^T + bn1))      (node_mlp.0 .. node_mlp.3)
+//   u    = a1n Wn2^T + bn2                                                                (node_mlp.4)
+//   h'   = s u + (1 - s) h   when d_in == d_out, else u                                    (:332-337)
+// The same row-chain jobs eqd_model_forward / eqd_model_backward enqueue per layer (one launch forward; one chain + the
+// weight-gradient GEMMs + one reduction backward), behind their own entry points.
+// ---------------------------------------------------------------------------------------------
+namespace {
+int node_update_check(int rows, const EqdNodeUpdateParams* p, const char* who) {
+    if (!p || !p->Wn1 || !p->bn1 || !p->ln_g || !p->ln_b || !p->Wn2 || !p->bn2) {
+        eqd_set_error("%s: NULL parameter pointer", who);
+        return EQD_ERR_NULL;
+    }
+    if (rows < 0 || p->d_in < 4 || p->d_in > 80 || p->d0 < 4 || p->d0 > 80 || p->d_out != 64 || p->ld_cross < p->d_in) {
+        eqd_set_error("%s: unsupported widths d_in=%d d0=%d d_out=%d ld_cross=%d (need 4..80, 4..80, 64, >= d_in)", who,
+                      p->d_in, p->d0, p->d_out, p->ld_cross);
+        return EQD_ERR_UNSUPPORTED;
+    }
+    return EQD_OK;
+}
+struct NodeUpdateWs {
+    float *dz, *ln_part, *atb_part;
+    size_t atb_bytes;
+};
+void node_update_atb_jobs(int rows, const EqdNodeUpdateParams* p, const float* h, const float* aggr_msg,
+                          const float* aggr_cross, const float* h0, const float* a1n, const float* d_h_out, const float* dz,
+                          const EqdNodeUpdateGrads* gr, EqdAtbJob* jobs, int* n_out) {
+    const int d = p->d_in, ldn = p->d0 + 2 * d + 64;
+    const float alpha = d == p->d_out ? p->skip_weight_h : 1.f;
+    int n = 0;
+    jobs[n++] = atb_job(d_h_out, p->d_out, p->d_out, a1n, d, d, rows, gr ? gr->dWn2 : nullptr, d, gr ? gr->dbn2 : nullptr,
+                        p->slope, nullptr, alpha);
+    jobs[n++] = atb_job(dz, d, d, aggr_msg, 64, 64, rows, gr ? gr->dWn1 + d : nullptr, ldn, nullptr, p->slope);
+    if (aggr_cross || !gr)
+        jobs[n++] = atb_job(dz, d, d, aggr_cross, p->ld_cross, d, rows, gr ? gr->dWn1 + d + 64 : nullptr, ldn, nullptr, p->slope);
+    jobs[n++] = atb_job(dz, d, d, h0, p->d0, p->d0, rows, gr ? gr->dWn1 + 2 * d + 64 : nullptr, ldn, nullptr, p->slope);
+    jobs[n++] = atb_job(dz, d, d, h, d, d, rows, gr ? gr->dWn1 : nullptr, ldn, gr ? gr->dbn1 : nullptr, p->slope);
+    *n_out = n;
+}
+size_t node_update_carve(int rows, const EqdNodeUpdateParams* p, EqdArena& A, NodeUpdateWs& W) {
+    W.dz = A.take<float>((size_t)rows * p->d_in);
+    W.ln_part = A.take<float>(eqd_ln_act_bwd_partial_floats(rows, 80));
+    EqdAtbJob jobs[8];
+    int n = 0;
+    // (sizing: the operand pointers are not read, the shapes are)
+    static const float dummy = 0.f;
+    node_update_atb_jobs(rows, p, &dummy, &dummy, &dummy, &dummy, &dummy, &dummy, &dummy, nullptr, jobs, &n);
+    // (distinct, never dereferenced output addresses: jobs that share an output are split over launches)
+    for (int i = 0; i < n; ++i) jobs[i].out = (float*)(uintptr_t)(4096 * (i + 1));
+    W.atb_bytes = eqd_atb_partial_bytes(jobs, n);
+    W.atb_part = (float*)A.take<char>(W.atb_bytes);
+    return A.off + 256;
+}
+}  // namespace
+
+extern "C" int eqd_node_update_fwd(int rows, const EqdNodeUpdateParams* p, const float* h, const float* aggr_msg,
+                                   const float* aggr_cross, const float* h0, float* h_out, float* y_act, float* a1n,
+                                   void* stream) {
+    RC(node_update_check(rows, p, "eqd_node_update_fwd"));
+    if (!h || !aggr_msg || !h0 || !h_out || !y_act || !a1n) {
+        eqd_set_error("eqd_node_update_fwd: NULL argument");
+        return EQD_ERR_NULL;
+    }
+    if (rows == 0) return EQD_OK;
+    g_bf16_mode = p->bf16 ? 1 : 0;
+    const int d = p->d_in, ldn = p->d0 + 2 * d + 64;
+    EqdLinJob j1 = lin_job(rows, d, a1n, d, p->slope, p->ln_eps);
+    int ns = 0;
+    lin_src(j1, ns++, h, d, d, p->Wn1, ldn, 1);
+    lin_src(j1, ns++, aggr_msg, 64, 64, p->Wn1 + d, ldn, 1);
+    if (aggr_cross) lin_src(j1, ns++, aggr_cross, p->ld_cross, d, p->Wn1 + d + 64, ldn, 1);      // NULL: cross_msgs off (zeros)
+    lin_src(j1, ns++, h0, p->d0, p->d0, p->Wn1 + 2 * d + 64, ldn, 1);
+    j1.nsrc = ns; j1.bias = p->bn1; j1.act = 1; j1.ln_g = p->ln_g; j1.ln_b = p->ln_b;
+    j1.pre_ln = y_act; j1.ld_pre = d;
+    j1.mul = p->drop_mul; j1.ld_mul = d;
+    EqdLinJob j2 = lin_job(rows, p->d_out, h_out, p->d_out, p->slope, p->ln_eps);
+    lin_src(j2, 0, a1n, d, d, p->Wn2, d, 1);
+    j2.nsrc = 1; j2.bias = p->bn2;
+    if (d == p->d_out) {
+        j2.alpha = p->skip_weight_h; j2.beta = 1.f - p->skip_weight_h; j2.R = h; j2.ldr = d;
+    }
+    EqdChainJob cj[2];
+    memset(cj, 0, sizeof(cj));
+    for (int k = 0; k < 2; ++k) {
+        for (int i = 0; i < EQD_MAX_SRC; ++i) cj[k].src_local[i] = -1;
+        cj[k].out_local = -1;
+    }
+    cj[0].lin = j1; cj[0].out_local = 0;
+    cj[1].lin = j2; cj[1].src_local[0] = 0;
+    return eqd_launch_rowchain(cj, 2, rows, (hipStream_t)stream);
+}
+
+extern "C" size_t eqd_node_update_bwd_workspace_bytes(int rows, const EqdNodeUpdateParams* p) {
+    if (node_update_check(rows, p, "eqd_node_update_bwd_workspace_bytes")) return 0;
+    EqdArena A(nullptr, 0);
+    NodeUpdateWs W;
+    return node_update_carve(rows, p, A, W);
+}
+
+extern "C" int eqd_node_update_bwd(int rows, const EqdNodeUpdateParams* p, const float* h, const float* aggr_msg,
+                                   const float* aggr_cross, const float* h0, const float* y_act, const float* a1n,
+                                   const float* d_h_out, float* d_h, float* d_aggr_msg, float* d_aggr_cross, float* d_h0,
+                                   const EqdNodeUpdateGrads* grads, void* workspace, size_t ws_bytes, void* stream) {
+    RC(node_update_check(rows, p, "eqd_node_update_bwd"));
+    if (!h || !aggr_msg || !h0 || !y_act || !a1n || !d_h_out || !d_h || !d_aggr_msg || !d_h0 || !grads ||
+        (aggr_cross && !d_aggr_cross) || !grads->dWn1 || !grads->dbn1 || !grads->dln_g || !grads->dln_b || !grads->dWn2 ||
+        !grads->dbn2) {
+        eqd_set_error("eqd_node_update_bwd: NULL argument");
+        return EQD_ERR_NULL;
+    }
+    if (rows == 0) return EQD_OK;
+    g_bf16_mode = p->bf16 ? 1 : 0;
+    hipStream_t st = (hipStream_t)stream;
+    EqdArena A(workspace, ws_bytes);
+    NodeUpdateWs W;
+    node_update_carve(rows, p, A, W);
+    if (!A.ok) {
+        eqd_set_error("eqd_node_update_bwd: workspace too small (%zu needed)", A.off + 256);
+        return EQD_ERR_WORKSPACE;
+    }
+    const int d = p->d_in, ldn = p->d0 + 2 * d + 64;
+    const bool skip = d == p->d_out;
+    const float alpha = skip ? p->skip_weight_h : 1.f;
+    // ONE row chain: d a1n = alpha d_h_out Wn2 -> LeakyReLU / LayerNorm backward (dz) -> dz times the four column blocks
+    // of Wn1 (the gradient w.r.t. h also takes the skip connection's (1 - s) d_h_out)
+    EqdChainJob cj[EQD_CHAIN_MAXJOBS];
+    int nj = 0;
+    auto clear = [&](EqdChainJob& C) {
+        memset(&C, 0, sizeof(C));
+        for (int i = 0; i < EQD_MAX_SRC; ++i) C.src_local[i] = -1;
+        C.out_local = -1;
+    };
+    {
+        EqdChainJob& C = cj[nj++];
+        clear(C);
+        C.lin = lin_job(rows, d, nullptr, d, p->slope, p->ln_eps);
+        lin_src(C.lin, 0, d_h_out, p->d_out, p->d_out, p->Wn2, 1, d);
+        C.lin.nsrc = 1; C.lin.alpha = alpha;
+        C.out_local = 0;
+    }
+    {
+        EqdChainJob& C = cj[nj++];
+        clear(C);
+        C.type = 1;
+        C.lin = lin_job(rows, d, W.dz, d, p->slope, p->ln_eps);
+        lin_src(C.lin, 0, y_act, d, d, nullptr, 0, 0);
+        C.lin.nsrc = 1; C.lin.ln_g = p->ln_g;
+        C.lin.mul = p->drop_mul; C.lin.ld_mul = d;
+        C.src_local[0] = 0;
+        C.out_local = 1;
+        C.aux = W.ln_part;
+    }
+    auto dx_job = [&](float* Y, int M, int ldy, int coff) -> EqdChainJob& {
+        EqdChainJob& C = cj[nj++];
+        clear(C);
+        C.lin = lin_job(rows, M, Y, ldy, p->slope, p->ln_eps);
+        lin_src(C.lin, 0, W.dz, d, d, p->Wn1 + coff, 1, ldn);
+        C.lin.nsrc = 1;
+        C.src_local[0] = 1;
+        return C;
+    };
+    dx_job(d_aggr_msg, 64, 64, d);
+    if (aggr_cross) dx_job(d_aggr_cross, d, p->ld_cross, d + 64).lin.pad_to = p->ld_cross != d ? p->ld_cross : 0;
+    dx_job(d_h0, p->d0, p->d0, 2 * d + 64);
+    {
+        EqdChainJob& C = dx_job(d_h, d, d, 0);
+        if (skip) { C.lin.R = d_h_out; C.lin.ldr = p->d_out; C.lin.beta = 1.f - p->skip_weight_h; }
+    }
+    int nb = 0;
+    RC(eqd_launch_rowchain(cj, nj, rows, st, &nb));
+    EqdRedSeg segs[2] = {{W.ln_part, nb, 256, d, grads->dln_g, 0, 0, 0}, {W.ln_part + 128, nb, 256, d, grads->dln_b, 0, 0, 0}};
+    RC(eqd_launch_reduce_segments(segs, 2, st));
+    EqdAtbJob jobs[8];
+    int na = 0;
+    node_update_atb_jobs(rows, p, h, aggr_msg, aggr_cross, h0, a1n, d_h_out, W.dz, grads, jobs, &na);
+    return eqd_atb(jobs, na, W.atb_part, W.atb_bytes, st);
+}

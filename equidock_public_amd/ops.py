@@ -6,11 +6,11 @@
 
 Inside IEGMN the layer loop never comes through here (one C call per pass, model._IEGMNFunction); these wrappers serve a
 caller that wants ONE IEGMN_Layer (reference signature, src/model/rigid_docking_model.py:189-352) or a single operator with
-autograd.  The two heavy operators of a layer - the edge messages + coordinate update (:204-237, 263-292) and the
-block-diagonal cross attention (:46-64, 244-256) - run in the HIP library forward and backward
-(eqd_edge_message_fwd / _bwd, eqd_cross_attention_fwd / _bwd); the node-level Linears / LayerNorm of the layer are the
-layer's own torch sub-modules (their arithmetic is a few small GEMMs; inside the model they run in the library's row
-kernels).  No CPU fallback: tensors must be on the GPU.
+autograd.  The three operators of a layer - the edge messages + coordinate update (:204-237, 263-292), the
+block-diagonal cross attention (:46-64, 244-256) and the node update (node_mlp + skip connection, :319-337) - run in the
+HIP library forward and backward (eqd_edge_message_fwd / _bwd, eqd_cross_attention_fwd / _bwd, eqd_node_update_fwd /
+_bwd); the five node projections in front of them (P, Q, q, k, v: one nn.Linear each) are torch's.  No CPU fallback:
+tensors must be on the GPU.
 """
 import ctypes as C
 
@@ -120,6 +120,57 @@ class _CrossAttention(torch.autograd.Function):
         return None, dq, dk, dv
 
 
+class _NodeUpdate(torch.autograd.Function):
+    """eqd_node_update_fwd / _bwd: node_mlp([h | aggr_msg | aggr_cross | h0]) and the skip connection
+    (rigid_docking_model.py:319-337).  aggr_cross rows are ld_cross = aggr_cross.shape[1] floats wide (>= d_in: the attention
+    operator's padded rows of a 69-wide layer are taken as they are)."""
+
+    @staticmethod
+    def forward(ctx, skip_weight_h, slope, ln_eps, h, aggr_msg, aggr_cross, h0, Wn1, bn1, ln_g, ln_b, Wn2, bn2):
+        lib = _lib.load_library()
+        dev = h.device
+        ts = [_f32(t, 'node_update operand') for t in (h, aggr_msg, aggr_cross, h0, Wn1, bn1, ln_g, ln_b, Wn2, bn2)]
+        h_, am, ac, h0_, Wn1_, bn1_, lg, lb, Wn2_, bn2_ = ts
+        rows, d = h_.shape
+        p = _lib.EqdNodeUpdateParams()
+        p.d_in, p.d0, p.d_out, p.ld_cross = int(d), int(h0_.shape[1]), int(Wn2_.shape[0]), int(ac.shape[1])
+        p.Wn1, p.bn1, p.ln_g, p.ln_b, p.Wn2, p.bn2 = (t.data_ptr() for t in (Wn1_, bn1_, lg, lb, Wn2_, bn2_))
+        p.skip_weight_h, p.slope, p.ln_eps, p.bf16, p.drop_mul = float(skip_weight_h), float(slope), float(ln_eps), 0, None
+        if Wn1_.shape[1] != p.d0 + 2 * d + 64 or am.shape[1] != 64:
+            raise _lib.EquidockHipError(f"node_update: node_mlp.0.weight is {tuple(Wn1_.shape)}, expected [{d}, {p.d0 + 2 * d + 64}]")
+        z = dict(dtype=torch.float32, device=dev)
+        h_out, y_act, a1n = torch.empty(rows, p.d_out, **z), torch.empty(rows, d, **z), torch.empty(rows, d, **z)
+        with _lib.device_guard(dev):
+            _lib.check(lib.eqd_node_update_fwd(int(rows), C.byref(p), _lib.ptr(h_), _lib.ptr(am), _lib.ptr(ac), _lib.ptr(h0_),
+                                               _lib.ptr(h_out), _lib.ptr(y_act), _lib.ptr(a1n), _lib.stream_ptr(dev)))
+        ctx.p, ctx.ts, ctx.state = p, ts, (y_act, a1n)
+        return h_out
+
+    @staticmethod
+    def backward(ctx, d_h_out):
+        lib = _lib.load_library()
+        p = ctx.p
+        h_, am, ac, h0_, Wn1_, bn1_, lg, lb, Wn2_, bn2_ = ctx.ts
+        y_act, a1n = ctx.state
+        dev = h_.device
+        rows = h_.shape[0]
+        d_h_out = _f32(d_h_out, 'd h_out')
+        z = dict(dtype=torch.float32, device=dev)
+        d_h, d_am, d_h0 = torch.empty_like(h_), torch.empty_like(am), torch.empty_like(h0_)
+        d_ac = torch.zeros_like(ac)      # (padding columns beyond d_in stay zero)
+        g = [torch.zeros_like(t) for t in (Wn1_, bn1_, lg, lb, Wn2_, bn2_)]
+        gr = _lib.EqdNodeUpdateGrads()
+        gr.dWn1, gr.dbn1, gr.dln_g, gr.dln_b, gr.dWn2, gr.dbn2 = (t.data_ptr() for t in g)
+        with _lib.device_guard(dev):
+            wsb = lib.eqd_node_update_bwd_workspace_bytes(int(rows), C.byref(p))
+            ws = torch.empty(max(int(wsb), 1), dtype=torch.uint8, device=dev)
+            _lib.check(lib.eqd_node_update_bwd(int(rows), C.byref(p), _lib.ptr(h_), _lib.ptr(am), _lib.ptr(ac), _lib.ptr(h0_),
+                                               _lib.ptr(y_act), _lib.ptr(a1n), _lib.ptr(d_h_out), _lib.ptr(d_h), _lib.ptr(d_am),
+                                               _lib.ptr(d_ac), _lib.ptr(d_h0), C.byref(gr), _lib.ptr(ws), C.c_size_t(wsb),
+                                               _lib.stream_ptr(dev)))
+        return (None, None, None, d_h, d_am, d_ac, d_h0) + tuple(g)
+
+
 def graph_view(packed, x0=None, he=None):
     """Kernel-side view of a packed batch (graph.PackedGraph) with the given original coordinates [n_nodes, 3] (ligand rows
     first; default: the batch's own) and edge features [n_edges, 27] in the PACKED edge order (default: the batch's own)."""
@@ -139,12 +190,20 @@ def cross_attention(view, q, k, v):
     return _CrossAttention.apply(view, q, k, v)
 
 
+def node_update(h, aggr_msg, aggr_cross, h0, Wn1, bn1, ln_g, ln_b, Wn2, bn2, skip_weight_h, slope=0.01, ln_eps=1e-5):
+    """h' [rows, 64] = eqd_node_update_fwd: skip(node_mlp([h | aggr_msg | aggr_cross | h0])), differentiable w.r.t. the four
+    inputs and the six parameter tensors (eqd_node_update_bwd)."""
+    return _NodeUpdate.apply(skip_weight_h, slope, ln_eps, h, aggr_msg, aggr_cross, h0, Wn1, bn1, ln_g, ln_b, Wn2, bn2)
+
+
 def layer_supported(layer):
     """The standalone layer runs its two heavy operators in the HIP library for the published configuration family
     (model.hip_path_supported's conditions on one layer) when no dropout mask is due."""
     em, cm = layer.edge_mlp, layer.coors_mlp
     return (not layer.fine_tune and isinstance(em[2], torch.nn.LeakyReLU) and isinstance(em[3], torch.nn.LayerNorm)
             and isinstance(cm[3], torch.nn.Identity) and isinstance(layer.final_h_layernorm_layer, torch.nn.Identity)
+            and isinstance(layer.node_mlp[2], torch.nn.LeakyReLU) and isinstance(layer.node_mlp[3], torch.nn.LayerNorm)
+            and isinstance(layer.node_norm, torch.nn.Identity)
             and layer.out_feats_dim == 64 and em[0].in_features == 2 * layer.h_feats_dim + 42
             and not (layer.training and layer.dropout_p > 0))
 
@@ -180,7 +239,7 @@ def layer_forward(layer, g, x_l, h_l, h0_l, he_l, x0_l, x_r, h_r, h0_r, he_r, x0
         cross = cross_attention(view, layer.att_mlp_Q(h), layer.att_mlp_K(h), layer.att_mlp_V(h))
     else:
         cross = torch.zeros_like(h)
-    upd = layer.node_mlp(torch.cat((layer.node_norm(h), aggr_msg, cross, h0), dim=-1))     # :319-329
-    if layer.h_feats_dim == layer.out_feats_dim:                                  # :332-337
-        upd = layer.skip_weight_h * upd + (1. - layer.skip_weight_h) * h
+    nm = layer.node_mlp                                                           # :319-337, eqd_node_update_fwd / _bwd
+    upd = node_update(h, aggr_msg, cross, h0, nm[0].weight, nm[0].bias, nm[3].weight, nm[3].bias, nm[4].weight, nm[4].bias,
+                      layer.skip_weight_h, slope=nm[2].negative_slope, ln_eps=nm[3].eps)
     return x_new[:nl], upd[:nl], x_new[nl:], upd[nl:]

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define EQD_ABI_VERSION 6
+#define EQD_ABI_VERSION 7
 #define EQD_TILE_EDGES 32   /* edges per node-aligned tile (max supported in-degree) */
 #define EQD_ATT_BLOCK 32    /* nodes per cross-attention work item */
 #define EQD_MAX_SRC 6
@@ -351,6 +351,45 @@ int eqd_cross_attention_fwd_bf16(const EqdGraph* g, int d, const float* q, const
 int eqd_cross_attention_bwd_bf16(const EqdGraph* g, int d, const float* q, const float* k, const float* v,
                                  const float* out, const float* lse, const float* d_out,
                                  float* dq, float* dk, float* dv, float* delta, void* stream);
+
+/* Node update of one IEGMN layer (rigid_docking_model.py:319-337; node_mlp = Linear, Dropout, LeakyReLU, LayerNorm,
+ * Linear - :142-148 - and the skip connection :332-337):
+ *   a1n = LayerNorm(mul * LeakyReLU([h | aggr_msg | aggr_cross | h0] Wn1^T + bn1)),  u = a1n Wn2^T + bn2,
+ *   h_out = s u + (1 - s) h  when d_in == d_out, else u.
+ * One row-chain launch forward; backward = one row chain (d a1n, LayerNorm / LeakyReLU backward, the four input gradients)
+ * + the weight-gradient GEMMs (eqd_atb) + one deterministic reduction.  The same jobs eqd_model_forward / _backward
+ * enqueue per layer. */
+typedef struct EqdNodeUpdateParams {
+    int32_t d_in;          /* width of h: 64, or d_emb + 5 = 69 for the first layer (4..80) */
+    int32_t d0;            /* width of h0 = orig_h_feats_dim (4..80) */
+    int32_t d_out;         /* out_feats_dim: 64 */
+    int32_t ld_cross;      /* row stride of aggr_cross / d_aggr_cross (>= d_in; the attention operators' 16-float blocks: 80
+                              for a 69-wide layer) */
+    const float* Wn1;      /* node_mlp.0.weight [d_in][d_in + 64 + d_in + d0], column blocks [h | aggr_msg | aggr_cross | h0] */
+    const float* bn1;      /* node_mlp.0.bias [d_in] */
+    const float* ln_g; const float* ln_b;   /* node_mlp.3 (LayerNorm) weight / bias [d_in] */
+    const float* Wn2;      /* node_mlp.4.weight [d_out][d_in] */
+    const float* bn2;      /* node_mlp.4.bias [d_out] */
+    float skip_weight_h, slope, ln_eps;
+    int32_t bf16;          /* 1: GEMM inputs rounded to bf16 (EqdLinJob.bf16 / EqdAtbJob.bf16) */
+    const float* drop_mul; /* [rows][d_in] nn.Dropout factors of node_mlp.1 in training mode (0 or 1 / (1 - p)), or NULL */
+} EqdNodeUpdateParams;
+typedef struct EqdNodeUpdateGrads {   /* ACCUMULATED into (the caller zeroes them); shapes as the parameters */
+    float* dWn1; float* dbn1; float* dln_g; float* dln_b; float* dWn2; float* dbn2;
+} EqdNodeUpdateGrads;
+/* h [rows][d_in], aggr_msg [rows][64], aggr_cross [rows][ld_cross] (NULL: no cross messages, the block is skipped),
+ * h0 [rows][d0] -> h_out [rows][d_out]; y_act [rows][d_in] (the LayerNorm's input) and a1n [rows][d_in] (its output) are
+ * the state the backward needs. */
+int eqd_node_update_fwd(int rows, const EqdNodeUpdateParams* p, const float* h, const float* aggr_msg,
+                        const float* aggr_cross, const float* h0, float* h_out, float* y_act, float* a1n, void* stream);
+size_t eqd_node_update_bwd_workspace_bytes(int rows, const EqdNodeUpdateParams* p);
+/* d_h_out [rows][d_out] -> d_h [rows][d_in], d_aggr_msg [rows][64], d_aggr_cross [rows][ld_cross] (columns d_in ..
+ * ld_cross - 1 written as zeros when d_in is not a multiple of 4 - the 69-wide layer's padding -, else untouched),
+ * d_h0 [rows][d0] (all written), parameter gradients accumulated. */
+int eqd_node_update_bwd(int rows, const EqdNodeUpdateParams* p, const float* h, const float* aggr_msg,
+                        const float* aggr_cross, const float* h0, const float* y_act, const float* a1n,
+                        const float* d_h_out, float* d_h, float* d_aggr_msg, float* d_aggr_cross, float* d_h0,
+                        const EqdNodeUpdateGrads* grads, void* workspace, size_t ws_bytes, void* stream);
 
 /* K-head attention keypoint pooling (rigid_docking_model.py:521-560) with collapsed heads:
  * u[s][k] = W_K^(k)T (W_Q^(k) qmean[partner(s)]) / sqrt(d);  scores = H u^T; softmax over the

@@ -8,7 +8,10 @@ rows = list(cur.execute(f"select d.start, d.end, s.kernel_name, d.stream_id, d.q
 # find step boundaries: k_embed_fwd marks the start of a forward
 starts = [i for i, r in enumerate(rows) if 'k_embed_fwd' in r[2]]
 print('steps found', len(starts))
-i0, i1 = starts[-3], starts[-2]
+# the last complete TRAINING step: an interval between two forward starts that contains a backward kernel (the bench's
+# forward-only inference passes and secondary workloads, if any ran, are skipped)
+cands = [(a, b) for a, b in zip(starts[:-1], starts[1:]) if any('k_edge_bwd' in r[2] for r in rows[a:b])]
+i0, i1 = cands[-2] if len(cands) > 1 else cands[-1]
 step = rows[i0:i1]
 t0, t1 = step[0][0], max(r[1] for r in step)
 print(f'step wall {(t1-t0)/1e3:.1f} us, kernels {len(step)}, sum durations {sum(r[1]-r[0] for r in step)/1e3:.1f} us')

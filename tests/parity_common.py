@@ -1368,6 +1368,76 @@ def check_dropout_library(dev):
     assert w2 <= 5e-3 and wm <= 2e-2
 
 
+def check_node_update(dev, rows=301):
+    """eqd_node_update_fwd / _bwd (rigid_docking_model.py:319-337) against torch autograd of the as-written node_mlp
+    (Linear, LeakyReLU, LayerNorm, Linear) + skip connection: the 64-wide layer (skip), the 69-wide first layer with the
+    attention operator's 80-float aggr_cross rows (no skip), and a layer without cross messages (aggr_cross = NULL)."""
+    torch.manual_seed(31)
+    for d, ldc, cross, s in ((64, 64, True, 0.75), (69, 80, True, 0.5), (64, 64, False, 0.25)):
+        d0, dout = 69, 64
+        ldn = d0 + 2 * d + 64
+        mk = lambda *sh: torch.randn(*sh) * 0.5      # noqa: E731
+        h, am, ac, h0 = mk(rows, d), mk(rows, 64), torch.zeros(rows, ldc), mk(rows, d0)
+        ac[:, :d] = mk(rows, d)
+        if not cross:
+            ac.zero_()
+        Wn1, bn1 = mk(d, ldn) * 0.3, mk(d)
+        lg, lb = 1.0 + 0.2 * torch.randn(d), 0.2 * torch.randn(d)
+        Wn2, bn2 = mk(dout, d) * 0.3, mk(dout)
+        host = [h, am, ac, h0, Wn1, bn1, lg, lb, Wn2, bn2]
+        lv = [t.clone().requires_grad_(True) for t in host]
+        h_, am_, ac_, h0_, W1_, b1_, lg_, lb_, W2_, b2_ = lv
+        z = F.leaky_relu(F.linear(torch.cat([h_, am_, ac_[:, :d], h0_], 1), W1_, b1_), 0.01)
+        u = F.linear(F.layer_norm(z, (d,), lg_, lb_, 1e-5), W2_, b2_)
+        ref = s * u + (1 - s) * h_ if d == dout else u
+        w = torch.randn(rows, dout)
+        (ref * w).sum().backward()
+        dd = [t.to(dev).contiguous() for t in host]
+        prm = L.EqdNodeUpdateParams()
+        prm.d_in, prm.d0, prm.d_out, prm.ld_cross = d, d0, dout, ldc
+        prm.Wn1, prm.bn1, prm.ln_g, prm.ln_b, prm.Wn2, prm.bn2 = (t.data_ptr() for t in dd[4:])
+        prm.skip_weight_h, prm.slope, prm.ln_eps, prm.bf16, prm.drop_mul = s, 0.01, 1e-5, 0, None
+        f = dict(dtype=torch.float32, device=dev)
+        h_out, y_act, a1n = torch.zeros(rows, dout, **f), torch.zeros(rows, d, **f), torch.zeros(rows, d, **f)
+        acp = P(dd[2]) if cross else None
+        L.check(lib().eqd_node_update_fwd(rows, C.byref(prm), P(dd[0]), P(dd[1]), acp, P(dd[3]), P(h_out), P(y_act), P(a1n),
+                                          st(dev)))
+        sync(dev)
+        close(h_out, ref, what=f'node_update d={d} cross={cross} h_out')
+        close(y_act, z, what=f'node_update d={d} y_act')
+        wsb = lib().eqd_node_update_bwd_workspace_bytes(rows, C.byref(prm))
+        assert wsb > 0
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        gout = w.to(dev).contiguous()
+        d_h, d_am, d_h0 = torch.zeros(rows, d, **f), torch.zeros(rows, 64, **f), torch.zeros(rows, d0, **f)
+        d_ac = torch.full((rows, ldc), float('nan'), **f)
+        gs_ = [torch.zeros_like(t) for t in dd[4:]]
+        gr = L.EqdNodeUpdateGrads()
+        gr.dWn1, gr.dbn1, gr.dln_g, gr.dln_b, gr.dWn2, gr.dbn2 = (t.data_ptr() for t in gs_)
+        L.check(lib().eqd_node_update_bwd(rows, C.byref(prm), P(dd[0]), P(dd[1]), acp, P(dd[3]), P(y_act), P(a1n), P(gout),
+                                          P(d_h), P(d_am), P(d_ac) if cross else None, P(d_h0), C.byref(gr), P(ws),
+                                          C.c_size_t(wsb), st(dev)))
+        sync(dev)
+        tag = f'node_update d={d} cross={cross}'
+        grad_close(d_h, h_.grad, what=tag + ' d_h', l2=1e-4, mx=1e-4)
+        grad_close(d_am, am_.grad, what=tag + ' d_aggr_msg', l2=1e-4, mx=1e-4)
+        grad_close(d_h0, h0_.grad, what=tag + ' d_h0', l2=1e-4, mx=1e-4)
+        if cross:
+            grad_close(d_ac[:, :d], ac_.grad[:, :d], what=tag + ' d_aggr_cross', l2=1e-4, mx=1e-4)
+            if ldc > d:
+                assert float(d_ac[:, d:].abs().max()) == 0.0, 'padding columns of d_aggr_cross must be zeros'
+        refs = [W1_.grad, b1_.grad, lg_.grad, lb_.grad, W2_.grad, b2_.grad]
+        if not cross:      # the aggr_cross block of node_mlp.0.weight receives no gradient from the library
+            refs[0] = refs[0].clone()
+            refs[0][:, d + 64:2 * d + 64] = 0
+        for nm, a, b in zip(('dWn1', 'dbn1', 'dln_g', 'dln_b', 'dWn2', 'dbn2'), gs_, refs):
+            grad_close(a, b, what=f'{tag} {nm}', l2=1e-4, mx=1e-4)
+        # too small a workspace is an error, not a write
+        rc = lib().eqd_node_update_bwd(rows, C.byref(prm), P(dd[0]), P(dd[1]), acp, P(dd[3]), P(y_act), P(a1n), P(gout), P(d_h),
+                                       P(d_am), P(d_ac) if cross else None, P(d_h0), C.byref(gr), P(ws), C.c_size_t(64), st(dev))
+        assert rc == 4
+
+
 def check_standalone_layer(dev):
     """IEGMN_Layer.forward on its own (reference signature, rigid_docking_model.py:189-352): the HIP composition
     (equidock_public_amd/ops.py: edge messages + cross attention in the library, forward and backward) against the

@@ -98,3 +98,27 @@ def test_two_rank_gradients_equal_single_process(tmp_path):
     ref = flat
     err = float((r0['flat'] - ref).norm() / ref.norm())
     assert err < 1e-5, err
+
+
+def test_bench_gpus2_relaunches_itself_under_torchrun():
+    """`python bench.py --gpus 2` WITHOUT a launcher (no RANK in the environment) must re-execute itself under
+    torch.distributed.run with two ranks, print exactly one JSON line (rank 0) and propagate the exit code.  Here (no GPU)
+    the ranks run the launcher rehearsal (EQD_BENCH_DRY_RUN=1: gloo rendezvous, barrier, max over ranks); the same
+    command with the workload runs on the GPU box in tests/test_gpu_parity.py."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['EQD_BENCH_DRY_RUN'] = '1'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1'],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out['dry_run'] is True and out['n_gpus'] == 2 and out['steps'] == 2 and out['warmup'] == 1
+    assert 'torch.distributed.run' in r.stderr
+    # a failing rank must surface as a non-zero exit code of the plain command
+    env['EQD_BENCH_DRY_RUN_FAIL'] = '1'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1'],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode != 0

@@ -180,6 +180,14 @@ def test_model_forked_attention_stream(dev, monkeypatch):
     pc.check_model_case(dev, 'D_degraded3')
 
 
+def test_node_update_operator(dev):
+    """eqd_node_update_fwd / _bwd vs torch autograd of node_mlp + skip (64-wide, 69-wide with 80-float cross rows, no cross);
+    at 301 rows (four-wave kernels) and at 40 000 rows (k_rowres for the 64-wide chains)"""
+    from tests import parity_common as pc
+    pc.check_node_update(dev, rows=301)
+    pc.check_node_update(dev, rows=40000)
+
+
 def test_standalone_layer_through_the_library(dev):
     """IEGMN_Layer.forward on its own: edge messages + cross attention in the HIP library vs the torch-operator restatement"""
     from tests import parity_common as pc
@@ -454,6 +462,32 @@ def test_bench_workload_d_on_rccl_world_of_one(dev):
                   f"in the replayed hipGraph: {out['allreduce_in_graph']}")
 
 
+def test_bench_gpus2_plain_command_two_ranks_on_one_gpu(dev):
+    """`python bench.py --gpus 2 --steps 2` with NO launcher: bench.py re-executes itself under torch.distributed.run.  On
+    this one-GPU box both ranks share cuda:0 over gloo (EQD_BENCH_ONE_DEVICE=1, EQD_BENCH_BACKEND=gloo: a rehearsal of the
+    N > 1 control flow - rendezvous, barriers, max over ranks, the flat-gradient all-reduce every step, one line from rank
+    0 - not a measurement).  The secondary workload of a distributed default run (D) rides along."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY='0', EQD_BENCH_ONE_DEVICE='1', EQD_BENCH_BACKEND='gloo')
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--no-cpu-baseline',
+           '--no-roofline', '--no-secondary']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['steps'] == 2 and out['scaling'] == 'weak' and out['value'] > 0
+    assert out['config']['parallelism'] == 'dp2' and out['config']['pairs_per_gpu'] == 8
+    assert out['allreduce_us_per_step'] is not None
+    REPORT.append(f"python bench.py --gpus 2 (no launcher; self-relaunch, 2 ranks on one GPU over gloo): rc 0, one line, "
+                  f"{out['value']} pairs/s (rehearsal, not a measurement)")
+
+
 def test_big_batch_equals_small_batches(dev):
     """Config C regime (> 16 384 nodes: several super-tiles per workgroup in the edge backward, capped AtB parts):
     pairs are independent, so outputs must equal those of the same pairs run in batches of 4 (different kernel decompositions), and the gradient of the summed loss must equal the sum."""
@@ -596,7 +630,7 @@ def test_non_published_options_on_gpu(dev, name):
         assert float((got - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max())), (name, nm)
     loss = port.scalar_loss(outs)
     loss.backward()
-    assert abs(float(loss) - float(z[f'{name}_loss'])) <= 1e-4 * abs(float(z[f'{name}_loss']))
+    assert abs(float(loss.detach()) - float(z[f'{name}_loss'])) <= 1e-4 * abs(float(z[f'{name}_loss']))
     # (biases in front of a BatchNorm / GraphNorm: mathematically zero gradient, computed value = rounding noise of the
     # device's summation order - hence the floor relative to the largest gradient norm, as in tests/test_torch_path.py)
     floor = 1e-6 * max(v['grad_norms'].values()) + 1e-5

@@ -154,6 +154,10 @@ def test_model_forked_attention_stream(monkeypatch):
     pc.check_model_case(DEV, 'D_degraded3')
 
 
+def test_node_update_operator():
+    pc.check_node_update(DEV, rows=77)
+
+
 def test_standalone_layer_through_the_library():
     pc.check_standalone_layer(DEV)
 
