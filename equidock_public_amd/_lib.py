@@ -122,7 +122,7 @@ def _declare(lib):
                  'eqd_rigid_apply_fwd', 'eqd_rigid_apply_bwd', 'eqd_pair_losses_fwd', 'eqd_pair_losses_bwd', 'eqd_scalar_loss', 'eqd_pocket_ot_cost',
                  'eqd_pocket_ot_fwd', 'eqd_pocket_ot_bwd', 'eqd_rigid_augment', 'eqd_protein_graph_distances',
                  'eqd_protein_graph_select', 'eqd_protein_graph_edges', 'eqd_clash_iterations', 'eqd_dropout_pack_edges', 'eqd_dropout_draw',
-                 'eqd_node_update_fwd', 'eqd_node_update_bwd'):
+                 'eqd_node_update_fwd', 'eqd_node_update_bwd', 'eqd_selftest_lane_exchanges'):
         getattr(lib, name).restype = C.c_int
 
 
@@ -137,7 +137,8 @@ EXPORTS = ('eqd_model_layer_state', 'eqd_model_lrelu_signs', 'eqd_model_head_bac
            'eqd_pair_losses_bwd', 'eqd_scalar_loss', 'eqd_pocket_ot_cost', 'eqd_pocket_ot_fwd', 'eqd_pocket_ot_bwd',
            'eqd_rigid_augment', 'eqd_protein_graph_distances', 'eqd_protein_graph_select', 'eqd_protein_graph_edges',
            'eqd_clash_workspace_bytes', 'eqd_clash_iterations', 'eqd_dropout_pack_edges', 'eqd_dropout_draw',
-           'eqd_tunables_reload', 'eqd_node_update_fwd', 'eqd_node_update_bwd_workspace_bytes', 'eqd_node_update_bwd')
+           'eqd_tunables_reload', 'eqd_node_update_fwd', 'eqd_node_update_bwd_workspace_bytes', 'eqd_node_update_bwd',
+           'eqd_selftest_lane_exchanges')
 
 
 def load_library():
@@ -171,9 +172,14 @@ def unload_for_testing():
     _lib, _is_sim = None, False
 
 
+tunables_generation = 0      # bumped by reload_tunables(): sizes cached per PackedGraph depend on the switches
+
+
 def reload_tunables():
     """Make the loaded library re-read its EQD_* experiment switches (it snapshots them once per process; tests and A/B
     measurements that change the environment afterwards call this).  No-op when no library is loaded yet."""
+    global tunables_generation
+    tunables_generation += 1
     if _lib is not None:
         _lib.eqd_tunables_reload()
 

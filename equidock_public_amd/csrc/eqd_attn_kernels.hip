@@ -951,8 +951,16 @@ size_t eqd_attention_ds_bytes(const EqdGraph* g) {
 // Taken when the batch gives every CU more than one attention item (64 x (300, 300): 1 280; 4 x (2000, 2000): 504): there
 // the backward is arithmetic-bound and 5 / 7 of the MFMA work wins; a DB5.5-sized batch (112 items) is one latency-bound
 // round of workgroups either way and keeps the single launch.  EQD_ATT_DS=0|1 forces either (tests, A/B runs).
+// max_seg sets the dS row stride, and the kernels index a row by (key - first node of the key's protein) without a bound
+// check: a max_seg below the longest protein would write across rows / past the arena.  The host cannot see seg_off (device
+// memory), but it can reject values that are impossible for ANY segmentation of the node counts: the longest of n_pairs
+// proteins is at least their average and at most their sum.  An implausible max_seg keeps the recompute form (no workspace).
+static bool att_max_seg_plausible(const EqdGraph* g) {
+    const long long big = g->n_lig > g->n_rec ? g->n_lig : g->n_rec;
+    return g->n_pairs > 0 && g->max_seg > 0 && (long long)g->max_seg * g->n_pairs >= big && g->max_seg <= big;
+}
 int eqd_attention_ds_wanted(const EqdGraph* g, int d, bool bf16) {
-    if ((d != 64 && d != 80) || g->n_att_items <= 0 || g->n_att_items % 8 != 0 || g->max_seg <= 0) return 0;
+    if ((d != 64 && d != 80) || g->n_att_items <= 0 || g->n_att_items % 8 != 0 || !att_max_seg_plausible(g)) return 0;
     if (bf16 && d == 64) {      // bf16 mode: the LDS-bf16 kernels of the 64-wide layers (the 80-wide first layer: fp32 tiles, bf16 operands)
         const char* nb2 = eqd_tunable("EQD_ATT_LB_NB");
         if (!att_lds_bf16() || (nb2 && nb2[0] == '2')) return 0;
@@ -1051,6 +1059,11 @@ extern "C" int eqd_cross_attention_bwd_ds(const EqdGraph* g, int d, const float*
     if (!g || !q || !k || !v || !out || !lse || !d_out || !dq || !dk || !dv || !ws) {
         eqd_set_error("eqd_cross_attention_bwd_ds: NULL argument");
         return EQD_ERR_NULL;
+    }
+    if (!att_max_seg_plausible(g)) {
+        eqd_set_error("eqd_cross_attention_bwd_ds: EqdGraph.max_seg = %d cannot be the longest protein of %d pairs with %d + %d "
+                      "nodes (it is the dS row stride: see include/equidock_hip.h)", g->max_seg, g->n_pairs, g->n_lig, g->n_rec);
+        return EQD_ERR_SHAPE;
     }
     if ((d != 64 && d != 80) || g->n_att_items % 8 != 0 || g->max_seg <= 0 ||
         !(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(d_out) && aligned16(out) && aligned16(ws))) {

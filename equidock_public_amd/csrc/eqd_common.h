@@ -245,7 +245,11 @@ __device__ __forceinline__ float lane_swap_sum(float v, int want_max) {
     return want_max ? fmaxf(v, o) : v + o;
 #else
     // (inline assembly: the instruction rewrites BOTH registers; s_nop 1 = the wait states hipcc itself puts between a VALU
-    //  write of an operand and the swap)
+    //  write of an operand and the swap.  The other direction needs none: for the builtin hipcc (ROCm 7.2, -O3, gfx950) emits
+    //  `s_nop 1; v_permlane16_swap_b32 v1, v2; v_add_f32 v1, ...` - the VALU read of the swapped register follows the swap
+    //  directly, LLVM's gfx950 hazard recognizer has no wait state after it (checked in the round-5 ADVICE pass by compiling
+    //  the builtin form and reading the assembly); tests/parity_common.py: check_lane_exchanges compares group_sum / group_max
+    //  with __shfl_xor sums on the GPU)
     float x = v, y = v;
     if constexpr (M == 16) asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
     else asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));

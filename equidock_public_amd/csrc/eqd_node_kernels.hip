@@ -45,16 +45,29 @@ int g_tun_n = 0;
 std::mutex g_tun_mu;
 }  // namespace
 const char* eqd_tunable(const char* name) {
+    // the value is copied out while the lock is held: the returned pointer is the calling thread's own buffer (a ring of
+    // eight, so that a caller may hold a few lookups at once), never a slot a concurrent eqd_tunables_reload() rewrites
+    static thread_local char ring[8][sizeof(((EqdTunable*)0)->value)];
+    static thread_local int ring_at = 0;
     std::lock_guard<std::mutex> lk(g_tun_mu);
-    for (int i = 0; i < g_tun_n; ++i)
-        if (strcmp(g_tun[i].name, name) == 0) return g_tun[i].set ? g_tun[i].value : nullptr;
-    const char* v = getenv(name);
-    if (g_tun_n >= 32 || strlen(name) >= sizeof(g_tun[0].name)) return v;      // (table full: uncached, never wrong)
-    EqdTunable& t = g_tun[g_tun_n++];
-    snprintf(t.name, sizeof(t.name), "%s", name);
-    t.set = v != nullptr;
-    snprintf(t.value, sizeof(t.value), "%s", v ? v : "");
-    return t.set ? t.value : nullptr;
+    const EqdTunable* hit = nullptr;
+    for (int i = 0; i < g_tun_n && !hit; ++i)
+        if (strcmp(g_tun[i].name, name) == 0) hit = &g_tun[i];
+    if (!hit) {
+        const char* v = getenv(name);
+        // (table full, a name or a value that does not fit a slot: uncached, never truncated, never wrong)
+        if (g_tun_n >= 32 || strlen(name) >= sizeof(g_tun[0].name) || (v && strlen(v) >= sizeof(g_tun[0].value))) return v;
+        EqdTunable& t = g_tun[g_tun_n++];
+        snprintf(t.name, sizeof(t.name), "%s", name);
+        t.set = v != nullptr;
+        snprintf(t.value, sizeof(t.value), "%s", v ? v : "");
+        hit = &t;
+    }
+    if (!hit->set) return nullptr;
+    char* out = ring[ring_at];
+    ring_at = (ring_at + 1) & 7;
+    memcpy(out, hit->value, sizeof(hit->value));
+    return out;
 }
 extern "C" void eqd_tunables_reload(void) {
     std::lock_guard<std::mutex> lk(g_tun_mu);
@@ -173,6 +186,61 @@ int eqd_num_cus() {
 extern "C" const char* eqd_last_error(void) { return g_err; }
 extern "C" int eqd_abi_version(void) { return EQD_ABI_VERSION; }
 extern "C" int eqd_tile_edges(void) { return EQD_TILE_EDGES; }
+
+// ------------------------------------------------------------------------------------------
+// Self test of the lane exchanges of eqd_common.h (DPP moves, v_permlane{16,32}_swap through inline assembly) against
+// the plain __shfl_xor forms they replace, on lane-distinct values and at several points of one kernel (the hazards
+// around the swap instruction depend on the neighbouring instructions).  mismatch[0] = number of (lane, check) pairs
+// whose bits differ.  Test aid (tests/parity_common.py: check_lane_exchanges).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(EQD_BLOCK) void k_selftest_lanes(const float* __restrict__ in, int* __restrict__ mismatch,
+                                                              float* __restrict__ out) {
+    const int t = threadIdx.x, lane = t & 63;
+    int bad = 0;
+    auto same = [&](float a, float b) { bad += __builtin_bit_cast(unsigned, a) != __builtin_bit_cast(unsigned, b); };
+    auto ref_sum = [&](float v, int lo, int hi) {      // butterfly over masks lo .. hi (the order the helpers use)
+        for (int m = lo; m <= hi; m <<= 1) v += __shfl_xor(v, m);
+        return v;
+    };
+    float v = in[t];
+    float acc = 0.f;
+    for (int rep = 0; rep < 3; ++rep) {
+        v = v * 1.25f + (float)rep;                        // a VALU write right in front of the exchanges
+        const float gs = group_sum(v);
+        same(gs, ref_sum(v, 16, 32));
+        const float w = gs * 0.5f - v;                     // a VALU read right behind them
+        same(group_max(w), fmaxf(fmaxf(w, __shfl_xor(w, 16)), __shfl_xor(fmaxf(w, __shfl_xor(w, 16)), 32)));
+        same(l16_sum(w), ref_sum(w, 1, 8));
+        same(wave_sum(v), ref_sum(ref_sum(v, 1, 8), 16, 32));
+        same(lane_xor<1>(w), __shfl_xor(w, 1));
+        same(lane_xor<2>(w), __shfl_xor(w, 2));
+        same(lane_xor<4>(w), __shfl_xor(w, 4));
+        same(lane_xor<8>(w), __shfl_xor(w, 8));
+        float a16[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a16[i] = w * (float)(i + 1) + v;
+        float r16 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float si = ref_sum(a16[i], 1, 8);
+            r16 = (lane & 15) == i ? si : r16;
+        }
+        // (reduce16x16 sums in a different order than a plain butterfly: compared to rounding, not bit for bit)
+        const float got = reduce16x16(a16, lane & 15);
+        bad += !(fabsf(got - r16) <= 1e-5f * (fabsf(r16) + 1.f));
+        acc += gs + w;
+    }
+    out[t] = acc;
+    if (bad) atomicAdd(mismatch, bad);
+}
+extern "C" int eqd_selftest_lane_exchanges(const float* in256, int* mismatch, float* out256, void* stream) {
+    if (!in256 || !mismatch || !out256) {
+        eqd_set_error("eqd_selftest_lane_exchanges: NULL argument");
+        return EQD_ERR_NULL;
+    }
+    hipLaunchKernelGGL(k_selftest_lanes, dim3(1), dim3(EQD_BLOCK), 0, (hipStream_t)stream, in256, mismatch, out256);
+    return eqd_check_launch("k_selftest_lanes");
+}
 
 // ------------------------------------------------------------------------------------------
 // k_linear: Y = alpha * f(sum_s (X_s * lrelu'(mask_s)) W_s^T + bias) + beta * R

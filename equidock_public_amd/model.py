@@ -264,10 +264,20 @@ class DropoutMasks:
         out.seed = seed
         return out
 
+    _told_default = False
+
     @staticmethod
     def draw(iegmn, g, packed):
         import torch.nn.functional as F
         src = iegmn.args.get('hip_dropout_masks', DEFAULT_DROPOUT_MASKS)
+        if 'hip_dropout_masks' not in iegmn.args and not DropoutMasks._told_default:
+            # once per process: a run compared against a reference run with the same seed needs nn.Dropout's own stream
+            DropoutMasks._told_default = True
+            import warnings
+            warnings.warn("equidock_public_amd: training-mode dropout masks are drawn by the library (eqd_dropout_draw: same "
+                          "Bernoulli law as nn.Dropout, NOT torch's random stream).  Set args['hip_dropout_masks'] = 'torch' to "
+                          "consume nn.Dropout's stream in the reference's order (bit-for-bit masks of a reference run with the "
+                          "same seed), or 'library' to silence this note.", stacklevel=2)
         if src == 'library':
             return DropoutMasks.draw_library(iegmn, packed)
         if src != 'torch':
@@ -380,7 +390,10 @@ class _IEGMNFunction(torch.autograd.Function):
         T = torch.empty(B, 3, 3, **f32)
         b = torch.empty(B, 3, **f32)
         status = torch.empty(B, dtype=torch.int32, device=dev)
-        key = (desc.n_layers, desc.n_heads, desc.d_emb, desc.use_mean_node_features)
+        # (the scratch size also depends on the arithmetic mode and on the EQD_* switches that select the dS hand-off form of the
+        #  attention backward: the mode is part of the key, _lib.reload_tunables() bumps the generation)
+        key = (desc.n_layers, desc.n_heads, desc.d_emb, desc.use_mean_node_features, desc.storage_bf16, desc.cross_msgs,
+               _lib.tunables_generation)
         if packed.ws_sizes.get(key) is None:
             with _lib.device_guard(dev):    # workgroup counts (hence partial-sum workspaces) follow the device's CU count
                 sb = lib.eqd_model_saved_bytes(C.byref(desc), C.byref(gs))

@@ -61,6 +61,10 @@ int eqd_is_simulator(void);
  * agree on the forms they run.  A caller that changes one of them afterwards calls this to make the library forget its
  * snapshot (nothing in the reference corresponds to it). */
 void eqd_tunables_reload(void);
+/* Test aid: one 256-thread workgroup runs the library's cross-lane helpers (DPP moves, v_permlane{16,32}_swap) on in256
+ * [256] beside the plain ds_bpermute forms; *mismatch (device int, zeroed by the caller) receives the number of differing
+ * (lane, check) pairs, out256 [256] a value that depends on every exchange. */
+int eqd_selftest_lane_exchanges(const float* in256, int* mismatch, float* out256, void* stream);
 
 /* ---- per-launch timing (measurement aid for bench.py; nothing in the reference corresponds to it) ----
  * Between eqd_profile_begin(stream, max) and eqd_profile_end() every kernel this library launches (from any thread:
@@ -81,6 +85,13 @@ float eqd_profile_us(int i);
  *      heterograph (src/utils/train_utils.py:61-100). Built by equidock_public_amd/graph.py. ---- */
 typedef struct EqdGraph {
     int32_t n_pairs, n_lig, n_rec, n_nodes, n_edges, n_tiles, n_att_items, max_seg;
+    /* max_seg = the node count of the LONGEST protein of the batch (max over seg_off differences).  Not only a scheduling
+     * hint: the dS hand-off form of the attention backward (eqd_cross_attention_bwd_ds, and eqd_model_backward for large
+     * batches) uses it as the row stride of its workspace and writes row[key - first node of the key's protein] without a
+     * bound check - a smaller value corrupts the workspace.  The library can only reject values impossible for the node
+     * counts (max_seg * n_pairs < max(n_lig, n_rec), or max_seg > max(n_lig, n_rec)); the packers (graph.py,
+     * eqd_host_pack.cpp) compute it from the same counts as seg_off.  That form also assumes att_items[i].other_begin /
+     * other_end are exactly the partner protein's segment bounds (what the packers emit). */
     const int32_t* seg_off;    /* [2*n_pairs+1] global node offsets: ligand segments then receptor segments */
     const int32_t* src;        /* [n_edges] */
     const int32_t* dst;        /* [n_edges] sorted ascending */

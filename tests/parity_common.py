@@ -1368,6 +1368,18 @@ def check_dropout_library(dev):
     assert w2 <= 5e-3 and wm <= 2e-2
 
 
+def check_lane_exchanges(dev):
+    """The DPP / v_permlane*_swap lane exchanges (csrc/eqd_common.h) against __shfl_xor inside one kernel, bit for bit."""
+    torch.manual_seed(2)
+    x = (torch.randn(256) * 3).to(dev)
+    bad = torch.zeros(1, dtype=torch.int32, device=dev)
+    out = torch.zeros(256, device=dev)
+    L.check(lib().eqd_selftest_lane_exchanges(P(x), P(bad), P(out), st(dev)))
+    sync(dev)
+    assert int(bad.item()) == 0, f'{int(bad.item())} lane-exchange mismatches'
+    assert bool(torch.isfinite(out).all()) and float(out.abs().sum()) > 0
+
+
 def check_node_update(dev, rows=301):
     """eqd_node_update_fwd / _bwd (rigid_docking_model.py:319-337) against torch autograd of the as-written node_mlp
     (Linear, LeakyReLU, LayerNorm, Linear) + skip connection: the 64-wide layer (skip), the 69-wide first layer with the

@@ -180,6 +180,12 @@ def test_model_forked_attention_stream(dev, monkeypatch):
     pc.check_model_case(dev, 'D_degraded3')
 
 
+def test_lane_exchanges(dev):
+    """DPP / v_permlane*_swap helpers vs __shfl_xor, bit for bit, inside one kernel"""
+    from tests import parity_common as pc
+    pc.check_lane_exchanges(dev)
+
+
 def test_node_update_operator(dev):
     """eqd_node_update_fwd / _bwd vs torch autograd of node_mlp + skip (64-wide, 69-wide with 80-float cross rows, no cross);
     at 301 rows (four-wave kernels) and at 40 000 rows (k_rowres for the 64-wide chains)"""

@@ -154,6 +154,10 @@ def test_model_forked_attention_stream(monkeypatch):
     pc.check_model_case(DEV, 'D_degraded3')
 
 
+def test_lane_exchanges():
+    pc.check_lane_exchanges(DEV)
+
+
 def test_node_update_operator():
     pc.check_node_update(DEV, rows=77)
 
