@@ -549,76 +549,102 @@ extern "C" int eqd_keypoint_pool_bwd(const EqdGraph* g, int n_heads, const float
 }
 
 // ---------------------------------------------------------------------------------------------
-// Kabsch: 3x3 SVD by one-sided Jacobi in fp64 (one thread per pair; singular values descending)
+// Kabsch (rigid_docking_model.py:563-589), one WAVE per pair:
+//   * lane k holds keypoint k of both proteins (two per lane when K > 64); the 6 mean and the 9 covariance sums are
+//     wave reductions (DPP steps inside a row of 16 lanes, v_permlane swaps across rows; fixed order, no LDS);
+//   * the 3x3 SVD is a one-sided (Hestenes) Jacobi iteration in fp32 with the matrix held ACROSS lanes: lane r (r = lane
+//     & 3 < 3) of a quad holds row r of B = A V and row r of V; a column dot product is two DPP steps inside the quad,
+//     the rotation parameters are computed redundantly, every lane rotates its own row (every quad does the same work);
+//   * fp64 only where a sign or a threshold is decided: det A and the reference's stability guard (:574).
+// Rounding-level differences to an fp64 SVD (the previous form, one lane per pair in fp64): T to ~3e-7.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void svd3(const double A[3][3], double U[3][3], double S[3], double V[3][3]) {
-    double Bm[3][3];
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) {
-            Bm[i][j] = A[i][j];
-            V[i][j] = (i == j) ? 1.0 : 0.0;
-        }
-    for (int sweep = 0; sweep < 30; ++sweep) {
-        double off = 0.0;
-        for (int p = 0; p < 2; ++p)
-            for (int q = p + 1; q < 3; ++q) {
-                double al = 0, be = 0, ga = 0;
-                for (int i = 0; i < 3; ++i) {
-                    al += Bm[i][p] * Bm[i][p];
-                    be += Bm[i][q] * Bm[i][q];
-                    ga += Bm[i][p] * Bm[i][q];
-                }
-                if (fabs(ga) <= 2e-16 * sqrt(al * be) || ga == 0.0) continue;   // converged to fp64 rounding
-                off += fabs(ga);
-                const double zeta = (be - al) / (2.0 * ga);
-                const double tt = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
-                for (int i = 0; i < 3; ++i) {
-                    const double bp = Bm[i][p], bq = Bm[i][q];
-                    Bm[i][p] = cs * bp - sn * bq;
-                    Bm[i][q] = sn * bp + cs * bq;
-                    const double vp = V[i][p], vq = V[i][q];
-                    V[i][p] = cs * vp - sn * vq;
-                    V[i][q] = sn * vp + cs * vq;
-                }
-            }
-        if (off == 0.0) break;
-    }
+__device__ __forceinline__ float quad_sum(float v) {
+    v += lane_xor<1>(v);
+    v += lane_xor<2>(v);
+    return v;
+}
+template <int J>
+__device__ __forceinline__ float quad_bcast(float v) {      // lane J of the caller's quad
+#if defined(EQD_HOSTSIM) || defined(EQD_NO_DPP)
+    return __shfl(v, (int)((threadIdx.x & 63) & ~3u) + J);
+#else
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), J * 0x55, 0xf, 0xf, false));
+#endif
+}
+__device__ __forceinline__ float kab_rcp(float x) {
+#ifdef EQD_HOSTSIM
+    return 1.f / x;
+#else
+    return __builtin_amdgcn_rcpf(x);
+#endif
+}
+__device__ __forceinline__ float kab_rsqrt(float x) {      // one Newton step on v_rsq_f32: c^2 + s^2 = 1 to half an ulp
+#ifdef EQD_HOSTSIM
+    return 1.f / sqrtf(x);
+#else
+    const float r = __builtin_amdgcn_rsqf(x);
+    return r * (1.5f - 0.5f * x * r * r);
+#endif
+}
+// in: A (every lane, fp32), row = lane & 3.  out: this lane's row of U and of V (zeros on row 3), S descending (every lane)
+__device__ __forceinline__ void svd3_lanes(const float (&A)[3][3], int row, float (&u)[3], float (&v)[3], float (&S)[3]) {
+    float b[3];
+#pragma unroll
     for (int j = 0; j < 3; ++j) {
-        double n = 0;
-        for (int i = 0; i < 3; ++i) n += Bm[i][j] * Bm[i][j];
-        S[j] = sqrt(n);
+        b[j] = row == 0 ? A[0][j] : row == 1 ? A[1][j] : row == 2 ? A[2][j] : 0.f;
+        v[j] = row == j ? 1.f : 0.f;
     }
-    // sort descending (selection sort on columns)
-    for (int a = 0; a < 2; ++a) {
-        int best = a;
-        for (int b = a + 1; b < 3; ++b)
-            if (S[b] > S[best]) best = b;
-        if (best != a) {
-            const double ts = S[a]; S[a] = S[best]; S[best] = ts;
-            for (int i = 0; i < 3; ++i) {
-                double tb = Bm[i][a]; Bm[i][a] = Bm[i][best]; Bm[i][best] = tb;
-                double tv = V[i][a]; V[i][a] = V[i][best]; V[i][best] = tv;
-            }
+    const float TOL2 = 9e-14f;      // (3e-7)^2: columns orthogonal to fp32 rounding
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        bool rotated = false;
+#pragma unroll
+        for (int pq = 0; pq < 3; ++pq) {
+            const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2;      // (0,1), (0,2), (1,2): cyclic by rows
+            const float al = quad_sum(b[p] * b[p]), be = quad_sum(b[q] * b[q]), ga = quad_sum(b[p] * b[q]);
+            if (ga * ga <= TOL2 * (al * be)) continue;               // (uniform over the wave: every quad holds the same matrix)
+            rotated = true;
+            const float zeta = (be - al) * kab_rcp(2.f * ga);
+            const float tt = copysignf(1.f, zeta) * kab_rcp(fabsf(zeta) + sqrtf(1.f + zeta * zeta));
+            const float cs = kab_rsqrt(1.f + tt * tt), sn = cs * tt;
+            const float bp = b[p], bq = b[q], vp = v[p], vq = v[q];
+            b[p] = cs * bp - sn * bq;
+            b[q] = sn * bp + cs * bq;
+            v[p] = cs * vp - sn * vq;
+            v[q] = sn * vp + cs * vq;
         }
+        if (!rotated) break;
     }
-    for (int j = 0; j < 3; ++j)
-        for (int i = 0; i < 3; ++i) U[i][j] = S[j] > 1e-300 ? Bm[i][j] / S[j] : 0.0;
-    if (!(S[2] > 1e-300)) {  // rank deficient: complete the basis so that U stays orthonormal
-        U[0][2] = U[1][0] * U[2][1] - U[2][0] * U[1][1];
-        U[1][2] = U[2][0] * U[0][1] - U[0][0] * U[2][1];
-        U[2][2] = U[0][0] * U[1][1] - U[1][0] * U[0][1];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) S[j] = sqrtf(quad_sum(b[j] * b[j]));
+    auto swap_cols = [&](int a, int c) {
+        float t0 = S[a]; S[a] = S[c]; S[c] = t0;
+        t0 = b[a]; b[a] = b[c]; b[c] = t0;
+        t0 = v[a]; v[a] = v[c]; v[c] = t0;
+    };
+    // descending (selection sort on columns, decisions uniform)
+    if (S[1] > S[0] && S[1] >= S[2]) swap_cols(0, 1);
+    else if (S[2] > S[0]) swap_cols(0, 2);
+    if (S[2] > S[1]) swap_cols(1, 2);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) u[j] = S[j] > 0.f ? b[j] / S[j] : 0.f;
+    if (!(S[2] > 0.f)) {   // rank deficient: complete the basis so that U stays orthonormal, U[:,2] = U[:,0] x U[:,1]
+        const int base = (int)((threadIdx.x & 63) & ~3u), r1 = (row + 1) % 3, r2 = (row + 2) % 3;
+        const float a0 = __shfl(u[0], base + r1), a1 = __shfl(u[1], base + r1);
+        const float c0 = __shfl(u[0], base + r2), c1 = __shfl(u[1], base + r2);
+        u[2] = row < 3 ? a0 * c1 - c0 * a1 : 0.f;
     }
 }
-__device__ __forceinline__ double det3(const double A[3][3]) {
-    return A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
-           A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+__device__ __forceinline__ double det3f(const float (&A)[3][3]) {
+    const double a00 = A[0][0], a01 = A[0][1], a02 = A[0][2], a10 = A[1][0], a11 = A[1][1], a12 = A[1][2], a20 = A[2][0],
+                 a21 = A[2][1], a22 = A[2][2];
+    return a00 * (a11 * a22 - a12 * a21) - a01 * (a10 * a22 - a12 * a20) + a02 * (a10 * a21 - a11 * a20);
 }
-__device__ __forceinline__ bool svd_unstable(const double S[3]) {
-    // rigid_docking_model.py:574 (the "+ eye" keeps the diagonal out of the min)
-    double mn = fmin(S[0], fmin(S[1], S[2]));
+__device__ __forceinline__ bool svd_unstable(const float (&Sf)[3]) {
+    // rigid_docking_model.py:574 (the "+ eye" keeps the diagonal out of the min); thresholds evaluated in fp64
+    const double S0 = Sf[0], S1 = Sf[1], S2 = Sf[2];
+    const double mn = fmin(S0, fmin(S1, S2));
     if (mn < 1e-3) return true;
-    const double s0 = S[0] * S[0], s1 = S[1] * S[1], s2 = S[2] * S[2];
+    const double s0 = S0 * S0, s1 = S1 * S1, s2 = S2 * S2;
     const double gap = fmin(fabs(s0 - s1), fmin(fabs(s0 - s2), fabs(s1 - s2)));
     return gap < 1e-2;
 }
@@ -628,10 +654,24 @@ __device__ __forceinline__ float uniform_draw(unsigned seed, unsigned pair, unsi
     return (float)(h >> 8) * (1.0f / 16777216.0f);
 }
 
-// One 64-thread workgroup per pair: the keypoints are staged in LDS with coalesced loads, the 6 mean and 9
-// covariance sums run on 15 lanes (each in the sequential k order of the reference's fp32 reductions), lane 0
-// does the fp64 SVD and the guard loop.
 #define KAB_MAXK 128
+#define KAB_KPL (KAB_MAXK / 64)      /* keypoints per lane */
+// this lane's keypoints of both proteins (zeros beyond K), their means and the covariance A = (Yr - mr)^T (Yl - ml)
+__device__ __forceinline__ void kab_load(const float* __restrict__ Yl, const float* __restrict__ Yr, int K, int t,
+                                         float (&yl)[KAB_KPL][3], float (&yr)[KAB_KPL][3]) {
+#pragma unroll
+    for (int kk = 0; kk < KAB_KPL; ++kk) {
+        const int k = t + 64 * kk;
+        const bool ok = k < K;
+        const size_t o = (size_t)(ok ? k : 0) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float a = Yl[o + c], b = Yr[o + c];
+            yl[kk][c] = ok ? a : 0.f;
+            yr[kk][c] = ok ? b : 0.f;
+        }
+    }
+}
 __global__ __launch_bounds__(64) void k_kabsch_fwd(int B, int K, const float* __restrict__ Y,
                                                    const float* __restrict__ draws, int seed, float* __restrict__ T,
                                                    float* __restrict__ T2, float* __restrict__ bvec,
@@ -639,91 +679,100 @@ __global__ __launch_bounds__(64) void k_kabsch_fwd(int B, int K, const float* __
                                                    const int32_t* __restrict__ seg_off, const float* __restrict__ x0,
                                                    float* __restrict__ lig_out, double* __restrict__ usv) {
     // lig_out != NULL: the rigid apply of the pair's ligand nodes (k_apply_fwd's arithmetic) runs here as well
-    __shared__ float sy[2][KAB_MAXK * 3];
-    __shared__ float smean[6], sA[9], sTb[12];
-    const int p = blockIdx.x, t = threadIdx.x;
-    const float* Yl = Y + (size_t)p * K * 3;
-    const float* Yr = Y + (size_t)(B + p) * K * 3;
-    for (int i = t; i < 3 * K; i += 64) {
-        sy[0][i] = Yl[i];
-        sy[1][i] = Yr[i];
+    const int p = blockIdx.x, t = threadIdx.x, row = t & 3;
+    float yl[KAB_KPL][3], yr[KAB_KPL][3];
+    kab_load(Y + (size_t)p * K * 3, Y + (size_t)(B + p) * K * 3, K, t, yl, yr);
+    // (the rigid apply's first rows are requested now, beside the keypoints: one memory round trip instead of two)
+    int n0 = 0, n1 = 0;
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (lig_out) {
+        n0 = seg_off[p]; n1 = seg_off[p + 1];      // ligand segments are the first B entries
+        if (n0 + t < n1) {
+            px = x0[(size_t)(n0 + t) * 3]; py = x0[(size_t)(n0 + t) * 3 + 1]; pz = x0[(size_t)(n0 + t) * 3 + 2];
+        }
     }
-    __syncthreads();
-    if (t < 6) {
-        const int side = t / 3, c = t - 3 * side;
-        float a = 0.f;
-        for (int k = 0; k < K; ++k) a += sy[side][k * 3 + c];
-        smean[t] = a / (float)K;
-    }
-    __syncthreads();
-    if (t < 9) {
-        const int i = t / 3, j = t - 3 * i;
-        float a = 0.f;
-        for (int k = 0; k < K; ++k) a += (sy[1][k * 3 + i] - smean[3 + i]) * (sy[0][k * 3 + j] - smean[j]);
-        sA[t] = a;
-    }
-    __syncthreads();
-    if (t == 0) {
+    const float invK = 1.f / (float)K;
     float ml[3], mr[3], Af[3][3];
+#pragma unroll
     for (int c = 0; c < 3; ++c) {
-        ml[c] = smean[c];
-        mr[c] = smean[3 + c];
+        float sl = 0.f, sr = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KAB_KPL; ++kk) {
+            sl += yl[kk][c];
+            sr += yr[kk][c];
+        }
+        ml[c] = wave_sum(sl) * invK;
+        mr[c] = wave_sum(sr) * invK;
     }
+#pragma unroll
     for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) Af[i][j] = sA[i * 3 + j];
-    double A[3][3], U[3][3], S[3], V[3][3];
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) A[i][j] = (double)Af[i][j];
-    svd3(A, U, S, V);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float a = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < KAB_KPL; ++kk)
+                a += (t + 64 * kk < K) ? (yr[kk][i] - mr[i]) * (yl[kk][j] - ml[j]) : 0.f;
+            Af[i][j] = wave_sum(a);
+        }
+    float u[3], v[3], S[3];
+    svd3_lanes(Af, row, u, v, S);
     int it = 0;
     while (svd_unstable(S)) {
         if (it >= 10) {   // reference: sys.exit(1) (:582-584); here: status 11, keep going
             it = 11;
             break;
         }
-        for (int c = 0; c < 3; ++c) {
-            const float dr = draws ? draws[((size_t)p * 10 + it) * 3 + c] : uniform_draw((unsigned)seed, p, it, c);
-            Af[c][c] += dr;                       // A = A + rand(3,3) * eye(3)  (:578), in fp32 like the reference
-            A[c][c] = (double)Af[c][c];
-        }
-        svd3(A, U, S, V);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)      // A = A + rand(3,3) * eye(3)  (:578), in fp32 like the reference
+            Af[c][c] += draws ? draws[((size_t)p * 10 + it) * 3 + c] : uniform_draw((unsigned)seed, p, it, c);
+        svd3_lanes(Af, row, u, v, S);
         ++it;
     }
-    status[p] = it;
-    if (usv) {       // U, S, V of the (guarded) A for the backward: the serial fp64 Jacobi SVD is most of that kernel's time
-        double* o = usv + (size_t)p * 21;
-        for (int i = 0; i < 3; ++i) {
-            o[9 + i] = S[i];
-            for (int j = 0; j < 3; ++j) {
-                o[i * 3 + j] = U[i][j];
-                o[12 + i * 3 + j] = V[i][j];
-            }
-        }
+    const float sd = det3f(Af) < 0.0 ? -1.f : 1.f;
+    // T = U diag(1, 1, sd) V^T: lane `row` computes row `row` (the rows of V come from the quad's lanes 0..2)
+    float Trow[3];
+    {
+        const float v00 = quad_bcast<0>(v[0]), v01 = quad_bcast<0>(v[1]), v02 = quad_bcast<0>(v[2]);
+        const float v10 = quad_bcast<1>(v[0]), v11 = quad_bcast<1>(v[1]), v12 = quad_bcast<1>(v[2]);
+        const float v20 = quad_bcast<2>(v[0]), v21 = quad_bcast<2>(v[1]), v22 = quad_bcast<2>(v[2]);
+        Trow[0] = u[0] * v00 + u[1] * v01 + sd * u[2] * v02;
+        Trow[1] = u[0] * v10 + u[1] * v11 + sd * u[2] * v12;
+        Trow[2] = u[0] * v20 + u[1] * v21 + sd * u[2] * v22;
     }
-    const double sd = det3(A) < 0.0 ? -1.0 : 1.0;
-    float Tm[3][3];
-    for (int i = 0; i < 3; ++i)
+    const float mrr = row == 0 ? mr[0] : row == 1 ? mr[1] : mr[2];
+    const float brow = mrr - (Trow[0] * ml[0] + Trow[1] * ml[1] + Trow[2] * ml[2]);
+    if (t < 3) {
+#pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const double tt = U[i][0] * V[j][0] + U[i][1] * V[j][1] + sd * U[i][2] * V[j][2];
-            Tm[i][j] = (float)tt;
-            T[(size_t)p * 9 + i * 3 + j] = (float)tt;
-            if (T2) T2[(size_t)p * 9 + i * 3 + j] = (float)tt;
-            A_out[(size_t)p * 9 + i * 3 + j] = Af[i][j];
-            sTb[i * 3 + j] = (float)tt;
+            T[(size_t)p * 9 + t * 3 + j] = Trow[j];
+            if (T2) T2[(size_t)p * 9 + t * 3 + j] = Trow[j];
+            A_out[(size_t)p * 9 + t * 3 + j] = t == 0 ? Af[0][j] : t == 1 ? Af[1][j] : Af[2][j];
         }
-    for (int i = 0; i < 3; ++i) {
-        const float bi = mr[i] - (Tm[i][0] * ml[0] + Tm[i][1] * ml[1] + Tm[i][2] * ml[2]);
-        bvec[(size_t)p * 3 + i] = bi;
-        sTb[9 + i] = bi;
+        bvec[(size_t)p * 3 + t] = brow;
+        if (usv) {       // U, S, V of the (guarded) A for the backward
+            double* o = usv + (size_t)p * 21;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                o[t * 3 + j] = (double)u[j];
+                o[12 + t * 3 + j] = (double)v[j];
+            }
+            o[9 + t] = (double)(t == 0 ? S[0] : t == 1 ? S[1] : S[2]);
+        }
     }
-    }
+    if (t == 0) status[p] = it;
     if (!lig_out) return;
-    __syncthreads();
-    const int n0 = seg_off[p], n1 = seg_off[p + 1];      // ligand segments are the first B entries
+    float Tm[3][3], bb[3];
+    Tm[0][0] = quad_bcast<0>(Trow[0]); Tm[0][1] = quad_bcast<0>(Trow[1]); Tm[0][2] = quad_bcast<0>(Trow[2]);
+    Tm[1][0] = quad_bcast<1>(Trow[0]); Tm[1][1] = quad_bcast<1>(Trow[1]); Tm[1][2] = quad_bcast<1>(Trow[2]);
+    Tm[2][0] = quad_bcast<2>(Trow[0]); Tm[2][1] = quad_bcast<2>(Trow[1]); Tm[2][2] = quad_bcast<2>(Trow[2]);
+    bb[0] = quad_bcast<0>(brow); bb[1] = quad_bcast<1>(brow); bb[2] = quad_bcast<2>(brow);
     for (int i = n0 + t; i < n1; i += 64) {
-        const float x = x0[(size_t)i * 3], y = x0[(size_t)i * 3 + 1], z = x0[(size_t)i * 3 + 2];
-        for (int r = 0; r < 3; ++r)
-            lig_out[(size_t)i * 3 + r] = sTb[r * 3] * x + sTb[r * 3 + 1] * y + sTb[r * 3 + 2] * z + sTb[9 + r];
+        float x = px, y = py, z = pz;
+        if (i != n0 + t) {
+            x = x0[(size_t)i * 3]; y = x0[(size_t)i * 3 + 1]; z = x0[(size_t)i * 3 + 2];
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) lig_out[(size_t)i * 3 + r] = Tm[r][0] * x + Tm[r][1] * y + Tm[r][2] * z + bb[r];
     }
 }
 
@@ -754,6 +803,8 @@ int eqd_kabsch_fwd_impl(int n_pairs, int n_heads, const float* Y, const float* s
 // Closed-form backward: with G = dL/dT (including the b = mean_r - T mean_l
 // path), M = U^T G V, c = (1, 1, sign det A):
 //   dP_ij = (c_j M_ij - c_i M_ji) / (s_j + c_i c_j s_i)  (i != j),  dA = U dP V^T
+// One wave per pair like the forward: lane k holds keypoint k of both proteins, sums over keypoints / ligand nodes are
+// wave reductions, the 3x3 algebra (fp64, ~150 multiply-adds) runs redundantly on every lane - no LDS, no barrier.
 __global__ __launch_bounds__(64) void k_kabsch_bwd(int B, int K, const float* __restrict__ Y,
                                                    const float* __restrict__ A_in, const float* __restrict__ T,
                                                    const float* __restrict__ dT, const float* __restrict__ db,
@@ -762,14 +813,14 @@ __global__ __launch_bounds__(64) void k_kabsch_bwd(int B, int K, const float* __
                                                    float* __restrict__ dY, const int32_t* __restrict__ seg_off,
                                                    const float* __restrict__ x0, const float* __restrict__ d_lig,
                                                    const double* __restrict__ usv) {
-    // one 64-thread workgroup per pair; lane 0 does the 3x3 algebra, the per-keypoint work is spread over lanes,
-    // every sum over keypoints runs sequentially on one lane (fixed order)
-    __shared__ float sy[2][KAB_MAXK * 3];
-    __shared__ double smean[6], sdA[9], sdb[3], sdml[3], sg[2][KAB_MAXK * 3], sgm[6];
-    __shared__ float sapp[12];
     const int p = blockIdx.x, t = threadIdx.x;
     // seg_off != NULL: the backward of the rigid apply (k_apply_bwd: dT += d_lig^T x0, db += colsum d_lig over the pair's
     // ligand nodes) is taken here, on top of the external dT / db
+    float yl[KAB_KPL][3], yr[KAB_KPL][3];
+    kab_load(Y + (size_t)p * K * 3, Y + (size_t)(B + p) * K * 3, K, t, yl, yr);
+    float app[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) app[i] = 0.f;
     if (seg_off) {
         float acc[12];
 #pragma unroll
@@ -784,63 +835,74 @@ __global__ __launch_bounds__(64) void k_kabsch_bwd(int B, int K, const float* __
             acc[9] += g0; acc[10] += g1; acc[11] += g2;
         }
 #pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            const float sum = wave_sum(acc[i]);
-            if (t == 0) sapp[i] = sum;
-        }
+        for (int i = 0; i < 12; ++i) app[i] = wave_sum(acc[i]);
     }
-    const float* Yl = Y + (size_t)p * K * 3;
-    const float* Yr = Y + (size_t)(B + p) * K * 3;
     float* dYl = dY + (size_t)p * K * 3;
     float* dYr = dY + (size_t)(B + p) * K * 3;
-    for (int i = t; i < 3 * K; i += 64) {
-        sy[0][i] = Yl[i];
-        sy[1][i] = Yr[i];
+    const float invK = 1.f / (float)K;
+    float ml[3], mr[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float sl = 0.f, sr = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KAB_KPL; ++kk) {
+            sl += yl[kk][c];
+            sr += yr[kk][c];
+        }
+        ml[c] = wave_sum(sl) * invK;
+        mr[c] = wave_sum(sr) * invK;
     }
-    __syncthreads();
-    if (t < 6) {
-        const int side = t / 3, c = t - 3 * side;
-        double a = 0.0;
-        for (int k = 0; k < K; ++k) a += sy[side][k * 3 + c];
-        smean[t] = a / K;
+    double U[3][3], S[3], V[3][3], G[3][3], Tm[3][3], dbv[3], dA[3][3];
+    float Af[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        dbv[i] = (db ? (double)db[(size_t)p * 3 + i] : 0.0) + (double)app[9 + i];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            Af[i][j] = A_in[(size_t)p * 9 + i * 3 + j];
+            Tm[i][j] = (double)T[(size_t)p * 9 + i * 3 + j];
+        }
     }
-    __syncthreads();
-    if (t == 0) {
-        double ml[3] = {smean[0], smean[1], smean[2]};
-        double A[3][3], U[3][3], S[3], V[3][3], G[3][3], Tm[3][3], dbv[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            G[i][j] = (dT ? (double)dT[(size_t)p * 9 + i * 3 + j] : 0.0) + (double)app[i * 3 + j] - dbv[i] * (double)ml[j];
+    if (usv) {       // saved by the forward
+        const double* o = usv + (size_t)p * 21;
+#pragma unroll
         for (int i = 0; i < 3; ++i) {
-            dbv[i] = (db ? (double)db[(size_t)p * 3 + i] : 0.0) + (seg_off ? (double)sapp[9 + i] : 0.0);
+            S[i] = o[9 + i];
+#pragma unroll
             for (int j = 0; j < 3; ++j) {
-                A[i][j] = (double)A_in[(size_t)p * 9 + i * 3 + j];
-                Tm[i][j] = (double)T[(size_t)p * 9 + i * 3 + j];
+                U[i][j] = o[i * 3 + j];
+                V[i][j] = o[12 + i * 3 + j];
             }
         }
-        for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j)
-                G[i][j] = (dT ? (double)dT[(size_t)p * 9 + i * 3 + j] : 0.0) + (seg_off ? (double)sapp[i * 3 + j] : 0.0) -
-                          dbv[i] * ml[j];
-        if (usv) {       // saved by the forward
-            const double* o = usv + (size_t)p * 21;
-            for (int i = 0; i < 3; ++i) {
-                S[i] = o[9 + i];
-                for (int j = 0; j < 3; ++j) {
-                    U[i][j] = o[i * 3 + j];
-                    V[i][j] = o[12 + i * 3 + j];
-                }
-            }
-        } else {
-            svd3(A, U, S, V);
+    } else {         // the operator on its own: the forward's decomposition again (same arithmetic, same bits)
+        float u[3], v[3], Sf[3];
+        svd3_lanes(Af, t & 3, u, v, Sf);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            S[j] = (double)Sf[j];
+            U[0][j] = (double)quad_bcast<0>(u[j]); U[1][j] = (double)quad_bcast<1>(u[j]); U[2][j] = (double)quad_bcast<2>(u[j]);
+            V[0][j] = (double)quad_bcast<0>(v[j]); V[1][j] = (double)quad_bcast<1>(v[j]); V[2][j] = (double)quad_bcast<2>(v[j]);
         }
-        const double c[3] = {1.0, 1.0, det3(A) < 0.0 ? -1.0 : 1.0};
-        double M[3][3], dP[3][3];
+    }
+    {
+        const double c[3] = {1.0, 1.0, det3f(Af) < 0.0 ? -1.0 : 1.0};
+        double M[3][3], dP[3][3], GV[3][3], UdP[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) GV[a][j] = G[a][0] * V[0][j] + G[a][1] * V[1][j] + G[a][2] * V[2][j];
+#pragma unroll
         for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) {
-                double tt = 0;
-                for (int a = 0; a < 3; ++a)
-                    for (int b2 = 0; b2 < 3; ++b2) tt += U[a][i] * G[a][b2] * V[b2][j];
-                M[i][j] = tt;
-            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) M[i][j] = U[0][i] * GV[0][j] + U[1][i] * GV[1][j] + U[2][i] * GV[2][j];
+#pragma unroll
         for (int i = 0; i < 3; ++i)
+#pragma unroll
             for (int j = 0; j < 3; ++j) {
                 if (i == j) {
                     dP[i][j] = 0.0;
@@ -850,43 +912,55 @@ __global__ __launch_bounds__(64) void k_kabsch_bwd(int B, int K, const float* __
                 if (fabs(den) < 1e-12) den = den < 0 ? -1e-12 : 1e-12;
                 dP[i][j] = (c[j] * M[i][j] - c[i] * M[j][i]) / den;
             }
+#pragma unroll
         for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) {
-                double tt = 0;
-                for (int a = 0; a < 3; ++a)
-                    for (int b2 = 0; b2 < 3; ++b2) tt += U[i][a] * dP[a][b2] * V[j][b2];
-                sdA[i * 3 + j] = tt;
-            }
-        // means: d mean_r = db ; d mean_l = -T^T db
-        for (int j = 0; j < 3; ++j) {
-            sdb[j] = dbv[j];
-            sdml[j] = -(Tm[0][j] * dbv[0] + Tm[1][j] * dbv[1] + Tm[2][j] * dbv[2]);
-        }
+#pragma unroll
+            for (int b2 = 0; b2 < 3; ++b2) UdP[i][b2] = U[i][0] * dP[0][b2] + U[i][1] * dP[1][b2] + U[i][2] * dP[2][b2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) dA[i][j] = UdP[i][0] * V[j][0] + UdP[i][1] * V[j][1] + UdP[i][2] * V[j][2];
     }
-    __syncthreads();
+    // means: d mean_r = db ; d mean_l = -T^T db
+    double dml[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) dml[j] = -(Tm[0][j] * dbv[0] + Tm[1][j] * dbv[1] + Tm[2][j] * dbv[2]);
     // centred-point gradients, then un-centre (the mean of the centred gradients is removed)
-    for (int k = t; k < K; k += 64)
+    float gr[KAB_KPL][3], gl[KAB_KPL][3], gmr[3], gml[3];
+#pragma unroll
+    for (int kk = 0; kk < KAB_KPL; ++kk) {
+        const bool ok = t + 64 * kk < K;
+#pragma unroll
         for (int i = 0; i < 3; ++i) {
-            double gr = 0, gl = 0;
+            double a = 0, b2 = 0;
+#pragma unroll
             for (int j = 0; j < 3; ++j) {
-                gr += sdA[i * 3 + j] * ((double)sy[0][k * 3 + j] - smean[j]);
-                gl += sdA[j * 3 + i] * ((double)sy[1][k * 3 + j] - smean[3 + j]);
+                a += dA[i][j] * (double)(yl[kk][j] - ml[j]);
+                b2 += dA[j][i] * (double)(yr[kk][j] - mr[j]);
             }
-            sg[0][k * 3 + i] = gr;
-            sg[1][k * 3 + i] = gl;
+            gr[kk][i] = ok ? (float)a : 0.f;
+            gl[kk][i] = ok ? (float)b2 : 0.f;
         }
-    __syncthreads();
-    if (t < 6) {
-        const int side = t / 3, c = t - 3 * side;
-        double a = 0.0;
-        for (int k = 0; k < K; ++k) a += sg[side][k * 3 + c];
-        sgm[t] = a / K;
     }
-    __syncthreads();
-    for (int k = t; k < K; k += 64)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float sr = 0.f, sl = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KAB_KPL; ++kk) {
+            sr += gr[kk][i];
+            sl += gl[kk][i];
+        }
+        gmr[i] = wave_sum(sr) * invK;
+        gml[i] = wave_sum(sl) * invK;
+    }
+#pragma unroll
+    for (int kk = 0; kk < KAB_KPL; ++kk) {
+        const int k = t + 64 * kk;
+        if (k >= K) continue;
+#pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const float vr = (float)(sg[0][k * 3 + i] - sgm[i] + sdb[i] / K);
-            const float vl = (float)(sg[1][k * 3 + i] - sgm[3 + i] + sdml[i] / K);
+            const float vr = gr[kk][i] - gmr[i] + (float)(dbv[i] * (double)invK);
+            const float vl = gl[kk][i] - gml[i] + (float)(dml[i] * (double)invK);
             if (use_ext) {   // dY = external gradient (or 0) + Kabsch path; no pre-initialised buffer needed
                 dYr[k * 3 + i] = vr + (dYr_ext ? dYr_ext[(size_t)p * K * 3 + k * 3 + i] : 0.f);
                 dYl[k * 3 + i] = vl + (dYl_ext ? dYl_ext[(size_t)p * K * 3 + k * 3 + i] : 0.f);
@@ -895,6 +969,7 @@ __global__ __launch_bounds__(64) void k_kabsch_bwd(int B, int K, const float* __
                 dYl[k * 3 + i] += vl;
             }
         }
+    }
 }
 
 extern "C" int eqd_kabsch_bwd(int n_pairs, int n_heads, const float* Y, const float* A, const float* T,
