@@ -54,13 +54,15 @@ class EqdLinJob(C.Structure):
                 ('rows', C.c_int32), ('bias', C.c_void_p), ('ln_g', C.c_void_p), ('ln_b', C.c_void_p),
                 ('pre_ln', C.c_void_p), ('ld_pre', C.c_int32), ('R', C.c_void_p), ('ldr', C.c_int32),
                 ('alpha', C.c_float), ('beta', C.c_float), ('slope', C.c_float), ('ln_eps', C.c_float),
-                ('Y', C.c_void_p), ('ldy', C.c_int32), ('bf16', C.c_int32), ('mul', C.c_void_p), ('ld_mul', C.c_int32), ('pad_to', C.c_int32)]
+                ('Y', C.c_void_p), ('ldy', C.c_int32), ('bf16', C.c_int32), ('mul', C.c_void_p), ('ld_mul', C.c_int32), ('pad_to', C.c_int32),
+                ('Yb', C.c_void_p), ('ldyb', C.c_int32)]
 
 
 class EqdAtbJob(C.Structure):
     _fields_ = [('X', C.c_void_p), ('xmask', C.c_void_p), ('ldx', C.c_int32), ('M', C.c_int32), ('Y', C.c_void_p),
                 ('ldy', C.c_int32), ('N', C.c_int32), ('rows', C.c_int32), ('out', C.c_void_p), ('o_rs', C.c_int32),
-                ('o_cs', C.c_int32), ('bias_out', C.c_void_p), ('slope', C.c_float), ('scale', C.c_float), ('bf16', C.c_int32)]
+                ('o_cs', C.c_int32), ('bias_out', C.c_void_p), ('slope', C.c_float), ('scale', C.c_float), ('bf16', C.c_int32),
+                ('y_bf16', C.c_int32)]
 
 
 class EqdEdgeParams(C.Structure):
@@ -68,7 +70,8 @@ class EqdEdgeParams(C.Structure):
                 ('ln_b', C.c_void_p), ('W2', C.c_void_p), ('b2', C.c_void_p), ('Wc1', C.c_void_p),
                 ('bc1', C.c_void_p), ('wc2', C.c_void_p), ('bc2', C.c_void_p), ('slope', C.c_float),
                 ('ln_eps', C.c_float), ('eta', C.c_float), ('use_dist', C.c_int32), ('use_he', C.c_int32),
-                ('bf16', C.c_int32), ('drop_z1', C.c_void_p), ('drop_ch', C.c_void_p), ('drop_scale', C.c_float)]
+                ('bf16', C.c_int32), ('drop_z1', C.c_void_p), ('drop_ch', C.c_void_p), ('drop_scale', C.c_float),
+                ('aggr_bf16', C.c_void_p)]
 
 
 class EqdNodeUpdateParams(C.Structure):

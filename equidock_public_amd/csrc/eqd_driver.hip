@@ -42,19 +42,37 @@ Dims make_dims(const EqdModelDesc* m, const EqdGraph* g) {
 
 struct LayerSaved {
     float *P, *Q, *qa, *ka, *va, *aggr_msg, *aggr_cross, *lse, *y_act, *a1n;
+    // bf16 storage mode (EqdModelDesc.storage_bf16): the SAVED form of tensors whose every use in the backward rounds them
+    // to bf16 anyway (operands of the weight-gradient GEMMs); the fp32 originals the forward itself reads (aggr_msg, h) are
+    // transients of the scratch workspace, shared by all layers.  NULL otherwise.
+    uint16_t *a1n_b, *aggr_b;
+    int ld_a1n;
 };
 struct Saved {
     float* h[64 + 1];
+    uint16_t* hb[64 + 1];      // bf16 storage mode: saved bf16 copy of h[l], 0 < l < L ([N][64]); NULL otherwise
+    bool bfs;                  // bf16 storage layout
     float* x[64 + 1];
     LayerSaved lay[64];
     float *hm, *qmean, *qp, *u, *scores, *klse, *Y, *A, *T;
     double* usv;     // [B][21] U, S, V of the Kabsch SVD (fp64), reused by the backward
 };
 
-void carve_saved(const Dims& D, const EqdGraph* g, EqdArena& A, Saved& S) {
+// A: the saved state (forward -> backward); T: transients of the forward (bf16 storage mode only; the same arena as A when
+// the forward keeps no state).  bfs = EqdModelDesc.storage_bf16.
+void carve_saved(const Dims& D, const EqdGraph* g, EqdArena& A, Saved& S, bool bfs, EqdArena& T) {
     const size_t N = (size_t)D.N;
+    S.bfs = bfs;
     S.h[0] = A.take<float>(N * D.d0);
+    S.hb[0] = nullptr;
     S.x[0] = const_cast<float*>(g->x0);
+    float* hp[2] = {nullptr, nullptr};
+    float* aggr_t = nullptr;
+    if (bfs) {
+        hp[0] = T.take<float>(N * D.dh);
+        hp[1] = T.take<float>(N * D.dh);
+        aggr_t = T.take<float>(N * 64);
+    }
     for (int l = 0; l < D.L; ++l) {
         const int d = D.d_in(l);
         LayerSaved& Ls = S.lay[l];
@@ -64,12 +82,30 @@ void carve_saved(const Dims& D, const EqdGraph* g, EqdArena& A, Saved& S) {
         Ls.qa = A.take<float>(N * da);
         Ls.ka = A.take<float>(N * da);
         Ls.va = A.take<float>(N * da);
-        Ls.aggr_msg = A.take<float>(N * 64);
         Ls.aggr_cross = A.take<float>(N * da);
         Ls.lse = A.take<float>(N);
         Ls.y_act = A.take<float>(N * d);
-        Ls.a1n = A.take<float>(N * d);
-        S.h[l + 1] = A.take<float>(N * D.dh);
+        Ls.a1n_b = Ls.aggr_b = nullptr;
+        Ls.ld_a1n = d;
+        if (bfs) {
+            Ls.aggr_msg = aggr_t;
+            Ls.aggr_b = A.take<uint16_t>(N * 64);
+            Ls.a1n = nullptr;                     // node_mlp's LayerNorm output only travels through LDS in the forward
+            Ls.ld_a1n = (d + 7) / 8 * 8;          // 16-byte rows
+            Ls.a1n_b = A.take<uint16_t>(N * Ls.ld_a1n);
+            if (l + 1 < D.L) {
+                S.h[l + 1] = hp[l & 1];
+                S.hb[l + 1] = A.take<uint16_t>(N * D.dh);
+            } else {
+                S.h[l + 1] = A.take<float>(N * D.dh);      // what the keypoint head consumes: fp32
+                S.hb[l + 1] = nullptr;
+            }
+        } else {
+            Ls.aggr_msg = A.take<float>(N * 64);
+            Ls.a1n = A.take<float>(N * d);
+            S.h[l + 1] = A.take<float>(N * D.dh);
+            S.hb[l + 1] = nullptr;
+        }
         S.x[l + 1] = A.take<float>(N * 3);
     }
     S.hm = A.take<float>(N * 64);
@@ -82,6 +118,11 @@ void carve_saved(const Dims& D, const EqdGraph* g, EqdArena& A, Saved& S) {
     S.A = A.take<float>((size_t)D.B * 9);
     S.usv = A.take<double>((size_t)D.B * 21);
     S.T = A.take<float>((size_t)D.B * 9);
+}
+// the saved part alone (the backward and the test aids: the transients are dead by then and get no memory)
+void carve_saved(const Dims& D, const EqdGraph* g, EqdArena& A, Saved& S, bool bfs) {
+    EqdArena none(nullptr, 0);
+    carve_saved(D, g, A, S, bfs, none);
 }
 
 void lin_src(EqdLinJob& J, int i, const float* X, int ldx, int K, const float* W, int w_rs, int w_cs,
@@ -120,19 +161,27 @@ int node_atb_jobs(const Dims& D, int l, const EqdModelDesc* m, const Saved* S, c
     auto G = [&](int i) -> float* { return gp ? gp[i] : nullptr; };
     int n = 0;
     // node_mlp.4: dWn2 = alpha dH^T a1n, dbn2 = alpha colsum(dH)
+    const bool bfs = S && S->bfs;      // bf16 storage: a1n, aggr_msg and h[l] (l > 0) are saved as bf16 rows
+    auto ybf = [&](EqdAtbJob& J, const uint16_t* Yb, int ldy) {
+        J.Y = (const float*)Yb; J.ldy = ldy; J.y_bf16 = 1;
+    };
     jobs[n++] = atb_job(dHout, D.dh, D.dh, Ls ? Ls->a1n : nullptr, d, d, N, G(P_WN2), d, G(P_BN2), m->lrelu_slope,
                         nullptr, alpha);
+    if (bfs) ybf(jobs[n - 1], Ls->a1n_b, Ls->ld_a1n);
     // (order: the jobs that share dz back to back, then the six that share h - eqd_atb runs units that are neighbours in
     // the list on the same XCD at about the same time, so a shared operand's rows are fetched into that L2 once)
     // node_mlp.0: four column segments [h | aggr_msg | aggr_cross | h0]
     const int ldn = D.ldwn(l);
     jobs[n++] = atb_job(dz, d, d, Ls ? Ls->aggr_msg : nullptr, 64, 64, N, gp ? G(P_WN1) + d : nullptr, ldn, nullptr,
                         m->lrelu_slope);
+    if (bfs) ybf(jobs[n - 1], Ls->aggr_b, 64);
+    const bool hbf = bfs && S->hb[l] != nullptr;      // (layer 0 reads the fp32 embedding h[0])
     if (m->cross_msgs)
         jobs[n++] = atb_job(dz, d, d, Ls ? Ls->aggr_cross : nullptr, da, d, N, gp ? G(P_WN1) + d + 64 : nullptr, ldn,
                             nullptr, m->lrelu_slope);
     jobs[n++] = atb_job(dz, d, d, h0, D.d0, D.d0, N, gp ? G(P_WN1) + 2 * d + 64 : nullptr, ldn, nullptr,
                         m->lrelu_slope);
+    const int n_h0 = n;
     jobs[n++] = atb_job(dz, d, d, h, d, d, N, G(P_WN1), ldn, G(P_BN1), m->lrelu_slope);
     // edge_mlp.0 node part: dW1a = dP^T h, dW1b = dQ^T h, db1 = colsum dQ
     const int ld1 = D.ldw1(l);
@@ -144,6 +193,8 @@ int node_atb_jobs(const Dims& D, int l, const EqdModelDesc* m, const Saved* S, c
         jobs[n++] = atb_job(dk, da, d, h, d, d, N, G(P_WK), d, nullptr, m->lrelu_slope);
         jobs[n++] = atb_job(dv, da, d, h, d, d, N, G(P_WV), d, nullptr, m->lrelu_slope);
     }
+    if (hbf)
+        for (int i = n_h0; i < n; ++i) ybf(jobs[i], S->hb[l], D.dh);
     return n;
 }
 
@@ -348,8 +399,17 @@ extern "C" size_t eqd_model_saved_bytes(const EqdModelDesc* m, const EqdGraph* g
     Dims D = make_dims(m, g);
     EqdArena A(nullptr, 0);
     Saved S;
-    carve_saved(D, g, A, S);
+    carve_saved(D, g, A, S, m->storage_bf16 != 0);
     return A.off + 256;
+}
+// transients of a forward in bf16 storage mode (fp32 h ping-pong, aggr_msg): carved from the scratch workspace
+static size_t forward_transient_bytes(const EqdModelDesc* m, const EqdGraph* g) {
+    if (!m->storage_bf16) return 0;
+    Dims D = make_dims(m, g);
+    EqdArena A(nullptr, 0), T(nullptr, 0);
+    Saved S;
+    carve_saved(D, g, A, S, true, T);
+    return T.off + 256;
 }
 
 extern "C" size_t eqd_model_scratch_bytes(const EqdModelDesc* m, const EqdGraph* g) {
@@ -359,7 +419,9 @@ extern "C" size_t eqd_model_scratch_bytes(const EqdModelDesc* m, const EqdGraph*
     Scratch W;
     carve_scratch(D, m, g, A, W);
     size_t bwd = A.off + 256;
-    size_t sv = eqd_model_saved_bytes(m, g);
+    // a forward without a saved-state buffer (inference) carves state + transients from the scratch workspace; a training
+    // forward in bf16 storage mode its transients
+    size_t sv = eqd_model_saved_bytes(m, g) + forward_transient_bytes(m, g);
     return bwd > sv ? bwd : sv;
 }
 
@@ -378,10 +440,15 @@ extern "C" int eqd_model_layer_state(const EqdModelDesc* m, const EqdGraph* g, c
     }
     EqdArena A(const_cast<void*>(saved), saved_bytes);
     Saved S;
-    carve_saved(D, g, A, S);
+    carve_saved(D, g, A, S, m->storage_bf16 != 0);
     if (!A.ok) {
         eqd_set_error("eqd_model_layer_state: saved buffer too small");
         return EQD_ERR_WORKSPACE;
+    }
+    if (m->storage_bf16 && layer > 0 && layer < D.L) {
+        eqd_set_error("eqd_model_layer_state: in bf16 storage mode the fp32 node features of layers 1 .. n_layers - 1 are "
+                      "transients of the forward (their saved form is bf16); layer 0 and n_layers are available");
+        return EQD_ERR_UNSUPPORTED;
     }
     *h = S.h[layer];
     *h_width = layer == 0 ? D.d0 : D.dh;
@@ -422,7 +489,7 @@ extern "C" int eqd_model_lrelu_signs(const EqdModelDesc* m, const EqdGraph* g, c
     }
     EqdArena A(const_cast<void*>(saved), saved_bytes);
     Saved S;
-    carve_saved(D, g, A, S);
+    carve_saved(D, g, A, S, m->storage_bf16 != 0);
     if (!A.ok) {
         eqd_set_error("eqd_model_lrelu_signs: saved buffer too small");
         return EQD_ERR_WORKSPACE;
@@ -510,11 +577,17 @@ extern "C" int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const
     EqdCtx* cx = (EqdCtx*)ctx;
     const Dims D = make_dims(m, g);
     g_bf16_mode = m->storage_bf16 ? 1 : 0;
+    // state: `saved` when a backward will follow, else the scratch workspace; bf16 storage mode also needs transients
+    // (fp32 h ping-pong, aggr_msg), always from the scratch workspace - behind the state when both live there
+    const bool bfs = m->storage_bf16 != 0;
     EqdArena A(saved ? saved : scratch, saved ? saved_bytes : scratch_bytes);
+    EqdArena Tr(scratch, scratch_bytes);
     Saved S;
-    carve_saved(D, g, A, S);
-    if (!A.ok) {
-        eqd_set_error("eqd_model_forward: state workspace too small (%zu needed)", A.off);
+    carve_saved(D, g, A, S, bfs, saved ? Tr : A);
+    if (!A.ok || (bfs && saved && !Tr.ok)) {
+        eqd_set_error("eqd_model_forward: workspace too small or missing (state %zu bytes%s)", A.off,
+                      bfs && saved ? "; bf16 storage mode also needs the scratch workspace (eqd_model_scratch_bytes) in a "
+                                     "forward that saves state" : "");
         return EQD_ERR_WORKSPACE;
     }
     const float slope = m->lrelu_slope, eps = m->ln_eps;
@@ -576,6 +649,7 @@ extern "C" int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const
             HIPOK(hipStreamWaitEvent(sat, cx->fork, 0));
         }
         EqdEdgeParams ep = edge_params(D, m, l, p, drop);
+        ep.aggr_bf16 = Ls.aggr_b;      // bf16 storage mode: the saved copy (the fp32 aggr_msg is a transient)
         if (m->cross_msgs && sat == st && !m->storage_bf16) {
             // the two independent halves of the layer: ONE launch when both fit the chip at once (small batches)
             RC(eqd_edge_attn_fwd(g, &ep, Ls.P, Ls.Q, S.x[l], Ls.aggr_msg, S.x[l + 1], da, Ls.qa, Ls.ka, Ls.va, Ls.aggr_cross,
@@ -604,10 +678,12 @@ extern "C" int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const
         lin_src(j1, 3, S.h[0], D.d0, D.d0, p[P_WN1] + 2 * d + 64, ldn, 1);
         j1.nsrc = 4; j1.bias = p[P_BN1]; j1.act = 1; j1.ln_g = p[P_NLG]; j1.ln_b = p[P_NLB];
         j1.pre_ln = Ls.y_act; j1.ld_pre = d;
+        j1.Yb = Ls.a1n_b; j1.ldyb = Ls.ld_a1n;               // bf16 storage mode: a1n is saved as bf16 (Y = NULL)
         j1.mul = drop_node(D, drop, l); j1.ld_mul = d;       // node_mlp.1 (Dropout) in training mode
         EqdLinJob j2 = lin_job(N, D.dh, S.h[l + 1], D.dh, slope, eps);
         lin_src(j2, 0, Ls.a1n, d, d, p[P_WN2], d, 1);
         j2.nsrc = 1; j2.bias = p[P_BN2];
+        j2.Yb = S.hb[l + 1]; j2.ldyb = D.dh;                 // bf16 storage mode: the saved copy of h[l + 1] (or NULL)
         if (d == D.dh) {
             j2.alpha = m->skip_weight_h; j2.beta = 1.f - m->skip_weight_h; j2.R = h; j2.ldr = d;
         }
@@ -708,7 +784,7 @@ extern "C" int eqd_model_head_backward(const EqdModelDesc* m, const EqdGraph* g,
     g_bf16_mode = m->storage_bf16 ? 1 : 0;
     EqdArena As(const_cast<void*>(saved), saved_bytes);
     Saved S;
-    carve_saved(D, g, As, S);
+    carve_saved(D, g, As, S, m->storage_bf16 != 0);
     EqdArena Aw(scratch, scratch_bytes);
     Scratch W;
     carve_scratch(D, m, g, Aw, W);
@@ -754,7 +830,7 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
     g_bf16_mode = m->storage_bf16 ? 1 : 0;
     EqdArena As(const_cast<void*>(saved), saved_bytes);
     Saved S;
-    carve_saved(D, g, As, S);
+    carve_saved(D, g, As, S, m->storage_bf16 != 0);
     EqdArena Aw(scratch, scratch_bytes);
     Scratch W;
     carve_scratch(D, m, g, Aw, W);

@@ -124,6 +124,14 @@ __device__ __forceinline__ float rbf_sigma(int k) {
     return t[k & 15];
 }
 
+__device__ __forceinline__ float rbf_neg_inv_sigma(int k) {      // -1.f / rbf_sigma(k), the correctly rounded quotients
+    const float t[16] = {-1.f / 1.f,          -1.f / 1.5f,         -1.f / 2.25f,        -1.f / 3.375f,        -1.f / 5.0625f,
+                         -1.f / 7.59375f,     -1.f / 11.390625f,   -1.f / 17.0859375f,  -1.f / 25.62890625f,  -1.f / 38.443359375f,
+                         -1.f / 57.6650390625f, -1.f / 86.49755859375f, -1.f / 129.746337890625f, -1.f / 194.6195068359375f,
+                         -1.f / 291.92926025390625f, -1.f};
+    return t[k & 15];
+}
+
 // y = W x chained through registers: out[mbo][nb] += sum_{mbi,r} W[16 mbo + l15][16 mbi + 4 g + r] * in[mbi][nb][r]
 // W staged in LDS with row stride WS2.  If AFF, `in` is first mapped through v * ga[f] + be[f].
 template <bool AFF, int NB>
@@ -179,6 +187,7 @@ struct EdgeTileState {
     bool ev[NB];
     float xrel[NB][3];
     float d2[NB];
+    float rbf[NB][4];   // PRE (the backward's recompute), bf16 mode: exp(-d2 / sigma_k) of k = 4 g + j in fp32, for d rbf -> d(d^2)
     float mean[NB], rstd[NB];
     float coef[NB];
     unsigned zpos;   // bit (16 nb + 4 mb + r): edge_mlp.0 pre-activation > 0 (exact LeakyReLU mask for the backward)
@@ -297,7 +306,7 @@ __device__ __forceinline__ void edge_tile_forward(const EqdGraph& G, const EqdEd
         const int el = 16 * nb + l15;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int k = g + 4 * j;
+            const int k = PRE ? 4 * g + j : g + 4 * j;      // (which lane computes which k is free: same expression, same bits)
             if (k < 15 && S.ev[nb]) {
                 const float v = P.use_dist ? expf(-S.d2[nb] / rbf_sigma(k)) : 0.f;
                 tile[el * FS + 27 + k] = v;
@@ -613,8 +622,13 @@ __device__ __forceinline__ void edge_tile_forward_bf(const EqdGraph& G, const Eq
         const int el = 16 * nb + l15;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int k = g + 4 * j;
-            if (k < 15 && S.ev[nb]) ft[el * FSB + 27 + k] = f2bf(P.use_dist ? expf(-q / rbf_sigma(k)) : 0.f);
+            const int k = PRE ? 4 * g + j : g + 4 * j;
+            float v = 0.f;
+            if (k < 15 && S.ev[nb]) {
+                v = P.use_dist ? expf(-q / rbf_sigma(k)) : 0.f;
+                ft[el * FSB + 27 + k] = f2bf(v);
+            }
+            if constexpr (PRE) S.rbf[nb][j] = v;      // fp32 copy for the backward's d rbf -> d(d^2) (the tile holds bf16)
         }
     }
     wave_lds_fence();
@@ -890,7 +904,13 @@ __device__ __forceinline__ void edge_fwd_body(EdgeFwdSmem<NW, BF>& S_, const Eqd
                 const float inv = __shfl(invl, nd);
                 if (nd < nn) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) aggr_msg[(size_t)(S.n0 + nd) * 64 + 16 * j + l15] = acc[j][r] * inv;
+                    for (int j = 0; j < 4; ++j) {
+                        const float vv = acc[j][r] * inv;
+                        aggr_msg[(size_t)(S.n0 + nd) * 64 + 16 * j + l15] = vv;
+                        if constexpr (BF) {      // the saved bf16 copy of the bf16 storage mode (EqdEdgeParams.aggr_bf16)
+                            if (P.aggr_bf16) P.aggr_bf16[(size_t)(S.n0 + nd) * 64 + 16 * j + l15] = f2bf(vv);
+                        }
+                    }
                     if (l15 < 3) sxw[wave][3 * nd + l15] = acc[4][r] * inv;
                 }
             }
@@ -1457,13 +1477,18 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
                         dr = mfma4(w, dz[mbi][0][r], dr);
                     }
             }
+            // d rbf_k / d(d^2) = rbf_k * (-1 / sigma_k): the recompute above evaluated exp(-d^2 / sigma_k) for exactly this
+            // lane's k = 4 g + r (fp32: still in the feature tile; bf16: S.rbf) - until round 5 both the exponential and two
+            // divisions per k were evaluated again here (12 of the kernel's 14 fp32 divisions).  Same values, same products.
             float s = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int k = 4 * g + r;
                 if (k < 15) {
-                    const float sg = rbf_sigma(k);
-                    s += dr[r] * expf(-S.d2[0] / sg) * (-1.f / sg);
+                    float e;
+                    if constexpr (BF) e = S.rbf[0][r];
+                    else e = S.ev[0] ? tile[l15 * FS + 27 + k] : 1.f;      // (lanes beyond the tile: exp(-0) as before)
+                    s += dr[r] * e * rbf_neg_inv_sigma(k);
                 }
             }
             const float dd2 = group_sum(s);

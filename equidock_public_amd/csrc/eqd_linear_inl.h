@@ -494,6 +494,9 @@ __device__ __forceinline__ void linear_tile_lean(const JobW& W, bool chain, int 
     float* const jY = jw_p<float>(W, LJ(Y));
     const int ldy = jw_i(W, LJ(ldy));
     if (jY && rv) *(EQD_GAS f4v*)&jY[(size_t)rowi * ldy + f0] = yv;
+    unsigned short* const jYb = jw_p<unsigned short>(W, LJ(Yb));      // bf16 copy (EqdLinJob.Yb), or NULL
+    const int ldyb = jw_i(W, LJ(ldyb));
+    if (jYb && rv) *(EQD_GAS s16x4*)&jYb[(size_t)rowi * ldyb + f0] = pack_bf4(yv[0], yv[1], yv[2], yv[3]);
     if (out_local >= 0) *(f32x4*)&Lb[0][out_local][l15 * LIN_S + f0] = yv;
     LIN_TR(tr_i++);
 #undef LJ
@@ -540,6 +543,8 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const JobW& W, b
     float* const jpre = jw_p<float>(W, LJ(pre_ln));
     const int ldr = jw_i(W, LJ(ldr)), ldy = jw_i(W, LJ(ldy)), ld_pre = jw_i(W, LJ(ld_pre)), pad_to = jw_i(W, LJ(pad_to));
     const float alpha = jw_f(W, LJ(alpha)), beta = jw_f(W, LJ(beta)), slope = jw_f(W, LJ(slope)), ln_eps = jw_f(W, LJ(ln_eps));
+    unsigned short* const jYb = jw_p<unsigned short>(W, LJ(Yb));      // bf16 copy of the output (EqdLinJob.Yb), or NULL
+    const int ldyb = jw_i(W, LJ(ldyb));
     const int mbn = (M + 15) >> 4;
     // this wave's output blocks and their epilogue operands (fetched now: the latency hides under the GEMM)
     const int mbs[2] = {wave, wave + 4};
@@ -733,6 +738,7 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const JobW& W, b
                 if (nf[i] > 0) {
                     const f32x4 yv = {y[0], y[1], y[2], y[3]};
                     if (jY && rv) *(EQD_GAS f4v*)&jY[(size_t)rowi * ldy + f0] = yv;
+                    if (jYb && rv) *(EQD_GAS s16x4*)&jYb[(size_t)rowi * ldyb + f0] = pack_bf4(y[0], y[1], y[2], y[3]);
                     if (out_local >= 0) *(f32x4*)&Lb[rt][out_local][l15 * LIN_S + f0] = yv;
                 } else if (own[i] && f0 < pad_to) {      // zero padding of the row (EqdLinJob.pad_to; pad_to is a multiple of 16)
                     if (jY && rv) *(EQD_GAS f4v*)&jY[(size_t)rowi * ldy + f0] = f4zero();
@@ -742,9 +748,15 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const JobW& W, b
                 for (int r = 0; r < 4; ++r)
                     if (r < nf[i]) {
                         if (jY && rv) ((EQD_GAS float*)jY)[(size_t)rowi * ldy + f0 + r] = y[r];
+                        if (jYb && rv) ((EQD_GAS unsigned short*)jYb)[(size_t)rowi * ldyb + f0 + r] = f2bf(y[r]);
                         if (out_local >= 0) Lb[rt][out_local][l15 * LIN_S + f0 + r] = y[r];
-                    } else if (f0 + r < pad_to) {      // zero padding of the row (EqdLinJob.pad_to)
-                        if (jY && rv) ((EQD_GAS float*)jY)[(size_t)rowi * ldy + f0 + r] = 0.f;
+                    } else {
+                        if (f0 + r < pad_to) {      // zero padding of the row (EqdLinJob.pad_to)
+                            if (jY && rv) ((EQD_GAS float*)jY)[(size_t)rowi * ldy + f0 + r] = 0.f;
+                        }
+                        // (the bf16 copy: zeros up to the end of the last started 4-column group, what a vector load of it covers)
+                        if (jYb && rv && own[i] && nf[i] > 0 && f0 + r < ldyb)
+                            ((EQD_GAS unsigned short*)jYb)[(size_t)rowi * ldyb + f0 + r] = 0;
                     }
             }
         }

@@ -809,6 +809,15 @@ struct AtbUnitsArg {
 // thread, 64-byte coalesced row segments) WHILE the previous chunk is multiplied, then written to LDS;
 // wave w accumulates the output column block nb = w for every row block mb.  One partial tile per
 // workgroup (no cross-wave reduction), summed later in a fixed order by k_atb_reduce.
+// four bf16 of a saved tensor (EqdAtbJob.y_bf16) as fp32: p 8-byte aligned; n = valid elements at p (>= 4 all, <= 0 none:
+// the load then goes to `safe`); exact values, so rounding them again when the MFMA operand is formed gives the same bits
+__device__ __forceinline__ f32x4 ld4_bf16(const unsigned short* __restrict__ p, int n, const unsigned short* __restrict__ safe) {
+    const s16x4 h = *(const EQD_GAS s16x4*)(n > 0 ? p : safe);
+    f32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = i < n ? bf2f((unsigned short)h[i]) : 0.f;
+    return r;
+}
 struct AtbRegs {
     f32x4 x[4][2], xm[4][2], y[4];   // raw 16-byte loads (see ld4u_raw / ld4u_fix)
 };
@@ -834,7 +843,11 @@ __device__ __forceinline__ void atb_load(const EqdAtbJob& J, int n0, int chunk, 
             R.x[jr][h] = ld4u_raw(J.X + o, n, J.X);
             if (J.xmask) R.xm[jr][h] = ld4u_raw(J.xmask + o, n, J.xmask);
         }
-        R.y[jr] = ld4u_raw(J.Y + ro * J.ldy + n0 + 4 * tc, atb_ny(J, n0, chunk, t, jr), J.Y);
+        if (J.y_bf16)
+            R.y[jr] = ld4_bf16((const unsigned short*)J.Y + ro * J.ldy + n0 + 4 * tc, atb_ny(J, n0, chunk, t, jr),
+                               (const unsigned short*)J.Y);
+        else
+            R.y[jr] = ld4u_raw(J.Y + ro * J.ldy + n0 + 4 * tc, atb_ny(J, n0, chunk, t, jr), J.Y);
     }
 }
 __device__ __forceinline__ void atb_store(const EqdAtbJob& J, int n0, int chunk, int t, const AtbRegs& R,
@@ -855,7 +868,8 @@ __device__ __forceinline__ void atb_store(const EqdAtbJob& J, int n0, int chunk,
             }
             *(float4*)&Xl[row * ATB_LS + 4 * tc + 64 * h] = v;
         }
-        *(float4*)&Yl[row * ATB_LS + 4 * tc] = ld4u_fix(R.y[jr], atb_ny(J, n0, chunk, t, jr));
+        if (J.y_bf16) *(f32x4*)&Yl[row * ATB_LS + 4 * tc] = R.y[jr];      // (already in place, zero beyond the matrix)
+        else *(float4*)&Yl[row * ATB_LS + 4 * tc] = ld4u_fix(R.y[jr], atb_ny(J, n0, chunk, t, jr));
     }
 }
 // one 64-row chunk: acc[mb] += X[:, 16 mb ..]^T Y[:, 16 wave ..]; MBN row blocks, no predicates in the loop
@@ -1005,6 +1019,8 @@ __device__ __forceinline__ void atb_fast_bf(const AtbUnit& u, int c, float* __re
     const EQD_GAS float* const Y = (const EQD_GAS float*)J.Y + u.n0 + 4 * tc;
     const int ny = J.N - (u.n0 + 4 * tc);
     const bool yfull = u.fast == 1;
+    const bool ybf = J.y_bf16 != 0;      // Y is a saved bf16 tensor (uint16 rows): 8-byte loads, exact conversion
+    const unsigned short* const Yh = (const unsigned short*)J.Y + u.n0 + 4 * tc;
     static_assert(2 * 64 * ATB_KG * 8 <= ATB_ROWS * ATB_LS * 4, "two bf16 chunks must fit one fp32 tile");
     s16x4* const Xb = (s16x4*)Xl_;      // [2][64 columns][ATB_KG]
     s16x4* const Yb = (s16x4*)Yl_;
@@ -1020,8 +1036,9 @@ __device__ __forceinline__ void atb_fast_bf(const AtbUnit& u, int c, float* __re
             row = row < rows ? row : rows - 1;
             rx[jr] = *(const EQD_GAS f4v*)(X + (size_t)row * ldx);
             if (masked) rm[jr] = *(const EQD_GAS f4v*)(Xm + (size_t)row * ldx);
-            ry[jr] = yfull ? *(const EQD_GAS f4v*)(Y + (size_t)row * ldy)
-                           : ld4u_raw((const float*)(Y + (size_t)row * ldy), ny, J.Y);
+            if (ybf) ry[jr] = ld4_bf16(Yh + (size_t)row * ldy, ny, (const unsigned short*)J.Y);
+            else ry[jr] = yfull ? *(const EQD_GAS f4v*)(Y + (size_t)row * ldy)
+                                : ld4u_raw((const float*)(Y + (size_t)row * ldy), ny, J.Y);
         }
     };
     load(c);
@@ -1032,7 +1049,7 @@ __device__ __forceinline__ void atb_fast_bf(const AtbUnit& u, int c, float* __re
         for (int jr = 0; jr < 4; ++jr) {
             const bool rvalid = chunk * ATB_ROWS + tr + 16 * jr < rows;
             f32x4 v = rx[jr], y = ry[jr];
-            if (!yfull) {
+            if (!yfull && !ybf) {
                 const float4 f = ld4u_fix(ry[jr], ny);
                 y = f32x4{f.x, f.y, f.z, f.w};
             }
@@ -1187,6 +1204,11 @@ static int atb_units(const EqdAtbJob* jobs, int njobs, std::vector<AtbUnit>& uni
             eqd_set_error("eqd_atb: job %d has M=%d N=%d rows=%d (need M in 4..80, N >= 4)", i, J.M, J.N, J.rows);
             return EQD_ERR_SHAPE;
         }
+        if (J.y_bf16 && ((J.ldy & 3) != 0 || (((uintptr_t)J.Y) & 7) != 0)) {
+            eqd_set_error("eqd_atb: job %d has a bf16 Y (y_bf16) with ldy = %d not a multiple of 4, or Y not 8-byte aligned", i,
+                          J.ldy);
+            return EQD_ERR_SHAPE;
+        }
         const int nchunks = J.rows > 0 ? (J.rows + ATB_ROWS - 1) / ATB_ROWS : 0;
         for (int n0 = 0; n0 < J.N; n0 += 64) {
             AtbUnit u;
@@ -1199,6 +1221,7 @@ static int atb_units(const EqdAtbJob* jobs, int njobs, std::vector<AtbUnit>& uni
             // columns left over of the 69-wide h0: a general-path unit costs twice a fast one for 1/13 of the columns)
             const bool xfast = J.M == 64 && J.rows > 0 && (J.ldx & 3) == 0 && al16(J.X) && (!J.xmask || al16(J.xmask));
             u.fast = !xfast ? 0 : (J.N - n0 >= 64 && (J.ldy & 3) == 0 && al16(J.Y)) ? 1 : (J.N - n0 >= 4 || n0 >= 4) ? 2 : 0;
+            if (J.y_bf16 && u.fast && !J.bf16) u.fast = 0;      // (the fp32 fast body has no bf16 loader; not a shape the model makes)
             units.push_back(u);
         }
     }

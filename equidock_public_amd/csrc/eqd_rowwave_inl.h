@@ -347,6 +347,13 @@ __device__ __forceinline__ void rw_epi_finish(const JobW& W, bool tp, const f32x
 #pragma unroll
         for (int a = 0; a < 4; ++a) *(EQD_GAS f4v*)(yp + ft[a]) = v[a];
     }
+    unsigned short* const jYb = jw_p<unsigned short>(W, LJ(Yb));      // bf16 copy of the output (EqdLinJob.Yb), or NULL
+    const int ldyb = jw_i(W, LJ(ldyb));
+    if (jYb && rv) {
+        unsigned short* yp = jYb + (size_t)rowi * ldyb;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) *(EQD_GAS s16x4*)(yp + ft[a]) = pack_bf4(v[a][0], v[a][1], v[a][2], v[a][3]);
+    }
     const int out_l = jw_i(W, JW_OFF(EqdChainJob, out_local));
     if (out_l >= 0) {
         float* T = tiles + out_l * tstride + l15 * RW_S;

@@ -405,7 +405,10 @@ class _IEGMNFunction(torch.autograd.Function):
         # the forward carves its state from `saved` when a backward will follow and from `scratch` otherwise: only one
         # of the two is ever touched (the state is hundreds of MB at 64 x (300, 300))
         saved = _workspace(sb, dev) if need_grad else None
-        scratch = None if need_grad else _workspace(wb, dev)
+        # (bf16 storage mode: a forward that saves state also needs the scratch workspace - the fp32 tensors the forward itself
+        #  reads but the backward only needs rounded to bf16 are transients there; the same buffer then serves the backward)
+        fwd_scratch = (not need_grad) or bool(desc.storage_bf16)
+        scratch = _workspace(wb, dev) if fwd_scratch else None
         if svd_draws is not None:
             svd_draws = _lib.require_device(svd_draws.to(torch.float32).contiguous(), 'svd_draws')
         if _lib.profiling:
@@ -416,11 +419,12 @@ class _IEGMNFunction(torch.autograd.Function):
                 C.byref(desc), C.byref(gs), ptrs, None if dstruct is None else C.byref(dstruct),
                 _lib.ptr(svd_draws), _lib.ptr(lig), _lib.ptr(Yl), _lib.ptr(Yr),
                 _lib.ptr(T), _lib.ptr(b), _lib.ptr(status), _lib.ptr(saved), C.c_size_t(sb if need_grad else 0),
-                _lib.ptr(scratch), C.c_size_t(0 if need_grad else wb), _lib.stream_ptr(dev), _lib.exec_ctx(dev)))
+                _lib.ptr(scratch), C.c_size_t(wb if fwd_scratch else 0), _lib.stream_ptr(dev), _lib.exec_ctx(dev)))
         packed._last_saved = (saved, sb, drop) if need_grad else None     # for IEGMN.layer_state (tests); freed with the batch
         ctx.drop = drop                 # the masks of THIS forward: the backward applies the same ones
         ctx.packed, ctx.desc, ctx.table_idx, ctx.saved, ctx.sb, ctx.wb = packed, desc, table_idx, saved, sb, wb
         ctx.tensors, ctx.ptrs = tensors, ptrs
+        ctx.scratch = scratch if need_grad else None      # (bf16 storage mode: reused by the backward)
         ctx.flat_state = flat_state
         ctx.x0 = packed.x0      # keep the coordinates this forward used alive (the saved state points at them)
         ctx.mark_non_differentiable(status)
@@ -445,7 +449,7 @@ class _IEGMNFunction(torch.autograd.Function):
             offs, total = flat_layout(tensors)
             flat = torch.zeros(total, dtype=torch.float32, device=dev)
             goffs = (C.c_int64 * len(ctx.table_idx))(*[offs[i] for i in ctx.table_idx])
-        scratch = _workspace(ctx.wb, dev)
+        scratch = ctx.scratch if ctx.scratch is not None else _workspace(ctx.wb, dev)
 
         def prep(t):
             return None if t is None else _lib.require_device(t.to(torch.float32).contiguous(), 'output gradient')

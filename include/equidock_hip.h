@@ -278,6 +278,10 @@ typedef struct EqdLinJob {
     int32_t pad_to;   /* > M: columns M .. pad_to - 1 of every output row are written as zeros (the zero padding of a
                          69-wide layer's 80-float attention rows, without a separate fill); 0 = none.  Honoured by the
                          general (M % 4 != 0) epilogue - the only place such widths occur. */
+    uint16_t* Yb; int32_t ldyb;   /* optional bf16 COPY of the output, [rows][ldyb] (round to nearest even of the fp32
+                         result; ldyb >= M).  Y may be NULL when only the copy is wanted.  bf16 storage of the saved state
+                         (EqdModelDesc.storage_bf16): a tensor whose every later use rounds it to bf16 anyway - a GEMM
+                         operand of the bf16 mode - is kept as bf16, with the same bits the consumer would have formed. */
 } EqdLinJob;
 int eqd_linear(const EqdLinJob* jobs /* host */, int njobs, void* stream);
 
@@ -292,6 +296,9 @@ typedef struct EqdAtbJob {
     float slope;
     float scale;   /* multiplier applied to both results; 0 means 1 */
     int32_t bf16;  /* 1: X^T Y on the bf16 MFMA (inputs rounded, fp32 accumulate); column sums stay fp32 */
+    int32_t y_bf16; /* 1: Y points at bf16 rows (uint16_t [rows][ldy], ldy in elements, a multiple of 4, rows 8-byte aligned;
+                       columns N .. round_up(N, 4) - 1 must be readable) - a saved tensor of the bf16 storage mode; with
+                       bf16 = 1 the products round Y to bf16 anyway: the same bits as with the fp32 tensor */
 } EqdAtbJob;
 size_t eqd_atb_partial_bytes(const EqdAtbJob* jobs /* host */, int njobs);
 int eqd_atb(const EqdAtbJob* jobs /* host */, int njobs, void* partial, size_t partial_bytes, void* stream);
@@ -312,6 +319,9 @@ typedef struct EqdEdgeParams {
      * caller, bit-packed [n_edges][2] uint32 in the graph's edge order (bit f of the 64-bit pair = feature f is kept),
      * kept elements are scaled by drop_scale = 1 / (1 - p).  Both NULL = no dropout (eval mode / p = 0). */
     const uint32_t* drop_z1; const uint32_t* drop_ch; float drop_scale;
+    uint16_t* aggr_bf16;   /* optional (bf16 = 1 only): a bf16 copy of aggr_msg, [n_nodes][64], written by the forward beside
+                              the fp32 result - the saved copy of the bf16 storage mode (the backward's weight-gradient
+                              GEMM rounds aggr_msg to bf16 anyway); NULL = none */
 } EqdEdgeParams;
 /* P = h W1[:, :d_in]^T, Q = h W1[:, d_in:2 d_in]^T + b1 are node-level inputs ([n_nodes][64]). */
 int eqd_edge_message_fwd(const EqdGraph* g, const EqdEdgeParams* p, const float* P, const float* Q,
