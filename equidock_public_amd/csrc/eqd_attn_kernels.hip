@@ -578,7 +578,7 @@ __global__ __launch_bounds__(EQD_BLOCK, 2) void k_attn_bwd_kvds(EqdGraph G, cons
                                                                           seg_start);
 }
 // bf16 mode (bf16 tiles in LDS), d = 64: the same two launches
-template <bool BF_DZ>
+template <bool BF_DZ, bool QB = false>
 __global__ __launch_bounds__(EQD_BLOCK, 2) void k_attn_bwd_kvds_lb(EqdGraph G, const float* __restrict__ q, const float* __restrict__ k,
                                                                    const float* __restrict__ v, const float* __restrict__ out,
                                                                    const float* __restrict__ lse, const float* __restrict__ d_out,
@@ -599,16 +599,17 @@ __global__ __launch_bounds__(EQD_BLOCK, 2) void k_attn_bwd_kvds_lb(EqdGraph G, c
     }
     __shared__ AttnBwdSmemLb sm;
     const int b = (int)blockIdx.x;
-    attn_bwd_kv_body_lb<1, true>(sm, G, att_half_item(b), q, k, v, out, lse, d_out, dk, dv, att_half_of(b), qk_slope, ds, ds_stride,
-                                 seg_start);
+    // (the dS workspace of this pair of kernels holds bf16 - same bits as the dq pass would form, half the round trip)
+    attn_bwd_kv_body_lb<1, true, QB, true>(sm, G, att_half_item(b), q, k, v, out, lse, d_out, dk, dv, att_half_of(b), qk_slope, ds,
+                                           ds_stride, seg_start);
 }
-template <int NB>
+template <int NB, bool QB = false>
 __global__ __launch_bounds__(EQD_BLOCK, 2) void k_attn_bwd_qds_lb(EqdGraph G, const float* __restrict__ q, const float* __restrict__ k,
                                                                   const float* __restrict__ ds, int ds_stride,
                                                                   float* __restrict__ dq, float qk_slope) {
     __shared__ AttnQdsSmemLb sm;
     const int item = NB == 1 ? att_half_item((int)blockIdx.x) : (int)blockIdx.x;
-    attn_bwd_qds_body_lb<NB>(sm, G, item, q, k, ds, ds_stride, dq, NB == 1 ? att_half_of((int)blockIdx.x) : 0, qk_slope);
+    attn_bwd_qds_body_lb<NB, QB, true>(sm, G, item, q, k, ds, ds_stride, dq, NB == 1 ? att_half_of((int)blockIdx.x) : 0, qk_slope);
 }
 // seg_start[node] = first node of the node's protein (EqdGraph.seg_off: ligand segments, then receptor segments)
 __global__ void k_seg_start(const int32_t* __restrict__ seg_off, int nseg, int n, int32_t* __restrict__ out) {
@@ -981,7 +982,11 @@ int eqd_launch_seg_start(const EqdGraph* g, int32_t* seg_start, hipStream_t st) 
 static int attention_bwd_ds(const EqdGraph* g, int d, const float* q, const float* k, const float* v, const float* out, const float* lse,
                             const float* d_out, float* dq, float* dk, float* dv, float qk_slope, float* ds,
                             const int32_t* seg_start, const EqdGatherCall* gc, EqdRedList* pending, hipStream_t st,
-                            bool bf16 = false) {
+                            bool bf16 = false, bool qkv_bf16 = false) {
+    if (qkv_bf16 && !(bf16 && d == 64)) {
+        eqd_set_error("attention backward: saved bf16 q / k / v are only read by the bf16 kernels of the 64-wide layers");
+        return EQD_ERR_UNSUPPORTED;
+    }
     if (d == 80) {
         static thread_local EqdRedArg RA8;
         EqdGatherArgs GA8;
@@ -1021,15 +1026,21 @@ static int attention_bwd_ds(const EqdGraph* g, int d, const float* q, const floa
     const int n_attn = 2 * g->n_att_items, stride = eqd_attention_ds_stride(g);
     const dim3 grid(n_attn + GA.ngather + nred);
     if (bf16) {
-        if (gc && gc->dz_bf16)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_kvds_lb<true>), grid, dim3(EQD_BLOCK), 0, st, *g, q, k, v, out, lse, d_out, dk,
-                               dv, qk_slope, ds, stride, seg_start, n_attn, nred, GA, RA);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_kvds_lb<false>), grid, dim3(EQD_BLOCK), 0, st, *g, q, k, v, out, lse, d_out, dk,
-                               dv, qk_slope, ds, stride, seg_start, n_attn, nred, GA, RA);
+        // (row stride of the bf16 dS workspace in ELEMENTS: the same count, rows half as long in bytes)
+        const bool dzb = gc && gc->dz_bf16;
+#define EQD_KVLB(DZ_, QB_)                                                                                                        \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_kvds_lb<DZ_, QB_>), grid, dim3(EQD_BLOCK), 0, st, *g, q, k, v, out, lse, d_out, dk, \
+                       dv, qk_slope, ds, stride, seg_start, n_attn, nred, GA, RA)
+        if (qkv_bf16) { if (dzb) EQD_KVLB(true, true); else EQD_KVLB(false, true); }
+        else { if (dzb) EQD_KVLB(true, false); else EQD_KVLB(false, false); }
+#undef EQD_KVLB
         if (int rc = eqd_check_launch("k_attn_bwd_kvds")) return rc;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_qds_lb<2>), dim3(g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, q, k,
-                           (const float*)ds, stride, dq, qk_slope);
+        if (qkv_bf16)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_qds_lb<2, true>), dim3(g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, q, k,
+                               (const float*)ds, stride, dq, qk_slope);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_bwd_qds_lb<2, false>), dim3(g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, q, k,
+                               (const float*)ds, stride, dq, qk_slope);
         if (int rc = eqd_check_launch("k_attn_bwd_qds")) return rc;
         return gc ? eqd_gather_rest(pending, st) : EQD_OK;
     }
@@ -1084,10 +1095,14 @@ extern "C" int eqd_cross_attention_bwd_ds(const EqdGraph* g, int d, const float*
 int eqd_launch_attention_bwd_gather(const EqdGraph* g, int d, const float* q, const float* k, const float* v, const float* out,
                                     const float* lse, const float* d_out, float* dq, float* dk, float* dv, float* delta,
                                     float qk_slope, bool bf16, const EqdGatherCall* gc, EqdRedList* pending, hipStream_t st,
-                                    float* ds, const int32_t* seg_start) {
+                                    float* ds, const int32_t* seg_start, bool qkv_bf16) {
     if (ds && seg_start && eqd_attention_ds_wanted(g, d, bf16) && aligned16(q) && aligned16(k) && aligned16(v) &&
         aligned16(d_out) && aligned16(out) && aligned16(ds))
-        return attention_bwd_ds(g, d, q, k, v, out, lse, d_out, dq, dk, dv, qk_slope, ds, seg_start, gc, pending, st, bf16);
+        return attention_bwd_ds(g, d, q, k, v, out, lse, d_out, dq, dk, dv, qk_slope, ds, seg_start, gc, pending, st, bf16, qkv_bf16);
+    if (qkv_bf16) {      // (the driver saves q / k / v as bf16 exactly when this launcher will take the dS form: same predicate)
+        eqd_set_error("attention backward: q / k / v were saved as bf16 but the dS hand-off form is not taken");
+        return EQD_ERR_UNSUPPORTED;
+    }
     if (!eqd_attention_bwd_gather_fused(g, d, q, k, v, out, d_out, bf16)) {
         int rc = eqd_launch_attention_bwd_act(g, d, q, k, v, out, lse, d_out, dq, dk, dv, delta, qk_slope, bf16, st);
         if (rc) return rc;

@@ -48,6 +48,49 @@ __device__ __forceinline__ void lb_load(LbRegs& R, const float* __restrict__ M, 
         }
     }
 }
+// The same tile from a SAVED bf16 tensor ([.][64] bf16 rows, 128 B: the bf16 storage mode keeps q / k / v of the 64-wide layers
+// that way for the backward): 8-byte loads, exact conversion - rounding the values again when the tile is parked in LDS
+// gives back the same bits, so the kernels' results do not depend on which form they were handed.
+__device__ __forceinline__ float4 lb_cvt4(s16x4 h) {
+    return make_float4(bf2f((unsigned short)h[0]), bf2f((unsigned short)h[1]), bf2f((unsigned short)h[2]), bf2f((unsigned short)h[3]));
+}
+__device__ __forceinline__ void lb_load_bf(LbRegs& R, const unsigned short* __restrict__ M, int r0, int r1, int lane) {
+    int nrows = r1 - r0;
+    nrows = nrows < 0 ? 0 : (nrows > 32 ? 32 : nrows);
+    R.nrows = nrows;
+    const int a = lane >> 3, cg = lane & 7;
+    if (nrows > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * a + r;
+            const s16x4* __restrict__ p = (const s16x4*)(M + (size_t)(r0 + (row < nrows ? row : nrows - 1)) * 64 + 4 * cg);
+            R.lo[r] = lb_cvt4(p[0]);
+            R.hi[r] = lb_cvt4(p[8]);
+        }
+    }
+}
+template <bool QB>
+__device__ __forceinline__ void lb_load_any(LbRegs& R, const float* __restrict__ M, int r0, int r1, int lane) {
+    if constexpr (QB) lb_load_bf(R, (const unsigned short*)M, r0, r1, lane);
+    else lb_load(R, M, r0, r1, lane);
+}
+// [32][64] block tile of a saved bf16 tensor -> the fp32 LDS tile block_tile_stage_fast<4> makes (rows beyond the block: zeros)
+__device__ __forceinline__ void block_tile_stage_bf(const unsigned short* __restrict__ M, int DS, int r0, int r1,
+                                                    float* __restrict__ L, int t) {
+    int nrows = r1 - r0;
+    nrows = nrows > 32 ? 32 : nrows;
+    const int row = t >> 3, c8 = t & 7;
+    typedef short s16x8v __attribute__((ext_vector_type(8)));
+    const s16x8v h = *(const s16x8v*)(M + (size_t)(r0 + (row < nrows ? row : nrows - 1)) * 64 + 8 * c8);
+    const bool ok = row < nrows;
+    float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+    if (ok) {
+        lo = make_float4(bf2f((unsigned short)h[0]), bf2f((unsigned short)h[1]), bf2f((unsigned short)h[2]), bf2f((unsigned short)h[3]));
+        hi = make_float4(bf2f((unsigned short)h[4]), bf2f((unsigned short)h[5]), bf2f((unsigned short)h[6]), bf2f((unsigned short)h[7]));
+    }
+    *(float4*)&L[row * DS + 8 * c8] = lo;
+    *(float4*)&L[row * DS + 8 * c8 + 4] = hi;
+}
 __device__ __forceinline__ s16x4 lb_pack(float a, float b, float c, float d, bool ok) {
     return pack_bf4(ok ? a : 0.f, ok ? b : 0.f, ok ? c : 0.f, ok ? d : 0.f);
 }
@@ -448,7 +491,9 @@ __device__ __forceinline__ void attn_bwd_q_body_lb(AttnBwdSmemLb& sm, const EqdG
 }
 
 // WDS: the dS hand-off (eqd_attn_kernels.hip: attn_bwd_kv_body) - the pass also writes its dS tiles (fp32) for the dq pass
-template <int NB, bool WDS = false>
+// QB: q, k, v point at saved bf16 tensors (bf16 storage mode); DSB: the dS workspace holds bf16 (the dq pass rounds dS to
+// bf16 when it forms its MFMA operand: the same bits, half the round trip)
+template <int NB, bool WDS = false, bool QB = false, bool DSB = false>
 __device__ __forceinline__ void attn_bwd_kv_body_lb(AttnBwdSmemLb& sm, const EqdGraph& G, int item,
                                                     const float* __restrict__ q, const float* __restrict__ k,
                                                     const float* __restrict__ v, const float* __restrict__ out,
@@ -484,7 +529,7 @@ __device__ __forceinline__ void attn_bwd_kv_body_lb(AttnBwdSmemLb& sm, const Eqd
     }
     LbRegs rq, rg, ro;
     int qt = o0 + 32 * wave;
-    lb_load(rq, q, qt, o1, lane);
+    lb_load_any<QB>(rq, q, qt, o1, lane);
     lb_load(rg, d_out, qt, o1, lane);
     lb_load(ro, out, qt, o1, lane);
     float lr[2][4];      // lse of the tile's query rows 16 mb + 4 g + r
@@ -497,8 +542,13 @@ __device__ __forceinline__ void attn_bwd_kv_body_lb(AttnBwdSmemLb& sm, const Eqd
             const float lv = lse[qc];
             lr[mb][r] = qr < o1 ? lv : 0.f;
         }
-    block_tile_stage_fast<4>(k, DS, b0, b1, Kb, t);
-    block_tile_stage_fast<4>(v, DS, b0, b1, Vb, t);
+    if constexpr (QB) {
+        block_tile_stage_bf((const unsigned short*)k, DS, b0, b1, Kb, t);
+        block_tile_stage_bf((const unsigned short*)v, DS, b0, b1, Vb, t);
+    } else {
+        block_tile_stage_fast<4>(k, DS, b0, b1, Kb, t);
+        block_tile_stage_fast<4>(v, DS, b0, b1, Vb, t);
+    }
     __syncthreads();
     s16x4 kf[NB][4], vf[NB][4];
 #pragma unroll
@@ -539,7 +589,7 @@ __device__ __forceinline__ void attn_bwd_kv_body_lb(AttnBwdSmemLb& sm, const Eqd
 #pragma unroll
             for (int r = 0; r < 4; ++r) dc[mb][r] = sm.dls[wave][16 * mb + 4 * g + r];
         const int qn = qt + 32 * EQD_WAVES;
-        lb_load(rq, q, qn, o1, lane);
+        lb_load_any<QB>(rq, q, qn, o1, lane);
         lb_load(rg, d_out, qn, o1, lane);
         lb_load(ro, out, qn, o1, lane);
 #pragma unroll
@@ -580,10 +630,17 @@ __device__ __forceinline__ void attn_bwd_kv_body_lb(AttnBwdSmemLb& sm, const Eqd
                 for (int r = 0; r < 4; ++r) {
                     const int qr = qt + 16 * mb + 4 * g + r;
                     if (qr < o1) {
-                        float* __restrict__ row = ds + (size_t)qr * ds_stride;
+                        if constexpr (DSB) {
+                            unsigned short* __restrict__ row = (unsigned short*)ds + (size_t)qr * ds_stride;
 #pragma unroll
-                        for (int nb = 0; nb < NB; ++nb)
-                            if (kvd[nb]) row[kcol[nb]] = dP[mb][nb][r];
+                            for (int nb = 0; nb < NB; ++nb)
+                                if (kvd[nb]) row[kcol[nb]] = f2bf(dP[mb][nb][r]);
+                        } else {
+                            float* __restrict__ row = ds + (size_t)qr * ds_stride;
+#pragma unroll
+                            for (int nb = 0; nb < NB; ++nb)
+                                if (kvd[nb]) row[kcol[nb]] = dP[mb][nb][r];
+                        }
                     }
                 }
         }
@@ -612,7 +669,10 @@ __device__ __forceinline__ void attn_bwd_kv_body_lb(AttnBwdSmemLb& sm, const Eqd
                     const int o = ((db * 2 + nb) * 4 + r) * 64 + lane;
                     const size_t at = (size_t)rowk[nb] * d + 16 * db + 4 * g + r;
                     const float s = sm.red(0)[o] + sm.red(1)[o] + sm.red(2)[o] + sm.red(3)[o];
-                    dst[at] = pass ? s : s * lrelu_grad(k[at], qk_slope);
+                    float kval;      // (only its sign is used: LeakyReLU'(k))
+                    if constexpr (QB) kval = bf2f(((const unsigned short*)k)[at]);
+                    else kval = k[at];
+                    dst[at] = pass ? s : s * lrelu_grad(kval, qk_slope);
                 }
             }
     }
@@ -628,7 +688,7 @@ struct alignas(16) AttnQdsSmemLb {
     } w[EQD_WAVES];
     __device__ __forceinline__ float* red(int wv) { return (float*)&w[wv]; }
 };
-template <int NB>
+template <int NB, bool QB = false, bool DSB = false>
 __device__ __forceinline__ void attn_bwd_qds_body_lb(AttnQdsSmemLb& sm, const EqdGraph& G, int item, const float* __restrict__ q,
                                                      const float* __restrict__ k, const float* __restrict__ ds, int ds_stride,
                                                      float* __restrict__ dq, int half, float qk_slope) {
@@ -644,16 +704,17 @@ __device__ __forceinline__ void attn_bwd_qds_body_lb(AttnQdsSmemLb& sm, const Eq
     if (b0 >= b1) return;
     int rowq[NB];
     bool qv[NB];
-    const float* __restrict__ dsr[NB];
+    const float* __restrict__ dsr[NB];      // (DSB: in units of bf16 elements, see ds_load)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         rowq[nb] = b0 + 16 * nb + l15;
         qv[nb] = rowq[nb] < b1;
-        dsr[nb] = ds + (size_t)(qv[nb] ? rowq[nb] : b1 - 1) * ds_stride;      // + (key - o0)
+        const size_t ro = (size_t)(qv[nb] ? rowq[nb] : b1 - 1) * ds_stride;      // + (key - o0)
+        dsr[nb] = DSB ? (const float*)((const unsigned short*)ds + ro) : ds + ro;
     }
     LbRegs rk;
     int kt = o0 + 32 * wave;
-    lb_load(rk, k, kt, o1, lane);
+    lb_load_any<QB>(rk, k, kt, o1, lane);
     f32x4 sv[2][NB];
     auto ds_load = [&](int kt_) {
 #pragma unroll
@@ -661,7 +722,12 @@ __device__ __forceinline__ void attn_bwd_qds_body_lb(AttnQdsSmemLb& sm, const Eq
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 const int col = kt_ < o1 ? kt_ - o0 + 16 * mb + 4 * g : 0;
-                sv[mb][nb] = *(const f32x4*)(dsr[nb] + col);
+                if constexpr (DSB) {
+                    const float4 f = lb_cvt4(*(const s16x4*)((const unsigned short*)dsr[nb] + col));
+                    sv[mb][nb] = f32x4{f.x, f.y, f.z, f.w};
+                } else {
+                    sv[mb][nb] = *(const f32x4*)(dsr[nb] + col);
+                }
             }
     };
     ds_load(kt);
@@ -682,7 +748,7 @@ __device__ __forceinline__ void attn_bwd_qds_body_lb(AttnQdsSmemLb& sm, const Eq
             for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) S[mb][nb][r] = kt + 16 * mb + 4 * g + r < o1 ? sv[mb][nb][r] : 0.f;
-        lb_load(rk, k, kt + 32 * EQD_WAVES, o1, lane);
+        lb_load_any<QB>(rk, k, kt + 32 * EQD_WAVES, o1, lane);
         ds_load(kt + 32 * EQD_WAVES);
         lb_mma_r<NB>(dQ, Kt, g, l15, S);
     }
@@ -702,8 +768,11 @@ __device__ __forceinline__ void attn_bwd_qds_body_lb(AttnQdsSmemLb& sm, const Eq
             for (int r = 0; r < 4; ++r) {
                 const int o = ((db * 2 + nb) * 4 + r) * 64 + lane;
                 const int f = 16 * db + 4 * g + r;
+                float qval;      // (only its sign is used: LeakyReLU'(q))
+                if constexpr (QB) qval = bf2f(((const unsigned short*)q)[(size_t)rowq[nb] * d + f]);
+                else qval = q[(size_t)rowq[nb] * d + f];
                 dq[(size_t)rowq[nb] * d + f] = (sm.red(0)[o] + sm.red(1)[o] + sm.red(2)[o] + sm.red(3)[o]) *
-                                               lrelu_grad(q[(size_t)rowq[nb] * d + f], qk_slope);
+                                               lrelu_grad(qval, qk_slope);
             }
         }
 }

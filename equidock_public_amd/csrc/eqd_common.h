@@ -411,7 +411,7 @@ int eqd_launch_seg_start(const EqdGraph* g, int32_t* seg_start, hipStream_t st);
 int eqd_launch_attention_bwd_gather(const EqdGraph* g, int d, const float* q, const float* k, const float* v, const float* out,
                                     const float* lse, const float* d_out, float* dq, float* dk, float* dv, float* delta,
                                     float qk_slope, bool bf16, const EqdGatherCall* gc, EqdRedList* pending, hipStream_t st,
-                                    float* ds = nullptr, const int32_t* seg_start = nullptr);
+                                    float* ds = nullptr, const int32_t* seg_start = nullptr, bool qkv_bf16 = false);
 int eqd_launch_node_gather(const EqdGraph* g, const float* dz, const float* dxrel, const float* d_xnew, float a,
                            float* dP, float* dQ, float* dx, hipStream_t st, EqdRedList* pending = nullptr,
                            bool dz_bf16 = false);

@@ -47,6 +47,9 @@ struct LayerSaved {
     // transients of the scratch workspace, shared by all layers.  NULL otherwise.
     uint16_t *a1n_b, *aggr_b;
     int ld_a1n;
+    // q / k / v of a 64-wide layer whose attention backward will run in the dS hand-off form on the bf16 LDS kernels (large
+    // batches): saved as bf16 ([N][64]); qa / ka / va are then fp32 transients shared by all such layers.  NULL otherwise.
+    uint16_t *qa_b, *ka_b, *va_b;
 };
 struct Saved {
     float* h[64 + 1];
@@ -60,9 +63,12 @@ struct Saved {
 
 // A: the saved state (forward -> backward); T: transients of the forward (bf16 storage mode only; the same arena as A when
 // the forward keeps no state).  bfs = EqdModelDesc.storage_bf16.
-void carve_saved(const Dims& D, const EqdGraph* g, EqdArena& A, Saved& S, bool bfs, EqdArena& T) {
+void carve_saved(const Dims& D, const EqdGraph* g, EqdArena& A, Saved& S, bool bfs, EqdArena& T, bool qkv_b = false) {
     const size_t N = (size_t)D.N;
     S.bfs = bfs;
+    float* qkv_t[3] = {nullptr, nullptr, nullptr};
+    if (bfs && qkv_b)
+        for (int i = 0; i < 3; ++i) qkv_t[i] = T.take<float>(N * 64);
     S.h[0] = A.take<float>(N * D.d0);
     S.hb[0] = nullptr;
     S.x[0] = const_cast<float*>(g->x0);
@@ -79,9 +85,17 @@ void carve_saved(const Dims& D, const EqdGraph* g, EqdArena& A, Saved& S, bool b
         Ls.P = A.take<float>(N * 64);
         Ls.Q = A.take<float>(N * 64);
         const int da = D.d_att(l);
-        Ls.qa = A.take<float>(N * da);
-        Ls.ka = A.take<float>(N * da);
-        Ls.va = A.take<float>(N * da);
+        Ls.qa_b = Ls.ka_b = Ls.va_b = nullptr;
+        if (bfs && qkv_b && d == 64) {
+            Ls.qa = qkv_t[0]; Ls.ka = qkv_t[1]; Ls.va = qkv_t[2];
+            Ls.qa_b = A.take<uint16_t>(N * 64);
+            Ls.ka_b = A.take<uint16_t>(N * 64);
+            Ls.va_b = A.take<uint16_t>(N * 64);
+        } else {
+            Ls.qa = A.take<float>(N * da);
+            Ls.ka = A.take<float>(N * da);
+            Ls.va = A.take<float>(N * da);
+        }
         Ls.aggr_cross = A.take<float>(N * da);
         Ls.lse = A.take<float>(N);
         Ls.y_act = A.take<float>(N * d);
@@ -120,9 +134,16 @@ void carve_saved(const Dims& D, const EqdGraph* g, EqdArena& A, Saved& S, bool b
     S.T = A.take<float>((size_t)D.B * 9);
 }
 // the saved part alone (the backward and the test aids: the transients are dead by then and get no memory)
-void carve_saved(const Dims& D, const EqdGraph* g, EqdArena& A, Saved& S, bool bfs) {
+void carve_saved(const Dims& D, const EqdGraph* g, EqdArena& A, Saved& S, bool bfs, bool qkv_b) {
     EqdArena none(nullptr, 0);
-    carve_saved(D, g, A, S, bfs, none);
+    carve_saved(D, g, A, S, bfs, none, qkv_b);
+}
+// bf16 storage mode: are q / k / v of the 64-wide layers saved as bf16?  Exactly when eqd_launch_attention_bwd_gather will
+// run their backward in the dS hand-off form on the bf16 LDS kernels - the only kernels that read the bf16 form (same
+// predicate as carve_scratch's W.att_ds; the EQD_* switches are snapshotted once per process, so a forward and its
+// backward agree).
+bool qkv_saved_bf16(const Dims& D, const EqdModelDesc* m, const EqdGraph* g) {
+    return m->storage_bf16 && m->cross_msgs && D.dh == 64 && eqd_attention_ds_wanted(g, 64, true);
 }
 
 void lin_src(EqdLinJob& J, int i, const float* X, int ldx, int K, const float* W, int w_rs, int w_cs,
@@ -399,7 +420,7 @@ extern "C" size_t eqd_model_saved_bytes(const EqdModelDesc* m, const EqdGraph* g
     Dims D = make_dims(m, g);
     EqdArena A(nullptr, 0);
     Saved S;
-    carve_saved(D, g, A, S, m->storage_bf16 != 0);
+    carve_saved(D, g, A, S, m->storage_bf16 != 0, qkv_saved_bf16(D, m, g));
     return A.off + 256;
 }
 // transients of a forward in bf16 storage mode (fp32 h ping-pong, aggr_msg): carved from the scratch workspace
@@ -408,7 +429,7 @@ static size_t forward_transient_bytes(const EqdModelDesc* m, const EqdGraph* g) 
     Dims D = make_dims(m, g);
     EqdArena A(nullptr, 0), T(nullptr, 0);
     Saved S;
-    carve_saved(D, g, A, S, true, T);
+    carve_saved(D, g, A, S, true, T, qkv_saved_bf16(D, m, g));
     return T.off + 256;
 }
 
@@ -440,7 +461,7 @@ extern "C" int eqd_model_layer_state(const EqdModelDesc* m, const EqdGraph* g, c
     }
     EqdArena A(const_cast<void*>(saved), saved_bytes);
     Saved S;
-    carve_saved(D, g, A, S, m->storage_bf16 != 0);
+    carve_saved(D, g, A, S, m->storage_bf16 != 0, qkv_saved_bf16(D, m, g));
     if (!A.ok) {
         eqd_set_error("eqd_model_layer_state: saved buffer too small");
         return EQD_ERR_WORKSPACE;
@@ -469,6 +490,13 @@ __global__ void k_sign_rows(const float* __restrict__ src, int ld, int rows, int
         out[i] = src[r * ld + (i - r * d)] > 0.f ? 1 : 0;
     }
 }
+__global__ void k_sign_rows_bf(const uint16_t* __restrict__ src, int ld, int rows, int d, unsigned char* __restrict__ out) {
+    const size_t n = (size_t)rows * d;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / d;
+        out[i] = bf2f(src[r * ld + (i - r * d)]) > 0.f ? 1 : 0;
+    }
+}
 int eqd_launch_edge_signs(const EqdGraph* g, const EqdEdgeParams* p, const float* P, const float* Q, const float* x,
                           unsigned char* z1_pos, unsigned char* ch_pos, hipStream_t st);
 
@@ -489,7 +517,7 @@ extern "C" int eqd_model_lrelu_signs(const EqdModelDesc* m, const EqdGraph* g, c
     }
     EqdArena A(const_cast<void*>(saved), saved_bytes);
     Saved S;
-    carve_saved(D, g, A, S, m->storage_bf16 != 0);
+    carve_saved(D, g, A, S, m->storage_bf16 != 0, qkv_saved_bf16(D, m, g));
     if (!A.ok) {
         eqd_set_error("eqd_model_lrelu_signs: saved buffer too small");
         return EQD_ERR_WORKSPACE;
@@ -503,6 +531,14 @@ extern "C" int eqd_model_lrelu_signs(const EqdModelDesc* m, const EqdGraph* g, c
         hipLaunchKernelGGL(k_sign_rows, dim3(blocks), dim3(256), 0, st, src, ld, D.N, d, out);
         return eqd_check_launch("k_sign_rows");
     };
+    auto rows_b = [&](const uint16_t* src, int ld, int d, unsigned char* out) -> int {
+        if (!out) return EQD_OK;
+        const size_t n = (size_t)D.N * d;
+        int blocks = (int)((n + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(k_sign_rows_bf, dim3(blocks), dim3(256), 0, st, src, ld, D.N, d, out);
+        return eqd_check_launch("k_sign_rows");
+    };
     if (layer == D.L)      // head: mlp_h_mean_ROT's LeakyReLU (rigid_docking_model.py:434-438), [n_nodes][64]
         return rows(S.hm, 64, 64, node);
     const float* const* p = params + (size_t)EQD_PARAMS_PER_LAYER * layer;
@@ -510,8 +546,13 @@ extern "C" int eqd_model_lrelu_signs(const EqdModelDesc* m, const EqdGraph* g, c
     const int d = D.d_in(layer), da = D.d_att(layer);
     if (int rc = rows(Ls.y_act, d, d, node)) return rc;
     if (m->cross_msgs) {
-        if (int rc = rows(Ls.qa, da, d, q)) return rc;
-        if (int rc = rows(Ls.ka, da, d, k)) return rc;
+        if (Ls.qa_b) {      // saved as bf16 (sign of a bf16-rounded value = sign of the value)
+            if (int rc = rows_b(Ls.qa_b, 64, d, q)) return rc;
+            if (int rc = rows_b(Ls.ka_b, 64, d, k)) return rc;
+        } else {
+            if (int rc = rows(Ls.qa, da, d, q)) return rc;
+            if (int rc = rows(Ls.ka, da, d, k)) return rc;
+        }
     }
     if (edge_z1 && edge_ch) {
         if (int rc = drop_check(drop)) return rc;
@@ -583,7 +624,7 @@ extern "C" int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const
     EqdArena A(saved ? saved : scratch, saved ? saved_bytes : scratch_bytes);
     EqdArena Tr(scratch, scratch_bytes);
     Saved S;
-    carve_saved(D, g, A, S, bfs, saved ? Tr : A);
+    carve_saved(D, g, A, S, bfs, saved ? Tr : A, qkv_saved_bf16(D, m, g));
     if (!A.ok || (bfs && saved && !Tr.ok)) {
         eqd_set_error("eqd_model_forward: workspace too small or missing (state %zu bytes%s)", A.off,
                       bfs && saved ? "; bf16 storage mode also needs the scratch workspace (eqd_model_scratch_bytes) in a "
@@ -619,6 +660,10 @@ extern "C" int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const
             add(Ls.qa, d, da, p[P_WQ], d, nullptr, 1);
             add(Ls.ka, d, da, p[P_WK], d, nullptr, 1);
             add(Ls.va, d, da, p[P_WV], d, nullptr, 0);
+            if (Ls.qa_b) {      // bf16 storage mode: the saved form of q / k / v (the fp32 rows are transients of this layer)
+                cj[nj - 3].lin.Yb = Ls.qa_b; cj[nj - 2].lin.Yb = Ls.ka_b; cj[nj - 1].lin.Yb = Ls.va_b;
+                for (int i = nj - 3; i < nj; ++i) cj[i].lin.ldyb = 64;
+            }
             if (da != d)
                 for (int i = nj - 3; i < nj; ++i) cj[i].lin.pad_to = da;
         }
@@ -784,7 +829,7 @@ extern "C" int eqd_model_head_backward(const EqdModelDesc* m, const EqdGraph* g,
     g_bf16_mode = m->storage_bf16 ? 1 : 0;
     EqdArena As(const_cast<void*>(saved), saved_bytes);
     Saved S;
-    carve_saved(D, g, As, S, m->storage_bf16 != 0);
+    carve_saved(D, g, As, S, m->storage_bf16 != 0, qkv_saved_bf16(D, m, g));
     EqdArena Aw(scratch, scratch_bytes);
     Scratch W;
     carve_scratch(D, m, g, Aw, W);
@@ -830,7 +875,7 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
     g_bf16_mode = m->storage_bf16 ? 1 : 0;
     EqdArena As(const_cast<void*>(saved), saved_bytes);
     Saved S;
-    carve_saved(D, g, As, S, m->storage_bf16 != 0);
+    carve_saved(D, g, As, S, m->storage_bf16 != 0, qkv_saved_bf16(D, m, g));
     EqdArena Aw(scratch, scratch_bytes);
     Scratch W;
     carve_scratch(D, m, g, Aw, W);
@@ -980,10 +1025,13 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
             RC(eqd_edge_message_bwd_impl(g, &ep, Ls.P, Ls.Q, S.x[l], W.d_aggr_msg, dXcur, dP, dQ, dXnext, &eg, W.edge_ws,
                                          W.edge_ws_bytes, st, W.vecp_all + (size_t)l * W.vecp_stride, defer,
                                          m->cross_msgs ? &gc : nullptr));
-            if (m->cross_msgs)
-                RC(eqd_launch_attention_bwd_gather(g, da, Ls.qa, Ls.ka, Ls.va, Ls.aggr_cross, Ls.lse, W.d_aggr_cross, dq, dk,
+            if (m->cross_msgs) {
+                const bool qb = Ls.qa_b != nullptr;      // saved as bf16 (bf16 storage mode, dS hand-off form)
+                RC(eqd_launch_attention_bwd_gather(g, da, qb ? (const float*)Ls.qa_b : Ls.qa, qb ? (const float*)Ls.ka_b : Ls.ka,
+                                                   qb ? (const float*)Ls.va_b : Ls.va, Ls.aggr_cross, Ls.lse, W.d_aggr_cross, dq, dk,
                                                    dv, W.delta, m->lrelu_slope, m->storage_bf16 != 0, &gc, defer, st, W.att_ds,
-                                                   W.att_seg_start));
+                                                   W.att_seg_start, qb));
+            }
         }
         {
             EqdAtbJob ajobs[16];

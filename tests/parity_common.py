@@ -1368,6 +1368,121 @@ def check_dropout_library(dev):
     assert w2 <= 5e-3 and wm <= 2e-2
 
 
+def check_bf16_storage_ops(dev):
+    """The operator-level pieces of the bf16 storage mode: (1) EqdLinJob.Yb - the bf16 copy an
+    epilogue writes is the round-to-nearest-even of the fp32 output it writes beside it, bit for bit, in the lean (M = 64),
+    the general (M = 69, padded rows) and the LDS-resident-weights kernels; (2) EqdAtbJob.y_bf16 - a weight-gradient GEMM in
+    bf16 mode gives the SAME bits whether Y is the fp32 tensor or its saved bf16 form (the product rounds Y anyway)."""
+    torch.manual_seed(8)
+
+    def bf16_bits(t):
+        return t.detach().cpu().to(torch.bfloat16).view(torch.int16)
+
+    for rows, M, ldyb, K in ((301, 64, 64, 64), (77, 69, 72, 69), (301, 64, 64, 69)):
+        X, Wt, bias = torch.randn(rows, K), torch.randn(M, K) * 0.3, torch.randn(M)
+        Xd, Wd, bd = X.to(dev), Wt.to(dev), bias.to(dev)
+        Y = torch.zeros(rows, M, device=dev)
+        Yb = torch.full((rows, ldyb), 0x7fc0, dtype=torch.int16, device=dev)      # NaN bit patterns
+        J = L.EqdLinJob()
+        J.s[0].X, J.s[0].ldx, J.s[0].K, J.s[0].W, J.s[0].w_rs, J.s[0].w_cs = Xd.data_ptr(), K, K, Wd.data_ptr(), K, 1
+        J.nsrc, J.M, J.act, J.rows, J.bias = 1, M, 1, rows, bd.data_ptr()
+        J.alpha, J.beta, J.slope, J.ln_eps, J.Y, J.ldy, J.bf16 = 1.0, 0.0, 0.01, 1e-5, Y.data_ptr(), M, 1
+        J.Yb, J.ldyb = Yb.data_ptr(), ldyb
+        L.check(lib().eqd_linear(C.byref(J), 1, st(dev)))
+        sync(dev)
+        assert torch.equal(Yb.cpu()[:, :M], bf16_bits(Y)), f'bf16 copy of a linear output (M={M}, K={K})'
+        if ldyb > M:      # the started 4-column group is completed with zeros; nothing beyond it is touched
+            pad_end = (M + 3) // 4 * 4
+            assert int(Yb.cpu()[:, M:pad_end].abs().max()) == 0
+            assert bool((Yb.cpu()[:, pad_end:] == 0x7fc0).all())
+    # the same epilogue in the kernel with LDS-resident weights (k_rowres), forced at this size
+    import os
+    old = os.environ.get('EQD_ROWWAVE')
+    try:
+        for mode in ('1', '2'):
+            os.environ['EQD_ROWWAVE'] = mode
+            L.reload_tunables()
+            rows, M, K = 333, 64, 64
+            X, Wt = torch.randn(rows, K), torch.randn(M, K) * 0.3
+            Xd, Wd = X.to(dev), Wt.to(dev)
+            Y = torch.zeros(rows, M, device=dev)
+            Yb = torch.zeros(rows, M, dtype=torch.int16, device=dev)
+            J = L.EqdLinJob()
+            J.s[0].X, J.s[0].ldx, J.s[0].K, J.s[0].W, J.s[0].w_rs, J.s[0].w_cs = Xd.data_ptr(), K, K, Wd.data_ptr(), K, 1
+            J.nsrc, J.M, J.act, J.rows = 1, M, 0, rows
+            J.alpha, J.beta, J.slope, J.ln_eps, J.Y, J.ldy, J.bf16 = 1.0, 0.0, 0.01, 1e-5, Y.data_ptr(), M, 1
+            J.Yb, J.ldyb = Yb.data_ptr(), M
+            L.check(lib().eqd_linear(C.byref(J), 1, st(dev)))
+            sync(dev)
+            assert torch.equal(Yb.cpu(), bf16_bits(Y)), f'bf16 copy, EQD_ROWWAVE={mode}'
+    finally:
+        if old is None:
+            os.environ.pop('EQD_ROWWAVE', None)
+        else:
+            os.environ['EQD_ROWWAVE'] = old
+        L.reload_tunables()
+    # (2) A^T B with a bf16 Y: fast body (M = 64, whole and ragged column blocks) and the general body (M = 69)
+    for rows, M, N, ldy in ((777, 64, 64, 64), (333, 64, 69, 72), (500, 69, 64, 64), (129, 69, 69, 72)):
+        X, Yf = torch.randn(rows, M), torch.randn(rows, N)
+        Yh = Yf.to(torch.bfloat16)
+        Yexact = Yh.to(torch.float32)                      # fp32 tensor holding the bf16 values
+        Ypad = torch.full((rows, ldy), 0x7fc0, dtype=torch.int16)
+        Ypad[:, :N] = Yh.view(torch.int16)
+        res = []
+        for use_bf in (False, True):
+            out, bo = torch.zeros(M, N, device=dev), torch.zeros(M, device=dev)
+            Xd = X.to(dev)
+            Yd = (Ypad if use_bf else Yexact).to(dev).contiguous()
+            A = L.EqdAtbJob()
+            A.X, A.ldx, A.M, A.Y, A.ldy, A.N = Xd.data_ptr(), M, M, Yd.data_ptr(), (ldy if use_bf else N), N
+            A.rows, A.out, A.o_rs, A.o_cs, A.bias_out, A.slope, A.scale = rows, out.data_ptr(), N, 1, bo.data_ptr(), 0.01, 1.0
+            A.bf16, A.y_bf16 = 1, int(use_bf)
+            nb = lib().eqd_atb_partial_bytes(C.byref(A), 1)
+            part = torch.zeros(nb // 4 + 64, device=dev)
+            L.check(lib().eqd_atb(C.byref(A), 1, P(part), C.c_size_t(nb), st(dev)))
+            sync(dev)
+            res.append((out.cpu().clone(), bo.cpu().clone()))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), f'A^T B with a bf16 Y (M={M}, N={N})'
+        close(res[1][0], X.to(torch.bfloat16).to(torch.float32).t() @ Yexact, tol=2e-4, what='A^T B, bf16 Y')
+
+
+def check_bf16_storage_model(dev, monkeypatch):
+    """bf16 storage of the saved state: with the dS hand-off form of the attention backward (what large batches run; forced
+    here) the state a bf16-mode forward keeps for its backward is >= 24 % smaller than the fp32 mode's (a1n, aggr_msg, h and
+    the 64-wide layers' q / k / v as bf16), a training forward needs the scratch workspace too (clean error without it), and
+    intermediate fp32 layer states are no longer retrievable (clean error)."""
+    monkeypatch.setenv('EQD_ATT_DS', '1')
+    sizes = [(60, 75), (90, 48), (64, 64)]
+    g = G.batch_pairs(synthetic.make_pairs(sizes, 5)).to(dev)
+    nbytes = {}
+    for mode in ('f32', 'bf16'):
+        args = port.default_args(iegmn_n_lays=8, skip_weight_h=0.75, device=torch.device(dev))
+        if mode == 'bf16':
+            args = dict(args, hip_storage_dtype='bf16')
+        sd = port.init_state_dict(args, seed=5)
+        net = build_model(args, sd, dev)
+        pk = g.pack()
+        desc, gs = net.iegmn_original._desc(), pk.c_struct()
+        nbytes[mode] = int(lib().eqd_model_saved_bytes(C.byref(desc), C.byref(gs)))
+        if mode == 'bf16':
+            outs = net(g, epoch=0)
+            port.scalar_loss(outs).backward()
+            sync(dev)
+            assert all(torch.isfinite(p_.grad).all() for p_ in net.parameters())
+            h_L, _ = net.iegmn_original.layer_state(g, 8)
+            assert bool(torch.isfinite(h_L).all())
+            with pytest_raises(L.EquidockHipError):
+                net.iegmn_original.layer_state(g, 3)
+    ratio = nbytes['bf16'] / nbytes['f32']
+    print(f'saved state: fp32 {nbytes["f32"]} B, bf16 storage {nbytes["bf16"]} B ({100 * (1 - ratio):.1f} % smaller)')
+    assert ratio <= 0.76, ratio
+
+
+def pytest_raises(exc):
+    import pytest
+    return pytest.raises(exc)
+
+
 def check_lane_exchanges(dev):
     """The DPP / v_permlane*_swap lane exchanges (csrc/eqd_common.h) against __shfl_xor inside one kernel, bit for bit."""
     torch.manual_seed(2)

@@ -180,6 +180,17 @@ def test_model_forked_attention_stream(dev, monkeypatch):
     pc.check_model_case(dev, 'D_degraded3')
 
 
+def test_bf16_storage_operators(dev):
+    """EqdLinJob.Yb (bf16 copy == RNE of the fp32 output, every epilogue) and EqdAtbJob.y_bf16 (same bits as the fp32 Y)"""
+    from tests import parity_common as pc
+    pc.check_bf16_storage_ops(dev)
+
+
+def test_bf16_storage_of_the_saved_state(dev, monkeypatch):
+    from tests import parity_common as pc
+    pc.check_bf16_storage_model(dev, monkeypatch)
+
+
 def test_lane_exchanges(dev):
     """DPP / v_permlane*_swap helpers vs __shfl_xor, bit for bit, inside one kernel"""
     from tests import parity_common as pc

@@ -154,6 +154,14 @@ def test_model_forked_attention_stream(monkeypatch):
     pc.check_model_case(DEV, 'D_degraded3')
 
 
+def test_bf16_storage_operators():
+    pc.check_bf16_storage_ops(DEV)
+
+
+def test_bf16_storage_of_the_saved_state(monkeypatch):
+    pc.check_bf16_storage_model(DEV, monkeypatch)
+
+
 def test_lane_exchanges():
     pc.check_lane_exchanges(DEV)
 
