@@ -54,6 +54,18 @@ __device__ __forceinline__ void lb_load(LbRegs& R, const float* __restrict__ M, 
 __device__ __forceinline__ float4 lb_cvt4(s16x4 h) {
     return make_float4(bf2f((unsigned short)h[0]), bf2f((unsigned short)h[1]), bf2f((unsigned short)h[2]), bf2f((unsigned short)h[3]));
 }
+// RAW like lb_load: the 8 bytes of a piece are parked in .x / .y of its float4 as they come; lb_fix_bf converts them in
+// place when the tile is consumed (a conversion next to the load would make the loads of the NEXT tile - issued a whole
+// iteration ahead - wait at once)
+__device__ __forceinline__ float4 lb_raw8(const unsigned short* __restrict__ p) {
+    const unsigned long long h = *(const unsigned long long*)p;      // (one 8-byte load)
+    return make_float4(__builtin_bit_cast(float, (unsigned)h), __builtin_bit_cast(float, (unsigned)(h >> 32)), 0.f, 0.f);
+}
+__device__ __forceinline__ float4 lb_fix8(float4 raw) {
+    const unsigned lo = __builtin_bit_cast(unsigned, raw.x), hi = __builtin_bit_cast(unsigned, raw.y);
+    return make_float4(__builtin_bit_cast(float, lo << 16), __builtin_bit_cast(float, lo & 0xffff0000u),
+                       __builtin_bit_cast(float, hi << 16), __builtin_bit_cast(float, hi & 0xffff0000u));
+}
 __device__ __forceinline__ void lb_load_bf(LbRegs& R, const unsigned short* __restrict__ M, int r0, int r1, int lane) {
     int nrows = r1 - r0;
     nrows = nrows < 0 ? 0 : (nrows > 32 ? 32 : nrows);
@@ -63,9 +75,9 @@ __device__ __forceinline__ void lb_load_bf(LbRegs& R, const unsigned short* __re
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 4 * a + r;
-            const s16x4* __restrict__ p = (const s16x4*)(M + (size_t)(r0 + (row < nrows ? row : nrows - 1)) * 64 + 4 * cg);
-            R.lo[r] = lb_cvt4(p[0]);
-            R.hi[r] = lb_cvt4(p[8]);
+            const unsigned short* __restrict__ p = M + (size_t)(r0 + (row < nrows ? row : nrows - 1)) * 64 + 4 * cg;
+            R.lo[r] = lb_raw8(p);
+            R.hi[r] = lb_raw8(p + 32);
         }
     }
 }
@@ -73,6 +85,18 @@ template <bool QB>
 __device__ __forceinline__ void lb_load_any(LbRegs& R, const float* __restrict__ M, int r0, int r1, int lane) {
     if constexpr (QB) lb_load_bf(R, (const unsigned short*)M, r0, r1, lane);
     else lb_load(R, M, r0, r1, lane);
+}
+template <bool QB>
+__device__ __forceinline__ void lb_fix_any(LbRegs& R) {      // before the first use of a tile loaded by lb_load_any<true>
+    if constexpr (QB) {
+        if (R.nrows > 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                R.lo[r] = lb_fix8(R.lo[r]);
+                R.hi[r] = lb_fix8(R.hi[r]);
+            }
+        }
+    }
 }
 // [32][64] block tile of a saved bf16 tensor -> the fp32 LDS tile block_tile_stage_fast<4> makes (rows beyond the block: zeros)
 __device__ __forceinline__ void block_tile_stage_bf(const unsigned short* __restrict__ M, int DS, int r0, int r1,
@@ -566,6 +590,7 @@ __device__ __forceinline__ void attn_bwd_kv_body_lb(AttnBwdSmemLb& sm, const Eqd
     const int a8 = lane >> 3;
     for (; qt < o1; qt += 32 * EQD_WAVES) {
         wave_lds_fence();
+        lb_fix_any<QB>(rq);
         lb_store_rm(rq, W.a_rm, lane);
         lb_store_rm(rg, W.b_rm, lane);
         // delta = rowsum(dO * O) of the streamed query rows (fp32, from the rows as loaded): the lane's 8 columns of its
@@ -723,7 +748,7 @@ __device__ __forceinline__ void attn_bwd_qds_body_lb(AttnQdsSmemLb& sm, const Eq
             for (int nb = 0; nb < NB; ++nb) {
                 const int col = kt_ < o1 ? kt_ - o0 + 16 * mb + 4 * g : 0;
                 if constexpr (DSB) {
-                    const float4 f = lb_cvt4(*(const s16x4*)((const unsigned short*)dsr[nb] + col));
+                    const float4 f = lb_raw8((const unsigned short*)dsr[nb] + col);
                     sv[mb][nb] = f32x4{f.x, f.y, f.z, f.w};
                 } else {
                     sv[mb][nb] = *(const f32x4*)(dsr[nb] + col);
@@ -739,15 +764,22 @@ __device__ __forceinline__ void attn_bwd_qds_body_lb(AttnQdsSmemLb& sm, const Eq
     unsigned short* __restrict__ Kt = sm.w[wave].a_tr;
     for (; kt < o1; kt += 32 * EQD_WAVES) {
         wave_lds_fence();
+        lb_fix_any<QB>(rk);
         lb_store_tr(rk, Kt, lane);
         wave_lds_fence();
         f32x4 S[2][NB];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
+            for (int nb = 0; nb < NB; ++nb) {
+                f32x4 cur = sv[mb][nb];
+                if constexpr (DSB) {      // (the raw 8 bytes of four bf16, converted now)
+                    const float4 f = lb_fix8(make_float4(cur[0], cur[1], 0.f, 0.f));
+                    cur = f32x4{f.x, f.y, f.z, f.w};
+                }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) S[mb][nb][r] = kt + 16 * mb + 4 * g + r < o1 ? sv[mb][nb][r] : 0.f;
+                for (int r = 0; r < 4; ++r) S[mb][nb][r] = kt + 16 * mb + 4 * g + r < o1 ? cur[r] : 0.f;
+            }
         lb_load_any<QB>(rk, k, kt + 32 * EQD_WAVES, o1, lane);
         ds_load(kt + 32 * EQD_WAVES);
         lb_mma_r<NB>(dQ, Kt, g, l15, S);

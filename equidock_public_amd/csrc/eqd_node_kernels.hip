@@ -488,10 +488,27 @@ __global__ __launch_bounds__(EQD_BLOCK, OCC) void k_rowchain(EqdChainArg A_) {
     constexpr int CJ_DW = (int)(sizeof(EqdChainJob) / 4);
     const int lane = threadIdx.x & 63;
     JobW Wc = jobw_load(&A.j[0], CJ_DW, lane);      // descriptor words of the current job (see JobW)
+    // The LayerNorm-backward job's saved activations (one 16-byte vector per thread) are requested BEFORE the linear job in
+    // front of it runs (DB5.5-sized batches, the 512-register instances): the job then starts on data that has landed
+    // instead of with an exposed round trip to memory - one per backward chain.  Same loads, same bits.
+    f32x4 yp_pre = f4zero();
+    bool have_yp = false;
     for (int jj = 0; jj < njobs; ++jj) {
         const EqdChainJob& C = A.j[jj];
         const JobW Wn = jobw_load(&A.j[jj + 1 < njobs ? jj + 1 : jj], CJ_DW, lane);      // consumed a job later
         if (jw_i(Wc, JW_OFF(EqdChainJob, type)) == 0) {
+            if constexpr (RT == 1 && OCC == 1) {
+                if (jj + 1 < njobs && jw_i(Wn, JW_OFF(EqdChainJob, type)) != 0 && jw_i(Wn, JW_OFF(EqdLinJob, M)) == 64) {
+#define LJ(f) JW_OFF(EqdLinJob, f)
+                    const int rows_n = jw_i(Wn, LJ(rows)), ldx_n = jw_i(Wn, LJ(s) + JW_OFF(EqdLinSrc, ldx));
+                    const int l15 = lane & 15, g = lane >> 4, wave = (int)threadIdx.x >> 6;
+                    const int rowi = row0 + l15;
+                    yp_pre = *(const EQD_GAS f4v*)(jw_p<const float>(Wn, LJ(s) + JW_OFF(EqdLinSrc, X)) +
+                                                   (size_t)(rowi < rows_n ? rowi : rows_n - 1) * ldx_n + 16 * wave + 4 * g);
+#undef LJ
+                    have_yp = true;
+                }
+            }
             const int nj = jw_i(Wc, JW_OFF(EqdChainJob, prefetch_next));   // next linear job whose first step may be fetched early, or -1
             JobW Wp = Wn;
             if (nj >= 0 && nj != jj + 1) Wp = jobw_load(&A.j[nj], CJ_DW, lane);
@@ -502,9 +519,10 @@ __global__ __launch_bounds__(EQD_BLOCK, OCC) void k_rowchain(EqdChainArg A_) {
             bool fast = false;
             if constexpr (RT == 1) fast = jw_i(Wc, JW_OFF(EqdLinJob, M)) == 64;
             if constexpr (RT == 1) {
-                if (fast) chain_lnbwd64(Wc, Lb, sm4, row0, false, f4zero());
+                if (fast) chain_lnbwd64(Wc, Lb, sm4, row0, have_yp, yp_pre);
             }
             if (!fast) chain_lnbwd<RT>(C, Lb, red, row0);
+            have_yp = false;
         }
         Wc = Wn;
         __syncthreads();
@@ -809,13 +827,28 @@ struct AtbUnitsArg {
 // thread, 64-byte coalesced row segments) WHILE the previous chunk is multiplied, then written to LDS;
 // wave w accumulates the output column block nb = w for every row block mb.  One partial tile per
 // workgroup (no cross-wave reduction), summed later in a fixed order by k_atb_reduce.
-// four bf16 of a saved tensor (EqdAtbJob.y_bf16) as fp32: p 8-byte aligned; n = valid elements at p (>= 4 all, <= 0 none:
-// the load then goes to `safe`); exact values, so rounding them again when the MFMA operand is formed gives the same bits
-__device__ __forceinline__ f32x4 ld4_bf16(const unsigned short* __restrict__ p, int n, const unsigned short* __restrict__ safe) {
-    const s16x4 h = *(const EQD_GAS s16x4*)(n > 0 ? p : safe);
+// Four bf16 of a saved tensor (EqdAtbJob.y_bf16), split like ld4u_raw / ld4u_fix so that a batch of loads is issued
+// without anything waiting on it: ld4_bf16_raw is ONE 8-byte load (p 8-byte aligned; n = valid elements at p, <= 0: the load
+// goes to `safe`) whose two dwords are parked in the first two lanes of an f32x4; ld4_bf16_fix converts when the data is
+// consumed (exact values: rounding them again when the MFMA operand is formed gives the same bits), zero beyond n.
+__device__ __forceinline__ f32x4 ld4_bf16_raw(const unsigned short* __restrict__ p, int n, const unsigned short* __restrict__ safe) {
+    const unsigned long long h = *(const EQD_GAS unsigned long long*)(n > 0 ? p : safe);      // (one global_load_dwordx2)
     f32x4 r;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) r[i] = i < n ? bf2f((unsigned short)h[i]) : 0.f;
+    r[0] = __builtin_bit_cast(float, (unsigned)h);
+    r[1] = __builtin_bit_cast(float, (unsigned)(h >> 32));
+    r[2] = 0.f;
+    r[3] = 0.f;
+    return r;
+}
+__device__ __forceinline__ f32x4 ld4_bf16_fix(f32x4 raw, int n) {
+    // (through scalar temporaries: __builtin_bit_cast applied to `raw[1]` directly returns element 0 with this clang)
+    const float f0 = raw[0], f1 = raw[1];
+    const unsigned lo = __builtin_bit_cast(unsigned, f0), hi = __builtin_bit_cast(unsigned, f1);
+    f32x4 r;
+    r[0] = n > 0 ? __builtin_bit_cast(float, lo << 16) : 0.f;
+    r[1] = n > 1 ? __builtin_bit_cast(float, lo & 0xffff0000u) : 0.f;
+    r[2] = n > 2 ? __builtin_bit_cast(float, hi << 16) : 0.f;
+    r[3] = n > 3 ? __builtin_bit_cast(float, hi & 0xffff0000u) : 0.f;
     return r;
 }
 struct AtbRegs {
@@ -844,8 +877,8 @@ __device__ __forceinline__ void atb_load(const EqdAtbJob& J, int n0, int chunk, 
             if (J.xmask) R.xm[jr][h] = ld4u_raw(J.xmask + o, n, J.xmask);
         }
         if (J.y_bf16)
-            R.y[jr] = ld4_bf16((const unsigned short*)J.Y + ro * J.ldy + n0 + 4 * tc, atb_ny(J, n0, chunk, t, jr),
-                               (const unsigned short*)J.Y);
+            R.y[jr] = ld4_bf16_raw((const unsigned short*)J.Y + ro * J.ldy + n0 + 4 * tc, atb_ny(J, n0, chunk, t, jr),
+                                   (const unsigned short*)J.Y);
         else
             R.y[jr] = ld4u_raw(J.Y + ro * J.ldy + n0 + 4 * tc, atb_ny(J, n0, chunk, t, jr), J.Y);
     }
@@ -868,7 +901,7 @@ __device__ __forceinline__ void atb_store(const EqdAtbJob& J, int n0, int chunk,
             }
             *(float4*)&Xl[row * ATB_LS + 4 * tc + 64 * h] = v;
         }
-        if (J.y_bf16) *(f32x4*)&Yl[row * ATB_LS + 4 * tc] = R.y[jr];      // (already in place, zero beyond the matrix)
+        if (J.y_bf16) *(f32x4*)&Yl[row * ATB_LS + 4 * tc] = ld4_bf16_fix(R.y[jr], atb_ny(J, n0, chunk, t, jr));
         else *(float4*)&Yl[row * ATB_LS + 4 * tc] = ld4u_fix(R.y[jr], atb_ny(J, n0, chunk, t, jr));
     }
 }
@@ -1036,7 +1069,7 @@ __device__ __forceinline__ void atb_fast_bf(const AtbUnit& u, int c, float* __re
             row = row < rows ? row : rows - 1;
             rx[jr] = *(const EQD_GAS f4v*)(X + (size_t)row * ldx);
             if (masked) rm[jr] = *(const EQD_GAS f4v*)(Xm + (size_t)row * ldx);
-            if (ybf) ry[jr] = ld4_bf16(Yh + (size_t)row * ldy, ny, (const unsigned short*)J.Y);
+            if (ybf) ry[jr] = ld4_bf16_raw(Yh + (size_t)row * ldy, ny, (const unsigned short*)J.Y);
             else ry[jr] = yfull ? *(const EQD_GAS f4v*)(Y + (size_t)row * ldy)
                                 : ld4u_raw((const float*)(Y + (size_t)row * ldy), ny, J.Y);
         }
@@ -1049,7 +1082,9 @@ __device__ __forceinline__ void atb_fast_bf(const AtbUnit& u, int c, float* __re
         for (int jr = 0; jr < 4; ++jr) {
             const bool rvalid = chunk * ATB_ROWS + tr + 16 * jr < rows;
             f32x4 v = rx[jr], y = ry[jr];
-            if (!yfull && !ybf) {
+            if (ybf) {
+                y = ld4_bf16_fix(ry[jr], ny);
+            } else if (!yfull) {
                 const float4 f = ld4u_fix(ry[jr], ny);
                 y = f32x4{f.x, f.y, f.z, f.w};
             }
