@@ -1525,6 +1525,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
             vp[i] = a;
         }
     }
+    if (!W.wpart) return;      // (timing experiment only, eqd_edge_message_bwd_kernel_only with EQD_EXP_EDGE_NO_PARTIALS=1)
     float* wp = W.wpart + (size_t)blockIdx.x * WP_N;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -1654,6 +1655,10 @@ extern "C" int eqd_edge_message_bwd_kernel_only(const EqdGraph* g, const EqdEdge
         return EQD_ERR_WORKSPACE;
     }
     if (g->n_edges <= 0) return EQD_OK;
+    // knock-out experiment: the launch WITHOUT its 45 KB-per-workgroup weight-gradient partial writes
+    // (results incomplete, timing only) prices that write stream
+    if (const char* ko = eqd_tunable("EQD_EXP_EDGE_NO_PARTIALS"))
+        if (ko[0] == '1' && ko[1] == 0) W.wpart = nullptr;
     if (p->bf16)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_edge_bwd<true>), dim3(edge_bwd_blocks(g)), dim3(64 * BWD_WAVES), 0,
                            (hipStream_t)stream, *g, *p, P, Q, x, d_aggr_msg, d_xnew, W);

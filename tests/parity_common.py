@@ -284,7 +284,19 @@ def check_model_bf16_states(dev, sizes, layers=8, seed=3, pair_seed=34, faithful
     if report is not None:
         report.append(line)
     assert eh <= 2e-2 and ex <= 2e-3, line
-    assert abs(float(loss.detach()) - ref_loss) <= 0.3 * abs(ref_loss), line
+    # the whole-model OUTPUTS at this ROT scale (10: the keypoint softmax amplifies the layers' rounding noise ~1.3x instead
+    # of 18x, see BF16_ROT_SCALE): every output within BF16_OUT_TOL = 2e-2 of the oracle's (relative to the output's
+    # largest magnitude), the loss within 5 %
+    worst = 0.0
+    for o_got, o_ref in zip(outs, ref):      # five outputs, each a list with one tensor per pair
+        a, b_ = cat_out(list(o_got)).detach().cpu().double(), cat_out(list(o_ref)).detach().cpu().double()
+        worst = max(worst, float((a - b_).abs().max()) / max(1.0, float(b_.abs().max())))
+    line2 = f'{what}: bf16 whole-model outputs vs the oracle (ROT scale {rot_scale:g}): worst rel err {worst:.2e} (bound {BF16_OUT_TOL:g})'
+    print(line2)
+    if report is not None:
+        report.append(line2)
+    assert worst <= BF16_OUT_TOL, line2
+    assert abs(float(loss.detach()) - ref_loss) <= 0.05 * abs(ref_loss), line
     for T in outs[3]:
         t = T.detach().cpu()
         close(t @ t.t(), torch.eye(3), tol=1e-4, what='bf16 T T^T')
