@@ -853,6 +853,12 @@ static bool att_lds_bf16() {
 // first layer, 16-byte aligned operands), which is what the model always presents; anything else is an error here.
 extern "C" int eqd_cross_attention_fwd_bf16(const EqdGraph* g, int d, const float* q, const float* k, const float* v,
                                             float* out, float* lse, void* stream) {
+    return eqd_attention_fwd_bf16_impl(g, d, q, k, v, out, lse, (hipStream_t)stream, false);
+}
+// qkv_bf16: q, k, v are bf16 rows ([n_nodes][64]; the saved form of the bf16 storage mode) - only the LDS-bf16 kernels of the
+// 64-wide layers read them
+int eqd_attention_fwd_bf16_impl(const EqdGraph* g, int d, const float* q, const float* k, const float* v, float* out,
+                                float* lse, hipStream_t stream, bool qkv_bf16) {
     if (!g || !q || !k || !v || !out || !lse) {
         eqd_set_error("eqd_cross_attention_fwd_bf16: NULL argument");
         return EQD_ERR_NULL;
@@ -862,10 +868,19 @@ extern "C" int eqd_cross_attention_fwd_bf16(const EqdGraph* g, int d, const floa
         return EQD_ERR_UNSUPPORTED;
     }
     if (g->n_att_items <= 0) return EQD_OK;
-    hipStream_t st = (hipStream_t)stream;
+    hipStream_t st = stream;
     const bool half = att_half_blocks(g);
+    if (qkv_bf16 && !(d == 64 && att_lds_bf16())) {
+        eqd_set_error("attention forward: bf16 q / k / v are only read by the LDS-bf16 kernels of the 64-wide layers");
+        return EQD_ERR_UNSUPPORTED;
+    }
     if (d == 64 && att_lds_bf16()) {      // streamed tiles held in LDS as bf16 (eqd_attn_lb_inl.h)
-        if (half)
+        if (qkv_bf16) {
+            if (half)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_fwd_lb<1, true>), dim3(2 * g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, q, k, v, out, lse);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_fwd_lb<2, true>), dim3(g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, q, k, v, out, lse);
+        } else if (half)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_fwd_lb<1>), dim3(2 * g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, q, k, v, out, lse);
         else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attn_fwd_lb<2>), dim3(g->n_att_items), dim3(EQD_BLOCK), 0, st, *g, q, k, v, out, lse);

@@ -221,7 +221,8 @@ struct alignas(16) AttnFwdSmemLb {
     static_assert(sizeof(LbFwdWave) >= AttnCfg<4>::RED * sizeof(float), "merge buffer must fit a wave's tiles");
 };
 
-template <int NB>
+// QB: q, k, v point at bf16 rows (the saved form of the bf16 storage mode: the projections then write no fp32 q / k / v at all)
+template <int NB, bool QB = false>
 __device__ __forceinline__ void attn_fwd_body_lb(AttnFwdSmemLb& sm, const EqdGraph& G, int item, int half, int t,
                                                  const float* __restrict__ q, const float* __restrict__ k,
                                                  const float* __restrict__ v, float* __restrict__ out,
@@ -246,9 +247,10 @@ __device__ __forceinline__ void attn_fwd_body_lb(AttnFwdSmemLb& sm, const EqdGra
     }
     LbRegs rk, rv;
     int kt = o0 + 32 * wave;
-    lb_load(rk, k, kt, o1, lane);
-    lb_load(rv, v, kt, o1, lane);
-    block_tile_stage_fast<4>(q, DS, b0, b1, sm.Qt, t);
+    lb_load_any<QB>(rk, k, kt, o1, lane);
+    lb_load_any<QB>(rv, v, kt, o1, lane);
+    if constexpr (QB) block_tile_stage_bf((const unsigned short*)q, DS, b0, b1, sm.Qt, t);
+    else block_tile_stage_fast<4>(q, DS, b0, b1, sm.Qt, t);
     __syncthreads();
     s16x4 qf[NB][4];
 #pragma unroll
@@ -266,11 +268,13 @@ __device__ __forceinline__ void attn_fwd_body_lb(AttnFwdSmemLb& sm, const EqdGra
     unsigned short* const Vw = sm.w[wave].vtr;
     for (; kt < o1; kt += 32 * EQD_WAVES) {
         wave_lds_fence();
+        lb_fix_any<QB>(rk);
+        lb_fix_any<QB>(rv);
         lb_store_rm(rk, Kw, lane);
         lb_store_tr(rv, Vw, lane);
         wave_lds_fence();
-        lb_load(rk, k, kt + 32 * EQD_WAVES, o1, lane);      // prefetch the wave's next tile
-        lb_load(rv, v, kt + 32 * EQD_WAVES, o1, lane);
+        lb_load_any<QB>(rk, k, kt + 32 * EQD_WAVES, o1, lane);      // prefetch the wave's next tile
+        lb_load_any<QB>(rv, v, kt + 32 * EQD_WAVES, o1, lane);
         f32x4 S[2][NB];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
@@ -362,13 +366,13 @@ __device__ __forceinline__ void attn_fwd_body_lb(AttnFwdSmemLb& sm, const EqdGra
     }
 }
 
-template <int NB>
+template <int NB, bool QB = false>
 __global__ __launch_bounds__(EQD_BLOCK) void k_attn_fwd_lb(EqdGraph G, const float* __restrict__ q,
                                                            const float* __restrict__ k, const float* __restrict__ v,
                                                            float* __restrict__ out, float* __restrict__ lse) {
     __shared__ AttnFwdSmemLb sm;
     const int item = NB == 1 ? att_half_item((int)blockIdx.x) : (int)blockIdx.x;
-    attn_fwd_body_lb<NB>(sm, G, item, att_half_of((int)blockIdx.x), (int)threadIdx.x, q, k, v, out, lse);
+    attn_fwd_body_lb<NB, QB>(sm, G, item, att_half_of((int)blockIdx.x), (int)threadIdx.x, q, k, v, out, lse);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -408,6 +408,8 @@ int eqd_attention_ds_stride(const EqdGraph* g);
 size_t eqd_attention_ds_bytes(const EqdGraph* g);
 int eqd_attention_ds_wanted(const EqdGraph* g, int d, bool bf16);
 int eqd_launch_seg_start(const EqdGraph* g, int32_t* seg_start, hipStream_t st);
+int eqd_attention_fwd_bf16_impl(const EqdGraph* g, int d, const float* q, const float* k, const float* v, float* out,
+                                float* lse, hipStream_t stream, bool qkv_bf16);
 int eqd_launch_attention_bwd_gather(const EqdGraph* g, int d, const float* q, const float* k, const float* v, const float* out,
                                     const float* lse, const float* d_out, float* dq, float* dk, float* dv, float* delta,
                                     float qk_slope, bool bf16, const EqdGatherCall* gc, EqdRedList* pending, hipStream_t st,

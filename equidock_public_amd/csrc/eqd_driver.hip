@@ -48,7 +48,8 @@ struct LayerSaved {
     uint16_t *a1n_b, *aggr_b;
     int ld_a1n;
     // q / k / v of a 64-wide layer whose attention backward will run in the dS hand-off form on the bf16 LDS kernels (large
-    // batches): saved as bf16 ([N][64]); qa / ka / va are then fp32 transients shared by all such layers.  NULL otherwise.
+    // batches): written by the projections as bf16 ([N][64]) and read as bf16 by the attention forward and backward; no fp32
+    // form exists then (qa / ka / va NULL).  NULL otherwise.
     uint16_t *qa_b, *ka_b, *va_b;
 };
 struct Saved {
@@ -66,9 +67,7 @@ struct Saved {
 void carve_saved(const Dims& D, const EqdGraph* g, EqdArena& A, Saved& S, bool bfs, EqdArena& T, bool qkv_b = false) {
     const size_t N = (size_t)D.N;
     S.bfs = bfs;
-    float* qkv_t[3] = {nullptr, nullptr, nullptr};
-    if (bfs && qkv_b)
-        for (int i = 0; i < 3; ++i) qkv_t[i] = T.take<float>(N * 64);
+    (void)T;
     S.h[0] = A.take<float>(N * D.d0);
     S.hb[0] = nullptr;
     S.x[0] = const_cast<float*>(g->x0);
@@ -87,7 +86,7 @@ void carve_saved(const Dims& D, const EqdGraph* g, EqdArena& A, Saved& S, bool b
         const int da = D.d_att(l);
         Ls.qa_b = Ls.ka_b = Ls.va_b = nullptr;
         if (bfs && qkv_b && d == 64) {
-            Ls.qa = qkv_t[0]; Ls.ka = qkv_t[1]; Ls.va = qkv_t[2];
+            Ls.qa = Ls.ka = Ls.va = nullptr;      // (no fp32 form at all: the attention kernels of these layers read bf16)
             Ls.qa_b = A.take<uint16_t>(N * 64);
             Ls.ka_b = A.take<uint16_t>(N * 64);
             Ls.va_b = A.take<uint16_t>(N * 64);
@@ -660,7 +659,7 @@ extern "C" int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const
             add(Ls.qa, d, da, p[P_WQ], d, nullptr, 1);
             add(Ls.ka, d, da, p[P_WK], d, nullptr, 1);
             add(Ls.va, d, da, p[P_WV], d, nullptr, 0);
-            if (Ls.qa_b) {      // bf16 storage mode: the saved form of q / k / v (the fp32 rows are transients of this layer)
+            if (Ls.qa_b) {      // bf16 storage mode: q / k / v leave the projections as bf16 only (Y = NULL)
                 cj[nj - 3].lin.Yb = Ls.qa_b; cj[nj - 2].lin.Yb = Ls.ka_b; cj[nj - 1].lin.Yb = Ls.va_b;
                 for (int i = nj - 3; i < nj; ++i) cj[i].lin.ldyb = 64;
             }
@@ -701,7 +700,10 @@ extern "C" int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const
                                  Ls.lse, st));
         } else {
             if (m->cross_msgs) {
-                if (m->storage_bf16)
+                if (m->storage_bf16 && Ls.qa_b)
+                    RC(eqd_attention_fwd_bf16_impl(g, da, (const float*)Ls.qa_b, (const float*)Ls.ka_b, (const float*)Ls.va_b,
+                                                   Ls.aggr_cross, Ls.lse, sat, true));
+                else if (m->storage_bf16)
                     RC(eqd_cross_attention_fwd_bf16(g, da, Ls.qa, Ls.ka, Ls.va, Ls.aggr_cross, Ls.lse, sat));
                 else
                     RC(eqd_cross_attention_fwd(g, da, Ls.qa, Ls.ka, Ls.va, Ls.aggr_cross, Ls.lse, sat));

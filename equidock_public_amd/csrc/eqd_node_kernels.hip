@@ -749,7 +749,7 @@ extern "C" int eqd_linear(const EqdLinJob* jobs, int njobs, void* stream) {
             C.lin = jobs[i];
             for (int s = 0; s < EQD_MAX_SRC; ++s) C.src_local[s] = -1;
             C.out_local = -1;
-            ok = jobs[i].Y != nullptr && jobs[i].rows == jobs[0].rows;
+            ok = (jobs[i].Y != nullptr || jobs[i].Yb != nullptr) && jobs[i].rows == jobs[0].rows;
         }
         if (ok && rw_eligible(carg.j, njobs, jobs[0].rows)) {
             for (int i = 0; i < njobs; ++i)
@@ -768,7 +768,7 @@ extern "C" int eqd_linear(const EqdLinJob* jobs, int njobs, void* stream) {
         int maxrows = 0;
         for (int i = 0; i < n; ++i) {
             const EqdLinJob& J = jobs[base + i];
-            if (J.M < 4 || J.M > 80 || J.nsrc <= 0 || J.nsrc > EQD_MAX_SRC || !J.Y) {
+            if (J.M < 4 || J.M > 80 || J.nsrc <= 0 || J.nsrc > EQD_MAX_SRC || (!J.Y && !J.Yb)) {
                 eqd_set_error("eqd_linear: job %d has M=%d nsrc=%d (need 4..80 outputs, 1..%d sources)", base + i, J.M,
                               J.nsrc, EQD_MAX_SRC);
                 return EQD_ERR_SHAPE;
@@ -831,6 +831,17 @@ struct AtbUnitsArg {
 // without anything waiting on it: ld4_bf16_raw is ONE 8-byte load (p 8-byte aligned; n = valid elements at p, <= 0: the load
 // goes to `safe`) whose two dwords are parked in the first two lanes of an f32x4; ld4_bf16_fix converts when the data is
 // consumed (exact values: rounding them again when the MFMA operand is formed gives the same bits), zero beyond n.
+// v_perm_b32: byte i of the result = byte sel[i] of the 8 bytes {hi : lo} (selector 0..3 = bytes of lo, 4..7 = bytes of hi)
+__device__ __forceinline__ unsigned eqd_perm_b32(unsigned hi, unsigned lo, unsigned sel) {
+#ifdef EQD_HOSTSIM
+    const unsigned long long both = ((unsigned long long)hi << 32) | lo;
+    unsigned r = 0;
+    for (int i = 0; i < 4; ++i) r |= (unsigned)((both >> (8 * ((sel >> (8 * i)) & 7u))) & 0xffu) << (8 * i);
+    return r;
+#else
+    return __builtin_amdgcn_perm(hi, lo, sel);
+#endif
+}
 __device__ __forceinline__ f32x4 ld4_bf16_raw(const unsigned short* __restrict__ p, int n, const unsigned short* __restrict__ safe) {
     const unsigned long long h = *(const EQD_GAS unsigned long long*)(n > 0 ? p : safe);      // (one global_load_dwordx2)
     f32x4 r;
@@ -1037,6 +1048,10 @@ __device__ __forceinline__ void atb_fast(const AtbUnit& u, int c, float* __restr
 // of two chunks back, which are behind the barrier in between).  Column sums (bias gradients) are taken from the fp32
 // registers, as before from the fp32 tile.
 #define ATB_KG 17      /* k-groups per column row: 16 + 1 (34 dwords: the 16 lanes of a b64 read phase hit distinct banks) */
+// YBF: Y is a saved bf16 tensor (EqdAtbJob.y_bf16) - a template parameter, not a run-time branch: with the two load forms in
+// one loop body the compiler's wait-count pass put an s_waitcnt vmcnt(0) behind every Y load at the branch merges (the loads
+// of the next chunk, issued a whole chunk ahead, then ran one round trip after the other: 321 -> 376 us per pass)
+template <bool YBF>
 __device__ __forceinline__ void atb_fast_bf(const AtbUnit& u, int c, float* __restrict__ partial, float* __restrict__ Xl_,
                                             float* __restrict__ Yl_) {
     const EqdAtbJob& J = u.job;
@@ -1052,7 +1067,7 @@ __device__ __forceinline__ void atb_fast_bf(const AtbUnit& u, int c, float* __re
     const EQD_GAS float* const Y = (const EQD_GAS float*)J.Y + u.n0 + 4 * tc;
     const int ny = J.N - (u.n0 + 4 * tc);
     const bool yfull = u.fast == 1;
-    const bool ybf = J.y_bf16 != 0;      // Y is a saved bf16 tensor (uint16 rows): 8-byte loads, exact conversion
+    constexpr bool ybf = YBF;            // Y is a saved bf16 tensor (uint16 rows): 8-byte loads
     const unsigned short* const Yh = (const unsigned short*)J.Y + u.n0 + 4 * tc;
     static_assert(2 * 64 * ATB_KG * 8 <= ATB_ROWS * ATB_LS * 4, "two bf16 chunks must fit one fp32 tile");
     s16x4* const Xb = (s16x4*)Xl_;      // [2][64 columns][ATB_KG]
@@ -1062,6 +1077,7 @@ __device__ __forceinline__ void atb_fast_bf(const AtbUnit& u, int c, float* __re
     for (int mb = 0; mb < 4; ++mb) acc[mb] = f4zero();
     float bs[4] = {0.f, 0.f, 0.f, 0.f};
     f32x4 rx[4], rm[4], ry[4];
+    unsigned long long ryh[4] = {0ull, 0ull, 0ull, 0ull};      // raw rows of a saved bf16 Y (whole column blocks)
     auto load = [&](int chunk) {
 #pragma unroll
         for (int jr = 0; jr < 4; ++jr) {
@@ -1069,18 +1085,14 @@ __device__ __forceinline__ void atb_fast_bf(const AtbUnit& u, int c, float* __re
             row = row < rows ? row : rows - 1;
             rx[jr] = *(const EQD_GAS f4v*)(X + (size_t)row * ldx);
             if (masked) rm[jr] = *(const EQD_GAS f4v*)(Xm + (size_t)row * ldx);
-            if (ybf) {      // (a whole column block: no address select, no masks - the selects of the general form doubled
-                            //  the kernel's VALU work per chunk: 274 -> 375 us at 64 x (300, 300))
-                if (yfull) {
-                    const unsigned long long h = *(const EQD_GAS unsigned long long*)(Yh + (size_t)row * ldy);
-                    ry[jr][0] = __builtin_bit_cast(float, (unsigned)h);
-                    ry[jr][1] = __builtin_bit_cast(float, (unsigned)(h >> 32));
-                } else {
-                    ry[jr] = ld4_bf16_raw(Yh + (size_t)row * ldy, ny, (const unsigned short*)J.Y);
-                }
+            if constexpr (ybf) {
+                // ONE unconditional 8-byte load into registers nothing else writes (a ragged last block: the address is
+                // clamped like ld4u_raw's; the columns beyond the matrix are masked when the block is converted)
+                ryh[jr] = *(const EQD_GAS unsigned long long*)(ny > 0 ? Yh + (size_t)row * ldy : (const unsigned short*)J.Y);
+            } else {
+                ry[jr] = yfull ? *(const EQD_GAS f4v*)(Y + (size_t)row * ldy)
+                               : ld4u_raw((const float*)(Y + (size_t)row * ldy), ny, J.Y);
             }
-            else ry[jr] = yfull ? *(const EQD_GAS f4v*)(Y + (size_t)row * ldy)
-                                : ld4u_raw((const float*)(Y + (size_t)row * ldy), ny, J.Y);
         }
     };
     load(c);
@@ -1091,16 +1103,12 @@ __device__ __forceinline__ void atb_fast_bf(const AtbUnit& u, int c, float* __re
         for (int jr = 0; jr < 4; ++jr) {
             const bool rvalid = chunk * ATB_ROWS + tr + 16 * jr < rows;
             f32x4 v = rx[jr], y = ry[jr];
-            if (ybf) {
-                if (yfull) {      // (uniform branch: four shifts / masks, no selects)
-                    const float f0 = ry[jr][0], f1 = ry[jr][1];
-                    const unsigned lo = __builtin_bit_cast(unsigned, f0), hi = __builtin_bit_cast(unsigned, f1);
-                    y[0] = __builtin_bit_cast(float, lo << 16);
-                    y[1] = __builtin_bit_cast(float, lo & 0xffff0000u);
-                    y[2] = __builtin_bit_cast(float, hi << 16);
-                    y[3] = __builtin_bit_cast(float, hi & 0xffff0000u);
-                } else {
-                    y = ld4_bf16_fix(ry[jr], ny);
+            if constexpr (ybf) {
+                if (!yfull) {      // (a ragged last column block: converted, packed below)
+                    f32x4 raw = f4zero();
+                    raw[0] = __builtin_bit_cast(float, (unsigned)ryh[jr]);
+                    raw[1] = __builtin_bit_cast(float, (unsigned)(ryh[jr] >> 32));
+                    y = ld4_bf16_fix(raw, ny);
                 }
             } else if (!yfull) {
                 const float4 f = ld4u_fix(ry[jr], ny);
@@ -1122,8 +1130,32 @@ __device__ __forceinline__ void atb_fast_bf(const AtbUnit& u, int c, float* __re
 #pragma unroll
         for (int i = 0; i < 4; ++i) {      // column 4 tc + i, k-group tr = this thread's four rows
             Xc[(4 * tc + i) * ATB_KG + tr] = pack_bf4(xv[0][i], xv[1][i], xv[2][i], xv[3][i]);
-            Yc[(4 * tc + i) * ATB_KG + tr] = pack_bf4(yv[0][i], yv[1][i], yv[2][i], yv[3][i]);
             if (want_bias) bs[i] += (xv[0][i] + xv[1][i]) + (xv[2][i] + xv[3][i]);
+        }
+        if (ybf && yfull) {
+            // a saved bf16 Y: the column-major groups are assembled from the raw halves (one byte permute per dword - a
+            // conversion to fp32 and back costs twice the VALU work of the fp32 operand's packing, and this kernel's chunk
+            // loop is bound by its VALU work: measured 321 -> 376 us per pass at 64 x (300, 300), profiles/r05_f_atb_ab.txt)
+            unsigned lo[4], hi[4];
+#pragma unroll
+            for (int jr = 0; jr < 4; ++jr) {      // (rows beyond the matrix: zeros)
+                const bool rvalid = chunk * ATB_ROWS + tr + 16 * jr < rows;
+                lo[jr] = rvalid ? (unsigned)ryh[jr] : 0u;
+                hi[jr] = rvalid ? (unsigned)(ryh[jr] >> 32) : 0u;
+            }
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            auto col = [&](unsigned a0, unsigned a1, unsigned a2, unsigned a3, bool high) {
+                const unsigned sel = high ? 0x07060302u : 0x05040100u;
+                const u32x2 d = {eqd_perm_b32(a1, a0, sel), eqd_perm_b32(a3, a2, sel)};
+                return __builtin_bit_cast(s16x4, d);
+            };
+            Yc[(4 * tc + 0) * ATB_KG + tr] = col(lo[0], lo[1], lo[2], lo[3], false);
+            Yc[(4 * tc + 1) * ATB_KG + tr] = col(lo[0], lo[1], lo[2], lo[3], true);
+            Yc[(4 * tc + 2) * ATB_KG + tr] = col(hi[0], hi[1], hi[2], hi[3], false);
+            Yc[(4 * tc + 3) * ATB_KG + tr] = col(hi[0], hi[1], hi[2], hi[3], true);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Yc[(4 * tc + i) * ATB_KG + tr] = pack_bf4(yv[0][i], yv[1][i], yv[2][i], yv[3][i]);
         }
         __syncthreads();             // the chunk is in LDS (and every wave is past its reads of the chunk before the last)
         if (chunk + nparts < nchunks) load(chunk + nparts);
@@ -1164,8 +1196,12 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_atb(AtbUnitsArg U, float* __restr
     const int c = blockIdx.x;
     if (c >= u.nparts) return;       // uniform per workgroup
     if (u.fast) {
-        if (u.job.bf16) atb_fast_bf(u, c, partial, Xl, Yl);
-        else atb_fast(u, c, partial, Xl, Yl);
+        if (u.job.bf16) {
+            if (u.job.y_bf16) atb_fast_bf<true>(u, c, partial, Xl, Yl);
+            else atb_fast_bf<false>(u, c, partial, Xl, Yl);
+        } else {
+            atb_fast(u, c, partial, Xl, Yl);
+        }
         return;
     }
     const EqdAtbJob& J = u.job;
