@@ -979,6 +979,37 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void k_edge_attn_fwd(EqdGraph G, Eq
     }
 }
 
+// The same for the 69-wide FIRST layer (attention rows zero-padded to 80): one 32-row attention item per workgroup on its
+// first four waves (the other four exit at once; two 16-row halves of the 80-wide forward would need 2 x 98 KB of LDS), the
+// edge tiles as above.  A row's keys are split over the waves and merged in the same order whatever the block height: the
+// same bits as the separate launches.  At 8 x (200, 200): 134 + 112 workgroups on 256 CUs, the attention (12 us on its
+// own) runs beside the 24 us edge forward instead of in front of it.
+union alignas(16) EdgeAttnFwdSmem80 {
+    EdgeFwdSmem<FWD_WAVES, false> edge;
+    AttnFwdSmem<5> att;
+    __device__ EdgeAttnFwdSmem80() {}
+};
+template <bool DROP>
+__global__ __launch_bounds__(64 * FWD_WAVES) void k_edge_attn_fwd80(EqdGraph G, EqdEdgeParams P, int n_edge,
+                                                                     const float* __restrict__ Pn,
+                                                                     const float* __restrict__ Qn,
+                                                                     const float* __restrict__ x,
+                                                                     float* __restrict__ aggr_msg,
+                                                                     float* __restrict__ x_new,
+                                                                     const float* __restrict__ q,
+                                                                     const float* __restrict__ k,
+                                                                     const float* __restrict__ v,
+                                                                     float* __restrict__ att_out,
+                                                                     float* __restrict__ lse) {
+    __shared__ EdgeAttnFwdSmem80 S;
+    if ((int)blockIdx.x < n_edge) {
+        edge_fwd_body<FWD_WAVES, false, DROP>(S.edge, G, P, (int)blockIdx.x, n_edge, Pn, Qn, x, aggr_msg, x_new);
+    } else {
+        if (threadIdx.x >= 256) return;      // (a finished wave does not take part in the others' barriers)
+        attn_fwd_body<5, true, 2>(S.att, G, (int)blockIdx.x - n_edge, 0, (int)threadIdx.x, 80, q, k, v, att_out, lse, false);
+    }
+}
+
 // Smallest grid with the minimal number of tile rounds: with `wg_per_cu` workgroups per CU the makespan is
 // ceil(tiles / (CUs * wg_per_cu * waves)) tile times whatever the grid, so use as few CUs as that allows
 // and leave the rest to the kernels that run concurrently on the auxiliary streams.
@@ -1025,7 +1056,11 @@ extern "C" int eqd_edge_message_fwd(const EqdGraph* g, const EqdEdgeParams* p, c
 int eqd_edge_attn_fused(const EqdGraph* g, const EqdEdgeParams* p, int d_att, const float* q, const float* k, const float* v) {
     const char* f = eqd_tunable("EQD_FUSE_FWD");
     if (f && f[0] == '0' && f[1] == 0) return 0;
-    if (p->bf16 || d_att != 64 || g->n_tiles <= 0 || g->n_att_items <= 0) return 0;
+    if (p->bf16 || (d_att != 64 && d_att != 80) || g->n_tiles <= 0 || g->n_att_items <= 0) return 0;
+    if (d_att == 80) {      // the first layer's form (round 5); EQD_FUSE_FWD80=0 keeps the two launches
+        const char* f8 = eqd_tunable("EQD_FUSE_FWD80");
+        if (f8 && f8[0] == '0' && f8[1] == 0) return 0;
+    }
     if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) != 0) return 0;
     const int n_edge = edge_grid(g->n_tiles, FWD_WAVES, 1);
     return n_edge + g->n_att_items <= eqd_num_cus();
@@ -1043,6 +1078,15 @@ int eqd_edge_attn_fwd(const EqdGraph* g, const EqdEdgeParams* p, const float* P,
     const int n_edge = edge_grid(g->n_tiles, FWD_WAVES, 1);
     const int drop = edge_drop_mode(p, "eqd_edge_attn_fwd");
     if (drop < 0) return EQD_ERR_NULL;
+    if (d_att == 80) {
+        if (drop)
+            hipLaunchKernelGGL(k_edge_attn_fwd80<true>, dim3(n_edge + g->n_att_items), dim3(64 * FWD_WAVES), 0, st, *g, *p, n_edge,
+                               P, Q, x, aggr_msg, x_new, q, k, v, att_out, lse);
+        else
+            hipLaunchKernelGGL(k_edge_attn_fwd80<false>, dim3(n_edge + g->n_att_items), dim3(64 * FWD_WAVES), 0, st, *g, *p, n_edge,
+                               P, Q, x, aggr_msg, x_new, q, k, v, att_out, lse);
+        return eqd_check_launch("k_edge_attn_fwd");
+    }
     if (drop)
         hipLaunchKernelGGL(k_edge_attn_fwd<true>, dim3(n_edge + g->n_att_items), dim3(64 * FWD_WAVES), 0, st, *g, *p, n_edge, P,
                            Q, x, aggr_msg, x_new, q, k, v, att_out, lse);

@@ -59,6 +59,7 @@ static void* g_sched_sp;
 static Fiber* g_cur;
 static const std::function<void()>* g_body;
 static int g_nthreads, g_blk_arrived;
+static int g_alive;      // threads of the block that have not finished: like s_barrier, __syncthreads only counts those
 static unsigned g_blk_gen;
 static unsigned long g_progress;
 
@@ -70,6 +71,11 @@ static void yield() {
 static void fiber_main() {
     (*g_body)();
     g_cur->done = true;
+    --g_alive;
+    if (g_blk_arrived > 0 && g_blk_arrived == g_alive) {      // the threads waiting at a barrier were waiting for this one only
+        g_blk_arrived = 0;
+        g_blk_gen++;
+    }
     g_progress++;
     yield();
     abort();
@@ -93,7 +99,7 @@ void wave_barrier() { g_cur->ncoll++; wave_sync(); }
 
 void sync_block() {
     unsigned my = g_blk_gen;
-    if (++g_blk_arrived == g_nthreads) {
+    if (++g_blk_arrived == g_alive) {
         g_blk_arrived = 0;
         g_blk_gen++;
         g_progress++;
@@ -186,6 +192,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
     for (unsigned bx = 0; bx < grid.x; ++bx) {
         g_blk_arrived = 0;
         g_blk_gen = 0;
+        g_alive = nt;
         for (int w = 0; w < nwaves; ++w) {
             g_wave[w].nlanes = (w == nwaves - 1) ? nt - 64 * w : 64;
             g_wave[w].arrived = 0;
