@@ -535,6 +535,21 @@ def load_traffic(workload):
     return {}, None
 
 
+def load_issue_floor(workload):
+    """Per-family issue floors of `workload` from the newest committed SQ-counter summary (profiles/*issue_floor.json,
+    profiles/issue_floor.py): the busy time of the launch's busiest issue pipe (VALU / LDS / MFMA) and the launch time it was
+    measured against - the roof a latency-bound kernel is actually running under."""
+    import glob
+    for f in reversed(sorted(glob.glob(os.path.join(ROOT, 'profiles', '*issue_floor.json')), key=_profile_order)):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if workload in d:
+            return d[workload], 'profiles/' + os.path.basename(f)
+    return {}, None
+
+
 def load_pmc(workload):
     """MFMA utilisation / executed MFMA FLOPs per kernel from the newest committed PMC summary (profiles/*pmc_mfma*.json)."""
     import glob
@@ -963,6 +978,12 @@ def main():
                 wkey = a.workload + ('_bf16' if dtype == 'bf16' else '')
                 traffic, traffic_src = load_traffic(wkey)
                 allk, ktot, covered = kernel_rooflines(prof, work, dtype == 'bf16', ms_step * 1e3, load_pmc(wkey), traffic)
+                floors, floor_src = load_issue_floor(wkey)
+                for k, e in allk.items():      # issue floor of the family (SQ counters of an earlier rocprofv3 --pmc pass)
+                    fl = floors.get(k) or next((v for kk, v in floors.items() if k.startswith(kk)), None)
+                    if fl:
+                        e["issue_floor"] = dict(fl, source=floor_src,
+                                                live_frac_of_floor=round(fl["floor_us"] / e["avg_launch_us"], 4))
                 for k in ('k_edge_fwd', 'k_edge_bwd'):     # keep the standalone batched-launch figures beside the in-step ones
                     if k in allk:
                         allk[k]["standalone"] = rl[k]
