@@ -964,6 +964,7 @@ __device__ __forceinline__ void atb_mma(f32x4 (&acc)[5], const float* __restrict
 // nothing when M <= 64 - the general path is bound by its ~800 VALU instructions per chunk, not by memory (its time
 // does not change between 256 and 1 536 workgroups).  The column sums (bias gradients) are taken by all four waves,
 // 16 rows each, and only when a bias gradient is wanted.
+template <bool MASKED>      // (a template flag, not a run-time one: see atb_fast_bf)
 __device__ __forceinline__ void atb_fast(const AtbUnit& u, int c, float* __restrict__ partial, float* __restrict__ Xl,
                                          float* __restrict__ Yl) {
     const EqdAtbJob& J = u.job;
@@ -971,7 +972,7 @@ __device__ __forceinline__ void atb_fast(const AtbUnit& u, int c, float* __restr
     const int l15 = lane & 15, g = lane >> 4;
     const int tr = t >> 4, tc = t & 15;
     const int rows = J.rows, ldx = J.ldx, ldy = J.ldy, nparts = u.nparts, nchunks = u.nchunks;
-    const bool masked = J.xmask != nullptr;
+    constexpr bool masked = MASKED;
     const bool want_bias = J.bias_out != nullptr && u.n0 == 0;
     const float slope = J.slope;
     const EQD_GAS float* const X = (const EQD_GAS float*)J.X + 4 * tc;
@@ -990,7 +991,7 @@ __device__ __forceinline__ void atb_fast(const AtbUnit& u, int c, float* __restr
             int row = chunk * ATB_ROWS + tr + 16 * jr;
             row = row < rows ? row : rows - 1;
             rx[jr] = *(const EQD_GAS f4v*)(X + (size_t)row * ldx);
-            if (masked) rm[jr] = *(const EQD_GAS f4v*)(Xm + (size_t)row * ldx);
+            if constexpr (masked) rm[jr] = *(const EQD_GAS f4v*)(Xm + (size_t)row * ldx);
             ry[jr] = yfull ? *(const EQD_GAS f4v*)(Y + (size_t)row * ldy)
                            : ld4u_raw((const float*)(Y + (size_t)row * ldy), ny, J.Y);
         }
@@ -1006,7 +1007,7 @@ __device__ __forceinline__ void atb_fast(const AtbUnit& u, int c, float* __restr
                 const float4 f = ld4u_fix(ry[jr], ny);
                 y = f32x4{f.x, f.y, f.z, f.w};
             }
-            if (masked) {
+            if constexpr (masked) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] *= lrelu_grad(rm[jr][i], slope);
             }
@@ -1051,7 +1052,9 @@ __device__ __forceinline__ void atb_fast(const AtbUnit& u, int c, float* __restr
 // YBF: Y is a saved bf16 tensor (EqdAtbJob.y_bf16) - a template parameter, not a run-time branch: with the two load forms in
 // one loop body the compiler's wait-count pass put an s_waitcnt vmcnt(0) behind every Y load at the branch merges (the loads
 // of the next chunk, issued a whole chunk ahead, then ran one round trip after the other: 321 -> 376 us per pass)
-template <bool YBF>
+// MASKED (X multiplied by LeakyReLU'(xmask): one unit per backward pass, the head's mlp_h_mean_ROT) likewise: as a run-time
+// flag the mask rows were loaded for every unit (the compiler turned `if (masked) load` into an unconditional load of X again)
+template <bool YBF, bool MASKED>
 __device__ __forceinline__ void atb_fast_bf(const AtbUnit& u, int c, float* __restrict__ partial, float* __restrict__ Xl_,
                                             float* __restrict__ Yl_) {
     const EqdAtbJob& J = u.job;
@@ -1059,7 +1062,7 @@ __device__ __forceinline__ void atb_fast_bf(const AtbUnit& u, int c, float* __re
     const int l15 = lane & 15, g = lane >> 4;
     const int tr = t >> 4, tc = t & 15;
     const int rows = J.rows, ldx = J.ldx, ldy = J.ldy, nparts = u.nparts, nchunks = u.nchunks;
-    const bool masked = J.xmask != nullptr;
+    constexpr bool masked = MASKED;
     const bool want_bias = J.bias_out != nullptr && u.n0 == 0;
     const float slope = J.slope;
     const EQD_GAS float* const X = (const EQD_GAS float*)J.X + 4 * tc;
@@ -1083,12 +1086,16 @@ __device__ __forceinline__ void atb_fast_bf(const AtbUnit& u, int c, float* __re
         for (int jr = 0; jr < 4; ++jr) {
             int row = chunk * ATB_ROWS + tr + 16 * jr;
             row = row < rows ? row : rows - 1;
-            rx[jr] = *(const EQD_GAS f4v*)(X + (size_t)row * ldx);
-            if (masked) rm[jr] = *(const EQD_GAS f4v*)(Xm + (size_t)row * ldx);
+            // (wave-uniform base + 32-bit per-lane byte offset: no 64-bit address arithmetic per load; the host takes this
+            //  body only for operands below 2 GB, atb_units)
+            const unsigned xo = 4u * (unsigned)(row * ldx + 4 * tc);
+            rx[jr] = *(const EQD_GAS f4v*)((const char*)J.X + xo);
+            if constexpr (masked) rm[jr] = *(const EQD_GAS f4v*)((const char*)J.xmask + xo);
             if constexpr (ybf) {
                 // ONE unconditional 8-byte load into registers nothing else writes (a ragged last block: the address is
                 // clamped like ld4u_raw's; the columns beyond the matrix are masked when the block is converted)
-                ryh[jr] = *(const EQD_GAS unsigned long long*)(ny > 0 ? Yh + (size_t)row * ldy : (const unsigned short*)J.Y);
+                const unsigned yo = ny > 0 ? 2u * (unsigned)(row * ldy + u.n0 + 4 * tc) : 0u;
+                ryh[jr] = *(const EQD_GAS unsigned long long*)((const char*)J.Y + yo);
             } else {
                 ry[jr] = yfull ? *(const EQD_GAS f4v*)(Y + (size_t)row * ldy)
                                : ld4u_raw((const float*)(Y + (size_t)row * ldy), ny, J.Y);
@@ -1099,6 +1106,7 @@ __device__ __forceinline__ void atb_fast_bf(const AtbUnit& u, int c, float* __re
     int buf = 0;
     for (int chunk = c; chunk < nchunks; chunk += nparts) {
         f32x4 xv[4], yv[4];
+        const bool tail = (chunk + 1) * ATB_ROWS > rows;
 #pragma unroll
         for (int jr = 0; jr < 4; ++jr) {
             const bool rvalid = chunk * ATB_ROWS + tr + 16 * jr < rows;
@@ -1114,11 +1122,11 @@ __device__ __forceinline__ void atb_fast_bf(const AtbUnit& u, int c, float* __re
                 const float4 f = ld4u_fix(ry[jr], ny);
                 y = f32x4{f.x, f.y, f.z, f.w};
             }
-            if (masked) {
+            if constexpr (masked) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] *= lrelu_grad(rm[jr][i], slope);
             }
-            if (!rvalid) {
+            if (tail && !rvalid) {      // (only the matrix's last chunk has rows beyond it: a uniform test everywhere else)
                 v = f4zero();
                 y = f4zero();
             }
@@ -1139,7 +1147,7 @@ __device__ __forceinline__ void atb_fast_bf(const AtbUnit& u, int c, float* __re
             unsigned lo[4], hi[4];
 #pragma unroll
             for (int jr = 0; jr < 4; ++jr) {      // (rows beyond the matrix: zeros)
-                const bool rvalid = chunk * ATB_ROWS + tr + 16 * jr < rows;
+                const bool rvalid = !tail || chunk * ATB_ROWS + tr + 16 * jr < rows;
                 lo[jr] = rvalid ? (unsigned)ryh[jr] : 0u;
                 hi[jr] = rvalid ? (unsigned)(ryh[jr] >> 32) : 0u;
             }
@@ -1197,10 +1205,17 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_atb(AtbUnitsArg U, float* __restr
     if (c >= u.nparts) return;       // uniform per workgroup
     if (u.fast) {
         if (u.job.bf16) {
-            if (u.job.y_bf16) atb_fast_bf<true>(u, c, partial, Xl, Yl);
-            else atb_fast_bf<false>(u, c, partial, Xl, Yl);
+            const bool mk = u.job.xmask != nullptr;
+            if (u.job.y_bf16) {
+                if (mk) atb_fast_bf<true, true>(u, c, partial, Xl, Yl);
+                else atb_fast_bf<true, false>(u, c, partial, Xl, Yl);
+            } else {
+                if (mk) atb_fast_bf<false, true>(u, c, partial, Xl, Yl);
+                else atb_fast_bf<false, false>(u, c, partial, Xl, Yl);
+            }
         } else {
-            atb_fast(u, c, partial, Xl, Yl);
+            if (u.job.xmask) atb_fast<true>(u, c, partial, Xl, Yl);
+            else atb_fast<false>(u, c, partial, Xl, Yl);
         }
         return;
     }
@@ -1311,6 +1326,8 @@ static int atb_units(const EqdAtbJob* jobs, int njobs, std::vector<AtbUnit>& uni
             const bool xfast = J.M == 64 && J.rows > 0 && (J.ldx & 3) == 0 && al16(J.X) && (!J.xmask || al16(J.xmask));
             u.fast = !xfast ? 0 : (J.N - n0 >= 64 && (J.ldy & 3) == 0 && al16(J.Y)) ? 1 : (J.N - n0 >= 4 || n0 >= 4) ? 2 : 0;
             if (J.y_bf16 && u.fast && !J.bf16) u.fast = 0;      // (the fp32 fast body has no bf16 loader; not a shape the model makes)
+            // (the bf16 fast body addresses its operands with 32-bit byte offsets)
+            if (u.fast && J.bf16 && ((size_t)J.rows * J.ldx * 4 >= (1ull << 31) || (size_t)J.rows * J.ldy * 4 >= (1ull << 31))) u.fast = 0;
             units.push_back(u);
         }
     }
