@@ -380,6 +380,11 @@ struct EqdChainArg {
 // partial_rows (optional): rows of LayerNorm-backward partial sums the launch wrote (= its workgroups)
 int eqd_launch_rowchain(const EqdChainJob* jobs, int njobs, int rows, hipStream_t st, int* partial_rows = nullptr);
 size_t eqd_atb_batch_partial_bytes(int rows);
+// the end of the backward riding in the weight-gradient launches (eqd_node_kernels.hip)
+int eqd_atb_tail_wanted(const EqdLinJob* dh0_job, int n_atb_jobs);
+int eqd_atb_with_tail(const EqdAtbJob* jobs, int njobs, void* partial, size_t partial_bytes, hipStream_t st,
+                      const EqdLinJob* dh0_job, const EqdGraph* g, const float* dh0acc, const float* dh0b, int ld, int d_emb,
+                      float* demb, float* emb_partial, EqdRedList* defer);
 int eqd_rows_resident(int rows);      // 1: row chains of this size run on k_rowres (eqd_node_kernels.hip)
 int eqd_row_tiles(int rows);          // 16-row tiles per workgroup of the row kernels
 int eqd_rowchain_blocks(int rows);    // = workgroups of a row-chain launch = LayerNorm-backward partial rows

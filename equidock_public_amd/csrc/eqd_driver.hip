@@ -1043,12 +1043,18 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
         float* t = dXcur; dXcur = dXnext; dXnext = t;
     }
     {
+        // h[0] = h0 feeds layer 0 directly (dH of h[0]) as well as every layer's node_mlp (dh0acc).  DB5.5-sized batches: the
+        // chain d h[0] -> embedding gradient rides in the weight-gradient launches it does not depend on
         EqdLinJob j = dh_job(0);
-        RC(eqd_linear(&j, 1, st));
+        if (eqd_atb_tail_wanted(&j, (int)wjobs.size())) {
+            RC(eqd_atb_with_tail(wjobs.data(), (int)wjobs.size(), W.atb_part, W.atb_bytes, st, &j, g, W.dh0acc, dHof(0), D.d0,
+                                 m->d_emb, ggrad[G_EMB], W.emb_part, defer));
+        } else {
+            RC(eqd_linear(&j, 1, st));
+            RC(eqd_launch_embed_bwd(g, W.dh0acc, dHof(0), D.d0, m->d_emb, ggrad[G_EMB], W.emb_part, st, defer));
+            RC(eqd_atb(wjobs.data(), (int)wjobs.size(), W.atb_part, W.atb_bytes, st));
+        }
     }
-    // h[0] = h0 feeds layer 0 directly (dH of h[0]) as well as every layer's node_mlp (dh0acc)
-    RC(eqd_launch_embed_bwd(g, W.dh0acc, dHof(0), D.d0, m->d_emb, ggrad[G_EMB], W.emb_part, st, defer));
-    RC(eqd_atb(wjobs.data(), (int)wjobs.size(), W.atb_part, W.atb_bytes, st));
     // deferred LayerNorm / coordinate-MLP vector reductions, edge weight-gradient partials and embedding tables
     RC(eqd_launch_reduce_segments(defer->seg, defer->n, st));
     return EQD_OK;

@@ -1197,9 +1197,54 @@ __device__ __forceinline__ void atb_fast_bf(const AtbUnit& u, int c, float* __re
     }
 }
 
-__global__ __launch_bounds__(EQD_BLOCK) void k_atb(AtbUnitsArg U, float* __restrict__ partial) {
-    __shared__ __attribute__((aligned(16))) float Xl[ATB_ROWS * ATB_LS];
-    __shared__ __attribute__((aligned(16))) float Yl[ATB_ROWS * ATB_LS];
+// Tail work that rides in the two launches (DB5.5-sized batches, eqd_atb_with_tail): the end of the backward is the chain
+// d h[0] (one linear job) -> embedding gradient (k_embed_bwd's body), 20 us of small launches that the weight-gradient GEMMs do
+// not depend on.  As trailing workgroups of k_atb (the linear job: grid rows y >= y0) and of k_atb_reduce (the embedding
+// partials) they run beside them - a second BRANCH of the step graph for the same two kernels measured slower (the fork /
+// join of a replayed graph costs more than it hides).
+#define EMB_ROWS 16      /* nodes per block of the embedding backward (k_embed_bwd) */
+struct AtbLinTail {
+    EqdLinJob job;
+    int y0, nblk;      // first grid row of the tail, 16-row tiles of the job (0: no tail)
+};
+struct AtbEmbTail {
+    const int32_t* res;
+    const float *dh0, *dh0b;
+    float* partial;
+    int ld, n, d_emb, y0, nblk;      // nblk: blocks of EMB_ROWS nodes (0: no tail)
+};
+union alignas(16) AtbSmem {
+    struct {
+        float Xl[ATB_ROWS * ATB_LS];
+        float Yl[ATB_ROWS * ATB_LS];
+    } a;
+    struct {
+        LinSmem<1> sm;
+        EqdLinJob J;
+    } lin;
+    __device__ AtbSmem() {}
+};
+__global__ __launch_bounds__(EQD_BLOCK) void k_atb(AtbUnitsArg U, float* __restrict__ partial, AtbLinTail T) {
+    __shared__ AtbSmem S;
+    float* const Xl = S.a.Xl;
+    float* const Yl = S.a.Yl;
+    if (T.nblk > 0 && (int)blockIdx.y >= T.y0) {      // the ride-along linear job: k_linear<1>'s body on tile b
+        const int b = ((int)blockIdx.y - T.y0) * (int)gridDim.x + (int)blockIdx.x;
+        if (b >= T.nblk) return;
+#ifdef EQD_HOSTSIM
+        for (int i = threadIdx.x; i < (int)(sizeof(EqdLinJob) / 4); i += blockDim.x) ((int*)&S.lin.J)[i] = ((const int*)&T.job)[i];
+#else
+        // (kernarg segment: U, the 8-byte `partial`, then T - copied with vector loads like every job descriptor)
+        static_assert(alignof(AtbLinTail) == 8 && sizeof(AtbUnitsArg) % 8 == 0, "kernarg layout of k_atb");
+        kernarg_to_lds(S.lin.J, EQD_KERNARG_PTR(U), (int)(sizeof(AtbUnitsArg) + sizeof(float*) + offsetof(AtbLinTail, job)));
+#endif
+        __syncthreads();
+        LinRegs<1> RA;
+        const JobW W = jobw_load(&S.lin.J, (int)(sizeof(EqdLinJob) / 4), threadIdx.x & 63);
+        if (S.lin.J.bf16) linear_tile<1, true>(S.lin.J, W, false, nullptr, -1, S.lin.sm, nullptr, 16 * b, RA, false, false, W);
+        else linear_tile<1, false>(S.lin.J, W, false, nullptr, -1, S.lin.sm, nullptr, 16 * b, RA, false, false, W);
+        return;
+    }
     const AtbUnit& u = U.u[blockIdx.y];
     const int c = blockIdx.x;
     if (c >= u.nparts) return;       // uniform per workgroup
@@ -1261,8 +1306,17 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_atb(AtbUnitsArg U, float* __restr
 // earlier one-element-per-thread kernel, which issued 4 x the load instructions (26.9 us for the ~100 units of a
 // config-B pass in one launch).
 #define ATB_RED_ELEMS 256
-__global__ __launch_bounds__(1024) void k_atb_reduce(AtbUnitsArg U, const float* __restrict__ partial) {
+__device__ __forceinline__ void embed_bwd_body(float* __restrict__ acc, const int32_t* __restrict__ res,
+                                               const float* __restrict__ dh0, const float* __restrict__ dh0b, int ld, int n,
+                                               int d_emb, float* __restrict__ partial, int blk);
+__global__ __launch_bounds__(1024) void k_atb_reduce(AtbUnitsArg U, const float* __restrict__ partial, AtbEmbTail E) {
     __shared__ __attribute__((aligned(16))) float red[16][ATB_RED_ELEMS + 4];
+    if (E.nblk > 0 && (int)blockIdx.y >= E.y0) {      // the ride-along embedding partials: k_embed_bwd's body on block b
+        const int b = ((int)blockIdx.y - E.y0) * (int)gridDim.x + (int)blockIdx.x;
+        if (b >= E.nblk || threadIdx.x >= 64) return;      // (one wave works; a finished wave is not waited for)
+        embed_bwd_body(&red[0][0], E.res, E.dh0, E.dh0b, E.ld, E.n, E.d_emb, E.partial, b);
+        return;
+    }
     const AtbUnit& u = U.u[blockIdx.y];
     const EqdAtbJob& J = u.job;
     const int t = threadIdx.x, cg = t & 63, pl = t >> 6;       // element group cg (4 elements), part lane pl
@@ -1392,11 +1446,12 @@ extern "C" size_t eqd_atb_partial_bytes(const EqdAtbJob* jobs, int njobs) {
     return (size_t)worst * sizeof(float) + 256;
 }
 
-extern "C" int eqd_atb(const EqdAtbJob* jobs, int njobs, void* partial, size_t partial_bytes, void* stream) {
+static int atb_launch_all(const EqdAtbJob* jobs, int njobs, void* partial, size_t partial_bytes, hipStream_t st,
+                          const EqdLinJob* lin_tail, const AtbEmbTail* emb_tail) {
     std::vector<AtbUnit> units;
     int rc = atb_units(jobs, njobs, units);
     if (rc) return rc;
-    hipStream_t st = (hipStream_t)stream;
+    bool tails_done = false;
     for (size_t first = 0; first < units.size();) {
         long long f = 0;
         const int n = atb_next_batch(units, first, &f);
@@ -1411,17 +1466,74 @@ extern "C" int eqd_atb(const EqdAtbJob* jobs, int njobs, void* partial, size_t p
             arg.u[i] = units[first + i];
             if (arg.u[i].nparts > maxparts) maxparts = arg.u[i].nparts;
         }
+        // the tails ride in the FIRST batch's two launches (the linear job in k_atb, the embedding partials - which read its
+        // output - in the k_atb_reduce behind it)
+        AtbLinTail LT;
+        AtbEmbTail ET;
+        memset(&LT, 0, sizeof(LT));
+        memset(&ET, 0, sizeof(ET));
+        int ly = 0, ey = 0;
+        const int redx = (ATB_PSTRIDE + ATB_RED_ELEMS - 1) / ATB_RED_ELEMS;
+        if (!tails_done && maxparts > 0) {
+            if (lin_tail) {
+                LT.job = *lin_tail;
+                LT.y0 = n;
+                LT.nblk = (lin_tail->rows + 15) / 16;
+                ly = (LT.nblk + maxparts - 1) / maxparts;
+            }
+            if (emb_tail) {
+                ET = *emb_tail;
+                ET.y0 = n;
+                ey = (ET.nblk + redx - 1) / redx;
+            }
+            tails_done = true;
+        }
         if (maxparts > 0) {
-            hipLaunchKernelGGL(k_atb, dim3(maxparts, n), dim3(EQD_BLOCK), 0, st, arg, (float*)partial);
+            hipLaunchKernelGGL(k_atb, dim3(maxparts, n + ly), dim3(EQD_BLOCK), 0, st, arg, (float*)partial, LT);
             rc = eqd_check_launch("k_atb");
             if (rc) return rc;
         }
-        hipLaunchKernelGGL(k_atb_reduce, dim3((ATB_PSTRIDE + ATB_RED_ELEMS - 1) / ATB_RED_ELEMS, n), dim3(1024), 0, st, arg,
-                           (const float*)partial);
+        hipLaunchKernelGGL(k_atb_reduce, dim3(redx, n + ey), dim3(1024), 0, st, arg, (const float*)partial, ET);
         rc = eqd_check_launch("k_atb_reduce");
         if (rc) return rc;
         first += n;
     }
+    if ((lin_tail || emb_tail) && !tails_done) {
+        eqd_set_error("eqd_atb_with_tail: no weight-gradient launch to ride in");
+        return EQD_ERR_SHAPE;
+    }
+    return EQD_OK;
+}
+extern "C" int eqd_atb(const EqdAtbJob* jobs, int njobs, void* partial, size_t partial_bytes, void* stream) {
+    return atb_launch_all(jobs, njobs, partial, partial_bytes, (hipStream_t)stream, nullptr, nullptr);
+}
+// 1 when `dh0_job` (the gradient w.r.t. h[0], a general linear job) would run on k_linear's one-tile body anyway - the form
+// that rides in k_atb: small batches (no LDS-resident-weights kernel, one row tile per workgroup)
+int eqd_atb_tail_wanted(const EqdLinJob* dh0_job, int n_atb_jobs) {
+    const char* f = eqd_tunable("EQD_ATB_TAIL");      // 0: keep the separate launches (A/B runs)
+    if (f && f[0] == '0' && f[1] == 0) return 0;
+    if (!dh0_job || n_atb_jobs <= 0 || dh0_job->rows <= 0) return 0;
+    if (rw_mode(dh0_job->rows) != 0 || linear_row_tiles(dh0_job->rows) != 1) return 0;
+    return dh0_job->M >= 4 && dh0_job->M <= 80 && dh0_job->nsrc >= 1 && dh0_job->nsrc <= EQD_MAX_SRC && dh0_job->Y != nullptr &&
+           lin_check_sources(*dh0_job) == EQD_OK;
+}
+// eqd_atb + the end-of-backward chain riding in its launches: dh0_job in k_atb, then k_embed_bwd's work (inputs dh0acc / dh0b
+// = dh0_job's output, partials -> `emb_partial`, reduced later through `defer` like eqd_launch_embed_bwd's)
+int eqd_atb_with_tail(const EqdAtbJob* jobs, int njobs, void* partial, size_t partial_bytes, hipStream_t st,
+                      const EqdLinJob* dh0_job, const EqdGraph* g, const float* dh0acc, const float* dh0b, int ld, int d_emb,
+                      float* demb, float* emb_partial, EqdRedList* defer) {
+    if (d_emb > 64 || !defer || defer->n + 1 > 512) {
+        eqd_set_error("eqd_atb_with_tail: embedding width %d > 64, or no room on the deferred-reduction list", d_emb);
+        return EQD_ERR_UNSUPPORTED;
+    }
+    AtbEmbTail ET;
+    memset(&ET, 0, sizeof(ET));
+    ET.res = g->res_id; ET.dh0 = dh0acc; ET.dh0b = dh0b; ET.partial = emb_partial;
+    ET.ld = ld; ET.n = g->n_nodes; ET.d_emb = d_emb;
+    ET.nblk = (g->n_nodes + EMB_ROWS - 1) / EMB_ROWS;
+    int rc = atb_launch_all(jobs, njobs, partial, partial_bytes, st, dh0_job, &ET);
+    if (rc) return rc;
+    defer->seg[defer->n++] = EqdRedSeg{emb_partial, ET.nblk, 21 * d_emb, 21 * d_emb, demb, 0, 0, 0};
     return EQD_OK;
 }
 
@@ -1553,14 +1665,12 @@ int eqd_launch_embed_fwd(const EqdGraph* g, const float* emb, int d_emb, int use
 
 // Embedding backward: per block of 16 nodes, thread c owns column c -> deterministic per-type sums.  All
 // loads of the block are in flight together; the (small) per-block tables are summed by k_reduce_segments.
-#define EMB_ROWS 16
-__global__ __launch_bounds__(64) void k_embed_bwd(const int32_t* __restrict__ res, const float* __restrict__ dh0,
-                                                  const float* __restrict__ dh0b, int ld, int n, int d_emb,
-                                                  float* __restrict__ partial) {
-    __shared__ float acc[21 * 64];
-    const int c = threadIdx.x;  // 64 threads
+__device__ __forceinline__ void embed_bwd_body(float* __restrict__ acc, const int32_t* __restrict__ res,
+                                               const float* __restrict__ dh0, const float* __restrict__ dh0b, int ld, int n,
+                                               int d_emb, float* __restrict__ partial, int blk) {
+    const int c = threadIdx.x;  // 64 threads (one wave: its LDS accesses are ordered)
     for (int t = 0; t < 21; ++t) acc[t * 64 + c] = 0.f;
-    const int i0 = blockIdx.x * EMB_ROWS;
+    const int i0 = blk * EMB_ROWS;
     int rid[EMB_ROWS];
     float v[EMB_ROWS];
 #pragma unroll
@@ -1573,7 +1683,13 @@ __global__ __launch_bounds__(64) void k_embed_bwd(const int32_t* __restrict__ re
 #pragma unroll
     for (int r = 0; r < EMB_ROWS; ++r) acc[rid[r] * 64 + c] += v[r];
     for (int t = 0; t < 21; ++t)
-        if (c < d_emb) partial[((size_t)blockIdx.x * 21 + t) * d_emb + c] = acc[t * 64 + c];
+        if (c < d_emb) partial[((size_t)blk * 21 + t) * d_emb + c] = acc[t * 64 + c];
+}
+__global__ __launch_bounds__(64) void k_embed_bwd(const int32_t* __restrict__ res, const float* __restrict__ dh0,
+                                                  const float* __restrict__ dh0b, int ld, int n, int d_emb,
+                                                  float* __restrict__ partial) {
+    __shared__ float acc[21 * 64];
+    embed_bwd_body(acc, res, dh0, dh0b, ld, n, d_emb, partial, (int)blockIdx.x);
 }
 size_t eqd_embed_bwd_partial_floats(const EqdGraph* g, int d_emb) {
     return (size_t)((g->n_nodes + EMB_ROWS - 1) / EMB_ROWS) * 21 * d_emb;
