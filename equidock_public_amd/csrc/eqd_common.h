@@ -385,7 +385,8 @@ int eqd_atb_tail_wanted(const EqdLinJob* dh0_job, int n_atb_jobs);
 int eqd_atb_with_tail(const EqdAtbJob* jobs, int njobs, void* partial, size_t partial_bytes, hipStream_t st,
                       const EqdLinJob* dh0_job, const EqdGraph* g, const float* dh0acc, const float* dh0b, int ld, int d_emb,
                       float* demb, float* emb_partial, EqdRedList* defer);
-int eqd_rows_resident(int rows);      // 1: row chains of this size run on k_rowres (eqd_node_kernels.hip)
+int eqd_rows_resident(int rows);
+int eqd_rowres80_on();                // 1 unless EQD_ROWRES80=0 (the first layer's bf16 forward chains on k_rowres80)      // 1: row chains of this size run on k_rowres (eqd_node_kernels.hip)
 int eqd_row_tiles(int rows);          // 16-row tiles per workgroup of the row kernels
 int eqd_rowchain_blocks(int rows);    // = workgroups of a row-chain launch = LayerNorm-backward partial rows
 

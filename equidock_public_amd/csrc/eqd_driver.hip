@@ -749,8 +749,10 @@ extern "C" int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const
             // pass over the h rows, less per layer.  (With the four-wave kernels of small batches this was measured
             // slower: 46 vs 33 us, the five projections then run one after the other instead of side by side; layer 0's
             // 69-wide chain stays on those kernels at every size, so it never carries projections.)
-            proj_in_chain = l + 1 < D.L && d == 64 && D.d_in(l + 1) == 64 && D.dh == 64 && eqd_rows_resident(N) &&
-                            2 + (m->cross_msgs ? 5 : 2) <= EQD_CHAIN_MAXJOBS;
+            // (round 5: in bf16 mode the 69-wide first layer's chain runs on k_rowres80 at these sizes and carries layer 1's
+            //  projections the same way)
+            proj_in_chain = l + 1 < D.L && (d == 64 || (m->storage_bf16 && eqd_rowres80_on())) && D.d_in(l + 1) == 64 &&
+                            D.dh == 64 && eqd_rows_resident(N) && 2 + (m->cross_msgs ? 5 : 2) <= EQD_CHAIN_MAXJOBS;
             if (proj_in_chain) {
                 cj[1].out_local = 1;
                 nj += node_pre_jobs(l + 1, S.h[l + 1], 1, cj + 2);

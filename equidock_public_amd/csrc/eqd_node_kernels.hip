@@ -7,6 +7,7 @@
 #include "eqd_linear_inl.h"
 #include "eqd_rowwave_inl.h"
 #include "eqd_rowres_inl.h"
+#include "eqd_rowres80_inl.h"
 #include "eqd_gather_inl.h"
 
 #include <mutex>
@@ -614,6 +615,49 @@ static bool rw_eligible(const EqdChainJob* jobs, int njobs, int rows) {
     }
     return true;
 }
+// k_rowres80 (eqd_rowres80_inl.h): the 69-wide first layer's FORWARD jobs in bf16 mode at sizes where the row kernels keep
+// their weights in LDS.  EQD_ROWRES80=0 keeps them on the four-wave kernels (A/B runs, tests of both forms).
+int eqd_rowres80_on() {
+    const char* f = eqd_tunable("EQD_ROWRES80");
+    return !(f && f[0] == '0' && f[1] == 0);
+}
+static bool rw80_eligible(const EqdChainJob* jobs, int njobs, int rows) {
+    if (njobs <= 0 || rows <= 0 || rw_mode(rows) != 2 || !eqd_rowres80_on()) return false;
+    bool wide = false;
+    for (int i = 0; i < njobs; ++i) {
+        const EqdChainJob& C = jobs[i];
+        const EqdLinJob& J = C.lin;
+        if (!J.bf16 || C.type != 0 || J.rows != rows || J.M < 4 || J.M > 80 || C.out_local >= LIN_LOCALS) return false;
+        if (J.nsrc <= 0 || J.nsrc > EQD_MAX_SRC || (J.ln_g && !J.ln_b)) return false;
+        if (J.Yb && ((J.ldyb & 3) != 0 || (((uintptr_t)J.Yb) & 7) != 0)) return false;
+        wide = wide || J.M > 64;
+        for (int s = 0; s < J.nsrc; ++s) {
+            const EqdLinSrc& S = J.s[s];
+            const bool local = C.src_local[s] >= 0;
+            if (!S.W || S.w_cs != 1 || S.mask) return false;      // k-contiguous weights, no masks: forward jobs
+            if (local ? (C.src_local[s] >= LIN_LOCALS || S.K < 64 || S.K > 80) : (!S.X || S.K < 64 || S.K > 80)) return false;
+            wide = wide || S.K > 64;
+        }
+    }
+    if (!wide) return false;      // (plain 64-wide chains: k_rowres)
+    // no global source that an earlier job of the chain writes (rows are fetched ahead), one live intermediate tile
+    for (int i = 0; i < njobs; ++i)
+        for (int s = 0; s < jobs[i].lin.nsrc; ++s) {
+            if (jobs[i].src_local[s] >= 0) continue;
+            for (int m = 0; m < i; ++m) {
+                const float* outs[2] = {jobs[m].lin.Y, jobs[m].lin.pre_ln};
+                for (int q = 0; q < 2; ++q)
+                    if (outs[q] && outs[q] == jobs[i].lin.s[s].X) return false;
+            }
+        }
+    int cur = -1;
+    for (int i = 0; i < njobs; ++i) {
+        for (int s = 0; s < jobs[i].lin.nsrc; ++s)
+            if (jobs[i].src_local[s] >= 0 && jobs[i].src_local[s] != cur) return false;
+        if (jobs[i].out_local >= 0) cur = jobs[i].out_local;
+    }
+    return true;
+}
 static void chain_links(EqdChainArg& arg, const EqdChainJob* jobs, int njobs) {
     // prefetch_next[i]: the next linear job n whose first step may be loaded before job i's epilogue: its first
     // source is an LDS tile, or global data that none of the jobs i .. n-1 writes
@@ -712,6 +756,12 @@ int eqd_launch_rowchain(const EqdChainJob* jobs, int njobs, int rows, hipStream_
             return EQD_ERR_SHAPE;
         }
     const bool bf = njobs > 0 && jobs[0].lin.bf16;     // one arithmetic mode per launch
+    if (!rw_eligible(jobs, njobs, rows) && rw80_eligible(jobs, njobs, rows)) {      // the first layer's forward chain, bf16
+        if (partial_rows) *partial_rows = 0;      // (no LayerNorm-backward job in such a chain)
+        const int tps = rr_tiles_per_wg(rows);
+        hipLaunchKernelGGL(k_rowres80, dim3(rr_blocks(rows)), dim3(64 * RR_WAVES), 0, st, arg, tps);
+        return eqd_check_launch("k_rowres");
+    }
     if (rw_eligible(jobs, njobs, rows)) {
         if (partial_rows) *partial_rows = rw_launch_blocks(jobs, njobs, rows);
         return launch_rowwave(arg, rows, bf, st);
@@ -750,6 +800,14 @@ extern "C" int eqd_linear(const EqdLinJob* jobs, int njobs, void* stream) {
             for (int s = 0; s < EQD_MAX_SRC; ++s) C.src_local[s] = -1;
             C.out_local = -1;
             ok = (jobs[i].Y != nullptr || jobs[i].Yb != nullptr) && jobs[i].rows == jobs[0].rows;
+        }
+        if (ok && !rw_eligible(carg.j, njobs, jobs[0].rows) && rw80_eligible(carg.j, njobs, jobs[0].rows)) {
+            for (int i = 0; i < njobs; ++i)
+                if (int e = lin_check_sources(jobs[i])) return e;
+            carg.njobs = njobs;
+            const int rows80 = jobs[0].rows, tps = rr_tiles_per_wg(rows80);
+            hipLaunchKernelGGL(k_rowres80, dim3(rr_blocks(rows80)), dim3(64 * RR_WAVES), 0, st, carg, tps);
+            return eqd_check_launch("k_rowres");
         }
         if (ok && rw_eligible(carg.j, njobs, jobs[0].rows)) {
             for (int i = 0; i < njobs; ++i)

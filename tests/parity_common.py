@@ -1461,6 +1461,97 @@ def check_bf16_storage_ops(dev):
         close(res[1][0], X.to(torch.bfloat16).to(torch.float32).t() @ Yexact, tol=2e-4, what='A^T B, bf16 Y')
 
 
+def check_first_layer_rowres80(dev, rows=333):
+    """The 69-wide first layer's forward jobs in bf16 mode on the kernel with LDS-resident weights (k_rowres80, taken at large
+    sizes; forced here with EQD_ROWWAVE=2) and on the four-wave kernels (EQD_ROWRES80=0): the node update (eqd_node_update_fwd
+    with d_in = 69: node_mlp.0 over four sources + LeakyReLU + LayerNorm(69), node_mlp.4 from the LDS tile) and the projection
+    group (five jobs from the 69-wide h: 64-wide P / Q, 69-wide q / k / v zero-padded to 80) against torch with the mode's
+    rounding points (every GEMM input rounded to bf16, fp32 accumulate)."""
+    import os
+    torch.manual_seed(12)
+    bf = lambda t: t.to(torch.bfloat16).to(torch.float32)      # noqa: E731
+    d, d0, dout, ldc = 69, 69, 64, 80
+    ldn = d0 + 2 * d + 64
+    mk = lambda *sh: torch.randn(*sh) * 0.5      # noqa: E731
+    h, am, h0 = mk(rows, d), mk(rows, 64), mk(rows, d0)
+    ac = torch.zeros(rows, ldc)
+    ac[:, :d] = mk(rows, d)
+    Wn1, bn1 = mk(d, ldn) * 0.3, mk(d)
+    lg, lb = 1.0 + 0.2 * torch.randn(d), 0.2 * torch.randn(d)
+    Wn2, bn2 = mk(dout, d) * 0.3, mk(dout)
+    z = F.leaky_relu(F.linear(bf(torch.cat([h, am, ac[:, :d], h0], 1)), bf(Wn1), bn1), 0.01)
+    a1n_ref = F.layer_norm(z, (d,), lg, lb, 1e-5)
+    u_ref = F.linear(bf(a1n_ref), bf(Wn2), bn2)
+    Wp = [mk(64, d) * 0.3, mk(64, d) * 0.3, mk(d, d) * 0.3, mk(d, d) * 0.3, mk(d, d) * 0.3]
+    bq = mk(64)
+    old = {k: os.environ.get(k) for k in ('EQD_ROWWAVE', 'EQD_ROWRES80')}
+    try:
+        for form in ('rowres80', 'four-wave'):
+            os.environ['EQD_ROWWAVE'] = '2'
+            if form == 'four-wave':
+                os.environ['EQD_ROWRES80'] = '0'
+            else:
+                os.environ.pop('EQD_ROWRES80', None)
+            L.reload_tunables()
+            dd = [t.to(dev).contiguous() for t in (h, am, ac, h0, Wn1, bn1, lg, lb, Wn2, bn2)]
+            prm = L.EqdNodeUpdateParams()
+            prm.d_in, prm.d0, prm.d_out, prm.ld_cross = d, d0, dout, ldc
+            prm.Wn1, prm.bn1, prm.ln_g, prm.ln_b, prm.Wn2, prm.bn2 = (t.data_ptr() for t in dd[4:])
+            prm.skip_weight_h, prm.slope, prm.ln_eps, prm.bf16, prm.drop_mul = 0.5, 0.01, 1e-5, 1, None
+            f = dict(dtype=torch.float32, device=dev)
+            h_out, y_act, a1n = torch.zeros(rows, dout, **f), torch.zeros(rows, d, **f), torch.zeros(rows, d, **f)
+            names = launch_names(dev, lambda: L.check(lib().eqd_node_update_fwd(rows, C.byref(prm), P(dd[0]), P(dd[1]), P(dd[2]),
+                                                                                P(dd[3]), P(h_out), P(y_act), P(a1n), st(dev))))
+            assert ('k_rowres' in names) == (form == 'rowres80'), (form, names)
+            close(y_act, z, tol=1e-4, what=f'first layer ({form}): node_mlp.0 activation')
+            close(a1n, a1n_ref, tol=1e-4, what=f'first layer ({form}): LayerNorm(69) output')
+            close(h_out, u_ref, tol=5e-3, what=f'first layer ({form}): node update')      # (bf16 flips of a1n: 2^-9 steps)
+            # projection group: P, Q (64 wide, Q with bias), q, k (LeakyReLU), v, 69 wide, rows padded to 80 with zeros
+            hd = h.to(dev).contiguous()
+            Wd = [w.to(dev).contiguous() for w in Wp]
+            bqd = bq.to(dev)
+            outs = [torch.full((rows, 64 if i < 2 else 80), float('nan'), **f) for i in range(5)]
+            jobs = (L.EqdLinJob * 5)()
+            for i in range(5):
+                J = jobs[i]
+                M = 64 if i < 2 else d
+                J.s[0].X, J.s[0].ldx, J.s[0].K, J.s[0].W, J.s[0].w_rs, J.s[0].w_cs = hd.data_ptr(), d, d, Wd[i].data_ptr(), d, 1
+                J.nsrc, J.M, J.act, J.rows = 1, M, int(i in (2, 3)), rows
+                J.bias = bqd.data_ptr() if i == 1 else None
+                J.alpha, J.beta, J.slope, J.ln_eps, J.bf16 = 1.0, 0.0, 0.01, 1e-5, 1
+                J.Y, J.ldy = outs[i].data_ptr(), outs[i].shape[1]
+                J.pad_to = 80 if i >= 2 else 0
+            names = launch_names(dev, lambda: L.check(lib().eqd_linear(jobs, 5, st(dev))))
+            assert ('k_rowres' in names) == (form == 'rowres80'), (form, names)
+            for i in range(5):
+                ref = F.linear(bf(h), bf(Wp[i]), bq if i == 1 else None)
+                if i in (2, 3):
+                    ref = F.leaky_relu(ref, 0.01)
+                M = ref.shape[1]
+                close(outs[i][:, :M], ref, tol=1e-4, what=f'first layer ({form}): projection {i}')
+                if M < outs[i].shape[1]:
+                    assert float(outs[i][:, M:].abs().max()) == 0.0, 'padding columns must be zeros'
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        L.reload_tunables()
+
+
+def launch_names(dev, fn):
+    """kernel names the library launches while fn() runs (eqd_profile_*)"""
+    sync(dev)
+    L.check(lib().eqd_profile_begin(st(dev), 256))
+    try:
+        fn()
+    finally:
+        n = lib().eqd_profile_end()
+    sync(dev)
+    return [lib().eqd_profile_name(i).decode() for i in range(n)]
+
+
 def check_bf16_storage_model(dev, monkeypatch):
     """bf16 storage of the saved state: with the dS hand-off form of the attention backward (what large batches run; forced
     here) the state a bf16-mode forward keeps for its backward is >= 24 % smaller than the fp32 mode's (a1n, aggr_msg, h and

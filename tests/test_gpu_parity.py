@@ -180,6 +180,13 @@ def test_model_forked_attention_stream(dev, monkeypatch):
     pc.check_model_case(dev, 'D_degraded3')
 
 
+def test_first_layer_on_rowres80(dev):
+    """the 69-wide first layer's forward jobs (bf16 mode) on k_rowres80 and on the four-wave kernels vs torch with the mode's rounding points"""
+    from tests import parity_common as pc
+    pc.check_first_layer_rowres80(dev, rows=333)
+    pc.check_first_layer_rowres80(dev, rows=5000)
+
+
 def test_bf16_storage_operators(dev):
     """EqdLinJob.Yb (bf16 copy == RNE of the fp32 output, every epilogue) and EqdAtbJob.y_bf16 (same bits as the fp32 Y)"""
     from tests import parity_common as pc

@@ -143,6 +143,18 @@ def test_rowres_tiles_per_workgroup(tps, monkeypatch):
     pc.check_linear(DEV)
     pc.check_linear_atb_bf16(DEV)
     pc.check_model_case(DEV, 'D_degraded3')
+    pc.check_first_layer_rowres80(DEV, rows=16 * int(tps) + 5)      # (k_rowres80: one / two tile slots, a ragged last tile)
+
+
+def test_model_bf16_on_resident_row_kernels(monkeypatch):
+    """bf16 mode with every row chain on the LDS-resident-weights kernels (what large batches run): k_rowres for the 64-wide
+    layers, k_rowres80 for the first layer's forward chain (carrying layer 1's projections) and projection group"""
+    monkeypatch.setenv('EQD_ROWWAVE', '2')
+    monkeypatch.setenv('EQD_ROWRES_TPS', '3')
+    pc.check_model_bf16(DEV, 'D_degraded3')
+    pc.check_model_bf16_states(DEV, [(60, 75), (90, 48), (120, 100)], layers=4, seed=5, pair_seed=7, faithful=True, what='sim, resident')
+    names = pc.launch_names_of_a_step(DEV, 'D_degraded3')
+    assert 'k_rowres' in names
 
 
 def test_model_bf16_mode():
@@ -152,6 +164,10 @@ def test_model_bf16_mode():
 def test_model_forked_attention_stream(monkeypatch):
     monkeypatch.setenv('EQD_FORK', '1')
     pc.check_model_case(DEV, 'D_degraded3')
+
+
+def test_first_layer_on_rowres80():
+    pc.check_first_layer_rowres80(DEV, rows=77)
 
 
 def test_bf16_storage_operators():
