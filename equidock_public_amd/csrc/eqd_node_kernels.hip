@@ -624,17 +624,23 @@ int eqd_rowres80_on() {
 static bool rw80_eligible(const EqdChainJob* jobs, int njobs, int rows) {
     if (njobs <= 0 || rows <= 0 || rw_mode(rows) != 2 || !eqd_rowres80_on()) return false;
     bool wide = false;
+    if (jobs[0].type != 0) return false;      // (the kernel stages the first LINEAR job's weights in its prologue)
     for (int i = 0; i < njobs; ++i) {
         const EqdChainJob& C = jobs[i];
         const EqdLinJob& J = C.lin;
-        if (!J.bf16 || C.type != 0 || J.rows != rows || J.M < 4 || J.M > 80 || C.out_local >= LIN_LOCALS) return false;
+        if (!J.bf16 || J.rows != rows || J.M < 4 || J.M > 80 || C.out_local >= LIN_LOCALS) return false;
+        wide = wide || J.M > 64;
+        if (C.type != 0) {      // LeakyReLU -> LayerNorm backward: the wave's tile in, the wave's tile out
+            if (C.src_local[0] < 0 || C.src_local[0] >= LIN_LOCALS || C.out_local < 0 || !J.s[0].X || !J.ln_g || !C.aux) return false;
+            continue;
+        }
         if (J.nsrc <= 0 || J.nsrc > EQD_MAX_SRC || (J.ln_g && !J.ln_b)) return false;
         if (J.Yb && ((J.ldyb & 3) != 0 || (((uintptr_t)J.Yb) & 7) != 0)) return false;
-        wide = wide || J.M > 64;
         for (int s = 0; s < J.nsrc; ++s) {
             const EqdLinSrc& S = J.s[s];
             const bool local = C.src_local[s] >= 0;
-            if (!S.W || S.w_cs != 1 || S.mask) return false;      // k-contiguous weights, no masks: forward jobs
+            if (!S.W || S.mask) return false;                       // no masked sources (none in the first layer's chains)
+            if (S.w_cs != 1 && S.w_rs != 1) return false;           // one unit stride: either orientation is restaged as [m][k]
             if (local ? (C.src_local[s] >= LIN_LOCALS || S.K < 64 || S.K > 80) : (!S.X || S.K < 64 || S.K > 80)) return false;
             wide = wide || S.K > 64;
         }
@@ -652,7 +658,8 @@ static bool rw80_eligible(const EqdChainJob* jobs, int njobs, int rows) {
         }
     int cur = -1;
     for (int i = 0; i < njobs; ++i) {
-        for (int s = 0; s < jobs[i].lin.nsrc; ++s)
+        const int ns = jobs[i].type != 0 ? 1 : jobs[i].lin.nsrc;
+        for (int s = 0; s < ns; ++s)
             if (jobs[i].src_local[s] >= 0 && jobs[i].src_local[s] != cur) return false;
         if (jobs[i].out_local >= 0) cur = jobs[i].out_local;
     }
@@ -757,7 +764,7 @@ int eqd_launch_rowchain(const EqdChainJob* jobs, int njobs, int rows, hipStream_
         }
     const bool bf = njobs > 0 && jobs[0].lin.bf16;     // one arithmetic mode per launch
     if (!rw_eligible(jobs, njobs, rows) && rw80_eligible(jobs, njobs, rows)) {      // the first layer's forward chain, bf16
-        if (partial_rows) *partial_rows = 0;      // (no LayerNorm-backward job in such a chain)
+        if (partial_rows) *partial_rows = rr_blocks(rows);      // (LayerNorm-backward partial sums: one row per workgroup)
         const int tps = rr_tiles_per_wg(rows);
         hipLaunchKernelGGL(k_rowres80, dim3(rr_blocks(rows)), dim3(64 * RR_WAVES), 0, st, arg, tps);
         return eqd_check_launch("k_rowres");

@@ -4,10 +4,12 @@
 // node-update chain ran on the four-wave kernels (k_linear<2> 77 us, k_rowchain 135 us per launch against 36 us for a 64-wide
 // layer's chain on k_rowres) because k_rowres takes 64-wide outputs only.
 //
-// Scope (rw80_eligible, host): bf16 mode; LINEAR jobs only (no LayerNorm-backward job: the backward chain of the first layer
-// stays on k_rowchain); k-contiguous weights (w_cs == 1: every forward Linear); outputs M <= 80; global sources 64..80 wide
-// without mask, LDS-resident sources (the tile written last) up to 80 wide.  Differences to k_rowres:
-//   * weights staged as bf16 [80][88] (rows >= M and columns >= K zero), four 16-byte loads per thread and source;
+// Scope (rw80_eligible, host): bf16 mode; outputs M <= 80; global sources 64..80 wide without mask, LDS-resident sources (the
+// tile written last) up to 80 wide; weights of either orientation (k-contiguous: the forward Linears; m-contiguous: the
+// backward's dX = dY W); LayerNorm-backward jobs up to 80 features - i.e. the first layer's projection group, node-update
+// chain and backward chain.  Differences to k_rowres:
+//   * weights staged as bf16 [80][88] (rows >= M and columns >= K zero) whatever their orientation in memory, four 16-byte
+//     loads per thread and source;
 //   * five accumulator blocks per tile slot; a job with M <= 64 uses four (wave-uniform);
 //   * tiles of 84 floats per row (80 + 4: 16-byte aligned rows, 21 l15 + g covers the banks), columns >= M written as zeros so
 //     that a consumer's remainder chunk (columns 64..79) needs no mask;
@@ -23,29 +25,43 @@
 struct Rr80Smem {
     unsigned short Wl[2][R8_WROWS * R8_KP];
     float tile[RR_WAVES][RR_TMAX][16 * R8_TS];
+    float red[RR_WAVES][256];      // LayerNorm-backward partial sums of a wave's rows: [d gamma 0..127 | d beta 128..255]
 };
 
 struct Rr80Stage {
     f32x4 v[4];
 };
-// W[m][k], k contiguous (rows may be unaligned: 69-float rows): idx -> (m, 4-column group c4 of 20)
+// k-contiguous W[m][k] (w_cs == 1; rows may be unaligned: 69-float rows): idx -> (m, 4-column group c4 of 20 along k);
+// m-contiguous W[k][m] (w_rs == 1): idx -> (k, 4-column group c4 of 20 along m), transposed by the staging stores
 __device__ __forceinline__ void rr80_stage_load(const EqdLinSrc S, int M, int t, Rr80Stage& R) {
+    const bool tp = S.w_cs != 1;
+    const int nrow = tp ? S.K : M, ncol = tp ? M : S.K;      // rows / columns of the matrix as it lies in memory
+    const int stride = tp ? S.w_cs : S.w_rs;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int idx = t + 64 * RR_WAVES * j;
-        const int m = idx / 20, c4 = idx - m * 20;
-        const int mm = m < M ? m : M - 1;
-        R.v[j] = ld4u_raw(S.W + (size_t)mm * S.w_rs + 4 * c4, idx < R8_WROWS * 20 ? S.K - 4 * c4 : 0, S.W);
+        const int r = idx / 20, c4 = idx - r * 20;
+        const int rr = r < nrow ? r : nrow - 1;
+        R.v[j] = ld4u_raw(S.W + (size_t)rr * stride + 4 * c4, idx < R8_WROWS * 20 ? ncol - 4 * c4 : 0, S.W);
     }
 }
 __device__ __forceinline__ void rr80_stage_store(const EqdLinSrc S, int M, int t, const Rr80Stage& R, unsigned short* Wl) {
+    const bool tp = S.w_cs != 1;
+    const int nrow = tp ? S.K : M, ncol = tp ? M : S.K;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int idx = t + 64 * RR_WAVES * j;
-        const int m = idx / 20, c4 = idx - m * 20;
+        const int r = idx / 20, c4 = idx - r * 20;
         if (idx < R8_WROWS * 20) {
-            const float4 f = ld4u_fix(R.v[j], m < M ? S.K - 4 * c4 : 0);      // zeros beyond K and for rows >= M
-            *(s16x4*)&Wl[m * R8_KP + 4 * c4] = pack_bf4(f.x, f.y, f.z, f.w);
+            const float4 f = ld4u_fix(R.v[j], r < nrow ? ncol - 4 * c4 : 0);      // zeros beyond the matrix
+            if (!tp) {
+                *(s16x4*)&Wl[r * R8_KP + 4 * c4] = pack_bf4(f.x, f.y, f.z, f.w);
+            } else {      // (r = k, columns 4 c4 .. = m): element (m, k) -> Wl[m][k]
+                Wl[(4 * c4 + 0) * R8_KP + r] = f2bf(f.x);
+                Wl[(4 * c4 + 1) * R8_KP + r] = f2bf(f.y);
+                Wl[(4 * c4 + 2) * R8_KP + r] = f2bf(f.z);
+                Wl[(4 * c4 + 3) * R8_KP + r] = f2bf(f.w);
+            }
         }
     }
 }
@@ -214,11 +230,119 @@ __device__ __forceinline__ void rr80_epilogue(const JobW& W, int nmb, const f32x
 #undef LJ
 }
 
+// LeakyReLU -> LayerNorm backward of the wave's rows over M <= 80 features (EqdChainJob.type 1; the mathematics of
+// rw_lnbwd_finish / chain_lnbwd): incoming gradient = the wave's tile, saved activations y_act = lin.s[0].X (rows of any
+// stride), dz -> the tile (zeros beyond M) and lin.Y, per-wave sums of d gamma / d beta -> red
+__device__ __forceinline__ void rr80_lnbwd(const JobW& W, float* tile, float* red, int row0, int l15, int g) {
+#define LJ(f) JW_OFF(EqdLinJob, f)
+    const int rows = jw_i(W, LJ(rows)), M = jw_i(W, LJ(M));
+    const int nmb = (M + 15) >> 4;
+    const float slope = jw_f(W, LJ(slope)), ln_eps = jw_f(W, LJ(ln_eps));
+    const int rowi = row0 + l15;
+    const bool rv = rowi < rows;
+    const size_t rowe = (size_t)(rv ? rowi : rows - 1);
+    const float* const yrow = jw_p<const float>(W, LJ(s) + JW_OFF(EqdLinSrc, X)) + rowe * jw_i(W, LJ(s) + JW_OFF(EqdLinSrc, ldx));
+    const float* const jg = jw_p<const float>(W, LJ(ln_g));
+    const float* const jmul = jw_p<const float>(W, LJ(mul));
+    const int ld_mul = jw_i(W, LJ(ld_mul));
+    auto ld4 = [&](const float* p, int f0) -> f32x4 {
+        const int n = M - f0;
+        const float4 f = ld4u_fix(ld4u_raw(p + f0, n, p), n);
+        return f32x4{f.x, f.y, f.z, f.w};
+    };
+    // (register diet: only y and o stay live across the passes - gamma is folded into o's copy dx, the normalised
+    //  activations are recomputed where they are used, the dropout factors are read per block in the last pass)
+    f32x4 y[5], o[5], dx[5];
+#pragma unroll
+    for (int a = 0; a < 5; ++a) {
+        const int f0 = 16 * a + 4 * g;
+        y[a] = o[a] = dx[a] = f4zero();
+        if (a < nmb) {
+            y[a] = ld4(yrow, f0);
+            o[a] = *(const f32x4*)(tile + l15 * R8_TS + f0);      // (zeros beyond M: the producer's epilogue)
+            const f32x4 gam = ld4(jg, f0);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) dx[a][b] = o[a][b] * gam[b];
+        }
+        if (!rv) o[a] = y[a] = dx[a] = f4zero();
+    }
+    const float invM = 1.f / (float)M;
+    float s = 0.f;
+#pragma unroll
+    for (int a = 0; a < 5; ++a) s += (y[a][0] + y[a][1]) + (y[a][2] + y[a][3]);
+    const float mean = group_sum(s) * invM;
+    float q = 0.f;
+#pragma unroll
+    for (int a = 0; a < 5; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const float c = 16 * a + 4 * g + b < M ? y[a][b] - mean : 0.f;
+            q += c * c;
+        }
+    const float rstd = 1.f / sqrtf(group_sum(q) * invM + ln_eps);
+    auto xh_of = [&](int a, int b) { return 16 * a + 4 * g + b < M ? (y[a][b] - mean) * rstd : 0.f; };
+    float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+    for (int a = 0; a < 5; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            p1 += dx[a][b];
+            p2 += dx[a][b] * xh_of(a, b);
+        }
+    const float s1 = group_sum(p1) * invM, s2 = group_sum(p2) * invM;
+    float* const jY = jw_p<float>(W, LJ(Y));
+    const int ldy = jw_i(W, LJ(ldy));
+    float* const zp = jY ? jY + (size_t)(rv ? rowi : 0) * ldy : nullptr;
+    float* const T = tile + l15 * R8_TS;
+#pragma unroll
+    for (int a = 0; a < 5; ++a) {      // dz -> lin.Y and the tile (zeros beyond M; out_local names the wave's one tile)
+        const int f0 = 16 * a + 4 * g;
+        f32x4 mm = {1.f, 1.f, 1.f, 1.f};
+        if (jmul && a < nmb) mm = ld4(jmul + rowe * ld_mul, f0);
+        f32x4 z;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const bool ok = rv && f0 + b < M;
+            z[b] = ok ? rstd * (dx[a][b] - s1 - xh_of(a, b) * s2) * (lrelu_grad(y[a][b], slope) * mm[b]) : 0.f;
+            if (zp && rv && a < nmb && f0 + b < M) ((EQD_GAS float*)zp)[f0 + b] = z[b];
+        }
+        *(f32x4*)(T + f0) = z;
+    }
+    wave_lds_fence();
+    // d gamma / d beta over the wave's 16 rows: blocks 0..3 through the 16 x 16 butterfly (lane l15 ends with entry l15 = 4 a +
+    // b, feature 16 a + 4 g + b), block 4 (features 64 + 4 g + b) with four plain 16-lane sums
+    float vg[16], vb[16];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            vg[4 * a + b] = o[a][b] * xh_of(a, b);      // rows beyond the matrix carry o = 0
+            vb[4 * a + b] = o[a][b];
+        }
+    const float dg = reduce16x16(vg, l15), db = reduce16x16(vb, l15);
+    const int f = 16 * (l15 >> 2) + 4 * g + (l15 & 3);
+    red[f] += dg;
+    red[128 + f] += db;
+    if (nmb > 4) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const float sg = l16_sum(o[4][b] * xh_of(4, b)), sb = l16_sum(o[4][b]);
+            if (l15 == b) {
+                red[64 + 4 * g + b] += sg;
+                red[128 + 64 + 4 * g + b] += sb;
+            }
+        }
+    }
+#undef LJ
+}
+
 __global__ __launch_bounds__(64 * RR_WAVES, 1) void k_rowres80(EqdChainArg A_, int tps) {
     __shared__ __attribute__((aligned(16))) EqdChainArg A;
     __shared__ __attribute__((aligned(16))) Rr80Smem sm;
     kernarg_to_lds(A, EQD_KERNARG_PTR(A_), 0);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, g = lane >> 4;
+    float* const red = sm.red[wave];
+    for (int i = lane; i < 256; i += 64) red[i] = 0.f;
     __syncthreads();
     constexpr int CJ_DW = (int)(sizeof(EqdChainJob) / 4);
     const int njobs = uni(A.njobs);
@@ -226,6 +350,7 @@ __global__ __launch_bounds__(64 * RR_WAVES, 1) void k_rowres80(EqdChainArg A_, i
     const int rows = jw_i(Wc, JW_OFF(EqdLinJob, rows));
     const int ntiles = (rows + 15) >> 4;
     const int tile0 = (int)blockIdx.x * tps;
+    float* aux = nullptr;
     int nt_wg = ntiles - tile0;
     nt_wg = nt_wg < tps ? nt_wg : tps;
     int nslots = 0;
@@ -244,6 +369,7 @@ __global__ __launch_bounds__(64 * RR_WAVES, 1) void k_rowres80(EqdChainArg A_, i
     RrRows XR[RR_TMAX];
     const float* held_x = nullptr;      // the global source whose rows XR holds (wave-uniform)
     int held_ld = 0, held_k = 0;
+    // (the host only sends chains whose FIRST job is a linear one: rw80_eligible)
     {      // the first source's weights
         const EqdLinSrc S0 = jw_src(Wc, 0);
         const int M0 = jw_i(Wc, JW_OFF(EqdLinJob, M));
@@ -251,13 +377,17 @@ __global__ __launch_bounds__(64 * RR_WAVES, 1) void k_rowres80(EqdChainArg A_, i
         rr80_stage_store(S0, M0, t, WS, sm.Wl[0]);
     }
     __syncthreads();
-    for (int jj = 0; jj < njobs; ++jj) {
+    int jj = 0;
+    while (jj < njobs) {
+        // the next LINEAR job behind this one (LayerNorm-backward jobs in between run in this job's tail), or -1
+        int nl = jj + 1;
+        while (nl < njobs && uni(A.j[nl].type) != 0) ++nl;
+        const bool have_nj = nl < njobs;
         const int nsrc = jw_i(Wc, JW_OFF(EqdLinJob, nsrc));
         const int M = jw_i(Wc, JW_OFF(EqdLinJob, M));
         const int nmb = (M + 15) >> 4;
-        const bool have_nj = jj + 1 < njobs;
         JobW Wnl = Wc;
-        if (have_nj) Wnl = jobw_load(&A.j[jj + 1], CJ_DW, lane);
+        if (have_nj) Wnl = jobw_load(&A.j[nl], CJ_DW, lane);
         const int Mn = jw_i(Wnl, JW_OFF(EqdLinJob, M));
         f32x4 acc[RR_TMAX][5];
 #pragma unroll
@@ -304,6 +434,36 @@ __global__ __launch_bounds__(64 * RR_WAVES, 1) void k_rowres80(EqdChainArg A_, i
 #pragma unroll
         for (int s = 0; s < RR_TMAX; ++s)
             if (s < nslots) rr80_epilogue(Wc, nmb, acc[s], sm.tile[wave][s], row0s[s], l15, g);
+        // the LayerNorm-backward jobs behind it, then the next linear job
+        if (nl > jj + 1) {
+            for (int q = jj + 1; q < nl; ++q) {
+                const JobW Wl_ = jobw_load(&A.j[q], CJ_DW, lane);
+#pragma unroll
+                for (int s = 0; s < RR_TMAX; ++s)
+                    if (s < nslots) rr80_lnbwd(Wl_, sm.tile[wave][s], red, row0s[s], l15, g);
+                aux = jw_p<float>(Wl_, JW_OFF(EqdChainJob, aux));
+            }
+            // rows fetched ahead for the next job are dropped (it re-requests them): the 40 registers of the row buffers are
+            // then dead across the LayerNorm backward instead of being parked in scratch memory around it
+            held_x = nullptr;
+#pragma unroll
+            for (int s = 0; s < RR_TMAX; ++s) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) XR[s].x[a] = f4zero();
+                XR[s].xr = f4zero();
+            }
+        }
         Wc = Wnl;
+        jj = nl;
+    }
+    __syncthreads();
+    if (aux) {      // (every wave walks the whole job list, so every wave knows aux)
+        float* ap = aux + (size_t)blockIdx.x * 256;
+        if (t < 256) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int w = 0; w < RR_WAVES; ++w) sacc += sm.red[w][t];
+            ap[t] = sacc;
+        }
     }
 }

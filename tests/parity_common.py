@@ -1506,6 +1506,38 @@ def check_first_layer_rowres80(dev, rows=333):
             close(y_act, z, tol=1e-4, what=f'first layer ({form}): node_mlp.0 activation')
             close(a1n, a1n_ref, tol=1e-4, what=f'first layer ({form}): LayerNorm(69) output')
             close(h_out, u_ref, tol=5e-3, what=f'first layer ({form}): node update')      # (bf16 flips of a1n: 2^-9 steps)
+            # the backward chain (eqd_node_update_bwd): d a1n = d h' Wn2 (bf16 GEMM) -> LeakyReLU / LayerNorm(69) backward (fp32)
+            # -> dz times the four column blocks of Wn1 (bf16 GEMMs); d gamma / d beta from the chain's partial sums
+            gout = torch.randn(rows, dout, generator=torch.Generator().manual_seed(3))
+            da1n = F.linear(bf(gout), bf(Wn2).t().contiguous())
+            mu = z.mean(1, keepdim=True)
+            rstd = 1.0 / torch.sqrt(((z - mu) ** 2).mean(1, keepdim=True) + 1e-5)
+            xh = (z - mu) * rstd
+            dxh = da1n * lg
+            dz_ref = rstd * (dxh - dxh.mean(1, keepdim=True) - xh * (dxh * xh).mean(1, keepdim=True)) * torch.where(z > 0, 1.0, 0.01)
+            refs = dict(d_h=F.linear(bf(dz_ref), bf(Wn1[:, :d]).t().contiguous()),
+                        d_am=F.linear(bf(dz_ref), bf(Wn1[:, d:d + 64]).t().contiguous()),
+                        d_ac=F.linear(bf(dz_ref), bf(Wn1[:, d + 64:2 * d + 64]).t().contiguous()),
+                        d_h0=F.linear(bf(dz_ref), bf(Wn1[:, 2 * d + 64:]).t().contiguous()))
+            wsb = lib().eqd_node_update_bwd_workspace_bytes(rows, C.byref(prm))
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            goutd = gout.to(dev).contiguous()
+            d_h, d_am, d_h0 = torch.zeros(rows, d, **f), torch.zeros(rows, 64, **f), torch.zeros(rows, d0, **f)
+            d_ac = torch.full((rows, ldc), float('nan'), **f)
+            gs_ = [torch.zeros_like(t) for t in dd[4:]]
+            gr = L.EqdNodeUpdateGrads()
+            gr.dWn1, gr.dbn1, gr.dln_g, gr.dln_b, gr.dWn2, gr.dbn2 = (t.data_ptr() for t in gs_)
+            names = launch_names(dev, lambda: L.check(lib().eqd_node_update_bwd(
+                rows, C.byref(prm), P(dd[0]), P(dd[1]), P(dd[2]), P(dd[3]), P(y_act), P(a1n), P(goutd), P(d_h), P(d_am), P(d_ac),
+                P(d_h0), C.byref(gr), P(ws), C.c_size_t(wsb), st(dev))))
+            assert ('k_rowres' in names) == (form == 'rowres80'), (form, names)
+            close(d_h, refs['d_h'], tol=5e-3, what=f'first layer ({form}): d h')
+            close(d_am, refs['d_am'], tol=5e-3, what=f'first layer ({form}): d aggr_msg')
+            close(d_ac[:, :d], refs['d_ac'], tol=5e-3, what=f'first layer ({form}): d aggr_cross')
+            assert float(d_ac[:, d:].abs().max()) == 0.0, 'padding columns of d aggr_cross must be zeros'
+            close(d_h0, refs['d_h0'], tol=5e-3, what=f'first layer ({form}): d h0')
+            grad_close(gs_[2], (da1n * xh).sum(0), what=f'first layer ({form}): d ln_g', l2=2e-4, mx=2e-4)
+            grad_close(gs_[3], da1n.sum(0), what=f'first layer ({form}): d ln_b', l2=2e-4, mx=2e-4)
             # projection group: P, Q (64 wide, Q with bias), q, k (LeakyReLU), v, 69 wide, rows padded to 80 with zeros
             hd = h.to(dev).contiguous()
             Wd = [w.to(dev).contiguous() for w in Wp]
