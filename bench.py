@@ -71,7 +71,7 @@ def step_flops_as_written(sizes, L, d0=69, d=64, K=50):
 
 
 def kernel_work_model(sizes, L, n_nodes, n_edges, cross=True, d0=69, dh=64, d_emb=64, K=50, fused_fwd=False, rowwave='k_rowres',
-                      fused_gather=False, ds_handoff=False):
+                      fused_gather=False, ds_handoff=False, wide_resident=False):
     """Per-STEP work of each kernel family, from the launch structure of eqd_model_forward / eqd_model_backward
     (csrc/eqd_driver.hip): `flops` = FLOPs the kernel executes on the MFMA pipes for its GEMMs (2 per MAC),
     `flops_written` = the model-as-written share where SURVEY.md section 8d defines one (edge kernels, attention),
@@ -92,8 +92,9 @@ def kernel_work_model(sizes, L, n_nodes, n_edges, cross=True, d0=69, dh=64, d_em
         # from 4 tiles per CU the node-level jobs of the 64-wide layers run on k_rowres (weights resident in LDS; `rowwave`
         # = the name seen in the profile, k_rowwave when forced), layer 0's 69-wide ones and small batches on k_linear /
         # k_rowchain (csrc/eqd_node_kernels.hip: rw_mode, rw_eligible)
-        lin = rowwave if (rowwave and d == 64) else 'k_linear'
-        chain = rowwave if (rowwave and d == 64) else 'k_rowchain'
+        # (wide_resident: bf16 mode at large sizes - the 69-wide first layer's jobs run on k_rowres80, profiled as k_rowres)
+        lin = rowwave if (rowwave and (d == 64 or wide_resident)) else 'k_linear'
+        chain = rowwave if (rowwave and (d == 64 or wide_resident)) else 'k_rowchain'
         # forward: five node projections (P, Q 64 wide; q, k, v d wide)
         W[lin]['flops'] += N * 2 * d * (128 + 3 * d)
         W[lin]['bytes'] += N * 4 * (d + 128 + 3 * da)
@@ -974,7 +975,8 @@ def main():
                 prof, ev_us, n_launch = profile_step(compute, dev)
                 work = kernel_work_model(sizes, L, packed.n_nodes, packed.n_edges, fused_fwd='k_edge_attn_fwd' in prof,
                                          rowwave=next((k for k in ('k_rowres', 'k_rowwave') if k in prof), None),
-                                         fused_gather='k_attn_bwd_gather' in prof, ds_handoff='k_attn_bwd_kvds' in prof)
+                                         fused_gather='k_attn_bwd_gather' in prof, ds_handoff='k_attn_bwd_kvds' in prof,
+                                         wide_resident=(dtype == 'bf16' and 'k_rowres' in prof and 'k_rowchain' not in prof))
                 wkey = a.workload + ('_bf16' if dtype == 'bf16' else '')
                 traffic, traffic_src = load_traffic(wkey)
                 allk, ktot, covered = kernel_rooflines(prof, work, dtype == 'bf16', ms_step * 1e3, load_pmc(wkey), traffic)
