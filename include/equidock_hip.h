@@ -213,8 +213,12 @@ int eqd_model_lrelu_signs(const EqdModelDesc* m, const EqdGraph* g, const float*
  * Outputs: lig_out [n_lig][3], Y_lig / Y_rec [n_pairs][n_heads][3], T [n_pairs][9], b [n_pairs][3],
  * svd_status [n_pairs] int32 (number of guard perturbations, 11 = "consistently unstable").
  * `svd_draws` may be NULL, or [n_pairs][10][3] diagonal perturbations to use when the guard
- * (:574) fires.  `saved` may be NULL for inference (no backward possible).  `drop`: the dropout masks of a training-mode
- * forward (EqdDropout), NULL otherwise. */
+ * (:574) fires.  `saved` may be NULL for inference (no backward possible; the state then lives in `scratch`).  `drop`: the
+ * dropout masks of a training-mode forward (EqdDropout), NULL otherwise.
+ * bf16 storage mode (EqdModelDesc.storage_bf16): a forward that SAVES state also needs `scratch` (eqd_model_scratch_bytes) -
+ * the fp32 tensors the forward itself reads but the backward only needs rounded to bf16 (the node features of the inner
+ * layers, aggr_msg) are transients there, their saved form is bf16; EQD_ERR_WORKSPACE without it.  The same buffer may be
+ * handed to the backward afterwards. */
 int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const float* const* params, const EqdDropout* drop,
                       const float* svd_draws,
                       float* lig_out, float* Y_lig, float* Y_rec, float* T, float* b, int32_t* svd_status,
