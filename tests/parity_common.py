@@ -1584,6 +1584,54 @@ def launch_names(dev, fn):
     return [lib().eqd_profile_name(i).decode() for i in range(n)]
 
 
+def check_rowres80_dropout(dev, sizes=((37, 52), (61, 33))):
+    """Training with dropout in bf16 mode, every row chain on the LDS-resident kernels (EQD_ROWWAVE=2): the 69-wide first layer
+    on k_rowres80 (masks applied in its epilogue / its LayerNorm backward) against the same run with the first layer on the
+    four-wave kernels (EQD_ROWRES80=0), same library-drawn masks (same torch seed): outputs within fp32 reassociation, the
+    flat gradient within bf16 flips of the re-rounded activations."""
+    import os
+    old = {k: os.environ.get(k) for k in ('EQD_ROWWAVE', 'EQD_ROWRES80')}
+    res = {}
+    try:
+        for form in ('rowres80', 'four-wave'):
+            os.environ['EQD_ROWWAVE'] = '2'
+            if form == 'four-wave':
+                os.environ['EQD_ROWRES80'] = '0'
+            else:
+                os.environ.pop('EQD_ROWRES80', None)
+            L.reload_tunables()
+            args = port.default_args(iegmn_n_lays=3, skip_weight_h=0.75, dropout=0.2)
+            args['hip_storage_dtype'] = 'bf16'
+            args['hip_dropout_masks'] = 'library'
+            net = M.Rigid_Body_Docking_Net(args)
+            net.load_state_dict(port.init_state_dict(args, seed=5))
+            net.to(dev).train()
+            g = G.batch_pairs(synthetic.make_pairs(list(sizes), 3)).to(dev)
+            flat = net.iegmn_original.enable_flat_grads()
+            torch.manual_seed(11)
+            if dev.type == 'cuda':
+                torch.cuda.manual_seed(11)
+            outs = net.forward_batched(g)
+            loss = sum((o * o).sum() for o in outs[:3]) + (outs[3] * outs[3]).mean()
+            loss.backward()
+            res[form] = [o.detach().cpu() for o in outs] + [flat.detach().cpu().clone()]
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        L.reload_tunables()
+    a, b = res['rowres80'], res['four-wave']
+    for i, (x, y) in enumerate(zip(a[:-1], b[:-1])):
+        assert torch.isfinite(x).all()
+        close(x, y, tol=1e-4, what=f'dropout on k_rowres80: output {i}')
+    scale = float(b[-1].abs().max())
+    err = float((a[-1] - b[-1]).abs().max())
+    assert err <= 5e-3 * scale, f'dropout on k_rowres80: flat gradient differs by {err:.3e} (scale {scale:.3e})'
+    assert float(a[-1].abs().sum()) > 0
+
+
 def check_bf16_storage_model(dev, monkeypatch):
     """bf16 storage of the saved state: with the dS hand-off form of the attention backward (what large batches run; forced
     here) the state a bf16-mode forward keeps for its backward is >= 24 % smaller than the fp32 mode's (a1n, aggr_msg, h and

@@ -187,6 +187,13 @@ def test_first_layer_on_rowres80(dev):
     pc.check_first_layer_rowres80(dev, rows=5000)
 
 
+def test_rowres80_dropout(dev):
+    """training with dropout, bf16 mode: the first layer on k_rowres80 vs on the four-wave kernels, same library-drawn masks"""
+    from tests import parity_common as pc
+    pc.check_rowres80_dropout(dev)
+    pc.check_rowres80_dropout(dev, sizes=((400, 380), (350, 410), (90, 120)))
+
+
 def test_bf16_storage_operators(dev):
     """EqdLinJob.Yb (bf16 copy == RNE of the fp32 output, every epilogue) and EqdAtbJob.y_bf16 (same bits as the fp32 Y)"""
     from tests import parity_common as pc

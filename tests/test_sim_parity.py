@@ -170,6 +170,10 @@ def test_first_layer_on_rowres80():
     pc.check_first_layer_rowres80(DEV, rows=77)
 
 
+def test_rowres80_dropout():
+    pc.check_rowres80_dropout(DEV)
+
+
 def test_bf16_storage_operators():
     pc.check_bf16_storage_ops(DEV)
 
