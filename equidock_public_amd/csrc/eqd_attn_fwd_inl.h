@@ -5,7 +5,7 @@
 
 // The backward passes recompute p = exp(S - lse) (arguments <= 0 up to rounding) with the hardware exponential
 // (v_exp_f32 on x log2 e: ~4e-6 relative error at |x| ~ 80, far inside the gradient tolerance) - 32 of them per
-// 32 x 32 score tile otherwise cost as many VALU cycles as a third of the tile's MFMAs.  The forward keeps expf.
+// 32 x 32 score tile otherwise cost as many VALU cycles as a third of the tile's MFMAs.  The forward keeps expf's bits (exp_nooverflow).
 #ifndef EQD_NATIVE_EXP
 #define EQD_NATIVE_EXP(x) __expf(x)
 #endif
@@ -412,14 +412,14 @@ __device__ __forceinline__ void attn_fwd_body(AttnFwdSmem<DB>& sm, const EqdGrap
             // rounds to does not depend on the tile schedule (and the oracle can state the rounding point:
             // 2^(s log2 e - ceil(max)) rounded to bf16)
             const float mnew = fmaxf(mrun[nb], BF ? ceilf(mx) : mx);
-            const float alpha = BF ? exp2f(mrun[nb] - mnew) : expf(mrun[nb] - mnew);
+            const float alpha = BF ? exp2_flush(mrun[nb] - mnew) : exp_nooverflow(mrun[nb] - mnew);
             float ps = 0.f;
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = kt + 16 * mb + 4 * g + r;
-                    const float p = key < o1 ? (BF ? exp2f(S[mb][nb][r] - mnew) : expf(S[mb][nb][r] - mnew)) : 0.f;
+                    const float p = key < o1 ? (BF ? exp2_flush(S[mb][nb][r] - mnew) : exp_nooverflow(S[mb][nb][r] - mnew)) : 0.f;
                     S[mb][nb][r] = p;
                     ps += p;
                 }
@@ -458,7 +458,7 @@ __device__ __forceinline__ void attn_fwd_body(AttnFwdSmem<DB>& sm, const EqdGrap
         float ll = 0.f;
 #pragma unroll
         for (int w = 0; w < EQD_WAVES; ++w) {
-            sc[nb][w] = BF ? exp2f(sm_m[w][16 * nb + l15] - mm) : expf(sm_m[w][16 * nb + l15] - mm);
+            sc[nb][w] = BF ? exp2_flush(sm_m[w][16 * nb + l15] - mm) : exp_nooverflow(sm_m[w][16 * nb + l15] - mm);
             ll += sm_l[w][16 * nb + l15] * sc[nb][w];
         }
         mtot[nb] = mm;

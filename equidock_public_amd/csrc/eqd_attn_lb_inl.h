@@ -296,14 +296,14 @@ __device__ __forceinline__ void attn_fwd_body_lb(AttnFwdSmemLb& sm, const EqdGra
                 }
             mx = group_max(mx);
             const float mnew = fmaxf(mrun[nb], ceilf(mx));       // integer running maximum (see attn_fwd_body)
-            const float alpha = exp2f(mrun[nb] - mnew);
+            const float alpha = exp2_flush(mrun[nb] - mnew);
             float ps = 0.f;
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = kt + 16 * mb + 4 * g + r;
-                    const float p = key < o1 ? exp2f(S[mb][nb][r] - mnew) : 0.f;
+                    const float p = key < o1 ? exp2_flush(S[mb][nb][r] - mnew) : 0.f;
                     S[mb][nb][r] = p;
                     ps += p;
                 }
@@ -340,7 +340,7 @@ __device__ __forceinline__ void attn_fwd_body_lb(AttnFwdSmemLb& sm, const EqdGra
         float ll = 0.f;
 #pragma unroll
         for (int w = 0; w < EQD_WAVES; ++w) {
-            sc[nb][w] = exp2f(sm.sm_m[w][16 * nb + l15] - mm);
+            sc[nb][w] = exp2_flush(sm.sm_m[w][16 * nb + l15] - mm);
             ll += sm.sm_l[w][16 * nb + l15] * sc[nb][w];
         }
         mtot[nb] = mm;

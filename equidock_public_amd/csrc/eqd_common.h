@@ -225,11 +225,14 @@ __device__ __forceinline__ float lane_xor(float v) {
 #else
     const int i = __builtin_bit_cast(int, v);
     int r;
-    if constexpr (M == 1) r = __builtin_amdgcn_update_dpp(0, i, 0xB1, 0xf, 0xf, false);           // quad_perm [1,0,3,2]
-    else if constexpr (M == 2) r = __builtin_amdgcn_update_dpp(0, i, 0x4E, 0xf, 0xf, false);      // quad_perm [2,3,0,1]
-    else if constexpr (M == 8) r = __builtin_amdgcn_update_dpp(0, i, 0x128, 0xf, 0xf, false);     // row_ror:8
-    else r = __builtin_amdgcn_update_dpp(0, __builtin_amdgcn_update_dpp(0, i, 0x141, 0xf, 0xf, false), 0x1B, 0xf, 0xf,
-                                         false);                                                   // half mirror, quad reverse
+    // (bound_ctrl = true with full row / bank masks: every lane has a valid source in these permutations, and the compiler
+    //  may then treat the "old" operand as undefined - with bound_ctrl = false it zeroed the destination before each move,
+    //  103 v_mov per 16-edge tile of k_edge_bwd<bf16> - and fold the move into the consuming add as v_add_f32_dpp)
+    if constexpr (M == 1) r = __builtin_amdgcn_update_dpp(0, i, 0xB1, 0xf, 0xf, true);            // quad_perm [1,0,3,2]
+    else if constexpr (M == 2) r = __builtin_amdgcn_update_dpp(0, i, 0x4E, 0xf, 0xf, true);       // quad_perm [2,3,0,1]
+    else if constexpr (M == 8) r = __builtin_amdgcn_update_dpp(0, i, 0x128, 0xf, 0xf, true);      // row_ror:8
+    else r = __builtin_amdgcn_update_dpp(0, __builtin_amdgcn_update_dpp(0, i, 0x141, 0xf, 0xf, true), 0x1B, 0xf, 0xf,
+                                         true);                                                    // half mirror, quad reverse
     return __builtin_bit_cast(float, r);
 #endif
 }
@@ -254,6 +257,38 @@ __device__ __forceinline__ float lane_swap_sum(float v, int want_max) {
     if constexpr (M == 16) asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
     else asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
     return want_max ? fmaxf(x, y) : x + y;
+#endif
+}
+// exp(x) for arguments that cannot overflow (softmax: x = score - running maximum <= 0; RBF features: x = -d^2 / sigma).
+// hipcc expands expf to  p = x log2e;  e = fma(x, log2e, -p) + x log2e_lo;  n = rint(p);  ldexp(exp2((p - n) + e), n)  and then
+// two compare / select pairs for x > 88.7 (-> inf) and x < -103.28 (-> 0): 13 VALU instructions per value, 18 values per
+// 32-key step of the attention forward.  Without the guards (one clamp instead, which keeps n inside the integers and the
+// error term e small for the -1e30 sentinels of masked keys) the sequence returns the same bits for every x in
+// [-103.28, 88.7] and 0 below -103.98; in between (the last half binade above the underflow) it returns the smallest
+// denormal, 2^-149, where expf returns 0 - next to the row maximum's exp(0) = 1 that changes no sum.
+// tests/parity_common.py: check_lane_exchanges compares it with expf on the GPU, denormal results included.
+__device__ __forceinline__ float exp_nooverflow(float x) {
+#ifdef EQD_HOSTSIM
+    return expf(x);
+#else
+    const float c = __builtin_bit_cast(float, 0x3fb8aa3bu), cl = __builtin_bit_cast(float, 0x32a5705fu);
+    x = __builtin_fmaxf(x, -1000.f);
+    const float p = x * c;
+    float e = __builtin_fmaf(x, c, -p);
+    e = __builtin_fmaf(x, cl, e);
+    const float n = __builtin_rintf(p);
+    const float f = (p - n) + e;
+    return __builtin_ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
+#endif
+}
+// 2^x on v_exp_f32 alone.  exp2f adds a compare, two selects, an add and an ldexp per value to return denormal results
+// for x < -126; the instruction itself returns 0 there.  bf16 mode's softmax: p < 2^-126 next to the row maximum's p = 1
+// changes neither the row sum nor the bf16-rounded probabilities.
+__device__ __forceinline__ float exp2_flush(float x) {
+#ifdef EQD_HOSTSIM
+    return exp2f(x);
+#else
+    return __builtin_amdgcn_exp2f(x);
 #endif
 }
 // sum / max over the 4 lane groups (same l15): after this every lane of the column has the total

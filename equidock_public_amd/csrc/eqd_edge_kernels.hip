@@ -308,7 +308,7 @@ __device__ __forceinline__ void edge_tile_forward(const EqdGraph& G, const EqdEd
         for (int j = 0; j < 4; ++j) {
             const int k = PRE ? 4 * g + j : g + 4 * j;      // (which lane computes which k is free: same expression, same bits)
             if (k < 15 && S.ev[nb]) {
-                const float v = P.use_dist ? expf(-S.d2[nb] / rbf_sigma(k)) : 0.f;
+                const float v = P.use_dist ? exp_nooverflow(-S.d2[nb] / rbf_sigma(k)) : 0.f;
                 tile[el * FS + 27 + k] = v;
                 if (rbf_out) rbf_out[(size_t)(S.e0 + el) * 16 + k] = v;
             }
@@ -625,7 +625,7 @@ __device__ __forceinline__ void edge_tile_forward_bf(const EqdGraph& G, const Eq
             const int k = PRE ? 4 * g + j : g + 4 * j;
             float v = 0.f;
             if (k < 15 && S.ev[nb]) {
-                v = P.use_dist ? expf(-q / rbf_sigma(k)) : 0.f;
+                v = P.use_dist ? exp_nooverflow(-q / rbf_sigma(k)) : 0.f;
                 ft[el * FSB + 27 + k] = f2bf(v);
             }
             if constexpr (PRE) S.rbf[nb][j] = v;      // fp32 copy for the backward's d rbf -> d(d^2) (the tile holds bf16)

@@ -568,7 +568,7 @@ __device__ __forceinline__ float quad_bcast(float v) {      // lane J of the cal
 #if defined(EQD_HOSTSIM) || defined(EQD_NO_DPP)
     return __shfl(v, (int)((threadIdx.x & 63) & ~3u) + J);
 #else
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), J * 0x55, 0xf, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), J * 0x55, 0xf, 0xf, true));
 #endif
 }
 __device__ __forceinline__ float kab_rcp(float x) {

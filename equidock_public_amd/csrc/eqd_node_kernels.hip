@@ -190,7 +190,7 @@ extern "C" int eqd_tile_edges(void) { return EQD_TILE_EDGES; }
 
 // ------------------------------------------------------------------------------------------
 // Self test of the lane exchanges of eqd_common.h (DPP moves, v_permlane{16,32}_swap through inline assembly) against
-// the plain __shfl_xor forms they replace, on lane-distinct values and at several points of one kernel (the hazards
+// the plain __shfl_xor forms they replace (and of exp_nooverflow / exp2_flush against expf / exp2f), on lane-distinct values and at several points of one kernel (the hazards
 // around the swap instruction depend on the neighbouring instructions).  mismatch[0] = number of (lane, check) pairs
 // whose bits differ.  Test aid (tests/parity_common.py: check_lane_exchanges).
 // ------------------------------------------------------------------------------------------
@@ -231,6 +231,32 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_selftest_lanes(const float* __res
         bad += !(fabsf(got - r16) <= 1e-5f * (fabsf(r16) + 1.f));
         acc += gs + w;
     }
+    // exp_nooverflow against expf, bit for bit: ordinary softmax arguments, the denormal results around -87 .. -104, the
+    // underflow threshold, far below it and the -1e30 sentinel (mismatch[1]); exp2_flush against exp2f where the result is
+    // normal (mismatch[2]) and 0 at the sentinel (mismatch[3])
+    int bad_e = 0, bad_e2 = 0, bad_s = 0;
+    {
+        const float u = fabsf(in[t]) + 1e-3f * (float)t;
+        const float xs[8] = {-u, -7.f * u, -40.f * u - 1.f, -87.f - 0.07f * (float)t, -103.f - 0.01f * (float)t, -150.f * u - 104.f,
+                             -1e30f, 0.25f * u};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float a = exp_nooverflow(xs[i]), b = expf(xs[i]);
+            // (x in (-103.98, -103.28): 2^-149 where expf returns 0, see exp_nooverflow)
+            const bool last_half_binade = xs[i] < -103.27f && xs[i] > -103.99f && b == 0.f && a <= 1.5e-45f;
+            if (__builtin_bit_cast(unsigned, a) != __builtin_bit_cast(unsigned, b) && !last_half_binade) {
+                ++bad_e;
+                acc = xs[i];      // (out256 then shows an argument that differs)
+            }
+            const float x2 = fmaxf(xs[i], -125.f);
+            bad_e2 += __builtin_bit_cast(unsigned, exp2_flush(x2)) != __builtin_bit_cast(unsigned, exp2f(x2));
+        }
+        bad_s += exp2_flush(-1e30f) != 0.f;
+        bad_s += exp2_flush(in[t] - 1e30f) != 0.f;
+    }
+    if (bad_e) atomicAdd(mismatch + 1, bad_e);
+    if (bad_e2) atomicAdd(mismatch + 2, bad_e2);
+    if (bad_s) atomicAdd(mismatch + 3, bad_s);
     out[t] = acc;
     if (bad) atomicAdd(mismatch, bad);
 }
@@ -1130,13 +1156,10 @@ __device__ __forceinline__ void atb_fast_bf(const AtbUnit& u, int c, float* __re
     constexpr bool masked = MASKED;
     const bool want_bias = J.bias_out != nullptr && u.n0 == 0;
     const float slope = J.slope;
-    const EQD_GAS float* const X = (const EQD_GAS float*)J.X + 4 * tc;
-    const EQD_GAS float* const Xm = (const EQD_GAS float*)(masked ? J.xmask : J.X) + 4 * tc;
     const EQD_GAS float* const Y = (const EQD_GAS float*)J.Y + u.n0 + 4 * tc;
     const int ny = J.N - (u.n0 + 4 * tc);
     const bool yfull = u.fast == 1;
     constexpr bool ybf = YBF;            // Y is a saved bf16 tensor (uint16 rows): 8-byte loads
-    const unsigned short* const Yh = (const unsigned short*)J.Y + u.n0 + 4 * tc;
     static_assert(2 * 64 * ATB_KG * 8 <= ATB_ROWS * ATB_LS * 4, "two bf16 chunks must fit one fp32 tile");
     s16x4* const Xb = (s16x4*)Xl_;      // [2][64 columns][ATB_KG]
     s16x4* const Yb = (s16x4*)Yl_;

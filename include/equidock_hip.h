@@ -62,8 +62,10 @@ int eqd_is_simulator(void);
  * snapshot (nothing in the reference corresponds to it). */
 void eqd_tunables_reload(void);
 /* Test aid: one 256-thread workgroup runs the library's cross-lane helpers (DPP moves, v_permlane{16,32}_swap) on in256
- * [256] beside the plain ds_bpermute forms; *mismatch (device int, zeroed by the caller) receives the number of differing
- * (lane, check) pairs, out256 [256] a value that depends on every exchange. */
+ * [256] beside the plain ds_bpermute forms, and the guard-free exponentials of the softmax kernels beside expf / exp2f;
+ * mismatch [4] (device ints, zeroed by the caller) receives the number of differing (lane, check) pairs of the exchanges [0],
+ * of exp_nooverflow vs expf [1] (bit for bit, except 2^-149 for 0 in (-103.98, -103.28)), of exp2_flush vs exp2f on normal results [2] and at the -1e30 sentinel [3];
+ * out256 [256] a value that depends on every exchange. */
 int eqd_selftest_lane_exchanges(const float* in256, int* mismatch, float* out256, void* stream);
 
 /* ---- per-launch timing (measurement aid for bench.py; nothing in the reference corresponds to it) ----

@@ -1670,14 +1670,17 @@ def pytest_raises(exc):
 
 
 def check_lane_exchanges(dev):
-    """The DPP / v_permlane*_swap lane exchanges (csrc/eqd_common.h) against __shfl_xor inside one kernel, bit for bit."""
+    """The DPP / v_permlane*_swap lane exchanges (csrc/eqd_common.h) against __shfl_xor inside one kernel, bit for bit, and the
+    guard-free exponentials of the softmax kernels (exp_nooverflow, exp2_flush) against expf / exp2f."""
     torch.manual_seed(2)
     x = (torch.randn(256) * 3).to(dev)
-    bad = torch.zeros(1, dtype=torch.int32, device=dev)
+    bad = torch.zeros(4, dtype=torch.int32, device=dev)
     out = torch.zeros(256, device=dev)
     L.check(lib().eqd_selftest_lane_exchanges(P(x), P(bad), P(out), st(dev)))
     sync(dev)
-    assert int(bad.item()) == 0, f'{int(bad.item())} lane-exchange mismatches'
+    b = [int(v) for v in bad.cpu()]
+    assert b == [0, 0, 0, 0], (f'lane-exchange mismatches {b[0]}, exp_nooverflow vs expf {b[1]}, exp2_flush vs exp2f {b[2]}, '
+                               f'sentinel {b[3]}; out256[::16] = {out.cpu()[::16].tolist()}')
     assert bool(torch.isfinite(out).all()) and float(out.abs().sum()) > 0
 
 
