@@ -35,9 +35,12 @@ __device__ __forceinline__ void tile_load(TileRegs<DB, FAST>& R, const float* __
     const float* __restrict__ base = M + (size_t)r0 * d;
     R.nvalid = nvalid;
     if (FAST) {
-        // unpredicated (a predicated load is an exec-masked branch with a wait behind it): rows beyond the range are
-        // fetched from its last row and zeroed; a tile entirely beyond the range is not fetched at all (wave-uniform)
+        // unpredicated: buffer loads whose descriptor ends behind the range's last row - the hardware returns zeros for the
+        // lanes beyond it (a select between the loaded value and 0 comes back from hipcc as an exec-masked load behind a
+        // branch with the destination zeroed in front: 8 extra instructions per load); a tile entirely beyond the range
+        // is not fetched at all (wave-uniform)
         if (nrows > 0) {
+#if defined(EQD_HOSTSIM) || defined(EQD_NO_BUFFER_LOADS) || defined(EQD_NO_BUFFER_LOADS_TILE)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int i4 = lane + 64 * j;
@@ -54,6 +57,28 @@ __device__ __forceinline__ void tile_load(TileRegs<DB, FAST>& R, const float* __
                     R.qx[j] = row < nrows ? v : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
+#else
+            // (one descriptor per tensor and range end - loop-invariant, built once: r1 is the same for the whole workgroup but
+            //  arrives in a vector register, hence the readfirstlane; the tile's first row goes into the lanes' offsets.
+            //  Byte offsets are 32-bit: tensors of up to 2^32 / (4 d) rows; FAST: d == 16 DB)
+            const __amdgpu_buffer_rsrc_t rs =
+                __builtin_amdgcn_make_buffer_rsrc((void*)M, 0, __builtin_amdgcn_readfirstlane(r1) * (64 * DB), 0x00020000);
+            const int vo = r0 * (64 * DB);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i4 = lane + 64 * j;
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, vo + 16 * ((i4 >> 4) * (4 * DB) + (i4 & 15)), 0, 0);
+                R.q[j] = __builtin_bit_cast(float4, v);
+            }
+            if constexpr (DB > 4) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int i = lane + 64 * j;
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, vo + 16 * ((i >> 2) * (4 * DB) + 16 + (i & 3)), 0, 0);
+                    R.qx[j] = __builtin_bit_cast(float4, v);
+                }
+            }
+#endif
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) R.q[j] = make_float4(0.f, 0.f, 0.f, 0.f);

@@ -33,11 +33,33 @@ struct LbRegs {
 // rows r0 .. r0 + 31 of M ([.][64] fp32, 16-byte aligned rows), clipped at r1 -> registers, RAW: rows beyond the range are
 // fetched from its last row and zeroed when the tile is stored (a select next to the load turns it into an exec-masked
 // branch with a wait behind it - and, here, parked half-loaded vectors in scratch memory: the kernel ran 1.4x slower)
+// On the GPU the loads are BUFFER loads whose descriptor ends behind the range's last row: the hardware returns zeros for
+// the rows beyond it (LB_ZERO_FILLED), no address clamp per row and no zeroing selects when the tile is stored (those were
+// 64 v_cndmask per tile); the descriptor is wave-uniform (r1, the end of the work item's range, is the same for the whole
+// workgroup but arrives in a vector register, hence the readfirstlane).  Byte offsets are 32-bit: tensors of up to 2^24 rows.
+// The host simulator keeps the clamped plain loads.
+#if defined(EQD_HOSTSIM) || defined(EQD_NO_BUFFER_LOADS)
+#define LB_ZERO_FILLED 0
+#else
+#define LB_ZERO_FILLED 1
+#endif
 __device__ __forceinline__ void lb_load(LbRegs& R, const float* __restrict__ M, int r0, int r1, int lane) {
     int nrows = r1 - r0;
     nrows = nrows < 0 ? 0 : (nrows > 32 ? 32 : nrows);
     R.nrows = nrows;
     const int a = lane >> 3, cg = lane & 7;
+#if LB_ZERO_FILLED && !defined(EQD_NO_BUFFER_LOADS_LB)
+    // (one descriptor per tensor and range end - loop-invariant, built once; the tile's first row goes into the lanes' offsets)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)M, 0, __builtin_amdgcn_readfirstlane(r1) * 256, 0x00020000);
+    const int vo = (r0 + 4 * a) * 256 + cg * 16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const f32x4 l = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo + 256 * r, 0, 0));
+        const f32x4 h = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo + 256 * r + 128, 0, 0));
+        R.lo[r] = make_float4(l[0], l[1], l[2], l[3]);
+        R.hi[r] = make_float4(h[0], h[1], h[2], h[3]);
+    }
+#else
     if (nrows > 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -45,8 +67,13 @@ __device__ __forceinline__ void lb_load(LbRegs& R, const float* __restrict__ M, 
             const float4* __restrict__ p = (const float4*)(M + (size_t)(r0 + (row < nrows ? row : nrows - 1)) * 64 + 4 * cg);
             R.lo[r] = p[0];
             R.hi[r] = p[8];
+            if (LB_ZERO_FILLED && row >= nrows) R.lo[r] = R.hi[r] = make_float4(0.f, 0.f, 0.f, 0.f);      // (bisecting builds only)
         }
+    } else if (LB_ZERO_FILLED) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) R.lo[r] = R.hi[r] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+#endif
 }
 // The same tile from a SAVED bf16 tensor ([.][64] bf16 rows, 128 B: the bf16 storage mode keeps q / k / v of the 64-wide layers
 // that way for the backward): 8-byte loads, exact conversion - rounding the values again when the tile is parked in LDS
@@ -71,6 +98,19 @@ __device__ __forceinline__ void lb_load_bf(LbRegs& R, const unsigned short* __re
     nrows = nrows < 0 ? 0 : (nrows > 32 ? 32 : nrows);
     R.nrows = nrows;
     const int a = lane >> 3, cg = lane & 7;
+#if LB_ZERO_FILLED && !defined(EQD_NO_BUFFER_LOADS_LBBF)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)M, 0, __builtin_amdgcn_readfirstlane(r1) * 128, 0x00020000);
+    const int vo = (r0 + 4 * a) * 128 + cg * 8;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const eqd_u32x2 l = __builtin_amdgcn_raw_buffer_load_b64(rs, vo + 128 * r, 0, 0);
+        const eqd_u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(rs, vo + 128 * r + 64, 0, 0);
+        // (scalar temporaries: __builtin_bit_cast applied to an element of an ext-vector returns element 0 with this hipcc)
+        const unsigned l0 = l.x, l1 = l.y, h0 = h.x, h1 = h.y;
+        R.lo[r] = make_float4(__builtin_bit_cast(float, l0), __builtin_bit_cast(float, l1), 0.f, 0.f);
+        R.hi[r] = make_float4(__builtin_bit_cast(float, h0), __builtin_bit_cast(float, h1), 0.f, 0.f);
+    }
+#else
     if (nrows > 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -78,8 +118,13 @@ __device__ __forceinline__ void lb_load_bf(LbRegs& R, const unsigned short* __re
             const unsigned short* __restrict__ p = M + (size_t)(r0 + (row < nrows ? row : nrows - 1)) * 64 + 4 * cg;
             R.lo[r] = lb_raw8(p);
             R.hi[r] = lb_raw8(p + 32);
+            if (LB_ZERO_FILLED && row >= nrows) R.lo[r] = R.hi[r] = make_float4(0.f, 0.f, 0.f, 0.f);      // (bisecting builds only)
         }
+    } else if (LB_ZERO_FILLED) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) R.lo[r] = R.hi[r] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+#endif
 }
 template <bool QB>
 __device__ __forceinline__ void lb_load_any(LbRegs& R, const float* __restrict__ M, int r0, int r1, int lane) {
@@ -89,7 +134,7 @@ __device__ __forceinline__ void lb_load_any(LbRegs& R, const float* __restrict__
 template <bool QB>
 __device__ __forceinline__ void lb_fix_any(LbRegs& R) {      // before the first use of a tile loaded by lb_load_any<true>
     if constexpr (QB) {
-        if (R.nrows > 0) {
+        if (LB_ZERO_FILLED || R.nrows > 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 R.lo[r] = lb_fix8(R.lo[r]);
@@ -122,12 +167,18 @@ __device__ __forceinline__ void lb_store_rm(const LbRegs& R, unsigned short* __r
     const int a = lane >> 3, cg = lane & 7;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const bool ok = 4 * a + r < R.nrows;
+        const bool ok = LB_ZERO_FILLED || 4 * a + r < R.nrows;
         *(s16x4*)&rm[(4 * a + r) * LB_RS + 4 * cg] = lb_pack(R.lo[r].x, R.lo[r].y, R.lo[r].z, R.lo[r].w, ok);
         *(s16x4*)&rm[(4 * a + r) * LB_RS + 32 + 4 * cg] = lb_pack(R.hi[r].x, R.hi[r].y, R.hi[r].z, R.hi[r].w, ok);
     }
 }
 __device__ __forceinline__ s16x4 lb_pack4(float a, float b, float c, float d, int row0, int nrows) {
+#if LB_ZERO_FILLED
+    // (the empty asm keeps the four values scalar: left alone, hipcc vectorizes this 4 x 4 transposition through a stack
+    //  object - 96 .. 144 B of scratch plus 5 KB of promoted LDS per workgroup, and the forward ran 12 % slower)
+    asm("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    return pack_bf4(a, b, c, d);
+#endif
     return pack_bf4(row0 < nrows ? a : 0.f, row0 + 1 < nrows ? b : 0.f, row0 + 2 < nrows ? c : 0.f, row0 + 3 < nrows ? d : 0.f);
 }
 __device__ __forceinline__ void lb_store_tr(const LbRegs& R, unsigned short* __restrict__ tr, int lane) {
@@ -147,7 +198,7 @@ __device__ __forceinline__ void lb_store_tr(const LbRegs& R, unsigned short* __r
 __device__ __forceinline__ float lb_rowdot(const LbRegs& A, const LbRegs& B, int r, int lane) {
     const float s = (A.lo[r].x * B.lo[r].x + A.lo[r].y * B.lo[r].y + A.lo[r].z * B.lo[r].z + A.lo[r].w * B.lo[r].w) +
                     (A.hi[r].x * B.hi[r].x + A.hi[r].y * B.hi[r].y + A.hi[r].z * B.hi[r].z + A.hi[r].w * B.hi[r].w);
-    return 4 * (lane >> 3) + r < A.nrows ? s : 0.f;
+    return (LB_ZERO_FILLED || 4 * (lane >> 3) + r < A.nrows) ? s : 0.f;
 }
 // B-operand fragments of row `row` of an fp32 block tile (row stride DS): chunk c = features 16 c + 4 g .. + 3
 __device__ __forceinline__ void lb_frag(s16x4 (&F)[4], const float* __restrict__ T, int row, int DS, int g) {

@@ -22,6 +22,7 @@
 #include "../../include/equidock_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #define EQD_BLOCK 256
 #define EQD_WAVES 4
@@ -228,11 +229,16 @@ __device__ __forceinline__ float lane_xor(float v) {
     // (bound_ctrl = true with full row / bank masks: every lane has a valid source in these permutations, and the compiler
     //  may then treat the "old" operand as undefined - with bound_ctrl = false it zeroed the destination before each move,
     //  103 v_mov per 16-edge tile of k_edge_bwd<bf16> - and fold the move into the consuming add as v_add_f32_dpp)
-    if constexpr (M == 1) r = __builtin_amdgcn_update_dpp(0, i, 0xB1, 0xf, 0xf, true);            // quad_perm [1,0,3,2]
-    else if constexpr (M == 2) r = __builtin_amdgcn_update_dpp(0, i, 0x4E, 0xf, 0xf, true);       // quad_perm [2,3,0,1]
-    else if constexpr (M == 8) r = __builtin_amdgcn_update_dpp(0, i, 0x128, 0xf, 0xf, true);      // row_ror:8
-    else r = __builtin_amdgcn_update_dpp(0, __builtin_amdgcn_update_dpp(0, i, 0x141, 0xf, 0xf, true), 0x1B, 0xf, 0xf,
-                                         true);                                                    // half mirror, quad reverse
+#ifdef EQD_DPP_ZEROED_OLD
+    constexpr bool BC = false;
+#else
+    constexpr bool BC = true;
+#endif
+    if constexpr (M == 1) r = __builtin_amdgcn_update_dpp(0, i, 0xB1, 0xf, 0xf, BC);            // quad_perm [1,0,3,2]
+    else if constexpr (M == 2) r = __builtin_amdgcn_update_dpp(0, i, 0x4E, 0xf, 0xf, BC);       // quad_perm [2,3,0,1]
+    else if constexpr (M == 8) r = __builtin_amdgcn_update_dpp(0, i, 0x128, 0xf, 0xf, BC);      // row_ror:8
+    else r = __builtin_amdgcn_update_dpp(0, __builtin_amdgcn_update_dpp(0, i, 0x141, 0xf, 0xf, BC), 0x1B, 0xf, 0xf,
+                                         BC);                                                    // half mirror, quad reverse
     return __builtin_bit_cast(float, r);
 #endif
 }
@@ -268,7 +274,7 @@ __device__ __forceinline__ float lane_swap_sum(float v, int want_max) {
 // denormal, 2^-149, where expf returns 0 - next to the row maximum's exp(0) = 1 that changes no sum.
 // tests/parity_common.py: check_lane_exchanges compares it with expf on the GPU, denormal results included.
 __device__ __forceinline__ float exp_nooverflow(float x) {
-#ifdef EQD_HOSTSIM
+#if defined(EQD_HOSTSIM) || defined(EQD_LIBM_EXP)
     return expf(x);
 #else
     const float c = __builtin_bit_cast(float, 0x3fb8aa3bu), cl = __builtin_bit_cast(float, 0x32a5705fu);
@@ -285,7 +291,7 @@ __device__ __forceinline__ float exp_nooverflow(float x) {
 // for x < -126; the instruction itself returns 0 there.  bf16 mode's softmax: p < 2^-126 next to the row maximum's p = 1
 // changes neither the row sum nor the bf16-rounded probabilities.
 __device__ __forceinline__ float exp2_flush(float x) {
-#ifdef EQD_HOSTSIM
+#if defined(EQD_HOSTSIM) || defined(EQD_LIBM_EXP)
     return exp2f(x);
 #else
     return __builtin_amdgcn_exp2f(x);
