@@ -332,10 +332,66 @@ __device__ __forceinline__ float wave_sum(float v) { return group_sum(l16_sum(v)
 __device__ __forceinline__ float reduce16x16(const float (&v)[16], int l15) {
     const bool b3 = (l15 & 8) != 0, b2 = (l15 & 4) != 0, b1 = (l15 & 2) != 0, b0 = (l15 & 1) != 0;
     float w8[8], w4[4], w2[2];
+#if defined(EQD_HOSTSIM) || defined(EQD_NO_DPP) || defined(EQD_NO_DPP_ASM)
 #pragma unroll
     for (int i = 0; i < 8; ++i) w8[i] = (b3 ? v[i + 8] : v[i]) + lane_xor<8>(b3 ? v[i] : v[i + 8]);
 #pragma unroll
     for (int i = 0; i < 4; ++i) w4[i] = (b2 ? w8[i + 4] : w8[i]) + lane_xor<4>(b2 ? w8[i] : w8[i + 4]);
+#else
+    // The first two steps as DPP adds with BANK masks (a bank = 4 consecutive lanes of the row): the lanes with bit 3 clear
+    // (banks 0, 1) want v[i] + v[i] of lane ^ 8, the others (banks 2, 3) v[i + 8] + v[i + 8] of lane ^ 8 - two masked
+    // v_add_f32_dpp per output instead of two selects, a DPP move and an add (the compiler cannot form them: a masked DPP
+    // operand folds into an add only when the untouched lanes' result is the add's other operand).  Same two addends per
+    // output as the plain form: same bits.  Lane ^ 4 = row_half_mirror, then the quads reversed (lane_xor<4>), bit 2
+    // = banks 1, 3.  s_nop 1: the two wait states between a VALU write and a DPP read of the same register (the inputs
+    // may have just been written; the hazard recognizer does not look inside an asm block).  Inside the second block every
+    // DPP read is at least 7 instructions behind the move that wrote its register.
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %8, %8 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %0, %16, %16 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %1, %9, %9 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %1, %17, %17 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %2, %10, %10 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %2, %18, %18 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %3, %11, %11 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %3, %19, %19 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %4, %12, %12 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %4, %20, %20 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %5, %13, %13 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %5, %21, %21 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %6, %14, %14 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %6, %22, %22 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %7, %15, %15 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %7, %23, %23 row_ror:8 row_mask:0xf bank_mask:0xc"
+        : "=&v"(w8[0]), "=&v"(w8[1]), "=&v"(w8[2]), "=&v"(w8[3]), "=&v"(w8[4]), "=&v"(w8[5]), "=&v"(w8[6]), "=&v"(w8[7])
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]),
+          "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]));
+    {
+        float t[8];
+        asm("s_nop 1\n\t"
+            "v_mov_b32_dpp %4, %12 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+            "v_mov_b32_dpp %5, %13 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+            "v_mov_b32_dpp %6, %14 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+            "v_mov_b32_dpp %7, %15 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+            "v_mov_b32_dpp %8, %16 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+            "v_mov_b32_dpp %9, %17 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+            "v_mov_b32_dpp %10, %18 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+            "v_mov_b32_dpp %11, %19 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, %4, %12 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %0, %8, %16 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %1, %5, %13 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %1, %9, %17 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %2, %6, %14 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %2, %10, %18 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %3, %7, %15 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %3, %11, %19 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xa"
+            : "=&v"(w4[0]), "=&v"(w4[1]), "=&v"(w4[2]), "=&v"(w4[3]), "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]),
+              "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7])
+            : "v"(w8[0]), "v"(w8[1]), "v"(w8[2]), "v"(w8[3]), "v"(w8[4]), "v"(w8[5]), "v"(w8[6]), "v"(w8[7]));
+    }
+    (void)b3;
+    (void)b2;
+#endif
 #pragma unroll
     for (int i = 0; i < 2; ++i) w2[i] = (b1 ? w4[i + 2] : w4[i]) + lane_xor<2>(b1 ? w4[i] : w4[i + 2]);
     return (b0 ? w2[1] : w2[0]) + lane_xor<1>(b0 ? w2[0] : w2[1]);

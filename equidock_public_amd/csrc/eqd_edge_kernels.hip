@@ -625,7 +625,9 @@ __device__ __forceinline__ void edge_tile_forward_bf(const EqdGraph& G, const Eq
             const int k = PRE ? 4 * g + j : g + 4 * j;
             float v = 0.f;
             if (k < 15 && S.ev[nb]) {
-                v = P.use_dist ? exp_nooverflow(-q / rbf_sigma(k)) : 0.f;
+                // (bf16 mode: times the rounded reciprocal instead of the fp32 division - ten VALU instructions per value; the
+                //  feature is rounded to bf16 below, the backward's recompute runs this same code)
+                v = P.use_dist ? exp_nooverflow(q * rbf_neg_inv_sigma(k)) : 0.f;
                 ft[el * FSB + 27 + k] = f2bf(v);
             }
             if constexpr (PRE) S.rbf[nb][j] = v;      // fp32 copy for the backward's d rbf -> d(d^2) (the tile holds bf16)

@@ -1587,8 +1587,8 @@ def launch_names(dev, fn):
 def check_rowres80_dropout(dev, sizes=((37, 52), (61, 33))):
     """Training with dropout in bf16 mode, every row chain on the LDS-resident kernels (EQD_ROWWAVE=2): the 69-wide first layer
     on k_rowres80 (masks applied in its epilogue / its LayerNorm backward) against the same run with the first layer on the
-    four-wave kernels (EQD_ROWRES80=0), same library-drawn masks (same torch seed): outputs within fp32 reassociation, the
-    flat gradient within bf16 flips of the re-rounded activations."""
+    four-wave kernels (EQD_ROWRES80=0), same library-drawn masks (same torch seed): outputs and the flat gradient within bf16
+    flips of the re-rounded activations."""
     import os
     old = {k: os.environ.get(k) for k in ('EQD_ROWWAVE', 'EQD_ROWRES80')}
     res = {}
@@ -1623,12 +1623,15 @@ def check_rowres80_dropout(dev, sizes=((37, 52), (61, 33))):
                 os.environ[k] = v
         L.reload_tunables()
     a, b = res['rowres80'], res['four-wave']
+    # (two kernel forms of bf16 GEMMs: different accumulation orders move single activations to the neighbouring bf16 value -
+    #  2^-9 relative per flip, 1.2e-3 of the output scale measured on MI355X after three layers; wrong or differing masks
+    #  would show at the scale of the outputs themselves)
     for i, (x, y) in enumerate(zip(a[:-1], b[:-1])):
         assert torch.isfinite(x).all()
-        close(x, y, tol=1e-4, what=f'dropout on k_rowres80: output {i}')
+        close(x, y, tol=5e-3, what=f'dropout on k_rowres80: output {i}')
     scale = float(b[-1].abs().max())
     err = float((a[-1] - b[-1]).abs().max())
-    assert err <= 5e-3 * scale, f'dropout on k_rowres80: flat gradient differs by {err:.3e} (scale {scale:.3e})'
+    assert err <= 2e-2 * scale, f'dropout on k_rowres80: flat gradient differs by {err:.3e} (scale {scale:.3e})'
     assert float(a[-1].abs().sum()) > 0
 
 
