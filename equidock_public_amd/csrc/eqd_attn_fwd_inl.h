@@ -241,11 +241,18 @@ __device__ __forceinline__ void mma_k(f32x4 (&acc)[NB], const float* __restrict_
             for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma_bf(a, F[nb].p[KS / 4 - 1], acc[nb]);
         }
     } else {
+        // (all A fragments first: with the read next to its use hipcc emitted  ds_read2_b32 - s_waitcnt lgkmcnt(0) - 4 MFMA
+        //  sixteen times per score block, the full LDS latency in front of every fourth MFMA)
+        float a[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) a[ks] = A[arow * DS + 4 * ks + g];
+#if !defined(EQD_HOSTSIM) && !defined(EQD_NO_LDS_BATCH)
+        __builtin_amdgcn_sched_barrier(0);      // (the scheduler otherwise sinks every read back next to its MFMAs)
+#endif
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const float a = A[arow * DS + 4 * ks + g];
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma4(a, F[nb].v[ks], acc[nb]);
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma4(a[ks], F[nb].v[ks], acc[nb]);
         }
     }
 }
@@ -270,13 +277,20 @@ __device__ __forceinline__ void mma_r(f32x4 (&acc)[DB][NB], const float* __restr
             for (int nb = 0; nb < NB; ++nb) acc[db][nb] = mfma_bf(a, b[nb], acc[db][nb]);
         }
     } else {
+        float a[4][DB];      // (all A fragments first, see mma_k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int db = 0; db < DB; ++db) a[r][db] = A[(row0 + r) * DS + 16 * db + l15];
+#if !defined(EQD_HOSTSIM) && !defined(EQD_NO_LDS_BATCH)
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
-                const float a = A[(row0 + r) * DS + 16 * db + l15];
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) acc[db][nb] = mfma4(a, B[nb][r], acc[db][nb]);
+                for (int nb = 0; nb < NB; ++nb) acc[db][nb] = mfma4(a[r][db], B[nb][r], acc[db][nb]);
             }
     }
 }

@@ -1584,7 +1584,7 @@ def launch_names(dev, fn):
     return [lib().eqd_profile_name(i).decode() for i in range(n)]
 
 
-def check_rowres80_dropout(dev, sizes=((37, 52), (61, 33))):
+def check_rowres80_dropout(dev, sizes=((37, 52), (61, 33)), out_tol=5e-3, grad_tol=2e-2):
     """Training with dropout in bf16 mode, every row chain on the LDS-resident kernels (EQD_ROWWAVE=2): the 69-wide first layer
     on k_rowres80 (masks applied in its epilogue / its LayerNorm backward) against the same run with the first layer on the
     four-wave kernels (EQD_ROWRES80=0), same library-drawn masks (same torch seed): outputs and the flat gradient within bf16
@@ -1628,10 +1628,10 @@ def check_rowres80_dropout(dev, sizes=((37, 52), (61, 33))):
     #  would show at the scale of the outputs themselves)
     for i, (x, y) in enumerate(zip(a[:-1], b[:-1])):
         assert torch.isfinite(x).all()
-        close(x, y, tol=5e-3, what=f'dropout on k_rowres80: output {i}')
+        close(x, y, tol=out_tol, what=f'dropout on k_rowres80: output {i}')
     scale = float(b[-1].abs().max())
     err = float((a[-1] - b[-1]).abs().max())
-    assert err <= 2e-2 * scale, f'dropout on k_rowres80: flat gradient differs by {err:.3e} (scale {scale:.3e})'
+    assert err <= grad_tol * scale, f'dropout on k_rowres80: flat gradient differs by {err:.3e} (scale {scale:.3e})'
     assert float(a[-1].abs().sum()) > 0
 
 
