@@ -153,10 +153,15 @@ __device__ __forceinline__ void chain64(f32x4 (&out)[4][NB], const f32x4 (&in)[4
                 b[nb][3] = b[nb][3] * gg.w + bb.w;
             }
         }
+        float4 w[4];      // (the four weight fragments of the input block first, see chain64T)
+#pragma unroll
+        for (int mbo = 0; mbo < 4; ++mbo) w[mbo] = *(const float4*)&W[(16 * mbo + l15) * WS2 + 16 * mbi + 4 * g];
+#if !defined(EQD_HOSTSIM) && !defined(EQD_NO_LDS_BATCH) && !defined(EQD_NO_LDS_BATCH_ROWEDGE)
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int mbo = 0; mbo < 4; ++mbo) {
-            const float4 w = *(const float4*)&W[(16 * mbo + l15) * WS2 + 16 * mbi + 4 * g];
-            const float wv[4] = {w.x, w.y, w.z, w.w};
+            const float wv[4] = {w[mbo].x, w[mbo].y, w[mbo].z, w[mbo].w};
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -169,15 +174,25 @@ template <int NB>
 __device__ __forceinline__ void chain64T(f32x4 (&out)[4][NB], const f32x4 (&in)[4][NB], const float* __restrict__ W,
                                          int l15, int g) {
 #pragma unroll
-    for (int mbi = 0; mbi < 4; ++mbi)
+    for (int mbi = 0; mbi < 4; ++mbi) {
+        // the 16 weight fragments of the input block first, then its 16 NB MFMAs (left alone the scheduler puts every LDS
+        // read right in front of its MFMA: read - s_waitcnt lgkmcnt(0) - MFMA, 64 times per call)
+        float w[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int mbo = 0; mbo < 4; ++mbo) w[r][mbo] = W[(16 * mbi + 4 * g + r) * WS2 + 16 * mbo + l15];
+#if !defined(EQD_HOSTSIM) && !defined(EQD_NO_LDS_BATCH) && !defined(EQD_NO_LDS_BATCH_ROWEDGE)
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int mbo = 0; mbo < 4; ++mbo) {
-                const float w = W[(16 * mbi + 4 * g + r) * WS2 + 16 * mbo + l15];
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) out[mbo][nb] = mfma4(w, in[mbi][nb][r], out[mbo][nb]);
+                for (int nb = 0; nb < NB; ++nb) out[mbo][nb] = mfma4(w[r][mbo], in[mbi][nb][r], out[mbo][nb]);
             }
+    }
 }
 
 template <int NB>
@@ -541,12 +556,18 @@ __device__ __forceinline__ void chain64_bf(f32x4 (&out)[4][NB], const f32x4 (&in
         }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) b[nb] = cat_bf(bh[0][nb], bh[1][nb]);
+        s16x8 a[4];      // (the chunk's four weight fragments first, see chain64T)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+            a[mb] = cat_bf(*(const s16x4*)&w[(16 * mb + l15) * WSB + 32 * mp + 4 * g],
+                           *(const s16x4*)&w[(16 * mb + l15) * WSB + 32 * mp + 16 + 4 * g]);
+#if !defined(EQD_HOSTSIM) && !defined(EQD_NO_LDS_BATCH) && !defined(EQD_NO_LDS_BATCH_ROWEDGE)
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
-            const s16x8 a = cat_bf(*(const s16x4*)&w[(16 * mb + l15) * WSB + 32 * mp + 4 * g],
-                                   *(const s16x4*)&w[(16 * mb + l15) * WSB + 32 * mp + 16 + 4 * g]);
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) out[mb][nb] = mfma_bf32(a, b[nb], out[mb][nb]);
+            for (int nb = 0; nb < NB; ++nb) out[mb][nb] = mfma_bf32(a[mb], b[nb], out[mb][nb]);
         }
     }
 }

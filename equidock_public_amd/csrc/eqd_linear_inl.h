@@ -247,7 +247,7 @@ __device__ __forceinline__ void lin_store(const EqdLinJob& J, const EqdLinSrc& S
 // acc[rt][i] (+)= W-fragment x X-fragment of the chunk for the wave's NOWN output blocks; no per-lane predicates.
 // The weight fragments are read once for the RT row tiles.  MFMAs alternate between two accumulator sets (a single
 // dependent chain leaves the matrix pipe idle).
-template <int RT, int NOWN, int NQ, bool WT, bool BF = false>
+template <int RT, int NOWN, int NQ, bool WT, bool BF = false, bool LB = true>
 __device__ __forceinline__ void lin_mma(f32x4 (&acc)[RT][2], f32x4 (&acc2)[RT][2], const float* (&Xs)[RT],
                                         const float* __restrict__ Wl, const int (&mb)[2], int l15, int g) {
     // WT: the weights lie as Wl[k][m] (full steps of transposed sources): the 4 k-values of a lane are 4 scalar reads
@@ -268,6 +268,12 @@ __device__ __forceinline__ void lin_mma(f32x4 (&acc)[RT][2], f32x4 (&acc2)[RT][2
         f32x4 b[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) b[q] = *(const f32x4*)&Xs[rt][l15 * LIN_S + 16 * q + 4 * g];
+#if !defined(EQD_HOSTSIM) && !defined(EQD_NO_LDS_BATCH) && !defined(EQD_NO_LDS_BATCH_ROWEDGE)
+        // every fragment read of the step is issued before its first MFMA (left alone the scheduler sinks each read next to
+        // its use: read - s_waitcnt lgkmcnt(0) - 4 MFMA, the LDS latency exposed sixteen times per step).  LB: off in the
+        // instances that are capped at 256 registers (two workgroups per SIMD pair), where holding every fragment spills.
+        if constexpr (LB) __builtin_amdgcn_sched_barrier(0);
+#endif
         if constexpr (BF) {
             // bf16 mode: the 4 k-values a lane holds for chunk q (k = 16 q + 4 g + j) are exactly one operand of
             // v_mfma_f32_16x16x16_bf16: four fp32 instructions become one (inputs rounded to bf16, fp32 accumulate)
@@ -316,7 +322,7 @@ __device__ __forceinline__ void lin_mma(f32x4 (&acc)[RT][2], f32x4 (&acc2)[RT][2
 //      (one wave per SIMD), so its instruction count is latency: the general path spends ~3 500 clocks per step and
 //      ~2 000 per job on descriptor handling; the floor with static addressing is 1 350 per step
 //      (profiles/exp_step_floor.hip).  Arithmetic (order of every sum) is the same as in linear_tile. -----------------
-template <bool BF>
+template <bool BF, bool LB = true>
 __device__ __forceinline__ void linear_tile_lean(const JobW& W, bool chain, int out_local, LinSmem<1>& sm,
                                                  float (*Lb)[LIN_LOCALS][16 * LIN_S], int row0, LinRegs<1>& RA,
                                                  bool have_first, bool has_next, const JobW& Wn, int trace_slot) {
@@ -412,9 +418,9 @@ __device__ __forceinline__ void linear_tile_lean(const JobW& W, bool chain, int 
             LIN_TR(tr_i++);
             const float* Xs[1] = {locs[si] >= 0 ? &Lb[0][locs[si]][0] : sm.Xl[0]};
             if ((kfm >> si) & 1u)
-                lin_mma<1, 1, 4, false, BF>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+                lin_mma<1, 1, 4, false, BF, LB>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
             else
-                lin_mma<1, 1, 4, true, BF>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+                lin_mma<1, 1, 4, true, BF, LB>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
             LIN_TR(tr_i++);
         }
     }
@@ -432,7 +438,7 @@ __device__ __forceinline__ void linear_tile_lean(const JobW& W, bool chain, int 
                     lin_store_s<1>(S, M, slope, locs[si] >= 0, c, t, RB, sm);
                     __syncthreads();
                     const float* Xs[1] = {locs[si] >= 0 ? &Lb[0][locs[si]][k0] : sm.Xl[0]};
-                    lin_mma<1, 1, 1, false, BF>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+                    lin_mma<1, 1, 1, false, BF, LB>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
                     k0 += c.kc;
                 }
             }
@@ -510,7 +516,7 @@ __device__ __forceinline__ void linear_tile_lean(const JobW& W, bool chain, int 
 // job's epilogue - otherwise every job of a chain starts with a fully exposed memory round trip.
 // W: the descriptor words of J (jobw_load); chain: J is the `lin` of an EqdChainJob, whose src_local / out_local words are
 // in W too; Wn: the words of the next job Jn (only read when has_next).
-template <int RT, bool BF = false>
+template <int RT, bool BF = false, bool LB = true>
 __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const JobW& W, bool chain,
                                             const int* __restrict__ src_local, int out_local,
                                             LinSmem<RT>& sm, float (*Lb)[LIN_LOCALS][16 * LIN_S], int row0,
@@ -526,7 +532,7 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const JobW& W, b
         for (int si = 0; si < EQD_MAX_SRC; ++si)
             if (si < nsrc && jw_i(W, LJ(s) + si * JW_SRC_DW + JW_OFF(EqdLinSrc, K)) < 64) lean = false;
         if (lean) {
-            linear_tile_lean<BF>(W, chain, out_local, sm, Lb, row0, RA, have_first, has_next, Wn, trace_slot);
+            linear_tile_lean<BF, LB>(W, chain, out_local, sm, Lb, row0, RA, have_first, has_next, Wn, trace_slot);
             return;
         }
     }
@@ -596,20 +602,20 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const JobW& W, b
             if (c.kc == 64) {
                 if (uni(S.w_cs) == 1) {
                     if (own[1])
-                        lin_mma<RT, 2, 4, false, BF>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+                        lin_mma<RT, 2, 4, false, BF, LB>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
                     else if (own[0])
-                        lin_mma<RT, 1, 4, false, BF>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+                        lin_mma<RT, 1, 4, false, BF, LB>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
                 } else {
                     if (own[1])
-                        lin_mma<RT, 2, 4, true, BF>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+                        lin_mma<RT, 2, 4, true, BF, LB>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
                     else if (own[0])
-                        lin_mma<RT, 1, 4, true, BF>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+                        lin_mma<RT, 1, 4, true, BF, LB>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
                 }
             } else {
                 if (own[1])
-                    lin_mma<RT, 2, 1, false, BF>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+                    lin_mma<RT, 2, 1, false, BF, LB>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
                 else if (own[0])
-                    lin_mma<RT, 1, 1, false, BF>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+                    lin_mma<RT, 1, 1, false, BF, LB>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
             }
             LIN_TR(tr_i++);
         };

@@ -290,7 +290,7 @@ __global__ __launch_bounds__(EQD_BLOCK, 2) void k_linear(LinJobsArg jobs) {
     EQD_TR_WG();
     LinRegs<RT> RA;
     const JobW W = jobw_load(&Jl, (int)(sizeof(EqdLinJob) / 4), threadIdx.x & 63);
-    linear_tile<RT, BF>(J, W, false, nullptr, -1, sm, nullptr, row0, RA, false, false, W);
+    linear_tile<RT, BF, RT == 1>(J, W, false, nullptr, -1, sm, nullptr, row0, RA, false, false, W);
     EQD_TR_WG_END();
 }
 // 16-row tiles per workgroup.  One tile everywhere: with the lean (precomputed-address) step pipeline, which only fits
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(EQD_BLOCK, OCC) void k_rowchain(EqdChainArg A_) {
             const int nj = jw_i(Wc, JW_OFF(EqdChainJob, prefetch_next));   // next linear job whose first step may be fetched early, or -1
             JobW Wp = Wn;
             if (nj >= 0 && nj != jj + 1) Wp = jobw_load(&A.j[nj], CJ_DW, lane);
-            linear_tile<RT, BF>(C.lin, Wc, true, C.src_local, jw_i(Wc, JW_OFF(EqdChainJob, out_local)), sm, Lb, row0, RA, have,
+            linear_tile<RT, BF, OCC == 1>(C.lin, Wc, true, C.src_local, jw_i(Wc, JW_OFF(EqdChainJob, out_local)), sm, Lb, row0, RA, have,
                             nj >= 0, Wp, 210 + 4 * jj);
             have = nj >= 0;
         } else {
