@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libequidock_hip.so')
 
 EQD_MAX_SRC = 6
-ABI_VERSION = 7
+ABI_VERSION = 8
 PARAMS_PER_LAYER = 19
 GLOBAL_PARAMS = 5
 

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define EQD_ABI_VERSION 7
+#define EQD_ABI_VERSION 8
 #define EQD_TILE_EDGES 32   /* edges per node-aligned tile (max supported in-degree) */
 #define EQD_ATT_BLOCK 32    /* nodes per cross-attention work item */
 #define EQD_MAX_SRC 6
