@@ -345,7 +345,9 @@ __device__ __forceinline__ float reduce16x16(const float (&v)[16], int l15) {
     // output as the plain form: same bits.  Lane ^ 4 = row_half_mirror, then the quads reversed (lane_xor<4>), bit 2
     // = banks 1, 3.  s_nop 1: the two wait states between a VALU write and a DPP read of the same register (the inputs
     // may have just been written; the hazard recognizer does not look inside an asm block).  Inside the second block every
-    // DPP read is at least 7 instructions behind the move that wrote its register.
+    // DPP read is at least 7 instructions behind the move that wrote its register.  (The other DPP hazard - a VALU write
+    // of EXEC less than 5 wait states earlier - cannot occur: on gfx9 hipcc changes EXEC with scalar instructions only,
+    // there is no v_cmpx in any code object of the library.)
     asm("s_nop 1\n\t"
         "v_add_f32_dpp %0, %8, %8 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
         "v_add_f32_dpp %0, %16, %16 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
