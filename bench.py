@@ -342,10 +342,14 @@ def edge_kernel_rooflines(net, packed, dev, workload='B', bf16=False):
         import glob
         files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*traffic.json')), key=_profile_order)      # newest last
         # (bf16 runs have their own counter passes: key '<workload>_bf16')
-        tr = {} if not files else json.load(open(files[-1])).get(workload + ('_bf16' if bf16 else ''), {})
+        wkey = workload + ('_bf16' if bf16 else '')
+        full = {} if not files else json.load(open(files[-1]))
+        tr = full.get(wkey, {})
+        stale = staleness(full.get('_workloads', {}).get(wkey, {}).get('csrc_digest'))
         for k, v in tr.items():
             if k in out:
                 out[k]['traffic'] = int((2 * v['FETCH_SIZE_KB'] + v['WRITE_SIZE_KB']) * 1024)
+                out[k]['traffic_stale'] = stale['stale']      # True: counters of another state of the kernel sources
                 out[k]['traffic_source'] = (f'profiles/{os.path.basename(files[-1])} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
                                             'separate passes; NOT measured in this run - hardware counters cannot be read '
                                             'from inside the process)')
@@ -518,6 +522,20 @@ def cpu_baseline(args_model, sd, pairs, budget_s=26.0):
                       f"{torch.__version__} CPU"}
 
 
+def running_digest():
+    from equidock_public_amd.build import csrc_digest
+    return csrc_digest()
+
+
+def staleness(counter_digest):
+    """{"csrc_digest", "running_csrc_digest", "stale"} for a committed counter summary: the hardware counters are collected
+    by separate rocprofv3 --pmc runs and committed under profiles/; they describe THIS library only when the kernel sources
+    they were measured on (equidock_public_amd.build.csrc_digest, stamped by profiles/measure_r06.sh) are the ones running
+    now.  A summary without a stamp (rounds 1-5) is stale by definition."""
+    run = running_digest()
+    return {"csrc_digest": counter_digest, "running_csrc_digest": run, "stale": counter_digest != run}
+
+
 def load_traffic(workload):
     """Per-family FETCH_SIZE / WRITE_SIZE (KB per launch) of `workload` from the newest committed PMC summary, and where it
     came from (file, the workload's own collection stamp and git hash when the summary carries them)."""
@@ -532,6 +550,7 @@ def load_traffic(workload):
             meta = d.get('_workloads', {}).get(workload, {})
             src = {"file": 'profiles/' + os.path.basename(f), "collected": meta.get('collected', d.get('_collected')),
                    "git_head": meta.get('git_head')}
+            src.update(staleness(meta.get('csrc_digest')))
             return d[workload], src
     return {}, None
 
@@ -547,7 +566,7 @@ def load_issue_floor(workload):
         except Exception:
             continue
         if workload in d:
-            return d[workload], 'profiles/' + os.path.basename(f)
+            return d[workload], dict({"file": 'profiles/' + os.path.basename(f)}, **staleness(d.get('_csrc_digest')))
     return {}, None
 
 
@@ -557,9 +576,11 @@ def load_pmc(workload):
     best = {}
     for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*pmc_mfma*.json')), key=_profile_order):
         try:
-            d = json.load(open(f)).get(workload)
+            full = json.load(open(f))
+            d = full.get(workload)
             if d:
-                best = {k: dict(v, source=os.path.basename(f)) for k, v in d.items()}
+                stale = staleness(full.get('_workloads', {}).get(workload, {}).get('csrc_digest'))['stale']
+                best = {k: dict(v, source=os.path.basename(f), stale=stale) for k, v in d.items()}
         except Exception:
             pass
     return best
@@ -762,7 +783,8 @@ def north_star_hbm_entry(rl):
     for k, v in rl.items():
         out[k] = {"avg_launch_us": v["avg_launch_us"], "algorithmic_bytes_per_launch": v["algorithmic_bytes_per_launch"],
                   "hbm_frac_algorithmic": v["hbm_frac_algorithmic"], "measured_bytes_per_launch": v.get("traffic"),
-                  "hbm_frac_measured_traffic": v.get("hbm_frac_measured_traffic")}
+                  "hbm_frac_measured_traffic": v.get("hbm_frac_measured_traffic"),
+                  "measured_traffic_stale": v.get("traffic_stale")}
     return out
 
 
@@ -984,12 +1006,17 @@ def main():
                 for k, e in allk.items():      # issue floor of the family (SQ counters of an earlier rocprofv3 --pmc pass)
                     fl = floors.get(k) or next((v for kk, v in floors.items() if k.startswith(kk)), None)
                     if fl:
-                        e["issue_floor"] = dict(fl, source=floor_src,
+                        e["issue_floor"] = dict(fl, source=floor_src["file"], stale=floor_src["stale"],
                                                 live_frac_of_floor=round(fl["floor_us"] / e["avg_launch_us"], 4))
                 for k in ('k_edge_fwd', 'k_edge_bwd'):     # keep the standalone batched-launch figures beside the in-step ones
                     if k in allk:
                         allk[k]["standalone"] = rl[k]
                 out["roofline_all"] = allk
+                # hardware counters come from committed rocprofv3 --pmc summaries: say which, and whether they were collected
+                # on the kernel sources that are running now (a duration divided by another code
+                # state's floor is not a measurement)
+                out["counters"] = {"traffic": traffic_src, "issue_floor": floor_src,
+                                   "stale": bool((traffic_src or {}).get("stale", True) or (floor_src or {}).get("stale", True))}
                 out["step_profile"] = {
                     "library_launches_per_step": n_launch, "kernel_us_per_step": round(ktot, 1),
                     "share_of_kernel_time_in_roofline_all": round(covered, 4), "traffic_source": traffic_src,

@@ -48,6 +48,20 @@ def build(force=False, verbose=True):
     return LIB
 
 
+def csrc_digest():
+    """16 hex digits over the contents of every kernel source (csrc/*.hip, csrc/*.h) and the C ABI header: the identity of
+    the code a counter summary under profiles/ was collected on.  bench.py compares it with the sources it runs on and
+    flags counters of another code state as stale (there is no .git on the GPU box, so a commit hash cannot do that)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(CSRC, '*.hip')) + glob.glob(os.path.join(CSRC, '*.h')))
+    files.append(os.path.join(os.path.dirname(HERE), 'include', 'equidock_hip.h'))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b'\0')
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
 HOST_LIB = os.path.join(HERE, 'libequidock_host.so')
 
 
@@ -65,4 +79,7 @@ def build_host(force=False, verbose=True):
 
 
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv))
+    if '--digest' in sys.argv:
+        print(csrc_digest())
+    else:
+        print(build(force='--force' in sys.argv))

@@ -278,7 +278,8 @@ __device__ __forceinline__ float exp_nooverflow(float x) {
     return expf(x);
 #else
     const float c = __builtin_bit_cast(float, 0x3fb8aa3bu), cl = __builtin_bit_cast(float, 0x32a5705fu);
-    x = __builtin_fmaxf(x, -1000.f);
+    x = x < -1000.f ? -1000.f : x;      // (a compare + select, not fmaxf: fmaxf(NaN, -1000) is -1000, and a NaN score or
+                                        //  distance would vanish from the softmax / the RBF features without a trace)
     const float p = x * c;
     float e = __builtin_fmaf(x, c, -p);
     e = __builtin_fmaf(x, cl, e);

@@ -1071,12 +1071,15 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
 // weight-gradient GEMMs + one reduction backward), behind their own entry points.
 // ---------------------------------------------------------------------------------------------
 namespace {
-int node_update_check(int rows, const EqdNodeUpdateParams* p, const char* who) {
+// has_cross: the call carries an aggr_cross array (ld_cross is only read then; the workspace query has no arrays and
+// does not depend on it)
+int node_update_check(int rows, const EqdNodeUpdateParams* p, const char* who, bool has_cross) {
     if (!p || !p->Wn1 || !p->bn1 || !p->ln_g || !p->ln_b || !p->Wn2 || !p->bn2) {
         eqd_set_error("%s: NULL parameter pointer", who);
         return EQD_ERR_NULL;
     }
-    if (rows < 0 || p->d_in < 4 || p->d_in > 80 || p->d0 < 4 || p->d0 > 80 || p->d_out != 64 || p->ld_cross < p->d_in) {
+    if (rows < 0 || p->d_in < 4 || p->d_in > 80 || p->d0 < 4 || p->d0 > 80 || p->d_out != 64 ||
+        (has_cross && p->ld_cross < p->d_in)) {
         eqd_set_error("%s: unsupported widths d_in=%d d0=%d d_out=%d ld_cross=%d (need 4..80, 4..80, 64, >= d_in)", who,
                       p->d_in, p->d0, p->d_out, p->ld_cross);
         return EQD_ERR_UNSUPPORTED;
@@ -1121,7 +1124,7 @@ size_t node_update_carve(int rows, const EqdNodeUpdateParams* p, EqdArena& A, No
 extern "C" int eqd_node_update_fwd(int rows, const EqdNodeUpdateParams* p, const float* h, const float* aggr_msg,
                                    const float* aggr_cross, const float* h0, float* h_out, float* y_act, float* a1n,
                                    void* stream) {
-    RC(node_update_check(rows, p, "eqd_node_update_fwd"));
+    RC(node_update_check(rows, p, "eqd_node_update_fwd", aggr_cross != nullptr));
     if (!h || !aggr_msg || !h0 || !h_out || !y_act || !a1n) {
         eqd_set_error("eqd_node_update_fwd: NULL argument");
         return EQD_ERR_NULL;
@@ -1156,7 +1159,7 @@ extern "C" int eqd_node_update_fwd(int rows, const EqdNodeUpdateParams* p, const
 }
 
 extern "C" size_t eqd_node_update_bwd_workspace_bytes(int rows, const EqdNodeUpdateParams* p) {
-    if (node_update_check(rows, p, "eqd_node_update_bwd_workspace_bytes")) return 0;
+    if (node_update_check(rows, p, "eqd_node_update_bwd_workspace_bytes", false)) return 0;
     EqdArena A(nullptr, 0);
     NodeUpdateWs W;
     return node_update_carve(rows, p, A, W);
@@ -1166,7 +1169,7 @@ extern "C" int eqd_node_update_bwd(int rows, const EqdNodeUpdateParams* p, const
                                    const float* aggr_cross, const float* h0, const float* y_act, const float* a1n,
                                    const float* d_h_out, float* d_h, float* d_aggr_msg, float* d_aggr_cross, float* d_h0,
                                    const EqdNodeUpdateGrads* grads, void* workspace, size_t ws_bytes, void* stream) {
-    RC(node_update_check(rows, p, "eqd_node_update_bwd"));
+    RC(node_update_check(rows, p, "eqd_node_update_bwd", aggr_cross != nullptr));
     if (!h || !aggr_msg || !h0 || !y_act || !a1n || !d_h_out || !d_h || !d_aggr_msg || !d_h0 || !grads ||
         (aggr_cross && !d_aggr_cross) || !grads->dWn1 || !grads->dbn1 || !grads->dln_g || !grads->dln_b || !grads->dWn2 ||
         !grads->dbn2) {

@@ -557,6 +557,7 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const JobW& W, b
     const bool own[2] = {wave < mbn, wave + 4 < mbn};
     f32x4 bias[2], lg[2], lb[2], res[RT][2];
     int nf[2];
+    const float* const jsafe = jw_p<const float>(W, LJ(s) + JW_OFF(EqdLinSrc, W));      // >= 16 readable bytes (source 0's weights)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int f0 = 16 * mbs[i] + 4 * g;
@@ -568,7 +569,9 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const JobW& W, b
         for (int rt = 0; rt < RT; ++rt) {
             int row = row0 + 16 * rt + l15;
             row = row < rows ? row : rows - 1;
-            res[rt][i] = jR ? ld4u_raw(jR + (size_t)row * ldr + f0, nf[i], jR) : f4zero();
+            // (without a residual the load goes to a valid dummy address and the epilogue selects 0: a `jR ? load : 0` here
+            //  kept a hoisted zero vector live across the whole pipeline - in scratch memory in the 256-register instances)
+            res[rt][i] = ld4u_raw((jR ? jR : jsafe) + (jR ? (size_t)row * ldr + f0 : (size_t)0), jR ? nf[i] : 0, jR ? jR : jsafe);
         }
     }
     f32x4 acc[RT][2], acc2[RT][2];
@@ -650,6 +653,19 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const JobW& W, b
     // ---- epilogue in F-layout: feature f = 16 mb + 4 g + r, row = row0 + 16 rt + l15 -----------------------------
     // `plain`: M is a multiple of 4, so an owned 4-feature group is always complete - no tail handling, 16-byte stores
     const bool plain = (M & 3) == 0;
+    // The register-capped instances (!LB) derive the epilogue's lane constants (offsets, feature counts) AGAIN from an
+    // opaque copy of the thread index: computed before the pipeline they stay live across it - hoisted out of a chain's job
+    // loop, even - and were what these instances spilled to scratch memory.  A dozen integer instructions per job instead.
+    int te = t;
+#ifndef EQD_HOSTSIM
+    if constexpr (!LB) asm volatile("" : "+v"(te));
+#endif
+    const int l15e = te & 15, ge = (te >> 4) & 3, wavee = LB ? wave : (te >> 6);
+    const int mbe[2] = {wavee, wavee + 4};
+    const bool owne[2] = {wavee < mbn, wavee + 4 < mbn};
+    int nfe[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) nfe[i] = owne[i] ? M - (16 * mbe[i] + 4 * ge) : 0;
     float4 bs[2], lgv[2], lbv[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -658,14 +674,14 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const JobW& W, b
             lgv[i] = make_float4(lg[i][0], lg[i][1], lg[i][2], lg[i][3]);
             lbv[i] = make_float4(lb[i][0], lb[i][1], lb[i][2], lb[i][3]);
         } else {
-            bs[i] = ld4u_fix(bias[i], nf[i]);
-            lgv[i] = ld4u_fix(lg[i], nf[i]);
-            lbv[i] = ld4u_fix(lb[i], nf[i]);
+            bs[i] = ld4u_fix(bias[i], nfe[i]);
+            lgv[i] = ld4u_fix(lg[i], nfe[i]);
+            lbv[i] = ld4u_fix(lb[i], nfe[i]);
         }
     }
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-        const int rowi = row0 + 16 * rt + l15;
+        const int rowi = row0 + 16 * rt + l15e;
         const bool rv = rowi < rows;
         float v[2][4];
 #pragma unroll
@@ -675,15 +691,15 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const JobW& W, b
             for (int r = 0; r < 4; ++r) {
                 float y = (acc[rt][i][r] + acc2[rt][i][r]) + bb[r];
                 if (act) y = lrelu(y, slope);
-                v[i][r] = r < nf[i] ? y : 0.f;
+                v[i][r] = r < nfe[i] ? y : 0.f;
             }
         }
         if (const float* const jmul = jw_p<const float>(W, LJ(mul))) {      // dropout factors (training mode only)
             const int ld_mul = jw_i(W, LJ(ld_mul));
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const float4 mm = ld4u_fix(ld4u_raw(jmul + (size_t)(rv ? rowi : rows - 1) * ld_mul + 16 * mbs[i] + 4 * g, nf[i], jmul),
-                                           nf[i]);
+                const float4 mm = ld4u_fix(ld4u_raw(jmul + (size_t)(rv ? rowi : rows - 1) * ld_mul + 16 * mbe[i] + 4 * ge, nfe[i], jmul),
+                                           nfe[i]);
                 v[i][0] *= mm.x; v[i][1] *= mm.y; v[i][2] *= mm.z; v[i][3] *= mm.w;
             }
         }
@@ -695,34 +711,34 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const JobW& W, b
 #pragma unroll
                 for (int r = 0; r < 4; ++r) s1 += v[i][r];
             s1 = group_sum(s1);
-            if (g == 0) sm.stat[rt][wave][l15] = s1;
+            if (ge == 0) sm.stat[rt][wavee][l15e] = s1;
             __syncthreads();
             const float mean =
-                (sm.stat[rt][0][l15] + sm.stat[rt][1][l15] + sm.stat[rt][2][l15] + sm.stat[rt][3][l15]) * invM;
+                (sm.stat[rt][0][l15e] + sm.stat[rt][1][l15e] + sm.stat[rt][2][l15e] + sm.stat[rt][3][l15e]) * invM;
             float q = 0.f;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float dlt = r < nf[i] ? v[i][r] - mean : 0.f;
+                    const float dlt = r < nfe[i] ? v[i][r] - mean : 0.f;
                     q += dlt * dlt;
                 }
             q = group_sum(q);
             __syncthreads();
-            if (g == 0) sm.stat[rt][wave][l15] = q;
+            if (ge == 0) sm.stat[rt][wavee][l15e] = q;
             __syncthreads();
-            const float rstd = 1.f / sqrtf((sm.stat[rt][0][l15] + sm.stat[rt][1][l15] + sm.stat[rt][2][l15] +
-                                            sm.stat[rt][3][l15]) * invM + ln_eps);
+            const float rstd = 1.f / sqrtf((sm.stat[rt][0][l15e] + sm.stat[rt][1][l15e] + sm.stat[rt][2][l15e] +
+                                            sm.stat[rt][3][l15e]) * invM + ln_eps);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const float gg[4] = {lgv[i].x, lgv[i].y, lgv[i].z, lgv[i].w};
                 const float be[4] = {lbv[i].x, lbv[i].y, lbv[i].z, lbv[i].w};
-                if (plain && nf[i] > 0 && jpre && rv)
-                    *(EQD_GAS f4v*)&jpre[(size_t)rowi * ld_pre + 16 * mbs[i] + 4 * g] = f32x4{v[i][0], v[i][1], v[i][2], v[i][3]};
+                if (plain && nfe[i] > 0 && jpre && rv)
+                    *(EQD_GAS f4v*)&jpre[(size_t)rowi * ld_pre + 16 * mbe[i] + 4 * ge] = f32x4{v[i][0], v[i][1], v[i][2], v[i][3]};
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (r < nf[i]) {
-                        const int f = 16 * mbs[i] + 4 * g + r;
+                    if (r < nfe[i]) {
+                        const int f = 16 * mbe[i] + 4 * ge + r;
                         if (!plain && jpre && rv) ((EQD_GAS float*)jpre)[(size_t)rowi * ld_pre + f] = v[i][r];
                         v[i][r] = (v[i][r] - mean) * rstd * gg[r] + be[r];
                     }
@@ -731,37 +747,39 @@ __device__ __forceinline__ void linear_tile(const EqdLinJob& J, const JobW& W, b
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             float4 rr;
-            if (plain)
+            if (!jR)
+                rr = make_float4(0.f, 0.f, 0.f, 0.f);
+            else if (plain)
                 rr = make_float4(res[rt][i][0], res[rt][i][1], res[rt][i][2], res[rt][i][3]);
             else
-                rr = ld4u_fix(res[rt][i], nf[i]);
+                rr = ld4u_fix(res[rt][i], nfe[i]);
             const float rs[4] = {rr.x, rr.y, rr.z, rr.w};
             float y[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) y[r] = alpha * v[i][r] + beta * rs[r];
-            const int f0 = 16 * mbs[i] + 4 * g;
+            const int f0 = 16 * mbe[i] + 4 * ge;
             if (plain) {
-                if (nf[i] > 0) {
+                if (nfe[i] > 0) {
                     const f32x4 yv = {y[0], y[1], y[2], y[3]};
                     if (jY && rv) *(EQD_GAS f4v*)&jY[(size_t)rowi * ldy + f0] = yv;
                     if (jYb && rv) *(EQD_GAS s16x4*)&jYb[(size_t)rowi * ldyb + f0] = pack_bf4(y[0], y[1], y[2], y[3]);
-                    if (out_local >= 0) *(f32x4*)&Lb[rt][out_local][l15 * LIN_S + f0] = yv;
-                } else if (own[i] && f0 < pad_to) {      // zero padding of the row (EqdLinJob.pad_to; pad_to is a multiple of 16)
+                    if (out_local >= 0) *(f32x4*)&Lb[rt][out_local][l15e * LIN_S + f0] = yv;
+                } else if (owne[i] && f0 < pad_to) {      // zero padding of the row (EqdLinJob.pad_to; pad_to is a multiple of 16)
                     if (jY && rv) *(EQD_GAS f4v*)&jY[(size_t)rowi * ldy + f0] = f4zero();
                 }
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (r < nf[i]) {
+                    if (r < nfe[i]) {
                         if (jY && rv) ((EQD_GAS float*)jY)[(size_t)rowi * ldy + f0 + r] = y[r];
                         if (jYb && rv) ((EQD_GAS unsigned short*)jYb)[(size_t)rowi * ldyb + f0 + r] = f2bf(y[r]);
-                        if (out_local >= 0) Lb[rt][out_local][l15 * LIN_S + f0 + r] = y[r];
+                        if (out_local >= 0) Lb[rt][out_local][l15e * LIN_S + f0 + r] = y[r];
                     } else {
                         if (f0 + r < pad_to) {      // zero padding of the row (EqdLinJob.pad_to)
                             if (jY && rv) ((EQD_GAS float*)jY)[(size_t)rowi * ldy + f0 + r] = 0.f;
                         }
                         // (the bf16 copy: zeros up to the end of the last started 4-column group, what a vector load of it covers)
-                        if (jYb && rv && own[i] && nf[i] > 0 && f0 + r < ldyb)
+                        if (jYb && rv && owne[i] && nfe[i] > 0 && f0 + r < ldyb)
                             ((EQD_GAS unsigned short*)jYb)[(size_t)rowi * ldyb + f0 + r] = 0;
                     }
             }

@@ -253,6 +253,14 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_selftest_lanes(const float* __res
         }
         bad_s += exp2_flush(-1e30f) != 0.f;
         bad_s += exp2_flush(in[t] - 1e30f) != 0.f;
+        // a NaN argument stays a NaN (a clamp written as fmaxf would turn it into exp(-1000) = 0); the NaN is made from the
+        // input so that the compiler cannot fold the test
+        const float qnan = __builtin_bit_cast(float, 0x7fc00000u | (__builtin_bit_cast(unsigned, in[t]) & 0xffu));
+        {
+            const float en = exp_nooverflow(qnan), e2n = exp2_flush(qnan);
+            bad_e += !(en != en);
+            bad_s += !(e2n != e2n);
+        }
     }
     if (bad_e) atomicAdd(mismatch + 1, bad_e);
     if (bad_e2) atomicAdd(mismatch + 2, bad_e2);

@@ -424,7 +424,10 @@ class _IEGMNFunction(torch.autograd.Function):
         ctx.drop = drop                 # the masks of THIS forward: the backward applies the same ones
         ctx.packed, ctx.desc, ctx.table_idx, ctx.saved, ctx.sb, ctx.wb = packed, desc, table_idx, saved, sb, wb
         ctx.tensors, ctx.ptrs = tensors, ptrs
-        ctx.scratch = scratch if need_grad else None      # (bf16 storage mode: reused by the backward)
+        # (bf16 storage mode: the forward's transients lived in `scratch`; they are dead now, so the buffer is NOT kept for
+        #  the backward - held on ctx across the loss, and across every other live forward, it gave back much of what the
+        #  bf16 saved state saves; the caching allocator hands the same block to the backward's _workspace(wb))
+        ctx.scratch = None
         ctx.flat_state = flat_state
         ctx.x0 = packed.x0      # keep the coordinates this forward used alive (the saved state points at them)
         ctx.mark_non_differentiable(status)

@@ -143,17 +143,23 @@ class _NodeUpdate(torch.autograd.Function):
         with _lib.device_guard(dev):
             _lib.check(lib.eqd_node_update_fwd(int(rows), C.byref(p), _lib.ptr(h_), _lib.ptr(am), _lib.ptr(ac), _lib.ptr(h0_),
                                                _lib.ptr(h_out), _lib.ptr(y_act), _lib.ptr(a1n), _lib.stream_ptr(dev)))
-        ctx.p, ctx.ts, ctx.state = p, ts, (y_act, a1n)
+        # inputs, parameters and the saved activations go through save_for_backward (autograd's in-place version checks; no
+        # reference cycle through ctx); the pointers of EqdNodeUpdateParams are rebuilt from them in backward
+        ctx.scalars = (float(skip_weight_h), float(slope), float(ln_eps))
+        ctx.save_for_backward(*ts, y_act, a1n)
         return h_out
 
     @staticmethod
     def backward(ctx, d_h_out):
         lib = _lib.load_library()
-        p = ctx.p
-        h_, am, ac, h0_, Wn1_, bn1_, lg, lb, Wn2_, bn2_ = ctx.ts
-        y_act, a1n = ctx.state
+        h_, am, ac, h0_, Wn1_, bn1_, lg, lb, Wn2_, bn2_, y_act, a1n = ctx.saved_tensors
         dev = h_.device
-        rows = h_.shape[0]
+        rows, d = h_.shape
+        p = _lib.EqdNodeUpdateParams()
+        p.d_in, p.d0, p.d_out, p.ld_cross = int(d), int(h0_.shape[1]), int(Wn2_.shape[0]), int(ac.shape[1])
+        p.Wn1, p.bn1, p.ln_g, p.ln_b, p.Wn2, p.bn2 = (t.data_ptr() for t in (Wn1_, bn1_, lg, lb, Wn2_, bn2_))
+        p.skip_weight_h, p.slope, p.ln_eps = ctx.scalars
+        p.bf16, p.drop_mul = 0, None
         d_h_out = _f32(d_h_out, 'd h_out')
         z = dict(dtype=torch.float32, device=dev)
         d_h, d_am, d_h0 = torch.empty_like(h_), torch.empty_like(am), torch.empty_like(h0_)

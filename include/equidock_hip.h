@@ -391,7 +391,7 @@ typedef struct EqdNodeUpdateParams {
     int32_t d0;            /* width of h0 = orig_h_feats_dim (4..80) */
     int32_t d_out;         /* out_feats_dim: 64 */
     int32_t ld_cross;      /* row stride of aggr_cross / d_aggr_cross (>= d_in; the attention operators' 16-float blocks: 80
-                              for a 69-wide layer) */
+                              for a 69-wide layer); not read when aggr_cross is NULL */
     const float* Wn1;      /* node_mlp.0.weight [d_in][d_in + 64 + d_in + d0], column blocks [h | aggr_msg | aggr_cross | h0] */
     const float* bn1;      /* node_mlp.0.bias [d_in] */
     const float* ln_g; const float* ln_b;   /* node_mlp.3 (LayerNorm) weight / bias [d_in] */

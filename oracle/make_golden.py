@@ -73,9 +73,13 @@ def fingerprint(sd):
     return {k: [float(v.double().sum()), float(v.double().abs().sum())] for k, v in sd.items()}
 
 
-def run_case(name, sizes, seed, args_over, rot_scale=40.0, degrade=False, full_grads=True, record_draws=False):
+def run_case(name, sizes, seed, args_over, rot_scale=40.0, degrade=False, full_grads=True, record_draws=False, pairs=None,
+             extra=None, note=None):
+    """pairs: given per-pair (ligand, receptor) arrays instead of the synthetic generator's (oracle/make_golden_real.py: the
+    graphs the reference's OWN builder made from real structures); extra: more arrays for the fixture."""
     args = port.default_args(**args_over)
-    pairs = synthetic.make_pairs(sizes, seed)
+    if pairs is None:
+        pairs = synthetic.make_pairs(sizes, seed)
     if degrade:
         # in-degree < 10 for some nodes and one isolated node (zero-fill semantics of fn.mean)
         for lig, rec in pairs:
@@ -168,15 +172,18 @@ def run_case(name, sizes, seed, args_over, rot_scale=40.0, degrade=False, full_g
     outs_b = port.forward(sd, args, raw, faithful=False,
                           rand_fn=(lambda n, it2=iter(draws): next(it2)) if record_draws else None)
     wb = max(float((x - y).abs().max()) for a, b in zip(outs, outs_b) for x, y in zip(a, b))
-    print(f'[{name}] block-diagonal attention vs reference: max abs diff {wb:.3e}')
-    assert wb < 2e-4
+    # relative to each output's largest magnitude (coordinates of real structures reach 70 A; the batch-wide softmax rows of the
+    # reference sum in another order than per-pair rows, fp32 rounding that 8 layers and the keypoint softmax carry to the outputs)
+    wbr = max(float((x - y).abs().max()) / max(1.0, float(x.abs().max())) for a, b in zip(outs, outs_b) for x, y in zip(a, b))
+    print(f'[{name}] block-diagonal attention vs reference: max abs diff {wb:.3e}, relative to the output\'s largest magnitude {wbr:.3e}')
+    assert wbr < 2e-5, (wb, wbr)
 
     # ---- write the fixture ------------------------------------------------------------------
     blob = {}
     meta = dict(name=name, sizes=[list(s) for s in sizes], seed=seed, rot_scale=rot_scale,
                 args={k: v for k, v in args.items() if k != 'device'}, fingerprint=fingerprint(sd_ref),
                 svd_iters=inter['svd_iters'], torch=torch.__version__, degrade=degrade,
-                note='generated by oracle/make_golden.py from the imported reference + DGL stand-in')
+                note=note or 'generated by oracle/make_golden.py from the imported reference + DGL stand-in')
     for k, v in raw.items():
         if torch.is_tensor(v):
             blob['in_' + k] = v.numpy()
@@ -201,6 +208,7 @@ def run_case(name, sizes, seed, args_over, rot_scale=40.0, degrade=False, full_g
             blob['grad_' + k] = gr.numpy()
     meta['grad_fingerprint'] = gnorm
     blob['meta'] = np.asarray(json.dumps(meta))
+    blob.update(extra or {})
     os.makedirs(GOLDEN, exist_ok=True)
     path = os.path.join(GOLDEN, f'case_{name}.npz')
     np.savez_compressed(path, **blob)

@@ -78,6 +78,10 @@ for w in wls:
                   'waves_waiting_frac': round(a['wait'] / a['wave'], 3) if a['wave'] else None,
                   'valu_insts_per_launch': int(a['nvalu'] / n)}
     out[w] = res
+try:      # the kernel-source digest the measurement script wrote on the GPU box (see merge_pmc.measured_digest)
+    out['_csrc_digest'] = open(os.path.join(src, f'{sq_tag}_csrc_digest.txt')).read().strip()
+except Exception:
+    out['_csrc_digest'] = None
 dst = os.path.join(root, 'profiles', f'{sq_tag}_issue_floor.json')
 json.dump(out, open(dst, 'w'), indent=1)
 print(dst)

@@ -94,7 +94,22 @@ for w in (sys.argv[3].split(',') if len(sys.argv) > 3 else ('B', 'C', 'E')):
 # every workload carries its own stamp: nothing is carried over from an older summary, and a reader can tell which
 # code state each entry was measured on
 head = git_head()
-stamps = {w: {'collected': datetime.datetime.fromtimestamp(t).isoformat(timespec='seconds'), 'git_head': head}
+
+
+def measured_digest():
+    """the kernel-source digest written ON THE GPU BOX by the measurement script (profiles/measure_r06.sh:
+    <TAG>_csrc_digest.txt = equidock_public_amd.build.csrc_digest() of the snapshot the counters ran on)"""
+    for tg in tags:
+        try:
+            return open(os.path.join(root, src, f'{tg}_csrc_digest.txt')).read().strip()
+        except Exception:
+            continue
+    return None
+
+
+digest = measured_digest()
+stamps = {w: {'collected': datetime.datetime.fromtimestamp(t).isoformat(timespec='seconds'), 'git_head': head,
+              'csrc_digest': digest}
           for w, t in when.items() if w in mfma or w in traffic}
 mfma['_workloads'] = traffic['_workloads'] = stamps
 json.dump(mfma, open(os.path.join(root, 'profiles', f'{tag}_pmc_mfma.json'), 'w'), indent=1)

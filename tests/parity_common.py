@@ -248,16 +248,35 @@ def check_model_vs_oracle(dev, sizes, layers=8, seed=3, pair_seed=33, faithful=T
         port.Bf16Mode.on = False
 
 
+# bf16 whole-model statement: the bound is MEASURED, not picked.  The bf16 model is chaotic at
+# the level of rounding flips - a value one fp32 ulp apart rounds to the other bf16 neighbour, a 2^-9 step - so the distance
+# between two CORRECT evaluations is itself finite.  That distance is measured on the same input: the bf16 oracle is
+# re-evaluated with every weight perturbed by a relative 1e-6 (an fp32-ulp-scale change: all up, all down, a seeded random
+# sign pattern), and the library must sit within BF16_NOISE_FACTOR x the largest oracle-vs-perturbed-oracle distance, per
+# tensor, at the worst element AND at the 99th percentile AND at the median of the element-wise errors.
+BF16_NOISE_FACTOR = 2.0
+BF16_PERTURBATION = 1e-6
+
+
+def _rel_errs(got, ref):
+    """element-wise |got - ref| / max(1, max|ref|) as a flat float64 tensor"""
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    return ((got - ref).abs() / max(1.0, float(ref.abs().max()))).flatten()
+
+
+def _stats(e):
+    e = e.flatten()
+    k99 = max(1, int(round(0.99 * e.numel())))
+    return float(e.median()), float(e.kthvalue(k99).values), float(e.max())
+
+
 def check_model_bf16_states(dev, sizes, layers=8, seed=3, pair_seed=34, faithful=False, what='', report=None,
                             rot_scale=10.0):
-    """bf16 mode at a BASELINE workload: the state after the last IEGMN layer (h, x: what the reference keeps as
-    'hv_iegmn_out' / 'x_iegmn_out') against the oracle evaluated with the same rounding points.  That is where a
-    whole-model statement is possible in bf16: bf16 rounding flips put ~4e-3 of noise on h and ~3e-4 on x whatever the
-    implementation (measured with the oracle alone under a 1e-6 perturbation of its weights), while the keypoint /
-    Kabsch head behind them amplifies that noise erratically - the oracle ALONE moves by 1 % ... 37 % on the final
-    outputs - so outputs and gradients are only checked for sanity here (finite, T orthonormal, loss within 30 %); per
-    operator the bf16 kernels agree with torch to fp32 summation order (check_linear_atb_bf16, check_attention_bf16,
-    check_edge_bf16).  Bounds: 2e-2 of max|h|, 2e-3 of max|x|."""
+    """bf16 mode at a BASELINE workload against the oracle evaluated with the same rounding points (Bf16Mode): the state after
+    the last IEGMN layer (h, x: what the reference keeps as 'hv_iegmn_out' / 'x_iegmn_out') and the five outputs.  No
+    hand-picked tolerance: per tensor, err(library, oracle) <= BF16_NOISE_FACTOR x max over three 1e-6 weight perturbations
+    of err(oracle, perturbed oracle), at the median, the 99th percentile and the worst element (see BF16_NOISE_FACTOR).  The
+    ROT scale is 10 (the keypoint softmax amplifies the layers' rounding noise ~1.3x instead of 18x, see BF16_ROT_SCALE)."""
     args = port.default_args(iegmn_n_lays=layers, skip_weight_h=0.75)
     sd = port.init_state_dict(args, seed=seed, rot_scale=rot_scale)
     net = build_model(dict(args, hip_storage_dtype='bf16'), sd, dev)
@@ -267,39 +286,55 @@ def check_model_bf16_states(dev, sizes, layers=8, seed=3, pair_seed=34, faithful
     loss.backward()
     sync(dev)
     h, x = net.iegmn_original.layer_state(g, layers)
-    port.Bf16Mode.on = True
-    try:
-        with torch.no_grad():
-            ref, inter = port.forward(sd, args, port.raw_from_graph(g), faithful=faithful, return_inter=True)
-    finally:
-        port.Bf16Mode.on = False
-    last = inter['layers'][-1]
-    h_ref, x_ref = torch.cat([last['h_l'], last['h_r']], 0), torch.cat([last['x_l'], last['x_r']], 0)
-    eh = float((h.cpu() - h_ref).abs().max()) / float(h_ref.abs().max())
-    ex = float((x.cpu() - x_ref).abs().max()) / float(x_ref.abs().max())
-    ref_loss = float(port.scalar_loss(ref))
-    line = (f'{what}: {len(sizes)} pairs, {layers} layers, bf16: last-layer h rel err {eh:.2e}, x rel err {ex:.2e}; '
-            f'loss {float(loss.detach()):.4f} vs oracle {ref_loss:.4f}')
+    raw = port.raw_from_graph(g)
+
+    def oracle(sd_):
+        port.Bf16Mode.on = True
+        try:
+            with torch.no_grad():
+                ref_, inter = port.forward(sd_, args, raw, faithful=faithful, return_inter=True)
+        finally:
+            port.Bf16Mode.on = False
+        last = inter['layers'][-1]
+        t = {'h_L': torch.cat([last['h_l'], last['h_r']], 0), 'x_L': torch.cat([last['x_l'], last['x_r']], 0)}
+        for nm, o in zip(('lig', 'Yl', 'Yr', 'T', 'b'), ref_):
+            t[nm] = cat_out(list(o))
+        return t, float(port.scalar_loss(ref_))
+
+    ref, ref_loss = oracle(sd)
+    got = {'h_L': h, 'x_L': x}
+    for nm, o in zip(('lig', 'Yl', 'Yr', 'T', 'b'), outs):
+        got[nm] = cat_out(list(o))
+    gen = torch.Generator().manual_seed(1234)
+    noise = {k: [0.0, 0.0, 0.0] for k in ref}
+    loss_noise = 0.0
+    for kind in ('up', 'down', 'random'):
+        sd_p = {}
+        for k, v in sd.items():
+            sgn = 1.0 if kind == 'up' else (-1.0 if kind == 'down' else
+                                            (torch.randint(0, 2, v.shape, generator=gen).to(v.dtype) * 2 - 1))
+            sd_p[k] = v * (1.0 + BF16_PERTURBATION * sgn)
+        pert, pl = oracle(sd_p)
+        loss_noise = max(loss_noise, abs(pl - ref_loss))
+        for k in ref:
+            st_ = _stats(_rel_errs(pert[k], ref[k]))
+            noise[k] = [max(a_, b_) for a_, b_ in zip(noise[k], st_)]
+    lines, bad = [], []
+    for k in ref:
+        med, p99, worst = _stats(_rel_errs(got[k], ref[k]))
+        lines.append(f'{k}: library vs oracle median {med:.1e} / p99 {p99:.1e} / worst {worst:.1e}; oracle vs its 1e-6 '
+                     f'perturbations {noise[k][0]:.1e} / {noise[k][1]:.1e} / {noise[k][2]:.1e}')
+        for nm_, v_, n_ in (('median', med, noise[k][0]), ('p99', p99, noise[k][1]), ('worst', worst, noise[k][2])):
+            if v_ > BF16_NOISE_FACTOR * n_ + 1e-7:      # (1e-7: fp32 rounding of a tensor no perturbation moved)
+                bad.append(f'{k} {nm_}: {v_:.2e} > {BF16_NOISE_FACTOR:g} x {n_:.2e}')
+    line = (f'{what}: {len(sizes)} pairs, {layers} layers, bf16 (ROT scale {rot_scale:g}), relative to each tensor\'s largest '
+            f'magnitude - ' + '; '.join(lines) + f'; loss {float(loss.detach()):.4f} vs oracle {ref_loss:.4f} (oracle moves by '
+            f'{loss_noise:.1e} under the perturbations)')
     print(line)
     if report is not None:
         report.append(line)
-    assert eh <= 2e-2 and ex <= 2e-3, line
-    # the whole-model OUTPUTS at this ROT scale (10: the keypoint softmax amplifies the layers' rounding noise ~1.3x instead
-    # of 18x, see BF16_ROT_SCALE): every output within `out_bound` of the oracle's (relative to the output's largest
-    # magnitude; worst element over all pairs), the loss within 10 %.  Measured: 5.9e-3 on the simulator case (3 pairs, 4
-    # layers), 7.0e-2 at config C on MI355X (64 pairs x 600 residues, 8 layers: the worst of 38 400 ligand coordinates and
-    # 6 400 keypoints; profiles/r05_e_pytest_gpu_sel.log) - the bound is 2e-2 below 1 000 nodes and 1.5e-1 above
-    worst = 0.0
-    for o_got, o_ref in zip(outs, ref):      # five outputs, each a list with one tensor per pair
-        a, b_ = cat_out(list(o_got)).detach().cpu().double(), cat_out(list(o_ref)).detach().cpu().double()
-        worst = max(worst, float((a - b_).abs().max()) / max(1.0, float(b_.abs().max())))
-    out_bound = BF16_OUT_TOL if sum(a + b_ for a, b_ in sizes) < 1000 else 1.5e-1
-    line2 = f'{what}: bf16 whole-model outputs vs the oracle (ROT scale {rot_scale:g}): worst rel err {worst:.2e} (bound {out_bound:g})'
-    print(line2)
-    if report is not None:
-        report.append(line2)
-    assert worst <= out_bound, line2
-    assert abs(float(loss.detach()) - ref_loss) <= 0.10 * abs(ref_loss), line
+    assert not bad, f'{what}: beyond {BF16_NOISE_FACTOR:g} x the oracle\'s own noise: ' + ', '.join(bad) + ' | ' + line
+    assert abs(float(loss.detach()) - ref_loss) <= BF16_NOISE_FACTOR * loss_noise + 1e-6 * abs(ref_loss), line
     for T in outs[3]:
         t = T.detach().cpu()
         close(t @ t.t(), torch.eye(3), tol=1e-4, what='bf16 T T^T')
@@ -2163,6 +2198,121 @@ def check_protein_graph_case(dev, name):
     if name == 'tiny':
         n = len(lig)
         assert n < int(z['max_neighbor']) and int(gl['src'].numel()) == n * (n - 1)
+
+
+def _seeded_rigid(seed, translation_interval=5.0):
+    rng = np.random.default_rng(seed)
+    q, r = np.linalg.qr(rng.normal(size=(3, 3)))
+    q = q * np.sign(np.diag(r))
+    if np.linalg.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    t = rng.normal(size=3)
+    t *= rng.uniform(0.0, translation_interval) / np.linalg.norm(t)
+    return q, t
+
+
+def check_real_structure_pipeline(dev, name):
+    """From the STRUCTURE to the outputs, every step in the HIP library, against the reference run end to end
+    (tests/golden/case_F_real_*.npz, oracle/make_golden_real.py: the reference's own graph builder on real DB5.5 complexes ->
+    the imported reference model, outputs + every parameter gradient).  The fixture's residues' atoms go through
+    equidock_public_amd.featurize (eqd_protein_graph_*: k-NN by mean all-atom distance, 27 edge features, mu_r_norm; int32
+    endpoints bit-equal to the reference's graph), the ligand gets the recorded pose (the fixture's new_x), and the HIP model's
+    outputs and gradients are compared with the REFERENCE's at the usual bounds - the features the kernels computed differ
+    from the reference's by float32 rounding (1e-6), which the model carries to its outputs within the 1e-4 bar.
+    src/utils/protein_utils.py:201-416 + src/model/rigid_docking_model.py:642-692."""
+    from equidock_public_amd import featurize as FZ
+    z, meta, args, raw = load_case(name)
+    sd = state_dict_for(meta, args)
+    net = build_model(args, sd, dev)
+    ref_pairs = pairs_from_raw(raw)
+    pairs = []
+    for i, (rl, rr) in enumerate(ref_pairs):
+        lig_all, rec_all = _residues_from_fixture(z, f'p{i}_lig_in_'), _residues_from_fixture(z, f'p{i}_rec_in_')
+        lig, rec, lig_ca, rec_ca = FZ.preprocess_unbound_bound(lig_all, rec_all, inference=True)
+        assert np.array_equal(lig_ca, z[f'p{i}_lig_ca']) and np.array_equal(rec_ca, z[f'p{i}_rec_ca'])
+        gl, gr = FZ.protein_to_graph_unbound_bound(lig, rec, lig_ca, rec_ca, cutoff=float(z['cutoff']),
+                                                   max_neighbor=int(z['max_neighbor']), device=dev)
+        sync(dev)
+        for nm, g_, r_ in (('ligand', gl, rl), ('receptor', gr, rr)):      # the graph the kernels built IS the reference's
+            assert np.array_equal(g_['src'].cpu().numpy(), r_['src']), f'{name} pair {i} {nm}: source indices differ'
+            assert np.array_equal(g_['dst'].cpu().numpy(), r_['dst']), f'{name} pair {i} {nm}: destination indices differ'
+            assert np.array_equal(g_['res_feat'].cpu().numpy(), r_['res_feat'])
+            close(g_['he'], torch.from_numpy(r_['he']), tol=1e-6, what=f'{name} pair {i} {nm} edge features')
+            close(g_['mu_r_norm'], torch.from_numpy(r_['mu_r_norm']), tol=1e-6, what=f'{name} pair {i} {nm} mu_r_norm')
+        pairs.append((dict(gl, new_x=torch.from_numpy(rl['new_x']).to(dev)), gr))
+    g = G.batch_pairs(pairs).to(dev)
+    outs = net(g, epoch=0)
+    worst = 0.0
+    for nm, lst in zip(('lig', 'Yl', 'Yr', 'T', 'b'), outs):
+        ref = torch.from_numpy(z['out_' + nm])
+        close(cat_out(lst), ref, what=f'{name} (structure -> HIP graph -> HIP model) {nm}')
+        worst = max(worst, float((cat_out(lst).detach().cpu() - ref).abs().max()) / max(1.0, float(ref.abs().max())))
+    assert net.iegmn_original.last_svd_status.cpu().tolist() == meta['svd_iters']
+    loss = port.scalar_loss(outs)
+    loss.backward()
+    sync(dev)
+    assert abs(float(loss.detach()) - float(z['loss'])) <= 1e-4 * abs(float(z['loss']))
+    w2 = wm = 0.0
+    gf = meta['grad_fingerprint']
+    for k, p in net.named_parameters():
+        if 'grad_' + k in z.files:
+            ref = torch.from_numpy(z['grad_' + k])
+            grad_close(p.grad, ref, what=f'{name} (from the structure) grad {k}')
+            e2, em = grad_err(p.grad, ref)
+            w2, wm = max(w2, e2), max(wm, em)
+        else:
+            nrm = gf[k][1]
+            assert abs(float(p.grad.double().norm().cpu()) - nrm) <= 2e-3 * max(nrm, 1e-6), f'{name} grad norm {k}'
+    line = (f'{name}: structure -> eqd_protein_graph_* -> HIP model vs the reference end to end: max rel output err {worst:.2e}, '
+            f'worst gradient rel-L2 {w2:.2e}, max-abs/max {wm:.2e} (vs the golden gradient, the reference\'s LeakyReLU decisions)')
+    print(line)
+    return line
+
+
+def check_real_ragged_batch_vs_oracle(dev, report=None):
+    """A ragged batch of REAL graphs - 1DE4's 1 270-residue ligand with a 40-residue partner beside the DIPS-sized 2J7P pair
+    (tests/golden/graph_case_{big,pair300}.npz: the atoms; the graphs are built by the HIP graph kernels and are bit-equal in
+    their indexing to the reference's, test_protein_graph_more_reference_complexes) - through the 8-layer model against the
+    oracle on the host with the library's LeakyReLU decisions, at the usual bounds.  Real k-NN graphs have other distance /
+    RBF / mu_r_norm statistics than the synthetic generator's, and this batch has a 1 270 x 40 attention problem beside a
+    259 x 286 one."""
+    import os
+    from equidock_public_amd import featurize as FZ
+    pairs = []
+    for i, nm in enumerate(('big', 'pair300')):
+        z = np.load(os.path.join(os.path.dirname(__file__), 'golden', f'graph_case_{nm}.npz'))
+        lig_all, rec_all = _residues_from_fixture(z, 'lig_in_'), _residues_from_fixture(z, 'rec_in_')
+        lig, rec, lig_ca, rec_ca = FZ.preprocess_unbound_bound(lig_all, rec_all, inference=True)
+        gl, gr = FZ.protein_to_graph_unbound_bound(lig, rec, lig_ca, rec_ca, cutoff=float(z['cutoff']),
+                                                   max_neighbor=int(z['max_neighbor']), device=dev)
+        sync(dev)
+        assert np.array_equal(gl['src'].cpu().numpy(), z['lig_src']) and np.array_equal(gr['dst'].cpu().numpy(), z['rec_dst'])
+        rot, t = _seeded_rigid(200 + i)
+        xl = gl['x'].double().cpu().numpy()
+        new_x = ((rot @ (xl - xl.mean(0, keepdims=True)).T).T + t).astype(np.float32)
+        pairs.append((dict(gl, new_x=torch.from_numpy(new_x).to(dev)), gr))
+    args = port.default_args(iegmn_n_lays=8, skip_weight_h=0.75)
+    sd = port.init_state_dict(args, seed=9, rot_scale=40.0)
+    net = build_model(args, sd, dev)
+    g = G.batch_pairs(pairs).to(dev)
+    outs = net(g, epoch=0)
+    port.scalar_loss(outs).backward()
+    sync(dev)
+    assert net.iegmn_original.last_svd_status.cpu().tolist() == [0, 0], 'SVD guard fired'
+    raw = port.raw_from_graph(g)
+    ref, grads, flips = oracle_given(net, g, sd, args, raw, faithful=False)
+    worst = 0.0
+    for nm, a, b in zip(('lig', 'Yl', 'Yr', 'T', 'b'), outs, ref):
+        got, exp = cat_out(a), cat_out(b)
+        close(got, exp, what=f'real ragged batch output {nm}')
+        worst = max(worst, float((got.detach().cpu() - exp.detach()).abs().max()) / max(1.0, float(exp.detach().abs().max())))
+    w2, wm = compare_grads(net, grads, 'real ragged batch', GRAD_L2, GRAD_MX)
+    line = (f'real ragged batch (1DE4 1270 + 40, 2J7P 259 + 286 residues; graphs by the HIP graph kernels), 8 layers: max rel output '
+            f'err {worst:.2e}; gradients vs the oracle with the library\'s LeakyReLU decisions (plain): worst rel-L2 {w2:.2e}, '
+            f'max-abs/max {wm:.2e}; decisions that differ from the oracle\'s own: {sum(n for _, n, _ in flips)}')
+    print(line)
+    if report is not None:
+        report.append(line)
 
 
 def check_inference_postprocessing(dev):

@@ -31,6 +31,54 @@ def test_hip_library_builds_and_exports_header_symbols():
     assert handle.eqd_tile_edges() == G.TILE_EDGES
 
 
+def _gfx950_kernel_notes(lib):
+    """[(mangled kernel name, {note field: value})] of every gfx950 code object bundled in `lib` (llvm-objcopy + llvm-readelf)."""
+    import struct
+    import subprocess
+    import tempfile
+    llvm = '/opt/rocm/lib/llvm/bin/'
+    out = []
+    with tempfile.TemporaryDirectory() as d:
+        fat = os.path.join(d, 'fat.bin')
+        subprocess.check_call([llvm + 'llvm-objcopy', '-O', 'binary', '--only-section=.hip_fatbin', lib, fat])
+        data = open(fat, 'rb').read()
+        starts = [m.start() for m in re.finditer(b'__CLANG_OFFLOAD_BUNDLE__', data)]
+        for bi, p0 in enumerate(starts):
+            blob = data[p0:(starts[bi + 1] if bi + 1 < len(starts) else len(data))]
+            n = struct.unpack_from('<Q', blob, 24)[0]
+            off = 32
+            for _ in range(n):
+                o, size, tl = struct.unpack_from('<QQQ', blob, off)
+                off += 24
+                triple = blob[off:off + tl].decode()
+                off += tl
+                if 'gfx950' not in triple:
+                    continue
+                co = os.path.join(d, 'x.co')
+                open(co, 'wb').write(blob[o:o + size])
+                txt = subprocess.run([llvm + 'llvm-readelf', '--notes', co], capture_output=True, text=True, check=True).stdout
+                for blk in re.split(r'\n\s+- \.agpr_count:', txt)[1:]:
+                    name = re.search(r'\.name:\s+(\S+)', blk).group(1)
+                    fields = dict(re.findall(r'\.(\w+):\s+(\S+)', blk))
+                    fields['agpr_count'] = blk.split()[0]
+                    out.append((name, fields))
+    return out
+
+
+def test_no_kernel_uses_scratch_memory():
+    """Every kernel of the shipped gfx950 library has .private_segment_fixed_size == 0 (no register spills, no stack
+    objects): scratch appeared three times through compiler behaviour alone ("compiler behaviours"), each time
+    unnoticed until a profile showed it."""
+    from equidock_public_amd import build as hip_build
+    lib = hip_build.build(verbose=False)
+    notes = _gfx950_kernel_notes(lib)
+    assert len(notes) > 100, len(notes)
+    bad = [(n, f['private_segment_fixed_size'], f.get('vgpr_spill_count')) for n, f in notes
+           if int(f['private_segment_fixed_size']) != 0 or int(f.get('vgpr_spill_count', 0)) != 0
+           or f.get('uses_dynamic_stack') == 'true']      # (SGPR spills go to VGPR lanes, not to memory: not counted)
+    assert not bad, bad
+
+
 def test_product_refuses_cpu_tensors():
     from equidock_public_amd import _lib
     _lib.unload_for_testing()

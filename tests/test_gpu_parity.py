@@ -120,10 +120,26 @@ def test_keypoint_kernel_forms(dev, form, monkeypatch):
     assert ('k_keypoint_bwd' in names) == (form != 'first') and ('k_keypoint_bwd_a' in names) == (form == 'first'), sorted(set(names))
 
 
-@pytest.mark.parametrize('name', ['A_b1_shared5', 'B_b3_dips8', 'C_b2_200', 'D_degraded3', 'E_svd_guard'])
+@pytest.mark.parametrize('name', ['A_b1_shared5', 'B_b3_dips8', 'C_b2_200', 'D_degraded3', 'E_svd_guard',
+                                  'F_real_1GL1', 'F_real_2J7P', 'F_real_batch2'])
 def test_model_vs_golden(dev, name):
+    """F_real_*: the real reference model on the graphs the reference's own builder made from real DB5.5 structures
+    (oracle/make_golden_real.py)"""
     from tests import parity_common as pc
     pc.check_model_case(dev, name)
+
+
+@pytest.mark.parametrize('name', ['F_real_1GL1', 'F_real_2J7P', 'F_real_batch2'])
+def test_real_structure_to_outputs_vs_reference(dev, name):
+    """atoms -> HIP graph kernels -> HIP model against the reference run end to end on the same structure"""
+    from tests import parity_common as pc
+    REPORT.append(pc.check_real_structure_pipeline(dev, name))
+
+
+def test_real_ragged_batch_vs_oracle(dev):
+    """1DE4 (1 270 + 40 residues) beside 2J7P (259 + 286): real graphs from the HIP graph kernels, model vs the oracle"""
+    from tests import parity_common as pc
+    pc.check_real_ragged_batch_vs_oracle(dev, report=REPORT)
 
 
 @pytest.mark.parametrize('name', ['D_degraded3', 'B_b3_dips8'])

@@ -5,10 +5,10 @@ import pytest
 import torch
 
 from oracle import iegmn_port as port
-from tests.util import CASES, cat_out, load_case, state_dict_for
+from tests.util import CASES, REAL_CASES, cat_out, load_case, state_dict_for
 
 
-@pytest.mark.parametrize('name', CASES)
+@pytest.mark.parametrize('name', CASES + REAL_CASES)
 @pytest.mark.parametrize('faithful', [True, False])
 def test_port_forward_matches_reference(name, faithful):
     z, meta, args, raw = load_case(name)
@@ -22,15 +22,19 @@ def test_port_forward_matches_reference(name, faithful):
     assert inter['svd_iters'] == meta['svd_iters']
     for nm, lst in zip(('lig', 'Yl', 'Yr', 'T', 'b'), outs):
         got = cat_out(lst).numpy()
-        np.testing.assert_allclose(got, z['out_' + nm], rtol=1e-5, atol=1e-5, err_msg=nm)
+        # (real structures: coordinates up to 70 A, and a batch-wide softmax row of the reference sums in another order than the
+        #  per-pair rows of the block-diagonal form - 6e-6 of the output's magnitude on the two-complex batch)
+        atol = 1e-5 * max(1.0, float(np.abs(z['out_' + nm]).max())) if name in REAL_CASES else 1e-5
+        np.testing.assert_allclose(got, z['out_' + nm], rtol=1e-5, atol=atol, err_msg=nm)
     L = args['iegmn_n_lays']
     for i in sorted({0, 1, L - 1}):
         li = inter['layers'][i]
-        np.testing.assert_allclose(torch.cat([li['x_l'], li['x_r']]).numpy(), z[f'layer{i}_x'], rtol=1e-5, atol=1e-5)
-        np.testing.assert_allclose(torch.cat([li['h_l'], li['h_r']]).numpy(), z[f'layer{i}_h'], rtol=1e-5, atol=1e-5)
+        for key, got in ((f'layer{i}_x', torch.cat([li['x_l'], li['x_r']])), (f'layer{i}_h', torch.cat([li['h_l'], li['h_r']]))):
+            atol = 1e-5 * max(1.0, float(np.abs(z[key]).max())) if name in REAL_CASES else 1e-5
+            np.testing.assert_allclose(got.numpy(), z[key], rtol=1e-5, atol=atol, err_msg=key)
 
 
-@pytest.mark.parametrize('name', ['A_b1_shared5', 'D_degraded3'])
+@pytest.mark.parametrize('name', ['A_b1_shared5', 'D_degraded3', 'F_real_1GL1'])
 def test_port_gradients_match_reference(name):
     z, meta, args, raw = load_case(name)
     sd = state_dict_for(meta, args)

@@ -243,6 +243,12 @@ def test_protein_graph_more_reference_complexes(name):
     pc.check_protein_graph_case(DEV, name)
 
 
+def test_real_structure_to_outputs_vs_reference():
+    """1GL1: atoms -> graph kernels -> model kernels (all on the simulator) against the reference run end to end
+    (tests/golden/case_F_real_1GL1.npz; the GPU suite also runs 2J7P and the two-complex batch)"""
+    pc.check_real_structure_pipeline(DEV, 'F_real_1GL1')
+
+
 def test_inference_postprocessing():
     pc.check_inference_postprocessing(DEV)
 

@@ -9,6 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 CASES = ['A_b1_shared5', 'B_b3_dips8', 'C_b2_200', 'D_degraded3', 'E_svd_guard']
+# the real reference model on graphs the reference's own builder made from real DB5.5 structures (oracle/make_golden_real.py)
+REAL_CASES = ['F_real_1GL1', 'F_real_2J7P', 'F_real_batch2']
 
 
 def load_case(name):
