@@ -776,6 +776,73 @@ def time_inference(net, g, ppg, dev, steps=30, warmup=5):
             "ms_per_forward": round(dt / steps * 1e3, 4), "steps": steps, "warmup": warmup, "launch_mode": "hipGraph replay"}
 
 
+def time_train_step(R, dev, world, use_dist, backend, steps=20, warmup=5, n_pocket=30):
+    """The reference's TRAINING step on this workload's batch (src/train.py:98-154): model -> MSE + pocket OT (exact EMD,
+    solved on the host) + body intersection -> backward (-> all-reduce under a process group), through
+    equidock_public_amd.train_step.TrainStep: three hipGraphs around the one host join.  Never the headline `value`
+    (BASELINE.json's metric is the IEGMN forward + backward alone); `ot_exposed_ms` = the GPU-timeline gap the host solve and
+    its two copies leave between the graphs.  Bound ligand / receptor coordinates: the pairs' own x; pocket points: a seeded
+    subset of `n_pocket` residues per protein (DB5.5 pockets have a few dozen residues)."""
+    import numpy as np
+    from equidock_public_amd import train_step as TS
+    rng = np.random.default_rng(77)
+    lig_t = torch.cat([torch.from_numpy(p[0]['x']) for p in R.pairs])
+    rec_t = torch.cat([torch.from_numpy(p[1]['x']) for p in R.pairs])
+    pl, pr = [], []
+    for lig, rec in R.pairs:
+        n = min(n_pocket, lig['x'].shape[0], rec['x'].shape[0])
+        pl.append(torch.from_numpy(lig['new_x'][rng.permutation(lig['x'].shape[0])[:n]].copy()))
+        pr.append(torch.from_numpy(rec['x'][rng.permutation(rec['x'].shape[0])[:n]].copy()))
+    ts = TS.TrainStep(R.net, R.g, lig_t, rec_t, pl, pr, reducer=R.reducer, allreduce=bool(use_dist and backend == 'nccl'))
+    l_eager = float(ts.step_eager().detach())
+    torch.cuda.synchronize()
+    g_eager = R.reducer.flat.clone()
+    ts.capture()
+    import torch.distributed as dist
+    for _ in range(warmup):
+        ts.step()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = ts.step()
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if use_dist:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if abs(float(loss) - l_eager) > 1e-5 * abs(l_eager) or \
+            (not use_dist and float((R.reducer.flat - g_eager).abs().max()) > 1e-5 * float(g_eager.abs().max())):
+        raise RuntimeError(f"graph form of the training step disagrees with its autograd form: {float(loss)} vs {l_eager}")
+    exposed, solve = [], []
+    for _ in range(10):      # outside the timed region: the gap on the GPU timeline and the host solve alone
+        ts.step()
+        exposed.append(ts.last_ot_exposed_ms())
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        ts._solve_on_host()
+        solve.append((time.perf_counter() - t1) * 1e3)
+    t1 = time.perf_counter()
+    for _ in range(5):
+        ts.step_eager()
+    torch.cuda.synchronize()
+    dt_eager = (time.perf_counter() - t1) / 5
+    ms = dt / steps * 1e3
+    return {"metric": "protein-pairs/sec of the reference's training step (model fwd + MSE / pocket-OT / intersection losses + bwd)",
+            "value": round(R.ppg * world * steps / dt, 2), "unit": "pairs/s", "ms_per_step": round(ms, 4), "steps": steps,
+            "warmup": warmup, "loss": float(loss), "pocket_points_per_pair": n_pocket,
+            "ot_exposed_ms": round(sorted(exposed)[len(exposed) // 2], 4),
+            "host_solve_ms": round(sorted(solve)[len(solve) // 2], 4),
+            "model_only_ms_per_step": round(R.dt / R.steps * 1e3, 4),
+            "autograd_form_ms_per_step": round(dt_eager * 1e3, 4),
+            "launch_mode": "three hipGraphs (forward + cost matrices | pair terms | OT terms + backward) around one host join",
+            "weights": {"pocket_ot": ts.w_ot, "intersection": ts.w_int, "sigma": ts.sigma, "surface_ct": ts.ct}}
+
+
 def north_star_hbm_entry(rl):
     """north_star's "achieved HBM bandwidth on the IEGMN message kernel": per edge kernel the live launch time of THIS run
     with (i) the algorithmic bytes and (ii) the rocprofv3-measured bytes of the committed PMC pass."""
@@ -929,11 +996,21 @@ def main():
                     # the message kernels of this workload, timed standalone like the primary "roofline" (north_star_hbm)
                     ns_hbm[key] = north_star_hbm_entry(edge_kernel_rooflines(R2.net, R2.packed, dev, wl,
                                                                              bf16=(R2.dtype == 'bf16')))
+                if key in ('C_bf16', 'D'):      # the reference's full training step on the bf16 configuration
+                    try:
+                        secondary['train_step_' + key] = time_train_step(R2, dev, world, use_dist, backend, steps=10, warmup=3)
+                    except Exception as e:
+                        secondary['train_step_' + key] = {"error": f"{type(e).__name__}: {e}"}
                 secondary[key]["wall_s_incl_setup"] = round(time.perf_counter() - t_sec, 2)
                 del R2
             except Exception as e:      # the primary line must not die on a secondary workload
                 secondary[key] = {"error": f"{type(e).__name__}: {e}"}
             torch.cuda.empty_cache()
+    if a.workload == 'B' and a.dropout == 0 and not a.eager and not a.no_secondary:
+        try:
+            secondary['train_step_B'] = time_train_step(R, dev, world, use_dist, backend)
+        except Exception as e:
+            secondary['train_step_B'] = {"error": f"{type(e).__name__}: {e}"}
     # inference (src/inference_rigid.py:194: the forward alone, no state kept): the primary workload's batch under
     # torch.no_grad(), replayed from its own hipGraph, timed like the step
     inference = None

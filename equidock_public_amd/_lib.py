@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libequidock_hip.so')
 
 EQD_MAX_SRC = 6
-ABI_VERSION = 8
+ABI_VERSION = 9
 PARAMS_PER_LAYER = 19
 GLOBAL_PARAMS = 5
 
@@ -71,7 +71,7 @@ class EqdEdgeParams(C.Structure):
                 ('bc1', C.c_void_p), ('wc2', C.c_void_p), ('bc2', C.c_void_p), ('slope', C.c_float),
                 ('ln_eps', C.c_float), ('eta', C.c_float), ('use_dist', C.c_int32), ('use_he', C.c_int32),
                 ('bf16', C.c_int32), ('drop_z1', C.c_void_p), ('drop_ch', C.c_void_p), ('drop_scale', C.c_float),
-                ('aggr_bf16', C.c_void_p)]
+                ('aggr_bf16', C.c_void_p), ('xh_save', C.c_void_p), ('rstd_save', C.c_void_p), ('zpos_save', C.c_void_p)]
 
 
 class EqdNodeUpdateParams(C.Structure):
@@ -129,7 +129,7 @@ def _declare(lib):
         getattr(lib, name).restype = C.c_int
 
 
-EXPORTS = ('eqd_model_layer_state', 'eqd_model_lrelu_signs', 'eqd_model_head_backward', 'eqd_profile_begin', 'eqd_profile_end', 'eqd_profile_mark', 'eqd_profile_name', 'eqd_profile_us', 'eqd_ctx_create', 'eqd_ctx_destroy', 'eqd_abi_version', 'eqd_last_error', 'eqd_tile_edges', 'eqd_is_simulator', 'eqd_model_saved_bytes',
+EXPORTS = ('eqd_model_layer_state', 'eqd_model_lrelu_signs', 'eqd_model_head_backward', 'eqd_profile_begin', 'eqd_profile_end', 'eqd_profile_mark', 'eqd_profile_name', 'eqd_profile_us', 'eqd_ctx_create', 'eqd_ctx_destroy', 'eqd_abi_version', 'eqd_last_error', 'eqd_tile_edges', 'eqd_is_simulator', 'eqd_model_saved_bytes', 'eqd_model_saved_layout',
            'eqd_model_scratch_bytes', 'eqd_model_check', 'eqd_model_forward', 'eqd_model_backward', 'eqd_linear',
            'eqd_atb_partial_bytes', 'eqd_atb', 'eqd_edge_message_fwd', 'eqd_edge_message_bwd_workspace_bytes',
            'eqd_edge_message_bwd', 'eqd_edge_message_bwd_kernel_only', 'eqd_cross_attention_fwd',

@@ -749,6 +749,19 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_attn_bwd80_gather(EqdGraph G, con
 
 // ---------------------------------------------------------------------------------------------
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+// The tile loaders address their tensors through buffer descriptors with 32-bit byte counts and lane offsets (tile_load:
+// 64 * DB <= 320 B per row; lb_load: 256 B per row): a tensor must stay below 2^31 bytes, i.e. 6.7 million rows.  Beyond
+// that the offsets would wrap and rows come back as zeros without an error - refused here instead (the 288 GB of one
+// MI355X hold ~400 million residues of saved state at 8 layers, so this is a guard, not a limit anyone meets).
+#define EQD_ATT_MAX_ROWS 6000000
+static int attn_rows_ok(const EqdGraph* g, const char* who) {
+    if (g->n_nodes > EQD_ATT_MAX_ROWS) {
+        eqd_set_error("%s: %d nodes in one batch; the attention kernels' 32-bit tile offsets allow %d", who, g->n_nodes,
+                      EQD_ATT_MAX_ROWS);
+        return EQD_ERR_UNSUPPORTED;
+    }
+    return EQD_OK;
+}
 
 template <int DB, bool FAST, int NB, bool BF = false>
 static int attn_launch_fwd(const EqdGraph* g, int d, const float* q, const float* k, const float* v, float* out,
@@ -796,6 +809,7 @@ extern "C" int eqd_cross_attention_fwd(const EqdGraph* g, int d, const float* q,
         eqd_set_error("eqd_cross_attention_fwd: NULL argument");
         return EQD_ERR_NULL;
     }
+    if (int rc = attn_rows_ok(g, "eqd_cross_attention_fwd")) return rc;
     if (d <= 0 || d > 80) {
         eqd_set_error("eqd_cross_attention_fwd: feature width %d outside 1..80", d);
         return EQD_ERR_UNSUPPORTED;
@@ -822,6 +836,7 @@ static int attention_bwd_f32(const EqdGraph* g, int d, const float* q, const flo
         eqd_set_error("eqd_cross_attention_bwd: NULL argument");
         return EQD_ERR_NULL;
     }
+    if (int rc = attn_rows_ok(g, "eqd_cross_attention_bwd")) return rc;
     if (d <= 0 || d > 80) {
         eqd_set_error("eqd_cross_attention_bwd: feature width %d outside 1..80", d);
         return EQD_ERR_UNSUPPORTED;
@@ -863,6 +878,7 @@ int eqd_attention_fwd_bf16_impl(const EqdGraph* g, int d, const float* q, const 
         eqd_set_error("eqd_cross_attention_fwd_bf16: NULL argument");
         return EQD_ERR_NULL;
     }
+    if (int rc = attn_rows_ok(g, "eqd_cross_attention_fwd_bf16")) return rc;
     if ((d != 64 && d != 80) || !(aligned16(q) && aligned16(k) && aligned16(v))) {
         eqd_set_error("eqd_cross_attention_fwd_bf16: needs d = 64 or 80 and 16-byte aligned operands (d = %d)", d);
         return EQD_ERR_UNSUPPORTED;
@@ -899,6 +915,7 @@ static int attention_bwd_bf16(const EqdGraph* g, int d, const float* q, const fl
         eqd_set_error("eqd_cross_attention_bwd_bf16: NULL argument");
         return EQD_ERR_NULL;
     }
+    if (int rc = attn_rows_ok(g, "eqd_cross_attention_bwd_bf16")) return rc;
     if ((d != 64 && d != 80) || !(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(d_out) && aligned16(out))) {
         eqd_set_error("eqd_cross_attention_bwd_bf16: needs d = 64 or 80 and 16-byte aligned operands (d = %d)", d);
         return EQD_ERR_UNSUPPORTED;
@@ -1002,6 +1019,7 @@ static int attention_bwd_ds(const EqdGraph* g, int d, const float* q, const floa
         eqd_set_error("attention backward: saved bf16 q / k / v are only read by the bf16 kernels of the 64-wide layers");
         return EQD_ERR_UNSUPPORTED;
     }
+    if (int rc = attn_rows_ok(g, "attention backward")) return rc;
     if (d == 80) {
         static thread_local EqdRedArg RA8;
         EqdGatherArgs GA8;

@@ -36,7 +36,7 @@ struct LbRegs {
 // On the GPU the loads are BUFFER loads whose descriptor ends behind the range's last row: the hardware returns zeros for
 // the rows beyond it (LB_ZERO_FILLED), no address clamp per row and no zeroing selects when the tile is stored (those were
 // 64 v_cndmask per tile); the descriptor is wave-uniform (r1, the end of the work item's range, is the same for the whole
-// workgroup but arrives in a vector register, hence the readfirstlane).  Byte offsets are 32-bit: tensors of up to 2^24 rows.
+// workgroup but arrives in a vector register, hence the readfirstlane).  Byte offsets are 32-bit signed: tensors of up to 2^23 rows (the launchers refuse more than EQD_ATT_MAX_ROWS, eqd_attn_kernels.hip).
 // The host simulator keeps the clamped plain loads.
 #if defined(EQD_HOSTSIM) || defined(EQD_NO_BUFFER_LOADS)
 #define LB_ZERO_FILLED 0

@@ -536,7 +536,7 @@ int eqd_edge_attn_fwd(const EqdGraph* g, const EqdEdgeParams* p, const float* P,
                       float* att_out, float* lse, hipStream_t st);
 int eqd_keypoint_pool_fwd_impl(const EqdGraph* g, int n_heads, const float* Wk, const float* Wq, const float* qmean,
                                const float* H, const float* Z, float* Y, float* Y_lig_out, float* Y_rec_out,
-                               float* scores, float* lse, float* qp, float* u, hipStream_t st);
+                               float* scores, float* lse, float* qp, float* u, hipStream_t st, float* Yc = nullptr);
 int eqd_kabsch_fwd_impl(int n_pairs, int n_heads, const float* Y, const float* svd_draws, int svd_seed, float* T,
                         float* T2, float* b, float* A_out, int32_t* status, hipStream_t st, const EqdGraph* g = nullptr,
                         float* lig_out = nullptr, double* usv = nullptr);

@@ -51,6 +51,10 @@ struct LayerSaved {
     // batches): written by the projections as bf16 ([N][64]) and read as bf16 by the attention forward and backward; no fp32
     // form exists then (qa / ka / va NULL).  NULL otherwise.
     uint16_t *qa_b, *ka_b, *va_b;
+    // saved per-edge state of the edge-message forward (EqdEdgeParams.xh_save / rstd_save / zpos_save): the backward loads it
+    // instead of recomputing the first Linear + LeakyReLU + LayerNorm statistics.  NULL: the backward recomputes.
+    float *xh_e, *rstd_e;
+    uint16_t* zpos_e;
 };
 struct Saved {
     float* h[64 + 1];
@@ -59,12 +63,13 @@ struct Saved {
     float* x[64 + 1];
     LayerSaved lay[64];
     float *hm, *qmean, *qp, *u, *scores, *klse, *Y, *A, *T;
+    float* Yc;       // [2 B][K][3] keypoints relative to their segment's first node (the keypoint backward's softmax)
     double* usv;     // [B][21] U, S, V of the Kabsch SVD (fp64), reused by the backward
 };
 
 // A: the saved state (forward -> backward); T: transients of the forward (bf16 storage mode only; the same arena as A when
 // the forward keeps no state).  bfs = EqdModelDesc.storage_bf16.
-void carve_saved(const Dims& D, const EqdGraph* g, EqdArena& A, Saved& S, bool bfs, EqdArena& T, bool qkv_b = false) {
+void carve_saved(const Dims& D, const EqdGraph* g, EqdArena& A, Saved& S, bool bfs, EqdArena& T, bool qkv_b, bool esave) {
     const size_t N = (size_t)D.N;
     S.bfs = bfs;
     (void)T;
@@ -131,11 +136,23 @@ void carve_saved(const Dims& D, const EqdGraph* g, EqdArena& A, Saved& S, bool b
     S.A = A.take<float>((size_t)D.B * 9);
     S.usv = A.take<double>((size_t)D.B * 21);
     S.T = A.take<float>((size_t)D.B * 9);
+    S.Yc = A.take<float>((size_t)2 * D.B * D.K * 3);
+    // the per-edge state comes LAST: everything above lies where it lay without it
+    for (int l = 0; l < D.L; ++l) {
+        LayerSaved& Ls = S.lay[l];
+        Ls.xh_e = Ls.rstd_e = nullptr;
+        Ls.zpos_e = nullptr;
+        if (esave) {
+            Ls.xh_e = A.take<float>((size_t)D.E * 64);
+            Ls.rstd_e = A.take<float>((size_t)D.E);
+            Ls.zpos_e = A.take<uint16_t>((size_t)D.E * 4);
+        }
+    }
 }
 // the saved part alone (the backward and the test aids: the transients are dead by then and get no memory)
-void carve_saved(const Dims& D, const EqdGraph* g, EqdArena& A, Saved& S, bool bfs, bool qkv_b) {
+void carve_saved(const Dims& D, const EqdGraph* g, EqdArena& A, Saved& S, bool bfs, bool qkv_b, bool esave) {
     EqdArena none(nullptr, 0);
-    carve_saved(D, g, A, S, bfs, none, qkv_b);
+    carve_saved(D, g, A, S, bfs, none, qkv_b, esave);
 }
 // bf16 storage mode: are q / k / v of the 64-wide layers saved as bf16?  Exactly when eqd_launch_attention_bwd_gather will
 // run their backward in the dS hand-off form on the bf16 LDS kernels - the only kernels that read the bf16 form (same
@@ -143,6 +160,20 @@ void carve_saved(const Dims& D, const EqdGraph* g, EqdArena& A, Saved& S, bool b
 // backward agree).
 bool qkv_saved_bf16(const Dims& D, const EqdModelDesc* m, const EqdGraph* g) {
     return m->storage_bf16 && m->cross_msgs && D.dh == 64 && eqd_attention_ds_wanted(g, 64, true);
+}
+// Does a training forward save the per-edge state of its edge-message kernels (268 B per edge and layer) for the backward?
+// EQD_EDGE_SAVE = 0 / 1 forces it off / on (A/B runs, tests); the default is in edge_state_default().  Like every EQD_*
+// switch it is snapshotted once per process; eqd_model_saved_layout lets a caller check that a forward and its backward
+// agree (model.py does).
+static bool edge_state_default(const EqdModelDesc* m, const EqdGraph* g) {
+    (void)m;
+    (void)g;
+    return true;
+}
+bool edge_state_saved(const EqdModelDesc* m, const EqdGraph* g) {
+    const char* f = eqd_tunable("EQD_EDGE_SAVE");
+    if (f && (f[0] == '0' || f[0] == '1') && f[1] == 0) return f[0] == '1';
+    return edge_state_default(m, g);
 }
 
 void lin_src(EqdLinJob& J, int i, const float* X, int ldx, int K, const float* W, int w_rs, int w_cs,
@@ -414,12 +445,22 @@ extern "C" int eqd_model_check(const EqdModelDesc* m, const EqdGraph* g) {
     return EQD_OK;
 }
 
+// The layout of the saved-state buffer depends on the process-wide EQD_* switches (which attention-backward form runs,
+// whether the per-edge state is saved): bit 0 = bf16 storage, bit 1 = q / k / v of the 64-wide layers saved as bf16, bit 2 =
+// per-edge state saved.  A forward and its backward must see the same value (eqd_tunables_reload in between is an error the
+// library cannot detect on its own - the buffer is device memory); model.py compares the two and refuses.  -1: bad arguments.
+extern "C" int eqd_model_saved_layout(const EqdModelDesc* m, const EqdGraph* g) {
+    if (eqd_model_check(m, g)) return -1;
+    const Dims D = make_dims(m, g);
+    return (m->storage_bf16 ? 1 : 0) | (qkv_saved_bf16(D, m, g) ? 2 : 0) | (edge_state_saved(m, g) ? 4 : 0);
+}
+
 extern "C" size_t eqd_model_saved_bytes(const EqdModelDesc* m, const EqdGraph* g) {
     if (eqd_model_check(m, g)) return 0;
     Dims D = make_dims(m, g);
     EqdArena A(nullptr, 0);
     Saved S;
-    carve_saved(D, g, A, S, m->storage_bf16 != 0, qkv_saved_bf16(D, m, g));
+    carve_saved(D, g, A, S, m->storage_bf16 != 0, qkv_saved_bf16(D, m, g), edge_state_saved(m, g));
     return A.off + 256;
 }
 // transients of a forward in bf16 storage mode (fp32 h ping-pong, aggr_msg): carved from the scratch workspace
@@ -428,7 +469,7 @@ static size_t forward_transient_bytes(const EqdModelDesc* m, const EqdGraph* g) 
     Dims D = make_dims(m, g);
     EqdArena A(nullptr, 0), T(nullptr, 0);
     Saved S;
-    carve_saved(D, g, A, S, true, T, qkv_saved_bf16(D, m, g));
+    carve_saved(D, g, A, S, true, T, qkv_saved_bf16(D, m, g), edge_state_saved(m, g));
     return T.off + 256;
 }
 
@@ -460,7 +501,7 @@ extern "C" int eqd_model_layer_state(const EqdModelDesc* m, const EqdGraph* g, c
     }
     EqdArena A(const_cast<void*>(saved), saved_bytes);
     Saved S;
-    carve_saved(D, g, A, S, m->storage_bf16 != 0, qkv_saved_bf16(D, m, g));
+    carve_saved(D, g, A, S, m->storage_bf16 != 0, qkv_saved_bf16(D, m, g), edge_state_saved(m, g));
     if (!A.ok) {
         eqd_set_error("eqd_model_layer_state: saved buffer too small");
         return EQD_ERR_WORKSPACE;
@@ -516,7 +557,7 @@ extern "C" int eqd_model_lrelu_signs(const EqdModelDesc* m, const EqdGraph* g, c
     }
     EqdArena A(const_cast<void*>(saved), saved_bytes);
     Saved S;
-    carve_saved(D, g, A, S, m->storage_bf16 != 0, qkv_saved_bf16(D, m, g));
+    carve_saved(D, g, A, S, m->storage_bf16 != 0, qkv_saved_bf16(D, m, g), edge_state_saved(m, g));
     if (!A.ok) {
         eqd_set_error("eqd_model_lrelu_signs: saved buffer too small");
         return EQD_ERR_WORKSPACE;
@@ -623,7 +664,7 @@ extern "C" int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const
     EqdArena A(saved ? saved : scratch, saved ? saved_bytes : scratch_bytes);
     EqdArena Tr(scratch, scratch_bytes);
     Saved S;
-    carve_saved(D, g, A, S, bfs, saved ? Tr : A, qkv_saved_bf16(D, m, g));
+    carve_saved(D, g, A, S, bfs, saved ? Tr : A, qkv_saved_bf16(D, m, g), saved != nullptr && edge_state_saved(m, g));
     if (!A.ok || (bfs && saved && !Tr.ok)) {
         eqd_set_error("eqd_model_forward: workspace too small or missing (state %zu bytes%s)", A.off,
                       bfs && saved ? "; bf16 storage mode also needs the scratch workspace (eqd_model_scratch_bytes) in a "
@@ -694,6 +735,7 @@ extern "C" int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const
         }
         EqdEdgeParams ep = edge_params(D, m, l, p, drop);
         ep.aggr_bf16 = Ls.aggr_b;      // bf16 storage mode: the saved copy (the fp32 aggr_msg is a transient)
+        ep.xh_save = Ls.xh_e; ep.rstd_save = Ls.rstd_e; ep.zpos_save = Ls.zpos_e;      // (NULL unless this forward saves them)
         if (m->cross_msgs && sat == st && !m->storage_bf16) {
             // the two independent halves of the layer: ONE launch when both fit the chip at once (small batches)
             RC(eqd_edge_attn_fwd(g, &ep, Ls.P, Ls.Q, S.x[l], Ls.aggr_msg, S.x[l + 1], da, Ls.qa, Ls.ka, Ls.va, Ls.aggr_cross,
@@ -772,7 +814,7 @@ extern "C" int eqd_model_forward(const EqdModelDesc* m, const EqdGraph* g, const
     const float* Z = S.x[D.L];
     RC(eqd_launch_seg_mean(g, S.hm, S.qmean, st));
     RC(eqd_keypoint_pool_fwd_impl(g, D.K, gp[G_WK], gp[G_WQ], S.qmean, H, Z, S.Y, Y_lig, Y_rec, S.scores, S.klse, S.qp,
-                                  S.u, st));
+                                  S.u, st, S.Yc));
     RC(eqd_kabsch_fwd_impl(D.B, D.K, S.Y, svd_draws, m->svd_seed, S.T, T, b, S.A, svd_status, st, g, lig_out,
                            S.usv));   // + rigid apply
     return EQD_OK;
@@ -793,7 +835,7 @@ static int head_backward(const EqdModelDesc* m, const EqdGraph* g, const Dims& D
     const float* H = S.h[D.L];
     const float* Z = S.x[D.L];
     int du_chunks = 1;      // > 1: the keypoint backward left partial du blocks in W.dscores for k_head_u_bwd to sum
-    RC(eqd_launch_keypoint_bwd(g, K, H, Z, S.scores, S.klse, S.u, W.dY, W.dscores, W.du, W.dHk, dX_L, st, S.Y, &du_chunks));
+    RC(eqd_launch_keypoint_bwd(g, K, H, Z, S.scores, S.klse, S.u, W.dY, W.dscores, W.du, W.dHk, dX_L, st, S.Yc, &du_chunks));
     if (d_h_last) RC(eqd_launch_axpy(W.dHk, d_h_last, 1.f, (size_t)N * 64, st));      // a loss on the last layer's node data
     if (d_x_last) RC(eqd_launch_axpy(dX_L, d_x_last, 1.f, (size_t)N * 3, st));
     RC(eqd_launch_head_u_bwd(g, K, gpar[G_WK], gpar[G_WQ], S.qmean, S.qp, du_chunks > 1 ? W.dscores : W.du, ggrad[G_WK],
@@ -833,7 +875,7 @@ extern "C" int eqd_model_head_backward(const EqdModelDesc* m, const EqdGraph* g,
     g_bf16_mode = m->storage_bf16 ? 1 : 0;
     EqdArena As(const_cast<void*>(saved), saved_bytes);
     Saved S;
-    carve_saved(D, g, As, S, m->storage_bf16 != 0, qkv_saved_bf16(D, m, g));
+    carve_saved(D, g, As, S, m->storage_bf16 != 0, qkv_saved_bf16(D, m, g), edge_state_saved(m, g));
     EqdArena Aw(scratch, scratch_bytes);
     Scratch W;
     carve_scratch(D, m, g, Aw, W);
@@ -879,7 +921,7 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
     g_bf16_mode = m->storage_bf16 ? 1 : 0;
     EqdArena As(const_cast<void*>(saved), saved_bytes);
     Saved S;
-    carve_saved(D, g, As, S, m->storage_bf16 != 0, qkv_saved_bf16(D, m, g));
+    carve_saved(D, g, As, S, m->storage_bf16 != 0, qkv_saved_bf16(D, m, g), edge_state_saved(m, g));
     EqdArena Aw(scratch, scratch_bytes);
     Scratch W;
     carve_scratch(D, m, g, Aw, W);
@@ -1021,6 +1063,7 @@ extern "C" int eqd_model_backward(const EqdModelDesc* m, const EqdGraph* g, cons
         // eqd_launch_attention_bwd_gather issues them one after the other otherwise).
         {
             EqdEdgeParams ep = edge_params(D, m, l, p, drop);
+            ep.xh_save = Ls.xh_e; ep.rstd_save = Ls.rstd_e; ep.zpos_save = Ls.zpos_e;      // saved by the forward, or NULL
             EqdEdgeGrads eg;
             memset(&eg, 0, sizeof(eg));
             eg.dW1 = gp[P_W1]; eg.ldw1 = D.ldw1(l); eg.dln_g = gp[P_LNG]; eg.dln_b = gp[P_LNB]; eg.dW2 = gp[P_W2];

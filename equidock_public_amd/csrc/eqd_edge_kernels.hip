@@ -237,7 +237,12 @@ __device__ __forceinline__ void drop_load(const EqdEdgeParams& P, EdgeTileState<
 //   xh = LayerNorm-normalised hidden (before the affine), m = msg, ch = coors_mlp hidden pre-activation.
 // If rbf_out != nullptr the 15 RBFs of each edge are also written there ([E][16]).
 // PRE: S.src / S.dst hold the tile's endpoints already (k_edge_bwd fetches them one tile ahead)
-template <int NB, bool DROP = false, bool PRE = false>
+// SAVED (the backward, round 6): the forward left the edge's LayerNorm-normalised hidden row xh (fp32), its rstd and the
+// LeakyReLU sign bits of z1 in HBM (EqdEdgeParams.xh_save / rstd_save / zpos_save, 268 B per edge).  The tile then LOADS
+// them - one contiguous 256-byte row per edge - instead of gathering P[src] and Q[dst] (512 B per edge from two random
+// rows), running the first Linear's feature GEMM, the LeakyReLU and both LayerNorm statistics again.  The saved values
+// are what this function computes: same bits downstream (test_edge_saved_state_is_bit_identical).
+template <int NB, bool DROP = false, bool PRE = false, bool SAVED = false>
 __device__ __forceinline__ void edge_tile_forward(const EqdGraph& G, const EqdEdgeParams& P, const float* __restrict__ w1,
                                                   const float* __restrict__ w2, const float* __restrict__ wc1,
                                                   const float* __restrict__ vec, float* __restrict__ tile,
@@ -272,7 +277,9 @@ __device__ __forceinline__ void edge_tile_forward(const EqdGraph& G, const EqdEd
         }
     }
     float xs[NB][3], xd[NB][3];
-    float4 pv[NB][4], qv[NB][4];
+    float4 pv[NB][4], qv[NB][4];      // !SAVED: P[src], Q[dst];  SAVED: pv = the edge's saved xh row (qv unused)
+    float rsv[NB];
+    unsigned zsv[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
@@ -280,10 +287,18 @@ __device__ __forceinline__ void edge_tile_forward(const EqdGraph& G, const EqdEd
             xs[nb][c] = x[(size_t)S.src[nb] * 3 + c];
             xd[nb][c] = x[(size_t)S.dst[nb] * 3 + c];
         }
+        if constexpr (SAVED) {
+            const size_t er = (size_t)S.e0 + (S.ev[nb] ? 16 * nb + l15 : 0);      // (lanes beyond the tile: its first edge)
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
-            pv[nb][mb] = *(const float4*)&Pn[(size_t)S.src[nb] * 64 + 16 * mb + 4 * g];
-            qv[nb][mb] = *(const float4*)&Qn[(size_t)S.dst[nb] * 64 + 16 * mb + 4 * g];
+            for (int mb = 0; mb < 4; ++mb) pv[nb][mb] = *(const float4*)&P.xh_save[er * 64 + 16 * mb + 4 * g];
+            rsv[nb] = P.rstd_save[er];
+            zsv[nb] = P.zpos_save[er * 4 + g];
+        } else {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                pv[nb][mb] = *(const float4*)&Pn[(size_t)S.src[nb] * 64 + 16 * mb + 4 * g];
+                qv[nb][mb] = *(const float4*)&Qn[(size_t)S.dst[nb] * 64 + 16 * mb + 4 * g];
+            }
         }
     }
     // ---- feature tile [16 NB][45]: he (27) | rbf (15) | 0 -----------------------------------------
@@ -332,6 +347,24 @@ __device__ __forceinline__ void edge_tile_forward(const EqdGraph& G, const EqdEd
     }
     wave_lds_fence();
     EQD_TR(4);
+    S.zpos = 0u;
+    if constexpr (DROP) drop_load<NB>(P, S, l15, g);
+    if constexpr (SAVED) {
+        // the saved row IS xh (lanes beyond the tile: 0, what the recompute gives them), with its rstd and sign bits
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const float4 v = pv[nb][mb];
+                f32x4 a;
+                a[0] = S.ev[nb] ? v.x : 0.f; a[1] = S.ev[nb] ? v.y : 0.f; a[2] = S.ev[nb] ? v.z : 0.f; a[3] = S.ev[nb] ? v.w : 0.f;
+                xh[mb][nb] = a;
+            }
+            S.zpos |= (S.ev[nb] ? zsv[nb] : 0u) << (16 * nb);
+            S.mean[nb] = 0.f;
+            S.rstd[nb] = rsv[nb];
+        }
+    } else {
     // ---- stage 1: z1 = P[src] + Q[dst] + W1cd feat ----------------------------------------------
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
@@ -359,8 +392,6 @@ __device__ __forceinline__ void edge_tile_forward(const EqdGraph& G, const EqdEd
     }
     EQD_TR(6);
     // ---- LeakyReLU + LayerNorm statistics (two-pass like torch) ------------------------------------
-    S.zpos = 0u;
-    if constexpr (DROP) drop_load<NB>(P, S, l15, g);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         float s = 0.f;
@@ -392,6 +423,7 @@ __device__ __forceinline__ void edge_tile_forward(const EqdGraph& G, const EqdEd
         S.mean[nb] = mean;
         S.rstd[nb] = rstd;
     }
+    }      // (!SAVED)
     EQD_TR(7);
     // ---- stage 2: m = W2 (xh * gamma + beta) + b2 --------------------------------------------------
 #pragma unroll
@@ -574,7 +606,7 @@ __device__ __forceinline__ void chain64_bf(f32x4 (&out)[4][NB], const f32x4 (&in
 
 // bf16 counterpart of edge_tile_forward (same outputs, same EdgeTileState)
 // PRE: S.src / S.dst hold the tile's endpoints already (k_edge_bwd fetches them one tile ahead)
-template <int NB, bool DROP = false, bool PRE = false>
+template <int NB, bool DROP = false, bool PRE = false, bool SAVED = false>
 __device__ __forceinline__ void edge_tile_forward_bf(const EqdGraph& G, const EqdEdgeParams& P,
                                                      const unsigned short* __restrict__ w1,
                                                      const unsigned short* __restrict__ w2,
@@ -604,7 +636,9 @@ __device__ __forceinline__ void edge_tile_forward_bf(const EqdGraph& G, const Eq
         }
     }
     float xs[NB][3], xd[NB][3];
-    float4 pv[NB][4], qv[NB][4];
+    float4 pv[NB][4], qv[NB][4];      // !SAVED: P[src], Q[dst];  SAVED: pv = the edge's saved xh row (qv unused)
+    float rsv[NB];
+    unsigned zsv[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
@@ -612,10 +646,18 @@ __device__ __forceinline__ void edge_tile_forward_bf(const EqdGraph& G, const Eq
             xs[nb][c] = x[(size_t)S.src[nb] * 3 + c];
             xd[nb][c] = x[(size_t)S.dst[nb] * 3 + c];
         }
+        if constexpr (SAVED) {
+            const size_t er = (size_t)S.e0 + (S.ev[nb] ? 16 * nb + l15 : 0);      // (lanes beyond the tile: its first edge)
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
-            pv[nb][mb] = *(const float4*)&Pn[(size_t)S.src[nb] * 64 + 16 * mb + 4 * g];
-            qv[nb][mb] = *(const float4*)&Qn[(size_t)S.dst[nb] * 64 + 16 * mb + 4 * g];
+            for (int mb = 0; mb < 4; ++mb) pv[nb][mb] = *(const float4*)&P.xh_save[er * 64 + 16 * mb + 4 * g];
+            rsv[nb] = P.rstd_save[er];
+            zsv[nb] = P.zpos_save[er * 4 + g];
+        } else {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                pv[nb][mb] = *(const float4*)&Pn[(size_t)S.src[nb] * 64 + 16 * mb + 4 * g];
+                qv[nb][mb] = *(const float4*)&Qn[(size_t)S.dst[nb] * 64 + 16 * mb + 4 * g];
+            }
         }
     }
     // ---- feature tile [16 NB][48] bf16: he (27) | rbf (15) | 0 (6) -------------------------------------------------
@@ -656,6 +698,23 @@ __device__ __forceinline__ void edge_tile_forward_bf(const EqdGraph& G, const Eq
     }
     wave_lds_fence();
     EQD_TR(4);
+    S.zpos = 0u;
+    if constexpr (DROP) drop_load<NB>(P, S, l15, g);
+    if constexpr (SAVED) {      // (see edge_tile_forward)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const float4 v = pv[nb][mb];
+                f32x4 a;
+                a[0] = S.ev[nb] ? v.x : 0.f; a[1] = S.ev[nb] ? v.y : 0.f; a[2] = S.ev[nb] ? v.z : 0.f; a[3] = S.ev[nb] ? v.w : 0.f;
+                xh[mb][nb] = a;
+            }
+            S.zpos |= (S.ev[nb] ? zsv[nb] : 0u) << (16 * nb);
+            S.mean[nb] = 0.f;
+            S.rstd[nb] = rsv[nb];
+        }
+    } else {
     // ---- stage 1: z1 = P[src] + Q[dst] (fp32) + W1cd feat (3 k-chunks of 16) ------------------------------------------
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
@@ -693,8 +752,6 @@ __device__ __forceinline__ void edge_tile_forward_bf(const EqdGraph& G, const Eq
     }
     EQD_TR(6);
     // ---- LeakyReLU + LayerNorm statistics (fp32, two-pass like torch) ------------------------------------------------
-    S.zpos = 0u;
-    if constexpr (DROP) drop_load<NB>(P, S, l15, g);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         float s = 0.f;
@@ -726,6 +783,7 @@ __device__ __forceinline__ void edge_tile_forward_bf(const EqdGraph& G, const Eq
         S.mean[nb] = mean;
         S.rstd[nb] = rstd;
     }
+    }      // (!SAVED)
     EQD_TR(7);
     // ---- stage 2: m = W2 bf16(xh * gamma + beta) + b2;  stage 3: ch = Wc1 bf16(m) + bc1 -----------------------------
 #pragma unroll
@@ -882,6 +940,19 @@ __device__ __forceinline__ void edge_fwd_body(EdgeFwdSmem<NW, BF>& S_, const Eqd
             edge_tile_forward_bf<2, DROP, true>(G, P, sm.w1, sm.w2, sm.wc1, sm.vec, tile, Pn, Qn, x, lane, S, xh, m, ch);
         else
             edge_tile_forward<2, DROP, false>(G, P, sm.w1, sm.w2, sm.wc1, sm.vec, tile, Pn, Qn, x, lane, S, xh, m, ch, nullptr);
+        if (P.xh_save) {      // training forward: the per-edge state the backward would otherwise recompute (see edge_tile_forward)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+                if (S.ev[nb]) {
+                    const size_t er = (size_t)S.e0 + 16 * nb + l15;
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb)
+                        *(float4*)&P.xh_save[er * 64 + 16 * mb + 4 * g] =
+                            make_float4(xh[mb][nb][0], xh[mb][nb][1], xh[mb][nb][2], xh[mb][nb][3]);
+                    P.zpos_save[er * 4 + g] = (uint16_t)((S.zpos >> (16 * nb)) & 0xffffu);
+                    if (g == 0) P.rstd_save[er] = S.rstd[nb];
+                }
+        }
         if (more) link_range();
         wave_lds_fence();   // feature tile is dead: reuse as the message tile [edge][64 + x_moment]
 #pragma unroll
@@ -955,6 +1026,15 @@ __global__ __launch_bounds__(64 * NW) void k_edge_fwd(EqdGraph G, EqdEdgeParams 
                                                               float* __restrict__ x_new) {
     __shared__ EdgeFwdSmem<NW, BF> S;
     edge_fwd_body<NW, BF, DROP>(S, G, P, (int)blockIdx.x, (int)gridDim.x, Pn, Qn, x, aggr_msg, x_new);
+}
+// the three arrays of the saved per-edge state come together or not at all
+static int edge_saved_check(const EqdEdgeParams* p, const char* who) {
+    const int n = (p->xh_save != nullptr) + (p->rstd_save != nullptr) + (p->zpos_save != nullptr);
+    if (n != 0 && n != 3) {
+        eqd_set_error("%s: xh_save, rstd_save and zpos_save must all be given or all be NULL", who);
+        return EQD_ERR_NULL;
+    }
+    return EQD_OK;
 }
 // NULL-ness of the two dropout masks must agree; returns 1 when dropout is active
 static int edge_drop_mode(const EqdEdgeParams* p, const char* who) {
@@ -1059,6 +1139,7 @@ extern "C" int eqd_edge_message_fwd(const EqdGraph* g, const EqdEdgeParams* p, c
     const int blocks = edge_grid(g->n_tiles, FWD_WAVES, 1);
     const int drop = edge_drop_mode(p, "eqd_edge_message_fwd");
     if (drop < 0) return EQD_ERR_NULL;
+    if (int rc = edge_saved_check(p, "eqd_edge_message_fwd")) return rc;
     if (p->bf16 && p->use_he && !g->he_bf16) {
         eqd_set_error("eqd_edge_message_fwd: bf16 mode needs EqdGraph.he_bf16");
         return EQD_ERR_NULL;
@@ -1101,6 +1182,7 @@ int eqd_edge_attn_fwd(const EqdGraph* g, const EqdEdgeParams* p, const float* P,
     const int n_edge = edge_grid(g->n_tiles, FWD_WAVES, 1);
     const int drop = edge_drop_mode(p, "eqd_edge_attn_fwd");
     if (drop < 0) return EQD_ERR_NULL;
+    if (int rc = edge_saved_check(p, "eqd_edge_attn_fwd")) return rc;
     if (d_att == 80) {
         if (drop)
             hipLaunchKernelGGL(k_edge_attn_fwd80<true>, dim3(n_edge + g->n_att_items), dim3(64 * FWD_WAVES), 0, st, *g, *p, n_edge,
@@ -1253,7 +1335,7 @@ struct EdgeBwdSmemSel<true> {
     enum { SLAB = 128 * USB };
 };
 
-template <bool BF, bool DROP = false>
+template <bool BF, bool DROP = false, bool SAVED = false>
 __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdgeParams P, const float* __restrict__ Pn,
                                                               const float* __restrict__ Qn,
                                                               const float* __restrict__ x,
@@ -1331,9 +1413,9 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
             for (int mb = 0; mb < 4; ++mb) dag[mb] = *(const float4*)&d_aggr[(size_t)d * 64 + 16 * mb + 4 * g];
         }
         if constexpr (BF)
-            edge_tile_forward_bf<1, DROP, true>(G, P, sm.w1, sm.w2, sm.wc1, sm.vec, tile, Pn, Qn, x, lane, S, xh, m, ch);
+            edge_tile_forward_bf<1, DROP, true, SAVED>(G, P, sm.w1, sm.w2, sm.wc1, sm.vec, tile, Pn, Qn, x, lane, S, xh, m, ch);
         else
-            edge_tile_forward<1, DROP, true>(G, P, sm.w1, sm.w2, sm.wc1, sm.vec, tile, Pn, Qn, x, lane, S, xh, m, ch, nullptr);
+            edge_tile_forward<1, DROP, true, SAVED>(G, P, sm.w1, sm.w2, sm.wc1, sm.vec, tile, Pn, Qn, x, lane, S, xh, m, ch, nullptr);
         // ---- coordinate path ---------------------------------------------------------------------
         float invdeg = 0.f, dcoef = 0.f, dxr[3] = {0.f, 0.f, 0.f};
         {
@@ -1726,12 +1808,17 @@ extern "C" int eqd_edge_message_bwd_kernel_only(const EqdGraph* g, const EqdEdge
     // (results incomplete, timing only) prices that write stream
     if (const char* ko = eqd_tunable("EQD_EXP_EDGE_NO_PARTIALS"))
         if (ko[0] == '1' && ko[1] == 0) W.wpart = nullptr;
-    if (p->bf16)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_edge_bwd<true>), dim3(edge_bwd_blocks(g)), dim3(64 * BWD_WAVES), 0,
-                           (hipStream_t)stream, *g, *p, P, Q, x, d_aggr_msg, d_xnew, W);
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_edge_bwd<false>), dim3(edge_bwd_blocks(g)), dim3(64 * BWD_WAVES), 0,
-                           (hipStream_t)stream, *g, *p, P, Q, x, d_aggr_msg, d_xnew, W);
+    if (int rc = edge_saved_check(p, "eqd_edge_message_bwd_kernel_only")) return rc;
+    const bool sv = p->xh_save != nullptr;
+#define EQD_EDGE_BWD_KO(BF_, SV_)                                                                                       \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_edge_bwd<BF_, false, SV_>), dim3(edge_bwd_blocks(g)), dim3(64 * BWD_WAVES), 0, \
+                       (hipStream_t)stream, *g, *p, P, Q, x, d_aggr_msg, d_xnew, W)
+    if (p->bf16) {
+        if (sv) EQD_EDGE_BWD_KO(true, true); else EQD_EDGE_BWD_KO(true, false);
+    } else {
+        if (sv) EQD_EDGE_BWD_KO(false, true); else EQD_EDGE_BWD_KO(false, false);
+    }
+#undef EQD_EDGE_BWD_KO
     return eqd_check_launch("k_edge_bwd");
 }
 
@@ -1770,14 +1857,18 @@ int eqd_edge_message_bwd_impl(const EqdGraph* g, const EqdEdgeParams* p, const f
             eqd_set_error("eqd_edge_message_bwd: bf16 mode needs EqdGraph.he_bf16");
             return EQD_ERR_NULL;
         }
-#define EQD_EDGE_BWD_LAUNCH(BF_, DROP_)                                                                                  \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_edge_bwd<BF_, DROP_>), dim3(blocks), dim3(64 * BWD_WAVES), 0, st, *g, *p, P, Q, x, \
-                       d_aggr_msg, d_xnew, W)
+        if (int rcs = edge_saved_check(p, "eqd_edge_message_bwd")) return rcs;
+        const bool sv = p->xh_save != nullptr;      // the forward saved the per-edge state: load it instead of recomputing
+#define EQD_EDGE_BWD_LAUNCH(BF_, DROP_, SV_)                                                                               \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_edge_bwd<BF_, DROP_, SV_>), dim3(blocks), dim3(64 * BWD_WAVES), 0, st, *g, *p, P, Q, \
+                       x, d_aggr_msg, d_xnew, W)
+#define EQD_EDGE_BWD_LAUNCH2(BF_, DROP_) do { if (sv) EQD_EDGE_BWD_LAUNCH(BF_, DROP_, true); else EQD_EDGE_BWD_LAUNCH(BF_, DROP_, false); } while (0)
         if (p->bf16) {
-            if (drop) EQD_EDGE_BWD_LAUNCH(true, true); else EQD_EDGE_BWD_LAUNCH(true, false);
+            if (drop) EQD_EDGE_BWD_LAUNCH2(true, true); else EQD_EDGE_BWD_LAUNCH2(true, false);
         } else {
-            if (drop) EQD_EDGE_BWD_LAUNCH(false, true); else EQD_EDGE_BWD_LAUNCH(false, false);
+            if (drop) EQD_EDGE_BWD_LAUNCH2(false, true); else EQD_EDGE_BWD_LAUNCH2(false, false);
         }
+#undef EQD_EDGE_BWD_LAUNCH2
 #undef EQD_EDGE_BWD_LAUNCH
         int rc = eqd_check_launch("k_edge_bwd");
         if (rc) return rc;

@@ -131,7 +131,8 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_keypoint(const int32_t* __restric
                                                         const float* __restrict__ u, const float* __restrict__ H,
                                                         const float* __restrict__ Z, float* __restrict__ Y,
                                                         float* __restrict__ Yl_out, float* __restrict__ Yr_out,
-                                                        int B, float* __restrict__ scores, float* __restrict__ lse) {
+                                                        int B, float* __restrict__ scores, float* __restrict__ lse,
+                                                        float* __restrict__ Yc) {
     __shared__ float su[64];
     __shared__ float red[4];
     const int s = blockIdx.x, k = blockIdx.y, t = threadIdx.x;
@@ -151,13 +152,15 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_keypoint(const int32_t* __restric
         mx = fmaxf(mx, a);
     }
     mx = block_reduce_max(mx, red);
+    // (sums over z - Z[n0], see k_keypoint_mm)
+    const float c0 = Z[(size_t)n0 * 3], c1 = Z[(size_t)n0 * 3 + 1], c2 = Z[(size_t)n0 * 3 + 2];
     float se = 0.f, y0 = 0.f, y1 = 0.f, y2 = 0.f;
     for (int i = n0 + t; i < n1; i += EQD_BLOCK) {
         const float p = expf(scores[(size_t)i * K + k] - mx);
         se += p;
-        y0 += p * Z[(size_t)i * 3 + 0];
-        y1 += p * Z[(size_t)i * 3 + 1];
-        y2 += p * Z[(size_t)i * 3 + 2];
+        y0 += p * (Z[(size_t)i * 3 + 0] - c0);
+        y1 += p * (Z[(size_t)i * 3 + 1] - c1);
+        y2 += p * (Z[(size_t)i * 3 + 2] - c2);
     }
     se = block_reduce_sum(se, red);
     y0 = block_reduce_sum(y0, red);
@@ -165,12 +168,17 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_keypoint(const int32_t* __restric
     y2 = block_reduce_sum(y2, red);
     if (t == 0) {
         const float inv = se > 0.f ? 1.f / se : 0.f;
+        const float a0 = se > 0.f ? c0 + y0 * inv : 0.f, a1 = se > 0.f ? c1 + y1 * inv : 0.f, a2 = se > 0.f ? c2 + y2 * inv : 0.f;
         float* y = Y + ((size_t)s * K + k) * 3;
-        y[0] = y0 * inv; y[1] = y1 * inv; y[2] = y2 * inv;
+        y[0] = a0; y[1] = a1; y[2] = a2;
+        if (Yc) {
+            float* yc = Yc + ((size_t)s * K + k) * 3;
+            yc[0] = y0 * inv; yc[1] = y1 * inv; yc[2] = y2 * inv;
+        }
         float* yo = s < B ? (Yl_out ? Yl_out + ((size_t)s * K + k) * 3 : nullptr)
                           : (Yr_out ? Yr_out + ((size_t)(s - B) * K + k) * 3 : nullptr);
         if (yo) {
-            yo[0] = y0 * inv; yo[1] = y1 * inv; yo[2] = y2 * inv;
+            yo[0] = a0; yo[1] = a1; yo[2] = a2;
         }
         lse[(size_t)s * K + k] = se > 0.f ? mx + logf(se) : 0.f;
     }
@@ -180,11 +188,13 @@ extern "C" int eqd_keypoint_pool_fwd(const EqdGraph* g, int n_heads, const float
                                      const float* qmean, const float* H, const float* Z, float* Y, float* scores,
                                      float* lse, float* qp, float* u, void* stream) {
     return eqd_keypoint_pool_fwd_impl(g, n_heads, Wk, Wq, qmean, H, Z, Y, nullptr, nullptr, scores, lse, qp, u,
-                                      (hipStream_t)stream);
+                                      (hipStream_t)stream, nullptr);
 }
+// Yc (optional): [2 B][K][3], the keypoints relative to their segment's first node (what the backward's softmax needs,
+// k_keypoint_bwd_mm)
 int eqd_keypoint_pool_fwd_impl(const EqdGraph* g, int n_heads, const float* Wk, const float* Wq, const float* qmean,
                                const float* H, const float* Z, float* Y, float* Y_lig_out, float* Y_rec_out,
-                               float* scores, float* lse, float* qp, float* u, hipStream_t st) {
+                               float* scores, float* lse, float* qp, float* u, hipStream_t st, float* Yc) {
     if (!g || !Wk || !Wq || !qmean || !H || !Z || !Y || !scores || !lse || !qp || !u) {
         eqd_set_error("eqd_keypoint_pool_fwd: NULL argument");
         return EQD_ERR_NULL;
@@ -202,13 +212,13 @@ int eqd_keypoint_pool_fwd_impl(const EqdGraph* g, int n_heads, const float* Wk, 
         const dim3 grid(2 * g->n_pairs, (n_heads + 15) / 16);
         if ((g->max_seg + 15) / 16 >= 64 && (int)(grid.x * grid.y) < eqd_num_cus())      // few long segments: 16 waves per workgroup
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_keypoint_mm<16>), grid, dim3(1024), 0, st, g->seg_off, n_heads, u, H, Z, Y,
-                               Y_lig_out, Y_rec_out, g->n_pairs, scores, lse);
+                               Y_lig_out, Y_rec_out, g->n_pairs, scores, lse, Yc);
         else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_keypoint_mm<4>), grid, dim3(EQD_BLOCK), 0, st, g->seg_off, n_heads, u, H, Z, Y,
-                               Y_lig_out, Y_rec_out, g->n_pairs, scores, lse);
+                               Y_lig_out, Y_rec_out, g->n_pairs, scores, lse, Yc);
     } else
         hipLaunchKernelGGL(k_keypoint, dim3(2 * g->n_pairs, n_heads), dim3(EQD_BLOCK), 0, st, g->seg_off, n_heads, u, H, Z,
-                           Y, Y_lig_out, Y_rec_out, g->n_pairs, scores, lse);
+                           Y, Y_lig_out, Y_rec_out, g->n_pairs, scores, lse, Yc);
     return eqd_check_launch("k_keypoint");
 }
 
@@ -227,17 +237,22 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_keypoint_bwd_a(const int32_t* __r
     const float* dy = dY + ((size_t)s * K + k) * 3;
     const float d0 = dy[0], d1 = dy[1], d2 = dy[2];
     const float L = lse[(size_t)s * K + k];
-    float dot = 0.f;
+    // dscore = att * (dY . (z - Y)), Y = sum att z: the coordinates are differenced first (see k_keypoint_bwd_mm)
+    const float c0 = Z[(size_t)n0 * 3], c1 = Z[(size_t)n0 * 3 + 1], c2 = Z[(size_t)n0 * 3 + 2];
+    float y0 = 0.f, y1 = 0.f, y2 = 0.f;
     for (int i = n0 + t; i < n1; i += EQD_BLOCK) {
         const float a = expf(scores[(size_t)i * K + k] - L);
-        const float da = d0 * Z[(size_t)i * 3] + d1 * Z[(size_t)i * 3 + 1] + d2 * Z[(size_t)i * 3 + 2];
-        dot += a * da;
+        y0 += a * (Z[(size_t)i * 3] - c0);
+        y1 += a * (Z[(size_t)i * 3 + 1] - c1);
+        y2 += a * (Z[(size_t)i * 3 + 2] - c2);
     }
-    dot = block_reduce_sum(dot, red);
+    y0 = block_reduce_sum(y0, red);
+    y1 = block_reduce_sum(y1, red);
+    y2 = block_reduce_sum(y2, red);
     for (int i = n0 + t; i < n1; i += EQD_BLOCK) {
         const float a = expf(scores[(size_t)i * K + k] - L);
-        const float da = d0 * Z[(size_t)i * 3] + d1 * Z[(size_t)i * 3 + 1] + d2 * Z[(size_t)i * 3 + 2];
-        dscores[(size_t)i * K + k] = a * (da - dot);
+        dscores[(size_t)i * K + k] = a * (d0 * ((Z[(size_t)i * 3] - c0) - y0) + d1 * ((Z[(size_t)i * 3 + 1] - c1) - y1) +
+                                          d2 * ((Z[(size_t)i * 3 + 2] - c2) - y2));
     }
     __syncthreads();   // dscores of this (segment, head) are re-read below by other threads of the block
     const int c = t & 63, rg = t >> 6;
@@ -284,7 +299,8 @@ __global__ void k_keypoint_bwd_b(const int32_t* __restrict__ seg_off, int nseg, 
 
 int eqd_launch_keypoint_bwd(const EqdGraph* g, int K, const float* H, const float* Z, const float* scores,
                             const float* lse, const float* u, const float* dY, float* dscores, float* du, float* dH,
-                            float* dZ, hipStream_t st, const float* Y, int* du_chunks) {
+                            float* dZ, hipStream_t st, const float* Yc, int* du_chunks) {
+    // Yc: the forward's keypoints relative to their segment's first node (eqd_keypoint_pool_fwd_impl), or NULL
     // du_chunks (optional): the caller's k_head_u_bwd sums the chunks' partial du blocks (they stay in `dscores`,
     // *du_chunks = their count per segment); without it the segments are not split
     if (du_chunks) *du_chunks = 1;
@@ -297,7 +313,7 @@ int eqd_launch_keypoint_bwd(const EqdGraph* g, int K, const float* H, const floa
         if (!du_chunks) nc = 1;
         // (dscores: the workspace of the first kernels holds the chunks' partial du blocks here)
         hipLaunchKernelGGL(k_keypoint_bwd_mm, dim3(2 * g->n_pairs, nc), dim3(EQD_BLOCK), 0, st, g->seg_off, K, H, Z, scores, lse,
-                           u, dY, Y, nc == 1 ? du : dscores, dH, dZ);
+                           u, dY, Yc, nc == 1 ? du : dscores, dH, dZ);
         if (du_chunks) *du_chunks = nc;
         return eqd_check_launch("k_keypoint_bwd");
     }

@@ -25,7 +25,11 @@ __global__ __launch_bounds__(64 * NW) void k_keypoint_mm(const int32_t* __restri
                                                            const float* __restrict__ u, const float* __restrict__ H,
                                                            const float* __restrict__ Z, float* __restrict__ Y,
                                                            float* __restrict__ Yl_out, float* __restrict__ Yr_out, int B,
-                                                           float* __restrict__ scores, float* __restrict__ lse) {
+                                                           float* __restrict__ scores, float* __restrict__ lse,
+                                                           float* __restrict__ Yc) {
+    // Yc (optional): the keypoints RELATIVE to the segment's first node, Yc = Y - Z[n0], for the backward.  The sums run over
+    // z - Z[n0] in any case: real structures lie 100 - 300 A from the origin of their PDB frame, and the softmax backward
+    // needs z - Y to better than fp32(Y) can carry at that magnitude (k_keypoint_bwd_mm).
     __shared__ float sred[NW][16][4];
     __shared__ float smx[16];
     const int s = blockIdx.x, hb = blockIdx.y, t = threadIdx.x;
@@ -103,6 +107,8 @@ __global__ __launch_bounds__(64 * NW) void k_keypoint_mm(const int32_t* __restri
     }
     __syncthreads();
     // second pass over the wave's own tiles (it reads back what its lanes stored): v[4 r + 0] = sum of exp, v[4 r + 1 + c] = Y
+    const float c0 = ((const EQD_GAS float*)Z)[(size_t)n0 * 3], c1 = ((const EQD_GAS float*)Z)[(size_t)n0 * 3 + 1],
+                c2 = ((const EQD_GAS float*)Z)[(size_t)n0 * 3 + 2];
     float v[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = 0.f;
@@ -120,8 +126,8 @@ __global__ __launch_bounds__(64 * NW) void k_keypoint_mm(const int32_t* __restri
             for (int r = 0; r < 4; ++r)
                 if (r < nh) sc[r] = ((const EQD_GAS float*)sp)[r];
         }
-        const float z0 = ((const EQD_GAS float*)Z)[(size_t)rowc * 3], z1 = ((const EQD_GAS float*)Z)[(size_t)rowc * 3 + 1],
-                    z2 = ((const EQD_GAS float*)Z)[(size_t)rowc * 3 + 2];
+        const float z0 = ((const EQD_GAS float*)Z)[(size_t)rowc * 3] - c0, z1 = ((const EQD_GAS float*)Z)[(size_t)rowc * 3 + 1] - c1,
+                    z2 = ((const EQD_GAS float*)Z)[(size_t)rowc * 3 + 2] - c2;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float p = (rv && r < nh) ? expf(sc[r] - mx[r]) : 0.f;
@@ -146,12 +152,18 @@ __global__ __launch_bounds__(64 * NW) void k_keypoint_mm(const int32_t* __restri
         }
         const float se = q[0];
         const float inv = se > 0.f ? 1.f / se : 0.f;
+        const float yc0 = q[1] * inv, yc1 = q[2] * inv, yc2 = q[3] * inv;
+        const float y0 = se > 0.f ? c0 + yc0 : 0.f, y1 = se > 0.f ? c1 + yc1 : 0.f, y2 = se > 0.f ? c2 + yc2 : 0.f;
         float* y = Y + ((size_t)s * K + k) * 3;
-        y[0] = q[1] * inv; y[1] = q[2] * inv; y[2] = q[3] * inv;
+        y[0] = y0; y[1] = y1; y[2] = y2;
+        if (Yc) {
+            float* yc = Yc + ((size_t)s * K + k) * 3;
+            yc[0] = yc0; yc[1] = yc1; yc[2] = yc2;
+        }
         float* yo = s < B ? (Yl_out ? Yl_out + ((size_t)s * K + k) * 3 : nullptr)
                           : (Yr_out ? Yr_out + ((size_t)(s - B) * K + k) * 3 : nullptr);
         if (yo) {
-            yo[0] = q[1] * inv; yo[1] = q[2] * inv; yo[2] = q[3] * inv;
+            yo[0] = y0; yo[1] = y1; yo[2] = y2;
         }
         lse[(size_t)s * K + k] = se > 0.f ? smx[t] + logf(se) : 0.f;
     }
@@ -202,16 +214,26 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_keypoint_bwd_mm(const int32_t* __
         }
         return sc;
     };
-    // dot[k] = sum over the segment's rows of att * (dY[k] . z) = dY[k] . Y[k] (Y = att^T Z is the forward's result); callers
-    // without Y (the operator-level entry point) get it from a pass over the segment's rows
-    float dt[4] = {0.f, 0.f, 0.f, 0.f};
+    // The softmax backward is dscore = att (dY[k] . z - sum_rows att (dY[k] . z)), and the sum is dY[k] . Y[k] (Y = att^T Z, the
+    // forward's result).  It is evaluated as att * (dY[k] . (z - Y[k])) - the coordinates are differenced FIRST: real structures
+    // lie 100 - 300 A from the origin of their PDB frame, both dot products are then ~ |dY| x 250 and their difference - what
+    // matters - ~ |dY| x 20, a decimal digit lost before du sums 1 270 of them to nearly zero (round 6: the head parameters'
+    // gradients of a 1 270 + 40-residue complex were 7e-4 from a float64 evaluation where torch's fp32 is 5e-5; now 4e-5).
+    // Both z and Y are taken RELATIVE to the segment's first node c = Z[n0] (fp32(Y) at |Y| = 250 is only good to 1.5e-5 A -
+    // with a sharp softmax z - Y of the dominant row is 1e-3 A): yk[j] = Yc[hB + j] = Y - c, written by k_keypoint_mm; callers
+    // without it (the operator-level entry point) get it from a pass over the segment's rows.
+    const float c0 = ((const EQD_GAS float*)Z)[(size_t)n0 * 3], c1 = ((const EQD_GAS float*)Z)[(size_t)n0 * 3 + 1],
+                c2 = ((const EQD_GAS float*)Z)[(size_t)n0 * 3 + 2];
+    float yk[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) yk[j][0] = yk[j][1] = yk[j][2] = 0.f;
     if (Yk) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             int hc = hB + j;
             hc = hc < K ? hc : K - 1;
             const float* y = Yk + ((size_t)s * K + hc) * 3;
-            dt[j] = dyj[j][0] * y[0] + dyj[j][1] * y[1] + dyj[j][2] * y[2];
+            yk[j][0] = y[0]; yk[j][1] = y[1]; yk[j][2] = y[2];
         }
     }
 #pragma unroll 2
@@ -220,18 +242,21 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_keypoint_bwd_mm(const int32_t* __
         const bool rv = row < n1;
         const int rowc = rv ? row : n1 - 1;
         const f32x4 sc = load_sc(rowc);
-        const float z0 = ((const EQD_GAS float*)Z)[(size_t)rowc * 3], z1 = ((const EQD_GAS float*)Z)[(size_t)rowc * 3 + 1],
-                    z2 = ((const EQD_GAS float*)Z)[(size_t)rowc * 3 + 2];
+        const float z0 = ((const EQD_GAS float*)Z)[(size_t)rowc * 3] - c0, z1 = ((const EQD_GAS float*)Z)[(size_t)rowc * 3 + 1] - c1,
+                    z2 = ((const EQD_GAS float*)Z)[(size_t)rowc * 3 + 2] - c2;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float a = expf(sc[j] - Lj[j]);
-            const float da = dyj[j][0] * z0 + dyj[j][1] * z1 + dyj[j][2] * z2;
-            dt[j] += (rv && j < nh) ? a * da : 0.f;
+            const float a = (rv && j < nh) ? expf(sc[j] - Lj[j]) : 0.f;
+            yk[j][0] += a * z0;
+            yk[j][1] += a * z1;
+            yk[j][2] += a * z2;
         }
     }
     if (!Yk) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dt[j] = l16_sum(dt[j]);
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) yk[j][c] = l16_sum(yk[j][c]);
     }
     const int NC = (int)gridDim.y, chunk = (int)blockIdx.y;
     const int tpc = (nt + NC - 1) / NC;
@@ -246,8 +271,8 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_keypoint_bwd_mm(const int32_t* __
         const bool rv = row < n1;
         const int rowc = rv ? row : n1 - 1;
         const f32x4 sc = load_sc(rowc);
-        const float z0 = ((const EQD_GAS float*)Z)[(size_t)rowc * 3], z1 = ((const EQD_GAS float*)Z)[(size_t)rowc * 3 + 1],
-                    z2 = ((const EQD_GAS float*)Z)[(size_t)rowc * 3 + 2];
+        const float z0 = ((const EQD_GAS float*)Z)[(size_t)rowc * 3] - c0, z1 = ((const EQD_GAS float*)Z)[(size_t)rowc * 3 + 1] - c1,
+                    z2 = ((const EQD_GAS float*)Z)[(size_t)rowc * 3 + 2] - c2;
         f32x4 hv[4];      // rows 4 ks + g of the tile, columns 4 l15 ..: B operand of du's product
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -260,8 +285,7 @@ __global__ __launch_bounds__(EQD_BLOCK) void k_keypoint_bwd_mm(const int32_t* __
         for (int j = 0; j < 4; ++j) {
             const bool ok = rv && j < nh;
             const float a = ok ? expf(sc[j] - Lj[j]) : 0.f;
-            const float da = dyj[j][0] * z0 + dyj[j][1] * z1 + dyj[j][2] * z2;
-            ds[j] = a * (da - dt[j]);
+            ds[j] = a * (dyj[j][0] * (z0 - yk[j][0]) + dyj[j][1] * (z1 - yk[j][1]) + dyj[j][2] * (z2 - yk[j][2]));
             dz0 += a * dyj[j][0];
             dz1 += a * dyj[j][1];
             dz2 += a * dyj[j][2];

@@ -420,6 +420,8 @@ class _IEGMNFunction(torch.autograd.Function):
                 _lib.ptr(svd_draws), _lib.ptr(lig), _lib.ptr(Yl), _lib.ptr(Yr),
                 _lib.ptr(T), _lib.ptr(b), _lib.ptr(status), _lib.ptr(saved), C.c_size_t(sb if need_grad else 0),
                 _lib.ptr(scratch), C.c_size_t(wb if fwd_scratch else 0), _lib.stream_ptr(dev), _lib.exec_ctx(dev)))
+        # the layout of `saved` under the EQD_* switches in force NOW; the backward checks that they have not changed
+        ctx.saved_layout = int(lib.eqd_model_saved_layout(C.byref(desc), C.byref(gs))) if need_grad else None
         packed._last_saved = (saved, sb, drop) if need_grad else None     # for IEGMN.layer_state (tests); freed with the batch
         ctx.drop = drop                 # the masks of THIS forward: the backward applies the same ones
         ctx.packed, ctx.desc, ctx.table_idx, ctx.saved, ctx.sb, ctx.wb = packed, desc, table_idx, saved, sb, wb
@@ -444,6 +446,9 @@ class _IEGMNFunction(torch.autograd.Function):
             packed.x0 = ctx.x0           # next forward re-read them again
             packed._x0_key = None
         gs = packed.c_struct()
+        if int(lib.eqd_model_saved_layout(C.byref(desc), C.byref(gs))) != ctx.saved_layout:
+            raise _lib.EquidockHipError("the EQD_* switches that decide the layout of the saved state changed between this "
+                                        "forward and its backward (eqd_tunables_reload): run the forward again")
         tensors = ctx.tensors
         ptrs = ctx.ptrs
         if ctx.flat_state is not None:      # accumulate straight into the model's persistent flat buffer

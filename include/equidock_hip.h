@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define EQD_ABI_VERSION 8
+#define EQD_ABI_VERSION 9
 #define EQD_TILE_EDGES 32   /* edges per node-aligned tile (max supported in-degree) */
 #define EQD_ATT_BLOCK 32    /* nodes per cross-attention work item */
 #define EQD_MAX_SRC 6
@@ -190,6 +190,10 @@ int eqd_ctx_destroy(void* ctx);
 /* workspace sizes (bytes) for a graph of the given dimensions */
 size_t eqd_model_saved_bytes(const EqdModelDesc* m, const EqdGraph* g);    /* forward -> backward state */
 size_t eqd_model_scratch_bytes(const EqdModelDesc* m, const EqdGraph* g);  /* transient, either pass */
+/* Layout of the saved-state buffer under the current EQD_* switches: bit 0 = bf16 storage, bit 1 = q / k / v of the 64-wide
+ * layers saved as bf16, bit 2 = per-edge state of the edge messages saved (EqdEdgeParams.xh_save).  A forward and the backward
+ * that consumes its buffer must see the same value: do not call eqd_tunables_reload between them (-1: bad arguments). */
+int eqd_model_saved_layout(const EqdModelDesc* m, const EqdGraph* g);
 int eqd_model_check(const EqdModelDesc* m, const EqdGraph* g);
 
 /* Test / debug aid: pointers to the node features h [n_nodes][*h_width] and coordinates x [n_nodes][3] after `layer`
@@ -328,6 +332,13 @@ typedef struct EqdEdgeParams {
     uint16_t* aggr_bf16;   /* optional (bf16 = 1 only): a bf16 copy of aggr_msg, [n_nodes][64], written by the forward beside
                               the fp32 result - the saved copy of the bf16 storage mode (the backward's weight-gradient
                               GEMM rounds aggr_msg to bf16 anyway); NULL = none */
+    /* Saved per-edge state (round 6, optional; all three or none).  eqd_edge_message_fwd WRITES, for every edge of the graph's
+     * edge order, the LayerNorm-normalised hidden row of edge_mlp (before the affine; fp32 [n_edges][64]), its 1 / std
+     * ([n_edges]) and the sign bits of edge_mlp.0's output ([n_edges][4] uint16: bit 4 mb + r of word g = feature
+     * 16 mb + 4 g + r is positive); eqd_edge_message_bwd READS them instead of gathering P[src] + Q[dst] and recomputing the
+     * first Linear, the LeakyReLU and the LayerNorm statistics (268 B per edge in one contiguous row against 512 B from two
+     * random rows): same bits either way.  NULL: the backward recomputes (and P, Q must be the forward's). */
+    float* xh_save; float* rstd_save; uint16_t* zpos_save;
 } EqdEdgeParams;
 /* P = h W1[:, :d_in]^T, Q = h W1[:, d_in:2 d_in]^T + b1 are node-level inputs ([n_nodes][64]). */
 int eqd_edge_message_fwd(const EqdGraph* g, const EqdEdgeParams* p, const float* P, const float* Q,

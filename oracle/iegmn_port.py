@@ -263,16 +263,16 @@ def kabsch(Yr, Yl, rand_fn=None, status=None):
     U, S, Vt = torch.linalg.svd(A)                                           # :571
     num_it = 0
     while torch.min(S) < 1e-3 or \
-            torch.min(torch.abs((S ** 2).view(1, 3) - (S ** 2).view(3, 1) + torch.eye(3))) < 1e-2:   # :574
+            torch.min(torch.abs((S ** 2).view(1, 3) - (S ** 2).view(3, 1) + torch.eye(3, dtype=S.dtype))) < 1e-2:   # :574
         draw = torch.rand(3, 3) if rand_fn is None else rand_fn(num_it)
-        A = A + draw * torch.eye(3)                                          # :578
+        A = A + draw.to(A.dtype) * torch.eye(3, dtype=A.dtype)                  # :578
         U, S, Vt = torch.linalg.svd(A)
         num_it += 1
         if num_it > 10:
             raise RuntimeError('SVD consistently numerically unstable')      # :582-584 (sys.exit there)
     if status is not None:
         status.append(num_it)
-    corr = torch.diag(torch.tensor([1., 1., float(torch.sign(torch.det(A.detach())))]))   # :586
+    corr = torch.diag(torch.tensor([1., 1., float(torch.sign(torch.det(A.detach())))], dtype=A.dtype))   # :586
     T = (U @ corr) @ Vt                                                      # :587
     b = Yr_mean - torch.t(T @ Yl_mean.t())                                   # :589
     return T, b, A

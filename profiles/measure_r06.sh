@@ -9,6 +9,7 @@
 #         pmc:<W>[:bf16]              MfmaUtil, MFMA ops, FETCH_SIZE, WRITE_SIZE (one counter per rocprofv3 pass)
 #         traffic:<W>[:bf16]          FETCH_SIZE, WRITE_SIZE only
 #         sq:<W>[:bf16]               SQ issue / stall counters per kernel (two passes of 8)
+#         ab:<W>[:bf16]               A/B of the 0 / 1 switch named in $AB_VAR (bench line per run -> <TAG>_ab.txt)
 #         collate | dprehearsal | frows
 # (bench.py with an explicit --workload runs that workload ALONE: no secondary / inference blocks in a profiled command)
 TAG=${1:-r06_a}; shift
@@ -78,6 +79,11 @@ for what in "$@"; do
       python $R/profiles/pmcstats.py $(find /tmp/pmc3 -name "*.db" | head -1) k_edge k_attn k_rowres k_rowchain k_atb k_linear k_node > $O/${TAG}_sq_${W}${SUF}_pass$P.json 2>&1
     done
     cd $R ;;
+  ab)        # ab:<W>[:bf16]  A/B of the switch named in $AB_VAR (0 / 1), two alternating repeats, one line per run
+    for rep in 1 2; do for val in 0 1; do
+      env $AB_VAR=$val python bench.py --workload $W $DT --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 | \
+        python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$W$SUF $AB_VAR=$val', d['value'], 'pairs/s', d['ms_per_step'], 'ms')" >> $O/${TAG}_ab.txt 2>&1
+    done; done ;;
   dprehearsal)   # the driver's N > 1 launch line with one rank on RCCL (world of one)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > $O/${TAG}_bench_rccl1_B.log 2>&1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 1 --workload D --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > $O/${TAG}_bench_rccl1_D.log 2>&1 ;;

@@ -75,12 +75,16 @@ BF16_OUT_TOL, BF16_GRAD_L2, BF16_GRAD_MX = 2e-2, 6e-2, 1.2e-1
 BF16_ROT_SCALE = 10.0
 
 
-def _oracle_run(sd, args, raw, faithful, loss_fn, mode, given=None):
-    """One oracle evaluation (outputs, parameter gradients of `loss_fn`) under a Kink mode."""
+def _oracle_run(sd, args, raw, faithful, loss_fn, mode, given=None, dtype=None):
+    """One oracle evaluation (outputs, parameter gradients of `loss_fn`) under a Kink mode.  dtype=torch.float64: the same
+    op sequence in double precision (parameters and inputs converted) - the yardstick for the fp32 noise floor of an input."""
     port.Kink.mode, port.Kink.near, port.Kink.given, port.Kink.flips = mode, 0, given, []
     try:
         uniq = {}       # shared layers: one leaf per distinct tensor, so that its gradient is the sum over the layers
-        leaves = {k: uniq.setdefault(id(v), v.clone().requires_grad_(True)) for k, v in sd.items()}
+        cv = (lambda v: v.clone()) if dtype is None else (lambda v: v.to(dtype).clone())
+        leaves = {k: uniq.setdefault(id(v), cv(v).requires_grad_(True)) for k, v in sd.items()}
+        if dtype is not None:
+            raw = {k: (v.to(dtype) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in raw.items()}
         outs = port.forward(leaves, args, raw, faithful=faithful)
         loss_fn(outs).backward()
         grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaves.items()}
@@ -152,12 +156,12 @@ FLIP_RATE_MAX_BF16 = 1e-2        # at most 1 % of all decisions may differ in bf
 FLIP_BELOW_2M8_BF16 = 0.99       # ... and at least 99 % of those that do sit below 2^-8 of the tensor's largest pre-activation
 
 
-def oracle_given(net, g, sd, args, raw, faithful=True, loss_fn=None, flip_rel_max=FLIP_REL_MAX):
+def oracle_given(net, g, sd, args, raw, faithful=True, loss_fn=None, flip_rel_max=FLIP_REL_MAX, dtype=None):
     """Oracle outputs + gradients evaluated with the library's own LeakyReLU decisions (oracle.iegmn_port.Kink 'given'):
     ONE gradient, compared plainly.  Returns (outs, grads, flips) - flips = [(tag, count, largest |z| / max|z|)] where the
     library's decision differs from the oracle's own sign; asserted to be at rounding level."""
     given = library_signs(net, g)
-    outs, grads, _, flips = _oracle_run(sd, args, raw, faithful, loss_fn or port.scalar_loss, 'given', given)
+    outs, grads, _, flips = _oracle_run(sd, args, raw, faithful, loss_fn or port.scalar_loss, 'given', given, dtype=dtype)
     for tag, n, rel in flips:
         assert rel <= flip_rel_max, f'LeakyReLU mask differs from the oracle at a pre-activation of relative size {rel:.2e}: {tag} ({n})'
     return outs, grads, flips
@@ -1677,6 +1681,8 @@ def check_bf16_storage_model(dev, monkeypatch):
     the 64-wide layers' q / k / v as bf16), a training forward needs the scratch workspace too (clean error without it), and
     intermediate fp32 layer states are no longer retrievable (clean error)."""
     monkeypatch.setenv('EQD_ATT_DS', '1')
+    monkeypatch.setenv('EQD_EDGE_SAVE', '0')      # (the statement is about the NODE-level state; the per-edge state, saved by default
+                                                  #  since round 6, is fp32 in both modes: check_edge_saved_state)
     sizes = [(60, 75), (90, 48), (64, 64)]
     g = G.batch_pairs(synthetic.make_pairs(sizes, 5)).to(dev)
     nbytes = {}
@@ -1701,6 +1707,64 @@ def check_bf16_storage_model(dev, monkeypatch):
     ratio = nbytes['bf16'] / nbytes['f32']
     print(f'saved state: fp32 {nbytes["f32"]} B, bf16 storage {nbytes["bf16"]} B ({100 * (1 - ratio):.1f} % smaller)')
     assert ratio <= 0.76, ratio
+
+
+def check_edge_saved_state(dev, monkeypatch):
+    """The per-edge state a training forward can leave for its backward (EqdEdgeParams.xh_save / rstd_save / zpos_save:
+    LayerNorm-normalised hidden row, 1 / std, LeakyReLU sign bits; EQD_EDGE_SAVE) is WHAT THE BACKWARD WOULD RECOMPUTE: outputs
+    and the flat gradient are bit-identical with and without it - fp32 and bf16 mode, with and without dropout masks, on a
+    ragged batch with degraded graphs (in-degree < 10, an isolated node) - and it costs 268 B per edge and layer of saved state."""
+    sizes = [(33, 47), (52, 29), (64, 64), (7, 90)]
+    pairs = synthetic.make_pairs(sizes, 13)
+    for lig, rec in pairs[:2]:      # (the golden case D's degradation: isolated destination, thinned in-edges)
+        for p_ in (lig, rec):
+            keep = np.ones(len(p_['dst']), dtype=bool)
+            keep[p_['dst'] == 3] = False
+            keep[(p_['dst'] == 5) & (np.arange(len(keep)) % 2 == 0)] = False
+            for k in ('src', 'dst', 'he'):
+                p_[k] = p_[k][keep]
+    g = G.batch_pairs(pairs).to(dev)
+    n_edges = int(g.num_edges('ll')) + int(g.num_edges('rr'))
+    for bf16 in (False, True):
+        for dropout in (0.0, 0.25):
+            res = {}
+            for save in ('0', '1'):
+                monkeypatch.setenv('EQD_EDGE_SAVE', save)
+                args = port.default_args(iegmn_n_lays=3, skip_weight_h=0.75, dropout=dropout, device=torch.device(dev))
+                if bf16:
+                    args = dict(args, hip_storage_dtype='bf16')
+                if dropout > 0:
+                    args = dict(args, hip_dropout_masks='library')
+                net = build_model(args, port.init_state_dict(args, seed=4, rot_scale=40.0), dev)
+                net.train(True)
+                flat = net.iegmn_original.enable_flat_grads()
+                flat.zero_()
+                torch.manual_seed(99)      # (the same library-drawn dropout masks in both runs)
+                outs = net(g, epoch=0)
+                port.scalar_loss(outs).backward()
+                sync(dev)
+                desc, gs = net.iegmn_original._desc(), g.pack().c_struct()
+                res[save] = ([cat_out(list(o)).detach().clone() for o in outs], flat.clone(),
+                             int(lib().eqd_model_saved_bytes(C.byref(desc), C.byref(gs))),
+                             int(lib().eqd_model_saved_layout(C.byref(desc), C.byref(gs))))
+            what = f'edge state saved vs recomputed (bf16={bf16}, dropout={dropout})'
+            assert float(res['1'][1].abs().max()) > 0, what
+            for a, b_ in zip(res['0'][0], res['1'][0]):
+                assert torch.equal(a, b_), what + ': outputs differ'
+            assert torch.equal(res['0'][1], res['1'][1]), \
+                what + f": gradients differ (max {float((res['0'][1] - res['1'][1]).abs().max()):.3e})"
+            assert res['1'][2] - res['0'][2] >= 3 * n_edges * 268 and res['1'][2] - res['0'][2] <= 3 * (n_edges * 268 + 3 * 256), \
+                (res['1'][2], res['0'][2], n_edges)
+            assert res['0'][3] & 4 == 0 and res['1'][3] & 4 == 4 and (res['1'][3] & 1) == int(bf16)
+    # a forward and its backward must see the same switches: model.py refuses a changed layout
+    monkeypatch.setenv('EQD_EDGE_SAVE', '1')
+    args = port.default_args(iegmn_n_lays=2, skip_weight_h=0.75, device=torch.device(dev))
+    net = build_model(args, port.init_state_dict(args, seed=4, rot_scale=40.0), dev)
+    loss = port.scalar_loss(net(g, epoch=0))
+    monkeypatch.setenv('EQD_EDGE_SAVE', '0')
+    with pytest_raises((L.EquidockHipError, RuntimeError)):
+        loss.backward()
+        sync(dev)
 
 
 def pytest_raises(exc):
@@ -2081,6 +2145,131 @@ def check_pocket_ot(dev):
     close(Yr_d.grad, Yr_r.grad, tol=2e-6, what='pocket OT d Y_rec')
 
 
+# the reference's loss recipe (src/train.py:112-150) with the weights of its argument defaults (src/utils/args.py:64-70)
+TRAIN_W_OT, TRAIN_W_INT, TRAIN_SIGMA, TRAIN_SURFACE_CT = 1.0, 10.0, 25.0, 10.0
+
+
+def training_batch(sizes, seed, dev, n_pocket=(12, 30)):
+    """A ragged training batch with everything src/train.py:88-92 unpacks: the graph, the bound ligand / receptor
+    coordinates (the ligand's un-moved x, the receptor's x) and matched pocket coordinates per pair (a random subset of the
+    moved ligand's residues, as many receptor residues: src/utils/db5_data.py:195-210 rotates the ligand's pocket points with it)."""
+    pairs = synthetic.make_pairs(list(sizes), seed)
+    rng = np.random.default_rng(seed + 1)
+    lig_t, rec_t, pl, pr = [], [], [], []
+    for lig, rec in pairs:
+        n = int(rng.integers(n_pocket[0], n_pocket[1] + 1))
+        n = min(n, lig['x'].shape[0], rec['x'].shape[0])
+        il, ir = rng.permutation(lig['x'].shape[0])[:n], rng.permutation(rec['x'].shape[0])[:n]
+        lig_t.append(torch.from_numpy(lig['x'].copy()))
+        rec_t.append(torch.from_numpy(rec['x'].copy()))
+        pl.append(torch.from_numpy(lig['new_x'][il].copy()))
+        pr.append(torch.from_numpy(rec['x'][ir].copy()))
+    return G.batch_pairs(pairs).to(dev), lig_t, rec_t, pl, pr
+
+
+def check_composite_training_step(dev, sizes=((41, 57), (66, 38), (120, 90), (23, 75)), layers=4, seed=17, report=None):
+    """THE training step of the reference, end to end through the library (VERDICT r05 missing 4): model -> per-pair MSE +
+    pocket OT (exact EMD) + body intersection, averaged over the batch and weighted as src/train.py:143-150 does, ->
+    backward, on a 4-pair ragged batch.  HIP side: Rigid_Body_Docking_Net.forward_batched -> losses.pair_losses
+    (eqd_pair_losses_*) + losses.pocket_ot_loss (eqd_pocket_ot_* around the exact host solver) -> autograd into
+    eqd_model_backward.  Oracle side: iegmn_port.forward -> loss_port (pinned to the reference's own loss functions) +
+    ot_port (the transport LP by HiGHS; POT parity unpinned, as stated there), autograd.  The loss value and EVERY parameter
+    gradient are compared at the usual bounds, with the library's LeakyReLU decisions."""
+    from equidock_public_amd import losses
+    from oracle import loss_port as lp
+    from oracle import ot_port as op
+    args = port.default_args(iegmn_n_lays=layers, skip_weight_h=0.75)
+    sd = port.init_state_dict(args, seed=seed, rot_scale=40.0)
+    net = build_model(args, sd, dev)
+    g, lig_t, rec_t, pl, pr = training_batch(sizes, seed, dev)
+    lig, Yl, Yr, T, b = net.forward_batched(g)
+    mse, inter = losses.pair_losses(g, lig, torch.cat(lig_t).to(dev), torch.cat(rec_t).to(dev), TRAIN_SIGMA, TRAIN_SURFACE_CT)
+    ot, plan = losses.pocket_ot_loss(Yl, Yr, [t.to(dev) for t in pl], [t.to(dev) for t in pr], return_plan=True)
+    loss = mse.mean() + TRAIN_W_OT * ot.mean() + TRAIN_W_INT * inter.mean()      # src/train.py:143-150
+    loss.backward()
+    sync(dev)
+    assert net.iegmn_original.last_svd_status.cpu().tolist() == [0] * len(sizes), 'SVD guard fired'
+    terms = {}
+
+    def ref_loss(outs):      # src/train.py:112-150 on the oracle's per-pair output lists
+        ligs, Yls, Yrs = outs[0], outs[1], outs[2]
+        B = len(ligs)
+        m = sum(lp.mse_loss(ligs[i], lig_t[i]) for i in range(B)) / float(B)
+        o = sum(op.pocket_ot_loss(pl[i], pr[i], Yls[i], Yrs[i])[0] for i in range(B)) / float(B)
+        it = sum(lp.body_intersection_loss(ligs[i], rec_t[i], TRAIN_SIGMA, TRAIN_SURFACE_CT) for i in range(B)) / float(B)
+        terms.update(mse=float(m.detach()), ot=float(o.detach()), inter=float(it.detach()))
+        return m + TRAIN_W_OT * o + TRAIN_W_INT * it
+
+    raw = port.raw_from_graph(g)
+    _, grads, flips = oracle_given(net, g, sd, args, raw, faithful=True, loss_fn=ref_loss)
+    got = dict(mse=float(mse.mean().detach()), ot=float(ot.mean().detach()), inter=float(inter.mean().detach()))
+    for k in terms:
+        assert abs(got[k] - terms[k]) <= 1e-4 * max(1.0, abs(terms[k])), f'training-step loss term {k}: {got[k]} vs oracle {terms[k]}'
+    ref_total = terms['mse'] + TRAIN_W_OT * terms['ot'] + TRAIN_W_INT * terms['inter']
+    assert abs(float(loss.detach()) - ref_total) <= 1e-4 * abs(ref_total)
+    # One-element tensors (coors_mlp.4.bias) are compared against the largest |gradient| of the same parameter over the layers:
+    # such a gradient is a sum of ~1e3 edge terms that can cancel (seen: 8.9e-4 in one layer against 2.6 and 3.4 in its
+    # neighbours), and then its own magnitude is no scale for an fp32 sum - oracle and library differ by 8e-5 there, 3e-5 of
+    # the neighbours' values.  Every other tensor: the usual per-tensor bounds.
+    import re
+    scal = {}
+    for k, r in grads.items():
+        if r.numel() == 1:
+            key = re.sub(r'\.iegmn_layers\.\d+\.', '.iegmn_layers.*.', k)
+            scal[key] = max(scal.get(key, 0.0), float(r.abs().max()))
+    multi = {k: v for k, v in grads.items() if v.numel() > 1}
+
+    class _Multi:      # compare_grads over the multi-element tensors only
+        @staticmethod
+        def named_parameters():
+            return [(k, p) for k, p in net.named_parameters() if k in multi]
+    w2, wm = compare_grads(_Multi, multi, 'composite training step', GRAD_L2, GRAD_MX)
+    for k, p in net.named_parameters():
+        if k in multi:
+            continue
+        scale = scal[re.sub(r'\.iegmn_layers\.\d+\.', '.iegmn_layers.*.', k)]
+        err = float((p.grad.detach().cpu().double() - grads[k].double()).abs().max())
+        assert err <= GRAD_L2 * max(scale, 1e-12), f'composite training step grad {k}: abs err {err:.3e} > {GRAD_L2} x {scale:.3e}'
+        w2 = max(w2, err / max(scale, 1e-12))
+    line = (f'composite training step (MSE + {TRAIN_W_OT:g} x pocket OT + {TRAIN_W_INT:g} x intersection; {len(sizes)} ragged pairs, '
+            f'{layers} layers): loss {float(loss.detach()):.4f} vs oracle {ref_total:.4f} (mse {got["mse"]:.4f}, ot {got["ot"]:.4f}, '
+            f'intersection {got["inter"]:.4f}); parameter gradients vs the oracle (plain): worst rel-L2 {w2:.2e}, max-abs/max '
+            f'{wm:.2e}; LeakyReLU decisions that differ from the oracle\'s own: {sum(n for _, n, _ in flips)}')
+    print(line)
+    if report is not None:
+        report.append(line)
+
+
+def check_train_step_forms(dev, sizes=((41, 57), (66, 38), (120, 90), (23, 75)), layers=3, seed=17, bf16=False):
+    """train_step.TrainStep: the step arranged around ONE host join (three device parts - replayed from hipGraphs on the GPU -
+    with the exact transport solve between them) gives the loss and the flat gradient of the plain autograd form
+    (step_eager: what check_composite_training_step pins to the oracle)."""
+    from equidock_public_amd import train_step as TS
+    args = port.default_args(iegmn_n_lays=layers, skip_weight_h=0.75)
+    sd = port.init_state_dict(args, seed=seed, rot_scale=40.0)
+    net = build_model(dict(args, hip_storage_dtype='bf16') if bf16 else args, sd, dev)
+    g, lig_t, rec_t, pl, pr = training_batch(sizes, seed, dev)
+    ts = TS.TrainStep(net, g, torch.cat(lig_t), torch.cat(rec_t), pl, pr, w_ot=TRAIN_W_OT, w_int=TRAIN_W_INT,
+                      sigma=TRAIN_SIGMA, surface_ct=TRAIN_SURFACE_CT)
+    l0 = float(ts.step_eager().detach())
+    sync(dev)
+    g0 = ts.reducer.flat.clone()
+    assert float(g0.abs().max()) > 0
+    forms = [('host-enqueued', ts.step_unfused)]
+    if torch.device(dev).type == 'cuda':
+        ts.capture()
+        forms.append(('hipGraph replay', ts.step))
+    for nm, fn in forms:
+        for rep in range(2):      # (twice: a replay must not depend on what the previous step left behind)
+            loss = fn()
+            sync(dev)
+            assert abs(float(loss) - l0) <= 1e-6 * abs(l0), f'TrainStep {nm}: loss {float(loss)} vs {l0}'
+            err = float((ts.reducer.flat - g0).abs().max()) / float(g0.abs().max())
+            assert err <= 1e-6, f'TrainStep {nm} (repeat {rep}): flat gradient differs from the autograd form by {err:.2e}'
+    if torch.device(dev).type == 'cuda':
+        assert ts.last_ot_exposed_ms() > 0
+
+
 def check_rigid_augment(dev):
     """eqd_rigid_augment through graph.augment_ligand against the reference's numpy formulation
     (src/utils/db5_data.py:195-204), and the model sees the new coordinates."""
@@ -2252,21 +2441,41 @@ def check_real_structure_pipeline(dev, name):
     loss.backward()
     sync(dev)
     assert abs(float(loss.detach()) - float(z['loss'])) <= 1e-4 * abs(float(z['loss']))
-    w2 = wm = 0.0
+    # Gradients, as in check_model_case: (1) against the oracle evaluated on the REFERENCE's graph arrays with the library's
+    # own LeakyReLU decisions - plain, tight (the kernels' features differ from the reference's by float32 rounding, 1e-6,
+    # which moves a gradient smoothly); (2) against the reference's GOLDEN gradient, which has the reference's decisions baked
+    # in: where the library decided a rounding-level pre-activation the other way (asserted: |z| / max|z| <= 1e-5; on 2J7P a
+    # handful of the 8 x 54 500 x 64 edge decisions, worth 6e-3 of layer 0's edge_mlp.0.weight gradient), the golden gradient
+    # is corrected by the oracle's estimate of those flips' effect (oracle_given - oracle_default).
+    _, ggiven, flips = oracle_given(net, g, sd, args, raw, faithful=True)
+    w2, wm = compare_grads(net, ggiven, f'{name} (from the structure; vs the oracle, library decisions)', GRAD_L2, GRAD_MX)
+    delta = None
+    if flips:
+        _, gdef, _, _ = _oracle_run(sd, args, raw, True, port.scalar_loss, None)
+        delta = {k: ggiven[k] - gdef[k] for k in ggiven}
     gf = meta['grad_fingerprint']
+    g2 = gm = 0.0
     for k, p in net.named_parameters():
         if 'grad_' + k in z.files:
             ref = torch.from_numpy(z['grad_' + k])
-            grad_close(p.grad, ref, what=f'{name} (from the structure) grad {k}')
+            if delta is not None:
+                ref = ref + delta[k]
+            grad_close(p.grad, ref, what=f'{name} (from the structure) golden grad {k}')
             e2, em = grad_err(p.grad, ref)
-            w2, wm = max(w2, e2), max(wm, em)
-        else:
+            g2, gm = max(g2, e2), max(gm, em)
+        elif delta is None:
             nrm = gf[k][1]
             assert abs(float(p.grad.double().norm().cpu()) - nrm) <= 2e-3 * max(nrm, 1e-6), f'{name} grad norm {k}'
-    line = (f'{name}: structure -> eqd_protein_graph_* -> HIP model vs the reference end to end: max rel output err {worst:.2e}, '
-            f'worst gradient rel-L2 {w2:.2e}, max-abs/max {wm:.2e} (vs the golden gradient, the reference\'s LeakyReLU decisions)')
+    nfl = sum(n for _, n, _ in flips)
+    line = (f'{name}: structure -> eqd_protein_graph_* -> HIP model vs the reference end to end: max rel output err {worst:.2e}; '
+            f'gradients vs the oracle on the reference\'s graph with the library\'s LeakyReLU decisions (plain): worst rel-L2 {w2:.2e}, '
+            f'max-abs/max {wm:.2e}; vs the golden gradient ({nfl} rounding-level decisions differ'
+            f'{", corrected by the oracle" if nfl else ""}): {g2:.2e} / {gm:.2e}')
     print(line)
     return line
+
+
+REAL_NOISE_FACTOR = 2.0
 
 
 def check_real_ragged_batch_vs_oracle(dev, report=None):
@@ -2306,10 +2515,28 @@ def check_real_ragged_batch_vs_oracle(dev, report=None):
         got, exp = cat_out(a), cat_out(b)
         close(got, exp, what=f'real ragged batch output {nm}')
         worst = max(worst, float((got.detach().cpu() - exp.detach()).abs().max()) / max(1.0, float(exp.detach().abs().max())))
-    w2, wm = compare_grads(net, grads, 'real ragged batch', GRAD_L2, GRAD_MX)
+    # Gradients.  Real structures are NOT centred (1DE4's atoms lie 40 - 130 A from the origin of its PDB frame) and one of
+    # the two attention problems is 1 270 x 40: fp32 evaluations of this batch are further apart than on the synthetic
+    # workloads (coordinates of that size lose 4 more bits in every difference the keypoint / Kabsch head takes).  The bound
+    # is therefore MEASURED on this input: the same oracle, same LeakyReLU decisions, evaluated in float64 is the yardstick,
+    # and the library may be at most REAL_NOISE_FACTOR x as far from it as the fp32 oracle is (or within the usual bounds).
+    _, g64, _ = oracle_given(net, g, sd, args, raw, faithful=False, dtype=torch.float64)
+    w2 = wm = n2 = l2_ = 0.0
+    for k, p in net.named_parameters():
+        r64 = g64[k]
+        if float(r64.norm()) < 1e-12:
+            continue
+        e_lib, m_lib = grad_err(p.grad, r64)
+        e_o32, m_o32 = grad_err(grads[k], r64)
+        e_lo, m_lo = grad_err(p.grad, grads[k])
+        assert e_lib <= max(GRAD_L2, REAL_NOISE_FACTOR * e_o32) and m_lib <= max(GRAD_MX, REAL_NOISE_FACTOR * m_o32), \
+            (f'real ragged batch grad {k}: library vs the float64 oracle rel-L2 {e_lib:.2e} / max-abs {m_lib:.2e}; the fp32 oracle '
+             f'vs the float64 oracle {e_o32:.2e} / {m_o32:.2e}')
+        w2, wm, n2, l2_ = max(w2, e_lib), max(wm, m_lib), max(n2, e_o32), max(l2_, e_lo)
     line = (f'real ragged batch (1DE4 1270 + 40, 2J7P 259 + 286 residues; graphs by the HIP graph kernels), 8 layers: max rel output '
-            f'err {worst:.2e}; gradients vs the oracle with the library\'s LeakyReLU decisions (plain): worst rel-L2 {w2:.2e}, '
-            f'max-abs/max {wm:.2e}; decisions that differ from the oracle\'s own: {sum(n for _, n, _ in flips)}')
+            f'err {worst:.2e}; gradients with the library\'s LeakyReLU decisions, worst rel-L2 over the tensors: library vs the '
+            f'float64 oracle {w2:.2e} (max-abs/max {wm:.2e}), fp32 oracle vs the float64 oracle {n2:.2e}, library vs the fp32 oracle '
+            f'{l2_:.2e}; decisions that differ from the oracle\'s own: {sum(n for _, n, _ in flips)}')
     print(line)
     if report is not None:
         report.append(line)

@@ -26,7 +26,7 @@ def test_hip_library_builds_and_exports_header_symbols():
         assert hasattr(handle, sym), f"{sym} declared in include/equidock_hip.h but not exported"
     assert set(_lib.EXPORTS) <= declared
     handle.eqd_abi_version.restype = ctypes.c_int
-    assert handle.eqd_abi_version() == _lib.ABI_VERSION == 8
+    assert handle.eqd_abi_version() == _lib.ABI_VERSION == 9
     assert handle.eqd_is_simulator() == 0
     assert handle.eqd_tile_edges() == G.TILE_EDGES
 

@@ -293,6 +293,28 @@ def test_pocket_ot(dev):
     pc.check_pocket_ot(dev)
 
 
+def test_composite_training_step(dev):
+    """the reference's training step (model -> MSE + pocket OT + intersection -> backward) through the library: loss and every
+    parameter gradient vs the oracle (src/train.py:98-154)"""
+    from tests import parity_common as pc
+    pc.check_composite_training_step(dev, report=REPORT)
+
+
+@pytest.mark.parametrize('bf16', [False, True])
+def test_train_step_graphs_around_one_host_join(dev, bf16):
+    """train_step.TrainStep: forward / pair terms / backward as three hipGraphs around the exact transport solve on the host -
+    same loss and flat gradient as the autograd form"""
+    from tests import parity_common as pc
+    pc.check_train_step_forms(dev, bf16=bf16)
+    pc.check_train_step_forms(dev, sizes=[(200, 200)] * 8, layers=8, bf16=bf16)
+
+
+def test_edge_saved_state_is_bit_identical(dev, monkeypatch):
+    """the per-edge state a training forward saves for the edge backward (round 6) against the recompute: same bits"""
+    from tests import parity_common as pc
+    pc.check_edge_saved_state(dev, monkeypatch)
+
+
 def test_rigid_augment(dev):
     from tests import parity_common as pc
     pc.check_rigid_augment(dev)

@@ -230,8 +230,19 @@ def test_pocket_ot():
     pc.check_pocket_ot(DEV)
 
 
+def test_edge_saved_state_is_bit_identical(monkeypatch):
+    pc.check_edge_saved_state(DEV, monkeypatch)
+
+
 def test_rigid_augment():
     pc.check_rigid_augment(DEV)
+
+
+def test_composite_training_step():
+    """model -> MSE + pocket OT + intersection (src/train.py:112-150) -> backward: loss and every parameter gradient vs the
+    oracle's restatement of the same recipe"""
+    pc.check_composite_training_step(DEV, sizes=((21, 37), (46, 18), (33, 40), (13, 25)), layers=3)
+    pc.check_train_step_forms(DEV, sizes=((21, 37), (46, 18), (33, 40), (13, 25)), layers=2)
 
 
 def test_protein_graph_vs_reference_golden():
