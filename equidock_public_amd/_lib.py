@@ -12,6 +12,8 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libequidock_hip.so')
+if os.environ.get('EQD_EXP_LIBRARY'):      # knock-out builds of the SAME sources (profiles/exp_r06_knockouts.sh: timing experiments)
+    LIB_PATH = os.environ['EQD_EXP_LIBRARY']
 
 EQD_MAX_SRC = 6
 ABI_VERSION = 9

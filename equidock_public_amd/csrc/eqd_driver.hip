@@ -162,13 +162,17 @@ bool qkv_saved_bf16(const Dims& D, const EqdModelDesc* m, const EqdGraph* g) {
     return m->storage_bf16 && m->cross_msgs && D.dh == 64 && eqd_attention_ds_wanted(g, 64, true);
 }
 // Does a training forward save the per-edge state of its edge-message kernels (268 B per edge and layer) for the backward?
-// EQD_EDGE_SAVE = 0 / 1 forces it off / on (A/B runs, tests); the default is in edge_state_default().  Like every EQD_*
-// switch it is snapshotted once per process; eqd_model_saved_layout lets a caller check that a forward and its backward
-// agree (model.py does).
+// EQD_EDGE_SAVE = 1 turns it on (0: off).  DEFAULT OFF - measured on MI355X (profiles/r06_c_edge_save_ab.txt, r06_b_kernels_*):
+// the backward gains less than the forward's stores cost.  64 x (300, 300) bf16: k_edge_bwd 124.3 -> 117.2 us per launch but
+// k_edge_fwd 66.2 -> 82.6 us (103 MB of stores per launch), step 16 260 -> 16 065 pairs/s; fp32: 8 898 -> 8 948 (+ 0.6 %);
+// 4 x (2000, 2000): 735 -> 736.5; 8 x (200, 200): 7 240 -> 7 067 (- 2.4 %) - and the saved state doubles.  Recomputing the
+// tile from P[src] + Q[dst] is cheaper than reading it back: the fused design stands.  Kept as a tested option (same bits).
+// Like every EQD_* switch it is snapshotted once per process; eqd_model_saved_layout lets a caller check that a forward and
+// its backward agree (model.py does).
 static bool edge_state_default(const EqdModelDesc* m, const EqdGraph* g) {
     (void)m;
     (void)g;
-    return true;
+    return false;
 }
 bool edge_state_saved(const EqdModelDesc* m, const EqdGraph* g) {
     const char* f = eqd_tunable("EQD_EDGE_SAVE");

@@ -233,6 +233,27 @@ __device__ __forceinline__ void drop_load(const EqdEdgeParams& P, EdgeTileState<
     }
 }
 
+// Training forward: leave the per-edge state the backward would otherwise recompute (EqdEdgeParams.xh_save / rstd_save /
+// zpos_save).  Called INSIDE the tile forward, as soon as xh is final: the two 64 x 64 GEMM chains, the coefficient and the
+// per-node aggregation that follow issue no global load, so the stores drain behind arithmetic.  Placed after the tile
+// forward - in front of the next tile's index loads, whose s_waitcnt vmcnt counts the stores too - they cost k_edge_fwd<bf16>
+// + 16 us per launch at 64 x (300, 300) (66 -> 83 us; profiles/r06_b_kernels_C_bf16.md).
+template <int NB>
+__device__ __forceinline__ void edge_state_store(const EqdEdgeParams& P, const EdgeTileState<NB>& S, const f32x4 (&xh)[4][NB],
+                                                 int l15, int g) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+        if (S.ev[nb]) {
+            const size_t er = (size_t)S.e0 + 16 * nb + l15;
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+                *(float4*)&P.xh_save[er * 64 + 16 * mb + 4 * g] =
+                    make_float4(xh[mb][nb][0], xh[mb][nb][1], xh[mb][nb][2], xh[mb][nb][3]);
+            P.zpos_save[er * 4 + g] = (uint16_t)((S.zpos >> (16 * nb)) & 0xffffu);
+            if (g == 0) P.rstd_save[er] = S.rstd[nb];
+        }
+}
+
 // Forward of one tile of 16*NB edges up to (and including) the coefficient. On return:
 //   xh = LayerNorm-normalised hidden (before the affine), m = msg, ch = coors_mlp hidden pre-activation.
 // If rbf_out != nullptr the 15 RBFs of each edge are also written there ([E][16]).
@@ -424,6 +445,9 @@ __device__ __forceinline__ void edge_tile_forward(const EqdGraph& G, const EqdEd
         S.rstd[nb] = rstd;
     }
     }      // (!SAVED)
+    if constexpr (!SAVED) {
+        if (P.xh_save) edge_state_store<NB>(P, S, xh, l15, g);
+    }
     EQD_TR(7);
     // ---- stage 2: m = W2 (xh * gamma + beta) + b2 --------------------------------------------------
 #pragma unroll
@@ -784,6 +808,9 @@ __device__ __forceinline__ void edge_tile_forward_bf(const EqdGraph& G, const Eq
         S.rstd[nb] = rstd;
     }
     }      // (!SAVED)
+    if constexpr (!SAVED) {
+        if (P.xh_save) edge_state_store<NB>(P, S, xh, l15, g);
+    }
     EQD_TR(7);
     // ---- stage 2: m = W2 bf16(xh * gamma + beta) + b2;  stage 3: ch = Wc1 bf16(m) + bc1 -----------------------------
 #pragma unroll
@@ -940,19 +967,6 @@ __device__ __forceinline__ void edge_fwd_body(EdgeFwdSmem<NW, BF>& S_, const Eqd
             edge_tile_forward_bf<2, DROP, true>(G, P, sm.w1, sm.w2, sm.wc1, sm.vec, tile, Pn, Qn, x, lane, S, xh, m, ch);
         else
             edge_tile_forward<2, DROP, false>(G, P, sm.w1, sm.w2, sm.wc1, sm.vec, tile, Pn, Qn, x, lane, S, xh, m, ch, nullptr);
-        if (P.xh_save) {      // training forward: the per-edge state the backward would otherwise recompute (see edge_tile_forward)
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-                if (S.ev[nb]) {
-                    const size_t er = (size_t)S.e0 + 16 * nb + l15;
-#pragma unroll
-                    for (int mb = 0; mb < 4; ++mb)
-                        *(float4*)&P.xh_save[er * 64 + 16 * mb + 4 * g] =
-                            make_float4(xh[mb][nb][0], xh[mb][nb][1], xh[mb][nb][2], xh[mb][nb][3]);
-                    P.zpos_save[er * 4 + g] = (uint16_t)((S.zpos >> (16 * nb)) & 0xffffu);
-                    if (g == 0) P.rstd_save[er] = S.rstd[nb];
-                }
-        }
         if (more) link_range();
         wave_lds_fence();   // feature tile is dead: reuse as the message tile [edge][64 + x_moment]
 #pragma unroll
@@ -1350,6 +1364,13 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
     // barriers / s_waitcnt 48 % of their cycles at 64 x (300, 300), profiles/r03_l_sq_C_bf16_pass1.json).  The fp32 slabs
     // (2 x 33.8 KB) have no room for a second pair.
     constexpr bool DBUF = BF;
+    // knock-out build for pricing (-DEQD_EXP_NO_SLABS, profiles/exp_r06_knockouts.sh: results WRONG, timing only): the kernel
+    // without its three weight-gradient slab GEMMs, their LDS stores and barriers
+#ifdef EQD_EXP_NO_SLABS
+    constexpr bool NOSLAB = true;
+#else
+    constexpr bool NOSLAB = false;
+#endif
     __shared__ __attribute__((aligned(16))) typename Sel::slab_t Ubuf[(DBUF ? 2 : 1) * Sel::SLAB];
     __shared__ __attribute__((aligned(16))) typename Sel::slab_t Vbuf[(DBUF ? 2 : 1) * Sel::SLAB];
     int slab_par = 0;
@@ -1454,6 +1475,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
         typename Sel::slab_t* U = Ubuf + slab_par * Sel::SLAB;
         typename Sel::slab_t* V = Vbuf + slab_par * Sel::SLAB;
         if constexpr (DBUF) slab_par ^= 1;
+        if constexpr (!NOSLAB) {
         if constexpr (BF) {
             slab_store_bf(U, wave, ch, l15, g);
             slab_store_bf(V, wave, m, l15, g);
@@ -1467,6 +1489,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
             slab_atb_bf<2, !DROP>(gWc1, U, V, wmb, wnb, l15, g);
         else
             slab_atb<2>(gWc1, U, V, wmb, wnb, l15, g);
+        }
         EQD_TR(14);
         // ---- dm = d_aggr[dst] / deg + Wc1^T d_chid ---------------------------------------------------
 #pragma unroll
@@ -1490,15 +1513,17 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
         }
         EQD_TR(15);
         // ---- phase 2: dW2 += dm^T a1 ---------------------------------------------------------------------
-        if constexpr (!DBUF) __syncthreads();      // every wave is done reading the phase-1 slabs
+        if constexpr (!DBUF && !NOSLAB) __syncthreads();      // every wave is done reading the phase-1 slabs
         U = Ubuf + slab_par * Sel::SLAB;
         V = Vbuf + slab_par * Sel::SLAB;
         if constexpr (DBUF) slab_par ^= 1;
+        if constexpr (!NOSLAB) {
         if constexpr (BF)
             slab_store_bf(U, wave, m, l15, g);
         else
             slab_store(U, wave, m, l15, g);
-        {
+        }
+        if constexpr (!NOSLAB) {
             f32x4 a1[4][1];
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
@@ -1514,12 +1539,14 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
             else
                 slab_store(V, wave, a1, l15, g);
         }
+        if constexpr (!NOSLAB) {
         __syncthreads();
         EQD_TR(16);
         if constexpr (BF)
             slab_atb_bf<2, !DROP>(gW2, U, V, wmb, wnb, l15, g);
         else
             slab_atb<2>(gW2, U, V, wmb, wnb, l15, g);
+        }
         EQD_TR(17);
         // ---- da1 = W2^T dm ---------------------------------------------------------------------------
         f32x4 dz[4][1];
@@ -1584,11 +1611,12 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
             hbm_store<1>(W.dz1, dz, S, l15, g);
         }
         // ---- phase 3: dW1[:, 2d:] += dz1^T [he | rbf] ------------------------------------------------------
-        if constexpr (!DBUF) __syncthreads();      // phase-2 slabs are free
+        if constexpr (!DBUF && !NOSLAB) __syncthreads();      // phase-2 slabs are free
         U = Ubuf + slab_par * Sel::SLAB;
         V = Vbuf + slab_par * Sel::SLAB;
         if constexpr (DBUF) slab_par ^= 1;
-        if constexpr (BF) {
+        if constexpr (NOSLAB) {
+        } else if constexpr (BF) {
             slab_store_bf(U, wave, dz, l15, g);
             // this wave's [16][48] feature tile is rows 16 w .. of V (a copy: the tile is overwritten by the next iteration's
             // recompute while other waves may still be in this phase)
@@ -1648,7 +1676,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_edge_bwd(EqdGraph G, EqdEdge
             float* o = W.dxrel + (size_t)(S.e0 + l15) * 4;
             o[0] = dxr[0]; o[1] = dxr[1]; o[2] = dxr[2]; o[3] = 0.f;
         }
-        if constexpr (!DBUF) __syncthreads();      // phase-3 slabs and the feature tiles are free for the next iteration
+        if constexpr (!DBUF && !NOSLAB) __syncthreads();      // phase-3 slabs and the feature tiles are free for the next iteration
         EQD_TR(21);
     }
     // ---- partials: the workgroup's vector sums (its 8 waves' sums added in wave order through the free U slab: one

@@ -13,11 +13,16 @@
 // at the first sink that still has demand.  Costs in double; exact up to floating-point ties, which only matter when
 // the optimal plan is not unique.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdint>
+#include <functional>
 #include <limits>
+#include <mutex>
 #include <numeric>
 #include <thread>
+#include <unistd.h>
 #include <vector>
 
 namespace {
@@ -133,6 +138,76 @@ double emd_uniform(int n, int m, const float* cost, float* plan, EmdScratch& S) 
     return val;
 }
 
+// Persistent worker threads (round 6): a training step calls the solver once, between two hipGraph replays, and the GPU
+// idles while it runs - creating and joining 7 threads per call (~40 us each) was a third of that gap at 8 pairs.  Workers
+// sleep on a condition variable between calls and take problem indices from a shared counter until none is left.  A
+// forked child (DataLoader workers import this library too) starts its own pool: threads do not survive fork().
+class EmdPool {
+public:
+    static EmdPool& get() {
+        static EmdPool* pool = nullptr;
+        static pid_t owner = 0;
+        static std::mutex guard;
+        std::lock_guard<std::mutex> lk(guard);
+        if (!pool || owner != getpid()) {      // (after fork(): the parent's pool object is abandoned, never destroyed)
+            pool = new EmdPool();
+            owner = getpid();
+        }
+        return *pool;
+    }
+    // run job(t) for t = 0 .. n - 1, the caller takes t = 0; returns when all are done
+    void run(int n, const std::function<void(int)>& job) {
+        std::lock_guard<std::mutex> serial(call_);      // one batch at a time
+        grow(n - 1);
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            job_ = &job;
+            n_ = n;
+            next_ = 1;
+            pending_ = n - 1;
+            ++gen_;
+        }
+        cv_.notify_all();
+        job(0);
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [&] { return pending_ == 0; });
+        job_ = nullptr;
+    }
+
+private:
+    void grow(int workers) {
+        while ((int)th_.size() < workers) {
+            th_.emplace_back([this] { loop(); });
+            th_.back().detach();
+        }
+    }
+    void loop() {
+        unsigned long seen = 0;
+        for (;;) {
+            int t = -1;
+            const std::function<void(int)>* job = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return gen_ != seen && next_ < n_; });
+                t = next_++;
+                if (next_ >= n_) seen = gen_;
+                job = job_;
+            }
+            (*job)(t);
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                if (--pending_ == 0) done_.notify_one();
+            }
+        }
+    }
+    std::mutex m_, call_;
+    std::condition_variable cv_, done_;
+    std::vector<std::thread> th_;
+    const std::function<void(int)>* job_ = nullptr;
+    int n_ = 0, next_ = 0, pending_ = 0;
+    unsigned long gen_ = 0;
+};
+
 }  // namespace
 
 extern "C" {
@@ -161,10 +236,8 @@ int eqd_host_emd_uniform(int n_problems, const int32_t* n_src, int n_snk, const 
     if (n_threads == 1) {
         work(0);
     } else {
-        std::vector<std::thread> th;
-        for (int t = 1; t < n_threads; ++t) th.emplace_back(work, t);
-        work(0);
-        for (auto& x : th) x.join();
+        const std::function<void(int)> job = work;
+        EmdPool::get().run(n_threads, job);
     }
     int bad = 0;
     for (int p = 0; p < n_problems; ++p) {

@@ -337,7 +337,9 @@ typedef struct EqdEdgeParams {
      * ([n_edges]) and the sign bits of edge_mlp.0's output ([n_edges][4] uint16: bit 4 mb + r of word g = feature
      * 16 mb + 4 g + r is positive); eqd_edge_message_bwd READS them instead of gathering P[src] + Q[dst] and recomputing the
      * first Linear, the LeakyReLU and the LayerNorm statistics (268 B per edge in one contiguous row against 512 B from two
-     * random rows): same bits either way.  NULL: the backward recomputes (and P, Q must be the forward's). */
+     * random rows): same bits either way.  NULL: the backward recomputes (and P, Q must be the forward's).  The model calls
+     * leave it off by default (EQD_EDGE_SAVE=1 turns it on): measured, the forward's stores cost more than the backward gains
+     * (DESIGN.md section 7). */
     float* xh_save; float* rstd_save; uint16_t* zpos_save;
 } EqdEdgeParams;
 /* P = h W1[:, :d_in]^T, Q = h W1[:, d_in:2 d_in]^T + b1 are node-level inputs ([n_nodes][64]). */

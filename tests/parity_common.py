@@ -1681,8 +1681,8 @@ def check_bf16_storage_model(dev, monkeypatch):
     the 64-wide layers' q / k / v as bf16), a training forward needs the scratch workspace too (clean error without it), and
     intermediate fp32 layer states are no longer retrievable (clean error)."""
     monkeypatch.setenv('EQD_ATT_DS', '1')
-    monkeypatch.setenv('EQD_EDGE_SAVE', '0')      # (the statement is about the NODE-level state; the per-edge state, saved by default
-                                                  #  since round 6, is fp32 in both modes: check_edge_saved_state)
+    monkeypatch.setenv('EQD_EDGE_SAVE', '0')      # (the statement is about the NODE-level state; the optional per-edge state of
+                                                  #  round 6 is fp32 in both modes: check_edge_saved_state)
     sizes = [(60, 75), (90, 48), (64, 64)]
     g = G.batch_pairs(synthetic.make_pairs(sizes, 5)).to(dev)
     nbytes = {}
