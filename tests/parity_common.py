@@ -877,12 +877,17 @@ def check_poisoned_workspaces(dev, sizes=((60, 75), (90, 48), (7, 130), (33, 16)
     68-wide first layers -, partial buffers, the dS hand-off's rows beyond the partner)."""
     import os
     pairs = synthetic.make_pairs(list(sizes), 21)
-    for over, env in (({}, None), ({'residue_emb_dim': 63}, None), ({}, '1'), ({'hip_storage_dtype': 'bf16'}, '1')):
+    # (the last two cases: the optional saved per-edge state, EQD_EDGE_SAVE=1 - every edge's row must be written by the forward)
+    for over, env, esave in (({}, None, None), ({'residue_emb_dim': 63}, None, None), ({}, '1', None),
+                             ({'hip_storage_dtype': 'bf16'}, '1', None), ({}, None, '1'), ({'hip_storage_dtype': 'bf16'}, '1', '1')):
         args = dict(port.default_args(iegmn_n_lays=2, skip_weight_h=0.75), **over)
         sd = port.init_state_dict(args, seed=4)
         res = {}
+        if esave is not None:
+            os.environ['EQD_EDGE_SAVE'] = esave
         if env is not None:
             os.environ['EQD_ATT_DS'] = env
+        if env is not None or esave is not None:
             L.reload_tunables()
         try:
             for poison in (False, True):
@@ -899,6 +904,9 @@ def check_poisoned_workspaces(dev, sizes=((60, 75), (90, 48), (7, 130), (33, 16)
         finally:
             if env is not None:
                 del os.environ['EQD_ATT_DS']
+            if esave is not None:
+                del os.environ['EQD_EDGE_SAVE']
+            if env is not None or esave is not None:
                 L.reload_tunables()
         for a, b in zip(res[True], res[False]):
             assert torch.isfinite(a).all(), f'NaN from a poisoned workspace ({over}, EQD_ATT_DS={env})'
