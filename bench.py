@@ -346,9 +346,16 @@ def edge_kernel_rooflines(net, packed, dev, workload='B', bf16=False):
         full = {} if not files else json.load(open(files[-1]))
         tr = full.get(wkey, {})
         stale = staleness(full.get('_workloads', {}).get(wkey, {}).get('csrc_digest'))
+        if 'k_edge_fwd' not in tr and 'k_edge_attn_fwd' in tr:
+            # DB5.5-sized batches run the edge forward inside the fused edge + attention launch: its counters are the only
+            # measured traffic of the message forward there (they include the attention half's q / k / v / out rows)
+            tr = dict(tr, k_edge_fwd=dict(tr['k_edge_attn_fwd'], fused_with_attention=True))
         for k, v in tr.items():
             if k in out:
                 out[k]['traffic'] = int((2 * v['FETCH_SIZE_KB'] + v['WRITE_SIZE_KB']) * 1024)
+                if v.get('fused_with_attention'):
+                    out[k]['traffic_note'] = ('PMC bytes of k_edge_attn_fwd (edge messages + cross attention in one launch: what '
+                                              'runs in the step at this size), against the standalone k_edge_fwd launch time')
                 out[k]['traffic_stale'] = stale['stale']      # True: counters of another state of the kernel sources
                 out[k]['traffic_source'] = (f'profiles/{os.path.basename(files[-1])} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
                                             'separate passes; NOT measured in this run - hardware counters cannot be read '
