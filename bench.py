@@ -783,7 +783,7 @@ def time_inference(net, g, ppg, dev, steps=30, warmup=5):
             "ms_per_forward": round(dt / steps * 1e3, 4), "steps": steps, "warmup": warmup, "launch_mode": "hipGraph replay"}
 
 
-def time_train_step(R, dev, world, use_dist, backend, steps=20, warmup=5, n_pocket=30):
+def time_train_step(R, dev, world, use_dist, backend, steps=20, warmup=5, n_pocket=30, eager_tail=True):
     """The reference's TRAINING step on this workload's batch (src/train.py:98-154): model -> MSE + pocket OT (exact EMD,
     solved on the host) + body intersection -> backward (-> all-reduce under a process group), through
     equidock_public_amd.train_step.TrainStep: three hipGraphs around the one host join.  Never the headline `value`
@@ -833,11 +833,13 @@ def time_train_step(R, dev, world, use_dist, backend, steps=20, warmup=5, n_pock
         t1 = time.perf_counter()
         ts._solve_on_host()
         solve.append((time.perf_counter() - t1) * 1e3)
-    t1 = time.perf_counter()
-    for _ in range(5):
-        ts.step_eager()
-    torch.cuda.synchronize()
-    dt_eager = (time.perf_counter() - t1) / 5
+    dt_eager = float('nan')
+    if eager_tail:      # (a profiler run leaves it out: the trace then ends with graph-form steps)
+        t1 = time.perf_counter()
+        for _ in range(5):
+            ts.step_eager()
+        torch.cuda.synchronize()
+        dt_eager = (time.perf_counter() - t1) / 5
     ms = dt / steps * 1e3
     return {"metric": "protein-pairs/sec of the reference's training step (model fwd + MSE / pocket-OT / intersection losses + bwd)",
             "value": round(R.ppg * world * steps / dt, 2), "unit": "pairs/s", "ms_per_step": round(ms, 4), "steps": steps,
@@ -845,7 +847,7 @@ def time_train_step(R, dev, world, use_dist, backend, steps=20, warmup=5, n_pock
             "ot_exposed_ms": round(sorted(exposed)[len(exposed) // 2], 4),
             "host_solve_ms": round(sorted(solve)[len(solve) // 2], 4),
             "model_only_ms_per_step": round(R.dt / R.steps * 1e3, 4),
-            "autograd_form_ms_per_step": round(dt_eager * 1e3, 4),
+            "autograd_form_ms_per_step": (round(dt_eager * 1e3, 4) if eager_tail else None),
             "launch_mode": "three hipGraphs (forward + cost matrices | pair terms | OT terms + backward) around one host join",
             "weights": {"pocket_ot": ts.w_ot, "intersection": ts.w_int, "sigma": ts.sigma, "surface_ct": ts.ct}}
 
@@ -919,6 +921,10 @@ def main():
                     help="with --dropout: 'torch' = nn.Dropout's own random stream (torch's dropout on [E, 64] tensors of "
                          "ones, bit-packed by eqd_dropout_pack_edges); 'library' = eqd_dropout_draw (counter-based, one launch, "
                          "no [E, 64] tensors; args['hip_dropout_masks'])")
+    ap.add_argument('--train-step', action='store_true',
+                    help="run ONLY the reference's training step (model + MSE / pocket-OT / intersection losses + backward: "
+                         "train_step.TrainStep, three hipGraphs around the exact-OT host solve) on the named workload and print its "
+                         "block - what a profiler should wrap to see the gap the host solve leaves on the GPU timeline")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true',
@@ -982,6 +988,15 @@ def main():
 
     R = run_workload(a.workload, a.dtype, a.steps, a.warmup, dev, rank, world, use_dist, backend, dropout=a.dropout,
                      dropout_masks=a.dropout_masks, eager=a.eager)
+    if a.train_step:
+        blk = time_train_step(R, dev, world, use_dist, backend, steps=a.steps, warmup=a.warmup,
+                              eager_tail=os.environ.get('EQD_BENCH_TRAIN_EAGER_TAIL', '1') != '0')
+        if rank == 0:
+            print(json.dumps(dict(blk, workload=R.desc, dtype=R.dtype)), flush=True)
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if a.dropout > 0:
         a.no_cpu_baseline = a.no_roofline = True
     dtype, desc, ppg, L, shared, skh = R.dtype, R.desc, R.ppg, R.L, R.shared, R.skh

@@ -216,7 +216,7 @@ int eqd_host_emd_abi(void) { return 1; }
 
 // n_problems independent problems; problem p has n_src[p] sources (rows) and n_snk sinks (columns); cost / plan are the
 // row blocks of all problems one after the other ([sum n_src][n_snk] fp32).  value[p] (optional) = sum plan * cost.
-// n_threads <= 0: min(n_problems, hardware threads / 2, 16).  Returns 0, or 1 if a problem failed (NaN value).
+// n_threads <= 0: min(n_problems, hardware threads / 2, 64).  Returns 0, or 1 if a problem failed (NaN value).
 int eqd_host_emd_uniform(int n_problems, const int32_t* n_src, int n_snk, const float* cost, float* plan, double* value,
                          int n_threads) {
     if (n_problems <= 0) return 0;
@@ -224,7 +224,7 @@ int eqd_host_emd_uniform(int n_problems, const int32_t* n_src, int n_snk, const 
     for (int p = 0; p < n_problems; ++p) off[p + 1] = off[p] + (size_t)std::max(0, n_src[p]) * (size_t)n_snk;
     if (n_threads <= 0) {
         const unsigned hw = std::thread::hardware_concurrency();
-        n_threads = (int)std::min<unsigned>(std::max(1u, hw / 2), 16u);
+        n_threads = (int)std::min<unsigned>(std::max(1u, hw / 2), 64u);      // (the workers are persistent: see EmdPool)
     }
     n_threads = std::min(n_threads, n_problems);
     std::vector<double> val(n_problems, 0.0);

@@ -53,6 +53,15 @@ for what in "$@"; do
     python $R/profiles/summarize.py $DB $O/${TAG}_kernels_$W$SUF.md "round 6 (${TAG}): workload $W${SUF}" "rocprofv3 --kernel-trace --stats -- python bench.py --workload $W $DT --steps 20 --warmup 5 --no-cpu-baseline --no-roofline" > $O/${TAG}_kernels_$W$SUF.txt 2>&1
     python $R/profiles/timeline.py $DB 130 > $O/${TAG}_timeline_$W$SUF.txt 2>&1
     cd $R ;;
+  proftrain)     # the reference's training step (TrainStep: three hipGraphs around the host OT solve): kernel table + timeline
+    cd /tmp; export TMPDIR=/tmp
+    rm -rf /tmp/proft_$W$SUF
+    EQD_BENCH_TRAIN_EAGER_TAIL=0 rocprofv3 --kernel-trace --stats -d /tmp/proft_$W$SUF -o h -- python $R/bench.py --workload $W $DT --train-step --steps 20 --warmup 5 > $O/${TAG}_proftrain_$W$SUF.log 2>&1
+    DB=$(find /tmp/proft_$W$SUF -name "*.db" | head -1)
+    python $R/profiles/timeline.py $DB 160 > $O/${TAG}_timeline_train_step_$W$SUF.txt 2>&1
+    cd $R ;;
+  trainstep)     # the training step's bench block alone
+    python bench.py --workload $W $DT --train-step --steps 20 --warmup 5 > $O/${TAG}_train_step_$W$SUF.log 2>&1 ;;
   profdrop)      # the kernel table of a training step with dropout 0.25; profdrop:<W>[:bf16][:lib]
     MS="torch"; [ "$opt1" = "lib" -o "$opt2" = "lib" ] && MS="library"
     cd /tmp; export TMPDIR=/tmp
