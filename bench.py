@@ -804,7 +804,8 @@ def time_train_step(R, dev, world, use_dist, backend, steps=20, warmup=5, n_pock
     l_eager = float(ts.step_eager().detach())
     torch.cuda.synchronize()
     g_eager = R.reducer.flat.clone()
-    ts.capture()
+    if os.environ.get('EQD_TRAINSTEP_NO_GRAPHS') != '1':      # (experiment: every launch from the host)
+        ts.capture()
     import torch.distributed as dist
     for _ in range(warmup):
         ts.step()
