@@ -275,7 +275,7 @@ def _stats(e):
 
 
 def check_model_bf16_states(dev, sizes, layers=8, seed=3, pair_seed=34, faithful=False, what='', report=None,
-                            rot_scale=10.0):
+                            rot_scale=10.0, pairs=None):
     """bf16 mode at a BASELINE workload against the oracle evaluated with the same rounding points (Bf16Mode): the state after
     the last IEGMN layer (h, x: what the reference keeps as 'hv_iegmn_out' / 'x_iegmn_out') and the five outputs.  No
     hand-picked tolerance: per tensor, err(library, oracle) <= BF16_NOISE_FACTOR x max over three 1e-6 weight perturbations
@@ -284,7 +284,10 @@ def check_model_bf16_states(dev, sizes, layers=8, seed=3, pair_seed=34, faithful
     args = port.default_args(iegmn_n_lays=layers, skip_weight_h=0.75)
     sd = port.init_state_dict(args, seed=seed, rot_scale=rot_scale)
     net = build_model(dict(args, hip_storage_dtype='bf16'), sd, dev)
-    g = G.batch_pairs(synthetic.make_pairs(list(sizes), pair_seed)).to(dev)
+    # (pairs: given per-pair arrays - e.g. the real-structure graphs of tests/golden/case_F_real_*.npz - instead of the generator's)
+    g = G.batch_pairs(pairs if pairs is not None else synthetic.make_pairs(list(sizes), pair_seed)).to(dev)
+    if pairs is not None:
+        sizes = [(int(a), int(b_)) for a, b_ in zip(g.batch_num_nodes('ligand'), g.batch_num_nodes('receptor'))]
     outs = net(g, epoch=0)
     loss = port.scalar_loss(outs)
     loss.backward()
@@ -2276,6 +2279,36 @@ def check_train_step_forms(dev, sizes=((41, 57), (66, 38), (120, 90), (23, 75)),
             assert err <= 1e-6, f'TrainStep {nm} (repeat {rep}): flat gradient differs from the autograd form by {err:.2e}'
     if torch.device(dev).type == 'cuda':
         assert ts.last_ot_exposed_ms() > 0
+
+
+def check_train_step_dropout(dev, sizes=((41, 57), (66, 38), (30, 44)), layers=2):
+    """TrainStep in training mode with dropout 0.25 and library-drawn masks: every step (every replay of the captured graphs on
+    the GPU) draws fresh masks - consecutive steps give different, finite losses and gradients - and the backward applies the
+    masks of ITS forward (the gradient of a step equals the autograd form's under the same generator state)."""
+    from equidock_public_amd import train_step as TS
+    args = dict(port.default_args(iegmn_n_lays=layers, skip_weight_h=0.75, dropout=0.25), hip_dropout_masks='library')
+    sd = port.init_state_dict(args, seed=23, rot_scale=40.0)
+    net = build_model(args, sd, dev)
+    net.train(True)
+    g, lig_t, rec_t, pl, pr = training_batch(sizes, 23, dev)
+    ts = TS.TrainStep(net, g, torch.cat(lig_t), torch.cat(rec_t), pl, pr)
+    torch.manual_seed(5)
+    l_ref = float(ts.step_eager().detach())
+    sync(dev)
+    g_ref = ts.reducer.flat.clone()
+    torch.manual_seed(5)
+    l_got = float(ts.step_unfused())
+    sync(dev)
+    assert abs(l_got - l_ref) <= 1e-6 * abs(l_ref), (l_got, l_ref)
+    assert float((ts.reducer.flat - g_ref).abs().max()) <= 1e-6 * float(g_ref.abs().max())
+    if torch.device(dev).type == 'cuda':
+        ts.capture()
+    losses_ = []
+    for _ in range(3):
+        losses_.append(float(ts.step()))
+        sync(dev)
+        assert torch.isfinite(ts.reducer.flat).all() and float(ts.reducer.flat.abs().max()) > 0
+    assert all(np.isfinite(losses_)) and len(set(losses_)) == 3, losses_
 
 
 def check_rigid_augment(dev):

@@ -79,6 +79,24 @@ def test_no_kernel_uses_scratch_memory():
     assert not bad, bad
 
 
+def test_committed_counter_summaries_match_the_kernel_sources():
+    """bench.py's hardware-counter fields (roofline.traffic, roofline_all[*].issue_floor / pmc, north_star_hbm) come from
+    rocprofv3 --pmc summaries committed under profiles/.  They describe THIS library only if they were collected on these
+    kernel sources: the newest summary of every reported workload carries the digest the measurement script stamped on the GPU
+    box (profiles/measure_r06.sh -> build.csrc_digest) and it equals the digest of the tree - i.e. bench.py reports
+    counters.stale = false (round 5 shipped counters five kernel commits old)."""
+    import bench
+    from equidock_public_amd.build import csrc_digest
+    run = csrc_digest()
+    for w in ('B', 'C_bf16', 'C', 'E'):
+        tr, src = bench.load_traffic(w)
+        assert tr and src and src['csrc_digest'] == run and src['stale'] is False, (w, src)
+        fl, fsrc = bench.load_issue_floor(w)
+        assert fl and fsrc and fsrc['csrc_digest'] == run and fsrc['stale'] is False, (w, fsrc)
+        pmc = bench.load_pmc(w)
+        assert pmc and not any(v['stale'] for v in pmc.values()), w
+
+
 def test_product_refuses_cpu_tensors():
     from equidock_public_amd import _lib
     _lib.unload_for_testing()

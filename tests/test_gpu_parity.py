@@ -136,6 +136,17 @@ def test_real_structure_to_outputs_vs_reference(dev, name):
     REPORT.append(pc.check_real_structure_pipeline(dev, name))
 
 
+def test_model_bf16_on_real_structures(dev):
+    """bf16 mode on the graphs the reference's own builder made from 1GL1 + 2J7P (tests/golden/case_F_real_batch2.npz), 8 layers:
+    last-layer state and the five outputs within 2 x the bf16 oracle's own distance to its 1e-6-perturbed copies (the measured
+    bound of check_model_bf16_states), on coordinates that are not centred"""
+    from tests import parity_common as pc
+    from tests.util import load_case, pairs_from_raw
+    z, meta, args, raw = load_case('F_real_batch2')
+    pc.check_model_bf16_states(dev, None, layers=8, seed=3, what='real structures 1GL1 + 2J7P, bf16', report=REPORT,
+                               pairs=pairs_from_raw(raw))
+
+
 def test_real_ragged_batch_vs_oracle(dev):
     """1DE4 (1 270 + 40 residues) beside 2J7P (259 + 286): real graphs from the HIP graph kernels, model vs the oracle"""
     from tests import parity_common as pc
@@ -307,6 +318,12 @@ def test_train_step_graphs_around_one_host_join(dev, bf16):
     from tests import parity_common as pc
     pc.check_train_step_forms(dev, bf16=bf16)
     pc.check_train_step_forms(dev, sizes=[(200, 200)] * 8, layers=8, bf16=bf16)
+
+
+def test_train_step_with_dropout_masks_per_replay(dev):
+    """TrainStep with dropout 0.25: fresh library-drawn masks in every replay of the captured graphs"""
+    from tests import parity_common as pc
+    pc.check_train_step_dropout(dev)
 
 
 def test_edge_saved_state_is_bit_identical(dev, monkeypatch):

@@ -243,6 +243,7 @@ def test_composite_training_step():
     oracle's restatement of the same recipe"""
     pc.check_composite_training_step(DEV, sizes=((21, 37), (46, 18), (33, 40), (13, 25)), layers=3)
     pc.check_train_step_forms(DEV, sizes=((21, 37), (46, 18), (33, 40), (13, 25)), layers=2)
+    pc.check_train_step_dropout(DEV, sizes=((21, 37), (26, 18)), layers=2)
 
 
 def test_protein_graph_vs_reference_golden():
