@@ -516,8 +516,9 @@ __device__ __forceinline__ void attn_bwd_qds_body(AttnQdsSmem<DB>& sm, const Eqd
 }
 // (half blocks like the kernels around it: workgroup b -> item 8 (b / 16) + b % 8, half (b / 8) % 2, so a direction's blocks
 // and the dS rows they read stay on the XCD whose L2 the key / value pass left them in)
+// (launch bound 4 for the 64-wide fp32 instance: 130 registers unasked, 127 when asked - four workgroups per CU instead of three)
 template <int DB, int NB, bool BF = false>
-__global__ __launch_bounds__(EQD_BLOCK, 2) void k_attn_bwd_qds(EqdGraph G, const float* __restrict__ q, const float* __restrict__ k,
+__global__ __launch_bounds__(EQD_BLOCK, (DB == 4 && !BF) ? 4 : 2) void k_attn_bwd_qds(EqdGraph G, const float* __restrict__ q, const float* __restrict__ k,
                                                                const float* __restrict__ ds, int ds_stride,
                                                                float* __restrict__ dq, float qk_slope) {
     __shared__ __attribute__((aligned(16))) AttnQdsSmem<DB> sm;

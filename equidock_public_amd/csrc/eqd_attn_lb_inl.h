@@ -417,8 +417,10 @@ __device__ __forceinline__ void attn_fwd_body_lb(AttnFwdSmemLb& sm, const EqdGra
     }
 }
 
+// (launch bound 3: the kernel then fits 153 - 164 registers without a spill - it took 184 - 196 unasked - and three workgroups
+//  share a CU's 160 KB of LDS instead of two: round 6, profiles/r06_y_occupancy_ab.txt)
 template <int NB, bool QB = false>
-__global__ __launch_bounds__(EQD_BLOCK) void k_attn_fwd_lb(EqdGraph G, const float* __restrict__ q,
+__global__ __launch_bounds__(EQD_BLOCK, 3) void k_attn_fwd_lb(EqdGraph G, const float* __restrict__ q,
                                                            const float* __restrict__ k, const float* __restrict__ v,
                                                            float* __restrict__ out, float* __restrict__ lse) {
     __shared__ AttnFwdSmemLb sm;

@@ -301,6 +301,83 @@ __global__ __launch_bounds__(EQD_BLOCK, 2) void k_linear(LinJobsArg jobs) {
     linear_tile<RT, BF, RT == 1>(J, W, false, nullptr, -1, sm, nullptr, row0, RA, false, false, W);
     EQD_TR_WG_END();
 }
+// k_linear_simple (round 6): the jobs that need none of linear_tile's generality - ONE 64-wide source with k-contiguous
+// weights, 64 outputs, optional bias / LeakyReLU, no mask, LayerNorm, residual or dropout factor: the five node projections
+// (P, Q, q, k, v) of every 64-wide layer, i.e. 8 of the 10 k_linear launches of a DB5.5-sized step.  k_linear<1> allocates
+// 218 registers for its lean + general bodies (six sources' addresses, two register sets, LayerNorm state): two workgroups
+// per CU, and the 1 000 workgroups of a projection launch (5 jobs x 200 row tiles) ran as TWO rounds of 512.  This body
+// needs < 64: with a third of the LDS it runs five workgroups per CU and the launch is one round.  Same loads, the same
+// lin_mma call and the same epilogue expressions as linear_tile_lean: same bits.
+struct alignas(16) LinSimpleSmem {
+    float Xl[16 * LIN_S];
+    float Wl[64 * LIN_S];
+};
+template <bool BF>
+__global__ __launch_bounds__(EQD_BLOCK, 4) void k_linear_simple(LinJobsArg jobs) {
+    __shared__ LinSimpleSmem sm;
+    __shared__ __attribute__((aligned(16))) EqdLinJob Jl;
+    kernarg_to_lds(Jl, EQD_KERNARG_PTR(jobs), (int)(blockIdx.y * sizeof(EqdLinJob)));
+    __syncthreads();
+#define LJ(f) JW_OFF(EqdLinJob, f)
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, g = lane >> 4, tr = t >> 4, tc = t & 15;
+    const JobW W = jobw_load(&Jl, (int)(sizeof(EqdLinJob) / 4), lane);
+    const int rows = jw_i(W, LJ(rows));
+    const int row0 = (int)blockIdx.x * 16;
+    if (row0 >= rows) return;      // uniform for the whole workgroup
+    const EqdLinSrc S = jw_src(W, 0);
+    // this thread's part of the step: X row tr (clamped), columns 4 tc ..; weight rows tr + 16 j, columns 4 tc ..
+    int rowc = row0 + tr;
+    rowc = rowc < rows ? rowc : rows - 1;
+    const f32x4 xv = *(const EQD_GAS f4v*)(S.X + (size_t)rowc * S.ldx + 4 * tc);
+    f32x4 wv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wv[j] = *(const EQD_GAS f4v*)(S.W + (size_t)(tr + 16 * j) * S.w_rs + 4 * tc);
+    // epilogue operands of this wave's output block (features f0 .. f0 + 3 of row row0 + l15)
+    const int f0 = 16 * wave + 4 * g;
+    const int rowi = row0 + l15;
+    const bool rv = rowi < rows;
+    const float* const jbias = jw_p<const float>(W, LJ(bias));
+    f32x4 bias = f4zero();
+    if (jbias) bias = *(const EQD_GAS f4v*)(jbias + f0);
+    *(f32x4*)&sm.Xl[tr * LIN_S + 4 * tc] = xv;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *(f32x4*)&sm.Wl[(tr + 16 * j) * LIN_S + 4 * tc] = wv[j];
+    __syncthreads();
+    f32x4 acc[1][2], acc2[1][2];
+    acc[0][0] = acc[0][1] = acc2[0][0] = acc2[0][1] = f4zero();
+    const int mbs[2] = {wave, wave + 4};
+    const float* Xs[1] = {sm.Xl};
+    lin_mma<1, 1, 4, false, BF, true>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+    const int act = jw_i(W, LJ(act));
+    const float slope = jw_f(W, LJ(slope)), alpha = jw_f(W, LJ(alpha)), beta = jw_f(W, LJ(beta));
+    f32x4 yv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float y = (acc[0][0][r] + acc2[0][0][r]) + bias[r];
+        if (act) y = lrelu(y, slope);
+        yv[r] = alpha * y + beta * 0.f;      // (no residual: linear_tile_lean's expression with res = 0)
+    }
+    float* const jY = jw_p<float>(W, LJ(Y));
+    const int ldy = jw_i(W, LJ(ldy));      // (descriptor reads are lane exchanges: outside the predicated stores)
+    if (jY && rv) *(EQD_GAS f4v*)&jY[(size_t)rowi * ldy + f0] = yv;
+    unsigned short* const jYb = jw_p<unsigned short>(W, LJ(Yb));      // bf16 copy (EqdLinJob.Yb), or NULL
+    const int ldyb = jw_i(W, LJ(ldyb));
+    if (jYb && rv) *(EQD_GAS s16x4*)&jYb[(size_t)rowi * ldyb + f0] = pack_bf4(yv[0], yv[1], yv[2], yv[3]);
+#undef LJ
+}
+// may every job of the launch run on k_linear_simple?  (EQD_LINEAR_SIMPLE=0 keeps k_linear: tests, A/B runs)
+static bool lin_simple_eligible(const EqdLinJob* jobs, int n) {
+    const char* f = eqd_tunable("EQD_LINEAR_SIMPLE");
+    if (f && f[0] == '0' && f[1] == 0) return false;
+    for (int i = 0; i < n; ++i) {
+        const EqdLinJob& J = jobs[i];
+        if (J.nsrc != 1 || J.M != 64 || J.s[0].K != 64 || J.s[0].w_cs != 1 || J.s[0].mask || !J.s[0].W || !J.s[0].X || J.ln_g ||
+            J.R || J.mul || J.pre_ln || J.pad_to != 0 || J.rows <= 0)
+            return false;
+    }
+    return n > 0;
+}
+
 // 16-row tiles per workgroup.  One tile everywhere: with the lean (precomputed-address) step pipeline, which only fits
 // the register budget with one tile, 16-row workgroups at two per CU measured faster than 32-row workgroups at every
 // size (config C: 6 040 vs 5 950 pairs/s).  EQD_ROW_TILES=2 selects the two-tile kernels (kept and tested: they stage a
@@ -884,7 +961,10 @@ extern "C" int eqd_linear(const EqdLinJob* jobs, int njobs, void* stream) {
         const int rt = linear_row_tiles(maxrows);
         dim3 grid((maxrows + 16 * rt - 1) / (16 * rt), n);
         const bool bf = jobs[base].bf16 != 0;       // one arithmetic mode per launch
-        if (rt == 2) {
+        if (rt == 1 && lin_simple_eligible(arg.j, n)) {      // plain 64 x 64 projections: the small body, one round of workgroups
+            if (bf) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear_simple<true>), grid, dim3(EQD_BLOCK), 0, st, arg);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear_simple<false>), grid, dim3(EQD_BLOCK), 0, st, arg);
+        } else if (rt == 2) {
             if (bf) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear<2, true>), grid, dim3(EQD_BLOCK), 0, st, arg);
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear<2, false>), grid, dim3(EQD_BLOCK), 0, st, arg);
         } else {

@@ -611,6 +611,48 @@ def check_linear(dev):
     close(dX, (dY * torch.where(mask > 0, 1.0, 0.01)) @ W[:, K1:K1 + 64], what='dX')
 
 
+def check_linear_simple_form(dev, monkeypatch):
+    """k_linear_simple (round 6: the small body for plain 64 x 64 jobs - the five node projections of a 64-wide layer - five
+    workgroups per CU instead of two) against k_linear on the same jobs: BIT-identical, fp32 and bf16 mode, partial last tile,
+    weights inside a wider matrix (row stride 170), bias / LeakyReLU / bf16 copy; and it IS the kernel that takes them."""
+    torch.manual_seed(3)
+    rows = 333
+    X = torch.randn(rows, 64)
+    W1 = torch.randn(64, 170) * 0.2
+    Wq, Wv, b1 = torch.randn(64, 64) * 0.2, torch.randn(64, 64) * 0.2, torch.randn(64)
+    d = [t.to(dev) for t in (X, W1, Wq, Wv, b1)]
+
+    def run(bf16):
+        Ys = [torch.zeros(rows, 64, device=dev) for _ in range(4)]
+        Yb = torch.zeros(rows, 64, dtype=torch.int16, device=dev)
+        jobs = (L.EqdLinJob * 4)()
+        spec = ((d[1].data_ptr(), 170, None, 0), (d[1].data_ptr() + 4 * 64, 170, d[4].data_ptr(), 0),      # P, Q (+ b1)
+                (d[2].data_ptr(), 64, None, 1), (d[3].data_ptr(), 64, None, 0))                            # q (LeakyReLU), v
+        for i, (wp, wrs, bias, act) in enumerate(spec):
+            J = jobs[i]
+            J.nsrc, J.M, J.rows, J.act, J.bias = 1, 64, rows, act, bias
+            J.s[0].X, J.s[0].W, J.s[0].ldx, J.s[0].K, J.s[0].w_rs, J.s[0].w_cs = d[0].data_ptr(), wp, 64, 64, wrs, 1
+            J.alpha, J.beta, J.slope, J.Y, J.ldy, J.bf16 = 1.0, 0.0, 0.01, Ys[i].data_ptr(), 64, int(bf16)
+        jobs[3].Yb, jobs[3].ldyb = Yb.data_ptr(), 64
+        names = launch_names(dev, lambda: L.check(lib().eqd_linear(jobs, 4, st(dev))))
+        sync(dev)
+        return [y.clone() for y in Ys] + [Yb.clone()], names
+    for bf16 in (False, True):
+        monkeypatch.setenv('EQD_LINEAR_SIMPLE', '0')
+        ref, n0 = run(bf16)
+        monkeypatch.delenv('EQD_LINEAR_SIMPLE')
+        got, n1 = run(bf16)
+        assert n0 == ['k_linear'] and n1 == ['k_linear'], (n0, n1)
+        for a, b_ in zip(got, ref):
+            assert torch.equal(a, b_), f'k_linear_simple differs from k_linear (bf16={bf16}): {float((a.float() - b_.float()).abs().max()):.3e}'
+        if not bf16:
+            close(got[0], X @ W1[:, :64].t(), what='P')
+            close(got[1], X @ W1[:, 64:128].t() + b1, what='Q')
+            close(got[2], F.leaky_relu(X @ Wq.t(), 0.01), what='q')
+            close(got[3], X @ Wv.t(), what='v')
+            assert torch.equal(got[4].cpu().view(torch.bfloat16).float(), got[3].cpu().to(torch.bfloat16).float())
+
+
 def check_atb(dev):
     torch.manual_seed(1)
     rows = 1000

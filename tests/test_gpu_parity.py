@@ -22,6 +22,12 @@ def test_linear(dev):
     pc.check_linear(dev)
 
 
+def test_linear_simple_form_is_bit_identical(dev, monkeypatch):
+    """k_linear_simple (plain 64 x 64 projections, five workgroups per CU) against k_linear: same bits"""
+    from tests import parity_common as pc
+    pc.check_linear_simple_form(dev, monkeypatch)
+
+
 def test_atb(dev):
     from tests import parity_common as pc
     pc.check_atb(dev)
