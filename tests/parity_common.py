@@ -958,7 +958,7 @@ def check_poisoned_workspaces(dev, sizes=((60, 75), (90, 48), (7, 130), (33, 16)
             assert torch.equal(a, b), f'result depends on stale workspace contents ({over}, EQD_ATT_DS={env})'
 
 
-def check_attention_ds_in_model(dev, bf16=False):
+def check_attention_ds_in_model(dev, bf16=False, sizes=((60, 75), (90, 48), (7, 130), (33, 16))):
     """The whole model with the dS hand-off form of the attention backward forced on (EQD_ATT_DS=1: what large batches run)
     against the recompute form (EQD_ATT_DS=0): same outputs bit for bit (the forward is untouched), gradients equal up to fp32
     summation order; and the switch really selects the launches."""
@@ -967,7 +967,7 @@ def check_attention_ds_in_model(dev, bf16=False):
     sd = port.init_state_dict(args, seed=4)
     if bf16:      # bf16 mode: the 64-wide layers' LDS-bf16 kernels and the 80-wide first layer's fp32-tile kernels take the hand-off
         args = dict(args, hip_storage_dtype='bf16')
-    pairs = synthetic.make_pairs([(60, 75), (90, 48), (7, 130), (33, 16)], 21)
+    pairs = synthetic.make_pairs(list(sizes), 21)
     res, names = {}, {}
     for mode in ('1', '0'):
         os.environ['EQD_ATT_DS'] = mode
@@ -1762,13 +1762,12 @@ def check_bf16_storage_model(dev, monkeypatch):
     assert ratio <= 0.76, ratio
 
 
-def check_edge_saved_state(dev, monkeypatch):
+def check_edge_saved_state(dev, monkeypatch, sizes=((33, 47), (52, 29), (64, 64), (7, 90)), layers=3):
     """The per-edge state a training forward can leave for its backward (EqdEdgeParams.xh_save / rstd_save / zpos_save:
     LayerNorm-normalised hidden row, 1 / std, LeakyReLU sign bits; EQD_EDGE_SAVE) is WHAT THE BACKWARD WOULD RECOMPUTE: outputs
     and the flat gradient are bit-identical with and without it - fp32 and bf16 mode, with and without dropout masks, on a
     ragged batch with degraded graphs (in-degree < 10, an isolated node) - and it costs 268 B per edge and layer of saved state."""
-    sizes = [(33, 47), (52, 29), (64, 64), (7, 90)]
-    pairs = synthetic.make_pairs(sizes, 13)
+    pairs = synthetic.make_pairs(list(sizes), 13)
     for lig, rec in pairs[:2]:      # (the golden case D's degradation: isolated destination, thinned in-edges)
         for p_ in (lig, rec):
             keep = np.ones(len(p_['dst']), dtype=bool)
@@ -1783,7 +1782,7 @@ def check_edge_saved_state(dev, monkeypatch):
             res = {}
             for save in ('0', '1'):
                 monkeypatch.setenv('EQD_EDGE_SAVE', save)
-                args = port.default_args(iegmn_n_lays=3, skip_weight_h=0.75, dropout=dropout, device=torch.device(dev))
+                args = port.default_args(iegmn_n_lays=layers, skip_weight_h=0.75, dropout=dropout, device=torch.device(dev))
                 if bf16:
                     args = dict(args, hip_storage_dtype='bf16')
                 if dropout > 0:
@@ -1806,7 +1805,8 @@ def check_edge_saved_state(dev, monkeypatch):
                 assert torch.equal(a, b_), what + ': outputs differ'
             assert torch.equal(res['0'][1], res['1'][1]), \
                 what + f": gradients differ (max {float((res['0'][1] - res['1'][1]).abs().max()):.3e})"
-            assert res['1'][2] - res['0'][2] >= 3 * n_edges * 268 and res['1'][2] - res['0'][2] <= 3 * (n_edges * 268 + 3 * 256), \
+            assert res['1'][2] - res['0'][2] >= layers * n_edges * 268 and \
+                res['1'][2] - res['0'][2] <= layers * (n_edges * 268 + 3 * 256), \
                 (res['1'][2], res['0'][2], n_edges)
             assert res['0'][3] & 4 == 0 and res['1'][3] & 4 == 4 and (res['1'][3] & 1) == int(bf16)
     # a forward and its backward must see the same switches: model.py refuses a changed layout
@@ -2695,13 +2695,13 @@ def check_fused_forward(dev):
         assert torch.equal(a, b)
 
 
-def check_gather_rides_in_attention_backward(dev):
+def check_gather_rides_in_attention_backward(dev, sizes=((60, 75), (90, 48), (7, 130), (33, 16))):
     """The node gather + pending reductions as trailing workgroups of the attention-backward launch (k_attn_bwd_gather,
     csrc/eqd_attn_kernels.hip) against the separate launches (EQD_FUSE_GATHER=0): the same device bodies, so bit-identical
     outputs and gradients, fp32 and bf16 mode; and the switch really selects the launch (every layer since round 4: the
     69-wide first layer's merged backward carries its gather as well)."""
     import os
-    pairs = synthetic.make_pairs([(60, 75), (90, 48), (7, 130), (33, 16)], 21)
+    pairs = synthetic.make_pairs(list(sizes), 21)
     for over in ({}, {'hip_storage_dtype': 'bf16'}):
         args = dict(port.default_args(iegmn_n_lays=3, skip_weight_h=0.75), **over)
         sd = port.init_state_dict(args, seed=4)
