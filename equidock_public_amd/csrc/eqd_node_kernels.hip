@@ -378,6 +378,139 @@ static bool lin_simple_eligible(const EqdLinJob* jobs, int n) {
     return n > 0;
 }
 
+// k_linear_simple80 (round 6): the same idea for the FIRST layer's projection group - one source of 65 .. 80 columns (69:
+// residue embedding + surface features), 64 .. 80 outputs, rows zero-padded to pad_to (the attention operands' 80-wide rows).
+// On k_linear these jobs take the general body: two pipeline steps (64 columns, then the 5 left over) with two barriers each,
+// element-wise stores for the 69-wide outputs, 218 registers - 16.6 us per launch at 8 x (200, 200) against 5 us for a 64-wide
+// layer's group.  Here both steps' operands are requested up front, the small step's columns go to columns 64 .. 79 of the same
+// LDS rows (the row stride has room for 80), ONE barrier, and lin_mma is called as the general body calls it (4 chunks, then 1):
+// the same products in the same order, the same epilogue expressions - same bits.  Whole 4-column groups only (eligibility:
+// the row is padded at least to the end of M's last group), so every store is 16 bytes.
+struct alignas(16) LinSimple80Smem {
+    float Xl[16 * LIN_S];
+    float Wl[80 * LIN_S];
+};
+template <bool BF>
+__global__ __launch_bounds__(EQD_BLOCK, 4) void k_linear_simple80(LinJobsArg jobs) {
+    __shared__ LinSimple80Smem sm;
+    __shared__ __attribute__((aligned(16))) EqdLinJob Jl;
+    kernarg_to_lds(Jl, EQD_KERNARG_PTR(jobs), (int)(blockIdx.y * sizeof(EqdLinJob)));
+    __syncthreads();
+#define LJ(f) JW_OFF(EqdLinJob, f)
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, g = lane >> 4, tr = t >> 4, tc = t & 15;
+    const JobW W = jobw_load(&Jl, (int)(sizeof(EqdLinJob) / 4), lane);
+    const int rows = jw_i(W, LJ(rows)), M = jw_i(W, LJ(M));
+    const int row0 = (int)blockIdx.x * 16;
+    if (row0 >= rows) return;      // uniform for the whole workgroup
+    const EqdLinSrc S = jw_src(W, 0);
+    const int kc = S.K - 64;       // the small step's width, 1 .. 16
+    int rowc = row0 + tr;
+    rowc = rowc < rows ? rowc : rows - 1;
+    // full step: X row tr, columns 4 tc ..; weight rows tr + 16 j (clamped into the matrix), columns 4 tc ..
+    const float* __restrict__ xrow = S.X + (size_t)rowc * S.ldx;
+    const f32x4 xv = *(const EQD_GAS f4v*)(xrow + 4 * tc);
+    f32x4 wv[5];
+    int mrow[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int m = tr + 16 * j;
+        mrow[j] = m < M ? m : M - 1;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wv[j] = *(const EQD_GAS f4v*)(S.W + (size_t)mrow[j] * S.w_rs + 4 * tc);
+    wv[4] = f4zero();
+    if (M > 64) wv[4] = *(const EQD_GAS f4v*)(S.W + (size_t)mrow[4] * S.w_rs + 4 * tc);
+    // small step: one element per (row, k) / (weight row, k), k clamped into the chunk
+    const int kk = 64 + (tc < kc ? tc : kc - 1);
+    const float xs = ((const EQD_GAS float*)xrow)[kk];
+    float ws[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) ws[j] = ((const EQD_GAS float*)S.W)[(size_t)mrow[j] * S.w_rs + kk];
+    // epilogue operands of this wave's output blocks (wave 0 also owns block 4 when M > 64)
+    const int mbn = (M + 15) >> 4;
+    const int mbs[2] = {wave, wave + 4};
+    const bool own[2] = {wave < mbn, wave + 4 < mbn};
+    const float* const jbias = jw_p<const float>(W, LJ(bias));
+    f32x4 bias[2];
+    int nf[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int f0 = 16 * mbs[i] + 4 * g;
+        nf[i] = own[i] ? M - f0 : 0;            // valid features at f0 (<= 0: none)
+        bias[i] = jbias ? ld4u_raw(jbias + f0, nf[i], jbias) : f4zero();
+    }
+    const f32x4 z = f4zero();
+    const bool kv = tc < kc;
+    *(f32x4*)&sm.Xl[tr * LIN_S + 4 * tc] = xv;
+    sm.Xl[tr * LIN_S + 64 + tc] = kv ? xs : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *(f32x4*)&sm.Wl[(tr + 16 * j) * LIN_S + 4 * tc] = (tr + 16 * j < M) ? wv[j] : z;
+    if (M > 64) *(f32x4*)&sm.Wl[(64 + tr) * LIN_S + 4 * tc] = (64 + tr < M) ? wv[4] : z;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) sm.Wl[(tr + 16 * j) * LIN_S + 64 + tc] = (kv && tr + 16 * j < M) ? ws[j] : 0.f;
+    __syncthreads();
+    f32x4 acc[1][2], acc2[1][2];
+    acc[0][0] = acc[0][1] = acc2[0][0] = acc2[0][1] = f4zero();
+    const float* Xs[1] = {sm.Xl};
+    const float* Xs2[1] = {sm.Xl + 64};
+    if (own[1]) {
+        lin_mma<1, 2, 4, false, BF, true>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+        lin_mma<1, 2, 1, false, BF, true>(acc, acc2, Xs2, sm.Wl + 64, mbs, l15, g);
+    } else if (own[0]) {
+        lin_mma<1, 1, 4, false, BF, true>(acc, acc2, Xs, sm.Wl, mbs, l15, g);
+        lin_mma<1, 1, 1, false, BF, true>(acc, acc2, Xs2, sm.Wl + 64, mbs, l15, g);
+    }
+    const int act = jw_i(W, LJ(act)), pad_to = jw_i(W, LJ(pad_to));
+    const float slope = jw_f(W, LJ(slope)), alpha = jw_f(W, LJ(alpha)), beta = jw_f(W, LJ(beta));
+    float* const jY = jw_p<float>(W, LJ(Y));
+    const int ldy = jw_i(W, LJ(ldy));      // (descriptor reads are lane exchanges: outside the predicated stores)
+    unsigned short* const jYb = jw_p<unsigned short>(W, LJ(Yb));
+    const int ldyb = jw_i(W, LJ(ldyb));
+    const int rowi = row0 + l15;
+    const bool rv = rowi < rows;
+    const bool plain = (M & 3) == 0;
+    const int lim = pad_to > M ? pad_to : M;      // columns written in every row
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float4 bs = plain ? make_float4(bias[i][0], bias[i][1], bias[i][2], bias[i][3]) : ld4u_fix(bias[i], nf[i]);
+        const float bb[4] = {bs.x, bs.y, bs.z, bs.w};
+        f32x4 yv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float y = (acc[0][i][r] + acc2[0][i][r]) + bb[r];
+            if (act) y = lrelu(y, slope);
+            const float v = r < nf[i] ? y : 0.f;
+            yv[r] = alpha * v + beta * 0.f;      // (no residual: linear_tile's expression with res = 0)
+        }
+        const int f0 = 16 * mbs[i] + 4 * g;
+        if (own[i] && f0 < lim && rv) {
+            if (jY) *(EQD_GAS f4v*)&jY[(size_t)rowi * ldy + f0] = yv;
+            if (jYb && nf[i] > 0) *(EQD_GAS s16x4*)&jYb[(size_t)rowi * ldyb + f0] = pack_bf4(yv[0], yv[1], yv[2], yv[3]);
+        }
+    }
+#undef LJ
+}
+// EQD_LINEAR_SIMPLE80: 0 = off, 1 = only where k_linear would run one row tile per workgroup, 2 = at every size
+static int lin_simple80_mode() {
+    const char* f = eqd_tunable("EQD_LINEAR_SIMPLE80");
+    if (f && f[0] >= '0' && f[0] <= '2' && f[1] == 0) return f[0] - '0';
+    return 2;
+}
+static bool lin_simple80_eligible(const EqdLinJob* jobs, int n) {
+    for (int i = 0; i < n; ++i) {
+        const EqdLinJob& J = jobs[i];
+        if (J.nsrc != 1 || J.M < 64 || J.M > 80 || J.s[0].K <= 64 || J.s[0].K > 80 || J.s[0].w_cs != 1 || J.s[0].mask || !J.s[0].W ||
+            !J.s[0].X || J.ln_g || J.R || J.mul || J.pre_ln || J.rows <= 0)
+            return false;
+        const int m4 = (J.M + 3) & ~3, m16 = (J.M + 15) & ~15;
+        if (J.pad_to != 0 && ((J.pad_to & 3) || J.pad_to < m4 || J.pad_to > m16)) return false;
+        if ((J.M & 3) && (J.pad_to == 0 || J.Yb)) return false;      // a started 4-column group must be written whole
+        if (J.Y && ((J.ldy & 3) || ((uintptr_t)J.Y & 15))) return false;
+        if (J.Yb && ((J.ldyb & 3) || ((uintptr_t)J.Yb & 7))) return false;
+    }
+    return n > 0;
+}
+
 // 16-row tiles per workgroup.  One tile everywhere: with the lean (precomputed-address) step pipeline, which only fits
 // the register budget with one tile, 16-row workgroups at two per CU measured faster than 32-row workgroups at every
 // size (config C: 6 040 vs 5 950 pairs/s).  EQD_ROW_TILES=2 selects the two-tile kernels (kept and tested: they stage a
@@ -961,9 +1094,14 @@ extern "C" int eqd_linear(const EqdLinJob* jobs, int njobs, void* stream) {
         const int rt = linear_row_tiles(maxrows);
         dim3 grid((maxrows + 16 * rt - 1) / (16 * rt), n);
         const bool bf = jobs[base].bf16 != 0;       // one arithmetic mode per launch
+        const int s80 = lin_simple80_mode();
         if (rt == 1 && lin_simple_eligible(arg.j, n)) {      // plain 64 x 64 projections: the small body, one round of workgroups
             if (bf) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear_simple<true>), grid, dim3(EQD_BLOCK), 0, st, arg);
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear_simple<false>), grid, dim3(EQD_BLOCK), 0, st, arg);
+        } else if (s80 >= (rt == 1 ? 1 : 2) && lin_simple80_eligible(arg.j, n)) {      // the first layer's 69-wide projections
+            const dim3 grid16((maxrows + 15) / 16, n);
+            if (bf) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear_simple80<true>), grid16, dim3(EQD_BLOCK), 0, st, arg);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear_simple80<false>), grid16, dim3(EQD_BLOCK), 0, st, arg);
         } else if (rt == 2) {
             if (bf) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear<2, true>), grid, dim3(EQD_BLOCK), 0, st, arg);
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear<2, false>), grid, dim3(EQD_BLOCK), 0, st, arg);

@@ -653,6 +653,59 @@ def check_linear_simple_form(dev, monkeypatch):
             assert torch.equal(got[4].cpu().view(torch.bfloat16).float(), got[3].cpu().to(torch.bfloat16).float())
 
 
+def check_linear_simple80_form(dev, monkeypatch):
+    """k_linear_simple80 (round 6: the small body for the FIRST layer's projection group - one 69-wide source, 64 or 69 outputs,
+    attention rows zero-padded to 80 - both pipeline steps behind one barrier, four workgroups per CU) against k_linear's
+    general body on the same jobs: BIT-identical, fp32 and bf16 mode, partial last tile, weights inside a wider matrix at an
+    unaligned column offset (the edge MLP's first Linear: row stride 180, Q's block starts at column 69), bias / LeakyReLU,
+    every padded column written (outputs pre-filled with NaN), an 80-wide source, a 64-output job with a bf16 copy."""
+    torch.manual_seed(5)
+    rows = 333
+    X, X80 = torch.randn(rows, 69), torch.randn(rows, 80)
+    W1 = torch.randn(64, 180) * 0.2
+    Wq, Wv, bv = torch.randn(69, 69) * 0.2, torch.randn(69, 69) * 0.2, torch.randn(69)
+    W80, b64 = torch.randn(64, 80) * 0.2, torch.randn(64)
+    d = [t.to(dev) for t in (X, W1, Wq, Wv, bv, X80, W80, b64)]
+
+    def run(bf16):
+        widths = (64, 64, 80, 80, 64)
+        Ys = [torch.full((rows, w), float('nan'), device=dev) for w in widths]
+        Yb = torch.zeros(rows, 64, dtype=torch.int16, device=dev)
+        jobs = (L.EqdLinJob * 5)()
+        #        X, ldx, K, W, w_rs, M, bias, act, pad_to
+        spec = ((d[0], 69, 69, d[1].data_ptr(), 180, 64, None, 0, 0),                          # P
+                (d[0], 69, 69, d[1].data_ptr() + 4 * 69, 180, 64, None, 0, 0),                 # Q: unaligned weight rows
+                (d[0], 69, 69, d[2].data_ptr(), 69, 69, None, 1, 80),                          # q: LeakyReLU, padded to 80
+                (d[0], 69, 69, d[3].data_ptr(), 69, 69, d[4].data_ptr(), 0, 80),               # v: bias, padded to 80
+                (d[5], 80, 80, d[6].data_ptr(), 80, 64, d[7].data_ptr(), 1, 0))                # an 80-wide source
+        for i, (x, ldx, K, wp, wrs, M, bias, act, pad) in enumerate(spec):
+            J = jobs[i]
+            J.nsrc, J.M, J.rows, J.act, J.bias, J.pad_to = 1, M, rows, act, bias, pad
+            J.s[0].X, J.s[0].W, J.s[0].ldx, J.s[0].K, J.s[0].w_rs, J.s[0].w_cs = x.data_ptr(), wp, ldx, K, wrs, 1
+            J.alpha, J.beta, J.slope, J.Y, J.ldy, J.bf16 = 1.0, 0.0, 0.01, Ys[i].data_ptr(), widths[i], int(bf16)
+        jobs[4].Yb, jobs[4].ldyb = Yb.data_ptr(), 64
+        L.check(lib().eqd_linear(jobs, 5, st(dev)))
+        sync(dev)
+        return [y.clone() for y in Ys] + [Yb.clone()]
+    for bf16 in (False, True):
+        monkeypatch.setenv('EQD_LINEAR_SIMPLE80', '0')
+        ref = run(bf16)
+        monkeypatch.delenv('EQD_LINEAR_SIMPLE80')
+        got = run(bf16)
+        for i, (a, b_) in enumerate(zip(got, ref)):
+            assert torch.isfinite(a.float()).all(), f'job {i}: columns left unwritten (bf16={bf16})'
+            assert torch.equal(a, b_), f'k_linear_simple80 differs from k_linear, job {i} (bf16={bf16}): ' \
+                                       f'{float((a.float() - b_.float()).abs().max()):.3e}'
+        if not bf16:
+            close(got[0], X @ W1[:, :69].t(), what='P')
+            close(got[1], X @ W1[:, 69:138].t(), what='Q')
+            close(got[2][:, :69], F.leaky_relu(X @ Wq.t(), 0.01), what='q')
+            close(got[3][:, :69], X @ Wv.t() + bv, what='v')
+            close(got[4], F.leaky_relu(X80 @ W80.t() + b64, 0.01), what='80-wide source')
+            assert float(got[2][:, 69:].abs().max()) == 0.0 and float(got[3][:, 69:].abs().max()) == 0.0
+            assert torch.equal(got[5].cpu().view(torch.bfloat16).float(), got[4].cpu().to(torch.bfloat16).float())
+
+
 def check_atb(dev):
     torch.manual_seed(1)
     rows = 1000

@@ -28,6 +28,12 @@ def test_linear_simple_form_is_bit_identical(dev, monkeypatch):
     pc.check_linear_simple_form(dev, monkeypatch)
 
 
+def test_linear_simple80_form_is_bit_identical(dev, monkeypatch):
+    """k_linear_simple80 (the first layer's 69-wide projection group, four workgroups per CU) against k_linear: same bits"""
+    from tests import parity_common as pc
+    pc.check_linear_simple80_form(dev, monkeypatch)
+
+
 def test_atb(dev):
     from tests import parity_common as pc
     pc.check_atb(dev)

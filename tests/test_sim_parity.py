@@ -29,6 +29,10 @@ def test_linear_simple_form_is_bit_identical(monkeypatch):
     pc.check_linear_simple_form(DEV, monkeypatch)
 
 
+def test_linear_simple80_form_is_bit_identical(monkeypatch):
+    pc.check_linear_simple80_form(DEV, monkeypatch)
+
+
 def test_atb():
     pc.check_atb(DEV)
 
