@@ -171,12 +171,17 @@ __device__ __forceinline__ f32x4 mfma_bf32(s16x8 a, s16x8 b, f32x4 c) {
     return mfma_bf(a1, b1, mfma_bf(a0, b0, c));
 #else
     typedef __bf16 eqd_bf16x8 __attribute__((ext_vector_type(8)));
-    const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(eqd_bf16x8, a), __builtin_bit_cast(eqd_bf16x8, b), c, 0, 0, 0);
-    // MEASURED on MI355X (profiles/_exp/mfma32b.hip, profiles/r04_h_mfma_overlap.txt): with vdst == srcA this instruction
+    f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(eqd_bf16x8, a), __builtin_bit_cast(eqd_bf16x8, b), c, 0, 0, 0);
+    // MEASURED on MI355X (profiles/exp_r04/mfma32b.hip, profiles/r04_h_mfma_overlap.txt): with vdst == srcA this instruction
     // returns wrong values (vdst == srcB, and either overlap of the 16x16x16 form, are fine), and hipcc (ROCm 7.2) does
-    // allocate vdst onto a dead A operand - k_edge_bwd<bf16, DROP> came out 29 % wrong, run-to-run different, on the GPU
-    // only.  Keeping A live past the instruction costs no instruction and makes the overlap impossible.
-    asm volatile("" ::"v"(a));
+    // allocate vdst onto a dead A operand.  A must therefore stay live PAST the instruction.  Round 4 wrote that as an empty
+    // asm that reads `a` behind the builtin - but nothing ordered it after the MFMA: the scheduler moved it in front (it
+    // sits right behind the LDS read of the operand in the round-6 assembly), A was dead at the MFMA again, 19 kernels carried
+    // 1 - 8 such instructions, and k_edge_bwd<bf16, dropout> gave run-to-run DIFFERENT weight gradients (1e-3 relative) at
+    // 8 x (200, 200) - found in round 6 by comparing two runs bit for bit (profiles/r06_zy_det*.txt).  The result now passes
+    // THROUGH the asm: it cannot move in front of the instruction that defines d, and a is one of its inputs, so a and d are
+    // live together and cannot share registers.  tests/test_abi_and_graph.py scans the shipped code object for the overlap.
+    asm volatile("" : "+v"(d) : "v"(a));
     return d;
 #endif
 }

@@ -34,6 +34,12 @@ def test_linear_simple80_form_is_bit_identical(dev, monkeypatch):
     pc.check_linear_simple80_form(dev, monkeypatch)
 
 
+def test_training_step_is_bit_reproducible(dev):
+    """run-to-run bits of a seeded training step (bf16 + dropout at DB5.5 batch size: the case that was not, round 6)"""
+    from tests import parity_common as pc
+    pc.check_run_to_run_bits(dev)
+
+
 def test_atb(dev):
     from tests import parity_common as pc
     pc.check_atb(dev)

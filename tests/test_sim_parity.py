@@ -33,6 +33,10 @@ def test_linear_simple80_form_is_bit_identical(monkeypatch):
     pc.check_linear_simple80_form(DEV, monkeypatch)
 
 
+def test_training_step_is_bit_reproducible():
+    pc.check_run_to_run_bits(DEV, cases=((True, 0.25, 1, 2, 40), (False, 0.25, 1, 2, 40)), runs=2)      # (host logic; the GPU test runs the sizes that matter)
+
+
 def test_atb():
     pc.check_atb(DEV)
 
