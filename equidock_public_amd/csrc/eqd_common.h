@@ -181,7 +181,7 @@ __device__ __forceinline__ f32x4 mfma_bf32(s16x8 a, s16x8 b, f32x4 c) {
     // 8 x (200, 200) - found in round 6 by comparing two runs bit for bit (profiles/r06_zy_det*.txt).  The result now passes
     // THROUGH the asm: it cannot move in front of the instruction that defines d, and a is one of its inputs, so a and d are
     // live together and cannot share registers.  tests/test_abi_and_graph.py scans the shipped code object for the overlap.
-    asm volatile("" : "+v"(d) : "v"(a));
+    asm volatile("" ::"v"(a), "v"(d[0]));
     return d;
 #endif
 }
