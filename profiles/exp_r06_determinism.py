@@ -26,7 +26,12 @@ if drop > 0:
 net = build_model(args, port.init_state_dict(args, seed=4, rot_scale=10.0), dev)
 net.train(os.environ.get('DET_EVAL', '0') != '1')
 flat = net.iegmn_original.enable_flat_grads()
-g = G.batch_pairs(synthetic.make_pairs([(size, size)] * pairs, 13)).to(dev)
+sizes = [(size, size)] * pairs
+if os.environ.get('DET_RAGGED', '0') == '1':      # a ragged batch: `pairs` pairs between 29 and `size` residues
+    import random
+    rnd = random.Random(7)
+    sizes = [(rnd.randint(29, size), rnd.randint(40, size)) for _ in range(pairs)]
+g = G.batch_pairs(synthetic.make_pairs(sizes, 13)).to(dev)
 names = [n for n, _ in net.named_parameters()]
 ref = None
 print(f'bf16={bf16} dropout={drop} layers={layers} pairs={pairs} x ({size},{size}) train={net.training}')
