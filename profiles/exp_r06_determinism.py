@@ -23,6 +23,9 @@ if bf16:
     args = dict(args, hip_storage_dtype='bf16')
 if drop > 0:
     args = dict(args, hip_dropout_masks=os.environ.get('DET_MASKS', 'library'))
+if os.environ.get('DET_POISON', '0') == '1':      # saved-state / scratch workspaces pre-filled with NaN bit patterns before every call
+    from equidock_public_amd import model as _M
+    _M.POISON_WORKSPACES = True
 net = build_model(args, port.init_state_dict(args, seed=4, rot_scale=10.0), dev)
 net.train(os.environ.get('DET_EVAL', '0') != '1')
 flat = net.iegmn_original.enable_flat_grads()
@@ -46,6 +49,7 @@ for r in range(runs):
         ref = cur
         continue
     od = [float((a - b).abs().max()) for a, b in zip(cur[0], ref[0])]
+    nan = sum(int(not torch.isfinite(v).all()) for v in cur[1].values())
     gd = {n: float((cur[1][n] - ref[1][n]).abs().max()) for n in names if not torch.equal(cur[1][n], ref[1][n])}
     short = {n.replace('iegmn_original.', '').replace('iegmn_layers.', 'L'): f'{v:.1e}' for n, v in gd.items()}
-    print(f'run {r}: outputs max |diff| {od}; {len(gd)} of {len(names)} gradient tensors differ', short if len(short) <= 30 else list(short)[:30])
+    print(f'run {r}: outputs max |diff| {od}; {len(gd)} of {len(names)} gradient tensors differ, {nan} with NaN', short if len(short) <= 30 else list(short)[:30])

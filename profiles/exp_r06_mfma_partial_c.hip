@@ -33,7 +33,11 @@ __global__ void k(const s16x8* a, const s16x8* b, const f32x4* c, f32x4* ref, f3
     asm volatile("v_mov_b32 %0, v15\n v_mov_b32 %1, v16\n v_mov_b32 %2, v17" : "=v"(rh[1]), "=v"(rh[2]), "=v"(rh[3]));
     // the round-4 case again: destination == srcA
     ra = av;
+#ifdef NO_PRE_NOP      // (round 4's form: the copy ra = av - four v_mov - sits directly in front of the instruction)
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %0, %1, %2\n s_nop 15\n s_nop 15" : "+v"(ra) : "v"(bv), "v"(cv));
+#else
     asm volatile("s_nop 4\n v_mfma_f32_16x16x32_bf16 %0, %0, %1, %2\n s_nop 15\n s_nop 15" : "+v"(ra) : "v"(bv), "v"(cv));
+#endif
     ref[l] = r; lo[l] = rl; hi[l] = rh; ova[l] = ra;
 }
 int main() {
