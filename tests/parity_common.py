@@ -706,8 +706,8 @@ def check_linear_simple80_form(dev, monkeypatch):
             assert torch.equal(got[5].cpu().view(torch.bfloat16).float(), got[4].cpu().to(torch.bfloat16).float())
 
 
-def check_run_to_run_bits(dev, cases=((True, 0.25, 2, 8, 200), (True, 0.25, 1, 8, 100), (True, 0.0, 2, 8, 200), (False, 0.25, 2, 8, 200)),
-                          runs=3):
+def check_run_to_run_bits(dev, cases=((True, 0.25, 2, 8, 200), (True, 0.25, 1, 8, 100), (True, 0.0, 2, 8, 200), (False, 0.25, 2, 8, 200),
+                                     (True, 0.25, 2, 64, 300), (True, 0.25, 1, 4, 2000)), runs=3):
     """The same seeded training step, run several times in one process, gives the same BITS - every output and every parameter
     gradient.  No kernel of the library uses atomics and every reduction has a fixed order, so anything else is a defect.
     Round 6 found one this way: bf16 mode with dropout at 8 x (200, 200) gave run-to-run different edge-MLP gradients (1e-3
