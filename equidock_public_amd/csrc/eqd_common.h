@@ -172,15 +172,19 @@ __device__ __forceinline__ f32x4 mfma_bf32(s16x8 a, s16x8 b, f32x4 c) {
 #else
     typedef __bf16 eqd_bf16x8 __attribute__((ext_vector_type(8)));
     f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(eqd_bf16x8, a), __builtin_bit_cast(eqd_bf16x8, b), c, 0, 0, 0);
-    // MEASURED on MI355X (profiles/exp_r04/mfma32b.hip, profiles/r04_h_mfma_overlap.txt): with vdst == srcA this instruction
-    // returns wrong values (vdst == srcB, and either overlap of the 16x16x16 form, are fine), and hipcc (ROCm 7.2) does
-    // allocate vdst onto a dead A operand.  A must therefore stay live PAST the instruction.  Round 4 wrote that as an empty
-    // asm that reads `a` behind the builtin - but nothing ordered it after the MFMA: the scheduler moved it in front (it
-    // sits right behind the LDS read of the operand in the round-6 assembly), A was dead at the MFMA again, 19 kernels carried
-    // 1 - 8 such instructions, and k_edge_bwd<bf16, dropout> gave run-to-run DIFFERENT weight gradients (1e-3 relative) at
-    // 8 x (200, 200) - found in round 6 by comparing two runs bit for bit (profiles/r06_zy_det*.txt).  The result now passes
-    // THROUGH the asm: it cannot move in front of the instruction that defines d, and a is one of its inputs, so a and d are
-    // live together and cannot share registers.  tests/test_abi_and_graph.py scans the shipped code object for the overlap.
+    // The A operand stays live PAST the instruction, so that hipcc (ROCm 7.2) cannot allocate vdst onto it - which it does
+    // whenever A is dead at the MFMA.  Why: builds of this library that carried such instructions were run-to-run
+    // NONDETERMINISTIC in k_edge_bwd<bf16, dropout> twice (round 4: "29 % wrong, run-to-run different"; round 6: weight
+    // gradients 1e-3 relative apart at 8 x (200, 200), found by comparing two runs bit for bit, profiles/r06_zy_det*.txt), builds
+    // without them never.  The overlap looks necessary, not sufficient: micro-tests compute vdst == srcA correctly, alone and
+    // under load (profiles/exp_r06_mfma_*.hip; round 4's micro-test, which reported it wrong, has a register copy directly in
+    // front of its inline-asm MFMA), and variants of the failing build that kept the overlap but changed the schedule were
+    // deterministic (HISTORY.md, round 6) - the mechanism is open.  Round 4 wrote the guard as an empty asm reading `a` behind
+    // the builtin; nothing ordered it after the MFMA, the scheduler moved it in front, and 19 kernels carried 1 - 8 such
+    // instructions again.  Now the asm also reads one register of the RESULT: it cannot move in front of the instruction that
+    // defines d, a is live there, so a and d cannot share registers (one register, not all four: a "+v"(d) pulls accumulators
+    // out of the AGPRs, + 655 VALU instructions in k_atb against + 226).  tests/test_abi_and_graph.py scans the shipped code
+    // object for the overlap; tests/test_gpu_parity.py repeats seeded steps and compares bits.
     asm volatile("" ::"v"(a), "v"(d[0]));
     return d;
 #endif
